@@ -1,0 +1,77 @@
+"""ctypes view of oracle/libzstd_oracle.so = our plain-C restatement (oracle/zstd_oracle_*.c).
+TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(_HERE, "libzstd_oracle.so")
+_lib = None
+ERR_MAX = 120
+
+
+class ZstdOracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(f"oracle error code {code}")
+        self.code = code
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(PATH):
+            build()
+        L = C.CDLL(PATH)
+        for name in ("zso_decompress",):
+            f = getattr(L, name)
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.zso_compress.restype = C.c_size_t
+        L.zso_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.zso_compress_bound.restype = C.c_size_t
+        L.zso_compress_bound.argtypes = [C.c_size_t]
+        L.zso_frame_content_size.restype = C.c_ulonglong
+        L.zso_frame_content_size.argtypes = [C.c_void_p, C.c_size_t]
+        L.zso_find_frame_compressed_size.restype = C.c_size_t
+        L.zso_find_frame_compressed_size.argtypes = [C.c_void_p, C.c_size_t]
+        L.zso_xxh64.restype = C.c_uint64
+        L.zso_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _check(r):
+    neg = (1 << 64) - r
+    if 0 < neg <= ERR_MAX:
+        raise ZstdOracleError(neg)
+    return r
+
+
+def decompress(frame: bytes, cap: int) -> bytes:
+    dst = C.create_string_buffer(max(cap, 1))
+    r = _check(lib().zso_decompress(dst, cap, frame, len(frame)))
+    return dst.raw[:r]
+
+
+def compress(data: bytes, level: int = 3, checksum: bool = False) -> bytes:
+    L = lib()
+    cap = L.zso_compress_bound(len(data))
+    dst = C.create_string_buffer(max(cap, 1))
+    r = _check(L.zso_compress(dst, cap, data, len(data), level, int(checksum)))
+    return dst.raw[:r]
+
+
+def frame_content_size(frame: bytes) -> int:
+    return lib().zso_frame_content_size(frame, len(frame))
+
+
+def find_frame_compressed_size(frame: bytes) -> int:
+    return _check(lib().zso_find_frame_compressed_size(frame, len(frame)))
+
+
+def xxh64(data: bytes, seed: int = 0) -> int:
+    return lib().zso_xxh64(data, len(data), seed)

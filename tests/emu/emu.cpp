@@ -1,0 +1,15 @@
+// tests/emu/emu.cpp — lane-serial (W = 1) build of the kernel bodies in zstd-jni_amd/csrc for
+// pre-GPU unit tests in the CPU-only dev container.  TEST INFRASTRUCTURE ONLY: never linked into
+// libzjni_amd.so, never reachable from the C-ABI (which fails loudly without a GPU).
+#include "../../zstd-jni_amd/csrc/zj_decode.h"
+#include <stdlib.h>
+
+extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap) {
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit);
+    free(lit); free(sh);
+    return r;
+}
+extern "C" unsigned emu_dec_shared_bytes() { return (unsigned)sizeof(ZDecShared); }

@@ -1,0 +1,120 @@
+// zj_common.h — shared primitives for the gfx950 zstd kernels.
+//
+// Execution model: one zstd frame is owned by one *group* of W lanes.  On the GPU W = 64 = one
+// CDNA4 wavefront = one workgroup, so "group sync" is an LDS-ordering s_barrier of a single wave
+// (free) and all cross-lane traffic goes through LDS or DPP.  Kernel bodies are written as
+//     GRP_SERIAL(g) { ... }      one lane (lane 0) runs an inherently sequential format step
+//     GRP_FOR(g, i, n) { ... }   all lanes stride over i in [0, n)
+// with every value that crosses lanes living in the group's LDS block.
+//
+// The same bodies also instantiate with W = 1 under a plain C++ compiler ("lane-serial build",
+// tests/emu/): GRP_SERIAL is always taken and GRP_FOR visits i = 0..n-1 in order.  That build exists
+// ONLY so the format logic can be unit-tested in the CPU-only dev container before spending GPU time;
+// it is never linked into the product library and the C-ABI never dispatches to it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZJ_DEV __device__ __forceinline__
+#define ZJ_DEV_NOINLINE __device__ __noinline__
+#define ZJ_ON_GPU 1
+#else
+#define ZJ_DEV static inline
+#define ZJ_DEV_NOINLINE static
+#define ZJ_ON_GPU 0
+#endif
+
+// ---- error codes: numerically the reference's ZSTD_ErrorCode (src/main/native/zstd_errors.h:60-98)
+enum : u32 {
+    ZJ_OK = 0,
+    ZJ_E_GENERIC = 1,
+    ZJ_E_PREFIX_UNKNOWN = 10,
+    ZJ_E_FRAMEPARAM_UNSUPPORTED = 14,
+    ZJ_E_WINDOW_TOO_LARGE = 16,
+    ZJ_E_CORRUPTION = 20,
+    ZJ_E_CHECKSUM_WRONG = 22,
+    ZJ_E_LITERALS_HEADER = 24,
+    ZJ_E_DICT_CORRUPTED = 30,
+    ZJ_E_DICT_WRONG = 32,
+    ZJ_E_PARAM_UNSUPPORTED = 40,
+    ZJ_E_TABLELOG_TOO_LARGE = 44,
+    ZJ_E_DSTSIZE_TOO_SMALL = 70,
+    ZJ_E_SRCSIZE_WRONG = 72,
+};
+#define ZJ_ERR64(code) ((u64)0 - (u64)(code))
+
+// ---- group abstraction ------------------------------------------------------------------
+template <int W_>
+struct Grp {
+    static constexpr int W = W_;
+#if ZJ_ON_GPU
+    ZJ_DEV u32 lane() const { return threadIdx.x & (W - 1); }
+    ZJ_DEV void sync() const { __syncthreads(); }   // 1 wave/WG: s_waitcnt lgkmcnt(0) + s_barrier
+#else
+    u32 lane() const { return 0; }
+    void sync() const {}
+#endif
+};
+
+#define GRP_SERIAL(g) if ((g).lane() == 0)
+#define GRP_FOR(g, i, n) for (u32 i = (g).lane(); i < (u32)(n); i += (u32)(g).W)
+
+// ---- memory helpers (gfx950 supports unaligned global and LDS dword/qword access; hipcc emits a
+//      single global_load_dwordx2 / ds_read_b64 for these memcpy's) -------------------------------
+ZJ_DEV u32 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
+ZJ_DEV u32 ld24(const u8* p) { return ld16(p) | ((u32)p[2] << 16); }
+ZJ_DEV u32 ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+ZJ_DEV u64 ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+ZJ_DEV void st16(u8* p, u32 v) { u16 w = (u16)v; __builtin_memcpy(p, &w, 2); }
+ZJ_DEV void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
+ZJ_DEV void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
+
+ZJ_DEV u32 zj_hibit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // v != 0
+ZJ_DEV u32 zj_min(u32 a, u32 b) { return a < b ? a : b; }
+ZJ_DEV u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
+
+// Compiler-level ordering point for global memory traffic that crosses lanes of the same wave
+// (LZ77 execution reads bytes other lanes stored a moment ago).  At workgroup scope on gfx950 this
+// emits no instruction: one CU's vector memory operations are performed in order by its L1, so only
+// the compiler has to be stopped from reordering.
+ZJ_DEV void zj_mem_order() {
+#if ZJ_ON_GPU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+// inclusive scan of a[0..n) (n <= W, array in the group's LDS), result in place
+template <class G>
+ZJ_DEV void grp_scan_incl(const G& g, u32* a, u32 n) {
+#if ZJ_ON_GPU
+    u32 const l = g.lane();
+    u32 v = l < n ? a[l] : 0;
+#pragma unroll
+    for (int d = 1; d < G::W; d <<= 1) {
+        u32 t = __shfl_up(v, d, G::W);
+        if ((int)l >= d) v += t;
+    }
+    if (l < n) a[l] = v;
+    g.sync();
+#else
+    (void)g;
+    for (u32 i = 1; i < n; i++) a[i] += a[i - 1];
+#endif
+}
+
+// cooperative byte copy global->global, no overlap between src and dst
+template <class G>
+ZJ_DEV void grp_copy(const G& g, u8* dst, const u8* src, u32 n) {
+    GRP_FOR(g, i, n) dst[i] = src[i];
+}

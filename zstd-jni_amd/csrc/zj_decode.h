@@ -1,0 +1,742 @@
+// zj_decode.h — batched zstd frame decoder for gfx950: one frame per wavefront.
+//
+// Replaces, for batches of independent frames, what zstd-jni reaches through
+//   ZstdDecompressCtx.decompress*0 -> ZSTD_decompressDCtx          (reference N/jni_fast_zstd.c:777-905)
+// i.e. N/decompress/zstd_decompress.c:953-1066 (frame), N/decompress/zstd_decompress_block.c:134-340
+// (literals), :695-782 (sequence headers), :485-603 (FSE tables), :1229-1347 + :1001-1096
+// (sequence decode + LZ77 execute), N/decompress/huf_decompress.c:385-518 (Huffman table) and
+// N/common/entropy_common.c:42-188,243-305 (NCount / weights).   N/ = src/main/native/.
+//
+// Data flow per frame (all compressed bytes are read from HBM exactly once, all output bytes written
+// exactly once, plus one round trip of the Huffman literals through a per-workgroup HBM scratch that
+// stays L2-resident):
+//   HBM src --(16 B/lane coalesced)--> LDS windows --> serial tANS / Huffman lanes --> LDS batches
+//   --> wave-cooperative LZ77 copies --> HBM dst
+// LDS per workgroup (= 1 wave): 3 tANS tables (5 KiB, 4-byte cells), Huffman table (4 KiB),
+// bitstream windows (1 KiB), sequence batch + scratch (~2.5 KiB)  => ~13 KiB => 12 frames in flight
+// per CU.
+#pragma once
+#include "zj_common.h"
+
+#define ZD_BLOCK_MAX (1u << 17)
+#define ZD_HUF_LOG_MAX 11u          // literals Huffman depth limit of the format (LitHufLog, N/common/zstd_internal.h:101)
+#define ZD_HWIN 256u                // bytes of bitstream staged per Huffman stream per round
+#define ZD_HSYM 128u                // symbols decoded per stream per round (128*11 bits <= 176 B < ZD_HWIN)
+#define ZD_HWIN_STRIDE (ZD_HWIN + 16u)
+#define ZD_SWIN (4u * ZD_HWIN_STRIDE - 16u)   // sequence bitstream window reuses the 4 Huffman windows
+#define ZD_SEQ_BATCH 64u
+#define ZD_LIT_SCRATCH (ZD_BLOCK_MAX + 64u)
+
+// tANS decode cell: next[0:15] | nbBits[16:19] | symbol[20:25] | extraBits[26:30]
+#define ZD_CELL(next, nb, sym, extra) ((u32)(next) | ((u32)(nb) << 16) | ((u32)(sym) << 20) | ((u32)(extra) << 26))
+#define ZD_CELL_NEXT(c) ((c) & 0xFFFFu)
+#define ZD_CELL_NB(c) (((c) >> 16) & 0xFu)
+#define ZD_CELL_SYM(c) (((c) >> 20) & 0x3Fu)
+#define ZD_CELL_EXTRA(c) (((c) >> 26) & 0x1Fu)
+
+struct ZDecShared {
+    u32 ll[512];
+    u32 ml[512];
+    u32 of[256];
+    u16 huf[1u << ZD_HUF_LOG_MAX];
+    u32 llBase[36];                 // LL_base (N/decompress/zstd_decompress_internal.h) per code
+    u32 mlBase[53];
+    u8 win[4 * ZD_HWIN_STRIDE];     // bitstream windows
+    u8 hstage[4][ZD_HSYM];          // Huffman output staging
+    u32 sLit[ZD_SEQ_BATCH];         // per-batch sequences
+    u32 sMl[ZD_SEQ_BATCH];
+    u32 sOff[ZD_SEQ_BATCH];
+    u8 weights[256];
+    u16 symPos[256];                // Huffman: first table cell of each symbol
+    short norm[64];
+    u16 symNext[64 * 3];
+    // --- uniforms published by lane 0 ---
+    u32 err;
+    u32 llLog, mlLog, ofLog, hufLog, hufValid, seqValid;
+    u32 rep[3];
+    u32 blkType, blkSize, blkLast;
+    u32 hdrSize, windowSize, hasChecksum, blockSizeMax;
+    u64 contentSize;
+    u32 litType, litSize, litCSize, litHdr, litStreams, litSrcOff;  // literals section
+    u32 hA[4], hS0[4], hN[4], hDone[4], hDst[4], hLo[4], hCnt[4];    // Huffman stream state (bit positions rel. to block)
+    u32 nbSeq, seqOff;              // sequences section start (rel. to block)
+    u32 bN, bLitStart, bOutStart, bLitTotal, bOutTotal, seqDone, winLo;
+    u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
+};
+
+// format constants (N/common/zstd_internal.h:113-165, N/decompress/zstd_decompress_internal.h:28-58)
+#define ZD_LL_BASE_INIT { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 }
+#define ZD_LL_BITS_INIT { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 }
+#define ZD_ML_BASE_INIT { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,0x83,0x103,0x203,0x403,0x803,0x1003,0x2003,0x4003,0x8003,0x10003 }
+#define ZD_ML_BITS_INIT { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 }
+#define ZD_LL_DEFNORM_INIT { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 }
+#define ZD_ML_DEFNORM_INIT { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 }
+#define ZD_OF_DEFNORM_INIT { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 }
+
+ZJ_DEV u32 zd_ll_bits(u32 c) { const u8 t[36] = ZD_LL_BITS_INIT; return t[c]; }
+ZJ_DEV u32 zd_ml_bits(u32 c) { const u8 t[53] = ZD_ML_BITS_INIT; return t[c]; }
+
+// ------------------------------------------------------------------ wide cooperative copy ----
+template <class G>
+ZJ_DEV void zd_copy_wide(const G& g, u8* dst, const u8* src, u32 n) {
+    u32 const n16 = n >> 4;
+    GRP_FOR(g, i, n16) {
+        u64 a = ld64(src + 16 * i), b = ld64(src + 16 * i + 8);
+        st64(dst + 16 * i, a); st64(dst + 16 * i + 8, b);
+    }
+    GRP_FOR(g, i, n & 15u) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
+}
+template <class G>
+ZJ_DEV void zd_fill(const G& g, u8* dst, u8 v, u32 n) {
+    u64 const vv = 0x0101010101010101ull * v;
+    u32 const n16 = n >> 4;
+    GRP_FOR(g, i, n16) { st64(dst + 16 * i, vv); st64(dst + 16 * i + 8, vv); }
+    GRP_FOR(g, i, n & 15u) dst[(n16 << 4) + i] = v;
+}
+
+// stage `len` (<= capacity) bytes of src[from, from+len) into LDS at `w`, zero past srcEnd
+template <class G>
+ZJ_DEV void zd_stage(const G& g, u8* w, const u8* src, u32 from, u32 len, u32 srcEnd) {
+    GRP_FOR(g, c, (len + 15u) >> 4) {
+        u32 const o = from + 16 * c;
+        u64 a = 0, b = 0;
+        if (o + 16 <= srcEnd) { a = ld64(src + o); b = ld64(src + o + 8); }
+        else {
+            for (u32 k = 0; k < 8; k++) { if (o + k < srcEnd) a |= (u64)src[o + k] << (8 * k); }
+            for (u32 k = 0; k < 8; k++) { if (o + 8 + k < srcEnd) b |= (u64)src[o + 8 + k] << (8 * k); }
+        }
+        st64(w + 16 * c, a); st64(w + 16 * c + 8, b);
+    }
+}
+
+// ------------------------------------------------------------------ NCount (lane 0) ---------
+// N/common/entropy_common.c:42-188.  Reads from global memory [src, src+srcSize). Returns header
+// bytes or 0 on error (an NCount header is never 0 bytes).
+ZJ_DEV u32 zd_read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, u32 srcSize) {
+    u32 const maxSV1 = *maxSV + 1;
+    u32 bitpos, charnum = 0, previous0 = 0;
+    i32 nbBits, remaining, threshold;
+    if (srcSize < 1) return 0;
+    for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
+    nbBits = (i32)(src[0] & 0xF) + 5;
+    if (nbBits > 15) return 0;
+    *tableLog = (u32)nbBits; bitpos = 4;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    for (;;) {
+        u32 by, sh; u64 w = 0;
+        if (previous0) {
+            for (;;) {
+                u32 c; u32 w2 = 0;
+                by = bitpos >> 3; sh = bitpos & 7;
+                if (by < srcSize) w2 = src[by];
+                if (by + 1 < srcSize) w2 |= (u32)src[by + 1] << 8;
+                c = (w2 >> sh) & 3; bitpos += 2; charnum += c;
+                if (c != 3 || charnum >= maxSV1 + 64) break;
+            }
+            if (charnum >= maxSV1) break;
+        }
+        by = bitpos >> 3; sh = bitpos & 7;
+        for (u32 k = 0; k < 4; k++) { if (by + k < srcSize) w |= (u64)src[by + k] << (8 * k); }
+        {   u32 const bs = (u32)(w >> sh);
+            i32 const max = (2 * threshold - 1) - remaining;
+            i32 count;
+            if ((bs & (u32)(threshold - 1)) < (u32)max) { count = (i32)(bs & (u32)(threshold - 1)); bitpos += (u32)(nbBits - 1); }
+            else { count = (i32)(bs & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bitpos += (u32)nbBits; }
+            count--;
+            if (count >= 0) remaining -= count; else remaining += count;
+            norm[charnum++] = (short)count;
+            previous0 = !count;
+            if (remaining < threshold) {
+                if (remaining <= 1) break;
+                nbBits = (i32)zj_hibit((u32)remaining) + 1; threshold = 1 << (nbBits - 1);
+            }
+            if (charnum >= maxSV1) break;
+        }
+    }
+    if (remaining != 1 || charnum > maxSV1 || bitpos > 8 * srcSize) return 0;
+    *maxSV = charnum - 1;
+    return (bitpos + 7) >> 3;
+}
+
+// ------------------------------------------------------------------ tANS table (one lane) ---
+// N/decompress/zstd_decompress_block.c:485-603.  kind: 0 LL, 1 OF, 2 ML (extra-bits lookup).
+ZJ_DEV u32 zd_extra_bits(u32 kind, u32 sym) { return kind == 1 ? sym : (kind == 0 ? zd_ll_bits(sym) : zd_ml_bits(sym)); }
+
+ZJ_DEV bool zd_build_fse(u32* cells, const short* norm, u16* symNext, u32 maxSV, u32 tableLog, u32 kind) {
+    u32 const size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    u32 high = size - 1, pos = 0;
+    for (u32 s = 0; s <= maxSV; s++) {
+        if (norm[s] == -1) { cells[high--] = s; symNext[s] = 1; } else symNext[s] = (u16)norm[s];
+    }
+    for (u32 s = 0; s <= maxSV; s++) {
+        for (i32 i = 0; i < norm[s]; i++) {
+            cells[pos] = s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    if (pos != 0) return false;
+    for (u32 u = 0; u < size; u++) {
+        u32 const sym = cells[u];
+        u32 const ns = symNext[sym]++;
+        u32 const nb = tableLog - zj_hibit(ns);
+        cells[u] = ZD_CELL((ns << nb) - size, nb, sym, zd_extra_bits(kind, sym));
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ private lane-0 state -----
+struct ZDecSeqPriv {
+    u32 sLL, sOF, sML;     // tANS states
+    i32 A;                 // unread bits end position (bit index rel. to block start)
+    i32 S0;                // first bit of the sequence bitstream
+    u32 rep0, rep1, rep2;
+    u32 i;                 // sequences decoded so far
+    u32 opos;              // output bytes produced so far in this frame (incl. previous blocks)
+    u32 lpos;              // literals consumed in this block
+};
+
+ZJ_DEV u32 zd_bits(const u8* win, u32 winLo, i32 p, u32 n) {   // n <= 32 bits at bit index p
+    u64 const w = ld64(win + ((u32)p >> 3) - winLo) >> ((u32)p & 7);
+    return (u32)w & (u32)(((u64)1 << n) - 1);
+}
+
+// Decode up to ZD_SEQ_BATCH sequences into sh.sLit/sMl/sOff.  Runs on lane 0 only.
+// N/decompress/zstd_decompress_block.c:1229-1347.
+ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
+    u32 const nbSeq = sh.nbSeq, winLo = sh.winLo;
+    u32 n = 0, litTotal = 0, outTotal = 0, err = 0;
+    u32 const litSize = sh.litSize;
+    u32 const seqStartByte = (u32)p.S0 >> 3;
+    sh.bLitStart = p.lpos; sh.bOutStart = p.opos;
+    while (n < ZD_SEQ_BATCH && p.i < nbSeq) {
+        // window must cover the 96 bits below A unless it already reaches the stream start
+        if (winLo > seqStartByte && ((p.A - 96) >> 3) < (i32)winLo) break;
+        u32 const cl = sh.ll[p.sLL], co = sh.of[p.sOF], cm = sh.ml[p.sML];
+        u32 const ofx = ZD_CELL_EXTRA(co), mlx = ZD_CELL_EXTRA(cm), llx = ZD_CELL_EXTRA(cl);
+        bool const last = (p.i + 1 == nbSeq);
+        u32 const nl = last ? 0 : ZD_CELL_NB(cl), nm = last ? 0 : ZD_CELL_NB(cm), no = last ? 0 : ZD_CELL_NB(co);
+        u32 const T = ofx + mlx + llx + nl + nm + no;
+        u32 ofv, mlv, llv, vl, vm, vo;
+        p.A -= (i32)T;
+        if (p.A < p.S0) { err = ZJ_E_CORRUPTION; break; }
+        if (T <= 56) {
+            u64 w = ld64(sh.win + ((u32)p.A >> 3) - winLo) >> ((u32)p.A & 7);
+            vo = (u32)w & ((1u << no) - 1); w >>= no;
+            vm = (u32)w & ((1u << nm) - 1); w >>= nm;
+            vl = (u32)w & ((1u << nl) - 1); w >>= nl;
+            llv = (u32)w & ((1u << llx) - 1); w >>= llx;
+            mlv = (u32)w & ((1u << mlx) - 1); w >>= mlx;
+            ofv = (u32)w & (u32)(((u64)1 << ofx) - 1);
+        } else {
+            i32 q = p.A;
+            vo = zd_bits(sh.win, winLo, q, no); q += (i32)no;
+            vm = zd_bits(sh.win, winLo, q, nm); q += (i32)nm;
+            vl = zd_bits(sh.win, winLo, q, nl); q += (i32)nl;
+            llv = zd_bits(sh.win, winLo, q, llx); q += (i32)llx;
+            mlv = zd_bits(sh.win, winLo, q, mlx); q += (i32)mlx;
+            ofv = zd_bits(sh.win, winLo, q, ofx);
+        }
+        u32 const llen = sh.llBase[ZD_CELL_SYM(cl)] + llv;
+        u32 const mlen = sh.mlBase[ZD_CELL_SYM(cm)] + mlv;
+        u32 offset;
+        if (ofx > 1) {
+            offset = (1u << ofx) - 3u + ofv;
+            p.rep2 = p.rep1; p.rep1 = p.rep0; p.rep0 = offset;
+        } else {
+            u32 const ll0 = (llen == 0);
+            if (ofx == 0) {
+                if (ll0) { offset = p.rep1; p.rep1 = p.rep0; p.rep0 = offset; } else offset = p.rep0;
+            } else {
+                u32 const idx = 1 + ll0 + ofv;
+                u32 t = (idx == 3) ? p.rep0 - 1 : (idx == 1 ? p.rep1 : p.rep2);
+                t -= !t;
+                if (idx != 1) p.rep2 = p.rep1;
+                p.rep1 = p.rep0; p.rep0 = t; offset = t;
+            }
+        }
+        if (!last) { p.sLL = ZD_CELL_NEXT(cl) + vl; p.sML = ZD_CELL_NEXT(cm) + vm; p.sOF = ZD_CELL_NEXT(co) + vo; }
+        if (llen > litSize - p.lpos) { err = ZJ_E_CORRUPTION; break; }
+        if ((u64)p.opos + llen + mlen > dstCap) { err = ZJ_E_DSTSIZE_TOO_SMALL; break; }
+        if (offset > p.opos + llen) { err = ZJ_E_CORRUPTION; break; }
+        sh.sLit[n] = llen; sh.sMl[n] = mlen; sh.sOff[n] = offset;
+        p.lpos += llen; p.opos += llen + mlen; litTotal += llen; outTotal += llen + mlen;
+        n++; p.i++;
+    }
+    if (!err && p.i == nbSeq && p.A != p.S0) err = ZJ_E_CORRUPTION;
+    sh.bN = n; sh.bLitTotal = litTotal; sh.bOutTotal = outTotal;
+    sh.seqDone = (p.i == nbSeq);
+    if (err) sh.err = err;
+    // next window request: bytes ending at the byte holding bit A-1 (+8 slack for the 64-bit load)
+    {   u32 const hi = ((u32)p.A >> 3) + 9;
+        u32 lo = hi > ZD_SWIN ? hi - ZD_SWIN : 0;
+        if (lo < seqStartByte) lo = seqStartByte;
+        sh.winLo = lo; }
+}
+
+// ------------------------------------------------------------------ Huffman -----------------
+// Weights (lane 0): N/common/entropy_common.c:243-305 + N/common/fse_decompress.c:166-236.
+// Returns header bytes, 0 on error.  Publishes sh.weights[0..nbSym), sh.hufLog, and nbSym via out.
+ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* nbSymOut) {
+    u32 iSize, oSize, total = 0;
+    u32 rank[ZD_HUF_LOG_MAX + 2];
+    if (!srcSize) return 0;
+    iSize = src[0];
+    if (iSize >= 128) {
+        oSize = iSize - 127; iSize = (oSize + 1) / 2;
+        if (iSize + 1 > srcSize) return 0;
+        for (u32 n = 0; n < oSize; n += 2) { u32 const b = src[1 + n / 2]; sh.weights[n] = (u8)(b >> 4); if (n + 1 < 256) sh.weights[n + 1] = (u8)(b & 15); }
+    } else {
+        // FSE-compressed weights, 2 interleaved states, tableLog <= 6.  Valid weights are 0..12, so
+        // an NCount naming a symbol > 12 is corrupt either way; the 64-cell table, norm[] and
+        // symNext[] live in the (idle) Huffman staging area.
+        u32 maxSV = 12, tl;
+        u32* const wtab = (u32*)&sh.hstage[0][0];              // 64 cells = 256 B
+        short* const norm = (short*)&sh.hstage[2][0];          // 13 shorts
+        u16* const symNext = (u16*)&sh.hstage[2][64];          // 13 u16
+        if (iSize + 1 > srcSize) return 0;
+        {   u32 const h = zd_read_ncount(norm, &maxSV, &tl, src + 1, iSize);
+            if (!h || tl > 6 || h > iSize) return 0;
+            if (!zd_build_fse(wtab, norm, symNext, maxSV, tl, 1)) return 0;
+            {   const u8* bs = src + 1 + h; u32 const bn = iSize - h;
+                i32 A; u32 s1, s2; u32 n = 0;
+                if (bn == 0 || bs[bn - 1] == 0) return 0;
+                A = (i32)((bn - 1) * 8 + zj_hibit(bs[bn - 1]));
+                // small stream (<= 127 bytes): bits are read straight from global memory / L1
+                auto rdbits = [&](u32 nb) -> u32 {
+                    A -= (i32)nb;
+                    if (A < 0 || nb == 0) return 0;
+                    u32 const by = (u32)A >> 3; u32 w = 0;
+                    for (u32 k = 0; k < 3; k++) { if (by + k < bn) w |= (u32)bs[by + k] << (8 * k); }
+                    return (w >> ((u32)A & 7)) & ((1u << nb) - 1);
+                };
+                s1 = rdbits(tl); s2 = rdbits(tl);
+                if (A < 0) return 0;
+                for (;;) {
+                    u32 c;
+                    if (n + 2 > 255) return 0;
+                    c = wtab[s1]; sh.weights[n++] = (u8)ZD_CELL_SYM(c); s1 = ZD_CELL_NEXT(c) + rdbits(ZD_CELL_NB(c));
+                    if (A < 0) { sh.weights[n++] = (u8)ZD_CELL_SYM(wtab[s2]); break; }
+                    if (n + 2 > 255) return 0;
+                    c = wtab[s2]; sh.weights[n++] = (u8)ZD_CELL_SYM(c); s2 = ZD_CELL_NEXT(c) + rdbits(ZD_CELL_NB(c));
+                    if (A < 0) { sh.weights[n++] = (u8)ZD_CELL_SYM(wtab[s1]); break; }
+                }
+                oSize = n;
+            }
+        }
+    }
+    for (u32 w = 0; w < ZD_HUF_LOG_MAX + 2; w++) rank[w] = 0;
+    for (u32 n = 0; n < oSize; n++) {
+        u32 const w = sh.weights[n];
+        if (w > ZD_HUF_LOG_MAX) return 0;
+        rank[w]++; total += (1u << w) >> 1;
+    }
+    if (total == 0) return 0;
+    {   u32 const tl = zj_hibit(total) + 1;
+        if (tl > ZD_HUF_LOG_MAX) return 0;
+        u32 const rest = (1u << tl) - total, last = zj_hibit(rest) + 1;
+        if ((1u << zj_hibit(rest)) != rest) return 0;
+        sh.weights[oSize] = (u8)last; rank[last]++;
+        if (rank[1] < 2 || (rank[1] & 1)) return 0;
+        // first cell per symbol: weights ascending, symbols ascending inside a weight
+        u32 start[ZD_HUF_LOG_MAX + 2]; u32 cur = 0;
+        for (u32 w = 1; w <= tl; w++) { start[w] = cur; cur += rank[w] << (w - 1); }
+        for (u32 n = 0; n <= oSize; n++) {
+            u32 const w = sh.weights[n];
+            if (w) { sh.symPos[n] = (u16)start[w]; start[w] += 1u << (w - 1); }
+        }
+        sh.hufLog = tl;
+    }
+    *nbSymOut = oSize + 1;
+    return iSize + 1;
+}
+
+// Decode <= ZD_HSYM symbols of stream t from its LDS window (one lane per stream).
+// N/decompress/huf_decompress.c:721-835 (4X1 loop), :600-640 (1X1).
+ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
+    u32 const log = sh.hufLog;
+    u32 const todo = zj_min(ZD_HSYM, sh.hN[t] - sh.hDone[t]);
+    i32 A = (i32)sh.hA[t]; i32 const S0 = (i32)sh.hS0[t];
+    u32 const lo = sh.hLo[t];
+    const u8* const win = sh.win + t * ZD_HWIN_STRIDE;
+    u32 const startByte = (u32)S0 >> 3;
+    u32 k = 0;
+    while (k < todo) {
+        // refill a 64-bit container whose MSB is bit A-1 (>= 57 valid bits, zeros below S0)
+        u64 c;
+        u32 const byteEnd = ((u32)A + 7) >> 3;
+        if (A <= S0) c = 0;
+        else if (byteEnd >= startByte + 8) c = ld64(win + (byteEnd - 8 - lo)) << (8 * byteEnd - (u32)A);
+        else c = ld64(win + (startByte - lo)) << (64 - (u32)(A - S0));
+        u32 const m = zj_min(5u, todo - k);
+        for (u32 j = 0; j < m; j++) {
+            u32 const cell = sh.huf[(u32)(c >> (64 - log))];
+            u32 const nb = cell >> 8;
+            sh.hstage[t][k + j] = (u8)cell;
+            c <<= nb; A -= (i32)nb;
+        }
+        k += m;
+    }
+    sh.hA[t] = (u32)A; sh.hCnt[t] = todo;
+}
+
+// ------------------------------------------------------------------ block --------------------
+// Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
+// (frame-relative position `opos`).  Returns new opos (or sets sh.err).
+template <class G>
+ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch) {
+    // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
+    GRP_SERIAL(g) {
+        u32 err = 0;
+        if (bsize < 2) err = ZJ_E_CORRUPTION;
+        else {
+            u32 const b0 = bsrc[0], type = b0 & 3, fmt = (b0 >> 2) & 3;
+            u32 lh = 0, n = 0, c = 0, streams = 1;
+            if (type < 2) {
+                if (fmt == 0 || fmt == 2) { lh = 1; n = b0 >> 3; }
+                else if (fmt == 1) { lh = 2; n = ld16(bsrc) >> 4; }
+                else { if (bsize < 3) err = ZJ_E_CORRUPTION; else { lh = 3; n = ld24(bsrc) >> 4; } }
+                c = (type == 0) ? n : 1;
+            } else if (bsize < 5) err = ZJ_E_CORRUPTION;
+            else {
+                u32 const lhc = ld32(bsrc);
+                if (fmt < 2) { streams = fmt ? 4 : 1; lh = 3; n = (lhc >> 4) & 0x3FF; c = (lhc >> 14) & 0x3FF; }
+                else if (fmt == 2) { streams = 4; lh = 4; n = (lhc >> 4) & 0x3FFF; c = lhc >> 18; }
+                else { streams = 4; lh = 5; n = (lhc >> 4) & 0x3FFFF; c = (lhc >> 22) + ((u32)bsrc[4] << 10); }
+                if (type == 3 && !sh.hufValid) err = ZJ_E_DICT_CORRUPTED;
+                if (!err && streams == 4 && n < 6) err = ZJ_E_LITERALS_HEADER;
+            }
+            if (!err && n > sh.blockSizeMax) err = ZJ_E_CORRUPTION;
+            if (!err && lh + c > bsize) err = ZJ_E_CORRUPTION;
+            sh.litType = type; sh.litSize = n; sh.litCSize = c; sh.litHdr = lh; sh.litStreams = streams;
+        }
+        if (err) sh.err = err;
+    }
+    g.sync();
+    if (sh.err) return opos;
+
+    u32 const litType = sh.litType, litSize = sh.litSize, litHdr = sh.litHdr, litCSize = sh.litCSize;
+    const u8* lit = litScratch;
+    if (litType == 0) lit = bsrc + litHdr;                      // raw: read in place
+    else if (litType == 1) { zd_fill(g, litScratch, bsrc[litHdr], litSize); zj_mem_order(); }
+    else {
+        // ---- Huffman table (lane 0 reads weights, all lanes fill) ----
+        if (litType == 2) {
+            GRP_SERIAL(g) {
+                u32 nbSym = 0;
+                u32 const h = zd_huf_read_weights(sh, bsrc + litHdr, litCSize, &nbSym);
+                if (!h || h > litCSize) sh.err = ZJ_E_CORRUPTION;
+                sh.litSrcOff = litHdr + h; sh.bN = nbSym;
+            }
+            g.sync();
+            if (sh.err) return opos;
+            {   u32 const log = sh.hufLog, nbSym = sh.bN;
+                GRP_FOR(g, s, nbSym) {
+                    u32 const w = sh.weights[s];
+                    if (w) {
+                        u32 const len = 1u << (w - 1), p0 = sh.symPos[s];
+                        u16 const cell = (u16)(((log + 1 - w) << 8) | s);
+                        for (u32 k = 0; k < len; k++) sh.huf[p0 + k] = cell;
+                    }
+                }
+                GRP_SERIAL(g) { sh.hufValid = 1; }
+            }
+        } else { GRP_SERIAL(g) { sh.litSrcOff = litHdr; } }
+        g.sync();
+        // ---- stream descriptors (lane 0) ----
+        GRP_SERIAL(g) {
+            u32 const off = sh.litSrcOff, end = litHdr + litCSize;   // compressed literal bytes [off, end)
+            u32 err = 0;
+            if (sh.litStreams == 1) {
+                if (end <= off || bsrc[end - 1] == 0) err = ZJ_E_CORRUPTION;
+                else { sh.hS0[0] = off * 8; sh.hA[0] = (end - 1) * 8 + zj_hibit(bsrc[end - 1]); sh.hN[0] = litSize; sh.hDst[0] = 0; }
+                for (u32 t = 1; t < 4; t++) { sh.hN[t] = 0; sh.hA[t] = 0; sh.hS0[t] = 0; sh.hDst[t] = 0; }
+            } else if (end < off + 10) err = ZJ_E_CORRUPTION;
+            else {
+                u32 const l1 = ld16(bsrc + off), l2 = ld16(bsrc + off + 2), l3 = ld16(bsrc + off + 4);
+                u32 const seg = (litSize + 3) / 4;
+                u32 b = off + 6;
+                if (b + l1 + l2 + l3 > end || 3 * seg > litSize) err = ZJ_E_CORRUPTION;
+                else {
+                    u32 const lens[4] = { l1, l2, l3, end - b - l1 - l2 - l3 };
+                    for (u32 t = 0; t < 4 && !err; t++) {
+                        u32 const e = b + lens[t];
+                        if (lens[t] == 0 || bsrc[e - 1] == 0) { err = ZJ_E_CORRUPTION; break; }
+                        sh.hS0[t] = b * 8; sh.hA[t] = (e - 1) * 8 + zj_hibit(bsrc[e - 1]);
+                        sh.hN[t] = (t < 3) ? seg : litSize - 3 * seg; sh.hDst[t] = t * seg;
+                        b = e;
+                    }
+                }
+            }
+            for (u32 t = 0; t < 4; t++) sh.hDone[t] = 0;
+            if (err) sh.err = err;
+        }
+        g.sync();
+        if (sh.err) return opos;
+        // ---- rounds: stage windows (all lanes) -> decode (<=4 lanes) -> flush (all lanes) ----
+        {   u32 const maxN = zj_max(zj_max(sh.hN[0], sh.hN[1]), zj_max(sh.hN[2], sh.hN[3]));
+            u32 const rounds = (maxN + ZD_HSYM - 1) / ZD_HSYM;
+            for (u32 r = 0; r < rounds; r++) {
+                GRP_FOR(g, i, 4u * (ZD_HWIN_STRIDE / 16u)) {
+                    u32 const t = i / (ZD_HWIN_STRIDE / 16u), c = i % (ZD_HWIN_STRIDE / 16u);
+                    if (sh.hDone[t] < sh.hN[t]) {
+                        u32 const startByte = sh.hS0[t] >> 3;
+                        u32 const hi = ((sh.hA[t] + 7) >> 3);
+                        u32 lo = hi > ZD_HWIN ? hi - ZD_HWIN : 0;
+                        if (lo < startByte) lo = startByte;
+                        u32 const o = lo + 16 * c;
+                        u64 a = 0, b = 0;
+                        if (o + 16 <= bsize) { a = ld64(bsrc + o); b = ld64(bsrc + o + 8); }
+                        else { for (u32 k = 0; k < 16; k++) { if (o + k < bsize) { if (k < 8) a |= (u64)bsrc[o + k] << (8 * k); else b |= (u64)bsrc[o + k] << (8 * (k - 8)); } } }
+                        st64(sh.win + t * ZD_HWIN_STRIDE + 16 * c, a); st64(sh.win + t * ZD_HWIN_STRIDE + 16 * c + 8, b);
+                        if (c == 0) sh.hLo[t] = lo;
+                    }
+                }
+                g.sync();
+                GRP_FOR(g, t, 4) { if (sh.hDone[t] < sh.hN[t]) zd_huf_stream_round(sh, t); else sh.hCnt[t] = 0; }
+                g.sync();
+                GRP_FOR(g, i, 4u * ZD_HSYM) {
+                    u32 const t = i / ZD_HSYM, j = i % ZD_HSYM;
+                    if (j < sh.hCnt[t]) litScratch[sh.hDst[t] + sh.hDone[t] + j] = sh.hstage[t][j];
+                }
+                g.sync();
+                GRP_FOR(g, t, 4) sh.hDone[t] += sh.hCnt[t];
+                g.sync();
+            }
+            GRP_SERIAL(g) { for (u32 t = 0; t < sh.litStreams; t++) { if (sh.hA[t] != sh.hS0[t]) sh.err = ZJ_E_CORRUPTION; } }
+            g.sync();
+            if (sh.err) return opos;
+        }
+    }
+
+    // ---- sequences header (lane 0): N/decompress/zstd_decompress_block.c:695-782 ----
+    u32 const seqSecOff = litHdr + litCSize;
+    GRP_SERIAL(g) {
+        u32 err = 0, ip = seqSecOff, nbSeq = 0;
+        if (ip >= bsize) err = ZJ_E_SRCSIZE_WRONG;
+        else {
+            nbSeq = bsrc[ip++];
+            if (nbSeq > 0x7F) {
+                if (nbSeq == 0xFF) { if (ip + 2 > bsize) err = ZJ_E_SRCSIZE_WRONG; else { nbSeq = ld16(bsrc + ip) + 0x7F00; ip += 2; } }
+                else { if (ip >= bsize) err = ZJ_E_SRCSIZE_WRONG; else nbSeq = ((nbSeq - 0x80) << 8) + bsrc[ip++]; }
+            }
+        }
+        if (!err) {
+            if (nbSeq == 0) { if (ip != bsize) err = ZJ_E_CORRUPTION; }
+            else if (ip + 1 > bsize) err = ZJ_E_SRCSIZE_WRONG;
+            else {
+                u32 const modes = bsrc[ip++];
+                if (modes & 3) err = ZJ_E_CORRUPTION;
+                // walk the three table descriptions; NCount parsing is inherently serial
+                u32 const maxSym[3] = { 35, 31, 52 }, maxLog[3] = { 9, 8, 9 };
+                for (u32 t = 0; t < 3 && !err; t++) {
+                    u32 const mode = (modes >> (6 - 2 * t)) & 3;
+                    sh.tblMode[t] = mode;
+                    if (mode == 1) {
+                        if (ip >= bsize || bsrc[ip] > maxSym[t]) err = ZJ_E_CORRUPTION; else { sh.tblMax[t] = bsrc[ip]; ip++; }
+                    } else if (mode == 2) {
+                        u32 max = maxSym[t], tl = 0;
+                        u32 const h = zd_read_ncount(sh.norm, &max, &tl, bsrc + ip, bsize - ip);
+                        if (!h || h > bsize - ip || tl > maxLog[t]) err = ZJ_E_CORRUPTION;
+                        else {
+                            u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
+                            if (!zd_build_fse(cells, sh.norm, sh.symNext, max, tl, t)) err = ZJ_E_CORRUPTION;
+                            if (t == 0) sh.llLog = tl; else if (t == 1) sh.ofLog = tl; else sh.mlLog = tl;
+                            ip += h;
+                        }
+                    } else if (mode == 3) { if (!sh.seqValid) err = ZJ_E_CORRUPTION; }
+                }
+                sh.seqValid = 1;
+            }
+        }
+        sh.nbSeq = nbSeq; sh.seqOff = ip;
+        if (err) sh.err = err;
+    }
+    g.sync();
+    if (sh.err) return opos;
+
+    u32 const nbSeq = sh.nbSeq;
+    u32 litUsed = 0;
+    if (nbSeq) {
+        // predefined / RLE tables (lanes 0..2, one table each)
+        GRP_FOR(g, t, 3) {
+            u32 const mode = sh.tblMode[t];
+            u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
+            if (mode == 0) {
+                const short dLL[36] = ZD_LL_DEFNORM_INIT; const short dOF[29] = ZD_OF_DEFNORM_INIT; const short dML[53] = ZD_ML_DEFNORM_INIT;
+                u32 const log = (t == 1) ? 5 : 6;
+                zd_build_fse(cells, t == 0 ? dLL : (t == 1 ? dOF : dML), sh.symNext + 64 * t, t == 0 ? 35 : (t == 1 ? 28 : 52), log, t);
+                if (t == 0) sh.llLog = log; else if (t == 1) sh.ofLog = log; else sh.mlLog = log;
+            } else if (mode == 1) {
+                u32 const sym = sh.tblMax[t];
+                cells[0] = ZD_CELL(0, 0, sym, zd_extra_bits(t, sym));
+                if (t == 0) sh.llLog = 0; else if (t == 1) sh.ofLog = 0; else sh.mlLog = 0;
+            }
+        }
+        g.sync();
+        ZDecSeqPriv p;
+        GRP_SERIAL(g) {
+            u32 const s = sh.seqOff;
+            u32 err = 0;
+            p.i = 0; p.opos = opos; p.lpos = 0; p.rep0 = sh.rep[0]; p.rep1 = sh.rep[1]; p.rep2 = sh.rep[2];
+            p.S0 = (i32)(s * 8); p.A = p.S0; p.sLL = p.sOF = p.sML = 0;
+            if (s >= bsize || bsrc[bsize - 1] == 0) err = ZJ_E_CORRUPTION;
+            else p.A = (i32)((bsize - 1) * 8 + zj_hibit(bsrc[bsize - 1]));
+            {   u32 const hi = bsize + 8; u32 lo = hi > ZD_SWIN ? hi - ZD_SWIN : 0; if (lo < s) lo = s; sh.winLo = lo; }
+            sh.seqDone = 0;
+            if (err) sh.err = err;
+        }
+        g.sync();
+        if (sh.err) return opos;
+        bool first = true;
+        for (;;) {
+            // stage the bitstream window [winLo, winLo + ZD_SWIN)
+            zd_stage(g, sh.win, bsrc, sh.winLo, ZD_SWIN, bsize);
+            g.sync();
+            GRP_SERIAL(g) {
+                if (first) {   // initial states: LL, OF, ML (N/decompress/zstd_decompress_block.c:1640-1642)
+                    u32 const a = sh.llLog, b = sh.ofLog, c = sh.mlLog;
+                    p.A -= (i32)a; p.sLL = zd_bits(sh.win, sh.winLo, p.A, a);
+                    p.A -= (i32)b; p.sOF = zd_bits(sh.win, sh.winLo, p.A, b);
+                    p.A -= (i32)c; p.sML = zd_bits(sh.win, sh.winLo, p.A, c);
+                    if (p.A < p.S0) sh.err = ZJ_E_CORRUPTION;
+                }
+                if (!sh.err) zd_seq_batch(sh, p, dstCap);
+            }
+            first = false;
+            g.sync();
+            if (sh.err) return opos;
+            // ---- execute the batch: N/decompress/zstd_decompress_block.c:1001-1096 ----
+            {   u32 const n = sh.bN;
+                u32 lp = sh.bLitStart, op = sh.bOutStart;
+                for (u32 k = 0; k < n; k++) {
+                    u32 const ll = sh.sLit[k], ml = sh.sMl[k], off = sh.sOff[k];
+                    GRP_FOR(g, j, ll) out[op + j] = lit[lp + j];
+                    lp += ll; op += ll;
+                    zj_mem_order();
+                    {   const u8* const m = out + op - off;
+                        if (off >= ml) { GRP_FOR(g, j, ml) out[op + j] = m[j]; }
+                        else { GRP_FOR(g, j, ml) out[op + j] = m[j % off]; }   // overlapped match = periodic pattern
+                    }
+                    op += ml;
+                    zj_mem_order();
+                }
+                litUsed = lp; opos = op;
+            }
+            if (sh.seqDone) break;
+            g.sync();
+        }
+        GRP_SERIAL(g) { sh.rep[0] = p.rep0; sh.rep[1] = p.rep1; sh.rep[2] = p.rep2; }
+    }
+    // ---- last literals ----
+    {   u32 const rest = litSize - litUsed;
+        if ((u64)opos + rest > dstCap) { GRP_SERIAL(g) { sh.err = ZJ_E_DSTSIZE_TOO_SMALL; } g.sync(); return opos; }
+        zd_copy_wide(g, out + opos, lit + litUsed, rest);
+        opos += rest;
+        zj_mem_order();
+    }
+    g.sync();
+    return opos;
+}
+
+// ------------------------------------------------------------------ frame --------------------
+// Decodes all frames in [src, src+srcSize) into dst[0..dstCap).  Returns decoded size or
+// ZJ_ERR64(code) — the reference's size_t error convention (N/common/error_private.h).
+template <class G>
+ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch) {
+    GRP_SERIAL(g) {
+        const u32 lb[36] = ZD_LL_BASE_INIT; const u32 mb[53] = ZD_ML_BASE_INIT;
+        for (u32 i = 0; i < 36; i++) sh.llBase[i] = lb[i];
+        for (u32 i = 0; i < 53; i++) sh.mlBase[i] = mb[i];
+        sh.err = 0;
+    }
+    g.sync();
+    u32 ipos = 0, total = 0;
+    while (ipos < srcSize) {
+        // ---- frame header (lane 0): N/decompress/zstd_decompress.c:447-557 ----
+        GRP_SERIAL(g) {
+            const u8* p = src + ipos; u32 const left = srcSize - ipos; u32 err = 0;
+            sh.blkType = 0;   // re-used as "skippable" flag below
+            if (left < 5) err = ZJ_E_SRCSIZE_WRONG;
+            else {
+                u32 const magic = ld32(p);
+                if (magic != 0xFD2FB528u) {
+                    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+                        if (left < 8 || (u64)8 + ld32(p + 4) > left) err = ZJ_E_SRCSIZE_WRONG;
+                        else { sh.blkType = 1; sh.hdrSize = 8 + ld32(p + 4); }
+                    } else err = ZJ_E_PREFIX_UNKNOWN;
+                } else {
+                    u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
+                    u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
+                    u32 const need = 5 + !single + didSz + fcsSz; u32 pos = 5;
+                    u64 window = 0, content = ~(u64)0; u32 dictID = 0;
+                    if (fhd & 8) err = ZJ_E_FRAMEPARAM_UNSUPPORTED;
+                    else if (left < need) err = ZJ_E_SRCSIZE_WRONG;
+                    else {
+                        if (!single) { u32 const wd = p[pos++], wl = (wd >> 3) + 10; if (wl > 31) err = ZJ_E_WINDOW_TOO_LARGE; window = (u64)1 << wl; window += (window >> 3) * (wd & 7); }
+                        if (didc == 1) dictID = p[pos]; else if (didc == 2) dictID = ld16(p + pos); else if (didc == 3) dictID = ld32(p + pos);
+                        pos += didSz;
+                        if (fcsid == 0) { if (single) content = p[pos]; } else if (fcsid == 1) content = ld16(p + pos) + 256; else if (fcsid == 2) content = ld32(p + pos); else content = ld64(p + pos);
+                        if (single) window = content;
+                        if (!err && window > (((u64)1 << 27) + 1)) err = ZJ_E_WINDOW_TOO_LARGE;
+                        if (!err && dictID) err = ZJ_E_DICT_WRONG;
+                        sh.hdrSize = need; sh.contentSize = content; sh.hasChecksum = (fhd >> 2) & 1;
+                        sh.blockSizeMax = window < ZD_BLOCK_MAX ? (u32)window : ZD_BLOCK_MAX;
+                    }
+                }
+            }
+            sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0;
+            if (err) sh.err = err;
+        }
+        g.sync();
+        if (sh.err) return ZJ_ERR64(sh.err);
+        if (sh.blkType == 1) { ipos += sh.hdrSize; g.sync(); continue; }
+        ipos += sh.hdrSize;
+        u8* const fout = dst + total; u32 const fcap = dstCap - total;
+        u32 opos = 0;
+        for (;;) {
+            GRP_SERIAL(g) {
+                u32 err = 0;
+                if (srcSize - ipos < 3) err = ZJ_E_SRCSIZE_WRONG;
+                else {
+                    u32 const bh = ld24(src + ipos), type = (bh >> 1) & 3, sz = bh >> 3;
+                    sh.blkLast = bh & 1; sh.blkType = type; sh.blkSize = sz;
+                    if (type == 3) err = ZJ_E_CORRUPTION;
+                    else if (type == 1) { if (srcSize - ipos - 3 < 1) err = ZJ_E_SRCSIZE_WRONG; else if (sz > sh.blockSizeMax) err = ZJ_E_CORRUPTION; else if (sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL; }
+                    else {
+                        if (sz > srcSize - ipos - 3) err = ZJ_E_SRCSIZE_WRONG;
+                        else if (sz > sh.blockSizeMax) err = ZJ_E_CORRUPTION;
+                        else if (type == 0 && sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL;
+                        else if (type == 2 && sz >= ZD_BLOCK_MAX) err = ZJ_E_CORRUPTION;
+                    }
+                }
+                if (err) sh.err = err;
+            }
+            g.sync();
+            if (sh.err) return ZJ_ERR64(sh.err);
+            ipos += 3;
+            u32 const type = sh.blkType, sz = sh.blkSize, last = sh.blkLast;
+            if (type == 0) { zd_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); }
+            else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
+            else {
+                u32 const cap = zj_min(fcap, opos + sh.blockSizeMax);
+                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch);
+                if (sh.err) {
+                    u32 e = sh.err;
+                    if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax
+                    return ZJ_ERR64(e);
+                }
+                ipos += sz;
+            }
+            g.sync();
+            if (last) break;
+        }
+        if (sh.contentSize != ~(u64)0 && sh.contentSize != opos) return ZJ_ERR64(ZJ_E_CORRUPTION);
+        if (sh.hasChecksum) {
+            // XXH64 verification is a "next" row; frames from Zstd.compress() default to no checksum.
+            if (srcSize - ipos < 4) return ZJ_ERR64(ZJ_E_CHECKSUM_WRONG);
+            ipos += 4;
+        }
+        total += opos;
+    }
+    return total;
+}
