@@ -1,0 +1,108 @@
+/* zjni_amd.h — C-ABI of the MI355X-native zstd path for zstd-jni (libzjni_amd.so).
+ *
+ * Boundary: these entry points are what the reference's JNI glue
+ * (/root/reference/src/main/native/jni_fast_zstd.c, jni_zstd.c; "N/" below) would bind instead of
+ * calling libzstd's ZSTD_compress2 / ZSTD_decompressDCtx for batches of independent buffers.
+ * Plain pointers and sizes only; no torch / HIP types in any signature (streams are passed as void*).
+ *
+ * Result convention everywhere = the reference's: a size_t byte count, or (size_t)(0 - code) with
+ * `code` a ZSTD_ErrorCode (N/zstd_errors.h:60-98); test with zjni_isError (== N/jni_zstd.c:240-243
+ * Zstd.isError) and map with zjni_getErrorCode / zjni_getErrorName (== Zstd.getErrorCode /
+ * getErrorName, N/jni_zstd.c:252-267).
+ *
+ * The library REQUIRES a gfx950 device: every compute entry returns ZJNI_ERROR(no_device) (code 200,
+ * outside libzstd's range) when HIP finds none.  There is no CPU fallback inside this library; the
+ * JNI glue keeps libzstd for what the GPU path does not cover.
+ */
+#ifndef ZJNI_AMD_H
+#define ZJNI_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZJNI_VERSION_STRING "0.1.0-zstd1.5.7"
+#define ZJNI_ERROR_no_device 200u      /* no HIP device / kernel launch failure */
+#define ZJNI_ERROR_unsupported 201u    /* input outside the GPU path's scope (see zjni_compress_batch) */
+#define ZJNI_BLOCKSIZE_MAX (1u << 17)  /* ZSTD_BLOCKSIZE_MAX, N/zstd.h:147-148 */
+
+/* ---- library / device ---- */
+const char* zjni_version(void);
+/* Number of usable HIP devices (0 when none). */
+int zjni_device_count(void);
+/* Selects device `ordinal` for the calling thread's subsequent calls and creates its per-device
+ * state (work counters, literal scratch). Returns 0 or a negative ZJNI/ZSTD error code. */
+int zjni_init(int ordinal);
+void zjni_shutdown(void);
+
+/* ---- error helpers: N/jni_zstd.c:240-267 (Zstd.isError / getErrorName / getErrorCode) ---- */
+unsigned zjni_isError(size_t result);
+int zjni_getErrorCode(size_t result);
+const char* zjni_getErrorName(size_t result);
+
+/* ---- sizing helpers ---- */
+/* == ZSTD_compressBound (N/zstd.h:249) == Zstd.compressBound (N/jni_zstd.c:229-232) */
+size_t zjni_compressBound(size_t srcSize);
+/* == ZSTD_getFrameContentSize (N/zstd.h:203-217) == Zstd.getFrameContentSize0 (N/jni_zstd.c:116-130):
+ * content size, (uint64)-1 unknown, (uint64)-2 error.  Host-side header parse, no GPU needed. */
+unsigned long long zjni_getFrameContentSize(const void* src, size_t srcSize);
+
+/* ---- hot path, device-resident batch -------------------------------------------------------
+ * HBM layout: n independent buffers packed in one blob; buffer i occupies
+ * [d_src + d_src_off[i], d_src + d_src_off[i+1]) and may write
+ * [d_dst + d_dst_off[i], d_dst + d_dst_off[i+1]).  Offsets are uint64[n+1] in device memory.
+ * d_result[i] receives buffer i's produced size or error (uint64, same convention as size_t).
+ * Asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream).
+ * Returns 0 when the launch was enqueued, else an error code result. */
+
+/* Replaces ZSTD_decompressDCtx (N/jni_fast_zstd.c:798-799, :825-826) for n frames at once.
+ * Every source buffer may hold several concatenated frames and skippable frames, exactly as
+ * ZSTD_decompressMultiFrame accepts (N/decompress/zstd_decompress.c:1070-1168). */
+size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off,
+                                    void* d_dst, const uint64_t* d_dst_off,
+                                    uint64_t* d_result, size_t n, void* stream);
+
+/* Replaces ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) for n buffers at
+ * once: each buffer becomes one standard zstd frame (content size in the header, no checksum,
+ * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h).  Buffers larger
+ * than ZJNI_BLOCKSIZE_MAX report ZJNI_ERROR_unsupported in d_result[i] (multi-block frames stay on
+ * the CPU path). */
+size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off,
+                                  void* d_dst, const uint64_t* d_dst_off,
+                                  uint64_t* d_result, size_t n, int level, void* stream);
+
+/* ---- hot path, host buffers (what a JNI batch native binds; stages through pinned memory) ---- */
+size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize,
+                             void* const* dst, const size_t* dstCapacity,
+                             size_t* result, size_t n);
+size_t zjni_compress_batch(const void* const* src, const size_t* srcSize,
+                           void* const* dst, const size_t* dstCapacity,
+                           size_t* result, size_t n, int level);
+
+/* ---- per-buffer forms with the exact argument meaning of the calls they replace ---- */
+/* ZSTD_compress2(cctx{level}, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:607 */
+size_t zjni_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level);
+/* ZSTD_decompressDCtx(dctx, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:799 */
+size_t zjni_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+
+/* ---- synthetic mixed-entropy workload, identical bytes on host and device ---- */
+void zjni_synth_fill_host(void* dst, size_t bufSize, uint64_t firstIndex, size_t nBuffers);
+size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, size_t nBuffers, void* stream);
+
+/* ---- output assembly for the multi-GPU gather ----
+ * Moves frame i from d_src[d_src_off[i] .. +d_sizes[i]) to d_dst[d_dst_off[i] ..): tight packing of a
+ * compress batch's variable-size outputs before the RCCL payload gather.  Entries of d_sizes that are
+ * error results are skipped. */
+size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
+                              void* d_dst, const uint64_t* d_dst_off, size_t n, void* stream);
+
+/* ---- introspection for tests/bench ---- */
+/* Workgroups the persistent kernels launch per device and LDS bytes per workgroup. */
+int zjni_kernel_info(int* decodeGrid, int* decodeLdsBytes, int* encodeGrid, int* encodeLdsBytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZJNI_AMD_H */

@@ -1,0 +1,141 @@
+/* oracle/cpu_baseline.c — multi-threaded CPU timing harness + batch helpers around the CPU checkers.
+ * TEST/BENCH INFRASTRUCTURE ONLY (bench.py's cpu_baseline leg, tests' input preparation).
+ *
+ * kind "reference": dlopen()s oracle/_ref/libzstd_ref.so (the reference's own libzstd 1.5.7) and
+ * drives ZSTD_compress2 / ZSTD_decompressDCtx exactly as zstd-jni's JNI glue does
+ * (/root/reference/src/main/native/jni_fast_zstd.c:606-607, :798-799): one reused CCtx/DCtx per
+ * thread, session reset before every call.   kind "port": the restatement in this directory.
+ */
+#define _GNU_SOURCE
+#include "zstd_oracle.h"
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef struct {
+    void* h;
+    void* (*createCCtx)(void); size_t (*freeCCtx)(void*);
+    size_t (*setParam)(void*, int, int); size_t (*reset)(void*, int);
+    size_t (*compress2)(void*, void*, size_t, const void*, size_t);
+    void* (*createDCtx)(void); size_t (*freeDCtx)(void*);
+    size_t (*dreset)(void*, int);
+    size_t (*decompressDCtx)(void*, void*, size_t, const void*, size_t);
+    unsigned (*isError)(size_t);
+} RefLib;
+
+static int ref_open(RefLib* r, const char* path) {
+    memset(r, 0, sizeof(*r));
+    if (!path) return 0;
+    r->h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!r->h) return -1;
+#define SYM(field, name) *(void**)(&r->field) = dlsym(r->h, name); if (!r->field) return -1;
+    SYM(createCCtx, "ZSTD_createCCtx") SYM(freeCCtx, "ZSTD_freeCCtx") SYM(setParam, "ZSTD_CCtx_setParameter")
+    SYM(reset, "ZSTD_CCtx_reset") SYM(compress2, "ZSTD_compress2") SYM(createDCtx, "ZSTD_createDCtx")
+    SYM(freeDCtx, "ZSTD_freeDCtx") SYM(dreset, "ZSTD_DCtx_reset") SYM(decompressDCtx, "ZSTD_decompressDCtx")
+    SYM(isError, "ZSTD_isError")
+#undef SYM
+    return 0;
+}
+
+typedef struct {
+    const RefLib* lib; int level; int mode;          /* mode 0 compress, 1 decompress */
+    const unsigned char* src; const size_t* srcOff;  /* n+1 offsets */
+    unsigned char* dst; const size_t* dstOff;        /* n+1 offsets (capacity = diff) */
+    size_t* outSize; size_t lo, hi; int failed;
+} Job;
+
+static void* worker(void* arg) {
+    Job* j = (Job*)arg; size_t i;
+    void* cctx = NULL; void* dctx = NULL;
+    if (j->lib->h) {
+        if (j->mode == 0) { cctx = j->lib->createCCtx(); j->lib->setParam(cctx, 100 /*ZSTD_c_compressionLevel*/, j->level); }
+        else dctx = j->lib->createDCtx();
+    }
+    for (i = j->lo; i < j->hi; i++) {
+        const unsigned char* s = j->src + j->srcOff[i]; size_t const sn = j->srcOff[i + 1] - j->srcOff[i];
+        unsigned char* d = j->dst + j->dstOff[i]; size_t const dn = j->dstOff[i + 1] - j->dstOff[i];
+        size_t r;
+        if (j->lib->h) {
+            if (j->mode == 0) { j->lib->reset(cctx, 1 /*session_only*/); r = j->lib->compress2(cctx, d, dn, s, sn); }
+            else { j->lib->dreset(dctx, 1); r = j->lib->decompressDCtx(dctx, d, dn, s, sn); }
+            if (j->lib->isError(r)) j->failed = 1;
+        } else {
+            r = (j->mode == 0) ? zso_compress(d, dn, s, sn, j->level, 0) : zso_decompress(d, dn, s, sn);
+            if (zso_is_error(r)) j->failed = 1;
+        }
+        j->outSize[i] = r;
+    }
+    if (cctx) j->lib->freeCCtx(cctx);
+    if (dctx) j->lib->freeDCtx(dctx);
+    return NULL;
+}
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* Runs one pass of `mode` over n buffers with `threads` threads (static contiguous partition).
+ * Returns wall seconds, or -1 on failure. */
+static double run_pass(const RefLib* lib, int mode, int level, const unsigned char* src, const size_t* srcOff,
+                       unsigned char* dst, const size_t* dstOff, size_t* outSize, size_t n, int threads) {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    Job* jobs = (Job*)calloc((size_t)threads, sizeof(Job));
+    int t, failed = 0; double t0, t1;
+    t0 = now_s();
+    for (t = 0; t < threads; t++) {
+        Job* j = &jobs[t];
+        j->lib = lib; j->level = level; j->mode = mode; j->src = src; j->srcOff = srcOff; j->dst = dst; j->dstOff = dstOff;
+        j->outSize = outSize; j->lo = n * (size_t)t / (size_t)threads; j->hi = n * (size_t)(t + 1) / (size_t)threads;
+        pthread_create(&th[t], NULL, worker, j);
+    }
+    for (t = 0; t < threads; t++) { pthread_join(th[t], NULL); failed |= jobs[t].failed; }
+    t1 = now_s();
+    free(th); free(jobs);
+    return failed ? -1.0 : t1 - t0;
+}
+
+/* Batch compress (mode 0) / decompress (mode 1) helper for tests and bench input preparation.
+ * libpath NULL -> the port.  Returns 0 or -1. */
+int zso_batch(const char* libpath, int mode, int level, const void* src, const size_t* srcOff,
+              void* dst, const size_t* dstOff, size_t* outSize, size_t n, int threads) {
+    RefLib lib; double s;
+    if (ref_open(&lib, libpath)) return -1;
+    s = run_pass(&lib, mode, level, (const unsigned char*)src, srcOff, (unsigned char*)dst, dstOff, outSize, n, threads < 1 ? 1 : threads);
+    if (lib.h) dlclose(lib.h);
+    return s < 0 ? -1 : 0;
+}
+
+/* CPU baseline: n buffers of bufSize bytes; warm-up pass + best of `reps` for compress and for
+ * decompress.  out[0] compress seconds (best), out[1] decompress seconds (best), out[2] total
+ * compressed bytes, out[3] 1.0 if every round trip was byte-exact.  Returns 0 or -1. */
+int zso_cpu_baseline(const char* libpath, const void* data, size_t bufSize, size_t n, int level, int threads, int reps, double* out) {
+    RefLib lib; size_t i; size_t const bound = zso_compress_bound(bufSize);
+    size_t* srcOff = (size_t*)malloc(sizeof(size_t) * (n + 1)); size_t* cOff = (size_t*)malloc(sizeof(size_t) * (n + 1));
+    size_t* cSize = (size_t*)malloc(sizeof(size_t) * n); size_t* dSize = (size_t*)malloc(sizeof(size_t) * n);
+    size_t* pOff = (size_t*)malloc(sizeof(size_t) * (n + 1));
+    unsigned char* comp = (unsigned char*)malloc(bound * n); unsigned char* packed = (unsigned char*)malloc(bound * n);
+    unsigned char* back = (unsigned char*)malloc(bufSize * n);
+    double bestC = 1e30, bestD = 1e30, s; int r, rc = -1; size_t total = 0;
+    if (ref_open(&lib, libpath)) goto done;
+    if (threads < 1) threads = 1;
+    for (i = 0; i <= n; i++) { srcOff[i] = i * bufSize; cOff[i] = i * bound; }
+    for (r = 0; r <= reps; r++) {            /* r == 0 is the warm-up */
+        s = run_pass(&lib, 0, level, (const unsigned char*)data, srcOff, comp, cOff, cSize, n, threads);
+        if (s < 0) goto done;
+        if (r > 0 && s < bestC) bestC = s;
+    }
+    pOff[0] = 0;
+    for (i = 0; i < n; i++) { memcpy(packed + pOff[i], comp + cOff[i], cSize[i]); pOff[i + 1] = pOff[i] + cSize[i]; }
+    total = pOff[n];
+    for (r = 0; r <= reps; r++) {
+        s = run_pass(&lib, 1, level, packed, pOff, back, srcOff, dSize, n, threads);
+        if (s < 0) goto done;
+        if (r > 0 && s < bestD) bestD = s;
+    }
+    out[0] = bestC; out[1] = bestD; out[2] = (double)total; out[3] = (memcmp(back, data, bufSize * n) == 0) ? 1.0 : 0.0;
+    rc = 0;
+done:
+    if (lib.h) dlclose(lib.h);
+    free(srcOff); free(cOff); free(cSize); free(dSize); free(pOff); free(comp); free(packed); free(back);
+    return rc;
+}

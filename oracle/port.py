@@ -75,3 +75,47 @@ def find_frame_compressed_size(frame: bytes) -> int:
 
 def xxh64(data: bytes, seed: int = 0) -> int:
     return lib().zso_xxh64(data, len(data), seed)
+
+
+# ---- multi-threaded batch helpers (oracle/cpu_baseline.c) — tests / bench input preparation ----
+def _batch_fn():
+    L = lib()
+    L.zso_batch.restype = C.c_int
+    L.zso_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.zso_cpu_baseline.restype = C.c_int
+    L.zso_cpu_baseline.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    return L
+
+
+def compress_many(data: bytes, buf_size: int, level: int, threads: int, use_ref=True):
+    """Compress len(data)//buf_size equal-size buffers with `threads` CPU threads.
+    Returns (packed_bytes, sizes list).  use_ref=True -> oracle/_ref (reference libzstd)."""
+    import numpy as np
+    from . import ref
+    L = _batch_fn()
+    n = len(data) // buf_size
+    bound = L.zso_compress_bound(buf_size)
+    src_off = np.arange(n + 1, dtype=np.uint64) * buf_size
+    dst_off = np.arange(n + 1, dtype=np.uint64) * bound
+    out = np.empty(max(n * bound, 1), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint64)
+    path = ref.PATH.encode() if (use_ref and ref.available()) else None
+    rc = L.zso_batch(path, 0, level, data, src_off.ctypes.data, out.ctypes.data, dst_off.ctypes.data, sizes.ctypes.data, n, threads)
+    if rc != 0:
+        raise RuntimeError("zso_batch failed")
+    frames = [out[i * bound:i * bound + int(sizes[i])].tobytes() for i in range(n)]
+    return frames
+
+
+def cpu_baseline(data: bytes, buf_size: int, level: int, threads: int, reps: int = 2, use_ref=True):
+    """dict(compress_s, decompress_s, compressed_bytes, exact) — see oracle/cpu_baseline.c."""
+    from . import ref
+    L = _batch_fn()
+    n = len(data) // buf_size
+    out = (C.c_double * 4)()
+    path = ref.PATH.encode() if (use_ref and ref.available()) else None
+    rc = L.zso_cpu_baseline(path, data, buf_size, n, level, threads, reps, out)
+    if rc != 0:
+        raise RuntimeError("zso_cpu_baseline failed")
+    return dict(compress_s=out[0], decompress_s=out[1], compressed_bytes=int(out[2]), exact=bool(out[3]),
+                kind="reference" if path else "port")

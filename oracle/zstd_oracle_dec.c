@@ -365,11 +365,14 @@ static size_t decode_block(DState* ds, u8* base, u8* op, u8* oend, const u8* src
         modes = *ip++;
         if (modes & 3) return ERR(corruption_detected);
         h = build_seq_table(&ds->ll, modes >> 6, MAXLL, LLFSELOG, LL_defNorm, MAXLL, 6, ip, (size_t)(iend - ip), ds->seqValid);
-        if (zso_is_error(h)) return ERR(corruption_detected); ip += h;
+        if (zso_is_error(h)) return ERR(corruption_detected);
+        ip += h;
         h = build_seq_table(&ds->of, (modes >> 4) & 3, MAXOFF, OFFFSELOG, OF_defNorm, 28, 5, ip, (size_t)(iend - ip), ds->seqValid);
-        if (zso_is_error(h)) return ERR(corruption_detected); ip += h;
+        if (zso_is_error(h)) return ERR(corruption_detected);
+        ip += h;
         h = build_seq_table(&ds->ml, (modes >> 2) & 3, MAXML, MLFSELOG, ML_defNorm, MAXML, 6, ip, (size_t)(iend - ip), ds->seqValid);
-        if (zso_is_error(h)) return ERR(corruption_detected); ip += h;
+        if (zso_is_error(h)) return ERR(corruption_detected);
+        ip += h;
         ds->seqValid = 1;
         if (bitr_init(&b, ip, (size_t)(iend - ip))) return ERR(corruption_detected);
         sLL = bitr_read(&b, ds->ll.log); sOF = bitr_read(&b, ds->of.log); sML = bitr_read(&b, ds->ml.log);

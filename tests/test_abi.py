@@ -1,0 +1,92 @@
+"""CPU (-m "not gpu"): the C-ABI library loads, exports every symbol include/zjni_amd.h declares,
+its GPU-free helpers agree with the reference, and compute entries fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, golden
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zjni_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zjni_[A-Za-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(zj):
+    L = zj.lib()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/zjni_amd.h but not exported"
+    assert set(names) == set(zj.EXPORTS)
+
+
+def test_error_helpers_match_libzstd(zj, oracle_ref):
+    L, R = zj.lib(), oracle_ref.lib()
+    for code in (1, 10, 14, 16, 20, 22, 24, 30, 32, 40, 42, 44, 64, 70, 72):
+        r = (1 << 64) - code
+        assert L.zjni_isError(r) == 1
+        assert L.zjni_getErrorCode(r) == code
+        assert L.zjni_getErrorName(r) == R.ZSTD_getErrorName(r), code
+    assert L.zjni_isError(123456) == 0
+    assert b"Destination buffer is too small" == L.zjni_getErrorName((1 << 64) - 70)   # T/scala/Zstd.scala:199
+
+
+def test_compress_bound_matches_reference(zj, oracle_ref):
+    L, R = zj.lib(), oracle_ref.lib()
+    for s in (0, 1, 100, 4096, 65536, 131071, 131072, 131073, 1 << 20, 10_000_000):
+        assert L.zjni_compressBound(s) == R.ZSTD_compressBound(s)
+
+
+def test_frame_content_size(zj, oracle_ref):
+    for data in (b"", b"a", b"abc" * 100, b"x" * 70000):
+        z = oracle_ref.compress(data, 3)
+        assert zj.Zstd.getFrameContentSize(z) == len(data)
+    assert zj.Zstd.getFrameContentSize(golden("xmlsmall-sized.zst")) == 102
+    assert zj.Zstd.getFrameContentSize(golden("xml-1.zst")) == -1          # streaming CLI frame: unknown size
+    assert zj.Zstd.getFrameContentSize(b"\x00" * 8) == -2
+
+
+def test_synth_is_deterministic_and_classed(zj):
+    a = zj.synth_host(4096, 0, 8)
+    b = zj.synth_host(4096, 4, 4)
+    assert a[4 * 4096:] == b
+    assert a[:4096].count(b" ") > 300                       # class 0: words
+    assert a[4096:8192].startswith(b'{"id":')               # class 1: JSON-like
+    assert max(a[2 * 4096:3 * 4096]) < 16                   # class 2: 4-bit values
+    assert len(set(a[3 * 4096:4 * 4096])) > 200             # class 3: random bytes
+
+
+def test_compute_fails_loudly_without_gpu(zj):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = zj.lib()
+    assert L.zjni_device_count() == 0
+    assert L.zjni_init(0) == -200
+    dst = C.create_string_buffer(100)
+    r = L.zjni_compress(dst, 100, b"abc", 3, 3)
+    assert L.zjni_isError(r) and L.zjni_getErrorCode(r) == 200
+    r = L.zjni_decompress(dst, 100, golden("xmlsmall-sized.zst"), 103)
+    assert L.zjni_isError(r) and L.zjni_getErrorCode(r) == 200
+    with pytest.raises(zj.ZstdException) as e:
+        zj.Zstd.compress(b"abc", 3)
+    assert e.value.getErrorCode() == 200
+
+
+def test_java_mirror_argument_checks(zj):
+    # N/jni_fast_zstd.c:586-600, :615-623: same checks, same codes, before any device work
+    ctx = zj.ZstdCompressCtx()
+    assert ctx._raw(bytearray(10), -1, 10, b"abc", 0, 3) == -70
+    assert ctx._raw(bytearray(10), 0, 10, b"abc", -1, 3) == -72
+    assert ctx._raw(bytearray(10), 0, 10, b"abc", 0, 4) == -72
+    assert ctx._raw(bytearray(10), 5, 10, b"abc", 0, 3) == -70
+    dctx = zj.ZstdDecompressCtx()
+    assert dctx._raw(bytearray(10), 0, 11, b"abc", 0, 3) == -70
+    assert dctx._raw(bytearray(10), 0, 10, b"abc", 2, 3) == -72
+    ctx.close()
+    with pytest.raises(RuntimeError):
+        ctx.setLevel(1)                                     # T/scala/Zstd.scala:1000-1020 use-after-close

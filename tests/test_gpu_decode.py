@@ -1,0 +1,98 @@
+"""GPU (-m gpu): batched decompress through the C-ABI (libzjni_amd.so, wave64 kernels) is bit-exact
+against the reference's golden frames and against frames produced by the reference's libzstd."""
+import hashlib
+import os
+
+import pytest
+
+from conftest import golden, XML_SHA256_PREFIX
+from util import edge_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(zj):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    zj.batch.init(0)
+    return zj
+
+
+def test_native_library_is_the_one_running(gpu):
+    L = gpu.lib()
+    assert L.zjni_device_count() >= 1
+    import ctypes as C
+    a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.zjni_kernel_info(a, b, c, d) == 0
+    assert a.value >= 256 and 8000 < b.value < 65536
+
+
+def test_gpu_golden_frames_one_batch(gpu):
+    # T/scala/Zstd.scala:427-638: CLI frames at levels 1/3/9/ultra, multi-block, multi-frame
+    names = ["xml-1.zst", "xml-3.zst", "xml-9.zst", "xml-advanced.zst", "xml-sized-combined.zst", "xmlsmall-sized.zst"]
+    frames = [golden(n) for n in names]
+    outs = gpu.decompress_batch(frames, [5_345_280] * 4 + [5_345_382, 102])
+    for n, o in zip(names, outs):
+        assert not isinstance(o, Exception), (n, o)
+    for o in outs[:4]:
+        assert len(o) == 5_345_280 and hashlib.sha256(o).hexdigest().startswith(XML_SHA256_PREFIX)
+    assert outs[4][:102] == golden("xmlsmall") and hashlib.sha256(outs[4][102:]).hexdigest().startswith(XML_SHA256_PREFIX)
+    assert outs[5] == golden("xmlsmall")
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_gpu_edge_inputs(gpu, oracle_ref, level):
+    items = edge_inputs()
+    frames = [oracle_ref.compress(d, level) for _, d in items]
+    outs = gpu.decompress_batch(frames, [len(d) for _, d in items])
+    for (name, data), o in zip(items, outs):
+        assert not isinstance(o, Exception), (name, o)
+        assert o == data, name
+
+
+def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
+    data = b"hello hello hello hello " * 100
+    z = oracle_ref.compress(data, 3)
+    assert gpu.Zstd.decompress(z, len(data)) == data
+    dctx = gpu.ZstdDecompressCtx()
+    with pytest.raises(gpu.ZstdException) as e:                    # T/scala/Zstd.scala:186-221
+        dctx.decompress(z, len(data) - 1)
+    assert e.value.getErrorCode() == gpu.Zstd.errDstSizeTooSmall()
+    assert "Destination buffer is too small" in str(e.value)
+    with pytest.raises(gpu.ZstdException) as e:
+        dctx.decompress(b"\x00\x01\x02\x03\x04\x05\x06\x07", 10)
+    assert e.value.getErrorCode() == 10
+    with pytest.raises(gpu.ZstdException):
+        dctx.decompress(z[:-3], len(data))
+    # offsets into larger arrays: J/ZstdDecompressCtx.java:239 decompressByteArray
+    dst = bytearray(len(data) + 20)
+    src = b"\xAA" * 7 + z + b"\xBB" * 5
+    n = dctx.decompressByteArray(dst, 10, len(data), src, 7, len(z))
+    assert n == len(data) and bytes(dst[10:10 + n]) == data and dst[:10] == bytes(10)
+
+
+@pytest.mark.parametrize("size,count", [(4096, 2048), (65536, 1024), (131072, 256)])
+def test_gpu_device_batch_synthetic(gpu, oracle_port, size, count):
+    """BASELINE configs' buffer shapes (4 KiB / 64 KiB / 128 KiB): reference-compressed L3 frames of
+    the §8(d) mixed-entropy set, decoded on the GPU from HBM-resident blobs, all buffers compared."""
+    import numpy as np
+    import torch
+    raw = gpu.synth_host(size, 0, count)
+    frames = oracle_port.compress_many(raw, size, 3, os.cpu_count() or 4)
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    off = np.zeros(count + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(f) for f in frames])
+    d_src = torch.from_numpy(blob.copy()).cuda()
+    d_soff = torch.from_numpy(off).cuda()
+    d_dst = torch.zeros(count * size, dtype=torch.uint8, device="cuda")
+    d_doff = gpu.batch.uniform_offsets(count, size, "cuda")
+    res = gpu.batch.decompress(d_src, d_soff, d_dst, d_doff)
+    torch.cuda.synchronize()
+    assert bool((res == size).all()), res[res != size][:8]
+    want = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
+    assert torch.equal(d_dst, want)
+    # device-side generator produces the same bytes as the host-side one
+    gen = gpu.batch.synth(count, size, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(gen, want)

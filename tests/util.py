@@ -1,0 +1,67 @@
+"""Shared test helpers: seeded inputs covering the block/literal/sequence modes of the format."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def emu_lib():
+    """tests/emu/libzjni_emu.so — lane-serial build of the kernel bodies (test infrastructure)."""
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", d])
+    L = C.CDLL(os.path.join(d, "libzjni_emu.so"))
+    L.emu_decompress.restype = C.c_ulonglong
+    L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
+    if hasattr(L, "emu_compress"):
+        L.emu_compress.restype = C.c_ulonglong
+        L.emu_compress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    return L
+
+
+def emu_decompress(L, frame, cap):
+    dst = C.create_string_buffer(max(cap, 1))
+    r = L.emu_decompress(frame, len(frame), dst, cap)
+    if r >= (1 << 63):
+        return -((1 << 64) - r)
+    return dst.raw[:r]
+
+
+def emu_compress(L, data, level):
+    cap = len(data) + (len(data) >> 8) + 64 + 128
+    dst = C.create_string_buffer(cap)
+    r = L.emu_compress(data, len(data), dst, cap, level)
+    if r >= (1 << 63):
+        return -((1 << 64) - r)
+    return dst.raw[:r]
+
+
+def edge_inputs(seed=1234):
+    """(name, bytes) inputs exercising: empty, tiny, RLE block, raw block, 1-stream and 4-stream
+    literals, predefined / RLE / compressed FSE modes, long matches, long literal runs, max block."""
+    rnd = random.Random(seed)
+    words = [b"alpha", b"beta", b"gamma", b"delta", b"epsilon", b"zeta", b"eta", b"theta"]
+    out = [
+        ("empty", b""),
+        ("one", b"x"),
+        ("two", b"ab"),
+        ("rle_small", b"a" * 100),
+        ("rle_block", b"\x00" * 65536),
+        ("rle_max", b"z" * 131072),
+        ("random_64k", bytes(rnd.getrandbits(8) for _ in range(65536))),
+        ("random_300", bytes(rnd.getrandbits(8) for _ in range(300))),
+        ("text_small", b" ".join(rnd.choice(words) for _ in range(40))),
+        ("text_4k", b" ".join(rnd.choice(words) for _ in range(700))[:4096]),
+        ("text_64k", b" ".join(rnd.choice(words) for _ in range(12000))[:65536]),
+        ("text_128k", b" ".join(rnd.choice(words) for _ in range(24000))[:131072]),
+        ("lowent_64k", bytes(rnd.choice(b"abcdefgh") for _ in range(65536))),
+        ("lowent_1k", bytes(rnd.choice(b"abc") for _ in range(1000))),
+        ("skewed_64k", bytes(min(255, int(rnd.expovariate(0.08))) for _ in range(65536))),
+        ("long_match", (b"0123456789abcdef" * 64) + bytes(rnd.getrandbits(8) for _ in range(500)) + (b"0123456789abcdef" * 4000)),
+        ("periodic_3", b"abc" * 20000),
+        ("lit_run_then_match", bytes(rnd.getrandbits(8) for _ in range(40000)) + b"Q" * 30 + bytes(rnd.getrandbits(8) for _ in range(20000))),
+        ("mixed_100k", (b" ".join(rnd.choice(words) for _ in range(5000)) + bytes(rnd.getrandbits(8) for _ in range(30000)) + bytes(rnd.choice(b"01") for _ in range(40000)))[:100000]),
+        ("binary_struct", b"".join((i % 251).to_bytes(4, "little") + b"\x00\x00\x01\x00" + bytes([rnd.getrandbits(8) & 0x0F]) for i in range(7000))),
+    ]
+    return out

@@ -1,0 +1,366 @@
+"""zstd-jni_amd — MI355X-native batched zstd path behind the com.github.luben.zstd API.
+
+Layout (only what the hot path needs):
+  csrc/      HIP kernels (gfx950) + the C-ABI of include/zjni_amd.h  -> lib/libzjni_amd.so
+  __init__   loader + host-side mirror of the reference's Java classes for this path
+             (Zstd, ZstdCompressCtx, ZstdDecompressCtx, ZstdException: same method names, argument
+             meaning and error behaviour as /root/reference/src/main/java/com/github/luben/zstd/*.java),
+             written in Python because no JVM/javac exists in this image.
+  batch      device-resident batch helpers (torch is used for HBM buffers and streams only)
+
+There is NO CPU fallback: every compute entry raises ZstdException(code 200) when no gfx950 device
+or no built library is present.  The CPU oracle lives in /oracle and is never imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libzjni_amd.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in
+           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_encode.h", "zj_synth.h")]
+BLOCKSIZE_MAX = 1 << 17
+ERR_NO_DEVICE = 200
+ERR_UNSUPPORTED = 201
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU) into lib/libzjni_amd.so."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in SOURCES + [os.path.join(ROOT, "include", "zjni_amd.h")])
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """ctypes handle on libzjni_amd.so.  Fails loudly when the HIP library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run __graft_entry__.build() (needs hipcc); "
+                           "there is no CPU fallback for the zstd hot path")
+    L = C.CDLL(LIB_PATH)
+    sz, vp, u64p = C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)
+    L.zjni_version.restype = C.c_char_p
+    L.zjni_device_count.restype = C.c_int
+    L.zjni_init.restype = C.c_int
+    L.zjni_init.argtypes = [C.c_int]
+    L.zjni_isError.restype = C.c_uint
+    L.zjni_isError.argtypes = [sz]
+    L.zjni_getErrorCode.restype = C.c_int
+    L.zjni_getErrorCode.argtypes = [sz]
+    L.zjni_getErrorName.restype = C.c_char_p
+    L.zjni_getErrorName.argtypes = [sz]
+    L.zjni_compressBound.restype = sz
+    L.zjni_compressBound.argtypes = [sz]
+    L.zjni_getFrameContentSize.restype = C.c_ulonglong
+    L.zjni_getFrameContentSize.argtypes = [vp, sz]
+    for name in ("zjni_decompress_batch_device",):
+        f = getattr(L, name)
+        f.restype = sz
+        f.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.zjni_compress_batch_device.restype = sz
+    L.zjni_compress_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, vp]
+    L.zjni_decompress_batch.restype = sz
+    L.zjni_decompress_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz]
+    L.zjni_compress_batch.restype = sz
+    L.zjni_compress_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int]
+    L.zjni_compress.restype = sz
+    L.zjni_compress.argtypes = [vp, sz, vp, sz, C.c_int]
+    L.zjni_decompress.restype = sz
+    L.zjni_decompress.argtypes = [vp, sz, vp, sz]
+    L.zjni_synth_fill_host.restype = None
+    L.zjni_synth_fill_host.argtypes = [vp, sz, C.c_uint64, sz]
+    L.zjni_synth_fill_device.restype = sz
+    L.zjni_synth_fill_device.argtypes = [vp, sz, C.c_uint64, sz, vp]
+    L.zjni_pack_batch_device.restype = sz
+    L.zjni_pack_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.zjni_kernel_info.restype = C.c_int
+    L.zjni_kernel_info.argtypes = [C.POINTER(C.c_int)] * 4
+    L.zjni_shutdown.restype = None
+    _lib = L
+    return L
+
+
+EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "zjni_isError",
+           "zjni_getErrorCode", "zjni_getErrorName", "zjni_compressBound", "zjni_getFrameContentSize",
+           "zjni_decompress_batch_device", "zjni_compress_batch_device", "zjni_decompress_batch",
+           "zjni_compress_batch", "zjni_compress", "zjni_decompress", "zjni_synth_fill_host",
+           "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device")
+
+
+# --------------------------------------------------------------------------- Java API mirror --
+class ZstdException(RuntimeError):
+    """com.github.luben.zstd.ZstdException (J/ZstdException.java:16-18): code + libzstd's message."""
+
+    def __init__(self, result_or_code, message=None):
+        if message is None:
+            code = Zstd.getErrorCode(result_or_code)
+            message = Zstd.getErrorName(result_or_code)
+        else:
+            code = result_or_code
+        super().__init__(message)
+        self.code = code
+
+    def getErrorCode(self):
+        return self.code
+
+
+def _addr(buf, offset=0):
+    """(address, keepalive) of a bytes / bytearray / memoryview / ctypes buffer."""
+    if isinstance(buf, (bytes,)):
+        keep = C.create_string_buffer(buf, len(buf))
+        return C.addressof(keep) + offset, keep
+    mv = memoryview(buf)
+    keep = (C.c_char * mv.nbytes).from_buffer(buf) if not mv.readonly else C.create_string_buffer(bytes(mv), mv.nbytes)
+    return C.addressof(keep) + offset, keep
+
+
+class Zstd:
+    """Static helpers of J/Zstd.java for this path (one-shot, no dictionary)."""
+
+    @staticmethod
+    def compressBound(srcSize):                                    # J/Zstd.java:914
+        return lib().zjni_compressBound(srcSize)
+
+    @staticmethod
+    def isError(code):                                             # J/Zstd.java:923
+        return bool(lib().zjni_isError(code & 0xFFFFFFFFFFFFFFFF))
+
+    @staticmethod
+    def getErrorName(code):                                        # J/Zstd.java:924
+        return lib().zjni_getErrorName(code & 0xFFFFFFFFFFFFFFFF).decode()
+
+    @staticmethod
+    def getErrorCode(code):                                        # J/Zstd.java:925
+        return lib().zjni_getErrorCode(code & 0xFFFFFFFFFFFFFFFF)
+
+    @staticmethod
+    def errDstSizeTooSmall():                                      # N/jni_zstd.c:638-667
+        return 70
+
+    @staticmethod
+    def errSrcSizeWrong():
+        return 72
+
+    @staticmethod
+    def errCorruptionDetected():
+        return 20
+
+    @staticmethod
+    def defaultCompressionLevel():                                 # J/Zstd.java:1111
+        return 3
+
+    @staticmethod
+    def getFrameContentSize(src, srcPosition=0, srcSize=None):     # J/Zstd.java:776
+        if srcSize is None:
+            srcSize = len(src) - srcPosition
+        a, keep = _addr(src, srcPosition)
+        r = lib().zjni_getFrameContentSize(a, srcSize)
+        return -1 if r == (1 << 64) - 1 else (-2 if r == (1 << 64) - 2 else r)
+
+    decompressedSize = getFrameContentSize                         # J/Zstd.java:792
+
+    @staticmethod
+    def compressByteArray(dst, dstOffset, dstSize, src, srcOffset, srcSize, level):   # J/Zstd.java:151
+        with ZstdCompressCtx() as ctx:
+            ctx.setLevel(level)
+            return ctx._raw(dst, dstOffset, dstSize, src, srcOffset, srcSize)
+
+    @staticmethod
+    def compress(src, level=3):                                    # J/Zstd.java:1137 (byte[] -> byte[])
+        with ZstdCompressCtx() as ctx:
+            ctx.setLevel(level)
+            return ctx.compress(src)
+
+    @staticmethod
+    def decompressByteArray(dst, dstOffset, dstSize, src, srcOffset, srcSize):        # J/Zstd.java:463
+        with ZstdDecompressCtx() as ctx:
+            return ctx._raw(dst, dstOffset, dstSize, src, srcOffset, srcSize)
+
+    @staticmethod
+    def decompress(src, originalSize):                             # J/Zstd.java:1435 (byte[], int -> byte[])
+        with ZstdDecompressCtx() as ctx:
+            return ctx.decompress(src, originalSize)
+
+
+class _AutoClose:
+    """J/AutoCloseBase.java: use-after-close raises."""
+
+    def __init__(self):
+        self._closed = False
+
+    def close(self):
+        self._closed = True
+
+    def _ensure_open(self):
+        if self._closed:
+            raise RuntimeError("Closed")          # IllegalStateException("Closed") in Java
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class ZstdCompressCtx(_AutoClose):
+    """J/ZstdCompressCtx.java — one-shot methods of the hot path."""
+
+    def __init__(self):
+        super().__init__()
+        self.level = 3                                             # ZSTD_CLEVEL_DEFAULT
+
+    def setLevel(self, level):                                     # J/ZstdCompressCtx.java:69
+        self._ensure_open()
+        self.level = level
+        return self
+
+    def _raw(self, dst, dstOffset, dstSize, src, srcOffset, srcSize):
+        """compressByteArray0 / compressDirectByteBuffer0 (N/jni_fast_zstd.c:586-640): argument checks
+        in the same order with the same error codes, then the GPU path instead of ZSTD_compress2."""
+        if dst is None:
+            return -70
+        if src is None:
+            return -72
+        if dstOffset < 0:
+            return -70
+        if srcOffset < 0 or srcSize < 0:
+            return -72
+        if srcOffset + srcSize > len(src):
+            return -72
+        if dstOffset + dstSize > len(dst):
+            return -70
+        sa, k1 = _addr(src, srcOffset)
+        da, k2 = _addr(dst, dstOffset)
+        r = lib().zjni_compress(da, dstSize, sa, srcSize, self.level)
+        return r - (1 << 64) if r >= (1 << 63) else r
+
+    def compressByteArray(self, dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize):   # J/ZstdCompressCtx.java:691
+        self._ensure_open()
+        size = self._raw(dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize)
+        if Zstd.isError(size):
+            raise ZstdException(size)
+        if size > 0x7FFFFFFF:
+            raise ZstdException(1, "Output size is greater than MAX_INT")
+        return size
+
+    compressDirectByteBuffer = compressByteArray                   # J/ZstdCompressCtx.java:647 (same contract)
+
+    def compress(self, src, dst=None):                             # J/ZstdCompressCtx.java:780-797
+        self._ensure_open()
+        if dst is not None:
+            return self.compressByteArray(dst, 0, len(dst), src, 0, len(src))
+        bound = Zstd.compressBound(len(src))
+        if bound > 0x7FFFFFFF:
+            raise ZstdException(1, "Max output size is greater than MAX_INT")
+        out = bytearray(bound)
+        n = self.compressByteArray(out, 0, bound, src, 0, len(src))
+        return bytes(out[:n])
+
+
+class ZstdDecompressCtx(_AutoClose):
+    """J/ZstdDecompressCtx.java — one-shot methods of the hot path."""
+
+    def _raw(self, dst, dstOffset, dstSize, src, srcOffset, srcSize):
+        """decompressByteArray0 / decompressDirectByteBuffer0 (N/jni_fast_zstd.c:777-836)."""
+        if dst is None:
+            return -70
+        if src is None:
+            return -72
+        if dstOffset < 0:
+            return -70
+        if srcOffset < 0 or srcSize < 0:
+            return -72
+        if srcOffset + srcSize > len(src):
+            return -72
+        if dstOffset + dstSize > len(dst):
+            return -70
+        sa, k1 = _addr(src, srcOffset)
+        da, k2 = _addr(dst, dstOffset)
+        r = lib().zjni_decompress(da, dstSize, sa, srcSize)
+        return r - (1 << 64) if r >= (1 << 63) else r
+
+    def decompressByteArray(self, dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize):   # J/ZstdDecompressCtx.java:239
+        self._ensure_open()
+        size = self._raw(dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize)
+        if Zstd.isError(size):
+            raise ZstdException(size)
+        if size > 0x7FFFFFFF:
+            raise ZstdException(1, "Output size is greater than MAX_INT")
+        return size
+
+    decompressDirectByteBuffer = decompressByteArray               # J/ZstdDecompressCtx.java:197
+
+    def decompress(self, src, originalSize=None, dst=None):        # J/ZstdDecompressCtx.java:381-420
+        self._ensure_open()
+        if dst is not None:
+            return self.decompressByteArray(dst, 0, len(dst), src, 0, len(src))
+        if originalSize is None or originalSize < 0:
+            raise ZstdException(72, "Original size should not be negative")
+        out = bytearray(originalSize)
+        n = self.decompressByteArray(out, 0, originalSize, src, 0, len(src))
+        return bytes(out[:n])
+
+
+# --------------------------------------------------------------------------- batch entries ----
+def _check_launch(r):
+    if lib().zjni_isError(r):
+        raise ZstdException(r)
+
+
+def compress_batch(buffers, level=3):
+    """n independent buffers -> n zstd frames through zjni_compress_batch (host pointers)."""
+    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level)
+
+
+def decompress_batch(frames, capacities):
+    """n independent frames -> n buffers through zjni_decompress_batch (host pointers)."""
+    return _host_batch(frames, list(capacities), False, 0)
+
+
+def _host_batch(srcs, caps, is_compress, level):
+    L = lib()
+    n = len(srcs)
+    if n == 0:
+        return []
+    keep = [C.create_string_buffer(bytes(s), max(len(s), 1)) for s in srcs]
+    outs = [C.create_string_buffer(max(c, 1)) for c in caps]
+    sp = (C.c_void_p * n)(*[C.addressof(k) for k in keep])
+    dp = (C.c_void_p * n)(*[C.addressof(o) for o in outs])
+    ss = (C.c_size_t * n)(*[len(s) for s in srcs])
+    dc = (C.c_size_t * n)(*caps)
+    res = (C.c_size_t * n)()
+    if is_compress:
+        r = L.zjni_compress_batch(sp, ss, dp, dc, res, n, level)
+    else:
+        r = L.zjni_decompress_batch(sp, ss, dp, dc, res, n)
+    _check_launch(r)
+    out = []
+    for i in range(n):
+        if L.zjni_isError(res[i]):
+            out.append(ZstdException(res[i]))
+        else:
+            out.append(outs[i].raw[:res[i]])
+    return out
+
+
+def synth_host(buf_size, first_index, n):
+    """The SURVEY §8(d) mixed-entropy generator on the host (same bytes as the device generator)."""
+    out = C.create_string_buffer(buf_size * n)
+    lib().zjni_synth_fill_host(out, buf_size, first_index, n)
+    return out.raw
+
+
+from . import batch, shard  # noqa: E402,F401

@@ -1,0 +1,78 @@
+"""Device-resident batches: the HBM layout the kernels consume (include/zjni_amd.h).
+
+A batch is one uint8 blob in HBM plus an int64[n+1] offsets tensor (buffer i = blob[off[i]:off[i+1]]).
+torch is used only for device memory and the stream handle; all compute is in libzjni_amd.so.
+"""
+import torch
+
+from . import lib, ZstdException
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(r):
+    L = lib()
+    if L.zjni_isError(r):
+        raise ZstdException(r)
+
+
+def init(device_index=None):
+    """Bind the calling thread to a GPU and create its persistent-kernel state."""
+    if not torch.cuda.is_available():
+        raise ZstdException(200, "zjni: no gfx950 device available")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    torch.cuda.set_device(device_index)
+    r = lib().zjni_init(device_index)
+    if r != 0:
+        raise ZstdException(-r, "zjni_init failed")
+    return device_index
+
+
+def uniform_offsets(n, size, device):
+    return torch.arange(0, n + 1, dtype=torch.int64, device=device) * size
+
+
+def synth(n, buf_size, first_index=0, device="cuda"):
+    """n mixed-entropy buffers of buf_size bytes generated in HBM."""
+    blob = torch.empty(n * buf_size, dtype=torch.uint8, device=device)
+    _check(lib().zjni_synth_fill_device(blob.data_ptr(), buf_size, first_index, n, _stream_ptr()))
+    return blob
+
+
+def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None):
+    """Enqueue zjni_compress_batch_device on the current stream; returns the int64[n] result tensor
+    (compressed size per buffer, or a negative ZSTD/ZJNI error code)."""
+    n = src_off.numel() - 1
+    if results is None:
+        results = torch.empty(n, dtype=torch.int64, device=src_blob.device)
+    _check(lib().zjni_compress_batch_device(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
+                                            results.data_ptr(), n, level, _stream_ptr()))
+    return results
+
+
+def decompress(src_blob, src_off, dst_blob, dst_off, results=None):
+    """Enqueue zjni_decompress_batch_device on the current stream; returns int64[n] results."""
+    n = src_off.numel() - 1
+    if results is None:
+        results = torch.empty(n, dtype=torch.int64, device=src_blob.device)
+    _check(lib().zjni_decompress_batch_device(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
+                                              results.data_ptr(), n, _stream_ptr()))
+    return results
+
+
+def pack(results, dst_blob, dst_off):
+    """Tightly pack a compress batch's variable-size outputs (sizes = results) into one blob:
+    returns (packed_blob, packed_off int64[n+1]).  The exclusive scan is torch plumbing; the byte
+    movement is zj_pack_kernel."""
+    n = results.numel()
+    sizes = results.clamp(min=0)
+    packed_off = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
+    packed_off[1:] = torch.cumsum(sizes, 0)
+    total = int(packed_off[-1].item())
+    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=results.device)
+    _check(lib().zjni_pack_batch_device(dst_blob.data_ptr(), dst_off.data_ptr(), sizes.data_ptr(), packed.data_ptr(),
+                                        packed_off.data_ptr(), n, _stream_ptr()))
+    return packed[:total], packed_off

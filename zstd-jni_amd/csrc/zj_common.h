@@ -27,10 +27,12 @@ typedef int64_t i64;
 #include <hip/hip_runtime.h>
 #define ZJ_DEV __device__ __forceinline__
 #define ZJ_DEV_NOINLINE __device__ __noinline__
+#define ZJ_HD __host__ __device__ __forceinline__
 #define ZJ_ON_GPU 1
 #else
 #define ZJ_DEV static inline
 #define ZJ_DEV_NOINLINE static
+#define ZJ_HD static inline
 #define ZJ_ON_GPU 0
 #endif
 
@@ -71,17 +73,17 @@ struct Grp {
 
 // ---- memory helpers (gfx950 supports unaligned global and LDS dword/qword access; hipcc emits a
 //      single global_load_dwordx2 / ds_read_b64 for these memcpy's) -------------------------------
-ZJ_DEV u32 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
-ZJ_DEV u32 ld24(const u8* p) { return ld16(p) | ((u32)p[2] << 16); }
-ZJ_DEV u32 ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
-ZJ_DEV u64 ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
-ZJ_DEV void st16(u8* p, u32 v) { u16 w = (u16)v; __builtin_memcpy(p, &w, 2); }
-ZJ_DEV void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
-ZJ_DEV void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
+ZJ_HD u32 ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
+ZJ_HD u32 ld24(const u8* p) { return ld16(p) | ((u32)p[2] << 16); }
+ZJ_HD u32 ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+ZJ_HD u64 ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+ZJ_HD void st16(u8* p, u32 v) { u16 w = (u16)v; __builtin_memcpy(p, &w, 2); }
+ZJ_HD void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
+ZJ_HD void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 
-ZJ_DEV u32 zj_hibit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // v != 0
-ZJ_DEV u32 zj_min(u32 a, u32 b) { return a < b ? a : b; }
-ZJ_DEV u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
+ZJ_HD u32 zj_hibit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // v != 0
+ZJ_HD u32 zj_min(u32 a, u32 b) { return a < b ? a : b; }
+ZJ_HD u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
 
 // Compiler-level ordering point for global memory traffic that crosses lanes of the same wave
 // (LZ77 execution reads bytes other lanes stored a moment ago).  At workgroup scope on gfx950 this

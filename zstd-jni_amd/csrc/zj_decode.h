@@ -47,6 +47,7 @@ struct ZDecShared {
     u32 sMl[ZD_SEQ_BATCH];
     u32 sOff[ZD_SEQ_BATCH];
     u8 weights[256];
+    u32 hrank[32];
     u16 symPos[256];                // Huffman: first table cell of each symbol
     short norm[64];
     u16 symNext[64 * 3];
@@ -73,8 +74,20 @@ struct ZDecShared {
 #define ZD_ML_DEFNORM_INIT { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 }
 #define ZD_OF_DEFNORM_INIT { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 }
 
-ZJ_DEV u32 zd_ll_bits(u32 c) { const u8 t[36] = ZD_LL_BITS_INIT; return t[c]; }
-ZJ_DEV u32 zd_ml_bits(u32 c) { const u8 t[53] = ZD_ML_BITS_INIT; return t[c]; }
+#if ZJ_ON_GPU
+#define ZD_CONST static __device__ const
+#else
+#define ZD_CONST static const
+#endif
+ZD_CONST u8 zd_k_ll_bits[36] = ZD_LL_BITS_INIT;
+ZD_CONST u8 zd_k_ml_bits[53] = ZD_ML_BITS_INIT;
+ZD_CONST u32 zd_k_ll_base[36] = ZD_LL_BASE_INIT;
+ZD_CONST u32 zd_k_ml_base[53] = ZD_ML_BASE_INIT;
+ZD_CONST short zd_k_ll_defnorm[36] = ZD_LL_DEFNORM_INIT;
+ZD_CONST short zd_k_ml_defnorm[53] = ZD_ML_DEFNORM_INIT;
+ZD_CONST short zd_k_of_defnorm[29] = ZD_OF_DEFNORM_INIT;
+ZJ_DEV u32 zd_ll_bits(u32 c) { return zd_k_ll_bits[c]; }
+ZJ_DEV u32 zd_ml_bits(u32 c) { return zd_k_ml_bits[c]; }
 
 // ------------------------------------------------------------------ wide cooperative copy ----
 template <class G>
@@ -278,7 +291,8 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
 // Returns header bytes, 0 on error.  Publishes sh.weights[0..nbSym), sh.hufLog, and nbSym via out.
 ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* nbSymOut) {
     u32 iSize, oSize, total = 0;
-    u32 rank[ZD_HUF_LOG_MAX + 2];
+    u32* const rank = sh.hrank;            // [ZD_HUF_LOG_MAX + 2] in LDS (dynamic indexing)
+    u32* const start = sh.hrank + 16;
     if (!srcSize) return 0;
     iSize = src[0];
     if (iSize >= 128) {
@@ -338,7 +352,7 @@ ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* 
         sh.weights[oSize] = (u8)last; rank[last]++;
         if (rank[1] < 2 || (rank[1] & 1)) return 0;
         // first cell per symbol: weights ascending, symbols ascending inside a weight
-        u32 start[ZD_HUF_LOG_MAX + 2]; u32 cur = 0;
+        u32 cur = 0;
         for (u32 w = 1; w <= tl; w++) { start[w] = cur; cur += rank[w] << (w - 1); }
         for (u32 n = 0; n <= oSize; n++) {
             u32 const w = sh.weights[n];
@@ -457,10 +471,10 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 u32 b = off + 6;
                 if (b + l1 + l2 + l3 > end || 3 * seg > litSize) err = ZJ_E_CORRUPTION;
                 else {
-                    u32 const lens[4] = { l1, l2, l3, end - b - l1 - l2 - l3 };
+                    sh.hCnt[0] = l1; sh.hCnt[1] = l2; sh.hCnt[2] = l3; sh.hCnt[3] = end - b - l1 - l2 - l3;
                     for (u32 t = 0; t < 4 && !err; t++) {
-                        u32 const e = b + lens[t];
-                        if (lens[t] == 0 || bsrc[e - 1] == 0) { err = ZJ_E_CORRUPTION; break; }
+                        u32 const len = sh.hCnt[t], e = b + len;
+                        if (len == 0 || bsrc[e - 1] == 0) { err = ZJ_E_CORRUPTION; break; }
                         sh.hS0[t] = b * 8; sh.hA[t] = (e - 1) * 8 + zj_hibit(bsrc[e - 1]);
                         sh.hN[t] = (t < 3) ? seg : litSize - 3 * seg; sh.hDst[t] = t * seg;
                         b = e;
@@ -527,16 +541,15 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 u32 const modes = bsrc[ip++];
                 if (modes & 3) err = ZJ_E_CORRUPTION;
                 // walk the three table descriptions; NCount parsing is inherently serial
-                u32 const maxSym[3] = { 35, 31, 52 }, maxLog[3] = { 9, 8, 9 };
                 for (u32 t = 0; t < 3 && !err; t++) {
                     u32 const mode = (modes >> (6 - 2 * t)) & 3;
                     sh.tblMode[t] = mode;
                     if (mode == 1) {
-                        if (ip >= bsize || bsrc[ip] > maxSym[t]) err = ZJ_E_CORRUPTION; else { sh.tblMax[t] = bsrc[ip]; ip++; }
+                        if (ip >= bsize || bsrc[ip] > (t == 0 ? 35u : (t == 1 ? 31u : 52u))) err = ZJ_E_CORRUPTION; else { sh.tblMax[t] = bsrc[ip]; ip++; }
                     } else if (mode == 2) {
-                        u32 max = maxSym[t], tl = 0;
+                        u32 max = (t == 0 ? 35u : (t == 1 ? 31u : 52u)), tl = 0;
                         u32 const h = zd_read_ncount(sh.norm, &max, &tl, bsrc + ip, bsize - ip);
-                        if (!h || h > bsize - ip || tl > maxLog[t]) err = ZJ_E_CORRUPTION;
+                        if (!h || h > bsize - ip || tl > (t == 1 ? 8u : 9u)) err = ZJ_E_CORRUPTION;
                         else {
                             u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
                             if (!zd_build_fse(cells, sh.norm, sh.symNext, max, tl, t)) err = ZJ_E_CORRUPTION;
@@ -562,9 +575,8 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             u32 const mode = sh.tblMode[t];
             u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
             if (mode == 0) {
-                const short dLL[36] = ZD_LL_DEFNORM_INIT; const short dOF[29] = ZD_OF_DEFNORM_INIT; const short dML[53] = ZD_ML_DEFNORM_INIT;
                 u32 const log = (t == 1) ? 5 : 6;
-                zd_build_fse(cells, t == 0 ? dLL : (t == 1 ? dOF : dML), sh.symNext + 64 * t, t == 0 ? 35 : (t == 1 ? 28 : 52), log, t);
+                zd_build_fse(cells, t == 0 ? zd_k_ll_defnorm : (t == 1 ? zd_k_of_defnorm : zd_k_ml_defnorm), sh.symNext + 64 * t, t == 0 ? 35 : (t == 1 ? 28 : 52), log, t);
                 if (t == 0) sh.llLog = log; else if (t == 1) sh.ofLog = log; else sh.mlLog = log;
             } else if (mode == 1) {
                 u32 const sym = sh.tblMax[t];
@@ -644,11 +656,10 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
 template <class G>
 ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch) {
     GRP_SERIAL(g) {
-        const u32 lb[36] = ZD_LL_BASE_INIT; const u32 mb[53] = ZD_ML_BASE_INIT;
-        for (u32 i = 0; i < 36; i++) sh.llBase[i] = lb[i];
-        for (u32 i = 0; i < 53; i++) sh.mlBase[i] = mb[i];
         sh.err = 0;
     }
+    GRP_FOR(g, i, 36) sh.llBase[i] = zd_k_ll_base[i];
+    GRP_FOR(g, i, 53) sh.mlBase[i] = zd_k_ml_base[i];
     g.sync();
     u32 ipos = 0, total = 0;
     while (ipos < srcSize) {

@@ -1,0 +1,346 @@
+// zj_kernels.hip — gfx950 kernels + the C-ABI of include/zjni_amd.h (libzjni_amd.so).
+//
+// Launch shape: persistent workgroups of ONE wavefront (64 lanes); each pulls frame indices from a
+// device-scope atomic counter (frames differ 4x in cost), so the grid is
+// (#CUs x resident workgroups/CU), not the batch size.  Block b lands on XCD b % 8; frames are
+// independent, so no cross-XCD traffic exists and the per-XCD L2s only see their own frames.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include <string.h>
+#include <stdio.h>
+#include "../../include/zjni_amd.h"
+#include "zj_decode.h"
+#include "zj_encode.h"
+#include "zj_synth.h"
+
+#define ZJNI_ERR(code) ((size_t)0 - (size_t)(code))
+
+// ============================================================================ kernels ==========
+__global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
+                                                        u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                        u64* __restrict__ result, u32 n, u32* counter, u8* scratch) {
+    __shared__ ZDecShared sh;
+    __shared__ u32 s_idx;
+    Grp<64> g;
+    u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
+    for (;;) {
+        if (threadIdx.x == 0) s_idx = atomicAdd(counter, 1u);
+        __syncthreads();
+        u32 const i = s_idx;
+        __syncthreads();
+        if (i >= n) break;
+        u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
+        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit);
+        if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
+                                                        u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                        u64* __restrict__ result, u32 n, u32 level, u32* counter, u8* scratch) {
+    __shared__ ZEncShared sh;
+    __shared__ u32 s_idx;
+    Grp<64> g;
+    u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
+    for (;;) {
+        if (threadIdx.x == 0) s_idx = atomicAdd(counter, 1u);
+        __syncthreads();
+        u32 const i = s_idx;
+        __syncthreads();
+        if (i >= n) break;
+        u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
+        u64 const r = ze_compress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0 > 0xFFFFFFFFull ? 0xFFFFFFFFull : d1 - d0), level, ws);
+        if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
+__global__ void zj_synth_kernel(u8* dst, u32 bufSize, u64 firstIndex, u32 n) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) zs_fill(dst + (size_t)i * bufSize, bufSize, firstIndex + i);
+}
+
+// Tight packing of a batch's variable-size outputs (for the multi-GPU gather): frame i moves from
+// src[srcOff[i] .. +size[i]) to dst[dstOff[i] ..).  One workgroup per frame, 16 B per lane.
+__global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ sizes,
+                                                       u8* __restrict__ dst, const u64* __restrict__ dstOff, u32 n) {
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        u64 const sz = sizes[i];
+        if (sz > ((u64)1 << 40)) continue;              // error result: nothing to move
+        const u8* s = src + srcOff[i]; u8* d = dst + dstOff[i];
+        u32 const n16 = (u32)(sz >> 4);
+        for (u32 k = threadIdx.x; k < n16; k += 256) { u64 a = ld64(s + 16 * k), b = ld64(s + 16 * k + 8); st64(d + 16 * k, a); st64(d + 16 * k + 8, b); }
+        for (u32 k = (n16 << 4) + threadIdx.x; k < (u32)sz; k += 256) d[k] = s[k];
+    }
+}
+
+// ============================================================================ host state =======
+namespace {
+struct DevState {
+    int ordinal = -1;
+    int numCU = 0;
+    int decGrid = 0, encGrid = 0;
+    u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
+    u8* decScratch = nullptr;
+    u8* encScratch = nullptr;
+    // staging for the host-pointer entries
+    u8* hPinned = nullptr; size_t hPinnedCap = 0;
+    u8* dStage = nullptr; size_t dStageCap = 0;
+};
+std::mutex g_mu;        // guards g_dev
+std::mutex g_stage_mu;  // serialises users of the per-device host staging area
+std::vector<DevState> g_dev;
+thread_local int t_dev = -1;
+
+int dev_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+DevState* get_state(int ordinal) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int const n = dev_count();
+    if (n <= 0 || ordinal < 0 || ordinal >= n) return nullptr;
+    if ((int)g_dev.size() < n) g_dev.resize(n);
+    DevState& d = g_dev[ordinal];
+    if (hipSetDevice(ordinal) != hipSuccess) return nullptr;
+    if (d.ordinal < 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return nullptr;
+        d.numCU = prop.multiProcessorCount;
+        int perCU = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_decode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 8;
+        d.decGrid = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
+        d.encGrid = d.numCU * perCU;
+        if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
+        if (hipMalloc(&d.decScratch, (size_t)d.decGrid * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
+        if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
+        if (hipMemset(d.encScratch, 0, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
+        d.ordinal = ordinal;
+    }
+    return &d;
+}
+
+DevState* cur_state() {
+    if (t_dev < 0) {
+        int cur = 0;
+        if (dev_count() <= 0) return nullptr;
+        if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+        t_dev = cur;
+    }
+    return get_state(t_dev);
+}
+
+bool ensure_staging(DevState* d, size_t bytes) {
+    if (d->hPinnedCap < bytes) {
+        if (d->hPinned) (void)hipHostFree(d->hPinned);
+        if (d->dStage) (void)hipFree(d->dStage);
+        d->hPinned = nullptr; d->dStage = nullptr; d->hPinnedCap = d->dStageCap = 0;
+        size_t const cap = bytes + (bytes >> 2) + (1u << 20);
+        if (hipHostMalloc(&d->hPinned, cap, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipMalloc(&d->dStage, cap) != hipSuccess) return false;
+        d->hPinnedCap = d->dStageCap = cap;
+    }
+    return true;
+}
+}  // namespace
+
+// ============================================================================ C-ABI ============
+extern "C" {
+
+const char* zjni_version(void) { return ZJNI_VERSION_STRING; }
+int zjni_device_count(void) { return dev_count(); }
+
+int zjni_init(int ordinal) {
+    if (dev_count() <= 0) return -(int)ZJNI_ERROR_no_device;
+    DevState* d = get_state(ordinal);
+    if (!d) return -(int)ZJNI_ERROR_no_device;
+    t_dev = ordinal;
+    return 0;
+}
+
+void zjni_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& d : g_dev) {
+        if (d.ordinal < 0) continue;
+        (void)hipSetDevice(d.ordinal);
+        (void)hipFree(d.counters); (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
+        if (d.hPinned) (void)hipHostFree(d.hPinned);
+        if (d.dStage) (void)hipFree(d.dStage);
+        d = DevState();
+    }
+}
+
+unsigned zjni_isError(size_t r) { return r > ZJNI_ERR(256) ? 1u : 0u; }
+int zjni_getErrorCode(size_t r) { return zjni_isError(r) ? (int)(0 - r) : 0; }
+const char* zjni_getErrorName(size_t r) {
+    // strings are libzstd's (N/common/error_private.c:15-65) so Java-side message checks keep passing
+    switch (zjni_getErrorCode(r)) {
+    case 0: return "No error detected";
+    case 1: return "Error (generic)";
+    case 10: return "Unknown frame descriptor";
+    case 14: return "Unsupported frame parameter";
+    case 16: return "Frame requires too much memory for decoding";
+    case 20: return "Data corruption detected";
+    case 22: return "Restored data doesn't match checksum";
+    case 24: return "Header of Literals' block doesn't respect format specification";
+    case 30: return "Dictionary is corrupted";
+    case 32: return "Dictionary mismatch";
+    case 40: return "Unsupported parameter";
+    case 42: return "Parameter is out of bound";
+    case 44: return "tableLog requires too much memory : unsupported";
+    case 64: return "Allocation error : not enough memory";
+    case 70: return "Destination buffer is too small";
+    case 72: return "Src size is incorrect";
+    case 200: return "zjni: no gfx950 device available";
+    case 201: return "zjni: input outside the GPU path (use the CPU path)";
+    default: return "Unspecified error code";
+    }
+}
+
+size_t zjni_compressBound(size_t s) {
+    return s + (s >> 8) + (s < (128u << 10) ? (((128u << 10) - s) >> 11) : 0);
+}
+
+unsigned long long zjni_getFrameContentSize(const void* srcv, size_t srcSize) {
+    // N/decompress/zstd_decompress.c:447-557 / :588-603
+    const u8* p = (const u8*)srcv;
+    if (srcSize < 5) return (unsigned long long)-2;
+    u32 const magic = ld32(p);
+    if (magic != 0xFD2FB528u) return ((magic & 0xFFFFFFF0u) == 0x184D2A50u) ? 0ull : (unsigned long long)-2;
+    u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
+    u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
+    size_t pos = 5 + !single + didSz;
+    if ((fhd & 8) || srcSize < pos + fcsSz) return (unsigned long long)-2;
+    if (fcsid == 0) return single ? p[pos] : (unsigned long long)-1;
+    if (fcsid == 1) return ld16(p + pos) + 256;
+    if (fcsid == 2) return ld32(p + pos);
+    return ld64(p + pos);
+}
+
+int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* encodeLds) {
+    DevState* d = cur_state();
+    if (decodeLds) *decodeLds = (int)sizeof(ZDecShared);
+    if (encodeLds) *encodeLds = (int)sizeof(ZEncShared);
+    if (!d) return -(int)ZJNI_ERROR_no_device;
+    if (decodeGrid) *decodeGrid = d->decGrid;
+    if (encodeGrid) *encodeGrid = d->encGrid;
+    return 0;
+}
+
+size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                    uint64_t* d_result, size_t n, void* stream) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32 const grid = (u32)(n < (size_t)d->decGrid ? n : (size_t)d->decGrid);
+    hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+
+size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                  uint64_t* d_result, size_t n, int level, void* stream) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d->counters + 16, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32 const grid = (u32)(n < (size_t)d->encGrid ? n : (size_t)d->encGrid);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, d->counters + 16, d->encScratch);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+
+// ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
+static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
+                         size_t* result, size_t n, int level) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    size_t srcTotal = 0, dstTotal = 0;
+    for (size_t i = 0; i < n; i++) { srcTotal += srcSize[i]; dstTotal += dstCap[i]; }
+    size_t const offBytes = (n + 1) * 8;
+    // staging layout: [srcOff][dstOff][result][src blob][dst blob]
+    size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
+    size_t const total = oDst + dstTotal + 16;
+    std::lock_guard<std::mutex> lk(g_stage_mu);   // one staging area per device
+    if (!ensure_staging(d, total)) return ZJNI_ERR(64);
+    u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff);
+    size_t a = 0, b = 0;
+    for (size_t i = 0; i < n; i++) {
+        hs[i] = a; hd[i] = b;
+        if (srcSize[i]) memcpy(d->hPinned + oSrc + a, src[i], srcSize[i]);
+        a += srcSize[i]; b += dstCap[i];
+    }
+    hs[n] = a; hd[n] = b;
+    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcTotal, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    size_t r;
+    if (compress)
+        r = zjni_compress_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                                       (u64*)(d->dStage + oRes), n, level, nullptr);
+    else
+        r = zjni_decompress_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                                         (u64*)(d->dStage + oRes), n, nullptr);
+    if (zjni_isError(r)) return r;
+    if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, n * 8, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (hipMemcpyAsync(d->hPinned + oDst, d->dStage + oDst, dstTotal, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    const u64* hr = (const u64*)(d->hPinned + oRes);
+    for (size_t i = 0; i < n; i++) {
+        result[i] = (size_t)hr[i];
+        if (!zjni_isError(result[i]) && result[i]) memcpy(dst[i], d->hPinned + oDst + hd[i], result[i]);
+    }
+    return 0;
+}
+
+size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n) {
+    return host_batch(false, src, srcSize, dst, dstCap, result, n, 0);
+}
+size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level) {
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    return host_batch(true, src, srcSize, dst, dstCap, result, n, level);
+}
+
+size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
+    size_t res = 0; const void* s = src; void* dd = dst;
+    size_t const r = zjni_compress_batch(&s, &srcSize, &dd, &dstCap, &res, 1, level);
+    return zjni_isError(r) ? r : res;
+}
+size_t zjni_decompress(void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    size_t res = 0; const void* s = src; void* dd = dst;
+    size_t const r = zjni_decompress_batch(&s, &srcSize, &dd, &dstCap, &res, 1);
+    return zjni_isError(r) ? r : res;
+}
+
+void zjni_synth_fill_host(void* dst, size_t bufSize, uint64_t firstIndex, size_t nBuffers) {
+    for (size_t i = 0; i < nBuffers; i++) zs_fill((u8*)dst + i * bufSize, (u32)bufSize, firstIndex + i);
+}
+size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, size_t nBuffers, void* stream) {
+    if (!cur_state()) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (nBuffers == 0) return 0;
+    hipLaunchKernelGGL(zj_synth_kernel, dim3((u32)((nBuffers + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (u8*)d_dst, (u32)bufSize, firstIndex, (u32)nBuffers);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+
+size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
+                              void* d_dst, const uint64_t* d_dst_off, size_t n, void* stream) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    u32 const grid = (u32)(n < (size_t)d->numCU * 8 ? n : (size_t)d->numCU * 8);
+    hipLaunchKernelGGL(zj_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u8*)d_src, (const u64*)d_src_off,
+                       (const u64*)d_sizes, (u8*)d_dst, (const u64*)d_dst_off, (u32)n);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+
+}  // extern "C"
