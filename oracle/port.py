@@ -32,6 +32,8 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.zso_compress.restype = C.c_size_t
         L.zso_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.zso_compress_ex.restype = C.c_size_t
+        L.zso_compress_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.zso_compress_bound.restype = C.c_size_t
         L.zso_compress_bound.argtypes = [C.c_size_t]
         L.zso_frame_content_size.restype = C.c_ulonglong
@@ -57,11 +59,11 @@ def decompress(frame: bytes, cap: int) -> bytes:
     return dst.raw[:r]
 
 
-def compress(data: bytes, level: int = 3, checksum: bool = False) -> bytes:
+def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0) -> bytes:
     L = lib()
     cap = L.zso_compress_bound(len(data))
     dst = C.create_string_buffer(max(cap, 1))
-    r = _check(L.zso_compress(dst, cap, data, len(data), level, int(checksum)))
+    r = _check(L.zso_compress_ex(dst, cap, data, len(data), level, int(checksum), hash_log, chain_log))
     return dst.raw[:r]
 
 

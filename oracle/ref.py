@@ -44,6 +44,8 @@ def lib():
 
 
 ZSTD_c_compressionLevel = 100
+ZSTD_c_hashLog = 102
+ZSTD_c_chainLog = 103
 ZSTD_c_checksumFlag = 201
 ZSTD_c_contentSizeFlag = 200
 
@@ -59,7 +61,7 @@ def _check(r):
     return r
 
 
-def compress(data: bytes, level: int = 3, checksum: bool = False) -> bytes:
+def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0) -> bytes:
     """ZSTD_compress2 with the parameters zstd-jni's ZstdCompressCtx sets
     (reference src/main/native/jni_fast_zstd.c:606-607)."""
     L = lib()
@@ -67,6 +69,10 @@ def compress(data: bytes, level: int = 3, checksum: bool = False) -> bytes:
     try:
         _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_compressionLevel, level))
         _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_checksumFlag, int(checksum)))
+        if hash_log:
+            _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_hashLog, hash_log))      # ZstdCompressCtx.setHashLog
+        if chain_log:
+            _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_chainLog, chain_log))    # ZstdCompressCtx.setChainLog
         cap = L.ZSTD_compressBound(len(data))
         dst = C.create_string_buffer(max(cap, 1))
         r = _check(L.ZSTD_compress2(cctx, dst, cap, data, len(data)))

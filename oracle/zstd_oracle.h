@@ -56,9 +56,11 @@ size_t zso_find_frame_compressed_size(const void* src, size_t srcSize);
 /* ---- encode (oracle/zstd_oracle_enc.c) ---- */
 size_t zso_compress_bound(size_t srcSize);
 /* One-shot ZSTD_compress2 restatement for level in [1,3], no dictionary, checksum optional,
- * any srcSize (multi-block inputs are split in 128 KiB blocks with window/entropy carry-over like
- * ZSTD_compress_frameChunk).  Returns compressed size or error. */
+ * srcSize <= 128 KiB (one block; larger inputs return ZSO_error_parameter_unsupported).
+ * Output is byte-identical to the reference's.  Returns compressed size or error. */
 size_t zso_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum);
+/* Same with ZSTD_c_hashLog / ZSTD_c_chainLog overrides (0 = level default). */
+size_t zso_compress_ex(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum, int hashLog, int chainLog);
 
 /* XXH64 (N/common/xxhash.h) — used for the optional frame checksum */
 uint64_t zso_xxh64(const void* p, size_t len, uint64_t seed);

@@ -66,3 +66,46 @@ def test_port_decoder_errors(oracle_port, oracle_ref):
     with pytest.raises(oracle_port.ZstdOracleError) as e:
         oracle_port.decompress(b"\x00\x01\x02\x03\x04\x05", 10)
     assert e.value.code == 10
+
+
+# ---------------------------------------------------------------- encoder restatement -------
+def test_port_encoder_reproduces_reference_golden(oracle_port, oracle_ref):
+    # one-shot ZSTD_compress2(xmlsmall, L3) == xmlsmall-sized.zst, byte for byte
+    xs = golden("xmlsmall")
+    assert oracle_port.compress(xs, 3) == golden("xmlsmall-sized.zst") == oracle_ref.compress(xs, 3)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_port_encoder_byte_identical_on_edge_inputs(oracle_port, oracle_ref, level):
+    for name, data in edge_inputs():
+        assert oracle_port.compress(data, level) == oracle_ref.compress(data, level), name
+
+
+def test_port_encoder_byte_identical_on_xml_and_synthetic(oracle_port, oracle_ref, zj):
+    import random
+    rnd = random.Random(7)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for size in (4096, 65536, 131072):
+        for _ in range(3):
+            off = rnd.randrange(0, len(xml) - size)
+            d = xml[off:off + size]
+            for level in (1, 2, 3):
+                assert oracle_port.compress(d, level) == oracle_ref.compress(d, level), (size, off, level)
+            # ZSTD_c_hashLog / ZSTD_c_chainLog overrides (ZstdCompressCtx.setHashLog/setChainLog):
+            # (14, 13) is the LDS-sized level-3 variant the GPU path runs
+            for hl, cl in ((14, 13), (13, 12)):
+                assert oracle_port.compress(d, 3, False, hl, cl) == oracle_ref.compress(d, 3, False, hl, cl), (size, off, hl, cl)
+    for _ in range(120):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 70000), rnd.randrange(0, 131073), 65536, 4096, 131072])
+        idx = rnd.randrange(0, 10000)
+        d = zj.synth_host(size, idx, 1) if size else b""
+        for level in (1, 2, 3):
+            assert oracle_port.compress(d, level) == oracle_ref.compress(d, level), (size, idx, level)
+        assert oracle_port.compress(d, 3, True, 14, 13) == oracle_ref.compress(d, 3, True, 14, 13), (size, idx)
+
+
+def test_port_encoder_scope_and_errors(oracle_port):
+    with pytest.raises(oracle_port.ZstdOracleError) as e:
+        oracle_port.compress(b"x" * 131073, 3)
+    assert e.value.code == 40
+    assert oracle_port.compress(b"", 3) == bytes.fromhex("28b52ffd2000010000")
