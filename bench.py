@@ -108,6 +108,8 @@ def main():
     bound = zj.Zstd.compressBound(size)
     comp = torch.empty(n * bound, dtype=torch.uint8, device=dev)
     comp_off = B.uniform_offsets(n, bound, dev)
+    packed = torch.empty(n * bound, dtype=torch.uint8, device=dev)      # frames back to back (what a consumer / the gather sees)
+    packed_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     back = torch.empty(n * size, dtype=torch.uint8, device=dev)
     csz = torch.empty(n, dtype=torch.int64, device=dev)
     dsz = torch.empty(n, dtype=torch.int64, device=dev)
@@ -118,20 +120,20 @@ def main():
         return
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # recorded on the stream the kernels run on
-    t_c, t_d, t_g = [], [], []
+    t_c, t_p, t_d, t_g = [], [], [], []
 
     def step(timed):
-        e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+        e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
         e0.record(); B.compress(src, src_off, comp, comp_off, level, csz); e1.record()
-        # decompress reads each frame in place (frame i at comp_off[i], size csz[i] <= capacity)
-        B.decompress(comp, comp_off, back, src_off, dsz); e2.record()
+        B.pack(csz, comp, comp_off, out=packed, out_off=packed_off); e2.record()      # frames back to back
+        B.decompress(packed, packed_off, back, src_off, dsz); e3.record()
         if world > 1 and not a.no_gather:
-            packed, poff = B.pack(csz, comp, comp_off)
-            shard.gather_packed(packed, csz, dst=0)
-        e3.record()
+            total = int(packed_off[-1].item())
+            shard.gather_packed(packed[:total], csz, dst=0)
+        e4.record()
         if timed:
             torch.cuda.synchronize()
-            t_c.append(e0.elapsed_time(e1)); t_d.append(e1.elapsed_time(e2)); t_g.append(e2.elapsed_time(e3))
+            t_c.append(e0.elapsed_time(e1)); t_p.append(e1.elapsed_time(e2)); t_d.append(e2.elapsed_time(e3)); t_g.append(e3.elapsed_time(e4))
 
     for _ in range(a.warmup):
         step(False)
@@ -163,6 +165,7 @@ def main():
         k = min(a.verify_sample, n)
         sizes = csz[:k].cpu().tolist()
         blob = comp[:k * bound].cpu().numpy()
+        host_off = None
         host_src = src[:k * size].cpu().numpy().tobytes()
         checker = ref if ref.available() else port
         cpu_ok = True
@@ -189,7 +192,7 @@ def main():
     if rank == 0:
         ms = wall * 1000.0 / a.steps
         total_unc = world * n * size
-        mc, md, mg = (sum(x) / len(x) for x in (t_c, t_d, t_g))
+        mc, mp, md, mg = (sum(x) / len(x) for x in (t_c, t_p, t_d, t_g))
         alg = n * size + csum                                  # S + C per launch
         dom_ms, dom = (mc, "zj_encode_kernel") if mc >= md else (md, "zj_decode_kernel")
         achieved = alg / 1e9 / (dom_ms / 1e3)
@@ -201,7 +204,7 @@ def main():
                        "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
                        "gather": bool(world > 1 and not a.no_gather)},
             "compress_GiBps_per_gpu": n * size / GIB / (mc / 1e3), "decompress_GiBps_per_gpu": n * size / GIB / (md / 1e3),
-            "kernel_ms": {"zj_encode_kernel": mc, "zj_decode_kernel": md, "pack+gather": mg},
+            "kernel_ms": {"zj_encode_kernel": mc, "zj_pack_kernel": mp, "zj_decode_kernel": md, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

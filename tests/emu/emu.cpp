@@ -13,3 +13,15 @@ extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned 
     return r;
 }
 extern "C" unsigned emu_dec_shared_bytes() { return (unsigned)sizeof(ZDecShared); }
+
+#include "../../zstd-jni_amd/csrc/zj_encode.h"
+extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    Grp<1> g;
+    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
+    u8* lds = (u8*)calloc(1, 160 * 1024);
+    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws);
+    free(ws); free(lds); free(sh);
+    return r;
+}
+extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return ze_lds_need(level, srcSize); }

@@ -1,0 +1,57 @@
+"""CPU (-m "not gpu"): the encoder kernel BODY (zstd-jni_amd/csrc/zj_encode.h), built lane-serial
+(W = 1, tests/emu), is byte-identical to the reference's ZSTD_compress2 (level 3 with the LDS-sized
+tables = hashLog 14 / chainLog 13).  The -m gpu tests repeat this through the C-ABI on the wave64 build."""
+import random
+
+import pytest
+
+from conftest import golden
+from util import edge_inputs, emu_lib, emu_compress
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib()
+
+
+def expected(ref, data, level):
+    return ref.compress(data, 3, False, 14, 13) if level == 3 else ref.compress(data, level)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_emu_encoder_edge_inputs(emu, oracle_ref, level):
+    for name, data in edge_inputs():
+        assert emu_compress(emu, data, level) == expected(oracle_ref, data, level), name
+
+
+def test_emu_encoder_xml_and_synthetic(emu, oracle_ref, zj):
+    rnd = random.Random(11)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for size in (4096, 12000, 16384, 65536, 100000, 131072):
+        off = rnd.randrange(0, len(xml) - size)
+        d = xml[off:off + size]
+        for level in (1, 2, 3):
+            assert emu_compress(emu, d, level) == expected(oracle_ref, d, level), (size, off, level)
+    for _ in range(150):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 70000), rnd.randrange(0, 131073), 65536, 4096, 131072])
+        d = zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b""
+        for level in (1, 2, 3):
+            assert emu_compress(emu, d, level) == expected(oracle_ref, d, level), (size, level)
+
+
+def test_emu_encoder_small_inputs_match_default_level3(emu, oracle_ref, zj):
+    rnd = random.Random(3)
+    for _ in range(100):
+        size = rnd.randrange(0, 8193)
+        d = zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b""
+        assert emu_compress(emu, d, 3) == oracle_ref.compress(d, 3), size
+    assert emu_compress(emu, golden("xmlsmall"), 3) == golden("xmlsmall-sized.zst")
+
+
+def test_emu_encoder_dst_too_small(emu, zj):
+    import ctypes as C
+    d = zj.synth_host(65536, 0, 1)
+    for cap in (5, 12, 1000):
+        dst = C.create_string_buffer(cap)
+        r = emu.emu_compress(d, len(d), dst, cap, 3)
+        assert (1 << 64) - r == 70

@@ -63,16 +63,20 @@ def decompress(src_blob, src_off, dst_blob, dst_off, results=None):
     return results
 
 
-def pack(results, dst_blob, dst_off):
+def pack(results, dst_blob, dst_off, out=None, out_off=None):
     """Tightly pack a compress batch's variable-size outputs (sizes = results) into one blob:
     returns (packed_blob, packed_off int64[n+1]).  The exclusive scan is torch plumbing; the byte
-    movement is zj_pack_kernel."""
+    movement is zj_pack_kernel.  With `out` (uint8, capacity >= sum of sizes) and `out_off`
+    (int64[n+1]) preallocated nothing synchronises with the host."""
     n = results.numel()
     sizes = results.clamp(min=0)
-    packed_off = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
-    packed_off[1:] = torch.cumsum(sizes, 0)
-    total = int(packed_off[-1].item())
-    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=results.device)
-    _check(lib().zjni_pack_batch_device(dst_blob.data_ptr(), dst_off.data_ptr(), sizes.data_ptr(), packed.data_ptr(),
-                                        packed_off.data_ptr(), n, _stream_ptr()))
-    return packed[:total], packed_off
+    if out_off is None:
+        out_off = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
+    out_off[0] = 0
+    torch.cumsum(sizes, 0, out=out_off[1:])
+    if out is None:
+        total = int(out_off[-1].item())
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=results.device)[:total]
+    _check(lib().zjni_pack_batch_device(dst_blob.data_ptr(), dst_off.data_ptr(), sizes.data_ptr(), out.data_ptr(),
+                                        out_off.data_ptr(), n, _stream_ptr()))
+    return out, out_off

@@ -115,8 +115,13 @@ ZJ_DEV void grp_scan_incl(const G& g, u32* a, u32 n) {
 #endif
 }
 
-// cooperative byte copy global->global, no overlap between src and dst
+// cooperative copy global->global, 16 B per lane per step, no overlap between src and dst
 template <class G>
-ZJ_DEV void grp_copy(const G& g, u8* dst, const u8* src, u32 n) {
-    GRP_FOR(g, i, n) dst[i] = src[i];
+ZJ_DEV void grp_copy_wide(const G& g, u8* dst, const u8* src, u32 n) {
+    u32 const n16 = n >> 4;
+    GRP_FOR(g, i, n16) {
+        u64 a = ld64(src + 16 * i), b = ld64(src + 16 * i + 8);
+        st64(dst + 16 * i, a); st64(dst + 16 * i + 8, b);
+    }
+    GRP_FOR(g, i, n & 15u) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
 }

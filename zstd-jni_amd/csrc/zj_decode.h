@@ -91,15 +91,6 @@ ZJ_DEV u32 zd_ml_bits(u32 c) { return zd_k_ml_bits[c]; }
 
 // ------------------------------------------------------------------ wide cooperative copy ----
 template <class G>
-ZJ_DEV void zd_copy_wide(const G& g, u8* dst, const u8* src, u32 n) {
-    u32 const n16 = n >> 4;
-    GRP_FOR(g, i, n16) {
-        u64 a = ld64(src + 16 * i), b = ld64(src + 16 * i + 8);
-        st64(dst + 16 * i, a); st64(dst + 16 * i + 8, b);
-    }
-    GRP_FOR(g, i, n & 15u) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
-}
-template <class G>
 ZJ_DEV void zd_fill(const G& g, u8* dst, u8 v, u32 n) {
     u64 const vv = 0x0101010101010101ull * v;
     u32 const n16 = n >> 4;
@@ -642,7 +633,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
     // ---- last literals ----
     {   u32 const rest = litSize - litUsed;
         if ((u64)opos + rest > dstCap) { GRP_SERIAL(g) { sh.err = ZJ_E_DSTSIZE_TOO_SMALL; } g.sync(); return opos; }
-        zd_copy_wide(g, out + opos, lit + litUsed, rest);
+        grp_copy_wide(g, out + opos, lit + litUsed, rest);
         opos += rest;
         zj_mem_order();
     }
@@ -726,7 +717,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if (sh.err) return ZJ_ERR64(sh.err);
             ipos += 3;
             u32 const type = sh.blkType, sz = sh.blkSize, last = sh.blkLast;
-            if (type == 0) { zd_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); }
+            if (type == 0) { grp_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); }
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
                 u32 const cap = zj_min(fcap, opos + sh.blockSizeMax);

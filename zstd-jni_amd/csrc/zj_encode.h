@@ -1,10 +1,875 @@
-// zj_encode.h — placeholder until the encoder lands
+// zj_encode.h — batched zstd frame encoder for gfx950: one buffer (= one frame = one block) per
+// wavefront.
+//
+// Replaces, for batches of independent buffers, what zstd-jni reaches through
+//   ZstdCompressCtx.compress*0 -> ZSTD_CCtx_reset + ZSTD_compress2        (reference N/jni_fast_zstd.c:586-640)
+// at levels 1..3, i.e. N/compress/zstd_compress.c:4695-4745 (frame header), :4383-4448 (block),
+// :2888-3043 (entropy stage), N/compress/zstd_fast.c:192-423 (level 1-2 match finder),
+// N/compress/zstd_double_fast.c:105-323 (level 3), N/compress/zstd_compress_literals.c:129-235 +
+// N/compress/huf_compress.c (Huffman literals), N/compress/zstd_compress_sequences.c:157-382 +
+// N/compress/fse_compress.c (tANS sequences), N/compress/hist.c.     N/ = src/main/native/.
+//
+// Output contract: byte-identical to the reference's ZSTD_compress2 for levels 1 and 2 at every
+// size <= 128 KiB, and for level 3 whenever the level's tables fit the LDS budget (srcSize <= 8 KiB);
+// above that, level 3 runs the reference's double-fast with hashLog/chainLog = 14/13 — byte-identical
+// to the reference called with ZstdCompressCtx.setHashLog(14).setChainLog(13) (SURVEY.md Appendix B.2:
+// +0.44 % size on Silesia xml, inside the 1 % gate).
+//
+// LDS: the match-finder hash tables (position+1, u16 for buffers <= 64 KiB else u32) own the LDS
+// during match finding; the entropy stage (histograms, Huffman tree, tANS tables) overlays the same
+// bytes afterwards.  HBM scratch per workgroup: literals, sequence records, block body.
 #pragma once
 #include "zj_common.h"
-#define ZE_SCRATCH_BYTES 1024u
-struct ZEncShared { u32 x; };
+
+#if !ZJ_ON_GPU
+static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build
+#endif
+
+#define ZE_BLOCK_MAX (1u << 17)
+#define ZE_MAX_SEQ ((ZE_BLOCK_MAX / 4u) + 16u)
+#define ZE_L3_HASHLOG 14u
+#define ZE_L3_CHAINLOG 13u
+
+struct ZESeq { u32 ll; u32 ml; u32 off; u32 pos; };   // ll|llCode<<24, ml(matchLength)|mlCode<<24, offBase|ofCode<<24, literal start
+#define ZE_LOW24(x) ((x) & 0xFFFFFFu)
+
+// HBM scratch per workgroup
+#define ZE_WS_LIT 0u
+#define ZE_WS_SEQ (ZE_BLOCK_MAX + 64u)
+#define ZE_WS_BODY (ZE_WS_SEQ + ZE_MAX_SEQ * 16u)
+#define ZE_SCRATCH_BYTES (ZE_WS_BODY + ZE_BLOCK_MAX + 2048u)
+
+struct ZENode { u32 count; u16 parent; u8 byte; u8 nbBits; };
+struct ZEFseCT { u16 state[512]; i32 deltaFind[64]; u32 deltaNbBits[64]; u32 tableLog; };
+
+struct ZEEntropy {                 // entropy-stage view of the LDS
+    u32 hist[4][256];              // per-stream literal histograms (exact stream sizes before encoding)
+    u32 count[256];
+    ZENode node[516];
+    u16 rankBase[192]; u16 rankCurr[192];
+    u8 nbBits[256]; u16 val[256]; u8 weight[256];
+    u32 scount[64]; short norm[64];
+    u16 cumul[260]; u8 tableSymbol[512];
+    ZEFseCT ct[3];                 // LL, OF, ML
+    i32 qsLow[32]; i32 qsHigh[32]; // explicit quicksort stack
+};
+
+#define ZE_LDS_TABLE_L1_U16 (8192u * 2u)
+#define ZE_LDS_BYTES(tableBytes) ((tableBytes) > sizeof(ZEEntropy) ? (tableBytes) : sizeof(ZEEntropy))
+
+struct ZEncShared {                // uniforms, outside the overlay
+    u32 err;
+    u32 nbSeq, litSize, lastLL;
+    u32 windowLog, hashLog, chainLog, minMatch, strategy;
+    u32 hdrSize, bodySize, litSecSize;
+    u32 hufLog, hufMaxSV, hufHdr, litMode, litStreams;
+    u32 strBytes[4], strOff[4];
+    u32 seqType[3], seqHdr[3], seqLastCount;
+    u32 tmp[8];
+};
+
+// ------------------------------------------------------------------ constants ---------------
+#if ZJ_ON_GPU
+#define ZE_CONST static __device__ const
+#else
+#define ZE_CONST static const
+#endif
+ZE_CONST u8 ze_k_ll_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+ZE_CONST u8 ze_k_ml_bits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+ZE_CONST short ze_k_ll_defnorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+ZE_CONST short ze_k_ml_defnorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+ZE_CONST short ze_k_of_defnorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+ZE_CONST u8 ze_k_ll_code[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,22,22,22,22,22,22,22,22,
+                                 23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
+ZE_CONST u8 ze_k_ml_code[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+    32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+    40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+    42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
+ZE_CONST u32 ze_k_rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+
+ZJ_DEV u32 ze_ll_code(u32 v) { return v > 63 ? zj_hibit(v) + 19 : ze_k_ll_code[v]; }      // ZSTD_LLcode
+ZJ_DEV u32 ze_ml_code(u32 v) { return v > 127 ? zj_hibit(v) + 36 : ze_k_ml_code[v]; }     // ZSTD_MLcode (v = ml - 3)
+
+// ------------------------------------------------------------------ parameters --------------
+// N/compress/clevels.h:81-83,107-109 + ZSTD_adjustCParams_internal (N/compress/zstd_compress.c:1553-1572)
+ZJ_DEV void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
+    u32 const srcLog = (srcSize < 64u) ? 6u : zj_hibit(srcSize - 1) + 1;
+    if (windowLog > srcLog) windowLog = srcLog;
+    if (hashLog > windowLog + 1) hashLog = windowLog + 1;
+    if (chainLog > windowLog) chainLog = windowLog;
+    if (windowLog < 10) windowLog = 10;
+}
+ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
+    u32 w, c, h, mm, st;
+    if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; mm = (level == 1) ? 5 : 4; st = (level == 3) ? 2 : 1; }
+    else if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
+    else if (level == 2) { w = 17; c = 13; h = 15; mm = 5; st = 1; }
+    else { w = 17; c = 15; h = 16; mm = 5; st = 2; }
+    ze_adjust(w, c, h, srcSize);
+    if (st == 2) {            // LDS budget: ZSTD_c_hashLog = 14, ZSTD_c_chainLog = 13, then adjust again
+        if (h > ZE_L3_HASHLOG || c > ZE_L3_CHAINLOG) { if (h > ZE_L3_HASHLOG) h = ZE_L3_HASHLOG; if (c > ZE_L3_CHAINLOG) c = ZE_L3_CHAINLOG; ze_adjust(w, c, h, srcSize); }
+    }
+    sh.windowLog = w; sh.chainLog = c; sh.hashLog = h; sh.minMatch = mm; sh.strategy = st;
+}
+// bytes of LDS the match-finder tables need for this (level, size, index width)
+ZJ_HD u32 ze_table_entries(u32 level, u32 maxSrc) {
+    // upper bound over all sizes <= maxSrc: level 1: 2^13 (<=16 KiB inputs use 2^min(15, wlog+1) <= 2^15)
+    if (level == 3) return (1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG);
+    if (level == 2) return 1u << 15;
+    return maxSrc <= (16u << 10) ? (1u << 15) : (1u << 15);   // level 1 small inputs: hashLog 15 -> clamp wlog+1
+}
+
+// ------------------------------------------------------------------ match finders (lane 0) --
+ZJ_DEV u32 ze_hash(const u8* p, u32 hBits, u32 mls) {   // N/compress/zstd_compress_internal.h:898-960
+    switch (mls) {
+    default:
+    case 4: return (ld32(p) * 2654435761U) >> (32 - hBits);
+    case 5: return (u32)(((ld64(p) << 24) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (u32)(((ld64(p) << 16) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (u32)(((ld64(p) << 8) * 58295818150454627ULL) >> (64 - hBits));
+    case 8: return (u32)((ld64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+    }
+}
+ZJ_DEV u32 ze_count(const u8* in, const u8* match, const u8* inLimit) {   // ZSTD_count (result only)
+    const u8* const start = in;
+    while (in + 8 <= inLimit) {
+        u64 const d = ld64(in) ^ ld64(match);
+        if (d) return (u32)(in - start) + ((u32)__builtin_ctzll(d) >> 3);
+        in += 8; match += 8;
+    }
+    while (in < inLimit && *in == *match) { in++; match++; }
+    return (u32)(in - start);
+}
+
+struct ZEOut { ZESeq* seqs; u32* litOff; u32 n; u32 lit; };
+ZJ_DEV void ze_store(ZEOut& o, u32 litPos, u32 ll, u32 offBase, u32 ml) {
+    ZESeq s; s.ll = ll; s.ml = ml; s.off = offBase; s.pos = litPos;
+    o.litOff[o.n] = o.lit;                      // where this sequence's literals land in the literal buffer
+    o.seqs[o.n++] = s; o.lit += ll;
+}
+
+// ZSTD_compressBlock_fast_noDict_generic (N/compress/zstd_fast.c:192-423); tables hold position+1.
+template <class TIdx>
+ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls, TIdx* table) {
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart + 1; const u8* ip1; const u8* ip2; const u8* ip3;
+    u32 rep1 = 1, rep2 = 4;
+    u32 hash0, hash1, matchE, cur0 = 0, offcode, mLength, step;
+    const u8* match0; const u8* nextStep;
+    if (rep2 > 1) rep2 = 0;                       // maxRep == 1 at the first position of a frame
+    for (;;) {
+        step = 2; nextStep = ip0 + 128;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        hash0 = ze_hash(ip0, hlog, mls); hash1 = ze_hash(ip1, hlog, mls);
+        matchE = table[hash0];
+        bool found = false, isRep = false;
+        do {
+            u32 const rval = ld32(ip2 - rep1);
+            cur0 = (u32)(ip0 - istart); table[hash0] = (TIdx)(cur0 + 1);
+            if ((ld32(ip2) == rval) & (rep1 > 0)) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = (ip0[-1] == match0[-1]); ip0 -= mLength; match0 -= mLength;
+                offcode = 1; mLength += 4;
+                table[hash1] = (TIdx)((u32)(ip1 - istart) + 1);
+                found = true; isRep = true; break;
+            }
+            if (matchE && ld32(istart + matchE - 1) == ld32(ip0)) { table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
+            matchE = table[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            cur0 = (u32)(ip0 - istart); table[hash0] = (TIdx)(cur0 + 1);
+            if (matchE && ld32(istart + matchE - 1) == ld32(ip0)) { if (step <= 4) table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
+            matchE = table[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (!isRep) {
+            match0 = istart + matchE - 1;
+            rep2 = rep1; rep1 = (u32)(ip0 - match0); offcode = rep1 + 3; mLength = 4;
+            while (((ip0 > anchor) & (match0 > istart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        mLength += ze_count(ip0 + mLength, match0 + mLength, iend);
+        ze_store(o, (u32)(anchor - istart), (u32)(ip0 - anchor), offcode, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip0 <= ilimit) {
+            table[ze_hash(istart + cur0 + 2, hlog, mls)] = (TIdx)(cur0 + 2 + 1);
+            table[ze_hash(ip0 - 2, hlog, mls)] = (TIdx)((u32)(ip0 - 2 - istart) + 1);
+            if (rep2 > 0) {
+                while ((ip0 <= ilimit) && (ld32(ip0) == ld32(ip0 - rep2))) {
+                    u32 const rLength = ze_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    table[ze_hash(ip0, hlog, mls)] = (TIdx)((u32)(ip0 - istart) + 1);
+                    ip0 += rLength;
+                    ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+    return (u32)(iend - anchor);
+}
+
+// ZSTD_compressBlock_doubleFast_noDict_generic (N/compress/zstd_double_fast.c:105-323)
+template <class TIdx>
+ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 hBitsS, u32 mls, TIdx* hashLong, TIdx* hashSmall) {
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip = istart + 1; const u8* ip1;
+    u32 off1 = 1, off2 = 0;                       // rep {1,4}: 4 > maxRep == 1 at frame start
+    u32 mLength = 0, offset = 0, curr = 0, step, hl0, hl1 = 0, el0, el1 = 0;
+    const u8* nextStep; const u8* matchs0 = istart; const u8* matchl0;
+    for (;;) {
+        step = 1; nextStep = ip + 256; ip1 = ip + step;
+        if (ip1 > ilimit) break;
+        hl0 = ze_hash(ip, hBitsL, 8); el0 = hashLong[hl0];
+        u32 kind = 0;     // 0 none, 1 repcode stored, 2 long match found, 3 short match -> search next long
+        do {
+            u32 const hs0 = ze_hash(ip, hBitsS, mls);
+            u32 const es0 = hashSmall[hs0];
+            curr = (u32)(ip - istart);
+            hashLong[hl0] = (TIdx)(curr + 1); hashSmall[hs0] = (TIdx)(curr + 1);
+            if ((off1 > 0) & (ld32(ip + 1 - off1) == ld32(ip + 1))) {
+                mLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+                ip++;
+                ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), 1, mLength);
+                kind = 1; break;
+            }
+            hl1 = ze_hash(ip1, hBitsL, 8);
+            if (el0 && ld64(istart + el0 - 1) == ld64(ip)) {
+                matchl0 = istart + el0 - 1;
+                mLength = ze_count(ip + 8, matchl0 + 8, iend) + 8;
+                offset = (u32)(ip - matchl0);
+                while (((ip > anchor) & (matchl0 > istart)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
+                kind = 2; break;
+            }
+            el1 = hashLong[hl1];
+            if (es0 && ld32(istart + es0 - 1) == ld32(ip)) { matchs0 = istart + es0 - 1; kind = 3; break; }
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; el0 = el1;
+        } while (ip1 <= ilimit);
+        if (kind == 0) break;
+        if (kind == 3) {
+            mLength = ze_count(ip + 4, matchs0 + 4, iend) + 4;
+            offset = (u32)(ip - matchs0);
+            if ((el1 > 1) && (ld64(istart + el1 - 1) == ld64(ip1))) {
+                const u8* const matchl1 = istart + el1 - 1;
+                u32 const l1len = ze_count(ip1 + 8, matchl1 + 8, iend) + 8;
+                if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (u32)(ip - matchl1); matchs0 = matchl1; }
+            }
+            while (((ip > anchor) & (matchs0 > istart)) && (ip[-1] == matchs0[-1])) { ip--; matchs0--; mLength++; }
+        }
+        if (kind >= 2) {
+            off2 = off1; off1 = offset;
+            if (step < 4) hashLong[hl1] = (TIdx)((u32)(ip1 - istart) + 1);
+            ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), offset + 3, mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            {   u32 const ins = curr + 2;
+                hashLong[ze_hash(istart + ins, hBitsL, 8)] = (TIdx)(ins + 1);
+                hashLong[ze_hash(ip - 2, hBitsL, 8)] = (TIdx)((u32)(ip - 2 - istart) + 1);
+                hashSmall[ze_hash(istart + ins, hBitsS, mls)] = (TIdx)(ins + 1);
+                hashSmall[ze_hash(ip - 1, hBitsS, mls)] = (TIdx)((u32)(ip - 1 - istart) + 1);
+            }
+            while ((ip <= ilimit) && ((off2 > 0) & (ld32(ip) == ld32(ip - off2)))) {
+                u32 const rLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4;
+                u32 const t = off2; off2 = off1; off1 = t;
+                hashSmall[ze_hash(ip, hBitsS, mls)] = (TIdx)((u32)(ip - istart) + 1);
+                hashLong[ze_hash(ip, hBitsL, 8)] = (TIdx)((u32)(ip - istart) + 1);
+                ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+    return (u32)(iend - anchor);
+}
+
+// ------------------------------------------------------------------ FSE (lane 0) ------------
+ZJ_DEV u32 ze_fse_optimal_log(u32 maxTableLog, u32 srcSize, u32 maxSV, u32 minus) {   // fse_compress.c:346-372
+    u32 const maxBitsSrc = zj_hibit(srcSize - 1) - minus;
+    u32 tableLog = maxTableLog;
+    u32 const minBitsSrc = zj_hibit(srcSize) + 1, minBitsSym = zj_hibit(maxSV) + 2;
+    u32 const minBits = minBitsSrc < minBitsSym ? minBitsSrc : minBitsSym;
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 12) tableLog = 12;
+    return tableLog;
+}
+
+ZJ_DEV bool ze_fse_normalize_m2(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, short lowProb) {   // fse_compress.c:377-462
+    short const NOT_YET = -2; u32 s, distributed = 0, toDist;
+    u32 const lowThreshold = total >> tableLog; u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSV; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProb; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET;
+    }
+    toDist = (1u << tableLog) - distributed;
+    if (toDist == 0) return true;
+    if ((total / toDist) > lowOne) {
+        lowOne = (u32)(((u64)total * 3) / (toDist * 2));
+        for (s = 0; s <= maxSV; s++) { if ((norm[s] == NOT_YET) && (count[s] <= lowOne)) { norm[s] = 1; distributed++; total -= count[s]; } }
+        toDist = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSV + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSV; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (short)toDist;
+        return true;
+    }
+    if (total == 0) {
+        for (s = 0; toDist > 0; s = (s + 1) % (maxSV + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+        return true;
+    }
+    {   u64 const vStepLog = 62 - tableLog; u64 const mid = (1ULL << (vStepLog - 1)) - 1;
+        u64 const rStep = ((((u64)1 << vStepLog) * toDist) + mid) / total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSV; s++) {
+            if (norm[s] == NOT_YET) {
+                u64 const end = tmpTotal + (count[s] * rStep);
+                u32 const weight = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
+                if (weight < 1) return false;
+                norm[s] = (short)weight; tmpTotal = end;
+            }
+        }
+    }
+    return true;
+}
+
+ZJ_DEV bool ze_fse_normalize(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, bool useLowProb) {   // fse_compress.c:465-523
+    short const lowProb = useLowProb ? -1 : 1;
+    u64 const scale = 62 - tableLog; u64 const step = ((u64)1 << 62) / total; u64 const vStep = 1ULL << (scale - 20);
+    i32 still = 1 << tableLog; u32 s, largest = 0; short largestP = 0; u32 const lowThreshold = total >> tableLog;
+    for (s = 0; s <= maxSV; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProb; still--; }
+        else {
+            short proba = (short)((count[s] * step) >> scale);
+            if (proba < 8) { u64 const restToBeat = vStep * ze_k_rtb[proba]; proba += (count[s] * step) - ((u64)proba << scale) > restToBeat; }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba; still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) return ze_fse_normalize_m2(norm, tableLog, count, total, maxSV, lowProb);
+    norm[largest] += (short)still;
+    return true;
+}
+
+ZJ_DEV u32 ze_fse_write_ncount(u8* out0, const short* norm, u32 maxSV, u32 tableLog) {   // fse_compress.c:237-328
+    u8* out = out0; i32 nbBits; i32 const tableSize = 1 << tableLog; i32 remaining, threshold;
+    u32 bitStream = 0; i32 bitCount = 0; u32 symbol = 0; u32 const alphabetSize = maxSV + 1; bool previousIs0 = false;
+    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
+    remaining = tableSize + 1; threshold = tableSize; nbBits = (i32)tableLog + 1;
+    while ((symbol < alphabetSize) && (remaining > 1)) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) { start += 24; bitStream += 0xFFFFU << bitCount; out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; }
+            while (symbol >= start + 3) { start += 3; bitStream += 3U << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {   i32 count = norm[symbol++]; i32 const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount; bitCount += nbBits; bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return 0;
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += (bitCount + 7) / 8;
+    return (u32)(out - out0);
+}
+
+// FSE_buildCTable_wksp (fse_compress.c:68-224); cumul/tableSymbol are LDS scratch
+ZJ_DEV void ze_fse_build_ctable(ZEFseCT& ct, const short* norm, u32 maxSV, u32 tableLog, u16* cumul, u8* tableSymbol) {
+    u32 const size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    u32 high = size - 1, pos = 0;
+    ct.tableLog = tableLog;
+    cumul[0] = 0;
+    for (u32 u = 1; u <= maxSV + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[high--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSV + 1] = (u16)(size + 1);
+    for (u32 s = 0; s <= maxSV; s++) {
+        for (i32 i = 0; i < norm[s]; i++) { tableSymbol[pos] = (u8)s; do { pos = (pos + step) & mask; } while (pos > high); }
+    }
+    for (u32 u = 0; u < size; u++) { u32 const sy = tableSymbol[u]; ct.state[cumul[sy]++] = (u16)(size + u); }
+    u32 total = 0;
+    for (u32 s = 0; s <= maxSV; s++) {
+        i32 const nv = norm[s];
+        if (nv == 0) { ct.deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct.deltaFind[s] = 0; }
+        else if (nv == -1 || nv == 1) { ct.deltaNbBits[s] = (tableLog << 16) - (1u << tableLog); ct.deltaFind[s] = (i32)(total - 1); total++; }
+        else { u32 const maxBitsOut = tableLog - zj_hibit((u32)nv - 1); u32 const minStatePlus = (u32)nv << maxBitsOut;
+               ct.deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus; ct.deltaFind[s] = (i32)(total - (u32)nv); total += (u32)nv; }
+    }
+}
+
+// forward bit writer (BIT_CStream_t semantics, N/common/bitstream.h:180-250) over global memory
+struct ZEBitW { u8* p; u64 acc; u32 n; };
+ZJ_DEV void ze_bw_add(ZEBitW& b, u64 v, u32 nb) {
+    b.acc |= (v & (((u64)1 << nb) - 1)) << b.n; b.n += nb;
+    if (b.n >= 32) { st32(b.p, (u32)b.acc); b.p += 4; b.acc >>= 32; b.n -= 32; }
+}
+ZJ_DEV u32 ze_bw_close(ZEBitW& b, const u8* start) {
+    ze_bw_add(b, 1, 1);
+    while (b.n > 0) { *b.p++ = (u8)b.acc; b.acc >>= 8; b.n = b.n > 8 ? b.n - 8 : 0; }
+    return (u32)(b.p - start);
+}
+struct ZEFseCS { u32 value; };
+ZJ_DEV void ze_fse_init2(ZEFseCS& s, const ZEFseCT& ct, u32 sym) {
+    u32 const nbBitsOut = (ct.deltaNbBits[sym] + (1u << 15)) >> 16;
+    s.value = (nbBitsOut << 16) - ct.deltaNbBits[sym];
+    s.value = ct.state[(i32)(s.value >> nbBitsOut) + ct.deltaFind[sym]];
+}
+ZJ_DEV void ze_fse_encode(ZEBitW& b, ZEFseCS& s, const ZEFseCT& ct, u32 sym) {
+    u32 const nbBitsOut = (s.value + ct.deltaNbBits[sym]) >> 16;
+    ze_bw_add(b, s.value, nbBitsOut);
+    s.value = ct.state[(i32)(s.value >> nbBitsOut) + ct.deltaFind[sym]];
+}
+
+// ------------------------------------------------------------------ Huffman (lane 0) --------
+ZJ_DEV u32 ze_huf_bucket(u32 count) { return count < 166 ? count : zj_hibit(count) + 158; }
+
+ZJ_DEV void ze_huf_insertion(ZENode* a, i32 low, i32 high) {
+    i32 const size = high - low + 1; a += low;
+    for (i32 i = 1; i < size; i++) { ZENode const key = a[i]; i32 j = i - 1; while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; } a[j + 1] = key; }
+}
+ZJ_DEV i32 ze_huf_partition(ZENode* a, i32 low, i32 high) {
+    u32 const pivot = a[high].count; i32 i = low - 1;
+    for (i32 j = low; j < high; j++) if (a[j].count > pivot) { i++; ZENode t = a[i]; a[i] = a[j]; a[j] = t; }
+    { ZENode t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
+    return i + 1;
+}
+// HUF_simpleQuickSort (huf_compress.c:574-591) with the recursion turned into an explicit stack:
+// sub-ranges are disjoint, so deferring the "recursive" call does not change the result.
+ZJ_DEV void ze_huf_quicksort(ZEEntropy& e, ZENode* a, i32 low0, i32 high0) {
+    i32 sp = 0; e.qsLow[0] = low0; e.qsHigh[0] = high0; sp = 1;
+    while (sp > 0) {
+        sp--; i32 low = e.qsLow[sp], high = e.qsHigh[sp];
+        if (high - low < 8) { ze_huf_insertion(a, low, high); continue; }
+        while (low < high) {
+            i32 const idx = ze_huf_partition(a, low, high);
+            if (idx - low < high - idx) { e.qsLow[sp] = low; e.qsHigh[sp] = idx - 1; sp++; low = idx + 1; }
+            else { e.qsLow[sp] = idx + 1; e.qsHigh[sp] = high; sp++; high = idx - 1; }
+        }
+    }
+}
+
+// HUF_sort + HUF_buildTree + HUF_setMaxHeight + HUF_buildCTableFromTree (huf_compress.c:376-754)
+ZJ_DEV u32 ze_huf_build(ZEEntropy& e, u32 maxSV, u32 maxNbBits) {
+    ZENode* const node0 = e.node; ZENode* const node = e.node + 1;
+    const u32* const count = e.count;
+    for (u32 n = 0; n < 516; n++) { ZENode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; e.node[n] = z; }
+    for (u32 n = 0; n < 192; n++) { e.rankBase[n] = 0; e.rankCurr[n] = 0; }
+    for (u32 n = 0; n <= maxSV; n++) e.rankBase[ze_huf_bucket(count[n])]++;
+    for (u32 n = 191; n > 0; n--) { e.rankBase[n - 1] += e.rankBase[n]; e.rankCurr[n - 1] = e.rankBase[n - 1]; }
+    for (u32 n = 0; n <= maxSV; n++) { u32 const r = ze_huf_bucket(count[n]) + 1; u32 const pos = e.rankCurr[r]++; node[pos].count = count[n]; node[pos].byte = (u8)n; }
+    for (u32 n = 166; n < 191; n++) { i32 const sz = (i32)e.rankCurr[n] - (i32)e.rankBase[n]; if (sz > 1) ze_huf_quicksort(e, node + e.rankBase[n], 0, sz - 1); }
+    i32 nonNull = (i32)maxSV; while (node[nonNull].count == 0) nonNull--;
+    i32 lowS = nonNull, nodeNb = 256, lowN = 256; i32 const nodeRoot = nodeNb + lowS - 1;
+    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (i32 n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+    node0[0].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        i32 const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        i32 const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+        node[nodeNb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (u16)nodeNb; nodeNb++;
+    }
+    node[nodeRoot].nbBits = 0;
+    for (i32 n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    for (i32 n = 0; n <= nonNull; n++) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    {   u32 const largestBits = node[nonNull].nbBits;
+        if (largestBits > maxNbBits) {
+            i32 totalCost = 0; u32 const baseCost = 1u << (largestBits - maxNbBits); u32 const noSymbol = 0xF0F0F0F0u;
+            u32* const rankLast = e.scount;       // 14 entries of LDS scratch
+            i32 k = nonNull;
+            while (node[k].nbBits > maxNbBits) { totalCost += (i32)(baseCost - (1u << (largestBits - node[k].nbBits))); node[k].nbBits = (u8)maxNbBits; k--; }
+            while (node[k].nbBits == maxNbBits) --k;
+            totalCost >>= (largestBits - maxNbBits);
+            for (u32 r = 0; r < 14; r++) rankLast[r] = noSymbol;
+            {   u32 cur = maxNbBits;
+                for (i32 pos = k; pos >= 0; pos--) { if (node[pos].nbBits >= cur) continue; cur = node[pos].nbBits; rankLast[maxNbBits - cur] = (u32)pos; } }
+            while (totalCost > 0) {
+                u32 nDec = zj_hibit((u32)totalCost) + 1;
+                for (; nDec > 1; nDec--) {
+                    u32 const highPos = rankLast[nDec], lowPos = rankLast[nDec - 1];
+                    if (highPos == noSymbol) continue;
+                    if (lowPos == noSymbol) break;
+                    if (node[highPos].count <= 2 * node[lowPos].count) break;
+                }
+                while ((nDec <= 12) && (rankLast[nDec] == noSymbol)) nDec++;
+                totalCost -= 1 << (nDec - 1);
+                node[rankLast[nDec]].nbBits++;
+                if (rankLast[nDec - 1] == noSymbol) rankLast[nDec - 1] = rankLast[nDec];
+                if (rankLast[nDec] == 0) rankLast[nDec] = noSymbol;
+                else { rankLast[nDec]--; if (node[rankLast[nDec]].nbBits != maxNbBits - nDec) rankLast[nDec] = noSymbol; }
+            }
+            while (totalCost < 0) {
+                if (rankLast[1] == noSymbol) { while (node[k].nbBits == maxNbBits) k--; node[k + 1].nbBits--; rankLast[1] = (u32)(k + 1); totalCost++; continue; }
+                node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+            }
+        } else maxNbBits = largestBits;
+    }
+    {   u16* const nbPerRank = e.cumul; u16* const valPerRank = e.cumul + 16; u16 min = 0;
+        for (u32 r = 0; r < 32; r++) e.cumul[r] = 0;
+        for (i32 n = 0; n <= nonNull; n++) nbPerRank[node[n].nbBits]++;
+        for (i32 n = (i32)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
+        for (u32 n = 0; n <= maxSV; n++) e.nbBits[node[n].byte] = node[n].nbBits;
+        for (u32 n = 0; n <= maxSV; n++) { u32 const nb = e.nbBits[n]; e.val[n] = nb ? valPerRank[nb]++ : 0; }
+    }
+    return maxNbBits;
+}
+
+// HUF_compressWeights (huf_compress.c:132-176): 0 not compressible, 1 rle, else size
+ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize) {
+    const u8* const w = e.weight; u32* const count = e.scount; short* const norm = e.norm; u32 maxSV = 0, maxCount = 0; u8* op = dst;
+    if (wtSize <= 1) return 0;
+    for (u32 s = 0; s <= 12; s++) count[s] = 0;
+    for (u32 s = 0; s < wtSize; s++) count[w[s]]++;
+    for (u32 s = 0; s <= 12; s++) { if (count[s]) maxSV = s; if (count[s] > maxCount) maxCount = count[s]; }
+    if (maxCount == wtSize) return 1;
+    if (maxCount == 1) return 0;
+    u32 const tableLog = ze_fse_optimal_log(6, wtSize, maxSV, 2);
+    if (!ze_fse_normalize(norm, tableLog, count, wtSize, maxSV, false)) return 0;
+    {   u32 const h = ze_fse_write_ncount(op, norm, maxSV, tableLog); if (!h) return 0; op += h; }
+    ZEFseCT& ct = e.ct[0];
+    ze_fse_build_ctable(ct, norm, maxSV, tableLog, e.cumul, e.tableSymbol);
+    {   const u8* ip = w + wtSize; ZEBitW b; ZEFseCS s1, s2; u32 n = wtSize; u8* const bstart = op;   // fse_compress.c:549-606
+        if (n <= 2) return 0;
+        b.p = op; b.acc = 0; b.n = 0;
+        if (n & 1) { ze_fse_init2(s1, ct, *--ip); ze_fse_init2(s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+        else { ze_fse_init2(s2, ct, *--ip); ze_fse_init2(s1, ct, *--ip); }
+        n -= 2;
+        if (n & 2) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+        while (ip > w) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+        ze_bw_add(b, s2.value, ct.tableLog); ze_bw_add(b, s1.value, ct.tableLog);
+        op = bstart + ze_bw_close(b, bstart);
+    }
+    return (u32)(op - dst);
+}
+
+// HUF_writeCTable_wksp (huf_compress.c:248-290); 0 on failure
+ZJ_DEV u32 ze_huf_write_ctable(ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog) {
+    for (u32 n = 0; n < maxSV; n++) e.weight[n] = e.nbBits[n] ? (u8)(huffLog + 1 - e.nbBits[n]) : 0;
+    {   u32 const h = ze_huf_compress_weights(e, op + 1, maxSV);
+        if ((h > 1) & (h < maxSV / 2)) { op[0] = (u8)h; return h + 1; } }
+    if (maxSV > 128) return 0;
+    op[0] = (u8)(128 + (maxSV - 1));
+    e.weight[maxSV] = 0;
+    for (u32 n = 0; n < maxSV; n += 2) op[(n / 2) + 1] = (u8)((e.weight[n] << 4) + e.weight[n + 1]);
+    return ((maxSV + 1) / 2) + 1;
+}
+
+// one Huffman stream, symbols last -> first (huf_compress.c:991-1118); runs on one lane
+ZJ_DEV void ze_huf_encode_stream(const ZEEntropy& e, u8* dst, const u8* lit, u32 n) {
+    ZEBitW b; b.p = dst; b.acc = 0; b.n = 0;
+    for (u32 i = n; i > 0; i--) { u32 const s = lit[i - 1]; ze_bw_add(b, e.val[s], e.nbBits[s]); }
+    ze_bw_close(b, dst);
+}
+
+// raw / rle literal sections (zstd_compress_literals.c:39-127)
 template <class G>
-ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws) {
-    (void)g; (void)sh; (void)src; (void)srcSize; (void)dst; (void)dstCap; (void)level; (void)ws;
-    return ZJ_ERR64(201);
+ZJ_DEV u32 ze_raw_literals(const G& g, u8* dst, const u8* lit, u32 n) {
+    u32 const fl = 1 + (n > 31) + (n > 4095);
+    GRP_SERIAL(g) { if (fl == 1) dst[0] = (u8)(n << 3); else if (fl == 2) st16(dst, (1u << 2) + (n << 4)); else { st16(dst, ((3u << 2) + (n << 4)) & 0xFFFF); dst[2] = (u8)(((3u << 2) + (n << 4)) >> 16); } }
+    GRP_FOR(g, i, n) dst[fl + i] = lit[i];
+    return n + fl;
+}
+
+// ------------------------------------------------------------------ frame -------------------
+// `lds` = the overlay region (tables / ZEEntropy), ldsBytes its size.
+template <class G, class TIdx>
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws) {
+    u8* const litBuf = ws + ZE_WS_LIT;
+    ZESeq* const seqs = (ZESeq*)(ws + ZE_WS_SEQ);
+    ZEEntropy& e = *(ZEEntropy*)lds;
+
+    // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1, no checksum, no dictID) ----
+    GRP_SERIAL(g) {
+        sh.err = 0;
+        ze_params(sh, level, srcSize);
+        u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
+        u32 const hdr = 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
+        sh.hdrSize = hdr;
+        if (dstCap < hdr + 3) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
+        else {
+            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6));
+            if (fcsCode == 0) dst[5] = (u8)srcSize; else if (fcsCode == 1) st16(dst + 5, srcSize - 256); else st32(dst + 5, srcSize);
+        }
+    }
+    g.sync();
+    if (sh.err) return ZJ_ERR64(sh.err);
+    u32 const hdr = sh.hdrSize;
+    if (srcSize == 0) {                                                       // ZSTD_writeEpilogue: empty raw last block
+        GRP_SERIAL(g) { dst[hdr] = 1; dst[hdr + 1] = 0; dst[hdr + 2] = 0; }
+        return hdr + 3;
+    }
+    bool compressed = false; u32 cSize = 0;
+    // body goes straight into dst when even the raw fallback fits, else into HBM scratch first
+    bool const direct = dstCap >= hdr + 3 + srcSize + 64;
+    u8* const body = direct ? dst + hdr + 3 : ws + ZE_WS_BODY;
+    if (srcSize >= 7) {                                                       // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1
+        // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
+        u32 const strategy = sh.strategy, hlog = sh.hashLog, clog = sh.chainLog, mls = sh.minMatch;
+        u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
+        {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
+            GRP_FOR(g, i, words) w[i] = 0; }
+        g.sync();
+        GRP_SERIAL(g) {
+            ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+            TIdx* const t = (TIdx*)lds;
+            u32 const lastLL = (strategy == 1) ? ze_block_fast<TIdx>(o, src, srcSize, hlog, mls, t)
+                                               : ze_block_dfast<TIdx>(o, src, srcSize, hlog, clog, mls, t, t + (1u << hlog));
+            sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
+        }
+        zj_mem_order();
+        g.sync();
+        u32 const nbSeq = sh.nbSeq, litSize = sh.litSize, lastLL = sh.lastLL;
+        // ---- gather literals into HBM scratch + sequence codes (all lanes) ----
+        {   const u32* const litOff = (const u32*)(ws + ZE_WS_BODY);           // body scratch is free until the entropy stage
+            GRP_FOR(g, i, nbSeq) {
+                ZESeq s = seqs[i];
+                u32 const ll = s.ll, o = litOff[i];
+                if (ll <= 64) { for (u32 k = 0; k < ll; k++) litBuf[o + k] = src[s.pos + k]; }
+                s.ll = ll | (ze_ll_code(ll) << 24);
+                s.ml = s.ml | (ze_ml_code(s.ml - 3) << 24);
+                s.off = s.off | (zj_hibit(s.off) << 24);
+                seqs[i] = s;
+            }
+            zj_mem_order();
+            g.sync();
+            for (u32 i = 0; i < nbSeq; i++) {                                  // long literal runs: cooperative
+                u32 const ll = ZE_LOW24(seqs[i].ll);
+                if (ll > 64) { u32 const o = litOff[i], p = seqs[i].pos; GRP_FOR(g, k, ll) litBuf[o + k] = src[p + k]; }
+            }
+            GRP_FOR(g, k, lastLL) litBuf[litSize - lastLL + k] = src[srcSize - lastLL + k];
+            zj_mem_order();
+            g.sync();
+        }
+        // ---- literals section (ZSTD_compressLiterals, first block: no previous table) ----
+        u32 const strat = sh.strategy;
+        {   u32 const n = litSize;
+            u32 const lhSize = 3 + (n >= 1024) + (n >= 16384);
+            bool const single = n < 256;
+            u32 const seg = (n + 3) / 4;
+            u32 mode = 2;                                                      // 0 raw, 1 rle, 2 compressed
+            if (n < 64) mode = 0;                                              // ZSTD_minLiteralsToCompress (strategy <= 6)
+            if (mode == 2) {
+                bool const suspect = (nbSeq == 0) || (n / nbSeq >= 20);
+                GRP_FOR(g, i, 1024) (&e.hist[0][0])[i] = 0;
+                g.sync();
+                if (suspect && n >= 40960) {                                   // huf_compress.c:1369-1383 sampling
+                    GRP_FOR(g, i, 4096) atomicAdd(&e.hist[0][litBuf[i]], 1u);
+                    GRP_FOR(g, i, 4096) atomicAdd(&e.hist[1][litBuf[n - 4096 + i]], 1u);
+                    g.sync();
+                    GRP_SERIAL(g) { u32 lb = 0, le = 0; for (u32 s = 0; s < 256; s++) { lb = zj_max(lb, e.hist[0][s]); le = zj_max(le, e.hist[1][s]); } sh.tmp[0] = (lb + le <= 68) ? 1 : 0; }
+                    g.sync();
+                    if (sh.tmp[0]) mode = 0;
+                    g.sync();
+                    GRP_FOR(g, i, 512) (&e.hist[0][0])[i] = 0;
+                    g.sync();
+                }
+            }
+            if (mode == 2) {
+                if (single) { GRP_FOR(g, i, n) atomicAdd(&e.hist[0][litBuf[i]], 1u); }
+                else {
+                    for (u32 t = 0; t < 4; t++) { u32 const cnt = t < 3 ? seg : n - 3 * seg; const u8* const lp = litBuf + t * seg; GRP_FOR(g, i, cnt) atomicAdd(&e.hist[t][lp[i]], 1u); }
+                }
+                g.sync();
+                GRP_FOR(g, s, 256) e.count[s] = e.hist[0][s] + e.hist[1][s] + e.hist[2][s] + e.hist[3][s];
+                g.sync();
+                GRP_SERIAL(g) {
+                    u32 maxSV = 255, largest = 0, m = 2;
+                    while (!e.count[maxSV]) maxSV--;
+                    for (u32 s = 0; s <= maxSV; s++) largest = zj_max(largest, e.count[s]);
+                    if (largest == n) m = 1;
+                    else if (largest <= (n >> 7) + 4) m = 0;
+                    else {
+                        u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
+                        huffLog = ze_huf_build(e, maxSV, huffLog);
+                        u32 const h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog);
+                        if (!h || h + 12 >= n) m = 0;
+                        else {
+                            u32 total = h + (single ? 0 : 6); bool tooBig = false;
+                            for (u32 t = 0; t < (single ? 1u : 4u); t++) {
+                                u32 bits = 0; for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * e.nbBits[s];
+                                u32 const bytes = (bits + 1 + 7) >> 3;
+                                sh.strBytes[t] = bytes; sh.strOff[t] = total; total += bytes;
+                                if (bytes > 65535) tooBig = true;
+                            }
+                            if (!single && n < 12) tooBig = true;
+                            if (tooBig || total >= n - 1 || total >= n - ((n >> 6) + 2)) m = 0;
+                            else {
+                                u8* const hp = body;
+                                if (lhSize == 3) { u32 const lhc = 2 + ((u32)(!single) << 2) + (n << 4) + (total << 14); st16(hp, lhc & 0xFFFF); hp[2] = (u8)(lhc >> 16); }
+                                else if (lhSize == 4) st32(hp, 2 + (2u << 2) + (n << 4) + (total << 18));
+                                else { st32(hp, 2 + (3u << 2) + (n << 4) + (total << 22)); hp[4] = (u8)(total >> 10); }
+                                if (!single) { u8* const jt = body + lhSize + h; st16(jt, sh.strBytes[0]); st16(jt + 2, sh.strBytes[1]); st16(jt + 4, sh.strBytes[2]); }
+                                sh.litSecSize = lhSize + total;
+                            }
+                        }
+                    }
+                    sh.litMode = m;
+                }
+                g.sync();
+                mode = sh.litMode;
+            }
+            if (mode == 2) {
+                u32 const streams = single ? 1u : 4u;
+                GRP_FOR(g, t, streams) {
+                    u32 const cnt = single ? n : (t < 3 ? seg : n - 3 * seg);
+                    ze_huf_encode_stream(e, body + lhSize + sh.strOff[t], litBuf + t * seg, cnt);
+                }
+            } else if (mode == 1) {
+                GRP_SERIAL(g) {
+                    u32 const fl = 1 + (n > 31) + (n > 4095);
+                    if (fl == 1) body[0] = (u8)(1 + (n << 3)); else if (fl == 2) st16(body, 1 + (1u << 2) + (n << 4)); else { u32 const v = 1 + (3u << 2) + (n << 4); st16(body, v & 0xFFFF); body[2] = (u8)(v >> 16); }
+                    body[fl] = litBuf[0]; sh.litSecSize = fl + 1;
+                }
+            } else {
+                u32 const sz = ze_raw_literals(g, body, litBuf, n);
+                GRP_SERIAL(g) { sh.litSecSize = sz; }
+            }
+            zj_mem_order();
+            g.sync();
+        }
+        // ---- sequences section (zstd_compress.c:2940-3003) ----
+        {   u32 const maxCSize = srcSize - ((srcSize >> 6) + 2);              // ZSTD_minGain
+            u32 pos = sh.litSecSize;
+            GRP_SERIAL(g) {
+                u8* op = body + pos;
+                if (nbSeq < 128) *op++ = (u8)nbSeq;
+                else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
+                else { op[0] = 0xFF; st16(op + 1, nbSeq - 0x7F00); op += 3; }
+                sh.tmp[1] = (u32)(op - body);
+            }
+            g.sync();
+            pos = sh.tmp[1];
+            bool ok = true;
+            if (pos + 4 >= maxCSize) ok = false;                              // cannot win any more: raw block
+            if (ok && nbSeq) {
+                u32 const seqHead = pos; pos += 1;
+                for (u32 t = 0; t < 3; t++) {                                 // LL, OF, ML in stream order
+                    GRP_FOR(g, s, 64) e.scount[s] = 0;
+                    g.sync();
+                    GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; u32 const code = (t == 0 ? s.ll : (t == 1 ? s.off : s.ml)) >> 24; atomicAdd(&e.scount[code], 1u); }
+                    g.sync();
+                    GRP_SERIAL(g) {
+                        u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;
+                        const short* const defNorm = t == 0 ? ze_k_ll_defnorm : (t == 1 ? ze_k_of_defnorm : ze_k_ml_defnorm);
+                        u32 const defMax = t == 0 ? 35u : (t == 1 ? 28u : 52u);
+                        u32 max = 0, most = 0;
+                        for (u32 s = 0; s <= maxSym; s++) { if (e.scount[s]) max = s; most = zj_max(most, e.scount[s]); }
+                        bool const defaultAllowed = (t != 1) || (max <= 28);
+                        u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy, no repeat
+                        if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+                        else {
+                            u32 const dynMin = ((1u << defLog) * (10 - strat)) >> 3;
+                            type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
+                        }
+                        u32 h = 0;
+                        u32 const lastCode = (t == 0 ? seqs[nbSeq - 1].ll : (t == 1 ? seqs[nbSeq - 1].off : seqs[nbSeq - 1].ml)) >> 24;
+                        u32 const firstCode = (t == 0 ? seqs[0].ll : (t == 1 ? seqs[0].off : seqs[0].ml)) >> 24;
+                        if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1; }
+                        else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, e.cumul, e.tableSymbol);
+                        else {
+                            u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
+                            if (e.scount[lastCode] > 1) { e.scount[lastCode]--; nbSeq1--; }
+                            ze_fse_normalize(e.norm, tableLog, e.scount, nbSeq1, max, nbSeq1 >= 2048);
+                            h = ze_fse_write_ncount(body + pos, e.norm, max, tableLog);
+                            ze_fse_build_ctable(e.ct[t], e.norm, max, tableLog, e.cumul, e.tableSymbol);
+                            sh.seqLastCount = h;
+                        }
+                        sh.seqType[t] = type; sh.seqHdr[t] = h;
+                        if (t == 0) sh.seqLastCount = (type == 2) ? h : 0;
+                        else if (type == 2) sh.seqLastCount = h;
+                    }
+                    g.sync();
+                    pos += sh.seqHdr[t];
+                }
+                // ---- ZSTD_encodeSequences_body (lane 0; tANS state chains are sequential) ----
+                GRP_SERIAL(g) {
+                    body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2));
+                    ZEBitW b; ZEFseCS sML, sOF, sLL; u32 n = nbSeq - 1; u8* const bstart = body + pos;
+                    const ZEFseCT& ctLL = e.ct[0]; const ZEFseCT& ctOF = e.ct[1]; const ZEFseCT& ctML = e.ct[2];
+                    b.p = bstart; b.acc = 0; b.n = 0;
+                    ZESeq s = seqs[n];
+                    ze_fse_init2(sML, ctML, s.ml >> 24); ze_fse_init2(sOF, ctOF, s.off >> 24); ze_fse_init2(sLL, ctLL, s.ll >> 24);
+                    ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
+                    ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
+                    ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                    bool over = false;
+                    while (n-- > 0) {
+                        s = seqs[n];
+                        ze_fse_encode(b, sOF, ctOF, s.off >> 24); ze_fse_encode(b, sML, ctML, s.ml >> 24); ze_fse_encode(b, sLL, ctLL, s.ll >> 24);
+                        ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
+                        ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
+                        ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                        if ((u32)(b.p - body) >= maxCSize) { over = true; break; }       // block will be emitted raw anyway
+                    }
+                    u32 bitSize = 0;
+                    if (!over) {
+                        ze_bw_add(b, sML.value, ctML.tableLog); ze_bw_add(b, sOF.value, ctOF.tableLog); ze_bw_add(b, sLL.value, ctLL.tableLog);
+                        bitSize = ze_bw_close(b, bstart);
+                    }
+                    sh.tmp[2] = over ? 0xFFFFFFFFu : bitSize;
+                }
+                g.sync();
+                if (sh.tmp[2] == 0xFFFFFFFFu) ok = false;
+                else { if (sh.seqLastCount && (sh.seqLastCount + sh.tmp[2]) < 4) ok = false; pos += sh.tmp[2]; }
+            }
+            if (ok && pos < maxCSize) { compressed = true; cSize = pos; }
+        }
+    }
+    zj_mem_order();
+    g.sync();
+    // ---- block header + placement ----
+    if (compressed) {
+        if (dstCap < hdr + 3 + cSize) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+        if (!direct) grp_copy_wide(g, dst + hdr + 3, body, cSize);
+        GRP_SERIAL(g) { u32 const bh = 1 + (2u << 1) + (cSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
+        return hdr + 3 + cSize;
+    }
+    if (dstCap < hdr + 3 + srcSize) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    grp_copy_wide(g, dst + hdr + 3, src, srcSize);
+    GRP_SERIAL(g) { u32 const bh = 1 + (srcSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
+    return hdr + 3 + srcSize;
+}
+
+// LDS bytes the match finder needs for (level, srcSize); the entropy stage needs sizeof(ZEEntropy).
+ZJ_HD u32 ze_lds_need(u32 level, u32 srcSize) {
+    u32 w, c, h, st;
+    if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; st = (level == 3) ? 2 : 1; }
+    else if (level == 1) { w = 17; c = 12; h = 13; st = 1; }
+    else if (level == 2) { w = 17; c = 13; h = 15; st = 1; }
+    else { w = 17; c = 15; h = 16; st = 2; }
+    u32 const srcLog = (srcSize < 64u) ? 6u : zj_hibit(srcSize - 1) + 1;
+    if (w > srcLog) w = srcLog;
+    if (h > w + 1) h = w + 1;
+    if (c > w) c = w;
+    if (st == 2) { if (h > ZE_L3_HASHLOG) h = ZE_L3_HASHLOG; if (c > ZE_L3_CHAINLOG) c = ZE_L3_CHAINLOG; if (h > w + 1) h = w + 1; if (c > w) c = w; }
+    u32 const entries = (1u << h) + (st == 2 ? (1u << c) : 0u);
+    u32 const bytes = entries * (srcSize <= 65536u ? 2u : 4u);
+    return bytes > (u32)sizeof(ZEEntropy) ? bytes : (u32)sizeof(ZEEntropy);
+}
+
+template <class G>
+ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws) {
+    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws);
+    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws);
 }

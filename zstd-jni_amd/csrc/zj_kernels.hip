@@ -37,21 +37,38 @@ __global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ sr
     }
 }
 
+// Encoder: dynamic LDS = the match-finder tables of the launch's (level, size class); the entropy stage
+// overlays them.  Pass 0 runs with the LDS of the common case and defers the few frames whose tables
+// need more (e.g. level-1 inputs of 8-16 KiB use hashLog 15) to pass 1, which runs with 128 KiB of LDS
+// and exits at once when nothing was deferred.
+#define ZJ_DEFER_SENTINEL 0xFFFFFFFFFFFFFF00ull
+extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
-                                                        u64* __restrict__ result, u32 n, u32 level, u32* counter, u8* scratch) {
+                                                        u64* result, u32 n, u32 level, u32* counters, u8* scratch,
+                                                        u32 ldsBytes, u32 pass) {
     __shared__ ZEncShared sh;
     __shared__ u32 s_idx;
     Grp<64> g;
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
+    if (pass == 1 && counters[1] == 0) return;
     for (;;) {
-        if (threadIdx.x == 0) s_idx = atomicAdd(counter, 1u);
+        if (threadIdx.x == 0) s_idx = atomicAdd(&counters[pass ? 2 : 0], 1u);
         __syncthreads();
         u32 const i = s_idx;
         __syncthreads();
         if (i >= n) break;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const r = ze_compress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0 > 0xFFFFFFFFull ? 0xFFFFFFFFull : d1 - d0), level, ws);
+        u64 const size = s1 - s0;
+        if (pass == 0) {
+            if (size > ZE_BLOCK_MAX) { if (threadIdx.x == 0) result[i] = ZJ_ERR64(201); continue; }
+            if (ze_lds_need(level, (u32)size) > ldsBytes) {
+                if (threadIdx.x == 0) { result[i] = ZJ_DEFER_SENTINEL; atomicAdd(&counters[1], 1u); }
+                continue;
+            }
+        } else if (result[i] != ZJ_DEFER_SENTINEL) continue;
+        u64 const cap = d1 - d0;
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)size, dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
@@ -78,10 +95,18 @@ __global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src
 
 // ============================================================================ host state =======
 namespace {
+#define ZJ_ENC_LDS_BIG 131072u
+// pass-0 LDS per level: the tables of > 16 KiB inputs up to 64 KiB (u16 positions)
+size_t enc_lds_pass0(int level) {
+    size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
+    return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);
+}
 struct DevState {
     int ordinal = -1;
     int numCU = 0;
-    int decGrid = 0, encGrid = 0;
+    int decGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
+    int encGridLvl[4] = {0, 0, 0, 0};     // resident workgroups per level for pass 0
+    int encGridBig = 0;                    // pass 1 (128 KiB LDS)
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
     u8* decScratch = nullptr;
     u8* encScratch = nullptr;
@@ -114,12 +139,17 @@ DevState* get_state(int ordinal) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_decode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 8;
         d.decGrid = d.numCU * perCU;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
-        d.encGrid = d.numCU * perCU;
+        if (hipFuncSetAttribute((const void*)zj_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZJ_ENC_LDS_BIG) != hipSuccess) return nullptr;
+        for (int lvl = 1; lvl <= 3; lvl++) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, enc_lds_pass0(lvl)) != hipSuccess || perCU < 1) perCU = 1;
+            d.encGridLvl[lvl] = d.numCU * perCU;
+            if (d.encGridLvl[lvl] > d.encGrid) d.encGrid = d.encGridLvl[lvl];
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZJ_ENC_LDS_BIG) != hipSuccess || perCU < 1) perCU = 1;
+        d.encGridBig = d.numCU * perCU;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
         if (hipMalloc(&d.decScratch, (size_t)d.decGrid * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
-        if (hipMemset(d.encScratch, 0, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
         d.ordinal = ordinal;
     }
     return &d;
@@ -225,7 +255,7 @@ unsigned long long zjni_getFrameContentSize(const void* srcv, size_t srcSize) {
 int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* encodeLds) {
     DevState* d = cur_state();
     if (decodeLds) *decodeLds = (int)sizeof(ZDecShared);
-    if (encodeLds) *encodeLds = (int)sizeof(ZEncShared);
+    if (encodeLds) *encodeLds = (int)(enc_lds_pass0(3) + sizeof(ZEncShared));
     if (!d) return -(int)ZJNI_ERROR_no_device;
     if (decodeGrid) *decodeGrid = d->decGrid;
     if (encodeGrid) *encodeGrid = d->encGrid;
@@ -254,10 +284,16 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(d->counters + 16, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    u32 const grid = (u32)(n < (size_t)d->encGrid ? n : (size_t)d->encGrid);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, d->counters + 16, d->encScratch);
+    u32* const ctr = d->counters + 16;
+    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32 const lds0 = (u32)enc_lds_pass0(level);
+    u32 const grid0 = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid0), dim3(64), lds0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, ctr, d->encScratch, lds0, 0u);
+    if (hipGetLastError() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32 const grid1 = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid1), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, ctr, d->encScratch, ZJ_ENC_LDS_BIG, 1u);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
