@@ -168,13 +168,24 @@ def main():
         host_off = None
         host_src = src[:k * size].cpu().numpy().tobytes()
         checker = ref if ref.available() else port
-        cpu_ok = True
+        cpu_ok, first_bad = True, None
         for i in range(k):
-            f = blob[i * bound:i * bound + sizes[i]].tobytes()
-            if checker.decompress(f, size) != host_src[i * size:(i + 1) * size]:
+            f = blob[i * bound:i * bound + max(sizes[i], 0)].tobytes()
+            try:
+                good = sizes[i] > 0 and checker.decompress(f, size) == host_src[i * size:(i + 1) * size]
+            except Exception as ex:          # noqa: BLE001 - report, do not crash the bench line
+                good = False
+                first_bad = first_bad or f"{i}: size {sizes[i]} {ex} head {f[:12].hex()}"
+            if not good:
                 cpu_ok = False
-                break
+                first_bad = first_bad or f"{i}: size {sizes[i]} head {f[:12].hex()}"
         gates["cpu_decodes_gpu_frames"] = cpu_ok
+        if first_bad:
+            gates["first_bad_frame"] = first_bad
+        neg = int((csz <= 0).sum().item())
+        if neg:
+            gates["frames_with_error_result"] = neg
+            gates["error_results"] = sorted(set(csz[csz <= 0].cpu().tolist()))[:4]
         # CPU baseline on a bounded sample of the same workload (same generator, same indices)
         m = min(a.cpu_sample, n)
         sample = zj.synth_host(size, first, m)

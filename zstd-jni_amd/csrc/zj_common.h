@@ -68,6 +68,20 @@ struct Grp {
 #endif
 };
 
+// Values that lane 0 publishes through LDS are the same in every lane, but the compiler cannot know
+// that and would build exec-masked ("divergent") control flow around them.  With single-wave
+// workgroups hipcc also elides s_barrier, so a divergent loop whose exit depends on such a value can
+// leave lanes spinning on LDS while the producing lane is masked off (observed: persistent-loop hang).
+// ZJ_UNI() re-reads the value through v_readfirstlane so it lives in an SGPR and every branch on it is
+// a scalar branch taken by the whole wave.
+#if ZJ_ON_GPU
+#define ZJ_UNI(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+ZJ_DEV u64 zj_uni64(u64 v) { return ((u64)ZJ_UNI((u32)(v >> 32)) << 32) | ZJ_UNI((u32)v); }
+#else
+#define ZJ_UNI(x) ((u32)(x))
+ZJ_DEV u64 zj_uni64(u64 v) { return v; }
+#endif
+
 #define GRP_SERIAL(g) if ((g).lane() == 0)
 #define GRP_FOR(g, i, n) for (u32 i = (g).lane(); i < (u32)(n); i += (u32)(g).W)
 
@@ -93,6 +107,16 @@ ZJ_DEV void zj_mem_order() {
 #if ZJ_ON_GPU
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+// wave-wide vote: bit l set iff lane l's predicate holds (lane-serial build: bit 0)
+template <class G>
+ZJ_DEV u64 grp_ballot(const G& g, bool pred) {
+#if ZJ_ON_GPU
+    (void)g; return __ballot(pred);
+#else
+    (void)g; return pred ? 1ull : 0ull;
 #endif
 }
 

@@ -417,9 +417,9 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         if (err) sh.err = err;
     }
     g.sync();
-    if (sh.err) return opos;
+    if (ZJ_UNI(sh.err)) return opos;
 
-    u32 const litType = sh.litType, litSize = sh.litSize, litHdr = sh.litHdr, litCSize = sh.litCSize;
+    u32 const litType = ZJ_UNI(sh.litType), litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
     const u8* lit = litScratch;
     if (litType == 0) lit = bsrc + litHdr;                      // raw: read in place
     else if (litType == 1) { zd_fill(g, litScratch, bsrc[litHdr], litSize); zj_mem_order(); }
@@ -433,8 +433,8 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 sh.litSrcOff = litHdr + h; sh.bN = nbSym;
             }
             g.sync();
-            if (sh.err) return opos;
-            {   u32 const log = sh.hufLog, nbSym = sh.bN;
+            if (ZJ_UNI(sh.err)) return opos;
+            {   u32 const log = ZJ_UNI(sh.hufLog), nbSym = ZJ_UNI(sh.bN);
                 GRP_FOR(g, s, nbSym) {
                     u32 const w = sh.weights[s];
                     if (w) {
@@ -476,9 +476,9 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             if (err) sh.err = err;
         }
         g.sync();
-        if (sh.err) return opos;
+        if (ZJ_UNI(sh.err)) return opos;
         // ---- rounds: stage windows (all lanes) -> decode (<=4 lanes) -> flush (all lanes) ----
-        {   u32 const maxN = zj_max(zj_max(sh.hN[0], sh.hN[1]), zj_max(sh.hN[2], sh.hN[3]));
+        {   u32 const maxN = ZJ_UNI(zj_max(zj_max(sh.hN[0], sh.hN[1]), zj_max(sh.hN[2], sh.hN[3])));
             u32 const rounds = (maxN + ZD_HSYM - 1) / ZD_HSYM;
             for (u32 r = 0; r < rounds; r++) {
                 GRP_FOR(g, i, 4u * (ZD_HWIN_STRIDE / 16u)) {
@@ -509,7 +509,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
             GRP_SERIAL(g) { for (u32 t = 0; t < sh.litStreams; t++) { if (sh.hA[t] != sh.hS0[t]) sh.err = ZJ_E_CORRUPTION; } }
             g.sync();
-            if (sh.err) return opos;
+            if (ZJ_UNI(sh.err)) return opos;
         }
     }
 
@@ -556,9 +556,9 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         if (err) sh.err = err;
     }
     g.sync();
-    if (sh.err) return opos;
+    if (ZJ_UNI(sh.err)) return opos;
 
-    u32 const nbSeq = sh.nbSeq;
+    u32 const nbSeq = ZJ_UNI(sh.nbSeq);
     u32 litUsed = 0;
     if (nbSeq) {
         // predefined / RLE tables (lanes 0..2, one table each)
@@ -589,11 +589,11 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             if (err) sh.err = err;
         }
         g.sync();
-        if (sh.err) return opos;
+        if (ZJ_UNI(sh.err)) return opos;
         bool first = true;
         for (;;) {
             // stage the bitstream window [winLo, winLo + ZD_SWIN)
-            zd_stage(g, sh.win, bsrc, sh.winLo, ZD_SWIN, bsize);
+            zd_stage(g, sh.win, bsrc, ZJ_UNI(sh.winLo), ZD_SWIN, bsize);
             g.sync();
             GRP_SERIAL(g) {
                 if (first) {   // initial states: LL, OF, ML (N/decompress/zstd_decompress_block.c:1640-1642)
@@ -607,12 +607,12 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
             first = false;
             g.sync();
-            if (sh.err) return opos;
+            if (ZJ_UNI(sh.err)) return opos;
             // ---- execute the batch: N/decompress/zstd_decompress_block.c:1001-1096 ----
-            {   u32 const n = sh.bN;
-                u32 lp = sh.bLitStart, op = sh.bOutStart;
+            {   u32 const n = ZJ_UNI(sh.bN);
+                u32 lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
                 for (u32 k = 0; k < n; k++) {
-                    u32 const ll = sh.sLit[k], ml = sh.sMl[k], off = sh.sOff[k];
+                    u32 const ll = ZJ_UNI(sh.sLit[k]), ml = ZJ_UNI(sh.sMl[k]), off = ZJ_UNI(sh.sOff[k]);
                     GRP_FOR(g, j, ll) out[op + j] = lit[lp + j];
                     lp += ll; op += ll;
                     zj_mem_order();
@@ -625,7 +625,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 }
                 litUsed = lp; opos = op;
             }
-            if (sh.seqDone) break;
+            if (ZJ_UNI(sh.seqDone)) break;
             g.sync();
         }
         GRP_SERIAL(g) { sh.rep[0] = p.rep0; sh.rep[1] = p.rep1; sh.rep[2] = p.rep2; }
@@ -690,9 +690,9 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if (err) sh.err = err;
         }
         g.sync();
-        if (sh.err) return ZJ_ERR64(sh.err);
-        if (sh.blkType == 1) { ipos += sh.hdrSize; g.sync(); continue; }
-        ipos += sh.hdrSize;
+        if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
+        if (ZJ_UNI(sh.blkType) == 1) { ipos += ZJ_UNI(sh.hdrSize); g.sync(); continue; }
+        ipos += ZJ_UNI(sh.hdrSize);
         u8* const fout = dst + total; u32 const fcap = dstCap - total;
         u32 opos = 0;
         for (;;) {
@@ -714,16 +714,16 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
                 if (err) sh.err = err;
             }
             g.sync();
-            if (sh.err) return ZJ_ERR64(sh.err);
+            if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
             ipos += 3;
             u32 const type = sh.blkType, sz = sh.blkSize, last = sh.blkLast;
             if (type == 0) { grp_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); }
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
-                u32 const cap = zj_min(fcap, opos + sh.blockSizeMax);
+                u32 const cap = zj_min(fcap, opos + ZJ_UNI(sh.blockSizeMax));
                 opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch);
-                if (sh.err) {
-                    u32 e = sh.err;
+                if (ZJ_UNI(sh.err)) {
+                    u32 e = ZJ_UNI(sh.err);
                     if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax
                     return ZJ_ERR64(e);
                 }
@@ -732,8 +732,8 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             g.sync();
             if (last) break;
         }
-        if (sh.contentSize != ~(u64)0 && sh.contentSize != opos) return ZJ_ERR64(ZJ_E_CORRUPTION);
-        if (sh.hasChecksum) {
+        {   u64 const cs = zj_uni64(sh.contentSize); if (cs != ~(u64)0 && cs != opos) return ZJ_ERR64(ZJ_E_CORRUPTION); }
+        if (ZJ_UNI(sh.hasChecksum)) {
             // XXH64 verification is a "next" row; frames from Zstd.compress() default to no checksum.
             if (srcSize - ipos < 4) return ZJ_ERR64(ZJ_E_CHECKSUM_WRONG);
             ipos += 4;

@@ -51,7 +51,7 @@ struct ZEEntropy {                 // entropy-stage view of the LDS
     u32 scount[64]; short norm[64];
     u16 cumul[260]; u8 tableSymbol[512];
     ZEFseCT ct[3];                 // LL, OF, ML
-    i32 qsLow[32]; i32 qsHigh[32]; // explicit quicksort stack
+    i32 qsLow[64]; i32 qsHigh[64]; // explicit quicksort stack
 };
 
 #define ZE_LDS_TABLE_L1_U16 (8192u * 2u)
@@ -613,8 +613,8 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         }
     }
     g.sync();
-    if (sh.err) return ZJ_ERR64(sh.err);
-    u32 const hdr = sh.hdrSize;
+    if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
+    u32 const hdr = ZJ_UNI(sh.hdrSize);
     if (srcSize == 0) {                                                       // ZSTD_writeEpilogue: empty raw last block
         GRP_SERIAL(g) { dst[hdr] = 1; dst[hdr + 1] = 0; dst[hdr + 2] = 0; }
         return hdr + 3;
@@ -625,7 +625,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
     u8* const body = direct ? dst + hdr + 3 : ws + ZE_WS_BODY;
     if (srcSize >= 7) {                                                       // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
-        u32 const strategy = sh.strategy, hlog = sh.hashLog, clog = sh.chainLog, mls = sh.minMatch;
+        u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
         u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
         {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
             GRP_FOR(g, i, words) w[i] = 0; }
@@ -639,7 +639,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         }
         zj_mem_order();
         g.sync();
-        u32 const nbSeq = sh.nbSeq, litSize = sh.litSize, lastLL = sh.lastLL;
+        u32 const nbSeq = ZJ_UNI(sh.nbSeq), litSize = ZJ_UNI(sh.litSize), lastLL = ZJ_UNI(sh.lastLL);
         // ---- gather literals into HBM scratch + sequence codes (all lanes) ----
         {   const u32* const litOff = (const u32*)(ws + ZE_WS_BODY);           // body scratch is free until the entropy stage
             GRP_FOR(g, i, nbSeq) {
@@ -653,16 +653,22 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             }
             zj_mem_order();
             g.sync();
-            for (u32 i = 0; i < nbSeq; i++) {                                  // long literal runs: cooperative
-                u32 const ll = ZE_LOW24(seqs[i].ll);
-                if (ll > 64) { u32 const o = litOff[i], p = seqs[i].pos; GRP_FOR(g, k, ll) litBuf[o + k] = src[p + k]; }
+            for (u32 base = 0; base < nbSeq; base += (u32)G::W) {                  // long literal runs: cooperative
+                u32 const i = base + g.lane();
+                u32 const myLL = i < nbSeq ? ZE_LOW24(seqs[i].ll) : 0;
+                u64 m = grp_ballot(g, myLL > 64);
+                while (m) {
+                    u32 const k = (u32)__builtin_ctzll(m); m &= m - 1;
+                    u32 const ll = ZJ_UNI(ZE_LOW24(seqs[base + k].ll)), o = ZJ_UNI(litOff[base + k]), p = ZJ_UNI(seqs[base + k].pos);
+                    GRP_FOR(g, q, ll) litBuf[o + q] = src[p + q];
+                }
             }
             GRP_FOR(g, k, lastLL) litBuf[litSize - lastLL + k] = src[srcSize - lastLL + k];
             zj_mem_order();
             g.sync();
         }
         // ---- literals section (ZSTD_compressLiterals, first block: no previous table) ----
-        u32 const strat = sh.strategy;
+        u32 const strat = strategy;
         {   u32 const n = litSize;
             u32 const lhSize = 3 + (n >= 1024) + (n >= 16384);
             bool const single = n < 256;
@@ -679,7 +685,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     g.sync();
                     GRP_SERIAL(g) { u32 lb = 0, le = 0; for (u32 s = 0; s < 256; s++) { lb = zj_max(lb, e.hist[0][s]); le = zj_max(le, e.hist[1][s]); } sh.tmp[0] = (lb + le <= 68) ? 1 : 0; }
                     g.sync();
-                    if (sh.tmp[0]) mode = 0;
+                    if (ZJ_UNI(sh.tmp[0])) mode = 0;
                     g.sync();
                     GRP_FOR(g, i, 512) (&e.hist[0][0])[i] = 0;
                     g.sync();
@@ -727,7 +733,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     sh.litMode = m;
                 }
                 g.sync();
-                mode = sh.litMode;
+                mode = ZJ_UNI(sh.litMode);
             }
             if (mode == 2) {
                 u32 const streams = single ? 1u : 4u;
@@ -750,7 +756,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         }
         // ---- sequences section (zstd_compress.c:2940-3003) ----
         {   u32 const maxCSize = srcSize - ((srcSize >> 6) + 2);              // ZSTD_minGain
-            u32 pos = sh.litSecSize;
+            u32 pos = ZJ_UNI(sh.litSecSize);
             GRP_SERIAL(g) {
                 u8* op = body + pos;
                 if (nbSeq < 128) *op++ = (u8)nbSeq;
@@ -759,7 +765,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                 sh.tmp[1] = (u32)(op - body);
             }
             g.sync();
-            pos = sh.tmp[1];
+            pos = ZJ_UNI(sh.tmp[1]);
             bool ok = true;
             if (pos + 4 >= maxCSize) ok = false;                              // cannot win any more: raw block
             if (ok && nbSeq) {
@@ -800,7 +806,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                         else if (type == 2) sh.seqLastCount = h;
                     }
                     g.sync();
-                    pos += sh.seqHdr[t];
+                    pos += ZJ_UNI(sh.seqHdr[t]);
                 }
                 // ---- ZSTD_encodeSequences_body (lane 0; tANS state chains are sequential) ----
                 GRP_SERIAL(g) {
@@ -830,8 +836,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     sh.tmp[2] = over ? 0xFFFFFFFFu : bitSize;
                 }
                 g.sync();
-                if (sh.tmp[2] == 0xFFFFFFFFu) ok = false;
-                else { if (sh.seqLastCount && (sh.seqLastCount + sh.tmp[2]) < 4) ok = false; pos += sh.tmp[2]; }
+                {   u32 const bits = ZJ_UNI(sh.tmp[2]), lastCount = ZJ_UNI(sh.seqLastCount);
+                    if (bits == 0xFFFFFFFFu) ok = false;
+                    else { if (lastCount && (lastCount + bits) < 4) ok = false; pos += bits; } }
             }
             if (ok && pos < maxCSize) { compressed = true; cSize = pos; }
         }

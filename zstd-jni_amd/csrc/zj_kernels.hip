@@ -9,6 +9,7 @@
 #include <vector>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/zjni_amd.h"
 #include "zj_decode.h"
 #include "zj_encode.h"
@@ -17,18 +18,22 @@
 #define ZJNI_ERR(code) ((size_t)0 - (size_t)(code))
 
 // ============================================================================ kernels ==========
+// Next work item of a persistent workgroup: one device-scope atomic by lane 0, broadcast through
+// v_readfirstlane so the index (and everything derived from it) is wave-uniform.
+__device__ __forceinline__ u32 zj_next_index(u32* counter) {
+    u32 v = 0;
+    if (threadIdx.x == 0) v = atomicAdd(counter, 1u);
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 __global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 n, u32* counter, u8* scratch) {
     __shared__ ZDecShared sh;
-    __shared__ u32 s_idx;
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
     for (;;) {
-        if (threadIdx.x == 0) s_idx = atomicAdd(counter, 1u);
-        __syncthreads();
-        u32 const i = s_idx;
-        __syncthreads();
+        u32 const i = zj_next_index(counter);      // wave-uniform (SGPR)
         if (i >= n) break;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
         u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit);
@@ -38,37 +43,37 @@ __global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ sr
 }
 
 // Encoder: dynamic LDS = the match-finder tables of the launch's (level, size class); the entropy stage
-// overlays them.  Pass 0 runs with the LDS of the common case and defers the few frames whose tables
-// need more (e.g. level-1 inputs of 8-16 KiB use hashLog 15) to pass 1, which runs with 128 KiB of LDS
-// and exits at once when nothing was deferred.
-#define ZJ_DEFER_SENTINEL 0xFFFFFFFFFFFFFF00ull
+// overlays them.  A classification kernel splits the batch into two index lists: frames whose tables
+// fit the LDS of the common case (list A) and the few that need more (list B; e.g. level-1 inputs of
+// 8-16 KiB use hashLog 15, inputs > 64 KiB use 4-byte positions).  The same persistent kernel then runs
+// once per list — with 128 KiB of LDS for list B, exiting at once when that list is empty.
 extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
+
+__global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restrict__ srcOff, u64* __restrict__ result, u32 n, u32 level,
+                                                               u32 ldsA, u32* counters, u32* listA, u32* listB) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 const size = srcOff[i + 1] - srcOff[i];
+    if (size > ZE_BLOCK_MAX) { result[i] = ZJ_ERR64(201); return; }
+    if (ze_lds_need(level, (u32)size) <= ldsA) listA[atomicAdd(&counters[0], 1u)] = i;
+    else listB[atomicAdd(&counters[1], 1u)] = i;
+}
+
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
-                                                        u64* result, u32 n, u32 level, u32* counters, u8* scratch,
-                                                        u32 ldsBytes, u32 pass) {
+                                                        u64* __restrict__ result, u32 level, const u32* __restrict__ list,
+                                                        const u32* countPtr, u32* workCounter, u8* scratch) {
     __shared__ ZEncShared sh;
-    __shared__ u32 s_idx;
     Grp<64> g;
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
-    if (pass == 1 && counters[1] == 0) return;
+    u32 const count = ZJ_UNI(*countPtr);
     for (;;) {
-        if (threadIdx.x == 0) s_idx = atomicAdd(&counters[pass ? 2 : 0], 1u);
-        __syncthreads();
-        u32 const i = s_idx;
-        __syncthreads();
-        if (i >= n) break;
-        u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const size = s1 - s0;
-        if (pass == 0) {
-            if (size > ZE_BLOCK_MAX) { if (threadIdx.x == 0) result[i] = ZJ_ERR64(201); continue; }
-            if (ze_lds_need(level, (u32)size) > ldsBytes) {
-                if (threadIdx.x == 0) { result[i] = ZJ_DEFER_SENTINEL; atomicAdd(&counters[1], 1u); }
-                continue;
-            }
-        } else if (result[i] != ZJ_DEFER_SENTINEL) continue;
+        u32 const k = zj_next_index(workCounter);     // wave-uniform (SGPR)
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
         u64 const cap = d1 - d0;
-        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)size, dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws);
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
@@ -111,6 +116,7 @@ struct DevState {
     u8* decScratch = nullptr;
     u8* encScratch = nullptr;
     // staging for the host-pointer entries
+    u32* encList = nullptr; size_t encListCap = 0;   // two index lists of encListCap entries each
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
@@ -199,6 +205,7 @@ void zjni_shutdown(void) {
         if (d.ordinal < 0) continue;
         (void)hipSetDevice(d.ordinal);
         (void)hipFree(d.counters); (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
+        if (d.encList) (void)hipFree(d.encList);
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
@@ -284,16 +291,24 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
-    u32* const ctr = d->counters + 16;
+    if (d->encListCap < n) {                      // grows rarely; the only synchronous step of this entry
+        if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
+        size_t const cap = n + (n >> 2) + 1024;
+        if (hipMalloc(&d->encList, 2 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
+        d->encListCap = cap;
+    }
+    u32* const ctr = d->counters + 16;            // [0] |A|, [1] |B|, [2] work A, [3] work B
+    u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap;
     if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    u32 const lds0 = (u32)enc_lds_pass0(level);
-    u32 const grid0 = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid0), dim3(64), lds0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, ctr, d->encScratch, lds0, 0u);
-    if (hipGetLastError() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    u32 const grid1 = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(grid1), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, (u32)level, ctr, d->encScratch, ZJ_ENC_LDS_BIG, 1u);
+    u32 const ldsA = (u32)enc_lds_pass0(level);
+    hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
+                       (u32)n, (u32)level, ldsA, ctr, listA, listB);
+    u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch);
+    u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
