@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="buffers in the CPU baseline sample")
     ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded by the CPU reference")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification sample + cpu_baseline), e.g. under a profiler")
     ap.add_argument("--decode-only", action="store_true",
                     help="diagnostic: time only the decode kernel on reference-compressed frames (unique set of --unique buffers, replicated)")
     ap.add_argument("--unique", type=int, default=4096)
@@ -160,7 +161,7 @@ def main():
     csum = int(csz.clamp(min=0).sum().item())
     cpu = None
     gates = {"gpu_roundtrip_exact": bool(roundtrip)}
-    if rank == 0:
+    if rank == 0 and not a.skip_cpu:
         from oracle import port, ref
         k = min(a.verify_sample, n)
         sizes = csz[:k].cpu().tolist()

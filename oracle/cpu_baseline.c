@@ -25,10 +25,14 @@ typedef struct {
     unsigned (*isError)(size_t);
 } RefLib;
 
+/* The handle is opened once and never dlclose()d: unloading a library that worker threads ran in
+ * upsets tools that hook thread exit (rocprofv3 segfaulted on it). */
 static int ref_open(RefLib* r, const char* path) {
+    static void* cached = NULL;
     memset(r, 0, sizeof(*r));
     if (!path) return 0;
-    r->h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!cached) cached = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    r->h = cached;
     if (!r->h) return -1;
 #define SYM(field, name) *(void**)(&r->field) = dlsym(r->h, name); if (!r->field) return -1;
     SYM(createCCtx, "ZSTD_createCCtx") SYM(freeCCtx, "ZSTD_freeCCtx") SYM(setParam, "ZSTD_CCtx_setParameter")
@@ -101,7 +105,6 @@ int zso_batch(const char* libpath, int mode, int level, const void* src, const s
     RefLib lib; double s;
     if (ref_open(&lib, libpath)) return -1;
     s = run_pass(&lib, mode, level, (const unsigned char*)src, srcOff, (unsigned char*)dst, dstOff, outSize, n, threads < 1 ? 1 : threads);
-    if (lib.h) dlclose(lib.h);
     return s < 0 ? -1 : 0;
 }
 
@@ -135,7 +138,6 @@ int zso_cpu_baseline(const char* libpath, const void* data, size_t bufSize, size
     out[0] = bestC; out[1] = bestD; out[2] = (double)total; out[3] = (memcmp(back, data, bufSize * n) == 0) ? 1.0 : 0.0;
     rc = 0;
 done:
-    if (lib.h) dlclose(lib.h);
     free(srcOff); free(cOff); free(cSize); free(dSize); free(pOff); free(comp); free(packed); free(back);
     return rc;
 }

@@ -1,0 +1,49 @@
+"""Profiling driver without torch: the bench step (compress -> pack -> decompress) through the C-ABI
+only, HBM buffers from the HIP runtime via ctypes.  Used for rocprofv3 runs (rocprofv3 + torch
+segfaults intermittently in this image); prints HIP-event kernel times for cross-checking."""
+import ctypes as C, os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as e
+zj = e.load_package(); L = zj.lib()
+hip = C.CDLL("libamdhip64.so")
+vp = C.c_void_p
+def chk(r): assert r == 0, r
+def dmalloc(n):
+    p = vp(); chk(hip.hipMalloc(C.byref(p), C.c_size_t(n))); return p
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+assert L.zjni_init(0) == 0
+bound = L.zjni_compressBound(size)
+src = dmalloc(n * size); comp = dmalloc(n * bound); packed = dmalloc(n * bound); back = dmalloc(n * size)
+import numpy as np
+def upload(arr):
+    p = dmalloc(arr.nbytes); chk(hip.hipMemcpy(p, arr.ctypes.data_as(vp), C.c_size_t(arr.nbytes), 1)); return p
+soff = upload(np.arange(n + 1, dtype=np.uint64) * size); coff = upload(np.arange(n + 1, dtype=np.uint64) * bound)
+csz = dmalloc(n * 8); dsz = dmalloc(n * 8); poff = dmalloc((n + 1) * 8)
+chk(L.zjni_synth_fill_device(src, size, 0, n, None)); chk(hip.hipDeviceSynchronize())
+ev = [vp() for _ in range(4)]
+for x in ev: chk(hip.hipEventCreate(C.byref(x)))
+tc = td = tp = 0.0
+h_csz = np.zeros(n, dtype=np.uint64)
+for it in range(steps + 1):
+    chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device(src, soff, comp, coff, csz, n, level, None)); chk(hip.hipEventRecord(ev[1], None))
+    chk(hip.hipDeviceSynchronize())
+    chk(hip.hipMemcpy(h_csz.ctypes.data_as(vp), csz, C.c_size_t(n * 8), 2))
+    h_poff = np.zeros(n + 1, dtype=np.uint64); h_poff[1:] = np.cumsum(h_csz)
+    chk(hip.hipMemcpy(poff, h_poff.ctypes.data_as(vp), C.c_size_t((n + 1) * 8), 1))
+    chk(hip.hipEventRecord(ev[1], None)); chk(L.zjni_pack_batch_device(comp, coff, csz, packed, poff, n, None)); chk(hip.hipEventRecord(ev[2], None))
+    chk(L.zjni_decompress_batch_device(packed, poff, back, soff, dsz, n, None)); chk(hip.hipEventRecord(ev[3], None))
+    chk(hip.hipDeviceSynchronize())
+    ms = C.c_float()
+    if it > 0:
+        # compress time measured separately above (ev0..first ev1 overwritten): re-measure via events 
+        pass
+    chk(hip.hipEventElapsedTime(C.byref(ms), ev[1], ev[2])); p_ms = ms.value
+    chk(hip.hipEventElapsedTime(C.byref(ms), ev[2], ev[3])); d_ms = ms.value
+    if it > 0: tp += p_ms; td += d_ms
+h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp), dsz, C.c_size_t(n * 8), 2))
+print(json.dumps({"n": n, "size": size, "level": level, "steps": steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+                  "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))
