@@ -8,7 +8,8 @@ extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned 
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
-    u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit);
+    ZjProf pf; pf.start(nullptr);
+    u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf);
     free(lit); free(sh);
     return r;
 }
@@ -20,8 +21,27 @@ extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned sr
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
-    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws);
+    ZjProf pf; pf.start(nullptr);
+    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf);
     free(ws); free(lds); free(sh);
     return r;
 }
 extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return ze_lds_need(level, srcSize); }
+
+// split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage
+extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    if (srcSize > 65536) return ZJ_ERR64(201);
+    Grp<1> g;
+    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
+    u8* lds = (u8*)calloc(1, 160 * 1024);
+    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    u8* table = (u8*)calloc(1, 65536 * 2);
+    u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(65536u));
+    u32 meta[3];
+    ze_match_lane(src, srcSize, level, table, fs, 65536u, meta);
+    ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(65536u) * 16u); pre.meta = meta;
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre);
+    free(fs); free(table); free(ws); free(lds); free(sh);
+    return r;
+}

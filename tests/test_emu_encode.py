@@ -39,6 +39,20 @@ def test_emu_encoder_xml_and_synthetic(emu, oracle_ref, zj):
             assert emu_compress(emu, d, level) == expected(oracle_ref, d, level), (size, level)
 
 
+def test_emu_split_pipeline_matches(emu, oracle_ref, zj):
+    """lane-per-frame match finding (records in HBM scratch) + entropy stage == fused path == reference"""
+    rnd = random.Random(21)
+    for name, data in edge_inputs():
+        if len(data) <= 65536:
+            for level in (1, 2, 3):
+                assert emu_compress(emu, data, level, split=True) == expected(oracle_ref, data, level), (name, level)
+    for _ in range(100):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 65537), 65536, 4096])
+        d = zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b""
+        for level in (1, 3):
+            assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
+
+
 def test_emu_encoder_small_inputs_match_default_level3(emu, oracle_ref, zj):
     rnd = random.Random(3)
     for _ in range(100):

@@ -14,9 +14,10 @@ def emu_lib():
     L = C.CDLL(os.path.join(d, "libzjni_emu.so"))
     L.emu_decompress.restype = C.c_ulonglong
     L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
-    if hasattr(L, "emu_compress"):
-        L.emu_compress.restype = C.c_ulonglong
-        L.emu_compress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    for fn in ("emu_compress", "emu_compress_split"):
+        if hasattr(L, fn):
+            getattr(L, fn).restype = C.c_ulonglong
+            getattr(L, fn).argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
     return L
 
 
@@ -28,10 +29,10 @@ def emu_decompress(L, frame, cap):
     return dst.raw[:r]
 
 
-def emu_compress(L, data, level):
+def emu_compress(L, data, level, split=False):
     cap = len(data) + (len(data) >> 8) + 64 + 128
     dst = C.create_string_buffer(cap)
-    r = L.emu_compress(data, len(data), dst, cap, level)
+    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level)
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

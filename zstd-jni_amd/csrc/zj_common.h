@@ -82,6 +82,21 @@ ZJ_DEV u64 zj_uni64(u64 v) { return ((u64)ZJ_UNI((u32)(v >> 32)) << 32) | ZJ_UNI
 ZJ_DEV u64 zj_uni64(u64 v) { return v; }
 #endif
 
+// Optional per-phase cycle accounting (kernel argument `prof`, nullptr in production): lane 0 adds the
+// shader-clock cycles spent since the previous mark to prof[idx].
+struct ZjProf {
+#if ZJ_ON_GPU
+    unsigned long long* acc; unsigned long long last;
+    ZJ_DEV void start(unsigned long long* p) { acc = p; last = p ? __builtin_readcyclecounter() : 0; }
+    ZJ_DEV void mark(u32 idx) {
+        if (acc) { unsigned long long const t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&acc[idx], t - last); last = t; }
+    }
+#else
+    void start(unsigned long long*) {}
+    void mark(u32) {}
+#endif
+};
+
 #define GRP_SERIAL(g) if ((g).lane() == 0)
 #define GRP_FOR(g, i, n) for (u32 i = (g).lane(); i < (u32)(n); i += (u32)(g).W)
 

@@ -388,7 +388,7 @@ ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
 // Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
 // (frame-relative position `opos`).  Returns new opos (or sets sh.err).
 template <class G>
-ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch) {
+ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -419,6 +419,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
     g.sync();
     if (ZJ_UNI(sh.err)) return opos;
 
+    pf.mark(0);
     u32 const litType = ZJ_UNI(sh.litType), litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
     const u8* lit = litScratch;
     if (litType == 0) lit = bsrc + litHdr;                      // raw: read in place
@@ -447,6 +448,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
         } else { GRP_SERIAL(g) { sh.litSrcOff = litHdr; } }
         g.sync();
+        pf.mark(1);
         // ---- stream descriptors (lane 0) ----
         GRP_SERIAL(g) {
             u32 const off = sh.litSrcOff, end = litHdr + litCSize;   // compressed literal bytes [off, end)
@@ -513,6 +515,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         }
     }
 
+    pf.mark(2);
     // ---- sequences header (lane 0): N/decompress/zstd_decompress_block.c:695-782 ----
     u32 const seqSecOff = litHdr + litCSize;
     GRP_SERIAL(g) {
@@ -576,6 +579,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
         }
         g.sync();
+        pf.mark(3);
         ZDecSeqPriv p;
         GRP_SERIAL(g) {
             u32 const s = sh.seqOff;
@@ -607,6 +611,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
             first = false;
             g.sync();
+            pf.mark(4);
             if (ZJ_UNI(sh.err)) return opos;
             // ---- execute the batch: N/decompress/zstd_decompress_block.c:1001-1096 ----
             {   u32 const n = ZJ_UNI(sh.bN);
@@ -625,6 +630,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 }
                 litUsed = lp; opos = op;
             }
+            pf.mark(5);
             if (ZJ_UNI(sh.seqDone)) break;
             g.sync();
         }
@@ -638,6 +644,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         zj_mem_order();
     }
     g.sync();
+    pf.mark(6);
     return opos;
 }
 
@@ -645,7 +652,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
 // Decodes all frames in [src, src+srcSize) into dst[0..dstCap).  Returns decoded size or
 // ZJ_ERR64(code) — the reference's size_t error convention (N/common/error_private.h).
 template <class G>
-ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch) {
+ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch, ZjProf& pf) {
     GRP_SERIAL(g) {
         sh.err = 0;
     }
@@ -717,11 +724,11 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
             ipos += 3;
             u32 const type = sh.blkType, sz = sh.blkSize, last = sh.blkLast;
-            if (type == 0) { grp_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); }
+            if (type == 0) { grp_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); pf.mark(7); }
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
                 u32 const cap = zj_min(fcap, opos + ZJ_UNI(sh.blockSizeMax));
-                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch);
+                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf);
                 if (ZJ_UNI(sh.err)) {
                     u32 e = ZJ_UNI(sh.err);
                     if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax

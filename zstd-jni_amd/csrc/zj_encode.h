@@ -52,6 +52,7 @@ struct ZEEntropy {                 // entropy-stage view of the LDS
     u16 cumul[260]; u8 tableSymbol[512];
     ZEFseCT ct[3];                 // LL, OF, ML
     i32 qsLow[64]; i32 qsHigh[64]; // explicit quicksort stack
+    ZESeq stage[64];               // sequence records staged for the tANS encoder
 };
 
 #define ZE_LDS_TABLE_L1_U16 (8192u * 2u)
@@ -99,7 +100,8 @@ ZJ_DEV void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) 
     if (chainLog > windowLog) chainLog = windowLog;
     if (windowLog < 10) windowLog = 10;
 }
-ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
+struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy; };
+ZJ_DEV ZEParams ze_params_of(u32 level, u32 srcSize) {
     u32 w, c, h, mm, st;
     if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; mm = (level == 1) ? 5 : 4; st = (level == 3) ? 2 : 1; }
     else if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
@@ -109,7 +111,12 @@ ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
     if (st == 2) {            // LDS budget: ZSTD_c_hashLog = 14, ZSTD_c_chainLog = 13, then adjust again
         if (h > ZE_L3_HASHLOG || c > ZE_L3_CHAINLOG) { if (h > ZE_L3_HASHLOG) h = ZE_L3_HASHLOG; if (c > ZE_L3_CHAINLOG) c = ZE_L3_CHAINLOG; ze_adjust(w, c, h, srcSize); }
     }
-    sh.windowLog = w; sh.chainLog = c; sh.hashLog = h; sh.minMatch = mm; sh.strategy = st;
+    ZEParams p; p.windowLog = w; p.chainLog = c; p.hashLog = h; p.minMatch = mm; p.strategy = st;
+    return p;
+}
+ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
+    ZEParams const p = ze_params_of(level, srcSize);
+    sh.windowLog = p.windowLog; sh.chainLog = p.chainLog; sh.hashLog = p.hashLog; sh.minMatch = p.minMatch; sh.strategy = p.strategy;
 }
 // bytes of LDS the match-finder tables need for this (level, size, index width)
 ZJ_HD u32 ze_table_entries(u32 level, u32 maxSrc) {
@@ -148,41 +155,66 @@ ZJ_DEV void ze_store(ZEOut& o, u32 litPos, u32 ll, u32 offBase, u32 ml) {
     o.seqs[o.n++] = s; o.lit += ll;
 }
 
+// hash of a position from its 8 already-loaded bytes (N/compress/zstd_compress_internal.h:898-960)
+ZJ_DEV u32 ze_hash_w(u64 w, u32 hBits, u32 mls) {
+    switch (mls) {
+    default:
+    case 4: return ((u32)w * 2654435761U) >> (32 - hBits);
+    case 5: return (u32)(((w << 24) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (u32)(((w << 16) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (u32)(((w << 8) * 58295818150454627ULL) >> (64 - hBits));
+    case 8: return (u32)((w * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+    }
+}
+
 // ZSTD_compressBlock_fast_noDict_generic (N/compress/zstd_fast.c:192-423); tables hold position+1.
+// Same decisions in the same order as the reference's pipelined loop; what changes is WHEN bytes are
+// fetched: every global load an iteration can need (the two new positions, the repcode candidate and
+// both table candidates) is issued at the top of the iteration, so one HBM/L2 round trip covers two
+// positions instead of five, and the 8 bytes of a position are loaded once and carried in registers as
+// it moves from ip2/ip3 to ip0/ip1.  The second table write of an iteration (table[hash1] = ip1) happens
+// on every path of the reference, so it is done up front, right after table[hash1] has been read.
 template <class TIdx>
 ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls, TIdx* table) {
     const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
     const u8* anchor = istart; const u8* ip0 = istart + 1; const u8* ip1; const u8* ip2; const u8* ip3;
-    u32 rep1 = 1, rep2 = 4;
-    u32 hash0, hash1, matchE, cur0 = 0, offcode, mLength, step;
-    const u8* match0; const u8* nextStep;
-    if (rep2 > 1) rep2 = 0;                       // maxRep == 1 at the first position of a frame
+    u32 rep1 = 1, rep2 = 0;                       // rep {1,4}: 4 > maxRep == 1 at the first position of a frame
+    u32 hash0, hash1, matchE, cur0 = 0, offcode = 0, mLength = 0, step;
+    const u8* match0 = istart; const u8* nextStep;
     for (;;) {
         step = 2; nextStep = ip0 + 128;
         ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
         if (ip3 >= ilimit) break;
-        hash0 = ze_hash(ip0, hlog, mls); hash1 = ze_hash(ip1, hlog, mls);
+        u64 w0 = ld64(ip0), w1 = ld64(ip1);
+        hash0 = ze_hash_w(w0, hlog, mls); hash1 = ze_hash_w(w1, hlog, mls);
         matchE = table[hash0];
         bool found = false, isRep = false;
         do {
+            // ---- issue everything this iteration may read ----
             u32 const rval = ld32(ip2 - rep1);
+            u64 const w2 = ld64(ip2), w3 = ld64(ip3);
+            u32 const c0 = matchE ? ld32(istart + matchE - 1) : ~(u32)w0;
             cur0 = (u32)(ip0 - istart); table[hash0] = (TIdx)(cur0 + 1);
-            if ((ld32(ip2) == rval) & (rep1 > 0)) {
+            u32 const matchE1 = table[hash1];
+            table[hash1] = (TIdx)((u32)(ip1 - istart) + 1);           // written on every path (see header comment)
+            u32 const c1 = matchE1 ? ld32(istart + matchE1 - 1) : ~(u32)w1;
+            // ---- decisions, reference order ----
+            if (((u32)w2 == rval) & (rep1 > 0)) {
                 ip0 = ip2; match0 = ip0 - rep1;
                 mLength = (ip0[-1] == match0[-1]); ip0 -= mLength; match0 -= mLength;
                 offcode = 1; mLength += 4;
-                table[hash1] = (TIdx)((u32)(ip1 - istart) + 1);
                 found = true; isRep = true; break;
             }
-            if (matchE && ld32(istart + matchE - 1) == ld32(ip0)) { table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
-            matchE = table[hash1];
-            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            if (matchE && c0 == (u32)w0) { found = true; break; }
+            matchE = matchE1;
+            hash0 = hash1; hash1 = ze_hash_w(w2, hlog, mls);
             ip0 = ip1; ip1 = ip2; ip2 = ip3;
-            cur0 = (u32)(ip0 - istart); table[hash0] = (TIdx)(cur0 + 1);
-            if (matchE && ld32(istart + matchE - 1) == ld32(ip0)) { if (step <= 4) table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
+            cur0 = (u32)(ip0 - istart);
+            if (matchE && c1 == (u32)w1) { if (step <= 4) table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
             matchE = table[hash1];
-            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            hash0 = hash1; hash1 = ze_hash_w(w3, hlog, mls);
             ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            w0 = w2; w1 = w3;
             if (ip2 >= nextStep) { step++; nextStep += 128; }
         } while (ip3 < ilimit);
         if (!found) break;
@@ -195,8 +227,9 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
         ze_store(o, (u32)(anchor - istart), (u32)(ip0 - anchor), offcode, mLength);
         ip0 += mLength; anchor = ip0;
         if (ip0 <= ilimit) {
-            table[ze_hash(istart + cur0 + 2, hlog, mls)] = (TIdx)(cur0 + 2 + 1);
-            table[ze_hash(ip0 - 2, hlog, mls)] = (TIdx)((u32)(ip0 - 2 - istart) + 1);
+            {   u64 const wa = ld64(istart + cur0 + 2), wb = ld64(ip0 - 2);
+                table[ze_hash_w(wa, hlog, mls)] = (TIdx)(cur0 + 2 + 1);
+                table[ze_hash_w(wb, hlog, mls)] = (TIdx)((u32)(ip0 - 2 - istart) + 1); }
             if (rep2 > 0) {
                 while ((ip0 <= ilimit) && (ld32(ip0) == ld32(ip0 - rep2))) {
                     u32 const rLength = ze_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
@@ -212,7 +245,8 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
     return (u32)(iend - anchor);
 }
 
-// ZSTD_compressBlock_doubleFast_noDict_generic (N/compress/zstd_double_fast.c:105-323)
+// ZSTD_compressBlock_doubleFast_noDict_generic (N/compress/zstd_double_fast.c:105-323), loads hoisted the
+// same way: the bytes of ip1, the repcode candidate and both table candidates are requested together.
 template <class TIdx>
 ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 hBitsS, u32 mls, TIdx* hashLong, TIdx* hashSmall) {
     const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
@@ -223,21 +257,28 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
     for (;;) {
         step = 1; nextStep = ip + 256; ip1 = ip + step;
         if (ip1 > ilimit) break;
-        hl0 = ze_hash(ip, hBitsL, 8); el0 = hashLong[hl0];
+        u64 w = ld64(ip);
+        hl0 = ze_hash_w(w, hBitsL, 8); el0 = hashLong[hl0];
         u32 kind = 0;     // 0 none, 1 repcode stored, 2 long match found, 3 short match -> search next long
         do {
-            u32 const hs0 = ze_hash(ip, hBitsS, mls);
+            // ---- issue everything this position may read ----
+            u64 const w1 = ld64(ip1);
+            u32 const rv = ld32(ip + 1 - off1);
+            u64 const cl = el0 ? ld64(istart + el0 - 1) : ~w;
+            u32 const hs0 = ze_hash_w(w, hBitsS, mls);
             u32 const es0 = hashSmall[hs0];
+            u32 const cs = es0 ? ld32(istart + es0 - 1) : ~(u32)w;
             curr = (u32)(ip - istart);
             hashLong[hl0] = (TIdx)(curr + 1); hashSmall[hs0] = (TIdx)(curr + 1);
-            if ((off1 > 0) & (ld32(ip + 1 - off1) == ld32(ip + 1))) {
+            // ---- decisions, reference order ----
+            if ((off1 > 0) & (rv == (u32)(w >> 8))) {
                 mLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
                 ip++;
                 ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), 1, mLength);
                 kind = 1; break;
             }
-            hl1 = ze_hash(ip1, hBitsL, 8);
-            if (el0 && ld64(istart + el0 - 1) == ld64(ip)) {
+            hl1 = ze_hash_w(w1, hBitsL, 8);
+            if (el0 && cl == w) {
                 matchl0 = istart + el0 - 1;
                 mLength = ze_count(ip + 8, matchl0 + 8, iend) + 8;
                 offset = (u32)(ip - matchl0);
@@ -245,10 +286,10 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
                 kind = 2; break;
             }
             el1 = hashLong[hl1];
-            if (es0 && ld32(istart + es0 - 1) == ld32(ip)) { matchs0 = istart + es0 - 1; kind = 3; break; }
+            if (es0 && cs == (u32)w) { matchs0 = istart + es0 - 1; kind = 3; break; }
             if (ip1 >= nextStep) { step++; nextStep += 256; }
             ip = ip1; ip1 += step;
-            hl0 = hl1; el0 = el1;
+            hl0 = hl1; el0 = el1; w = w1;
         } while (ip1 <= ilimit);
         if (kind == 0) break;
         if (kind == 3) {
@@ -269,16 +310,18 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
         ip += mLength; anchor = ip;
         if (ip <= ilimit) {
             {   u32 const ins = curr + 2;
-                hashLong[ze_hash(istart + ins, hBitsL, 8)] = (TIdx)(ins + 1);
-                hashLong[ze_hash(ip - 2, hBitsL, 8)] = (TIdx)((u32)(ip - 2 - istart) + 1);
-                hashSmall[ze_hash(istart + ins, hBitsS, mls)] = (TIdx)(ins + 1);
-                hashSmall[ze_hash(ip - 1, hBitsS, mls)] = (TIdx)((u32)(ip - 1 - istart) + 1);
+                u64 const wa = ld64(istart + ins), wb = ld64(ip - 2), wc = ld64(ip - 1);
+                hashLong[ze_hash_w(wa, hBitsL, 8)] = (TIdx)(ins + 1);
+                hashLong[ze_hash_w(wb, hBitsL, 8)] = (TIdx)((u32)(ip - 2 - istart) + 1);
+                hashSmall[ze_hash_w(wa, hBitsS, mls)] = (TIdx)(ins + 1);
+                hashSmall[ze_hash_w(wc, hBitsS, mls)] = (TIdx)((u32)(ip - 1 - istart) + 1);
             }
             while ((ip <= ilimit) && ((off2 > 0) & (ld32(ip) == ld32(ip - off2)))) {
                 u32 const rLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4;
                 u32 const t = off2; off2 = off1; off1 = t;
-                hashSmall[ze_hash(ip, hBitsS, mls)] = (TIdx)((u32)(ip - istart) + 1);
-                hashLong[ze_hash(ip, hBitsL, 8)] = (TIdx)((u32)(ip - istart) + 1);
+                {   u64 const wi = ld64(ip);
+                    hashSmall[ze_hash_w(wi, hBitsS, mls)] = (TIdx)((u32)(ip - istart) + 1);
+                    hashLong[ze_hash_w(wi, hBitsL, 8)] = (TIdx)((u32)(ip - istart) + 1); }
                 ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
                 ip += rLength; anchor = ip;
             }
@@ -578,7 +621,13 @@ ZJ_DEV u32 ze_huf_write_ctable(ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog) {
 // one Huffman stream, symbols last -> first (huf_compress.c:991-1118); runs on one lane
 ZJ_DEV void ze_huf_encode_stream(const ZEEntropy& e, u8* dst, const u8* lit, u32 n) {
     ZEBitW b; b.p = dst; b.acc = 0; b.n = 0;
-    for (u32 i = n; i > 0; i--) { u32 const s = lit[i - 1]; ze_bw_add(b, e.val[s], e.nbBits[s]); }
+    u32 i = n;
+    while (i >= 8) {                                   // 8 symbols per global load, last symbol first
+        u64 const w = ld64(lit + i - 8);
+        for (int k = 7; k >= 0; k--) { u32 const s = (u32)(w >> (8 * k)) & 0xFF; ze_bw_add(b, e.val[s], e.nbBits[s]); }
+        i -= 8;
+    }
+    for (; i > 0; i--) { u32 const s = lit[i - 1]; ze_bw_add(b, e.val[s], e.nbBits[s]); }
     ze_bw_close(b, dst);
 }
 
@@ -593,10 +642,13 @@ ZJ_DEV u32 ze_raw_literals(const G& g, u8* dst, const u8* lit, u32 n) {
 
 // ------------------------------------------------------------------ frame -------------------
 // `lds` = the overlay region (tables / ZEEntropy), ldsBytes its size.
+// Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
+struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
+
 template <class G, class TIdx>
-ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws) {
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre) {
     u8* const litBuf = ws + ZE_WS_LIT;
-    ZESeq* const seqs = (ZESeq*)(ws + ZE_WS_SEQ);
+    ZESeq* const seqs = pre ? pre->seqs : (ZESeq*)(ws + ZE_WS_SEQ);
     ZEEntropy& e = *(ZEEntropy*)lds;
 
     // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1, no checksum, no dictID) ----
@@ -626,22 +678,28 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
     if (srcSize >= 7) {                                                       // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
         u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
-        u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
-        {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
-            GRP_FOR(g, i, words) w[i] = 0; }
-        g.sync();
-        GRP_SERIAL(g) {
-            ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
-            TIdx* const t = (TIdx*)lds;
-            u32 const lastLL = (strategy == 1) ? ze_block_fast<TIdx>(o, src, srcSize, hlog, mls, t)
-                                               : ze_block_dfast<TIdx>(o, src, srcSize, hlog, clog, mls, t, t + (1u << hlog));
-            sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
+        if (pre) {
+            GRP_SERIAL(g) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
+        } else {
+            u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
+            {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
+                GRP_FOR(g, i, words) w[i] = 0; }
+            g.sync();
+            pf.mark(0);
+            GRP_SERIAL(g) {
+                ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+                TIdx* const t = (TIdx*)lds;
+                u32 const lastLL = (strategy == 1) ? ze_block_fast<TIdx>(o, src, srcSize, hlog, mls, t)
+                                                   : ze_block_dfast<TIdx>(o, src, srcSize, hlog, clog, mls, t, t + (1u << hlog));
+                sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
+            }
+            zj_mem_order();
         }
-        zj_mem_order();
         g.sync();
+        pf.mark(1);
         u32 const nbSeq = ZJ_UNI(sh.nbSeq), litSize = ZJ_UNI(sh.litSize), lastLL = ZJ_UNI(sh.lastLL);
         // ---- gather literals into HBM scratch + sequence codes (all lanes) ----
-        {   const u32* const litOff = (const u32*)(ws + ZE_WS_BODY);           // body scratch is free until the entropy stage
+        {   const u32* const litOff = pre ? pre->litOff : (const u32*)(ws + ZE_WS_BODY);   // body scratch is free until the entropy stage
             GRP_FOR(g, i, nbSeq) {
                 ZESeq s = seqs[i];
                 u32 const ll = s.ll, o = litOff[i];
@@ -667,6 +725,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             zj_mem_order();
             g.sync();
         }
+        pf.mark(2);
         // ---- literals section (ZSTD_compressLiterals, first block: no previous table) ----
         u32 const strat = strategy;
         {   u32 const n = litSize;
@@ -733,6 +792,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     sh.litMode = m;
                 }
                 g.sync();
+                pf.mark(3);
                 mode = ZJ_UNI(sh.litMode);
             }
             if (mode == 2) {
@@ -754,6 +814,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             zj_mem_order();
             g.sync();
         }
+        pf.mark(4);
         // ---- sequences section (zstd_compress.c:2940-3003) ----
         {   u32 const maxCSize = srcSize - ((srcSize >> 6) + 2);              // ZSTD_minGain
             u32 pos = ZJ_UNI(sh.litSecSize);
@@ -808,34 +869,51 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     g.sync();
                     pos += ZJ_UNI(sh.seqHdr[t]);
                 }
-                // ---- ZSTD_encodeSequences_body (lane 0; tANS state chains are sequential) ----
-                GRP_SERIAL(g) {
-                    body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2));
-                    ZEBitW b; ZEFseCS sML, sOF, sLL; u32 n = nbSeq - 1; u8* const bstart = body + pos;
-                    const ZEFseCT& ctLL = e.ct[0]; const ZEFseCT& ctOF = e.ct[1]; const ZEFseCT& ctML = e.ct[2];
-                    b.p = bstart; b.acc = 0; b.n = 0;
-                    ZESeq s = seqs[n];
-                    ze_fse_init2(sML, ctML, s.ml >> 24); ze_fse_init2(sOF, ctOF, s.off >> 24); ze_fse_init2(sLL, ctLL, s.ll >> 24);
-                    ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
-                    ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
-                    ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
-                    bool over = false;
-                    while (n-- > 0) {
-                        s = seqs[n];
-                        ze_fse_encode(b, sOF, ctOF, s.off >> 24); ze_fse_encode(b, sML, ctML, s.ml >> 24); ze_fse_encode(b, sLL, ctLL, s.ll >> 24);
-                        ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
-                        ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
-                        ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
-                        if ((u32)(b.p - body) >= maxCSize) { over = true; break; }       // block will be emitted raw anyway
+                pf.mark(5);
+                // ---- ZSTD_encodeSequences_body: tANS state chains are sequential (lane 0); the sequence
+                //      records are staged HBM -> LDS 64 at a time by all lanes so the chain never waits
+                //      on a global load ----
+                ZEBitW b; ZEFseCS sML, sOF, sLL; bool over = false;
+                u8* const bstart = body + pos;
+                b.p = bstart; b.acc = 0; b.n = 0; sML.value = sOF.value = sLL.value = 0;
+                for (u32 hi = nbSeq; hi > 0 && !over; ) {
+                    u32 const cnt = zj_min(64u, hi), lo = hi - cnt;
+                    GRP_FOR(g, k, cnt) e.stage[k] = seqs[lo + k];
+                    g.sync();
+                    GRP_SERIAL(g) {
+                        const ZEFseCT& ctLL = e.ct[0]; const ZEFseCT& ctOF = e.ct[1]; const ZEFseCT& ctML = e.ct[2];
+                        u32 k = cnt;
+                        if (hi == nbSeq) {                              // last sequence: state init (FSE_initCState2)
+                            body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2));
+                            ZESeq const s = e.stage[--k];
+                            ze_fse_init2(sML, ctML, s.ml >> 24); ze_fse_init2(sOF, ctOF, s.off >> 24); ze_fse_init2(sLL, ctLL, s.ll >> 24);
+                            ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
+                            ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
+                            ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                        }
+                        while (k-- > 0) {
+                            ZESeq const s = e.stage[k];
+                            ze_fse_encode(b, sOF, ctOF, s.off >> 24); ze_fse_encode(b, sML, ctML, s.ml >> 24); ze_fse_encode(b, sLL, ctLL, s.ll >> 24);
+                            ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
+                            ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
+                            ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                        }
+                        sh.tmp[3] = ((u32)(b.p - body) >= maxCSize) ? 1u : 0u;   // block will be emitted raw anyway
                     }
+                    g.sync();
+                    over = ZJ_UNI(sh.tmp[3]) != 0;
+                    hi = lo;
+                }
+                GRP_SERIAL(g) {
                     u32 bitSize = 0;
                     if (!over) {
-                        ze_bw_add(b, sML.value, ctML.tableLog); ze_bw_add(b, sOF.value, ctOF.tableLog); ze_bw_add(b, sLL.value, ctLL.tableLog);
+                        ze_bw_add(b, sML.value, e.ct[2].tableLog); ze_bw_add(b, sOF.value, e.ct[1].tableLog); ze_bw_add(b, sLL.value, e.ct[0].tableLog);
                         bitSize = ze_bw_close(b, bstart);
                     }
                     sh.tmp[2] = over ? 0xFFFFFFFFu : bitSize;
                 }
                 g.sync();
+                pf.mark(6);
                 {   u32 const bits = ZJ_UNI(sh.tmp[2]), lastCount = ZJ_UNI(sh.seqLastCount);
                     if (bits == 0xFFFFFFFFu) ok = false;
                     else { if (lastCount && (lastCount + bits) < 4) ok = false; pos += bits; } }
@@ -876,7 +954,26 @@ ZJ_HD u32 ze_lds_need(u32 level, u32 srcSize) {
 }
 
 template <class G>
-ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws) {
-    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws);
-    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws);
+ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr) {
+    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre);
+    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre);
+}
+
+// Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.
+#define ZE_FRAME_MAXSEQ(maxSrc) (((maxSrc) / 4u) + 16u)
+#define ZE_FRAME_STRIDE(maxSrc) (ZE_FRAME_MAXSEQ(maxSrc) * 20u)
+
+// One lane runs the reference's sequential parse for one frame; 64 frames per wavefront advance in
+// SIMT.  Hash tables (position+1, u16: only frames <= 64 KiB take this path) and the sequence records
+// live in HBM/L2 because 64 tables do not fit the LDS.  Output: records + meta {nbSeq, litSize, lastLL}.
+ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
+    ZEOut o; o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
+    u32 lastLL = srcSize;
+    if (srcSize >= 7) {
+        ZEParams const p = ze_params_of(level, srcSize);
+        u16* const t = (u16*)table;
+        lastLL = (p.strategy == 1) ? ze_block_fast<u16>(o, src, srcSize, p.hashLog, p.minMatch, t)
+                                   : ze_block_dfast<u16>(o, src, srcSize, p.hashLog, p.chainLog, p.minMatch, t, t + (1u << p.hashLog));
+    }
+    meta[0] = o.n; meta[1] = o.lit + lastLL; meta[2] = lastLL;
 }

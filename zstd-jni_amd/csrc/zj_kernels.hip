@@ -28,15 +28,17 @@ __device__ __forceinline__ u32 zj_next_index(u32* counter) {
 
 __global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
-                                                        u64* __restrict__ result, u32 n, u32* counter, u8* scratch) {
+                                                        u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof) {
     __shared__ ZDecShared sh;
+    ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
     for (;;) {
         u32 const i = zj_next_index(counter);      // wave-uniform (SGPR)
         if (i >= n) break;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit);
+        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf);
+        pf.mark(8);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
@@ -59,11 +61,30 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     else listB[atomicAdd(&counters[1], 1u)] = i;
 }
 
+// Lane-per-frame match finding (large batches): every lane owns one frame and runs the reference's
+// sequential parse; lanes pull list entries from a device counter until the list is drained, so a wave
+// stays full although frames differ 4x in cost.  Tables and sequence records of list entry k live at
+// tables + k*tableStride and fscratch + k*ZE_FRAME_STRIDE(maxSrc) in HBM.
+__global__ __launch_bounds__(64) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta) {
+    u32 const count = *countPtr;
+    for (;;) {
+        u32 const k = atomicAdd(workCounter, 1u);
+        if (k >= count) break;
+        u32 const i = list[k];
+        u64 const s0 = srcOff[i], s1 = srcOff[i + 1];
+        ze_match_lane(src + s0, (u32)(s1 - s0), level, tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc, meta + 3 * (size_t)k);
+    }
+}
+
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
-                                                        const u32* countPtr, u32* workCounter, u8* scratch) {
+                                                        const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
+                                                        u8* fscratch, u32 maxSrc, const u32* meta) {
     __shared__ ZEncShared sh;
+    ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
     u32 const count = ZJ_UNI(*countPtr);
@@ -73,7 +94,14 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
         u32 const i = ZJ_UNI(list[k]);
         u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
         u64 const cap = d1 - d0;
-        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws);
+        ZEPre pre; const ZEPre* prePtr = nullptr;
+        if (fscratch) {                                   // sequences were found by zj_enc_match_kernel
+            u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
+            pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta + 3 * (size_t)k;
+            prePtr = &pre;
+        }
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr);
+        pf.mark(7);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
@@ -116,7 +144,10 @@ struct DevState {
     u8* decScratch = nullptr;
     u8* encScratch = nullptr;
     // staging for the host-pointer entries
+    unsigned long long* prof = nullptr;    // 32 phase counters (16 decode + 16 encode) when ZJNI_PROFILE is set
     u32* encList = nullptr; size_t encListCap = 0;   // two index lists of encListCap entries each
+    u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
+    int matchGrid = 0;
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
@@ -145,17 +176,22 @@ DevState* get_state(int ordinal) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_decode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 8;
         d.decGrid = d.numCU * perCU;
+        if (const char* ov = getenv("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
         if (hipFuncSetAttribute((const void*)zj_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZJ_ENC_LDS_BIG) != hipSuccess) return nullptr;
         for (int lvl = 1; lvl <= 3; lvl++) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, enc_lds_pass0(lvl)) != hipSuccess || perCU < 1) perCU = 1;
             d.encGridLvl[lvl] = d.numCU * perCU;
+            if (const char* ov = getenv("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.encGridLvl[lvl] = d.numCU * v; }
             if (d.encGridLvl[lvl] > d.encGrid) d.encGrid = d.encGridLvl[lvl];
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZJ_ENC_LDS_BIG) != hipSuccess || perCU < 1) perCU = 1;
         d.encGridBig = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_enc_match_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
+        d.matchGrid = d.numCU * perCU;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
         if (hipMalloc(&d.decScratch, (size_t)d.decGrid * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
+        if (getenv("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
         d.ordinal = ordinal;
     }
     return &d;
@@ -206,6 +242,7 @@ void zjni_shutdown(void) {
         (void)hipSetDevice(d.ordinal);
         (void)hipFree(d.counters); (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
         if (d.encList) (void)hipFree(d.encList);
+        if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
@@ -259,6 +296,14 @@ unsigned long long zjni_getFrameContentSize(const void* srcv, size_t srcSize) {
     return ld64(p + pos);
 }
 
+/* debugging/profiling aid (not in the public header): copies the 32 phase-cycle counters and clears them */
+int zjni_debug_read_profile(unsigned long long* out32) {
+    DevState* d = cur_state();
+    if (!d || !d->prof) return -1;
+    if (hipMemcpy(out32, d->prof, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return hipMemset(d->prof, 0, 32 * 8) == hipSuccess ? 0 : -1;
+}
+
 int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* encodeLds) {
     DevState* d = cur_state();
     if (decodeLds) *decodeLds = (int)sizeof(ZDecShared);
@@ -279,7 +324,7 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
     if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     u32 const grid = (u32)(n < (size_t)d->decGrid ? n : (size_t)d->decGrid);
     hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch);
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
@@ -303,12 +348,36 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
     u32 const ldsA = (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
                        (u32)n, (u32)level, ldsA, ctr, listA, listB);
+    // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
+    // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
+    size_t splitMin = 4096;
+    if (const char* ov = getenv("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
+    u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
+    if (n >= splitMin) {
+        u32 const tableStride = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
+        size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12;
+        size_t const need = tablesBytes + fsBytes + metaBytes + 256;
+        if (d->splitBufCap < need) {
+            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
+            if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+            d->splitBufCap = need;
+        }
+        u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
+        if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipMemsetAsync(d->counters + 24, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        u32 const waves = (u32)((n + 63) / 64);
+        u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
+        hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+                           (const u32*)listA, (const u32*)ctr, d->counters + 24, tables, tableStride, fscratch, maxSrc, meta);
+    }
     u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch);
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                       fscratch, maxSrc, (const u32*)meta);
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch);
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
