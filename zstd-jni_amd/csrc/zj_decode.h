@@ -205,33 +205,44 @@ ZJ_DEV u32 zd_bits(const u8* win, u32 winLo, i32 p, u32 n) {   // n <= 32 bits a
 }
 
 // Decode up to ZD_SEQ_BATCH sequences into sh.sLit/sMl/sOff.  Runs on lane 0 only.
-// N/decompress/zstd_decompress_block.c:1229-1347.
+// N/decompress/zstd_decompress_block.c:1229-1347.  The chain that bounds this kernel is
+// state -> cell (LDS) -> bit counts -> next state; everything else is kept off it: the 64 bits below the
+// read position are fetched (two 8-byte LDS reads whose address only depends on the previous sequence)
+// together with the three cells, all fields are then cut from that register top-down, and validity is
+// accumulated and tested once per batch.
 ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
     u32 const nbSeq = sh.nbSeq, winLo = sh.winLo;
-    u32 n = 0, litTotal = 0, outTotal = 0, err = 0;
+    u32 n = 0, litTotal = 0, outTotal = 0, err = 0, bad = 0;
     u32 const litSize = sh.litSize;
     u32 const seqStartByte = (u32)p.S0 >> 3;
     sh.bLitStart = p.lpos; sh.bOutStart = p.opos;
     while (n < ZD_SEQ_BATCH && p.i < nbSeq) {
-        // window must cover the 96 bits below A unless it already reaches the stream start
-        if (winLo > seqStartByte && ((p.A - 96) >> 3) < (i32)winLo) break;
+        // window must cover the 136 bits below A unless it already reaches the stream start
+        if (winLo > seqStartByte && ((p.A - 136) >> 3) < (i32)winLo) break;
+        u32 const e = ((u32)p.A + 7) >> 3, shf = 8 * e - (u32)p.A;
+        bool const wide = e >= winLo + 16;                       // false only within 16 bytes of the stream start
+        u32 const wbase = wide ? (e - 16) - winLo : 0;
+        u64 const wlo = ld64(sh.win + wbase), whi = ld64(sh.win + wbase + 8);
         u32 const cl = sh.ll[p.sLL], co = sh.of[p.sOF], cm = sh.ml[p.sML];
+        u64 v = shf ? ((whi << shf) | (wlo >> (64 - shf))) : whi;         // bits [A-64, A), MSB = bit A-1
         u32 const ofx = ZD_CELL_EXTRA(co), mlx = ZD_CELL_EXTRA(cm), llx = ZD_CELL_EXTRA(cl);
         bool const last = (p.i + 1 == nbSeq);
         u32 const nl = last ? 0 : ZD_CELL_NB(cl), nm = last ? 0 : ZD_CELL_NB(cm), no = last ? 0 : ZD_CELL_NB(co);
         u32 const T = ofx + mlx + llx + nl + nm + no;
         u32 ofv, mlv, llv, vl, vm, vo;
-        p.A -= (i32)T;
-        if (p.A < p.S0) { err = ZJ_E_CORRUPTION; break; }
-        if (T <= 56) {
-            u64 w = ld64(sh.win + ((u32)p.A >> 3) - winLo) >> ((u32)p.A & 7);
-            vo = (u32)w & ((1u << no) - 1); w >>= no;
-            vm = (u32)w & ((1u << nm) - 1); w >>= nm;
-            vl = (u32)w & ((1u << nl) - 1); w >>= nl;
-            llv = (u32)w & ((1u << llx) - 1); w >>= llx;
-            mlv = (u32)w & ((1u << mlx) - 1); w >>= mlx;
-            ofv = (u32)w & (u32)(((u64)1 << ofx) - 1);
+        if (p.A - (i32)T < p.S0) { err = ZJ_E_CORRUPTION; break; }
+        if (T <= 56 && wide) {
+#define ZD_TAKE(nb) ((u32)((v >> 1) >> (63 - (nb))))
+            ofv = ZD_TAKE(ofx); v <<= ofx;
+            mlv = ZD_TAKE(mlx); v <<= mlx;
+            llv = ZD_TAKE(llx); v <<= llx;
+            vl = ZD_TAKE(nl); v <<= nl;
+            vm = ZD_TAKE(nm); v <<= nm;
+            vo = ZD_TAKE(no);
+#undef ZD_TAKE
+            p.A -= (i32)T;
         } else {
+            p.A -= (i32)T;
             i32 q = p.A;
             vo = zd_bits(sh.win, winLo, q, no); q += (i32)no;
             vm = zd_bits(sh.win, winLo, q, nm); q += (i32)nm;
@@ -240,6 +251,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
             mlv = zd_bits(sh.win, winLo, q, mlx); q += (i32)mlx;
             ofv = zd_bits(sh.win, winLo, q, ofx);
         }
+        if (!last) { p.sLL = ZD_CELL_NEXT(cl) + vl; p.sML = ZD_CELL_NEXT(cm) + vm; p.sOF = ZD_CELL_NEXT(co) + vo; }
         u32 const llen = sh.llBase[ZD_CELL_SYM(cl)] + llv;
         u32 const mlen = sh.mlBase[ZD_CELL_SYM(cm)] + mlv;
         u32 offset;
@@ -258,14 +270,16 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
                 p.rep1 = p.rep0; p.rep0 = t; offset = t;
             }
         }
-        if (!last) { p.sLL = ZD_CELL_NEXT(cl) + vl; p.sML = ZD_CELL_NEXT(cm) + vm; p.sOF = ZD_CELL_NEXT(co) + vo; }
-        if (llen > litSize - p.lpos) { err = ZJ_E_CORRUPTION; break; }
-        if ((u64)p.opos + llen + mlen > dstCap) { err = ZJ_E_DSTSIZE_TOO_SMALL; break; }
-        if (offset > p.opos + llen) { err = ZJ_E_CORRUPTION; break; }
+        // validity is accumulated (64-bit so nothing wraps) and tested after the batch; nothing is executed on a bad batch
+        bad |= (llen > litSize - p.lpos) ? 1u : 0u;
+        bad |= ((u64)p.opos + llen + mlen > dstCap) ? 2u : 0u;
+        bad |= ((u64)offset > (u64)p.opos + llen) ? 1u : 0u;
+        if (bad) break;
         sh.sLit[n] = llen; sh.sMl[n] = mlen; sh.sOff[n] = offset;
         p.lpos += llen; p.opos += llen + mlen; litTotal += llen; outTotal += llen + mlen;
         n++; p.i++;
     }
+    if (!err && bad) err = (bad & 1u) ? ZJ_E_CORRUPTION : ZJ_E_DSTSIZE_TOO_SMALL;
     if (!err && p.i == nbSeq && p.A != p.S0) err = ZJ_E_CORRUPTION;
     sh.bN = n; sh.bLitTotal = litTotal; sh.bOutTotal = outTotal;
     sh.seqDone = (p.i == nbSeq);
@@ -275,6 +289,96 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         u32 lo = hi > ZD_SWIN ? hi - ZD_SWIN : 0;
         if (lo < seqStartByte) lo = seqStartByte;
         sh.winLo = lo; }
+}
+
+// Execute one batch of n <= 64 decoded sequences (N/decompress/zstd_decompress_block.c:1001-1096).
+// GPU: one sequence per lane.  Output positions come from a wave prefix sum; all literal runs are copied
+// first (they only read the literal buffer); a match may read bytes that an earlier match of the same batch
+// produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
+// range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
+template <class G>
+ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0) {
+#if ZJ_ON_GPU
+    u32 const k = g.lane();
+    bool const valid = k < n;
+    u32 const ll = valid ? sh.sLit[k] : 0, ml = valid ? sh.sMl[k] : 0, off = valid ? sh.sOff[k] : 1;
+    u32 sl = ll, so = ll + ml;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 const a = __shfl_up(sl, d, 64), b = __shfl_up(so, d, 64);
+        if ((int)k >= d) { sl += a; so += b; }
+    }
+    u32 const lp = lp0 + sl - ll;                 // literal source
+    u32 const op = op0 + so - ll - ml;            // output position of this sequence's literals
+    u32 const mp = op + ll;                       // match destination
+    // ---- literals: short runs per lane, long runs by the whole wave ----
+    if (ll <= 32) {
+        u32 j = 0;
+        for (; j + 8 <= ll; j += 8) st64(out + op + j, ld64(lit + lp + j));
+        for (; j < ll; j++) out[op + j] = lit[lp + j];
+    }
+    {   u64 m = __ballot(ll > 32);
+        while (m) {
+            u32 const q = (u32)__builtin_ctzll(m); m &= m - 1;
+            u32 const qll = ZJ_UNI(__shfl(ll, q, 64)), qlp = ZJ_UNI(__shfl(lp, q, 64)), qop = ZJ_UNI(__shfl(op, q, 64));
+            grp_copy_wide(g, out + qop, lit + qlp, qll);
+        }
+    }
+    zj_mem_order();
+    // ---- matches: dependency rounds ----
+    sh.sLit[k] = mp; sh.sMl[k] = mp + ml;          // reuse as mStart / mEnd arrays (LDS)
+    g.sync();
+    u32 const ms = mp - off;                      // first source byte
+    u32 const me = zj_min(ms + ml, mp);           // source bytes at/after mp are produced by this match itself
+    // earlier lanes whose match output [mStart_j, mEnd_j) intersects [ms, me): a contiguous lane range
+    u64 dep = 0;
+    if (valid && ml) {
+        u32 lo = 0, hi = k;                       // first j in [0,k) with mEnd_j > ms
+        while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sMl[mid] > ms) hi = mid; else lo = mid + 1; }
+        u32 const jlo = lo;
+        lo = jlo; hi = k;                         // first j in [jlo,k) with mStart_j >= me
+        while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sLit[mid] >= me) hi = mid; else lo = mid + 1; }
+        u32 const jhi = lo;                       // deps = [jlo, jhi)
+        if (jhi > jlo) dep = ((jhi >= 64 ? ~0ull : ((1ull << jhi) - 1)) & ~((1ull << jlo) - 1));
+    }
+    u64 pending = __ballot(valid && ml > 0);
+    while (pending) {
+        bool const mine = (pending >> k) & 1;
+        bool const ready = mine && ((dep & pending) == 0);
+        u64 const readyMask = __ballot(ready);
+        // long matches: whole wave, one at a time (offset >= length or periodic pattern)
+        u64 big = __ballot(ready && ml > 64);
+        while (big) {
+            u32 const q = (u32)__builtin_ctzll(big); big &= big - 1;
+            u32 const qml = ZJ_UNI(__shfl(ml, q, 64)), qoff = ZJ_UNI(__shfl(off, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64));
+            const u8* const m = out + qmp - qoff;
+            if (qoff >= qml) grp_copy_wide(g, out + qmp, m, qml);
+            else if (qoff >= 64) { for (u32 base = 0; base < qml; base += 64) { u32 const j = base + k; if (j < qml) out[qmp + j] = m[j]; zj_mem_order(); } }
+            else { GRP_FOR(g, j, qml) out[qmp + j] = m[j % qoff]; }
+            zj_mem_order();
+        }
+        if (ready && ml <= 64) {
+            u8* const d = out + mp; const u8* const m = d - off;
+            u32 j = 0;
+            if (off >= 8) { for (; j + 8 <= ml; j += 8) st64(d + j, ld64(m + j)); }
+            for (; j < ml; j++) d[j] = m[j];
+        }
+        zj_mem_order();
+        pending &= ~readyMask;
+    }
+    g.sync();
+#else
+    u32 lp = lp0, op = op0;
+    for (u32 k = 0; k < n; k++) {
+        u32 const ll = sh.sLit[k], ml = sh.sMl[k], off = sh.sOff[k];
+        for (u32 j = 0; j < ll; j++) out[op + j] = lit[lp + j];
+        lp += ll; op += ll;
+        const u8* const m = out + op - off;
+        for (u32 j = 0; j < ml; j++) out[op + j] = m[j];
+        op += ml;
+    }
+    (void)g;
+#endif
 }
 
 // ------------------------------------------------------------------ Huffman -----------------
@@ -615,20 +719,10 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             if (ZJ_UNI(sh.err)) return opos;
             // ---- execute the batch: N/decompress/zstd_decompress_block.c:1001-1096 ----
             {   u32 const n = ZJ_UNI(sh.bN);
-                u32 lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
-                for (u32 k = 0; k < n; k++) {
-                    u32 const ll = ZJ_UNI(sh.sLit[k]), ml = ZJ_UNI(sh.sMl[k]), off = ZJ_UNI(sh.sOff[k]);
-                    GRP_FOR(g, j, ll) out[op + j] = lit[lp + j];
-                    lp += ll; op += ll;
-                    zj_mem_order();
-                    {   const u8* const m = out + op - off;
-                        if (off >= ml) { GRP_FOR(g, j, ml) out[op + j] = m[j]; }
-                        else { GRP_FOR(g, j, ml) out[op + j] = m[j % off]; }   // overlapped match = periodic pattern
-                    }
-                    op += ml;
-                    zj_mem_order();
-                }
-                litUsed = lp; opos = op;
+                u32 const lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
+                u32 const lt = ZJ_UNI(sh.bLitTotal), ot = ZJ_UNI(sh.bOutTotal);
+                zd_execute_batch(g, sh, out, lit, n, lp, op);
+                litUsed = lp + lt; opos = op + ot;
             }
             pf.mark(5);
             if (ZJ_UNI(sh.seqDone)) break;

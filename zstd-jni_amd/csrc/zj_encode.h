@@ -66,6 +66,7 @@ struct ZEncShared {                // uniforms, outside the overlay
     u32 hufLog, hufMaxSV, hufHdr, litMode, litStreams;
     u32 strBytes[4], strOff[4];
     u32 seqType[3], seqHdr[3], seqLastCount;
+    u32 tstate[3];                 // tANS encoder states LL, OF, ML carried across 64-sequence batches
     u32 tmp[8];
 };
 
@@ -631,6 +632,102 @@ ZJ_DEV void ze_huf_encode_stream(const ZEEntropy& e, u8* dst, const u8* lit, u32
     ze_bw_close(b, dst);
 }
 
+
+// ------------------------------------------------------------------ parallel bit packing -----
+// A forward bitstream (BIT_CStream_t layout) assembled by many lanes: every lane ORs its bits into a
+// zero-initialised LDS window at its own bit offset (offsets come from a prefix sum of bit counts), then
+// the wave flushes the completed 32-bit words to HBM and carries the partial word over.
+#if !ZJ_ON_GPU
+static inline u32 atomicOr(u32* p, u32 v) { u32 const o = *p; *p = o | v; return o; }   // lane-serial build
+#endif
+struct ZEStageBits { u32* w; u8* dst; u32 flushedWords; u32 carryBits; };   // wave-uniform
+
+ZJ_DEV void ze_or_bits(u32* w, u32 bitpos, u64 lo, u64 hi, u32 nbits) {    // OR nbits (<=128) of {hi:lo} at bitpos
+    u32 idx = bitpos >> 5; u32 const sh = bitpos & 31;
+    // shift the 128-bit value left by sh (<32) into 160 bits = 5 words
+    u32 const v0 = (u32)lo, v1 = (u32)(lo >> 32), v2 = (u32)hi, v3 = (u32)(hi >> 32);
+    u32 const o0 = v0 << sh;
+    u32 const o1 = sh ? ((v1 << sh) | (v0 >> (32 - sh))) : v1;
+    u32 const o2 = sh ? ((v2 << sh) | (v1 >> (32 - sh))) : v2;
+    u32 const o3 = sh ? ((v3 << sh) | (v2 >> (32 - sh))) : v3;
+    u32 const o4 = sh ? (v3 >> (32 - sh)) : 0;
+    u32 const words = (sh + nbits + 31) >> 5;
+    if (words > 0 && o0) atomicOr(&w[idx], o0);
+    if (words > 1 && o1) atomicOr(&w[idx + 1], o1);
+    if (words > 2 && o2) atomicOr(&w[idx + 2], o2);
+    if (words > 3 && o3) atomicOr(&w[idx + 3], o3);
+    if (words > 4 && o4) atomicOr(&w[idx + 4], o4);
+}
+
+// flush the words completed by `addBits` new bits; keeps the partial word as the new word 0
+template <class G>
+ZJ_DEV void ze_stage_flush(const G& g, ZEncShared& sh, ZEStageBits& st, u32 addBits) {
+    u32 const total = st.carryBits + addBits, nW = total >> 5;
+    g.sync();
+    GRP_FOR(g, i, nW) st32(st.dst + 4 * (st.flushedWords + i), st.w[i]);
+    GRP_SERIAL(g) { sh.tmp[4] = st.w[nW]; }
+    g.sync();
+    u32 const carry = ZJ_UNI(sh.tmp[4]);
+    GRP_FOR(g, i, nW + 1) st.w[i] = (i == 0) ? carry : 0u;
+    g.sync();
+    st.flushedWords += nW; st.carryBits = total & 31;
+}
+// final partial bytes; returns the stream size in bytes
+template <class G>
+ZJ_DEV u32 ze_stage_finish(const G& g, ZEStageBits& st) {
+    u32 const nbytes = (st.carryBits + 7) >> 3;
+    g.sync();
+    GRP_FOR(g, i, nbytes) st.dst[4 * st.flushedWords + i] = ((const u8*)st.w)[i];
+    g.sync();
+    return 4 * st.flushedWords + nbytes;
+}
+
+// One Huffman stream (huf_compress.c:991-1118: symbols last -> first, then the end mark) packed by the
+// whole wave: lane l takes 32 symbols, a prefix sum of chunk bit lengths gives its offset.
+// `codes` = e.val | e.nbBits << 16 per symbol (LDS), `stage` = >= 1024 zeroable LDS words.
+#define ZE_HUF_CHUNK 32u
+template <class G>
+ZJ_DEV u32 ze_huf_encode_wave(const G& g, ZEncShared& sh, const u32* codes, u32* stage, u32* lb, u8* dst, const u8* lit, u32 n) {
+    ZEStageBits st; st.w = stage; st.dst = dst; st.flushedWords = 0; st.carryBits = 0;
+    GRP_FOR(g, i, 1024) stage[i] = 0;
+    g.sync();
+    u32 const R = 64u * ZE_HUF_CHUNK;
+    for (u32 hi = n; hi > 0; ) {
+        u32 const take = zj_min(R, hi);
+        // pass 1: bit length of every lane's chunk (lane 0 = the last symbols = lowest bit positions)
+        GRP_FOR(g, l, 64) {
+            u32 const end = hi > l * ZE_HUF_CHUNK ? hi - l * ZE_HUF_CHUNK : 0, beg = hi > (l + 1) * ZE_HUF_CHUNK ? hi - (l + 1) * ZE_HUF_CHUNK : 0;
+            u32 bits = 0;
+            for (u32 i = beg; i < end; i++) bits += codes[lit[i]] >> 16;
+            lb[l] = bits;
+        }
+        g.sync();
+        grp_scan_incl(g, lb, 64);
+#if !ZJ_ON_GPU
+        g.sync();
+#endif
+        // pass 2: emit
+        GRP_FOR(g, l, 64) {
+            u32 const end = hi > l * ZE_HUF_CHUNK ? hi - l * ZE_HUF_CHUNK : 0, beg = hi > (l + 1) * ZE_HUF_CHUNK ? hi - (l + 1) * ZE_HUF_CHUNK : 0;
+            u32 pos = st.carryBits + (l ? lb[l - 1] : 0);
+            u32 idx = pos >> 5, nb = pos & 31; u64 acc = 0;
+            for (u32 i = end; i > beg; i--) {
+                u32 const c = codes[lit[i - 1]];
+                acc |= (u64)(c & 0xFFFF) << nb; nb += c >> 16;
+                if (nb >= 32) { atomicOr(&stage[idx++], (u32)acc); acc >>= 32; nb -= 32; }
+            }
+            if (nb && (u32)acc) atomicOr(&stage[idx], (u32)acc);
+        }
+        g.sync();
+        u32 const roundBits = ZJ_UNI(lb[63]);
+        ze_stage_flush(g, sh, st, roundBits);
+        hi -= take;
+    }
+    GRP_SERIAL(g) { atomicOr(&stage[st.carryBits >> 5], 1u << (st.carryBits & 31)); }    // end mark
+    st.carryBits += 1;
+    return ze_stage_finish(g, st);
+}
+
 // raw / rle literal sections (zstd_compress_literals.c:39-127)
 template <class G>
 ZJ_DEV u32 ze_raw_literals(const G& g, u8* dst, const u8* lit, u32 n) {
@@ -797,9 +894,12 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             }
             if (mode == 2) {
                 u32 const streams = single ? 1u : 4u;
-                GRP_FOR(g, t, streams) {
+                u32* const codes = e.count;                                    // histogram is dead: code | nbBits << 16 per symbol
+                GRP_FOR(g, s, 256) codes[s] = (u32)e.val[s] | ((u32)e.nbBits[s] << 16);
+                g.sync();
+                for (u32 t = 0; t < streams; t++) {
                     u32 const cnt = single ? n : (t < 3 ? seg : n - 3 * seg);
-                    ze_huf_encode_stream(e, body + lhSize + sh.strOff[t], litBuf + t * seg, cnt);
+                    ze_huf_encode_wave(g, sh, codes, &e.hist[0][0], e.scount, body + lhSize + ZJ_UNI(sh.strOff[t]), litBuf + t * seg, cnt);
                 }
             } else if (mode == 1) {
                 GRP_SERIAL(g) {
@@ -870,48 +970,98 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                     pos += ZJ_UNI(sh.seqHdr[t]);
                 }
                 pf.mark(5);
-                // ---- ZSTD_encodeSequences_body: tANS state chains are sequential (lane 0); the sequence
-                //      records are staged HBM -> LDS 64 at a time by all lanes so the chain never waits
-                //      on a global load ----
-                ZEBitW b; ZEFseCS sML, sOF, sLL; bool over = false;
-                u8* const bstart = body + pos;
-                b.p = bstart; b.acc = 0; b.n = 0; sML.value = sOF.value = sLL.value = 0;
+                // ---- ZSTD_encodeSequences_body (zstd_compress_sequences.c:291-382), restructured for the wave:
+                //      per 64 sequences (last -> first) the records are staged into LDS, the per-symbol
+                //      transforms are gathered by all lanes, the three tANS state chains (LL, OF, ML) advance on
+                //      three lanes (one dependent LDS read per step), and every lane then ORs its sequence's
+                //      bits {OF, ML, LL state bits; LL, ML, OF extra bits} at the prefix-summed bit offset ----
+                bool over = false;
+                ZEStageBits st; st.w = &e.hist[0][0]; st.dst = body + pos; st.flushedWords = 0; st.carryBits = 0;
+                u32* const dn = (u32*)&e.node[0];                  // [3][64] deltaNbBits of each sequence's symbol
+                i32* const df = (i32*)(dn + 192);                  // [3][64] deltaFindState
+                u32* const ob = (u32*)(df + 192);                  // [3][64] state bits out: value | nbBits << 16
+                u32* const lb = e.scount;                          // [64] bit counts (reversed order) -> prefix sums
+                GRP_FOR(g, i, 1024) st.w[i] = 0;
+                GRP_SERIAL(g) { body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2)); }
+                g.sync();
                 for (u32 hi = nbSeq; hi > 0 && !over; ) {
                     u32 const cnt = zj_min(64u, hi), lo = hi - cnt;
-                    GRP_FOR(g, k, cnt) e.stage[k] = seqs[lo + k];
+                    bool const firstBatch = (hi == nbSeq);
+                    GRP_FOR(g, k, cnt) {
+                        ZESeq const q = seqs[lo + k]; e.stage[k] = q;
+                        u32 const cLL = q.ll >> 24, cOF = q.off >> 24, cML = q.ml >> 24;
+                        dn[k] = e.ct[0].deltaNbBits[cLL]; df[k] = e.ct[0].deltaFind[cLL];
+                        dn[64 + k] = e.ct[1].deltaNbBits[cOF]; df[64 + k] = e.ct[1].deltaFind[cOF];
+                        dn[128 + k] = e.ct[2].deltaNbBits[cML]; df[128 + k] = e.ct[2].deltaFind[cML];
+                    }
                     g.sync();
-                    GRP_SERIAL(g) {
-                        const ZEFseCT& ctLL = e.ct[0]; const ZEFseCT& ctOF = e.ct[1]; const ZEFseCT& ctML = e.ct[2];
+                    GRP_FOR(g, t, 3) {                             // the three state chains
+                        const ZEFseCT& ct = e.ct[t];
+                        u32 state = sh.tstate[t];
                         u32 k = cnt;
-                        if (hi == nbSeq) {                              // last sequence: state init (FSE_initCState2)
-                            body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2));
-                            ZESeq const s = e.stage[--k];
-                            ze_fse_init2(sML, ctML, s.ml >> 24); ze_fse_init2(sOF, ctOF, s.off >> 24); ze_fse_init2(sLL, ctLL, s.ll >> 24);
-                            ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
-                            ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
-                            ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                        if (firstBatch) {                          // FSE_initCState2 with the last sequence's symbol
+                            k--;
+                            u32 const d = dn[64 * t + k];
+                            u32 const nbBitsOut = (d + (1u << 15)) >> 16;
+                            state = (nbBitsOut << 16) - d;
+                            state = ct.state[(i32)(state >> nbBitsOut) + df[64 * t + k]];
+                            ob[64 * t + k] = 0;
                         }
                         while (k-- > 0) {
-                            ZESeq const s = e.stage[k];
-                            ze_fse_encode(b, sOF, ctOF, s.off >> 24); ze_fse_encode(b, sML, ctML, s.ml >> 24); ze_fse_encode(b, sLL, ctLL, s.ll >> 24);
-                            ze_bw_add(b, ZE_LOW24(s.ll), ze_k_ll_bits[s.ll >> 24]);
-                            ze_bw_add(b, ZE_LOW24(s.ml) - 3, ze_k_ml_bits[s.ml >> 24]);
-                            ze_bw_add(b, ZE_LOW24(s.off), s.off >> 24);
+                            u32 const nbBitsOut = (state + dn[64 * t + k]) >> 16;
+                            ob[64 * t + k] = (state & ((1u << nbBitsOut) - 1)) | (nbBitsOut << 16);
+                            state = ct.state[(i32)(state >> nbBitsOut) + df[64 * t + k]];
                         }
-                        sh.tmp[3] = ((u32)(b.p - body) >= maxCSize) ? 1u : 0u;   // block will be emitted raw anyway
+                        sh.tstate[t] = state;
                     }
                     g.sync();
-                    over = ZJ_UNI(sh.tmp[3]) != 0;
+                    GRP_FOR(g, k, cnt) {                           // bit count per sequence, in emission order r = cnt-1-k
+                        ZESeq const q = e.stage[k];
+                        u32 const c = (ob[k] >> 16) + (ob[64 + k] >> 16) + (ob[128 + k] >> 16)
+                                    + ze_k_ll_bits[q.ll >> 24] + ze_k_ml_bits[q.ml >> 24] + (q.off >> 24);
+                        lb[cnt - 1 - k] = c;
+                    }
+                    GRP_FOR(g, k, 64 - cnt) lb[cnt + k] = 0;
+                    g.sync();
+                    grp_scan_incl(g, lb, 64);
+#if !ZJ_ON_GPU
+                    g.sync();
+#endif
+                    GRP_FOR(g, k, cnt) {
+                        ZESeq const q = e.stage[k];
+                        u32 const r = cnt - 1 - k;
+                        u32 const bitpos = st.carryBits + (r ? lb[r - 1] : 0);
+                        u64 lo64 = 0, hi64 = 0; u32 nb = 0;
+#define ZE_PUT(val, bits) do { u32 const b_ = (bits); u64 const v_ = (u64)(val) & (((u64)1 << b_) - 1); if (b_) { if (nb < 64) { lo64 |= v_ << nb; if (nb + b_ > 64) hi64 |= v_ >> (64 - nb); } else hi64 |= v_ << (nb - 64); nb += b_; } } while (0)
+                        ZE_PUT(ob[64 + k] & 0xFFFF, ob[64 + k] >> 16);         // OF state
+                        ZE_PUT(ob[128 + k] & 0xFFFF, ob[128 + k] >> 16);       // ML state
+                        ZE_PUT(ob[k] & 0xFFFF, ob[k] >> 16);                   // LL state
+                        ZE_PUT(ZE_LOW24(q.ll), ze_k_ll_bits[q.ll >> 24]);
+                        ZE_PUT(ZE_LOW24(q.ml) - 3, ze_k_ml_bits[q.ml >> 24]);
+                        ZE_PUT(ZE_LOW24(q.off), q.off >> 24);
+#undef ZE_PUT
+                        ze_or_bits(st.w, bitpos, lo64, hi64, nb);
+                    }
+                    g.sync();
+                    u32 const batchBits = ZJ_UNI(lb[63]);
+                    ze_stage_flush(g, sh, st, batchBits);
+                    over = (pos + 4 * st.flushedWords) >= maxCSize;             // block will be emitted raw anyway
                     hi = lo;
                 }
-                GRP_SERIAL(g) {
-                    u32 bitSize = 0;
-                    if (!over) {
-                        ze_bw_add(b, sML.value, e.ct[2].tableLog); ze_bw_add(b, sOF.value, e.ct[1].tableLog); ze_bw_add(b, sLL.value, e.ct[0].tableLog);
-                        bitSize = ze_bw_close(b, bstart);
+                if (!over) {                                       // FSE_flushCState x3 (ML, OF, LL) + end mark
+                    GRP_SERIAL(g) {
+                        u32 p0 = st.carryBits;
+                        ze_or_bits(st.w, p0, sh.tstate[2] & ((1u << e.ct[2].tableLog) - 1), 0, e.ct[2].tableLog); p0 += e.ct[2].tableLog;
+                        ze_or_bits(st.w, p0, sh.tstate[1] & ((1u << e.ct[1].tableLog) - 1), 0, e.ct[1].tableLog); p0 += e.ct[1].tableLog;
+                        ze_or_bits(st.w, p0, sh.tstate[0] & ((1u << e.ct[0].tableLog) - 1), 0, e.ct[0].tableLog); p0 += e.ct[0].tableLog;
+                        ze_or_bits(st.w, p0, 1, 0, 1);
+                        sh.tmp[5] = p0 + 1 - st.carryBits;
                     }
-                    sh.tmp[2] = over ? 0xFFFFFFFFu : bitSize;
-                }
+                    g.sync();
+                    ze_stage_flush(g, sh, st, ZJ_UNI(sh.tmp[5]));
+                    u32 const bitSize = ze_stage_finish(g, st);
+                    GRP_SERIAL(g) { sh.tmp[2] = bitSize; }
+                } else { GRP_SERIAL(g) { sh.tmp[2] = 0xFFFFFFFFu; } }
                 g.sync();
                 pf.mark(6);
                 {   u32 const bits = ZJ_UNI(sh.tmp[2]), lastCount = ZJ_UNI(sh.seqLastCount);

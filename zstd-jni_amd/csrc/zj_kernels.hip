@@ -26,7 +26,7 @@ __device__ __forceinline__ u32 zj_next_index(u32* counter) {
     return (u32)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-__global__ __launch_bounds__(64) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
+__global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof) {
     __shared__ ZDecShared sh;
@@ -370,8 +370,11 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
         hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
                            (const u32*)listA, (const u32*)ctr, d->counters + 24, tables, tableStride, fscratch, maxSrc, meta);
     }
-    u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+    // with the sequences already found the kernel only needs the entropy-stage LDS (more workgroups per CU)
+    u32 const ldsRun = fscratch ? (u32)sizeof(ZEEntropy) : ldsA;
+    int const gridCap = fscratch ? d->encGridLvl[1] : d->encGridLvl[level];
+    u32 const gridA = (u32)(n < (size_t)gridCap ? n : (size_t)gridCap);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
                        fscratch, maxSrc, (const u32*)meta);
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
