@@ -35,7 +35,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
-    u8* table = (u8*)calloc(1, 65536 * 2);
+    u8* table = (u8*)calloc(1, 65536 * 4);
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(65536u));
     u32 meta[3];
     ze_match_lane(src, srcSize, level, table, fs, 65536u, meta);

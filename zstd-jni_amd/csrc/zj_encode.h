@@ -168,6 +168,17 @@ ZJ_DEV u32 ze_hash_w(u64 w, u32 hBits, u32 mls) {
     }
 }
 
+// Table entry codecs.  Entries hold position+1 (0 = empty).  The HBM-resident tables of the
+// lane-per-frame path additionally carry 15 tag bits computed from exactly the bytes the reference
+// compares at that position (4 for the short/fast probe, 8 for the long probe): a tag mismatch proves the
+// byte comparison would fail, so the candidate's bytes are not fetched — same decisions, fewer HBM sectors.
+struct ZEEnt16 { typedef u16 T; ZJ_DEVM T make(u32 pos1, u32) { return (T)pos1; } ZJ_DEVM u32 pos(u32 e) { return e; } ZJ_DEVM bool maybe(u32 e, u32) { return e != 0; } };
+struct ZEEnt32 { typedef u32 T; ZJ_DEVM T make(u32 pos1, u32) { return pos1; } ZJ_DEVM u32 pos(u32 e) { return e; } ZJ_DEVM bool maybe(u32 e, u32) { return e != 0; } };
+struct ZEEntTag { typedef u32 T; ZJ_DEVM T make(u32 pos1, u32 tag) { return pos1 | (tag << 17); } ZJ_DEVM u32 pos(u32 e) { return e & 0x1FFFFu; }
+                  ZJ_DEVM bool maybe(u32 e, u32 tag) { return (e & 0x1FFFFu) != 0 && (e >> 17) == tag; } };
+ZJ_DEV u32 ze_tag4(u32 v) { return (v * 2246822519u) >> 17; }                                   // 15 bits from 4 bytes
+ZJ_DEV u32 ze_tag8(u64 w) { return (u32)((w * 0x9E3779B97F4A7C15ull) >> 49); }                    // 15 bits from 8 bytes
+
 // ZSTD_compressBlock_fast_noDict_generic (N/compress/zstd_fast.c:192-423); tables hold position+1.
 // Same decisions in the same order as the reference's pipelined loop; what changes is WHEN bytes are
 // fetched: every global load an iteration can need (the two new positions, the repcode candidate and
@@ -175,8 +186,8 @@ ZJ_DEV u32 ze_hash_w(u64 w, u32 hBits, u32 mls) {
 // positions instead of five, and the 8 bytes of a position are loaded once and carried in registers as
 // it moves from ip2/ip3 to ip0/ip1.  The second table write of an iteration (table[hash1] = ip1) happens
 // on every path of the reference, so it is done up front, right after table[hash1] has been read.
-template <class TIdx>
-ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls, TIdx* table) {
+template <class E>
+ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls, typename E::T* table) {
     const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
     const u8* anchor = istart; const u8* ip0 = istart + 1; const u8* ip1; const u8* ip2; const u8* ip3;
     u32 rep1 = 1, rep2 = 0;                       // rep {1,4}: 4 > maxRep == 1 at the first position of a frame
@@ -192,13 +203,16 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
         bool found = false, isRep = false;
         do {
             // ---- issue everything this iteration may read ----
+            u32 const t0 = ze_tag4((u32)w0), t1 = ze_tag4((u32)w1);
+            bool const m0 = E::maybe(matchE, t0);
             u32 const rval = ld32(ip2 - rep1);
             u64 const w2 = ld64(ip2), w3 = ld64(ip3);
-            u32 const c0 = matchE ? ld32(istart + matchE - 1) : ~(u32)w0;
-            cur0 = (u32)(ip0 - istart); table[hash0] = (TIdx)(cur0 + 1);
+            u32 const c0 = m0 ? ld32(istart + E::pos(matchE) - 1) : ~(u32)w0;
+            cur0 = (u32)(ip0 - istart); table[hash0] = E::make(cur0 + 1, t0);
             u32 const matchE1 = table[hash1];
-            table[hash1] = (TIdx)((u32)(ip1 - istart) + 1);           // written on every path (see header comment)
-            u32 const c1 = matchE1 ? ld32(istart + matchE1 - 1) : ~(u32)w1;
+            table[hash1] = E::make((u32)(ip1 - istart) + 1, t1);     // written on every path (see header comment)
+            bool const m1 = E::maybe(matchE1, t1);
+            u32 const c1 = m1 ? ld32(istart + E::pos(matchE1) - 1) : ~(u32)w1;
             // ---- decisions, reference order ----
             if (((u32)w2 == rval) & (rep1 > 0)) {
                 ip0 = ip2; match0 = ip0 - rep1;
@@ -206,12 +220,12 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
                 offcode = 1; mLength += 4;
                 found = true; isRep = true; break;
             }
-            if (matchE && c0 == (u32)w0) { found = true; break; }
+            if (m0 && c0 == (u32)w0) { found = true; break; }
             matchE = matchE1;
             hash0 = hash1; hash1 = ze_hash_w(w2, hlog, mls);
             ip0 = ip1; ip1 = ip2; ip2 = ip3;
             cur0 = (u32)(ip0 - istart);
-            if (matchE && c1 == (u32)w1) { if (step <= 4) table[hash1] = (TIdx)((u32)(ip1 - istart) + 1); found = true; break; }
+            if (m1 && c1 == (u32)w1) { if (step <= 4) table[hash1] = E::make((u32)(ip1 - istart) + 1, ze_tag4((u32)w2)); found = true; break; }
             matchE = table[hash1];
             hash0 = hash1; hash1 = ze_hash_w(w3, hlog, mls);
             ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
@@ -220,7 +234,7 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
         } while (ip3 < ilimit);
         if (!found) break;
         if (!isRep) {
-            match0 = istart + matchE - 1;
+            match0 = istart + E::pos(matchE) - 1;
             rep2 = rep1; rep1 = (u32)(ip0 - match0); offcode = rep1 + 3; mLength = 4;
             while (((ip0 > anchor) & (match0 > istart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
         }
@@ -229,13 +243,13 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
         ip0 += mLength; anchor = ip0;
         if (ip0 <= ilimit) {
             {   u64 const wa = ld64(istart + cur0 + 2), wb = ld64(ip0 - 2);
-                table[ze_hash_w(wa, hlog, mls)] = (TIdx)(cur0 + 2 + 1);
-                table[ze_hash_w(wb, hlog, mls)] = (TIdx)((u32)(ip0 - 2 - istart) + 1); }
+                table[ze_hash_w(wa, hlog, mls)] = E::make(cur0 + 2 + 1, ze_tag4((u32)wa));
+                table[ze_hash_w(wb, hlog, mls)] = E::make((u32)(ip0 - 2 - istart) + 1, ze_tag4((u32)wb)); }
             if (rep2 > 0) {
                 while ((ip0 <= ilimit) && (ld32(ip0) == ld32(ip0 - rep2))) {
                     u32 const rLength = ze_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
                     { u32 const t = rep2; rep2 = rep1; rep1 = t; }
-                    table[ze_hash(ip0, hlog, mls)] = (TIdx)((u32)(ip0 - istart) + 1);
+                    {   u64 const wi = ld64(ip0); table[ze_hash_w(wi, hlog, mls)] = E::make((u32)(ip0 - istart) + 1, ze_tag4((u32)wi)); }
                     ip0 += rLength;
                     ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
                     anchor = ip0;
@@ -248,8 +262,8 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
 
 // ZSTD_compressBlock_doubleFast_noDict_generic (N/compress/zstd_double_fast.c:105-323), loads hoisted the
 // same way: the bytes of ip1, the repcode candidate and both table candidates are requested together.
-template <class TIdx>
-ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 hBitsS, u32 mls, TIdx* hashLong, TIdx* hashSmall) {
+template <class E>
+ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 hBitsS, u32 mls, typename E::T* hashLong, typename E::T* hashSmall) {
     const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
     const u8* anchor = istart; const u8* ip = istart + 1; const u8* ip1;
     u32 off1 = 1, off2 = 0;                       // rep {1,4}: 4 > maxRep == 1 at frame start
@@ -258,19 +272,28 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
     for (;;) {
         step = 1; nextStep = ip + 256; ip1 = ip + step;
         if (ip1 > ilimit) break;
-        u64 w = ld64(ip);
-        hl0 = ze_hash_w(w, hBitsL, 8); el0 = hashLong[hl0];
+        // software pipeline: the table entries and input bytes of position p+1 are requested while
+        // position p is being decided, so a no-match step costs one memory round trip, not two.
+        // Reads for p+1 are issued after p's table writes, exactly where the reference reads them.
+        u64 w = ld64(ip), w1 = ld64(ip1);
+        hl0 = ze_hash_w(w, hBitsL, 8); u32 hs0 = ze_hash_w(w, hBitsS, mls);
+        el0 = hashLong[hl0]; u32 es0 = hashSmall[hs0];
         u32 kind = 0;     // 0 none, 1 repcode stored, 2 long match found, 3 short match -> search next long
         do {
-            // ---- issue everything this position may read ----
-            u64 const w1 = ld64(ip1);
-            u32 const rv = ld32(ip + 1 - off1);
-            u64 const cl = el0 ? ld64(istart + el0 - 1) : ~w;
-            u32 const hs0 = ze_hash_w(w, hBitsS, mls);
-            u32 const es0 = hashSmall[hs0];
-            u32 const cs = es0 ? ld32(istart + es0 - 1) : ~(u32)w;
             curr = (u32)(ip - istart);
-            hashLong[hl0] = (TIdx)(curr + 1); hashSmall[hs0] = (TIdx)(curr + 1);
+            u32 const tl = ze_tag8(w), ts = ze_tag4((u32)w);
+            hashLong[hl0] = E::make(curr + 1, tl); hashSmall[hs0] = E::make(curr + 1, ts);
+            // ---- everything this position may read ----
+            bool const ml0 = E::maybe(el0, tl), ms0 = E::maybe(es0, ts);
+            u32 const rv = ld32(ip + 1 - off1);
+            u64 const cl = ml0 ? ld64(istart + E::pos(el0) - 1) : ~w;
+            u32 const cs = ms0 ? ld32(istart + E::pos(es0) - 1) : ~(u32)w;
+            // ---- next position: hashes, table entries, and the input word after it ----
+            hl1 = ze_hash_w(w1, hBitsL, 8); u32 const hs1 = ze_hash_w(w1, hBitsS, mls);
+            el1 = hashLong[hl1]; u32 const es1 = hashSmall[hs1];
+            u32 const stepN = step + ((ip1 >= nextStep) ? 1u : 0u);
+            const u8* const ip2 = ip1 + stepN;
+            u64 const w2 = (ip2 <= ilimit) ? ld64(ip2) : 0;
             // ---- decisions, reference order ----
             if ((off1 > 0) & (rv == (u32)(w >> 8))) {
                 mLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
@@ -278,26 +301,24 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
                 ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), 1, mLength);
                 kind = 1; break;
             }
-            hl1 = ze_hash_w(w1, hBitsL, 8);
-            if (el0 && cl == w) {
-                matchl0 = istart + el0 - 1;
+            if (ml0 && cl == w) {
+                matchl0 = istart + E::pos(el0) - 1;
                 mLength = ze_count(ip + 8, matchl0 + 8, iend) + 8;
                 offset = (u32)(ip - matchl0);
                 while (((ip > anchor) & (matchl0 > istart)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
                 kind = 2; break;
             }
-            el1 = hashLong[hl1];
-            if (es0 && cs == (u32)w) { matchs0 = istart + es0 - 1; kind = 3; break; }
+            if (ms0 && cs == (u32)w) { matchs0 = istart + E::pos(es0) - 1; kind = 3; break; }
             if (ip1 >= nextStep) { step++; nextStep += 256; }
-            ip = ip1; ip1 += step;
-            hl0 = hl1; el0 = el1; w = w1;
+            ip = ip1; ip1 = ip2;
+            hl0 = hl1; hs0 = hs1; el0 = el1; es0 = es1; w = w1; w1 = w2;
         } while (ip1 <= ilimit);
         if (kind == 0) break;
         if (kind == 3) {
             mLength = ze_count(ip + 4, matchs0 + 4, iend) + 4;
             offset = (u32)(ip - matchs0);
-            if ((el1 > 1) && (ld64(istart + el1 - 1) == ld64(ip1))) {
-                const u8* const matchl1 = istart + el1 - 1;
+            if ((E::pos(el1) > 1) && E::maybe(el1, ze_tag8(w1)) && (ld64(istart + E::pos(el1) - 1) == w1)) {
+                const u8* const matchl1 = istart + E::pos(el1) - 1;
                 u32 const l1len = ze_count(ip1 + 8, matchl1 + 8, iend) + 8;
                 if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (u32)(ip - matchl1); matchs0 = matchl1; }
             }
@@ -305,24 +326,24 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
         }
         if (kind >= 2) {
             off2 = off1; off1 = offset;
-            if (step < 4) hashLong[hl1] = (TIdx)((u32)(ip1 - istart) + 1);
+            if (step < 4) hashLong[hl1] = E::make((u32)(ip1 - istart) + 1, ze_tag8(w1));
             ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), offset + 3, mLength);
         }
         ip += mLength; anchor = ip;
         if (ip <= ilimit) {
             {   u32 const ins = curr + 2;
                 u64 const wa = ld64(istart + ins), wb = ld64(ip - 2), wc = ld64(ip - 1);
-                hashLong[ze_hash_w(wa, hBitsL, 8)] = (TIdx)(ins + 1);
-                hashLong[ze_hash_w(wb, hBitsL, 8)] = (TIdx)((u32)(ip - 2 - istart) + 1);
-                hashSmall[ze_hash_w(wa, hBitsS, mls)] = (TIdx)(ins + 1);
-                hashSmall[ze_hash_w(wc, hBitsS, mls)] = (TIdx)((u32)(ip - 1 - istart) + 1);
+                hashLong[ze_hash_w(wa, hBitsL, 8)] = E::make(ins + 1, ze_tag8(wa));
+                hashLong[ze_hash_w(wb, hBitsL, 8)] = E::make((u32)(ip - 2 - istart) + 1, ze_tag8(wb));
+                hashSmall[ze_hash_w(wa, hBitsS, mls)] = E::make(ins + 1, ze_tag4((u32)wa));
+                hashSmall[ze_hash_w(wc, hBitsS, mls)] = E::make((u32)(ip - 1 - istart) + 1, ze_tag4((u32)wc));
             }
             while ((ip <= ilimit) && ((off2 > 0) & (ld32(ip) == ld32(ip - off2)))) {
                 u32 const rLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4;
                 u32 const t = off2; off2 = off1; off1 = t;
                 {   u64 const wi = ld64(ip);
-                    hashSmall[ze_hash_w(wi, hBitsS, mls)] = (TIdx)((u32)(ip - istart) + 1);
-                    hashLong[ze_hash_w(wi, hBitsL, 8)] = (TIdx)((u32)(ip - istart) + 1); }
+                    hashSmall[ze_hash_w(wi, hBitsS, mls)] = E::make((u32)(ip - istart) + 1, ze_tag4((u32)wi));
+                    hashLong[ze_hash_w(wi, hBitsL, 8)] = E::make((u32)(ip - istart) + 1, ze_tag8(wi)); }
                 ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
                 ip += rLength; anchor = ip;
             }
@@ -739,6 +760,10 @@ ZJ_DEV u32 ze_raw_literals(const G& g, u8* dst, const u8* lit, u32 n) {
 
 // ------------------------------------------------------------------ frame -------------------
 // `lds` = the overlay region (tables / ZEEntropy), ldsBytes its size.
+template <class TIdx> struct ZEEntOf;
+template <> struct ZEEntOf<u16> { typedef ZEEnt16 E; };
+template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
+
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
@@ -786,8 +811,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             GRP_SERIAL(g) {
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 TIdx* const t = (TIdx*)lds;
-                u32 const lastLL = (strategy == 1) ? ze_block_fast<TIdx>(o, src, srcSize, hlog, mls, t)
-                                                   : ze_block_dfast<TIdx>(o, src, srcSize, hlog, clog, mls, t, t + (1u << hlog));
+                typedef typename ZEEntOf<TIdx>::E EntLds;
+                u32 const lastLL = (strategy == 1) ? ze_block_fast<EntLds>(o, src, srcSize, hlog, mls, t)
+                                                   : ze_block_dfast<EntLds>(o, src, srcSize, hlog, clog, mls, t, t + (1u << hlog));
                 sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
             }
             zj_mem_order();
@@ -1114,16 +1140,17 @@ ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 s
 #define ZE_FRAME_STRIDE(maxSrc) (ZE_FRAME_MAXSEQ(maxSrc) * 20u)
 
 // One lane runs the reference's sequential parse for one frame; 64 frames per wavefront advance in
-// SIMT.  Hash tables (position+1, u16: only frames <= 64 KiB take this path) and the sequence records
+// SIMT.  Hash tables (position+1 plus 15 tag bits; only frames <= 64 KiB take this path) and the records
 // live in HBM/L2 because 64 tables do not fit the LDS.  Output: records + meta {nbSeq, litSize, lastLL}.
 ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
     ZEOut o; o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
     u32 lastLL = srcSize;
     if (srcSize >= 7) {
         ZEParams const p = ze_params_of(level, srcSize);
-        u16* const t = (u16*)table;
-        lastLL = (p.strategy == 1) ? ze_block_fast<u16>(o, src, srcSize, p.hashLog, p.minMatch, t)
-                                   : ze_block_dfast<u16>(o, src, srcSize, p.hashLog, p.chainLog, p.minMatch, t, t + (1u << p.hashLog));
+        // fast: plain u16 entries (one probe per position; tags cost more in table sectors than they save);
+        // double-fast: tagged 4-byte entries (two probes per position, most candidates rejected by tag)
+        if (p.strategy == 1) lastLL = ze_block_fast<ZEEnt16>(o, src, srcSize, p.hashLog, p.minMatch, (u16*)table);
+        else { u32* const t = (u32*)table; lastLL = ze_block_dfast<ZEEntTag>(o, src, srcSize, p.hashLog, p.chainLog, p.minMatch, t, t + (1u << p.hashLog)); }
     }
     meta[0] = o.n; meta[1] = o.lit + lastLL; meta[2] = lastLL;
 }

@@ -354,7 +354,7 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
     if (const char* ov = getenv("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
     if (n >= splitMin) {
-        u32 const tableStride = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
+        u32 const tableStride = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 4u));   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12;
         size_t const need = tablesBytes + fsBytes + metaBytes + 256;
         if (d->splitBufCap < need) {
