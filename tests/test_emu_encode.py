@@ -69,3 +69,18 @@ def test_emu_encoder_dst_too_small(emu, zj):
         dst = C.create_string_buffer(cap)
         r = emu.emu_compress(d, len(d), dst, cap, 3)
         assert (1 << 64) - r == 70
+
+
+def test_emu_encoder_tiny_text_frames(emu, oracle_ref):
+    """short natural-text frames sit right at the compressed-vs-raw block decision (ZSTD_minGain): both
+    pipelines must take the reference's side of it (regression: 70-byte frame with 0 sequences)"""
+    rnd = random.Random(5)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for _ in range(1500):
+        size = rnd.randrange(1, 400)
+        off = rnd.randrange(0, len(xml) - size)
+        d = xml[off:off + size]
+        for level in (1, 3):
+            want = expected(oracle_ref, d, level)
+            assert emu_compress(emu, d, level) == want, (size, off, level)
+            assert emu_compress(emu, d, level, split=True) == want, (size, off, level, "split")

@@ -27,12 +27,14 @@ typedef int64_t i64;
 #include <hip/hip_runtime.h>
 #define ZJ_DEV __device__ __forceinline__
 #define ZJ_DEVM static __device__ __forceinline__   /* static member functions */
+#define ZJ_DEV_MEMBER __device__ __forceinline__
 #define ZJ_DEV_NOINLINE __device__ __noinline__
 #define ZJ_HD __host__ __device__ __forceinline__
 #define ZJ_ON_GPU 1
 #else
 #define ZJ_DEV static inline
 #define ZJ_DEVM static inline
+#define ZJ_DEV_MEMBER inline
 #define ZJ_DEV_NOINLINE static
 #define ZJ_HD static inline
 #define ZJ_ON_GPU 0

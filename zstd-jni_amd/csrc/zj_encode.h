@@ -156,6 +156,9 @@ ZJ_DEV void ze_store(ZEOut& o, u32 litPos, u32 ll, u32 offBase, u32 ml) {
     o.seqs[o.n++] = s; o.lit += ll;
 }
 
+#ifndef ZE_COUNT_ITER
+#define ZE_COUNT_ITER() ((void)0)     /* instrumentation hook for tools; no-op in the product */
+#endif
 // hash of a position from its 8 already-loaded bytes (N/compress/zstd_compress_internal.h:898-960)
 ZJ_DEV u32 ze_hash_w(u64 w, u32 hBits, u32 mls) {
     switch (mls) {
@@ -202,6 +205,7 @@ ZJ_DEV u32 ze_block_fast(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32 mls
         matchE = table[hash0];
         bool found = false, isRep = false;
         do {
+            ZE_COUNT_ITER();
             // ---- issue everything this iteration may read ----
             u32 const t0 = ze_tag4((u32)w0), t1 = ze_tag4((u32)w1);
             bool const m0 = E::maybe(matchE, t0);
@@ -280,6 +284,7 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
         el0 = hashLong[hl0]; u32 es0 = hashSmall[hs0];
         u32 kind = 0;     // 0 none, 1 repcode stored, 2 long match found, 3 short match -> search next long
         do {
+            ZE_COUNT_ITER();
             curr = (u32)(ip - istart);
             u32 const tl = ze_tag8(w), ts = ze_tag4((u32)w);
             hashLong[hl0] = E::make(curr + 1, tl); hashSmall[hs0] = E::make(curr + 1, ts);
@@ -954,7 +959,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             g.sync();
             pos = ZJ_UNI(sh.tmp[1]);
             bool ok = true;
-            if (pos + 4 >= maxCSize) ok = false;                              // cannot win any more: raw block
+            if (pos + (nbSeq ? 2u : 0u) >= maxCSize) ok = false;                // cannot win any more (a sequences section is >= 2 bytes): raw block
             if (ok && nbSeq) {
                 u32 const seqHead = pos; pos += 1;
                 for (u32 t = 0; t < 3; t++) {                                 // LL, OF, ML in stream order
@@ -1139,10 +1144,8 @@ ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 s
 #define ZE_FRAME_MAXSEQ(maxSrc) (((maxSrc) / 4u) + 16u)
 #define ZE_FRAME_STRIDE(maxSrc) (ZE_FRAME_MAXSEQ(maxSrc) * 20u)
 
-// One lane runs the reference's sequential parse for one frame; 64 frames per wavefront advance in
-// SIMT.  Hash tables (position+1 plus 15 tag bits; only frames <= 64 KiB take this path) and the records
-// live in HBM/L2 because 64 tables do not fit the LDS.  Output: records + meta {nbSeq, litSize, lastLL}.
-ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
+// Plain-loop lane match finder (tiny frames; the round-synchronous machines of zj_match_lane.h do the rest).
+ZJ_DEV void ze_match_lane_serial(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
     ZEOut o; o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
     u32 lastLL = srcSize;
     if (srcSize >= 7) {
@@ -1153,4 +1156,20 @@ ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* 
         else { u32* const t = (u32*)table; lastLL = ze_block_dfast<ZEEntTag>(o, src, srcSize, p.hashLog, p.chainLog, p.minMatch, t, t + (1u << p.hashLog)); }
     }
     meta[0] = o.n; meta[1] = o.lit + lastLL; meta[2] = lastLL;
+}
+
+#include "zj_match_lane.h"
+
+// One frame through the lane machinery, start to finish (emulation and single-frame callers; the kernel
+// interleaves 64 of these per wavefront, see zj_enc_match_kernel).  Output: records + meta {nbSeq, litSize, lastLL}.
+template <class M>
+ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
+    M m; m.init(src, srcSize, ze_params_of(level, srcSize), table, fscratch, maxSrc);
+    for (u32 r = 0; m.st != ZL_DONE; r++) m.round(r);
+    meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
+}
+ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
+    if (srcSize < ZL_MIN_FRAME) ze_match_lane_serial(src, srcSize, level, table, fscratch, maxSrc, meta);
+    else if (level == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
+    else ze_match_lane_t<ZLaneF<ZEEnt16> >(src, srcSize, level, table, fscratch, maxSrc, meta);
 }

@@ -62,20 +62,40 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
 }
 
 // Lane-per-frame match finding (large batches): every lane owns one frame and runs the reference's
-// sequential parse; lanes pull list entries from a device counter until the list is drained, so a wave
-// stays full although frames differ 4x in cost.  Tables and sequence records of list entry k live at
-// tables + k*tableStride and fscratch + k*ZE_FRAME_STRIDE(maxSrc) in HBM.
+// sequential parse as a round-synchronous state machine (zj_match_lane.h); a lane whose frame is finished
+// pulls the next list entry from a device counter inside the same loop, so the 64 lanes of a wave keep
+// sharing memory round trips although frames differ 30x in cost.  Tables and sequence records of list
+// entry k live at tables + k*tableStride and fscratch + k*ZE_FRAME_STRIDE(maxSrc) in HBM.
+template <class M>
+__device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                             const u32* __restrict__ list, u32 count, u32* workCounter,
+                                             u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta) {
+    M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
+    bool have = false; u32 k = 0;
+    for (u32 r = 0;; r++) {
+        if (m.st == ZL_DONE) {
+            if (have) { u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false; }
+            k = atomicAdd(workCounter, 1u);
+            if (k >= count) break;
+            u32 const i = list[k];
+            u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
+            u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
+            if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); continue; }
+            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc);
+            have = true;
+        }
+        m.round(ZJ_UNI(r));
+    }
+#ifdef ZL_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) printf("match lane profile: rounds %llu, cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", m.pR, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
+#endif
+}
 __global__ __launch_bounds__(64) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta) {
     u32 const count = *countPtr;
-    for (;;) {
-        u32 const k = atomicAdd(workCounter, 1u);
-        if (k >= count) break;
-        u32 const i = list[k];
-        u64 const s0 = srcOff[i], s1 = srcOff[i + 1];
-        ze_match_lane(src + s0, (u32)(s1 - s0), level, tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc, meta + 3 * (size_t)k);
-    }
+    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta);
+    else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta);
 }
 
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,

@@ -1,0 +1,435 @@
+// zj_match_lane.h — lane-per-frame match finders as round-synchronous state machines.
+//
+// One lane owns one frame and runs the reference's sequential parse (ZSTD_compressBlock_fast /
+// _doubleFast, N/compress/zstd_fast.c:192-423, N/compress/zstd_double_fast.c:105-323); 64 frames advance
+// per wavefront.  Written as straight loops (ze_block_fast/ze_block_dfast in zj_encode.h) a wavefront pays
+// for SIMT divergence: as soon as one lane finds a match, all 64 lanes wait through that lane's chain of
+// dependent memory round trips (count forward, extend backward, re-insert, repcode loop, restart), and with
+// 64 lanes some lane almost always has a match (measured: 5.2 us per search step on a single idle wave,
+// 6-8 dependent HBM/L2 round trips of ~0.6 us each; tools/micro/chase.hip).
+//
+// Here every lane is a small state machine and the wavefront executes ROUNDS: each round every lane names
+// the few addresses its current state needs, all loads are issued together at one program point, and after
+// one wait every lane consumes its data, does its table/record stores and moves to its next state.  A lane
+// that is counting a match length and a lane that is probing the next position share the same round trip.
+// The decisions, their order, and every table write are exactly the reference's — the machine only changes
+// when bytes are fetched — so frames stay byte-identical (tests/test_emu_encode.py, tests/test_gpu_encode.py).
+#pragma once
+
+// bytes [pos, pos+8) of a frame of n >= 8 bytes; bytes at or beyond n read as zero (never touches memory past n)
+ZJ_DEV u64 zl_ld_fwd(const u8* s, u32 n, u32 pos) {
+    u32 const p = zj_min(pos, n - 8u);
+    u64 const v = ld64(s + p);
+    u32 const sh = (pos - p) * 8u;
+    return sh >= 64u ? 0 : (v >> sh);
+}
+// bytes [pos-8, pos): byte pos-1 is the most significant; bytes before the frame start read as zero
+ZJ_DEV u64 zl_ld_back(const u8* s, u32 pos) {
+    u32 const p = pos >= 8u ? pos - 8u : 0u;
+    u64 const v = ld64(s + p);
+    u32 const sh = (8u - (pos - p)) * 8u;
+    return sh >= 64u ? 0 : (v << sh);
+}
+// The same two loads split into "where to read" and "fix up what was read", so that a round can issue every
+// lane's loads back to back, unconditionally (slots a lane does not need read offset 0), and wait once.
+ZJ_DEV u32 zl_fwd_at(u32 n, u32 pos) { return zj_min(pos, n - 8u); }
+ZJ_DEV u64 zl_fwd_fix(u64 v, u32 pos, u32 at) { u32 const sh = (pos - at) * 8u; return sh >= 64u ? 0 : (v >> sh); }
+ZJ_DEV u32 zl_back_at(u32 pos) { return pos >= 8u ? pos - 8u : 0u; }
+ZJ_DEV u64 zl_back_fix(u64 v, u32 pos, u32 at) { u32 const sh = (8u - (pos - at)) * 8u; return sh >= 64u ? 0 : (v << sh); }
+// All loads of a round are consumed here, at one program point: without it the compiler sinks each load into
+// the state branch that uses it and the round degenerates into one memory round trip per state again.
+#if ZJ_ON_GPU
+#define ZL_ROUND_FENCE9(a, b, c, d, e, f, g, h, i) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "v"(i))
+#else
+#define ZL_ROUND_FENCE9(a, b, c, d, e, f, g, h, i) ((void)0)
+#endif
+ZJ_DEV u32 zl_common_fwd16(u64 a0, u64 a1, u64 b0, u64 b1) {
+    u64 const x0 = a0 ^ b0, x1 = a1 ^ b1;
+    if (x0) return (u32)__builtin_ctzll(x0) >> 3;
+    return 8u + (x1 ? ((u32)__builtin_ctzll(x1) >> 3) : 8u);
+}
+ZJ_DEV u32 zl_common_back8(u64 p, u64 q) { u64 const x = p ^ q; return x ? ((u32)__builtin_clzll(x) >> 3) : 8u; }
+
+#ifdef ZL_PROFILE
+#define ZL_PROF_MEMBERS u64 pT0 = 0, pT1 = 0, pA = 0, pB = 0, pC = 0, pR = 0;
+#define ZL_PROF_T0() do { u64 const t_ = __builtin_readcyclecounter(); if (pT0) pC += t_ - pT1; pT0 = t_; pR++; } while (0)
+#define ZL_PROF_T1() do { u64 const t_ = __builtin_readcyclecounter(); pA += t_ - pT0; pT1 = t_; } while (0)
+#define ZL_PROF_T2() do { u64 const t_ = __builtin_readcyclecounter(); pB += t_ - pT1; pT1 = t_; } while (0)
+#else
+#define ZL_PROF_MEMBERS
+#define ZL_PROF_T0() ((void)0)
+#define ZL_PROF_T1() ((void)0)
+#define ZL_PROF_T2() ((void)0)
+#endif
+enum { ZL_LOADW = 0, ZL_START, ZL_SEARCH, ZL_SEARCH_B, ZL_COUNT, ZL_BACK, ZL_POST, ZL_DONE };
+enum { ZL_EN_COUNT = 1, ZL_EN_POST = 2, ZL_EN_START = 4 };   // which non-search states a round serves
+enum { ZC_REP1 = 0, ZC_LONG, ZC_SHORT, ZC_SHORT_L1, ZC_REPLOOP, ZC_FOUND };
+
+// ---------------------------------------------------------------------------------------------
+// double-fast (level 3).  Positions are offsets from the frame start.
+template <class E>
+struct ZLaneD {
+    typedef typename E::T Ent;
+    const u8* src; u32 n, ilimit; Ent* HL; Ent* HS; u32 hBitsL, hBitsS, mls;
+    ZEOut o;
+    u32 st, cont, lastLL;
+    u32 ip, ip1, anchor, off1, off2, step, nextStep, curr;
+    u64 w, w1; u32 el0, es0, el1, hl0, hs0, hl1, hs1;
+    u32 ca, cb, acc;                                  // forward count in progress
+    u32 mpos, mpos2, mLength, offset, bk, bk2;       // chosen match / candidate at ip1 / backward extension
+    bool more, more2, cvalid, needBack, needCand, chk;
+
+    ZJ_DEVM u32 hashL(u64 v, u32 bits) { return ze_hash_w(v, bits, 8); }
+
+    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
+        src = s; n = size; ilimit = size - 8u; hBitsL = p.hashLog; hBitsS = p.chainLog; mls = p.minMatch;
+        HL = (Ent*)table; HS = HL + (1u << p.hashLog);
+        o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
+        ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
+        needBack = needCand = more = more2 = cvalid = false;
+        st = ZL_LOADW;
+    }
+    ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
+    // outer-loop header of the reference: reset the step and make sure one more position fits
+    ZJ_DEV_MEMBER void outer() {
+        step = 1; nextStep = ip + 256u; ip1 = ip + 1u;
+        if (ip1 > ilimit) finish(); else st = ZL_START;
+    }
+    ZJ_DEV_MEMBER void begin_count(u32 a, u32 b, u32 c) { ca = a; cb = b; acc = 0; cont = c; st = ZL_COUNT; }
+    ZJ_DEV_MEMBER void advance() { ip += mLength; anchor = ip; if (ip <= ilimit) st = ZL_POST; else finish(); }
+    ZJ_DEV_MEMBER void fin() {             // a long/short match is final: apply the backward extension, store it
+        ip -= bk; mLength += bk;
+        off2 = off1; off1 = offset;
+        if (step < 4u) HL[hl1] = E::make(ip1 + 1u, ze_tag8(w1));
+        ze_store(o, anchor, ip - anchor, offset + 3u, mLength);
+        advance();
+    }
+    ZJ_DEV_MEMBER void fin_or_back() { if (more) st = ZL_BACK; else fin(); }
+
+    ZL_PROF_MEMBERS
+    // Round r of the wavefront.  A searching lane advances every round; the other states take turns
+    // (r mod 4: count/backward, post-insert/reload, restart, none), so a round executes the search code plus at
+    // most one other state's code instead of all of them — the rounds are instruction-issue bound (a wave runs
+    // alone on its SIMD), and a lane that follows the natural order search -> count -> post -> restart ->
+    // search meets its slot every round.
+    ZJ_DEV_MEMBER void round(u32 r) {
+        switch (r & 3u) {
+        case 0: round_t<ZL_EN_COUNT>(); break;
+        case 1: round_t<ZL_EN_POST>(); break;
+        case 2: round_t<ZL_EN_START>(); break;
+        default: round_t<0>(); break;
+        }
+    }
+    template <int K>
+    ZJ_DEV_MEMBER void round_t() {
+        ZL_PROF_T0();
+        u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, ti0 = 0, ti1 = 0;
+        bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vt = false;
+        bool ml0 = false, ms0 = false; u32 ip2 = 0;
+        bool const on = (st == ZL_SEARCH) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
+                     || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW)) || ((K & ZL_EN_START) && st == ZL_START);
+        // ---- phase 1: what does this lane's state need (and the table writes that precede its reads) ----
+        if (st == ZL_SEARCH) {
+            ZE_COUNT_ITER();
+            curr = ip;
+            u32 const tl = ze_tag8(w), ts = ze_tag4((u32)w);
+            HL[hl0] = E::make(curr + 1u, tl); HS[hs0] = E::make(curr + 1u, ts);
+            ml0 = E::maybe(el0, tl); ms0 = E::maybe(es0, ts);
+            pa0 = ip + 1u - off1; v0 = true;
+            pa1 = E::pos(el0) - 1u; v1 = ml0;
+            pa2 = E::pos(es0) - 1u; v2 = ms0;
+            ip2 = ip1 + step + ((ip1 >= nextStep) ? 1u : 0u);
+            pa3 = ip2; v3 = ip2 <= ilimit;
+            hl1 = hashL(w1, hBitsL); hs1 = ze_hash_w(w1, hBitsS, mls);
+            ti0 = hl1; ti1 = hs1; vt = true;
+        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
+            pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
+            if (needBack) { vb = true; if (cont == ZC_SHORT_L1) { bp0 = ip1; bp1 = mpos2; } else { bp0 = ip; bp1 = mpos; } }
+            if (needCand) { v4 = true; pa4 = mpos2; }
+        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
+            vb = true; bp0 = ip - bk; bp1 = mpos - bk;
+        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
+            pa0 = curr + 2u; pa1 = ip - 2u; pa2 = ip + 6u; v0 = v1 = v2 = true;
+            pa3 = ip - off2; v3 = off2 > 0u;
+        } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
+            pa0 = ip; pa1 = ip + 1u; v0 = v1 = true;
+            pa3 = ip - off2; v3 = chk && off2 > 0u;
+        } else if ((K & ZL_EN_START) && st == ZL_START) {
+            hl0 = hashL(w, hBitsL); hs0 = ze_hash_w(w, hBitsS, mls);
+            ti0 = hl0; ti1 = hs0; vt = true;
+        }
+        // ---- phase 2: one batch of loads for all states ----
+        ZL_PROF_T1();
+        if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
+        if (!vb) { bp0 = 8; bp1 = 8; }
+        if (!vt) { ti0 = 0; ti1 = 0; }
+        u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
+        u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
+        u64 const r0 = ld64(src + q0), r1 = ld64(src + q1), r2 = ld64(src + q2), r3 = ld64(src + q3);
+        u64 const r4 = (K & ZL_EN_COUNT) ? ld64(src + q4) : 0;
+        u64 const rb0 = (K & ZL_EN_COUNT) ? ld64(src + qb0) : 0, rb1 = (K & ZL_EN_COUNT) ? ld64(src + qb1) : 0;
+        u32 const t0 = (u32)HL[ti0], t1 = (u32)HS[ti1];
+        ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t0, t1);
+        ZL_PROF_T2();
+        u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
+        u64 const d4 = zl_fwd_fix(r4, pa4, q4);
+        u64 const b0 = zl_back_fix(rb0, bp0, qb0), b1 = zl_back_fix(rb1, bp1, qb1);
+        if (!on) return;
+        // ---- phase 3: consume ----
+        if (st == ZL_SEARCH) {
+            u32 const rv = (u32)d0; u32 const es1 = t1; el1 = t0;
+            if ((off1 > 0u) & (rv == (u32)(w >> 8))) {
+                begin_count(ip + 5u, ip + 5u - off1, ZC_REP1); needBack = false; needCand = false;
+            } else if (ml0 && d1 == w) {
+                mpos = E::pos(el0) - 1u;
+                begin_count(ip + 8u, mpos + 8u, ZC_LONG); needBack = true; needCand = false;
+            } else if (ms0 && (u32)d2 == (u32)w) {
+                mpos = E::pos(es0) - 1u;
+                begin_count(ip + 4u, mpos + 4u, ZC_SHORT); needBack = true;
+                needCand = (E::pos(el1) > 1u) && E::maybe(el1, ze_tag8(w1)); mpos2 = E::pos(el1) - 1u; cvalid = false;
+            } else {
+                if (ip1 >= nextStep) { step++; nextStep += 256u; }
+                ip = ip1; ip1 = ip2; w = w1; w1 = d3; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1;
+                if (ip1 > ilimit) finish();
+            }
+        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
+            u32 const lim = n - ca;
+            u32 c = zl_common_fwd16(d0, d1, d2, d3);
+            if (c > lim) c = lim;
+            acc += c;
+            if (needBack) {
+                bool const second = (cont == ZC_SHORT_L1);
+                u32 const limit = second ? zj_min(ip1 - anchor, mpos2) : zj_min(ip - anchor, mpos);
+                u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+                bool const m = (e == 8u) && (limit > 8u);
+                if (second) { bk2 = e; more2 = m; } else { bk = e; more = m; }
+                needBack = false;
+            }
+            if (needCand) { cvalid = (d4 == w1); needCand = false; }
+            if (c == 16u && lim > 16u) { ca += 16u; cb += 16u; }
+            else if (cont == ZC_REP1) {
+                mLength = acc + 4u; ip += 1u;
+                ze_store(o, anchor, ip - anchor, 1u, mLength);
+                advance();
+            } else if (cont == ZC_LONG) {
+                mLength = acc + 8u; offset = ip - mpos; fin_or_back();
+            } else if (cont == ZC_SHORT) {
+                mLength = acc + 4u; offset = ip - mpos;
+                if (cvalid) { begin_count(ip1 + 8u, mpos2 + 8u, ZC_SHORT_L1); needBack = true; }
+                else fin_or_back();
+            } else if (cont == ZC_SHORT_L1) {
+                u32 const l1len = acc + 8u;
+                if (l1len > mLength) { ip = ip1; mLength = l1len; mpos = mpos2; offset = ip - mpos; bk = bk2; more = more2; }
+                fin_or_back();
+            } else {                                   // ZC_REPLOOP: immediate repcode after a match
+                u32 const rLength = acc + 4u;
+                { u32 const t = off2; off2 = off1; off1 = t; }
+                HS[ze_hash_w(w, hBitsS, mls)] = E::make(ip + 1u, ze_tag4((u32)w));
+                HL[hashL(w, hBitsL)] = E::make(ip + 1u, ze_tag8(w));
+                ze_store(o, anchor, 0u, 1u, rLength);
+                ip += rLength; anchor = ip;
+                if (ip <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
+            }
+        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
+            u64 const wa = d0, q0 = d1, q1 = d2;
+            u64 const wb = q0, wc = (q0 >> 8) | (q1 << 56);
+            u32 const ins = curr + 2u;
+            HL[hashL(wa, hBitsL)] = E::make(ins + 1u, ze_tag8(wa));
+            HL[hashL(wb, hBitsL)] = E::make(ip - 2u + 1u, ze_tag8(wb));
+            HS[ze_hash_w(wa, hBitsS, mls)] = E::make(ins + 1u, ze_tag4((u32)wa));
+            HS[ze_hash_w(wc, hBitsS, mls)] = E::make(ip - 1u + 1u, ze_tag4((u32)wc));
+            w = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
+            if ((off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
+            else outer();
+        } else if ((K & ZL_EN_START) && st == ZL_START) {
+            el0 = t0; es0 = t1; st = ZL_SEARCH;
+        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
+            u32 const limit = zj_min(ip - anchor, mpos) - bk;
+            u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+            bk += e; more = (e == 8u) && (limit > 8u);
+            if (!more) fin();
+        } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
+            w = d0; w1 = d1;
+            if (chk && (off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
+            else outer();
+            chk = false;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// fast (levels 1-2).  A pair of positions (ip0, ip1) is probed in two rounds: round A writes ip0, reads
+// and writes ip1's entry, fetches the repcode bytes at ip2, the next pair's bytes and ip0's candidate;
+// round B fetches ip1's candidate and the entry of ip2 (which the next pair starts from).
+template <class E>
+struct ZLaneF {
+    typedef typename E::T Ent;
+    const u8* src; u32 n, ilimit; Ent* T; u32 hlog, mls;
+    ZEOut o;
+    u32 st, cont, lastLL;
+    u32 ip0, ip1, ip2, ip3, anchor, rep1, rep2, step, nextStep, cur0;
+    u64 w0, w1, w2, w3; u32 eX, eY;
+    u32 ca, cb, acc, mpos, mLength, offcode, bk;
+    bool more, needBack, chk;
+
+    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
+        src = s; n = size; ilimit = size - 8u; hlog = p.hashLog; mls = p.minMatch; T = (Ent*)table;
+        o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
+        ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = false; bk = 0;
+        st = ZL_LOADW;
+    }
+    ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
+    ZJ_DEV_MEMBER void outer() {
+        step = 2; nextStep = ip0 + 128u; ip1 = ip0 + 1u; ip2 = ip0 + 2u; ip3 = ip0 + 3u;
+        if (ip3 >= ilimit) finish(); else st = ZL_START;
+    }
+    ZJ_DEV_MEMBER void begin_count(u32 a, u32 b, u32 c) { ca = a; cb = b; acc = 0; cont = c; st = ZL_COUNT; }
+    ZJ_DEV_MEMBER void fin() {
+        ip0 -= bk; mLength += bk;
+        ze_store(o, anchor, ip0 - anchor, offcode, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip0 <= ilimit) st = ZL_POST; else finish();
+    }
+    // a table candidate matched at ip0 (entry e): new offset, then extend both ways
+    ZJ_DEV_MEMBER void found_at(u32 e) {
+        mpos = E::pos(e) - 1u;
+        rep2 = rep1; rep1 = ip0 - mpos; offcode = rep1 + 3u; mLength = 4u;
+        begin_count(ip0 + 4u, mpos + 4u, ZC_FOUND); needBack = true; bk = 0; more = false;
+    }
+
+    ZL_PROF_MEMBERS
+    // Search rounds (A and B) run every round; count/backward, post-insert/reload and restart take turns
+    // (r mod 5 = 0, 1, 2; see ZLaneD::round).  Period 5 lets both the A-only and the A,B paths meet their slots.
+    ZJ_DEV_MEMBER void round(u32 r) {
+        switch (r % 5u) {
+        case 0: round_t<ZL_EN_COUNT>(); break;
+        case 1: round_t<ZL_EN_POST>(); break;
+        case 2: round_t<ZL_EN_START>(); break;
+        default: round_t<0>(); break;
+        }
+    }
+    template <int K>
+    ZJ_DEV_MEMBER void round_t() {
+        ZL_PROF_T0();
+        u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, ti = 0;
+        bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vt = false, m0 = false, m1 = false;
+        u32 t0tag = 0, t1tag = 0;
+        bool const on = (st == ZL_SEARCH) || (st == ZL_SEARCH_B) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
+                     || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW)) || ((K & ZL_EN_START) && st == ZL_START);
+        if (st == ZL_SEARCH) {                         // round A of a pair
+            ZE_COUNT_ITER();
+            t0tag = ze_tag4((u32)w0); t1tag = ze_tag4((u32)w1);
+            cur0 = ip0;
+            T[ze_hash_w(w0, hlog, mls)] = E::make(ip0 + 1u, t0tag);
+            ti = ze_hash_w(w1, hlog, mls); vt = true;
+            m0 = E::maybe(eX, t0tag);
+            pa0 = ip2 - 1u - rep1; v0 = true;          // byte before the repcode candidate + its 4 bytes
+            pa1 = ip2; pa2 = ip3; v1 = v2 = true;
+            pa3 = E::pos(eX) - 1u; v3 = m0;
+            pa4 = ip2 - 1u; v4 = true;
+        } else if (st == ZL_SEARCH_B) {
+            t1tag = ze_tag4((u32)w1);
+            m1 = E::maybe(eY, t1tag);
+            pa3 = E::pos(eY) - 1u; v3 = m1;
+            ti = ze_hash_w(w2, hlog, mls); vt = true;
+        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
+            pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
+            if (needBack) { vb = true; bp0 = ip0; bp1 = mpos; }
+        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
+            vb = true; bp0 = ip0 - bk; bp1 = mpos - bk;
+        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
+            pa0 = cur0 + 2u; pa1 = ip0 - 2u; pa2 = ip0 + 6u; v0 = v1 = v2 = true;
+            pa3 = ip0 - rep2; v3 = rep2 > 0u;
+        } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
+            pa0 = ip0; pa1 = ip0 + 1u; v0 = v1 = true;
+            pa3 = ip0 - rep2; v3 = chk && rep2 > 0u;
+        } else if ((K & ZL_EN_START) && st == ZL_START) {
+            ti = ze_hash_w(w0, hlog, mls); vt = true;
+        }
+        ZL_PROF_T1();
+        if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
+        if (!vb) { bp0 = 8; bp1 = 8; }
+        if (!vt) ti = 0;
+        u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
+        u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
+        u64 const r0 = ld64(src + q0), r1 = ld64(src + q1), r2 = ld64(src + q2), r3 = ld64(src + q3), r4 = ld64(src + q4);
+        u64 const rb0 = (K & ZL_EN_COUNT) ? ld64(src + qb0) : 0, rb1 = (K & ZL_EN_COUNT) ? ld64(src + qb1) : 0;
+        u32 const t = (u32)T[ti];
+        ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t, t);
+        ZL_PROF_T2();
+        u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
+        u64 const d4 = zl_fwd_fix(r4, pa4, q4);
+        u64 const b0 = zl_back_fix(rb0, bp0, qb0), b1 = zl_back_fix(rb1, bp1, qb1);
+        if (!on) return;
+        if (st == ZL_SEARCH) {
+            eY = t;
+            T[ti] = E::make(ip1 + 1u, t1tag);            // written on every path of the reference's iteration
+            w2 = d1; w3 = d2;
+            u32 const rval = (u32)(d0 >> 8);
+            if (((u32)w2 == rval) & (rep1 > 0u)) {
+                ip0 = ip2; mpos = ip0 - rep1;
+                u32 const e = ((u8)d4 == (u8)d0) ? 1u : 0u;
+                ip0 -= e; mpos -= e; offcode = 1u; mLength = 4u + e;
+                begin_count(ip0 + mLength, mpos + mLength, ZC_FOUND); needBack = false; bk = 0; more = false;
+            } else if (m0 && (u32)d3 == (u32)w0) {
+                found_at(eX);
+            } else st = ZL_SEARCH_B;
+        } else if (st == ZL_SEARCH_B) {
+            // reference: shift the pair by one (ip0 <- ip1, ip1 <- ip2, ip2 <- ip3), test ip1's candidate
+            u32 const oip2 = ip2, oip3 = ip3;
+            ip0 = ip1; cur0 = ip0;
+            if (m1 && (u32)d3 == (u32)w1) {
+                if (step <= 4u) T[ti] = E::make(oip2 + 1u, ze_tag4((u32)w2));
+                found_at(eY);
+            } else {
+                eX = t;
+                ip0 = oip2; ip1 = oip3; ip2 = ip0 + step; ip3 = ip1 + step; w0 = w2; w1 = w3;
+                if (ip2 >= nextStep) { step++; nextStep += 128u; }
+                if (ip3 >= ilimit) finish(); else st = ZL_SEARCH;
+            }
+        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
+            u32 const lim = n - ca;
+            u32 c = zl_common_fwd16(d0, d1, d2, d3);
+            if (c > lim) c = lim;
+            acc += c;
+            if (needBack) {
+                u32 const limit = zj_min(ip0 - anchor, mpos);
+                u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+                bk = e; more = (e == 8u) && (limit > 8u); needBack = false;
+            }
+            if (c == 16u && lim > 16u) { ca += 16u; cb += 16u; }
+            else if (cont == ZC_FOUND) { mLength += acc; if (more) st = ZL_BACK; else fin(); }
+            else {                                     // ZC_REPLOOP
+                u32 const rLength = acc + 4u;
+                { u32 const x = rep2; rep2 = rep1; rep1 = x; }
+                T[ze_hash_w(w0, hlog, mls)] = E::make(ip0 + 1u, ze_tag4((u32)w0));
+                ip0 += rLength;
+                ze_store(o, anchor, 0u, 1u, rLength);
+                anchor = ip0;
+                if (ip0 <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
+            }
+        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
+            u64 const wa = d0, q0 = d1, q1 = d2;
+            T[ze_hash_w(wa, hlog, mls)] = E::make(cur0 + 2u + 1u, ze_tag4((u32)wa));
+            T[ze_hash_w(q0, hlog, mls)] = E::make(ip0 - 2u + 1u, ze_tag4((u32)q0));
+            w0 = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
+            if ((rep2 > 0u) && ((u32)w0 == (u32)d3)) { begin_count(ip0 + 4u, ip0 + 4u - rep2, ZC_REPLOOP); needBack = false; }
+            else outer();
+        } else if ((K & ZL_EN_START) && st == ZL_START) {
+            eX = t; st = ZL_SEARCH;
+        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
+            u32 const limit = zj_min(ip0 - anchor, mpos) - bk;
+            u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+            bk += e; more = (e == 8u) && (limit > 8u);
+            if (!more) fin();
+        } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
+            w0 = d0; w1 = d1;
+            if (chk && (rep2 > 0u) && ((u32)w0 == (u32)d3)) { begin_count(ip0 + 4u, ip0 + 4u - rep2, ZC_REPLOOP); needBack = false; }
+            else outer();
+            chk = false;
+        }
+    }
+};
+
+// Frames below this size run the plain loops (the machines assume 8-byte loads always fit in the frame).
+#define ZL_MIN_FRAME 64u
