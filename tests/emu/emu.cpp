@@ -2,7 +2,9 @@
 // pre-GPU unit tests in the CPU-only dev container.  TEST INFRASTRUCTURE ONLY: never linked into
 // libzjni_amd.so, never reachable from the C-ABI (which fails loudly without a GPU).
 #include "../../zstd-jni_amd/csrc/zj_decode.h"
+#include "../../zstd-jni_amd/csrc/zj_decode_split.h"
 #include <stdlib.h>
+#include <string.h>
 
 extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap) {
     Grp<1> g;
@@ -11,6 +13,25 @@ extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned 
     ZjProf pf; pf.start(nullptr);
     u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf);
     free(lit); free(sh);
+    return r;
+}
+// split pipeline: prep -> lane sequence decode -> execute; frames the pipeline hands over go through the fused path
+extern "C" unsigned long long emu_decompress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, int* usedSplit) {
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    u64* tab = (u64*)calloc(ZD_SPLIT_CELLS, 8); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ~(u64)0;
+    if (usedSplit) *usedSplit = 0;
+    if (zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta)) {
+        ZDSeqLane m; m.init(src, tab, seqs, &meta);
+        while (m.st != 2) m.round();
+        r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf);
+        if (usedSplit && r != ~(u64)0) *usedSplit = 1;
+    }
+    if (r == ~(u64)0) { memset(sh, 0, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf); }
+    free(seqs); free(tab); free(lit); free(sh);
     return r;
 }
 extern "C" unsigned emu_dec_shared_bytes() { return (unsigned)sizeof(ZDecShared); }

@@ -96,3 +96,59 @@ def test_gpu_device_batch_synthetic(gpu, oracle_port, size, count):
     gen = gpu.batch.synth(count, size, 0)
     torch.cuda.synchronize()
     assert torch.equal(gen, want)
+
+
+@pytest.fixture
+def force_split(monkeypatch):
+    monkeypatch.setenv("ZJNI_DSPLIT_MIN", "1")        # every batch through prep -> lane sequence decode -> execute
+
+
+def test_gpu_split_pipeline_mixed_batch(gpu, oracle_ref, oracle_port, force_split):
+    """three-stage decoder: simple frames (one block, <= 64 KiB) next to frames it must hand to the fused kernel
+    (multi-block, multi-frame, raw blocks, truncated, corrupted) in ONE batch; results == fused path == reference"""
+    import random
+    rnd = random.Random(17)
+    items, caps = [], []
+    for name, data in edge_inputs():
+        for level in (1, 3):
+            items.append(oracle_ref.compress(data, level)); caps.append(len(data))
+    raw = gpu.synth_host(65536, 0, 64)
+    for i in range(64):
+        d = raw[i * 65536:(i + 1) * 65536][: rnd.choice([65536, 65536, 40000, 5000, 300, 17])]
+        items.append(oracle_ref.compress(d, rnd.choice([1, 3]))); caps.append(len(d))
+    items.append(golden("xml-sized-combined.zst")); caps.append(5_345_382)
+    good = oracle_ref.compress(raw[:65536], 3)
+    for cut in (1, 5):
+        items.append(good[:-cut]); caps.append(65536)
+    for pos in (7, 20, len(good) // 2, len(good) - 2):
+        bad = bytearray(good); bad[pos] ^= 0x5A
+        items.append(bytes(bad)); caps.append(65536)
+    items.append(good); caps.append(65535)               # destination one byte short
+    split = gpu.decompress_batch(items, caps)
+    import os
+    os.environ["ZJNI_DSPLIT_MIN"] = "1000000000"
+    fused = gpu.decompress_batch(items, caps)
+    for k, (a, b) in enumerate(zip(split, fused)):
+        if isinstance(b, Exception):
+            assert isinstance(a, Exception) and a.getErrorCode() == b.getErrorCode(), (k, a, b)
+        else:
+            assert a == b, k
+    for k, (z, cap) in enumerate(zip(items[: len(items) - 8], caps)):
+        assert split[k] == oracle_ref.decompress(z, cap), k
+
+
+def test_gpu_split_pipeline_device_batch(gpu, oracle_port, force_split):
+    import numpy as np
+    import torch
+    size, count = 65536, 2048
+    raw = gpu.synth_host(size, 0, count)
+    frames = oracle_port.compress_many(raw, size, 3, os.cpu_count() or 4)
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    off = np.zeros(count + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(f) for f in frames])
+    d_src = torch.from_numpy(blob.copy()).cuda(); d_soff = torch.from_numpy(off).cuda()
+    d_dst = torch.zeros(count * size, dtype=torch.uint8, device="cuda")
+    res = gpu.batch.decompress(d_src, d_soff, d_dst, gpu.batch.uniform_offsets(count, size, "cuda"))
+    torch.cuda.synchronize()
+    assert bool((res == size).all()), res[res != size][:8]
+    assert torch.equal(d_dst, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda())

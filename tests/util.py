@@ -14,6 +14,8 @@ def emu_lib():
     L = C.CDLL(os.path.join(d, "libzjni_emu.so"))
     L.emu_decompress.restype = C.c_ulonglong
     L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
+    L.emu_decompress_split.restype = C.c_ulonglong
+    L.emu_decompress_split.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.POINTER(C.c_int)]
     for fn in ("emu_compress", "emu_compress_split"):
         if hasattr(L, fn):
             getattr(L, fn).restype = C.c_ulonglong
@@ -27,6 +29,16 @@ def emu_decompress(L, frame, cap):
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]
+
+
+def emu_decompress_split(L, frame, cap):
+    """three-stage decode pipeline (prep -> lane sequence decode -> execute); returns (bytes | -code, took_split_path)"""
+    dst = C.create_string_buffer(max(cap, 1))
+    used = C.c_int(0)
+    r = L.emu_decompress_split(frame, len(frame), dst, cap, C.byref(used))
+    if r >= (1 << 63):
+        return -((1 << 64) - r), bool(used.value)
+    return dst.raw[:r], bool(used.value)
 
 
 def emu_compress(L, data, level, split=False):

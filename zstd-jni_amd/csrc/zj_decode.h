@@ -35,9 +35,6 @@
 #define ZD_CELL_EXTRA(c) (((c) >> 26) & 0x1Fu)
 
 struct ZDecShared {
-    u32 ll[512];
-    u32 ml[512];
-    u32 of[256];
     u16 huf[1u << ZD_HUF_LOG_MAX];
     u32 llBase[36];                 // LL_base (N/decompress/zstd_decompress_internal.h) per code
     u32 mlBase[53];
@@ -63,7 +60,12 @@ struct ZDecShared {
     u32 nbSeq, seqOff;              // sequences section start (rel. to block)
     u32 bN, bLitStart, bOutStart, bLitTotal, bOutTotal, seqDone, winLo;
     u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
+    // --- tANS tables last: the execute-only kernel of the split pipeline allocates the struct without them ---
+    u32 ll[512];
+    u32 ml[512];
+    u32 of[256];
 };
+#define ZD_SHARED_NO_FSE (sizeof(ZDecShared) - (512u + 512u + 256u) * 4u)
 
 // format constants (N/common/zstd_internal.h:113-165, N/decompress/zstd_decompress_internal.h:28-58)
 #define ZD_LL_BASE_INIT { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 }
@@ -297,7 +299,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
 // produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
 // range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
 template <class G>
-ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0) {
+ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot) {
 #if ZJ_ON_GPU
     u32 const k = g.lane();
     bool const valid = k < n;
@@ -308,6 +310,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         u32 const a = __shfl_up(sl, d, 64), b = __shfl_up(so, d, 64);
         if ((int)k >= d) { sl += a; so += b; }
     }
+    litTot = ZJ_UNI(__shfl(sl, 63, 64)); outTot = ZJ_UNI(__shfl(so, 63, 64));
     u32 const lp = lp0 + sl - ll;                 // literal source
     u32 const op = op0 + so - ll - ml;            // output position of this sequence's literals
     u32 const mp = op + ll;                       // match destination
@@ -369,8 +372,10 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     g.sync();
 #else
     u32 lp = lp0, op = op0;
+    litTot = 0; outTot = 0;
     for (u32 k = 0; k < n; k++) {
         u32 const ll = sh.sLit[k], ml = sh.sMl[k], off = sh.sOff[k];
+        litTot += ll; outTot += ll + ml;
         for (u32 j = 0; j < ll; j++) out[op + j] = lit[lp + j];
         lp += ll; op += ll;
         const u8* const m = out + op - off;
@@ -489,10 +494,11 @@ ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
 }
 
 // ------------------------------------------------------------------ block --------------------
-// Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
-// (frame-relative position `opos`).  Returns new opos (or sets sh.err).
+// Literals section of one compressed block: parses its header and regenerates the literals (raw: in place;
+// RLE / Huffman: into litScratch).  Returns where they are; sets sh.err and returns nullptr on error.
+// Publishes sh.litSize / litHdr / litCSize.
 template <class G>
-ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf) {
+ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -521,7 +527,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         if (err) sh.err = err;
     }
     g.sync();
-    if (ZJ_UNI(sh.err)) return opos;
+    if (ZJ_UNI(sh.err)) return nullptr;
 
     pf.mark(0);
     u32 const litType = ZJ_UNI(sh.litType), litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
@@ -538,7 +544,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 sh.litSrcOff = litHdr + h; sh.bN = nbSym;
             }
             g.sync();
-            if (ZJ_UNI(sh.err)) return opos;
+            if (ZJ_UNI(sh.err)) return nullptr;
             {   u32 const log = ZJ_UNI(sh.hufLog), nbSym = ZJ_UNI(sh.bN);
                 GRP_FOR(g, s, nbSym) {
                     u32 const w = sh.weights[s];
@@ -582,7 +588,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             if (err) sh.err = err;
         }
         g.sync();
-        if (ZJ_UNI(sh.err)) return opos;
+        if (ZJ_UNI(sh.err)) return nullptr;
         // ---- rounds: stage windows (all lanes) -> decode (<=4 lanes) -> flush (all lanes) ----
         {   u32 const maxN = ZJ_UNI(zj_max(zj_max(sh.hN[0], sh.hN[1]), zj_max(sh.hN[2], sh.hN[3])));
             u32 const rounds = (maxN + ZD_HSYM - 1) / ZD_HSYM;
@@ -615,13 +621,16 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
             GRP_SERIAL(g) { for (u32 t = 0; t < sh.litStreams; t++) { if (sh.hA[t] != sh.hS0[t]) sh.err = ZJ_E_CORRUPTION; } }
             g.sync();
-            if (ZJ_UNI(sh.err)) return opos;
+            if (ZJ_UNI(sh.err)) return nullptr;
         }
     }
+    return lit;
+}
 
-    pf.mark(2);
-    // ---- sequences header (lane 0): N/decompress/zstd_decompress_block.c:695-782 ----
-    u32 const seqSecOff = litHdr + litCSize;
+// Sequences section header + the three tANS tables into sh.ll/of/ml (N/decompress/zstd_decompress_block.c:695-782,
+// :485-603).  Publishes sh.nbSeq, sh.seqOff (first byte of the bitstream), sh.llLog/ofLog/mlLog; sets sh.err.
+template <class G>
+ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u32 seqSecOff) {
     GRP_SERIAL(g) {
         u32 err = 0, ip = seqSecOff, nbSeq = 0;
         if (ip >= bsize) err = ZJ_E_SRCSIZE_WRONG;
@@ -663,11 +672,8 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
         if (err) sh.err = err;
     }
     g.sync();
-    if (ZJ_UNI(sh.err)) return opos;
-
-    u32 const nbSeq = ZJ_UNI(sh.nbSeq);
-    u32 litUsed = 0;
-    if (nbSeq) {
+    if (ZJ_UNI(sh.err)) return;
+    if (ZJ_UNI(sh.nbSeq)) {
         // predefined / RLE tables (lanes 0..2, one table each)
         GRP_FOR(g, t, 3) {
             u32 const mode = sh.tblMode[t];
@@ -683,6 +689,24 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             }
         }
         g.sync();
+    }
+}
+
+// Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
+// (frame-relative position `opos`).  Returns new opos (or sets sh.err).
+template <class G>
+ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf) {
+    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
+    if (ZJ_UNI(sh.err)) return opos;
+    u32 const litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
+
+    pf.mark(2);
+    // ---- sequences header + tables ----
+    zd_seq_tables(g, sh, bsrc, bsize, litHdr + litCSize);
+    if (ZJ_UNI(sh.err)) return opos;
+    u32 const nbSeq = ZJ_UNI(sh.nbSeq);
+    u32 litUsed = 0;
+    if (nbSeq) {
         pf.mark(3);
         ZDecSeqPriv p;
         GRP_SERIAL(g) {
@@ -721,7 +745,8 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             {   u32 const n = ZJ_UNI(sh.bN);
                 u32 const lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
                 u32 const lt = ZJ_UNI(sh.bLitTotal), ot = ZJ_UNI(sh.bOutTotal);
-                zd_execute_batch(g, sh, out, lit, n, lp, op);
+                u32 lt2, ot2;
+                zd_execute_batch(g, sh, out, lit, n, lp, op, lt2, ot2);
                 litUsed = lp + lt; opos = op + ot;
             }
             pf.mark(5);

@@ -1,0 +1,258 @@
+// zj_decode_split.h — three-stage decoder for large batches of "simple" frames.
+//
+// The fused wave-per-frame decoder (zj_decode.h) spends most of its time on one lane: the tANS sequence decode
+// (N/decompress/zstd_decompress_block.c:1229-1347) is a dependent chain per frame, a wave issues it with 1 of
+// 64 lanes active, and three waves per SIMD already saturate the issue port (profiles/r01*_phase_cycles*).
+// For batches of thousands of frames the chain is moved to where it can use all lanes:
+//
+//   stage 1  zd_prep_frame   wave per frame   headers, NCounts, tANS tables -> HBM (8-byte cells), frame record
+//   stage 2  ZDSeqLane       LANE per frame   tANS sequence decode, 64 frames per wave in rounds: each round is
+//                                             one memory round trip (3 cells + 16 bitstream bytes) per lane
+//   stage 3  zd_exec_frame   wave per frame   literals (Huffman) + LZ77 execution of the decoded sequences
+//
+// "Simple" = one zstd frame filling its buffer, known content size <= 64 KiB, no dictionary, a single compressed
+// block — what the batched compressor emits for 64 KiB records.  Everything else (multi-block, multi-frame,
+// skippable, raw/RLE blocks, any error) is routed to the fused kernel, which stays the reference for behaviour
+// and error codes: stages 1-3 never report an error themselves, they hand the frame over.
+#pragma once
+
+#if ZJ_ON_GPU
+#define ZD_ROUND_FENCE5(a, b, c, d, e) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e))
+#else
+#define ZD_ROUND_FENCE5(a, b, c, d, e) ((void)0)
+#endif
+#define ZD_SPLIT_MAX_CONTENT 65536u
+#define ZD_SPLIT_MAXSEQ (ZD_SPLIT_MAX_CONTENT / 3u + 2u)      // every sequence emits >= 3 bytes (minimum match)
+#define ZD_SPLIT_CELLS 1280u                                  // LL 512 | OF 256 | ML 512
+#define ZD_SPLIT_OF 512u
+#define ZD_SPLIT_ML 768u
+#define ZD_SPLIT_TAB_BYTES (ZD_SPLIT_CELLS * 8u)
+#define ZD_SPLIT_SEQ_BYTES (ZD_SPLIT_MAXSEQ * 8u)
+
+// decode cell in HBM, the reference's ZSTD_seqSymbol (N/decompress/zstd_decompress_internal.h:68-73):
+// base | next << 32 | nbBits << 48 | extraBits << 56
+ZJ_DEV u64 zd_cell8(u32 base, u32 next, u32 nb, u32 extra) { return (u64)base | ((u64)next << 32) | ((u64)nb << 48) | ((u64)extra << 56); }
+// decoded sequence record: ll | ml << 18 | offset << 36 (all <= 2^17 for content <= 64 KiB)
+ZJ_DEV u64 zd_seq_pack(u32 ll, u32 ml, u32 off) { return (u64)ll | ((u64)ml << 18) | ((u64)off << 36); }
+
+struct ZDMeta {
+    u32 blockOff, blockSize;      // block body within the frame buffer
+    u32 seqOff;                   // first byte of the sequence bitstream, relative to the block body
+    u32 nbSeq, litSize;
+    u32 logs;                     // llLog | ofLog << 8 | mlLog << 16
+    u32 contentSize, blockSizeMax;
+    u32 status;                   // stage 2: 0 ok, 1 hand over to the fused kernel
+    u32 pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1.  Returns true (wave-uniform) when the frame is simple and its tables/record were written.
+template <class G>
+ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u64* tab, ZDMeta* meta) {
+    GRP_SERIAL(g) {
+        u32 ok = 0;
+        sh.err = 0; sh.seqValid = 0; sh.hufValid = 0;
+        // frame header, N/decompress/zstd_decompress.c:447-557
+        if (srcSize >= 16 && ld32(src) == 0xFD2FB528u) {
+            u32 const fhd = src[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
+            u32 const fcsSz = fcsid == 0 ? single : (1u << fcsid);
+            u32 const hdr = 5 + !single + fcsSz;
+            if (!(fhd & 8) && didc == 0 && fcsSz != 0 && fcsSz <= 4 && srcSize >= hdr + 3) {
+                u32 pos = 5; u64 window = 0; u32 content = 0; bool wok = true;
+                if (!single) { u32 const wd = src[pos++], wl = (wd >> 3) + 10; if (wl > 27) wok = false; window = (u64)1 << wl; window += (window >> 3) * (wd & 7); }
+                if (fcsid == 0) content = src[pos]; else if (fcsid == 1) content = ld16(src + pos) + 256; else content = ld32(src + pos);
+                if (single) window = content;
+                u32 const bh = ld24(src + hdr), last = bh & 1, type = (bh >> 1) & 3, sz = bh >> 3;
+                u32 const tail = ((fhd >> 2) & 1) ? 4u : 0u;
+                u32 const bmax = window < ZD_BLOCK_MAX ? (u32)window : ZD_BLOCK_MAX;
+                if (wok && content <= ZD_SPLIT_MAX_CONTENT && content <= dstCap && last && type == 2 && sz >= 2 && sz <= bmax
+                    && (u64)hdr + 3 + sz + tail == srcSize) {
+                    // literals section header, N/decompress/zstd_decompress_block.c:134-340 (sizes only)
+                    const u8* const b = src + hdr + 3;
+                    u32 const b0 = b[0], lt = b0 & 3, fmt = (b0 >> 2) & 3; u32 lh = 0, n = 0, c = 0; bool lok = true;
+                    if (lt < 2) {
+                        if (fmt == 0 || fmt == 2) { lh = 1; n = b0 >> 3; } else if (fmt == 1) { lh = 2; n = ld16(b) >> 4; }
+                        else if (sz < 3) lok = false; else { lh = 3; n = ld24(b) >> 4; }
+                        c = (lt == 0) ? n : 1;
+                    } else if (sz < 5 || lt == 3) lok = false;
+                    else {
+                        u32 const lhc = ld32(b);
+                        if (fmt < 2) { lh = 3; n = (lhc >> 4) & 0x3FF; c = (lhc >> 14) & 0x3FF; }
+                        else if (fmt == 2) { lh = 4; n = (lhc >> 4) & 0x3FFF; c = lhc >> 18; }
+                        else { lh = 5; n = (lhc >> 4) & 0x3FFFF; c = (lhc >> 22) + ((u32)b[4] << 10); }
+                    }
+                    if (lok && n <= bmax && lh + c < sz) {
+                        ok = 1;
+                        sh.hdrSize = hdr + 3; sh.blkSize = sz; sh.litSize = n; sh.litHdr = lh; sh.litCSize = c;
+                        sh.contentSize = content; sh.blockSizeMax = bmax;
+                    }
+                }
+            }
+        }
+        sh.blkType = ok;
+    }
+    g.sync();
+    if (!ZJ_UNI(sh.blkType)) return false;
+    u32 const boff = ZJ_UNI(sh.hdrSize), bsize = ZJ_UNI(sh.blkSize);
+    zd_seq_tables(g, sh, src + boff, bsize, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize));
+    g.sync();
+    u32 const nbSeq = ZJ_UNI(sh.nbSeq);
+    if (ZJ_UNI(sh.err) || nbSeq > ZD_SPLIT_MAXSEQ) { GRP_SERIAL(g) { sh.err = 0; } g.sync(); return false; }
+    if (nbSeq) {
+        u32 const llLog = ZJ_UNI(sh.llLog), ofLog = ZJ_UNI(sh.ofLog), mlLog = ZJ_UNI(sh.mlLog);
+        GRP_FOR(g, u, 1u << llLog) { u32 const c = sh.ll[u], s = ZD_CELL_SYM(c); tab[u] = zd_cell8(zd_k_ll_base[s], ZD_CELL_NEXT(c), ZD_CELL_NB(c), ZD_CELL_EXTRA(c)); }
+        GRP_FOR(g, u, 1u << ofLog) { u32 const c = sh.of[u], s = ZD_CELL_SYM(c); tab[ZD_SPLIT_OF + u] = zd_cell8(s > 1 ? (1u << s) - 3u : s, ZD_CELL_NEXT(c), ZD_CELL_NB(c), s); }
+        GRP_FOR(g, u, 1u << mlLog) { u32 const c = sh.ml[u], s = ZD_CELL_SYM(c); tab[ZD_SPLIT_ML + u] = zd_cell8(zd_k_ml_base[s], ZD_CELL_NEXT(c), ZD_CELL_NB(c), ZD_CELL_EXTRA(c)); }
+    }
+    GRP_SERIAL(g) {
+        ZDMeta m;
+        m.blockOff = boff; m.blockSize = bsize; m.seqOff = sh.seqOff; m.nbSeq = nbSeq; m.litSize = sh.litSize;
+        m.logs = sh.llLog | (sh.ofLog << 8) | (sh.mlLog << 16);
+        m.contentSize = (u32)sh.contentSize; m.blockSizeMax = sh.blockSizeMax; m.status = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0;
+        *meta = m;
+    }
+    zj_mem_order();
+    g.sync();
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2.  One lane per frame; round() is one memory round trip for every lane of the wave.
+// Bit positions are relative to the frame buffer.  N/decompress/zstd_decompress_block.c:1229-1347, :1615-1690.
+struct ZDSeqLane {
+    const u8* src; const u64* tab; u64* seqs; ZDMeta* meta;
+    i32 A, S0; u32 sLL, sOF, sML, rep0, rep1, rep2, i, nbSeq, opos, lpos, litSize, cap, logs, endByte;
+    u32 st;                       // 0 start, 1 running, 2 done
+    u32 bad;
+
+    ZJ_DEV_MEMBER void init(const u8* s, const u64* t, u64* q, ZDMeta* m) {
+        src = s; tab = t; seqs = q; meta = m;
+        ZDMeta const h = *m;
+        nbSeq = h.nbSeq; litSize = h.litSize; logs = h.logs;
+        cap = zj_min(h.contentSize, h.blockSizeMax);
+        S0 = (i32)((h.blockOff + h.seqOff) * 8u); endByte = h.blockOff + h.blockSize; A = S0;
+        rep0 = 1; rep1 = 4; rep2 = 8; i = 0; opos = 0; lpos = 0; bad = 0; sLL = sOF = sML = 0;
+        st = nbSeq ? 0u : 2u;
+    }
+    ZJ_DEV_MEMBER void finish() {
+        meta->status = bad ? 1u : 0u;
+        st = 2;
+    }
+    // top 64 bits below bit position `at` out of the 16 bytes [e-16, e) (hi = upper 8 bytes); at in (8e-128+63, 8e]
+    ZJ_DEVM u64 top64(u64 hi, u64 lo, u32 e, u32 at) {
+        u32 const s = 8u * e - at;                  // unused bits above `at`
+        if (s == 0) return hi;
+        if (s < 64u) return (hi << s) | (lo >> (64u - s));
+        return s == 64u ? lo : (lo << (s - 64u));
+    }
+    ZJ_DEV_MEMBER void round() {
+        // ---- addresses ----
+        u32 const e = (st == 0) ? endByte : (((u32)A + 7u) >> 3);
+        u32 const wp = e >= 16u ? e - 16u : 0u;
+        u32 const iLL = sLL, iOF = ZD_SPLIT_OF + sOF, iML = ZD_SPLIT_ML + sML;
+        // ---- one batch of loads ----
+        u64 lo = ld64(src + wp), hi = ld64(src + wp + 8);
+        u64 const cl = tab[iLL], co = tab[iOF], cm = tab[iML];
+        ZD_ROUND_FENCE5(lo, hi, cl, co, cm);
+        if (e < 16u) {                               // stream within 16 bytes of the buffer start: align [e-16, e) by hand
+            u32 const k = (16u - e) * 8u;            // shift left by k bits (8..120)
+            if (k < 64u) { hi = (hi << k) | (lo >> (64u - k)); lo <<= k; } else { hi = k == 64u ? lo : (lo << (k - 64u)); lo = 0; }
+        }
+        if (st == 0) {
+            // last byte carries the end mark; then the three initial states LL, OF, ML (:1640-1642)
+            u32 const lastByte = (u32)(hi >> 56);
+            if (lastByte == 0 || (u32)S0 >= 8u * endByte) { bad = 1; finish(); return; }
+            A = (i32)(8u * (endByte - 1u) + zj_hibit(lastByte));
+            u32 const a = logs & 0xFF, b = (logs >> 8) & 0xFF, c = (logs >> 16) & 0xFF;
+            if (A - (i32)(a + b + c) < S0) { bad = 1; finish(); return; }
+            u64 v = top64(hi, lo, e, (u32)A);
+            sLL = a ? (u32)(v >> (64u - a)) : 0u; v <<= a;
+            sOF = b ? (u32)(v >> (64u - b)) : 0u; v <<= b;
+            sML = c ? (u32)(v >> (64u - c)) : 0u;
+            A -= (i32)(a + b + c);
+            st = 1;
+            return;
+        }
+        if (st != 1) return;
+        u32 const ofx = (u32)(co >> 56), mlx = (u32)(cm >> 56), llx = (u32)(cl >> 56);
+        bool const last = (i + 1u == nbSeq);
+        u32 const nl = last ? 0u : (u32)(cl >> 48) & 0xFFu, nm = last ? 0u : (u32)(cm >> 48) & 0xFFu, no = last ? 0u : (u32)(co >> 48) & 0xFFu;
+        u32 const T1 = ofx + mlx + llx, T = T1 + nl + nm + no;
+        if (A - (i32)T < S0) { bad = 1; finish(); return; }
+#define ZD_TAKE(v, nb) ((u32)(((v) >> 1) >> (63u - (nb))))
+        u64 v = top64(hi, lo, e, (u32)A);
+        u32 const ofv = ZD_TAKE(v, ofx); v <<= ofx;
+        u32 const mlv = ZD_TAKE(v, mlx); v <<= mlx;
+        u32 const llv = ZD_TAKE(v, llx);
+        u64 v2 = top64(hi, lo, e, (u32)A - T1);
+        u32 const vl = ZD_TAKE(v2, nl); v2 <<= nl;
+        u32 const vm = ZD_TAKE(v2, nm); v2 <<= nm;
+        u32 const vo = ZD_TAKE(v2, no);
+#undef ZD_TAKE
+        A -= (i32)T;
+        u32 const llen = (u32)cl + llv, mlen = (u32)cm + mlv;
+        u32 offset;
+        if (ofx > 1u) { offset = (u32)co + ofv; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+        else {
+            u32 const ll0 = (llen == 0u);
+            if (ofx == 0u) { if (ll0) { offset = rep1; rep1 = rep0; rep0 = offset; } else offset = rep0; }
+            else {
+                u32 const idx = 1u + ll0 + ofv;
+                u32 t = (idx == 3u) ? rep0 - 1u : (idx == 1u ? rep1 : rep2);
+                t -= !t;
+                if (idx != 1u) rep2 = rep1;
+                rep1 = rep0; rep0 = t; offset = t;
+            }
+        }
+        if (!last) { sLL = ((u32)(cl >> 32) & 0xFFFFu) + vl; sML = ((u32)(cm >> 32) & 0xFFFFu) + vm; sOF = ((u32)(co >> 32) & 0xFFFFu) + vo; }
+        // the checks of ZSTD_execSequence (:1001-1096): literals available, room in the block, offset inside the output
+        if (llen > litSize - lpos || (u64)opos + llen + mlen > cap || offset > opos + llen) { bad = 1; finish(); return; }
+        seqs[i] = zd_seq_pack(llen, mlen, offset);
+        lpos += llen; opos += llen + mlen; i++;
+        if (i == nbSeq) { if (A != S0) bad = 1; finish(); }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Stage 3.  Returns the decoded size, or ~0 (wave-uniform) to hand the frame to the fused kernel.
+template <class G>
+ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, const ZDMeta* meta, const u64* seqs, u8* litScratch, ZjProf& pf) {
+    GRP_SERIAL(g) {
+        ZDMeta const m = *meta;
+        sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0;
+        sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.nbSeq = m.nbSeq; sh.blockSizeMax = m.blockSizeMax; sh.contentSize = m.contentSize;
+    }
+    g.sync();
+    if (ZJ_UNI(sh.err)) return ~(u64)0;
+    const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);
+    u32 const nbSeq = ZJ_UNI(sh.nbSeq), content = (u32)zj_uni64(sh.contentSize);
+    u32 const cap = zj_min(content, ZJ_UNI(sh.blockSizeMax));
+    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
+    if (ZJ_UNI(sh.err)) return ~(u64)0;
+    pf.mark(2);
+    u32 const litSize = ZJ_UNI(sh.litSize);
+    u32 lp = 0, op = 0;
+    for (u32 base = 0; base < nbSeq; base += ZD_SEQ_BATCH) {
+        u32 const cnt = zj_min(ZD_SEQ_BATCH, nbSeq - base);
+        GRP_FOR(g, k, cnt) {
+            u64 const q = seqs[base + k];
+            sh.sLit[k] = (u32)q & 0x3FFFFu; sh.sMl[k] = (u32)(q >> 18) & 0x3FFFFu; sh.sOff[k] = (u32)(q >> 36);
+        }
+        g.sync();
+        u32 lt, ot;
+        zd_execute_batch(g, sh, dst, lit, cnt, lp, op, lt, ot);
+        lp += lt; op += ot;
+        g.sync();
+    }
+    pf.mark(5);
+    {   u32 const rest = litSize - lp;               // stage 2 checked lp <= litSize
+        if ((u64)op + rest > cap) return ~(u64)0;
+        grp_copy_wide(g, dst + op, lit + lp, rest);
+        op += rest;
+        zj_mem_order();
+    }
+    g.sync();
+    pf.mark(6);
+    if (op != content) return ~(u64)0;
+    return op;
+}

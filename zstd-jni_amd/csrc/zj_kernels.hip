@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include "../../include/zjni_amd.h"
 #include "zj_decode.h"
+#include "zj_decode_split.h"
 #include "zj_encode.h"
 #include "zj_synth.h"
 
@@ -26,20 +27,79 @@ __device__ __forceinline__ u32 zj_next_index(u32* counter) {
     return (u32)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// Fused wave-per-frame decoder: frame i of the batch, or (list != nullptr) the frames a list names.
 __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
-                                                        u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof) {
+                                                        u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof,
+                                                        const u32* __restrict__ list, const u32* listCount) {
     __shared__ ZDecShared sh;
     ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
+    u32 const count = list ? ZJ_UNI(*listCount) : n;
     for (;;) {
-        u32 const i = zj_next_index(counter);      // wave-uniform (SGPR)
-        if (i >= n) break;
+        u32 const k = zj_next_index(counter);      // wave-uniform (SGPR)
+        if (k >= count) break;
+        u32 const i = list ? ZJ_UNI(list[k]) : k;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
         u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf);
         pf.mark(8);
         if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
+
+// ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
+__global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
+                                                          u32 n, u32* counter, u64* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts) {
+    __shared__ ZDecShared sh;
+    Grp<64> g;
+    for (;;) {
+        u32 const i = zj_next_index(counter);
+        if (i >= n) break;
+        u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
+        u64 const cap = d1 - d0;
+        bool const simple = zd_prep_frame(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
+                                          tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i);
+        if (threadIdx.x == 0) { if (simple) listA[atomicAdd(&listCounts[0], 1u)] = i; else listB[atomicAdd(&listCounts[1], 1u)] = i; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
+                                                         const u32* countPtr, u32* workCounter, const u64* tabs, u64* seqs, ZDMeta* metas) {
+    u32 const count = *countPtr;
+    ZDSeqLane m; m.st = 2;
+    for (;;) {
+        if (m.st == 2) {
+            u32 const k = atomicAdd(workCounter, 1u);
+            if (k >= count) break;
+            u32 const i = list[k];
+            m.init(src + srcOff[i], tabs + (size_t)i * ZD_SPLIT_CELLS, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, metas + i);
+            continue;
+        }
+        m.round();
+    }
+}
+
+__global__ __launch_bounds__(64) void zj_dec_exec_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
+                                                          const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
+                                                          const u32* countPtr, u32* workCounter, const ZDMeta* metas, const u64* seqs, u8* scratch,
+                                                          u32* listB, u32* listBCount, unsigned long long* prof) {
+    ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
+    ZjProf pf; pf.start(prof);
+    Grp<64> g;
+    u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 const k = zj_next_index(workCounter);
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const r = zd_exec_frame(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf);
+        pf.mark(8);
+        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; }
         __syncthreads();
     }
 }
@@ -49,7 +109,6 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__
 // fit the LDS of the common case (list A) and the few that need more (list B; e.g. level-1 inputs of
 // 8-16 KiB use hashLog 15, inputs > 64 KiB use 4-byte positions).  The same persistent kernel then runs
 // once per list — with 128 KiB of LDS for list B, exiting at once when that list is empty.
-extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
 
 __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restrict__ srcOff, u64* __restrict__ result, u32 n, u32 level,
                                                                u32 ldsA, u32* counters, u32* listA, u32* listB) {
@@ -168,6 +227,8 @@ struct DevState {
     u32* encList = nullptr; size_t encListCap = 0;   // two index lists of encListCap entries each
     u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
     int matchGrid = 0;
+    int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
+    u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
@@ -208,8 +269,12 @@ DevState* get_state(int ordinal) {
         d.encGridBig = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_enc_match_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
         d.matchGrid = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_seq_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
+        d.dseqGrid = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
+        d.dexecGrid = d.numCU * perCU;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
-        if (hipMalloc(&d.decScratch, (size_t)d.decGrid * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
+        if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
         if (getenv("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
         d.ordinal = ordinal;
@@ -263,6 +328,7 @@ void zjni_shutdown(void) {
         (void)hipFree(d.counters); (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
+        if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
@@ -341,10 +407,39 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     u32 const grid = (u32)(n < (size_t)d->decGrid ? n : (size_t)d->decGrid);
+    // Large batches: the three-stage pipeline (tANS decode lane-per-frame); whatever is not a simple frame, and
+    // anything that fails on the way, ends on list B and goes through the fused kernel.  Small batches: fused only.
+    size_t splitMin = 4096;
+    if (const char* ov = getenv("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
+    if (n >= splitMin) {
+        size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
+        size_t const need = tabBytes + seqBytes + metaBytes + 2 * listBytes + 256;
+        if (d->dsplitBufCap < need) {
+            if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
+            if (hipMalloc(&d->dsplitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+            d->dsplitBufCap = need;
+        }
+        u64* const tabs = (u64*)d->dsplitBuf; u64* const seqs = (u64*)(d->dsplitBuf + tabBytes);
+        ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
+        u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
+        u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused
+        if (hipMemsetAsync(c, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
+                           (u32)n, c + 2, tabs, metas, listA, listB, c);
+        u32 const waves = (u32)((n + 63) / 64);
+        hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
+                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u64*)tabs, seqs, metas);
+        hipLaunchKernelGGL(zj_dec_exec_kernel, dim3((u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid)), dim3(64), ZD_SHARED_NO_FSE, st,
+                           (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
+                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof);
+        hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1));
+        return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+    }
+    if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof);
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 

@@ -62,6 +62,24 @@ ZJ_DEV u32 zl_common_back8(u64 p, u64 q) { u64 const x = p ^ q; return x ? ((u32
 #define ZL_PROF_T2() ((void)0)
 #endif
 enum { ZL_LOADW = 0, ZL_START, ZL_SEARCH, ZL_SEARCH_B, ZL_COUNT, ZL_BACK, ZL_POST, ZL_DONE };
+// ZSTD_hashPtr without the switch on minMatch: every variant is ((bytes << s) * prime) >> (64 - hBits) with a
+// per-frame (s, prime) — minMatch 4 is the 64-bit form of its 32-bit product — and hBits <= 17 only needs the
+// high dword of the product: three 32-bit multiplies, no branches (N/compress/zstd_compress_internal.h:898-960).
+struct ZLHash { u32 sh, plo, phi, rsh; };
+ZJ_DEV ZLHash zl_hash_of(u32 mls, u32 hBits) {
+    ZLHash h; u64 p;
+    if (mls == 5) { h.sh = 24; p = 889523592379ULL; } else if (mls == 6) { h.sh = 16; p = 227718039650203ULL; }
+    else if (mls == 7) { h.sh = 8; p = 58295818150454627ULL; } else if (mls == 8) { h.sh = 0; p = 0xCF1BBCDCB7A56463ULL; }
+    else { h.sh = 32; p = 2654435761ULL; }
+    h.plo = (u32)p; h.phi = (u32)(p >> 32); h.rsh = 32u - hBits;
+    return h;
+}
+ZJ_DEV u32 zl_mulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
+ZJ_DEV u32 zl_prod_hi(const ZLHash& h, u64 w) {            // high dword of ((w << sh) * prime)
+    u64 const x = w << h.sh; u32 const xlo = (u32)x, xhi = (u32)(x >> 32);
+    return zl_mulhi(xlo, h.plo) + xlo * h.phi + xhi * h.plo;
+}
+ZJ_DEV u32 zl_hash(const ZLHash& h, u64 w) { return zl_prod_hi(h, w) >> h.rsh; }
 enum { ZL_EN_COUNT = 1, ZL_EN_POST = 2, ZL_EN_START = 4 };   // which non-search states a round serves
 enum { ZC_REP1 = 0, ZC_LONG, ZC_SHORT, ZC_SHORT_L1, ZC_REPLOOP, ZC_FOUND };
 
@@ -70,25 +88,27 @@ enum { ZC_REP1 = 0, ZC_LONG, ZC_SHORT, ZC_SHORT_L1, ZC_REPLOOP, ZC_FOUND };
 template <class E>
 struct ZLaneD {
     typedef typename E::T Ent;
-    const u8* src; u32 n, ilimit; Ent* HL; Ent* HS; u32 hBitsL, hBitsS, mls;
+    const u8* src; u32 n, ilimit; Ent* HL; Ent* HS; ZLHash hL, hS;
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip, ip1, anchor, off1, off2, step, nextStep, curr;
-    u64 w, w1; u32 el0, es0, el1, hl0, hs0, hl1, hs1;
+    u64 w, w1; u32 el0, es0, el1, hl0, hs0, hl1, hs1, tl0, tl1;   // tl: long-table tag of w / w1
     u32 ca, cb, acc;                                  // forward count in progress
     u32 mpos, mpos2, mLength, offset, bk, bk2;       // chosen match / candidate at ip1 / backward extension
     bool more, more2, cvalid, needBack, needCand, chk;
 
-    ZJ_DEVM u32 hashL(u64 v, u32 bits) { return ze_hash_w(v, bits, 8); }
 
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
-        src = s; n = size; ilimit = size - 8u; hBitsL = p.hashLog; hBitsS = p.chainLog; mls = p.minMatch;
+        src = s; n = size; ilimit = size - 8u; hL = zl_hash_of(8, p.hashLog); hS = zl_hash_of(p.minMatch, p.chainLog);
         HL = (Ent*)table; HS = HL + (1u << p.hashLog);
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
         needBack = needCand = more = more2 = cvalid = false;
         st = ZL_LOADW;
     }
+    // long-table index and tag from ONE product: index = top hashLog bits, tag = the next 15 bits (hashLog <= 17)
+    ZJ_DEV_MEMBER void hash_long(u64 v, u32& idx, u32& tag) const { u32 const p = zl_prod_hi(hL, v); idx = p >> hL.rsh; tag = (p >> (hL.rsh - 15u)) & 0x7FFFu; }
+    ZJ_DEV_MEMBER void put_long(u64 v, u32 pos1) { u32 i, t; hash_long(v, i, t); HL[i] = E::make(pos1, t); }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
     // outer-loop header of the reference: reset the step and make sure one more position fits
     ZJ_DEV_MEMBER void outer() {
@@ -100,7 +120,7 @@ struct ZLaneD {
     ZJ_DEV_MEMBER void fin() {             // a long/short match is final: apply the backward extension, store it
         ip -= bk; mLength += bk;
         off2 = off1; off1 = offset;
-        if (step < 4u) HL[hl1] = E::make(ip1 + 1u, ze_tag8(w1));
+        if (step < 4u) HL[hl1] = E::make(ip1 + 1u, tl1);
         ze_store(o, anchor, ip - anchor, offset + 3u, mLength);
         advance();
     }
@@ -132,7 +152,7 @@ struct ZLaneD {
         if (st == ZL_SEARCH) {
             ZE_COUNT_ITER();
             curr = ip;
-            u32 const tl = ze_tag8(w), ts = ze_tag4((u32)w);
+            u32 const tl = tl0, ts = ze_tag4((u32)w);
             HL[hl0] = E::make(curr + 1u, tl); HS[hs0] = E::make(curr + 1u, ts);
             ml0 = E::maybe(el0, tl); ms0 = E::maybe(es0, ts);
             pa0 = ip + 1u - off1; v0 = true;
@@ -140,7 +160,7 @@ struct ZLaneD {
             pa2 = E::pos(es0) - 1u; v2 = ms0;
             ip2 = ip1 + step + ((ip1 >= nextStep) ? 1u : 0u);
             pa3 = ip2; v3 = ip2 <= ilimit;
-            hl1 = hashL(w1, hBitsL); hs1 = ze_hash_w(w1, hBitsS, mls);
+            hash_long(w1, hl1, tl1); hs1 = zl_hash(hS, w1);
             ti0 = hl1; ti1 = hs1; vt = true;
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
@@ -155,7 +175,7 @@ struct ZLaneD {
             pa0 = ip; pa1 = ip + 1u; v0 = v1 = true;
             pa3 = ip - off2; v3 = chk && off2 > 0u;
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            hl0 = hashL(w, hBitsL); hs0 = ze_hash_w(w, hBitsS, mls);
+            hash_long(w, hl0, tl0); hs0 = zl_hash(hS, w);
             ti0 = hl0; ti1 = hs0; vt = true;
         }
         // ---- phase 2: one batch of loads for all states ----
@@ -165,10 +185,13 @@ struct ZLaneD {
         if (!vt) { ti0 = 0; ti1 = 0; }
         u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
-        u64 const r0 = ld64(src + q0), r1 = ld64(src + q1), r2 = ld64(src + q2), r3 = ld64(src + q3);
-        u64 const r4 = (K & ZL_EN_COUNT) ? ld64(src + q4) : 0;
-        u64 const rb0 = (K & ZL_EN_COUNT) ? ld64(src + qb0) : 0, rb1 = (K & ZL_EN_COUNT) ? ld64(src + qb1) : 0;
-        u32 const t0 = (u32)HL[ti0], t1 = (u32)HS[ti1];
+        // predicated: a slot nobody asked for costs no transaction (the fence below keeps the loads together)
+        u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t0 = 0, t1 = 0;
+        if (on) { r0 = ld64(src + q0); r3 = ld64(src + q3); t0 = (u32)HL[ti0]; t1 = (u32)HS[ti1]; }
+        if (v1) r1 = ld64(src + q1);
+        if (v2) r2 = ld64(src + q2);
+        if ((K & ZL_EN_COUNT) && v4) r4 = ld64(src + q4);
+        if ((K & ZL_EN_COUNT) && vb) { rb0 = ld64(src + qb0); rb1 = ld64(src + qb1); }
         ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t0, t1);
         ZL_PROF_T2();
         u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
@@ -186,10 +209,10 @@ struct ZLaneD {
             } else if (ms0 && (u32)d2 == (u32)w) {
                 mpos = E::pos(es0) - 1u;
                 begin_count(ip + 4u, mpos + 4u, ZC_SHORT); needBack = true;
-                needCand = (E::pos(el1) > 1u) && E::maybe(el1, ze_tag8(w1)); mpos2 = E::pos(el1) - 1u; cvalid = false;
+                needCand = (E::pos(el1) > 1u) && E::maybe(el1, tl1); mpos2 = E::pos(el1) - 1u; cvalid = false;
             } else {
                 if (ip1 >= nextStep) { step++; nextStep += 256u; }
-                ip = ip1; ip1 = ip2; w = w1; w1 = d3; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1;
+                ip = ip1; ip1 = ip2; w = w1; w1 = d3; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1; tl0 = tl1;
                 if (ip1 > ilimit) finish();
             }
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
@@ -224,8 +247,8 @@ struct ZLaneD {
             } else {                                   // ZC_REPLOOP: immediate repcode after a match
                 u32 const rLength = acc + 4u;
                 { u32 const t = off2; off2 = off1; off1 = t; }
-                HS[ze_hash_w(w, hBitsS, mls)] = E::make(ip + 1u, ze_tag4((u32)w));
-                HL[hashL(w, hBitsL)] = E::make(ip + 1u, ze_tag8(w));
+                HS[zl_hash(hS, w)] = E::make(ip + 1u, ze_tag4((u32)w));
+                put_long(w, ip + 1u);
                 ze_store(o, anchor, 0u, 1u, rLength);
                 ip += rLength; anchor = ip;
                 if (ip <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
@@ -234,10 +257,10 @@ struct ZLaneD {
             u64 const wa = d0, q0 = d1, q1 = d2;
             u64 const wb = q0, wc = (q0 >> 8) | (q1 << 56);
             u32 const ins = curr + 2u;
-            HL[hashL(wa, hBitsL)] = E::make(ins + 1u, ze_tag8(wa));
-            HL[hashL(wb, hBitsL)] = E::make(ip - 2u + 1u, ze_tag8(wb));
-            HS[ze_hash_w(wa, hBitsS, mls)] = E::make(ins + 1u, ze_tag4((u32)wa));
-            HS[ze_hash_w(wc, hBitsS, mls)] = E::make(ip - 1u + 1u, ze_tag4((u32)wc));
+            put_long(wa, ins + 1u);
+            put_long(wb, ip - 2u + 1u);
+            HS[zl_hash(hS, wa)] = E::make(ins + 1u, ze_tag4((u32)wa));
+            HS[zl_hash(hS, wc)] = E::make(ip - 1u + 1u, ze_tag4((u32)wc));
             w = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
             if ((off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
@@ -264,7 +287,7 @@ struct ZLaneD {
 template <class E>
 struct ZLaneF {
     typedef typename E::T Ent;
-    const u8* src; u32 n, ilimit; Ent* T; u32 hlog, mls;
+    const u8* src; u32 n, ilimit; Ent* T; ZLHash hT;
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip0, ip1, ip2, ip3, anchor, rep1, rep2, step, nextStep, cur0;
@@ -273,7 +296,7 @@ struct ZLaneF {
     bool more, needBack, chk;
 
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
-        src = s; n = size; ilimit = size - 8u; hlog = p.hashLog; mls = p.minMatch; T = (Ent*)table;
+        src = s; n = size; ilimit = size - 8u; hT = zl_hash_of(p.minMatch, p.hashLog); T = (Ent*)table;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = false; bk = 0;
         st = ZL_LOADW;
@@ -320,8 +343,8 @@ struct ZLaneF {
             ZE_COUNT_ITER();
             t0tag = ze_tag4((u32)w0); t1tag = ze_tag4((u32)w1);
             cur0 = ip0;
-            T[ze_hash_w(w0, hlog, mls)] = E::make(ip0 + 1u, t0tag);
-            ti = ze_hash_w(w1, hlog, mls); vt = true;
+            T[zl_hash(hT, w0)] = E::make(ip0 + 1u, t0tag);
+            ti = zl_hash(hT, w1); vt = true;
             m0 = E::maybe(eX, t0tag);
             pa0 = ip2 - 1u - rep1; v0 = true;          // byte before the repcode candidate + its 4 bytes
             pa1 = ip2; pa2 = ip3; v1 = v2 = true;
@@ -331,7 +354,7 @@ struct ZLaneF {
             t1tag = ze_tag4((u32)w1);
             m1 = E::maybe(eY, t1tag);
             pa3 = E::pos(eY) - 1u; v3 = m1;
-            ti = ze_hash_w(w2, hlog, mls); vt = true;
+            ti = zl_hash(hT, w2); vt = true;
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
             if (needBack) { vb = true; bp0 = ip0; bp1 = mpos; }
@@ -344,7 +367,7 @@ struct ZLaneF {
             pa0 = ip0; pa1 = ip0 + 1u; v0 = v1 = true;
             pa3 = ip0 - rep2; v3 = chk && rep2 > 0u;
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            ti = ze_hash_w(w0, hlog, mls); vt = true;
+            ti = zl_hash(hT, w0); vt = true;
         }
         ZL_PROF_T1();
         if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
@@ -352,9 +375,14 @@ struct ZLaneF {
         if (!vt) ti = 0;
         u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
-        u64 const r0 = ld64(src + q0), r1 = ld64(src + q1), r2 = ld64(src + q2), r3 = ld64(src + q3), r4 = ld64(src + q4);
-        u64 const rb0 = (K & ZL_EN_COUNT) ? ld64(src + qb0) : 0, rb1 = (K & ZL_EN_COUNT) ? ld64(src + qb1) : 0;
-        u32 const t = (u32)T[ti];
+        u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t = 0;
+        if (v0) r0 = ld64(src + q0);
+        if (v1) r1 = ld64(src + q1);
+        if (v2) r2 = ld64(src + q2);
+        if (v3) r3 = ld64(src + q3);
+        if (v4) r4 = ld64(src + q4);
+        if ((K & ZL_EN_COUNT) && vb) { rb0 = ld64(src + qb0); rb1 = ld64(src + qb1); }
+        if (vt) t = (u32)T[ti];
         ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t, t);
         ZL_PROF_T2();
         u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
@@ -402,7 +430,7 @@ struct ZLaneF {
             else {                                     // ZC_REPLOOP
                 u32 const rLength = acc + 4u;
                 { u32 const x = rep2; rep2 = rep1; rep1 = x; }
-                T[ze_hash_w(w0, hlog, mls)] = E::make(ip0 + 1u, ze_tag4((u32)w0));
+                T[zl_hash(hT, w0)] = E::make(ip0 + 1u, ze_tag4((u32)w0));
                 ip0 += rLength;
                 ze_store(o, anchor, 0u, 1u, rLength);
                 anchor = ip0;
@@ -410,8 +438,8 @@ struct ZLaneF {
             }
         } else if ((K & ZL_EN_POST) && st == ZL_POST) {
             u64 const wa = d0, q0 = d1, q1 = d2;
-            T[ze_hash_w(wa, hlog, mls)] = E::make(cur0 + 2u + 1u, ze_tag4((u32)wa));
-            T[ze_hash_w(q0, hlog, mls)] = E::make(ip0 - 2u + 1u, ze_tag4((u32)q0));
+            T[zl_hash(hT, wa)] = E::make(cur0 + 2u + 1u, ze_tag4((u32)wa));
+            T[zl_hash(hT, q0)] = E::make(ip0 - 2u + 1u, ze_tag4((u32)q0));
             w0 = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
             if ((rep2 > 0u) && ((u32)w0 == (u32)d3)) { begin_count(ip0 + 4u, ip0 + 4u - rep2, ZC_REPLOOP); needBack = false; }
             else outer();
