@@ -125,21 +125,34 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
 // pulls the next list entry from a device counter inside the same loop, so the 64 lanes of a wave keep
 // sharing memory round trips although frames differ 30x in cost.  Tables and sequence records of list
 // entry k live at tables + k*tableStride and fscratch + k*ZE_FRAME_STRIDE(maxSrc) in HBM.
+// Completion queue between the match kernel and the entropy kernel running beside it: a lane that has
+// finished frame k (records and meta written) appends k; entropy workgroups consume the queue in order, so
+// the cheap frames are entropy-coded while the expensive ones are still being parsed.
+__device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
+    if (!doneList) return;
+    __threadfence();                                       // records + meta visible before the queue entry
+    u32 const slot = atomicAdd(doneCount, 1u);
+    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
-                                             u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta) {
+                                             u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
     bool have = false; u32 k = 0;
     for (u32 r = 0;; r++) {
         if (m.st == ZL_DONE) {
-            if (have) { u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false; }
+            if (have) {
+                u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false;
+                zj_publish_done(doneList, doneCount, k);
+            }
             k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
             u32 const i = list[k];
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
-            if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); continue; }
+            if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
             m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc);
             have = true;
         }
@@ -151,25 +164,48 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
 }
 __global__ __launch_bounds__(64) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta) {
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
     u32 const count = *countPtr;
-    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta);
-    else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta);
+    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
+    else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
 }
 
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
-                                                        u8* fscratch, u32 maxSrc, const u32* meta) {
+                                                        u8* fscratch, u32 maxSrc, const u32* meta,
+                                                        u32 mode, const u32* doneList, u32* procFlag) {
+    // mode 0: list entry k.  mode 1: k-th entry of the completion queue the match kernel fills while this kernel
+    // runs (bounded wait; a workgroup that gives up leaves its frame to the mode-2 pass).  mode 2: list entries
+    // mode 1 did not finish.
     __shared__ ZEncShared sh;
     ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
     u32 const count = ZJ_UNI(*countPtr);
     for (;;) {
-        u32 const k = zj_next_index(workCounter);     // wave-uniform (SGPR)
+        u32 k = zj_next_index(workCounter);           // wave-uniform (SGPR)
         if (k >= count) break;
+        if (mode == 1) {
+            u32 v = 0xFFFFFFFFu;
+            if (threadIdx.x == 0) {
+                u64 const t0 = wall_clock64();            // 100 MHz
+                for (;;) {
+                    // relaxed poll: an acquire here would invalidate this CU's L1 every few microseconds, under the
+                    // match waves that share it; the fence after the loop orders the reads of the frame's records
+                    v = __hip_atomic_load(&doneList[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != 0xFFFFFFFFu || wall_clock64() - t0 > 200000000ull) break;     // 2 s
+                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                }
+            }
+            v = (u32)__builtin_amdgcn_readfirstlane((int)v);
+            if (v == 0xFFFFFFFFu) break;
+            __threadfence();
+            k = v;
+        } else if (mode == 2) {
+            if (ZJ_UNI(procFlag[k])) continue;
+        }
         u32 const i = ZJ_UNI(list[k]);
         u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
         u64 const cap = d1 - d0;
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
         }
         u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr);
         pf.mark(7);
-        if (threadIdx.x == 0) result[i] = r;
+        if (threadIdx.x == 0) { result[i] = r; if (mode == 1) procFlag[k] = 1u; }
         __syncthreads();
     }
 }
@@ -228,6 +264,7 @@ struct DevState {
     u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
     int matchGrid = 0;
     int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
+    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
@@ -273,6 +310,8 @@ DevState* get_state(int ordinal) {
         d.dseqGrid = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
+        if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
@@ -329,6 +368,7 @@ void zjni_shutdown(void) {
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
+        if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
@@ -470,32 +510,60 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
     if (n >= splitMin) {
         u32 const tableStride = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 4u));   // fast: u16 entries; dfast: 4-byte tagged entries
-        size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12;
-        size_t const need = tablesBytes + fsBytes + metaBytes + 256;
+        size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
+        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + 256;
         if (d->splitBufCap < need) {
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->splitBufCap = need;
         }
         u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
+        u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n;
+        u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
+        bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
         if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        if (hipMemsetAsync(d->counters + 24, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
-        hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
-                           (const u32*)listA, (const u32*)ctr, d->counters + 24, tables, tableStride, fscratch, maxSrc, meta);
+        // with the sequences already found the entropy kernel only needs the entropy-stage LDS (more workgroups per CU)
+        u32 const ldsRun = (u32)sizeof(ZEEntropy);
+        u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
+        unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
+        if (overlap) {
+            // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
+            // frames that parse quickly are entropy-coded while the slow ones still occupy their lanes (the match
+            // kernel leaves most of every CU idle in its tail).  A sweep pass afterwards takes whatever the side
+            // kernel did not get to (its waits are bounded), so completion never depends on the two kernels
+            // actually being co-scheduled.
+            if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1);
+            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
+                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag);
+            if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
+                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag);
+        } else {
+            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
+                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr);
+        }
+    } else {
+        // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
+        u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
+        hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr);
     }
-    // with the sequences already found the kernel only needs the entropy-stage LDS (more workgroups per CU)
-    u32 const ldsRun = fscratch ? (u32)sizeof(ZEEntropy) : ldsA;
-    int const gridCap = fscratch ? d->encGridLvl[1] : d->encGridLvl[level];
-    u32 const gridA = (u32)(n < (size_t)gridCap ? n : (size_t)gridCap);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       fscratch, maxSrc, (const u32*)meta);
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       (u8*)nullptr, maxSrc, (const u32*)nullptr);
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
