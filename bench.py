@@ -122,6 +122,7 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # recorded on the stream the kernels run on
     t_c, t_p, t_d, t_g = [], [], [], []
+    t_stage = []                                        # per-kernel HIP-event times from inside the library (same stream)
 
     def step(timed):
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
@@ -135,6 +136,7 @@ def main():
         if timed:
             torch.cuda.synchronize()
             t_c.append(e0.elapsed_time(e1)); t_p.append(e1.elapsed_time(e2)); t_d.append(e2.elapsed_time(e3)); t_g.append(e3.elapsed_time(e4))
+            t_stage.append(B.last_timing())
 
     for _ in range(a.warmup):
         step(False)
@@ -206,8 +208,29 @@ def main():
         total_unc = world * n * size
         mc, mp, md, mg = (sum(x) / len(x) for x in (t_c, t_p, t_d, t_g))
         alg = n * size + csum                                  # S + C per launch
-        dom_ms, dom = (mc, "zj_encode_kernel") if mc >= md else (md, "zj_decode_kernel")
+        stage = {k: sum(t[k] for t in t_stage) / len(t_stage) for k in t_stage[0]} if t_stage else {}
+        # kernels of the two paths with their own HIP-event durations (ms); "compress_rest" = classify + table memset +
+        # entropy kernel (it runs beside the match kernel on a side stream) + sweep, i.e. compress call minus match kernel
+        kernels = {"zj_enc_match_kernel": stage.get("match", -1.0), "zj_dec_prep_kernel": stage.get("dec_prep", -1.0),
+                   "zj_dec_seq_kernel": stage.get("dec_seq", -1.0), "zj_dec_exec_kernel": stage.get("dec_exec", -1.0),
+                   "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0), "zj_pack_kernel": mp}
+        if kernels["zj_enc_match_kernel"] > 0:
+            kernels["compress_rest(entropy beside match, memset, sweep)"] = mc - kernels["zj_enc_match_kernel"]
+        dom = max((k for k in kernels if kernels[k] > 0 and not k.startswith("compress_rest")), key=lambda k: kernels[k], default=None)
+        if dom is None:                                        # small batches: fused kernels only
+            dom, dom_ms = ("zj_encode_kernel", mc) if mc >= md else ("zj_decode_kernel", md)
+        else:
+            dom_ms = kernels[dom]
         achieved = alg / 1e9 / (dom_ms / 1e3)
+        traffic, traffic_note = None, None
+        try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            rec = pmc.get(f"L{level}_{n}x{size}", {}).get(dom.split("(")[0])
+            if rec:
+                traffic, traffic_note = rec["hbm_bytes_per_launch"], pmc.get("note")
+        except OSError:
+            pass
         out = {
             "metric": "GiB/s compress+decompress (L3, 64Ki x 64KiB)", "value": total_unc / GIB / (ms / 1e3), "unit": "GiB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -216,13 +239,13 @@ def main():
                        "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
                        "gather": bool(world > 1 and not a.no_gather)},
             "compress_GiBps_per_gpu": n * size / GIB / (mc / 1e3), "decompress_GiBps_per_gpu": n * size / GIB / (md / 1e3),
-            "kernel_ms": {"zj_encode_kernel": mc, "zj_pack_kernel": mp, "zj_decode_kernel": md, "rccl_gather": mg},
+            "kernel_ms": {"compress_call": mc, "decompress_call": md, **kernels, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg,
-                         "decode": {"achieved": alg / 1e9 / (md / 1e3), "frac": alg / 1e9 / (md / 1e3) / HBM_PEAK_GBPS},
-                         "encode": {"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS}},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg,
+                         "decompress_path": {"achieved": alg / 1e9 / (md / 1e3), "frac": alg / 1e9 / (md / 1e3) / HBM_PEAK_GBPS},
+                         "compress_path": {"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS}},
             "cpu_baseline": cpu, "parity": gates,
         }
         print(json.dumps(out))

@@ -101,6 +101,11 @@ size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, cons
 /* ---- introspection for tests/bench ---- */
 /* Workgroups the persistent kernels launch per device and LDS bytes per workgroup. */
 int zjni_kernel_info(int* decodeGrid, int* decodeLdsBytes, int* encodeGrid, int* encodeLdsBytes);
+/* Stage durations (ms) of the last large-batch device calls, from HIP events recorded on the caller's stream
+ * around the kernels: out5[0] lane-per-frame match-finder kernel (compress); out5[1..4] decode stages prep /
+ * lane-per-frame sequence decode / execute / fused leftovers.  Blocks until those stages have completed;
+ * stages that did not run read -1.  Profiling aid (bench.py roofline), not on the data path. */
+int zjni_last_timing(float* out5);
 
 #ifdef __cplusplus
 }

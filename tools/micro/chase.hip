@@ -32,6 +32,11 @@ int main(int argc, char** argv) {
     size_t const bytes = (size_t)maxWaves * 64 * entries * 4;
     hipMalloc(&mem, bytes); hipMemset(mem, 0, bytes); hipMalloc(&sink, maxWaves * 64 * 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    if (argc > 1) {      // calibration run for rocprofv3 --pmc: one known access count per launch (1024 waves x 64 lanes x steps)
+        for (int wr = 0; wr < 2; wr++) { chase<<<1024, 64>>>(mem, entries, steps, 0, 64, wr, sink); hipDeviceSynchronize(); }
+        printf("calibration: %llu random 4-byte accesses per launch (launch 1 read-only, launch 2 read+write)\n", (unsigned long long)1024 * 64 * steps);
+        return 0;
+    }
     int const waveCounts[] = {64, 256, 1024};
     for (int mode = 0; mode < 3; mode++) for (int wr = 0; wr < 2; wr++) for (int al : {1, 16, 64}) for (int w : waveCounts) {
         chase<<<w, 64>>>(mem, entries, 10, mode, al, wr, sink);

@@ -86,6 +86,8 @@ def lib():
     L.zjni_synth_fill_device.argtypes = [vp, sz, C.c_uint64, sz, vp]
     L.zjni_pack_batch_device.restype = sz
     L.zjni_pack_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.zjni_last_timing.restype = C.c_int
+    L.zjni_last_timing.argtypes = [C.POINTER(C.c_float)]
     L.zjni_kernel_info.restype = C.c_int
     L.zjni_kernel_info.argtypes = [C.POINTER(C.c_int)] * 4
     L.zjni_shutdown.restype = None
@@ -97,7 +99,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_getErrorCode", "zjni_getErrorName", "zjni_compressBound", "zjni_getFrameContentSize",
            "zjni_decompress_batch_device", "zjni_compress_batch_device", "zjni_decompress_batch",
            "zjni_compress_batch", "zjni_compress", "zjni_decompress", "zjni_synth_fill_host",
-           "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device")
+           "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

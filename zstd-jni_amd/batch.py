@@ -80,3 +80,12 @@ def pack(results, dst_blob, dst_off, out=None, out_off=None):
     _check(lib().zjni_pack_batch_device(dst_blob.data_ptr(), dst_off.data_ptr(), sizes.data_ptr(), out.data_ptr(),
                                         out_off.data_ptr(), n, _stream_ptr()))
     return out, out_off
+
+
+def last_timing():
+    """ms of the stages of the last large-batch device calls (HIP events on the launch stream, see zjni_last_timing):
+    {"match": .., "dec_prep": .., "dec_seq": .., "dec_exec": .., "dec_fused": ..}; -1 where a stage did not run."""
+    import ctypes as C
+    out = (C.c_float * 5)()
+    _check(lib().zjni_last_timing(out))
+    return dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused"), [float(x) for x in out]))

@@ -264,6 +264,8 @@ struct DevState {
     u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
     int matchGrid = 0;
     int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
+    hipEvent_t tev[8] = {};                           // stage boundaries of the last batch calls (zjni_last_timing)
+    bool tevCompress = false, tevDecompress = false;
     hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
@@ -310,6 +312,7 @@ DevState* get_state(int ordinal) {
         d.dseqGrid = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
+        for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
@@ -430,6 +433,21 @@ int zjni_debug_read_profile(unsigned long long* out32) {
     return hipMemset(d->prof, 0, 32 * 8) == hipSuccess ? 0 : -1;
 }
 
+/* Stage durations (ms) of the last large-batch device calls on this device, from HIP events recorded on the
+ * caller's stream around the kernels: out[0] match-finder kernel (compress); out[1..4] decode stages prep /
+ * sequence decode / execute / fused leftovers.  Blocks until those events have completed; entries whose stage
+ * did not run are -1.  A profiling aid for bench.py's roofline line, not part of the data path. */
+int zjni_last_timing(float* out5) {
+    DevState* d = cur_state();
+    if (!d) return -(int)ZJNI_ERROR_no_device;
+    for (int i = 0; i < 5; i++) out5[i] = -1.0f;
+    if (d->tevCompress) { if (hipEventSynchronize(d->tev[1]) == hipSuccess) (void)hipEventElapsedTime(&out5[0], d->tev[0], d->tev[1]); }
+    if (d->tevDecompress && hipEventSynchronize(d->tev[6]) == hipSuccess) {
+        for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&out5[1 + i], d->tev[2 + i], d->tev[3 + i]);
+    }
+    return 0;
+}
+
 int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* encodeLds) {
     DevState* d = cur_state();
     if (decodeLds) *decodeLds = (int)sizeof(ZDecShared);
@@ -465,16 +483,21 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused
         if (hipMemsetAsync(c, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        (void)hipEventRecord(d->tev[2], st);
         hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
                            (u32)n, c + 2, tabs, metas, listA, listB, c);
+        (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
                            (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u64*)tabs, seqs, metas);
+        (void)hipEventRecord(d->tev[4], st);
         hipLaunchKernelGGL(zj_dec_exec_kernel, dim3((u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid)), dim3(64), ZD_SHARED_NO_FSE, st,
                            (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
                            (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof);
+        (void)hipEventRecord(d->tev[5], st);
         hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1));
+        (void)hipEventRecord(d->tev[6], st); d->tevDecompress = true;
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -537,8 +560,10 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
             // actually being co-scheduled.
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1);
+            (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag);
@@ -547,8 +572,10 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag);
         } else {
+            (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+            (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr);
