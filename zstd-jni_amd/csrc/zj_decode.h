@@ -293,13 +293,105 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         sh.winLo = lo; }
 }
 
+// The same batch assembled in LDS.  In text-like data most matches copy bytes that an earlier sequence of the
+// same batch has just produced, so the batch resolves in ~10 dependency rounds; through HBM/L2 every round is a
+// store -> load round trip of thousands of cycles, in LDS it is a hundred.  The batch's output window
+// [op0, op0 + outTot) (<= ZD_STAGE_BYTES, else the global-memory path below is used) is built in `stage`: literals
+// land there from the literal buffer, match bytes come from `stage` when their source lies in the window and
+// from the already final output in HBM when it lies before it, and the finished window goes out as one
+// coalesced copy.
+#define ZD_STAGE_BYTES 4096u
+#if ZJ_ON_GPU
+template <class G>
+ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 litAvail, u8* stage, bool valid, u32 ll, u32 ml, u32 off,
+                              u32 lp, u32 op, u32 op0, u32 outTot) {
+    u32 const k = g.lane();
+    u32 const so = op - op0;                      // window offset of this sequence's literals
+    u32 const mp = op + ll, md = mp - op0;        // match destination: absolute / in the window
+    // ---- literals: every lane fetches its (<= 32-byte) run in one go, long runs go through the whole wave ----
+    if (ll && ll <= 32 && lp + 32u > litAvail) {  // within 32 bytes of the end of what may be read: byte by byte
+        for (u32 j = 0; j < ll; j++) stage[so + j] = lit[lp + j];
+    } else if (ll && ll <= 32) {
+        const u8* const s = lit + lp;
+        u64 const a = ld64(s), b = ll > 8 ? ld64(s + 8) : 0, c = ll > 16 ? ld64(s + 16) : 0, d = ll > 24 ? ld64(s + 24) : 0;
+        u8* const t = stage + so;
+        u32 const full = ll >> 3, rest = ll & 7u;
+        if (full > 0) st64(t, a);
+        if (full > 1) st64(t + 8, b);
+        if (full > 2) st64(t + 16, c);
+        if (full > 3) st64(t + 24, d);
+        u64 const last = full == 0 ? a : (full == 1 ? b : (full == 2 ? c : d));
+        for (u32 j = 0; j < rest; j++) t[8 * full + j] = (u8)(last >> (8 * j));
+    }
+    {   u64 m = __ballot(ll > 32);
+        while (m) {
+            u32 const q = (u32)__builtin_ctzll(m); m &= m - 1;
+            u32 const qll = ZJ_UNI(__shfl(ll, q, 64)), qlp = ZJ_UNI(__shfl(lp, q, 64)), qso = ZJ_UNI(__shfl(so, q, 64));
+            grp_copy_wide(g, stage + qso, lit + qlp, qll);
+        }
+    }
+    // ---- matches: dependency rounds (same rule as the global-memory path) ----
+    sh.sLit[k] = mp; sh.sMl[k] = mp + ml;
+    g.sync();
+    u32 const ms = mp - off;
+    u32 const me = zj_min(ms + ml, mp);
+    u64 dep = 0;
+    if (valid && ml) {
+        u32 lo = 0, hi = k;
+        while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sMl[mid] > ms) hi = mid; else lo = mid + 1; }
+        u32 const jlo = lo;
+        lo = jlo; hi = k;
+        while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sLit[mid] >= me) hi = mid; else lo = mid + 1; }
+        u32 const jhi = lo;
+        if (jhi > jlo) dep = ((jhi >= 64 ? ~0ull : ((1ull << jhi) - 1)) & ~((1ull << jlo) - 1));
+    }
+    u64 pending = __ballot(valid && ml > 0);
+    while (pending) {
+        bool const mine = (pending >> k) & 1;
+        bool const ready = mine && ((dep & pending) == 0);
+        u64 const readyMask = __ballot(ready);
+        u64 big = __ballot(ready && ml > 64);
+        while (big) {                             // long matches: the whole wave, byte j of the match from source byte j mod offset
+            u32 const q = (u32)__builtin_ctzll(big); big &= big - 1;
+            u32 const qml = ZJ_UNI(__shfl(ml, q, 64)), qoff = ZJ_UNI(__shfl(off, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64));
+            u32 const qms = qmp - qoff, qmd = qmp - op0;
+            GRP_FOR(g, j, qml) {
+                u32 const sp = qms + (qoff >= qml ? j : j % qoff);
+                stage[qmd + j] = sp < op0 ? out[sp] : stage[sp - op0];
+            }
+            g.sync();
+        }
+        if (ready && ml <= 64) {
+            u8* const d = stage + md;
+            u32 j = 0;
+            if (ms < op0) {                       // leading part from the final output before the window
+                u32 const gc = zj_min(ml, op0 - ms);
+                const u8* const m = out + ms;
+                for (; j + 8 <= gc; j += 8) st64(d + j, ld64(m + j));
+                for (; j < gc; j++) d[j] = m[j];
+            }
+            u32 const wo = ms + j >= op0 ? ms + j - op0 : 0u;
+            const u8* const w = stage + wo - j;                  // w[j] = window byte of source position ms + j
+            if (off >= 8) { for (; j + 8 <= ml; j += 8) st64(d + j, ld64(w + j)); }
+            for (; j < ml; j++) d[j] = w[j];
+        }
+        g.sync();
+        pending &= ~readyMask;
+    }
+    // ---- the finished window goes out in one coalesced copy ----
+    grp_copy_wide(g, out + op0, stage, outTot);
+    zj_mem_order();
+    g.sync();
+}
+#endif
+
 // Execute one batch of n <= 64 decoded sequences (N/decompress/zstd_decompress_block.c:1001-1096).
 // GPU: one sequence per lane.  Output positions come from a wave prefix sum; all literal runs are copied
 // first (they only read the literal buffer); a match may read bytes that an earlier match of the same batch
 // produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
 // range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
 template <class G>
-ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot) {
+ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot, u8* stage = nullptr, u32 litAvail = 0) {
 #if ZJ_ON_GPU
     u32 const k = g.lane();
     bool const valid = k < n;
@@ -314,6 +406,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     u32 const lp = lp0 + sl - ll;                 // literal source
     u32 const op = op0 + so - ll - ml;            // output position of this sequence's literals
     u32 const mp = op + ll;                       // match destination
+    if (stage && outTot <= ZD_STAGE_BYTES) { zd_execute_staged(g, sh, out, lit, litAvail, stage, valid, ll, ml, off, lp, op, op0, outTot); return; }
     // ---- literals: short runs per lane, long runs by the whole wave ----
     if (ll <= 32) {
         u32 j = 0;

@@ -231,6 +231,8 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     if (ZJ_UNI(sh.err)) return ~(u64)0;
     pf.mark(2);
     u32 const litSize = ZJ_UNI(sh.litSize);
+    // bytes that may be read starting at `lit`: the rest of the block for raw literals, the scratch otherwise
+    u32 const litAvail = (ZJ_UNI(sh.litType) == 0) ? bsize - ZJ_UNI(sh.litHdr) : ZD_LIT_SCRATCH;
     u32 lp = 0, op = 0;
     for (u32 base = 0; base < nbSeq; base += ZD_SEQ_BATCH) {
         u32 const cnt = zj_min(ZD_SEQ_BATCH, nbSeq - base);
@@ -240,7 +242,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
         }
         g.sync();
         u32 lt, ot;
-        zd_execute_batch(g, sh, dst, lit, cnt, lp, op, lt, ot);
+        zd_execute_batch(g, sh, dst, lit, cnt, lp, op, lt, ot, (u8*)sh.huf, litAvail);   // the Huffman table is dead once the literals are decoded
         lp += lt; op += ot;
         g.sync();
     }
