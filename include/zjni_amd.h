@@ -72,6 +72,13 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off,
                                   void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream);
+/* Same with ZSTD_c_checksumFlag = checksum (ZstdCompressCtx.setChecksum0, N/jni_fast_zstd.c:276-282;
+ * Zstd.compressUnsafe(..., checksumFlag), N/jni_zstd.c:50-63): frames end with the low 32 bits of
+ * XXH64(content, 0).  The decompress entries verify a frame's checksum whenever its header announces one
+ * (ZSTD_error_checksum_wrong on mismatch), like ZSTD_decompressDCtx. */
+size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off,
+                                   void* d_dst, const uint64_t* d_dst_off,
+                                   uint64_t* d_result, size_t n, int level, int checksum, void* stream);
 
 /* ---- hot path, host buffers (what a JNI batch native binds; stages through pinned memory) ---- */
 size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize,
@@ -80,10 +87,15 @@ size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize,
 size_t zjni_compress_batch(const void* const* src, const size_t* srcSize,
                            void* const* dst, const size_t* dstCapacity,
                            size_t* result, size_t n, int level);
+size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize,
+                            void* const* dst, const size_t* dstCapacity,
+                            size_t* result, size_t n, int level, int checksum);
 
 /* ---- per-buffer forms with the exact argument meaning of the calls they replace ---- */
 /* ZSTD_compress2(cctx{level}, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:607 */
 size_t zjni_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level);
+/* the same with ZSTD_c_checksumFlag (Zstd.compress(dst, src, level, checksumFlag), J/Zstd.java) */
+size_t zjni_compress2(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksum);
 /* ZSTD_decompressDCtx(dctx, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:799 */
 size_t zjni_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 

@@ -43,7 +43,8 @@ extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned sr
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
     ZjProf pf; pf.start(nullptr);
-    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf);
+    // level & 0xFF = level, bit 8 = checksum flag
+    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level & 0xFFu, ws, pf, nullptr, (level >> 8) & 1u);
     free(ws); free(lds); free(sh);
     return r;
 }
@@ -59,10 +60,11 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     u8* table = (u8*)calloc(1, 65536 * 4);
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(65536u));
     u32 meta[3];
+    u32 const flags = (level >> 8) & 1u; level &= 0xFFu;
     ze_match_lane(src, srcSize, level, table, fs, 65536u, meta);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(65536u) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
-    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags);
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }

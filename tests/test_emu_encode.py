@@ -84,3 +84,27 @@ def test_emu_encoder_tiny_text_frames(emu, oracle_ref):
             want = expected(oracle_ref, d, level)
             assert emu_compress(emu, d, level) == want, (size, off, level)
             assert emu_compress(emu, d, level, split=True) == want, (size, off, level, "split")
+
+
+def test_emu_checksum_frames(emu, oracle_ref, zj):
+    """ZSTD_c_checksumFlag: frames carry XXH64(content) & 0xFFFFFFFF and stay byte-identical to the reference's
+    (ZstdCompressCtx.setChecksum(true), T/scala/Zstd.scala checksum tests); both decoders verify it"""
+    from util import emu_decompress, emu_decompress_split
+    rnd = random.Random(77)
+    cases = [d for _, d in edge_inputs() if len(d) <= 131072]
+    for _ in range(60):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 65537), 65536, 31, 32, 33, 63, 64])
+        cases.append(zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b"")
+    for d in cases:
+        for level in (1, 3):
+            want = oracle_ref.compress(d, 3, True, 14, 13) if level == 3 else oracle_ref.compress(d, level, True)
+            got = emu_compress(emu, d, level, checksum=True)
+            assert got == want, (len(d), level)
+            if len(d) <= 65536:
+                assert emu_compress(emu, d, level, split=True, checksum=True) == want, (len(d), level, "split")
+            assert emu_decompress(emu, got, len(d)) == d
+            assert emu_decompress_split(emu, got, len(d))[0] == d
+            if len(got) > 12:
+                bad = bytearray(got); bad[-1] ^= 0x01                  # wrong checksum byte
+                assert emu_decompress(emu, bytes(bad), len(d)) == -22
+                assert emu_decompress_split(emu, bytes(bad), len(d))[0] == -22

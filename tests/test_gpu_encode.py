@@ -110,3 +110,27 @@ def test_gpu_device_batch_roundtrip_and_ratio(gpu, oracle_port, oracle_ref, leve
     cpu_frames = oracle_port.compress_many(raw, size, level, os.cpu_count() or 4)     # default CPU level
     cpu_total = sum(len(f) for f in cpu_frames)
     assert int(csz.sum().item()) <= 1.01 * cpu_total, (int(csz.sum().item()), cpu_total)   # gate (iii)
+
+
+@pytest.mark.parametrize("split_min", ["1", "1000000000"])
+def test_gpu_checksum_flag(gpu, oracle_ref, monkeypatch, split_min):
+    """ZstdCompressCtx.setChecksum(true) / Zstd.compress(src, level, checksumFlag): frames byte-identical to the
+    reference's with ZSTD_c_checksumFlag, the GPU decoders verify the checksum (T/scala/Zstd.scala checksum cases)"""
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", split_min)
+    monkeypatch.setenv("ZJNI_DSPLIT_MIN", split_min)
+    items = [d for _, d in edge_inputs()] + [gpu.synth_host(65536, k, 1) for k in range(8)] + [gpu.synth_host(4097, 9, 1)]
+    for level in (1, 3):
+        outs = gpu.compress_batch(items, level, checksum=True)
+        for d, z in zip(items, outs):
+            assert not isinstance(z, Exception), (len(d), z)
+            want = oracle_ref.compress(d, 3, True, 14, 13) if level == 3 else oracle_ref.compress(d, level, True)
+            assert z == want, (len(d), level)
+        back = gpu.decompress_batch(outs, [len(d) for d in items])
+        assert back == items
+        broken = [bytes(z[:-1]) + bytes([z[-1] ^ 0x80]) for z in outs]
+        for d, r in zip(items, gpu.decompress_batch(broken, [len(d) for d in items])):
+            assert isinstance(r, Exception) and r.getErrorCode() == 22, (len(d), r)
+    with gpu.ZstdCompressCtx() as ctx:
+        z = ctx.setLevel(1).setChecksum(True).compress(items[-1])
+        assert z == oracle_ref.compress(items[-1], 1, True)
+    assert gpu.Zstd.compress(items[-2], 3, True) == oracle_ref.compress(items[-2], 3, True, 14, 13)

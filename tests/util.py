@@ -41,10 +41,10 @@ def emu_decompress_split(L, frame, cap):
     return dst.raw[:r], bool(used.value)
 
 
-def emu_compress(L, data, level, split=False):
+def emu_compress(L, data, level, split=False, checksum=False):
     cap = len(data) + (len(data) >> 8) + 64 + 128
     dst = C.create_string_buffer(cap)
-    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level)
+    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level | (0x100 if checksum else 0))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

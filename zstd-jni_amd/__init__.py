@@ -72,6 +72,12 @@ def lib():
         f.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     L.zjni_compress_batch_device.restype = sz
     L.zjni_compress_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, vp]
+    L.zjni_compress_batch_device2.restype = sz
+    L.zjni_compress_batch_device2.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, C.c_int, vp]
+    L.zjni_compress_batch2.restype = sz
+    L.zjni_compress_batch2.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int, C.c_int]
+    L.zjni_compress2.restype = sz
+    L.zjni_compress2.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int]
     L.zjni_decompress_batch.restype = sz
     L.zjni_decompress_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz]
     L.zjni_compress_batch.restype = sz
@@ -99,7 +105,8 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_getErrorCode", "zjni_getErrorName", "zjni_compressBound", "zjni_getFrameContentSize",
            "zjni_decompress_batch_device", "zjni_compress_batch_device", "zjni_decompress_batch",
            "zjni_compress_batch", "zjni_compress", "zjni_decompress", "zjni_synth_fill_host",
-           "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing")
+           "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing",
+           "zjni_compress_batch_device2", "zjni_compress_batch2", "zjni_compress2")
 
 
 # --------------------------------------------------------------------------- Java API mirror --
@@ -181,9 +188,10 @@ class Zstd:
             return ctx._raw(dst, dstOffset, dstSize, src, srcOffset, srcSize)
 
     @staticmethod
-    def compress(src, level=3):                                    # J/Zstd.java:1137 (byte[] -> byte[])
+    def compress(src, level=3, checksumFlag=False):                # J/Zstd.java:1137 (byte[] -> byte[]), :60-78 (checksumFlag)
         with ZstdCompressCtx() as ctx:
             ctx.setLevel(level)
+            ctx.setChecksum(checksumFlag)
             return ctx.compress(src)
 
     @staticmethod
@@ -223,6 +231,12 @@ class ZstdCompressCtx(_AutoClose):
     def __init__(self):
         super().__init__()
         self.level = 3                                             # ZSTD_CLEVEL_DEFAULT
+        self.checksum = False                                      # ZSTD_c_checksumFlag default
+
+    def setChecksum(self, checksumFlag):                           # J/ZstdCompressCtx.java:105 -> setChecksum0 (N/jni_fast_zstd.c:276-282)
+        self._ensure_open()
+        self.checksum = bool(checksumFlag)
+        return self
 
     def setLevel(self, level):                                     # J/ZstdCompressCtx.java:69
         self._ensure_open()
@@ -246,7 +260,7 @@ class ZstdCompressCtx(_AutoClose):
             return -70
         sa, k1 = _addr(src, srcOffset)
         da, k2 = _addr(dst, dstOffset)
-        r = lib().zjni_compress(da, dstSize, sa, srcSize, self.level)
+        r = lib().zjni_compress2(da, dstSize, sa, srcSize, self.level, 1 if self.checksum else 0)
         return r - (1 << 64) if r >= (1 << 63) else r
 
     def compressByteArray(self, dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize):   # J/ZstdCompressCtx.java:691
@@ -322,9 +336,9 @@ def _check_launch(r):
         raise ZstdException(r)
 
 
-def compress_batch(buffers, level=3):
-    """n independent buffers -> n zstd frames through zjni_compress_batch (host pointers)."""
-    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level)
+def compress_batch(buffers, level=3, checksum=False):
+    """n independent buffers -> n zstd frames through zjni_compress_batch2 (host pointers)."""
+    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum)
 
 
 def decompress_batch(frames, capacities):
@@ -332,7 +346,7 @@ def decompress_batch(frames, capacities):
     return _host_batch(frames, list(capacities), False, 0)
 
 
-def _host_batch(srcs, caps, is_compress, level):
+def _host_batch(srcs, caps, is_compress, level, checksum=False):
     L = lib()
     n = len(srcs)
     if n == 0:
@@ -345,7 +359,7 @@ def _host_batch(srcs, caps, is_compress, level):
     dc = (C.c_size_t * n)(*caps)
     res = (C.c_size_t * n)()
     if is_compress:
-        r = L.zjni_compress_batch(sp, ss, dp, dc, res, n, level)
+        r = L.zjni_compress_batch2(sp, ss, dp, dc, res, n, level, 1 if checksum else 0)
     else:
         r = L.zjni_decompress_batch(sp, ss, dp, dc, res, n)
     _check_launch(r)

@@ -168,3 +168,57 @@ ZJ_DEV void grp_copy_wide(const G& g, u8* dst, const u8* src, u32 n) {
     }
     GRP_FOR(g, i, n & 15u) dst[(n16 << 4) + i] = src[(n16 << 4) + i];
 }
+
+// ------------------------------------------------------------------ XXH64 (frame checksum) ----
+// N/common/xxhash.h (XXH64, seed 0); zstd stores its low 32 bits after the last block (N/compress/zstd_compress.c:
+// ZSTD_writeEpilogue, N/decompress/zstd_decompress.c:1050-1060).  The four accumulators are four dependent chains:
+// lanes 0..3 each run one over the 32-byte stripes, lane 0 merges and finishes.  Returns a wave-uniform value.
+#define ZJ_XXP1 0x9E3779B185EBCA87ULL
+#define ZJ_XXP2 0xC2B2AE3D27D4EB4FULL
+#define ZJ_XXP3 0x165667B19E3779F9ULL
+#define ZJ_XXP4 0x85EBCA77C2B2AE63ULL
+#define ZJ_XXP5 0x27D4EB2F165667C5ULL
+ZJ_HD u64 zj_rotl64(u64 x, u32 r) { return (x << r) | (x >> (64 - r)); }
+ZJ_HD u64 zj_xx_round(u64 acc, u64 in) { return zj_rotl64(acc + in * ZJ_XXP2, 31) * ZJ_XXP1; }
+ZJ_HD u64 zj_xx_merge(u64 h, u64 v) { return (h ^ zj_xx_round(0, v)) * ZJ_XXP1 + ZJ_XXP4; }
+ZJ_HD u64 zj_xx_finish(u64 h, const u8* p, u32 rem) {          // rem < 32 trailing bytes, then the avalanche
+    while (rem >= 8) { h ^= zj_xx_round(0, ld64(p)); h = zj_rotl64(h, 27) * ZJ_XXP1 + ZJ_XXP4; p += 8; rem -= 8; }
+    if (rem >= 4) { h ^= (u64)ld32(p) * ZJ_XXP1; h = zj_rotl64(h, 23) * ZJ_XXP2 + ZJ_XXP3; p += 4; rem -= 4; }
+    while (rem) { h ^= (u64)(*p) * ZJ_XXP5; h = zj_rotl64(h, 11) * ZJ_XXP1; p++; rem--; }
+    h ^= h >> 33; h *= ZJ_XXP2; h ^= h >> 29; h *= ZJ_XXP3; h ^= h >> 32;
+    return h;
+}
+template <class G>
+ZJ_DEV u64 zj_xxh64(const G& g, const u8* p, u32 len) {
+    u64 h;
+    u32 const stripes = len >> 5;
+#if ZJ_ON_GPU
+    u32 const k = g.lane() & 3u;
+    u64 v = k == 0 ? ZJ_XXP1 + ZJ_XXP2 : (k == 1 ? ZJ_XXP2 : (k == 2 ? 0 : 0 - ZJ_XXP1));
+    if (g.lane() < 4u) {
+        const u8* q = p + 8u * k;
+        u32 s = 0;
+        for (; s + 4 <= stripes; s += 4) {                 // four loads in flight per round trip
+            u64 const a = ld64(q), b = ld64(q + 32), c = ld64(q + 64), d = ld64(q + 96);
+            v = zj_xx_round(v, a); v = zj_xx_round(v, b); v = zj_xx_round(v, c); v = zj_xx_round(v, d);
+            q += 128;
+        }
+        for (; s < stripes; s++) { v = zj_xx_round(v, ld64(q)); q += 32; }
+    }
+    u64 const v1 = __shfl(v, 0, 64), v2 = __shfl(v, 1, 64), v3 = __shfl(v, 2, 64), v4 = __shfl(v, 3, 64);
+#else
+    u64 v1 = ZJ_XXP1 + ZJ_XXP2, v2 = ZJ_XXP2, v3 = 0, v4 = 0 - ZJ_XXP1;
+    for (u32 s = 0; s < stripes; s++) {
+        const u8* q = p + 32u * s;
+        v1 = zj_xx_round(v1, ld64(q)); v2 = zj_xx_round(v2, ld64(q + 8)); v3 = zj_xx_round(v3, ld64(q + 16)); v4 = zj_xx_round(v4, ld64(q + 24));
+    }
+    (void)g;
+#endif
+    if (len >= 32) {
+        h = zj_rotl64(v1, 1) + zj_rotl64(v2, 7) + zj_rotl64(v3, 12) + zj_rotl64(v4, 18);
+        h = zj_xx_merge(h, v1); h = zj_xx_merge(h, v2); h = zj_xx_merge(h, v3); h = zj_xx_merge(h, v4);
+    } else h = ZJ_XXP5;
+    h += len;
+    h = zj_xx_finish(h, p + 32u * stripes, len & 31u);     // every lane computes the same short tail
+    return zj_uni64(h);
+}

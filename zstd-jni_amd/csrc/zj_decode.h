@@ -953,8 +953,10 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
         }
         {   u64 const cs = zj_uni64(sh.contentSize); if (cs != ~(u64)0 && cs != opos) return ZJ_ERR64(ZJ_E_CORRUPTION); }
         if (ZJ_UNI(sh.hasChecksum)) {
-            // XXH64 verification is a "next" row; frames from Zstd.compress() default to no checksum.
+            // frame content checksum: low 32 bits of XXH64(content, 0), N/decompress/zstd_decompress.c:1050-1060
             if (srcSize - ipos < 4) return ZJ_ERR64(ZJ_E_CHECKSUM_WRONG);
+            zj_mem_order(); g.sync();
+            if ((u32)zj_xxh64(g, fout, opos) != ZJ_UNI(ld32(src + ipos))) return ZJ_ERR64(ZJ_E_CHECKSUM_WRONG);
             ipos += 4;
         }
         total += opos;

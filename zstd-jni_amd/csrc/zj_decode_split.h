@@ -42,7 +42,8 @@ struct ZDMeta {
     u32 logs;                     // llLog | ofLog << 8 | mlLog << 16
     u32 contentSize, blockSizeMax;
     u32 status;                   // stage 2: 0 ok, 1 hand over to the fused kernel
-    u32 pad[3];
+    u32 hasChecksum;              // 4 checksum bytes follow the block
+    u32 pad[2];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -84,7 +85,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
                     if (lok && n <= bmax && lh + c < sz) {
                         ok = 1;
                         sh.hdrSize = hdr + 3; sh.blkSize = sz; sh.litSize = n; sh.litHdr = lh; sh.litCSize = c;
-                        sh.contentSize = content; sh.blockSizeMax = bmax;
+                        sh.contentSize = content; sh.blockSizeMax = bmax; sh.hasChecksum = tail ? 1u : 0u;
                     }
                 }
             }
@@ -108,7 +109,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
         ZDMeta m;
         m.blockOff = boff; m.blockSize = bsize; m.seqOff = sh.seqOff; m.nbSeq = nbSeq; m.litSize = sh.litSize;
         m.logs = sh.llLog | (sh.ofLog << 8) | (sh.mlLog << 16);
-        m.contentSize = (u32)sh.contentSize; m.blockSizeMax = sh.blockSizeMax; m.status = 0; m.pad[0] = m.pad[1] = m.pad[2] = 0;
+        m.contentSize = (u32)sh.contentSize; m.blockSizeMax = sh.blockSizeMax; m.status = 0; m.hasChecksum = sh.hasChecksum; m.pad[0] = m.pad[1] = 0;
         *meta = m;
     }
     zj_mem_order();
@@ -221,6 +222,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
         ZDMeta const m = *meta;
         sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0;
         sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.nbSeq = m.nbSeq; sh.blockSizeMax = m.blockSizeMax; sh.contentSize = m.contentSize;
+        sh.hasChecksum = m.hasChecksum;
     }
     g.sync();
     if (ZJ_UNI(sh.err)) return ~(u64)0;
@@ -256,5 +258,8 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     g.sync();
     pf.mark(6);
     if (op != content) return ~(u64)0;
+    if (ZJ_UNI(sh.hasChecksum)) {                    // the fused kernel reports a mismatch (checksum_wrong)
+        if ((u32)zj_xxh64(g, dst, op) != ZJ_UNI(ld32(bsrc + bsize))) return ~(u64)0;
+    }
     return op;
 }

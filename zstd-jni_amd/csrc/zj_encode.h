@@ -769,25 +769,27 @@ template <class TIdx> struct ZEEntOf;
 template <> struct ZEEntOf<u16> { typedef ZEEnt16 E; };
 template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 
+#define ZE_FLAG_CHECKSUM 1u      /* ZSTD_c_checksumFlag: append XXH64(content) & 0xFFFFFFFF */
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
 template <class G, class TIdx>
-ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre) {
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags) {
+    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
     u8* const litBuf = ws + ZE_WS_LIT;
     ZESeq* const seqs = pre ? pre->seqs : (ZESeq*)(ws + ZE_WS_SEQ);
     ZEEntropy& e = *(ZEEntropy*)lds;
 
-    // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1, no checksum, no dictID) ----
+    // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1, no dictID) ----
     GRP_SERIAL(g) {
         sh.err = 0;
         ze_params(sh, level, srcSize);
         u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
         u32 const hdr = 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
         sh.hdrSize = hdr;
-        if (dstCap < hdr + 3) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
+        if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {
-            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6));
+            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6) + (tail ? 4u : 0u));
             if (fcsCode == 0) dst[5] = (u8)srcSize; else if (fcsCode == 1) st16(dst + 5, srcSize - 256); else st32(dst + 5, srcSize);
         }
     }
@@ -795,8 +797,8 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
     if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
     u32 const hdr = ZJ_UNI(sh.hdrSize);
     if (srcSize == 0) {                                                       // ZSTD_writeEpilogue: empty raw last block
-        GRP_SERIAL(g) { dst[hdr] = 1; dst[hdr + 1] = 0; dst[hdr + 2] = 0; }
-        return hdr + 3;
+        GRP_SERIAL(g) { dst[hdr] = 1; dst[hdr + 1] = 0; dst[hdr + 2] = 0; if (tail) st32(dst + hdr + 3, (u32)zj_xx_finish(ZJ_XXP5, src, 0)); }
+        return hdr + 3 + tail;
     }
     bool compressed = false; u32 cSize = 0;
     // body goes straight into dst when even the raw fallback fits, else into HBM scratch first
@@ -1105,16 +1107,20 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
     zj_mem_order();
     g.sync();
     // ---- block header + placement ----
+    u32 const bodySize = compressed ? cSize : srcSize;
+    if (dstCap < hdr + 3 + bodySize + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
     if (compressed) {
-        if (dstCap < hdr + 3 + cSize) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
         if (!direct) grp_copy_wide(g, dst + hdr + 3, body, cSize);
         GRP_SERIAL(g) { u32 const bh = 1 + (2u << 1) + (cSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
-        return hdr + 3 + cSize;
+    } else {
+        grp_copy_wide(g, dst + hdr + 3, src, srcSize);
+        GRP_SERIAL(g) { u32 const bh = 1 + (srcSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
     }
-    if (dstCap < hdr + 3 + srcSize) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
-    grp_copy_wide(g, dst + hdr + 3, src, srcSize);
-    GRP_SERIAL(g) { u32 const bh = 1 + (srcSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
-    return hdr + 3 + srcSize;
+    if (tail) {
+        u64 const h = zj_xxh64(g, src, srcSize);
+        GRP_SERIAL(g) { st32(dst + hdr + 3 + bodySize, (u32)h); }
+    }
+    return hdr + 3 + bodySize + tail;
 }
 
 // LDS bytes the match finder needs for (level, srcSize); the entropy stage needs sizeof(ZEEntropy).
@@ -1135,9 +1141,9 @@ ZJ_HD u32 ze_lds_need(u32 level, u32 srcSize) {
 }
 
 template <class G>
-ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr) {
-    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre);
-    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre);
+ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr, u32 flags = 0) {
+    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags);
+    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags);
 }
 
 // Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.

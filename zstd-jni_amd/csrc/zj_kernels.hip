@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
                                                         u8* fscratch, u32 maxSrc, const u32* meta,
-                                                        u32 mode, const u32* doneList, u32* procFlag) {
+                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags) {
     // mode 0: list entry k.  mode 1: k-th entry of the completion queue the match kernel fills while this kernel
     // runs (bounded wait; a workgroup that gives up leaves its frame to the mode-2 pass).  mode 2: list entries
     // mode 1 did not finish.
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
             pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta + 3 * (size_t)k;
             prePtr = &pre;
         }
-        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr);
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr, flags);
         pf.mark(7);
         if (threadIdx.x == 0) { result[i] = r; if (mode == 1) procFlag[k] = 1u; }
         __syncthreads();
@@ -506,8 +506,8 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
-size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
-                                  uint64_t* d_result, size_t n, int level, void* stream) {
+static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                         uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (level < 1 || level > 3) return ZJNI_ERR(42);
@@ -566,11 +566,11 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag);
+                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag);
+                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags);
         } else {
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
@@ -578,25 +578,33 @@ size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, 
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr);
+                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr);
+                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
     }
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr);
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                  uint64_t* d_result, size_t n, int level, void* stream) {
+    return compress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
+}
+size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                   uint64_t* d_result, size_t n, int level, int checksum, void* stream) {
+    return compress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
 
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
 static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
-                         size_t* result, size_t n, int level) {
+                         size_t* result, size_t n, int level, int checksum = 0) {
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (n == 0) return 0;
@@ -619,8 +627,8 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcTotal, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     size_t r;
     if (compress)
-        r = zjni_compress_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                                       (u64*)(d->dStage + oRes), n, level, nullptr);
+        r = zjni_compress_batch_device2(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                                        (u64*)(d->dStage + oRes), n, level, checksum, nullptr);
     else
         r = zjni_decompress_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                          (u64*)(d->dStage + oRes), n, nullptr);
@@ -644,9 +652,19 @@ size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* 
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level);
 }
 
+size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level, int checksum) {
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum);
+}
+
 size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
     size_t res = 0; const void* s = src; void* dd = dst;
     size_t const r = zjni_compress_batch(&s, &srcSize, &dd, &dstCap, &res, 1, level);
+    return zjni_isError(r) ? r : res;
+}
+size_t zjni_compress2(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum) {
+    size_t res = 0; const void* s = src; void* dd = dst;
+    size_t const r = zjni_compress_batch2(&s, &srcSize, &dd, &dstCap, &res, 1, level, checksum);
     return zjni_isError(r) ? r : res;
 }
 size_t zjni_decompress(void* dst, size_t dstCap, const void* src, size_t srcSize) {
