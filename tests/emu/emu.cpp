@@ -20,12 +20,12 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
-    u64* tab = (u64*)calloc(ZD_SPLIT_CELLS, 8); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
+    u32* tab = (u32*)calloc(ZD_SPLIT_CELLS, 4); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
     ZjProf pf; pf.start(nullptr);
     u64 r = ~(u64)0;
     if (usedSplit) *usedSplit = 0;
     if (zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta)) {
-        ZDSeqLane m; m.init(src, tab, seqs, &meta);
+        ZDSeqLane m; m.llBase = zd_k_ll_base; m.mlBase = zd_k_ml_base; m.init(src, tab, seqs, &meta);
         while (m.st != 2) m.round();
         r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf);
         if (usedSplit && r != ~(u64)0) *usedSplit = 1;

@@ -26,12 +26,13 @@
 #define ZD_SPLIT_CELLS 1280u                                  // LL 512 | OF 256 | ML 512
 #define ZD_SPLIT_OF 512u
 #define ZD_SPLIT_ML 768u
-#define ZD_SPLIT_TAB_BYTES (ZD_SPLIT_CELLS * 8u)
+#define ZD_SPLIT_TAB_BYTES (ZD_SPLIT_CELLS * 4u)
 #define ZD_SPLIT_SEQ_BYTES (ZD_SPLIT_MAXSEQ * 8u)
 
-// decode cell in HBM, the reference's ZSTD_seqSymbol (N/decompress/zstd_decompress_internal.h:68-73):
-// base | next << 32 | nbBits << 48 | extraBits << 56
-ZJ_DEV u64 zd_cell8(u32 base, u32 next, u32 nb, u32 extra) { return (u64)base | ((u64)next << 32) | ((u64)nb << 48) | ((u64)extra << 56); }
+// Decode cells go to HBM in the 4-byte form the fused kernel keeps in LDS (ZD_CELL: next | nbBits | symbol |
+// extraBits; the reference's ZSTD_seqSymbol minus baseValue, N/decompress/zstd_decompress_internal.h:68-73):
+// 5 KiB per frame instead of 10 keeps more of the tables in L2/Infinity Cache under the lane-per-frame decode;
+// baseValue comes from the symbol through two small LDS tables.
 // decoded sequence record: ll | ml << 18 | offset << 36 (all <= 2^17 for content <= 64 KiB)
 ZJ_DEV u64 zd_seq_pack(u32 ll, u32 ml, u32 off) { return (u64)ll | ((u64)ml << 18) | ((u64)off << 36); }
 
@@ -49,7 +50,7 @@ struct ZDMeta {
 // ---------------------------------------------------------------------------------------------
 // Stage 1.  Returns true (wave-uniform) when the frame is simple and its tables/record were written.
 template <class G>
-ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u64* tab, ZDMeta* meta) {
+ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u32* tab, ZDMeta* meta) {
     GRP_SERIAL(g) {
         u32 ok = 0;
         sh.err = 0; sh.seqValid = 0; sh.hufValid = 0;
@@ -101,9 +102,9 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     if (ZJ_UNI(sh.err) || nbSeq > ZD_SPLIT_MAXSEQ) { GRP_SERIAL(g) { sh.err = 0; } g.sync(); return false; }
     if (nbSeq) {
         u32 const llLog = ZJ_UNI(sh.llLog), ofLog = ZJ_UNI(sh.ofLog), mlLog = ZJ_UNI(sh.mlLog);
-        GRP_FOR(g, u, 1u << llLog) { u32 const c = sh.ll[u], s = ZD_CELL_SYM(c); tab[u] = zd_cell8(zd_k_ll_base[s], ZD_CELL_NEXT(c), ZD_CELL_NB(c), ZD_CELL_EXTRA(c)); }
-        GRP_FOR(g, u, 1u << ofLog) { u32 const c = sh.of[u], s = ZD_CELL_SYM(c); tab[ZD_SPLIT_OF + u] = zd_cell8(s > 1 ? (1u << s) - 3u : s, ZD_CELL_NEXT(c), ZD_CELL_NB(c), s); }
-        GRP_FOR(g, u, 1u << mlLog) { u32 const c = sh.ml[u], s = ZD_CELL_SYM(c); tab[ZD_SPLIT_ML + u] = zd_cell8(zd_k_ml_base[s], ZD_CELL_NEXT(c), ZD_CELL_NB(c), ZD_CELL_EXTRA(c)); }
+        GRP_FOR(g, u, 1u << llLog) tab[u] = sh.ll[u];
+        GRP_FOR(g, u, 1u << ofLog) tab[ZD_SPLIT_OF + u] = sh.of[u];
+        GRP_FOR(g, u, 1u << mlLog) tab[ZD_SPLIT_ML + u] = sh.ml[u];
     }
     GRP_SERIAL(g) {
         ZDMeta m;
@@ -121,12 +122,12 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
 // Stage 2.  One lane per frame; round() is one memory round trip for every lane of the wave.
 // Bit positions are relative to the frame buffer.  N/decompress/zstd_decompress_block.c:1229-1347, :1615-1690.
 struct ZDSeqLane {
-    const u8* src; const u64* tab; u64* seqs; ZDMeta* meta;
+    const u8* src; const u32* tab; u64* seqs; ZDMeta* meta; const u32* llBase; const u32* mlBase;   // bases: LDS tables of the kernel
     i32 A, S0; u32 sLL, sOF, sML, rep0, rep1, rep2, i, nbSeq, opos, lpos, litSize, cap, logs, endByte;
     u32 st;                       // 0 start, 1 running, 2 done
     u32 bad;
 
-    ZJ_DEV_MEMBER void init(const u8* s, const u64* t, u64* q, ZDMeta* m) {
+    ZJ_DEV_MEMBER void init(const u8* s, const u32* t, u64* q, ZDMeta* m) {
         src = s; tab = t; seqs = q; meta = m;
         ZDMeta const h = *m;
         nbSeq = h.nbSeq; litSize = h.litSize; logs = h.logs;
@@ -153,7 +154,7 @@ struct ZDSeqLane {
         u32 const iLL = sLL, iOF = ZD_SPLIT_OF + sOF, iML = ZD_SPLIT_ML + sML;
         // ---- one batch of loads ----
         u64 lo = ld64(src + wp), hi = ld64(src + wp + 8);
-        u64 const cl = tab[iLL], co = tab[iOF], cm = tab[iML];
+        u32 const cl = tab[iLL], co = tab[iOF], cm = tab[iML];
         ZD_ROUND_FENCE5(lo, hi, cl, co, cm);
         if (e < 16u) {                               // stream within 16 bytes of the buffer start: align [e-16, e) by hand
             u32 const k = (16u - e) * 8u;            // shift left by k bits (8..120)
@@ -175,9 +176,11 @@ struct ZDSeqLane {
             return;
         }
         if (st != 1) return;
-        u32 const ofx = (u32)(co >> 56), mlx = (u32)(cm >> 56), llx = (u32)(cl >> 56);
+        u32 const ofx = ZD_CELL_EXTRA(co), mlx = ZD_CELL_EXTRA(cm), llx = ZD_CELL_EXTRA(cl);
         bool const last = (i + 1u == nbSeq);
-        u32 const nl = last ? 0u : (u32)(cl >> 48) & 0xFFu, nm = last ? 0u : (u32)(cm >> 48) & 0xFFu, no = last ? 0u : (u32)(co >> 48) & 0xFFu;
+        u32 const nl = last ? 0u : ZD_CELL_NB(cl), nm = last ? 0u : ZD_CELL_NB(cm), no = last ? 0u : ZD_CELL_NB(co);
+        u32 const llb = llBase[ZD_CELL_SYM(cl)], mlb = mlBase[ZD_CELL_SYM(cm)];
+        u32 const ofb = ofx > 1u ? (1u << ofx) - 3u : ofx;                // OF_base of code ofx
         u32 const T1 = ofx + mlx + llx, T = T1 + nl + nm + no;
         if (A - (i32)T < S0) { bad = 1; finish(); return; }
 #define ZD_TAKE(v, nb) ((u32)(((v) >> 1) >> (63u - (nb))))
@@ -191,9 +194,9 @@ struct ZDSeqLane {
         u32 const vo = ZD_TAKE(v2, no);
 #undef ZD_TAKE
         A -= (i32)T;
-        u32 const llen = (u32)cl + llv, mlen = (u32)cm + mlv;
+        u32 const llen = llb + llv, mlen = mlb + mlv;
         u32 offset;
-        if (ofx > 1u) { offset = (u32)co + ofv; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+        if (ofx > 1u) { offset = ofb + ofv; rep2 = rep1; rep1 = rep0; rep0 = offset; }
         else {
             u32 const ll0 = (llen == 0u);
             if (ofx == 0u) { if (ll0) { offset = rep1; rep1 = rep0; rep0 = offset; } else offset = rep0; }
@@ -205,7 +208,7 @@ struct ZDSeqLane {
                 rep1 = rep0; rep0 = t; offset = t;
             }
         }
-        if (!last) { sLL = ((u32)(cl >> 32) & 0xFFFFu) + vl; sML = ((u32)(cm >> 32) & 0xFFFFu) + vm; sOF = ((u32)(co >> 32) & 0xFFFFu) + vo; }
+        if (!last) { sLL = ZD_CELL_NEXT(cl) + vl; sML = ZD_CELL_NEXT(cm) + vm; sOF = ZD_CELL_NEXT(co) + vo; }
         // the checks of ZSTD_execSequence (:1001-1096): literals available, room in the block, offset inside the output
         if (llen > litSize - lpos || (u64)opos + llen + mlen > cap || offset > opos + llen) { bad = 1; finish(); return; }
         seqs[i] = zd_seq_pack(llen, mlen, offset);

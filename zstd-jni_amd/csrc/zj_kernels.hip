@@ -53,7 +53,7 @@ extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
-                                                          u32 n, u32* counter, u64* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts) {
+                                                          u32 n, u32* counter, u32* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts) {
     __shared__ ZDecShared sh;
     Grp<64> g;
     for (;;) {
@@ -69,9 +69,13 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict
 }
 
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
-                                                         const u32* countPtr, u32* workCounter, const u64* tabs, u64* seqs, ZDMeta* metas) {
+                                                         const u32* countPtr, u32* workCounter, const u32* tabs, u64* seqs, ZDMeta* metas) {
+    __shared__ u32 llBase[36], mlBase[53];
+    if (threadIdx.x < 36) llBase[threadIdx.x] = zd_k_ll_base[threadIdx.x];
+    if (threadIdx.x < 53) mlBase[threadIdx.x] = zd_k_ml_base[threadIdx.x];
+    __syncthreads();
     u32 const count = *countPtr;
-    ZDSeqLane m; m.st = 2;
+    ZDSeqLane m; m.st = 2; m.llBase = llBase; m.mlBase = mlBase;
     for (;;) {
         if (m.st == 2) {
             u32 const k = atomicAdd(workCounter, 1u);
@@ -478,7 +482,7 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
             if (hipMalloc(&d->dsplitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->dsplitBufCap = need;
         }
-        u64* const tabs = (u64*)d->dsplitBuf; u64* const seqs = (u64*)(d->dsplitBuf + tabBytes);
+        u32* const tabs = (u32*)d->dsplitBuf; u64* const seqs = (u64*)(d->dsplitBuf + tabBytes);
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused
@@ -489,7 +493,7 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
-                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u64*)tabs, seqs, metas);
+                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u32*)tabs, seqs, metas);
         (void)hipEventRecord(d->tev[4], st);
         hipLaunchKernelGGL(zj_dec_exec_kernel, dim3((u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid)), dim3(64), ZD_SHARED_NO_FSE, st,
                            (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
