@@ -80,6 +80,26 @@ size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off,
                                    void* d_dst, const uint64_t* d_dst_off,
                                    uint64_t* d_result, size_t n, int level, int checksum, void* stream);
 
+/* ---- dictionaries, decompress side (SURVEY.md §8a last rows; BASELINE config 4) ----
+ * zjni_ddict == ZSTD_DDict as zstd-jni holds it in ZstdDictDecompress.nativePtr (J/ZstdDictDecompress.java,
+ * N/jni_fast_zstd.c:56-96): created once from the dictionary bytes (zstd dictionary format with magic
+ * 0xEC30A437, or raw content), shared read-only by any number of batch calls on the device it was created on.
+ * createDDict returns NULL for a corrupted dictionary (ZSTD_createDDict does the same) or without a device. */
+typedef struct zjni_ddict zjni_ddict;
+zjni_ddict* zjni_createDDict(const void* dict, size_t dictSize);
+size_t zjni_freeDDict(zjni_ddict* ddict);
+unsigned zjni_getDictID_fromDDict(const zjni_ddict* ddict);
+/* Replaces ZSTD_decompress_usingDDict (N/jni_fast_zstd.c:133-183 decompress*FastDict0, and
+ * ZstdDecompressCtx.loadDict + decompress*0) for n frames at once.  ddict == NULL behaves like
+ * zjni_decompress_batch_device.  Frames naming another dictionary ID report ZSTD_error_dictionary_wrong. */
+size_t zjni_decompress_batch_device_usingDDict(const void* d_src, const uint64_t* d_src_off,
+                                               void* d_dst, const uint64_t* d_dst_off,
+                                               uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream);
+size_t zjni_decompress_batch_usingDDict(const void* const* src, const size_t* srcSize,
+                                        void* const* dst, const size_t* dstCapacity,
+                                        size_t* result, size_t n, const zjni_ddict* ddict);
+size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zjni_ddict* ddict);
+
 /* ---- hot path, host buffers (what a JNI batch native binds; stages through pinned memory) ---- */
 size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize,
                              void* const* dst, const size_t* dstCapacity,

@@ -39,6 +39,18 @@ def lib():
         L.ZSTD_findFrameCompressedSize.restype = C.c_size_t
         L.ZSTD_findFrameCompressedSize.argtypes = [C.c_void_p, C.c_size_t]
         L.ZSTD_versionString.restype = C.c_char_p
+        # dictionary entry points (reference N/jni_fast_zstd.c:133-244 -> ZSTD_compress_usingDict / ZSTD_decompress_usingDict,
+        # N/jni_zdict.c -> ZDICT_trainFromBuffer)
+        L.ZSTD_compress_usingDict.restype = C.c_size_t
+        L.ZSTD_compress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.ZSTD_decompress_usingDict.restype = C.c_size_t
+        L.ZSTD_decompress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ZDICT_trainFromBuffer.restype = C.c_size_t
+        L.ZDICT_trainFromBuffer.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_uint]
+        L.ZDICT_isError.restype = C.c_uint
+        L.ZDICT_isError.argtypes = [C.c_size_t]
+        L.ZDICT_getDictID.restype = C.c_uint
+        L.ZDICT_getDictID.argtypes = [C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -90,6 +102,46 @@ def decompress(frame: bytes, cap: int) -> bytes:
         return dst.raw[:r]
     finally:
         L.ZSTD_freeDCtx(dctx)
+
+
+def compress_using_dict(data: bytes, dictionary: bytes, level: int = 3) -> bytes:
+    """ZSTD_compress_usingDict — what Zstd.compressUsingDict / compressFastDict reach (reference N/jni_zstd.c, jni_fast_zstd.c)."""
+    L = lib()
+    cctx = L.ZSTD_createCCtx()
+    try:
+        cap = L.ZSTD_compressBound(len(data))
+        dst = C.create_string_buffer(max(cap, 1))
+        r = _check(L.ZSTD_compress_usingDict(cctx, dst, cap, data, len(data), dictionary, len(dictionary), level))
+        return dst.raw[:r]
+    finally:
+        L.ZSTD_freeCCtx(cctx)
+
+
+def decompress_using_dict(frame: bytes, dictionary: bytes, cap: int) -> bytes:
+    L = lib()
+    dctx = L.ZSTD_createDCtx()
+    try:
+        dst = C.create_string_buffer(max(cap, 1))
+        r = _check(L.ZSTD_decompress_usingDict(dctx, dst, cap, frame, len(frame), dictionary, len(dictionary)))
+        return dst.raw[:r]
+    finally:
+        L.ZSTD_freeDCtx(dctx)
+
+
+def train_dict(samples, dict_size: int) -> bytes:
+    """ZDICT_trainFromBuffer (Zstd.trainFromBuffer, reference N/jni_zdict.c)."""
+    L = lib()
+    blob = b"".join(samples)
+    sizes = (C.c_size_t * len(samples))(*[len(x) for x in samples])
+    dst = C.create_string_buffer(dict_size)
+    r = L.ZDICT_trainFromBuffer(dst, dict_size, blob, sizes, len(samples))
+    if L.ZDICT_isError(r):
+        raise ZstdRefError("ZDICT_trainFromBuffer failed")
+    return dst.raw[:r]
+
+
+def dict_id(dictionary: bytes) -> int:
+    return lib().ZDICT_getDictID(dictionary, len(dictionary))
 
 
 def frame_content_size(frame: bytes) -> int:

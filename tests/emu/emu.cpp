@@ -34,6 +34,21 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     free(seqs); free(tab); free(lit); free(sh);
     return r;
 }
+// dictionary decode: digest (ZSTD_createDDict) + ZSTD_decompress_usingDDict
+extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
+                                                  const unsigned char* dict, unsigned dictSize) {
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    ZDDictDev* dd = (ZDDictDev*)calloc(1, sizeof(ZDDictDev));
+    ZjProf pf; pf.start(nullptr);
+    zd_ddict_digest(g, *sh, dict, dictSize, dd);
+    u64 r;
+    if (dd->status) r = ZJ_ERR64(dd->status);
+    else { memset(sh, 0, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
+    free(dd); free(lit); free(sh);
+    return r;
+}
 extern "C" unsigned emu_dec_shared_bytes() { return (unsigned)sizeof(ZDecShared); }
 
 #include "../../zstd-jni_amd/csrc/zj_encode.h"

@@ -7,7 +7,7 @@ import hashlib
 import pytest
 
 from conftest import golden, XML_SHA256_PREFIX
-from util import edge_inputs, emu_lib, emu_decompress, emu_decompress_split
+from util import edge_inputs, emu_lib, emu_decompress, emu_decompress_split, emu_decompress_dict, json_records
 
 
 @pytest.fixture(scope="module")
@@ -92,3 +92,45 @@ def test_emu_split_pipeline(emu, oracle_ref, zj):
         bad = bytearray(z); bad[pos] ^= 0x41
         a = emu_decompress_split(emu, bytes(bad), len(data))[0]; b = emu_decompress(emu, bytes(bad), len(data))
         assert a == b, pos
+
+
+def test_emu_dictionary_decode(emu, oracle_ref, zj):
+    """ZstdDictDecompress / ZSTD_decompress_usingDDict (T/scala/ZstdDict.scala:58-216): frames the reference compressed
+    with a trained dictionary and with a raw-content dictionary decode to the original; wrong / missing / corrupted
+    dictionaries give the reference's error codes"""
+    import random
+    rnd = random.Random(5)
+    trained = oracle_ref.train_dict(json_records(2000), 16384)
+    assert trained[:4] == bytes.fromhex("37a430ec")
+    raw = b"".join(json_records(40, seed=9, first=7000))                    # content-only dictionary (no magic)
+    for d in (trained, raw):
+        for _ in range(40):
+            k = rnd.choice([1, 1, 2, 5, 30, 300])
+            data = b"".join(json_records(k, seed=rnd.randrange(1000), first=rnd.randrange(100000)))
+            if rnd.random() < 0.2:
+                data = zj.synth_host(rnd.randrange(1, 70000), rnd.randrange(1000), 1)
+            for level in (1, 3, 5, 9):
+                z = oracle_ref.compress_using_dict(data, d, level)
+                assert oracle_ref.decompress_using_dict(z, d, len(data)) == data
+                out = emu_decompress_dict(emu, z, len(data), d)
+                assert out == data, (len(data), level, out if isinstance(out, int) else "bytes differ")
+        # a buffer of two frames, both using the dictionary
+        a, b = b"".join(json_records(3, first=11)), b"".join(json_records(4, first=99))
+        z = oracle_ref.compress_using_dict(a, d, 3) + oracle_ref.compress_using_dict(b, d, 3)
+        assert emu_decompress_dict(emu, z, len(a) + len(b), d) == a + b
+    data = b"".join(json_records(5, first=3))
+    z = oracle_ref.compress_using_dict(data, trained, 3)
+    assert emu_decompress(emu, z, len(data)) == -32                          # frame names a dictionary, none given
+    other = oracle_ref.train_dict(json_records(2000, seed=4, first=50000), 8192)
+    if oracle_ref.dict_id(other) != oracle_ref.dict_id(trained):
+        assert emu_decompress_dict(emu, z, len(data), other) == -32          # dictionary_wrong
+    broken = bytearray(trained); broken[9] ^= 0xFF; broken[10] ^= 0xFF; broken[12] ^= 0xFF
+    r = emu_decompress_dict(emu, z, len(data), bytes(broken))
+    try:
+        oracle_ref.decompress_using_dict(z, bytes(broken), len(data)); ref_ok = True
+    except Exception:                                                        # noqa: BLE001
+        ref_ok = False
+    assert ref_ok or r == -30
+    # frames made without a dictionary still decode when one is loaded
+    plain = oracle_ref.compress(data, 3)
+    assert emu_decompress_dict(emu, plain, len(data), trained) == data

@@ -152,3 +152,51 @@ def test_gpu_split_pipeline_device_batch(gpu, oracle_port, force_split):
     torch.cuda.synchronize()
     assert bool((res == size).all()), res[res != size][:8]
     assert torch.equal(d_dst, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda())
+
+
+def test_gpu_dictionary_decode(gpu, oracle_ref):
+    """ZstdDictDecompress + ZstdDecompressCtx.loadDict / Zstd.decompress(src, dict, size) (T/scala/ZstdDict.scala:58-216):
+    reference-made dictionary frames (trained dictionary and raw-content dictionary) decode bit-exactly in one batch;
+    missing / wrong dictionaries give the reference's error codes"""
+    import random
+    from util import json_records
+    rnd = random.Random(5)
+    trained = oracle_ref.train_dict(json_records(2000), 16384)
+    raw = b"".join(json_records(40, seed=9, first=7000))
+    for dbytes in (trained, raw):
+        with gpu.ZstdDictDecompress(dbytes) as dd:
+            if dbytes is trained:
+                assert dd.getDictID() == oracle_ref.dict_id(trained)
+            datas, frames = [], []
+            for _ in range(200):
+                k = rnd.choice([1, 1, 2, 5, 30, 300])
+                data = b"".join(json_records(k, seed=rnd.randrange(1000), first=rnd.randrange(100000)))
+                if rnd.random() < 0.15:
+                    data = gpu.synth_host(rnd.randrange(1, 70000), rnd.randrange(1000), 1)
+                datas.append(data); frames.append(oracle_ref.compress_using_dict(data, dbytes, rnd.choice([1, 3, 5, 9])))
+            a, b = datas[0], datas[1]
+            datas.append(a + b); frames.append(frames[0] + frames[1])        # two frames in one buffer
+            outs = gpu.decompress_batch(frames, [len(d) for d in datas], dd)
+            for k, (d, o) in enumerate(zip(datas, outs)):
+                assert not isinstance(o, Exception), (k, o)
+                assert o == d, k
+            # per-buffer API
+            with gpu.ZstdDecompressCtx() as ctx:
+                ctx.loadDict(dd)
+                assert ctx.decompress(frames[3], len(datas[3])) == datas[3]
+                ctx.loadDict(dbytes)
+                assert ctx.decompress(frames[4], len(datas[4])) == datas[4]
+            assert gpu.Zstd.decompress(frames[5], dbytes, len(datas[5])) == datas[5]
+    data = b"".join(json_records(5, first=3))
+    z = oracle_ref.compress_using_dict(data, trained, 3)
+    with pytest.raises(gpu.ZstdException) as e:
+        gpu.Zstd.decompress(z, len(data))                                # frame names a dictionary, none loaded
+    assert e.value.getErrorCode() == 32
+    other = oracle_ref.train_dict(json_records(2000, seed=4, first=50000), 8192)
+    if oracle_ref.dict_id(other) != oracle_ref.dict_id(trained):
+        with pytest.raises(gpu.ZstdException) as e:
+            gpu.Zstd.decompress(z, other, len(data))
+        assert e.value.getErrorCode() == 32
+    with gpu.ZstdDictDecompress(trained) as dd:                           # dictionary loaded, plain frames still fine
+        plain = [oracle_ref.compress(d, 3) for d in (data, data * 7)]
+        assert gpu.decompress_batch(plain, [len(data), 7 * len(data)], dd) == [data, data * 7]

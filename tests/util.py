@@ -16,6 +16,8 @@ def emu_lib():
     L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
     L.emu_decompress_split.restype = C.c_ulonglong
     L.emu_decompress_split.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.POINTER(C.c_int)]
+    L.emu_decompress_dict.restype = C.c_ulonglong
+    L.emu_decompress_dict.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
     for fn in ("emu_compress", "emu_compress_split"):
         if hasattr(L, fn):
             getattr(L, fn).restype = C.c_ulonglong
@@ -29,6 +31,25 @@ def emu_decompress(L, frame, cap):
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]
+
+
+def emu_decompress_dict(L, frame, cap, dictionary):
+    dst = C.create_string_buffer(max(cap, 1))
+    r = L.emu_decompress_dict(frame, len(frame), dst, cap, dictionary, len(dictionary))
+    if r >= (1 << 63):
+        return -((1 << 64) - r)
+    return dst.raw[:r]
+
+
+def json_records(n, seed=1, first=0):
+    """small JSON-like records (the shape of BASELINE config 4) for dictionary tests"""
+    rnd = random.Random(seed)
+    names = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel"]
+    out = []
+    for i in range(first, first + n):
+        out.append(('{"id":%d,"name":"%s","tags":["%s","%s"],"score":%d,"active":%s,"note":"record number %d of the set"}'
+                    % (i, names[i % 8], names[(i * 3) % 8], names[(i * 5) % 8], rnd.randrange(1000), "true" if i % 2 else "false", i)).encode())
+    return out
 
 
 def emu_decompress_split(L, frame, cap):

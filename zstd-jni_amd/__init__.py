@@ -38,7 +38,17 @@ def build(force=False, verbose=False):
            "-o", LIB_PATH, SOURCES[0]]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+
+    def _big_stack():
+        # the fully inlined kernels make clang's inliner/optimizer recurse deeply; with the default 8 MiB stack
+        # the device compilation can die with SIGSEGV, so the compiler runs with the hard limit as soft limit
+        import resource
+        soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+        try:
+            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+        except (ValueError, OSError):
+            pass
+    subprocess.check_call(cmd, preexec_fn=_big_stack)
     return LIB_PATH
 
 
@@ -78,6 +88,18 @@ def lib():
     L.zjni_compress_batch2.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int, C.c_int]
     L.zjni_compress2.restype = sz
     L.zjni_compress2.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int]
+    L.zjni_createDDict.restype = vp
+    L.zjni_createDDict.argtypes = [vp, sz]
+    L.zjni_freeDDict.restype = sz
+    L.zjni_freeDDict.argtypes = [vp]
+    L.zjni_getDictID_fromDDict.restype = C.c_uint
+    L.zjni_getDictID_fromDDict.argtypes = [vp]
+    L.zjni_decompress_batch_device_usingDDict.restype = sz
+    L.zjni_decompress_batch_device_usingDDict.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
+    L.zjni_decompress_batch_usingDDict.restype = sz
+    L.zjni_decompress_batch_usingDDict.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, vp]
+    L.zjni_decompress_usingDDict.restype = sz
+    L.zjni_decompress_usingDDict.argtypes = [vp, sz, vp, sz, vp]
     L.zjni_decompress_batch.restype = sz
     L.zjni_decompress_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz]
     L.zjni_compress_batch.restype = sz
@@ -106,7 +128,9 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_decompress_batch_device", "zjni_compress_batch_device", "zjni_decompress_batch",
            "zjni_compress_batch", "zjni_compress", "zjni_decompress", "zjni_synth_fill_host",
            "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing",
-           "zjni_compress_batch_device2", "zjni_compress_batch2", "zjni_compress2")
+           "zjni_compress_batch_device2", "zjni_compress_batch2", "zjni_compress2",
+           "zjni_createDDict", "zjni_freeDDict", "zjni_getDictID_fromDDict", "zjni_decompress_batch_device_usingDDict",
+           "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict")
 
 
 # --------------------------------------------------------------------------- Java API mirror --
@@ -200,8 +224,11 @@ class Zstd:
             return ctx._raw(dst, dstOffset, dstSize, src, srcOffset, srcSize)
 
     @staticmethod
-    def decompress(src, originalSize):                             # J/Zstd.java:1435 (byte[], int -> byte[])
+    def decompress(src, originalSize_or_dict, originalSize=None):   # J/Zstd.java:1435 (byte[], int), :1470-1500 (byte[], dict, int)
         with ZstdDecompressCtx() as ctx:
+            if originalSize is None:
+                return ctx.decompress(src, originalSize_or_dict)
+            ctx.loadDict(originalSize_or_dict)
             return ctx.decompress(src, originalSize)
 
 
@@ -286,8 +313,56 @@ class ZstdCompressCtx(_AutoClose):
         return bytes(out[:n])
 
 
+class ZstdDictDecompress(_AutoClose):
+    """J/ZstdDictDecompress.java: a dictionary digested once (ZSTD_createDDict, N/jni_fast_zstd.c:56-75) and shared
+    read-only by any number of decompress calls; close() frees the device copy."""
+
+    def __init__(self, dictionary, offset=0, length=None):
+        super().__init__()
+        data = bytes(dictionary)[offset:(None if length is None else offset + length)]
+        self._ptr = lib().zjni_createDDict(data, len(data))
+        if not self._ptr:
+            raise ZstdException(30)                              # dictionary_corrupted (the Java class throws IllegalStateException)
+
+    def close(self):
+        if not self._closed and self._ptr:
+            lib().zjni_freeDDict(self._ptr)
+            self._ptr = None
+        super().close()
+
+    def getDictID(self):                                         # Zstd.getDictIdFromDict
+        self._ensure_open()
+        return lib().zjni_getDictID_fromDDict(self._ptr)
+
+
 class ZstdDecompressCtx(_AutoClose):
     """J/ZstdDecompressCtx.java — one-shot methods of the hot path."""
+
+    def __init__(self):
+        super().__init__()
+        self._ddict = None
+        self._owned = None
+
+    def loadDict(self, dictionary):                              # J/ZstdDecompressCtx.java:88-121 (ZstdDictDecompress or byte[])
+        self._ensure_open()
+        if self._owned is not None:
+            self._owned.close()
+            self._owned = None
+        if dictionary is None:
+            self._ddict = None
+        elif isinstance(dictionary, ZstdDictDecompress):
+            dictionary._ensure_open()
+            self._ddict = dictionary
+        else:
+            self._owned = ZstdDictDecompress(dictionary)
+            self._ddict = self._owned
+        return self
+
+    def close(self):
+        if self._owned is not None:
+            self._owned.close()
+            self._owned = None
+        super().close()
 
     def _raw(self, dst, dstOffset, dstSize, src, srcOffset, srcSize):
         """decompressByteArray0 / decompressDirectByteBuffer0 (N/jni_fast_zstd.c:777-836)."""
@@ -305,7 +380,8 @@ class ZstdDecompressCtx(_AutoClose):
             return -70
         sa, k1 = _addr(src, srcOffset)
         da, k2 = _addr(dst, dstOffset)
-        r = lib().zjni_decompress(da, dstSize, sa, srcSize)
+        dd = self._ddict._ptr if self._ddict is not None else None
+        r = lib().zjni_decompress_usingDDict(da, dstSize, sa, srcSize, dd)
         return r - (1 << 64) if r >= (1 << 63) else r
 
     def decompressByteArray(self, dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize):   # J/ZstdDecompressCtx.java:239
@@ -341,12 +417,12 @@ def compress_batch(buffers, level=3, checksum=False):
     return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum)
 
 
-def decompress_batch(frames, capacities):
-    """n independent frames -> n buffers through zjni_decompress_batch (host pointers)."""
-    return _host_batch(frames, list(capacities), False, 0)
+def decompress_batch(frames, capacities, dictionary=None):
+    """n independent frames -> n buffers through zjni_decompress_batch[_usingDDict] (host pointers)."""
+    return _host_batch(frames, list(capacities), False, 0, False, dictionary)
 
 
-def _host_batch(srcs, caps, is_compress, level, checksum=False):
+def _host_batch(srcs, caps, is_compress, level, checksum=False, dictionary=None):
     L = lib()
     n = len(srcs)
     if n == 0:
@@ -361,7 +437,7 @@ def _host_batch(srcs, caps, is_compress, level, checksum=False):
     if is_compress:
         r = L.zjni_compress_batch2(sp, ss, dp, dc, res, n, level, 1 if checksum else 0)
     else:
-        r = L.zjni_decompress_batch(sp, ss, dp, dc, res, n)
+        r = L.zjni_decompress_batch_usingDDict(sp, ss, dp, dc, res, n, dictionary._ptr if dictionary is not None else None)
     _check_launch(r)
     out = []
     for i in range(n):

@@ -53,13 +53,14 @@ def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checks
     return results
 
 
-def decompress(src_blob, src_off, dst_blob, dst_off, results=None):
-    """Enqueue zjni_decompress_batch_device on the current stream; returns int64[n] results."""
+def decompress(src_blob, src_off, dst_blob, dst_off, results=None, dictionary=None):
+    """Enqueue zjni_decompress_batch_device[_usingDDict] on the current stream; returns int64[n] results."""
     n = src_off.numel() - 1
     if results is None:
         results = torch.empty(n, dtype=torch.int64, device=src_blob.device)
-    _check(lib().zjni_decompress_batch_device(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
-                                              results.data_ptr(), n, _stream_ptr()))
+    dd = dictionary._ptr if dictionary is not None else None    # a zstd_jni_amd.ZstdDictDecompress
+    _check(lib().zjni_decompress_batch_device_usingDDict(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
+                                                         results.data_ptr(), n, dd, _stream_ptr()))
     return results
 
 

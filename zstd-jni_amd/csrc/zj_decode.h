@@ -60,6 +60,7 @@ struct ZDecShared {
     u32 nbSeq, seqOff;              // sequences section start (rel. to block)
     u32 bN, bLitStart, bOutStart, bLitTotal, bOutTotal, seqDone, winLo;
     u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
+    u32 dictSize;                   // bytes of dictionary content before the frame's output (0 = none)
     // --- tANS tables last: the execute-only kernel of the split pipeline allocates the struct without them ---
     u32 ll[512];
     u32 ml[512];
@@ -275,7 +276,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         // validity is accumulated (64-bit so nothing wraps) and tested after the batch; nothing is executed on a bad batch
         bad |= (llen > litSize - p.lpos) ? 1u : 0u;
         bad |= ((u64)p.opos + llen + mlen > dstCap) ? 2u : 0u;
-        bad |= ((u64)offset > (u64)p.opos + llen) ? 1u : 0u;
+        bad |= ((u64)offset > (u64)p.opos + llen + sh.dictSize) ? 1u : 0u;     // may reach into the dictionary content
         if (bad) break;
         sh.sLit[n] = llen; sh.sMl[n] = mlen; sh.sOff[n] = offset;
         p.lpos += llen; p.opos += llen + mlen; litTotal += llen; outTotal += llen + mlen;
@@ -391,7 +392,7 @@ ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit
 // produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
 // range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
 template <class G>
-ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot, u8* stage = nullptr, u32 litAvail = 0) {
+ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot, u8* stage = nullptr, u32 litAvail = 0, const u8* dictEnd = nullptr) {
 #if ZJ_ON_GPU
     u32 const k = g.lane();
     bool const valid = k < n;
@@ -424,11 +425,15 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     // ---- matches: dependency rounds ----
     sh.sLit[k] = mp; sh.sMl[k] = mp + ml;          // reuse as mStart / mEnd arrays (LDS)
     g.sync();
-    u32 const ms = mp - off;                      // first source byte
-    u32 const me = zj_min(ms + ml, mp);           // source bytes at/after mp are produced by this match itself
+    // a source position before the frame's output lies in the dictionary content (ZSTD_execSequence's extDict branch,
+    // N/decompress/zstd_decompress_block.c:1051-1068): dn bytes come from there, the rest from the output
+    i32 const sp = (i32)mp - (i32)off;
+    u32 const dn = sp < 0 ? zj_min(ml, (u32)(-sp)) : 0u;
+    u32 const ms = sp < 0 ? 0u : (u32)sp;         // first source byte inside the output
+    u32 const me = zj_min(ms + (ml - dn), mp);    // source bytes at/after mp are produced by this match itself
     // earlier lanes whose match output [mStart_j, mEnd_j) intersects [ms, me): a contiguous lane range
     u64 dep = 0;
-    if (valid && ml) {
+    if (valid && ml > dn) {
         u32 lo = 0, hi = k;                       // first j in [0,k) with mEnd_j > ms
         while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sMl[mid] > ms) hi = mid; else lo = mid + 1; }
         u32 const jlo = lo;
@@ -446,9 +451,16 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         u64 big = __ballot(ready && ml > 64);
         while (big) {
             u32 const q = (u32)__builtin_ctzll(big); big &= big - 1;
-            u32 const qml = ZJ_UNI(__shfl(ml, q, 64)), qoff = ZJ_UNI(__shfl(off, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64));
+            u32 qml = ZJ_UNI(__shfl(ml, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64)); u32 const qoff = ZJ_UNI(__shfl(off, q, 64));
+            if (qoff > qmp) {                     // starts in the dictionary content: that part first, the rest is an ordinary match
+                u32 const used = zj_min(qml, qoff - qmp);
+                grp_copy_wide(g, out + qmp, dictEnd - (qoff - qmp), used);
+                zj_mem_order();
+                qmp += used; qml -= used;
+            }
             const u8* const m = out + qmp - qoff;
-            if (qoff >= qml) grp_copy_wide(g, out + qmp, m, qml);
+            if (qml == 0) { }
+            else if (qoff >= qml) grp_copy_wide(g, out + qmp, m, qml);
             else if (qoff >= 64) { for (u32 base = 0; base < qml; base += 64) { u32 const j = base + k; if (j < qml) out[qmp + j] = m[j]; zj_mem_order(); } }
             else { GRP_FOR(g, j, qml) out[qmp + j] = m[j % qoff]; }
             zj_mem_order();
@@ -456,6 +468,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         if (ready && ml <= 64) {
             u8* const d = out + mp; const u8* const m = d - off;
             u32 j = 0;
+            if (dn) { const u8* const dm = dictEnd + sp; for (; j + 8 <= dn; j += 8) st64(d + j, ld64(dm + j)); for (; j < dn; j++) d[j] = dm[j]; }
             if (off >= 8) { for (; j + 8 <= ml; j += 8) st64(d + j, ld64(m + j)); }
             for (; j < ml; j++) d[j] = m[j];
         }
@@ -471,8 +484,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         litTot += ll; outTot += ll + ml;
         for (u32 j = 0; j < ll; j++) out[op + j] = lit[lp + j];
         lp += ll; op += ll;
-        const u8* const m = out + op - off;
-        for (u32 j = 0; j < ml; j++) out[op + j] = m[j];
+        for (u32 j = 0; j < ml; j++) { i32 const v = (i32)op - (i32)off + (i32)j; out[op + j] = v < 0 ? dictEnd[v] : out[v]; }
         op += ml;
     }
     (void)g;
@@ -557,6 +569,79 @@ ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* 
     return iSize + 1;
 }
 
+// Huffman decode table from the weights zd_huf_read_weights left in sh (all lanes): cell = nbBits << 8 | symbol
+template <class G>
+ZJ_DEV void zd_huf_fill(const G& g, ZDecShared& sh, u32 nbSym) {
+    u32 const log = ZJ_UNI(sh.hufLog);
+    GRP_FOR(g, s, nbSym) {
+        u32 const w = sh.weights[s];
+        if (w) {
+            u32 const len = 1u << (w - 1), p0 = sh.symPos[s];
+            u16 const cell = (u16)(((log + 1 - w) << 8) | s);
+            for (u32 k = 0; k < len; k++) sh.huf[p0 + k] = cell;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dictionaries -------------
+// A digested dictionary in HBM = what ZSTD_createDDict keeps (N/decompress/zstd_ddict.c:36-130,
+// ZSTD_loadDEntropy N/decompress/zstd_decompress.c:1448-1533): entropy tables in the decoder's own cell
+// formats, the three start repcodes, and where the content starts in the raw dictionary bytes.
+struct ZDDictDev {
+    u32 status;                     // 0 ok, else ZJ_E_* (dictionary_corrupted)
+    u32 dictID, contentOff, contentSize, hasEntropy;
+    u32 rep[3];
+    u32 hufLog, llLog, ofLog, mlLog;
+    u16 huf[1u << ZD_HUF_LOG_MAX];
+    u32 ll[512], ml[512], of[256];
+};
+// Runs on one workgroup; `sh` is scratch.  Raw-content dictionaries (no magic) have no entropy section.
+template <class G>
+ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dictSize, ZDDictDev* out) {
+    GRP_SERIAL(g) {
+        sh.err = 0; sh.bN = 0; sh.blkType = 0;            // blkType: has entropy
+        sh.hdrSize = 0;                                    // content offset
+        sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8;
+        sh.windowSize = 0;                                 // dictID
+        if (dictSize >= 8 && ld32(dict) == 0xEC30A437u) {
+            u32 pos = 8, err = 0, nbSym = 0;
+            sh.windowSize = ld32(dict + 4);
+            {   u32 const h = zd_huf_read_weights(sh, dict + pos, dictSize - pos, &nbSym);
+                if (!h || h > dictSize - pos) err = ZJ_E_DICT_CORRUPTED; else pos += h; }
+            sh.bN = nbSym;
+            for (u32 t = 0; t < 3 && !err; t++) {          // order in the dictionary: OF, ML, LL
+                u32 const kind = t == 0 ? 1u : (t == 1 ? 2u : 0u);
+                u32 max = kind == 0 ? 35u : (kind == 1 ? 31u : 52u), tl = 0;
+                u32 const h = zd_read_ncount(sh.norm, &max, &tl, dict + pos, dictSize - pos);
+                if (!h || h > dictSize - pos || tl > (kind == 1 ? 8u : 9u)) { err = ZJ_E_DICT_CORRUPTED; break; }
+                u32* const cells = kind == 0 ? sh.ll : (kind == 1 ? sh.of : sh.ml);
+                if (!zd_build_fse(cells, sh.norm, sh.symNext, max, tl, kind)) { err = ZJ_E_DICT_CORRUPTED; break; }
+                if (kind == 0) sh.llLog = tl; else if (kind == 1) sh.ofLog = tl; else sh.mlLog = tl;
+                pos += h;
+            }
+            if (!err && pos + 12 > dictSize) err = ZJ_E_DICT_CORRUPTED;
+            if (!err) {
+                u32 const content = dictSize - (pos + 12);
+                for (u32 i = 0; i < 3; i++) { u32 const r = ld32(dict + pos + 4 * i); if (r == 0 || r > content) err = ZJ_E_DICT_CORRUPTED; sh.rep[i] = r; }
+                sh.hdrSize = pos + 12; sh.blkType = 1;
+            }
+            if (err) sh.err = err;
+        }
+    }
+    g.sync();
+    if (!ZJ_UNI(sh.err) && ZJ_UNI(sh.blkType)) { zd_huf_fill(g, sh, ZJ_UNI(sh.bN)); g.sync(); }
+    GRP_FOR(g, i, 1u << ZD_HUF_LOG_MAX) out->huf[i] = sh.huf[i];
+    GRP_FOR(g, i, 512) { out->ll[i] = sh.ll[i]; out->ml[i] = sh.ml[i]; }
+    GRP_FOR(g, i, 256) out->of[i] = sh.of[i];
+    GRP_SERIAL(g) {
+        out->status = sh.err; out->dictID = sh.windowSize; out->contentOff = sh.hdrSize; out->contentSize = dictSize - sh.hdrSize;
+        out->hasEntropy = sh.blkType; out->rep[0] = sh.rep[0]; out->rep[1] = sh.rep[1]; out->rep[2] = sh.rep[2];
+        out->hufLog = sh.hufLog; out->llLog = sh.llLog; out->ofLog = sh.ofLog; out->mlLog = sh.mlLog;
+    }
+    zj_mem_order();
+    g.sync();
+}
+
 // Decode <= ZD_HSYM symbols of stream t from its LDS window (one lane per stream).
 // N/decompress/huf_decompress.c:721-835 (4X1 loop), :600-640 (1X1).
 ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
@@ -638,17 +723,8 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
             }
             g.sync();
             if (ZJ_UNI(sh.err)) return nullptr;
-            {   u32 const log = ZJ_UNI(sh.hufLog), nbSym = ZJ_UNI(sh.bN);
-                GRP_FOR(g, s, nbSym) {
-                    u32 const w = sh.weights[s];
-                    if (w) {
-                        u32 const len = 1u << (w - 1), p0 = sh.symPos[s];
-                        u16 const cell = (u16)(((log + 1 - w) << 8) | s);
-                        for (u32 k = 0; k < len; k++) sh.huf[p0 + k] = cell;
-                    }
-                }
-                GRP_SERIAL(g) { sh.hufValid = 1; }
-            }
+            zd_huf_fill(g, sh, ZJ_UNI(sh.bN));
+            GRP_SERIAL(g) { sh.hufValid = 1; }
         } else { GRP_SERIAL(g) { sh.litSrcOff = litHdr; } }
         g.sync();
         pf.mark(1);
@@ -788,7 +864,7 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
 // Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
 // (frame-relative position `opos`).  Returns new opos (or sets sh.err).
 template <class G>
-ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf) {
+ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf, const u8* dictEnd = nullptr) {
     const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
     if (ZJ_UNI(sh.err)) return opos;
     u32 const litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
@@ -839,7 +915,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 u32 const lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
                 u32 const lt = ZJ_UNI(sh.bLitTotal), ot = ZJ_UNI(sh.bOutTotal);
                 u32 lt2, ot2;
-                zd_execute_batch(g, sh, out, lit, n, lp, op, lt2, ot2);
+                zd_execute_batch(g, sh, out, lit, n, lp, op, lt2, ot2, nullptr, 0, dictEnd);
                 litUsed = lp + lt; opos = op + ot;
             }
             pf.mark(5);
@@ -864,9 +940,13 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
 // Decodes all frames in [src, src+srcSize) into dst[0..dstCap).  Returns decoded size or
 // ZJ_ERR64(code) — the reference's size_t error convention (N/common/error_private.h).
 template <class G>
-ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch, ZjProf& pf) {
+ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch, ZjProf& pf,
+                         const ZDDictDev* dd = nullptr, const u8* dictRaw = nullptr) {
+    // dd: digested dictionary (ZSTD_decompress_usingDDict, N/decompress/zstd_decompress.c:1661-1672); every frame of the
+    // buffer starts from its entropy tables / repcodes and may copy from its content
+    const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
-        sh.err = 0;
+        sh.err = 0; sh.dictSize = dd ? dd->contentSize : 0u;
     }
     GRP_FOR(g, i, 36) sh.llBase[i] = zd_k_ll_base[i];
     GRP_FOR(g, i, 53) sh.mlBase[i] = zd_k_ml_base[i];
@@ -899,18 +979,28 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
                         if (fcsid == 0) { if (single) content = p[pos]; } else if (fcsid == 1) content = ld16(p + pos) + 256; else if (fcsid == 2) content = ld32(p + pos); else content = ld64(p + pos);
                         if (single) window = content;
                         if (!err && window > (((u64)1 << 27) + 1)) err = ZJ_E_WINDOW_TOO_LARGE;
-                        if (!err && dictID) err = ZJ_E_DICT_WRONG;
+                        if (!err && dictID && dictID != (dd ? dd->dictID : 0u)) err = ZJ_E_DICT_WRONG;   // zstd_decompress.c:717
                         sh.hdrSize = need; sh.contentSize = content; sh.hasChecksum = (fhd >> 2) & 1;
                         sh.blockSizeMax = window < ZD_BLOCK_MAX ? (u32)window : ZD_BLOCK_MAX;
                     }
                 }
             }
             sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0;
+            if (dd && dd->hasEntropy) {
+                sh.rep[0] = dd->rep[0]; sh.rep[1] = dd->rep[1]; sh.rep[2] = dd->rep[2]; sh.hufValid = 1; sh.seqValid = 1;
+                sh.hufLog = dd->hufLog; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
+            }
             if (err) sh.err = err;
         }
         g.sync();
         if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
         if (ZJ_UNI(sh.blkType) == 1) { ipos += ZJ_UNI(sh.hdrSize); g.sync(); continue; }
+        if (dd && dd->hasEntropy) {                     // litEntropy = fseEntropy = 1 (zstd_decompress.c:1554)
+            GRP_FOR(g, i, 1u << ZD_HUF_LOG_MAX) sh.huf[i] = dd->huf[i];
+            GRP_FOR(g, i, 512) { sh.ll[i] = dd->ll[i]; sh.ml[i] = dd->ml[i]; }
+            GRP_FOR(g, i, 256) sh.of[i] = dd->of[i];
+            g.sync();
+        }
         ipos += ZJ_UNI(sh.hdrSize);
         u8* const fout = dst + total; u32 const fcap = dstCap - total;
         u32 opos = 0;
@@ -940,7 +1030,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
                 u32 const cap = zj_min(fcap, opos + ZJ_UNI(sh.blockSizeMax));
-                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf);
+                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf, dictEnd);
                 if (ZJ_UNI(sh.err)) {
                     u32 e = ZJ_UNI(sh.err);
                     if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax

@@ -31,7 +31,8 @@ __device__ __forceinline__ u32 zj_next_index(u32* counter) {
 __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof,
-                                                        const u32* __restrict__ list, const u32* listCount) {
+                                                        const u32* __restrict__ list, const u32* listCount,
+                                                        const ZDDictDev* dd, const u8* dictRaw) {
     __shared__ ZDecShared sh;
     ZjProf pf; pf.start(prof);
     Grp<64> g;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__
         if (k >= count) break;
         u32 const i = list ? ZJ_UNI(list[k]) : k;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf);
+        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf, dd, dictRaw);
         pf.mark(8);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
@@ -50,6 +51,13 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__
 }
 
 extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
+
+// ZSTD_createDDict on the device: one workgroup digests the raw dictionary at dictRaw into *out
+__global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, u32 dictSize, ZDDictDev* out) {
+    __shared__ ZDecShared sh;
+    Grp<64> g;
+    zd_ddict_digest(g, sh, dictRaw, dictSize, out);
+}
 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
@@ -462,9 +470,13 @@ int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* enco
     return 0;
 }
 
-size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
-                                    uint64_t* d_result, size_t n, void* stream) {
+struct zjni_ddict { int ordinal; u8* buf; size_t rawSize; unsigned dictID; };   // buf = [ZDDictDev][raw dictionary bytes]
+
+static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                           uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
     DevState* d = cur_state();
+    const ZDDictDev* const ddDev = ddict ? (const ZDDictDev*)ddict->buf : nullptr;
+    const u8* const ddRaw = ddict ? ddict->buf + sizeof(ZDDictDev) : nullptr;
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
@@ -474,7 +486,7 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
     // anything that fails on the way, ends on list B and goes through the fused kernel.  Small batches: fused only.
     size_t splitMin = 4096;
     if (const char* ov = getenv("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
-    if (n >= splitMin) {
+    if (n >= splitMin && !ddict) {                // dictionary frames: fused kernel only (for now)
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
         size_t const need = tabBytes + seqBytes + metaBytes + 2 * listBytes + 256;
         if (d->dsplitBufCap < need) {
@@ -500,15 +512,50 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
                            (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof);
         (void)hipEventRecord(d->tev[5], st);
         hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                           (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1));
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
         (void)hipEventRecord(d->tev[6], st); d->tevDecompress = true;
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr);
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr, ddDev, ddRaw);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
+size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                    uint64_t* d_result, size_t n, void* stream) {
+    return decompress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, nullptr, stream);
+}
+size_t zjni_decompress_batch_device_usingDDict(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                               uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
+    if (ddict && ddict->ordinal != t_dev && t_dev >= 0) return ZJNI_ERR(32);      // digested on another device
+    return decompress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, ddict, stream);
+}
+
+// ZSTD_createDDict (N/decompress/zstd_ddict.c:36-130; ZstdDictDecompress.init, N/jni_fast_zstd.c:56-75): the raw
+// dictionary goes to HBM once and one workgroup digests it there.  NULL when the device or the dictionary is bad.
+zjni_ddict* zjni_createDDict(const void* dict, size_t dictSize) {
+    DevState* d = cur_state();
+    if (!d || !dict || dictSize == 0 || dictSize > 0x7FFFFFFFull) return nullptr;
+    zjni_ddict* dd = new zjni_ddict{t_dev, nullptr, dictSize, 0};
+    if (hipMalloc(&dd->buf, sizeof(ZDDictDev) + dictSize + 16) != hipSuccess) { delete dd; return nullptr; }
+    ZDDictDev head;
+    bool ok = hipMemcpy(dd->buf + sizeof(ZDDictDev), dict, dictSize, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(zj_ddict_digest_kernel, dim3(1), dim3(64), 0, 0, (const u8*)(dd->buf + sizeof(ZDDictDev)), (u32)dictSize, (ZDDictDev*)dd->buf);
+        ok = hipMemcpy(&head, dd->buf, 64, hipMemcpyDeviceToHost) == hipSuccess && head.status == 0;
+    }
+    if (!ok) { (void)hipFree(dd->buf); delete dd; return nullptr; }
+    dd->dictID = head.dictID;
+    return dd;
+}
+size_t zjni_freeDDict(zjni_ddict* dd) {
+    if (!dd) return 0;
+    (void)hipSetDevice(dd->ordinal);
+    (void)hipFree(dd->buf);
+    delete dd;
+    return 0;
+}
+unsigned zjni_getDictID_fromDDict(const zjni_ddict* dd) { return dd ? dd->dictID : 0u; }
 
 static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                          uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
@@ -608,7 +655,7 @@ size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off,
 
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
 static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
-                         size_t* result, size_t n, int level, int checksum = 0) {
+                         size_t* result, size_t n, int level, int checksum = 0, const zjni_ddict* ddict = nullptr) {
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (n == 0) return 0;
@@ -634,8 +681,8 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
         r = zjni_compress_batch_device2(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                         (u64*)(d->dStage + oRes), n, level, checksum, nullptr);
     else
-        r = zjni_decompress_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                                         (u64*)(d->dStage + oRes), n, nullptr);
+        r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                                                    (u64*)(d->dStage + oRes), n, ddict, nullptr);
     if (zjni_isError(r)) return r;
     if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, n * 8, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (hipMemcpyAsync(d->hPinned + oDst, d->dStage + oDst, dstTotal, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -669,6 +716,15 @@ size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, 
 size_t zjni_compress2(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum) {
     size_t res = 0; const void* s = src; void* dd = dst;
     size_t const r = zjni_compress_batch2(&s, &srcSize, &dd, &dstCap, &res, 1, level, checksum);
+    return zjni_isError(r) ? r : res;
+}
+size_t zjni_decompress_batch_usingDDict(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                        const zjni_ddict* ddict) {
+    return host_batch(false, src, srcSize, dst, dstCap, result, n, 0, 0, ddict);
+}
+size_t zjni_decompress_usingDDict(void* dst, size_t dstCap, const void* src, size_t srcSize, const zjni_ddict* ddict) {
+    size_t res = 0; const void* s = src; void* dd = dst;
+    size_t const r = zjni_decompress_batch_usingDDict(&s, &srcSize, &dd, &dstCap, &res, 1, ddict);
     return zjni_isError(r) ? r : res;
 }
 size_t zjni_decompress(void* dst, size_t dstCap, const void* src, size_t srcSize) {
