@@ -45,7 +45,7 @@ extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsi
     zd_ddict_digest(g, *sh, dict, dictSize, dd);
     u64 r;
     if (dd->status) r = ZJ_ERR64(dd->status);
-    else { memset(sh, 0, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
+    else { memset(sh, 0, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
     free(dd); free(lit); free(sh);
     return r;
 }

@@ -46,8 +46,6 @@ struct ZDecShared {
     u8 weights[256];
     u32 hrank[32];
     u16 symPos[256];                // Huffman: first table cell of each symbol
-    short norm[64];
-    u16 symNext[64 * 3];
     // --- uniforms published by lane 0 ---
     u32 err;
     u32 llLog, mlLog, ofLog, hufLog, hufValid, seqValid;
@@ -62,11 +60,13 @@ struct ZDecShared {
     u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
     u32 dictSize;                   // bytes of dictionary content before the frame's output (0 = none)
     // --- tANS tables last: the execute-only kernel of the split pipeline allocates the struct without them ---
+    short norm[3][64];              // NCount of the LL / OF / ML table being described
+    u16 symNext[64 * 3];
     u32 ll[512];
     u32 ml[512];
     u32 of[256];
 };
-#define ZD_SHARED_NO_FSE (sizeof(ZDecShared) - (512u + 512u + 256u) * 4u)
+#define ZD_SHARED_NO_FSE (sizeof(ZDecShared) - (512u + 512u + 256u) * 4u - 3u * 64u * 2u - 64u * 3u * 2u)
 
 // format constants (N/common/zstd_internal.h:113-165, N/decompress/zstd_decompress_internal.h:28-58)
 #define ZD_LL_BASE_INIT { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 }
@@ -391,7 +391,7 @@ ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit
 // first (they only read the literal buffer); a match may read bytes that an earlier match of the same batch
 // produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
 // range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
-template <class G>
+template <bool DICT = false, class G>
 ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot, u8* stage = nullptr, u32 litAvail = 0, const u8* dictEnd = nullptr) {
 #if ZJ_ON_GPU
     u32 const k = g.lane();
@@ -428,8 +428,8 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     // a source position before the frame's output lies in the dictionary content (ZSTD_execSequence's extDict branch,
     // N/decompress/zstd_decompress_block.c:1051-1068): dn bytes come from there, the rest from the output
     i32 const sp = (i32)mp - (i32)off;
-    u32 const dn = sp < 0 ? zj_min(ml, (u32)(-sp)) : 0u;
-    u32 const ms = sp < 0 ? 0u : (u32)sp;         // first source byte inside the output
+    u32 const dn = (DICT && sp < 0) ? zj_min(ml, (u32)(-sp)) : 0u;      // DICT = false: the sequence checks guarantee sp >= 0
+    u32 const ms = (DICT && sp < 0) ? 0u : (u32)sp;         // first source byte inside the output
     u32 const me = zj_min(ms + (ml - dn), mp);    // source bytes at/after mp are produced by this match itself
     // earlier lanes whose match output [mStart_j, mEnd_j) intersects [ms, me): a contiguous lane range
     u64 dep = 0;
@@ -452,7 +452,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         while (big) {
             u32 const q = (u32)__builtin_ctzll(big); big &= big - 1;
             u32 qml = ZJ_UNI(__shfl(ml, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64)); u32 const qoff = ZJ_UNI(__shfl(off, q, 64));
-            if (qoff > qmp) {                     // starts in the dictionary content: that part first, the rest is an ordinary match
+            if (DICT && qoff > qmp) {             // starts in the dictionary content: that part first, the rest is an ordinary match
                 u32 const used = zj_min(qml, qoff - qmp);
                 grp_copy_wide(g, out + qmp, dictEnd - (qoff - qmp), used);
                 zj_mem_order();
@@ -468,7 +468,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         if (ready && ml <= 64) {
             u8* const d = out + mp; const u8* const m = d - off;
             u32 j = 0;
-            if (dn) { const u8* const dm = dictEnd + sp; for (; j + 8 <= dn; j += 8) st64(d + j, ld64(dm + j)); for (; j < dn; j++) d[j] = dm[j]; }
+            if (DICT && dn) { const u8* const dm = dictEnd + sp; for (; j + 8 <= dn; j += 8) st64(d + j, ld64(dm + j)); for (; j < dn; j++) d[j] = dm[j]; }
             if (off >= 8) { for (; j + 8 <= ml; j += 8) st64(d + j, ld64(m + j)); }
             for (; j < ml; j++) d[j] = m[j];
         }
@@ -484,7 +484,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
         litTot += ll; outTot += ll + ml;
         for (u32 j = 0; j < ll; j++) out[op + j] = lit[lp + j];
         lp += ll; op += ll;
-        for (u32 j = 0; j < ml; j++) { i32 const v = (i32)op - (i32)off + (i32)j; out[op + j] = v < 0 ? dictEnd[v] : out[v]; }
+        for (u32 j = 0; j < ml; j++) { i32 const v = (i32)op - (i32)off + (i32)j; out[op + j] = (DICT && v < 0) ? dictEnd[v] : out[v]; }
         op += ml;
     }
     (void)g;
@@ -612,10 +612,10 @@ ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dict
             for (u32 t = 0; t < 3 && !err; t++) {          // order in the dictionary: OF, ML, LL
                 u32 const kind = t == 0 ? 1u : (t == 1 ? 2u : 0u);
                 u32 max = kind == 0 ? 35u : (kind == 1 ? 31u : 52u), tl = 0;
-                u32 const h = zd_read_ncount(sh.norm, &max, &tl, dict + pos, dictSize - pos);
+                u32 const h = zd_read_ncount(sh.norm[0], &max, &tl, dict + pos, dictSize - pos);
                 if (!h || h > dictSize - pos || tl > (kind == 1 ? 8u : 9u)) { err = ZJ_E_DICT_CORRUPTED; break; }
                 u32* const cells = kind == 0 ? sh.ll : (kind == 1 ? sh.of : sh.ml);
-                if (!zd_build_fse(cells, sh.norm, sh.symNext, max, tl, kind)) { err = ZJ_E_DICT_CORRUPTED; break; }
+                if (!zd_build_fse(cells, sh.norm[0], sh.symNext, max, tl, kind)) { err = ZJ_E_DICT_CORRUPTED; break; }
                 if (kind == 0) sh.llLog = tl; else if (kind == 1) sh.ofLog = tl; else sh.mlLog = tl;
                 pos += h;
             }
@@ -816,7 +816,8 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
             else {
                 u32 const modes = bsrc[ip++];
                 if (modes & 3) err = ZJ_E_CORRUPTION;
-                // walk the three table descriptions; NCount parsing is inherently serial
+                // walk the three table descriptions; NCount parsing is inherently serial (each header starts where the
+                // previous one ends), building the tables from the parsed counts is not
                 for (u32 t = 0; t < 3 && !err; t++) {
                     u32 const mode = (modes >> (6 - 2 * t)) & 3;
                     sh.tblMode[t] = mode;
@@ -824,14 +825,9 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
                         if (ip >= bsize || bsrc[ip] > (t == 0 ? 35u : (t == 1 ? 31u : 52u))) err = ZJ_E_CORRUPTION; else { sh.tblMax[t] = bsrc[ip]; ip++; }
                     } else if (mode == 2) {
                         u32 max = (t == 0 ? 35u : (t == 1 ? 31u : 52u)), tl = 0;
-                        u32 const h = zd_read_ncount(sh.norm, &max, &tl, bsrc + ip, bsize - ip);
+                        u32 const h = zd_read_ncount(sh.norm[t], &max, &tl, bsrc + ip, bsize - ip);
                         if (!h || h > bsize - ip || tl > (t == 1 ? 8u : 9u)) err = ZJ_E_CORRUPTION;
-                        else {
-                            u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
-                            if (!zd_build_fse(cells, sh.norm, sh.symNext, max, tl, t)) err = ZJ_E_CORRUPTION;
-                            if (t == 0) sh.llLog = tl; else if (t == 1) sh.ofLog = tl; else sh.mlLog = tl;
-                            ip += h;
-                        }
+                        else { sh.tblMax[t] = max; sh.tblLog[t] = tl; ip += h; }     // built below, three tables on three lanes
                     } else if (mode == 3) { if (!sh.seqValid) err = ZJ_E_CORRUPTION; }
                 }
                 sh.seqValid = 1;
@@ -843,11 +839,15 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
     g.sync();
     if (ZJ_UNI(sh.err)) return;
     if (ZJ_UNI(sh.nbSeq)) {
-        // predefined / RLE tables (lanes 0..2, one table each)
+        // the three tables on lanes 0..2: described (from the counts just parsed), predefined or RLE
         GRP_FOR(g, t, 3) {
             u32 const mode = sh.tblMode[t];
             u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
-            if (mode == 0) {
+            if (mode == 2) {
+                u32 const tl = sh.tblLog[t];
+                if (!zd_build_fse(cells, sh.norm[t], sh.symNext + 64 * t, sh.tblMax[t], tl, t)) sh.err = ZJ_E_CORRUPTION;
+                if (t == 0) sh.llLog = tl; else if (t == 1) sh.ofLog = tl; else sh.mlLog = tl;
+            } else if (mode == 0) {
                 u32 const log = (t == 1) ? 5 : 6;
                 zd_build_fse(cells, t == 0 ? zd_k_ll_defnorm : (t == 1 ? zd_k_of_defnorm : zd_k_ml_defnorm), sh.symNext + 64 * t, t == 0 ? 35 : (t == 1 ? 28 : 52), log, t);
                 if (t == 0) sh.llLog = log; else if (t == 1) sh.ofLog = log; else sh.mlLog = log;
@@ -863,7 +863,7 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
 
 // Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
 // (frame-relative position `opos`).  Returns new opos (or sets sh.err).
-template <class G>
+template <bool DICT = false, class G>
 ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf, const u8* dictEnd = nullptr) {
     const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
     if (ZJ_UNI(sh.err)) return opos;
@@ -915,7 +915,7 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
                 u32 const lp = ZJ_UNI(sh.bLitStart), op = ZJ_UNI(sh.bOutStart);
                 u32 const lt = ZJ_UNI(sh.bLitTotal), ot = ZJ_UNI(sh.bOutTotal);
                 u32 lt2, ot2;
-                zd_execute_batch(g, sh, out, lit, n, lp, op, lt2, ot2, nullptr, 0, dictEnd);
+                zd_execute_batch<DICT>(g, sh, out, lit, n, lp, op, lt2, ot2, nullptr, 0, dictEnd);
                 litUsed = lp + lt; opos = op + ot;
             }
             pf.mark(5);
@@ -939,9 +939,10 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
 // ------------------------------------------------------------------ frame --------------------
 // Decodes all frames in [src, src+srcSize) into dst[0..dstCap).  Returns decoded size or
 // ZJ_ERR64(code) — the reference's size_t error convention (N/common/error_private.h).
-template <class G>
+template <bool DICT = false, class G>
 ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u8* litScratch, ZjProf& pf,
-                         const ZDDictDev* dd = nullptr, const u8* dictRaw = nullptr) {
+                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr) {
+    const ZDDictDev* const dd = DICT ? ddArg : nullptr;     // the no-dictionary instantiation carries none of the dictionary code
     // dd: digested dictionary (ZSTD_decompress_usingDDict, N/decompress/zstd_decompress.c:1661-1672); every frame of the
     // buffer starts from its entropy tables / repcodes and may copy from its content
     const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
@@ -996,9 +997,15 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
         if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
         if (ZJ_UNI(sh.blkType) == 1) { ipos += ZJ_UNI(sh.hdrSize); g.sync(); continue; }
         if (dd && dd->hasEntropy) {                     // litEntropy = fseEntropy = 1 (zstd_decompress.c:1554)
-            GRP_FOR(g, i, 1u << ZD_HUF_LOG_MAX) sh.huf[i] = dd->huf[i];
-            GRP_FOR(g, i, 512) { sh.ll[i] = dd->ll[i]; sh.ml[i] = dd->ml[i]; }
-            GRP_FOR(g, i, 256) sh.of[i] = dd->of[i];
+            // one 9 KiB copy as words, not unrolled: a handful of loads in flight is enough and keeps the kernel's
+            // register budget (and with it the resident frames per CU) where it is without dictionaries
+            const u32* const s32 = (const u32*)dd->huf; u32* const h32 = (u32*)sh.huf;
+#pragma clang loop unroll(disable)
+            for (u32 i = g.lane(); i < (1u << ZD_HUF_LOG_MAX) / 2u; i += (u32)g.W) h32[i] = s32[i];
+#pragma clang loop unroll(disable)
+            for (u32 i = g.lane(); i < 512u; i += (u32)g.W) { sh.ll[i] = dd->ll[i]; sh.ml[i] = dd->ml[i]; }
+#pragma clang loop unroll(disable)
+            for (u32 i = g.lane(); i < 256u; i += (u32)g.W) sh.of[i] = dd->of[i];
             g.sync();
         }
         ipos += ZJ_UNI(sh.hdrSize);
@@ -1030,7 +1037,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
                 u32 const cap = zj_min(fcap, opos + ZJ_UNI(sh.blockSizeMax));
-                opos = zd_compressed_block(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf, dictEnd);
+                opos = zd_compressed_block<DICT>(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf, dictEnd);
                 if (ZJ_UNI(sh.err)) {
                     u32 e = ZJ_UNI(sh.err);
                     if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax

@@ -28,7 +28,9 @@ __device__ __forceinline__ u32 zj_next_index(u32* counter) {
 }
 
 // Fused wave-per-frame decoder: frame i of the batch, or (list != nullptr) the frames a list names.
-__global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
+// DICT = true is the ZSTD_decompress_usingDDict variant (a second kernel, so that the common one keeps its registers).
+template <bool DICT>
+__global__ __launch_bounds__(64, 4) void zj_decode_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 n, u32* counter, u8* scratch, unsigned long long* prof,
                                                         const u32* __restrict__ list, const u32* listCount,
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__
         if (k >= count) break;
         u32 const i = list ? ZJ_UNI(list[k]) : k;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const r = zd_decompress(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf, dd, dictRaw);
+        u64 const r = zd_decompress<DICT>(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf, dd, dictRaw);
         pf.mark(8);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
@@ -51,6 +53,9 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel(const u8* __restrict__
 }
 
 extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
+
+#define zj_decode_kernel zj_decode_kernel_t<false>
+#define zj_decode_dict_kernel zj_decode_kernel_t<true>
 
 // ZSTD_createDDict on the device: one workgroup digests the raw dictionary at dictRaw into *out
 __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, u32 dictSize, ZDDictDev* out) {
@@ -264,7 +269,7 @@ size_t enc_lds_pass0(int level) {
 struct DevState {
     int ordinal = -1;
     int numCU = 0;
-    int decGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
+    int decGrid = 0, decDictGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
     int encGridLvl[4] = {0, 0, 0, 0};     // resident workgroups per level for pass 0
     int encGridBig = 0;                    // pass 1 (128 KiB LDS)
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
@@ -308,6 +313,8 @@ DevState* get_state(int ordinal) {
         int perCU = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_decode_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 8;
         d.decGrid = d.numCU * perCU;
+        {   int p2 = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, zj_decode_dict_kernel, 64, 0) != hipSuccess || p2 < 1) p2 = 4;
+            d.decDictGrid = d.numCU * (p2 < perCU ? p2 : perCU); }
         if (const char* ov = getenv("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
         if (hipFuncSetAttribute((const void*)zj_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZJ_ENC_LDS_BIG) != hipSuccess) return nullptr;
         for (int lvl = 1; lvl <= 3; lvl++) {
@@ -517,6 +524,11 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (ddict) {
+        u32 const gridD = (u32)(n < (size_t)d->decDictGrid ? n : (size_t)d->decDictGrid);
+        hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(gridD), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr, ddDev, ddRaw);
+    } else
     hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr, ddDev, ddRaw);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
