@@ -134,3 +134,22 @@ def test_gpu_checksum_flag(gpu, oracle_ref, monkeypatch, split_min):
         z = ctx.setLevel(1).setChecksum(True).compress(items[-1])
         assert z == oracle_ref.compress(items[-1], 1, True)
     assert gpu.Zstd.compress(items[-2], 3, True) == oracle_ref.compress(items[-2], 3, True, 14, 13)
+
+
+def test_gpu_batch_larger_than_one_scratch_slice(gpu, oracle_ref):
+    """batches beyond 65 536 buffers run through the per-frame scratch in slices (config 4 has 2^20 records)"""
+    import torch
+    n, size = 70001, 512
+    src = gpu.batch.synth(n, size, 0)
+    soff = gpu.batch.uniform_offsets(n, size, "cuda")
+    bound = gpu.Zstd.compressBound(size)
+    comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); coff = gpu.batch.uniform_offsets(n, bound, "cuda")
+    csz = gpu.batch.compress(src, soff, comp, coff, 3)
+    packed, poff = gpu.batch.pack(csz, comp, coff)
+    back = torch.empty_like(src)
+    dsz = gpu.batch.decompress(packed, poff, back, soff)
+    torch.cuda.synchronize()
+    assert bool((csz > 0).all()) and bool((dsz == size).all()) and torch.equal(back, src)
+    for i in (0, 65535, 65536, 70000):
+        f = packed[int(poff[i]):int(poff[i + 1])].cpu().numpy().tobytes()
+        assert f == oracle_ref.compress(src[i * size:(i + 1) * size].cpu().numpy().tobytes(), 3, False, 14, 13), i

@@ -533,14 +533,27 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
                        (const u64*)d_dst_off, (u64*)d_result, (u32)n, d->counters, d->decScratch, d->prof, (const u32*)nullptr, (const u32*)nullptr, ddDev, ddRaw);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
+// The per-frame scratch of the pipelines (176 KiB decode, 416 KiB compress) is sized per call; very large batches go
+// through it in slices of ZJ_CHUNK_FRAMES on the same stream (stream order makes the reuse safe), so a batch of a
+// million buffers needs no more scratch than one of 65 536.
+#define ZJ_CHUNK_FRAMES 65536u
+static size_t decompress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                 uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
+    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
+        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+        size_t const r = decompress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, ddict, stream);
+        if (r != 0 || n == 0) return r;
+    }
+    return 0;
+}
 size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                     uint64_t* d_result, size_t n, void* stream) {
-    return decompress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, nullptr, stream);
+    return decompress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, nullptr, stream);
 }
 size_t zjni_decompress_batch_device_usingDDict(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                                uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
     if (ddict && ddict->ordinal != t_dev && t_dev >= 0) return ZJNI_ERR(32);      // digested on another device
-    return decompress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, ddict, stream);
+    return decompress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, ddict, stream);
 }
 
 // ZSTD_createDDict (N/decompress/zstd_ddict.c:36-130; ZstdDictDecompress.init, N/jni_fast_zstd.c:56-75): the raw
@@ -656,13 +669,22 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                        (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
+static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                               uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
+    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
+        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+        size_t const r = compress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, level, flags, stream);
+        if (r != 0 || n == 0) return r;
+    }
+    return 0;
+}
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream) {
-    return compress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
+    return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
 }
 size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                    uint64_t* d_result, size_t n, int level, int checksum, void* stream) {
-    return compress_batch_device_impl(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
+    return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
 
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
