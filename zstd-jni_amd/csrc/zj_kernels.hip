@@ -179,7 +179,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
     if (blockIdx.x == 0 && threadIdx.x == 0) printf("match lane profile: rounds %llu, cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", m.pR, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
 #endif
 }
-__global__ __launch_bounds__(64) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
     u32 const count = *countPtr;

@@ -98,7 +98,8 @@ struct ZLaneD {
     u64 w, w1; u32 el0, es0, el1, hl0, hs0, hl1, hs1, tl0, tl1;   // tl: long-table tag of w / w1
     u32 ca, cb, acc;                                  // forward count in progress
     u32 mpos, mpos2, mLength, offset, bk, bk2;       // chosen match / candidate at ip1 / backward extension
-    bool more, more2, cvalid, needBack, needCand, chk;
+    bool more, more2, cvalid, needBack, needCand, chk, haveIns;
+    u64 wIns;                                         // the word at curr + 2 (first post-insert) when the search round already holds it
 
 
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
@@ -106,12 +107,15 @@ struct ZLaneD {
         HL = (Ent*)table; HS = HL + (1u << p.hashLog);
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
-        needBack = needCand = more = more2 = cvalid = false;
+        needBack = needCand = more = more2 = cvalid = haveIns = false;
         st = ZL_LOADW;
     }
     // long-table index and tag from ONE product: index = top hashLog bits, tag = the next 15 bits (hashLog <= 17)
-    ZJ_DEV_MEMBER void hash_long(u64 v, u32& idx, u32& tag) const { u32 const p = zl_prod_hi(hL, v); idx = p >> hL.rsh; tag = (p >> (hL.rsh - 15u)) & 0x7FFFu; }
-    ZJ_DEV_MEMBER void put_long(u64 v, u32 pos1) { u32 i, t; hash_long(v, i, t); HL[i] = E::make(pos1, t); }
+    // (returned by value: references to members keep part of the machine on the stack)
+    ZJ_DEV_MEMBER u32 prod_long(u64 v) const { return zl_prod_hi(hL, v); }
+    ZJ_DEV_MEMBER u32 idx_long(u32 p) const { return p >> hL.rsh; }
+    ZJ_DEV_MEMBER u32 tag_long(u32 p) const { return (p >> (hL.rsh - 15u)) & 0x7FFFu; }
+    ZJ_DEV_MEMBER void put_long(u64 v, u32 pos1) { u32 const p = prod_long(v); HL[idx_long(p)] = E::make(pos1, tag_long(p)); }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
     // outer-loop header of the reference: reset the step and make sure one more position fits
     ZJ_DEV_MEMBER void outer() {
@@ -152,7 +156,7 @@ struct ZLaneD {
         ZL_PROF_T0();
         u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, ti0 = 0, ti1 = 0;
         bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vt = false;
-        bool ml0 = false, ms0 = false; u32 ip2 = 0;
+        bool ml0 = false, ms0 = false; u32 ip2 = 0; u64 hw = 0;
         bool const on = (st == ZL_SEARCH) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
                      || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW)) || ((K & ZL_EN_START) && st == ZL_START);
         // ---- phase 1: what does this lane's state need (and the table writes that precede its reads) ----
@@ -167,8 +171,7 @@ struct ZLaneD {
             pa2 = E::pos(es0) - 1u; v2 = ms0;
             ip2 = ip1 + step + ((ip1 >= nextStep) ? 1u : 0u);
             pa3 = ip2; v3 = ip2 <= ilimit;
-            hash_long(w1, hl1, tl1); hs1 = zl_hash(hS, w1);
-            ti0 = hl1; ti1 = hs1; vt = true;
+            hw = w1; vt = true;
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
             if (needBack) { vb = true; if (cont == ZC_SHORT_L1) { bp0 = ip1; bp1 = mpos2; } else { bp0 = ip; bp1 = mpos; } }
@@ -176,15 +179,18 @@ struct ZLaneD {
         } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
             vb = true; bp0 = ip - bk; bp1 = mpos - bk;
         } else if ((K & ZL_EN_POST) && st == ZL_POST) {
-            pa0 = curr + 2u; pa1 = ip - 2u; pa2 = ip + 6u; v0 = v1 = v2 = true;
+            pa0 = curr + 2u; pa1 = ip - 2u; pa2 = ip + 6u; v0 = !haveIns; v1 = v2 = true;
             pa3 = ip - off2; v3 = off2 > 0u;
         } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
             pa0 = ip; pa1 = ip + 1u; v0 = v1 = true;
             pa3 = ip - off2; v3 = chk && off2 > 0u;
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            hash_long(w, hl0, tl0); hs0 = zl_hash(hS, w);
-            ti0 = hl0; ti1 = hs0; vt = true;
+            hw = w; vt = true;
         }
+        // the hashes of the word whose table entries this round reads (search: next position; restart: this one) —
+        // computed once here for both states, assigned to the state's own fields after the loads
+        u32 const hp = prod_long(hw), nhl = idx_long(hp), ntl = tag_long(hp), nhs = zl_hash(hS, hw);
+        ti0 = nhl; ti1 = nhs;
         // ---- phase 2: one batch of loads for all states ----
         ZL_PROF_T1();
         if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
@@ -194,7 +200,8 @@ struct ZLaneD {
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
         // predicated: a slot nobody asked for costs no transaction (the fence below keeps the loads together)
         u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t0 = 0, t1 = 0;
-        if (on) { r0 = ld64(src + q0); r3 = ld64(src + q3); t0 = (u32)HL[ti0]; t1 = (u32)HS[ti1]; }
+        if (v0) r0 = ld64(src + q0);
+        if (on) { r3 = ld64(src + q3); t0 = (u32)HL[ti0]; t1 = (u32)HS[ti1]; }
         if (v1) r1 = ld64(src + q1);
         if (v2) r2 = ld64(src + q2);
         if ((K & ZL_EN_COUNT) && v4) r4 = ld64(src + q4);
@@ -207,7 +214,8 @@ struct ZLaneD {
         if (!on) return;
         // ---- phase 3: consume ----
         if (st == ZL_SEARCH) {
-            u32 const rv = (u32)d0; u32 const es1 = t1; el1 = t0;
+            u32 const rv = (u32)d0; u32 const es1 = t1; el1 = t0; hl1 = nhl; hs1 = nhs; tl1 = ntl;
+            wIns = d3; haveIns = v3 && (ip2 == ip + 2u);        // curr + 2 == ip2: its bytes arrived with this round
             if ((off1 > 0u) & (rv == (u32)(w >> 8))) {
                 begin_count(ip + 5u, ip + 5u - off1, ZC_REP1); needBack = false; needCand = false;
             } else if (ml0 && d1 == w) {
@@ -261,7 +269,7 @@ struct ZLaneD {
                 if (ip <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
             }
         } else if ((K & ZL_EN_POST) && st == ZL_POST) {
-            u64 const wa = d0, q0 = d1, q1 = d2;
+            u64 const wa = haveIns ? wIns : d0, q0 = d1, q1 = d2;
             u64 const wb = q0, wc = (q0 >> 8) | (q1 << 56);
             u32 const ins = curr + 2u;
             put_long(wa, ins + 1u);
@@ -272,7 +280,7 @@ struct ZLaneD {
             if ((off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            el0 = t0; es0 = t1; st = ZL_SEARCH;
+            el0 = t0; es0 = t1; hl0 = nhl; hs0 = nhs; tl0 = ntl; st = ZL_SEARCH;
         } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
             u32 const limit = zj_min(ip - anchor, mpos) - bk;
             u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
@@ -298,14 +306,14 @@ struct ZLaneF {
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip0, ip1, ip2, ip3, anchor, rep1, rep2, step, nextStep, cur0;
-    u64 w0, w1, w2, w3; u32 eX, eY;
+    u64 w0, w1, w2, w3, wIns; u32 eX, eY;
     u32 ca, cb, acc, mpos, mLength, offcode, bk;
-    bool more, needBack, chk;
+    bool more, needBack, chk, haveIns;               // wIns/haveIns: the word at cur0 + 2 (first post-insert) when the search round already holds it
 
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
         src = s; n = size; ilimit = size - 8u; hT = zl_hash_of(p.minMatch, p.hashLog); T = (Ent*)table;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
-        ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = false; bk = 0;
+        ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = haveIns = false; bk = 0;
         st = ZL_LOADW;
     }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
@@ -356,7 +364,7 @@ struct ZLaneF {
             pa0 = ip2 - 1u - rep1; v0 = true;          // byte before the repcode candidate + its 4 bytes
             pa1 = ip2; pa2 = ip3; v1 = v2 = true;
             pa3 = E::pos(eX) - 1u; v3 = m0;
-            pa4 = ip2 - 1u; v4 = true;
+            pa4 = ip2 - 1u; v4 = ip2 - ip0 > 8u;         // the byte before ip2 is in w0 unless the step is large
         } else if (st == ZL_SEARCH_B) {
             t1tag = ze_tag4((u32)w1);
             m1 = E::maybe(eY, t1tag);
@@ -368,7 +376,7 @@ struct ZLaneF {
         } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
             vb = true; bp0 = ip0 - bk; bp1 = mpos - bk;
         } else if ((K & ZL_EN_POST) && st == ZL_POST) {
-            pa0 = cur0 + 2u; pa1 = ip0 - 2u; pa2 = ip0 + 6u; v0 = v1 = v2 = true;
+            pa0 = cur0 + 2u; pa1 = ip0 - 2u; pa2 = ip0 + 6u; v0 = !haveIns; v1 = v2 = true;
             pa3 = ip0 - rep2; v3 = rep2 > 0u;
         } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
             pa0 = ip0; pa1 = ip0 + 1u; v0 = v1 = true;
@@ -400,10 +408,13 @@ struct ZLaneF {
             eY = t;
             T[ti] = E::make(ip1 + 1u, t1tag);            // written on every path of the reference's iteration
             w2 = d1; w3 = d2;
+            u32 const gap = ip2 - ip0;                       // == step, or step - 1 right after a step increment
+            wIns = w2; haveIns = (gap == 2u);                // cur0 + 2 == ip2 for a match found in this round
             u32 const rval = (u32)(d0 >> 8);
             if (((u32)w2 == rval) & (rep1 > 0u)) {
                 ip0 = ip2; mpos = ip0 - rep1;
-                u32 const e = ((u8)d4 == (u8)d0) ? 1u : 0u;
+                u8 const prev = gap > 8u ? (u8)d4 : (u8)(w0 >> (8u * (gap - 1u)));
+                u32 const e = (prev == (u8)d0) ? 1u : 0u;
                 ip0 -= e; mpos -= e; offcode = 1u; mLength = 4u + e;
                 begin_count(ip0 + mLength, mpos + mLength, ZC_FOUND); needBack = false; bk = 0; more = false;
             } else if (m0 && (u32)d3 == (u32)w0) {
@@ -414,6 +425,7 @@ struct ZLaneF {
             u32 const oip2 = ip2, oip3 = ip3;
             ip0 = ip1; cur0 = ip0;
             if (m1 && (u32)d3 == (u32)w1) {
+                wIns = w3;                                   // cur0 is the old ip1: cur0 + 2 == ip3 when ip2 == ip0 + 2
                 if (step <= 4u) T[ti] = E::make(oip2 + 1u, ze_tag4((u32)w2));
                 found_at(eY);
             } else {
@@ -444,7 +456,7 @@ struct ZLaneF {
                 if (ip0 <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
             }
         } else if ((K & ZL_EN_POST) && st == ZL_POST) {
-            u64 const wa = d0, q0 = d1, q1 = d2;
+            u64 const wa = haveIns ? wIns : d0, q0 = d1, q1 = d2;
             T[zl_hash(hT, wa)] = E::make(cur0 + 2u + 1u, ze_tag4((u32)wa));
             T[zl_hash(hT, q0)] = E::make(ip0 - 2u + 1u, ze_tag4((u32)q0));
             w0 = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
