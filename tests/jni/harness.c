@@ -1,0 +1,195 @@
+/* tests/jni/harness.c — drives JNI natives the way the JVM would, through a hand-built JNIEnv (only the ~12 env
+ * functions the one-shot hot path uses), against TWO libraries:
+ *   the reference's own JNI library (oracle/_ref/libzstd-jni-ref.so, built from the reference sources in place)
+ *   the GPU shim (zstd-jni_amd/lib/libzstd-jni-amd.so)
+ * and checks that the hot-path natives return the same values and write the same bytes.  TEST INFRASTRUCTURE.
+ * usage: harness <ref-jni.so> <shim.so>        prints "JNI-HARNESS OK checks=N" or the first mismatches; exit 0/1 */
+#include <jni.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string */
+static Obj* mk(int kind, jsize len) { Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = kind; o->len = len; o->data = (char*)calloc((size_t)len + 16, kind == 4 ? 8 : 1); return o; }
+
+static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b ? ((Obj*)b)->data : NULL; }
+static jlong JNICALL f_GetDirectBufferCapacity(JNIEnv* e, jobject b) { (void)e; return b ? ((Obj*)b)->len : -1; }
+static jsize JNICALL f_GetArrayLength(JNIEnv* e, jarray a) { (void)e; return ((Obj*)a)->len; }
+static void* JNICALL f_GetPrimitiveArrayCritical(JNIEnv* e, jarray a, jboolean* c) { (void)e; if (c) *c = JNI_FALSE; return ((Obj*)a)->data; }
+static void JNICALL f_ReleasePrimitiveArrayCritical(JNIEnv* e, jarray a, void* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
+static void JNICALL f_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* buf) { (void)e; memcpy(buf, ((Obj*)a)->data + s, (size_t)l); }
+static void JNICALL f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* buf) { (void)e; memcpy(((Obj*)a)->data + s, buf, (size_t)l); }
+static jobject JNICALL f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (void)e; return (jobject)((Obj*)a)->elems[i]; }
+static void JNICALL f_SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const jlong* buf) { (void)e; memcpy(((Obj*)a)->data + 8 * (size_t)s, buf, 8 * (size_t)l); }
+static jstring JNICALL f_NewStringUTF(JNIEnv* e, const char* s) { (void)e; Obj* o = mk(5, (jsize)strlen(s) + 1); strcpy(o->data, s); return (jstring)o; }
+
+static struct JNINativeInterface_ g_fn;
+static const struct JNINativeInterface_* g_envp = &g_fn;
+static JNIEnv* env(void) {
+    g_fn.GetDirectBufferAddress = f_GetDirectBufferAddress; g_fn.GetDirectBufferCapacity = f_GetDirectBufferCapacity;
+    g_fn.GetArrayLength = f_GetArrayLength; g_fn.GetPrimitiveArrayCritical = f_GetPrimitiveArrayCritical;
+    g_fn.ReleasePrimitiveArrayCritical = f_ReleasePrimitiveArrayCritical; g_fn.GetByteArrayRegion = f_GetByteArrayRegion;
+    g_fn.SetByteArrayRegion = f_SetByteArrayRegion; g_fn.GetObjectArrayElement = f_GetObjectArrayElement;
+    g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
+    return (JNIEnv*)&g_envp;
+}
+
+/* the natives of one library */
+typedef struct {
+    jlong (*cinit)(JNIEnv*, jclass); void (*cfree)(JNIEnv*, jclass, jlong);
+    void (*setLevel)(JNIEnv*, jclass, jlong, jint); void (*setChecksum)(JNIEnv*, jclass, jlong, jboolean);
+    jlong (*cDirect)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+    jlong (*cArray)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jbyteArray, jint, jint);
+    jlong (*dinit)(JNIEnv*, jclass); void (*dfree)(JNIEnv*, jclass, jlong);
+    jlong (*dDirect)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+    jlong (*dArray)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jbyteArray, jint, jint);
+    jlong (*bound)(JNIEnv*, jclass, jlong); jboolean (*isError)(JNIEnv*, jclass, jlong);
+    jstring (*errName)(JNIEnv*, jclass, jlong); jlong (*errCode)(JNIEnv*, jclass, jlong);
+    jlong (*cUnsafe)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean);
+    jlong (*dUnsafe)(JNIEnv*, jclass, jlong, jlong, jlong, jlong);
+    jint (*setHashLog)(JNIEnv*, jclass, jlong, jint); jint (*setChainLog)(JNIEnv*, jclass, jlong, jint);     /* reference only */
+    jlong (*cBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jint, jboolean);                 /* shim only */
+    jlong (*dBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray);
+} Lib;
+#define P "Java_com_github_luben_zstd_"
+static int load(Lib* L, const char* path, int isRef) {
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { printf("dlopen %s: %s\n", path, dlerror()); return 0; }
+#define S(field, name) *(void**)&L->field = dlsym(h, P name)
+    S(cinit, "ZstdCompressCtx_init"); S(cfree, "ZstdCompressCtx_free"); S(setLevel, "ZstdCompressCtx_setLevel0"); S(setChecksum, "ZstdCompressCtx_setChecksum0");
+    S(cDirect, "ZstdCompressCtx_compressDirectByteBuffer0"); S(cArray, "ZstdCompressCtx_compressByteArray0");
+    S(dinit, "ZstdDecompressCtx_init"); S(dfree, "ZstdDecompressCtx_free");
+    S(dDirect, "ZstdDecompressCtx_decompressDirectByteBuffer0"); S(dArray, "ZstdDecompressCtx_decompressByteArray0");
+    S(bound, "Zstd_compressBound"); S(isError, "Zstd_isError"); S(errName, "Zstd_getErrorName"); S(errCode, "Zstd_getErrorCode");
+    S(cUnsafe, "Zstd_compressUnsafe"); S(dUnsafe, "Zstd_decompressUnsafe");
+    S(setHashLog, "Zstd_setCompressionHashLog"); S(setChainLog, "Zstd_setCompressionChainLog");
+    S(cBatch, "Zstd_compressBatch0"); S(dBatch, "Zstd_decompressBatch0");
+#undef S
+    if (!L->cinit || !L->cDirect || !L->cArray || !L->dDirect || !L->dArray || !L->bound || !L->errName || !L->cUnsafe) { printf("%s: hot-path natives missing\n", path); return 0; }
+    if (isRef && (!L->setHashLog || !L->setChainLog)) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
+    if (!isRef && (!L->cBatch || !L->dBatch)) { printf("%s: batch natives missing\n", path); return 0; }
+    return 1;
+}
+
+/* deterministic test data: text-like / low-entropy / random, the classes of the benchmark generator */
+static uint64_t g_x = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd(void) { g_x ^= g_x << 13; g_x ^= g_x >> 7; g_x ^= g_x << 17; return (uint32_t)(g_x >> 11); }
+static void fill(char* p, jsize n, int cls) {
+    static const char* words[8] = {"alpha ", "bravo ", "compress ", "zstandard ", "delta ", "wavefront ", "entropy ", "table "};
+    jsize i = 0;
+    if (cls == 0) { while (i < n) { const char* w = words[rnd() & 7]; while (*w && i < n) p[i++] = *w++; } }
+    else if (cls == 1) { for (; i < n; i++) p[i] = (i > 64 && (rnd() & 7)) ? p[i - 1 - (rnd() & 63)] : (char)(rnd() & 15); }
+    else { for (; i < n; i++) p[i] = (char)rnd(); }
+}
+
+static int g_checks, g_bad;
+#define CHECK(cond, ...) do { g_checks++; if (!(cond)) { if (g_bad++ < 12) { printf("MISMATCH: "); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+int main(int argc, char** argv) {
+    Lib R, G; JNIEnv* e = env();
+    jsize const sizes[] = {0, 1, 17, 100, 4096, 20000, 65536, 131072};
+    if (argc < 3) { printf("usage: harness <ref-jni.so> <shim.so>\n"); return 2; }
+    memset(&R, 0, sizeof R); memset(&G, 0, sizeof G);
+    if (!load(&R, argv[1], 1) || !load(&G, argv[2], 0)) return 2;
+
+    /* class Zstd helpers */
+    {   jlong const probes[] = {0, 1, 255, 4096, 65536, 131072, 1 << 20};
+        for (unsigned i = 0; i < sizeof probes / sizeof *probes; i++) CHECK(R.bound(e, NULL, probes[i]) == G.bound(e, NULL, probes[i]), "compressBound(%lld)", (long long)probes[i]);
+        jlong const codes[] = {-70, -72, -20, -10, -64, -22, -32, 5};
+        for (unsigned i = 0; i < sizeof codes / sizeof *codes; i++) {
+            CHECK(R.isError(e, NULL, codes[i]) == G.isError(e, NULL, codes[i]), "isError(%lld)", (long long)codes[i]);
+            CHECK(R.errCode(e, NULL, codes[i]) == G.errCode(e, NULL, codes[i]), "getErrorCode(%lld)", (long long)codes[i]);
+            CHECK(!strcmp(((Obj*)R.errName(e, NULL, codes[i]))->data, ((Obj*)G.errName(e, NULL, codes[i]))->data), "getErrorName(%lld)", (long long)codes[i]);
+        }
+    }
+    /* ZstdCompressCtx / ZstdDecompressCtx one-shot natives, direct buffers and byte[] */
+    int const maxLevel = getenv("HARNESS_MAX_LEVEL") ? atoi(getenv("HARNESS_MAX_LEVEL")) : 3;
+    for (int level = 1; level <= maxLevel; level++) for (int ck = 0; ck < 2; ck++) {
+        jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
+        R.setLevel(e, NULL, rc, level); G.setLevel(e, NULL, gc, level);
+        R.setChecksum(e, NULL, rc, ck ? JNI_TRUE : JNI_FALSE); G.setChecksum(e, NULL, gc, ck ? JNI_TRUE : JNI_FALSE);
+        if (level == 3) { R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13); }      /* the GPU path's level-3 tables */
+        for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
+            jsize const n = sizes[si], off = 5, cap = (jsize)R.bound(e, NULL, n) + 40;
+            for (int kind = 1; kind <= 2; kind++) {
+                Obj* src = mk(kind, n + off + 3); Obj* rdst = mk(kind, cap); Obj* gdst = mk(kind, cap);
+                fill(src->data + off, n, cls);
+                jlong const rr = kind == 1 ? R.cDirect(e, NULL, rc, rdst, 7, cap - 7, src, off, n) : R.cArray(e, NULL, rc, (jbyteArray)rdst, 7, cap - 7, (jbyteArray)src, off, n);
+                jlong const gr = kind == 1 ? G.cDirect(e, NULL, gc, gdst, 7, cap - 7, src, off, n) : G.cArray(e, NULL, gc, (jbyteArray)gdst, 7, cap - 7, (jbyteArray)src, off, n);
+                CHECK(rr == gr, "compress L%d ck%d n=%d cls=%d kind=%d: ref %lld gpu %lld", level, ck, n, cls, kind, (long long)rr, (long long)gr);
+                if (rr == gr && rr > 0) CHECK(!memcmp(rdst->data, gdst->data, (size_t)rr + 7), "compressed bytes L%d ck%d n=%d cls=%d kind=%d", level, ck, n, cls, kind);   /* (past the frame the reference may leave scratch bytes) */
+                if (rr > 0) {       /* decompress the reference's frame with both */
+                    Obj* rout = mk(kind, n + 9); Obj* gout = mk(kind, n + 9);
+                    jlong const a = kind == 1 ? R.dDirect(e, NULL, rd, rout, 3, n, rdst, 7, (jint)rr) : R.dArray(e, NULL, rd, (jbyteArray)rout, 3, n, (jbyteArray)rdst, 7, (jint)rr);
+                    jlong const b = kind == 1 ? G.dDirect(e, NULL, gd, gout, 3, n, rdst, 7, (jint)rr) : G.dArray(e, NULL, gd, (jbyteArray)gout, 3, n, (jbyteArray)rdst, 7, (jint)rr);
+                    CHECK(a == b && a == n, "decompress n=%d cls=%d kind=%d: ref %lld gpu %lld", n, cls, kind, (long long)a, (long long)b);
+                    CHECK(!memcmp(rout->data, gout->data, (size_t)n + 9) && !memcmp(gout->data + 3, src->data + off, (size_t)n), "decompressed bytes n=%d cls=%d kind=%d", n, cls, kind);
+                    if (n > 0) {    /* destination one byte short, truncated source */
+                        jlong const a2 = kind == 1 ? R.dDirect(e, NULL, rd, rout, 0, n - 1, rdst, 7, (jint)rr) : R.dArray(e, NULL, rd, (jbyteArray)rout, 0, n - 1, (jbyteArray)rdst, 7, (jint)rr);
+                        jlong const b2 = kind == 1 ? G.dDirect(e, NULL, gd, gout, 0, n - 1, rdst, 7, (jint)rr) : G.dArray(e, NULL, gd, (jbyteArray)gout, 0, n - 1, (jbyteArray)rdst, 7, (jint)rr);
+                        CHECK(a2 == b2, "decompress short dst n=%d kind=%d: ref %lld gpu %lld", n, kind, (long long)a2, (long long)b2);
+                        jlong const a3 = kind == 1 ? R.dDirect(e, NULL, rd, rout, 0, n, rdst, 7, (jint)rr - 2) : R.dArray(e, NULL, rd, (jbyteArray)rout, 0, n, (jbyteArray)rdst, 7, (jint)rr - 2);
+                        jlong const b3 = kind == 1 ? G.dDirect(e, NULL, gd, gout, 0, n, rdst, 7, (jint)rr - 2) : G.dArray(e, NULL, gd, (jbyteArray)gout, 0, n, (jbyteArray)rdst, 7, (jint)rr - 2);
+                        CHECK(a3 == b3, "decompress truncated n=%d kind=%d: ref %lld gpu %lld", n, kind, (long long)a3, (long long)b3);
+                    }
+                }
+            }
+        }
+        /* argument checks, in the reference's order (N/jni_fast_zstd.c:588-600, :617-623) */
+        {   Obj* s = mk(1, 100); Obj* d = mk(1, 200); Obj* sa = mk(2, 100); Obj* da = mk(2, 200);
+            fill(s->data, 100, 0); memcpy(sa->data, s->data, 100);
+            CHECK(R.cDirect(e, NULL, rc, NULL, 0, 10, s, 0, 10) == G.cDirect(e, NULL, gc, NULL, 0, 10, s, 0, 10), "null dst");
+            CHECK(R.cDirect(e, NULL, rc, d, 0, 10, NULL, 0, 10) == G.cDirect(e, NULL, gc, d, 0, 10, NULL, 0, 10), "null src");
+            CHECK(R.cDirect(e, NULL, rc, d, -1, 10, s, 0, 10) == G.cDirect(e, NULL, gc, d, -1, 10, s, 0, 10), "negative dst offset");
+            CHECK(R.cDirect(e, NULL, rc, d, 0, 10, s, -1, 10) == G.cDirect(e, NULL, gc, d, 0, 10, s, -1, 10), "negative src offset");
+            CHECK(R.cDirect(e, NULL, rc, d, 0, 10, s, 0, -1) == G.cDirect(e, NULL, gc, d, 0, 10, s, 0, -1), "negative src size");
+            CHECK(R.cDirect(e, NULL, rc, d, 150, 100, s, 0, 10) == G.cDirect(e, NULL, gc, d, 150, 100, s, 0, 10), "dst range");
+            CHECK(R.cDirect(e, NULL, rc, d, 0, 100, s, 50, 60) == G.cDirect(e, NULL, gc, d, 0, 100, s, 50, 60), "src range");
+            CHECK(R.cDirect(e, NULL, rc, d, 0, 5, s, 0, 100) == G.cDirect(e, NULL, gc, d, 0, 5, s, 0, 100), "dst too small");
+            CHECK(R.cArray(e, NULL, rc, (jbyteArray)da, -1, 10, (jbyteArray)sa, 0, 10) == G.cArray(e, NULL, gc, (jbyteArray)da, -1, 10, (jbyteArray)sa, 0, 10), "array negative dst offset");
+            CHECK(R.cArray(e, NULL, rc, (jbyteArray)da, 0, 100, (jbyteArray)sa, 50, 60) == G.cArray(e, NULL, gc, (jbyteArray)da, 0, 100, (jbyteArray)sa, 50, 60), "array src range");
+            CHECK(R.cArray(e, NULL, rc, (jbyteArray)da, 150, 100, (jbyteArray)sa, 0, 10) == G.cArray(e, NULL, gc, (jbyteArray)da, 150, 100, (jbyteArray)sa, 0, 10), "array dst range");
+            CHECK(R.cArray(e, NULL, rc, (jbyteArray)da, 0, 5, (jbyteArray)sa, 0, 100) == G.cArray(e, NULL, gc, (jbyteArray)da, 0, 5, (jbyteArray)sa, 0, 100), "array dst too small");
+            CHECK(R.dDirect(e, NULL, rd, d, 0, 100, s, 0, 100) == G.dDirect(e, NULL, gd, d, 0, 100, s, 0, 100), "decompress garbage");
+            CHECK(R.dDirect(e, NULL, rd, NULL, 0, 100, s, 0, 100) == G.dDirect(e, NULL, gd, NULL, 0, 100, s, 0, 100), "decompress null dst");
+            CHECK(R.dArray(e, NULL, rd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20) == G.dArray(e, NULL, gd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20), "decompress array src range");
+        }
+        R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+    }
+    /* Zstd.compressUnsafe / decompressUnsafe (levels 1-2: the reference cannot be given the level-3 table sizes here) */
+    for (int level = 1; level <= 2; level++) for (int ck = 0; ck < 2; ck++) {
+        jsize const n = 50000; jsize const cap = (jsize)R.bound(e, NULL, n);
+        char* s = (char*)malloc(n); char* a = (char*)calloc(cap, 1); char* b = (char*)calloc(cap, 1); char* o = (char*)malloc(n);
+        fill(s, n, 0);
+        jlong const rr = R.cUnsafe(e, NULL, (jlong)(intptr_t)a, cap, (jlong)(intptr_t)s, n, level, ck ? JNI_TRUE : JNI_FALSE);
+        jlong const gr = G.cUnsafe(e, NULL, (jlong)(intptr_t)b, cap, (jlong)(intptr_t)s, n, level, ck ? JNI_TRUE : JNI_FALSE);
+        CHECK(rr == gr && rr > 0 && !memcmp(a, b, (size_t)rr), "compressUnsafe L%d ck%d: ref %lld gpu %lld", level, ck, (long long)rr, (long long)gr);
+        CHECK(G.dUnsafe(e, NULL, (jlong)(intptr_t)o, n, (jlong)(intptr_t)a, rr) == n && !memcmp(o, s, n), "decompressUnsafe L%d", level);
+        free(s); free(a); free(b); free(o);
+    }
+    /* the batch natives: 300 direct buffers at once == the per-buffer native of the reference, buffer by buffer */
+    if (!getenv("HARNESS_SKIP_BATCH")) {   enum { NB = 300 }; jlong rc = R.cinit(e, NULL); R.setLevel(e, NULL, rc, 1);
+        Obj* srcs = mk(3, NB); Obj* dsts = mk(3, NB); Obj* res = mk(4, NB); Obj* outs = mk(3, NB); Obj* res2 = mk(4, NB);
+        srcs->elems = (Obj**)calloc(NB, sizeof(Obj*)); dsts->elems = (Obj**)calloc(NB, sizeof(Obj*)); outs->elems = (Obj**)calloc(NB, sizeof(Obj*));
+        for (int i = 0; i < NB; i++) { jsize const n = (jsize)(rnd() % 70000); srcs->elems[i] = mk(1, n); fill(srcs->elems[i]->data, n, i % 3); dsts->elems[i] = mk(1, (jsize)R.bound(e, NULL, n)); outs->elems[i] = mk(1, n); }
+        jlong const r = G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE);
+        CHECK(r == 0, "compressBatch0 returned %lld", (long long)r);
+        Obj* fr = mk(3, NB); fr->elems = (Obj**)calloc(NB, sizeof(Obj*));
+        for (int i = 0; i < NB; i++) {
+            Obj* one = mk(1, dsts->elems[i]->len);
+            jlong const rr = R.cDirect(e, NULL, rc, one, 0, one->len, srcs->elems[i], 0, srcs->elems[i]->len);
+            jlong const gr = ((jlong*)res->data)[i];
+            CHECK(rr == gr && !memcmp(one->data, dsts->elems[i]->data, (size_t)rr), "batch buffer %d: ref %lld gpu %lld", i, (long long)rr, (long long)gr);
+            fr->elems[i] = mk(1, (jsize)gr); memcpy(fr->elems[i]->data, dsts->elems[i]->data, (size_t)gr);
+        }
+        jlong const r2 = G.dBatch(e, NULL, (jobjectArray)fr, (jobjectArray)outs, (jlongArray)res2);
+        CHECK(r2 == 0, "decompressBatch0 returned %lld", (long long)r2);
+        for (int i = 0; i < NB; i++) CHECK(((jlong*)res2->data)[i] == srcs->elems[i]->len && !memcmp(outs->elems[i]->data, srcs->elems[i]->data, (size_t)srcs->elems[i]->len), "batch round trip %d", i);
+        R.cfree(e, NULL, rc);
+    }
+    if (g_bad) { printf("JNI-HARNESS FAILED bad=%d checks=%d\n", g_bad, g_checks); return 1; }
+    printf("JNI-HARNESS OK checks=%d\n", g_checks);
+    return 0;
+}

@@ -1,0 +1,272 @@
+/* zjni_shim.c — the JNI side of the drop-in: the hot-path natives of zstd-jni, bound to libzjni_amd.so.
+ *
+ * zstd-jni's Java classes call per-buffer natives (reference src/main/native/jni_fast_zstd.c, jni_zstd.c, "N/").
+ * This file defines the SAME Java_com_github_luben_zstd_* symbols for the one-shot hot path and sends the buffers
+ * to the GPU library through its C-ABI (include/zjni_amd.h) instead of calling ZSTD_compress2 /
+ * ZSTD_decompressDCtx.  Argument checks, their order and the returned error codes are the reference's
+ * (N/jni_fast_zstd.c:586-640, :777-905; N/jni_zstd.c:50-63, :230-267), so the Java/Scala layer above cannot
+ * tell the difference except by speed.  Two batch natives are added (no Java signature changes elsewhere).
+ *
+ * What the GPU path does not take (levels > 3, inputs > 128 KiB, no device) is FORWARDED to the bundled CPU
+ * library's own native of the same name, looked up with dlsym in the library named by $ZSTD_JNI_CPU_LIB — the CPU
+ * code stays where it is, this file contains none.  Without that library such calls return the zjni error code.
+ *
+ * Built against the JDK's <jni.h>; this image has no JDK, so the build (Makefile next to this file) uses the copy
+ * zstd-jni vendors under /root/reference/jni when it is present and the prebuilt .so travels to the GPU box.
+ * Heap-array natives copy through Get/SetByteArrayRegion instead of pinning with GetPrimitiveArrayCritical: a GPU
+ * round trip inside a critical section would stall the collector (SURVEY.md §8b "Ownership").
+ */
+#include <jni.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/zjni_amd.h"
+
+#define E_DST ((jlong)-70)   /* -ZSTD_error_dstSize_tooSmall */
+#define E_SRC ((jlong)-72)   /* -ZSTD_error_srcSize_wrong */
+#define E_MEM ((jlong)-64)   /* -ZSTD_error_memory_allocation */
+
+/* ---- the bundled CPU library (optional) ------------------------------------------------------------- */
+static void* g_cpu;
+static int g_cpu_tried;
+static void* cpu_sym(const char* name) {
+    if (!g_cpu_tried) {
+        const char* p = getenv("ZSTD_JNI_CPU_LIB");
+        g_cpu_tried = 1;
+        if (p && *p) g_cpu = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+    }
+    return g_cpu ? dlsym(g_cpu, name) : NULL;
+}
+static int gpu_on(void) {
+    static int state = -1;
+    if (state < 0) state = (zjni_device_count() > 0 && zjni_init(0) == 0) ? 1 : 0;
+    return state;
+}
+static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
+    return !(zjni_isError(r) && zjni_getErrorCode(r) >= 200);
+}
+
+/* ---- contexts: what ZstdCompressCtx / ZstdDecompressCtx keep in nativePtr ---------------------------- */
+typedef struct { int level; int checksum; jlong cpu; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent */
+typedef struct { jlong cpu; } ZDCtx;
+
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* env, jclass cls) {
+    ZCtx* c = (ZCtx*)calloc(1, sizeof(ZCtx));
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_init");
+    if (!c) return 0;
+    c->level = 3;                                   /* ZSTD_CLEVEL_DEFAULT */
+    if (f) c->cpu = f(env, cls);
+    return (jlong)(intptr_t)c;
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_free(JNIEnv* env, jclass cls, jlong ptr) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_free");
+    if (!c) return;
+    if (f && c->cpu) f(env, cls, c->cpu);
+    free(c);
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_setLevel0(JNIEnv* env, jclass cls, jlong ptr, jint level) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    void (*f)(JNIEnv*, jclass, jlong, jint) = (void (*)(JNIEnv*, jclass, jlong, jint))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_setLevel0");
+    c->level = level;
+    if (f && c->cpu) f(env, cls, c->cpu, level);
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_setChecksum0(JNIEnv* env, jclass cls, jlong ptr, jboolean flag) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    void (*f)(JNIEnv*, jclass, jlong, jboolean) = (void (*)(JNIEnv*, jclass, jlong, jboolean))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_setChecksum0");
+    c->checksum = (flag == JNI_TRUE);
+    if (f && c->cpu) f(env, cls, c->cpu, flag);
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_init(JNIEnv* env, jclass cls) {
+    ZDCtx* c = (ZDCtx*)calloc(1, sizeof(ZDCtx));
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_init");
+    if (!c) return 0;
+    if (f) c->cpu = f(env, cls);
+    return (jlong)(intptr_t)c;
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_free(JNIEnv* env, jclass cls, jlong ptr) {
+    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_free");
+    if (!c) return;
+    if (f && c->cpu) f(env, cls, c->cpu);
+    free(c);
+}
+
+/* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
+static int gpu_takes(const ZCtx* c, jint srcSize) {
+    return gpu_on() && c->level >= 1 && c->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
+}
+typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressDirectByteBuffer0
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return E_DST;
+    if (src_offset + src_size > (*env)->GetDirectBufferCapacity(env, src)) return E_SRC;
+    {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
+        char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
+        if (d == NULL || s == NULL) return E_MEM;
+        if (gpu_takes(c, src_size)) {
+            size_t const r = zjni_compress2(d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size, c->level, c->checksum);
+            if (gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressDirectByteBuffer0");
+        if (f && c->cpu) return f(env, cls, c->cpu, dst, dst_offset, dst_size, src, src_offset, src_size);
+    }
+    return -(jlong)ZJNI_ERROR_unsupported;
+}
+
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressByteArray0
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
+    if (gpu_takes(c, src_size)) {
+        jbyte* s = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+        size_t r = (size_t)E_MEM;
+        if (s && d) {
+            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
+            r = zjni_compress2(d, (size_t)dst_size, s, (size_t)src_size, c->level, c->checksum);
+            if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
+        }
+        free(s); free(d);
+        if (gpu_result_final(r)) return (jlong)r;
+    }
+    {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressByteArray0");
+        if (f && c->cpu) return f(env, cls, c->cpu, dst, dst_offset, dst_size, src, src_offset, src_size);
+    }
+    return -(jlong)ZJNI_ERROR_unsupported;
+}
+
+/* ---- decompress: ZSTD_DCtx_reset + ZSTD_decompressDCtx (N/jni_fast_zstd.c:798-799, :825-826, :858-860, :892-894) */
+static jlong dec_forward(const char* name, JNIEnv* env, jclass cls, ZDCtx* c, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
+    cbuf_fn f = (cbuf_fn)cpu_sym(name);
+    if (f && c->cpu) return f(env, cls, c->cpu, dst, doff, dsize, src, soff, ssize);
+    return -(jlong)ZJNI_ERROR_no_device;
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressDirectByteBuffer0
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
+    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return E_DST;
+    if (src_offset + src_size > (*env)->GetDirectBufferCapacity(env, src)) return E_SRC;
+    {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
+        char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
+        if (d == NULL || s == NULL) return E_MEM;
+        if (gpu_on()) {
+            size_t const r = zjni_decompress(d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
+            if (gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return dec_forward("Java_com_github_luben_zstd_ZstdDecompressCtx_decompressDirectByteBuffer0", env, cls, c, dst, dst_offset, dst_size, src, src_offset, src_size);
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressByteArray0
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
+    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
+    if (gpu_on()) {
+        jbyte* s = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+        size_t r = (size_t)E_MEM;
+        if (s && d) {
+            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
+            r = zjni_decompress(d, (size_t)dst_size, s, (size_t)src_size);
+            if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
+        }
+        free(s); free(d);
+        if (gpu_result_final(r)) return (jlong)r;
+    }
+    return dec_forward("Java_com_github_luben_zstd_ZstdDecompressCtx_decompressByteArray0", env, cls, c, dst, dst_offset, dst_size, src, src_offset, src_size);
+}
+
+/* ---- class Zstd: helpers with the reference's semantics (N/jni_zstd.c:230-267, :50-63) ---------------- */
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBound(JNIEnv* env, jclass cls, jlong size) {
+    (void)env; (void)cls; return (jlong)zjni_compressBound((size_t)size);
+}
+JNIEXPORT jboolean JNICALL Java_com_github_luben_zstd_Zstd_isError(JNIEnv* env, jclass cls, jlong code) {
+    (void)env; (void)cls; return zjni_isError((size_t)code) != 0;
+}
+JNIEXPORT jstring JNICALL Java_com_github_luben_zstd_Zstd_getErrorName(JNIEnv* env, jclass cls, jlong code) {
+    (void)cls; return (*env)->NewStringUTF(env, zjni_getErrorName((size_t)code));
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_getErrorCode(JNIEnv* env, jclass cls, jlong code) {
+    (void)env; (void)cls; return (jlong)zjni_getErrorCode((size_t)code);
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressUnsafe
+  (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size, jint level, jboolean checksumFlag) {
+    if (gpu_on() && level >= 1 && level <= 3 && (size_t)src_size <= ZJNI_BLOCKSIZE_MAX) {
+        size_t const r = zjni_compress2((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size, level, checksumFlag == JNI_TRUE);
+        if (gpu_result_final(r)) return (jlong)r;
+    }
+    {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean) =
+            (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean))cpu_sym("Java_com_github_luben_zstd_Zstd_compressUnsafe");
+        if (f) return f(env, cls, dst, dst_size, src, src_size, level, checksumFlag);
+    }
+    return -(jlong)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressUnsafe
+  (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size) {
+    if (gpu_on()) {
+        size_t const r = zjni_decompress((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size);
+        if (gpu_result_final(r)) return (jlong)r;
+    }
+    {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong) =
+            (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong))cpu_sym("Java_com_github_luben_zstd_Zstd_decompressUnsafe");
+        if (f) return f(env, cls, dst, dst_size, src, src_size);
+    }
+    return -(jlong)ZJNI_ERROR_no_device;
+}
+
+/* ---- new, additive: batch natives over arrays of direct ByteBuffers ----------------
+ * static native long compressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, int level, boolean checksum);
+ * static native long decompressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results);
+ * Each buffer is taken from position 0 to its capacity.  results[i] = size or the error code compress*0 /
+ * decompress*0 would have returned for that buffer; the return value is 0 or a launch-level error. */
+static jlong batch(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, jlongArray results, int compress, int level, int checksum) {
+    jsize const n = (*env)->GetArrayLength(env, srcs);
+    const void** sp; void** dp; size_t* ss; size_t* dc; size_t* res; jlong* out; size_t r; jsize i;
+    if ((*env)->GetArrayLength(env, dsts) != n || (*env)->GetArrayLength(env, results) < n) return E_SRC;
+    if (n == 0) return 0;
+    sp = (const void**)malloc(n * sizeof(*sp)); dp = (void**)malloc(n * sizeof(*dp));
+    ss = (size_t*)malloc(n * sizeof(*ss)); dc = (size_t*)malloc(n * sizeof(*dc)); res = (size_t*)malloc(n * sizeof(*res));
+    out = (jlong*)malloc(n * sizeof(*out));
+    if (!sp || !dp || !ss || !dc || !res || !out) { free(sp); free(dp); free(ss); free(dc); free(res); free(out); return E_MEM; }
+    for (i = 0; i < n; i++) {
+        jobject s = (*env)->GetObjectArrayElement(env, srcs, i), d = (*env)->GetObjectArrayElement(env, dsts, i);
+        sp[i] = (*env)->GetDirectBufferAddress(env, s); ss[i] = (size_t)(*env)->GetDirectBufferCapacity(env, s);
+        dp[i] = (*env)->GetDirectBufferAddress(env, d); dc[i] = (size_t)(*env)->GetDirectBufferCapacity(env, d);
+    }
+    r = compress ? zjni_compress_batch2(sp, ss, dp, dc, res, (size_t)n, level, checksum) : zjni_decompress_batch(sp, ss, dp, dc, res, (size_t)n);
+    if (!zjni_isError(r)) { for (i = 0; i < n; i++) out[i] = (jlong)res[i]; (*env)->SetLongArrayRegion(env, results, 0, n, out); }
+    free(sp); free(dp); free(ss); free(dc); free(res); free(out);
+    return (jlong)r;
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatch0
+  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jint level, jboolean checksum) {
+    (void)cls;
+    if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
+    return batch(env, srcs, dsts, results, 1, level, checksum == JNI_TRUE);
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressBatch0
+  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results) {
+    (void)cls;
+    if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
+    return batch(env, srcs, dsts, results, 0, 0, 0);
+}
