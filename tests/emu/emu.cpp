@@ -35,6 +35,32 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     return r;
 }
 // dictionary decode: digest (ZSTD_createDDict) + ZSTD_decompress_usingDDict
+// dictionary frames through the three-stage pipeline
+extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
+                                                        const unsigned char* dict, unsigned dictSize, int* usedSplit) {
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    u32* tab = (u32*)calloc(ZD_SPLIT_CELLS, 4); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
+    ZDDictDev* dd = (ZDDictDev*)calloc(1, sizeof(ZDDictDev));
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ~(u64)0;
+    if (usedSplit) *usedSplit = 0;
+    zd_ddict_digest(g, *sh, dict, dictSize, dd);
+    if (dd->status) r = ZJ_ERR64(dd->status);
+    else {
+        memset(sh, 0, sizeof(*sh));
+        if (zd_prep_frame<true>(g, *sh, src, srcSize, dstCap, tab, &meta, dd)) {
+            ZDSeqLane m; m.llBase = zd_k_ll_base; m.mlBase = zd_k_ml_base; m.init(src, tab, seqs, &meta, dd);
+            while (m.st != 2) m.round();
+            r = zd_exec_frame<true>(g, *sh, src, dst, &meta, seqs, lit, pf, dd, dict);
+            if (usedSplit && r != ~(u64)0) *usedSplit = 1;
+        }
+        if (r == ~(u64)0) { memset(sh, 0, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
+    }
+    free(dd); free(seqs); free(tab); free(lit); free(sh);
+    return r;
+}
 extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
                                                   const unsigned char* dict, unsigned dictSize) {
     Grp<1> g;

@@ -114,6 +114,8 @@ def test_emu_dictionary_decode(emu, oracle_ref, zj):
                 assert oracle_ref.decompress_using_dict(z, d, len(data)) == data
                 out = emu_decompress_dict(emu, z, len(data), d)
                 assert out == data, (len(data), level, out if isinstance(out, int) else "bytes differ")
+                out = emu_decompress_dict(emu, z, len(data), d, split=True)       # three-stage pipeline with the dictionary
+                assert out == data, (len(data), level, "split", out if isinstance(out, int) else "bytes differ")
         # a buffer of two frames, both using the dictionary
         a, b = b"".join(json_records(3, first=11)), b"".join(json_records(4, first=99))
         z = oracle_ref.compress_using_dict(a, d, 3) + oracle_ref.compress_using_dict(b, d, 3)
@@ -124,6 +126,7 @@ def test_emu_dictionary_decode(emu, oracle_ref, zj):
     other = oracle_ref.train_dict(json_records(2000, seed=4, first=50000), 8192)
     if oracle_ref.dict_id(other) != oracle_ref.dict_id(trained):
         assert emu_decompress_dict(emu, z, len(data), other) == -32          # dictionary_wrong
+        assert emu_decompress_dict(emu, z, len(data), other, split=True) == -32
     broken = bytearray(trained); broken[9] ^= 0xFF; broken[10] ^= 0xFF; broken[12] ^= 0xFF
     r = emu_decompress_dict(emu, z, len(data), bytes(broken))
     try:

@@ -154,12 +154,14 @@ def test_gpu_split_pipeline_device_batch(gpu, oracle_port, force_split):
     assert torch.equal(d_dst, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda())
 
 
-def test_gpu_dictionary_decode(gpu, oracle_ref):
+@pytest.mark.parametrize("split_min", ["1", "1000000000"])
+def test_gpu_dictionary_decode(gpu, oracle_ref, monkeypatch, split_min):
     """ZstdDictDecompress + ZstdDecompressCtx.loadDict / Zstd.decompress(src, dict, size) (T/scala/ZstdDict.scala:58-216):
     reference-made dictionary frames (trained dictionary and raw-content dictionary) decode bit-exactly in one batch;
     missing / wrong dictionaries give the reference's error codes"""
     import random
     from util import json_records
+    monkeypatch.setenv("ZJNI_DSPLIT_MIN", split_min)          # three-stage pipeline / fused kernel
     rnd = random.Random(5)
     trained = oracle_ref.train_dict(json_records(2000), 16384)
     raw = b"".join(json_records(40, seed=9, first=7000))

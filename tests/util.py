@@ -16,6 +16,8 @@ def emu_lib():
     L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
     L.emu_decompress_split.restype = C.c_ulonglong
     L.emu_decompress_split.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.POINTER(C.c_int)]
+    L.emu_decompress_split_dict.restype = C.c_ulonglong
+    L.emu_decompress_split_dict.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.POINTER(C.c_int)]
     L.emu_decompress_dict.restype = C.c_ulonglong
     L.emu_decompress_dict.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
     for fn in ("emu_compress", "emu_compress_split"):
@@ -33,9 +35,13 @@ def emu_decompress(L, frame, cap):
     return dst.raw[:r]
 
 
-def emu_decompress_dict(L, frame, cap, dictionary):
+def emu_decompress_dict(L, frame, cap, dictionary, split=False):
     dst = C.create_string_buffer(max(cap, 1))
-    r = L.emu_decompress_dict(frame, len(frame), dst, cap, dictionary, len(dictionary))
+    if split:
+        used = C.c_int(0)
+        r = L.emu_decompress_split_dict(frame, len(frame), dst, cap, dictionary, len(dictionary), C.byref(used))
+    else:
+        r = L.emu_decompress_dict(frame, len(frame), dst, cap, dictionary, len(dictionary))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

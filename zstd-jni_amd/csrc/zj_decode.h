@@ -303,9 +303,9 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
 // coalesced copy.
 #define ZD_STAGE_BYTES 4096u
 #if ZJ_ON_GPU
-template <class G>
+template <bool DICT, class G>
 ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 litAvail, u8* stage, bool valid, u32 ll, u32 ml, u32 off,
-                              u32 lp, u32 op, u32 op0, u32 outTot) {
+                              u32 lp, u32 op, u32 op0, u32 outTot, const u8* dictEnd) {
     u32 const k = g.lane();
     u32 const so = op - op0;                      // window offset of this sequence's literals
     u32 const mp = op + ll, md = mp - op0;        // match destination: absolute / in the window
@@ -334,10 +334,14 @@ ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit
     // ---- matches: dependency rounds (same rule as the global-memory path) ----
     sh.sLit[k] = mp; sh.sMl[k] = mp + ml;
     g.sync();
-    u32 const ms = mp - off;
-    u32 const me = zj_min(ms + ml, mp);
+    // source position: negative = in the dictionary content (dn bytes come from there), then the final output
+    // before the window, then the window itself
+    i32 const sp = (i32)mp - (i32)off;
+    u32 const dn = (DICT && sp < 0) ? zj_min(ml, (u32)(-sp)) : 0u;
+    u32 const ms = (DICT && sp < 0) ? 0u : (u32)sp;
+    u32 const me = zj_min(ms + (ml - dn), mp);
     u64 dep = 0;
-    if (valid && ml) {
+    if (valid && ml > dn) {
         u32 lo = 0, hi = k;
         while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (sh.sMl[mid] > ms) hi = mid; else lo = mid + 1; }
         u32 const jlo = lo;
@@ -354,25 +358,32 @@ ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit
         u64 big = __ballot(ready && ml > 64);
         while (big) {                             // long matches: the whole wave, byte j of the match from source byte j mod offset
             u32 const q = (u32)__builtin_ctzll(big); big &= big - 1;
-            u32 const qml = ZJ_UNI(__shfl(ml, q, 64)), qoff = ZJ_UNI(__shfl(off, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64));
+            u32 qml = ZJ_UNI(__shfl(ml, q, 64)), qmp = ZJ_UNI(__shfl(mp, q, 64)); u32 const qoff = ZJ_UNI(__shfl(off, q, 64));
+            if (DICT && qoff > qmp) {             // the part inside the dictionary first; the rest is an ordinary match
+                u32 const used = zj_min(qml, qoff - qmp);
+                grp_copy_wide(g, stage + (qmp - op0), dictEnd - (qoff - qmp), used);
+                g.sync();
+                qmp += used; qml -= used;
+            }
             u32 const qms = qmp - qoff, qmd = qmp - op0;
             GRP_FOR(g, j, qml) {
-                u32 const sp = qms + (qoff >= qml ? j : j % qoff);
-                stage[qmd + j] = sp < op0 ? out[sp] : stage[sp - op0];
+                u32 const spq = qms + (qoff >= qml ? j : j % qoff);
+                stage[qmd + j] = spq < op0 ? out[spq] : stage[spq - op0];
             }
             g.sync();
         }
         if (ready && ml <= 64) {
             u8* const d = stage + md;
             u32 j = 0;
-            if (ms < op0) {                       // leading part from the final output before the window
-                u32 const gc = zj_min(ml, op0 - ms);
-                const u8* const m = out + ms;
+            if (DICT && dn) { const u8* const dm = dictEnd + sp; for (; j + 8 <= dn; j += 8) st64(d + j, ld64(dm + j)); for (; j < dn; j++) d[j] = dm[j]; }
+            if (ms + (j - dn) < op0 && j < ml) {  // then the part from the final output before the window
+                u32 const gc = j + zj_min(ml - j, op0 - (ms + (j - dn)));
+                const u8* const m = out + ms - dn;                   // m[j] = output byte of source position ms + (j - dn)
                 for (; j + 8 <= gc; j += 8) st64(d + j, ld64(m + j));
                 for (; j < gc; j++) d[j] = m[j];
             }
-            u32 const wo = ms + j >= op0 ? ms + j - op0 : 0u;
-            const u8* const w = stage + wo - j;                  // w[j] = window byte of source position ms + j
+            u32 const wo = ms + (j - dn) >= op0 ? ms + (j - dn) - op0 : 0u;
+            const u8* const w = stage + wo - j;                      // w[j] = window byte of source position ms + (j - dn)
             if (off >= 8) { for (; j + 8 <= ml; j += 8) st64(d + j, ld64(w + j)); }
             for (; j < ml; j++) d[j] = w[j];
         }
@@ -407,7 +418,7 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     u32 const lp = lp0 + sl - ll;                 // literal source
     u32 const op = op0 + so - ll - ml;            // output position of this sequence's literals
     u32 const mp = op + ll;                       // match destination
-    if (stage && outTot <= ZD_STAGE_BYTES) { zd_execute_staged(g, sh, out, lit, litAvail, stage, valid, ll, ml, off, lp, op, op0, outTot); return; }
+    if (stage && outTot <= ZD_STAGE_BYTES) { zd_execute_staged<DICT>(g, sh, out, lit, litAvail, stage, valid, ll, ml, off, lp, op, op0, outTot, dictEnd); return; }
     // ---- literals: short runs per lane, long runs by the whole wave ----
     if (ll <= 32) {
         u32 j = 0;
@@ -640,6 +651,30 @@ ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dict
     }
     zj_mem_order();
     g.sync();
+}
+
+// The dictionary's entropy tables into LDS (a frame that uses a dictionary starts from them): 4 KiB Huffman table
+// and/or 5 KiB of tANS cells, copied as words, not unrolled — a handful of loads in flight is enough and keeps the
+// kernels' register budget where it is without dictionaries.
+template <class G>
+ZJ_DEV void zd_load_dict_entropy(const G& g, ZDecShared& sh, const ZDDictDev* dd, bool huf, bool fse) {
+    if (huf) {
+        const u32* const s32 = (const u32*)dd->huf; u32* const h32 = (u32*)sh.huf;
+#if ZJ_ON_GPU
+#pragma clang loop unroll(disable)
+#endif
+        for (u32 i = g.lane(); i < (1u << ZD_HUF_LOG_MAX) / 2u; i += (u32)g.W) h32[i] = s32[i];
+    }
+    if (fse) {
+#if ZJ_ON_GPU
+#pragma clang loop unroll(disable)
+#endif
+        for (u32 i = g.lane(); i < 512u; i += (u32)g.W) { sh.ll[i] = dd->ll[i]; sh.ml[i] = dd->ml[i]; }
+#if ZJ_ON_GPU
+#pragma clang loop unroll(disable)
+#endif
+        for (u32 i = g.lane(); i < 256u; i += (u32)g.W) sh.of[i] = dd->of[i];
+    }
 }
 
 // Decode <= ZD_HSYM symbols of stream t from its LDS window (one lane per stream).
@@ -996,18 +1031,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
         g.sync();
         if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
         if (ZJ_UNI(sh.blkType) == 1) { ipos += ZJ_UNI(sh.hdrSize); g.sync(); continue; }
-        if (dd && dd->hasEntropy) {                     // litEntropy = fseEntropy = 1 (zstd_decompress.c:1554)
-            // one 9 KiB copy as words, not unrolled: a handful of loads in flight is enough and keeps the kernel's
-            // register budget (and with it the resident frames per CU) where it is without dictionaries
-            const u32* const s32 = (const u32*)dd->huf; u32* const h32 = (u32*)sh.huf;
-#pragma clang loop unroll(disable)
-            for (u32 i = g.lane(); i < (1u << ZD_HUF_LOG_MAX) / 2u; i += (u32)g.W) h32[i] = s32[i];
-#pragma clang loop unroll(disable)
-            for (u32 i = g.lane(); i < 512u; i += (u32)g.W) { sh.ll[i] = dd->ll[i]; sh.ml[i] = dd->ml[i]; }
-#pragma clang loop unroll(disable)
-            for (u32 i = g.lane(); i < 256u; i += (u32)g.W) sh.of[i] = dd->of[i];
-            g.sync();
-        }
+        if (dd && dd->hasEntropy) { zd_load_dict_entropy(g, sh, dd, true, true); g.sync(); }   // litEntropy = fseEntropy = 1 (zstd_decompress.c:1554)
         ipos += ZJ_UNI(sh.hdrSize);
         u8* const fout = dst + total; u32 const fcap = dstCap - total;
         u32 opos = 0;

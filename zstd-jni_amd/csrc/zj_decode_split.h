@@ -49,19 +49,24 @@ struct ZDMeta {
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1.  Returns true (wave-uniform) when the frame is simple and its tables/record were written.
-template <class G>
-ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u32* tab, ZDMeta* meta) {
+template <bool DICT = false, class G>
+ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u32* tab, ZDMeta* meta, const ZDDictDev* ddArg = nullptr) {
+    const ZDDictDev* const dd = DICT ? ddArg : nullptr;
+    bool const dictEntropy = DICT && dd && dd->hasEntropy;      // the frame may start in repeat / treeless modes
     GRP_SERIAL(g) {
         u32 ok = 0;
-        sh.err = 0; sh.seqValid = 0; sh.hufValid = 0;
+        sh.err = 0; sh.seqValid = dictEntropy ? 1u : 0u; sh.hufValid = 0;
+        if (dictEntropy) { sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog; }
         // frame header, N/decompress/zstd_decompress.c:447-557
         if (srcSize >= 16 && ld32(src) == 0xFD2FB528u) {
             u32 const fhd = src[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
             u32 const fcsSz = fcsid == 0 ? single : (1u << fcsid);
-            u32 const hdr = 5 + !single + fcsSz;
-            if (!(fhd & 8) && didc == 0 && fcsSz != 0 && fcsSz <= 4 && srcSize >= hdr + 3) {
+            u32 const didSz = didc == 3 ? 4u : didc;
+            u32 const hdr = 5 + !single + didSz + fcsSz;
+            if (!(fhd & 8) && (didc == 0 || DICT) && fcsSz != 0 && fcsSz <= 4 && srcSize >= hdr + 3) {
                 u32 pos = 5; u64 window = 0; u32 content = 0; bool wok = true;
                 if (!single) { u32 const wd = src[pos++], wl = (wd >> 3) + 10; if (wl > 27) wok = false; window = (u64)1 << wl; window += (window >> 3) * (wd & 7); }
+                if (didc) { u32 const id = didc == 1 ? src[pos] : (didc == 2 ? ld16(src + pos) : ld32(src + pos)); if (!dd || id != dd->dictID) wok = false; pos += didSz; }   // a wrong dictionary is the fused kernel's to report
                 if (fcsid == 0) content = src[pos]; else if (fcsid == 1) content = ld16(src + pos) + 256; else content = ld32(src + pos);
                 if (single) window = content;
                 u32 const bh = ld24(src + hdr), last = bh & 1, type = (bh >> 1) & 3, sz = bh >> 3;
@@ -76,7 +81,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
                         if (fmt == 0 || fmt == 2) { lh = 1; n = b0 >> 3; } else if (fmt == 1) { lh = 2; n = ld16(b) >> 4; }
                         else if (sz < 3) lok = false; else { lh = 3; n = ld24(b) >> 4; }
                         c = (lt == 0) ? n : 1;
-                    } else if (sz < 5 || lt == 3) lok = false;
+                    } else if (sz < 5 || (lt == 3 && !dictEntropy)) lok = false;
                     else {
                         u32 const lhc = ld32(b);
                         if (fmt < 2) { lh = 3; n = (lhc >> 4) & 0x3FF; c = (lhc >> 14) & 0x3FF; }
@@ -96,6 +101,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     g.sync();
     if (!ZJ_UNI(sh.blkType)) return false;
     u32 const boff = ZJ_UNI(sh.hdrSize), bsize = ZJ_UNI(sh.blkSize);
+    if (dictEntropy) { zd_load_dict_entropy(g, sh, dd, false, true); g.sync(); }      // repeat modes copy the dictionary's tables
     zd_seq_tables(g, sh, src + boff, bsize, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize));
     g.sync();
     u32 const nbSeq = ZJ_UNI(sh.nbSeq);
@@ -125,15 +131,16 @@ struct ZDSeqLane {
     const u8* src; const u32* tab; u64* seqs; ZDMeta* meta; const u32* llBase; const u32* mlBase;   // bases: LDS tables of the kernel
     i32 A, S0; u32 sLL, sOF, sML, rep0, rep1, rep2, i, nbSeq, opos, lpos, litSize, cap, logs, endByte;
     u32 st;                       // 0 start, 1 running, 2 done
-    u32 bad;
+    u32 bad, dictSize;
 
-    ZJ_DEV_MEMBER void init(const u8* s, const u32* t, u64* q, ZDMeta* m) {
+    ZJ_DEV_MEMBER void init(const u8* s, const u32* t, u64* q, ZDMeta* m, const ZDDictDev* dd = nullptr) {
         src = s; tab = t; seqs = q; meta = m;
         ZDMeta const h = *m;
         nbSeq = h.nbSeq; litSize = h.litSize; logs = h.logs;
         cap = zj_min(h.contentSize, h.blockSizeMax);
         S0 = (i32)((h.blockOff + h.seqOff) * 8u); endByte = h.blockOff + h.blockSize; A = S0;
-        rep0 = 1; rep1 = 4; rep2 = 8; i = 0; opos = 0; lpos = 0; bad = 0; sLL = sOF = sML = 0;
+        rep0 = 1; rep1 = 4; rep2 = 8; i = 0; opos = 0; lpos = 0; bad = 0; sLL = sOF = sML = 0; dictSize = 0;
+        if (dd) { dictSize = dd->contentSize; if (dd->hasEntropy) { rep0 = dd->rep[0]; rep1 = dd->rep[1]; rep2 = dd->rep[2]; } }
         st = nbSeq ? 0u : 2u;
     }
     ZJ_DEV_MEMBER void finish() {
@@ -210,7 +217,7 @@ struct ZDSeqLane {
         }
         if (!last) { sLL = ZD_CELL_NEXT(cl) + vl; sML = ZD_CELL_NEXT(cm) + vm; sOF = ZD_CELL_NEXT(co) + vo; }
         // the checks of ZSTD_execSequence (:1001-1096): literals available, room in the block, offset inside the output
-        if (llen > litSize - lpos || (u64)opos + llen + mlen > cap || offset > opos + llen) { bad = 1; finish(); return; }
+        if (llen > litSize - lpos || (u64)opos + llen + mlen > cap || offset > opos + llen + dictSize) { bad = 1; finish(); return; }
         seqs[i] = zd_seq_pack(llen, mlen, offset);
         lpos += llen; opos += llen + mlen; i++;
         if (i == nbSeq) { if (A != S0) bad = 1; finish(); }
@@ -219,8 +226,11 @@ struct ZDSeqLane {
 
 // ---------------------------------------------------------------------------------------------
 // Stage 3.  Returns the decoded size, or ~0 (wave-uniform) to hand the frame to the fused kernel.
-template <class G>
-ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, const ZDMeta* meta, const u64* seqs, u8* litScratch, ZjProf& pf) {
+template <bool DICT = false, class G>
+ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, const ZDMeta* meta, const u64* seqs, u8* litScratch, ZjProf& pf,
+                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr) {
+    const ZDDictDev* const dd = DICT ? ddArg : nullptr;
+    const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
         ZDMeta const m = *meta;
         sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0;
@@ -229,6 +239,11 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     }
     g.sync();
     if (ZJ_UNI(sh.err)) return ~(u64)0;
+    if (DICT && dd && dd->hasEntropy) {               // treeless literals decode with the dictionary's Huffman table
+        zd_load_dict_entropy(g, sh, dd, true, false);
+        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufLog = dd->hufLog; }
+        g.sync();
+    }
     const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);
     u32 const nbSeq = ZJ_UNI(sh.nbSeq), content = (u32)zj_uni64(sh.contentSize);
     u32 const cap = zj_min(content, ZJ_UNI(sh.blockSizeMax));
@@ -247,7 +262,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
         }
         g.sync();
         u32 lt, ot;
-        zd_execute_batch(g, sh, dst, lit, cnt, lp, op, lt, ot, (u8*)sh.huf, litAvail);   // the Huffman table is dead once the literals are decoded
+        zd_execute_batch<DICT>(g, sh, dst, lit, cnt, lp, op, lt, ot, (u8*)sh.huf, litAvail, dictEnd);   // the Huffman table is dead once the literals are decoded
         lp += lt; op += ot;
         g.sync();
     }

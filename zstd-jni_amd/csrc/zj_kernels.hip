@@ -55,6 +55,8 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel_t(const u8* __restrict
 extern __shared__ __attribute__((aligned(16))) u8 zj_dyn_lds[];
 
 #define zj_decode_kernel zj_decode_kernel_t<false>
+#define zj_dec_prep_kernel zj_dec_prep_kernel_t<false>
+#define zj_dec_exec_kernel zj_dec_exec_kernel_t<false>
 #define zj_decode_dict_kernel zj_decode_kernel_t<true>
 
 // ZSTD_createDDict on the device: one workgroup digests the raw dictionary at dictRaw into *out
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 }
 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
-__global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
-                                                          u32 n, u32* counter, u32* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts) {
+template <bool DICT>
+__global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
+                                                          u32 n, u32* counter, u32* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
+                                                          const ZDDictDev* dd) {
     __shared__ ZDecShared sh;
     Grp<64> g;
     for (;;) {
@@ -74,15 +78,16 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel(const u8* __restrict
         if (i >= n) break;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
         u64 const cap = d1 - d0;
-        bool const simple = zd_prep_frame(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
-                                          tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i);
+        bool const simple = zd_prep_frame<DICT>(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
+                                                tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i, dd);
         if (threadIdx.x == 0) { if (simple) listA[atomicAdd(&listCounts[0], 1u)] = i; else listB[atomicAdd(&listCounts[1], 1u)] = i; }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
-                                                         const u32* countPtr, u32* workCounter, const u32* tabs, u64* seqs, ZDMeta* metas) {
+                                                         const u32* countPtr, u32* workCounter, const u32* tabs, u64* seqs, ZDMeta* metas,
+                                                         const ZDDictDev* dd) {
     __shared__ u32 llBase[36], mlBase[53];
     if (threadIdx.x < 36) llBase[threadIdx.x] = zd_k_ll_base[threadIdx.x];
     if (threadIdx.x < 53) mlBase[threadIdx.x] = zd_k_ml_base[threadIdx.x];
@@ -94,17 +99,18 @@ __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ s
             u32 const k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
             u32 const i = list[k];
-            m.init(src + srcOff[i], tabs + (size_t)i * ZD_SPLIT_CELLS, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, metas + i);
+            m.init(src + srcOff[i], tabs + (size_t)i * ZD_SPLIT_CELLS, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, metas + i, dd);
             continue;
         }
         m.round();
     }
 }
 
-__global__ __launch_bounds__(64) void zj_dec_exec_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
+template <bool DICT>
+__global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
                                                           const u32* countPtr, u32* workCounter, const ZDMeta* metas, const u64* seqs, u8* scratch,
-                                                          u32* listB, u32* listBCount, unsigned long long* prof) {
+                                                          u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw) {
     ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
     ZjProf pf; pf.start(prof);
     Grp<64> g;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel(const u8* __restrict__ 
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
         u32 const i = ZJ_UNI(list[k]);
-        u64 const r = zd_exec_frame(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf);
+        u64 const r = zd_exec_frame<DICT>(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf, dd, dictRaw);
         pf.mark(8);
         if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; }
         __syncthreads();
@@ -493,7 +499,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
     // anything that fails on the way, ends on list B and goes through the fused kernel.  Small batches: fused only.
     size_t splitMin = 4096;
     if (const char* ov = getenv("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
-    if (n >= splitMin && !ddict) {                // dictionary frames: fused kernel only (for now)
+    if (n >= splitMin) {
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
         size_t const need = tabBytes + seqBytes + metaBytes + 2 * listBytes + 256;
         if (d->dsplitBufCap < need) {
@@ -507,18 +513,26 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused
         if (hipMemsetAsync(c, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         (void)hipEventRecord(d->tev[2], st);
-        hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                           (u32)n, c + 2, tabs, metas, listA, listB, c);
+        if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
+                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
+        else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
+                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
-                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u32*)tabs, seqs, metas);
+                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u32*)tabs, seqs, metas, ddDev);
         (void)hipEventRecord(d->tev[4], st);
-        hipLaunchKernelGGL(zj_dec_exec_kernel, dim3((u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid)), dim3(64), ZD_SHARED_NO_FSE, st,
+        u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
+        if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, st,
                            (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof);
+                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw);
+        else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, st,
+                           (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
+                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw);
         (void)hipEventRecord(d->tev[5], st);
-        hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+        if (ddict) hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(grid < (u32)d->decDictGrid ? grid : (u32)d->decDictGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
+        else hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
         (void)hipEventRecord(d->tev[6], st); d->tevDecompress = true;
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
