@@ -604,7 +604,8 @@ struct ZDDictDev {
     u32 rep[3];
     u32 hufLog, llLog, ofLog, mlLog;
     u16 huf[1u << ZD_HUF_LOG_MAX];
-    u32 ll[512], ml[512], of[256];
+    u32 ll[512], of[256], ml[512];  // in the cell-table order of the split pipeline (ZD_SPLIT_OF / ZD_SPLIT_ML): a frame whose three
+                                    // tables are all "repeat" decodes straight from here
 };
 // Runs on one workgroup; `sh` is scratch.  Raw-content dictionaries (no magic) have no entropy section.
 template <class G>

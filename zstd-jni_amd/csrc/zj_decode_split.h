@@ -44,7 +44,8 @@ struct ZDMeta {
     u32 contentSize, blockSizeMax;
     u32 status;                   // stage 2: 0 ok, 1 hand over to the fused kernel
     u32 hasChecksum;              // 4 checksum bytes follow the block
-    u32 pad[2];
+    u32 dictTables;               // all three tANS tables are the dictionary's: stage 2 reads them there (shared, cache-resident)
+    u32 pad;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -106,7 +107,8 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     g.sync();
     u32 const nbSeq = ZJ_UNI(sh.nbSeq);
     if (ZJ_UNI(sh.err) || nbSeq > ZD_SPLIT_MAXSEQ) { GRP_SERIAL(g) { sh.err = 0; } g.sync(); return false; }
-    if (nbSeq) {
+    bool const allRepeat = dictEntropy && nbSeq && ZJ_UNI(sh.tblMode[0]) == 3 && ZJ_UNI(sh.tblMode[1]) == 3 && ZJ_UNI(sh.tblMode[2]) == 3;
+    if (nbSeq && !allRepeat) {
         u32 const llLog = ZJ_UNI(sh.llLog), ofLog = ZJ_UNI(sh.ofLog), mlLog = ZJ_UNI(sh.mlLog);
         GRP_FOR(g, u, 1u << llLog) tab[u] = sh.ll[u];
         GRP_FOR(g, u, 1u << ofLog) tab[ZD_SPLIT_OF + u] = sh.of[u];
@@ -116,7 +118,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
         ZDMeta m;
         m.blockOff = boff; m.blockSize = bsize; m.seqOff = sh.seqOff; m.nbSeq = nbSeq; m.litSize = sh.litSize;
         m.logs = sh.llLog | (sh.ofLog << 8) | (sh.mlLog << 16);
-        m.contentSize = (u32)sh.contentSize; m.blockSizeMax = sh.blockSizeMax; m.status = 0; m.hasChecksum = sh.hasChecksum; m.pad[0] = m.pad[1] = 0;
+        m.contentSize = (u32)sh.contentSize; m.blockSizeMax = sh.blockSizeMax; m.status = 0; m.hasChecksum = sh.hasChecksum; m.dictTables = allRepeat ? 1u : 0u; m.pad = 0;
         *meta = m;
     }
     zj_mem_order();
@@ -136,6 +138,7 @@ struct ZDSeqLane {
     ZJ_DEV_MEMBER void init(const u8* s, const u32* t, u64* q, ZDMeta* m, const ZDDictDev* dd = nullptr) {
         src = s; tab = t; seqs = q; meta = m;
         ZDMeta const h = *m;
+        if (dd && h.dictTables) tab = dd->ll;
         nbSeq = h.nbSeq; litSize = h.litSize; logs = h.logs;
         cap = zj_min(h.contentSize, h.blockSizeMax);
         S0 = (i32)((h.blockOff + h.seqOff) * 8u); endByte = h.blockOff + h.blockSize; A = S0;
@@ -239,7 +242,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     }
     g.sync();
     if (ZJ_UNI(sh.err)) return ~(u64)0;
-    if (DICT && dd && dd->hasEntropy) {               // treeless literals decode with the dictionary's Huffman table
+    if (DICT && dd && dd->hasEntropy && (src[ZJ_UNI(sh.hdrSize)] & 3u) == 3u) {   // treeless literals decode with the dictionary's Huffman table
         zd_load_dict_entropy(g, sh, dd, true, false);
         GRP_SERIAL(g) { sh.hufValid = 1; sh.hufLog = dd->hufLog; }
         g.sync();
