@@ -153,3 +153,40 @@ def test_gpu_batch_larger_than_one_scratch_slice(gpu, oracle_ref):
     for i in (0, 65535, 65536, 70000):
         f = packed[int(poff[i]):int(poff[i + 1])].cpu().numpy().tobytes()
         assert f == oracle_ref.compress(src[i * size:(i + 1) * size].cpu().numpy().tobytes(), 3, False, 14, 13), i
+
+
+def test_gpu_concurrent_callers(gpu, oracle_ref):
+    """"One context per thread, many threads" (J/ZstdCompressCtx.java:32-34): host threads on their own streams share the
+    device; results must not depend on the interleaving"""
+    import threading
+    import torch
+    size = 16384
+    want, errors = {}, []
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(3):
+                    n = 300 + 50 * t
+                    src = gpu.batch.synth(n, size, 1000 * t)
+                    soff = gpu.batch.uniform_offsets(n, size, "cuda")
+                    bound = gpu.Zstd.compressBound(size)
+                    comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); coff = gpu.batch.uniform_offsets(n, bound, "cuda")
+                    csz = gpu.batch.compress(src, soff, comp, coff, 1 + (t % 3))
+                    packed, poff = gpu.batch.pack(csz, comp, coff)
+                    back = torch.empty_like(src)
+                    dsz = gpu.batch.decompress(packed, poff, back, soff)
+                    st.synchronize()
+                    assert bool((dsz == size).all()) and torch.equal(back, src)
+                    digest = (int(csz.sum()), int(packed[: int(poff[-1])].to(torch.int64).sum()))
+                    assert want.setdefault(t, digest) == digest
+                    data = gpu.synth_host(5000, t, 1)
+                    assert gpu.Zstd.decompress(gpu.Zstd.compress(data, 2), len(data)) == data
+        except Exception as ex:          # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors

@@ -289,7 +289,10 @@ struct DevState {
     int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
     hipEvent_t tev[8] = {};                           // stage boundaries of the last batch calls (zjni_last_timing)
     bool tevCompress = false, tevDecompress = false;
-    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;   // entropy stage beside the match kernel
+    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // batch calls share the per-device scratch: they are enqueued under `enqueueMu`, and each call's kernels wait (on the
+    // GPU) for the previous call's last kernel, whatever streams the callers use — many host threads may call at once
+    std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
@@ -338,6 +341,8 @@ DevState* get_state(int ordinal) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
+        d.enqueueMu = new std::mutex();
+        if (hipEventCreateWithFlags(&d.lastDone, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
@@ -551,8 +556,19 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
 // through it in slices of ZJ_CHUNK_FRAMES on the same stream (stream order makes the reuse safe), so a batch of a
 // million buffers needs no more scratch than one of 65 536.
 #define ZJ_CHUNK_FRAMES 65536u
+// one batch call at a time per device on the host side, and in order on the GPU side
+struct BatchOrder {
+    DevState* d; hipStream_t st;
+    BatchOrder(DevState* dev, void* stream) : d(dev), st((hipStream_t)stream) {
+        if (!d) return;
+        d->enqueueMu->lock();
+        if (d->lastValid) (void)hipStreamWaitEvent(st, d->lastDone, 0);
+    }
+    ~BatchOrder() { if (!d) return; d->lastValid = (hipEventRecord(d->lastDone, st) == hipSuccess); d->enqueueMu->unlock(); }
+};
 static size_t decompress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                  uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
+    BatchOrder order(cur_state(), stream);
     for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
         size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
         size_t const r = decompress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, ddict, stream);
@@ -685,6 +701,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
+    BatchOrder order(cur_state(), stream);
     for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
         size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
         size_t const r = compress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, level, flags, stream);
