@@ -43,6 +43,14 @@ static int gpu_on(void) {
     if (state < 0) state = (zjni_device_count() > 0 && zjni_init(0) == 0) ? 1 : 0;
     return state;
 }
+/* A single buffer cannot amortise a GPU launch (a 64 KiB buffer takes milliseconds on a device built for 65 536 at a
+ * time), so when the bundled CPU library is available the per-buffer natives go there and the GPU serves the batch
+ * natives; ZSTD_JNI_GPU_PER_BUFFER=1 (or no CPU library, as in the tests) sends per-buffer calls to the GPU as well. */
+static int per_buffer_on_gpu(void) {
+    static int state = -1;
+    if (state < 0) { const char* e = getenv("ZSTD_JNI_GPU_PER_BUFFER"); state = ((e && *e == '1') || !cpu_sym("Java_com_github_luben_zstd_Zstd_compressBound")) ? 1 : 0; }
+    return state && gpu_on();
+}
 static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
     return !(zjni_isError(r) && zjni_getErrorCode(r) >= 200);
 }
@@ -95,7 +103,7 @@ JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_free(JNIEnv*
 
 /* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
 static int gpu_takes(const ZCtx* c, jint srcSize) {
-    return gpu_on() && c->level >= 1 && c->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
+    return per_buffer_on_gpu() && c->level >= 1 && c->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
 }
 typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
 
@@ -167,7 +175,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressD
     {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
         char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
         if (d == NULL || s == NULL) return E_MEM;
-        if (gpu_on()) {
+        if (per_buffer_on_gpu()) {
             size_t const r = zjni_decompress(d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
             if (gpu_result_final(r)) return (jlong)r;
         }
@@ -182,7 +190,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressB
     if (0 > src_size) return E_SRC;
     if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
     if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
-    if (gpu_on()) {
+    if (per_buffer_on_gpu()) {
         jbyte* s = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
         size_t r = (size_t)E_MEM;
         if (s && d) {
@@ -211,7 +219,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_getErrorCode(JNIEnv* env
 }
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressUnsafe
   (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size, jint level, jboolean checksumFlag) {
-    if (gpu_on() && level >= 1 && level <= 3 && (size_t)src_size <= ZJNI_BLOCKSIZE_MAX) {
+    if (per_buffer_on_gpu() && level >= 1 && level <= 3 && (size_t)src_size <= ZJNI_BLOCKSIZE_MAX) {
         size_t const r = zjni_compress2((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size, level, checksumFlag == JNI_TRUE);
         if (gpu_result_final(r)) return (jlong)r;
     }
@@ -223,7 +231,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressUnsafe
 }
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressUnsafe
   (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size) {
-    if (gpu_on()) {
+    if (per_buffer_on_gpu()) {
         size_t const r = zjni_decompress((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size);
         if (gpu_result_final(r)) return (jlong)r;
     }
