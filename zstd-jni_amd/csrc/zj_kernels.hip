@@ -182,7 +182,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         m.round(ZJ_UNI(r));
     }
 #ifdef ZL_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x == 0) printf("match lane profile: rounds %llu, cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", m.pR, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
+    if (blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
 #endif
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
