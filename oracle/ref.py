@@ -45,6 +45,15 @@ def lib():
         L.ZSTD_compress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         L.ZSTD_decompress_usingDict.restype = C.c_size_t
         L.ZSTD_decompress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        # ZstdDictCompress (reference N/jni_fast_zstd.c:26,47-49) and its two users: ZstdCompressCtx.loadDict ->
+        # ZSTD_CCtx_refCDict (:335) + ZSTD_compress2, and Zstd.compress(dst, src, ZstdDictCompress) -> ZSTD_compress_usingCDict (:191,:216)
+        L.ZSTD_createCDict.restype = C.c_void_p
+        L.ZSTD_createCDict.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+        L.ZSTD_freeCDict.argtypes = [C.c_void_p]
+        L.ZSTD_CCtx_refCDict.restype = C.c_size_t
+        L.ZSTD_CCtx_refCDict.argtypes = [C.c_void_p, C.c_void_p]
+        L.ZSTD_compress_usingCDict.restype = C.c_size_t
+        L.ZSTD_compress_usingCDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ZDICT_trainFromBuffer.restype = C.c_size_t
         L.ZDICT_trainFromBuffer.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_uint]
         L.ZDICT_isError.restype = C.c_uint
@@ -115,6 +124,50 @@ def compress_using_dict(data: bytes, dictionary: bytes, level: int = 3) -> bytes
         return dst.raw[:r]
     finally:
         L.ZSTD_freeCCtx(cctx)
+
+
+class CDict:
+    """ZSTD_createCDict(dict, level) — ZstdDictCompress (reference N/jni_fast_zstd.c:26)."""
+
+    def __init__(self, dictionary: bytes, level: int = 3):
+        self._buf = bytes(dictionary)
+        self.ptr = lib().ZSTD_createCDict(self._buf, len(self._buf), level)
+        if not self.ptr:
+            raise ZstdRefError("ZSTD_createCDict failed")
+
+    def close(self):
+        if self.ptr:
+            lib().ZSTD_freeCDict(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+    def compress(self, data: bytes, checksum: bool = False) -> bytes:
+        """ZstdCompressCtx.loadDict(ZstdDictCompress) + compress: ZSTD_CCtx_refCDict then ZSTD_compress2."""
+        L = lib()
+        cctx = L.ZSTD_createCCtx()
+        try:
+            _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_checksumFlag, int(checksum)))
+            _check(L.ZSTD_CCtx_refCDict(cctx, self.ptr))
+            cap = L.ZSTD_compressBound(len(data))
+            dst = C.create_string_buffer(max(cap, 1))
+            r = _check(L.ZSTD_compress2(cctx, dst, cap, data, len(data)))
+            return dst.raw[:r]
+        finally:
+            L.ZSTD_freeCCtx(cctx)
+
+    def compress_using(self, data: bytes) -> bytes:
+        """Zstd.compress(dst, src, ZstdDictCompress): ZSTD_compress_usingCDict."""
+        L = lib()
+        cctx = L.ZSTD_createCCtx()
+        try:
+            cap = L.ZSTD_compressBound(len(data))
+            dst = C.create_string_buffer(max(cap, 1))
+            r = _check(L.ZSTD_compress_usingCDict(cctx, dst, cap, data, len(data), self.ptr))
+            return dst.raw[:r]
+        finally:
+            L.ZSTD_freeCCtx(cctx)
 
 
 def decompress_using_dict(frame: bytes, dictionary: bytes, cap: int) -> bytes:

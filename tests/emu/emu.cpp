@@ -109,3 +109,45 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }
+
+// dictionary compression: digest (ZSTD_createCDict) + ZSTD_CCtx_refCDict / ZSTD_compress2
+#include "../../zstd-jni_amd/csrc/zj_cdict.h"
+extern "C" void* emu_cdict_create(const unsigned char* dict, unsigned dictSize, unsigned level) {
+    if (dictSize < 8 || level < 1 || level > 3) return nullptr;
+    ZEParams const cp = ze_cdict_params(level, dictSize);
+    size_t const tablesBytes = (size_t)ze_cdict_table_entries(cp) * 4u;
+    size_t const head = (sizeof(ZECDictDev) + 15) & ~(size_t)15;
+    u8* buf = (u8*)calloc(1, head + tablesBytes + dictSize + 16);
+    ZECDictDev* cd = (ZECDictDev*)buf;
+    cd->tablesOff = (u32)head; cd->rawOff = (u32)(head + tablesBytes);
+    memcpy(buf + cd->rawOff, dict, dictSize);
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    ZEEntropy* e = (ZEEntropy*)calloc(1, sizeof(ZEEntropy));
+    ze_cdict_digest(g, *sh, *e, dictSize, level, cd);
+    free(e); free(sh);
+    if (cd->status) { free(buf); return nullptr; }
+    return buf;
+}
+extern "C" void emu_cdict_free(void* cd) { free(cd); }
+extern "C" void emu_cdict_info(const void* p, unsigned* out) {
+    const ZECDictDev* cd = (const ZECDictDev*)p;
+    out[0] = cd->dictID; out[1] = cd->contentSize; out[2] = cd->windowLog; out[3] = cd->chainLog; out[4] = cd->hashLog; out[5] = cd->minMatch; out[6] = cd->strategy;
+    out[7] = cd->hufRepeat; out[8] = cd->llRepeat; out[9] = cd->ofRepeat; out[10] = cd->mlRepeat; out[11] = cd->fillStart;
+}
+extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned flags) {
+    const ZECDictDev* cd = (const ZECDictDev*)p;
+    Grp<1> g;
+    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
+    u8* lds = (u8*)calloc(1, 160 * 1024);
+    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    u8* table = (u8*)calloc(1, ZC_TABLE_STRIDE);
+    u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(ZC_MAX_SRC));
+    u32 meta[3] = {0, srcSize, srcSize};
+    if (srcSize <= ze_attach_cutoff(cd->strategy)) ze_match_lane_dict(src, srcSize, cd, table, fs, ZC_MAX_SRC, meta);
+    ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZC_MAX_SRC) * 16u); pre.meta = meta;
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & 1u, cd);
+    free(fs); free(table); free(ws); free(lds); free(sh);
+    return r;
+}

@@ -24,7 +24,45 @@ def emu_lib():
         if hasattr(L, fn):
             getattr(L, fn).restype = C.c_ulonglong
             getattr(L, fn).argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    L.emu_cdict_create.restype = C.c_void_p
+    L.emu_cdict_create.argtypes = [C.c_char_p, C.c_uint, C.c_uint]
+    L.emu_cdict_free.argtypes = [C.c_void_p]
+    L.emu_cdict_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    L.emu_compress_cdict.restype = C.c_ulonglong
+    L.emu_compress_cdict.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
     return L
+
+
+class EmuCDict:
+    """lane-serial build of the dictionary digest + attach-mode compress (ZstdDictCompress + ZstdCompressCtx.loadDict)"""
+
+    def __init__(self, L, dictionary, level):
+        self.L = L
+        self.ptr = L.emu_cdict_create(dictionary, len(dictionary), level)
+        if not self.ptr:
+            raise ValueError("dictionary rejected")
+
+    def info(self):
+        out = (C.c_uint * 12)()
+        self.L.emu_cdict_info(self.ptr, out)
+        keys = ["dictID", "contentSize", "windowLog", "chainLog", "hashLog", "minMatch", "strategy", "hufRepeat", "llRepeat", "ofRepeat", "mlRepeat", "fillStart"]
+        return dict(zip(keys, list(out)))
+
+    def compress(self, data, checksum=False):
+        cap = len(data) + (len(data) >> 8) + 64 + 128
+        dst = C.create_string_buffer(cap)
+        r = self.L.emu_compress_cdict(self.ptr, data, len(data), dst, cap, int(checksum))
+        if r >= (1 << 63):
+            return -((1 << 64) - r)
+        return dst.raw[:r]
+
+    def close(self):
+        if self.ptr:
+            self.L.emu_cdict_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
 
 
 def emu_decompress(L, frame, cap):

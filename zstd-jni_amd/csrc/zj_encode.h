@@ -763,6 +763,29 @@ ZJ_DEV u32 ze_raw_literals(const G& g, u8* dst, const u8* lit, u32 n) {
     return n + fl;
 }
 
+// ------------------------------------------------------------------ dictionary (ZSTD_CDict) --
+#define ZC_REPEAT_NONE 0u                    /* HUF_repeat / FSE_repeat */
+#define ZC_REPEAT_CHECK 1u
+#define ZC_REPEAT_VALID 2u
+// A digested dictionary in HBM: header, then the tagged tables (hashLong[1 << hashLog], hashSmall[1 << chainLog] for
+// double-fast; one table for fast), then the raw dictionary bytes.
+struct ZECDictDev {
+    u32 status;                         // 0 ok, else ZJ_E_*
+    u32 dictID, contentOff, contentSize;
+    u32 level, hasEntropy;
+    u32 windowLog, chainLog, hashLog, minMatch, strategy;       // the dictionary's own cParams
+    u32 fillStart;                      // first content offset inserted into the tables
+    u32 rep[3];
+    u32 hufRepeat, llRepeat, ofRepeat, mlRepeat;
+    u32 hufMaxSV, hufLog;
+    u32 tablesOff, rawOff;              // byte offsets from the start of this struct
+    u8 hufNbBits[256]; u16 hufVal[256];
+    ZEFseCT fse[3];                     // LL, OF, ML encoding tables (FSE_buildCTable_wksp of the dictionary's NCounts)
+};
+
+ZJ_DEV const u32* ze_cdict_tables(const ZECDictDev* cd) { return (const u32*)((const u8*)cd + cd->tablesOff); }
+ZJ_DEV const u8* ze_cdict_content(const ZECDictDev* cd) { return (const u8*)cd + cd->rawOff + cd->contentOff; }
+
 // ------------------------------------------------------------------ frame -------------------
 // `lds` = the overlay region (tables / ZEEntropy), ldsBytes its size.
 template <class TIdx> struct ZEEntOf;
@@ -774,23 +797,30 @@ template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
 template <class G, class TIdx>
-ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags) {
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd) {
     u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
     u8* const litBuf = ws + ZE_WS_LIT;
     ZESeq* const seqs = pre ? pre->seqs : (ZESeq*)(ws + ZE_WS_SEQ);
     ZEEntropy& e = *(ZEEntropy*)lds;
 
-    // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1, no dictID) ----
+    // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1; dictID of the attached dictionary if it has one) ----
     GRP_SERIAL(g) {
         sh.err = 0;
-        ze_params(sh, level, srcSize);
+        if (cd) { sh.strategy = cd->strategy; sh.minMatch = cd->minMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
+        else ze_params(sh, level, srcSize);
+        u32 const dictID = cd ? cd->dictID : 0u;
+        u32 const didCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
+        u32 const didBytes = didCode == 3 ? 4u : didCode;
         u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
-        u32 const hdr = 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
+        u32 const hdr = 5 + didBytes + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
         sh.hdrSize = hdr;
-        if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
+        if (cd && (!pre || srcSize > (cd->strategy == 2 ? (16u << 10) : (8u << 10)))) sh.err = ZJ_E_PARAM_UNSUPPORTED;   // outside the attach range
+        else if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {
-            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6) + (tail ? 4u : 0u));
-            if (fcsCode == 0) dst[5] = (u8)srcSize; else if (fcsCode == 1) st16(dst + 5, srcSize - 256); else st32(dst + 5, srcSize);
+            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6) + (tail ? 4u : 0u) + didCode);
+            if (didBytes == 1) dst[5] = (u8)dictID; else if (didBytes == 2) st16(dst + 5, dictID); else if (didBytes == 4) st32(dst + 5, dictID);
+            u8* const fp = dst + 5 + didBytes;
+            if (fcsCode == 0) fp[0] = (u8)srcSize; else if (fcsCode == 1) st16(fp, srcSize - 256); else st32(fp, srcSize);
         }
     }
     g.sync();
@@ -860,10 +890,12 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         u32 const strat = strategy;
         {   u32 const n = litSize;
             u32 const lhSize = 3 + (n >= 1024) + (n >= 16384);
-            bool const single = n < 256;
+            u32 const hufRep = cd ? cd->hufRepeat : ZC_REPEAT_NONE;           // the dictionary's Huffman table is "the previous block's"
+            bool const single = (n < 256) || (hufRep == ZC_REPEAT_VALID && lhSize == 3);
+            bool const preferRepeat = n <= 1024;                              // HUF_flags_preferRepeat (strategy < lazy)
             u32 const seg = (n + 3) / 4;
-            u32 mode = 2;                                                      // 0 raw, 1 rle, 2 compressed
-            if (n < 64) mode = 0;                                              // ZSTD_minLiteralsToCompress (strategy <= 6)
+            u32 mode = 2;                                                      // 0 raw, 1 rle, 2 compressed (new table), 3 compressed (dictionary's table)
+            if (n < (hufRep == ZC_REPEAT_VALID ? 6u : 64u)) mode = 0;           // ZSTD_minLiteralsToCompress (strategy <= 6)
             if (mode == 2) {
                 bool const suspect = (nbSeq == 0) || (n / nbSeq >= 20);
                 GRP_FOR(g, i, 1024) (&e.hist[0][0])[i] = 0;
@@ -888,35 +920,56 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                 g.sync();
                 GRP_FOR(g, s, 256) e.count[s] = e.hist[0][s] + e.hist[1][s] + e.hist[2][s] + e.hist[3][s];
                 g.sync();
-                GRP_SERIAL(g) {
-                    u32 maxSV = 255, largest = 0, m = 2;
+                GRP_SERIAL(g) {                                                // HUF_compress_internal (huf_compress.c:1333-1434) + ZSTD_compressLiterals' checks
+                    u32 maxSV = 255, largest = 0, m = 2, h = 0, rep = hufRep;
+                    bool useOld = false;
                     while (!e.count[maxSV]) maxSV--;
                     for (u32 s = 0; s <= maxSV; s++) largest = zj_max(largest, e.count[s]);
-                    if (largest == n) m = 1;
+                    if (preferRepeat && rep == ZC_REPEAT_VALID) useOld = true;    // valid table + small input: no statistics at all
+                    else if (largest == n) m = 1;
                     else if (largest <= (n >> 7) + 4) m = 0;
                     else {
-                        u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
-                        huffLog = ze_huf_build(e, maxSV, huffLog);
-                        u32 const h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog);
-                        if (!h || h + 12 >= n) m = 0;
+                        if (rep == ZC_REPEAT_CHECK) {                             // HUF_validateCTable
+                            if (cd->hufMaxSV < maxSV) rep = ZC_REPEAT_NONE;
+                            else for (u32 s = 0; s <= maxSV; s++) if (e.count[s] && !cd->hufNbBits[s]) { rep = ZC_REPEAT_NONE; break; }
+                        }
+                        if (preferRepeat && rep != ZC_REPEAT_NONE) useOld = true;
                         else {
-                            u32 total = h + (single ? 0 : 6); bool tooBig = false;
-                            for (u32 t = 0; t < (single ? 1u : 4u); t++) {
-                                u32 bits = 0; for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * e.nbBits[s];
-                                u32 const bytes = (bits + 1 + 7) >> 3;
-                                sh.strBytes[t] = bytes; sh.strOff[t] = total; total += bytes;
-                                if (bytes > 65535) tooBig = true;
-                            }
-                            if (!single && n < 12) tooBig = true;
-                            if (tooBig || total >= n - 1 || total >= n - ((n >> 6) + 2)) m = 0;
+                            u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
+                            huffLog = ze_huf_build(e, maxSV, huffLog);
+                            h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog);
+                            if (!h) m = 0;
                             else {
-                                u8* const hp = body;
-                                if (lhSize == 3) { u32 const lhc = 2 + ((u32)(!single) << 2) + (n << 4) + (total << 14); st16(hp, lhc & 0xFFFF); hp[2] = (u8)(lhc >> 16); }
-                                else if (lhSize == 4) st32(hp, 2 + (2u << 2) + (n << 4) + (total << 18));
-                                else { st32(hp, 2 + (3u << 2) + (n << 4) + (total << 22)); hp[4] = (u8)(total >> 10); }
-                                if (!single) { u8* const jt = body + lhSize + h; st16(jt, sh.strBytes[0]); st16(jt + 2, sh.strBytes[1]); st16(jt + 4, sh.strBytes[2]); }
-                                sh.litSecSize = lhSize + total;
+                                if (rep != ZC_REPEAT_NONE) {                      // is the dictionary's table at least as good?
+                                    u32 oldBits = 0, newBits = 0;
+                                    for (u32 s = 0; s <= maxSV; s++) { oldBits += e.count[s] * cd->hufNbBits[s]; newBits += e.count[s] * e.nbBits[s]; }
+                                    if ((oldBits >> 3) <= h + (newBits >> 3) || h + 12 >= n) useOld = true;
+                                }
+                                if (!useOld && h + 12 >= n) m = 0;
                             }
+                        }
+                    }
+                    if (useOld) { m = 3; h = 0; }
+                    if (m >= 2) {
+                        u32 total = h + (single ? 0 : 6); bool tooBig = false;
+                        for (u32 t = 0; t < (single ? 1u : 4u); t++) {
+                            u32 bits = 0;
+                            if (useOld) { for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * cd->hufNbBits[s]; }
+                            else { for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * e.nbBits[s]; }
+                            u32 const bytes = (bits + 1 + 7) >> 3;
+                            sh.strBytes[t] = bytes; sh.strOff[t] = total; total += bytes;
+                            if (bytes > 65535) tooBig = true;
+                        }
+                        if (!single && n < 12) tooBig = true;
+                        if (tooBig || total >= n - 1 || total >= n - ((n >> 6) + 2)) m = 0;
+                        else if (total == 1 && largest == n) m = 1;              // one byte out: rle if all literals are the same byte (n < 8 here)
+                        else {
+                            u8* const hp = body;
+                            if (lhSize == 3) { u32 const lhc = m + ((u32)(!single) << 2) + (n << 4) + (total << 14); st16(hp, lhc & 0xFFFF); hp[2] = (u8)(lhc >> 16); }
+                            else if (lhSize == 4) st32(hp, m + (2u << 2) + (n << 4) + (total << 18));
+                            else { st32(hp, m + (3u << 2) + (n << 4) + (total << 22)); hp[4] = (u8)(total >> 10); }
+                            if (!single) { u8* const jt = body + lhSize + h; st16(jt, sh.strBytes[0]); st16(jt + 2, sh.strBytes[1]); st16(jt + 4, sh.strBytes[2]); }
+                            sh.litSecSize = lhSize + total;
                         }
                     }
                     sh.litMode = m;
@@ -925,10 +978,11 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                 pf.mark(3);
                 mode = ZJ_UNI(sh.litMode);
             }
-            if (mode == 2) {
+            if (mode >= 2) {
                 u32 const streams = single ? 1u : 4u;
                 u32* const codes = e.count;                                    // histogram is dead: code | nbBits << 16 per symbol
-                GRP_FOR(g, s, 256) codes[s] = (u32)e.val[s] | ((u32)e.nbBits[s] << 16);
+                if (mode == 3) { GRP_FOR(g, s, 256) codes[s] = (u32)cd->hufVal[s] | ((u32)cd->hufNbBits[s] << 16); }
+                else { GRP_FOR(g, s, 256) codes[s] = (u32)e.val[s] | ((u32)e.nbBits[s] << 16); }
                 g.sync();
                 for (u32 t = 0; t < streams; t++) {
                     u32 const cnt = single ? n : (t < 3 ? seg : n - 3 * seg);
@@ -976,8 +1030,10 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                         u32 max = 0, most = 0;
                         for (u32 s = 0; s <= maxSym; s++) { if (e.scount[s]) max = s; most = zj_max(most, e.scount[s]); }
                         bool const defaultAllowed = (t != 1) || (max <= 28);
-                        u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy, no repeat
+                        u32 const fseRep = cd ? (t == 0 ? cd->llRepeat : (t == 1 ? cd->ofRepeat : cd->mlRepeat)) : ZC_REPEAT_NONE;
+                        u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
                         if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+                        else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
                         else {
                             u32 const dynMin = ((1u << defLog) * (10 - strat)) >> 3;
                             type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
@@ -987,6 +1043,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                         u32 const firstCode = (t == 0 ? seqs[0].ll : (t == 1 ? seqs[0].off : seqs[0].ml)) >> 24;
                         if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1; }
                         else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, e.cumul, e.tableSymbol);
+                        else if (type == 3) h = 0;                             // table copied below by the whole wave
                         else {
                             u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
                             if (e.scount[lastCode] > 1) { e.scount[lastCode]--; nbSeq1--; }
@@ -1000,6 +1057,11 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                         else if (type == 2) sh.seqLastCount = h;
                     }
                     g.sync();
+                    if (ZJ_UNI(sh.seqType[t]) == 3) {
+                        const u32* const from = (const u32*)&cd->fse[t]; u32* const to = (u32*)&e.ct[t];
+                        GRP_FOR(g, i, (u32)(sizeof(ZEFseCT) / 4)) to[i] = from[i];
+                        g.sync();
+                    }
                     pos += ZJ_UNI(sh.seqHdr[t]);
                 }
                 pf.mark(5);
@@ -1141,9 +1203,10 @@ ZJ_HD u32 ze_lds_need(u32 level, u32 srcSize) {
 }
 
 template <class G>
-ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr, u32 flags = 0) {
-    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags);
-    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags);
+ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr, u32 flags = 0,
+                       const ZECDictDev* cd = nullptr) {
+    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd);
+    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd);
 }
 
 // Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.
