@@ -1,0 +1,121 @@
+"""CPU (-m "not gpu"): dictionary compression bodies (zstd-jni_amd/csrc/zj_cdict.h + the dictionary branches of
+zj_encode.h), built lane-serial (tests/emu), are byte-identical to the reference's ZstdDictCompress path:
+ZSTD_createCDict(dict, level) + ZSTD_CCtx_refCDict + ZSTD_compress2 (N/jni_fast_zstd.c:26,325-336,586-640), which
+equals ZSTD_compress_usingCDict (N/jni_fast_zstd.c:171-216) on these inputs.  Covered: trained dictionaries of the
+four parameter classes (<= 16 KiB, <= 128 KiB, <= 256 KiB, larger), raw-content dictionaries, hand-assembled
+dictionaries whose tables do not cover every symbol ("check" repeat modes) and 1/2/4-byte dictIDs, sources from 0
+bytes to the attach cutoff, and the refusal above it."""
+import random
+
+import pytest
+
+import dictutil as du
+from util import EmuCDict, emu_lib, json_records
+
+WORDS = [b"the", b"quick", b"brown", b"fox", b"jumps", b"over", b"lazy", b"dog", b"lorem", b"ipsum", b"dolor", b"sit", b"amet", b"zstd", b"frame", b"block"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib()
+
+
+def text(n, r):
+    out = bytearray()
+    while len(out) < n:
+        out += r.choice(WORDS) + b" "
+    return bytes(out[:n])
+
+
+def lowent(n, r):
+    out = bytearray()
+    for i in range(n):
+        out.append(out[i - r.randrange(1, min(i, 64) + 1)] if i and r.random() < 7 / 8 else r.randrange(16))
+    return bytes(out)
+
+
+def sources(recs, r, cutoff):
+    out = []
+    for size in [0, 1, 6, 7, 8, 9, 63, 64, 100, 255, 256, 1000, 1023, 1024, 1025, 4096, 8191, 8192, 12000, 16384]:
+        if size > cutoff:
+            continue
+        k = r.randrange(0, len(recs) - 300)
+        out += [b",".join(recs[k:k + 200])[:size], text(size, r), lowent(size, r), bytes(r.getrandbits(8) for _ in range(size))]
+    return out
+
+
+def check(emu, ref, dictionary, level, srcs_of):
+    cd = ref.CDict(dictionary, level)
+    ecd = EmuCDict(emu, dictionary, level)
+    info = ecd.info()
+    cutoff = 16384 if info["strategy"] == 2 else 8192
+    for x in srcs_of(cutoff):
+        want = cd.compress(x)
+        assert ecd.compress(x) == want, (len(dictionary), level, len(x))
+        assert want == cd.compress_using(x)
+        assert ref.decompress_using_dict(want, dictionary, len(x)) == x
+    assert ecd.compress(bytes(cutoff + 1)) == -40            # outside the attach range: parameter_unsupported
+    return info
+
+
+@pytest.mark.parametrize("dict_size", [2048, 16384, 112640, 200000, 300000])
+def test_emu_cdict_trained(emu, oracle_ref, dict_size):
+    r = random.Random(dict_size)
+    recs = json_records(30000, seed=3)
+    samples = [b",".join(recs[i * 13:i * 13 + 200])[:4096] for i in range(1500)] + [text(4096, r) for _ in range(200)]
+    d = oracle_ref.train_dict(samples, dict_size)
+    for level in (1, 2, 3):
+        info = check(emu, oracle_ref, d, level, lambda cut: sources(recs, r, cut))
+        assert (info["hufRepeat"], info["llRepeat"], info["ofRepeat"], info["mlRepeat"]) == (2, 2, 2, 2)
+        assert info["dictID"] == oracle_ref.dict_id(d)
+
+
+def test_emu_cdict_raw_content(emu, oracle_ref):
+    r = random.Random(5)
+    recs = json_records(3000, seed=9)
+    for d in (text(50000, r), b",".join(recs[:300]), b"0123456789abcdef" * 2, bytes(r.getrandbits(8) for _ in range(5000))):
+        for level in (1, 2, 3):
+            info = check(emu, oracle_ref, d, level, lambda cut: sources(recs, r, min(cut, 4096)))
+            assert info["dictID"] == 0 and info["hufRepeat"] == 0
+
+
+def test_emu_cdict_check_modes_and_dict_ids(emu, oracle_ref):
+    r = random.Random(11)
+    recs = json_records(5000, seed=5)
+    content = b",".join(recs[:150])
+    hist = [0] * 256
+    for b in content:
+        hist[b] += 1
+    seen = set()
+    for of_zero in (0, 1):
+        for ml_full in (0, 1):
+            for ll_full in (0, 1):
+                did = (7, 300, 70000)[(of_zero + ml_full + ll_full) % 3]
+                ofw = [1] * 20 if not of_zero else [1, 0, 1, 1, 0] + [2] * 12
+                mlw = [3 if i < 20 else 1 for i in range(53 if ml_full else 40)]
+                llw = [4 if i < 10 else 1 for i in range(36 if ll_full else 30)]
+                d = du.build(content, did, hist, du.normalise(ofw, 7), 7, du.normalise(mlw, 8), 8, du.normalise(llw, 8), 8)
+
+                def srcs(cut):
+                    out = [b",".join(recs[200 + i * 9:200 + i * 9 + k]) for i, k in enumerate([1, 2, 3, 5, 8, 13, 20, 30, 40, 60])]
+                    out += [bytes(r.choice(content) for _ in range(n)) for n in (50, 200, 800, 1500, 5000)] + [content[100:3000], content[5:7000]]
+                    return [x for x in out if len(x) <= cut]
+
+                for level in (1, 3):
+                    info = check(emu, oracle_ref, d, level, srcs)
+                    assert info["dictID"] == did and info["hufRepeat"] == 1
+                    seen.add((info["llRepeat"], info["ofRepeat"], info["mlRepeat"]))
+    assert (1, 1, 1) in seen and (2, 2, 2) in seen
+
+
+def test_emu_cdict_checksum_and_rejects(emu, oracle_ref):
+    recs = json_records(400, seed=2)
+    d = b",".join(recs[:100])
+    cd = oracle_ref.CDict(d, 3)
+    ecd = EmuCDict(emu, d, 3)
+    for x in (b"", recs[200], b",".join(recs[150:180])):
+        assert ecd.compress(x, checksum=True) == cd.compress(x, checksum=True)
+    with pytest.raises(ValueError):
+        EmuCDict(emu, b"\x37\xa4\x30\xec" + bytes(40), 3)        # magic + garbage: dictionary_corrupted, like ZSTD_createCDict -> NULL
+    with pytest.raises(oracle_ref.ZstdRefError):
+        oracle_ref.CDict(b"\x37\xa4\x30\xec" + bytes(40), 3)
