@@ -100,6 +100,29 @@ size_t zjni_decompress_batch_usingDDict(const void* const* src, const size_t* sr
                                         size_t* result, size_t n, const zjni_ddict* ddict);
 size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zjni_ddict* ddict);
 
+/* ---- compression dictionaries ----
+ * zjni_cdict == ZSTD_CDict as zstd-jni holds it in ZstdDictCompress.nativePtr (J/ZstdDictCompress.java;
+ * N/jni_fast_zstd.c:18-66: init = ZSTD_createCDict(dict, size, level), free = ZSTD_freeCDict).  The dictionary is
+ * digested once on the device: parameters of (level, dictSize), tagged hash tables over the content, the entropy
+ * tables and repcodes of its header.  Levels 1..3.  NULL for a corrupted dictionary, a bad level, fewer than
+ * 8 bytes, or without a device. */
+typedef struct zjni_cdict zjni_cdict;
+zjni_cdict* zjni_createCDict(const void* dict, size_t dictSize, int level);
+size_t zjni_freeCDict(zjni_cdict* cdict);
+unsigned zjni_getDictID_fromCDict(const zjni_cdict* cdict);
+/* Replaces ZstdCompressCtx.loadDict(ZstdDictCompress) + compress*0 = ZSTD_CCtx_refCDict + ZSTD_compress2
+ * (N/jni_fast_zstd.c:325-336, :586-640) and ZSTD_compress_usingCDict (compress*FastDict0, N/jni_fast_zstd.c:171-216)
+ * for n buffers at once; frames are byte-identical to the reference's.  Covers the sizes at which the reference
+ * searches the dictionary in place ("attach": srcSize <= 8 KiB when the dictionary's strategy is fast, <= 16 KiB when
+ * it is double-fast); a larger buffer reports ZSTD_error_parameter_unsupported in its result slot. */
+size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* d_src_off,
+                                             void* d_dst, const uint64_t* d_dst_off,
+                                             uint64_t* d_result, size_t n, const zjni_cdict* cdict, int checksum, void* stream);
+size_t zjni_compress_batch_usingCDict(const void* const* src, const size_t* srcSize,
+                                      void* const* dst, const size_t* dstCapacity,
+                                      size_t* result, size_t n, const zjni_cdict* cdict, int checksum);
+size_t zjni_compress_usingCDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zjni_cdict* cdict);
+
 /* ---- hot path, host buffers (what a JNI batch native binds; stages through pinned memory) ---- */
 size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize,
                              void* const* dst, const size_t* dstCapacity,

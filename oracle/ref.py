@@ -136,7 +136,7 @@ class CDict:
             raise ZstdRefError("ZSTD_createCDict failed")
 
     def close(self):
-        if self.ptr:
+        if self.ptr and lib is not None:
             lib().ZSTD_freeCDict(self.ptr)
             self.ptr = None
 

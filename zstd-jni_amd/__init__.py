@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libzjni_amd.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in
-           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_decode_split.h", "zj_encode.h", "zj_match_lane.h", "zj_synth.h")]
+           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_decode_split.h", "zj_encode.h", "zj_match_lane.h", "zj_cdict.h", "zj_synth.h")]
 BLOCKSIZE_MAX = 1 << 17
 ERR_NO_DEVICE = 200
 ERR_UNSUPPORTED = 201
@@ -100,6 +100,18 @@ def lib():
     L.zjni_decompress_batch_usingDDict.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, vp]
     L.zjni_decompress_usingDDict.restype = sz
     L.zjni_decompress_usingDDict.argtypes = [vp, sz, vp, sz, vp]
+    L.zjni_createCDict.restype = vp
+    L.zjni_createCDict.argtypes = [vp, sz, C.c_int]
+    L.zjni_freeCDict.restype = sz
+    L.zjni_freeCDict.argtypes = [vp]
+    L.zjni_getDictID_fromCDict.restype = C.c_uint
+    L.zjni_getDictID_fromCDict.argtypes = [vp]
+    L.zjni_compress_batch_device_usingCDict.restype = sz
+    L.zjni_compress_batch_device_usingCDict.argtypes = [vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]
+    L.zjni_compress_batch_usingCDict.restype = sz
+    L.zjni_compress_batch_usingCDict.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, vp, C.c_int]
+    L.zjni_compress_usingCDict.restype = sz
+    L.zjni_compress_usingCDict.argtypes = [vp, sz, vp, sz, vp]
     L.zjni_decompress_batch.restype = sz
     L.zjni_decompress_batch.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz]
     L.zjni_compress_batch.restype = sz
@@ -130,7 +142,9 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing",
            "zjni_compress_batch_device2", "zjni_compress_batch2", "zjni_compress2",
            "zjni_createDDict", "zjni_freeDDict", "zjni_getDictID_fromDDict", "zjni_decompress_batch_device_usingDDict",
-           "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict")
+           "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict",
+           "zjni_createCDict", "zjni_freeCDict", "zjni_getDictID_fromCDict", "zjni_compress_batch_device_usingCDict",
+           "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict")
 
 
 # --------------------------------------------------------------------------- Java API mirror --
@@ -212,8 +226,11 @@ class Zstd:
             return ctx._raw(dst, dstOffset, dstSize, src, srcOffset, srcSize)
 
     @staticmethod
-    def compress(src, level=3, checksumFlag=False):                # J/Zstd.java:1137 (byte[] -> byte[]), :60-78 (checksumFlag)
+    def compress(src, level=3, checksumFlag=False):                # J/Zstd.java:1137 (byte[] -> byte[]), :60-78 (checksumFlag), :1256 (byte[], ZstdDictCompress)
         with ZstdCompressCtx() as ctx:
+            if isinstance(level, ZstdDictCompress):
+                ctx.loadDict(level)
+                return ctx.compress(src)
             ctx.setLevel(level)
             ctx.setChecksum(checksumFlag)
             return ctx.compress(src)
@@ -259,6 +276,36 @@ class ZstdCompressCtx(_AutoClose):
         super().__init__()
         self.level = 3                                             # ZSTD_CLEVEL_DEFAULT
         self.checksum = False                                      # ZSTD_c_checksumFlag default
+        self._cdict = None                                         # ZstdDictCompress in use (ZSTD_CCtx_refCDict)
+        self._raw_dict = None                                      # byte[] dictionary (ZSTD_CCtx_loadDictionary): digested at the ctx's level
+        self._own = None
+
+    def loadDict(self, dictionary):                                # J/ZstdCompressCtx.java:424-470 (ZstdDictCompress, byte[] or null)
+        self._ensure_open()
+        if self._own is not None:
+            self._own[1].close()
+            self._own = None
+        self._cdict = dictionary if isinstance(dictionary, ZstdDictCompress) else None
+        self._raw_dict = None if (dictionary is None or self._cdict is not None) else bytes(dictionary)
+        return self
+
+    def close(self):
+        if self._own is not None:
+            self._own[1].close()
+            self._own = None
+        super().close()
+
+    def _active_dict(self):
+        if self._cdict is not None:
+            self._cdict._ensure_open()
+            return self._cdict
+        if self._raw_dict is not None:
+            if self._own is None or self._own[0] != self.level:    # ZSTD_initLocalDict: a CDict at the requested level
+                if self._own is not None:
+                    self._own[1].close()
+                self._own = (self.level, ZstdDictCompress(self._raw_dict, self.level))
+            return self._own[1]
+        return None
 
     def setChecksum(self, checksumFlag):                           # J/ZstdCompressCtx.java:105 -> setChecksum0 (N/jni_fast_zstd.c:276-282)
         self._ensure_open()
@@ -287,7 +334,15 @@ class ZstdCompressCtx(_AutoClose):
             return -70
         sa, k1 = _addr(src, srcOffset)
         da, k2 = _addr(dst, dstOffset)
-        r = lib().zjni_compress2(da, dstSize, sa, srcSize, self.level, 1 if self.checksum else 0)
+        cd = self._active_dict()
+        if cd is not None:                                         # ZSTD_CCtx_refCDict + ZSTD_compress2
+            sp, dp = (C.c_void_p * 1)(sa), (C.c_void_p * 1)(da)
+            ss, dc, res = (C.c_size_t * 1)(srcSize), (C.c_size_t * 1)(dstSize), (C.c_size_t * 1)()
+            r = lib().zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, 1, cd._ptr, 1 if self.checksum else 0)
+            if not lib().zjni_isError(r):
+                r = res[0]
+        else:
+            r = lib().zjni_compress2(da, dstSize, sa, srcSize, self.level, 1 if self.checksum else 0)
         return r - (1 << 64) if r >= (1 << 63) else r
 
     def compressByteArray(self, dstBuff, dstOffset, dstSize, srcBuff, srcOffset, srcSize):   # J/ZstdCompressCtx.java:691
@@ -311,6 +366,39 @@ class ZstdCompressCtx(_AutoClose):
         out = bytearray(bound)
         n = self.compressByteArray(out, 0, bound, src, 0, len(src))
         return bytes(out[:n])
+
+
+class ZstdDictCompress(_AutoClose):
+    """J/ZstdDictCompress.java: a dictionary digested once for one compression level (ZSTD_createCDict,
+    N/jni_fast_zstd.c:18-52) and shared read-only by any number of compress calls; close() frees the device copy.
+    Constructors: (dict, level) and (dict, offset, length, level)."""
+
+    def __init__(self, dictionary, *args):
+        super().__init__()
+        if len(args) == 1:
+            offset, length, level = 0, None, args[0]
+        elif len(args) == 3:
+            offset, length, level = args
+        else:
+            raise TypeError("ZstdDictCompress(dict, level) or ZstdDictCompress(dict, offset, length, level)")
+        data = bytes(dictionary)[offset:(None if length is None else offset + length)]
+        self._level = level
+        self._ptr = lib().zjni_createCDict(data, len(data), level)
+        if not self._ptr:
+            raise ZstdException(30 if 1 <= level <= 3 else 42)   # the Java class throws IllegalStateException("ZSTD_createCDict failed")
+
+    def level(self):                                             # J/ZstdDictCompress.java:110
+        return self._level
+
+    def getDictID(self):
+        self._ensure_open()
+        return lib().zjni_getDictID_fromCDict(self._ptr)
+
+    def close(self):
+        if not self._closed and self._ptr:
+            lib().zjni_freeCDict(self._ptr)
+            self._ptr = None
+        super().close()
 
 
 class ZstdDictDecompress(_AutoClose):
@@ -412,9 +500,10 @@ def _check_launch(r):
         raise ZstdException(r)
 
 
-def compress_batch(buffers, level=3, checksum=False):
-    """n independent buffers -> n zstd frames through zjni_compress_batch2 (host pointers)."""
-    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum)
+def compress_batch(buffers, level=3, checksum=False, dictionary=None):
+    """n independent buffers -> n zstd frames through zjni_compress_batch2 / _usingCDict (host pointers);
+    `dictionary` is a ZstdDictCompress (its level applies)."""
+    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum, dictionary)
 
 
 def decompress_batch(frames, capacities, dictionary=None):
@@ -434,7 +523,9 @@ def _host_batch(srcs, caps, is_compress, level, checksum=False, dictionary=None)
     ss = (C.c_size_t * n)(*[len(s) for s in srcs])
     dc = (C.c_size_t * n)(*caps)
     res = (C.c_size_t * n)()
-    if is_compress:
+    if is_compress and dictionary is not None:
+        r = L.zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, n, dictionary._ptr, 1 if checksum else 0)
+    elif is_compress:
         r = L.zjni_compress_batch2(sp, ss, dp, dc, res, n, level, 1 if checksum else 0)
     else:
         r = L.zjni_decompress_batch_usingDDict(sp, ss, dp, dc, res, n, dictionary._ptr if dictionary is not None else None)

@@ -42,12 +42,16 @@ def synth(n, buf_size, first_index=0, device="cuda"):
     return blob
 
 
-def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checksum=False):
-    """Enqueue zjni_compress_batch_device on the current stream; returns the int64[n] result tensor
-    (compressed size per buffer, or a negative ZSTD/ZJNI error code)."""
+def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checksum=False, dictionary=None):
+    """Enqueue zjni_compress_batch_device[2 / _usingCDict] on the current stream; returns the int64[n] result tensor
+    (compressed size per buffer, or a negative ZSTD/ZJNI error code).  `dictionary`: a ZstdDictCompress (its level applies)."""
     n = src_off.numel() - 1
     if results is None:
         results = torch.empty(n, dtype=torch.int64, device=src_blob.device)
+    if dictionary is not None:
+        _check(lib().zjni_compress_batch_device_usingCDict(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
+                                                           results.data_ptr(), n, dictionary._ptr, 1 if checksum else 0, _stream_ptr()))
+        return results
     _check(lib().zjni_compress_batch_device2(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
                                              results.data_ptr(), n, level, 1 if checksum else 0, _stream_ptr()))
     return results

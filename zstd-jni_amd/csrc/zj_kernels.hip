@@ -14,6 +14,7 @@
 #include "zj_decode.h"
 #include "zj_decode_split.h"
 #include "zj_encode.h"
+#include "zj_cdict.h"
 #include "zj_synth.h"
 
 #define ZJNI_ERR(code) ((size_t)0 - (size_t)(code))
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
                                                         u8* fscratch, u32 maxSrc, const u32* meta,
-                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags) {
+                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags, const ZECDictDev* cd) {
     // mode 0: list entry k.  mode 1: k-th entry of the completion queue the match kernel fills while this kernel
     // runs (bounded wait; a workgroup that gives up leaves its frame to the mode-2 pass).  mode 2: list entries
     // mode 1 did not finish.
@@ -238,10 +239,36 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
             pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta + 3 * (size_t)k;
             prePtr = &pre;
         }
-        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr, flags);
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr, flags, cd);
         pf.mark(7);
         if (threadIdx.x == 0) { result[i] = r; if (mode == 1) procFlag[k] = 1u; }
         __syncthreads();
+    }
+}
+
+// ZSTD_createCDict on the device: one workgroup digests the dictionary held in `out` (header, zeroed tables, raw bytes)
+__global__ __launch_bounds__(64) void zj_cdict_digest_kernel(u32 dictSize, u32 level, ZECDictDev* out) {
+    __shared__ ZDecShared sh;
+    __shared__ ZEEntropy e;
+    Grp<64> g;
+    ze_cdict_digest(g, sh, e, dictSize, level, out);
+}
+
+// Attach-mode match finding against a dictionary, lane per frame (zj_cdict.h): the dictionary's tables and content
+// are shared by every lane (L2-resident), each frame's own tables sit in its HBM slot.  Frames outside the attach
+// range are left to the entropy kernel, which reports them.
+__global__ __launch_bounds__(64) void zj_enc_match_dict_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const ZECDictDev* __restrict__ cd,
+                                                                const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                                u8* tables, u8* fscratch, u32* meta) {
+    u32 const count = *countPtr;
+    u32 const cutoff = ze_attach_cutoff(cd->strategy);
+    for (;;) {
+        u32 const k = atomicAdd(workCounter, 1u);
+        if (k >= count) break;
+        u32 const i = list[k];
+        u64 const s0 = srcOff[i]; u64 const size = srcOff[i + 1] - s0;
+        if (size > cutoff) continue;
+        ze_match_lane_dict(src + s0, (u32)size, cd, tables + (size_t)k * ZC_TABLE_STRIDE, fscratch + (size_t)k * ZE_FRAME_STRIDE(ZC_MAX_SRC), ZC_MAX_SRC, meta + 3 * (size_t)k);
     }
 }
 
@@ -488,6 +515,7 @@ int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* enco
     return 0;
 }
 
+struct zjni_cdict { int ordinal; u8* buf; unsigned dictID; int level; u32 strategy; };   // buf = [ZECDictDev][tagged tables][raw dictionary bytes]
 struct zjni_ddict { int ordinal; u8* buf; size_t rawSize; unsigned dictID; };   // buf = [ZDDictDev][raw dictionary bytes]
 
 static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -672,11 +700,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags);
+                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags);
+                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr);
         } else {
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
@@ -684,19 +712,19 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
+                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
+                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
     }
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags);
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -718,9 +746,96 @@ size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off,
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
 
+// ZSTD_createCDict (N/compress/zstd_compress.c:5710-5719; ZstdDictCompress.init, N/jni_fast_zstd.c:18-52): the raw dictionary
+// goes to HBM once, behind its (zeroed) tagged tables, and one workgroup digests it there.  NULL when the device, the level
+// or the dictionary is bad.
+zjni_cdict* zjni_createCDict(const void* dict, size_t dictSize, int level) {
+    DevState* d = cur_state();
+    if (!d || !dict || dictSize < 8 || dictSize > 0x3FFFFFFFull || level < 1 || level > 3) return nullptr;
+    ZEParams const cp = ze_cdict_params((u32)level, (u32)dictSize);
+    size_t const head = (sizeof(ZECDictDev) + 15) & ~(size_t)15, tablesBytes = (size_t)ze_cdict_table_entries(cp) * 4u;
+    zjni_cdict* cd = new zjni_cdict{t_dev, nullptr, 0, level, cp.strategy};
+    if (hipMalloc(&cd->buf, head + tablesBytes + dictSize + 16) != hipSuccess) { delete cd; return nullptr; }
+    ZECDictDev hd; memset(&hd, 0, sizeof(hd));
+    hd.tablesOff = (u32)head; hd.rawOff = (u32)(head + tablesBytes);
+    bool ok = hipMemset(cd->buf, 0, head + tablesBytes) == hipSuccess
+           && hipMemcpy(cd->buf, &hd, sizeof(hd), hipMemcpyHostToDevice) == hipSuccess
+           && hipMemcpy(cd->buf + hd.rawOff, dict, dictSize, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(zj_cdict_digest_kernel, dim3(1), dim3(64), 0, 0, (u32)dictSize, (u32)level, (ZECDictDev*)cd->buf);
+        ok = hipMemcpy(&hd, cd->buf, 64, hipMemcpyDeviceToHost) == hipSuccess && hd.status == 0;
+    }
+    if (!ok) { (void)hipFree(cd->buf); delete cd; return nullptr; }
+    cd->dictID = hd.dictID;
+    return cd;
+}
+size_t zjni_freeCDict(zjni_cdict* cd) {
+    if (!cd) return 0;
+    (void)hipSetDevice(cd->ordinal);
+    (void)hipFree(cd->buf);
+    delete cd;
+    return 0;
+}
+unsigned zjni_getDictID_fromCDict(const zjni_cdict* cd) { return cd ? cd->dictID : 0u; }
+
+// ZstdCompressCtx.loadDict(ZstdDictCompress) + compress, batched: lane-per-frame attach-mode search, then the
+// wave-per-frame entropy stage starting from the dictionary's tables.
+static size_t compress_cdict_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                         uint64_t* d_result, size_t n, const zjni_cdict* cdict, u32 flags, void* stream) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->encListCap < n) {
+        if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
+        size_t const cap = n + (n >> 2) + 1024;
+        if (hipMalloc(&d->encList, 2 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
+        d->encListCap = cap;
+    }
+    u32* const ctr = d->counters + 16; u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap;
+    u32* const mctr = d->counters + 24;
+    size_t const tablesBytes = n * (size_t)ZC_TABLE_STRIDE, fsBytes = n * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = n * 12;
+    size_t const need = tablesBytes + fsBytes + metaBytes + 256;
+    if (d->splitBufCap < need) {
+        if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
+        if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+        d->splitBufCap = need;
+    }
+    u8* const tables = d->splitBuf; u8* const fscratch = d->splitBuf + tablesBytes; u32* const meta = (u32*)(fscratch + fsBytes);
+    const ZECDictDev* const cd = (const ZECDictDev*)cdict->buf;
+    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess || hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
+                       (u32)n, 1u, 0xFFFFFFFFu, ctr, listA, listB);                     // every frame <= 128 KiB goes to list A
+    u32 const waves = (u32)((n + 63) / 64);
+    u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
+    (void)hipEventRecord(d->tev[0], st);
+    hipLaunchKernelGGL(zj_enc_match_dict_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, cd,
+                       (const u32*)listA, (const u32*)ctr, mctr, tables, fscratch, meta);
+    (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
+    u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)cdict->level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                       fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                             uint64_t* d_result, size_t n, const zjni_cdict* cdict, int checksum, void* stream) {
+    if (!cdict) return ZJNI_ERR(32);
+    if (cdict->ordinal != t_dev && t_dev >= 0) return ZJNI_ERR(32);                       // digested on another device
+    BatchOrder order(cur_state(), stream);
+    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
+        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+        size_t const r = compress_cdict_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, cdict, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
+        if (r != 0 || n == 0) return r;
+    }
+    return 0;
+}
+
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
 static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
-                         size_t* result, size_t n, int level, int checksum = 0, const zjni_ddict* ddict = nullptr) {
+                         size_t* result, size_t n, int level, int checksum = 0, const zjni_ddict* ddict = nullptr, const zjni_cdict* cdict = nullptr) {
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (n == 0) return 0;
@@ -742,7 +857,10 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     hs[n] = a; hd[n] = b;
     if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcTotal, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     size_t r;
-    if (compress)
+    if (compress && cdict)
+        r = zjni_compress_batch_device_usingCDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                                                  (u64*)(d->dStage + oRes), n, cdict, checksum, nullptr);
+    else if (compress)
         r = zjni_compress_batch_device2(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                         (u64*)(d->dStage + oRes), n, level, checksum, nullptr);
     else
@@ -781,6 +899,16 @@ size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, 
 size_t zjni_compress2(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum) {
     size_t res = 0; const void* s = src; void* dd = dst;
     size_t const r = zjni_compress_batch2(&s, &srcSize, &dd, &dstCap, &res, 1, level, checksum);
+    return zjni_isError(r) ? r : res;
+}
+size_t zjni_compress_batch_usingCDict(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                      const zjni_cdict* cdict, int checksum) {
+    if (!cdict) return ZJNI_ERR(32);
+    return host_batch(true, src, srcSize, dst, dstCap, result, n, cdict->level, checksum, nullptr, cdict);
+}
+size_t zjni_compress_usingCDict(void* dst, size_t dstCap, const void* src, size_t srcSize, const zjni_cdict* cdict) {
+    size_t res = 0; const void* s = src; void* dd = dst;
+    size_t const r = zjni_compress_batch_usingCDict(&s, &srcSize, &dd, &dstCap, &res, 1, cdict, 0);
     return zjni_isError(r) ? r : res;
 }
 size_t zjni_decompress_batch_usingDDict(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
