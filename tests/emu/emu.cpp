@@ -105,7 +105,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     ze_match_lane(src, srcSize, level, table, fs, 65536u, meta);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(65536u) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
-    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags, nullptr, 160u * 1024u);
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }
@@ -147,7 +147,7 @@ extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned c
     if (srcSize <= ze_attach_cutoff(cd->strategy)) ze_match_lane_dict(src, srcSize, cd, table, fs, ZC_MAX_SRC, meta);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZC_MAX_SRC) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
-    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & 1u, cd);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & 1u, cd, 160u * 1024u);
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }

@@ -18,13 +18,22 @@ def read_prof():
     a = (C.c_ulonglong * 32)(); assert zj.lib().zjni_debug_read_profile(a) == 0; return list(a)
 ENC = ["params", "match(l0)", "lit gather+codes", "hist+huf decide", "huf encode", "seq tables", "seq encode", "block place"]
 U = 4096; rep = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-recs = []
-for i in range(U):
-    r = b"".join(json_records(40, seed=i, first=i * 40))[:4096]
-    recs.append(r + b" " * (4096 - len(r)))
-dic = ref.train_dict([x for i in range(0, U, 4) for x in json_records(40, seed=i, first=i * 40)], 112640)
 n = U * rep
-src = torch.from_numpy(np.tile(np.frombuffer(b"".join(recs), dtype=np.uint8), rep)).cuda()
+if os.environ.get("CD_TILED"):
+    # 4096 distinct records tiled (cache-friendly; the first measurements used this)
+    recs = []
+    for i in range(U):
+        r = b"".join(json_records(40, seed=i, first=i * 40))[:4096]
+        recs.append(r + b" " * (4096 - len(r)))
+    dic = ref.train_dict([x for i in range(0, U, 4) for x in json_records(40, seed=i, first=i * 40)], 112640)
+    src = torch.from_numpy(np.tile(np.frombuffer(b"".join(recs), dtype=np.uint8), rep)).cuda()
+else:
+    # n distinct records: the JSON class of the SURVEY 8(d) generator (index & 3 == 1) at 4 KiB
+    src = B.synth(4 * n, 4096, 0).view(4 * n, 4096)[1::4].contiguous().view(-1)
+    host = zj.synth_host(4096, 0, 4 * 3000)
+    samples = [host[(4 * i + 1) * 4096:(4 * i + 2) * 4096] for i in range(3000)]
+    dic = ref.train_dict(samples, 112640)
+    recs = [bytes(src[i * 4096:(i + 1) * 4096].cpu().numpy().tobytes()) for i in range(64)]
 off = B.uniform_offsets(n, 4096, "cuda")
 bound = zj.Zstd.compressBound(4096)
 dst = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); doff = B.uniform_offsets(n, bound, "cuda")

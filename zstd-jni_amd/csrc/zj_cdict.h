@@ -16,11 +16,6 @@
 #include "zj_decode.h"
 #include "zj_encode.h"
 
-#if !ZJ_ON_GPU
-static inline u32 atomicMax(u32* p, u32 v) { u32 const o = *p; if (v > o) *p = v; return o; }
-static inline u32 atomicCAS(u32* p, u32 cmp, u32 v) { u32 const o = *p; if (o == cmp) *p = v; return o; }
-#endif
-
 #define ZC_TAG_BITS 8u                       /* ZSTD_SHORT_CACHE_TAG_BITS (N/compress/zstd_compress_internal.h:1482) */
 
 // ZSTD_getCParams_internal(level, CONTENTSIZE_UNKNOWN, dictSize, ZSTD_cpm_createCDict) for levels 1..3

@@ -23,6 +23,8 @@
 
 #if !ZJ_ON_GPU
 static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build
+static inline u32 atomicMax(u32* p, u32 v) { u32 const o = *p; if (v > o) *p = v; return o; }
+static inline u32 atomicCAS(u32* p, u32 cmp, u32 v) { u32 const o = *p; if (o == cmp) *p = v; return o; }
 #endif
 
 #define ZE_BLOCK_MAX (1u << 17)
@@ -68,7 +70,16 @@ struct ZEncShared {                // uniforms, outside the overlay
     u32 seqType[3], seqHdr[3], seqLastCount;
     u32 tstate[3];                 // tANS encoder states LL, OF, ML carried across 64-sequence batches
     u32 tmp[8];
+    u32 edge[6];                   // LL/OF/ML codes of the first and of the last sequence
+    // dictionary state kept across the frames one workgroup encodes (the kernel clears dictLoaded / ctDict once)
+    u32 dictLoaded, dictID, dictStrategy, dictMinMatch, dictHufRep, dictHufMaxSV, dictFseRep[3];
+    u32 ctDict[3];                 // e.ct[t] currently holds the dictionary's table
+    u32 dictCodes[256];            // Huffman code | nbBits << 16 of the dictionary's literal table
 };
+#define ZE_SMALL_MAX 4096u         /* frames up to this size are staged, gathered and assembled in LDS when the launch provides it */
+#define ZE_ALIGN16(x) (((x) + 15u) & ~15u)
+#define ZE_ENTROPY_LDS ZE_ALIGN16((u32)sizeof(ZEEntropy))
+#define ZE_SMALL_LDS_BYTES (ZE_ENTROPY_LDS + 2u * ZE_SMALL_MAX + 1024u + 128u)
 
 // ------------------------------------------------------------------ constants ---------------
 #if ZJ_ON_GPU
@@ -797,24 +808,41 @@ template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
 template <class G, class TIdx>
-ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd) {
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd, u32 ldsBytes) {
     u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
-    u8* const litBuf = ws + ZE_WS_LIT;
+    // Small frames whose sequences are already found: the source is staged into LDS once, literals are gathered and the
+    // block body is assembled there, so the stage's many short dependent steps run at LDS latency, not HBM latency.
+    u32 const a16 = ZE_ALIGN16(srcSize);
+    bool const small = pre && srcSize <= ZE_SMALL_MAX && srcSize > 0 && ldsBytes >= ZE_ENTROPY_LDS + 2u * a16 + 1024u + 128u;
+    u8* const xl = lds + ZE_ENTROPY_LDS;
+    const u8* const src = small ? (const u8*)xl : src0;
+    u8* const litBuf = small ? xl + a16 + 1024u + 64u : ws + ZE_WS_LIT;   // [staged source, later the block body | 1 KiB slack][literals]
     ZESeq* const seqs = pre ? pre->seqs : (ZESeq*)(ws + ZE_WS_SEQ);
     ZEEntropy& e = *(ZEEntropy*)lds;
+    if (small) grp_copy_wide(g, xl, src0, srcSize);                // in flight while lane 0 writes the header
+    if (cd && !ZJ_UNI(sh.dictLoaded)) {                            // once per workgroup: what every frame needs from the dictionary
+        GRP_FOR(g, s, 256) sh.dictCodes[s] = (u32)cd->hufVal[s] | ((u32)cd->hufNbBits[s] << 16);
+        GRP_SERIAL(g) {
+            sh.dictID = cd->dictID; sh.dictStrategy = cd->strategy; sh.dictMinMatch = cd->minMatch; sh.dictHufRep = cd->hufRepeat; sh.dictHufMaxSV = cd->hufMaxSV;
+            sh.dictFseRep[0] = cd->llRepeat; sh.dictFseRep[1] = cd->ofRepeat; sh.dictFseRep[2] = cd->mlRepeat;
+        }
+        g.sync();
+        GRP_SERIAL(g) { sh.dictLoaded = 1; }
+    }
 
     // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1; dictID of the attached dictionary if it has one) ----
     GRP_SERIAL(g) {
         sh.err = 0;
-        if (cd) { sh.strategy = cd->strategy; sh.minMatch = cd->minMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
+        if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
         else ze_params(sh, level, srcSize);
-        u32 const dictID = cd ? cd->dictID : 0u;
+        if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
+        u32 const dictID = cd ? sh.dictID : 0u;
         u32 const didCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
         u32 const didBytes = didCode == 3 ? 4u : didCode;
         u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
         u32 const hdr = 5 + didBytes + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
         sh.hdrSize = hdr;
-        if (cd && (!pre || srcSize > (cd->strategy == 2 ? (16u << 10) : (8u << 10)))) sh.err = ZJ_E_PARAM_UNSUPPORTED;   // outside the attach range
+        if (cd && (!pre || srcSize > (sh.dictStrategy == 2 ? (16u << 10) : (8u << 10)))) sh.err = ZJ_E_PARAM_UNSUPPORTED;   // outside the attach range
         else if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {
             st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6) + (tail ? 4u : 0u) + didCode);
@@ -832,14 +860,12 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
     }
     bool compressed = false; u32 cSize = 0;
     // body goes straight into dst when even the raw fallback fits, else into HBM scratch first
-    bool const direct = dstCap >= hdr + 3 + srcSize + 64;
-    u8* const body = direct ? dst + hdr + 3 : ws + ZE_WS_BODY;
+    bool const direct = !small && dstCap >= hdr + 3 + srcSize + 64;
+    u8* const body = small ? xl : (direct ? dst + hdr + 3 : ws + ZE_WS_BODY);   // small: over the staged source, dead once the literals are gathered
     if (srcSize >= 7) {                                                       // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
         u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
-        if (pre) {
-            GRP_SERIAL(g) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
-        } else {
+        if (!pre) {
             u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
             {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
                 GRP_FOR(g, i, words) w[i] = 0; }
@@ -868,6 +894,8 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                 s.ml = s.ml | (ze_ml_code(s.ml - 3) << 24);
                 s.off = s.off | (zj_hibit(s.off) << 24);
                 seqs[i] = s;
+                if (i == 0) { sh.edge[0] = s.ll >> 24; sh.edge[1] = s.off >> 24; sh.edge[2] = s.ml >> 24; }
+                if (i == nbSeq - 1) { sh.edge[3] = s.ll >> 24; sh.edge[4] = s.off >> 24; sh.edge[5] = s.ml >> 24; }
             }
             zj_mem_order();
             g.sync();
@@ -890,7 +918,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         u32 const strat = strategy;
         {   u32 const n = litSize;
             u32 const lhSize = 3 + (n >= 1024) + (n >= 16384);
-            u32 const hufRep = cd ? cd->hufRepeat : ZC_REPEAT_NONE;           // the dictionary's Huffman table is "the previous block's"
+            u32 const hufRep = cd ? ZJ_UNI(sh.dictHufRep) : ZC_REPEAT_NONE;   // the dictionary's Huffman table is "the previous block's"
             bool const single = (n < 256) || (hufRep == ZC_REPEAT_VALID && lhSize == 3);
             bool const preferRepeat = n <= 1024;                              // HUF_flags_preferRepeat (strategy < lazy)
             u32 const seg = (n + 3) / 4;
@@ -917,32 +945,37 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                 else {
                     for (u32 t = 0; t < 4; t++) { u32 const cnt = t < 3 ? seg : n - 3 * seg; const u8* const lp = litBuf + t * seg; GRP_FOR(g, i, cnt) atomicAdd(&e.hist[t][lp[i]], 1u); }
                 }
+                GRP_SERIAL(g) { sh.tmp[6] = 0; sh.tmp[7] = 0; sh.strBytes[0] = 0; sh.strBytes[1] = 0; sh.strBytes[2] = 0; sh.strBytes[3] = 0; }
                 g.sync();
-                GRP_FOR(g, s, 256) e.count[s] = e.hist[0][s] + e.hist[1][s] + e.hist[2][s] + e.hist[3][s];
+                GRP_FOR(g, s, 256) {
+                    u32 const c = e.hist[0][s] + e.hist[1][s] + e.hist[2][s] + e.hist[3][s];
+                    e.count[s] = c;
+                    if (c) { atomicMax(&sh.tmp[6], s); atomicMax(&sh.tmp[7], c); }
+                }
                 g.sync();
-                GRP_SERIAL(g) {                                                // HUF_compress_internal (huf_compress.c:1333-1434) + ZSTD_compressLiterals' checks
-                    u32 maxSV = 255, largest = 0, m = 2, h = 0, rep = hufRep;
+                GRP_SERIAL(g) {                                                // HUF_compress_internal (huf_compress.c:1333-1434), decisions
+                    u32 const maxSV = sh.tmp[6], largest = sh.tmp[7];
+                    u32 m = 2, h = 0, rep = hufRep;
                     bool useOld = false;
-                    while (!e.count[maxSV]) maxSV--;
-                    for (u32 s = 0; s <= maxSV; s++) largest = zj_max(largest, e.count[s]);
                     if (preferRepeat && rep == ZC_REPEAT_VALID) useOld = true;    // valid table + small input: no statistics at all
                     else if (largest == n) m = 1;
                     else if (largest <= (n >> 7) + 4) m = 0;
                     else {
                         if (rep == ZC_REPEAT_CHECK) {                             // HUF_validateCTable
-                            if (cd->hufMaxSV < maxSV) rep = ZC_REPEAT_NONE;
-                            else for (u32 s = 0; s <= maxSV; s++) if (e.count[s] && !cd->hufNbBits[s]) { rep = ZC_REPEAT_NONE; break; }
+                            if (sh.dictHufMaxSV < maxSV) rep = ZC_REPEAT_NONE;
+                            else for (u32 s = 0; s <= maxSV; s++) if (e.count[s] && !(sh.dictCodes[s] >> 16)) { rep = ZC_REPEAT_NONE; break; }
                         }
                         if (preferRepeat && rep != ZC_REPEAT_NONE) useOld = true;
                         else {
                             u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
                             huffLog = ze_huf_build(e, maxSV, huffLog);
                             h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog);
+                            sh.ctDict[0] = 0;                                     // the weights' tANS table went through e.ct[0]
                             if (!h) m = 0;
                             else {
                                 if (rep != ZC_REPEAT_NONE) {                      // is the dictionary's table at least as good?
                                     u32 oldBits = 0, newBits = 0;
-                                    for (u32 s = 0; s <= maxSV; s++) { oldBits += e.count[s] * cd->hufNbBits[s]; newBits += e.count[s] * e.nbBits[s]; }
+                                    for (u32 s = 0; s <= maxSV; s++) { oldBits += e.count[s] * (sh.dictCodes[s] >> 16); newBits += e.count[s] * e.nbBits[s]; }
                                     if ((oldBits >> 3) <= h + (newBits >> 3) || h + 12 >= n) useOld = true;
                                 }
                                 if (!useOld && h + 12 >= n) m = 0;
@@ -950,12 +983,24 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                         }
                     }
                     if (useOld) { m = 3; h = 0; }
+                    sh.litMode = m; sh.hufHdr = h;
+                }
+                g.sync();
+                mode = ZJ_UNI(sh.litMode);
+                if (mode >= 2) {                                               // exact bits of every stream under the chosen table (all lanes)
+                    u32 const streams = single ? 1u : 4u;
+                    GRP_FOR(g, s, 256) {
+                        u32 const nb = mode == 3 ? (sh.dictCodes[s] >> 16) : (u32)e.nbBits[s];
+                        for (u32 t = 0; t < streams; t++) { u32 const c = e.hist[t][s]; if (c) atomicAdd(&sh.strBytes[t], c * nb); }
+                    }
+                    g.sync();
+                }
+                GRP_SERIAL(g) {                                                // sizes + ZSTD_compressLiterals' checks
+                    u32 m = sh.litMode; u32 const h = sh.hufHdr, largest = sh.tmp[7];
                     if (m >= 2) {
                         u32 total = h + (single ? 0 : 6); bool tooBig = false;
                         for (u32 t = 0; t < (single ? 1u : 4u); t++) {
-                            u32 bits = 0;
-                            if (useOld) { for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * cd->hufNbBits[s]; }
-                            else { for (u32 s = 0; s <= maxSV; s++) bits += e.hist[t][s] * e.nbBits[s]; }
+                            u32 const bits = sh.strBytes[t];
                             u32 const bytes = (bits + 1 + 7) >> 3;
                             sh.strBytes[t] = bytes; sh.strOff[t] = total; total += bytes;
                             if (bytes > 65535) tooBig = true;
@@ -981,7 +1026,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             if (mode >= 2) {
                 u32 const streams = single ? 1u : 4u;
                 u32* const codes = e.count;                                    // histogram is dead: code | nbBits << 16 per symbol
-                if (mode == 3) { GRP_FOR(g, s, 256) codes[s] = (u32)cd->hufVal[s] | ((u32)cd->hufNbBits[s] << 16); }
+                if (mode == 3) { GRP_FOR(g, s, 256) codes[s] = sh.dictCodes[s]; }
                 else { GRP_FOR(g, s, 256) codes[s] = (u32)e.val[s] | ((u32)e.nbBits[s] << 16); }
                 g.sync();
                 for (u32 t = 0; t < streams; t++) {
@@ -1018,19 +1063,21 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
             if (pos + (nbSeq ? 2u : 0u) >= maxCSize) ok = false;                // cannot win any more (a sequences section is >= 2 bytes): raw block
             if (ok && nbSeq) {
                 u32 const seqHead = pos; pos += 1;
+                u32* const cnt3 = &e.hist[0][0];                              // three code histograms from one pass over the records
+                GRP_FOR(g, s, 192) cnt3[s] = 0;
+                g.sync();
+                GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; atomicAdd(&cnt3[s.ll >> 24], 1u); atomicAdd(&cnt3[64 + (s.off >> 24)], 1u); atomicAdd(&cnt3[128 + (s.ml >> 24)], 1u); }
+                g.sync();
                 for (u32 t = 0; t < 3; t++) {                                 // LL, OF, ML in stream order
-                    GRP_FOR(g, s, 64) e.scount[s] = 0;
-                    g.sync();
-                    GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; u32 const code = (t == 0 ? s.ll : (t == 1 ? s.off : s.ml)) >> 24; atomicAdd(&e.scount[code], 1u); }
-                    g.sync();
                     GRP_SERIAL(g) {
+                        u32* const scount = cnt3 + 64 * t;
                         u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;
                         const short* const defNorm = t == 0 ? ze_k_ll_defnorm : (t == 1 ? ze_k_of_defnorm : ze_k_ml_defnorm);
                         u32 const defMax = t == 0 ? 35u : (t == 1 ? 28u : 52u);
                         u32 max = 0, most = 0;
-                        for (u32 s = 0; s <= maxSym; s++) { if (e.scount[s]) max = s; most = zj_max(most, e.scount[s]); }
+                        for (u32 s = 0; s <= maxSym; s++) { if (scount[s]) max = s; most = zj_max(most, scount[s]); }
                         bool const defaultAllowed = (t != 1) || (max <= 28);
-                        u32 const fseRep = cd ? (t == 0 ? cd->llRepeat : (t == 1 ? cd->ofRepeat : cd->mlRepeat)) : ZC_REPEAT_NONE;
+                        u32 const fseRep = cd ? sh.dictFseRep[t] : ZC_REPEAT_NONE;
                         u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
                         if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
                         else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
@@ -1039,25 +1086,26 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                             type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
                         }
                         u32 h = 0;
-                        u32 const lastCode = (t == 0 ? seqs[nbSeq - 1].ll : (t == 1 ? seqs[nbSeq - 1].off : seqs[nbSeq - 1].ml)) >> 24;
-                        u32 const firstCode = (t == 0 ? seqs[0].ll : (t == 1 ? seqs[0].off : seqs[0].ml)) >> 24;
+                        u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];
                         if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1; }
                         else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, e.cumul, e.tableSymbol);
                         else if (type == 3) h = 0;                             // table copied below by the whole wave
                         else {
                             u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
-                            if (e.scount[lastCode] > 1) { e.scount[lastCode]--; nbSeq1--; }
-                            ze_fse_normalize(e.norm, tableLog, e.scount, nbSeq1, max, nbSeq1 >= 2048);
+                            if (scount[lastCode] > 1) { scount[lastCode]--; nbSeq1--; }
+                            ze_fse_normalize(e.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048);
                             h = ze_fse_write_ncount(body + pos, e.norm, max, tableLog);
                             ze_fse_build_ctable(e.ct[t], e.norm, max, tableLog, e.cumul, e.tableSymbol);
                             sh.seqLastCount = h;
                         }
                         sh.seqType[t] = type; sh.seqHdr[t] = h;
+                        sh.tmp[3] = (type == 3 && !sh.ctDict[t]) ? 1u : 0u;    // e.ct[t] has to be (re)loaded from the dictionary
+                        sh.ctDict[t] = (type == 3) ? 1u : 0u;
                         if (t == 0) sh.seqLastCount = (type == 2) ? h : 0;
                         else if (type == 2) sh.seqLastCount = h;
                     }
                     g.sync();
-                    if (ZJ_UNI(sh.seqType[t]) == 3) {
+                    if (ZJ_UNI(sh.tmp[3])) {
                         const u32* const from = (const u32*)&cd->fse[t]; u32* const to = (u32*)&e.ct[t];
                         GRP_FOR(g, i, (u32)(sizeof(ZEFseCT) / 4)) to[i] = from[i];
                         g.sync();
@@ -1101,6 +1149,26 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
                             state = (nbBitsOut << 16) - d;
                             state = ct.state[(i32)(state >> nbBitsOut) + df[64 * t + k]];
                             ob[64 * t + k] = 0;
+                        }
+                        while (k >= 8) {                           // 8 steps per block: the symbols' transforms are fetched together,
+                            u32 dnr[8]; i32 dfr[8]; u32 obr[8];     // so a step waits for one dependent LDS read (the state table), not four
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+                            for (u32 j = 0; j < 8; j++) { dnr[j] = dn[64 * t + k - 1 - j]; dfr[j] = df[64 * t + k - 1 - j]; }
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+                            for (u32 j = 0; j < 8; j++) {
+                                u32 const nbBitsOut = (state + dnr[j]) >> 16;
+                                obr[j] = (state & ((1u << nbBitsOut) - 1)) | (nbBitsOut << 16);
+                                state = ct.state[(i32)(state >> nbBitsOut) + dfr[j]];
+                            }
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+                            for (u32 j = 0; j < 8; j++) ob[64 * t + k - 1 - j] = obr[j];
+                            k -= 8;
                         }
                         while (k-- > 0) {
                             u32 const nbBitsOut = (state + dn[64 * t + k]) >> 16;
@@ -1175,11 +1243,11 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32
         if (!direct) grp_copy_wide(g, dst + hdr + 3, body, cSize);
         GRP_SERIAL(g) { u32 const bh = 1 + (2u << 1) + (cSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
     } else {
-        grp_copy_wide(g, dst + hdr + 3, src, srcSize);
+        grp_copy_wide(g, dst + hdr + 3, src0, srcSize);
         GRP_SERIAL(g) { u32 const bh = 1 + (srcSize << 3); dst[hdr] = (u8)bh; dst[hdr + 1] = (u8)(bh >> 8); dst[hdr + 2] = (u8)(bh >> 16); }
     }
     if (tail) {
-        u64 const h = zj_xxh64(g, src, srcSize);
+        u64 const h = zj_xxh64(g, src0, srcSize);
         GRP_SERIAL(g) { st32(dst + hdr + 3 + bodySize, (u32)h); }
     }
     return hdr + 3 + bodySize + tail;
@@ -1204,9 +1272,9 @@ ZJ_HD u32 ze_lds_need(u32 level, u32 srcSize) {
 
 template <class G>
 ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre = nullptr, u32 flags = 0,
-                       const ZECDictDev* cd = nullptr) {
-    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd);
-    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd);
+                       const ZECDictDev* cd = nullptr, u32 ldsBytes = 0) {
+    if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd, ldsBytes);
+    return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd, ldsBytes);
 }
 
 // Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.

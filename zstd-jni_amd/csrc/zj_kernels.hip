@@ -199,13 +199,15 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
                                                         u8* fscratch, u32 maxSrc, const u32* meta,
-                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags, const ZECDictDev* cd) {
+                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags, const ZECDictDev* cd, u32 ldsBytes) {
     // mode 0: list entry k.  mode 1: k-th entry of the completion queue the match kernel fills while this kernel
     // runs (bounded wait; a workgroup that gives up leaves its frame to the mode-2 pass).  mode 2: list entries
     // mode 1 did not finish.
     __shared__ ZEncShared sh;
     ZjProf pf; pf.start(prof);
     Grp<64> g;
+    if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
+    __syncthreads();
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
     u32 const count = ZJ_UNI(*countPtr);
     for (;;) {
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
             pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta + 3 * (size_t)k;
             prePtr = &pre;
         }
-        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr, flags, cd);
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, prePtr, flags, cd, ldsBytes);
         pf.mark(7);
         if (threadIdx.x == 0) { result[i] = r; if (mode == 1) procFlag[k] = 1u; }
         __syncthreads();
@@ -305,6 +307,7 @@ struct DevState {
     int decGrid = 0, decDictGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
     int encGridLvl[4] = {0, 0, 0, 0};     // resident workgroups per level for pass 0
     int encGridBig = 0;                    // pass 1 (128 KiB LDS)
+    int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
     u8* decScratch = nullptr;
     u8* encScratch = nullptr;
@@ -361,6 +364,8 @@ DevState* get_state(int ordinal) {
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZJ_ENC_LDS_BIG) != hipSuccess || perCU < 1) perCU = 1;
         d.encGridBig = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZE_SMALL_LDS_BYTES) != hipSuccess || perCU < 1) perCU = 1;
+        d.encGridSmall = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_enc_match_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
         d.matchGrid = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_seq_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
@@ -700,11 +705,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr);
+                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr);
+                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
         } else {
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
@@ -712,19 +717,19 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
+                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
+                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsA));
     }
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr);
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ZJ_ENC_LDS_BIG));
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -814,10 +819,10 @@ static size_t compress_cdict_device_impl(const void* d_src, const uint64_t* d_sr
     hipLaunchKernelGGL(zj_enc_match_dict_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, cd,
                        (const u32*)listA, (const u32*)ctr, mctr, tables, fscratch, meta);
     (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
-    u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+    u32 const gridA = (u32)(n < (size_t)d->encGridSmall ? n : (size_t)d->encGridSmall);
+    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ZE_SMALL_LDS_BYTES, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)cdict->level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd);
+                       fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd, (u32)ZE_SMALL_LDS_BYTES);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
