@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string */
+typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
 static Obj* mk(int kind, jsize len) { Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = kind; o->len = len; o->data = (char*)calloc((size_t)len + 16, kind == 4 ? 8 : 1); return o; }
 
 static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b ? ((Obj*)b)->data : NULL; }
@@ -23,6 +23,10 @@ static void JNICALL f_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize
 static void JNICALL f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* buf) { (void)e; memcpy(((Obj*)a)->data + s, buf, (size_t)l); }
 static jobject JNICALL f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (void)e; return (jobject)((Obj*)a)->elems[i]; }
 static void JNICALL f_SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const jlong* buf) { (void)e; memcpy(((Obj*)a)->data + 8 * (size_t)s, buf, 8 * (size_t)l); }
+static jclass JNICALL f_GetObjectClass(JNIEnv* e, jobject o) { (void)e; return (jclass)o; }
+static jfieldID JNICALL f_GetFieldID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)sig; return strcmp(n, "nativePtr") ? NULL : (jfieldID)(intptr_t)1; }
+static jlong JNICALL f_GetLongField(JNIEnv* e, jobject o, jfieldID f) { (void)e; (void)f; return ((Obj*)o)->field; }
+static void JNICALL f_SetLongField(JNIEnv* e, jobject o, jfieldID f, jlong v) { (void)e; (void)f; ((Obj*)o)->field = v; }
 static jstring JNICALL f_NewStringUTF(JNIEnv* e, const char* s) { (void)e; Obj* o = mk(5, (jsize)strlen(s) + 1); strcpy(o->data, s); return (jstring)o; }
 
 static struct JNINativeInterface_ g_fn;
@@ -33,6 +37,7 @@ static JNIEnv* env(void) {
     g_fn.ReleasePrimitiveArrayCritical = f_ReleasePrimitiveArrayCritical; g_fn.GetByteArrayRegion = f_GetByteArrayRegion;
     g_fn.SetByteArrayRegion = f_SetByteArrayRegion; g_fn.GetObjectArrayElement = f_GetObjectArrayElement;
     g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
+    g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField;
     return (JNIEnv*)&g_envp;
 }
 
@@ -52,6 +57,9 @@ typedef struct {
     jint (*setHashLog)(JNIEnv*, jclass, jlong, jint); jint (*setChainLog)(JNIEnv*, jclass, jlong, jint);     /* reference only */
     jlong (*cBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jint, jboolean);                 /* shim only */
     jlong (*dBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray);
+    void (*dictInit)(JNIEnv*, jobject, jbyteArray, jint, jint, jint); void (*dictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint, jint);
+    void (*dictFree)(JNIEnv*, jobject); jlong (*loadCDict)(JNIEnv*, jclass, jlong, jobject);
+    jlong (*cBatchDict)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jobject, jboolean);                /* shim only */
 } Lib;
 #define P "Java_com_github_luben_zstd_"
 static int load(Lib* L, const char* path, int isRef) {
@@ -66,10 +74,13 @@ static int load(Lib* L, const char* path, int isRef) {
     S(cUnsafe, "Zstd_compressUnsafe"); S(dUnsafe, "Zstd_decompressUnsafe");
     S(setHashLog, "Zstd_setCompressionHashLog"); S(setChainLog, "Zstd_setCompressionChainLog");
     S(cBatch, "Zstd_compressBatch0"); S(dBatch, "Zstd_decompressBatch0");
+    S(dictInit, "ZstdDictCompress_init"); S(dictInitDirect, "ZstdDictCompress_initDirect"); S(dictFree, "ZstdDictCompress_free");
+    S(loadCDict, "ZstdCompressCtx_loadCDictFast0"); S(cBatchDict, "Zstd_compressBatchDict0");
 #undef S
     if (!L->cinit || !L->cDirect || !L->cArray || !L->dDirect || !L->dArray || !L->bound || !L->errName || !L->cUnsafe) { printf("%s: hot-path natives missing\n", path); return 0; }
     if (isRef && (!L->setHashLog || !L->setChainLog)) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
-    if (!isRef && (!L->cBatch || !L->dBatch)) { printf("%s: batch natives missing\n", path); return 0; }
+    if (!isRef && (!L->cBatch || !L->dBatch || !L->cBatchDict)) { printf("%s: batch natives missing\n", path); return 0; }
+    if (!L->dictInit || !L->dictInitDirect || !L->dictFree || !L->loadCDict) { printf("%s: ZstdDictCompress natives missing\n", path); return 0; }
     return 1;
 }
 
@@ -157,6 +168,44 @@ int main(int argc, char** argv) {
             CHECK(R.dArray(e, NULL, rd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20) == G.dArray(e, NULL, gd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20), "decompress array src range");
         }
         R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+    }
+    /* ZstdDictCompress + ZstdCompressCtx.loadDict (N/jni_fast_zstd.c:13-66, :325-336): a raw-content dictionary, sources inside the
+     * attach range, byte[] and direct-buffer constructors */
+    for (int level = 1; level <= maxLevel; level++) for (int direct = 0; direct < 2; direct++) {
+        jsize const dlen = 20000; jsize const srcSizes[] = {0, 100, 1000, 4096, 8000};
+        Obj* darr = mk(direct ? 1 : 2, dlen + 11); Obj* robj = mk(6, 0); Obj* gobj = mk(6, 0);
+        jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
+        fill(darr->data + 11, dlen, 0);
+        if (direct) { R.dictInitDirect(e, robj, darr, 11, dlen, level, 0); G.dictInitDirect(e, gobj, darr, 11, dlen, level, 0); }
+        else { R.dictInit(e, robj, (jbyteArray)darr, 11, dlen, level); G.dictInit(e, gobj, (jbyteArray)darr, 11, dlen, level); }
+        CHECK(robj->field != 0 && gobj->field != 0, "ZstdDictCompress init L%d direct=%d", level, direct);
+        CHECK(R.loadCDict(e, NULL, rc, robj) == G.loadCDict(e, NULL, gc, gobj), "loadCDictFast0 L%d", level);
+        for (unsigned si = 0; si < sizeof srcSizes / sizeof *srcSizes; si++) for (int kind = 1; kind <= 2; kind++) {
+            jsize const n = srcSizes[si], cap = (jsize)R.bound(e, NULL, n) + 16;
+            Obj* src = mk(kind, n + 4); Obj* rdst = mk(kind, cap); Obj* gdst = mk(kind, cap);
+            fill(src->data + 2, n, 0);
+            jlong const rr = kind == 1 ? R.cDirect(e, NULL, rc, rdst, 3, cap - 3, src, 2, n) : R.cArray(e, NULL, rc, (jbyteArray)rdst, 3, cap - 3, (jbyteArray)src, 2, n);
+            jlong const gr = kind == 1 ? G.cDirect(e, NULL, gc, gdst, 3, cap - 3, src, 2, n) : G.cArray(e, NULL, gc, (jbyteArray)gdst, 3, cap - 3, (jbyteArray)src, 2, n);
+            CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr + 3), "dict compress L%d direct=%d n=%d kind=%d: ref %lld gpu %lld", level, direct, n, kind, (long long)rr, (long long)gr);
+        }
+        CHECK(R.loadCDict(e, NULL, rc, NULL) == G.loadCDict(e, NULL, gc, NULL), "loadCDictFast0(null)");
+        {   Obj* src = mk(1, 3000); Obj* rdst = mk(1, 4000); Obj* gdst = mk(1, 4000); fill(src->data, 3000, 0);
+            R.setLevel(e, NULL, rc, 1); G.setLevel(e, NULL, gc, 1);
+            jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, 4000, src, 0, 3000), gr = G.cDirect(e, NULL, gc, gdst, 0, 4000, src, 0, 3000);
+            CHECK(rr == gr && !memcmp(rdst->data, gdst->data, (size_t)rr), "compress after the dictionary was removed"); }
+        if (!getenv("HARNESS_SKIP_BATCH")) {                      /* the dictionary batch native == the reference's per-buffer native */
+            enum { ND = 100 }; Obj* srcs = mk(3, ND); Obj* dsts = mk(3, ND); Obj* res = mk(4, ND);
+            srcs->elems = (Obj**)calloc(ND, sizeof(Obj*)); dsts->elems = (Obj**)calloc(ND, sizeof(Obj*));
+            for (int i = 0; i < ND; i++) { jsize const n = (jsize)(rnd() % 8000); srcs->elems[i] = mk(1, n); fill(srcs->elems[i]->data, n, i % 3 == 2 ? 1 : 0); dsts->elems[i] = mk(1, (jsize)R.bound(e, NULL, n)); }
+            CHECK(G.cBatchDict(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, gobj, JNI_FALSE) == 0, "compressBatchDict0");
+            R.loadCDict(e, NULL, rc, robj);
+            for (int i = 0; i < ND; i++) {
+                Obj* one = mk(1, dsts->elems[i]->len);
+                jlong const rr = R.cDirect(e, NULL, rc, one, 0, one->len, srcs->elems[i], 0, srcs->elems[i]->len);
+                CHECK(rr == ((jlong*)res->data)[i] && !memcmp(one->data, dsts->elems[i]->data, (size_t)rr), "dict batch buffer %d L%d: ref %lld gpu %lld", i, level, (long long)rr, (long long)((jlong*)res->data)[i]);
+            }
+        }
+        R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dictFree(e, robj); G.dictFree(e, gobj);
     }
     /* Zstd.compressUnsafe / decompressUnsafe (levels 1-2: the reference cannot be given the level-3 table sizes here) */
     for (int level = 1; level <= 2; level++) for (int ck = 0; ck < 2; ck++) {

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "../../include/zjni_amd.h"
 
 #define E_DST ((jlong)-70)   /* -ZSTD_error_dstSize_tooSmall */
@@ -56,7 +57,8 @@ static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error
 }
 
 /* ---- contexts: what ZstdCompressCtx / ZstdDecompressCtx keep in nativePtr ---------------------------- */
-typedef struct { int level; int checksum; jlong cpu; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent */
+typedef struct { int level; int checksum; jlong cpu; zjni_cdict* gdict; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent;
+                                                                                       gdict = the GPU digest of the loaded ZstdDictCompress */
 typedef struct { jlong cpu; } ZDCtx;
 
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* env, jclass cls) {
@@ -101,9 +103,102 @@ JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_free(JNIEnv*
     free(c);
 }
 
+/* ---- ZstdDictCompress (N/jni_fast_zstd.c:13-66) -------------------------------------------------------
+ * The Java object keeps ONE long (nativePtr), and the bundled library's natives read it as their own ZSTD_CDict*.
+ * So nativePtr stays what the bundled library put there (when it is present), and the GPU digest of the same
+ * dictionary lives in a side table keyed by that value; without the bundled library nativePtr is the table key
+ * itself (a private handle). */
+typedef struct { jlong key; zjni_cdict* gpu; int level; } DictEnt;
+#define DICT_MAX 4096
+static DictEnt g_dicts[DICT_MAX];
+static pthread_mutex_t g_dict_mu = PTHREAD_MUTEX_INITIALIZER;
+static jfieldID g_cdict_field;
+static void dict_put(jlong key, zjni_cdict* gpu, int level) {
+    pthread_mutex_lock(&g_dict_mu);
+    for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; g_dicts[i].level = level; break; }
+    pthread_mutex_unlock(&g_dict_mu);
+}
+static zjni_cdict* dict_get(jlong key, int remove) {
+    zjni_cdict* r = NULL;
+    pthread_mutex_lock(&g_dict_mu);
+    for (int i = 0; i < DICT_MAX; i++) if (g_dicts[i].key == key && key) { r = g_dicts[i].gpu; if (remove) { g_dicts[i].key = 0; g_dicts[i].gpu = NULL; } break; }
+    pthread_mutex_unlock(&g_dict_mu);
+    return r;
+}
+static void dict_register(JNIEnv* env, jobject obj, const void* bytes, size_t size, jint level) {
+    jlong key = (*env)->GetLongField(env, obj, g_cdict_field);          /* the bundled library's ZSTD_CDict*, if it made one */
+    zjni_cdict* gpu = (gpu_on() && level >= 1 && level <= 3) ? zjni_createCDict(bytes, size, level) : NULL;
+    if (!key) {                                                         /* no bundled library: the handle is ours */
+        if (!gpu) return;                                               /* nativePtr stays 0: "ZSTD_createCDict failed" on the Java side */
+        key = (jlong)(intptr_t)gpu;
+        (*env)->SetLongField(env, obj, g_cdict_field, key);
+    }
+    if (gpu) dict_put(key, gpu, level);
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_init
+  (JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size, jint level) {
+    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_init");
+    jclass clazz = (*env)->GetObjectClass(env, obj);
+    g_cdict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+    if (NULL == dict) return;
+    if (f) f(env, obj, dict, dict_offset, dict_size, level);
+    if (dict_size >= 0) {
+        jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
+        if (!copy) return;
+        (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
+        dict_register(env, obj, copy, (size_t)dict_size, level);
+        free(copy);
+    }
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_initDirect
+  (JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint level, jint byReference) {
+    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_initDirect");
+    jclass clazz = (*env)->GetObjectClass(env, obj);
+    g_cdict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+    if (NULL == dict) return;
+    if (f) f(env, obj, dict, dict_offset, dict_size, level, byReference);
+    {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
+        if (p && dict_size >= 0) dict_register(env, obj, p + dict_offset, (size_t)dict_size, level); }   /* the device keeps its own copy either way */
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_free(JNIEnv* env, jobject obj) {
+    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_free");
+    if (g_cdict_field) {
+        jlong const key = (*env)->GetLongField(env, obj, g_cdict_field);
+        zjni_cdict* gpu = dict_get(key, 1);
+        if (gpu) zjni_freeCDict(gpu);
+    }
+    if (f) f(env, obj);
+}
+/* ZstdCompressCtx.loadDict(ZstdDictCompress) -> ZSTD_CCtx_refCDict (N/jni_fast_zstd.c:325-336) */
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_loadCDictFast0(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
+    ZCtx* c = (ZCtx*)(intptr_t)ptr;
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_loadCDictFast0");
+    jlong r = 0;
+    c->gdict = NULL;
+    if (dict != NULL) {
+        jlong const key = g_cdict_field ? (*env)->GetLongField(env, dict, g_cdict_field) : 0;
+        if (!key) return -32;                                           /* -ZSTD_error_dictionary_wrong */
+        c->gdict = dict_get(key, 0);
+    }
+    if (f && c->cpu) r = f(env, cls, c->cpu, dict);
+    return r;
+}
+
 /* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
 static int gpu_takes(const ZCtx* c, jint srcSize) {
+    if (c->gdict) return per_buffer_on_gpu();                           /* sizes beyond the attach range come back as 40 and are forwarded */
     return per_buffer_on_gpu() && c->level >= 1 && c->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
+}
+static size_t gpu_compress(const ZCtx* c, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    if (c->gdict) {
+        size_t res = 0; const void* s = src; void* d = dst;
+        size_t const r = zjni_compress_batch_usingCDict(&s, &srcSize, &d, &dstCap, &res, 1, c->gdict, c->checksum);
+        return zjni_isError(r) ? r : res;
+    }
+    return zjni_compress2(dst, dstCap, src, srcSize, c->level, c->checksum);
+}
+static int gpu_compress_final(const ZCtx* c, size_t r) {   /* with a dictionary, "outside the attach range" (40) means: not for the GPU path */
+    return gpu_result_final(r) && !(c->gdict && zjni_isError(r) && zjni_getErrorCode(r) == 40 && c->cpu);
 }
 typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
 
@@ -121,8 +216,8 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressDirec
         char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
         if (d == NULL || s == NULL) return E_MEM;
         if (gpu_takes(c, src_size)) {
-            size_t const r = zjni_compress2(d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size, c->level, c->checksum);
-            if (gpu_result_final(r)) return (jlong)r;
+            size_t const r = gpu_compress(c, d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
+            if (gpu_compress_final(c, r)) return (jlong)r;
         }
     }
     {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressDirectByteBuffer0");
@@ -144,11 +239,11 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressByteA
         size_t r = (size_t)E_MEM;
         if (s && d) {
             (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
-            r = zjni_compress2(d, (size_t)dst_size, s, (size_t)src_size, c->level, c->checksum);
+            r = gpu_compress(c, d, (size_t)dst_size, s, (size_t)src_size);
             if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
         }
         free(s); free(d);
-        if (gpu_result_final(r)) return (jlong)r;
+        if (gpu_compress_final(c, r)) return (jlong)r;
     }
     {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressByteArray0");
         if (f && c->cpu) return f(env, cls, c->cpu, dst, dst_offset, dst_size, src, src_offset, src_size);
@@ -247,7 +342,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressUnsafe
  * static native long decompressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results);
  * Each buffer is taken from position 0 to its capacity.  results[i] = size or the error code compress*0 /
  * decompress*0 would have returned for that buffer; the return value is 0 or a launch-level error. */
-static jlong batch(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, jlongArray results, int compress, int level, int checksum) {
+static jlong batch(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, jlongArray results, int compress, int level, int checksum, const zjni_cdict* cdict) {
     jsize const n = (*env)->GetArrayLength(env, srcs);
     const void** sp; void** dp; size_t* ss; size_t* dc; size_t* res; jlong* out; size_t r; jsize i;
     if ((*env)->GetArrayLength(env, dsts) != n || (*env)->GetArrayLength(env, results) < n) return E_SRC;
@@ -261,7 +356,8 @@ static jlong batch(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, jlongArray
         sp[i] = (*env)->GetDirectBufferAddress(env, s); ss[i] = (size_t)(*env)->GetDirectBufferCapacity(env, s);
         dp[i] = (*env)->GetDirectBufferAddress(env, d); dc[i] = (size_t)(*env)->GetDirectBufferCapacity(env, d);
     }
-    r = compress ? zjni_compress_batch2(sp, ss, dp, dc, res, (size_t)n, level, checksum) : zjni_decompress_batch(sp, ss, dp, dc, res, (size_t)n);
+    r = cdict ? zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, (size_t)n, cdict, checksum)
+      : compress ? zjni_compress_batch2(sp, ss, dp, dc, res, (size_t)n, level, checksum) : zjni_decompress_batch(sp, ss, dp, dc, res, (size_t)n);
     if (!zjni_isError(r)) { for (i = 0; i < n; i++) out[i] = (jlong)res[i]; (*env)->SetLongArrayRegion(env, results, 0, n, out); }
     free(sp); free(dp); free(ss); free(dc); free(res); free(out);
     return (jlong)r;
@@ -270,11 +366,22 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatch0
   (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jint level, jboolean checksum) {
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
-    return batch(env, srcs, dsts, results, 1, level, checksum == JNI_TRUE);
+    return batch(env, srcs, dsts, results, 1, level, checksum == JNI_TRUE, NULL);
 }
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressBatch0
   (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results) {
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
-    return batch(env, srcs, dsts, results, 0, 0, 0);
+    return batch(env, srcs, dsts, results, 0, 0, 0, NULL);
+}
+/* static native long compressBatchDict0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, ZstdDictCompress dict, boolean checksum); */
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatchDict0
+  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jobject dict, jboolean checksum) {
+    zjni_cdict* g;
+    (void)cls;
+    if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
+    if (dict == NULL || !g_cdict_field) return -32;
+    g = dict_get((*env)->GetLongField(env, dict, g_cdict_field), 0);
+    if (!g) return -32;
+    return batch(env, srcs, dsts, results, 1, 0, checksum == JNI_TRUE, g);
 }
