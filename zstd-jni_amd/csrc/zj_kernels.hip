@@ -274,6 +274,24 @@ __global__ __launch_bounds__(64) void zj_enc_match_dict_kernel(const u8* __restr
     }
 }
 
+// Clears exactly the part of each frame's table slot its attach-mode parameters use (24 KiB for a 4 KiB record, not the
+// 96 KiB slot): one workgroup per list entry, 16 bytes per lane per step.
+__global__ __launch_bounds__(256) void zj_cdict_zero_tables_kernel(const u64* __restrict__ srcOff, const ZECDictDev* __restrict__ cd,
+                                                                   const u32* __restrict__ list, const u32* countPtr, u8* tables) {
+    u32 const count = *countPtr;
+    ZEParams cdp; cdp.windowLog = cd->windowLog; cdp.chainLog = cd->chainLog; cdp.hashLog = cd->hashLog; cdp.minMatch = cd->minMatch; cdp.strategy = cd->strategy;
+    u32 const cutoff = ze_attach_cutoff(cdp.strategy);
+    for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+        u32 const i = list[k];
+        u64 const size = srcOff[i + 1] - srcOff[i];
+        if (size < 7 || size > cutoff) continue;
+        ZEParams const p = ze_attach_params(cdp, (u32)size);
+        u32 const bytes = ((1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u)) * 2u;
+        uint4* const w = (uint4*)(tables + (size_t)k * ZC_TABLE_STRIDE);
+        for (u32 j = threadIdx.x; j < bytes / 16u; j += 256) w[j] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 __global__ void zj_synth_kernel(u8* dst, u32 bufSize, u64 firstIndex, u32 n) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) zs_fill(dst + (size_t)i * bufSize, bufSize, firstIndex + i);
@@ -308,6 +326,10 @@ struct DevState {
     int encGridLvl[4] = {0, 0, 0, 0};     // resident workgroups per level for pass 0
     int encGridBig = 0;                    // pass 1 (128 KiB LDS)
     int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
+    // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
+    u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
+    u32* cdList = nullptr; size_t cdListCap = 0;
+    hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
     u8* decScratch = nullptr;
     u8* encScratch = nullptr;
@@ -378,6 +400,7 @@ DevState* get_state(int ordinal) {
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
+        for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
         if (getenv("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
@@ -785,57 +808,65 @@ unsigned zjni_getDictID_fromCDict(const zjni_cdict* cd) { return cd ? cd->dictID
 
 // ZstdCompressCtx.loadDict(ZstdDictCompress) + compress, batched: lane-per-frame attach-mode search, then the
 // wave-per-frame entropy stage starting from the dictionary's tables.
-static size_t compress_cdict_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
-                                         uint64_t* d_result, size_t n, const zjni_cdict* cdict, u32 flags, void* stream) {
-    DevState* d = cur_state();
-    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    if (n == 0) return 0;
-    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
-    hipStream_t st = (hipStream_t)stream;
-    if (d->encListCap < n) {
-        if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
-        size_t const cap = n + (n >> 2) + 1024;
-        if (hipMalloc(&d->encList, 2 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
-        d->encListCap = cap;
-    }
-    u32* const ctr = d->counters + 16; u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap;
-    u32* const mctr = d->counters + 24;
-    size_t const tablesBytes = n * (size_t)ZC_TABLE_STRIDE, fsBytes = n * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = n * 12;
-    size_t const need = tablesBytes + fsBytes + metaBytes + 256;
-    if (d->splitBufCap < need) {
-        if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
-        if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
-        d->splitBufCap = need;
-    }
-    u8* const tables = d->splitBuf; u8* const fscratch = d->splitBuf + tablesBytes; u32* const meta = (u32*)(fscratch + fsBytes);
-    const ZECDictDev* const cd = (const ZECDictDev*)cdict->buf;
-    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess || hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
-                       (u32)n, 1u, 0xFFFFFFFFu, ctr, listA, listB);                     // every frame <= 128 KiB goes to list A
-    u32 const waves = (u32)((n + 63) / 64);
-    u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
-    (void)hipEventRecord(d->tev[0], st);
-    hipLaunchKernelGGL(zj_enc_match_dict_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, cd,
-                       (const u32*)listA, (const u32*)ctr, mctr, tables, fscratch, meta);
-    (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
-    u32 const gridA = (u32)(n < (size_t)d->encGridSmall ? n : (size_t)d->encGridSmall);
-    hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ZE_SMALL_LDS_BYTES, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)cdict->level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd, (u32)ZE_SMALL_LDS_BYTES);
-    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
-}
+// Slices of ZJ_CHUNK_FRAMES: memset/classify/clear/match of slice s on the caller's stream, its entropy kernel on the side
+// stream — beside slice s+1's match kernel (which leaves most of every CU idle: one wave per SIMD, waiting on memory).
 size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                              uint64_t* d_result, size_t n, const zjni_cdict* cdict, int checksum, void* stream) {
     if (!cdict) return ZJNI_ERR(32);
     if (cdict->ordinal != t_dev && t_dev >= 0) return ZJNI_ERR(32);                       // digested on another device
-    BatchOrder order(cur_state(), stream);
-    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
-        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
-        size_t const r = compress_cdict_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, cdict, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
-        if (r != 0 || n == 0) return r;
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
+    BatchOrder order(d, stream);
+    hipStream_t st = (hipStream_t)stream;
+    u32 const flags = checksum ? ZE_FLAG_CHECKSUM : 0u;
+    size_t const slice = n < ZJ_CHUNK_FRAMES ? n : ZJ_CHUNK_FRAMES;
+    size_t const fsBytes = slice * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = (slice * 12 + 255) & ~(size_t)255, tablesBytes = slice * (size_t)ZC_TABLE_STRIDE;
+    size_t const need = tablesBytes + 2 * (fsBytes + metaBytes) + 256;
+    if (d->cdBufCap < need || d->cdSliceCap < slice) {
+        if (d->cdBuf) { if (hipDeviceSynchronize() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; }
+        if (hipMalloc(&d->cdBuf, need) != hipSuccess) return ZJNI_ERR(64);
+        d->cdBufCap = need; d->cdSliceCap = slice;
     }
-    return 0;
+    if (d->cdListCap < slice) {
+        if (d->cdList) { if (hipDeviceSynchronize() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->cdList); d->cdList = nullptr; d->cdListCap = 0; }
+        if (hipMalloc(&d->cdList, 2 * (slice + 1024) * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
+        d->cdListCap = slice;
+    }
+    size_t const sliceCap = d->cdSliceCap;
+    size_t const fsB = sliceCap * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaB = (sliceCap * 12 + 255) & ~(size_t)255;
+    u8* const tables = d->cdBuf;
+    const ZECDictDev* const cd = (const ZECDictDev*)cdict->buf;
+    unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
+    int pending[2] = {0, 0};
+    size_t s = 0;
+    for (size_t at = 0; at < n; at += ZJ_CHUNK_FRAMES, s++) {
+        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+        int const par = (int)(s & 1);
+        u8* const fscratch = d->cdBuf + sliceCap * (size_t)ZC_TABLE_STRIDE + (size_t)par * (fsB + metaB); u32* const meta = (u32*)(fscratch + fsB);
+        u32* const list = d->cdList + (size_t)par * (d->cdListCap + 1024);
+        u32* const ctr = d->counters + 32 + 8 * par;              // [0] |list|, [1] unused, [2] entropy work, [4] match work
+        const u64* const so = (const u64*)d_src_off + at; const u64* const dofs = (const u64*)d_dst_off + at; u64* const res = (u64*)d_result + at;
+        if (pending[par]) { if (hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); pending[par] = 0; }   // slice s-2 is done with this set
+        if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, so, res, (u32)m, 1u, 0xFFFFFFFFu, ctr, list, list);   // every frame <= 128 KiB is listed
+        hipLaunchKernelGGL(zj_cdict_zero_tables_kernel, dim3((u32)(m < 16384 ? m : 16384)), dim3(256), 0, st, so, cd, (const u32*)list, (const u32*)ctr, tables);
+        u32 const waves = (u32)((m + 63) / 64);
+        u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
+        (void)hipEventRecord(d->tev[0], st);
+        hipLaunchKernelGGL(zj_enc_match_dict_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, so, cd, (const u32*)list, (const u32*)ctr, ctr + 4, tables, fscratch, meta);
+        (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
+        if (hipEventRecord(d->cdMatchDone[par], st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->cdMatchDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        u32 const gridA = (u32)(m < (size_t)d->encGridSmall ? m : (size_t)d->encGridSmall);
+        hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ZE_SMALL_LDS_BYTES, d->sideStream, (const u8*)d_src, so, (u8*)d_dst, dofs, res, (u32)cdict->level,
+                           (const u32*)list, (const u32*)ctr, ctr + 2, d->encScratch, eprof, fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd,
+                           (u32)ZE_SMALL_LDS_BYTES);
+        if (hipEventRecord(d->cdEncDone[par], d->sideStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        pending[par] = 1;
+    }
+    for (int par = 0; par < 2; par++) if (pending[par] && hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
