@@ -91,19 +91,23 @@ extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned sr
 }
 extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return ze_lds_need(level, srcSize); }
 
-// split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage
+// split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
+// kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
-    if (srcSize > 65536) return ZJ_ERR64(201);
+    if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
     Grp<1> g;
+    u32 const flags = (level >> 8) & 1u; level &= 0xFFu;
+    u32 const ldsA = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
+    bool const wide = ze_lds_need(level, srcSize) > (ldsA > (u32)sizeof(ZEEntropy) ? ldsA : (u32)sizeof(ZEEntropy));
+    u32 const maxSrc = wide ? ZE_WIDE_MAX_SRC : 65536u;
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
-    u8* table = (u8*)calloc(1, 65536 * 4);
-    u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(65536u));
+    u8* table = (u8*)calloc(1, ze_lane_table_stride(level, wide));
+    u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(maxSrc));
     u32 meta[3];
-    u32 const flags = (level >> 8) & 1u; level &= 0xFFu;
-    ze_match_lane(src, srcSize, level, table, fs, 65536u, meta);
-    ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(65536u) * 16u); pre.meta = meta;
+    ze_match_lane(src, srcSize, level, table, fs, maxSrc, meta, wide);
+    ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
     u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags, nullptr, 160u * 1024u);
     free(fs); free(table); free(ws); free(lds); free(sh);

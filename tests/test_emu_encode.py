@@ -43,13 +43,18 @@ def test_emu_split_pipeline_matches(emu, oracle_ref, zj):
     """lane-per-frame match finding (records in HBM scratch) + entropy stage == fused path == reference"""
     rnd = random.Random(21)
     for name, data in edge_inputs():
-        if len(data) <= 65536:
-            for level in (1, 2, 3):
-                assert emu_compress(emu, data, level, split=True) == expected(oracle_ref, data, level), (name, level)
+        for level in (1, 2, 3):
+            assert emu_compress(emu, data, level, split=True) == expected(oracle_ref, data, level), (name, level)
     for _ in range(100):
         size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 65537), 65536, 4096])
         d = zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b""
         for level in (1, 3):
+            assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
+    # the wide launch: frames > 64 KiB (4-byte positions) and level-1/2 frames of 8-16 KiB (hashLog 15)
+    for _ in range(40):
+        size = rnd.choice([rnd.randrange(65537, 131073), 131072, 100000, rnd.randrange(8193, 16385), 12000])
+        d = zj.synth_host(size, rnd.randrange(0, 100000), 1)
+        for level in (1, 2, 3):
             assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
 
 

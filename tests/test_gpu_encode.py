@@ -61,6 +61,23 @@ def test_gpu_mixed_sizes_use_both_lds_passes(gpu, oracle_ref):
             assert z == ref_expected(oracle_ref, d, level), (level, len(d))
 
 
+@pytest.mark.parametrize("wide_slice", ["32768", "100"])
+def test_gpu_wide_frames_through_the_lane_pipeline(gpu, oracle_ref, monkeypatch, wide_slice):
+    """frames > 64 KiB (config 5's 128 KiB buffers) and the level-1/2 frames with larger tables take the lane-per-frame
+    pipeline too (4-byte positions), in slices; every frame byte-identical to the reference"""
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    monkeypatch.setenv("ZJNI_WIDE_SLICE", wide_slice)
+    rnd = random.Random(31)
+    sizes = [131072, 100000, 65537, 70000, 12000, 16384, 9000, 4096, 65536, 50, 0] * 28
+    datas = [gpu.synth_host(s, rnd.randrange(0, 100000), 1) if s else b"" for s in sizes]
+    for level in (1, 2, 3):
+        outs = gpu.compress_batch(datas, level)
+        for k, (d, z) in enumerate(zip(datas, outs)):
+            assert not isinstance(z, Exception), (level, k, len(d), z)
+            assert z == ref_expected(oracle_ref, d, level), (level, k, len(d))
+        assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
+
+
 def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     data = gpu.synth_host(30000, 1, 1)
     ctx = gpu.ZstdCompressCtx().setLevel(3)

@@ -24,13 +24,15 @@ def upload(arr):
 soff = upload(np.arange(n + 1, dtype=np.uint64) * size); coff = upload(np.arange(n + 1, dtype=np.uint64) * bound)
 csz = dmalloc(n * 8); dsz = dmalloc(n * 8); poff = dmalloc((n + 1) * 8)
 chk(L.zjni_synth_fill_device(src, size, 0, n, None)); chk(hip.hipDeviceSynchronize())
-ev = [vp() for _ in range(4)]
+ev = [vp() for _ in range(5)]
 for x in ev: chk(hip.hipEventCreate(C.byref(x)))
 tc = td = tp = 0.0
 h_csz = np.zeros(n, dtype=np.uint64)
 for it in range(steps + 1):
-    chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device(src, soff, comp, coff, csz, n, level, None)); chk(hip.hipEventRecord(ev[1], None))
+    chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device(src, soff, comp, coff, csz, n, level, None)); chk(hip.hipEventRecord(ev[4], None))
     chk(hip.hipDeviceSynchronize())
+    ms = C.c_float(); chk(hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[4]))
+    if it > 0: tc += ms.value
     chk(hip.hipMemcpy(h_csz.ctypes.data_as(vp), csz, C.c_size_t(n * 8), 2))
     h_poff = np.zeros(n + 1, dtype=np.uint64); h_poff[1:] = np.cumsum(h_csz)
     chk(hip.hipMemcpy(poff, h_poff.ctypes.data_as(vp), C.c_size_t((n + 1) * 8), 1))
@@ -45,5 +47,5 @@ for it in range(steps + 1):
     chk(hip.hipEventElapsedTime(C.byref(ms), ev[2], ev[3])); d_ms = ms.value
     if it > 0: tp += p_ms; td += d_ms
 h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp), dsz, C.c_size_t(n * 8), 2))
-print(json.dumps({"n": n, "size": size, "level": level, "steps": steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+print(json.dumps({"n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
                   "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))

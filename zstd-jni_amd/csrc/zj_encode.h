@@ -1305,8 +1305,19 @@ ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8
     for (u32 r = 0; m.st != ZL_DONE; r++) m.round(r);
     meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
 }
-ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
+// `wide`: the frame is in the launch whose fast-strategy tables hold 4-byte positions (frames > 64 KiB, and the few
+// small level-1/2 frames whose hashLog exceeds the common case)
+ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false) {
     if (srcSize < ZL_MIN_FRAME) ze_match_lane_serial(src, srcSize, level, table, fscratch, maxSrc, meta);
     else if (level == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
+    else if (wide) ze_match_lane_t<ZLaneF<ZEEnt32> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else ze_match_lane_t<ZLaneF<ZEEnt16> >(src, srcSize, level, table, fscratch, maxSrc, meta);
 }
+// per-frame table bytes of the two lane-machine launches: the common case (<= 64 KiB frames with the level's usual tables)
+// and the wide one (any frame <= 128 KiB: fast tables up to hashLog 15 with 4-byte entries)
+ZJ_HD u32 ze_lane_table_stride(u32 level, bool wide) {
+    if (level == 3) return ((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 4u;
+    if (wide) return (1u << 15) * 4u;
+    return level == 1 ? (8192u * 2u) : (32768u * 2u);
+}
+#define ZE_WIDE_MAX_SRC ZE_BLOCK_MAX

@@ -186,12 +186,35 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
     if (blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
 #endif
 }
+// entries [listBase, listBase + sliceLen) of a list whose length sits in device memory (a slice past its end is empty)
+__device__ __forceinline__ u32 zj_slice_count(const u32* countPtr, u32 listBase, u32 sliceLen) {
+    u32 const count = *countPtr;
+    return count > listBase ? zj_min(count - listBase, sliceLen) : 0u;
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
-    u32 const count = *countPtr;
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
+                                                           u32 listBase, u32 sliceLen) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    list += listBase;
     if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
     else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
+}
+// The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_wide_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    list += listBase;
+    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+    else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+}
+// zero the first `count` slots of `stride` bytes (the table slots of a slice; nothing to do for an empty slice)
+__global__ __launch_bounds__(256) void zj_zero_slots_kernel(u8* base, u32 stride, const u32* countPtr, u32 listBase, u32 sliceLen) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    size_t const total16 = (size_t)count * (stride / 16u);
+    uint4* const w = (uint4*)base;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < total16; j += (size_t)gridDim.x * 256) w[j] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
                                                         u8* fscratch, u32 maxSrc, const u32* meta,
-                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags, const ZECDictDev* cd, u32 ldsBytes) {
+                                                        u32 mode, const u32* doneList, u32* procFlag, u32 flags, const ZECDictDev* cd, u32 ldsBytes, u32 listBase, u32 sliceLen) {
     // mode 0: list entry k.  mode 1: k-th entry of the completion queue the match kernel fills while this kernel
     // runs (bounded wait; a workgroup that gives up leaves its frame to the mode-2 pass).  mode 2: list entries
     // mode 1 did not finish.
@@ -209,7 +232,8 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
     if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
     __syncthreads();
     u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
-    u32 const count = ZJ_UNI(*countPtr);
+    u32 const count = ZJ_UNI(zj_slice_count(countPtr, listBase, sliceLen));
+    list += listBase;
     for (;;) {
         u32 k = zj_next_index(workCounter);           // wave-uniform (SGPR)
         if (k >= count) break;
@@ -327,6 +351,7 @@ struct DevState {
     int encGridBig = 0;                    // pass 1 (128 KiB LDS)
     int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
     // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
+    u8* wideBuf = nullptr; size_t wideBufCap = 0;     // lane-per-frame path of list B: [tables][frame scratch][meta] for one slice
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
     hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
@@ -724,35 +749,66 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
-                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1);
+                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
+                               fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
+                               fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         } else {
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
-                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
-                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun));
+                               fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsA));
+                           (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsA), 0u, 0xFFFFFFFFu);
+    }
+    if (n >= splitMin) {
+        // List B (frames > 64 KiB, fast-strategy frames with larger tables) through the same two stages, in slices that
+        // share one scratch area sized for 4-byte positions and 128 KiB frames; a slice past the end of the list is empty.
+        size_t sliceB = 32768;
+        if (const char* ov = getenv("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
+        if (sliceB > n) sliceB = n;
+        if (sliceB < 64) sliceB = 64;
+        u32 const strideB = ze_lane_table_stride((u32)level, true);
+        size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12;
+        size_t const needB = tablesB + fsB + metaB + 256;
+        if (d->wideBufCap < needB) {
+            if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
+            if (hipMalloc(&d->wideBuf, needB) != hipSuccess) return ZJNI_ERR(64);
+            d->wideBufCap = needB;
+        }
+        u8* const tb = d->wideBuf; u8* const fs = d->wideBuf + tablesB; u32* const mt = (u32*)(fs + fsB);
+        u32* const wctr = d->counters + 48;           // [0] match work, [1] entropy work
+        u32 const wavesB = (u32)((sliceB + 63) / 64);
+        u32 const gridMB = wavesB < (u32)d->matchGrid ? wavesB : (u32)d->matchGrid;
+        u32 const gridEB = (u32)(sliceB < (size_t)d->encGridLvl[1] ? sliceB : (size_t)d->encGridLvl[1]);
+        for (size_t base = 0; base < n; base += sliceB) {
+            if (hipMemsetAsync(wctr, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            hipLaunchKernelGGL(zj_zero_slots_kernel, dim3((u32)d->numCU * 8), dim3(256), 0, st, tb, strideB, (const u32*)(ctr + 1), (u32)base, (u32)sliceB);
+            hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+                               (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB);
+            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                               fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                        (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ZJ_ENC_LDS_BIG));
+                       (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ZJ_ENC_LDS_BIG), 0u, 0xFFFFFFFFu);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -861,7 +917,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
         u32 const gridA = (u32)(m < (size_t)d->encGridSmall ? m : (size_t)d->encGridSmall);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ZE_SMALL_LDS_BYTES, d->sideStream, (const u8*)d_src, so, (u8*)d_dst, dofs, res, (u32)cdict->level,
                            (const u32*)list, (const u32*)ctr, ctr + 2, d->encScratch, eprof, fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd,
-                           (u32)ZE_SMALL_LDS_BYTES);
+                           (u32)ZE_SMALL_LDS_BYTES, 0u, 0xFFFFFFFFu);
         if (hipEventRecord(d->cdEncDone[par], d->sideStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         pending[par] = 1;
     }
