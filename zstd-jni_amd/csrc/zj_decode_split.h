@@ -10,8 +10,8 @@
 //                                             one memory round trip (3 cells + 16 bitstream bytes) per lane
 //   stage 3  zd_exec_frame   wave per frame   literals (Huffman) + LZ77 execution of the decoded sequences
 //
-// "Simple" = one zstd frame filling its buffer, known content size <= 64 KiB, no dictionary, a single compressed
-// block — what the batched compressor emits for 64 KiB records.  Everything else (multi-block, multi-frame,
+// "Simple" = one zstd frame filling its buffer, known content size <= 128 KiB (one block), a single compressed
+// block — what the batched compressor emits for its records.  Everything else (multi-block, multi-frame,
 // skippable, raw/RLE blocks, any error) is routed to the fused kernel, which stays the reference for behaviour
 // and error codes: stages 1-3 never report an error themselves, they hand the frame over.
 #pragma once
@@ -21,7 +21,7 @@
 #else
 #define ZD_ROUND_FENCE5(a, b, c, d, e) ((void)0)
 #endif
-#define ZD_SPLIT_MAX_CONTENT 65536u
+#define ZD_SPLIT_MAX_CONTENT 131072u
 #define ZD_SPLIT_MAXSEQ (ZD_SPLIT_MAX_CONTENT / 3u + 2u)      // every sequence emits >= 3 bytes (minimum match)
 #define ZD_SPLIT_CELLS 1280u                                  // LL 512 | OF 256 | ML 512
 #define ZD_SPLIT_OF 512u
@@ -33,7 +33,7 @@
 // extraBits; the reference's ZSTD_seqSymbol minus baseValue, N/decompress/zstd_decompress_internal.h:68-73):
 // 5 KiB per frame instead of 10 keeps more of the tables in L2/Infinity Cache under the lane-per-frame decode;
 // baseValue comes from the symbol through two small LDS tables.
-// decoded sequence record: ll | ml << 18 | offset << 36 (all <= 2^17 for content <= 64 KiB)
+// decoded sequence record: ll | ml << 18 | offset << 36 (ll, ml <= 2^17 for content <= 128 KiB; the offset field has 28 bits)
 ZJ_DEV u64 zd_seq_pack(u32 ll, u32 ml, u32 off) { return (u64)ll | ((u64)ml << 18) | ((u64)off << 36); }
 
 struct ZDMeta {
