@@ -59,6 +59,8 @@ typedef struct {
     jlong (*dBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray);
     void (*dictInit)(JNIEnv*, jobject, jbyteArray, jint, jint, jint); void (*dictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint, jint);
     void (*dictFree)(JNIEnv*, jobject); jlong (*loadCDict)(JNIEnv*, jclass, jlong, jobject);
+    void (*ddictInit)(JNIEnv*, jobject, jbyteArray, jint, jint); void (*ddictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint);
+    void (*ddictFree)(JNIEnv*, jobject); jlong (*loadDDict)(JNIEnv*, jclass, jlong, jobject);
     jlong (*cBatchDict)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jobject, jboolean);                /* shim only */
 } Lib;
 #define P "Java_com_github_luben_zstd_"
@@ -76,11 +78,12 @@ static int load(Lib* L, const char* path, int isRef) {
     S(cBatch, "Zstd_compressBatch0"); S(dBatch, "Zstd_decompressBatch0");
     S(dictInit, "ZstdDictCompress_init"); S(dictInitDirect, "ZstdDictCompress_initDirect"); S(dictFree, "ZstdDictCompress_free");
     S(loadCDict, "ZstdCompressCtx_loadCDictFast0"); S(cBatchDict, "Zstd_compressBatchDict0");
+    S(ddictInit, "ZstdDictDecompress_init"); S(ddictInitDirect, "ZstdDictDecompress_initDirect"); S(ddictFree, "ZstdDictDecompress_free"); S(loadDDict, "ZstdDecompressCtx_loadDDictFast0");
 #undef S
     if (!L->cinit || !L->cDirect || !L->cArray || !L->dDirect || !L->dArray || !L->bound || !L->errName || !L->cUnsafe) { printf("%s: hot-path natives missing\n", path); return 0; }
     if (isRef && (!L->setHashLog || !L->setChainLog)) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
     if (!isRef && (!L->cBatch || !L->dBatch || !L->cBatchDict)) { printf("%s: batch natives missing\n", path); return 0; }
-    if (!L->dictInit || !L->dictInitDirect || !L->dictFree || !L->loadCDict) { printf("%s: ZstdDictCompress natives missing\n", path); return 0; }
+    if (!L->dictInit || !L->dictInitDirect || !L->dictFree || !L->loadCDict || !L->ddictInit || !L->ddictInitDirect || !L->ddictFree || !L->loadDDict) { printf("%s: ZstdDictCompress natives missing\n", path); return 0; }
     return 1;
 }
 
@@ -173,13 +176,17 @@ int main(int argc, char** argv) {
      * attach range, byte[] and direct-buffer constructors */
     for (int level = 1; level <= maxLevel; level++) for (int direct = 0; direct < 2; direct++) {
         jsize const dlen = 20000; jsize const srcSizes[] = {0, 100, 1000, 4096, 8000};
-        Obj* darr = mk(direct ? 1 : 2, dlen + 11); Obj* robj = mk(6, 0); Obj* gobj = mk(6, 0);
-        jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
+        Obj* darr = mk(direct ? 1 : 2, dlen + 11); Obj* robj = mk(6, 0); Obj* gobj = mk(6, 0); Obj* rdobj = mk(6, 0); Obj* gdobj = mk(6, 0);
+        jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
         fill(darr->data + 11, dlen, 0);
         if (direct) { R.dictInitDirect(e, robj, darr, 11, dlen, level, 0); G.dictInitDirect(e, gobj, darr, 11, dlen, level, 0); }
         else { R.dictInit(e, robj, (jbyteArray)darr, 11, dlen, level); G.dictInit(e, gobj, (jbyteArray)darr, 11, dlen, level); }
         CHECK(robj->field != 0 && gobj->field != 0, "ZstdDictCompress init L%d direct=%d", level, direct);
         CHECK(R.loadCDict(e, NULL, rc, robj) == G.loadCDict(e, NULL, gc, gobj), "loadCDictFast0 L%d", level);
+        if (direct) { R.ddictInitDirect(e, rdobj, darr, 11, dlen, 0); G.ddictInitDirect(e, gdobj, darr, 11, dlen, 0); }
+        else { R.ddictInit(e, rdobj, (jbyteArray)darr, 11, dlen); G.ddictInit(e, gdobj, (jbyteArray)darr, 11, dlen); }
+        CHECK(rdobj->field != 0 && gdobj->field != 0, "ZstdDictDecompress init direct=%d", direct);
+        CHECK(R.loadDDict(e, NULL, rd, rdobj) == G.loadDDict(e, NULL, gd, gdobj), "loadDDictFast0");
         for (unsigned si = 0; si < sizeof srcSizes / sizeof *srcSizes; si++) for (int kind = 1; kind <= 2; kind++) {
             jsize const n = srcSizes[si], cap = (jsize)R.bound(e, NULL, n) + 16;
             Obj* src = mk(kind, n + 4); Obj* rdst = mk(kind, cap); Obj* gdst = mk(kind, cap);
@@ -187,6 +194,12 @@ int main(int argc, char** argv) {
             jlong const rr = kind == 1 ? R.cDirect(e, NULL, rc, rdst, 3, cap - 3, src, 2, n) : R.cArray(e, NULL, rc, (jbyteArray)rdst, 3, cap - 3, (jbyteArray)src, 2, n);
             jlong const gr = kind == 1 ? G.cDirect(e, NULL, gc, gdst, 3, cap - 3, src, 2, n) : G.cArray(e, NULL, gc, (jbyteArray)gdst, 3, cap - 3, (jbyteArray)src, 2, n);
             CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr + 3), "dict compress L%d direct=%d n=%d kind=%d: ref %lld gpu %lld", level, direct, n, kind, (long long)rr, (long long)gr);
+            if (rr > 0) {       /* and back, with the dictionary loaded on the decompress contexts */
+                Obj* rout = mk(kind, n + 5); Obj* gout = mk(kind, n + 5);
+                jlong const a = kind == 1 ? R.dDirect(e, NULL, rd, rout, 1, n, rdst, 3, (jint)rr) : R.dArray(e, NULL, rd, (jbyteArray)rout, 1, n, (jbyteArray)rdst, 3, (jint)rr);
+                jlong const b = kind == 1 ? G.dDirect(e, NULL, gd, gout, 1, n, rdst, 3, (jint)rr) : G.dArray(e, NULL, gd, (jbyteArray)gout, 1, n, (jbyteArray)rdst, 3, (jint)rr);
+                CHECK(a == b && a == n && !memcmp(gout->data + 1, src->data + 2, (size_t)n), "dict decompress L%d n=%d kind=%d: ref %lld gpu %lld", level, n, kind, (long long)a, (long long)b);
+            }
         }
         CHECK(R.loadCDict(e, NULL, rc, NULL) == G.loadCDict(e, NULL, gc, NULL), "loadCDictFast0(null)");
         {   Obj* src = mk(1, 3000); Obj* rdst = mk(1, 4000); Obj* gdst = mk(1, 4000); fill(src->data, 3000, 0);
@@ -205,7 +218,14 @@ int main(int argc, char** argv) {
                 CHECK(rr == ((jlong*)res->data)[i] && !memcmp(one->data, dsts->elems[i]->data, (size_t)rr), "dict batch buffer %d L%d: ref %lld gpu %lld", i, level, (long long)rr, (long long)((jlong*)res->data)[i]);
             }
         }
-        R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dictFree(e, robj); G.dictFree(e, gobj);
+        {   /* without the dictionary the frame of a non-empty source no longer decodes: same error from both */
+            Obj* src = mk(1, 1000); Obj* fr = mk(1, 2000); Obj* o1 = mk(1, 1000); Obj* o2 = mk(1, 1000); fill(src->data, 1000, 0);
+            R.loadCDict(e, NULL, rc, robj);
+            jlong const rr = R.cDirect(e, NULL, rc, fr, 0, 2000, src, 0, 1000);
+            CHECK(R.loadDDict(e, NULL, rd, NULL) == G.loadDDict(e, NULL, gd, NULL), "loadDDictFast0(null)");
+            CHECK(R.dDirect(e, NULL, rd, o1, 0, 1000, fr, 0, (jint)rr) == G.dDirect(e, NULL, gd, o2, 0, 1000, fr, 0, (jint)rr), "decompress a dictionary frame without the dictionary"); }
+        R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+        R.dictFree(e, robj); G.dictFree(e, gobj); R.ddictFree(e, rdobj); G.ddictFree(e, gdobj);
     }
     /* Zstd.compressUnsafe / decompressUnsafe (levels 1-2: the reference cannot be given the level-3 table sizes here) */
     for (int level = 1; level <= 2; level++) for (int ck = 0; ck < 2; ck++) {

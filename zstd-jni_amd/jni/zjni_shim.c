@@ -59,7 +59,7 @@ static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error
 /* ---- contexts: what ZstdCompressCtx / ZstdDecompressCtx keep in nativePtr ---------------------------- */
 typedef struct { int level; int checksum; jlong cpu; zjni_cdict* gdict; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent;
                                                                                        gdict = the GPU digest of the loaded ZstdDictCompress */
-typedef struct { jlong cpu; } ZDCtx;
+typedef struct { jlong cpu; zjni_ddict* gdict; } ZDCtx;                              /* gdict = the GPU digest of the loaded ZstdDictDecompress */
 
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* env, jclass cls) {
     ZCtx* c = (ZCtx*)calloc(1, sizeof(ZCtx));
@@ -108,18 +108,18 @@ JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_free(JNIEnv*
  * So nativePtr stays what the bundled library put there (when it is present), and the GPU digest of the same
  * dictionary lives in a side table keyed by that value; without the bundled library nativePtr is the table key
  * itself (a private handle). */
-typedef struct { jlong key; zjni_cdict* gpu; int level; } DictEnt;
+typedef struct { jlong key; void* gpu; int level; } DictEnt;              /* gpu: zjni_cdict* or zjni_ddict* (keys are distinct heap addresses) */
 #define DICT_MAX 4096
 static DictEnt g_dicts[DICT_MAX];
 static pthread_mutex_t g_dict_mu = PTHREAD_MUTEX_INITIALIZER;
 static jfieldID g_cdict_field;
-static void dict_put(jlong key, zjni_cdict* gpu, int level) {
+static void dict_put(jlong key, void* gpu, int level) {
     pthread_mutex_lock(&g_dict_mu);
     for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; g_dicts[i].level = level; break; }
     pthread_mutex_unlock(&g_dict_mu);
 }
-static zjni_cdict* dict_get(jlong key, int remove) {
-    zjni_cdict* r = NULL;
+static void* dict_get(jlong key, int remove) {
+    void* r = NULL;
     pthread_mutex_lock(&g_dict_mu);
     for (int i = 0; i < DICT_MAX; i++) if (g_dicts[i].key == key && key) { r = g_dicts[i].gpu; if (remove) { g_dicts[i].key = 0; g_dicts[i].gpu = NULL; } break; }
     pthread_mutex_unlock(&g_dict_mu);
@@ -164,7 +164,7 @@ JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_free(JNIEnv* 
     void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_free");
     if (g_cdict_field) {
         jlong const key = (*env)->GetLongField(env, obj, g_cdict_field);
-        zjni_cdict* gpu = dict_get(key, 1);
+        zjni_cdict* gpu = (zjni_cdict*)dict_get(key, 1);
         if (gpu) zjni_freeCDict(gpu);
     }
     if (f) f(env, obj);
@@ -178,7 +178,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_loadCDictFast
     if (dict != NULL) {
         jlong const key = g_cdict_field ? (*env)->GetLongField(env, dict, g_cdict_field) : 0;
         if (!key) return -32;                                           /* -ZSTD_error_dictionary_wrong */
-        c->gdict = dict_get(key, 0);
+        c->gdict = (zjni_cdict*)dict_get(key, 0);
     }
     if (f && c->cpu) r = f(env, cls, c->cpu, dict);
     return r;
@@ -252,6 +252,66 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressByteA
 }
 
 /* ---- decompress: ZSTD_DCtx_reset + ZSTD_decompressDCtx (N/jni_fast_zstd.c:798-799, :825-826, :858-860, :892-894) */
+/* ---- ZstdDictDecompress (N/jni_fast_zstd.c:68-125) + ZstdDecompressCtx.loadDict (:673-684): same arrangement as ZstdDictCompress */
+static jfieldID g_ddict_field;
+static void ddict_register(JNIEnv* env, jobject obj, const void* bytes, size_t size) {
+    jlong key = (*env)->GetLongField(env, obj, g_ddict_field);
+    zjni_ddict* gpu = gpu_on() ? zjni_createDDict(bytes, size) : NULL;
+    if (!key) {
+        if (!gpu) return;
+        key = (jlong)(intptr_t)gpu;
+        (*env)->SetLongField(env, obj, g_ddict_field, key);
+    }
+    if (gpu) dict_put(key, gpu, 0);
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_init(JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size) {
+    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_init");
+    jclass clazz = (*env)->GetObjectClass(env, obj);
+    g_ddict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+    if (NULL == dict) return;
+    if (f) f(env, obj, dict, dict_offset, dict_size);
+    if (dict_size >= 0) {
+        jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
+        if (!copy) return;
+        (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
+        ddict_register(env, obj, copy, (size_t)dict_size);
+        free(copy);
+    }
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_initDirect(JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint byReference) {
+    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_initDirect");
+    jclass clazz = (*env)->GetObjectClass(env, obj);
+    g_ddict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+    if (NULL == dict) return;
+    if (f) f(env, obj, dict, dict_offset, dict_size, byReference);
+    {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
+        if (p && dict_size >= 0) ddict_register(env, obj, p + dict_offset, (size_t)dict_size); }
+}
+JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_free(JNIEnv* env, jobject obj) {
+    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_free");
+    if (g_ddict_field) {
+        zjni_ddict* gpu = (zjni_ddict*)dict_get((*env)->GetLongField(env, obj, g_ddict_field), 1);
+        if (gpu) zjni_freeDDict(gpu);
+    }
+    if (f) f(env, obj);
+}
+JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_loadDDictFast0(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
+    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_loadDDictFast0");
+    jlong r = 0;
+    c->gdict = NULL;
+    if (dict != NULL) {
+        jlong const key = g_ddict_field ? (*env)->GetLongField(env, dict, g_ddict_field) : 0;
+        if (!key) return -32;                                           /* -ZSTD_error_dictionary_wrong */
+        c->gdict = (zjni_ddict*)dict_get(key, 0);
+    }
+    if (f && c->cpu) r = f(env, cls, c->cpu, dict);
+    return r;
+}
+static size_t gpu_decompress(const ZDCtx* c, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    return c->gdict ? zjni_decompress_usingDDict(dst, dstCap, src, srcSize, c->gdict) : zjni_decompress(dst, dstCap, src, srcSize);
+}
+
 static jlong dec_forward(const char* name, JNIEnv* env, jclass cls, ZDCtx* c, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
     cbuf_fn f = (cbuf_fn)cpu_sym(name);
     if (f && c->cpu) return f(env, cls, c->cpu, dst, doff, dsize, src, soff, ssize);
@@ -271,7 +331,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressD
         char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
         if (d == NULL || s == NULL) return E_MEM;
         if (per_buffer_on_gpu()) {
-            size_t const r = zjni_decompress(d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
+            size_t const r = gpu_decompress(c, d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
             if (gpu_result_final(r)) return (jlong)r;
         }
     }
@@ -290,7 +350,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressB
         size_t r = (size_t)E_MEM;
         if (s && d) {
             (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
-            r = zjni_decompress(d, (size_t)dst_size, s, (size_t)src_size);
+            r = gpu_decompress(c, d, (size_t)dst_size, s, (size_t)src_size);
             if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
         }
         free(s); free(d);
@@ -381,7 +441,7 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatchDict0
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
     if (dict == NULL || !g_cdict_field) return -32;
-    g = dict_get((*env)->GetLongField(env, dict, g_cdict_field), 0);
+    g = (zjni_cdict*)dict_get((*env)->GetLongField(env, dict, g_cdict_field), 0);
     if (!g) return -32;
     return batch(env, srcs, dsts, results, 1, 0, checksum == JNI_TRUE, g);
 }
