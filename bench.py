@@ -222,13 +222,19 @@ def main():
         else:
             dom_ms = kernels[dom]
         achieved = alg / 1e9 / (dom_ms / 1e3)
-        traffic, traffic_note = None, None
+        traffic, traffic_note, request_roof = None, None, None
         try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             rec = pmc.get(f"L{level}_{n}x{size}", {}).get(dom.split("(")[0])
             if rec:
                 traffic, traffic_note = rec["hbm_bytes_per_launch"], pmc.get("note")
+                # scattered table accesses: what bounds this kernel is HBM *requests* (64-B reads, 32-B writes), not bytes —
+                # the ceiling is tools/micro/chase's measurement on this part
+                reqs = rec["fetch_bytes_per_launch"] / 64.0 + rec["write_bytes_per_launch"] / 32.0
+                request_roof = {"hbm_requests_per_launch": reqs, "achieved_G_per_s": reqs / 1e9 / (dom_ms / 1e3),
+                                "measured_ceiling_G_per_s": 52.0, "frac": reqs / 1e9 / (dom_ms / 1e3) / 52.0,
+                                "note": "random-access request ceiling measured with tools/micro/chase (65 536 dependent chains over 6 GiB)"}
         except OSError:
             pass
         out = {
@@ -243,7 +249,7 @@ def main():
             "ratio": n * size / max(csum, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg, "request_roof": request_roof,
                          "decompress_path": {"achieved": alg / 1e9 / (md / 1e3), "frac": alg / 1e9 / (md / 1e3) / HBM_PEAK_GBPS},
                          "compress_path": {"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS}},
             "cpu_baseline": cpu, "parity": gates,
