@@ -201,10 +201,14 @@ ZJ_DEV u32 ze_block_dfast_dms(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, 
     const u8* const dictStart = d.content; const u8* const dictEnd = d.content + d.size;
     u32 const dsz = d.size;
     u32 off1 = rep0, off2 = rep1;
+    // The bytes of the next position (known in advance when this one finds nothing: ip + ((ip - anchor) >> 8) + 1) are
+    // requested together with this position's table entries, so a no-match step is two dependent round trips, not three.
+    u64 wNext = (ip < ilimit) ? ld64(ip) : 0; const u8* wNextAt = ip;
     while (ip < ilimit) {
         ZE_COUNT_ITER();
         u32 mLength, offset;
-        u64 const w = ld64(ip);
+        u64 const w = (wNextAt == ip) ? wNext : ld64(ip);
+        const u8* const ipn = ip + ((ip - anchor) >> 8) + 1;
         u32 const h2 = ze_hash_w(w, hBitsL, 8), h = ze_hash_w(w, hBitsS, mls);
         u32 const dhtL = ze_hash_w(w, d.hlogL + ZC_TAG_BITS, 8), dhtS = ze_hash_w(w, d.hlogS + ZC_TAG_BITS, mls);
         u32 const dL = d.hashLong[dhtL >> ZC_TAG_BITS], dS = d.hashSmall[dhtS >> ZC_TAG_BITS];
@@ -215,8 +219,10 @@ ZJ_DEV u32 ze_block_dfast_dms(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, 
         bool matchInDict = false;
         u32 const v = dsz + curr + 1 - off1;                                       // repcode candidate in the joint space
         const u8* const repMatch = v < dsz ? dictStart + v : istart + (v - dsz);
+        u32 const repBytes = ld32(repMatch);
+        wNext = (ipn < ilimit) ? ld64(ipn) : 0; wNextAt = ipn;
         hashLong[h2] = E::make(curr + 1, 0); hashSmall[h] = E::make(curr + 1, 0);
-        if (((u32)(dsz - 1 - v) >= 3) && (ld32(repMatch) == ld32(ip + 1))) {
+        if (((u32)(dsz - 1 - v) >= 3) && (repBytes == (u32)(w >> 8))) {
             const u8* const repEnd = v < dsz ? dictEnd : iend;
             mLength = ze_count2(ip + 1 + 4, repMatch + 4, iend, repEnd, istart) + 4;
             ip++;
@@ -247,7 +253,7 @@ ZJ_DEV u32 ze_block_dfast_dms(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, 
             match = dictStart + (di - 2);
             if (di > 2 && ld32(match) == (u32)w) { matchInDict = true; goto next_long; }
         }
-        ip += ((ip - anchor) >> 8) + 1;                                            // kSearchStrength
+        ip = ipn;                                                                  // ip += ((ip - anchor) >> kSearchStrength) + 1
         continue;
 next_long:
         {   u64 const w1 = ld64(ip + 1);
