@@ -481,6 +481,10 @@ void zjni_shutdown(void) {
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
+        if (d.wideBuf) (void)hipFree(d.wideBuf);
+        if (d.cdBuf) (void)hipFree(d.cdBuf);
+        if (d.cdList) (void)hipFree(d.cdList);
+        for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
         if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
