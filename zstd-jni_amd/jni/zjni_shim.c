@@ -113,10 +113,12 @@ typedef struct { jlong key; void* gpu; int level; } DictEnt;              /* gpu
 static DictEnt g_dicts[DICT_MAX];
 static pthread_mutex_t g_dict_mu = PTHREAD_MUTEX_INITIALIZER;
 static jfieldID g_cdict_field;
-static void dict_put(jlong key, void* gpu, int level) {
+static int dict_put(jlong key, void* gpu, int level) {           /* 0 when the table is full (the caller keeps the CPU path for this dictionary) */
+    int ok = 0;
     pthread_mutex_lock(&g_dict_mu);
-    for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; g_dicts[i].level = level; break; }
+    for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; g_dicts[i].level = level; ok = 1; break; }
     pthread_mutex_unlock(&g_dict_mu);
+    return ok;
 }
 static void* dict_get(jlong key, int remove) {
     void* r = NULL;
@@ -133,7 +135,10 @@ static void dict_register(JNIEnv* env, jobject obj, const void* bytes, size_t si
         key = (jlong)(intptr_t)gpu;
         (*env)->SetLongField(env, obj, g_cdict_field, key);
     }
-    if (gpu) dict_put(key, gpu, level);
+    if (gpu && !dict_put(key, gpu, level)) {
+        zjni_freeCDict(gpu);
+        if (key == (jlong)(intptr_t)gpu) (*env)->SetLongField(env, obj, g_cdict_field, 0);
+    }
 }
 JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_init
   (JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size, jint level) {
@@ -262,7 +267,10 @@ static void ddict_register(JNIEnv* env, jobject obj, const void* bytes, size_t s
         key = (jlong)(intptr_t)gpu;
         (*env)->SetLongField(env, obj, g_ddict_field, key);
     }
-    if (gpu) dict_put(key, gpu, 0);
+    if (gpu && !dict_put(key, gpu, 0)) {
+        zjni_freeDDict(gpu);
+        if (key == (jlong)(intptr_t)gpu) (*env)->SetLongField(env, obj, g_ddict_field, 0);
+    }
 }
 JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_init(JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size) {
     void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_init");
