@@ -738,7 +738,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
-        u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
+        u32 gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
+        if (const char* ov = getenv("ZJNI_MATCH_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridM) gridM = v; }   // experiments: fewer resident waves, more frames per lane
         // with the sequences already found the entropy kernel only needs the entropy-stage LDS (more workgroups per CU)
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
