@@ -100,6 +100,18 @@ size_t zjni_decompress_batch_usingDDict(const void* const* src, const size_t* sr
                                         size_t* result, size_t n, const zjni_ddict* ddict);
 size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zjni_ddict* ddict);
 
+/* ---- explicit table sizes: ZstdCompressCtx.setHashLog / setChainLog (J/ZstdCompressCtx.java; N/jni_fast_zstd.c setHashLog0 /
+ * setChainLog0 -> ZSTD_c_hashLog / ZSTD_c_chainLog) on top of level + checksum; 0 = not set.  Honoured for level 3
+ * (double-fast): hashLog 6..17, chainLog 6..16, frames byte-identical to the reference called with the same two
+ * parameters — with 16 / 15 that is the reference's plain level 3.  Not set, level 3 uses 14 / 13.
+ * Other levels with a non-zero value: ZSTD_error_parameter_unsupported; out of range: parameter_outOfBound. */
+size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_src_off,
+                                           void* d_dst, const uint64_t* d_dst_off,
+                                           uint64_t* d_result, size_t n, int level, int checksum, int hashLog, int chainLog, void* stream);
+size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSize,
+                                    void* const* dst, const size_t* dstCapacity,
+                                    size_t* result, size_t n, int level, int checksum, int hashLog, int chainLog);
+
 /* ---- compression dictionaries ----
  * zjni_cdict == ZSTD_CDict as zstd-jni holds it in ZstdDictCompress.nativePtr (J/ZstdDictCompress.java;
  * N/jni_fast_zstd.c:18-66: init = ZSTD_createCDict(dict, size, level), free = ZSTD_freeCDict).  The dictionary is

@@ -96,20 +96,21 @@ extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return 
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
     Grp<1> g;
-    u32 const flags = (level >> 8) & 1u; level &= 0xFFu;
+    u32 const flags = (level >> 8) & 1u, hl = (level >> 16) & 0xFFu, cl = (level >> 24) & 0xFFu; level &= 0xFFu;   // test encoding: level | checksum << 8 | hashLog << 16 | chainLog << 24
+    u32 const lw = ZE_LW(level, hl, cl);
     u32 const ldsA = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
-    bool const wide = ze_lds_need(level, srcSize) > (ldsA > (u32)sizeof(ZEEntropy) ? ldsA : (u32)sizeof(ZEEntropy));
+    bool const wide = (hl | cl) ? srcSize > 65536u : ze_lds_need(level, srcSize) > (ldsA > (u32)sizeof(ZEEntropy) ? ldsA : (u32)sizeof(ZEEntropy));
     u32 const maxSrc = wide ? ZE_WIDE_MAX_SRC : 65536u;
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
-    u8* table = (u8*)calloc(1, ze_lane_table_stride(level, wide));
+    u8* table = (u8*)calloc(1, ze_lane_table_stride(lw, wide));
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(maxSrc));
     u32 meta[3];
-    ze_match_lane(src, srcSize, level, table, fs, maxSrc, meta, wide);
+    ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
-    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags, nullptr, 160u * 1024u);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, lw, ws, pf, &pre, flags, nullptr, 160u * 1024u);
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }

@@ -58,6 +58,21 @@ def test_emu_split_pipeline_matches(emu, oracle_ref, zj):
             assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
 
 
+def test_emu_explicit_table_sizes(emu, oracle_ref, zj):
+    """ZstdCompressCtx.setHashLog / setChainLog on the lane-per-frame path: byte-identical to the reference given the same
+    ZSTD_c_hashLog / ZSTD_c_chainLog; 16 / 15 is the reference's plain level 3"""
+    rnd = random.Random(77)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for _ in range(36):
+        size = rnd.choice([rnd.randrange(64, 5000), rnd.randrange(1, 65537), 65536, 65536, rnd.randrange(65537, 131073), 131072])
+        d = xml[:size] if rnd.random() < 0.3 else zj.synth_host(size, rnd.randrange(0, 100000), 1)
+        for hl, cl in ((16, 15), (17, 16), (15, 14), (12, 12), (0, 15), (16, 0), (6, 6)):
+            want = oracle_ref.compress(d, 3, False, hl, cl)
+            assert emu_compress(emu, d, 3, split=True, hash_log=hl, chain_log=cl) == want, (size, hl, cl)
+            if (hl, cl) == (16, 15):
+                assert want == oracle_ref.compress(d, 3)                  # the level's own table sizes
+
+
 def test_emu_encoder_small_inputs_match_default_level3(emu, oracle_ref, zj):
     rnd = random.Random(3)
     for _ in range(100):

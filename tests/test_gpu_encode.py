@@ -78,6 +78,33 @@ def test_gpu_wide_frames_through_the_lane_pipeline(gpu, oracle_ref, monkeypatch,
         assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
 
 
+def test_gpu_explicit_table_sizes(gpu, oracle_ref):
+    """ZstdCompressCtx.setHashLog / setChainLog (level 3): byte-identical to the reference given the same two parameters;
+    16 / 15 = the reference's plain level 3.  Batches and the per-buffer API; other levels refuse the parameters."""
+    rnd = random.Random(41)
+    sizes = [131072, 100000, 65536, 65536, 40000, 12000, 4096, 700, 64, 10, 0] * 6
+    datas = [gpu.synth_host(s, rnd.randrange(0, 100000), 1) if s else b"" for s in sizes]
+    for hl, cl in ((16, 15), (17, 16), (12, 12), (0, 15)):
+        outs = gpu.compress_batch(datas, 3, hash_log=hl, chain_log=cl)
+        for k, (d, z) in enumerate(zip(datas, outs)):
+            assert not isinstance(z, Exception), (hl, cl, k, len(d), z)
+            assert z == oracle_ref.compress(d, 3, False, hl, cl), (hl, cl, k, len(d))
+            if (hl, cl) == (16, 15):
+                assert z == oracle_ref.compress(d, 3)
+        assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
+    with gpu.ZstdCompressCtx() as ctx:
+        ctx.setLevel(3).setHashLog(16).setChainLog(15).setChecksum(True)
+        assert ctx.compress(datas[2]) == oracle_ref.compress(datas[2], 3, True)
+        ctx.setLevel(1)
+        with pytest.raises(gpu.ZstdException) as e:
+            ctx.compress(datas[2])
+        assert e.value.getErrorCode() == 40
+        ctx.setLevel(3).setHashLog(25)
+        with pytest.raises(gpu.ZstdException) as e:
+            ctx.compress(datas[2])
+        assert e.value.getErrorCode() == 42
+
+
 def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     data = gpu.synth_host(30000, 1, 1)
     ctx = gpu.ZstdCompressCtx().setLevel(3)

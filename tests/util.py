@@ -106,10 +106,11 @@ def emu_decompress_split(L, frame, cap):
     return dst.raw[:r], bool(used.value)
 
 
-def emu_compress(L, data, level, split=False, checksum=False):
+def emu_compress(L, data, level, split=False, checksum=False, hash_log=0, chain_log=0):
     cap = len(data) + (len(data) >> 8) + 64 + 128
     dst = C.create_string_buffer(cap)
-    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level | (0x100 if checksum else 0))
+    assert split or not (hash_log or chain_log)           # explicit table sizes exist on the lane-per-frame path only
+    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (hash_log << 16) | (chain_log << 24))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

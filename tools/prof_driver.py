@@ -15,6 +15,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+hl = int(sys.argv[5]) if len(sys.argv) > 5 else 0          # ZSTD_c_hashLog / ZSTD_c_chainLog (level 3), 0 = the library's choice
+cl = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 assert L.zjni_init(0) == 0
 bound = L.zjni_compressBound(size)
 src = dmalloc(n * size); comp = dmalloc(n * bound); packed = dmalloc(n * bound); back = dmalloc(n * size)
@@ -29,7 +31,7 @@ for x in ev: chk(hip.hipEventCreate(C.byref(x)))
 tc = td = tp = 0.0
 h_csz = np.zeros(n, dtype=np.uint64)
 for it in range(steps + 1):
-    chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device(src, soff, comp, coff, csz, n, level, None)); chk(hip.hipEventRecord(ev[4], None))
+    chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device_advanced(src, soff, comp, coff, csz, n, level, 0, hl, cl, None)); chk(hip.hipEventRecord(ev[4], None))
     chk(hip.hipDeviceSynchronize())
     ms = C.c_float(); chk(hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[4]))
     if it > 0: tc += ms.value
@@ -47,5 +49,5 @@ for it in range(steps + 1):
     chk(hip.hipEventElapsedTime(C.byref(ms), ev[2], ev[3])); d_ms = ms.value
     if it > 0: tp += p_ms; td += d_ms
 h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp), dsz, C.c_size_t(n * 8), 2))
-print(json.dumps({"n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+print(json.dumps({"n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
                   "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))

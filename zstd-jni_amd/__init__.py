@@ -100,6 +100,10 @@ def lib():
     L.zjni_decompress_batch_usingDDict.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, vp]
     L.zjni_decompress_usingDDict.restype = sz
     L.zjni_decompress_usingDDict.argtypes = [vp, sz, vp, sz, vp]
+    L.zjni_compress_batch_device_advanced.restype = sz
+    L.zjni_compress_batch_device_advanced.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.zjni_compress_batch_advanced.restype = sz
+    L.zjni_compress_batch_advanced.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int, C.c_int, C.c_int, C.c_int]
     L.zjni_createCDict.restype = vp
     L.zjni_createCDict.argtypes = [vp, sz, C.c_int]
     L.zjni_freeCDict.restype = sz
@@ -144,7 +148,8 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_createDDict", "zjni_freeDDict", "zjni_getDictID_fromDDict", "zjni_decompress_batch_device_usingDDict",
            "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict",
            "zjni_createCDict", "zjni_freeCDict", "zjni_getDictID_fromCDict", "zjni_compress_batch_device_usingCDict",
-           "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict")
+           "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
+           "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced")
 
 
 # --------------------------------------------------------------------------- Java API mirror --
@@ -276,6 +281,8 @@ class ZstdCompressCtx(_AutoClose):
         super().__init__()
         self.level = 3                                             # ZSTD_CLEVEL_DEFAULT
         self.checksum = False                                      # ZSTD_c_checksumFlag default
+        self.hashLog = 0                                           # ZSTD_c_hashLog / ZSTD_c_chainLog, 0 = not set
+        self.chainLog = 0
         self._cdict = None                                         # ZstdDictCompress in use (ZSTD_CCtx_refCDict)
         self._raw_dict = None                                      # byte[] dictionary (ZSTD_CCtx_loadDictionary): digested at the ctx's level
         self._own = None
@@ -312,6 +319,16 @@ class ZstdCompressCtx(_AutoClose):
         self.checksum = bool(checksumFlag)
         return self
 
+    def setHashLog(self, hashLog):                                 # J/ZstdCompressCtx.java (setHashLog0 -> ZSTD_c_hashLog)
+        self._ensure_open()
+        self.hashLog = hashLog
+        return self
+
+    def setChainLog(self, chainLog):                               # J/ZstdCompressCtx.java (setChainLog0 -> ZSTD_c_chainLog)
+        self._ensure_open()
+        self.chainLog = chainLog
+        return self
+
     def setLevel(self, level):                                     # J/ZstdCompressCtx.java:69
         self._ensure_open()
         self.level = level
@@ -339,6 +356,12 @@ class ZstdCompressCtx(_AutoClose):
             sp, dp = (C.c_void_p * 1)(sa), (C.c_void_p * 1)(da)
             ss, dc, res = (C.c_size_t * 1)(srcSize), (C.c_size_t * 1)(dstSize), (C.c_size_t * 1)()
             r = lib().zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, 1, cd._ptr, 1 if self.checksum else 0)
+            if not lib().zjni_isError(r):
+                r = res[0]
+        elif self.hashLog or self.chainLog:
+            sp, dp = (C.c_void_p * 1)(sa), (C.c_void_p * 1)(da)
+            ss, dc, res = (C.c_size_t * 1)(srcSize), (C.c_size_t * 1)(dstSize), (C.c_size_t * 1)()
+            r = lib().zjni_compress_batch_advanced(sp, ss, dp, dc, res, 1, self.level, 1 if self.checksum else 0, self.hashLog, self.chainLog)
             if not lib().zjni_isError(r):
                 r = res[0]
         else:
@@ -500,10 +523,10 @@ def _check_launch(r):
         raise ZstdException(r)
 
 
-def compress_batch(buffers, level=3, checksum=False, dictionary=None):
-    """n independent buffers -> n zstd frames through zjni_compress_batch2 / _usingCDict (host pointers);
-    `dictionary` is a ZstdDictCompress (its level applies)."""
-    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum, dictionary)
+def compress_batch(buffers, level=3, checksum=False, dictionary=None, hash_log=0, chain_log=0):
+    """n independent buffers -> n zstd frames through zjni_compress_batch2 / _usingCDict / _advanced (host pointers);
+    `dictionary` is a ZstdDictCompress (its level applies); hash_log / chain_log = ZstdCompressCtx.setHashLog / setChainLog."""
+    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum, dictionary, hash_log, chain_log)
 
 
 def decompress_batch(frames, capacities, dictionary=None):
@@ -511,7 +534,7 @@ def decompress_batch(frames, capacities, dictionary=None):
     return _host_batch(frames, list(capacities), False, 0, False, dictionary)
 
 
-def _host_batch(srcs, caps, is_compress, level, checksum=False, dictionary=None):
+def _host_batch(srcs, caps, is_compress, level, checksum=False, dictionary=None, hash_log=0, chain_log=0):
     L = lib()
     n = len(srcs)
     if n == 0:
@@ -525,6 +548,8 @@ def _host_batch(srcs, caps, is_compress, level, checksum=False, dictionary=None)
     res = (C.c_size_t * n)()
     if is_compress and dictionary is not None:
         r = L.zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, n, dictionary._ptr, 1 if checksum else 0)
+    elif is_compress and (hash_log or chain_log):
+        r = L.zjni_compress_batch_advanced(sp, ss, dp, dc, res, n, level, 1 if checksum else 0, hash_log, chain_log)
     elif is_compress:
         r = L.zjni_compress_batch2(sp, ss, dp, dc, res, n, level, 1 if checksum else 0)
     else:

@@ -42,7 +42,7 @@ def synth(n, buf_size, first_index=0, device="cuda"):
     return blob
 
 
-def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checksum=False, dictionary=None):
+def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checksum=False, dictionary=None, hash_log=0, chain_log=0):
     """Enqueue zjni_compress_batch_device[2 / _usingCDict] on the current stream; returns the int64[n] result tensor
     (compressed size per buffer, or a negative ZSTD/ZJNI error code).  `dictionary`: a ZstdDictCompress (its level applies)."""
     n = src_off.numel() - 1
@@ -51,6 +51,10 @@ def compress(src_blob, src_off, dst_blob, dst_off, level=3, results=None, checks
     if dictionary is not None:
         _check(lib().zjni_compress_batch_device_usingCDict(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
                                                            results.data_ptr(), n, dictionary._ptr, 1 if checksum else 0, _stream_ptr()))
+        return results
+    if hash_log or chain_log:
+        _check(lib().zjni_compress_batch_device_advanced(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
+                                                         results.data_ptr(), n, level, 1 if checksum else 0, hash_log, chain_log, _stream_ptr()))
         return results
     _check(lib().zjni_compress_batch_device2(src_blob.data_ptr(), src_off.data_ptr(), dst_blob.data_ptr(), dst_off.data_ptr(),
                                              results.data_ptr(), n, level, 1 if checksum else 0, _stream_ptr()))

@@ -105,7 +105,7 @@ ZJ_DEV u32 ze_ml_code(u32 v) { return v > 127 ? zj_hibit(v) + 36 : ze_k_ml_code[
 
 // ------------------------------------------------------------------ parameters --------------
 // N/compress/clevels.h:81-83,107-109 + ZSTD_adjustCParams_internal (N/compress/zstd_compress.c:1553-1572)
-ZJ_DEV void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
+ZJ_HD void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
     u32 const srcLog = (srcSize < 64u) ? 6u : zj_hibit(srcSize - 1) + 1;
     if (windowLog > srcLog) windowLog = srcLog;
     if (hashLog > windowLog + 1) hashLog = windowLog + 1;
@@ -113,14 +113,28 @@ ZJ_DEV void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) 
     if (windowLog < 10) windowLog = 10;
 }
 struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy; };
-ZJ_DEV ZEParams ze_params_of(u32 level, u32 srcSize) {
+// "level" arguments are level words: the level in the low byte, then ZstdCompressCtx.setHashLog / setChainLog
+// (ZSTD_c_hashLog / ZSTD_c_chainLog, 0 = not set) — honoured for the double-fast strategy, whose tables live in HBM on
+// the lane-per-frame path and can therefore have the level's own sizes (16 / 15 at level 3) or any other.
+#define ZE_LW(level, hashLog, chainLog) ((u32)(level) | ((u32)(hashLog) << 8) | ((u32)(chainLog) << 16))
+#define ZE_LW_LEVEL(lw) ((lw) & 0xFFu)
+#define ZE_LW_HL(lw) (((lw) >> 8) & 0xFFu)
+#define ZE_LW_CL(lw) (((lw) >> 16) & 0xFFu)
+#define ZE_HASHLOG_CAP 17u       /* 15 tag bits below the index must fit the product's high dword */
+#define ZE_CHAINLOG_CAP 16u
+ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
+    u32 const level = ZE_LW_LEVEL(levelWord), hl = ZE_LW_HL(levelWord), cl = ZE_LW_CL(levelWord);
     u32 w, c, h, mm, st;
     if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; mm = (level == 1) ? 5 : 4; st = (level == 3) ? 2 : 1; }
     else if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
     else if (level == 2) { w = 17; c = 13; h = 15; mm = 5; st = 1; }
     else { w = 17; c = 15; h = 16; mm = 5; st = 2; }
     ze_adjust(w, c, h, srcSize);
-    if (st == 2) {            // LDS budget: ZSTD_c_hashLog = 14, ZSTD_c_chainLog = 13, then adjust again
+    if (st == 2 && (hl | cl)) {   // explicit ZSTD_c_hashLog / ZSTD_c_chainLog: override, then ZSTD_adjustCParams_internal again (zstd_compress.c:1640-1655)
+        if (hl) h = hl;
+        if (cl) c = cl;
+        ze_adjust(w, c, h, srcSize);
+    } else if (st == 2) {     // LDS budget: ZSTD_c_hashLog = 14, ZSTD_c_chainLog = 13, then adjust again
         if (h > ZE_L3_HASHLOG || c > ZE_L3_CHAINLOG) { if (h > ZE_L3_HASHLOG) h = ZE_L3_HASHLOG; if (c > ZE_L3_CHAINLOG) c = ZE_L3_CHAINLOG; ze_adjust(w, c, h, srcSize); }
     }
     ZEParams p; p.windowLog = w; p.chainLog = c; p.hashLog = h; p.minMatch = mm; p.strategy = st;
@@ -1309,13 +1323,15 @@ ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8
 // small level-1/2 frames whose hashLog exceeds the common case)
 ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false) {
     if (srcSize < ZL_MIN_FRAME) ze_match_lane_serial(src, srcSize, level, table, fscratch, maxSrc, meta);
-    else if (level == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
+    else if (ZE_LW_LEVEL(level) == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else if (wide) ze_match_lane_t<ZLaneF<ZEEnt32> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else ze_match_lane_t<ZLaneF<ZEEnt16> >(src, srcSize, level, table, fscratch, maxSrc, meta);
 }
 // per-frame table bytes of the two lane-machine launches: the common case (<= 64 KiB frames with the level's usual tables)
 // and the wide one (any frame <= 128 KiB: fast tables up to hashLog 15 with 4-byte entries)
-ZJ_HD u32 ze_lane_table_stride(u32 level, bool wide) {
+ZJ_HD u32 ze_lane_table_stride(u32 levelWord, bool wide) {
+    u32 const level = ZE_LW_LEVEL(levelWord), hl = ZE_LW_HL(levelWord), cl = ZE_LW_CL(levelWord);
+    if (level == 3 && (hl | cl)) return ((1u << (hl ? hl : 16u)) + (1u << (cl ? cl : 15u))) * 4u;   // the one not given keeps the level's own size; adjustment only shrinks
     if (level == 3) return ((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 4u;
     if (wide) return (1u << 15) * 4u;
     return level == 1 ? (8192u * 2u) : (32768u * 2u);

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
     if (size > ZE_BLOCK_MAX) { result[i] = ZJ_ERR64(201); return; }
-    if (ze_lds_need(level, (u32)size) <= ldsA) listA[atomicAdd(&counters[0], 1u)] = i;
+    bool const a = (ZE_LW_HL(level) | ZE_LW_CL(level)) ? (size <= 65536u)            // explicit table sizes: lane pipeline only, split by record width
+                                                         : (ze_lds_need(ZE_LW_LEVEL(level), (u32)size) <= ldsA);
+    if (a) listA[atomicAdd(&counters[0], 1u)] = i;
     else listB[atomicAdd(&counters[1], 1u)] = i;
 }
 
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                                            u32 listBase, u32 sliceLen) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
+    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
     else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
 }
 // The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    if (level == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
     else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
 }
 // zero the first `count` slots of `stride` bytes (the table slots of a slice; nothing to do for an empty slice)
@@ -698,9 +700,11 @@ size_t zjni_freeDDict(zjni_ddict* dd) {
 unsigned zjni_getDictID_fromDDict(const zjni_ddict* dd) { return dd ? dd->dictID : 0u; }
 
 static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
-                                         uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
+                                         uint64_t* d_result, size_t n, int levelWord, u32 flags, void* stream) {
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    int const level = (int)ZE_LW_LEVEL((u32)levelWord);       // kernels take the level word (level | hashLog << 8 | chainLog << 16)
+    bool const tuned = (ZE_LW_HL((u32)levelWord) | ZE_LW_CL((u32)levelWord)) != 0;
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
@@ -716,14 +720,15 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     u32 const ldsA = (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
-                       (u32)n, (u32)level, ldsA, ctr, listA, listB);
+                       (u32)n, (u32)levelWord, ldsA, ctr, listA, listB);
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
     // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
     size_t splitMin = 4096;
     if (const char* ov = getenv("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
+    if (tuned) splitMin = 1;                      // explicit table sizes exist only on the lane-per-frame path (tables in HBM)
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
     if (n >= splitMin) {
-        u32 const tableStride = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 4u));   // fast: u16 entries; dfast: 4-byte tagged entries
+        u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
         size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + 256;
         if (d->splitBufCap < need) {
@@ -753,30 +758,30 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             (void)hipEventRecord(d->tev[0], st);
-            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         } else {
             (void)hipEventRecord(d->tev[0], st);
-            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                           (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,
                            (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsA), 0u, 0xFFFFFFFFu);
     }
     if (n >= splitMin) {
@@ -786,7 +791,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (const char* ov = getenv("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
         if (sliceB > n) sliceB = n;
         if (sliceB < 64) sliceB = 64;
-        u32 const strideB = ze_lane_table_stride((u32)level, true);
+        u32 const strideB = ze_lane_table_stride((u32)levelWord, true);
         size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12;
         size_t const needB = tablesB + fsB + metaB + 256;
         if (d->wideBufCap < needB) {
@@ -802,17 +807,17 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         for (size_t base = 0; base < n; base += sliceB) {
             if (hipMemsetAsync(wctr, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_zero_slots_kernel, dim3((u32)d->numCU * 8), dim3(256), 0, st, tb, strideB, (const u32*)(ctr + 1), (u32)base, (u32)sliceB);
-            hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)level,
+            hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
                                fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
         }
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     u32 const gridB = (u32)(n < (size_t)d->encGridBig ? n : (size_t)d->encGridBig);
     hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ZJ_ENC_LDS_BIG, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                       (const u64*)d_dst_off, (u64*)d_result, (u32)level, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                       (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), ctr + 3, d->encScratch, d->prof ? d->prof + 16 : nullptr,
                        (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ZJ_ENC_LDS_BIG), 0u, 0xFFFFFFFFu);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
@@ -828,11 +833,29 @@ static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, voi
 }
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream) {
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
 }
 size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                    uint64_t* d_result, size_t n, int level, int checksum, void* stream) {
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
+}
+// ZstdCompressCtx.setHashLog / setChainLog (ZSTD_c_hashLog / ZSTD_c_chainLog; 0 = the library's choice) on top of level + checksum.
+// Honoured for level 3 (double-fast), hashLog 6..17, chainLog 6..16: with 16 / 15 the frames are the reference's plain level 3.
+static size_t level_word(int level, int hashLog, int chainLog, int* out) {
+    *out = level;
+    if (!hashLog && !chainLog) return 0;
+    if (level != 3) return ZJNI_ERR(40);
+    if ((hashLog && (hashLog < 6 || hashLog > (int)ZE_HASHLOG_CAP)) || (chainLog && (chainLog < 6 || chainLog > (int)ZE_CHAINLOG_CAP))) return ZJNI_ERR(42);
+    *out = (int)ZE_LW(level, hashLog, chainLog);
+    return 0;
+}
+size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                           uint64_t* d_result, size_t n, int level, int checksum, int hashLog, int chainLog, void* stream) {
+    int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
+    if (e) return e;
+    return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, lw, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
 
 // ZSTD_createCDict (N/compress/zstd_compress.c:5710-5719; ZstdDictCompress.init, N/jni_fast_zstd.c:18-52): the raw dictionary
@@ -957,9 +980,9 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     if (compress && cdict)
         r = zjni_compress_batch_device_usingCDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                                   (u64*)(d->dStage + oRes), n, cdict, checksum, nullptr);
-    else if (compress)
-        r = zjni_compress_batch_device2(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                                        (u64*)(d->dStage + oRes), n, level, checksum, nullptr);
+    else if (compress)                             // `level` may be a level word (zjni_compress_batch_advanced)
+        r = compress_chunked(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
+                             (u64*)(d->dStage + oRes), n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, nullptr);
     else
         r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                                     (u64*)(d->dStage + oRes), n, ddict, nullptr);
@@ -988,6 +1011,13 @@ size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize, void*
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum);
 }
 
+size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                    int level, int checksum, int hashLog, int chainLog) {
+    int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
+    if (e) return e;
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    return host_batch(true, src, srcSize, dst, dstCap, result, n, lw, checksum);
+}
 size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
     size_t res = 0; const void* s = src; void* dd = dst;
     size_t const r = zjni_compress_batch(&s, &srcSize, &dd, &dstCap, &res, 1, level);
