@@ -81,7 +81,7 @@ static int load(Lib* L, const char* path, int isRef) {
     S(ddictInit, "ZstdDictDecompress_init"); S(ddictInitDirect, "ZstdDictDecompress_initDirect"); S(ddictFree, "ZstdDictDecompress_free"); S(loadDDict, "ZstdDecompressCtx_loadDDictFast0");
 #undef S
     if (!L->cinit || !L->cDirect || !L->cArray || !L->dDirect || !L->dArray || !L->bound || !L->errName || !L->cUnsafe) { printf("%s: hot-path natives missing\n", path); return 0; }
-    if (isRef && (!L->setHashLog || !L->setChainLog)) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
+    if (!L->setHashLog || !L->setChainLog) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
     if (!isRef && (!L->cBatch || !L->dBatch || !L->cBatchDict)) { printf("%s: batch natives missing\n", path); return 0; }
     if (!L->dictInit || !L->dictInitDirect || !L->dictFree || !L->loadCDict || !L->ddictInit || !L->ddictInitDirect || !L->ddictFree || !L->loadDDict) { printf("%s: ZstdDictCompress natives missing\n", path); return 0; }
     return 1;
@@ -171,6 +171,20 @@ int main(int argc, char** argv) {
             CHECK(R.dArray(e, NULL, rd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20) == G.dArray(e, NULL, gd, (jbyteArray)da, 0, 100, (jbyteArray)sa, 90, 20), "decompress array src range");
         }
         R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+    }
+    /* ZstdCompressCtx.setHashLog / setChainLog: with the level's own table sizes the shim's frames are the reference's PLAIN level 3 */
+    if (maxLevel >= 3) {
+        jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
+        R.setLevel(e, NULL, rc, 3); G.setLevel(e, NULL, gc, 3);
+        CHECK(G.setHashLog(e, NULL, gc, 16) == 0 && G.setChainLog(e, NULL, gc, 15) == 0, "setCompressionHashLog/ChainLog on a shim context");
+        for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
+            jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
+            Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
+            fill(src->data, n, cls);
+            jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap, src, 0, n), gr = G.cDirect(e, NULL, gc, gdst, 0, cap, src, 0, n);
+            CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "plain level 3 (16/15) n=%d cls=%d: ref %lld gpu %lld", n, cls, (long long)rr, (long long)gr);
+        }
+        R.cfree(e, NULL, rc); G.cfree(e, NULL, gc);
     }
     /* ZstdDictCompress + ZstdCompressCtx.loadDict (N/jni_fast_zstd.c:13-66, :325-336): a raw-content dictionary, sources inside the
      * attach range, byte[] and direct-buffer constructors */

@@ -18,7 +18,8 @@ HOT = ["ZstdCompressCtx_init", "ZstdCompressCtx_free", "ZstdCompressCtx_setLevel
        "ZstdDecompressCtx_decompressByteArray0", "Zstd_compressBound", "Zstd_isError", "Zstd_getErrorName",
        "Zstd_getErrorCode", "Zstd_compressUnsafe", "Zstd_decompressUnsafe", "Zstd_compressBatch0", "Zstd_decompressBatch0",
        "ZstdDictCompress_init", "ZstdDictCompress_initDirect", "ZstdDictCompress_free", "ZstdCompressCtx_loadCDictFast0", "Zstd_compressBatchDict0",
-       "ZstdDictDecompress_init", "ZstdDictDecompress_initDirect", "ZstdDictDecompress_free", "ZstdDecompressCtx_loadDDictFast0"]
+       "ZstdDictDecompress_init", "ZstdDictDecompress_initDirect", "ZstdDictDecompress_free", "ZstdDecompressCtx_loadDDictFast0",
+       "Zstd_setCompressionHashLog", "Zstd_setCompressionChainLog"]
 
 
 def _built():

@@ -57,22 +57,57 @@ static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error
 }
 
 /* ---- contexts: what ZstdCompressCtx / ZstdDecompressCtx keep in nativePtr ---------------------------- */
-typedef struct { int level; int checksum; jlong cpu; zjni_cdict* gdict; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent;
+typedef struct { int level; int checksum; int hashLog; int chainLog; jlong cpu; zjni_cdict* gdict; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent;
                                                                                        gdict = the GPU digest of the loaded ZstdDictCompress */
 typedef struct { jlong cpu; zjni_ddict* gdict; } ZDCtx;                              /* gdict = the GPU digest of the loaded ZstdDictDecompress */
 
+/* The parameter natives of class Zstd (setCompressionHashLog, ...) receive a raw context pointer that may also belong to a
+ * stream class of the bundled library; the shim's own contexts are told apart by this registry. */
+#define CTX_MAX 8192
+static jlong g_ctxs[CTX_MAX];
+static pthread_mutex_t g_ctx_mu = PTHREAD_MUTEX_INITIALIZER;
+static void ctx_track(jlong p, int add) {
+    pthread_mutex_lock(&g_ctx_mu);
+    for (int i = 0; i < CTX_MAX; i++) if (g_ctxs[i] == (add ? 0 : p)) { g_ctxs[i] = add ? p : 0; break; }
+    pthread_mutex_unlock(&g_ctx_mu);
+}
+static int ctx_is_ours(jlong p) {
+    int r = 0;
+    pthread_mutex_lock(&g_ctx_mu);
+    for (int i = 0; i < CTX_MAX && !r; i++) r = (g_ctxs[i] == p && p != 0);
+    pthread_mutex_unlock(&g_ctx_mu);
+    return r;
+}
 JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* env, jclass cls) {
     ZCtx* c = (ZCtx*)calloc(1, sizeof(ZCtx));
     jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_init");
     if (!c) return 0;
     c->level = 3;                                   /* ZSTD_CLEVEL_DEFAULT */
     if (f) c->cpu = f(env, cls);
+    ctx_track((jlong)(intptr_t)c, 1);
     return (jlong)(intptr_t)c;
+}
+/* ZstdCompressCtx.setHashLog / setChainLog -> Zstd.setCompressionHashLog / ChainLog (N/jni_zstd.c:462-475): ZSTD_c_hashLog / ZSTD_c_chainLog */
+static jint set_log(JNIEnv* env, jclass cls, jlong stream, jint v, int chain, const char* name) {
+    jint (*f)(JNIEnv*, jclass, jlong, jint) = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(name);
+    if (ctx_is_ours(stream)) {
+        ZCtx* c = (ZCtx*)(intptr_t)stream;
+        if (chain) c->chainLog = v; else c->hashLog = v;
+        return (f && c->cpu) ? f(env, cls, c->cpu, v) : 0;
+    }
+    return f ? f(env, cls, stream, v) : -(jint)ZJNI_ERROR_unsupported;   /* a stream class's context: the bundled library's business */
+}
+JNIEXPORT jint JNICALL Java_com_github_luben_zstd_Zstd_setCompressionHashLog(JNIEnv* env, jclass cls, jlong stream, jint hashLog) {
+    return set_log(env, cls, stream, hashLog, 0, "Java_com_github_luben_zstd_Zstd_setCompressionHashLog");
+}
+JNIEXPORT jint JNICALL Java_com_github_luben_zstd_Zstd_setCompressionChainLog(JNIEnv* env, jclass cls, jlong stream, jint chainLog) {
+    return set_log(env, cls, stream, chainLog, 1, "Java_com_github_luben_zstd_Zstd_setCompressionChainLog");
 }
 JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_free(JNIEnv* env, jclass cls, jlong ptr) {
     ZCtx* c = (ZCtx*)(intptr_t)ptr;
     void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_free");
     if (!c) return;
+    ctx_track(ptr, 0);
     if (f && c->cpu) f(env, cls, c->cpu);
     free(c);
 }
@@ -200,10 +235,15 @@ static size_t gpu_compress(const ZCtx* c, void* dst, size_t dstCap, const void* 
         size_t const r = zjni_compress_batch_usingCDict(&s, &srcSize, &d, &dstCap, &res, 1, c->gdict, c->checksum);
         return zjni_isError(r) ? r : res;
     }
+    if (c->hashLog || c->chainLog) {                /* explicit table sizes: level 3 only on the GPU (40 otherwise -> forwarded) */
+        size_t res = 0; const void* s = src; void* d = dst;
+        size_t const r = zjni_compress_batch_advanced(&s, &srcSize, &d, &dstCap, &res, 1, c->level, c->checksum, c->hashLog, c->chainLog);
+        return zjni_isError(r) ? r : res;
+    }
     return zjni_compress2(dst, dstCap, src, srcSize, c->level, c->checksum);
 }
-static int gpu_compress_final(const ZCtx* c, size_t r) {   /* with a dictionary, "outside the attach range" (40) means: not for the GPU path */
-    return gpu_result_final(r) && !(c->gdict && zjni_isError(r) && zjni_getErrorCode(r) == 40 && c->cpu);
+static int gpu_compress_final(const ZCtx* c, size_t r) {   /* 40 = a dictionary frame outside the attach range / table sizes the GPU path does not take: forward when possible */
+    return gpu_result_final(r) && !((c->gdict || c->hashLog || c->chainLog) && zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && c->cpu);
 }
 typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
 
