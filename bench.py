@@ -185,6 +185,19 @@ def main():
         gates["cpu_decodes_gpu_frames"] = cpu_ok
         if first_bad:
             gates["first_bad_frame"] = first_bad
+        if ref.available():
+            # byte identity, outside the timed region: the frames above against the reference given the library's level-3
+            # table sizes, and a second GPU pass with the level's own sizes (setHashLog(16).setChainLog(15)) against the
+            # reference's plain call
+            want = [ref.compress(host_src[i * size:(i + 1) * size], 3, False, 14, 13) if level == 3 else ref.compress(host_src[i * size:(i + 1) * size], level) for i in range(k)]
+            gates["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + max(sizes[i], 0)].tobytes() == want[i] for i in range(k))
+            if level == 3:
+                c2 = torch.empty(k * bound, dtype=torch.uint8, device="cuda")
+                s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=16, chain_log=15)
+                torch.cuda.synchronize()
+                z2, b2 = s2.cpu().tolist(), c2.cpu().numpy()
+                gates["plain_level3_byte_identical_with_hashLog16_chainLog15"] = all(
+                    b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_src[i * size:(i + 1) * size], 3) for i in range(k))
         neg = int((csz <= 0).sum().item())
         if neg:
             gates["frames_with_error_result"] = neg
