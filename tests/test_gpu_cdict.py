@@ -89,6 +89,11 @@ def test_gpu_cdict_api_mirror(gpu, oracle_ref):
                     ctx.setLevel(level).loadDict(dbytes)                          # byte[] dictionary: digested at the ctx's level
                     assert ctx.compress(srcs[4]) == ref_cd.compress(srcs[4])
                 assert gpu.Zstd.compress(srcs[5], cd) == ref_cd.compress_using(srcs[5])
+                with gpu.ZstdCompressCtx() as ctx:                                # destination too small: the reference's code and message
+                    ctx.loadDict(cd)
+                    with pytest.raises(gpu.ZstdException) as e:
+                        ctx.compress(srcs[6], bytearray(12))
+                    assert e.value.getErrorCode() == 70 and "Destination buffer is too small" in str(e.value)
                 with pytest.raises(gpu.ZstdException) as e:
                     gpu.Zstd.compress(bytes(20000), cd)
                 assert e.value.getErrorCode() == 40
