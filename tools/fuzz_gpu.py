@@ -1,0 +1,55 @@
+"""Randomised byte-identity stress on the GPU (wave64 build, C-ABI): one batch of n random buffers per level through the lane
+pipelines (plain incl. wide, explicit table sizes, dictionary), every frame compared with the reference's and decoded
+back on the GPU.  usage: fuzz_gpu.py <seed> <n>   TEST INFRASTRUCTURE."""
+import os, sys, random, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as e
+import util
+from oracle import ref
+zj = e.load_package(); zj.batch.init(0)
+seed = int(sys.argv[1]); n = int(sys.argv[2])
+rnd = random.Random(seed)
+recs = util.json_records(20000, seed=seed)
+def gen(size):
+    k = rnd.randrange(4)
+    if k == 0: return os.urandom(size)
+    if k == 1:
+        i = rnd.randrange(0, len(recs) - 2000); return b",".join(recs[i:i + 2000])[:size]
+    if k == 2: return zj.synth_host(max(size, 1), rnd.randrange(1 << 20), 1)[:size]
+    a = gen(size // 2); return (a + gen(size - len(a)))[:size]
+def sizes(cap):
+    return [min(cap, rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 70000), rnd.randrange(60000, 131073), 65536, 4096, 131072])) for _ in range(n)]
+bad = 0; t0 = time.time()
+for level in (1, 2, 3):
+    datas = [gen(s) for s in sizes(131072)]
+    outs = zj.compress_batch(datas, level)
+    for k, (d, z) in enumerate(zip(datas, outs)):
+        want = ref.compress(d, 3, False, 14, 13) if level == 3 else ref.compress(d, level)
+        if isinstance(z, Exception) or z != want:
+            bad += 1; print("MISMATCH plain", level, k, len(d), z if isinstance(z, Exception) else len(z), flush=True)
+    back = zj.decompress_batch([z for z in outs if not isinstance(z, Exception)], [len(d) for d, z in zip(datas, outs) if not isinstance(z, Exception)])
+    bad += sum(1 for b, d in zip(back, datas) if b != d)
+    print(f"level {level}: {n} frames done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+datas = [gen(s) for s in sizes(131072)]
+for hl, cl in ((16, 15), (17, 16), (9, 12)):
+    outs = zj.compress_batch(datas, 3, hash_log=hl, chain_log=cl)
+    for k, (d, z) in enumerate(zip(datas, outs)):
+        if isinstance(z, Exception) or z != ref.compress(d, 3, False, hl, cl):
+            bad += 1; print("MISMATCH tuned", hl, cl, k, len(d), flush=True)
+    print(f"tables {hl}/{cl}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+samples = [b",".join(recs[i * 13:i * 13 + 200])[:4096] for i in range(1000)]
+for dbytes in (ref.train_dict(samples, 112640), b",".join(recs[:300])):
+    for level in (1, 3):
+        rcd = ref.CDict(dbytes, level)
+        with zj.ZstdDictCompress(dbytes, level) as cd, zj.ZstdDictDecompress(dbytes) as dd:
+            cut = 16384 if level == 3 else 8192
+            datas = [gen(s) for s in sizes(cut)]
+            outs = zj.compress_batch(datas, dictionary=cd)
+            for k, (d, z) in enumerate(zip(datas, outs)):
+                if isinstance(z, Exception) or z != rcd.compress(d):
+                    bad += 1; print("MISMATCH dict", level, k, len(d), flush=True)
+            back = zj.decompress_batch(outs, [len(d) for d in datas], dd)
+            bad += sum(1 for b, d in zip(back, datas) if b != d)
+        print(f"dict level {level}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+print("GPU-FUZZ", "OK" if bad == 0 else "FAILED", "bad", bad)
