@@ -13,11 +13,15 @@
 // size <= 128 KiB, and for level 3 whenever the level's tables fit the LDS budget (srcSize <= 8 KiB);
 // above that, level 3 runs the reference's double-fast with hashLog/chainLog = 14/13 — byte-identical
 // to the reference called with ZstdCompressCtx.setHashLog(14).setChainLog(13) (SURVEY.md Appendix B.2:
-// +0.44 % size on Silesia xml, inside the 1 % gate).
+// +0.44 % size on Silesia xml, inside the 1 % gate).  On the lane-per-frame path the tables live in HBM, so explicit
+// ZSTD_c_hashLog / ZSTD_c_chainLog (the "level word", ze_params_of) are honoured there: 16 / 15 gives the reference's plain
+// level 3.  With a dictionary (zj_cdict.h) frames are byte-identical to ZSTD_CCtx_refCDict + ZSTD_compress2.
 //
-// LDS: the match-finder hash tables (position+1, u16 for buffers <= 64 KiB else u32) own the LDS
-// during match finding; the entropy stage (histograms, Huffman tree, tANS tables) overlays the same
-// bytes afterwards.  HBM scratch per workgroup: literals, sequence records, block body.
+// LDS (fused small-batch kernel): the match-finder hash tables (position+1, u16 for buffers <= 64 KiB else u32) own the
+// LDS during match finding; the entropy stage (histograms, Huffman tree, tANS tables) overlays the same bytes
+// afterwards.  HBM scratch per workgroup: literals, sequence records, block body.  Large batches find the sequences
+// beforehand, lane per frame (zj_match_lane.h), and this file's ze_compress_t runs the entropy stage on them (`pre`);
+// frames <= 4 KiB are then staged, gathered and assembled in LDS when the launch provides the room.
 #pragma once
 #include "zj_common.h"
 
