@@ -128,10 +128,13 @@ def main():
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
         e0.record(); B.compress(src, src_off, comp, comp_off, level, csz); e1.record()
         B.pack(csz, comp, comp_off, out=packed, out_off=packed_off); e2.record()      # frames back to back
-        B.decompress(packed, packed_off, back, src_off, dsz); e3.record()
-        if world > 1 and not a.no_gather:
+        handle = None
+        if world > 1 and not a.no_gather:                   # posted before the local decompress: xGMI transfers run beside it
             total = int(packed_off[-1].item())
-            shard.gather_packed(packed[:total], csz, dst=0)
+            handle = shard.gather_packed_start(packed[:total], csz, dst=0)
+        B.decompress(packed, packed_off, back, src_off, dsz); e3.record()
+        if handle is not None:
+            shard.gather_packed_finish(handle)
         e4.record()
         if timed:
             torch.cuda.synchronize()

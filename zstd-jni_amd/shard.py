@@ -32,12 +32,12 @@ def gather_sizes(sizes):
     return [o[: int(c.item())] for o, c in zip(outs, counts)]
 
 
-def gather_packed(packed, sizes, dst=0):
-    """Gather every rank's packed compressed bytes on `dst`.
+def gather_packed_start(packed, sizes, dst=0):
+    """Post the gather of every rank's packed compressed bytes on `dst` and return a handle; the transfers run on the
+    backend's own stream, so work enqueued afterwards on the caller's stream (the local decompress) overlaps them.
+    `packed` must stay untouched until gather_packed_finish(handle).
 
-    packed: uint8[sum(sizes)] (this rank's frames back to back), sizes: int64[n_local].
-    On `dst` returns (blob uint8[total], offsets int64[n_total+1]) with ranks concatenated in rank
-    order — i.e. buffer order of the original batch; elsewhere returns (None, None)."""
+    packed: uint8[sum(sizes)] (this rank's frames back to back), sizes: int64[n_local]."""
     world, rank = dist.get_world_size(), dist.get_rank()
     all_sizes = gather_sizes(sizes.clamp(min=0))
     totals = [int(s.sum().item()) for s in all_sizes]
@@ -51,14 +51,28 @@ def gather_packed(packed, sizes, dst=0):
             elif totals[r]:
                 ops.append(dist.P2POp(dist.irecv, view, r))
             pos += totals[r]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        cat = torch.cat(all_sizes)
-        off = torch.zeros(cat.numel() + 1, dtype=torch.int64, device=packed.device)
-        off[1:] = torch.cumsum(cat, 0)
-        return blob, off
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return {"works": works, "blob": blob, "sizes": all_sizes, "keep": None}
+    works, keep = [], None
     if totals[rank]:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed[: totals[rank]].contiguous(), dst)]):
-            w.wait()
-    return None, None
+        keep = packed[: totals[rank]].contiguous()
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, keep, dst)])
+    return {"works": works, "blob": None, "sizes": all_sizes, "keep": keep}
+
+
+def gather_packed_finish(handle):
+    """Wait for the transfers of gather_packed_start.  On the destination rank returns (blob uint8[total], offsets
+    int64[n_total+1]) with ranks concatenated in rank order — i.e. buffer order of the original batch; elsewhere (None, None)."""
+    for w in handle["works"]:
+        w.wait()
+    if handle["blob"] is None:
+        return None, None
+    cat = torch.cat(handle["sizes"])
+    off = torch.zeros(cat.numel() + 1, dtype=torch.int64, device=handle["blob"].device)
+    off[1:] = torch.cumsum(cat, 0)
+    return handle["blob"], off
+
+
+def gather_packed(packed, sizes, dst=0):
+    """gather_packed_start + gather_packed_finish."""
+    return gather_packed_finish(gather_packed_start(packed, sizes, dst))
