@@ -105,6 +105,16 @@ def test_gpu_explicit_table_sizes(gpu, oracle_ref):
         assert e.value.getErrorCode() == 42
 
 
+def test_gpu_level_zero_is_the_default_level(gpu, oracle_ref):
+    """ZSTD_c_compressionLevel = 0 means ZSTD_CLEVEL_DEFAULT (3): ZstdCompressCtx.setLevel(0), ZstdDictCompress(dict, 0)"""
+    d = gpu.synth_host(30000, 5, 1)
+    with gpu.ZstdCompressCtx() as ctx:
+        assert ctx.setLevel(0).compress(d) == ref_expected(oracle_ref, d, 3)
+    dbytes = gpu.synth_host(20000, 9, 1)
+    with gpu.ZstdDictCompress(dbytes, 0) as cd:
+        assert gpu.compress_batch([d[:4000]], dictionary=cd)[0] == oracle_ref.CDict(dbytes, 0).compress(d[:4000])
+
+
 def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     data = gpu.synth_host(30000, 1, 1)
     ctx = gpu.ZstdCompressCtx().setLevel(3)

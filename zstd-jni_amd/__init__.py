@@ -408,7 +408,7 @@ class ZstdDictCompress(_AutoClose):
         self._level = level
         self._ptr = lib().zjni_createCDict(data, len(data), level)
         if not self._ptr:
-            raise ZstdException(30 if 1 <= level <= 3 else 42)   # the Java class throws IllegalStateException("ZSTD_createCDict failed")
+            raise ZstdException(30 if 0 <= level <= 3 else 42)   # the Java class throws IllegalStateException("ZSTD_createCDict failed")
 
     def level(self):                                             # J/ZstdDictCompress.java:110
         return self._level

@@ -833,11 +833,13 @@ static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, voi
 }
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream) {
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
 }
 size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                    uint64_t* d_result, size_t n, int level, int checksum, void* stream) {
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
@@ -853,6 +855,7 @@ static size_t level_word(int level, int hashLog, int chainLog, int* out) {
 }
 size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                            uint64_t* d_result, size_t n, int level, int checksum, int hashLog, int chainLog, void* stream) {
+    if (level == 0) level = 3;
     int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
     if (e) return e;
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, lw, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
@@ -863,6 +866,7 @@ size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_
 // or the dictionary is bad.
 zjni_cdict* zjni_createCDict(const void* dict, size_t dictSize, int level) {
     DevState* d = cur_state();
+    if (level == 0) level = 3;                        // ZSTD_createCDict: 0 = ZSTD_CLEVEL_DEFAULT
     if (!d || !dict || dictSize < 8 || dictSize > 0x3FFFFFFFull || level < 1 || level > 3) return nullptr;
     ZEParams const cp = ze_cdict_params((u32)level, (u32)dictSize);
     size_t const head = (sizeof(ZECDictDev) + 15) & ~(size_t)15, tablesBytes = (size_t)ze_cdict_table_entries(cp) * 4u;
@@ -1004,11 +1008,13 @@ size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize, void
     return host_batch(false, src, srcSize, dst, dstCap, result, n, 0);
 }
 size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level) {
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level);
 }
 
 size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level, int checksum) {
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum);
 }
@@ -1017,6 +1023,7 @@ size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSiz
                                     int level, int checksum, int hashLog, int chainLog) {
     int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
     if (e) return e;
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, lw, checksum);
 }
