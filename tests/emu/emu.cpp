@@ -90,6 +90,17 @@ extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned sr
     return r;
 }
 extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return ze_lds_need(level, srcSize); }
+// closed-form code / extra-bit functions against the format's tables, every input; returns the number of differences
+extern "C" unsigned emu_check_code_tables() {
+    unsigned bad = 0;
+    for (u32 v = 0; v < (1u << 17) + 8u; v++) {
+        if ((v > 63 ? zj_hibit(v) + 19 : ze_k_ll_code[v]) != ze_ll_code(v)) bad++;
+        if ((v > 127 ? zj_hibit(v) + 36 : ze_k_ml_code[v]) != ze_ml_code(v)) bad++;
+    }
+    for (u32 c = 0; c < 36; c++) if (ze_k_ll_bits[c] != ze_ll_bits_of(c)) bad++;
+    for (u32 c = 0; c < 53; c++) if (ze_k_ml_bits[c] != ze_ml_bits_of(c)) bad++;
+    return bad;
+}
 
 // split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
 // kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout

@@ -58,6 +58,13 @@ def test_emu_split_pipeline_matches(emu, oracle_ref, zj):
             assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
 
 
+def test_code_tables_closed_form(emu):
+    """ZSTD_LLcode / ZSTD_MLcode / LL_bits / ML_bits as arithmetic == the format's tables (N/common/zstd_internal.h:114-140,
+    N/compress/zstd_compress_internal.h:584-616), every input"""
+    emu.emu_check_code_tables.restype = __import__("ctypes").c_uint
+    assert emu.emu_check_code_tables() == 0
+
+
 def test_emu_explicit_table_sizes(emu, oracle_ref, zj):
     """ZstdCompressCtx.setHashLog / setChainLog on the lane-per-frame path: byte-identical to the reference given the same
     ZSTD_c_hashLog / ZSTD_c_chainLog; 16 / 15 is the reference's plain level 3"""

@@ -139,6 +139,16 @@ ZJ_DEV u64 grp_ballot(const G& g, bool pred) {
 #endif
 }
 
+// lane k's value in every lane (k wave-uniform; lane-serial build: the value itself)
+template <class G>
+ZJ_DEV u32 grp_bcast(const G& g, u32 v, u32 k) {
+#if ZJ_ON_GPU
+    (void)g; return (u32)__builtin_amdgcn_readlane((int)v, (int)k);
+#else
+    (void)g; (void)k; return v;
+#endif
+}
+
 // inclusive scan of a[0..n) (n <= W, array in the group's LDS), result in place
 template <class G>
 ZJ_DEV void grp_scan_incl(const G& g, u32* a, u32 n) {

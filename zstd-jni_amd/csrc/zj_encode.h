@@ -104,8 +104,28 @@ ZE_CONST u8 ze_k_ml_code[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18
     42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
 ZE_CONST u32 ze_k_rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
 
-ZJ_DEV u32 ze_ll_code(u32 v) { return v > 63 ? zj_hibit(v) + 19 : ze_k_ll_code[v]; }      // ZSTD_LLcode
-ZJ_DEV u32 ze_ml_code(u32 v) { return v > 127 ? zj_hibit(v) + 36 : ze_k_ml_code[v]; }     // ZSTD_MLcode (v = ml - 3)
+// ZSTD_LLcode / ZSTD_MLcode (v = ml - 3) and LL_bits / ML_bits in closed form: the tables above as arithmetic, so a lane
+// does not wait for a constant-memory load per sequence (checked against the tables for every input:
+// tests/test_emu_encode.py::test_code_tables_closed_form)
+ZJ_HD u32 ze_ll_code(u32 v) {
+    if (v < 16) return v;
+    if (v < 24) return 16 + ((v - 16) >> 1);
+    if (v < 32) return 20 + ((v - 24) >> 2);
+    if (v < 48) return 22 + ((v - 32) >> 3);
+    if (v < 64) return 24;
+    return zj_hibit(v) + 19;
+}
+ZJ_HD u32 ze_ml_code(u32 v) {
+    if (v < 32) return v;
+    if (v < 40) return 32 + ((v - 32) >> 1);
+    if (v < 48) return 36 + ((v - 40) >> 2);
+    if (v < 64) return 38 + ((v - 48) >> 3);
+    if (v < 96) return 40 + ((v - 64) >> 4);
+    if (v < 128) return 42;
+    return zj_hibit(v) + 36;
+}
+ZJ_HD u32 ze_ll_bits_of(u32 c) { return c < 16 ? 0u : (c >= 25 ? c - 19u : (u32)((0x433221111ull >> (4u * (c - 16u))) & 0xFu)); }
+ZJ_HD u32 ze_ml_bits_of(u32 c) { return c < 32 ? 0u : (c >= 43 ? c - 36u : (u32)((0x54433221111ull >> (4u * (c - 32u))) & 0xFu)); }
 
 // ------------------------------------------------------------------ parameters --------------
 // N/compress/clevels.h:81-83,107-109 + ZSTD_adjustCParams_internal (N/compress/zstd_compress.c:1553-1572)
@@ -741,19 +761,37 @@ ZJ_DEV u32 ze_stage_finish(const G& g, ZEStageBits& st) {
 // whole wave: lane l takes 32 symbols, a prefix sum of chunk bit lengths gives its offset.
 // `codes` = e.val | e.nbBits << 16 per symbol (LDS), `stage` = >= 1024 zeroable LDS words.
 #define ZE_HUF_CHUNK 32u
+// up to 32 symbols lit[beg .. beg+cnt) into four words (symbol i = byte i); full chunks take four 8-byte loads
+ZJ_DEV void ze_chunk_load(const u8* lit, u32 beg, u32 cnt, u64& c0, u64& c1, u64& c2, u64& c3) {
+    if (cnt == ZE_HUF_CHUNK) { c0 = ld64(lit + beg); c1 = ld64(lit + beg + 8); c2 = ld64(lit + beg + 16); c3 = ld64(lit + beg + 24); return; }
+    c0 = c1 = c2 = c3 = 0;
+    for (u32 i = 0; i < cnt; i++) {
+        u64 const b = (u64)lit[beg + i] << (8 * (i & 7));
+        if (i < 8) c0 |= b; else if (i < 16) c1 |= b; else if (i < 24) c2 |= b; else c3 |= b;
+    }
+}
+ZJ_DEV u32 ze_chunk_byte(u64 c0, u64 c1, u64 c2, u64 c3, u32 i) {      // i is a compile-time constant after unrolling
+    u64 const w = i < 8 ? c0 : (i < 16 ? c1 : (i < 24 ? c2 : c3));
+    return (u32)(w >> (8 * (i & 7))) & 0xFFu;
+}
 template <class G>
 ZJ_DEV u32 ze_huf_encode_wave(const G& g, ZEncShared& sh, const u32* codes, u32* stage, u32* lb, u8* dst, const u8* lit, u32 n) {
     ZEStageBits st; st.w = stage; st.dst = dst; st.flushedWords = 0; st.carryBits = 0;
     GRP_FOR(g, i, 1024) stage[i] = 0;
     g.sync();
     u32 const R = 64u * ZE_HUF_CHUNK;
+    u64 cw0 = 0, cw1 = 0, cw2 = 0, cw3 = 0;               // a lane's 32 symbols: fetched once per round (4 loads), used by both passes
     for (u32 hi = n; hi > 0; ) {
         u32 const take = zj_min(R, hi);
         // pass 1: bit length of every lane's chunk (lane 0 = the last symbols = lowest bit positions)
         GRP_FOR(g, l, 64) {
             u32 const end = hi > l * ZE_HUF_CHUNK ? hi - l * ZE_HUF_CHUNK : 0, beg = hi > (l + 1) * ZE_HUF_CHUNK ? hi - (l + 1) * ZE_HUF_CHUNK : 0;
+            ze_chunk_load(lit, beg, end - beg, cw0, cw1, cw2, cw3);
             u32 bits = 0;
-            for (u32 i = beg; i < end; i++) bits += codes[lit[i]] >> 16;
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+            for (u32 i = 0; i < ZE_HUF_CHUNK; i++) if (i < end - beg) bits += codes[ze_chunk_byte(cw0, cw1, cw2, cw3, i)] >> 16;
             lb[l] = bits;
         }
         g.sync();
@@ -764,12 +802,19 @@ ZJ_DEV u32 ze_huf_encode_wave(const G& g, ZEncShared& sh, const u32* codes, u32*
         // pass 2: emit
         GRP_FOR(g, l, 64) {
             u32 const end = hi > l * ZE_HUF_CHUNK ? hi - l * ZE_HUF_CHUNK : 0, beg = hi > (l + 1) * ZE_HUF_CHUNK ? hi - (l + 1) * ZE_HUF_CHUNK : 0;
+            if (G::W == 1) ze_chunk_load(lit, beg, end - beg, cw0, cw1, cw2, cw3);     // lane-serial build: one lane plays all 64
             u32 pos = st.carryBits + (l ? lb[l - 1] : 0);
             u32 idx = pos >> 5, nb = pos & 31; u64 acc = 0;
-            for (u32 i = end; i > beg; i--) {
-                u32 const c = codes[lit[i - 1]];
-                acc |= (u64)(c & 0xFFFF) << nb; nb += c >> 16;
-                if (nb >= 32) { atomicOr(&stage[idx++], (u32)acc); acc >>= 32; nb -= 32; }
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+            for (u32 r = 0; r < ZE_HUF_CHUNK; r++) {
+                u32 const i = ZE_HUF_CHUNK - 1u - r;                 // last symbol of the chunk first
+                if (i < end - beg) {
+                    u32 const c = codes[ze_chunk_byte(cw0, cw1, cw2, cw3, i)];
+                    acc |= (u64)(c & 0xFFFF) << nb; nb += c >> 16;
+                    if (nb >= 32) { atomicOr(&stage[idx++], (u32)acc); acc >>= 32; nb -= 32; }
+                }
             }
             if (nb && (u32)acc) atomicOr(&stage[idx], (u32)acc);
         }
@@ -781,6 +826,20 @@ ZJ_DEV u32 ze_huf_encode_wave(const G& g, ZEncShared& sh, const u32* codes, u32*
     GRP_SERIAL(g) { atomicOr(&stage[st.carryBits >> 5], 1u << (st.carryBits & 31)); }    // end mark
     st.carryBits += 1;
     return ze_stage_finish(g, st);
+}
+
+// byte histogram of p[0..cnt) into h[256] (LDS): 8 literals per load
+template <class G>
+ZJ_DEV void ze_hist_add(const G& g, u32* h, const u8* p, u32 cnt) {
+    u32 const words = cnt >> 3;
+    GRP_FOR(g, w, words) {
+        u64 const v = ld64(p + 8 * w);
+#if ZJ_ON_GPU
+#pragma unroll
+#endif
+        for (u32 b = 0; b < 8; b++) atomicAdd(&h[(u32)(v >> (8 * b)) & 0xFFu], 1u);
+    }
+    GRP_FOR(g, i, cnt & 7u) atomicAdd(&h[p[(words << 3) + i]], 1u);
 }
 
 // raw / rle literal sections (zstd_compress_literals.c:39-127)
@@ -904,28 +963,43 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         u32 const nbSeq = ZJ_UNI(sh.nbSeq), litSize = ZJ_UNI(sh.litSize), lastLL = ZJ_UNI(sh.lastLL);
         // ---- gather literals into HBM scratch + sequence codes (all lanes) ----
         {   const u32* const litOff = pre ? pre->litOff : (const u32*)(ws + ZE_WS_BODY);   // body scratch is free until the entropy stage
-            GRP_FOR(g, i, nbSeq) {
-                ZESeq s = seqs[i];
-                u32 const ll = s.ll, o = litOff[i];
-                if (ll <= 64) { for (u32 k = 0; k < ll; k++) litBuf[o + k] = src[s.pos + k]; }
-                s.ll = ll | (ze_ll_code(ll) << 24);
-                s.ml = s.ml | (ze_ml_code(s.ml - 3) << 24);
-                s.off = s.off | (zj_hibit(s.off) << 24);
-                seqs[i] = s;
-                if (i == 0) { sh.edge[0] = s.ll >> 24; sh.edge[1] = s.off >> 24; sh.edge[2] = s.ml >> 24; }
-                if (i == nbSeq - 1) { sh.edge[3] = s.ll >> 24; sh.edge[4] = s.off >> 24; sh.edge[5] = s.ml >> 24; }
-            }
-            zj_mem_order();
-            g.sync();
-            for (u32 base = 0; base < nbSeq; base += (u32)G::W) {                  // long literal runs: cooperative
-                u32 const i = base + g.lane();
-                u32 const myLL = i < nbSeq ? ZE_LOW24(seqs[i].ll) : 0;
-                u64 m = grp_ballot(g, myLL > 64);
+            for (u32 base = 0; base < nbSeq; base += 2u * (u32)G::W) {
+              ZESeq sA, sB; u32 oA = 0, oB = 0;                           // two records per lane per pass: both requested before either is used
+              sA.ll = sA.ml = sA.off = sA.pos = 0; sB = sA;
+              {   u32 const iA = base + g.lane(), iB = iA + (u32)G::W;
+                  if (iA < nbSeq) { sA = seqs[iA]; oA = litOff[iA]; }
+                  if (iB < nbSeq) { sB = seqs[iB]; oB = litOff[iB]; } }
+              for (u32 half = 0; half < 2u; half++) {
+                u32 const i = base + half * (u32)G::W + g.lane();
+                u32 ll = 0, o = 0, p = 0;
+                if (i < nbSeq) {
+                    ZESeq s = half ? sB : sA;
+                    ll = s.ll; o = half ? oB : oA; p = s.pos;
+                    if (ll <= 64) {                                            // short run: this lane, 8 bytes per load
+                        u32 k = 0;
+                        for (; k + 8 <= ll; k += 8) st64(litBuf + o + k, ld64(src + p + k));
+                        u32 const r = ll - k;
+                        if (r) {
+                            u64 w = 0;
+                            if (p + k + 8 <= srcSize) w = ld64(src + p + k);
+                            else for (u32 j = 0; j < r; j++) w |= (u64)src[p + k + j] << (8 * j);
+                            for (u32 j = 0; j < r; j++) litBuf[o + k + j] = (u8)(w >> (8 * j));
+                        }
+                    }
+                    s.ll = ll | (ze_ll_code(ll) << 24);
+                    s.ml = s.ml | (ze_ml_code(s.ml - 3) << 24);
+                    s.off = s.off | (zj_hibit(s.off) << 24);
+                    seqs[i] = s;
+                    if (i == 0) { sh.edge[0] = s.ll >> 24; sh.edge[1] = s.off >> 24; sh.edge[2] = s.ml >> 24; }
+                    if (i == nbSeq - 1) { sh.edge[3] = s.ll >> 24; sh.edge[4] = s.off >> 24; sh.edge[5] = s.ml >> 24; }
+                }
+                u64 m = grp_ballot(g, ll > 64);                                // long runs: the whole wave, one after the other
                 while (m) {
                     u32 const k = (u32)__builtin_ctzll(m); m &= m - 1;
-                    u32 const ll = ZJ_UNI(ZE_LOW24(seqs[base + k].ll)), o = ZJ_UNI(litOff[base + k]), p = ZJ_UNI(seqs[base + k].pos);
-                    GRP_FOR(g, q, ll) litBuf[o + q] = src[p + q];
+                    u32 const llk = grp_bcast(g, ll, k), ok = grp_bcast(g, o, k), pk = grp_bcast(g, p, k);
+                    GRP_FOR(g, q, llk) litBuf[ok + q] = src[pk + q];
                 }
+              }
             }
             GRP_FOR(g, k, lastLL) litBuf[litSize - lastLL + k] = src[srcSize - lastLL + k];
             zj_mem_order();
@@ -959,9 +1033,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 }
             }
             if (mode == 2) {
-                if (single) { GRP_FOR(g, i, n) atomicAdd(&e.hist[0][litBuf[i]], 1u); }
+                if (single) ze_hist_add(g, e.hist[0], litBuf, n);
                 else {
-                    for (u32 t = 0; t < 4; t++) { u32 const cnt = t < 3 ? seg : n - 3 * seg; const u8* const lp = litBuf + t * seg; GRP_FOR(g, i, cnt) atomicAdd(&e.hist[t][lp[i]], 1u); }
+                    for (u32 t = 0; t < 4; t++) ze_hist_add(g, e.hist[t], litBuf + t * seg, t < 3 ? seg : n - 3 * seg);
                 }
                 GRP_SERIAL(g) { sh.tmp[6] = 0; sh.tmp[7] = 0; sh.strBytes[0] = 0; sh.strBytes[1] = 0; sh.strBytes[2] = 0; sh.strBytes[3] = 0; }
                 g.sync();
@@ -1145,11 +1219,16 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 GRP_FOR(g, i, 1024) st.w[i] = 0;
                 GRP_SERIAL(g) { body[seqHead] = (u8)((sh.seqType[0] << 6) + (sh.seqType[1] << 4) + (sh.seqType[2] << 2)); }
                 g.sync();
+                ZESeq qNext; qNext.ll = 0; qNext.ml = 0; qNext.off = 0; qNext.pos = 0;   // the batch after this one, requested a batch ahead
+                {   u32 const c0 = zj_min(64u, nbSeq), l0 = nbSeq - c0;
+                    if (G::W > 1 && g.lane() < c0) qNext = seqs[l0 + g.lane()]; }
                 for (u32 hi = nbSeq; hi > 0 && !over; ) {
                     u32 const cnt = zj_min(64u, hi), lo = hi - cnt;
                     bool const firstBatch = (hi == nbSeq);
+                    ZESeq const qCur = qNext;
+                    if (G::W > 1 && lo > 0) { u32 const cn = zj_min(64u, lo), ln = lo - cn; if (g.lane() < cn) qNext = seqs[ln + g.lane()]; }
                     GRP_FOR(g, k, cnt) {
-                        ZESeq const q = seqs[lo + k]; e.stage[k] = q;
+                        ZESeq const q = (G::W > 1) ? qCur : seqs[lo + k]; e.stage[k] = q;
                         u32 const cLL = q.ll >> 24, cOF = q.off >> 24, cML = q.ml >> 24;
                         dn[k] = e.ct[0].deltaNbBits[cLL]; df[k] = e.ct[0].deltaFind[cLL];
                         dn[64 + k] = e.ct[1].deltaNbBits[cOF]; df[64 + k] = e.ct[1].deltaFind[cOF];
@@ -1199,7 +1278,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                     GRP_FOR(g, k, cnt) {                           // bit count per sequence, in emission order r = cnt-1-k
                         ZESeq const q = e.stage[k];
                         u32 const c = (ob[k] >> 16) + (ob[64 + k] >> 16) + (ob[128 + k] >> 16)
-                                    + ze_k_ll_bits[q.ll >> 24] + ze_k_ml_bits[q.ml >> 24] + (q.off >> 24);
+                                    + ze_ll_bits_of(q.ll >> 24) + ze_ml_bits_of(q.ml >> 24) + (q.off >> 24);
                         lb[cnt - 1 - k] = c;
                     }
                     GRP_FOR(g, k, 64 - cnt) lb[cnt + k] = 0;
@@ -1217,8 +1296,8 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         ZE_PUT(ob[64 + k] & 0xFFFF, ob[64 + k] >> 16);         // OF state
                         ZE_PUT(ob[128 + k] & 0xFFFF, ob[128 + k] >> 16);       // ML state
                         ZE_PUT(ob[k] & 0xFFFF, ob[k] >> 16);                   // LL state
-                        ZE_PUT(ZE_LOW24(q.ll), ze_k_ll_bits[q.ll >> 24]);
-                        ZE_PUT(ZE_LOW24(q.ml) - 3, ze_k_ml_bits[q.ml >> 24]);
+                        ZE_PUT(ZE_LOW24(q.ll), ze_ll_bits_of(q.ll >> 24));
+                        ZE_PUT(ZE_LOW24(q.ml) - 3, ze_ml_bits_of(q.ml >> 24));
                         ZE_PUT(ZE_LOW24(q.off), q.off >> 24);
 #undef ZE_PUT
                         ze_or_bits(st.w, bitpos, lo64, hi64, nb);
