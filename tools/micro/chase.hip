@@ -32,6 +32,20 @@ int main(int argc, char** argv) {
     size_t const bytes = (size_t)maxWaves * 64 * entries * 4;
     hipMalloc(&mem, bytes); hipMemset(mem, 0, bytes); hipMalloc(&sink, maxWaves * 64 * 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    if (argc > 1 && argv[1][0] == 's') {   // "sweep": request rate against chains in flight (1, 2, 4 waves per SIMD), private 96 KiB regions
+        u32 const big = 4096; u32* m2; u32* s2;
+        size_t const b2 = (size_t)big * 64 * entries * 4;
+        if (hipMalloc(&m2, b2) != hipSuccess) { printf("no memory for the sweep\n"); return 1; }
+        hipMemset(m2, 0, b2); hipMalloc(&s2, big * 64 * 4);
+        for (int wr = 0; wr < 2; wr++) for (u32 w : {512u, 1024u, 2048u, 4096u}) {
+            chase<<<w, 64>>>(m2, entries, 10, 0, 64, wr, s2);
+            hipEventRecord(a); chase<<<w, 64>>>(m2, entries, steps, 0, 64, wr, s2); hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            double const acc = (double)w * 64 * steps * (wr ? 2 : 1);
+            printf("sweep write %d waves %4u: %7.1f ns/step, %6.1f G requests/s\n", wr, w, ms * 1e6 / steps, acc / (ms * 1e6));
+        }
+        return 0;
+    }
     if (argc > 1) {      // calibration run for rocprofv3 --pmc: one known access count per launch (1024 waves x 64 lanes x steps)
         for (int wr = 0; wr < 2; wr++) { chase<<<1024, 64>>>(mem, entries, steps, 0, 64, wr, sink); hipDeviceSynchronize(); }
         printf("calibration: %llu random 4-byte accesses per launch (launch 1 read-only, launch 2 read+write)\n", (unsigned long long)1024 * 64 * steps);
