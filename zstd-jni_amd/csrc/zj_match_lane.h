@@ -61,7 +61,7 @@ ZJ_DEV u32 zl_common_back8(u64 p, u64 q) { u64 const x = p ^ q; return x ? ((u32
 #define ZL_PROF_T1() ((void)0)
 #define ZL_PROF_T2() ((void)0)
 #endif
-enum { ZL_LOADW = 0, ZL_START, ZL_SEARCH, ZL_SEARCH_B, ZL_COUNT, ZL_BACK, ZL_POST, ZL_DONE };
+enum { ZL_LOADW = 0, ZL_START, ZL_SEARCH, ZL_COUNT, ZL_BACK, ZL_POST, ZL_DONE };
 // ZSTD_hashPtr without the switch on minMatch: every variant is ((bytes << s) * prime) >> (64 - hBits) with a
 // per-frame (s, prime) — minMatch 4 is the 64-bit form of its 32-bit product — and hBits <= 17 only needs the
 // high dword of the product: three 32-bit multiplies, no branches (N/compress/zstd_compress_internal.h:898-960).
@@ -296,17 +296,20 @@ struct ZLaneD {
 };
 
 // ---------------------------------------------------------------------------------------------
-// fast (levels 1-2).  A pair of positions (ip0, ip1) is probed in two rounds: round A writes ip0, reads
-// and writes ip1's entry, fetches the repcode bytes at ip2, the next pair's bytes and ip0's candidate;
-// round B fetches ip1's candidate and the entry of ip2 (which the next pair starts from).
+// fast (levels 1-2), one round per position pair.  The reference's loop body handles the pair (ip0, ip1) and needs, in
+// dependency order, the pair's bytes, its two table entries, and the candidates' bytes; the machine keeps that as a
+// three-deep pipeline: the round that decides pair k fetches the candidates of pair k (entries already known), the table
+// entries of pair k+1 (its bytes already known) and the bytes of pair k+2 (positions follow from the step rule).  Table
+// reads issued a round early see exactly the writes the reference's read would see: the pair's own two writes are done
+// before the loads, and the one write that falls in between (ip2, when ip3's entry shares its bucket) is forwarded.
 template <class E>
 struct ZLaneF {
     typedef typename E::T Ent;
     const u8* src; u32 n, ilimit; Ent* T; ZLHash hT;
     ZEOut o;
     u32 st, cont, lastLL;
-    u32 ip0, ip1, ip2, ip3, anchor, rep1, rep2, step, nextStep, cur0;
-    u64 w0, w1, w2, w3, wIns; u32 eX, eY;
+    u32 ip0, ip1, ip2, ip3, anchor, rep1, rep2, step, nextStep, cur0, period;
+    u64 w0, w1, w2, w3, wIns; u32 eX, eY;                 // eX / eY: table entries of ip0 / ip1 as the reference reads them
     u32 ca, cb, acc, mpos, mLength, offcode, bk;
     bool more, needBack, chk, haveIns;               // wIns/haveIns: the word at cur0 + 2 (first post-insert) when the search round already holds it
 
@@ -314,6 +317,7 @@ struct ZLaneF {
         src = s; n = size; ilimit = size - 8u; hT = zl_hash_of(p.minMatch, p.hashLog); T = (Ent*)table;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = haveIns = false; bk = 0;
+        period = p.hashLog >= 15u ? 4u : 5u;          // measured: level 1 (hashLog 13) 84.0 ms at 5 / 85.3 at 4 / 99.0 at 3; level 2 (hashLog 15) 137.3 / 132.1 / 139.2
         st = ZL_LOADW;
     }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
@@ -336,10 +340,11 @@ struct ZLaneF {
     }
 
     ZL_PROF_MEMBERS
-    // Search rounds (A and B) run every round; count/backward, post-insert/reload and restart take turns
-    // (r mod 5 = 0, 1, 2; see ZLaneD::round).  Period 5 lets both the A-only and the A,B paths meet their slots.
+    // The search state runs every round; count/backward, post-insert/reload and restart take turns (r mod period = 0, 1, 2;
+    // see ZLaneD::round).  With one round per pair the kernel sits at ~80 % of the read+write request plateau
+    // (tools/micro/chase sweep), so the period only trades match-handling latency against code per round.
     ZJ_DEV_MEMBER void round(u32 r) {
-        switch (r % 5u) {
+        switch (period == 4u ? (r & 3u) : (r % 5u)) {           // constant divisors: a run-time modulo would cost a division per round
         case 0: round_t<ZL_EN_COUNT>(); break;
         case 1: round_t<ZL_EN_POST>(); break;
         case 2: round_t<ZL_EN_START>(); break;
@@ -352,24 +357,23 @@ struct ZLaneF {
         u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, ti = 0;
         bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vt = false, m0 = false, m1 = false;
         u32 t0tag = 0, t1tag = 0;
-        bool const on = (st == ZL_SEARCH) || (st == ZL_SEARCH_B) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
+        u32 pa5 = 0, ti2 = 0, ip4 = 0, ip5 = 0; bool v5 = false, vt2 = false;
+        bool const on = (st == ZL_SEARCH) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
                      || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW)) || ((K & ZL_EN_START) && st == ZL_START);
-        if (st == ZL_SEARCH) {                         // round A of a pair
+        if (st == ZL_SEARCH) {
             ZE_COUNT_ITER();
             t0tag = ze_tag4((u32)w0); t1tag = ze_tag4((u32)w1);
             cur0 = ip0;
-            T[zl_hash(hT, w0)] = E::make(ip0 + 1u, t0tag);
-            ti = zl_hash(hT, w1); vt = true;
-            m0 = E::maybe(eX, t0tag);
+            T[zl_hash(hT, w0)] = E::make(ip0 + 1u, t0tag);       // both writes of the pair (ip1's happens on every path of the reference's
+            T[zl_hash(hT, w1)] = E::make(ip1 + 1u, t1tag);       // iteration), in the reference's order, before the next pair's entries are read
+            m0 = E::maybe(eX, t0tag); m1 = E::maybe(eY, t1tag);
             pa0 = ip2 - 1u - rep1; v0 = true;          // byte before the repcode candidate + its 4 bytes
-            pa1 = ip2; pa2 = ip3; v1 = v2 = true;
+            ip4 = ip2 + step; ip5 = ip3 + step;
+            pa1 = ip4; pa2 = ip5; v1 = v2 = true;       // bytes of the pair after next
             pa3 = E::pos(eX) - 1u; v3 = m0;
+            pa5 = E::pos(eY) - 1u; v5 = m1;
             pa4 = ip2 - 1u; v4 = ip2 - ip0 > 8u;         // the byte before ip2 is in w0 unless the step is large
-        } else if (st == ZL_SEARCH_B) {
-            t1tag = ze_tag4((u32)w1);
-            m1 = E::maybe(eY, t1tag);
-            pa3 = E::pos(eY) - 1u; v3 = m1;
-            ti = zl_hash(hT, w2); vt = true;
+            ti = zl_hash(hT, w2); ti2 = zl_hash(hT, w3); vt = vt2 = true;   // entries of the next pair
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
             if (needBack) { vb = true; bp0 = ip0; bp1 = mpos; }
@@ -382,34 +386,36 @@ struct ZLaneF {
             pa0 = ip0; pa1 = ip0 + 1u; v0 = v1 = true;
             pa3 = ip0 - rep2; v3 = chk && rep2 > 0u;
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            ti = zl_hash(hT, w0); vt = true;
+            ti = zl_hash(hT, w0); ti2 = zl_hash(hT, w1); vt = vt2 = true;
+            pa1 = ip2; pa2 = ip3; v1 = v2 = true;
         }
         ZL_PROF_T1();
         if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
         if (!vb) { bp0 = 8; bp1 = 8; }
         if (!vt) ti = 0;
-        u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
+        if (!vt2) ti2 = 0;
+        if (!v5) pa5 = 0;
+        u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4), q5 = zl_fwd_at(n, pa5);
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
-        u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t = 0;
+        u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, rb0 = 0, rb1 = 0; u32 t = 0, t2 = 0;
         if (v0) r0 = ld64(src + q0);
         if (v1) r1 = ld64(src + q1);
         if (v2) r2 = ld64(src + q2);
         if (v3) r3 = ld64(src + q3);
         if (v4) r4 = ld64(src + q4);
+        if (v5) r5 = ld64(src + q5);
         if ((K & ZL_EN_COUNT) && vb) { rb0 = ld64(src + qb0); rb1 = ld64(src + qb1); }
         if (vt) t = (u32)T[ti];
-        ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t, t);
+        if (vt2) t2 = (u32)T[ti2];
+        ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t, t2); ZL_ROUND_FENCE9(r5, r5, r5, r5, r5, r5, r5, t, t2);
         ZL_PROF_T2();
         u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
-        u64 const d4 = zl_fwd_fix(r4, pa4, q4);
+        u64 const d4 = zl_fwd_fix(r4, pa4, q4), d5 = zl_fwd_fix(r5, pa5, q5);
         u64 const b0 = zl_back_fix(rb0, bp0, qb0), b1 = zl_back_fix(rb1, bp1, qb1);
         if (!on) return;
         if (st == ZL_SEARCH) {
-            eY = t;
-            T[ti] = E::make(ip1 + 1u, t1tag);            // written on every path of the reference's iteration
-            w2 = d1; w3 = d2;
             u32 const gap = ip2 - ip0;                       // == step, or step - 1 right after a step increment
-            wIns = w2; haveIns = (gap == 2u);                // cur0 + 2 == ip2 for a match found in this round
+            wIns = w2; haveIns = (gap == 2u);                // cur0 + 2 == ip2 for a match found at ip0 / the repcode position
             u32 const rval = (u32)(d0 >> 8);
             if (((u32)w2 == rval) & (rep1 > 0u)) {
                 ip0 = ip2; mpos = ip0 - rep1;
@@ -419,20 +425,20 @@ struct ZLaneF {
                 begin_count(ip0 + mLength, mpos + mLength, ZC_FOUND); needBack = false; bk = 0; more = false;
             } else if (m0 && (u32)d3 == (u32)w0) {
                 found_at(eX);
-            } else st = ZL_SEARCH_B;
-        } else if (st == ZL_SEARCH_B) {
-            // reference: shift the pair by one (ip0 <- ip1, ip1 <- ip2, ip2 <- ip3), test ip1's candidate
-            u32 const oip2 = ip2, oip3 = ip3;
-            ip0 = ip1; cur0 = ip0;
-            if (m1 && (u32)d3 == (u32)w1) {
-                wIns = w3;                                   // cur0 is the old ip1: cur0 + 2 == ip3 when ip2 == ip0 + 2
-                if (step <= 4u) T[ti] = E::make(oip2 + 1u, ze_tag4((u32)w2));
+            } else if (m1 && (u32)d5 == (u32)w1) {
+                // reference: shift the pair by one (ip0 <- ip1, ip1 <- ip2, ip2 <- ip3), ip1's candidate matched
+                ip0 = ip1; cur0 = ip0;
+                wIns = w3;                                   // cur0 is the old ip1: cur0 + 2 == ip3 when ip2 == old ip0 + 2
+                if (step <= 4u) T[ti] = E::make(ip2 + 1u, ze_tag4((u32)w2));
                 found_at(eY);
             } else {
-                eX = t;
-                ip0 = oip2; ip1 = oip3; ip2 = ip0 + step; ip3 = ip1 + step; w0 = w2; w1 = w3;
+                // next pair: its entries as the reference reads them — ip2's after this pair's writes (done above), ip3's also
+                // after the write of ip2 that the next round starts with
+                u32 const nX = t, nY = (ti2 == ti) ? (u32)E::make(ip2 + 1u, ze_tag4((u32)w2)) : t2;
+                ip0 = ip2; ip1 = ip3; w0 = w2; w1 = w3; eX = nX; eY = nY;
+                ip2 = ip4; ip3 = ip5; w2 = d1; w3 = d2;
                 if (ip2 >= nextStep) { step++; nextStep += 128u; }
-                if (ip3 >= ilimit) finish(); else st = ZL_SEARCH;
+                if (ip3 >= ilimit) finish();
             }
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             u32 const lim = n - ca;
@@ -463,7 +469,8 @@ struct ZLaneF {
             if ((rep2 > 0u) && ((u32)w0 == (u32)d3)) { begin_count(ip0 + 4u, ip0 + 4u - rep2, ZC_REPLOOP); needBack = false; }
             else outer();
         } else if ((K & ZL_EN_START) && st == ZL_START) {
-            eX = t; st = ZL_SEARCH;
+            eX = t; eY = (ti2 == ti) ? (u32)E::make(ip0 + 1u, ze_tag4((u32)w0)) : t2;     // ip1's entry is read after ip0's write
+            w2 = d1; w3 = d2; st = ZL_SEARCH;
         } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
             u32 const limit = zj_min(ip0 - anchor, mpos) - bk;
             u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
