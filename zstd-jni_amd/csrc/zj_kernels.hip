@@ -930,6 +930,10 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     const ZECDictDev* const cd = (const ZECDictDev*)cdict->buf;
     unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
     int pending[2] = {0, 0};
+    auto bail = [&](size_t code) {                       // an error mid-way still orders the caller's stream after the entropy kernels already posted
+        for (int p = 0; p < 2; p++) if (pending[p]) (void)hipStreamWaitEvent(st, d->cdEncDone[p], 0);
+        return code;
+    };
     size_t s = 0;
     for (size_t at = 0; at < n; at += chunk, s++) {
         size_t const m = n - at < chunk ? n - at : chunk;
@@ -938,8 +942,8 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
         u32* const list = d->cdList + (size_t)par * (d->cdListCap + 1024);
         u32* const ctr = d->counters + 32 + 8 * par;              // [0] |list|, [1] unused, [2] entropy work, [4] match work
         const u64* const so = (const u64*)d_src_off + at; const u64* const dofs = (const u64*)d_dst_off + at; u64* const res = (u64*)d_result + at;
-        if (pending[par]) { if (hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); pending[par] = 0; }   // slice s-2 is done with this set
-        if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (pending[par]) { if (hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device)); pending[par] = 0; }   // slice s-2 is done with this set
+        if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
         hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, so, res, (u32)m, 1u, 0xFFFFFFFFu, ctr, list, list);   // every frame <= 128 KiB is listed
         hipLaunchKernelGGL(zj_cdict_zero_tables_kernel, dim3((u32)(m < 16384 ? m : 16384)), dim3(256), 0, st, so, cd, (const u32*)list, (const u32*)ctr, tables);
         u32 const waves = (u32)((m + 63) / 64);
@@ -947,15 +951,15 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
         (void)hipEventRecord(d->tev[0], st);
         hipLaunchKernelGGL(zj_enc_match_dict_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, so, cd, (const u32*)list, (const u32*)ctr, ctr + 4, tables, fscratch, meta);
         (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
-        if (hipEventRecord(d->cdMatchDone[par], st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->cdMatchDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipEventRecord(d->cdMatchDone[par], st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->cdMatchDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
         u32 const gridA = (u32)(m < (size_t)d->encGridSmall ? m : (size_t)d->encGridSmall);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ZE_SMALL_LDS_BYTES, d->sideStream, (const u8*)d_src, so, (u8*)d_dst, dofs, res, (u32)cdict->level,
                            (const u32*)list, (const u32*)ctr, ctr + 2, d->encScratch, eprof, fscratch, ZC_MAX_SRC, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, cd,
                            (u32)ZE_SMALL_LDS_BYTES, 0u, 0xFFFFFFFFu);
-        if (hipEventRecord(d->cdEncDone[par], d->sideStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipEventRecord(d->cdEncDone[par], d->sideStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
         pending[par] = 1;
     }
-    for (int par = 0; par < 2; par++) if (pending[par] && hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    for (int par = 0; par < 2; par++) if (pending[par] && hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 

@@ -63,13 +63,15 @@ typedef struct { jlong cpu; zjni_ddict* gdict; } ZDCtx;                         
 
 /* The parameter natives of class Zstd (setCompressionHashLog, ...) receive a raw context pointer that may also belong to a
  * stream class of the bundled library; the shim's own contexts are told apart by this registry. */
-#define CTX_MAX 8192
+#define CTX_MAX 65536
 static jlong g_ctxs[CTX_MAX];
 static pthread_mutex_t g_ctx_mu = PTHREAD_MUTEX_INITIALIZER;
-static void ctx_track(jlong p, int add) {
+static int ctx_track(jlong p, int add) {            /* 0: registry full (init then fails: an untracked context could be mistaken for a stream's) */
+    int ok = 0;
     pthread_mutex_lock(&g_ctx_mu);
-    for (int i = 0; i < CTX_MAX; i++) if (g_ctxs[i] == (add ? 0 : p)) { g_ctxs[i] = add ? p : 0; break; }
+    for (int i = 0; i < CTX_MAX; i++) if (g_ctxs[i] == (add ? 0 : p)) { g_ctxs[i] = add ? p : 0; ok = 1; break; }
     pthread_mutex_unlock(&g_ctx_mu);
+    return ok;
 }
 static int ctx_is_ours(jlong p) {
     int r = 0;
@@ -83,8 +85,8 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* 
     jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_init");
     if (!c) return 0;
     c->level = 3;                                   /* ZSTD_CLEVEL_DEFAULT */
+    if (!ctx_track((jlong)(intptr_t)c, 1)) { free(c); return 0; }
     if (f) c->cpu = f(env, cls);
-    ctx_track((jlong)(intptr_t)c, 1);
     return (jlong)(intptr_t)c;
 }
 /* ZstdCompressCtx.setHashLog / setChainLog -> Zstd.setCompressionHashLog / ChainLog (N/jni_zstd.c:462-475): ZSTD_c_hashLog / ZSTD_c_chainLog */
