@@ -452,7 +452,8 @@ static void huf_sort(Node* node, const u32* count, u32 maxSV) {      /* HUF_sort
     for (n = 0; n <= maxSV; n++) rp[huf_bucket(count[n])].base++;
     for (n = 191; n > 0; n--) { rp[n - 1].base += rp[n].base; rp[n - 1].curr = rp[n - 1].base; }
     for (n = 0; n <= maxSV; n++) { u32 const r = huf_bucket(count[n]) + 1; u32 const pos = rp[r].curr++; node[pos].count = count[n]; node[pos].byte = (u8)n; }
-    for (n = 166; n < 191; n++) { int const sz = rp[n].curr - rp[n].base; if (sz > 1) huf_quicksort(node + rp[n].base, 0, sz - 1); }
+    /* RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) = 165 (not the 166 of the reference's comment): slot 165 holds count == 164 */
+    for (n = 165; n < 191; n++) { int const sz = rp[n].curr - rp[n].base; if (sz > 1) huf_quicksort(node + rp[n].base, 0, sz - 1); }
 }
 
 /* HUF_buildTree + HUF_setMaxHeight + HUF_buildCTableFromTree, huf_compress.c:376-754.

@@ -167,3 +167,13 @@ extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned c
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }
+
+// debugging aid: Huffman weights described at `hdr` (a literals section's tree description); returns the number of symbols
+extern "C" unsigned emu_huf_weights(const unsigned char* hdr, unsigned size, unsigned char* weightsOut, unsigned* logOut) {
+    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    u32 nbSym = 0;
+    u32 const h = zd_huf_read_weights(*sh, hdr, size, &nbSym);
+    if (h) { memcpy(weightsOut, sh->weights, 256); *logOut = sh->hufLog; }
+    free(sh);
+    return h ? nbSym : 0;
+}

@@ -58,6 +58,18 @@ def test_emu_split_pipeline_matches(emu, oracle_ref, zj):
             assert emu_compress(emu, d, level, split=True) == expected(oracle_ref, d, level), (size, level)
 
 
+def test_huf_sort_visits_the_count_164_slot(emu, oracle_ref, oracle_port):
+    """HUF_sort's quicksort loop starts at RANK_POSITION_DISTINCT_COUNT_CUTOFF = 158 + highbit32(158) = 165 (the reference's
+    comment says 166), i.e. at the slot of count == 164: nine or more literals with exactly that count get permuted by the
+    unstable quicksort, which changes which of them receive the longer codes.  tests/golden/huf_sort_count164.bin is the input
+    on which tools/fuzz_emu_encode.py (seed 82) found the restatements starting at 166."""
+    d = golden("huf_sort_count164.bin")
+    for level in (1, 2, 3):
+        want = expected(oracle_ref, d, level)
+        assert emu_compress(emu, d, level) == want and emu_compress(emu, d, level, split=True) == want, level
+        assert oracle_port.compress(d, level, False, 14 if level == 3 else 0, 13 if level == 3 else 0) == want, level
+
+
 def test_code_tables_closed_form(emu):
     """ZSTD_LLcode / ZSTD_MLcode / LL_bits / ML_bits as arithmetic == the format's tables (N/common/zstd_internal.h:114-140,
     N/compress/zstd_compress_internal.h:584-616), every input"""

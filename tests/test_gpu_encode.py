@@ -105,6 +105,14 @@ def test_gpu_explicit_table_sizes(gpu, oracle_ref):
         assert e.value.getErrorCode() == 42
 
 
+def test_gpu_huf_sort_count_164(gpu, oracle_ref):
+    """the input of tests/test_emu_encode.py::test_huf_sort_visits_the_count_164_slot through the C-ABI"""
+    from conftest import golden
+    d = golden("huf_sort_count164.bin")
+    for level in (1, 2, 3):
+        assert gpu.compress_batch([d], level)[0] == ref_expected(oracle_ref, d, level), level
+
+
 def test_gpu_level_zero_is_the_default_level(gpu, oracle_ref):
     """ZSTD_c_compressionLevel = 0 means ZSTD_CLEVEL_DEFAULT (3): ZstdCompressCtx.setLevel(0), ZstdDictCompress(dict, 0)"""
     d = gpu.synth_host(30000, 5, 1)

@@ -595,7 +595,9 @@ ZJ_DEV u32 ze_huf_build(ZEEntropy& e, u32 maxSV, u32 maxNbBits) {
     for (u32 n = 0; n <= maxSV; n++) e.rankBase[ze_huf_bucket(count[n])]++;
     for (u32 n = 191; n > 0; n--) { e.rankBase[n - 1] += e.rankBase[n]; e.rankCurr[n - 1] = e.rankBase[n - 1]; }
     for (u32 n = 0; n <= maxSV; n++) { u32 const r = ze_huf_bucket(count[n]) + 1; u32 const pos = e.rankCurr[r]++; node[pos].count = count[n]; node[pos].byte = (u8)n; }
-    for (u32 n = 166; n < 191; n++) { i32 const sz = (i32)e.rankCurr[n] - (i32)e.rankBase[n]; if (sz > 1) ze_huf_quicksort(e, node + e.rankBase[n], 0, sz - 1); }
+    // RANK_POSITION_DISTINCT_COUNT_CUTOFF evaluates to 158 + highbit32(158) = 165 (the reference's comment says 166): the loop
+    // also visits the slot of count == 164, where nine or more equal counts are permuted by the (unstable) quicksort
+    for (u32 n = 165; n < 191; n++) { i32 const sz = (i32)e.rankCurr[n] - (i32)e.rankBase[n]; if (sz > 1) ze_huf_quicksort(e, node + e.rankBase[n], 0, sz - 1); }
     i32 nonNull = (i32)maxSV; while (node[nonNull].count == 0) nonNull--;
     i32 lowS = nonNull, nodeNb = 256, lowN = 256; i32 const nodeRoot = nodeNb + lowS - 1;
     node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
