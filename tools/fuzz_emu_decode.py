@@ -1,6 +1,6 @@
 """Randomised stress of the three-stage decoder bodies (lane-serial build) against the reference's frames (levels 1-9, with and
 without dictionary / checksum, content up to 300 KB) and, for corrupted frames, against the fused decoder's answer.
-usage: fuzz_emu_decode.py <seed> <seconds>   (4 x 600 s: 769 000 cases, 0 mismatches.)  TEST INFRASTRUCTURE."""
+usage: fuzz_emu_decode.py <seed> <seconds>   (round 1: 3.5 M cases, 0 mismatches.)  TEST INFRASTRUCTURE."""
 import sys, time, random
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
