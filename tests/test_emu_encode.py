@@ -6,7 +6,7 @@ import random
 import pytest
 
 from conftest import golden
-from util import edge_inputs, emu_lib, emu_compress
+from util import edge_inputs, emu_lib, emu_compress, equal_count_inputs
 
 
 @pytest.fixture(scope="module")
@@ -68,6 +68,16 @@ def test_huf_sort_visits_the_count_164_slot(emu, oracle_ref, oracle_port):
         want = expected(oracle_ref, d, level)
         assert emu_compress(emu, d, level) == want and emu_compress(emu, d, level, split=True) == want, level
         assert oracle_port.compress(d, level, False, 14 if level == 3 else 0, 13 if level == 3 else 0) == want, level
+
+
+def test_equal_literal_counts(emu, oracle_ref, oracle_port):
+    """many literals with exactly equal counts: HUF_simpleQuickSort's behaviour on equal keys (every partition peels one
+    element; the iterative side never falls back to insertion sort) reproduced exactly, without overflowing the sort stack"""
+    for name, d in equal_count_inputs():
+        for level in (1, 3):
+            want = expected(oracle_ref, d, level)
+            assert emu_compress(emu, d, level) == want and emu_compress(emu, d, level, split=True) == want, (name, level)
+            assert oracle_port.compress(d, level, False, 14 if level == 3 else 0, 13 if level == 3 else 0) == want, (name, level)
 
 
 def test_code_tables_closed_form(emu):

@@ -113,6 +113,18 @@ def test_gpu_huf_sort_count_164(gpu, oracle_ref):
         assert gpu.compress_batch([d], level)[0] == ref_expected(oracle_ref, d, level), level
 
 
+def test_gpu_equal_literal_counts(gpu, oracle_ref):
+    """tests/test_emu_encode.py::test_equal_literal_counts through the C-ABI (fused kernel and lane pipeline)"""
+    from util import equal_count_inputs
+    items = [d for _, d in equal_count_inputs()]
+    for level in (1, 3):
+        for batch in (items, items * 500):                # 9 frames: fused kernel; 4 500: lane-per-frame pipeline
+            outs = gpu.compress_batch(batch, level)
+            for k, (d, z) in enumerate(zip(batch[:9], outs[:9])):
+                assert z == ref_expected(oracle_ref, d, level), (level, len(batch), k)
+            assert all(outs[k] == outs[k % 9] for k in range(len(outs)))
+
+
 def test_gpu_level_zero_is_the_default_level(gpu, oracle_ref):
     """ZSTD_c_compressionLevel = 0 means ZSTD_CLEVEL_DEFAULT (3): ZstdCompressCtx.setLevel(0), ZstdDictCompress(dict, 0)"""
     d = gpu.synth_host(30000, 5, 1)

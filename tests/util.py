@@ -116,6 +116,19 @@ def emu_compress(L, data, level, split=False, checksum=False, hash_log=0, chain_
     return dst.raw[:r]
 
 
+def equal_count_inputs(seed=7):
+    """shuffled multisets: many literal values with exactly the same count (the Huffman sort's quicksort then peels one
+    element per partition — the case that overflowed the kernels' explicit sort stack), incl. the counts around the
+    sort's bucket boundary (164, 165, 166)"""
+    rnd = random.Random(seed)
+    out = []
+    for a, c in ((98, 166), (99, 165), (40, 164), (12, 164), (130, 20), (256, 255), (256, 64), (9, 1000), (200, 300)):
+        v = [x for x in range(a) for _ in range(c)]
+        rnd.shuffle(v)
+        out.append((f"{a}x{c}", bytes(v)))
+    return out
+
+
 def edge_inputs(seed=1234):
     """(name, bytes) inputs exercising: empty, tiny, RLE block, raw block, 1-stream and 4-stream
     literals, predefined / RLE / compressed FSE modes, long matches, long literal runs, max block."""

@@ -24,6 +24,33 @@ def lowent(n):
         if i and rnd.random()<7/8: out.append(out[i-rnd.randrange(1,min(i,64)+1)])
         else: out.append(rnd.randrange(16))
     return bytes(out)
+def gen_edge(n):
+    """inputs aimed at thresholds of the entropy stage: near-uniform small alphabets, one dominant byte, short periods,
+    literal / sequence counts around the format's size classes"""
+    k = rnd.randrange(6)
+    if k == 0:                                      # uniform over an alphabet of a few to 256 values: many equal counts
+        a = rnd.choice([2, 3, 5, 16, 17, 64, 100, 200, 256]); base = rnd.randrange(0, 257 - a)
+        return bytes(base + rnd.randrange(a) for _ in range(n))
+    if k == 1:                                      # one dominant byte with sprinkles (rle / near-rle literals)
+        b = rnd.randrange(256); p = rnd.choice([0.0, 0.001, 0.01, 0.1])
+        return bytes(b if rnd.random() >= p else rnd.randrange(256) for _ in range(n))
+    if k == 2:                                      # short period with mutations: long matches, repcodes
+        per = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 63, 64, 65, 300])))
+        out = bytearray((per * (n // len(per) + 1))[:n])
+        for _ in range(rnd.choice([0, 1, 5, 50])):
+            if n: out[rnd.randrange(n)] = rnd.getrandbits(8)
+        return bytes(out)
+    if k == 3:                                      # exactly-equal counts: a shuffled multiset
+        a = rnd.choice([9, 12, 40, 130, 256]); c = rnd.choice([1, 2, 20, 163, 164, 165, 166, 255, 256])
+        v = [x for x in range(a) for _ in range(c)][:max(n, 1)]
+        rnd.shuffle(v)
+        return bytes(v[:n])
+    if k == 4:                                      # incompressible head + compressible tail (and the reverse)
+        h = bytes(rnd.getrandbits(8) for _ in range(n // 2)); t = text(n - len(h))
+        return (h + t) if rnd.random() < 0.5 else (t + h)
+    a = gen(n // 3); b = gen_edge(n // 3)
+    return (a + b + gen(n - len(a) - len(b)))[:n]
+EDGE_SIZES = [0, 1, 5, 6, 7, 8, 9, 12, 13, 62, 63, 64, 65, 255, 256, 257, 1022, 1023, 1024, 1025, 4095, 4096, 4097, 16383, 16384, 16385, 65535, 65536, 65537, 131071, 131072]
 def gen(n):
     k = rnd.randrange(6)
     if k==0: return text(n)
@@ -44,12 +71,14 @@ while time.time()-t0 < budget:
     mode = rnd.randrange(3)
     if mode==0:      # plain split path incl. wide, levels 1-3
         n = rnd.choice([rnd.randrange(0,300), rnd.randrange(0,5000), rnd.randrange(0,70000), rnd.randrange(60000,131073), 131072, 65536, 65537])
-        d = gen(n); lvl = rnd.choice([1,2,3])
+        if rnd.random() < 0.3: n = rnd.choice(EDGE_SIZES)
+        d = (gen_edge if rnd.random() < 0.5 else gen)(n); lvl = rnd.choice([1,2,3])
         want = ref.compress(d,3,False,14,13) if lvl==3 else ref.compress(d,lvl)
         got = util.emu_compress(L,d,lvl,split=True)
     elif mode==1:    # tuned tables
         n = rnd.choice([rnd.randrange(0,5000), rnd.randrange(0,70000), rnd.randrange(60000,131073)])
-        d = gen(n); hl=rnd.choice([0,6,9,12,14,15,16,17]); cl=rnd.choice([0,6,9,12,13,15,16])
+        if rnd.random() < 0.3: n = rnd.choice(EDGE_SIZES)
+        d = (gen_edge if rnd.random() < 0.5 else gen)(n); hl=rnd.choice([0,6,9,12,14,15,16,17]); cl=rnd.choice([0,6,9,12,13,15,16])
         if not (hl or cl): hl=16
         want = ref.compress(d,3,False,hl,cl); got = util.emu_compress(L,d,3,split=True,hash_log=hl,chain_log=cl)
     else:
@@ -59,7 +88,8 @@ while time.time()-t0 < budget:
         rc,ec = cds[key]
         cut = 16384 if ec.info()['strategy']==2 else 8192
         n = rnd.choice([rnd.randrange(0,300), rnd.randrange(0,5000), rnd.randrange(0,cut+1), cut])
-        d = gen(n); want = rc.compress(d); got = ec.compress(d)
+        if rnd.random() < 0.3: n = min(cut, rnd.choice(EDGE_SIZES))
+        d = (gen_edge if rnd.random() < 0.5 else gen)(n); want = rc.compress(d); got = ec.compress(d)
     cases+=1
     if want!=got:
         bad+=1

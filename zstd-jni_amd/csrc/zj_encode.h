@@ -571,8 +571,11 @@ ZJ_DEV i32 ze_huf_partition(ZENode* a, i32 low, i32 high) {
     { ZENode t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
     return i + 1;
 }
-// HUF_simpleQuickSort (huf_compress.c:574-591) with the recursion turned into an explicit stack:
-// sub-ranges are disjoint, so deferring the "recursive" call does not change the result.
+// HUF_simpleQuickSort (huf_compress.c:587-607) with the recursion turned into an explicit stack: sub-ranges are disjoint,
+// so deferring the "recursive" call does not change the result.  The recursive call applies the insertion-sort threshold
+// at its entry, the iterative continuation does not; a deferred range below the threshold is sorted on the spot, so only
+// ranges of >= 9 elements are ever stacked (<= 256 / 9 of them) — with equal counts every partition peels one element off
+// and would otherwise stack an empty range per element.
 ZJ_DEV void ze_huf_quicksort(ZEEntropy& e, ZENode* a, i32 low0, i32 high0) {
     i32 sp = 0; e.qsLow[0] = low0; e.qsHigh[0] = high0; sp = 1;
     while (sp > 0) {
@@ -580,8 +583,11 @@ ZJ_DEV void ze_huf_quicksort(ZEEntropy& e, ZENode* a, i32 low0, i32 high0) {
         if (high - low < 8) { ze_huf_insertion(a, low, high); continue; }
         while (low < high) {
             i32 const idx = ze_huf_partition(a, low, high);
-            if (idx - low < high - idx) { e.qsLow[sp] = low; e.qsHigh[sp] = idx - 1; sp++; low = idx + 1; }
-            else { e.qsLow[sp] = idx + 1; e.qsHigh[sp] = high; sp++; high = idx - 1; }
+            i32 lo2, hi2;
+            if (idx - low < high - idx) { lo2 = low; hi2 = idx - 1; low = idx + 1; }
+            else { lo2 = idx + 1; hi2 = high; high = idx - 1; }
+            if (hi2 - lo2 < 8) { if (hi2 > lo2) ze_huf_insertion(a, lo2, hi2); }
+            else { e.qsLow[sp] = lo2; e.qsHigh[sp] = hi2; sp++; }
         }
     }
 }
