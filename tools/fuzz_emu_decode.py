@@ -20,12 +20,37 @@ def gen(n):
         i=rnd.randrange(0,len(recs)-3000); return b",".join(recs[i:i+3000])[:n]
     if k==2: return zj.synth_host(max(n,1), rnd.randrange(1<<20), 1)[:n]
     a=gen(n//2); return (a+gen(n-len(a)))[:n]
+def gen_edge(n):
+    """frames with the block / literal / table modes ordinary data rarely produces: rle and raw blocks, rle literals, predefined
+    and rle tANS tables, overlapping matches with tiny offsets, very long matches"""
+    k = rnd.randrange(5)
+    if k == 0:
+        a = rnd.choice([2, 3, 5, 16, 17, 64, 100, 200, 256]); base = rnd.randrange(0, 257 - a)
+        return bytes(base + rnd.randrange(a) for _ in range(n))
+    if k == 1:
+        b = rnd.randrange(256); p = rnd.choice([0.0, 0.001, 0.01, 0.1])
+        return bytes(b if rnd.random() >= p else rnd.randrange(256) for _ in range(n))
+    if k == 2:
+        per = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 63, 64, 65, 300])))
+        out = bytearray((per * (n // len(per) + 1))[:n])
+        for _ in range(rnd.choice([0, 1, 5, 50])):
+            if n: out[rnd.randrange(n)] = rnd.getrandbits(8)
+        return bytes(out)
+    if k == 3:
+        a = rnd.choice([9, 12, 40, 130, 256]); c = rnd.choice([1, 2, 20, 163, 164, 165, 166, 255, 256])
+        v = [x for x in range(a) for _ in range(c)][:max(n, 1)]
+        rnd.shuffle(v)
+        return bytes(v[:n])
+    a = gen(n // 3); b = gen_edge(n // 3)
+    return (a + b + gen(n - len(a) - len(b)))[:n]
+EDGE_SIZES = [0, 1, 5, 6, 7, 8, 9, 12, 13, 62, 63, 64, 65, 255, 256, 257, 1022, 1023, 1024, 1025, 4095, 4096, 4097, 16383, 16384, 16385, 65535, 65536, 65537, 131071, 131072, 131073, 262144]
 samples=[b",".join(recs[i*13:i*13+200])[:4096] for i in range(1000)]
 dic = ref.train_dict(samples, 60000)
 t0=time.time(); cases=0; bad=0
 while time.time()-t0 < budget:
     n = rnd.choice([rnd.randrange(0,5000), rnd.randrange(0,70000), rnd.randrange(60000,131073), 131072, rnd.randrange(131073, 300000)])
-    d = gen(n); lvl = rnd.choice([1,3,5,9])
+    if rnd.random() < 0.3: n = rnd.choice(EDGE_SIZES)
+    d = (gen_edge if rnd.random() < 0.5 else gen)(n); lvl = rnd.choice([1,3,5,9,19])
     if rnd.random() < 0.3:
         z = ref.compress_using_dict(d, dic, lvl); out = util.emu_decompress_dict(L, z, len(d), dic, split=True)
     else:

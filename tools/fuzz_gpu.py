@@ -12,7 +12,21 @@ seed = int(sys.argv[1]); n = int(sys.argv[2])
 rnd = random.Random(seed)
 recs = util.json_records(20000, seed=seed)
 def gen(size):
-    k = rnd.randrange(4)
+    k = rnd.randrange(7)
+    if k == 4:                                      # uniform small alphabets / exactly equal counts (Huffman sort edge cases)
+        a = rnd.choice([2, 5, 16, 64, 98, 100, 200, 256]); base = rnd.randrange(0, 257 - a)
+        return bytes(base + rnd.randrange(a) for _ in range(size))
+    if k == 5:
+        a = rnd.choice([9, 12, 40, 98, 130, 256]); c = rnd.choice([2, 20, 163, 164, 165, 166, 255, 256])
+        v = [x for x in range(a) for _ in range(c)][:max(size, 1)]
+        rnd.shuffle(v)
+        return bytes(v[:size])
+    if k == 6:                                      # short period with mutations
+        per = os.urandom(rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 63, 64, 65, 300]))
+        out = bytearray((per * (size // len(per) + 1))[:size])
+        for _ in range(rnd.choice([0, 1, 5, 50])):
+            if size: out[rnd.randrange(size)] = rnd.getrandbits(8)
+        return bytes(out)
     if k == 0: return os.urandom(size)
     if k == 1:
         i = rnd.randrange(0, len(recs) - 2000); return b",".join(recs[i:i + 2000])[:size]
