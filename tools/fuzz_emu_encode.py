@@ -66,6 +66,8 @@ samples=[b",".join(recs[i*13:i*13+200])[:4096] for i in range(1000)]
 for dsz in (4096, 30000, 112640):
     dicts.append(ref.train_dict(samples+[text(4096) for _ in range(100)], dsz))
 dicts.append(text(20000)); dicts.append(b",".join(recs[:200]))
+dicts.append(bytes(rnd.getrandbits(8) for _ in range(9)))          # tiny raw dictionaries: every match into them is near the seam
+dicts.append(text(64)); dicts.append(bytes(rnd.getrandbits(8) for _ in range(3000)))
 cds={}
 while time.time()-t0 < budget:
     mode = rnd.randrange(3)
@@ -89,7 +91,16 @@ while time.time()-t0 < budget:
         cut = 16384 if ec.info()['strategy']==2 else 8192
         n = rnd.choice([rnd.randrange(0,300), rnd.randrange(0,5000), rnd.randrange(0,cut+1), cut])
         if rnd.random() < 0.3: n = min(cut, rnd.choice(EDGE_SIZES))
-        d = (gen_edge if rnd.random() < 0.5 else gen)(n); want = rc.compress(d); got = ec.compress(d)
+        d = (gen_edge if rnd.random() < 0.5 else gen)(n)
+        if rnd.random() < 0.3 and n > 16:                          # splice dictionary content in: matches that start in the dictionary,
+            dc = dicts[di][-min(len(dicts[di]), 6000):]            # run over its end into the source, repcodes across the seam
+            out = bytearray(d)
+            for _ in range(rnd.choice([1, 2, 5])):
+                ln = rnd.randrange(4, min(len(dc), n, 300) + 1); a = rnd.randrange(0, len(dc) - ln + 1); b = rnd.randrange(0, n - ln + 1)
+                out[b:b + ln] = dc[a:a + ln]
+            if rnd.random() < 0.3: out[:min(n, 40)] = dc[-min(n, 40):][:min(n, 40)]
+            d = bytes(out)
+        want = rc.compress(d); got = ec.compress(d)
     cases+=1
     if want!=got:
         bad+=1
