@@ -24,10 +24,25 @@ def lowent(n):
         if i and rnd.random()<7/8: out.append(out[i-rnd.randrange(1,min(i,64)+1)])
         else: out.append(rnd.randrange(16))
     return bytes(out)
+def gen_shaped(n):
+    """a stream of (fresh literals, copy of earlier bytes) pairs whose lengths and distances come from very skewed
+    distributions: the LL / ML / OF code histograms get one dominant code plus a tail of rare ones, which is where
+    FSE_normalizeCount's low-probability and secondary paths live"""
+    out = bytearray(bytes(rnd.getrandbits(8) for _ in range(min(n, 40))))
+    dom = (rnd.choice([0, 1, 2, 3, 8]), rnd.choice([4, 5, 6, 7, 8, 12, 35, 67]), rnd.choice([1, 2, 3, 8, 16, 37, 256, 1000]))
+    pd = rnd.choice([0.5, 0.9, 0.97, 0.995])
+    while len(out) < n:
+        if rnd.random() < pd: ll, ml, off = dom
+        else: ll, ml, off = rnd.choice([0, 1, 2, 5, 17, 40, 100, 300]), rnd.choice([4, 5, 6, 9, 20, 50, 130, 600]), rnd.randrange(1, len(out) + 1)
+        out += bytes(rnd.getrandbits(8) for _ in range(ll))
+        off = min(off, len(out))
+        for _ in range(ml): out.append(out[-off])
+    return bytes(out[:n])
 def gen_edge(n):
     """inputs aimed at thresholds of the entropy stage: near-uniform small alphabets, one dominant byte, short periods,
     literal / sequence counts around the format's size classes"""
-    k = rnd.randrange(6)
+    k = rnd.randrange(8)
+    if k >= 6: return gen_shaped(n)
     if k == 0:                                      # uniform over an alphabet of a few to 256 values: many equal counts
         a = rnd.choice([2, 3, 5, 16, 17, 64, 100, 200, 256]); base = rnd.randrange(0, 257 - a)
         return bytes(base + rnd.randrange(a) for _ in range(n))
