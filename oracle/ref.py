@@ -113,6 +113,40 @@ def decompress(frame: bytes, cap: int) -> bytes:
         L.ZSTD_freeDCtx(dctx)
 
 
+PORTABLE_PATH = os.path.join(_HERE, "_ref", "libzstd_ref_portable.so")
+_portable = None
+
+
+def decompress_portable(frame: bytes, cap: int, dictionary: bytes = None) -> bytes:
+    """ZSTD_decompress[_usingDict] of the reference built with its own HUF_DISABLE_FAST_DECODE switch (`make -C oracle refportable`,
+    N/decompress/huf_decompress.c:37): the decoder every platform without the 64-bit fast Huffman loops runs.  It differs from
+    decompress() only on corrupted frames (the fast loops skip the end-of-stream check, huf_decompress.c:873-888 vs :697)."""
+    global _portable
+    if _portable is None:
+        if not os.path.exists(PORTABLE_PATH):
+            raise RuntimeError(f"{PORTABLE_PATH} missing: run `make -C oracle refportable` where /root/reference exists")
+        P = C.CDLL(PORTABLE_PATH)
+        P.ZSTD_isError.restype = C.c_uint
+        P.ZSTD_isError.argtypes = [C.c_size_t]
+        P.ZSTD_getErrorName.restype = C.c_char_p
+        P.ZSTD_getErrorName.argtypes = [C.c_size_t]
+        P.ZSTD_createDCtx.restype = C.c_void_p
+        P.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+        P.ZSTD_decompress_usingDict.restype = C.c_size_t
+        P.ZSTD_decompress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _portable = P
+    P = _portable
+    dctx = P.ZSTD_createDCtx()
+    try:
+        dst = C.create_string_buffer(max(cap, 1))
+        r = P.ZSTD_decompress_usingDict(dctx, dst, cap, frame, len(frame), dictionary, len(dictionary) if dictionary else 0)
+        if P.ZSTD_isError(r):
+            raise ZstdRefError(P.ZSTD_getErrorName(r).decode())
+        return dst.raw[:r]
+    finally:
+        P.ZSTD_freeDCtx(dctx)
+
+
 def compress_using_dict(data: bytes, dictionary: bytes, level: int = 3) -> bytes:
     """ZSTD_compress_usingDict — what Zstd.compressUsingDict / compressFastDict reach (reference N/jni_zstd.c, jni_fast_zstd.c)."""
     L = lib()

@@ -160,7 +160,7 @@ static int fse_build(FseCell* t, const short* norm, u32 maxSV, u32 tableLog) {
 
 /* ---------------------------------------------------------------- Huffman ---------------- */
 typedef struct { u8 nbBits; u8 sym; } HufCell;
-typedef struct { HufCell cell[1 << HUFLOG_MAX]; u32 log; int valid; } HufTable;
+typedef struct { HufCell cell[1 << HUFLOG_MAX]; u32 log; int valid; int x2; } HufTable;   /* x2: the reference decodes it with its double-symbol table */
 
 /* FSE-compressed weights: N/common/fse_decompress.c:166-236 (two interleaved states) */
 static size_t fse_decode_weights(u8* out, size_t outCap, const u8* src, size_t srcSize) {
@@ -229,15 +229,61 @@ static size_t huf_read_table(HufTable* ht, const u8* src, size_t srcSize) {
     return iSize + 1;
 }
 
-/* one backward stream, exactly `n` symbols: N/decompress/huf_decompress.c:600-640 (1X1 body) */
+/* Which of its two table shapes the reference picks for a 4-stream literals section: HUF_selectDecoder,
+ * N/decompress/huf_decompress.c:1793-1843 (timing model: {table build, per-256-symbols} for single / double symbol cells,
+ * by compression-ratio bucket Q).  Both shapes decode a VALID stream to the same bytes; they differ on how a corrupted
+ * stream's last symbol is judged (huf_decode_stream below), so the restatement has to pick the same one. */
+static int huf_select_x2(size_t dstSize, size_t cSrcSize) {
+    static const u16 t[16][4] = {
+        {0,0,1,1}, {0,0,1,1}, {150,216,381,119}, {170,205,514,112}, {177,199,539,110}, {197,194,644,107}, {221,192,735,107},
+        {256,189,881,106}, {359,188,1167,109}, {582,187,1570,114}, {688,187,1712,122}, {825,186,1965,136}, {976,185,2131,150},
+        {1180,186,2070,175}, {1377,185,1731,202}, {1412,185,1695,202} };
+    u32 const q = cSrcSize >= dstSize ? 15u : (u32)(cSrcSize * 16 / dstSize), d256 = (u32)(dstSize >> 8);
+    u32 const t0 = t[q][0] + t[q][1] * d256; u32 t1 = t[q][2] + t[q][3] * d256;
+    t1 += t1 >> 5;
+    return t1 < t0;
+}
+
+/* one backward stream, exactly `n` symbols.  Single-symbol table: N/decompress/huf_decompress.c:600-640 (1X1 body): one code per
+ * step, and the stream must end exactly (:697).
+ * Double-symbol table (x2; HUF_decodeStreamX2 :1308-1349): one CELL per step.  The cell under the cursor (dtLog = 11 bits, zeros
+ * below the stream's first bit) holds two codes when both fit (k1 + k2 <= dtLog, HUF_fillDTableX2 :1117-1177), and then both are
+ * emitted and k1 + k2 bits skipped.  A valid stream decodes to the same bytes either way; a corrupted one is judged differently:
+ *   - a two-code cell whose second code lies in the zero padding overruns the stream (rejected), and
+ *   - when ONE byte is left to produce, HUF_decodeLastSymbolX2 (:1275-1290) emits the cell's first code and, for a two-code
+ *     cell, skips k1 + k2 bits CLAMPED to the end of the stream — up to k2 left-over bits are accepted; with no bit left at all
+ *     the cell index comes from the top of the last-loaded container (BIT_lookBitsFast with a shift of 64 & 63 = 0: the stream's
+ *     first 8 bytes) and nothing is skipped. */
 static int huf_decode_stream(u8* out, size_t n, const u8* src, size_t srcSize, const HufTable* ht) {
     BitR b; size_t i;
     if (bitr_init(&b, src, srcSize)) return -1;
-    for (i = 0; i < n; i++) {
-        HufCell const c = ht->cell[bitr_peek(&b, ht->log)];
-        out[i] = c.sym; b.left -= c.nbBits;
+    if (!ht->x2) {
+        for (i = 0; i < n; i++) {
+            HufCell const c = ht->cell[bitr_peek(&b, ht->log)];
+            out[i] = c.sym; b.left -= c.nbBits;
+        }
+        return b.left == 0 ? 0 : -1;
     }
-    return b.left == 0 ? 0 : -1;
+    {   u32 const D = ht->log > 11 ? ht->log : 11;                     /* HUF_readDTableX2_wksp:1208 builds the table at >= 11 bits */
+        for (i = 0; i < n; ) {
+            int const last = (i + 1 == n);
+            u32 idx; HufCell c1, c2; int two;
+            if (b.left < 0 || (!last && b.left == 0)) return -1;
+            if (b.left > 0) idx = bitr_peek(&b, D);
+            else { u64 c = 0; size_t k; for (k = 0; k < 8 && k < srcSize; k++) c |= (u64)src[k] << (8 * k); idx = (u32)(c >> (64 - D)); }
+            c1 = ht->cell[idx >> (D - ht->log)];
+            c2 = ht->cell[((idx << c1.nbBits) & ((1u << D) - 1)) >> (D - ht->log)];
+            two = (u32)c1.nbBits + c2.nbBits <= D;
+            out[i] = c1.sym;
+            if (last) {
+                if (!two) return b.left == (i64)c1.nbBits ? 0 : -1;
+                return (b.left > 0 && (i64)(c1.nbBits + c2.nbBits) < b.left) ? -1 : 0;
+            }
+            if (two) { out[i + 1] = c2.sym; b.left -= c1.nbBits + c2.nbBits; i += 2; }
+            else { b.left -= c1.nbBits; i += 1; }
+        }
+        return b.left == 0 ? 0 : -1;
+    }
 }
 
 /* ---------------------------------------------------------------- sequences -------------- */
@@ -324,6 +370,9 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
             if (zso_is_error(h)) return ERR(corruption_detected);
             if (h > cLeft) return ERR(corruption_detected);
             ip += h; cLeft -= h;
+            /* table shape: HUF_decompress4X_hufOnly_wksp (huf_decompress.c:1924-1944) asks HUF_selectDecoder with the section's
+             * sizes (tree description included); a single stream always takes the one-symbol table (zstd_decompress_block.c:219) */
+            ds->huf.x2 = single ? 0 : huf_select_x2(n, c);
         }
         if (single) {
             if (huf_decode_stream(ds->lit, n, ip, cLeft, &ds->huf)) return ERR(corruption_detected);

@@ -51,7 +51,8 @@ while time.time()-t0 < budget:
     n = rnd.choice([rnd.randrange(0,5000), rnd.randrange(0,70000), rnd.randrange(60000,131073), 131072, rnd.randrange(131073, 300000)])
     if rnd.random() < 0.3: n = rnd.choice(EDGE_SIZES)
     d = (gen_edge if rnd.random() < 0.5 else gen)(n); lvl = rnd.choice([1,3,5,9,19])
-    if rnd.random() < 0.3:
+    usedDict = rnd.random() < 0.3
+    if usedDict:
         z = ref.compress_using_dict(d, dic, lvl); out = util.emu_decompress_dict(L, z, len(d), dic, split=True)
     else:
         z = ref.compress(d, lvl, checksum=rnd.random()<0.3); out, used = util.emu_decompress_split(L, z, len(d))
@@ -59,8 +60,14 @@ while time.time()-t0 < budget:
     if out != d:
         bad+=1; print('MISMATCH', n, lvl, out if isinstance(out,int) else 'bytes', flush=True)
     # truncated / corrupted: same answer as the fused decoder
-    if len(z) > 12 and rnd.random() < 0.3:
+    if len(z) > 12 and rnd.random() < 0.5:
         zb = bytearray(z); zb[rnd.randrange(6, len(zb))] ^= 1 << rnd.randrange(8)
         a = util.emu_decompress_split(L, bytes(zb), len(d))[0]; b = util.emu_decompress(L, bytes(zb), len(d))
         if a != b: bad+=1; print('ERRDIFF', n, lvl, a if isinstance(a,int) else 'bytes', b if isinstance(b,int) else 'bytes', flush=True)
+        if not usedDict:                                            # and against the reference: both refuse, or both give the same bytes
+            try: r = ref.decompress(bytes(zb), len(d))
+            except ref.ZstdRefError: r = None
+            if (r is None) != isinstance(b, int) or (r is not None and r != b):
+                bad+=1; open(f'/tmp/fuzz_dec_bad_{seed}_{cases}.zst','wb').write(bytes(zb))
+                print('REFDIFF', n, lvl, 'ref', 'error' if r is None else len(r), 'ours', b if isinstance(b,int) else len(b), flush=True)
 print('seed',seed,'cases',cases,'bad',bad,flush=True)

@@ -49,12 +49,13 @@ struct ZDecShared {
     // --- uniforms published by lane 0 ---
     u32 err;
     u32 llLog, mlLog, ofLog, hufLog, hufValid, seqValid;
+    u32 hufX2;                      // the reference would decode with its two-code-per-cell table (matters only for corrupted streams)
     u32 rep[3];
     u32 blkType, blkSize, blkLast;
     u32 hdrSize, windowSize, hasChecksum, blockSizeMax;
     u64 contentSize;
     u32 litType, litSize, litCSize, litHdr, litStreams, litSrcOff;  // literals section
-    u32 hA[4], hS0[4], hN[4], hDone[4], hDst[4], hLo[4], hCnt[4];    // Huffman stream state (bit positions rel. to block)
+    u32 hA[4], hS0[4], hN[4], hDone[4], hDst[4], hLo[4], hCnt[4], hA0[4];    // Huffman stream state (bit positions rel. to block)
     u32 nbSeq, seqOff;              // sequences section start (rel. to block)
     u32 bN, bLitStart, bOutStart, bLitTotal, bOutTotal, seqDone, winLo;
     u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
@@ -707,6 +708,57 @@ ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
     sh.hA[t] = (u32)A; sh.hCnt[t] = todo;
 }
 
+// Which table shape the reference picks for a 4-stream literals section (HUF_selectDecoder, N/decompress/huf_decompress.c:
+// 1793-1843: {table build, per 256 symbols} costs of the one-code / two-code tables by compression-ratio bucket).  Valid streams
+// decode to the same bytes with either; zd_huf_x2_accepts below is where the choice shows.
+ZD_CONST u16 zd_k_huf_algo_time[16][4] = {
+    {0,0,1,1}, {0,0,1,1}, {150,216,381,119}, {170,205,514,112}, {177,199,539,110}, {197,194,644,107}, {221,192,735,107},
+    {256,189,881,106}, {359,188,1167,109}, {582,187,1570,114}, {688,187,1712,122}, {825,186,1965,136}, {976,185,2131,150},
+    {1180,186,2070,175}, {1377,185,1731,202}, {1412,185,1695,202} };
+ZJ_DEV u32 zd_huf_select_x2(u32 dstSize, u32 cSrcSize) {
+    u32 const q = cSrcSize >= dstSize ? 15u : cSrcSize * 16u / dstSize, d256 = dstSize >> 8;
+    u32 const t0 = zd_k_huf_algo_time[q][0] + zd_k_huf_algo_time[q][1] * d256;
+    u32 t1 = zd_k_huf_algo_time[q][2] + zd_k_huf_algo_time[q][3] * d256;
+    t1 += t1 >> 5;
+    return t1 < t0 ? 1u : 0u;
+}
+
+// COLD PATH — runs only for a stream that did not end exactly on its first bit, i.e. only on corrupted input.  The reference's
+// two-code table walks the stream one CELL at a time (HUF_decodeStreamX2, huf_decompress.c:1308-1349): the 11-bit cell under the
+// cursor holds two codes when both fit (k1 + k2 <= 11, HUF_fillDTableX2 :1117-1177).  When one byte is left to produce,
+// HUF_decodeLastSymbolX2 (:1275-1290) emits the cell's first code and, for a two-code cell, skips k1 + k2 bits clamped to the
+// stream's end — so up to k2 left-over bits pass its end-of-stream check — and with no bit left at all it indexes the table
+// with the top of the last-loaded container (the stream's first 8 bytes) and skips nothing.  Re-walks stream t by cells with
+// those rules (one lane, straight from the block's bytes); true = the reference accepts it.  The bytes already decoded stand
+// except possibly the last one, rewritten here.
+ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
+    u32 const log = sh.hufLog, D = log > 11u ? log : 11u, n = sh.hN[t];
+    i32 A = (i32)sh.hA0[t]; i32 const S0 = (i32)sh.hS0[t];
+    u32 const startByte = (u32)S0 >> 3, len = (sh.hA0[t] >> 3) + 1u - startByte;
+    for (u32 i = 0; i < n; ) {
+        bool const last = (i + 1u == n);
+        i32 const R = A - S0;
+        if (R < 0 || (!last && R == 0)) return false;
+        u32 idx = 0;
+        if (R > 0) {                                           // D bits below A, zeros below the stream's first bit
+            for (u32 k = 0; k < D; k++) { i32 const bit = A - 1 - (i32)k; idx <<= 1; if (bit >= S0) idx |= (bsrc[(u32)bit >> 3] >> ((u32)bit & 7u)) & 1u; }
+        } else {
+            u64 c = 0; for (u32 k = 0; k < 8u && k < len; k++) c |= (u64)bsrc[startByte + k] << (8u * k);
+            idx = (u32)(c >> (64u - D));
+        }
+        u32 const c1 = sh.huf[idx >> (D - log)], k1 = c1 >> 8;
+        u32 const c2 = sh.huf[((idx << k1) & ((1u << D) - 1u)) >> (D - log)], k2 = c2 >> 8;
+        bool const two = k1 + k2 <= D;
+        if (last) {
+            out[i] = (u8)c1;
+            if (!two) return (u32)R == k1;
+            return !(R > 0 && (i32)(k1 + k2) < R);
+        }
+        A -= (i32)(two ? k1 + k2 : k1); i += two ? 2u : 1u;
+    }
+    return A == S0;
+}
+
 // ------------------------------------------------------------------ block --------------------
 // Literals section of one compressed block: parses its header and regenerates the literals (raw: in place;
 // RLE / Huffman: into litScratch).  Returns where they are; sets sh.err and returns nullptr on error.
@@ -756,6 +808,9 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
                 u32 const h = zd_huf_read_weights(sh, bsrc + litHdr, litCSize, &nbSym);
                 if (!h || h > litCSize) sh.err = ZJ_E_CORRUPTION;
                 sh.litSrcOff = litHdr + h; sh.bN = nbSym;
+                // table shape the reference builds here: HUF_decompress4X_hufOnly_wksp asks HUF_selectDecoder (huf_decompress.c:1930);
+                // a single stream always takes the one-code table (zstd_decompress_block.c:219)
+                sh.hufX2 = sh.litStreams == 4 ? zd_huf_select_x2(litSize, litCSize) : 0u;
             }
             g.sync();
             if (ZJ_UNI(sh.err)) return nullptr;
@@ -770,7 +825,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
             u32 err = 0;
             if (sh.litStreams == 1) {
                 if (end <= off || bsrc[end - 1] == 0) err = ZJ_E_CORRUPTION;
-                else { sh.hS0[0] = off * 8; sh.hA[0] = (end - 1) * 8 + zj_hibit(bsrc[end - 1]); sh.hN[0] = litSize; sh.hDst[0] = 0; }
+                else { sh.hS0[0] = off * 8; sh.hA[0] = sh.hA0[0] = (end - 1) * 8 + zj_hibit(bsrc[end - 1]); sh.hN[0] = litSize; sh.hDst[0] = 0; }
                 for (u32 t = 1; t < 4; t++) { sh.hN[t] = 0; sh.hA[t] = 0; sh.hS0[t] = 0; sh.hDst[t] = 0; }
             } else if (end < off + 10) err = ZJ_E_CORRUPTION;
             else {
@@ -783,7 +838,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
                     for (u32 t = 0; t < 4 && !err; t++) {
                         u32 const len = sh.hCnt[t], e = b + len;
                         if (len == 0 || bsrc[e - 1] == 0) { err = ZJ_E_CORRUPTION; break; }
-                        sh.hS0[t] = b * 8; sh.hA[t] = (e - 1) * 8 + zj_hibit(bsrc[e - 1]);
+                        sh.hS0[t] = b * 8; sh.hA[t] = sh.hA0[t] = (e - 1) * 8 + zj_hibit(bsrc[e - 1]);
                         sh.hN[t] = (t < 3) ? seg : litSize - 3 * seg; sh.hDst[t] = t * seg;
                         b = e;
                     }
@@ -824,7 +879,11 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
                 GRP_FOR(g, t, 4) sh.hDone[t] += sh.hCnt[t];
                 g.sync();
             }
-            GRP_SERIAL(g) { for (u32 t = 0; t < sh.litStreams; t++) { if (sh.hA[t] != sh.hS0[t]) sh.err = ZJ_E_CORRUPTION; } }
+            GRP_SERIAL(g) {
+                for (u32 t = 0; t < sh.litStreams; t++) {           // every stream ends exactly on its first bit (huf_decompress.c:697, :830)
+                    if (sh.hA[t] != sh.hS0[t] && !(sh.hufX2 && zd_huf_x2_accepts(sh, bsrc, t, litScratch + sh.hDst[t]))) sh.err = ZJ_E_CORRUPTION;
+                }
+            }
             g.sync();
             if (ZJ_UNI(sh.err)) return nullptr;
         }
@@ -1022,9 +1081,9 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
                     }
                 }
             }
-            sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0;
+            sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0; sh.hufX2 = 0;
             if (dd && dd->hasEntropy) {
-                sh.rep[0] = dd->rep[0]; sh.rep[1] = dd->rep[1]; sh.rep[2] = dd->rep[2]; sh.hufValid = 1; sh.seqValid = 1;
+                sh.rep[0] = dd->rep[0]; sh.rep[1] = dd->rep[1]; sh.rep[2] = dd->rep[2]; sh.hufValid = 1; sh.seqValid = 1; sh.hufX2 = 1;   // ZSTD_loadDEntropy builds the two-code table (zstd_decompress.c:1473)
                 sh.hufLog = dd->hufLog; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
             }
             if (err) sh.err = err;

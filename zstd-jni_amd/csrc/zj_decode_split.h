@@ -56,7 +56,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     bool const dictEntropy = DICT && dd && dd->hasEntropy;      // the frame may start in repeat / treeless modes
     GRP_SERIAL(g) {
         u32 ok = 0;
-        sh.err = 0; sh.seqValid = dictEntropy ? 1u : 0u; sh.hufValid = 0;
+        sh.err = 0; sh.seqValid = dictEntropy ? 1u : 0u; sh.hufValid = 0; sh.hufX2 = 0;
         if (dictEntropy) { sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog; }
         // frame header, N/decompress/zstd_decompress.c:447-557
         if (srcSize >= 16 && ld32(src) == 0xFD2FB528u) {
@@ -236,7 +236,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
         ZDMeta const m = *meta;
-        sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0;
+        sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0; sh.hufX2 = 0;
         sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.nbSeq = m.nbSeq; sh.blockSizeMax = m.blockSizeMax; sh.contentSize = m.contentSize;
         sh.hasChecksum = m.hasChecksum;
     }
@@ -244,7 +244,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     if (ZJ_UNI(sh.err)) return ~(u64)0;
     if (DICT && dd && dd->hasEntropy && (src[ZJ_UNI(sh.hdrSize)] & 3u) == 3u) {   // treeless literals decode with the dictionary's Huffman table
         zd_load_dict_entropy(g, sh, dd, true, false);
-        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufLog = dd->hufLog; }
+        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; }
         g.sync();
     }
     const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);
