@@ -535,17 +535,17 @@ static size_t decode_frame(u8* dst, size_t dstCap, const u8* src, size_t srcSize
         if (type == 3) { r = ERR(corruption_detected); goto done; }
         if (type == 1) {                                        /* RLE */
             if (ip >= iend) { r = ERR(srcSize_wrong); goto done; }
-            if (sz > fh.blockSizeMax) { r = ERR(corruption_detected); goto done; }
+            /* raw and RLE blocks are bounded by the destination only in the one-shot frame loop (N/decompress/zstd_decompress.c:1020-1026) */
             if (sz > (size_t)(oend - op)) { r = ERR(dstSize_tooSmall); goto done; }
             memset(op, *ip, sz); op += sz; ip += 1;
         } else {
             if (sz > (size_t)(iend - ip)) { r = ERR(srcSize_wrong); goto done; }
-            if (sz > fh.blockSizeMax) { r = ERR(corruption_detected); goto done; }
             if (type == 0) {
                 if (sz > (size_t)(oend - op)) { r = ERR(dstSize_tooSmall); goto done; }
                 memcpy(op, ip, sz); op += sz;
             } else {
                 size_t d;
+                if (sz > fh.blockSizeMax) { r = ERR(srcSize_wrong); goto done; }    /* zstd_decompress_block.c:2081 */
                 if (sz >= BLOCK_MAX) { r = ERR(corruption_detected); goto done; }   /* zstd_decompress_block.c:2073-2081 */
                 {   size_t room = (size_t)(oend - op); if (room > fh.blockSizeMax) room = fh.blockSizeMax;
                     d = decode_block(ds, dst, op, op + room, ip, sz, fh.blockSizeMax);

@@ -283,7 +283,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         p.lpos += llen; p.opos += llen + mlen; litTotal += llen; outTotal += llen + mlen;
         n++; p.i++;
     }
-    if (!err && bad) err = (bad & 1u) ? ZJ_E_CORRUPTION : ZJ_E_DSTSIZE_TOO_SMALL;
+    if (!err && bad) err = (bad & 2u) ? ZJ_E_DSTSIZE_TOO_SMALL : ZJ_E_CORRUPTION;     // ZSTD_execSequence tests the destination first (zstd_decompress_block.c:919-920, :967-968)
     if (!err && p.i == nbSeq && p.A != p.S0) err = ZJ_E_CORRUPTION;
     sh.bN = n; sh.bLitTotal = litTotal; sh.bOutTotal = outTotal;
     sh.seqDone = (p.i == nbSeq);
@@ -1103,11 +1103,13 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
                     u32 const bh = ld24(src + ipos), type = (bh >> 1) & 3, sz = bh >> 3;
                     sh.blkLast = bh & 1; sh.blkType = type; sh.blkSize = sz;
                     if (type == 3) err = ZJ_E_CORRUPTION;
-                    else if (type == 1) { if (srcSize - ipos - 3 < 1) err = ZJ_E_SRCSIZE_WRONG; else if (sz > sh.blockSizeMax) err = ZJ_E_CORRUPTION; else if (sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL; }
+                    // the one-shot frame loop bounds raw and RLE blocks by the destination only (zstd_decompress.c:1020-1026); a
+                    // compressed block larger than blockSizeMax is srcSize_wrong (zstd_decompress_block.c:2081)
+                    else if (type == 1) { if (srcSize - ipos - 3 < 1) err = ZJ_E_SRCSIZE_WRONG; else if (sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL; }
                     else {
                         if (sz > srcSize - ipos - 3) err = ZJ_E_SRCSIZE_WRONG;
-                        else if (sz > sh.blockSizeMax) err = ZJ_E_CORRUPTION;
                         else if (type == 0 && sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL;
+                        else if (type == 2 && sz > sh.blockSizeMax) err = ZJ_E_SRCSIZE_WRONG;
                         else if (type == 2 && sz >= ZD_BLOCK_MAX) err = ZJ_E_CORRUPTION;
                     }
                 }

@@ -236,7 +236,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
         ZDMeta const m = *meta;
-        sh.err = m.status ? ZJ_E_CORRUPTION : 0; sh.hufValid = 0; sh.hufX2 = 0;
+        sh.err = m.status ? (u32)ZJ_E_CORRUPTION : 0u; sh.hufValid = 0; sh.hufX2 = 0;
         sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.nbSeq = m.nbSeq; sh.blockSizeMax = m.blockSizeMax; sh.contentSize = m.contentSize;
         sh.hasChecksum = m.hasChecksum;
     }

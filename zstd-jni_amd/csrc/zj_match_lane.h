@@ -193,7 +193,7 @@ struct ZLaneD {
         ti0 = nhl; ti1 = nhs;
         // ---- phase 2: one batch of loads for all states ----
         ZL_PROF_T1();
-        if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
+        pa0 = v0 ? pa0 : 0; pa1 = v1 ? pa1 : 0; pa2 = v2 ? pa2 : 0; pa3 = v3 ? pa3 : 0; pa4 = v4 ? pa4 : 0;
         if (!vb) { bp0 = 8; bp1 = 8; }
         if (!vt) { ti0 = 0; ti1 = 0; }
         u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
@@ -390,7 +390,7 @@ struct ZLaneF {
             pa1 = ip2; pa2 = ip3; v1 = v2 = true;
         }
         ZL_PROF_T1();
-        if (!v0) pa0 = 0; if (!v1) pa1 = 0; if (!v2) pa2 = 0; if (!v3) pa3 = 0; if (!v4) pa4 = 0;
+        pa0 = v0 ? pa0 : 0; pa1 = v1 ? pa1 : 0; pa2 = v2 ? pa2 : 0; pa3 = v3 ? pa3 : 0; pa4 = v4 ? pa4 : 0;
         if (!vb) { bp0 = 8; bp1 = 8; }
         if (!vt) ti = 0;
         if (!vt2) ti2 = 0;
