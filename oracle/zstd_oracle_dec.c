@@ -335,8 +335,10 @@ static size_t build_seq_table(SeqTable* t, int type, u32 maxSym, u32 maxLog, con
 }
 
 /* ---------------------------------------------------------------- one compressed block ---- */
-static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u8** litPtr, size_t* litSize, size_t blockSizeMax) {
+/* room = bytes left in the destination; *inPlace = raw literals read straight from the block (zstd_decompress_block.c:283-288) */
+static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u8** litPtr, size_t* litSize, size_t blockSizeMax, size_t room, int* inPlace) {
     u32 type, fmt;
+    *inPlace = 0;
     if (srcSize < 2) return ERR(corruption_detected);       /* MIN_CBLOCK_SIZE */
     type = src[0] & 3; fmt = (src[0] >> 2) & 3;
     if (type == 0 || type == 1) {                            /* raw / rle */
@@ -345,8 +347,10 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
         else if (fmt == 1) { lh = 2; n = rd16(src) >> 4; }
         else { if (srcSize < 3) return ERR(corruption_detected); lh = 3; n = rd24(src) >> 4; }
         if (n > blockSizeMax) return ERR(corruption_detected);
+        if (n > room) return ERR(dstSize_tooSmall);             /* expectedWriteSize < litSize, :268 / :318 */
         if (type == 0) {
             if (lh + n > srcSize) return ERR(corruption_detected);
+            *inPlace = (lh + n + 32 <= srcSize);
             *litPtr = src + lh; *litSize = n; return lh + n;
         }
         if (lh + 1 > srcSize) return ERR(corruption_detected);
@@ -355,8 +359,8 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
         memset(ds->lit, src[lh], n); *litPtr = ds->lit; *litSize = n; return lh + 1;
     }
     {   size_t lh, n, c; int single = 0; u32 lhc; const u8* ip; size_t cLeft;
+        if (type == 3 && !ds->huf.valid) return ERR(dictionary_corrupted);     /* tested before the size, :150-153 */
         if (srcSize < 5) return ERR(corruption_detected);
-        if (type == 3 && !ds->huf.valid) return ERR(dictionary_corrupted);
         lhc = rd32(src);
         if (fmt < 2) { single = !fmt; lh = 3; n = (lhc >> 4) & 0x3FF; c = (lhc >> 14) & 0x3FF; }
         else if (fmt == 2) { lh = 4; n = (lhc >> 4) & 0x3FFF; c = lhc >> 18; }
@@ -364,6 +368,7 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
         if (n > blockSizeMax) return ERR(corruption_detected);
         if (!single && n < 6) return ERR(literals_headerWrong);      /* MIN_LITERALS_FOR_4_STREAMS */
         if (c + lh > srcSize) return ERR(corruption_detected);
+        if (n > room) return ERR(dstSize_tooSmall);             /* :183 */
         ip = src + lh; cLeft = c;
         if (type == 2) {
             size_t const h = huf_read_table(&ds->huf, ip, cLeft);
@@ -395,10 +400,13 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
 
 /* `base` = first byte of this frame's output (window never reaches before it: no dictionary) */
 static size_t decode_block(DState* ds, u8* base, u8* op, u8* oend, const u8* src, size_t srcSize, size_t blockSizeMax) {
-    const u8* lit; size_t litSize; u8* const ostart = op;
-    size_t const lsz = decode_literals(ds, src, srcSize, &lit, &litSize, blockSizeMax);
+    const u8* lit; size_t litSize; u8* const ostart = op; int inPlace;
+    size_t const lsz = decode_literals(ds, src, srcSize, &lit, &litSize, blockSizeMax, (size_t)(oend - op), &inPlace);
     const u8* ip; const u8* iend = src + srcSize; int nbSeq;
     if (zso_is_error(lsz)) return lsz;
+    /* how far the block may write: the reference parks regenerated literals 32 bytes past the largest block when the destination
+     * has room (ZSTD_allocateLiteralsBuffer :86-94) and stops sequences there; otherwise at the destination's end */
+    if (!inPlace && (size_t)(oend - op) > blockSizeMax + 64 + litSize) oend = op + blockSizeMax + 32;
     ip = src + lsz;
     if (ip >= iend) return ERR(srcSize_wrong);               /* MIN_SEQUENCES_SIZE */
     nbSeq = *ip++;
@@ -454,8 +462,8 @@ static size_t decode_block(DState* ds, u8* base, u8* op, u8* oend, const u8* src
             }
             if (b.left < 0) return ERR(corruption_detected);
             /* execute: N/decompress/zstd_decompress_block.c:1001-1096 */
+            if ((size_t)(oend - op) < (size_t)llen + mlen) return ERR(dstSize_tooSmall);   /* the destination first, :919-920 */
             if (llen > litSize) return ERR(corruption_detected);
-            if ((size_t)(oend - op) < (size_t)llen + mlen) return ERR(dstSize_tooSmall);
             memcpy(op, lit, llen); op += llen; lit += llen; litSize -= llen;
             if (offset > (size_t)(op - base)) return ERR(corruption_detected);
             { u32 k; const u8* m = op - offset; for (k = 0; k < mlen; k++) op[k] = m[k]; }
@@ -513,16 +521,25 @@ unsigned long long zso_frame_content_size(const void* src, size_t srcSize) {
 }
 
 static size_t decode_frame(u8* dst, size_t dstCap, const u8* src, size_t srcSize, size_t* consumed) {
-    FrameHdr fh; size_t r = parse_frame_header(&fh, src, srcSize);
+    FrameHdr fh; size_t r;
     const u8* ip; const u8* const iend = src + srcSize; u8* op = dst; u8* const oend = dst + dstCap;
     DState* ds;
+    /* ZSTD_decompressFrame (N/decompress/zstd_decompress.c:966-979) sizes the header from its descriptor byte and wants it plus
+     * one block header present BEFORE the magic number is examined */
+    if (srcSize >= 5 && (rd32(src) & 0xFFFFFFF0u) != 0x184D2A50u) {
+        static const size_t did[4] = { 0, 1, 2, 4 }, fcs[4] = { 0, 2, 4, 8 };
+        u8 const fhd = src[4]; u32 const single = (fhd >> 5) & 1;
+        size_t const need = 5 + !single + did[fhd & 3] + fcs[fhd >> 6] + (single && !(fhd >> 6));
+        if (srcSize < 9 || srcSize < need + 3) return ERR(srcSize_wrong);
+    }
+    r = parse_frame_header(&fh, src, srcSize);
     if (zso_is_error(r)) return r;
     if (fh.skippable) {
         if (8 + fh.contentSize > srcSize) return ERR(srcSize_wrong);
         *consumed = 8 + (size_t)fh.contentSize; return 0;
     }
     if (fh.dictID) return ERR(dictionary_wrong);
-    if (fh.windowSize > (((u64)1 << 27) + 1)) return ERR(frameParameter_windowTooLarge);   /* ZSTD_MAXWINDOWSIZE_DEFAULT */
+    /* no window-size limit here: ZSTD_MAXWINDOWSIZE_DEFAULT is ZSTD_decompressStream's (:2231), the one-shot call has none */
     ds = (DState*)calloc(1, sizeof(DState));
     if (!ds) return ERR(GENERIC);
     ds->litCap = BLOCK_MAX + 32; ds->lit = (u8*)malloc(ds->litCap);
@@ -547,12 +564,8 @@ static size_t decode_frame(u8* dst, size_t dstCap, const u8* src, size_t srcSize
                 size_t d;
                 if (sz > fh.blockSizeMax) { r = ERR(srcSize_wrong); goto done; }    /* zstd_decompress_block.c:2081 */
                 if (sz >= BLOCK_MAX) { r = ERR(corruption_detected); goto done; }   /* zstd_decompress_block.c:2073-2081 */
-                {   size_t room = (size_t)(oend - op); if (room > fh.blockSizeMax) room = fh.blockSizeMax;
-                    d = decode_block(ds, dst, op, op + room, ip, sz, fh.blockSizeMax);
-                    if (zso_is_error(d)) {
-                        if (d == ERR(dstSize_tooSmall) && room == fh.blockSizeMax) d = ERR(corruption_detected);
-                        r = d; goto done; }
-                }
+                d = decode_block(ds, dst, op, oend, ip, sz, fh.blockSizeMax);
+                if (zso_is_error(d)) { r = d; goto done; }
                 op += d;
             }
             ip += sz;
@@ -572,10 +585,12 @@ done:
 }
 
 size_t zso_decompress(void* dst, size_t dstCap, const void* src, size_t srcSize) {
-    const u8* ip = (const u8*)src; u8* op = (u8*)dst; size_t left = srcSize, room = dstCap;
+    const u8* ip = (const u8*)src; u8* op = (u8*)dst; size_t left = srcSize, room = dstCap; u32 frames = 0;
     while (left >= 5 || left > 0) {
         size_t used = 0; size_t const d = decode_frame(op, room, ip, left, &used);
+        if (d == ERR(prefix_unknown) && frames) return ERR(srcSize_wrong);   /* garbage after a complete frame, ZSTD_decompressMultiFrame :1136 */
         if (zso_is_error(d)) return d;
+        frames += !(left >= 4 && (rd32(ip) & 0xFFFFFFF0u) == 0x184D2A50u);
         op += d; room -= d; ip += used; left -= used;
         if (left == 0) break;
     }

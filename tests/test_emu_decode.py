@@ -49,7 +49,12 @@ def test_emu_errors(emu, oracle_ref):
     data = b"hello hello hello hello " * 100
     z = oracle_ref.compress(data, 3)
     assert emu_decompress(emu, z, len(data) - 1) == -70
-    assert emu_decompress(emu, b"\x00\x01\x02\x03\x04\x05", 10) == -10
+    # a header (sized from its descriptor byte) plus one block header must be present before the magic number is examined
+    # (zstd_decompress.c:966-979): short garbage is srcSize_wrong, long garbage prefix_unknown, garbage after a frame srcSize_wrong
+    for junk, code in ((b"\x00\x01\x02\x03\x04\x05", -72), (bytes(range(20)), -10), (z + bytes(range(20)), -72)):
+        assert emu_decompress(emu, junk, len(data)) == code
+        with pytest.raises(oracle_ref.ZstdRefError, match="Src size is incorrect" if code == -72 else "Unknown frame descriptor"):
+            oracle_ref.decompress(junk, len(data))
     assert isinstance(emu_decompress(emu, z[:-3], len(data)), int)
     bad = bytearray(z); bad[len(z) // 2] ^= 0x55
     out = emu_decompress(emu, bytes(bad), len(data))

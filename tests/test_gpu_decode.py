@@ -60,9 +60,14 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
         dctx.decompress(z, len(data) - 1)
     assert e.value.getErrorCode() == gpu.Zstd.errDstSizeTooSmall()
     assert "Destination buffer is too small" in str(e.value)
-    with pytest.raises(gpu.ZstdException) as e:
-        dctx.decompress(b"\x00\x01\x02\x03\x04\x05\x06\x07", 10)
-    assert e.value.getErrorCode() == 10
+    # short garbage is srcSize_wrong, long garbage prefix_unknown, garbage after a frame srcSize_wrong (zstd_decompress.c:966-979, :1136)
+    for junk, code, name in ((b"\x00\x01\x02\x03\x04\x05\x06\x07", 72, "Src size is incorrect"), (bytes(range(20)), 10, "Unknown frame descriptor"),
+                             (z + bytes(range(20)), 72, "Src size is incorrect")):
+        with pytest.raises(gpu.ZstdException) as e:
+            dctx.decompress(junk, len(data))
+        assert e.value.getErrorCode() == code
+        with pytest.raises(oracle_ref.ZstdRefError, match=name):
+            oracle_ref.decompress(junk, len(data))
     with pytest.raises(gpu.ZstdException):
         dctx.decompress(z[:-3], len(data))
     # offsets into larger arrays: J/ZstdDecompressCtx.java:239 decompressByteArray

@@ -63,9 +63,14 @@ def test_port_decoder_errors(oracle_port, oracle_ref):
     assert e.value.code == 70
     with pytest.raises(oracle_port.ZstdOracleError):
         oracle_port.decompress(z[:-3], len(data))
-    with pytest.raises(oracle_port.ZstdOracleError) as e:
-        oracle_port.decompress(b"\x00\x01\x02\x03\x04\x05", 10)
-    assert e.value.code == 10
+    # short garbage is srcSize_wrong, long garbage prefix_unknown, garbage after a frame srcSize_wrong (zstd_decompress.c:966-979, :1136)
+    for junk, code, name in ((b"\x00\x01\x02\x03\x04\x05", 72, "Src size is incorrect"), (bytes(range(20)), 10, "Unknown frame descriptor"),
+                             (z + bytes(range(20)), 72, "Src size is incorrect")):
+        with pytest.raises(oracle_port.ZstdOracleError) as e:
+            oracle_port.decompress(junk, len(data))
+        assert e.value.code == code
+        with pytest.raises(oracle_ref.ZstdRefError, match=name):
+            oracle_ref.decompress(junk, len(data))
 
 
 # ---------------------------------------------------------------- encoder restatement -------

@@ -762,9 +762,9 @@ ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
 // ------------------------------------------------------------------ block --------------------
 // Literals section of one compressed block: parses its header and regenerates the literals (raw: in place;
 // RLE / Huffman: into litScratch).  Returns where they are; sets sh.err and returns nullptr on error.
-// Publishes sh.litSize / litHdr / litCSize.
+// Publishes sh.litSize / litHdr / litCSize.  room = bytes left in the frame's destination.
 template <class G>
-ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf) {
+ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -777,17 +777,22 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
                 else if (fmt == 1) { lh = 2; n = ld16(bsrc) >> 4; }
                 else { if (bsize < 3) err = ZJ_E_CORRUPTION; else { lh = 3; n = ld24(bsrc) >> 4; } }
                 c = (type == 0) ? n : 1;
-            } else if (bsize < 5) err = ZJ_E_CORRUPTION;
+            } else if (type == 3 && !sh.hufValid) err = ZJ_E_DICT_CORRUPTED;
+            else if (bsize < 5) err = ZJ_E_CORRUPTION;
             else {
                 u32 const lhc = ld32(bsrc);
                 if (fmt < 2) { streams = fmt ? 4 : 1; lh = 3; n = (lhc >> 4) & 0x3FF; c = (lhc >> 14) & 0x3FF; }
                 else if (fmt == 2) { streams = 4; lh = 4; n = (lhc >> 4) & 0x3FFF; c = lhc >> 18; }
                 else { streams = 4; lh = 5; n = (lhc >> 4) & 0x3FFFF; c = (lhc >> 22) + ((u32)bsrc[4] << 10); }
-                if (type == 3 && !sh.hufValid) err = ZJ_E_DICT_CORRUPTED;
-                if (!err && streams == 4 && n < 6) err = ZJ_E_LITERALS_HEADER;
             }
+            // the reference's order of refusals (zstd_decompress_block.c:150-183, :250-276, :300-326): literals larger than a
+            // block, 4 streams for < 6 literals, section larger than the block — and literals larger than the room left in the
+            // destination before (raw / RLE) or after (Huffman) the section-size test
             if (!err && n > sh.blockSizeMax) err = ZJ_E_CORRUPTION;
+            if (!err && type >= 2 && streams == 4 && n < 6) err = ZJ_E_LITERALS_HEADER;
+            if (!err && type < 2 && n > room) err = ZJ_E_DSTSIZE_TOO_SMALL;
             if (!err && lh + c > bsize) err = ZJ_E_CORRUPTION;
+            if (!err && n > room) err = ZJ_E_DSTSIZE_TOO_SMALL;
             sh.litType = type; sh.litSize = n; sh.litCSize = c; sh.litHdr = lh; sh.litStreams = streams;
         }
         if (err) sh.err = err;
@@ -957,12 +962,20 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
 }
 
 // Decodes one compressed block [bsrc, bsrc+bsize) of the frame whose output starts at `out`
-// (frame-relative position `opos`).  Returns new opos (or sets sh.err).
+// (frame-relative position `opos`; the frame may write out[0..frameCap)).  Returns new opos (or sets sh.err).
 template <bool DICT = false, class G>
-ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 dstCap, u8* litScratch, ZjProf& pf, const u8* dictEnd = nullptr) {
-    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
+ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u32 opos, u32 frameCap, u8* litScratch, ZjProf& pf, const u8* dictEnd = nullptr) {
+    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, frameCap - opos);
     if (ZJ_UNI(sh.err)) return opos;
     u32 const litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
+    // How far this block may write.  The reference parks regenerated literals 32 bytes past the largest block the frame allows
+    // when the destination has room for that (ZSTD_allocateLiteralsBuffer, zstd_decompress_block.c:86-94) and stops sequences
+    // there (:1405, oend = litBuffer); otherwise (little room, or raw literals read in place :283-288) at the destination's end.
+    // Either way the refusal is dstSize_tooSmall; a block that ends inside the 32-byte slack goes through.
+    u32 dstCap = frameCap;
+    {   u32 const room = frameCap - opos, bsm = ZJ_UNI(sh.blockSizeMax);
+        bool const inPlace = ZJ_UNI(sh.litType) == 0 && litHdr + litSize + 32u <= bsize;
+        if (!inPlace && (u64)room > (u64)bsm + 64u + litSize) dstCap = opos + bsm + 32u; }
 
     pf.mark(2);
     // ---- sequences header + tables ----
@@ -1047,7 +1060,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
     GRP_FOR(g, i, 36) sh.llBase[i] = zd_k_ll_base[i];
     GRP_FOR(g, i, 53) sh.mlBase[i] = zd_k_ml_base[i];
     g.sync();
-    u32 ipos = 0, total = 0;
+    u32 ipos = 0, total = 0, nbFrames = 0;
     while (ipos < srcSize) {
         // ---- frame header (lane 0): N/decompress/zstd_decompress.c:447-557 ----
         GRP_SERIAL(g) {
@@ -1056,25 +1069,26 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if (left < 5) err = ZJ_E_SRCSIZE_WRONG;
             else {
                 u32 const magic = ld32(p);
-                if (magic != 0xFD2FB528u) {
-                    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
-                        if (left < 8 || (u64)8 + ld32(p + 4) > left) err = ZJ_E_SRCSIZE_WRONG;
-                        else { sh.blkType = 1; sh.hdrSize = 8 + ld32(p + 4); }
-                    } else err = ZJ_E_PREFIX_UNKNOWN;
+                if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+                    if (left < 8 || (u64)8 + ld32(p + 4) > left) err = ZJ_E_SRCSIZE_WRONG;
+                    else { sh.blkType = 1; sh.hdrSize = 8 + ld32(p + 4); }
                 } else {
                     u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
                     u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
                     u32 const need = 5 + !single + didSz + fcsSz; u32 pos = 5;
                     u64 window = 0, content = ~(u64)0; u32 dictID = 0;
-                    if (fhd & 8) err = ZJ_E_FRAMEPARAM_UNSUPPORTED;
-                    else if (left < need) err = ZJ_E_SRCSIZE_WRONG;
+                    // the header's size is taken from its descriptor byte and checked (with the first block header) before the
+                    // magic number is looked at (ZSTD_decompressFrame, zstd_decompress.c:966-979); garbage after a complete frame
+                    // is srcSize_wrong, not prefix_unknown (ZSTD_decompressMultiFrame :1136-1143)
+                    if (left < 9 || left < need + 3) err = ZJ_E_SRCSIZE_WRONG;
+                    else if (magic != 0xFD2FB528u) err = nbFrames ? ZJ_E_SRCSIZE_WRONG : ZJ_E_PREFIX_UNKNOWN;
+                    else if (fhd & 8) err = ZJ_E_FRAMEPARAM_UNSUPPORTED;
                     else {
                         if (!single) { u32 const wd = p[pos++], wl = (wd >> 3) + 10; if (wl > 31) err = ZJ_E_WINDOW_TOO_LARGE; window = (u64)1 << wl; window += (window >> 3) * (wd & 7); }
                         if (didc == 1) dictID = p[pos]; else if (didc == 2) dictID = ld16(p + pos); else if (didc == 3) dictID = ld32(p + pos);
                         pos += didSz;
                         if (fcsid == 0) { if (single) content = p[pos]; } else if (fcsid == 1) content = ld16(p + pos) + 256; else if (fcsid == 2) content = ld32(p + pos); else content = ld64(p + pos);
                         if (single) window = content;
-                        if (!err && window > (((u64)1 << 27) + 1)) err = ZJ_E_WINDOW_TOO_LARGE;
                         if (!err && dictID && dictID != (dd ? dd->dictID : 0u)) err = ZJ_E_DICT_WRONG;   // zstd_decompress.c:717
                         sh.hdrSize = need; sh.contentSize = content; sh.hasChecksum = (fhd >> 2) & 1;
                         sh.blockSizeMax = window < ZD_BLOCK_MAX ? (u32)window : ZD_BLOCK_MAX;
@@ -1122,13 +1136,8 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if (type == 0) { grp_copy_wide(g, fout + opos, src + ipos, sz); opos += sz; ipos += sz; zj_mem_order(); pf.mark(7); }
             else if (type == 1) { zd_fill(g, fout + opos, src[ipos], sz); opos += sz; ipos += 1; zj_mem_order(); }
             else {
-                u32 const cap = zj_min(fcap, opos + ZJ_UNI(sh.blockSizeMax));
-                opos = zd_compressed_block<DICT>(g, sh, src + ipos, sz, fout, opos, cap, litScratch, pf, dictEnd);
-                if (ZJ_UNI(sh.err)) {
-                    u32 e = ZJ_UNI(sh.err);
-                    if (e == ZJ_E_DSTSIZE_TOO_SMALL && cap < fcap) e = ZJ_E_CORRUPTION;   // block larger than blockSizeMax
-                    return ZJ_ERR64(e);
-                }
+                opos = zd_compressed_block<DICT>(g, sh, src + ipos, sz, fout, opos, fcap, litScratch, pf, dictEnd);
+                if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
                 ipos += sz;
             }
             g.sync();
@@ -1142,7 +1151,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             if ((u32)zj_xxh64(g, fout, opos) != ZJ_UNI(ld32(src + ipos))) return ZJ_ERR64(ZJ_E_CHECKSUM_WRONG);
             ipos += 4;
         }
-        total += opos;
+        total += opos; nbFrames++;
     }
     return total;
 }
