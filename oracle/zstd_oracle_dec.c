@@ -65,6 +65,25 @@ static u32 bits_at(const BitR* b, i64 pos, u32 nb) {
 static u32 bitr_read(BitR* b, u32 nb) { b->left -= nb; return bits_at(b, b->left, nb); }
 static u32 bitr_peek(const BitR* b, u32 nb) { return bits_at(b, b->left - (i64)nb, nb); }
 
+/* The sequence decoder does not stop when its bit stream runs dry: the reference reads on from the exhausted 64-bit container
+ * (by then the stream's first 8 bytes, or all of a shorter stream, N/common/bitstream.h:254-300, :370-420) with shifts that wrap
+ * at 64, and some later sequence trips a check (or the end-of-stream test does).  Which check — hence the error CODE — depends
+ * on those bits, so they are restated: BIT_readBitsFast = (C << (consumed & 63)) >> (64 - nb)  (:347-356),
+ * BIT_readBits = (C >> ((64 - consumed - nb) & 63)) & mask(nb)  (:303-343), consumed = 64 - left. */
+static u64 bitr_container(const BitR* b) { u64 c = 0; size_t k; for (k = 0; k < 8 && k < b->n; k++) c |= (u64)b->p[k] << (8 * k); return c; }
+static u32 seq_read_fast(BitR* b, u32 nb) {       /* nb >= 1 */
+    u32 v;
+    if ((i64)nb <= b->left) v = bits_at(b, b->left - (i64)nb, nb);
+    else { u32 const c = (u32)(64 - b->left); v = (u32)((bitr_container(b) << (c & 63)) >> (64 - nb)); }
+    b->left -= nb; return v;
+}
+static u32 seq_read(BitR* b, u32 nb) {
+    u32 v;
+    if ((i64)nb <= b->left) v = bits_at(b, b->left - (i64)nb, nb);
+    else { u32 const c = (u32)(64 - b->left); v = (u32)(bitr_container(b) >> ((64u - c - nb) & 63u)) & (u32)(((u64)1 << nb) - 1); }
+    b->left -= nb; return v;
+}
+
 /* ---------------------------------------------------------------- FSE NCount ------------- */
 /* N/common/entropy_common.c:42-188.  Returns header bytes consumed or error. */
 static size_t read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, size_t srcSize) {
@@ -432,35 +451,35 @@ static size_t decode_block(DState* ds, u8* base, u8* op, u8* oend, const u8* src
         ip += h;
         ds->seqValid = 1;
         if (bitr_init(&b, ip, (size_t)(iend - ip))) return ERR(corruption_detected);
-        sLL = bitr_read(&b, ds->ll.log); sOF = bitr_read(&b, ds->of.log); sML = bitr_read(&b, ds->ml.log);
+        sLL = seq_read(&b, ds->ll.log); sOF = seq_read(&b, ds->of.log); sML = seq_read(&b, ds->ml.log);
         for (i = 0; i < nbSeq; i++) {
             FseCell const cl = ds->ll.cell[sLL], co = ds->of.cell[sOF], cm = ds->ml.cell[sML];
             u32 const ofCode = co.sym, llCode = cl.sym, mlCode = cm.sym;
             u32 llen = LL_base[llCode], mlen = ML_base[mlCode]; size_t offset;
             /* offset: N/decompress/zstd_decompress_block.c:1279-1312 */
             if (ofCode > 1) {
-                offset = ((size_t)1 << ofCode) - 3 + bitr_read(&b, ofCode);     /* OF_base[c] = 2^c - 3 */
+                offset = ((size_t)1 << ofCode) - 3 + seq_read_fast(&b, ofCode);     /* OF_base[c] = 2^c - 3 */
                 ds->rep[2] = ds->rep[1]; ds->rep[1] = ds->rep[0]; ds->rep[0] = (u32)offset;
             } else {
                 u32 const ll0 = (llen == 0);
                 if (ofCode == 0) {
                     offset = ds->rep[ll0]; ds->rep[1] = ds->rep[!ll0]; ds->rep[0] = (u32)offset;
                 } else {
-                    u32 const idx = 1 + ll0 + bitr_read(&b, 1);
+                    u32 const idx = 1 + ll0 + seq_read_fast(&b, 1);
                     u32 t = (idx == 3) ? ds->rep[0] - 1 : ds->rep[idx];
                     t -= !t;
                     if (idx != 1) ds->rep[2] = ds->rep[1];
                     ds->rep[1] = ds->rep[0]; ds->rep[0] = t; offset = t;
                 }
             }
-            mlen += bitr_read(&b, ML_bits[mlCode]);
-            llen += bitr_read(&b, LL_bits[llCode]);
+            if (ML_bits[mlCode]) mlen += seq_read_fast(&b, ML_bits[mlCode]);
+            if (LL_bits[llCode]) llen += seq_read_fast(&b, LL_bits[llCode]);
             if (i + 1 < nbSeq) {
-                sLL = cl.next + bitr_read(&b, cl.nbBits);
-                sML = cm.next + bitr_read(&b, cm.nbBits);
-                sOF = co.next + bitr_read(&b, co.nbBits);
+                sLL = cl.next + seq_read(&b, cl.nbBits);
+                sML = cm.next + seq_read(&b, cm.nbBits);
+                sOF = co.next + seq_read(&b, co.nbBits);
             }
-            if (b.left < 0) return ERR(corruption_detected);
+            /* no test of b.left here: a stream that ran dry keeps yielding bits (above) until a check below, or the end test, fails */
             /* execute: N/decompress/zstd_decompress_block.c:1001-1096 */
             if ((size_t)(oend - op) < (size_t)llen + mlen) return ERR(dstSize_tooSmall);   /* the destination first, :919-920 */
             if (llen > litSize) return ERR(corruption_detected);

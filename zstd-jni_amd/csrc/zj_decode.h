@@ -208,6 +208,63 @@ ZJ_DEV u32 zd_bits(const u8* win, u32 winLo, i32 p, u32 n) {   // n <= 32 bits a
     return (u32)w & (u32)(((u64)1 << n) - 1);
 }
 
+// COLD PATH — entered only when the sequence bit stream runs dry before the last sequence (corrupted input): the refusal is
+// certain, the question is its CODE.  The reference does not stop there: it keeps reading from the exhausted 64-bit container
+// (by then the stream's first 8 bytes, or all of a shorter stream; N/common/bitstream.h:254-300, :370-420) with shifts that
+// wrap at 64 — BIT_readBitsFast = (C << (consumed & 63)) >> (64 - nb) (:347-356), BIT_readBits = (C >> ((64 - consumed - nb)
+// & 63)) & mask(nb) (:303-343), consumed = 64 - bits left — and a later sequence trips a check of ZSTD_execSequence
+// (dstSize_tooSmall before corruption_detected, zstd_decompress_block.c:919-934), or the end-of-stream test does (:1581).
+// Walks the remaining sequences (from state p; init: the three initial states are still to be read) with exactly those bits
+// and returns that code.  Nothing is written.  The window already reaches the stream's first byte here.
+ZJ_DEV u32 zd_seq_dry_code(ZDecShared& sh, ZDecSeqPriv p, bool init, u32 dstCap) {
+    u32 const nbSeq = sh.nbSeq, litSize = sh.litSize, winLo = sh.winLo;
+    u32 const startByte = (u32)p.S0 >> 3, len = sh.blkSize - startByte;
+    u64 C = 0;
+    for (u32 k = 0; k < 8u && k < len; k++) C |= (u64)sh.win[startByte - winLo + k] << (8u * k);
+    i32 R = p.A - p.S0;                                        // valid bits left; goes negative
+    auto fast = [&](u32 nb) -> u32 {                           // nb >= 1
+        u32 v;
+        if ((i32)nb <= R) v = zd_bits(sh.win, winLo, p.S0 + R - (i32)nb, nb);
+        else { u32 const c = (u32)(64 - R); v = (u32)((C << (c & 63u)) >> (64u - nb)); }
+        R -= (i32)nb; return v; };
+    auto slow = [&](u32 nb) -> u32 {
+        u32 v;
+        if ((i32)nb <= R) v = nb ? zd_bits(sh.win, winLo, p.S0 + R - (i32)nb, nb) : 0u;
+        else { u32 const c = (u32)(64 - R); v = (u32)(C >> ((64u - c - nb) & 63u)) & (u32)(((u64)1 << nb) - 1u); }
+        R -= (i32)nb; return v; };
+    if (init) { p.sLL = slow(sh.llLog); p.sOF = slow(sh.ofLog); p.sML = slow(sh.mlLog); }
+    for (u32 i = p.i; i < nbSeq; i++) {
+        u32 const cl = sh.ll[p.sLL], co = sh.of[p.sOF], cm = sh.ml[p.sML];
+        u32 const ofx = ZD_CELL_EXTRA(co), mlx = ZD_CELL_EXTRA(cm), llx = ZD_CELL_EXTRA(cl);
+        u32 const llBase = sh.llBase[ZD_CELL_SYM(cl)];
+        u32 offset;
+        if (ofx > 1) { offset = (1u << ofx) - 3u + fast(ofx); p.rep2 = p.rep1; p.rep1 = p.rep0; p.rep0 = offset; }
+        else {
+            u32 const ll0 = (llBase == 0);
+            if (ofx == 0) { if (ll0) { offset = p.rep1; p.rep1 = p.rep0; p.rep0 = offset; } else offset = p.rep0; }
+            else {
+                u32 const idx = 1 + ll0 + fast(1);
+                u32 t = (idx == 3) ? p.rep0 - 1 : (idx == 1 ? p.rep1 : p.rep2);
+                t -= !t;
+                if (idx != 1) p.rep2 = p.rep1;
+                p.rep1 = p.rep0; p.rep0 = t; offset = t;
+            }
+        }
+        u32 const mlen = sh.mlBase[ZD_CELL_SYM(cm)] + (mlx ? fast(mlx) : 0u);
+        u32 const llen = llBase + (llx ? fast(llx) : 0u);
+        if (i + 1 < nbSeq) {
+            p.sLL = ZD_CELL_NEXT(cl) + slow(ZD_CELL_NB(cl));
+            p.sML = ZD_CELL_NEXT(cm) + slow(ZD_CELL_NB(cm));
+            p.sOF = ZD_CELL_NEXT(co) + slow(ZD_CELL_NB(co));
+        }
+        if ((u64)p.opos + llen + mlen > dstCap) return ZJ_E_DSTSIZE_TOO_SMALL;
+        if (llen > litSize - p.lpos) return ZJ_E_CORRUPTION;
+        if ((u64)offset > (u64)p.opos + llen + sh.dictSize) return ZJ_E_CORRUPTION;
+        p.opos += llen + mlen; p.lpos += llen;
+    }
+    return ZJ_E_CORRUPTION;                                     // the stream did not end on its first bit
+}
+
 // Decode up to ZD_SEQ_BATCH sequences into sh.sLit/sMl/sOff.  Runs on lane 0 only.
 // N/decompress/zstd_decompress_block.c:1229-1347.  The chain that bounds this kernel is
 // state -> cell (LDS) -> bit counts -> next state; everything else is kept off it: the 64 bits below the
@@ -217,6 +274,7 @@ ZJ_DEV u32 zd_bits(const u8* win, u32 winLo, i32 p, u32 n) {   // n <= 32 bits a
 ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
     u32 const nbSeq = sh.nbSeq, winLo = sh.winLo;
     u32 n = 0, litTotal = 0, outTotal = 0, err = 0, bad = 0;
+    bool dry = false;
     u32 const litSize = sh.litSize;
     u32 const seqStartByte = (u32)p.S0 >> 3;
     sh.bLitStart = p.lpos; sh.bOutStart = p.opos;
@@ -234,7 +292,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         u32 const nl = last ? 0 : ZD_CELL_NB(cl), nm = last ? 0 : ZD_CELL_NB(cm), no = last ? 0 : ZD_CELL_NB(co);
         u32 const T = ofx + mlx + llx + nl + nm + no;
         u32 ofv, mlv, llv, vl, vm, vo;
-        if (p.A - (i32)T < p.S0) { err = ZJ_E_CORRUPTION; break; }
+        if (p.A - (i32)T < p.S0) { dry = true; break; }           // p is still the state before this sequence
         if (T <= 56 && wide) {
 #define ZD_TAKE(nb) ((u32)((v >> 1) >> (63 - (nb))))
             ofv = ZD_TAKE(ofx); v <<= ofx;
@@ -283,6 +341,7 @@ ZJ_DEV void zd_seq_batch(ZDecShared& sh, ZDecSeqPriv& p, u32 dstCap) {
         p.lpos += llen; p.opos += llen + mlen; litTotal += llen; outTotal += llen + mlen;
         n++; p.i++;
     }
+    if (dry) err = zd_seq_dry_code(sh, p, false, dstCap);           // cold: the code the reference's garbage sequences end on
     if (!err && bad) err = (bad & 2u) ? ZJ_E_DSTSIZE_TOO_SMALL : ZJ_E_CORRUPTION;     // ZSTD_execSequence tests the destination first (zstd_decompress_block.c:919-920, :967-968)
     if (!err && p.i == nbSeq && p.A != p.S0) err = ZJ_E_CORRUPTION;
     sh.bN = n; sh.bLitTotal = litTotal; sh.bOutTotal = outTotal;
@@ -1007,10 +1066,11 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
             GRP_SERIAL(g) {
                 if (first) {   // initial states: LL, OF, ML (N/decompress/zstd_decompress_block.c:1640-1642)
                     u32 const a = sh.llLog, b = sh.ofLog, c = sh.mlLog;
+                    ZDecSeqPriv const p0 = p;
                     p.A -= (i32)a; p.sLL = zd_bits(sh.win, sh.winLo, p.A, a);
                     p.A -= (i32)b; p.sOF = zd_bits(sh.win, sh.winLo, p.A, b);
                     p.A -= (i32)c; p.sML = zd_bits(sh.win, sh.winLo, p.A, c);
-                    if (p.A < p.S0) sh.err = ZJ_E_CORRUPTION;
+                    if (p.A < p.S0) sh.err = zd_seq_dry_code(sh, p0, true, dstCap);
                 }
                 if (!sh.err) zd_seq_batch(sh, p, dstCap);
             }
