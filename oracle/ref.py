@@ -72,13 +72,16 @@ ZSTD_c_contentSizeFlag = 200
 
 
 class ZstdRefError(RuntimeError):
-    pass
+    """message = ZSTD_getErrorName, .code = ZSTD_getErrorCode (N/zstd_errors.h)"""
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 def _check(r):
     L = lib()
     if L.ZSTD_isError(r):
-        raise ZstdRefError(L.ZSTD_getErrorName(r).decode())
+        raise ZstdRefError(L.ZSTD_getErrorName(r).decode(), (1 << 64) - r)
     return r
 
 
@@ -141,7 +144,7 @@ def decompress_portable(frame: bytes, cap: int, dictionary: bytes = None) -> byt
         dst = C.create_string_buffer(max(cap, 1))
         r = P.ZSTD_decompress_usingDict(dctx, dst, cap, frame, len(frame), dictionary, len(dictionary) if dictionary else 0)
         if P.ZSTD_isError(r):
-            raise ZstdRefError(P.ZSTD_getErrorName(r).decode())
+            raise ZstdRefError(P.ZSTD_getErrorName(r).decode(), (1 << 64) - r)
         return dst.raw[:r]
     finally:
         P.ZSTD_freeDCtx(dctx)

@@ -1,6 +1,7 @@
 """Randomised stress of the three-stage decoder bodies (lane-serial build) against the reference's frames (levels 1-9, with and
 without dictionary / checksum, content up to 300 KB) and, for corrupted frames (bit flips, byte stores, truncation), against
-the answer of the reference's portable decoder loops (oracle/_ref/libzstd_ref_portable.so) on both pipelines.
+the answer of the reference's portable decoder loops (oracle/_ref/libzstd_ref_portable.so) on both pipelines: the same bytes,
+or a refusal with the same error code.
 usage: fuzz_emu_decode.py <seed> <seconds>   TEST INFRASTRUCTURE."""
 import sys, time, random
 import os
@@ -71,15 +72,16 @@ while time.time()-t0 < budget:
                 for _ in range(3): zb[rnd.randrange(4, len(zb))] ^= 1 << rnd.randrange(8)
             else: zb = zb[:rnd.randrange(5, len(zb))]
             zb = bytes(zb); corrupted += 1
-            try: want = ref.decompress_portable(zb, len(d), dic if usedDict else None)
-            except ref.ZstdRefError: want = None
-            try: stock = ref.decompress_using_dict(zb, dic, len(d)) if usedDict else ref.decompress(zb, len(d))
-            except ref.ZstdRefError: stock = None
+            cap = len(d) if rnd.random() < 0.85 else rnd.randrange(0, len(d) + 1)     # sometimes an undersized destination
+            try: want = ref.decompress_portable(zb, cap, dic if usedDict else None)
+            except ref.ZstdRefError as e: want = -e.code                                # refusals must carry the same error code
+            try: stock = ref.decompress_using_dict(zb, dic, cap) if usedDict else ref.decompress(zb, cap)
+            except ref.ZstdRefError as e: stock = -e.code
             lax += (stock != want)
-            if usedDict: a = util.emu_decompress_dict(L, zb, len(d), dic, split=True); b = util.emu_decompress_dict(L, zb, len(d), dic)
-            else: a = util.emu_decompress_split(L, zb, len(d))[0]; b = util.emu_decompress(L, zb, len(d))
+            if usedDict: a = util.emu_decompress_dict(L, zb, cap, dic, split=True); b = util.emu_decompress_dict(L, zb, cap, dic)
+            else: a = util.emu_decompress_split(L, zb, cap)[0]; b = util.emu_decompress(L, zb, cap)
             for nm, x in (('split', a), ('fused', b)):
-                if (None if isinstance(x, int) else x) != want:
+                if x != want:
                     bad += 1; open(f'/tmp/fuzz_dec_bad_{seed}_{cases}.zst', 'wb').write(zb)
-                    print('REFDIFF', nm, n, lvl, 'dict' if usedDict else '', 'portable', 'refuses' if want is None else len(want), 'ours', x if isinstance(x, int) else len(x), flush=True)
+                    print('REFDIFF', nm, n, lvl, 'dict' if usedDict else '', 'portable', want if isinstance(want, int) else len(want), 'ours', x if isinstance(x, int) else len(x), flush=True)
 print('seed',seed,'cases',cases,'corrupted',corrupted,'stock_build_differs',lax,'bad',bad,flush=True)
