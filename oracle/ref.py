@@ -116,6 +116,44 @@ def decompress(frame: bytes, cap: int) -> bytes:
         L.ZSTD_freeDCtx(dctx)
 
 
+class _Buf(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+
+def compress_stream(data: bytes, level: int = 3, checksum: bool = False, chunk: int = 50000, flush_every: int = 0) -> bytes:
+    """ZSTD_compressStream2 without a pledged size — what ZstdOutputStream / ZstdDirectBufferCompressingStream produce
+    (reference N/jni_outputstream_zstd.c): the frame header carries NO content size; ZSTD_e_flush every `flush_every` chunks
+    closes blocks early (many small blocks)."""
+    L = lib()
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(_Buf), C.POINTER(_Buf), C.c_int]
+    cctx = L.ZSTD_createCCtx()
+    try:
+        _check(L.ZSTD_CCtx_setParameter(cctx, 100, level))              # ZSTD_c_compressionLevel
+        _check(L.ZSTD_CCtx_setParameter(cctx, 201, 1 if checksum else 0))  # ZSTD_c_checksumFlag
+        cap = L.ZSTD_compressBound(len(data)) + 1024 + 16 * (len(data) // max(chunk, 1) + 1)
+        dst = C.create_string_buffer(cap)
+        src = C.create_string_buffer(data, max(len(data), 1))
+        ob = _Buf(C.addressof(dst), cap, 0)
+        pos, k = 0, 0
+        while pos < len(data):
+            n = min(chunk, len(data) - pos)
+            ib = _Buf(C.addressof(src) + pos, n, 0)
+            k += 1
+            mode = 1 if (flush_every and k % flush_every == 0) else 0      # ZSTD_e_flush / ZSTD_e_continue
+            while True:
+                r = _check(L.ZSTD_compressStream2(cctx, C.byref(ob), C.byref(ib), mode))
+                if ib.pos == ib.size and (mode == 0 or r == 0):
+                    break
+            pos += n
+        ib = _Buf(C.addressof(src), 0, 0)
+        while _check(L.ZSTD_compressStream2(cctx, C.byref(ob), C.byref(ib), 2)) != 0:   # ZSTD_e_end
+            pass
+        return dst.raw[:ob.pos]
+    finally:
+        L.ZSTD_freeCCtx(cctx)
+
+
 PORTABLE_PATH = os.path.join(_HERE, "_ref", "libzstd_ref_portable.so")
 _portable = None
 

@@ -144,3 +144,18 @@ def test_emu_dictionary_decode(emu, oracle_ref, zj):
     # frames made without a dictionary still decode when one is loaded
     plain = oracle_ref.compress(data, 3)
     assert emu_decompress_dict(emu, plain, len(data), trained) == data
+
+
+def test_emu_streamed_frames_without_content_size(emu, oracle_ref, oracle_port):
+    """what ZstdOutputStream writes (reference N/jni_outputstream_zstd.c: ZSTD_compressStream2, no pledged size): no content
+    size in the header, blocks closed early by flushes, optional checksum; decoded with the caller's size as capacity, with a
+    larger one, and refused with dstSize_tooSmall when one byte short — by both pipelines and the C restatement"""
+    data = b",".join(json_records(12000, seed=21))[:400_000]
+    for level, checksum, flush_every in ((1, False, 0), (3, True, 1), (3, False, 3), (9, True, 0)):
+        z = oracle_ref.compress_stream(data, level, checksum, chunk=30000, flush_every=flush_every)
+        assert oracle_ref.lib().ZSTD_getFrameContentSize(z, len(z)) == (1 << 64) - 1           # ZSTD_CONTENTSIZE_UNKNOWN
+        assert emu_decompress(emu, z, len(data)) == data
+        assert emu_decompress_split(emu, z, len(data))[0] == data
+        assert emu_decompress(emu, z, len(data) + 1000) == data
+        assert emu_decompress(emu, z, len(data) - 1) == -70
+        assert oracle_port.decompress(z, len(data)) == data

@@ -207,3 +207,20 @@ def test_gpu_dictionary_decode(gpu, oracle_ref, monkeypatch, split_min):
     with gpu.ZstdDictDecompress(trained) as dd:                           # dictionary loaded, plain frames still fine
         plain = [oracle_ref.compress(d, 3) for d in (data, data * 7)]
         assert gpu.decompress_batch(plain, [len(data), 7 * len(data)], dd) == [data, data * 7]
+
+
+def test_gpu_streamed_frames_without_content_size(gpu, oracle_ref):
+    """ZstdOutputStream's output (no content size in the header, flushed blocks, optional checksum) through both pipelines"""
+    from util import json_records
+    data = b",".join(json_records(12000, seed=21))[:400_000]
+    frames = [oracle_ref.compress_stream(data, level, checksum, chunk=30000, flush_every=fe)
+              for level, checksum, fe in ((1, False, 0), (3, True, 1), (3, False, 3), (9, True, 0))]
+    for split_min in ("1", "1000000000"):
+        os.environ["ZJNI_DSPLIT_MIN"] = split_min
+        try:
+            outs = gpu.decompress_batch(frames * 2, [len(data)] * 4 + [len(data) + 1000] * 4)
+            assert all(o == data for o in outs)
+            short = gpu.decompress_batch(frames, [len(data) - 1] * 4)
+            assert all(isinstance(o, Exception) and o.getErrorCode() == 70 for o in short)
+        finally:
+            os.environ.pop("ZJNI_DSPLIT_MIN", None)

@@ -56,6 +56,9 @@ while time.time()-t0 < budget:
     usedDict = rnd.random() < 0.3
     if usedDict:
         z = ref.compress_using_dict(d, dic, lvl); out = util.emu_decompress_dict(L, z, len(d), dic, split=True)
+    elif rnd.random() < 0.25:      # streamed frame: no content size in the header, blocks closed by flushes (ZstdOutputStream's output)
+        z = ref.compress_stream(d, lvl, rnd.random()<0.3, chunk=rnd.choice([1000, 30000, 200000]), flush_every=rnd.choice([0, 1, 3]))
+        out, used = util.emu_decompress_split(L, z, len(d))
     else:
         z = ref.compress(d, lvl, checksum=rnd.random()<0.3); out, used = util.emu_decompress_split(L, z, len(d))
     cases+=1
