@@ -50,6 +50,26 @@ def test_frame_content_size(zj, oracle_ref):
     assert zj.Zstd.getFrameContentSize(b"\x00" * 8) == -2
 
 
+def test_frame_content_size_on_damaged_headers(zj, oracle_ref):
+    """ZSTD_getFrameContentSize on truncated / overwritten headers (zstd frames with every header shape, a streamed frame
+    without content size, a skippable frame): same value or the same ZSTD_CONTENTSIZE_ERROR as the reference"""
+    import ctypes as C
+    import random
+    import struct
+    L, R = zj.lib(), oracle_ref.lib()
+    R.ZSTD_getFrameContentSize.argtypes = [C.c_char_p, C.c_size_t]
+    rnd = random.Random(3)
+    base = [oracle_ref.compress(bytes(rnd.randrange(5) for _ in range(k)), 3, checksum=bool(k & 1)) for k in (0, 1, 100, 255, 256, 300, 70000)]
+    base += [struct.pack("<II", 0x184D2A53, 5) + b"hello", oracle_ref.compress_stream(b"abc" * 1000, 3)]
+    for _ in range(20000):
+        z = bytearray(rnd.choice(base))
+        for _ in range(rnd.randrange(0, 3)):
+            z[rnd.randrange(0, min(len(z), 14))] = rnd.getrandbits(8)
+        z = bytes(z[:rnd.randrange(0, min(len(z), 20) + 1)]) if rnd.random() < 0.5 else bytes(z)
+        buf = C.create_string_buffer(z, max(len(z), 1))
+        assert L.zjni_getFrameContentSize(buf, len(z)) == R.ZSTD_getFrameContentSize(z, len(z)), z[:16].hex()
+
+
 def test_synth_is_deterministic_and_classed(zj):
     a = zj.synth_host(4096, 0, 8)
     b = zj.synth_host(4096, 4, 4)

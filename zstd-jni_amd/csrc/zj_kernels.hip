@@ -530,11 +530,13 @@ unsigned long long zjni_getFrameContentSize(const void* srcv, size_t srcSize) {
     const u8* p = (const u8*)srcv;
     if (srcSize < 5) return (unsigned long long)-2;
     u32 const magic = ld32(p);
-    if (magic != 0xFD2FB528u) return ((magic & 0xFFFFFFF0u) == 0x184D2A50u) ? 0ull : (unsigned long long)-2;
+    if (magic != 0xFD2FB528u)       // a skippable frame needs its 8-byte header present (:476-478), then counts as size 0 (:596)
+        return ((magic & 0xFFFFFFF0u) == 0x184D2A50u && srcSize >= 8) ? 0ull : (unsigned long long)-2;
     u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
     u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
     size_t pos = 5 + !single + didSz;
-    if ((fhd & 8) || srcSize < pos + fcsSz) return (unsigned long long)-2;
+    if (srcSize < pos + fcsSz || (fhd & 8)) return (unsigned long long)-2;
+    if (!single && (p[5] >> 3) + 10u > 31u) return (unsigned long long)-2;     // windowLog > ZSTD_WINDOWLOG_MAX (:517)
     if (fcsid == 0) return single ? p[pos] : (unsigned long long)-1;
     if (fcsid == 1) return ld16(p + pos) + 256;
     if (fcsid == 2) return ld32(p + pos);
