@@ -3,7 +3,9 @@
 The frames were found by tools/fuzz_emu_decode.py (seeds 3 and 4: one flipped bit in a frame the reference compressed) or made
 by hand (truncation; raw_rle_blocks_beyond_window.zst: a 1 KiB window descriptor in front of a 5 120-byte raw block and a 5 000-byte
 RLE block — out of spec, but the one-shot frame loop bounds those block types by the destination only, zstd_decompress.c:1020-1026;
-window_1GiB_declared.zst: a 2^30 window descriptor, which only ZSTD_decompressStream limits, :2231).  For each, the manifest records the answer of
+window_1GiB_declared.zst: a 2^30 window descriptor, which only ZSTD_decompressStream limits, :2231;
+sequence_stream_runs_dry.zst: the sequence bit stream ends two sequences early and the reference's garbage sequences stop on
+dstSize_tooSmall).  For each, the manifest records the answer of
   * "portable": the reference's decoder built with its own HUF_DISABLE_FAST_DECODE switch (oracle/_ref/libzstd_ref_portable.so,
     `make -C oracle refportable`) — the loops every platform without the 64-bit fast Huffman path runs.  THIS is the contract
     the product decoder is tested against: bytes (sha256) or refusal.

@@ -14,7 +14,7 @@ from util import emu_lib, emu_decompress, emu_decompress_split
 
 CORRUPT = os.path.join(GOLDEN, "corrupt")
 MANIFEST = json.load(open(os.path.join(CORRUPT, "manifest.json")))
-ERR_CODE = {"Data corruption detected": 20, "Src size is incorrect": 72}     # ZSTD_ErrorCode, N/zstd_errors.h
+ERR_CODE = {"Data corruption detected": 20, "Src size is incorrect": 72, "Destination buffer is too small": 70}     # ZSTD_ErrorCode, N/zstd_errors.h
 
 
 def frame(name):

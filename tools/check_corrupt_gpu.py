@@ -32,7 +32,7 @@ def decompress_batch(frames, caps):
 
 d = os.path.join(ROOT, "tests", "golden", "corrupt")
 man = json.load(open(os.path.join(d, "manifest.json")))
-CODE = {"Data corruption detected": 20, "Src size is incorrect": 72}
+CODE = {"Data corruption detected": 20, "Src size is incorrect": 72, "Destination buffer is too small": 70}
 names = sorted(man)
 frames = [open(os.path.join(d, n), "rb").read() for n in names]
 good = open(os.path.join(ROOT, "tests", "golden", "xmlsmall-sized.zst"), "rb").read()
