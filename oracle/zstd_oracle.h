@@ -64,6 +64,8 @@ size_t zso_compress_ex(void* dst, size_t dstCap, const void* src, size_t srcSize
 
 /* XXH64 (N/common/xxhash.h) — used for the optional frame checksum */
 uint64_t zso_xxh64(const void* p, size_t len, uint64_t seed);
+/* FSE_readNCount restated (N/common/entropy_common.c:42-188), exposed for tests */
+size_t zso_read_ncount(short* norm, unsigned* maxSV, unsigned* tableLog, const void* src, size_t srcSize);
 
 #ifdef __cplusplus
 }

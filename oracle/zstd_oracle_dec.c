@@ -86,65 +86,72 @@ static u32 seq_read(BitR* b, u32 nb) {
 
 /* ---------------------------------------------------------------- FSE NCount ------------- */
 /* N/common/entropy_common.c:42-188.  Returns header bytes consumed or error. */
-static size_t read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, size_t srcSize) {
-    /* forward little-endian bit cursor */
-    size_t bitpos = 0; size_t const totalBits = srcSize * 8;
+/* The cursor is the reference's own (byte position + bit count + a 32-bit word re-read after every field) because its behaviour
+ * at the end of the buffer is part of the contract: the position is pinned 4 bytes before the end and the bit count taken
+ * modulo 32 (:146-153, :170-177), so a description running past its buffer wraps around on the last four bytes instead of
+ * failing; only the bit count after the last field is tested (:184).  Buffers under 8 bytes: zero-padded copy (:62-72). */
+static size_t read_ncount_body(short* norm, u32* maxSV, u32* tableLog, const u8* src, size_t hbSize) {   /* hbSize >= 8 */
     u32 const maxSV1 = *maxSV + 1;
+    int const iend = (int)hbSize;
+    int ip = 0, bitCount = 4, nbBits, remaining, threshold;
     u32 charnum = 0; int previous0 = 0;
-    int nbBits, remaining, threshold;
-    if (srcSize < 1) return ERR(srcSize_wrong);
+    u32 bitStream = rd32(src);
+    nbBits = (int)(bitStream & 0xF) + 5;
+    if (nbBits > 15) return ERR(tableLog_tooLarge);          /* FSE_TABLELOG_ABSOLUTE_MAX */
     memset(norm, 0, maxSV1 * sizeof(short));
-    {   u32 v = src[0] & 0xF;
-        nbBits = (int)v + 5;
-        if (nbBits > 15) return ERR(tableLog_tooLarge);   /* FSE_TABLELOG_ABSOLUTE_MAX */
-        bitpos = 4; *tableLog = (u32)nbBits;
-    }
+    bitStream >>= 4; *tableLog = (u32)nbBits;
     remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
     for (;;) {
-        u32 bs;
         if (previous0) {
-            /* 2-bit repeat codes: 3 = "three more zeros and continue" */
-            for (;;) {
-                u32 c;
-                {   size_t by = bitpos >> 3; u32 sh = (u32)(bitpos & 7); u32 w = 0; int i;
-                    for (i = 0; i < 2 && by + (size_t)i < srcSize; i++) w |= (u32)src[by + (size_t)i] << (8 * i);
-                    c = (w >> sh) & 3; }
-                bitpos += 2;
-                charnum += c;
-                if (c != 3) break;
-                if (charnum >= maxSV1 + 3 * 100) break;   /* bounded: error caught below */
+            u32 repeats = (u32)__builtin_ctz(~bitStream | 0x80000000u) >> 1;
+            while (repeats >= 12) {
+                charnum += 3 * 12;
+                if (ip <= iend - 7) ip += 3;
+                else { bitCount -= 8 * (iend - 7 - ip); bitCount &= 31; ip = iend - 4; }
+                bitStream = rd32(src + ip) >> bitCount;
+                repeats = (u32)__builtin_ctz(~bitStream | 0x80000000u) >> 1;
             }
+            charnum += 3 * repeats;
+            bitStream >>= 2 * repeats; bitCount += (int)(2 * repeats);
+            charnum += bitStream & 3; bitCount += 2;
             if (charnum >= maxSV1) break;
+            if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32(src + ip) >> bitCount;
         }
-        {   size_t by = bitpos >> 3; u32 sh = (u32)(bitpos & 7); u64 w = 0; int i;
-            for (i = 0; i < 4 && by + (size_t)i < srcSize; i++) w |= (u64)src[by + (size_t)i] << (8 * i);
-            bs = (u32)(w >> sh); }
         {   int const max = (2 * threshold - 1) - remaining;
             int count;
-            if ((bs & (u32)(threshold - 1)) < (u32)max) {
-                count = (int)(bs & (u32)(threshold - 1)); bitpos += (size_t)(nbBits - 1);
-            } else {
-                count = (int)(bs & (u32)(2 * threshold - 1));
-                if (count >= threshold) count -= max;
-                bitpos += (size_t)nbBits;
-            }
+            if ((bitStream & (u32)(threshold - 1)) < (u32)max) { count = (int)(bitStream & (u32)(threshold - 1)); bitCount += nbBits - 1; }
+            else { count = (int)(bitStream & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bitCount += nbBits; }
             count--;
             if (count >= 0) remaining -= count; else remaining += count;
             norm[charnum++] = (short)count;
             previous0 = !count;
             if (remaining < threshold) {
                 if (remaining <= 1) break;
-                nbBits = (int)hibit((u32)remaining) + 1;
-                threshold = 1 << (nbBits - 1);
+                nbBits = (int)hibit((u32)remaining) + 1; threshold = 1 << (nbBits - 1);
             }
             if (charnum >= maxSV1) break;
+            if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32(src + ip) >> bitCount;
         }
     }
     if (remaining != 1) return ERR(corruption_detected);
     if (charnum > maxSV1) return ERR(maxSymbolValue_tooSmall);
-    if (bitpos > totalBits) return ERR(corruption_detected);
+    if (bitCount > 32) return ERR(corruption_detected);
     *maxSV = charnum - 1;
-    return (bitpos + 7) >> 3;
+    return (size_t)(ip + ((bitCount + 7) >> 3));
+}
+static size_t read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, size_t srcSize) {
+    if (srcSize < 8) {
+        u8 pad[8] = { 0 }; size_t h;
+        memcpy(pad, src, srcSize);
+        h = read_ncount_body(norm, maxSV, tableLog, pad, 8);
+        if (zso_is_error(h)) return h;
+        return h > srcSize ? ERR(corruption_detected) : h;
+    }
+    return read_ncount_body(norm, maxSV, tableLog, src, srcSize);
 }
 
 /* ---------------------------------------------------------------- FSE decode tables ------ */
@@ -450,6 +457,7 @@ static size_t decode_block(DState* ds, u8* base, u8* op, u8* oend, const u8* src
         if (zso_is_error(h)) return ERR(corruption_detected);
         ip += h;
         ds->seqValid = 1;
+        if (oend == op) return ERR(dstSize_tooSmall);           /* sequences but no room at all, zstd_decompress_block.c:2119 */
         if (bitr_init(&b, ip, (size_t)(iend - ip))) return ERR(corruption_detected);
         sLL = seq_read(&b, ds->ll.log); sOF = seq_read(&b, ds->of.log); sML = seq_read(&b, ds->ml.log);
         for (i = 0; i < nbSeq; i++) {
@@ -661,4 +669,9 @@ uint64_t zso_xxh64(const void* data, size_t len, uint64_t seed) {
     while (p < end) { h ^= (*p) * P5; h = rotl64(h, 11) * P1; p++; }
     h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
     return h;
+}
+
+/* the NCount reader on its own, for tests/: header bytes or an error; norm[0..*maxSV], *tableLog filled on success */
+size_t zso_read_ncount(short* norm, unsigned* maxSV, unsigned* tableLog, const void* src, size_t srcSize) {
+    return read_ncount(norm, maxSV, tableLog, (const u8*)src, srcSize);
 }

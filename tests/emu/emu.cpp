@@ -177,3 +177,11 @@ extern "C" unsigned emu_huf_weights(const unsigned char* hdr, unsigned size, uns
     free(sh);
     return h ? nbSym : 0;
 }
+
+// the kernels' NCount reader on its own (zd_read_ncount): header bytes or 0; norm[0..*maxSV], *tableLog filled on success
+extern "C" unsigned emu_read_ncount(const unsigned char* src, unsigned size, unsigned maxSV, short* normOut, unsigned* maxOut, unsigned* logOut) {
+    short norm[256]; u32 mx = maxSV, tl = 0;
+    u32 const h = zd_read_ncount(norm, &mx, &tl, src, size);
+    if (h) { memcpy(normOut, norm, (mx + 1) * sizeof(short)); *maxOut = mx; *logOut = tl; }
+    return h;
+}

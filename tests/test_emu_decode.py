@@ -159,3 +159,46 @@ def test_emu_streamed_frames_without_content_size(emu, oracle_ref, oracle_port):
         assert emu_decompress(emu, z, len(data) + 1000) == data
         assert emu_decompress(emu, z, len(data) - 1) == -70
         assert oracle_port.decompress(z, len(data)) == data
+
+
+def test_ncount_reader_matches_reference_on_random_buffers(emu, oracle_ref, oracle_port):
+    """FSE_readNCount (N/common/entropy_common.c:42-188) against the kernels' reader and the C restatement on random and
+    truncated table descriptions — including descriptions that run past their buffer, where the reference wraps around on the
+    last four bytes instead of failing (:146-153) and the answer (size, counts, or refusal) has to be the same"""
+    import ctypes as C
+    import random
+    R, P = oracle_ref.lib(), oracle_port.lib()
+    R.FSE_readNCount.restype = C.c_size_t
+    R.FSE_readNCount.argtypes = [C.POINTER(C.c_short), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
+    P.zso_read_ncount.restype = C.c_size_t
+    P.zso_read_ncount.argtypes = [C.POINTER(C.c_short), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
+    emu.emu_read_ncount.restype = C.c_uint
+    emu.emu_read_ncount.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.POINTER(C.c_short), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    rnd = random.Random(11)
+    # real descriptions to mutate: sequence sections of reference-compressed frames hold them; plain random bytes parse too
+    seeds = [oracle_ref.compress(bytes(min(255, int(rnd.expovariate(0.03))) for _ in range(4000)), 3)[-400:] for _ in range(8)]
+    ok = 0
+    for it in range(60000):
+        if rnd.random() < 0.5:
+            s = rnd.choice(seeds); a = rnd.randrange(0, len(s) - 2); src = bytearray(s[a:a + rnd.randrange(1, 40)])
+        else:
+            src = bytearray(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 24)))
+        if rnd.random() < 0.5:
+            src[0] = (src[0] & 0xF0) | rnd.randrange(0, 5)                      # small table logs parse more often
+        if rnd.random() < 0.3 and len(src) > 4:
+            for k in range(rnd.randrange(1, 5)): src[-1 - k] = 0xFF               # long zero-runs near the end
+        src = bytes(src); maxSV = rnd.choice([35, 31, 52, 255])
+        n1 = (C.c_short * 256)(); m1 = C.c_uint(maxSV); t1 = C.c_uint(0)
+        r = R.FSE_readNCount(n1, C.byref(m1), C.byref(t1), src, len(src))
+        n2 = (C.c_short * 256)(); m2 = C.c_uint(maxSV); t2 = C.c_uint(0)
+        p = P.zso_read_ncount(n2, C.byref(m2), C.byref(t2), src, len(src))
+        n3 = (C.c_short * 256)(); m3 = C.c_uint(0); t3 = C.c_uint(0)
+        e = emu.emu_read_ncount(src, len(src), maxSV, n3, C.byref(m3), C.byref(t3))
+        if R.ZSTD_isError(r):
+            assert p == r and e == 0, (src.hex(), maxSV, hex(r), hex(p), e)
+        else:
+            ok += 1
+            assert p == r and e == r, (src.hex(), maxSV, r, p, e)
+            assert m1.value == m2.value == m3.value and t1.value == t2.value == t3.value, src.hex()
+            assert list(n1[:m1.value + 1]) == list(n2[:m1.value + 1]) == list(n3[:m1.value + 1]), src.hex()
+    assert ok > 3000

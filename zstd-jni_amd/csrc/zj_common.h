@@ -115,6 +115,7 @@ ZJ_HD void st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
 ZJ_HD void st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 
 ZJ_HD u32 zj_hibit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // v != 0
+ZJ_HD u32 zj_ctz32(u32 v) { return (u32)__builtin_ctz(v); }          // v != 0
 ZJ_HD u32 zj_min(u32 a, u32 b) { return a < b ? a : b; }
 ZJ_HD u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
 

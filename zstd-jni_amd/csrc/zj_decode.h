@@ -120,36 +120,47 @@ ZJ_DEV void zd_stage(const G& g, u8* w, const u8* src, u32 from, u32 len, u32 sr
 // ------------------------------------------------------------------ NCount (lane 0) ---------
 // N/common/entropy_common.c:42-188.  Reads from global memory [src, src+srcSize). Returns header
 // bytes or 0 on error (an NCount header is never 0 bytes).
-ZJ_DEV u32 zd_read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, u32 srcSize) {
+// The cursor is the reference's own — a byte position, a bit count and a 32-bit word re-read after every field — because its
+// behaviour at the end of the buffer is part of the contract: the position is pinned 4 bytes before the end and the bit count
+// taken modulo 32 (:146-153, :170-177), so a description that runs past its buffer WRAPS AROUND on the last four bytes
+// instead of failing; only the bit count after the last field is tested (:184).  Damaged blocks reach that, and whether they
+// are then refused — and with which code — depends on it.  Buffers under 8 bytes are parsed from a zero-padded copy (:62-72).
+template <class RD32>
+ZJ_DEV u32 zd_read_ncount_body(short* norm, u32* maxSV, u32* tableLog, RD32 rd32, u32 hbSize) {      // hbSize >= 8
     u32 const maxSV1 = *maxSV + 1;
-    u32 bitpos, charnum = 0, previous0 = 0;
-    i32 nbBits, remaining, threshold;
-    if (srcSize < 1) return 0;
-    for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
-    nbBits = (i32)(src[0] & 0xF) + 5;
+    i32 const iend = (i32)hbSize;
+    i32 ip = 0, bitCount = 4;
+    u32 charnum = 0, previous0 = 0;
+    u32 bitStream = rd32(0);
+    i32 nbBits = (i32)(bitStream & 0xF) + 5, remaining, threshold;
     if (nbBits > 15) return 0;
-    *tableLog = (u32)nbBits; bitpos = 4;
+    for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
+    bitStream >>= 4;
+    *tableLog = (u32)nbBits;
     remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
     for (;;) {
-        u32 by, sh; u64 w = 0;
         if (previous0) {
-            for (;;) {
-                u32 c; u32 w2 = 0;
-                by = bitpos >> 3; sh = bitpos & 7;
-                if (by < srcSize) w2 = src[by];
-                if (by + 1 < srcSize) w2 |= (u32)src[by + 1] << 8;
-                c = (w2 >> sh) & 3; bitpos += 2; charnum += c;
-                if (c != 3 || charnum >= maxSV1 + 64) break;
+            // pairs of 1-bits visible in the current word: each is three more zero-probability symbols
+            u32 repeats = (u32)zj_ctz32(~bitStream | 0x80000000u) >> 1;
+            while (repeats >= 12) {
+                charnum += 3 * 12;
+                if (ip <= iend - 7) ip += 3;
+                else { bitCount -= 8 * (iend - 7 - ip); bitCount &= 31; ip = iend - 4; }
+                bitStream = rd32((u32)ip) >> bitCount;
+                repeats = (u32)zj_ctz32(~bitStream | 0x80000000u) >> 1;
             }
+            charnum += 3 * repeats;
+            bitStream >>= 2 * repeats; bitCount += (i32)(2 * repeats);
+            charnum += bitStream & 3; bitCount += 2;
             if (charnum >= maxSV1) break;
+            if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32((u32)ip) >> bitCount;
         }
-        by = bitpos >> 3; sh = bitpos & 7;
-        for (u32 k = 0; k < 4; k++) { if (by + k < srcSize) w |= (u64)src[by + k] << (8 * k); }
-        {   u32 const bs = (u32)(w >> sh);
-            i32 const max = (2 * threshold - 1) - remaining;
+        {   i32 const max = (2 * threshold - 1) - remaining;
             i32 count;
-            if ((bs & (u32)(threshold - 1)) < (u32)max) { count = (i32)(bs & (u32)(threshold - 1)); bitpos += (u32)(nbBits - 1); }
-            else { count = (i32)(bs & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bitpos += (u32)nbBits; }
+            if ((bitStream & (u32)(threshold - 1)) < (u32)max) { count = (i32)(bitStream & (u32)(threshold - 1)); bitCount += nbBits - 1; }
+            else { count = (i32)(bitStream & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bitCount += nbBits; }
             count--;
             if (count >= 0) remaining -= count; else remaining += count;
             norm[charnum++] = (short)count;
@@ -159,11 +170,21 @@ ZJ_DEV u32 zd_read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src,
                 nbBits = (i32)zj_hibit((u32)remaining) + 1; threshold = 1 << (nbBits - 1);
             }
             if (charnum >= maxSV1) break;
+            if (ip <= iend - 7 || ip + (bitCount >> 3) <= iend - 4) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32((u32)ip) >> bitCount;
         }
     }
-    if (remaining != 1 || charnum > maxSV1 || bitpos > 8 * srcSize) return 0;
+    if (remaining != 1 || charnum > maxSV1 || bitCount > 32) return 0;
     *maxSV = charnum - 1;
-    return (bitpos + 7) >> 3;
+    return (u32)(ip + ((bitCount + 7) >> 3));
+}
+ZJ_DEV u32 zd_read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src, u32 srcSize) {
+    if (srcSize >= 8) return zd_read_ncount_body(norm, maxSV, tableLog, [&](u32 p) { return ld32(src + p); }, srcSize);
+    u64 pad = 0;
+    for (u32 k = 0; k < srcSize; k++) pad |= (u64)src[k] << (8 * k);
+    u32 const h = zd_read_ncount_body(norm, maxSV, tableLog, [&](u32 p) { return (u32)(pad >> (8 * p)); }, 8);
+    return h > srcSize ? 0 : h;
 }
 
 // ------------------------------------------------------------------ tANS table (one lane) ---
@@ -1042,6 +1063,8 @@ ZJ_DEV u32 zd_compressed_block(const G& g, ZDecShared& sh, const u8* bsrc, u32 b
     if (ZJ_UNI(sh.err)) return opos;
     u32 const nbSeq = ZJ_UNI(sh.nbSeq);
     u32 litUsed = 0;
+    if (nbSeq && frameCap == opos) {                            // sequences but no room at all: zstd_decompress_block.c:2119
+        GRP_SERIAL(g) { sh.err = ZJ_E_DSTSIZE_TOO_SMALL; } g.sync(); return opos; }
     if (nbSeq) {
         pf.mark(3);
         ZDecSeqPriv p;
