@@ -195,6 +195,9 @@ static size_t fse_decode_weights(u8* out, size_t outCap, const u8* src, size_t s
     BitR b; u32 s1, s2; size_t n = 0;
     if (zso_is_error(h)) return h;
     if (tl > 6) return ERR(tableLog_tooLarge);
+    /* table + build workspace for (tableLog, maxSymbol) must fit what HUF_readStats owns, FSE_DECOMPRESS_WKSP_SIZE_U32(6, 11) = 219
+     * words (N/common/fse_decompress.c:273, fse.h:267-273): maxSymbol <= 11 at tableLog 6, <= 91 at tableLog 5 */
+    if ((1u + (1u << tl)) + 1u + ((2u * (maxSV + 1u) + (1u << tl) + 8u + 3u) >> 2) + 129u > 219u) return ERR(tableLog_tooLarge);
     if (h > srcSize) return ERR(corruption_detected);
     if (fse_build(tab, norm, maxSV, tl)) return ERR(GENERIC);
     if (bitr_init(&b, src + h, srcSize - h)) return ERR(corruption_detected);

@@ -202,3 +202,44 @@ def test_ncount_reader_matches_reference_on_random_buffers(emu, oracle_ref, orac
             assert m1.value == m2.value == m3.value and t1.value == t2.value == t3.value, src.hex()
             assert list(n1[:m1.value + 1]) == list(n2[:m1.value + 1]) == list(n3[:m1.value + 1]), src.hex()
     assert ok > 3000
+
+
+def test_huffman_tree_description_reader_matches_reference(emu, oracle_ref):
+    """HUF_readStats (N/common/entropy_common.c:243-305) against the kernels' reader on mutated and random tree descriptions:
+    direct 4-bit weights and FSE-compressed ones — whose table description may name up to 92 symbols at tableLog 5 before the
+    reference's workspace test refuses it (fse_decompress.c:273).  Same verdict, symbol count, depth and weights."""
+    import ctypes as C
+    import random
+    R = oracle_ref.lib()
+    R.HUF_readStats.restype = C.c_size_t
+    R.HUF_readStats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
+    emu.emu_huf_weights.restype = C.c_uint
+    emu.emu_huf_weights.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.POINTER(C.c_uint)]
+    rnd = random.Random(5)
+    seeds = []
+    for _ in range(20):
+        a = rnd.choice([4, 17, 60, 200])
+        seeds.append(oracle_ref.compress(bytes(min(255, int(rnd.expovariate(1.0 / a))) for _ in range(3000)), 3)[9:149])
+    ok = 0
+    for it in range(40000):
+        k = rnd.random()
+        if k < 0.6:
+            s = bytearray(rnd.choice(seeds)); a = rnd.randrange(0, 8); s = s[a:a + rnd.randrange(1, 140)]
+            for _ in range(rnd.randrange(0, 3)):
+                if s: s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        elif k < 0.8:
+            n = rnd.randrange(1, 128)
+            s = bytearray([127 + n]) + bytearray((rnd.randrange(0, 4) << 4) | rnd.randrange(0, 4) for _ in range(rnd.randrange(0, (n + 1) // 2 + 3)))
+        else:
+            s = bytearray(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 40))); s[0] = rnd.randrange(1, min(len(s) + 3, 127))
+        s = bytes(s)
+        w = C.create_string_buffer(256); rank = (C.c_uint * 16)(); nb = C.c_uint(0); tl = C.c_uint(0)
+        r = R.HUF_readStats(w, 256, rank, C.byref(nb), C.byref(tl), s, len(s))
+        w2 = C.create_string_buffer(256); tl2 = C.c_uint(0)
+        e = emu.emu_huf_weights(s, len(s), w2, C.byref(tl2))
+        if R.ZSTD_isError(r) or tl.value > 11:          # 12-bit-deep tables: accepted by the reference, not by the kernels (DESIGN.md §7)
+            assert e == 0 or tl.value > 11, s.hex()
+        else:
+            ok += 1
+            assert e == nb.value and tl2.value == tl.value and w.raw[:nb.value] == w2.raw[:nb.value], s.hex()
+    assert ok > 800

@@ -29,6 +29,7 @@ typedef int64_t i64;
 #define ZJ_DEVM static __device__ __forceinline__   /* static member functions */
 #define ZJ_DEV_MEMBER __device__ __forceinline__
 #define ZJ_DEV_NOINLINE __device__ __noinline__
+#define ZJ_NO_UNROLL _Pragma("unroll 1")
 #define ZJ_HD __host__ __device__ __forceinline__
 #define ZJ_ON_GPU 1
 #else
@@ -36,6 +37,7 @@ typedef int64_t i64;
 #define ZJ_DEVM static inline
 #define ZJ_DEV_MEMBER inline
 #define ZJ_DEV_NOINLINE static
+#define ZJ_NO_UNROLL
 #define ZJ_HD static inline
 #define ZJ_ON_GPU 0
 #endif

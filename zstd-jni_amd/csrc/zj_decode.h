@@ -134,6 +134,7 @@ ZJ_DEV u32 zd_read_ncount_body(short* norm, u32* maxSV, u32* tableLog, RD32 rd32
     u32 bitStream = rd32(0);
     i32 nbBits = (i32)(bitStream & 0xF) + 5, remaining, threshold;
     if (nbBits > 15) return 0;
+    ZJ_NO_UNROLL             // a constant limit makes the compiler unroll this into a register-hungry store burst
     for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
     bitStream >>= 4;
     *tableLog = (u32)nbBits;
@@ -597,16 +598,20 @@ ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* 
         if (iSize + 1 > srcSize) return 0;
         for (u32 n = 0; n < oSize; n += 2) { u32 const b = src[1 + n / 2]; sh.weights[n] = (u8)(b >> 4); if (n + 1 < 256) sh.weights[n + 1] = (u8)(b & 15); }
     } else {
-        // FSE-compressed weights, 2 interleaved states, tableLog <= 6.  Valid weights are 0..12, so
-        // an NCount naming a symbol > 12 is corrupt either way; the 64-cell table, norm[] and
-        // symNext[] live in the (idle) Huffman staging area.
-        u32 maxSV = 12, tl;
+        // FSE-compressed weights, 2 interleaved states, tableLog <= 6.  The description may name more symbols than the 13 weight
+        // values: the reference reads it with a limit of 255 and then refuses it only if table + build workspace for (tableLog,
+        // maxSymbol) exceed the workspace HUF_readStats owns, FSE_DECOMPRESS_WKSP_SIZE_U32(6, 11) = 219 words
+        // (N/common/fse_decompress.c:273, fse.h:267-273) — i.e. maxSymbol <= 11 at tableLog 6 and <= 91 at tableLog 5; weights
+        // above 12 are refused after decoding.  Reading with a limit of 92 symbols gives the same verdicts.  The 64-cell table
+        // lives in the (idle) Huffman staging area, norm[] and symNext[] in the (idle) bit-stream windows.
+        u32 maxSV = 92, tl;
         u32* const wtab = (u32*)&sh.hstage[0][0];              // 64 cells = 256 B
-        short* const norm = (short*)&sh.hstage[2][0];          // 13 shorts
-        u16* const symNext = (u16*)&sh.hstage[2][64];          // 13 u16
+        short* const norm = (short*)&sh.win[0];                // 93 shorts
+        u16* const symNext = (u16*)&sh.win[256];               // 93 u16
         if (iSize + 1 > srcSize) return 0;
         {   u32 const h = zd_read_ncount(norm, &maxSV, &tl, src + 1, iSize);
             if (!h || tl > 6 || h > iSize) return 0;
+            if ((1u + (1u << tl)) + 1u + ((2u * (maxSV + 1u) + (1u << tl) + 8u + 3u) >> 2) + 129u > 219u) return 0;
             if (!zd_build_fse(wtab, norm, symNext, maxSV, tl, 1)) return 0;
             {   const u8* bs = src + 1 + h; u32 const bn = iSize - h;
                 i32 A; u32 s1, s2; u32 n = 0;
