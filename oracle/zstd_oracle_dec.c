@@ -375,6 +375,7 @@ static size_t decode_literals(DState* ds, const u8* src, size_t srcSize, const u
         if (fmt == 0 || fmt == 2) { lh = 1; n = src[0] >> 3; }
         else if (fmt == 1) { lh = 2; n = rd16(src) >> 4; }
         else { if (srcSize < 3) return ERR(corruption_detected); lh = 3; n = rd24(src) >> 4; }
+        if (type == 1 && lh + 1 > srcSize) return ERR(corruption_detected);   /* RLE: the byte must be there before anything else, :310, :315 */
         if (n > blockSizeMax) return ERR(corruption_detected);
         if (n > room) return ERR(dstSize_tooSmall);             /* expectedWriteSize < litSize, :268 / :318 */
         if (type == 0) {

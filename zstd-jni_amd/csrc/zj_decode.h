@@ -873,6 +873,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
             // the reference's order of refusals (zstd_decompress_block.c:150-183, :250-276, :300-326): literals larger than a
             // block, 4 streams for < 6 literals, section larger than the block — and literals larger than the room left in the
             // destination before (raw / RLE) or after (Huffman) the section-size test
+            if (!err && type == 1 && lh + 1 > bsize) err = ZJ_E_CORRUPTION;     // RLE: the byte must be there before anything else (:310, :315)
             if (!err && n > sh.blockSizeMax) err = ZJ_E_CORRUPTION;
             if (!err && type >= 2 && streams == 4 && n < 6) err = ZJ_E_LITERALS_HEADER;
             if (!err && type < 2 && n > room) err = ZJ_E_DSTSIZE_TOO_SMALL;
