@@ -3,7 +3,7 @@ reference, kernel bodies lane-serial:  decode <seed> <seconds>  — frames compr
 damaged one on both pipelines: same bytes or the same refusal code as the reference's portable build;  encode <seed> <seconds> —
 ZSTD_createCDict accepts / refuses the same dictionaries, and where it accepts the frames are byte-identical (dictionaries under
 8 bytes excepted: the reference ignores them, the device digest refuses them and the shim leaves them to the bundled library).
-Round 1: 1.3 M decode and 1.2 M encode cases; the only differences: dictionaries whose damaged Huffman table is 12 bits deep
+Round 1: 25 M decode and 1.2 M encode cases; the only differences: dictionaries whose damaged Huffman table is 12 bits deep
 (refused at load here with dictionary_corrupted; the reference loads them and fails in the block — DESIGN.md §7).  TEST INFRASTRUCTURE."""
 import sys
 mode = sys.argv.pop(1)
