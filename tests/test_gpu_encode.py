@@ -264,3 +264,36 @@ def test_gpu_concurrent_callers(gpu, oracle_ref):
     for th in threads: th.start()
     for th in threads: th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("mode", ["small-batch", "wave-only", "shared"])
+def test_gpu_wave_matcher(gpu, oracle_ref, monkeypatch, mode):
+    """level 3, frames <= 64 KiB: the wave-per-frame matcher (tables in LDS, zj_match_wave.h) gives the reference's bytes — as
+    the small-batch path (the default below 4 096 buffers), as the only matcher of the large-batch pipeline, and sharing a
+    batch with the lane-per-frame matcher through the partitioned queue (ZJNI_HYBRID, an experiment that stays off)"""
+    if mode != "small-batch":
+        monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+        monkeypatch.setenv("ZJNI_HYBRID", "1")
+    if mode == "wave-only":
+        monkeypatch.setenv("ZJNI_WAVE_ONLY", "1")
+    rnd = random.Random(41)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+    datas = [d for _, d in edge_inputs() if len(d) <= 65536]
+    datas += [noise[:3000] + noise[100:2500] + noise[3000:20000] + noise[5000:9000] + noise[20000:60000],
+              noise[:30000] + b"\x00" * 2000 + noise[:30000],
+              bytes(rnd.choice(b"ab") for _ in range(65000)),
+              b"".join(bytes([i & 255]) * rnd.randrange(1, 40) for i in range(4000))[:65536],
+              (noise[:37] * 2000)[:65536], (noise[:64] * 1100)[:65536], (noise[:700] * 100)[:65536]]
+    for _ in range(40):
+        size = rnd.choice([rnd.randrange(1, 300), rnd.randrange(64, 5000), rnd.randrange(64, 65537), 65536])
+        off = rnd.randrange(0, len(xml) - size)
+        datas.append(xml[off:off + size])
+    for _ in range(400):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(64, 5000), rnd.randrange(64, 65537), 65536, 4096])
+        datas.append(gpu.synth_host(size, rnd.randrange(0, 100000), 1) if size else b"")
+    for checksum in (False, True):
+        outs = gpu.compress_batch(datas, 3, checksum=checksum) if checksum else gpu.compress_batch(datas, 3)
+        for k, (d, z) in enumerate(zip(datas, outs)):
+            assert not isinstance(z, Exception), (k, len(d), z)
+            assert z == oracle_ref.compress(d, 3, checksum, 14, 13), (k, len(d), checksum)

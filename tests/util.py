@@ -116,6 +116,32 @@ def emu_compress(L, data, level, split=False, checksum=False, hash_log=0, chain_
     return dst.raw[:r]
 
 
+def emu_wave_libs():
+    """the explicit-SIMT builds of the wave-per-frame matcher: lanes visited in ascending and in descending order"""
+    d = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", d])
+    out = []
+    for name in ("libzjni_emu_wave.so", "libzjni_emu_wave_rev.so"):
+        L = C.CDLL(os.path.join(d, name))
+        L.emu_compress_wave.restype = C.c_ulonglong
+        L.emu_compress_wave.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+        out.append(L)
+    return out
+
+
+def emu_compress_wave(L, data, level=3, checksum=False):
+    """wave-per-frame matcher (zj_match_wave.h, 64 emulated lanes) + entropy stage; frame bytes, -code, or None when the
+    matcher does not take the frame (other level, > 64 KiB, < 64 B)"""
+    cap = len(data) + (len(data) >> 8) + 64 + 128
+    dst = C.create_string_buffer(cap)
+    r = L.emu_compress_wave(data, len(data), dst, cap, level | (0x100 if checksum else 0))
+    if r == (1 << 64) - 1:
+        return None
+    if r >= (1 << 63):
+        return -((1 << 64) - r)
+    return dst.raw[:r]
+
+
 def equal_count_inputs(seed=7):
     """shuffled multisets: many literal values with exactly the same count (the Huffman sort's quicksort then peels one
     element per partition — the case that overflowed the kernels' explicit sort stack), incl. the counts around the

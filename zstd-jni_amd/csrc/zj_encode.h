@@ -144,6 +144,7 @@ struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy; };
 #define ZE_LW_LEVEL(lw) ((lw) & 0xFFu)
 #define ZE_LW_HL(lw) (((lw) >> 8) & 0xFFu)
 #define ZE_LW_CL(lw) (((lw) >> 16) & 0xFFu)
+#define ZE_LW_PERIOD(lw) (((lw) >> 24) & 0xFu)    /* match kernel only: rotation period of the double-fast lane machine, 0 = default */
 #define ZE_HASHLOG_CAP 17u       /* 15 tag bits below the index must fit the product's high dword */
 #define ZE_CHAINLOG_CAP 16u
 ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
@@ -1407,7 +1408,7 @@ ZJ_DEV void ze_match_lane_serial(const u8* src, u32 srcSize, u32 level, u8* tabl
 template <class M>
 ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
     M m; m.init(src, srcSize, ze_params_of(level, srcSize), table, fscratch, maxSrc);
-    for (u32 r = 0; m.st != ZL_DONE; r++) m.round(r);
+    for (u32 r = 0; m.st != ZL_DONE; r++) m.round(M::phase_of(r));
     meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
 }
 // `wide`: the frame is in the launch whose fast-strategy tables hold 4-byte positions (frames > 64 KiB, and the few

@@ -15,6 +15,10 @@
 #include "zj_decode_split.h"
 #include "zj_encode.h"
 #include "zj_cdict.h"
+#ifndef ZW_FRAME_IN_LDS
+#define ZW_FRAME_IN_LDS 0
+#endif
+#include "zj_match_wave.h"
 #include "zj_synth.h"
 
 #define ZJNI_ERR(code) ((size_t)0 - (size_t)(code))
@@ -161,20 +165,49 @@ __device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u
     __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Work queue over a list sorted by search density (zj_enc_score_kernel), cut at `split` (the first entry whose score reaches
+// the threshold).  Entries [split, count) are the wave-per-frame kernel's alone (a lane would sit on such a frame for ~70 000
+// rounds); it takes them from the back with its own counter.  Entries [0, split) are a two-ended queue: the lane-per-frame
+// kernel claims from the front, the wave kernel — once its own part is done — from the back, and they meet wherever their
+// speeds put them.  One 64-bit counter holds both cursors of that part (front low, back high), so every claim sees a
+// consistent pair and exactly `split` claims succeed; a failed claim means the part is exhausted for good.
+// Layout at work2: [0] u64 cursor pair, [2] u32 split, [3] u32 cursor of the wave kernel's own part.
+__device__ __forceinline__ bool zj_claim_front(unsigned long long* work2, u32& k) {
+    u32 const split = ((const u32*)work2)[2];
+    unsigned long long const old = atomicAdd(work2, 1ull);
+    u32 const head = (u32)old, tail = (u32)(old >> 32);
+    k = head;
+    return (u64)head + tail < split;
+}
+__device__ __forceinline__ bool zj_claim_back(unsigned long long* work2, u32 count, u32& k) {
+    u32 const split = ((const u32*)work2)[2];
+    u32 const t = atomicAdd(&((u32*)work2)[3], 1u);
+    if (t < count - split) { k = count - 1u - t; return true; }
+    unsigned long long const old = atomicAdd(work2, 1ull << 32);
+    u32 const head = (u32)old, tail = (u32)(old >> 32);
+    k = split - 1u - tail;
+    return (u64)head + tail < split;
+}
+
 template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
-                                             u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
+                                             u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
+                                             unsigned long long* work2 = nullptr) {
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
     bool have = false; u32 k = 0;
+    u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : ZL_DFAST_PERIOD; u32 ph = 0;   // double-fast machine: rounds per rotation of the non-search states
     for (u32 r = 0;; r++) {
         if (m.st == ZL_DONE) {
             if (have) {
                 u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false;
                 zj_publish_done(doneList, doneCount, k);
             }
+            if (work2) { if (!zj_claim_front(work2, k)) break; }
+            else {
             k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
+            }
             u32 const i = list[k];
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
@@ -182,7 +215,8 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc);
             have = true;
         }
-        m.round(ZJ_UNI(r));
+        m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
+        ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
     if (blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
@@ -196,12 +230,97 @@ __device__ __forceinline__ u32 zj_slice_count(const u32* countPtr, u32 listBase,
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                                           u32 listBase, u32 sliceLen) {
+                                                           u32 listBase, u32 sliceLen, unsigned long long* work2) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
-    else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
+    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
+    else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
 }
+
+// Wave-per-frame match finding (zj_match_wave.h): level-3 frames <= 64 KiB with the tables in LDS, claimed from the back of the
+// sorted list.  Records and meta of list entry k go where the lane kernel would put them, completion goes to the same queue.
+__global__ __launch_bounds__(64) void zj_enc_match_wave_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                                const u32* __restrict__ list, const u32* countPtr, unsigned long long* work2,
+                                                                u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount) {
+    ZWLds& lds = *(ZWLds*)zj_dyn_lds;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 k = 0, ok = 0;
+        if (threadIdx.x == 0) ok = zj_claim_back(work2, count, k) ? 1u : 0u;
+        ok = ZJ_UNI(ok); k = ZJ_UNI(k);
+        if (!ok) break;
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const s0 = zj_uni64(srcOff[i]); u32 const size = (u32)(zj_uni64(srcOff[i + 1]) - s0);
+        u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc); u32* const mt = meta + 3 * (size_t)k;
+        if (size >= 64u) zw_match_frame(lds, src + s0, size, level, fs, maxSrc, mt);
+        else {                                           // tiny frame: the plain loop on lane 0, tables in LDS
+            ZEParams const p = ze_params_of(level, size);
+            for (u32 j = threadIdx.x; j < (1u << p.hashLog); j += 64u) lds.HL[j] = 0;
+            for (u32 j = threadIdx.x; j < (1u << p.chainLog); j += 64u) lds.HS[j] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                ZEOut o; o.seqs = (ZESeq*)fs; o.litOff = (u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
+                u32 lastLL = size;
+                if (size >= 7u) lastLL = ze_block_dfast<ZEEnt16>(o, src + s0, size, p.hashLog, p.chainLog, p.minMatch, lds.HL, lds.HS);
+                mt[0] = o.n; mt[1] = o.lit + lastLL; mt[2] = lastLL;
+            }
+        }
+        if (threadIdx.x == 0) zj_publish_done(doneList, doneCount, k);
+        __syncthreads();
+    }
+}
+
+// Search-density score of each listed frame: distinct 4-byte values among 1 024 consecutive positions from the middle of the
+// frame (hashed into a 4 096-bit set), 0..63.  Text-like frames (few distinct values: almost every position starts a match)
+// score low, frames that are searched position by position score high.
+__global__ __launch_bounds__(64) void zj_enc_score_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
+                                                           const u32* countPtr, u8* score) {
+    __shared__ u32 bm[128];
+    u32 const count = ZJ_UNI(*countPtr);
+    for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const s0 = zj_uni64(srcOff[i]); u32 const size = (u32)(zj_uni64(srcOff[i + 1]) - s0);
+        u32 sc = 0;
+        if (size >= 64u) {
+            u32 const avail = size - 4u, S = avail < 1024u ? avail : 1024u, off = (avail - S) >> 1;
+            bm[threadIdx.x] = 0; bm[threadIdx.x + 64u] = 0;
+            __syncthreads();
+            for (u32 p = threadIdx.x; p < S; p += 64u) {
+                u32 const h = (ld32(src + s0 + off + p) * 2654435761u) >> 20;
+                atomicOr(&bm[h >> 5], 1u << (h & 31u));
+            }
+            __syncthreads();
+            u32 c = (u32)__popc(bm[threadIdx.x]) + (u32)__popc(bm[threadIdx.x + 64u]);
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+            sc = (c * 64u) / S; if (sc > 63u) sc = 63u;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) score[k] = (u8)sc;
+    }
+}
+// Partition of the list for the two match kernels: frames scoring at least `threshold` go to the back (the wave kernel's own
+// part, counted from the end) — at most `cap` of them, the wave kernel is the slower of the two per frame and what it takes
+// off the lane kernel is HBM requests — everything else to the front IN LIST ORDER (as far as the atomics keep it): a lane
+// wave should hold a mix of cheap and expensive frames, 64 expensive ones in one wave leave it running alone at the end.
+// work2: [0] u64 cursor pair, [2] split, [3] cursor of the wave kernel's part, [4] search-dense frames seen, [5] front fill.
+__global__ __launch_bounds__(256) void zj_enc_partition_kernel(const u32* __restrict__ list, const u32* countPtr, const u8* __restrict__ score, u32 threshold,
+                                                               u32 sharePermille, unsigned long long* work2, u32* sorted) {
+    u32 const k = blockIdx.x * blockDim.x + threadIdx.x, count = *countPtr;
+    if (k >= count) return;
+    u32* const w = (u32*)work2;
+    u32 const cap = (u32)(((u64)count * sharePermille) / 1000u);
+    if (score[k] >= threshold) {
+        u32 const r = atomicAdd(&w[4], 1u);
+        if (r < cap) { sorted[count - 1u - r] = list[k]; return; }
+    }
+    sorted[atomicAdd(&w[5], 1u)] = list[k];
+}
+__global__ void zj_enc_partition_done_kernel(const u32* countPtr, u32 sharePermille, unsigned long long* work2) {
+    u32* const w = (u32*)work2;
+    u32 const count = *countPtr, cap = (u32)(((u64)count * sharePermille) / 1000u);
+    w[2] = count - (w[4] < cap ? w[4] : cap);
+}
+
 // The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_wide_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
@@ -369,6 +488,7 @@ struct DevState {
     hipEvent_t tev[8] = {};                           // stage boundaries of the last batch calls (zjni_last_timing)
     bool tevCompress = false, tevDecompress = false;
     hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t waveStream = nullptr; hipEvent_t evJoinWave = nullptr; int waveGrid = 0;   // wave-per-frame matcher beside the lane-per-frame one
     // batch calls share the per-device scratch: they are enqueued under `enqueueMu`, and each call's kernels wait (on the
     // GPU) for the previous call's last kernel, whatever streams the callers use — many host threads may call at once
     std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;   // entropy stage beside the match kernel
@@ -426,7 +546,11 @@ DevState* get_state(int ordinal) {
         if (hipEventCreateWithFlags(&d.lastDone, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipMalloc(&d.counters, 256) != hipSuccess) return nullptr;
+        if (hipMalloc(&d.counters, 1024) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&d.waveStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d.evJoinWave, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipFuncSetAttribute((const void*)zj_enc_match_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZWLds)) != hipSuccess) return nullptr;
+        {   int w = 3; if (const char* ov = getenv("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
+            d.waveGrid = d.numCU * w; }
         for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
@@ -488,6 +612,7 @@ void zjni_shutdown(void) {
         if (d.cdList) (void)hipFree(d.cdList);
         for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
         if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
+        if (d.waveStream) { (void)hipStreamDestroy(d.waveStream); (void)hipEventDestroy(d.evJoinWave); }
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
@@ -714,11 +839,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (d->encListCap < n) {                      // grows rarely; the only synchronous step of this entry
         if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
         size_t const cap = n + (n >> 2) + 1024;
-        if (hipMalloc(&d->encList, 2 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
+        if (hipMalloc(&d->encList, 3 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
         d->encListCap = cap;
     }
     u32* const ctr = d->counters + 16;            // [0] |A|, [1] |B|, [2] work A, [3] work B
-    u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap;
+    u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap; u32* const listS = d->encList + 2 * d->encListCap;
     if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     u32 const ldsA = (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
@@ -729,20 +854,44 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (const char* ov = getenv("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (tuned) splitMin = 1;                      // explicit table sizes exist only on the lane-per-frame path (tables in HBM)
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
-    if (n >= splitMin) {
+    // Small level-3 batches: list A goes through the wave-per-frame matcher (tables in LDS, 64 positions per step) and the
+    // entropy kernel instead of the fused kernel, whose match finder is one lane walking the frame (3-10x the latency).
+    bool const smallWave = n < splitMin && level == 3 && !tuned && getenv("ZJNI_NO_OVERLAP") == nullptr && getenv("ZJNI_NO_WAVE") == nullptr;
+    if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
-        size_t const tablesBytes = n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
-        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + 256;
+        size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
+        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256;
         if (d->splitBufCap < need) {
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->splitBufCap = need;
         }
         u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
-        u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n;
+        u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
         bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
-        if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        // Experiment (ZJNI_HYBRID=1, off by default): at level 3 with the LDS-sized tables the two match
+        // finders share a large batch — the list is partitioned by search density, the lane-per-frame kernel (tables in HBM,
+        // bound by their random requests) takes the match-dense part, the wave-per-frame kernel (tables in LDS) the rest.
+        // Measured on the metric configuration it does not pay: the wave kernel needs the LDS the entropy kernel runs in,
+        // and under the lane kernel's traffic it falls to half its stand-alone rate.
+        bool const hybrid = smallWave || (overlap && level == 3 && !tuned && getenv("ZJNI_HYBRID") != nullptr && getenv("ZJNI_NO_WAVE") == nullptr);
+        bool const waveOnly = smallWave || (hybrid && getenv("ZJNI_WAVE_ONLY") != nullptr);
+        unsigned long long* const work2 = (unsigned long long*)(d->counters + 192);
+        const u32* listM = listA;
+        if (hybrid && hipMemsetAsync(work2, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);   // split = 0: the whole list is the wave kernel's
+        if (hybrid && !waveOnly) {
+            u32 const gs = (u32)(n < (size_t)d->numCU * 16 ? n : (size_t)d->numCU * 16);
+            u32 threshold = 40;                       // text / JSON-like frames score 15-25, frames searched position by position 50+
+            if (const char* ov = getenv("ZJNI_WAVE_SCORE")) threshold = (u32)atoi(ov);
+            u32 share = 150;                          // permille of the batch the wave kernel takes at most
+            if (const char* ov = getenv("ZJNI_WAVE_SHARE")) share = (u32)atoi(ov);
+            hipLaunchKernelGGL(zj_enc_score_kernel, dim3(gs), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listA, (const u32*)ctr, score);
+            hipLaunchKernelGGL(zj_enc_partition_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u32*)listA, (const u32*)ctr, (const u8*)score, threshold, share, work2, listS);
+            hipLaunchKernelGGL(zj_enc_partition_done_kernel, dim3(1), dim3(1), 0, st, (const u32*)ctr, share, work2);
+            listM = listS;
+        }
+        if (tablesBytes && hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
         u32 gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
@@ -759,21 +908,33 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             // actually being co-scheduled.
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hybrid && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             (void)hipEventRecord(d->tev[0], st);
-            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu);
+            if (hybrid) {
+                u32 const gw = (u32)(n < (size_t)d->waveGrid ? n : (size_t)d->waveGrid);
+                hipLaunchKernelGGL(zj_enc_match_wave_kernel, dim3(gw), dim3(64), sizeof(ZWLds), d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   listM, (const u32*)ctr, work2, fscratch, maxSrc, meta, doneList, mctr + 1);
+                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            }
+            u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machine (0 = ZL_DFAST_PERIOD)
+            if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
+            if (!waveOnly)
+            hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
+                               listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu,
+                               hybrid ? work2 : (unsigned long long*)nullptr);
+            if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         } else {
             (void)hipEventRecord(d->tev[0], st);
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu);
+                               (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (unsigned long long*)nullptr);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,

@@ -133,6 +133,7 @@ struct ZLaneD {
     }
     ZJ_DEV_MEMBER void fin_or_back() { if (more) st = ZL_BACK; else fin(); }
 
+    ZJ_DEVM u32 phase_of(u32 r) { return r % ZL_DFAST_PERIOD; }
     ZL_PROF_MEMBERS
     // Round r of the wavefront.  A searching lane advances every round; the other states take turns (r mod 8:
     // count/backward, post-insert/reload, restart in consecutive rounds, then five search-only rounds), so a
@@ -143,8 +144,10 @@ struct ZLaneD {
     // and by latency once only the frames with the most positions are left; pacing the match-dense frames
     // (which need 3x fewer rounds) leaves request slots to the search-dense ones and evens out the finish
     // times (measured: period 4 -> 8 is -6 % kernel time at 65 536 frames).
+    // `r` is the round's phase within the period (0 .. period-1); the period is the caller's choice (ZL_DFAST_PERIOD when
+    // one match kernel parses the whole batch; shorter when the search-dense frames go to the wave-per-frame kernel)
     ZJ_DEV_MEMBER void round(u32 r) {
-        switch (r % ZL_DFAST_PERIOD) {
+        switch (r) {
         case 0: round_t<ZL_EN_COUNT>(); break;
         case 1: round_t<ZL_EN_POST>(); break;
         case 2: round_t<ZL_EN_START>(); break;
@@ -339,6 +342,7 @@ struct ZLaneF {
         begin_count(ip0 + 4u, mpos + 4u, ZC_FOUND); needBack = true; bk = 0; more = false;
     }
 
+    ZJ_DEVM u32 phase_of(u32 r) { return r; }
     ZL_PROF_MEMBERS
     // The search state runs every round; count/backward, post-insert/reload and restart take turns (r mod period = 0, 1, 2;
     // see ZLaneD::round).  With one round per pair the kernel sits at ~80 % of the read+write request plateau
