@@ -105,6 +105,13 @@ size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src
  * (double-fast): hashLog 6..17, chainLog 6..16, frames byte-identical to the reference called with the same two
  * parameters — with 16 / 15 that is the reference's plain level 3.  Not set, level 3 uses 14 / 13.
  * Other levels with a non-zero value: ZSTD_error_parameter_unsupported; out of range: parameter_outOfBound. */
+/* Frame-header parameters: the `checksum` argument of the *_advanced and *_usingCDict entries is a flag word —
+ * ZSTD_c_checksumFlag, ZSTD_c_contentSizeFlag = 0 (ZstdCompressCtx.setContentSize0(false), N/jni_fast_zstd.c:301-308: no frame
+ * content size, a window descriptor instead; without a dictionary only) and ZSTD_c_dictIDFlag = 0 (setDictID0(false), :313-320).
+ * A plain 0 / 1 keeps meaning "checksum off / on" with the other two at their defaults. */
+#define ZJNI_FRAME_CHECKSUM       1
+#define ZJNI_FRAME_NO_CONTENTSIZE 2
+#define ZJNI_FRAME_NO_DICTID      4
 size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_src_off,
                                            void* d_dst, const uint64_t* d_dst_off,
                                            uint64_t* d_result, size_t n, int level, int checksum, int hashLog, int chainLog, void* stream);

@@ -85,7 +85,7 @@ def _check(r):
     return r
 
 
-def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0) -> bytes:
+def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0, content_size: bool = True) -> bytes:
     """ZSTD_compress2 with the parameters zstd-jni's ZstdCompressCtx sets
     (reference src/main/native/jni_fast_zstd.c:606-607)."""
     L = lib()
@@ -93,6 +93,8 @@ def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int 
     try:
         _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_compressionLevel, level))
         _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_checksumFlag, int(checksum)))
+        if not content_size:
+            _check(L.ZSTD_CCtx_setParameter(cctx, 200, 0))                        # ZSTD_c_contentSizeFlag: ZstdCompressCtx.setContentSize(false)
         if hash_log:
             _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_hashLog, hash_log))      # ZstdCompressCtx.setHashLog
         if chain_log:
@@ -218,12 +220,14 @@ class CDict:
     def __del__(self):
         self.close()
 
-    def compress(self, data: bytes, checksum: bool = False) -> bytes:
+    def compress(self, data: bytes, checksum: bool = False, dict_id: bool = True) -> bytes:
         """ZstdCompressCtx.loadDict(ZstdDictCompress) + compress: ZSTD_CCtx_refCDict then ZSTD_compress2."""
         L = lib()
         cctx = L.ZSTD_createCCtx()
         try:
             _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_checksumFlag, int(checksum)))
+            if not dict_id:
+                _check(L.ZSTD_CCtx_setParameter(cctx, 202, 0))                    # ZSTD_c_dictIDFlag: ZstdCompressCtx.setDictID(false)
             _check(L.ZSTD_CCtx_refCDict(cctx, self.ptr))
             cap = L.ZSTD_compressBound(len(data))
             dst = C.create_string_buffer(max(cap, 1))

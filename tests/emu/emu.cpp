@@ -84,8 +84,8 @@ extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned sr
     u8* lds = (u8*)calloc(1, 160 * 1024);
     u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
     ZjProf pf; pf.start(nullptr);
-    // level & 0xFF = level, bit 8 = checksum flag
-    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level & 0xFFu, ws, pf, nullptr, (level >> 8) & 1u);
+    // level & 0xFF = level, bits 8-10 = frame flags (ZE_FLAG_CHECKSUM, ZE_FLAG_NO_FCS, ZE_FLAG_NO_DICTID)
+    u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level & 0xFFu, ws, pf, nullptr, (level >> 8) & ZE_FLAG_MASK);
     free(ws); free(lds); free(sh);
     return r;
 }
@@ -107,7 +107,7 @@ extern "C" unsigned emu_check_code_tables() {
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
     Grp<1> g;
-    u32 const flags = (level >> 8) & 1u, hl = (level >> 16) & 0xFFu, cl = (level >> 24) & 0xFFu; level &= 0xFFu;   // test encoding: level | checksum << 8 | hashLog << 16 | chainLog << 24
+    u32 const flags = (level >> 8) & ZE_FLAG_MASK, hl = (level >> 16) & 0xFFu, cl = (level >> 24) & 0xFFu; level &= 0xFFu;   // test encoding: level | frame flags << 8 | hashLog << 16 | chainLog << 24
     u32 const lw = ZE_LW(level, hl, cl);
     u32 const ldsA = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     bool const wide = (hl | cl) ? srcSize > 65536u : ze_lds_need(level, srcSize) > (ldsA > (u32)sizeof(ZEEntropy) ? ldsA : (u32)sizeof(ZEEntropy));
@@ -163,7 +163,7 @@ extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned c
     if (srcSize <= ze_attach_cutoff(cd->strategy)) ze_match_lane_dict(src, srcSize, cd, table, fs, ZC_MAX_SRC, meta);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZC_MAX_SRC) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
-    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & 1u, cd, 160u * 1024u);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & ZE_FLAG_MASK, cd, 160u * 1024u);
     free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }

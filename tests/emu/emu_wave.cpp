@@ -2,6 +2,8 @@
 // CPU-side parity tests: 64 emulated lanes, lockstep between the cross-lane points.  Built twice: lanes visited in ascending
 // order, and (-DZW_EMU_REVERSE) in descending order — where several lanes store to one LDS address in the same step the GPU
 // lets an unspecified lane win; the two builds let the lowest and the highest lane win, and the frames must not depend on it.
+// The descending build also reads the frame the way the product library does (ZW_FRAME_IN_LDS=0: clamped reads from global
+// memory), the ascending one from the staged copy with unclamped reads.
 // TEST INFRASTRUCTURE ONLY: never linked into libzjni_amd.so.
 #include "../../zstd-jni_amd/csrc/zj_encode.h"
 #include "../../zstd-jni_amd/csrc/zj_match_wave.h"
@@ -11,7 +13,7 @@
 // level word as in emu_compress_split (level | checksum << 8); returns ~0 when the wave matcher does not take the frame
 extern "C" unsigned long long emu_compress_wave(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     Grp<1> g;
-    u32 const flags = (level >> 8) & 1u; level &= 0xFFu;
+    u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
     if (level != 3 || srcSize > 65536u || !zw_takes(ze_params_of(level, srcSize), srcSize)) return ~0ull;
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
     u8* lds = (u8*)calloc(1, 160 * 1024);

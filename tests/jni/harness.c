@@ -14,8 +14,8 @@
 typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
 static Obj* mk(int kind, jsize len) { Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = kind; o->len = len; o->data = (char*)calloc((size_t)len + 16, kind == 4 ? 8 : 1); return o; }
 
-static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return b ? ((Obj*)b)->data : NULL; }
-static jlong JNICALL f_GetDirectBufferCapacity(JNIEnv* e, jobject b) { (void)e; return b ? ((Obj*)b)->len : -1; }
+static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return (b && ((Obj*)b)->kind == 1) ? ((Obj*)b)->data : NULL; }
+static jlong JNICALL f_GetDirectBufferCapacity(JNIEnv* e, jobject b) { (void)e; return (b && ((Obj*)b)->kind == 1) ? ((Obj*)b)->len : -1; }
 static jsize JNICALL f_GetArrayLength(JNIEnv* e, jarray a) { (void)e; return ((Obj*)a)->len; }
 static void* JNICALL f_GetPrimitiveArrayCritical(JNIEnv* e, jarray a, jboolean* c) { (void)e; if (c) *c = JNI_FALSE; return ((Obj*)a)->data; }
 static void JNICALL f_ReleasePrimitiveArrayCritical(JNIEnv* e, jarray a, void* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
@@ -29,6 +29,13 @@ static jlong JNICALL f_GetLongField(JNIEnv* e, jobject o, jfieldID f) { (void)e;
 static void JNICALL f_SetLongField(JNIEnv* e, jobject o, jfieldID f, jlong v) { (void)e; (void)f; ((Obj*)o)->field = v; }
 static jstring JNICALL f_NewStringUTF(JNIEnv* e, const char* s) { (void)e; Obj* o = mk(5, (jsize)strlen(s) + 1); strcpy(o->data, s); return (jstring)o; }
 
+static jclass JNICALL f_FindClass(JNIEnv* e, const char* n) { (void)e; (void)n; return (jclass)mk(7, 0); }
+static jmethodID JNICALL f_GetMethodID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)n; (void)sig; return (jmethodID)(intptr_t)2; }
+static jobject JNICALL f_NewObject(JNIEnv* e, jclass c, jmethodID m, ...) { (void)e; (void)c; (void)m; return (jobject)mk(7, 0); }
+static jbyte* JNICALL f_GetByteArrayElements(JNIEnv* e, jbyteArray a, jboolean* c) { (void)e; if (c) *c = JNI_FALSE; return (jbyte*)((Obj*)a)->data; }
+static void JNICALL f_ReleaseByteArrayElements(JNIEnv* e, jbyteArray a, jbyte* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
+static int g_deleted;
+static void JNICALL f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; g_deleted++; }
 static struct JNINativeInterface_ g_fn;
 static const struct JNINativeInterface_* g_envp = &g_fn;
 static JNIEnv* env(void) {
@@ -37,6 +44,8 @@ static JNIEnv* env(void) {
     g_fn.ReleasePrimitiveArrayCritical = f_ReleasePrimitiveArrayCritical; g_fn.GetByteArrayRegion = f_GetByteArrayRegion;
     g_fn.SetByteArrayRegion = f_SetByteArrayRegion; g_fn.GetObjectArrayElement = f_GetObjectArrayElement;
     g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
+    g_fn.GetByteArrayElements = f_GetByteArrayElements; g_fn.ReleaseByteArrayElements = f_ReleaseByteArrayElements;
+    g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef;
     g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField;
     return (JNIEnv*)&g_envp;
 }
@@ -62,11 +71,13 @@ typedef struct {
     void (*ddictInit)(JNIEnv*, jobject, jbyteArray, jint, jint); void (*ddictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint);
     void (*ddictFree)(JNIEnv*, jobject); jlong (*loadDDict)(JNIEnv*, jclass, jlong, jobject);
     jlong (*cBatchDict)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jobject, jboolean);                /* shim only */
+    void* h;
 } Lib;
 #define P "Java_com_github_luben_zstd_"
 static int load(Lib* L, const char* path, int isRef) {
     void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!h) { printf("dlopen %s: %s\n", path, dlerror()); return 0; }
+    L->h = h;
 #define S(field, name) *(void**)&L->field = dlsym(h, P name)
     S(cinit, "ZstdCompressCtx_init"); S(cfree, "ZstdCompressCtx_free"); S(setLevel, "ZstdCompressCtx_setLevel0"); S(setChecksum, "ZstdCompressCtx_setChecksum0");
     S(cDirect, "ZstdCompressCtx_compressDirectByteBuffer0"); S(cArray, "ZstdCompressCtx_compressByteArray0");
@@ -104,10 +115,13 @@ static int g_checks, g_bad;
 int main(int argc, char** argv) {
     Lib R, G; JNIEnv* e = env();
     jsize const sizes[] = {0, 1, 17, 100, 4096, 20000, 65536, 131072};
+    setvbuf(stdout, NULL, _IONBF, 0);
     if (argc < 3) { printf("usage: harness <ref-jni.so> <shim.so>\n"); return 2; }
+#define STAGE(name) do { if (getenv("HARNESS_VERBOSE")) printf("stage: %s (checks so far %d, bad %d)\n", name, g_checks, g_bad); } while (0)
     memset(&R, 0, sizeof R); memset(&G, 0, sizeof G);
     if (!load(&R, argv[1], 1) || !load(&G, argv[2], 0)) return 2;
 
+    STAGE("class Zstd helpers");
     /* class Zstd helpers */
     {   jlong const probes[] = {0, 1, 255, 4096, 65536, 131072, 1 << 20};
         for (unsigned i = 0; i < sizeof probes / sizeof *probes; i++) CHECK(R.bound(e, NULL, probes[i]) == G.bound(e, NULL, probes[i]), "compressBound(%lld)", (long long)probes[i]);
@@ -172,6 +186,7 @@ int main(int argc, char** argv) {
         }
         R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
     }
+    STAGE("explicit table sizes");
     /* ZstdCompressCtx.setHashLog / setChainLog: with the level's own table sizes the shim's frames are the reference's PLAIN level 3 */
     if (maxLevel >= 3) {
         jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
@@ -186,6 +201,7 @@ int main(int argc, char** argv) {
         }
         R.cfree(e, NULL, rc); G.cfree(e, NULL, gc);
     }
+    STAGE("raw-content dictionary");
     /* ZstdDictCompress + ZstdCompressCtx.loadDict (N/jni_fast_zstd.c:13-66, :325-336): a raw-content dictionary, sources inside the
      * attach range, byte[] and direct-buffer constructors */
     for (int level = 1; level <= maxLevel; level++) for (int direct = 0; direct < 2; direct++) {
@@ -271,6 +287,175 @@ int main(int argc, char** argv) {
         CHECK(r2 == 0, "decompressBatch0 returned %lld", (long long)r2);
         for (int i = 0; i < NB; i++) CHECK(((jlong*)res2->data)[i] == srcs->elems[i]->len && !memcmp(outs->elems[i]->data, srcs->elems[i]->data, (size_t)srcs->elems[i]->len), "batch round trip %d", i);
         R.cfree(e, NULL, rc);
+    }
+    STAGE("frame parameters");
+    /* ---- the natives that shape or reuse a context beyond level + checksum (N/jni_fast_zstd.c:296-390, :686-716, :832-905) ---- */
+#define SYM(L, T, name) ((T)dlsym((L).h, P name))
+    typedef void (*setflag_fn)(JNIEnv*, jclass, jlong, jboolean);
+    typedef jlong (*ctx1_fn)(JNIEnv*, jclass, jlong);
+    typedef jlong (*loadbytes_fn)(JNIEnv*, jclass, jlong, jbyteArray);
+    typedef jlong (*buf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+    {   setflag_fn rCS = SYM(R, setflag_fn, "ZstdCompressCtx_setContentSize0"), gCS = SYM(G, setflag_fn, "ZstdCompressCtx_setContentSize0");
+        ctx1_fn rReset = SYM(R, ctx1_fn, "ZstdCompressCtx_reset0"), gReset = SYM(G, ctx1_fn, "ZstdCompressCtx_reset0");
+        CHECK(rCS && gCS && rReset && gReset, "setContentSize0 / reset0 exported");
+        for (int level = 1; level <= maxLevel && gCS && gReset; level += 2) {
+            jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
+            R.setLevel(e, NULL, rc, level); G.setLevel(e, NULL, gc, level);
+            if (level == 3) { R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13); }
+            for (int pass = 0; pass < 3; pass++) {           /* content size off, on again, then after reset0 */
+                if (pass == 0) { rCS(e, NULL, rc, JNI_FALSE); gCS(e, NULL, gc, JNI_FALSE); }
+                if (pass == 1) { rCS(e, NULL, rc, JNI_TRUE); gCS(e, NULL, gc, JNI_TRUE); R.setChecksum(e, NULL, rc, JNI_TRUE); G.setChecksum(e, NULL, gc, JNI_TRUE); }
+                if (pass == 2) { CHECK(rReset(e, NULL, rc) == gReset(e, NULL, gc), "reset0 result"); R.setLevel(e, NULL, rc, 1); G.setLevel(e, NULL, gc, 1); }   /* reset dropped the checksum flag */
+                for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) {
+                    jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
+                    Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
+                    fill(src->data, n, (int)(si % 3));
+                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap, src, 0, n), gr = G.cDirect(e, NULL, gc, gdst, 0, cap, src, 0, n);
+                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "frame parameters pass %d L%d n=%d: ref %lld gpu %lld", pass, level, n, (long long)rr, (long long)gr);
+                    if (rr > 0 && pass == 0) {               /* a frame without content size decodes through the shim too */
+                        jlong dd = G.dinit(e, NULL); Obj* out = mk(1, n + 1);
+                        CHECK(G.dDirect(e, NULL, dd, out, 0, n, rdst, 0, (jint)rr) == n && !memcmp(out->data, src->data, (size_t)n), "decode frame without content size n=%d", n);
+                        G.dfree(e, NULL, dd);
+                    }
+                }
+            }
+            R.cfree(e, NULL, rc); G.cfree(e, NULL, gc);
+        }
+    }
+    STAGE("zstd-format dictionary");
+    /* a zstd-format dictionary (with an ID): setDictID0(false), loadDDict0(byte[]), loadCDict0(byte[]), the two mixed decompress natives */
+    if (getenv("HARNESS_DICT_FILE")) {
+        FILE* fp = fopen(getenv("HARNESS_DICT_FILE"), "rb"); Obj* darr = mk(2, 200000); jsize dlen = 0;
+        if (fp) { dlen = (jsize)fread(darr->data, 1, 200000, fp); fclose(fp); }
+        darr->len = dlen;
+        CHECK(dlen > 100, "dictionary file");
+        setflag_fn rDI = SYM(R, setflag_fn, "ZstdCompressCtx_setDictID0"), gDI = SYM(G, setflag_fn, "ZstdCompressCtx_setDictID0");
+        loadbytes_fn rLD = SYM(R, loadbytes_fn, "ZstdDecompressCtx_loadDDict0"), gLD = SYM(G, loadbytes_fn, "ZstdDecompressCtx_loadDDict0");
+        loadbytes_fn rLC = SYM(R, loadbytes_fn, "ZstdCompressCtx_loadCDict0"), gLC = SYM(G, loadbytes_fn, "ZstdCompressCtx_loadCDict0");
+        buf_fn rA2D = SYM(R, buf_fn, "ZstdDecompressCtx_decompressByteArrayToDirectByteBuffer0"), gA2D = SYM(G, buf_fn, "ZstdDecompressCtx_decompressByteArrayToDirectByteBuffer0");
+        buf_fn rD2A = SYM(R, buf_fn, "ZstdDecompressCtx_decompressDirectByteBufferToByteArray0"), gD2A = SYM(G, buf_fn, "ZstdDecompressCtx_decompressDirectByteBufferToByteArray0");
+        ctx1_fn rDReset = SYM(R, ctx1_fn, "ZstdDecompressCtx_reset0"), gDReset = SYM(G, ctx1_fn, "ZstdDecompressCtx_reset0");
+        CHECK(gDI && gLD && gLC && gA2D && gD2A && gDReset, "setDictID0 / loadDDict0 / loadCDict0 / mixed decompress natives / reset0 exported");
+        for (int level = 1; level <= maxLevel && gDI && gLD && gA2D && gD2A; level += 2) {
+            Obj* robj = mk(6, 0); Obj* gobj = mk(6, 0);
+            jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
+            R.dictInit(e, robj, (jbyteArray)darr, 0, dlen, level); G.dictInit(e, gobj, (jbyteArray)darr, 0, dlen, level);
+            CHECK(R.loadCDict(e, NULL, rc, robj) == G.loadCDict(e, NULL, gc, gobj), "loadCDictFast0 (zstd-format dictionary)");
+            CHECK(rLD(e, NULL, rd, (jbyteArray)darr) == gLD(e, NULL, gd, (jbyteArray)darr), "loadDDict0");
+            for (int noID = 0; noID < 2; noID++) {
+                jsize const srcSizes[] = {0, 300, 3000, 8000};
+                rDI(e, NULL, rc, noID ? JNI_FALSE : JNI_TRUE); gDI(e, NULL, gc, noID ? JNI_FALSE : JNI_TRUE);
+                for (unsigned si = 0; si < sizeof srcSizes / sizeof *srcSizes; si++) {
+                    jsize const n = srcSizes[si], cap = (jsize)R.bound(e, NULL, n) + 16;
+                    Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
+                    fill(src->data, n, 0);
+                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap, src, 0, n), gr = G.cDirect(e, NULL, gc, gdst, 0, cap, src, 0, n);
+                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "dictID flag %d L%d n=%d: ref %lld gpu %lld", !noID, level, n, (long long)rr, (long long)gr);
+                    if (rr > 0) {                               /* back through the byte[]-dictionary contexts, by the two mixed natives */
+                        Obj* farr = mk(2, (jsize)rr + 4); Obj* out1 = mk(1, n + 3); Obj* out2 = mk(1, n + 3); Obj* oarr1 = mk(2, n + 3); Obj* oarr2 = mk(2, n + 3);
+                        memcpy(farr->data + 2, rdst->data, (size_t)rr);
+                        jlong const a = rA2D(e, NULL, rd, out1, 1, n, farr, 2, (jint)rr), b = gA2D(e, NULL, gd, out2, 1, n, farr, 2, (jint)rr);
+                        CHECK(a == b && a == n && !memcmp(out2->data + 1, src->data, (size_t)n), "decompressByteArrayToDirectByteBuffer0 n=%d: ref %lld gpu %lld", n, (long long)a, (long long)b);
+                        jlong const c = rD2A(e, NULL, rd, oarr1, 2, n, rdst, 0, (jint)rr), d = gD2A(e, NULL, gd, oarr2, 2, n, rdst, 0, (jint)rr);
+                        CHECK(c == d && c == n && !memcmp(oarr2->data + 2, src->data, (size_t)n), "decompressDirectByteBufferToByteArray0 n=%d: ref %lld gpu %lld", n, (long long)c, (long long)d);
+                        CHECK(rA2D(e, NULL, rd, out1, 1, n, farr, 2, (jint)rr + 9) == gA2D(e, NULL, gd, out2, 1, n, farr, 2, (jint)rr + 9), "mixed native: src range");
+                        CHECK(rD2A(e, NULL, rd, oarr1, 5, n, rdst, 0, (jint)rr) == gD2A(e, NULL, gd, oarr2, 5, n, rdst, 0, (jint)rr), "mixed native: dst range");
+                        CHECK(rA2D(e, NULL, rd, NULL, 1, n, farr, 2, (jint)rr) == gA2D(e, NULL, gd, NULL, 1, n, farr, 2, (jint)rr), "mixed native: null dst");
+                    }
+                }
+            }
+            /* the decompress context after reset0 has no dictionary any more: same answer from both */
+            {   Obj* src = mk(1, 2000); Obj* fr = mk(1, 3000); Obj* o1 = mk(1, 2000); Obj* o2 = mk(1, 2000); fill(src->data, 2000, 0);
+                jlong const rr = R.cDirect(e, NULL, rc, fr, 0, 3000, src, 0, 2000);
+                CHECK(rDReset(e, NULL, rd) == gDReset(e, NULL, gd), "ZstdDecompressCtx.reset0");
+                CHECK(R.dDirect(e, NULL, rd, o1, 0, 2000, fr, 0, (jint)rr) == G.dDirect(e, NULL, gd, o2, 0, 2000, fr, 0, (jint)rr), "dictionary frame after reset0"); }
+            /* a byte[] dictionary on the compress side: the bundled library's business (forwarded), refused without it */
+            {   jlong const a = rLC(e, NULL, rc, (jbyteArray)darr), b = gLC(e, NULL, gc, (jbyteArray)darr);
+                if (getenv("ZSTD_JNI_CPU_LIB")) {
+                    Obj* src = mk(1, 3000); Obj* rdst = mk(1, 4000); Obj* gdst = mk(1, 4000); fill(src->data, 3000, 0);
+                    CHECK(a == b, "loadCDict0: ref %lld shim %lld", (long long)a, (long long)b);
+                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, 4000, src, 0, 3000), gr = G.cDirect(e, NULL, gc, gdst, 0, 4000, src, 0, 3000);
+                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "compress with a byte[] dictionary: ref %lld shim %lld", (long long)rr, (long long)gr);
+                } else CHECK(b < 0, "loadCDict0 without the bundled library must refuse, got %lld", (long long)b);
+                CHECK(rLC(e, NULL, rc, NULL) == gLC(e, NULL, gc, NULL), "loadCDict0(null)");
+            }
+            R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+            R.dictFree(e, robj); G.dictFree(e, gobj);
+        }
+    }
+    STAGE("getFrameContentSize0");
+    /* Zstd.getFrameContentSize0 (N/jni_zstd.c:86-96) */
+    {   typedef jlong (*fcs_fn)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean);
+        fcs_fn rF = SYM(R, fcs_fn, "Zstd_getFrameContentSize0"), gF = SYM(G, fcs_fn, "Zstd_getFrameContentSize0");
+        jlong rc = R.cinit(e, NULL);
+        CHECK(rF && gF, "getFrameContentSize0 exported");
+        for (unsigned si = 0; si < sizeof sizes / sizeof *sizes && gF; si++) {
+            jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
+            Obj* src = mk(2, n); Obj* fr = mk(2, cap + 3); fill(src->data, n, 0);
+            jlong const rr = R.cArray(e, NULL, rc, (jbyteArray)fr, 3, cap, (jbyteArray)src, 0, n);
+            CHECK(rF(e, NULL, (jbyteArray)fr, 3, (jint)rr, JNI_FALSE) == gF(e, NULL, (jbyteArray)fr, 3, (jint)rr, JNI_FALSE), "getFrameContentSize0 n=%d", n);
+            CHECK(rF(e, NULL, (jbyteArray)fr, 3, 4, JNI_FALSE) == gF(e, NULL, (jbyteArray)fr, 3, 4, JNI_FALSE), "getFrameContentSize0 short n=%d", n);
+            CHECK(rF(e, NULL, (jbyteArray)fr, 4, (jint)rr - 1, JNI_FALSE) == gF(e, NULL, (jbyteArray)fr, 4, (jint)rr - 1, JNI_FALSE), "getFrameContentSize0 garbage n=%d", n);
+        }
+        R.cfree(e, NULL, rc);
+    }
+    STAGE("every context native");
+    /* With the bundled library behind the shim: EVERY native of the two context classes goes through the shim's export and must
+     * behave like the reference's own (the handle in nativePtr is the bundled library's, whoever defines the native) */
+    if (getenv("ZSTD_JNI_CPU_LIB")) {
+        typedef jlong (*pledge_fn)(JNIEnv*, jclass, jlong, jlong);
+        typedef jobject (*prog_fn)(JNIEnv*, jclass, jlong);
+        typedef jlong (*sdd_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint, jint);
+        typedef jlong (*sad_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jbyteArray, jint, jint, jint, jint);
+        typedef jlong (*sda_fn)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jobject, jint, jint, jint);
+        typedef jlong (*saa_fn)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jbyteArray, jint, jint, jint, jint);
+        pledge_fn rP = SYM(R, pledge_fn, "ZstdCompressCtx_setPledgedSrcSize0"), gP = SYM(G, pledge_fn, "ZstdCompressCtx_setPledgedSrcSize0");
+        prog_fn gProg = SYM(G, prog_fn, "ZstdCompressCtx_getFrameProgression0");
+        sdd_fn rS1 = SYM(R, sdd_fn, "ZstdCompressCtx_compressDirectByteBufferStream0"), gS1 = SYM(G, sdd_fn, "ZstdCompressCtx_compressDirectByteBufferStream0");
+        sad_fn rS2 = SYM(R, sad_fn, "ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0"), gS2 = SYM(G, sad_fn, "ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0");
+        sda_fn rS3 = SYM(R, sda_fn, "ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0"), gS3 = SYM(G, sda_fn, "ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0");
+        saa_fn rS4 = SYM(R, saa_fn, "ZstdCompressCtx_compressByteArrayStream0"), gS4 = SYM(G, saa_fn, "ZstdCompressCtx_compressByteArrayStream0");
+        buf_fn rDS = SYM(R, buf_fn, "ZstdDecompressCtx_decompressDirectByteBufferStream0"), gDS = SYM(G, buf_fn, "ZstdDecompressCtx_decompressDirectByteBufferStream0");
+        CHECK(gP && gProg && gS1 && gS2 && gS3 && gS4 && gDS, "stream / progression / pledged-size natives exported");
+        if (gP && gProg && gS1 && gS2 && gS3 && gS4 && gDS) {
+            jsize const n = 30000, cap = 40000;
+            jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
+            Obj* sd = mk(1, n); Obj* sa = mk(2, n); fill(sd->data, n, 0); memcpy(sa->data, sd->data, (size_t)n);
+            R.setLevel(e, NULL, rc, 2); G.setLevel(e, NULL, gc, 2);
+            for (int v = 0; v < 4; v++) {
+                Obj* rdd = mk(1, cap); Obj* gdd = mk(1, cap); Obj* rda = mk(2, cap); Obj* gda = mk(2, cap); jlong a = 0, b = 0;
+                CHECK(rP(e, NULL, rc, n) == gP(e, NULL, gc, n), "setPledgedSrcSize0");
+                if (v == 0) { a = rS1(e, NULL, rc, rdd, 0, cap, sd, 0, n, 2); b = gS1(e, NULL, gc, gdd, 0, cap, sd, 0, n, 2); }
+                if (v == 1) { a = rS2(e, NULL, rc, rdd, 0, cap, (jbyteArray)sa, 0, 0, n, 2); b = gS2(e, NULL, gc, gdd, 0, cap, (jbyteArray)sa, 0, 0, n, 2); }
+                if (v == 2) { a = rS3(e, NULL, rc, (jbyteArray)rda, 0, 0, cap, sd, 0, n, 2); b = gS3(e, NULL, gc, (jbyteArray)gda, 0, 0, cap, sd, 0, n, 2); }
+                if (v == 3) { a = rS4(e, NULL, rc, (jbyteArray)rda, 0, 0, cap, (jbyteArray)sa, 0, 0, n, 2); b = gS4(e, NULL, gc, (jbyteArray)gda, 0, 0, cap, (jbyteArray)sa, 0, 0, n, 2); }
+                jsize const produced = (jsize)((a >> 32) & 0x7FFFFFFF);
+                CHECK(a == b && produced > 0 && !memcmp(v < 2 ? rdd->data : rda->data, v < 2 ? gdd->data : gda->data, (size_t)produced), "compress stream native %d: ref %llx shim %llx", v, (long long)a, (long long)b);
+                CHECK(gProg(e, NULL, gc) != NULL, "getFrameProgression0");
+                if (v == 0) {           /* and the streaming decompress native on that frame */
+                    Obj* o1 = mk(1, n); Obj* o2 = mk(1, n);
+                    jlong const c = rDS(e, NULL, rd, o1, 0, n, rdd, 0, produced), d = gDS(e, NULL, gd, o2, 0, n, rdd, 0, produced);
+                    CHECK(c == d && !memcmp(o1->data, o2->data, (size_t)n) && !memcmp(o2->data, sd->data, (size_t)n), "decompressDirectByteBufferStream0: ref %llx shim %llx", (long long)c, (long long)d);
+                }
+            }
+            R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+        }
+    }
+    /* batch natives refuse what the per-buffer natives refuse: a null or non-direct element is an error code, not a crash */
+    if (!getenv("HARNESS_SKIP_BATCH")) {
+        Obj* srcs = mk(3, 3); Obj* dsts = mk(3, 3); Obj* res = mk(4, 3);
+        srcs->elems = (Obj**)calloc(3, sizeof(Obj*)); dsts->elems = (Obj**)calloc(3, sizeof(Obj*));
+        for (int i = 0; i < 3; i++) { srcs->elems[i] = mk(1, 100); fill(srcs->elems[i]->data, 100, 0); dsts->elems[i] = mk(1, 200); }
+        g_deleted = 0;
+        CHECK(G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE) == 0 && g_deleted == 6, "batch of 3 (local references released: %d)", g_deleted);
+        srcs->elems[1] = NULL;
+        CHECK(G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE) == -72, "batch with a null source element");
+        srcs->elems[1] = mk(1, 100); dsts->elems[2] = NULL;
+        CHECK(G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE) == -70, "batch with a null destination element");
+        dsts->elems[2] = mk(1, 200);
+        {   Obj* heap = mk(2, 100); Obj* keep = srcs->elems[0]; srcs->elems[0] = heap;      /* a heap buffer: GetDirectBufferAddress NULL, capacity -1 */
+            CHECK(G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE) == -72, "batch with a non-direct source element");
+            srcs->elems[0] = keep; }
     }
     if (g_bad) { printf("JNI-HARNESS FAILED bad=%d checks=%d\n", g_bad, g_checks); return 1; }
     printf("JNI-HARNESS OK checks=%d\n", g_checks);

@@ -119,3 +119,22 @@ def test_emu_cdict_checksum_and_rejects(emu, oracle_ref):
         EmuCDict(emu, b"\x37\xa4\x30\xec" + bytes(40), 3)        # magic + garbage: dictionary_corrupted, like ZSTD_createCDict -> NULL
     with pytest.raises(oracle_ref.ZstdRefError):
         oracle_ref.CDict(b"\x37\xa4\x30\xec" + bytes(40), 3)
+
+
+def test_emu_cdict_without_dict_id(emu, oracle_ref):
+    """ZstdCompressCtx.setDictID(false) (ZSTD_c_dictIDFlag = 0): the dictionary's ID stays out of the frame header, the rest of the
+    frame is unchanged; 1-, 2- and 4-byte IDs"""
+    r = random.Random(77)
+    recs = json_records(20000, seed=3)
+    samples = [b",".join(recs[i * 13:i * 13 + 200])[:4096] for i in range(1000)]
+    d = oracle_ref.train_dict(samples, 30000)
+    assert oracle_ref.dict_id(d) > 0
+    for level in (1, 3):
+        rc = oracle_ref.CDict(d, level); ec = EmuCDict(emu, d, level)
+        for src in sources(recs, r, 8192)[:40]:
+            for ck in (False, True):
+                want = rc.compress(src, ck, dict_id=False)
+                assert ec.compress(src, ck, dict_id=False) == want, (level, len(src), ck)
+                if src:
+                    assert want != rc.compress(src, ck)
+        rc.close(); ec.close()

@@ -157,3 +157,22 @@ def test_emu_checksum_frames(emu, oracle_ref, zj):
                 bad = bytearray(got); bad[-1] ^= 0x01                  # wrong checksum byte
                 assert emu_decompress(emu, bytes(bad), len(d)) == -22
                 assert emu_decompress_split(emu, bytes(bad), len(d))[0] == -22
+
+
+def test_emu_frame_header_flags(emu, oracle_ref, zj):
+    """ZstdCompressCtx.setContentSize(false) (ZSTD_c_contentSizeFlag = 0: window descriptor instead of the content size,
+    N/compress/zstd_compress.c:4695-4745), with and without checksum, both pipelines; every decoder still takes the frames"""
+    from util import emu_decompress, emu_decompress_split
+    rnd = random.Random(123)
+    cases = [d for _, d in edge_inputs() if len(d) <= 131072]
+    for _ in range(40):
+        size = rnd.choice([rnd.randrange(0, 300), rnd.randrange(0, 5000), rnd.randrange(0, 131073), 65536, 255, 256, 1023, 1024, 1025])
+        cases.append(zj.synth_host(size, rnd.randrange(0, 100000), 1) if size else b"")
+    for d in cases:
+        for level in (1, 2, 3):
+            for ck in (False, True):
+                want = oracle_ref.compress(d, level, ck, 14 if level == 3 else 0, 13 if level == 3 else 0, content_size=False)
+                got = emu_compress(emu, d, level, checksum=ck, content_size=False)
+                assert got == want, (len(d), level, ck)
+                assert emu_compress(emu, d, level, split=True, checksum=ck, content_size=False) == want, (len(d), level, ck, "split")
+        assert emu_decompress(emu, got, len(d)) == d and emu_decompress_split(emu, got, len(d))[0] == d

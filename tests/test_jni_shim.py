@@ -1,7 +1,9 @@
 """The JNI side of the drop-in (zstd-jni_amd/jni/zjni_shim.c): the hot-path Java_com_github_luben_zstd_* natives, driven
 through a hand-built JNIEnv (tests/jni/harness.c) next to the reference's own JNI library built from its sources
 (oracle/_ref/libzstd-jni-ref.so).  CPU: symbol surface + the forwarding path (no GPU: every call goes to the bundled
-library's native of the same name).  GPU: return values and bytes of every native equal the reference's."""
+library's native of the same name).  GPU: return values and bytes of every native equal the reference's.  With the bundled library behind the shim every native
+of the two context classes (parameters, reset, pledged size, frame progression, the stream natives) is driven through the
+shim's export: nativePtr is the bundled library's own handle, whoever defines the native."""
 import os
 import subprocess
 
@@ -12,14 +14,20 @@ SHIM = os.path.join(ROOT, "zstd-jni_amd", "lib", "libzstd-jni-amd.so")
 REFJNI = os.path.join(ROOT, "oracle", "_ref", "libzstd-jni-ref.so")
 HARNESS = os.path.join(ROOT, "tests", "jni", "_build", "harness")
 
-HOT = ["ZstdCompressCtx_init", "ZstdCompressCtx_free", "ZstdCompressCtx_setLevel0", "ZstdCompressCtx_setChecksum0",
-       "ZstdCompressCtx_compressDirectByteBuffer0", "ZstdCompressCtx_compressByteArray0",
-       "ZstdDecompressCtx_init", "ZstdDecompressCtx_free", "ZstdDecompressCtx_decompressDirectByteBuffer0",
-       "ZstdDecompressCtx_decompressByteArray0", "Zstd_compressBound", "Zstd_isError", "Zstd_getErrorName",
-       "Zstd_getErrorCode", "Zstd_compressUnsafe", "Zstd_decompressUnsafe", "Zstd_compressBatch0", "Zstd_decompressBatch0",
-       "ZstdDictCompress_init", "ZstdDictCompress_initDirect", "ZstdDictCompress_free", "ZstdCompressCtx_loadCDictFast0", "Zstd_compressBatchDict0",
-       "ZstdDictDecompress_init", "ZstdDictDecompress_initDirect", "ZstdDictDecompress_free", "ZstdDecompressCtx_loadDDictFast0",
-       "Zstd_setCompressionHashLog", "Zstd_setCompressionChainLog"]
+def _dict_file(tmp_path_factory=None):
+    """a zstd-format dictionary (with a dictID) for the harness: trained by the reference's own trainer"""
+    import sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import ref
+    from util import json_records
+    recs = json_records(20000, seed=3)
+    samples = [b",".join(recs[i * 13:i * 13 + 200])[:4096] for i in range(1000)]
+    d = ref.train_dict(samples, 30000)
+    assert ref.dict_id(d) > 0
+    path = os.path.join(ROOT, "tests", "jni", "_build", "trained.dict")
+    with open(path, "wb") as f:
+        f.write(d)
+    return path
 
 
 def _built():
@@ -28,15 +36,22 @@ def _built():
     return all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS))
 
 
-def test_shim_exports_the_hot_path_natives():
+def _exports(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {l.split()[-1] for l in out.splitlines() if " T Java_com_github_luben_zstd_" in l}
+
+
+def test_shim_exports_every_native_of_the_reference_library():
+    """zstd-jni loads ONE library (J/util/Native.java:90-180): the shim's dynamic symbol table is a superset of the reference
+    library's 149 Java_* exports, plus the three batch natives"""
     if not _built():
         pytest.skip("no <jni.h> in this environment and no prebuilt shim")
-    syms = subprocess.check_output(["nm", "-D", "--defined-only", SHIM], text=True)
-    ref = subprocess.check_output(["nm", "-D", "--defined-only", REFJNI], text=True)
-    for name in HOT:
-        assert f"Java_com_github_luben_zstd_{name}" in syms, name
-        if "Batch" not in name:                      # every replaced native exists under the same name in the reference's library
-            assert f"Java_com_github_luben_zstd_{name}" in ref, name
+    ref, shim = _exports(REFJNI), _exports(SHIM)
+    assert len(ref) == 149
+    assert not (ref - shim), sorted(ref - shim)[:10]
+    assert shim - ref == {"Java_com_github_luben_zstd_Zstd_" + n for n in ("compressBatch0", "decompressBatch0", "compressBatchDict0")}
+    listed = open(os.path.join(ROOT, "zstd-jni_amd", "jni", "jni_symbols.txt")).read().split()
+    assert {"Java_com_github_luben_zstd_" + n for n in listed} == ref           # the committed list the build falls back on
 
 
 def test_shim_forwards_to_the_bundled_library_without_a_gpu():
@@ -45,7 +60,7 @@ def test_shim_forwards_to_the_bundled_library_without_a_gpu():
         pytest.skip("GPU present: covered by the gpu test")
     if not _built():
         pytest.skip("no <jni.h> in this environment and no prebuilt shim")
-    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2")
+    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2", HARNESS_DICT_FILE=_dict_file())
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
@@ -53,7 +68,7 @@ def test_shim_forwards_to_the_bundled_library_without_a_gpu():
 @pytest.mark.gpu
 def test_shim_equals_reference_jni_on_the_gpu():
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"
-    env = dict(os.environ)
+    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file())
     env.pop("ZSTD_JNI_CPU_LIB", None)                  # nothing to forward to: every result must come from the GPU library
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]

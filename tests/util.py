@@ -48,10 +48,10 @@ class EmuCDict:
         keys = ["dictID", "contentSize", "windowLog", "chainLog", "hashLog", "minMatch", "strategy", "hufRepeat", "llRepeat", "ofRepeat", "mlRepeat", "fillStart"]
         return dict(zip(keys, list(out)))
 
-    def compress(self, data, checksum=False):
+    def compress(self, data, checksum=False, dict_id=True):
         cap = len(data) + (len(data) >> 8) + 64 + 128
         dst = C.create_string_buffer(cap)
-        r = self.L.emu_compress_cdict(self.ptr, data, len(data), dst, cap, int(checksum))
+        r = self.L.emu_compress_cdict(self.ptr, data, len(data), dst, cap, int(checksum) | (0 if dict_id else 4))
         if r >= (1 << 63):
             return -((1 << 64) - r)
         return dst.raw[:r]
@@ -106,11 +106,11 @@ def emu_decompress_split(L, frame, cap):
     return dst.raw[:r], bool(used.value)
 
 
-def emu_compress(L, data, level, split=False, checksum=False, hash_log=0, chain_log=0):
+def emu_compress(L, data, level, split=False, checksum=False, hash_log=0, chain_log=0, content_size=True):
     cap = len(data) + (len(data) >> 8) + 64 + 128
     dst = C.create_string_buffer(cap)
     assert split or not (hash_log or chain_log)           # explicit table sizes exist on the lane-per-frame path only
-    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (hash_log << 16) | (chain_log << 24))
+    r = (L.emu_compress_split if split else L.emu_compress)(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (0 if content_size else 0x200) | (hash_log << 16) | (chain_log << 24))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

@@ -890,6 +890,9 @@ template <> struct ZEEntOf<u16> { typedef ZEEnt16 E; };
 template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 
 #define ZE_FLAG_CHECKSUM 1u      /* ZSTD_c_checksumFlag: append XXH64(content) & 0xFFFFFFFF */
+#define ZE_FLAG_NO_FCS 2u        /* ZSTD_c_contentSizeFlag = 0 (ZstdCompressCtx.setContentSize(false)): no frame content size, window descriptor instead */
+#define ZE_FLAG_NO_DICTID 4u     /* ZSTD_c_dictIDFlag = 0 (ZstdCompressCtx.setDictID(false)): the dictionary's ID stays out of the header */
+#define ZE_FLAG_MASK 7u
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
@@ -922,19 +925,25 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
         else ze_params(sh, level, srcSize);
         if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
-        u32 const dictID = cd ? sh.dictID : 0u;
+        // ZSTD_writeFrameHeader (zstd_compress.c:4695-4745): with the content size (the default) a frame <= 128 KiB is single-segment;
+        // without it (contentSizeFlag = 0) the window descriptor of the adjusted windowLog takes its place
+        bool const noFcs = (flags & ZE_FLAG_NO_FCS) != 0;
+        u32 const dictID = (cd && !(flags & ZE_FLAG_NO_DICTID)) ? sh.dictID : 0u;
         u32 const didCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
         u32 const didBytes = didCode == 3 ? 4u : didCode;
-        u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
-        u32 const hdr = 5 + didBytes + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));       // always single-segment for <= 128 KiB
+        u32 const fcsCode = noFcs ? 0u : (srcSize >= 256) + (srcSize >= 65536 + 256);
+        u32 const hdr = 5 + didBytes + (noFcs ? 1 : (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4)));
         sh.hdrSize = hdr;
         if (cd && (!pre || srcSize > (sh.dictStrategy == 2 ? (16u << 10) : (8u << 10)))) sh.err = ZJ_E_PARAM_UNSUPPORTED;   // outside the attach range
+        else if (cd && noFcs) sh.err = ZJ_E_PARAM_UNSUPPORTED;               // (the attached dictionary's window descriptor is not restated here)
         else if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {
-            st32(dst, 0xFD2FB528u); dst[4] = (u8)((1u << 5) + (fcsCode << 6) + (tail ? 4u : 0u) + didCode);
-            if (didBytes == 1) dst[5] = (u8)dictID; else if (didBytes == 2) st16(dst + 5, dictID); else if (didBytes == 4) st32(dst + 5, dictID);
-            u8* const fp = dst + 5 + didBytes;
-            if (fcsCode == 0) fp[0] = (u8)srcSize; else if (fcsCode == 1) st16(fp, srcSize - 256); else st32(fp, srcSize);
+            st32(dst, 0xFD2FB528u); dst[4] = (u8)((noFcs ? 0u : (1u << 5)) + (fcsCode << 6) + (tail ? 4u : 0u) + didCode);
+            u8* dp = dst + 5;
+            if (noFcs) *dp++ = (u8)((sh.windowLog - 10u) << 3);
+            if (didBytes == 1) dp[0] = (u8)dictID; else if (didBytes == 2) st16(dp, dictID); else if (didBytes == 4) st32(dp, dictID);
+            u8* const fp = dp + didBytes;
+            if (noFcs) {} else if (fcsCode == 0) fp[0] = (u8)srcSize; else if (fcsCode == 1) st16(fp, srcSize - 256); else st32(fp, srcSize);
         }
     }
     g.sync();

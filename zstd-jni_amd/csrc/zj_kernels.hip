@@ -50,7 +50,9 @@ __global__ __launch_bounds__(64, 4) void zj_decode_kernel_t(const u8* __restrict
         if (k >= count) break;
         u32 const i = list ? ZJ_UNI(list[k]) : k;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
-        u64 const r = zd_decompress<DICT>(g, sh, src + s0, (u32)(s1 - s0), dst + d0, (u32)(d1 - d0), lit, pf, dd, dictRaw);
+        u64 const cap = d1 - d0, len = s1 - s0;
+        u64 const r = len > 0xFFFFFFFFull ? ZJ_ERR64(ZJ_E_SRCSIZE_WRONG)      // sizes are 32-bit inside the decoder: no silent truncation
+                    : zd_decompress<DICT>(g, sh, src + s0, (u32)len, dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), lit, pf, dd, dictRaw);
         pf.mark(8);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
@@ -826,6 +828,9 @@ size_t zjni_freeDDict(zjni_ddict* dd) {
 }
 unsigned zjni_getDictID_fromDDict(const zjni_ddict* dd) { return dd ? dd->dictID : 0u; }
 
+// The `checksum` argument of the advanced / dictionary entries is a flag word (include/zjni_amd.h ZJNI_FRAME_*): 1 alone is what it
+// always meant; the boolean entries (zjni_compress*2) normalise their argument before they get here.
+static inline u32 zj_frame_flags(int word) { return (u32)word & ZE_FLAG_MASK; }
 static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                          uint64_t* d_result, size_t n, int levelWord, u32 flags, void* stream) {
     DevState* d = cur_state();
@@ -1021,7 +1026,7 @@ size_t zjni_compress_batch_device_advanced(const void* d_src, const uint64_t* d_
     if (level == 0) level = 3;
     int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
     if (e) return e;
-    return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, lw, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
+    return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, lw, zj_frame_flags(checksum), stream);
 }
 
 // ZSTD_createCDict (N/compress/zstd_compress.c:5710-5719; ZstdDictCompress.init, N/jni_fast_zstd.c:18-52): the raw dictionary
@@ -1071,7 +1076,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     BatchOrder order(d, stream);
     hipStream_t st = (hipStream_t)stream;
-    u32 const flags = checksum ? ZE_FLAG_CHECKSUM : 0u;
+    u32 const flags = zj_frame_flags(checksum);
     size_t chunk = 2 * ZJ_CHUNK_FRAMES;            // 2 048 match waves = every SIMD's second wave slot as well: more table requests in flight (measured: +15 % over 65 536)
     if (const char* ov = getenv("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
     size_t const slice = n < chunk ? n : chunk;
@@ -1133,7 +1138,12 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (n == 0) return 0;
     size_t srcTotal = 0, dstTotal = 0;
-    for (size_t i = 0; i < n; i++) { srcTotal += srcSize[i]; dstTotal += dstCap[i]; }
+    for (size_t i = 0; i < n; i++) {                   // one staging blob each way: its size must be representable (and allocatable)
+        if (srcSize[i] > ((size_t)1 << 46) || dstCap[i] > ((size_t)1 << 46)) return ZJNI_ERR(64);
+        srcTotal += srcSize[i]; dstTotal += dstCap[i];
+        if (srcTotal > ((size_t)1 << 46) || dstTotal > ((size_t)1 << 46)) return ZJNI_ERR(64);
+        if ((srcSize[i] && !src[i]) || (dstCap[i] && !dst[i])) return ZJNI_ERR(compress ? 72 : 72);
+    }
     size_t const offBytes = (n + 1) * 8;
     // staging layout: [srcOff][dstOff][result][src blob][dst blob]
     size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
@@ -1155,7 +1165,7 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
                                                   (u64*)(d->dStage + oRes), n, cdict, checksum, nullptr);
     else if (compress)                             // `level` may be a level word (zjni_compress_batch_advanced)
         r = compress_chunked(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                             (u64*)(d->dStage + oRes), n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, nullptr);
+                             (u64*)(d->dStage + oRes), n, level, zj_frame_flags(checksum), nullptr);
     else
         r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
                                                     (u64*)(d->dStage + oRes), n, ddict, nullptr);
@@ -1183,14 +1193,14 @@ size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* 
 size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level, int checksum) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
-    return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum);
+    return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0);
 }
 
 size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
                                     int level, int checksum, int hashLog, int chainLog) {
+    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
     if (e) return e;
-    if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     if (level < 1 || level > 3) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, lw, checksum);
 }

@@ -1,15 +1,26 @@
-/* zjni_shim.c — the JNI side of the drop-in: the hot-path natives of zstd-jni, bound to libzjni_amd.so.
+/* zjni_shim.c — the JNI side of the drop-in: libzstd-jni's natives, with the one-shot hot path bound to libzjni_amd.so.
  *
- * zstd-jni's Java classes call per-buffer natives (reference src/main/native/jni_fast_zstd.c, jni_zstd.c, "N/").
- * This file defines the SAME Java_com_github_luben_zstd_* symbols for the one-shot hot path and sends the buffers
- * to the GPU library through its C-ABI (include/zjni_amd.h) instead of calling ZSTD_compress2 /
- * ZSTD_decompressDCtx.  Argument checks, their order and the returned error codes are the reference's
- * (N/jni_fast_zstd.c:586-640, :777-905; N/jni_zstd.c:50-63, :230-267), so the Java/Scala layer above cannot
- * tell the difference except by speed.  Two batch natives are added (no Java signature changes elsewhere).
+ * zstd-jni loads ONE native library (J/util/Native.java:90-180) and its Java classes call per-buffer natives
+ * (reference src/main/native/jni_fast_zstd.c, jni_zstd.c, "N/").  This library exports every
+ * Java_com_github_luben_zstd_* symbol the reference's library exports (149; tests/test_jni_shim.py diffs the two
+ * symbol tables) plus three batch natives:
+ *   - the one-shot hot path (ZstdCompressCtx.compress*0, ZstdDecompressCtx.decompress*0, Zstd.compressUnsafe /
+ *     decompressUnsafe, the dictionary classes, the parameter natives that shape a one-shot frame) is defined HERE
+ *     and sends buffers to the GPU library through its C-ABI (include/zjni_amd.h) instead of calling ZSTD_compress2 /
+ *     ZSTD_decompressDCtx.  Argument checks, their order and the returned codes are the reference's
+ *     (N/jni_fast_zstd.c:586-640, :777-905; N/jni_zstd.c:50-63, :230-267);
+ *   - everything else (streams, training, constants, ...) is a trampoline (zjni_forward.c) into the bundled CPU
+ *     library named by $ZSTD_JNI_CPU_LIB, looked up with dlsym — the CPU code stays where it is, this file contains none.
  *
- * What the GPU path does not take (levels > 3, inputs > 128 KiB, no device) is FORWARDED to the bundled CPU
- * library's own native of the same name, looked up with dlsym in the library named by $ZSTD_JNI_CPU_LIB — the CPU
- * code stays where it is, this file contains none.  Without that library such calls return the zjni error code.
+ * Handles.  A context's nativePtr is the BUNDLED library's own ZSTD_CCtx* / ZSTD_DCtx* whenever that library is present,
+ * so a native this file does not define reaches the bundled library with the pointer it expects; what the GPU path
+ * needs to know about a context (level, flags, table sizes, dictionary digest) lives in a side table keyed by that
+ * pointer — the arrangement the dictionary classes always had.  Without the bundled library the handle is a private
+ * token and the trampolines return 0.
+ *
+ * What the GPU path does not take (levels > 3, inputs > 128 KiB, parameters it cannot honour such as windowLog,
+ * strategy or magicless frames, byte[] dictionaries on the compress side) is forwarded to the bundled library's native of
+ * the same name.  Without that library such calls return the zjni error code.
  *
  * Built against the JDK's <jni.h>; this image has no JDK, so the build (Makefile next to this file) uses the copy
  * zstd-jni vendors under /root/reference/jni when it is present and the prebuilt .so travels to the GPU box.
@@ -24,21 +35,25 @@
 #include <pthread.h>
 #include "../../include/zjni_amd.h"
 
+#define P(name) Java_com_github_luben_zstd_##name
+#define PS(name) "Java_com_github_luben_zstd_" name
 #define E_DST ((jlong)-70)   /* -ZSTD_error_dstSize_tooSmall */
 #define E_SRC ((jlong)-72)   /* -ZSTD_error_srcSize_wrong */
 #define E_MEM ((jlong)-64)   /* -ZSTD_error_memory_allocation */
+#define E_DICT ((jlong)-32)  /* -ZSTD_error_dictionary_wrong */
 
 /* ---- the bundled CPU library (optional) ------------------------------------------------------------- */
 static void* g_cpu;
-static int g_cpu_tried;
-static void* cpu_sym(const char* name) {
-    if (!g_cpu_tried) {
-        const char* p = getenv("ZSTD_JNI_CPU_LIB");
-        g_cpu_tried = 1;
-        if (p && *p) g_cpu = dlopen(p, RTLD_NOW | RTLD_LOCAL);
-    }
+static pthread_once_t g_cpu_once = PTHREAD_ONCE_INIT;
+static void cpu_open(void) {
+    const char* p = getenv("ZSTD_JNI_CPU_LIB");
+    if (p && *p) g_cpu = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+}
+void* zjni_shim_cpu_sym(const char* name) {                  /* also used by the trampolines (zjni_forward.c) */
+    pthread_once(&g_cpu_once, cpu_open);
     return g_cpu ? dlsym(g_cpu, name) : NULL;
 }
+#define cpu_sym zjni_shim_cpu_sym
 static int gpu_on(void) {
     static int state = -1;
     if (state < 0) state = (zjni_device_count() > 0 && zjni_init(0) == 0) ? 1 : 0;
@@ -49,111 +64,167 @@ static int gpu_on(void) {
  * natives; ZSTD_JNI_GPU_PER_BUFFER=1 (or no CPU library, as in the tests) sends per-buffer calls to the GPU as well. */
 static int per_buffer_on_gpu(void) {
     static int state = -1;
-    if (state < 0) { const char* e = getenv("ZSTD_JNI_GPU_PER_BUFFER"); state = ((e && *e == '1') || !cpu_sym("Java_com_github_luben_zstd_Zstd_compressBound")) ? 1 : 0; }
+    if (state < 0) { const char* e = getenv("ZSTD_JNI_GPU_PER_BUFFER"); state = ((e && *e == '1') || !cpu_sym(PS("Zstd_compressBound"))) ? 1 : 0; }
     return state && gpu_on();
 }
 static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
     return !(zjni_isError(r) && zjni_getErrorCode(r) >= 200);
 }
 
-/* ---- contexts: what ZstdCompressCtx / ZstdDecompressCtx keep in nativePtr ---------------------------- */
-typedef struct { int level; int checksum; int hashLog; int chainLog; jlong cpu; zjni_cdict* gdict; } ZCtx;     /* cpu = the bundled library's own ZSTD_CCtx handle, 0 if absent;
-                                                                                       gdict = the GPU digest of the loaded ZstdDictCompress */
-typedef struct { jlong cpu; zjni_ddict* gdict; } ZDCtx;                              /* gdict = the GPU digest of the loaded ZstdDictDecompress */
+/* ---- per-context state of the GPU path, keyed by nativePtr ------------------------------------------ */
+typedef struct CtxState {
+    struct CtxState* next; jlong key; int kind;            /* kind 'C' compress, 'D' decompress */
+    /* compress: what ZSTD_CCtx_setParameter calls have said so far (defaults = ZSTD_CCtx_reset's) */
+    int level, checksum, contentSize, dictIDFlag, hashLog, chainLog;
+    int cpuOnly;                                           /* a parameter the GPU path cannot honour is set (windowLog, strategy, magicless, workers, ...) */
+    int cpuDict;                                           /* a dictionary is loaded that has no GPU digest (byte[] dictionary, level > 3, digest table full, ...) */
+    zjni_cdict* cdict;                                     /* digest of the loaded ZstdDictCompress (owned by the dictionary object) */
+    zjni_ddict* ddict;                                     /* digest of the loaded ZstdDictDecompress (owned by the dictionary object) ... */
+    zjni_ddict* ddictOwned;                                /* ... or of the bytes given to loadDDict0 (owned by the context) */
+} CtxState;
+#define ST_BUCKETS 4096
+static CtxState* g_st[ST_BUCKETS];
+static pthread_mutex_t g_st_mu = PTHREAD_MUTEX_INITIALIZER;
+static unsigned st_bucket(jlong key) { uint64_t x = (uint64_t)key; x ^= x >> 17; x *= 0x9E3779B97F4A7C15ull; return (unsigned)(x >> 52) & (ST_BUCKETS - 1); }
+static void st_defaults(CtxState* s) {
+    s->level = 3; s->checksum = 0; s->contentSize = 1; s->dictIDFlag = 1; s->hashLog = 0; s->chainLog = 0; s->cpuOnly = 0; s->cpuDict = 0; s->cdict = NULL; s->ddict = NULL;
+}
+static CtxState* st_new(jlong key, int kind) {
+    CtxState* s = (CtxState*)calloc(1, sizeof(CtxState));
+    if (!s) return NULL;
+    s->key = key; s->kind = kind; st_defaults(s);
+    pthread_mutex_lock(&g_st_mu);
+    s->next = g_st[st_bucket(key)]; g_st[st_bucket(key)] = s;
+    pthread_mutex_unlock(&g_st_mu);
+    return s;
+}
+/* A context is used by one thread at a time (J/ZstdCompressCtx.java:32-34), so the state itself needs no lock — the table does. */
+static CtxState* st_get(jlong key, int kind) {
+    CtxState* s;
+    if (!key) return NULL;
+    pthread_mutex_lock(&g_st_mu);
+    for (s = g_st[st_bucket(key)]; s && !(s->key == key && s->kind == kind); s = s->next) {}
+    pthread_mutex_unlock(&g_st_mu);
+    return s;
+}
+static CtxState* st_take(jlong key, int kind) {
+    CtxState** pp; CtxState* s = NULL;
+    pthread_mutex_lock(&g_st_mu);
+    for (pp = &g_st[st_bucket(key)]; *pp; pp = &(*pp)->next) if ((*pp)->key == key && (*pp)->kind == kind) { s = *pp; *pp = s->next; break; }
+    pthread_mutex_unlock(&g_st_mu);
+    return s;
+}
 
-/* The parameter natives of class Zstd (setCompressionHashLog, ...) receive a raw context pointer that may also belong to a
- * stream class of the bundled library; the shim's own contexts are told apart by this registry. */
-#define CTX_MAX 65536
-static jlong g_ctxs[CTX_MAX];
-static pthread_mutex_t g_ctx_mu = PTHREAD_MUTEX_INITIALIZER;
-static int ctx_track(jlong p, int add) {            /* 0: registry full (init then fails: an untracked context could be mistaken for a stream's) */
-    int ok = 0;
-    pthread_mutex_lock(&g_ctx_mu);
-    for (int i = 0; i < CTX_MAX; i++) if (g_ctxs[i] == (add ? 0 : p)) { g_ctxs[i] = add ? p : 0; ok = 1; break; }
-    pthread_mutex_unlock(&g_ctx_mu);
-    return ok;
+/* ---- context lifecycle (N/jni_fast_zstd.c:253-270, :651-668) --------------------------------------- */
+static jlong ctx_init(JNIEnv* env, jclass cls, const char* name, int kind) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(name);
+    jlong h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);      /* the bundled library's handle, or a private token */
+    if (h && !st_new(h, kind)) { /* no state: the context works, on the CPU path only */ }
+    return h;
 }
-static int ctx_is_ours(jlong p) {
-    int r = 0;
-    pthread_mutex_lock(&g_ctx_mu);
-    for (int i = 0; i < CTX_MAX && !r; i++) r = (g_ctxs[i] == p && p != 0);
-    pthread_mutex_unlock(&g_ctx_mu);
-    return r;
+static void ctx_free(JNIEnv* env, jclass cls, jlong ptr, const char* name, int kind) {
+    void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym(name);
+    CtxState* s = st_take(ptr, kind);
+    if (s) { if (s->ddictOwned) zjni_freeDDict(s->ddictOwned); free(s); }
+    if (!ptr) return;
+    if (f) f(env, cls, ptr); else free((void*)(intptr_t)ptr);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_init(JNIEnv* env, jclass cls) {
-    ZCtx* c = (ZCtx*)calloc(1, sizeof(ZCtx));
-    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_init");
-    if (!c) return 0;
-    c->level = 3;                                   /* ZSTD_CLEVEL_DEFAULT */
-    if (!ctx_track((jlong)(intptr_t)c, 1)) { free(c); return 0; }
-    if (f) c->cpu = f(env, cls);
-    return (jlong)(intptr_t)c;
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_init)(JNIEnv* env, jclass cls) { return ctx_init(env, cls, PS("ZstdCompressCtx_init"), 'C'); }
+JNIEXPORT void JNICALL P(ZstdCompressCtx_free)(JNIEnv* env, jclass cls, jlong ptr) { ctx_free(env, cls, ptr, PS("ZstdCompressCtx_free"), 'C'); }
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_init)(JNIEnv* env, jclass cls) { return ctx_init(env, cls, PS("ZstdDecompressCtx_init"), 'D'); }
+JNIEXPORT void JNICALL P(ZstdDecompressCtx_free)(JNIEnv* env, jclass cls, jlong ptr) { ctx_free(env, cls, ptr, PS("ZstdDecompressCtx_free"), 'D'); }
+
+/* ---- parameters: recorded for the GPU path, and passed on to the bundled library's context -------- */
+#define FWD_VOID(name, T, ptr, v) do { void (*f_)(JNIEnv*, jclass, jlong, T) = (void (*)(JNIEnv*, jclass, jlong, T))cpu_sym(PS(name)); if (f_) f_(env, cls, ptr, v); } while (0)
+JNIEXPORT void JNICALL P(ZstdCompressCtx_setLevel0)(JNIEnv* env, jclass cls, jlong ptr, jint level) {
+    CtxState* s = st_get(ptr, 'C'); if (s) s->level = level;
+    FWD_VOID("ZstdCompressCtx_setLevel0", jint, ptr, level);
 }
-/* ZstdCompressCtx.setHashLog / setChainLog -> Zstd.setCompressionHashLog / ChainLog (N/jni_zstd.c:462-475): ZSTD_c_hashLog / ZSTD_c_chainLog */
-static jint set_log(JNIEnv* env, jclass cls, jlong stream, jint v, int chain, const char* name) {
+JNIEXPORT void JNICALL P(ZstdCompressCtx_setChecksum0)(JNIEnv* env, jclass cls, jlong ptr, jboolean flag) {
+    CtxState* s = st_get(ptr, 'C'); if (s) s->checksum = (flag == JNI_TRUE);
+    FWD_VOID("ZstdCompressCtx_setChecksum0", jboolean, ptr, flag);
+}
+JNIEXPORT void JNICALL P(ZstdCompressCtx_setContentSize0)(JNIEnv* env, jclass cls, jlong ptr, jboolean flag) {     /* N/jni_fast_zstd.c:301-308 */
+    CtxState* s = st_get(ptr, 'C'); if (s) s->contentSize = (flag == JNI_TRUE);
+    FWD_VOID("ZstdCompressCtx_setContentSize0", jboolean, ptr, flag);
+}
+JNIEXPORT void JNICALL P(ZstdCompressCtx_setDictID0)(JNIEnv* env, jclass cls, jlong ptr, jboolean flag) {          /* N/jni_fast_zstd.c:313-320 */
+    CtxState* s = st_get(ptr, 'C'); if (s) s->dictIDFlag = (flag == JNI_TRUE);
+    FWD_VOID("ZstdCompressCtx_setDictID0", jboolean, ptr, flag);
+}
+/* ZSTD_CCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:364-368): parameters back to their defaults, dictionary dropped */
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
+    jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdCompressCtx_reset0"));
+    CtxState* s = st_get(ptr, 'C'); if (s) st_defaults(s);
+    return f ? f(env, cls, ptr) : 0;
+}
+/* ZSTD_DCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:712-716) */
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
+    jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdDecompressCtx_reset0"));
+    CtxState* s = st_get(ptr, 'D');
+    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuOnly = 0; s->cpuDict = 0; }
+    return f ? f(env, cls, ptr) : 0;
+}
+/* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
+ * class's.  Recorded when the GPU path honours the parameter, otherwise the context is marked for the CPU path; always passed on. */
+static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const char* name, int what) {
     jint (*f)(JNIEnv*, jclass, jlong, jint) = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(name);
-    if (ctx_is_ours(stream)) {
-        ZCtx* c = (ZCtx*)(intptr_t)stream;
-        if (chain) c->chainLog = v; else c->hashLog = v;
-        return (f && c->cpu) ? f(env, cls, c->cpu, v) : 0;
+    CtxState* s = st_get(stream, what == 'd' ? 'D' : 'C');
+    if (s) switch (what) {
+        case 'l': s->level = v; break;
+        case 'k': s->checksum = (v & 0xFF) != 0; break;
+        case 'h': s->hashLog = v; break;
+        case 'c': s->chainLog = v; break;
+        default: s->cpuOnly = 1; break;                    /* 'x' / 'd': the GPU path does not implement it */
     }
-    return f ? f(env, cls, stream, v) : -(jint)ZJNI_ERROR_unsupported;   /* a stream class's context: the bundled library's business */
+    if (f) return f(env, cls, stream, v);
+    return (s && what != 'x' && what != 'd') ? 0 : -(jint)ZJNI_ERROR_unsupported;
 }
-JNIEXPORT jint JNICALL Java_com_github_luben_zstd_Zstd_setCompressionHashLog(JNIEnv* env, jclass cls, jlong stream, jint hashLog) {
-    return set_log(env, cls, stream, hashLog, 0, "Java_com_github_luben_zstd_Zstd_setCompressionHashLog");
-}
-JNIEXPORT jint JNICALL Java_com_github_luben_zstd_Zstd_setCompressionChainLog(JNIEnv* env, jclass cls, jlong stream, jint chainLog) {
-    return set_log(env, cls, stream, chainLog, 1, "Java_com_github_luben_zstd_Zstd_setCompressionChainLog");
-}
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_free(JNIEnv* env, jclass cls, jlong ptr) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_free");
-    if (!c) return;
-    ctx_track(ptr, 0);
-    if (f && c->cpu) f(env, cls, c->cpu);
-    free(c);
-}
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_setLevel0(JNIEnv* env, jclass cls, jlong ptr, jint level) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    void (*f)(JNIEnv*, jclass, jlong, jint) = (void (*)(JNIEnv*, jclass, jlong, jint))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_setLevel0");
-    c->level = level;
-    if (f && c->cpu) f(env, cls, c->cpu, level);
-}
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_setChecksum0(JNIEnv* env, jclass cls, jlong ptr, jboolean flag) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    void (*f)(JNIEnv*, jclass, jlong, jboolean) = (void (*)(JNIEnv*, jclass, jlong, jboolean))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_setChecksum0");
-    c->checksum = (flag == JNI_TRUE);
-    if (f && c->cpu) f(env, cls, c->cpu, flag);
-}
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_init(JNIEnv* env, jclass cls) {
-    ZDCtx* c = (ZDCtx*)calloc(1, sizeof(ZDCtx));
-    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_init");
-    if (!c) return 0;
-    if (f) c->cpu = f(env, cls);
-    return (jlong)(intptr_t)c;
-}
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_free(JNIEnv* env, jclass cls, jlong ptr) {
-    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
-    void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_free");
-    if (!c) return;
-    if (f && c->cpu) f(env, cls, c->cpu);
-    free(c);
+#define SETTER(name, T, what) JNIEXPORT jint JNICALL P(name)(JNIEnv* env, jclass cls, jlong stream, T v) { return zstd_setter(env, cls, stream, (jint)v, PS(#name), what); }
+SETTER(Zstd_setCompressionLevel, jint, 'l')
+SETTER(Zstd_setCompressionChecksums, jboolean, 'k')
+SETTER(Zstd_setCompressionHashLog, jint, 'h')              /* ZstdCompressCtx.setHashLog: ZSTD_c_hashLog */
+SETTER(Zstd_setCompressionChainLog, jint, 'c')             /* ZstdCompressCtx.setChainLog: ZSTD_c_chainLog */
+SETTER(Zstd_setCompressionMagicless, jboolean, 'x')
+SETTER(Zstd_setCompressionLong, jint, 'x')
+SETTER(Zstd_setCompressionWorkers, jint, 'x')
+SETTER(Zstd_setCompressionJobSize, jint, 'x')
+SETTER(Zstd_setCompressionOverlapLog, jint, 'x')
+SETTER(Zstd_setCompressionWindowLog, jint, 'x')
+SETTER(Zstd_setCompressionSearchLog, jint, 'x')
+SETTER(Zstd_setCompressionMinMatch, jint, 'x')
+SETTER(Zstd_setCompressionTargetLength, jint, 'x')
+SETTER(Zstd_setCompressionStrategy, jint, 'x')
+SETTER(Zstd_setEnableLongDistanceMatching, jint, 'x')
+SETTER(Zstd_setValidateSequences, jint, 'x')
+SETTER(Zstd_setSequenceProducerFallback, jboolean, 'x')
+SETTER(Zstd_setSearchForExternalRepcodes, jint, 'x')
+SETTER(Zstd_setDecompressionMagicless, jboolean, 'd')
+JNIEXPORT void JNICALL P(Zstd_registerSequenceProducer)(JNIEnv* env, jclass cls, jlong stream, jlong state, jlong fn) {
+    void (*f)(JNIEnv*, jclass, jlong, jlong, jlong) = (void (*)(JNIEnv*, jclass, jlong, jlong, jlong))cpu_sym(PS("Zstd_registerSequenceProducer"));
+    CtxState* s = st_get(stream, 'C'); if (s) s->cpuOnly = (fn != 0);
+    if (f) f(env, cls, stream, state, fn);
 }
 
-/* ---- ZstdDictCompress (N/jni_fast_zstd.c:13-66) -------------------------------------------------------
- * The Java object keeps ONE long (nativePtr), and the bundled library's natives read it as their own ZSTD_CDict*.
+/* ---- ZstdDictCompress / ZstdDictDecompress (N/jni_fast_zstd.c:13-125) --------------------------------
+ * The Java object keeps ONE long (nativePtr), and the bundled library's natives read it as their own ZSTD_CDict* / ZSTD_DDict*.
  * So nativePtr stays what the bundled library put there (when it is present), and the GPU digest of the same
  * dictionary lives in a side table keyed by that value; without the bundled library nativePtr is the table key
  * itself (a private handle). */
-typedef struct { jlong key; void* gpu; int level; } DictEnt;              /* gpu: zjni_cdict* or zjni_ddict* (keys are distinct heap addresses) */
+typedef struct { jlong key; void* gpu; } DictEnt;                       /* gpu: zjni_cdict* or zjni_ddict* (keys are distinct heap addresses) */
 #define DICT_MAX 4096
 static DictEnt g_dicts[DICT_MAX];
 static pthread_mutex_t g_dict_mu = PTHREAD_MUTEX_INITIALIZER;
-static jfieldID g_cdict_field;
-static int dict_put(jlong key, void* gpu, int level) {           /* 0 when the table is full (the caller keeps the CPU path for this dictionary) */
+static jfieldID g_cdict_field, g_ddict_field;                           /* written once each (the value is the same whoever writes it) */
+static jfieldID native_ptr_field(JNIEnv* env, jobject obj, jfieldID* cache) {
+    jfieldID f = __atomic_load_n(cache, __ATOMIC_ACQUIRE);
+    if (!f) { f = (*env)->GetFieldID(env, (*env)->GetObjectClass(env, obj), "nativePtr", "J"); __atomic_store_n(cache, f, __ATOMIC_RELEASE); }
+    return f;
+}
+static int dict_put(jlong key, void* gpu) {                       /* 0 when the table is full (the caller keeps the CPU path for this dictionary) */
     int ok = 0;
     pthread_mutex_lock(&g_dict_mu);
-    for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; g_dicts[i].level = level; ok = 1; break; }
+    for (int i = 0; i < DICT_MAX; i++) if (!g_dicts[i].key) { g_dicts[i].key = key; g_dicts[i].gpu = gpu; ok = 1; break; }
     pthread_mutex_unlock(&g_dict_mu);
     return ok;
 }
@@ -164,212 +235,155 @@ static void* dict_get(jlong key, int remove) {
     pthread_mutex_unlock(&g_dict_mu);
     return r;
 }
-static void dict_register(JNIEnv* env, jobject obj, const void* bytes, size_t size, jint level) {
-    jlong key = (*env)->GetLongField(env, obj, g_cdict_field);          /* the bundled library's ZSTD_CDict*, if it made one */
-    zjni_cdict* gpu = (gpu_on() && level >= 1 && level <= 3) ? zjni_createCDict(bytes, size, level) : NULL;
+/* after the bundled library's init: attach the GPU digest to whatever handle the object now carries */
+static void dict_register(JNIEnv* env, jobject obj, jfieldID field, void* gpu, int compressSide) {
+    jlong key = (*env)->GetLongField(env, obj, field);
     if (!key) {                                                         /* no bundled library: the handle is ours */
         if (!gpu) return;                                               /* nativePtr stays 0: "ZSTD_createCDict failed" on the Java side */
         key = (jlong)(intptr_t)gpu;
-        (*env)->SetLongField(env, obj, g_cdict_field, key);
+        (*env)->SetLongField(env, obj, field, key);
     }
-    if (gpu && !dict_put(key, gpu, level)) {
-        zjni_freeCDict(gpu);
-        if (key == (jlong)(intptr_t)gpu) (*env)->SetLongField(env, obj, g_cdict_field, 0);
+    if (gpu && !dict_put(key, gpu)) {
+        if (compressSide) zjni_freeCDict((zjni_cdict*)gpu); else zjni_freeDDict((zjni_ddict*)gpu);
+        if (key == (jlong)(intptr_t)gpu) (*env)->SetLongField(env, obj, field, 0);
     }
 }
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_init
-  (JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size, jint level) {
-    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_init");
-    jclass clazz = (*env)->GetObjectClass(env, obj);
-    g_cdict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+static void* dict_digest(const void* bytes, size_t size, jint level, int compressSide) {
+    if (!gpu_on()) return NULL;
+    if (compressSide) return (level >= 1 && level <= 3) ? (void*)zjni_createCDict(bytes, size, level) : NULL;
+    return (void*)zjni_createDDict(bytes, size);
+}
+JNIEXPORT void JNICALL P(ZstdDictCompress_init)(JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size, jint level) {
+    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint, jint))cpu_sym(PS("ZstdDictCompress_init"));
+    jfieldID const field = native_ptr_field(env, obj, &g_cdict_field);
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size, level);
     if (dict_size >= 0) {
         jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
         if (!copy) return;
         (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
-        dict_register(env, obj, copy, (size_t)dict_size, level);
+        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, level, 1), 1);
         free(copy);
     }
 }
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_initDirect
-  (JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint level, jint byReference) {
-    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_initDirect");
-    jclass clazz = (*env)->GetObjectClass(env, obj);
-    g_cdict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+JNIEXPORT void JNICALL P(ZstdDictCompress_initDirect)(JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint level, jint byReference) {
+    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint, jint))cpu_sym(PS("ZstdDictCompress_initDirect"));
+    jfieldID const field = native_ptr_field(env, obj, &g_cdict_field);
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size, level, byReference);
     {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
-        if (p && dict_size >= 0) dict_register(env, obj, p + dict_offset, (size_t)dict_size, level); }   /* the device keeps its own copy either way */
+        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, level, 1), 1); }   /* the device keeps its own copy either way */
 }
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictCompress_free(JNIEnv* env, jobject obj) {
-    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDictCompress_free");
-    if (g_cdict_field) {
-        jlong const key = (*env)->GetLongField(env, obj, g_cdict_field);
-        zjni_cdict* gpu = (zjni_cdict*)dict_get(key, 1);
-        if (gpu) zjni_freeCDict(gpu);
-    }
+JNIEXPORT void JNICALL P(ZstdDictCompress_free)(JNIEnv* env, jobject obj) {
+    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym(PS("ZstdDictCompress_free"));
+    zjni_cdict* gpu = (zjni_cdict*)dict_get((*env)->GetLongField(env, obj, native_ptr_field(env, obj, &g_cdict_field)), 1);
+    if (gpu) zjni_freeCDict(gpu);
     if (f) f(env, obj);
 }
-/* ZstdCompressCtx.loadDict(ZstdDictCompress) -> ZSTD_CCtx_refCDict (N/jni_fast_zstd.c:325-336) */
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_loadCDictFast0(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_loadCDictFast0");
-    jlong r = 0;
-    c->gdict = NULL;
-    if (dict != NULL) {
-        jlong const key = g_cdict_field ? (*env)->GetLongField(env, dict, g_cdict_field) : 0;
-        if (!key) return -32;                                           /* -ZSTD_error_dictionary_wrong */
-        c->gdict = (zjni_cdict*)dict_get(key, 0);
-    }
-    if (f && c->cpu) r = f(env, cls, c->cpu, dict);
-    return r;
-}
-
-/* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
-static int gpu_takes(const ZCtx* c, jint srcSize) {
-    if (c->gdict) return per_buffer_on_gpu();                           /* sizes beyond the attach range come back as 40 and are forwarded */
-    return per_buffer_on_gpu() && c->level >= 1 && c->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
-}
-static size_t gpu_compress(const ZCtx* c, void* dst, size_t dstCap, const void* src, size_t srcSize) {
-    if (c->gdict) {
-        size_t res = 0; const void* s = src; void* d = dst;
-        size_t const r = zjni_compress_batch_usingCDict(&s, &srcSize, &d, &dstCap, &res, 1, c->gdict, c->checksum);
-        return zjni_isError(r) ? r : res;
-    }
-    if (c->hashLog || c->chainLog) {                /* explicit table sizes: level 3 only on the GPU (40 otherwise -> forwarded) */
-        size_t res = 0; const void* s = src; void* d = dst;
-        size_t const r = zjni_compress_batch_advanced(&s, &srcSize, &d, &dstCap, &res, 1, c->level, c->checksum, c->hashLog, c->chainLog);
-        return zjni_isError(r) ? r : res;
-    }
-    return zjni_compress2(dst, dstCap, src, srcSize, c->level, c->checksum);
-}
-static int gpu_compress_final(const ZCtx* c, size_t r) {   /* 40 = a dictionary frame outside the attach range / table sizes the GPU path does not take: forward when possible */
-    return gpu_result_final(r) && !((c->gdict || c->hashLog || c->chainLog) && zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && c->cpu);
-}
-typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
-
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressDirectByteBuffer0
-  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    if (NULL == dst) return E_DST;
-    if (NULL == src) return E_SRC;
-    if (0 > dst_offset) return E_DST;
-    if (0 > src_offset) return E_SRC;
-    if (0 > src_size) return E_SRC;
-    if (dst_offset + dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return E_DST;
-    if (src_offset + src_size > (*env)->GetDirectBufferCapacity(env, src)) return E_SRC;
-    {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
-        char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
-        if (d == NULL || s == NULL) return E_MEM;
-        if (gpu_takes(c, src_size)) {
-            size_t const r = gpu_compress(c, d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
-            if (gpu_compress_final(c, r)) return (jlong)r;
-        }
-    }
-    {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressDirectByteBuffer0");
-        if (f && c->cpu) return f(env, cls, c->cpu, dst, dst_offset, dst_size, src, src_offset, src_size);
-    }
-    return -(jlong)ZJNI_ERROR_unsupported;
-}
-
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdCompressCtx_compressByteArray0
-  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
-    ZCtx* c = (ZCtx*)(intptr_t)ptr;
-    if (0 > dst_offset) return E_DST;
-    if (0 > src_offset) return E_SRC;
-    if (0 > src_size) return E_SRC;
-    if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
-    if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
-    if (gpu_takes(c, src_size)) {
-        jbyte* s = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
-        size_t r = (size_t)E_MEM;
-        if (s && d) {
-            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
-            r = gpu_compress(c, d, (size_t)dst_size, s, (size_t)src_size);
-            if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
-        }
-        free(s); free(d);
-        if (gpu_compress_final(c, r)) return (jlong)r;
-    }
-    {   cbuf_fn f = (cbuf_fn)cpu_sym("Java_com_github_luben_zstd_ZstdCompressCtx_compressByteArray0");
-        if (f && c->cpu) return f(env, cls, c->cpu, dst, dst_offset, dst_size, src, src_offset, src_size);
-    }
-    return -(jlong)ZJNI_ERROR_unsupported;
-}
-
-/* ---- decompress: ZSTD_DCtx_reset + ZSTD_decompressDCtx (N/jni_fast_zstd.c:798-799, :825-826, :858-860, :892-894) */
-/* ---- ZstdDictDecompress (N/jni_fast_zstd.c:68-125) + ZstdDecompressCtx.loadDict (:673-684): same arrangement as ZstdDictCompress */
-static jfieldID g_ddict_field;
-static void ddict_register(JNIEnv* env, jobject obj, const void* bytes, size_t size) {
-    jlong key = (*env)->GetLongField(env, obj, g_ddict_field);
-    zjni_ddict* gpu = gpu_on() ? zjni_createDDict(bytes, size) : NULL;
-    if (!key) {
-        if (!gpu) return;
-        key = (jlong)(intptr_t)gpu;
-        (*env)->SetLongField(env, obj, g_ddict_field, key);
-    }
-    if (gpu && !dict_put(key, gpu, 0)) {
-        zjni_freeDDict(gpu);
-        if (key == (jlong)(intptr_t)gpu) (*env)->SetLongField(env, obj, g_ddict_field, 0);
-    }
-}
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_init(JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size) {
-    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_init");
-    jclass clazz = (*env)->GetObjectClass(env, obj);
-    g_ddict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+JNIEXPORT void JNICALL P(ZstdDictDecompress_init)(JNIEnv* env, jobject obj, jbyteArray dict, jint dict_offset, jint dict_size) {
+    void (*f)(JNIEnv*, jobject, jbyteArray, jint, jint) = (void (*)(JNIEnv*, jobject, jbyteArray, jint, jint))cpu_sym(PS("ZstdDictDecompress_init"));
+    jfieldID const field = native_ptr_field(env, obj, &g_ddict_field);
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size);
     if (dict_size >= 0) {
         jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
         if (!copy) return;
         (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
-        ddict_register(env, obj, copy, (size_t)dict_size);
+        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, 0, 0), 0);
         free(copy);
     }
 }
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_initDirect(JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint byReference) {
-    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_initDirect");
-    jclass clazz = (*env)->GetObjectClass(env, obj);
-    g_ddict_field = (*env)->GetFieldID(env, clazz, "nativePtr", "J");
+JNIEXPORT void JNICALL P(ZstdDictDecompress_initDirect)(JNIEnv* env, jobject obj, jobject dict, jint dict_offset, jint dict_size, jint byReference) {
+    void (*f)(JNIEnv*, jobject, jobject, jint, jint, jint) = (void (*)(JNIEnv*, jobject, jobject, jint, jint, jint))cpu_sym(PS("ZstdDictDecompress_initDirect"));
+    jfieldID const field = native_ptr_field(env, obj, &g_ddict_field);
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size, byReference);
     {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
-        if (p && dict_size >= 0) ddict_register(env, obj, p + dict_offset, (size_t)dict_size); }
+        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, 0, 0), 0); }
 }
-JNIEXPORT void JNICALL Java_com_github_luben_zstd_ZstdDictDecompress_free(JNIEnv* env, jobject obj) {
-    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDictDecompress_free");
-    if (g_ddict_field) {
-        zjni_ddict* gpu = (zjni_ddict*)dict_get((*env)->GetLongField(env, obj, g_ddict_field), 1);
-        if (gpu) zjni_freeDDict(gpu);
-    }
+JNIEXPORT void JNICALL P(ZstdDictDecompress_free)(JNIEnv* env, jobject obj) {
+    void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym(PS("ZstdDictDecompress_free"));
+    zjni_ddict* gpu = (zjni_ddict*)dict_get((*env)->GetLongField(env, obj, native_ptr_field(env, obj, &g_ddict_field)), 1);
+    if (gpu) zjni_freeDDict(gpu);
     if (f) f(env, obj);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_loadDDictFast0(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
-    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
-    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym("Java_com_github_luben_zstd_ZstdDecompressCtx_loadDDictFast0");
-    jlong r = 0;
-    c->gdict = NULL;
+/* ZstdCompressCtx.loadDict(ZstdDictCompress) -> ZSTD_CCtx_refCDict (N/jni_fast_zstd.c:325-336) */
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_loadCDictFast0)(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("ZstdCompressCtx_loadCDictFast0"));
+    CtxState* s = st_get(ptr, 'C');
+    if (s) { s->cdict = NULL; s->cpuDict = 0; }
     if (dict != NULL) {
-        jlong const key = g_ddict_field ? (*env)->GetLongField(env, dict, g_ddict_field) : 0;
-        if (!key) return -32;                                           /* -ZSTD_error_dictionary_wrong */
-        c->gdict = (zjni_ddict*)dict_get(key, 0);
+        jlong const key = (*env)->GetLongField(env, dict, native_ptr_field(env, dict, &g_cdict_field));
+        if (!key) return E_DICT;
+        if (s) { s->cdict = (zjni_cdict*)dict_get(key, 0); s->cpuDict = (s->cdict == NULL); }   /* no digest (level > 3, table full, < 8 bytes): the bundled library has it */
     }
-    if (f && c->cpu) r = f(env, cls, c->cpu, dict);
+    return f ? f(env, cls, ptr, dict) : 0;
+}
+/* ZstdCompressCtx.loadDict(byte[]) -> ZSTD_CCtx_loadDictionary (N/jni_fast_zstd.c:343-357): the reference digests it per call with
+ * parameters that depend on the source size; that variant is not restated on the GPU, so the context goes to the CPU path. */
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_loadCDict0)(JNIEnv* env, jclass cls, jlong ptr, jbyteArray dict) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jbyteArray) = (jlong (*)(JNIEnv*, jclass, jlong, jbyteArray))cpu_sym(PS("ZstdCompressCtx_loadCDict0"));
+    CtxState* s = st_get(ptr, 'C');
+    if (s) { s->cdict = NULL; s->cpuDict = (dict != NULL); }
+    if (f) return f(env, cls, ptr, dict);
+    return dict == NULL ? 0 : -(jlong)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDictFast0)(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("ZstdDecompressCtx_loadDDictFast0"));
+    CtxState* s = st_get(ptr, 'D');
+    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuDict = 0; }
+    if (dict != NULL) {
+        jlong const key = (*env)->GetLongField(env, dict, native_ptr_field(env, dict, &g_ddict_field));
+        if (!key) return E_DICT;
+        if (s) { s->ddict = (zjni_ddict*)dict_get(key, 0); s->cpuDict = (s->ddict == NULL); }
+    }
+    return f ? f(env, cls, ptr, dict) : 0;
+}
+/* ZstdDecompressCtx.loadDict(byte[]) -> ZSTD_DCtx_loadDictionary (N/jni_fast_zstd.c:691-705): same frames as with a ZSTD_DDict */
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDict0)(JNIEnv* env, jclass cls, jlong ptr, jbyteArray dict) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jbyteArray) = (jlong (*)(JNIEnv*, jclass, jlong, jbyteArray))cpu_sym(PS("ZstdDecompressCtx_loadDDict0"));
+    CtxState* s = st_get(ptr, 'D');
+    jlong r = 0;
+    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuDict = 0; }
+    if (f) r = f(env, cls, ptr, dict);
+    if (s && dict != NULL && r == 0) {
+        jsize const n = (*env)->GetArrayLength(env, dict);
+        if (n > 0 && gpu_on()) {                                        /* (an empty dictionary = none, ZSTD_DCtx_loadDictionary) */
+            jbyte* copy = (jbyte*)malloc((size_t)n);
+            if (copy) { (*env)->GetByteArrayRegion(env, dict, 0, n, copy); s->ddictOwned = zjni_createDDict(copy, (size_t)n); free(copy); }
+            if (!s->ddictOwned) { if (f) s->cpuDict = 1; else r = -30; }   /* the reference answers a corrupted dictionary here (ZSTD_error_dictionary_corrupted) */
+        } else if (n > 0) s->cpuDict = 1;
+    }
     return r;
 }
-static size_t gpu_decompress(const ZDCtx* c, void* dst, size_t dstCap, const void* src, size_t srcSize) {
-    return c->gdict ? zjni_decompress_usingDDict(dst, dstCap, src, srcSize, c->gdict) : zjni_decompress(dst, dstCap, src, srcSize);
+
+/* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
+static int gpu_takes(const CtxState* s, jint srcSize) {
+    if (!s || s->cpuOnly || s->cpuDict || !per_buffer_on_gpu()) return 0;
+    if (s->cdict) return s->contentSize;                               /* sizes beyond the attach range come back as 40 and are forwarded */
+    return s->level >= 0 && s->level <= 3 && (size_t)srcSize <= ZJNI_BLOCKSIZE_MAX;
+}
+static int frame_flags(const CtxState* s) {
+    return (s->checksum ? ZJNI_FRAME_CHECKSUM : 0) | (s->contentSize ? 0 : ZJNI_FRAME_NO_CONTENTSIZE) | (s->dictIDFlag ? 0 : ZJNI_FRAME_NO_DICTID);
+}
+static size_t gpu_compress(const CtxState* s, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    size_t res = 0; const void* sp = src; void* dp = dst; size_t r;
+    if (s->cdict) r = zjni_compress_batch_usingCDict(&sp, &srcSize, &dp, &dstCap, &res, 1, s->cdict, frame_flags(s));
+    else r = zjni_compress_batch_advanced(&sp, &srcSize, &dp, &dstCap, &res, 1, s->level, frame_flags(s), s->hashLog, s->chainLog);   /* explicit table sizes: level 3 only (40 otherwise -> forwarded) */
+    return zjni_isError(r) ? r : res;
+}
+static int gpu_compress_final(const CtxState* s, size_t r, int haveCpu) {   /* 40 / 42 = outside what the GPU path takes (attach range, table sizes): forward when possible */
+    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && (s->cdict || s->hashLog || s->chainLog) && haveCpu);
+}
+typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+static jlong buf_forward(const char* name, jlong none, JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
+    cbuf_fn f = (cbuf_fn)cpu_sym(name);
+    return f ? f(env, cls, ptr, dst, doff, dsize, src, soff, ssize) : none;
 }
 
-static jlong dec_forward(const char* name, JNIEnv* env, jclass cls, ZDCtx* c, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
-    cbuf_fn f = (cbuf_fn)cpu_sym(name);
-    if (f && c->cpu) return f(env, cls, c->cpu, dst, doff, dsize, src, soff, ssize);
-    return -(jlong)ZJNI_ERROR_no_device;
-}
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressDirectByteBuffer0
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBuffer0)
   (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
-    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    CtxState* s = st_get(ptr, 'C');
     if (NULL == dst) return E_DST;
     if (NULL == src) return E_SRC;
     if (0 > dst_offset) return E_DST;
@@ -378,70 +392,167 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressD
     if (dst_offset + dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return E_DST;
     if (src_offset + src_size > (*env)->GetDirectBufferCapacity(env, src)) return E_SRC;
     {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
-        char* s = (char*)(*env)->GetDirectBufferAddress(env, src);
-        if (d == NULL || s == NULL) return E_MEM;
-        if (per_buffer_on_gpu()) {
-            size_t const r = gpu_decompress(c, d + dst_offset, (size_t)dst_size, s + src_offset, (size_t)src_size);
-            if (gpu_result_final(r)) return (jlong)r;
+        char* sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+        if (d == NULL || sb == NULL) return E_MEM;
+        if (gpu_takes(s, src_size)) {
+            size_t const r = gpu_compress(s, d + dst_offset, (size_t)dst_size, sb + src_offset, (size_t)src_size);
+            if (gpu_compress_final(s, r, cpu_sym(PS("ZstdCompressCtx_compressDirectByteBuffer0")) != NULL)) return (jlong)r;
         }
     }
-    return dec_forward("Java_com_github_luben_zstd_ZstdDecompressCtx_decompressDirectByteBuffer0", env, cls, c, dst, dst_offset, dst_size, src, src_offset, src_size);
+    return buf_forward(PS("ZstdCompressCtx_compressDirectByteBuffer0"), -(jlong)ZJNI_ERROR_unsupported, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_ZstdDecompressCtx_decompressByteArray0
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArray0)
   (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
-    ZDCtx* c = (ZDCtx*)(intptr_t)ptr;
+    CtxState* s = st_get(ptr, 'C');
     if (0 > dst_offset) return E_DST;
     if (0 > src_offset) return E_SRC;
     if (0 > src_size) return E_SRC;
     if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
     if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
-    if (per_buffer_on_gpu()) {
-        jbyte* s = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+    if (gpu_takes(s, src_size)) {
+        jbyte* sb = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
         size_t r = (size_t)E_MEM;
-        if (s && d) {
-            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, s);
-            r = gpu_decompress(c, d, (size_t)dst_size, s, (size_t)src_size);
+        if (sb && d) {
+            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, sb);
+            r = gpu_compress(s, d, (size_t)dst_size, sb, (size_t)src_size);
             if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
         }
-        free(s); free(d);
-        if (gpu_result_final(r)) return (jlong)r;
+        free(sb); free(d);
+        if (gpu_compress_final(s, r, cpu_sym(PS("ZstdCompressCtx_compressByteArray0")) != NULL)) return (jlong)r;
     }
-    return dec_forward("Java_com_github_luben_zstd_ZstdDecompressCtx_decompressByteArray0", env, cls, c, dst, dst_offset, dst_size, src, src_offset, src_size);
+    return buf_forward(PS("ZstdCompressCtx_compressByteArray0"), -(jlong)ZJNI_ERROR_unsupported, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
 }
 
-/* ---- class Zstd: helpers with the reference's semantics (N/jni_zstd.c:230-267, :50-63) ---------------- */
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBound(JNIEnv* env, jclass cls, jlong size) {
-    (void)env; (void)cls; return (jlong)zjni_compressBound((size_t)size);
+/* ---- decompress: ZSTD_DCtx_reset + ZSTD_decompressDCtx (N/jni_fast_zstd.c:798-799, :825-826, :858-860, :892-894) */
+static int gpu_dec_takes(const CtxState* s) { return s && !s->cpuOnly && !s->cpuDict && per_buffer_on_gpu(); }
+static size_t gpu_decompress(const CtxState* s, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    zjni_ddict* const dd = s->ddictOwned ? s->ddictOwned : s->ddict;
+    return dd ? zjni_decompress_usingDDict(dst, dstCap, src, srcSize, dd) : zjni_decompress(dst, dstCap, src, srcSize);
 }
-JNIEXPORT jboolean JNICALL Java_com_github_luben_zstd_Zstd_isError(JNIEnv* env, jclass cls, jlong code) {
-    (void)env; (void)cls; return zjni_isError((size_t)code) != 0;
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressDirectByteBuffer0)
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
+    CtxState* s = st_get(ptr, 'D');
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return E_DST;
+    if (src_offset + src_size > (*env)->GetDirectBufferCapacity(env, src)) return E_SRC;
+    {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
+        char* sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+        if (d == NULL || sb == NULL) return E_MEM;
+        if (gpu_dec_takes(s)) {
+            size_t const r = gpu_decompress(s, d + dst_offset, (size_t)dst_size, sb + src_offset, (size_t)src_size);
+            if (gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return buf_forward(PS("ZstdDecompressCtx_decompressDirectByteBuffer0"), -(jlong)ZJNI_ERROR_no_device, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
 }
-JNIEXPORT jstring JNICALL Java_com_github_luben_zstd_Zstd_getErrorName(JNIEnv* env, jclass cls, jlong code) {
-    (void)cls; return (*env)->NewStringUTF(env, zjni_getErrorName((size_t)code));
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressByteArray0)
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
+    CtxState* s = st_get(ptr, 'D');
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
+    if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
+    if (gpu_dec_takes(s)) {
+        jbyte* sb = (jbyte*)malloc((size_t)src_size + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+        size_t r = (size_t)E_MEM;
+        if (sb && d) {
+            (*env)->GetByteArrayRegion(env, src, src_offset, src_size, sb);
+            r = gpu_decompress(s, d, (size_t)dst_size, sb, (size_t)src_size);
+            if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
+        }
+        free(sb); free(d);
+        if (gpu_result_final(r)) return (jlong)r;
+    }
+    return buf_forward(PS("ZstdDecompressCtx_decompressByteArray0"), -(jlong)ZJNI_ERROR_no_device, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_getErrorCode(JNIEnv* env, jclass cls, jlong code) {
-    (void)env; (void)cls; return (jlong)zjni_getErrorCode((size_t)code);
+/* byte[] source into a direct destination (N/jni_fast_zstd.c:838-866) */
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressByteArrayToDirectByteBuffer0)
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
+    CtxState* s = st_get(ptr, 'D');
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > dst_size) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (src_offset > (*env)->GetArrayLength(env, src) - src_size) return E_SRC;
+    if (dst_offset > (jint)(*env)->GetDirectBufferCapacity(env, dst) - dst_size) return E_DST;
+    {   char* d = (char*)(*env)->GetDirectBufferAddress(env, dst);
+        if (d == NULL) return E_MEM;
+        if (gpu_dec_takes(s)) {
+            jbyte* sb = (jbyte*)malloc((size_t)src_size + 1);
+            size_t r = (size_t)E_MEM;
+            if (sb) { (*env)->GetByteArrayRegion(env, src, src_offset, src_size, sb); r = gpu_decompress(s, d + dst_offset, (size_t)dst_size, sb, (size_t)src_size); }
+            free(sb);
+            if (gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return buf_forward(PS("ZstdDecompressCtx_decompressByteArrayToDirectByteBuffer0"), -(jlong)ZJNI_ERROR_no_device, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressUnsafe
+/* direct source into a byte[] destination (N/jni_fast_zstd.c:872-900) */
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressDirectByteBufferToByteArray0)
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
+    CtxState* s = st_get(ptr, 'D');
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > dst_size) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    if (dst_offset > (*env)->GetArrayLength(env, dst) - dst_size) return E_DST;
+    if (src_offset > (jint)(*env)->GetDirectBufferCapacity(env, src) - src_size) return E_SRC;
+    {   char* sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+        if (sb == NULL) return E_MEM;
+        if (gpu_dec_takes(s)) {
+            jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+            size_t r = (size_t)E_MEM;
+            if (d) { r = gpu_decompress(s, d, (size_t)dst_size, sb + src_offset, (size_t)src_size); if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d); }
+            free(d);
+            if (gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return buf_forward(PS("ZstdDecompressCtx_decompressDirectByteBufferToByteArray0"), -(jlong)ZJNI_ERROR_no_device, env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
+}
+
+/* ---- class Zstd: helpers with the reference's semantics (N/jni_zstd.c:230-267, :50-63, :86-96) -------- */
+JNIEXPORT jlong JNICALL P(Zstd_compressBound)(JNIEnv* env, jclass cls, jlong size) { (void)env; (void)cls; return (jlong)zjni_compressBound((size_t)size); }
+JNIEXPORT jboolean JNICALL P(Zstd_isError)(JNIEnv* env, jclass cls, jlong code) { (void)env; (void)cls; return zjni_isError((size_t)code) != 0; }
+JNIEXPORT jstring JNICALL P(Zstd_getErrorName)(JNIEnv* env, jclass cls, jlong code) { (void)cls; return (*env)->NewStringUTF(env, zjni_getErrorName((size_t)code)); }
+JNIEXPORT jlong JNICALL P(Zstd_getErrorCode)(JNIEnv* env, jclass cls, jlong code) { (void)env; (void)cls; return (jlong)zjni_getErrorCode((size_t)code); }
+/* Zstd.getFrameContentSize(byte[], offset, limit, magicless) -> ZSTD_getFrameContentSize (N/jni_zstd.c:30-43, :86-96); the magicless
+ * format is the bundled library's */
+JNIEXPORT jlong JNICALL P(Zstd_getFrameContentSize0)(JNIEnv* env, jclass cls, jbyteArray src, jint offset, jint limit, jboolean magicless) {
+    jlong (*f)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean) = (jlong (*)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean))cpu_sym(PS("Zstd_getFrameContentSize0"));
+    if (f) return f(env, cls, src, offset, limit, magicless);
+    if (magicless) return -(jlong)ZJNI_ERROR_unsupported;
+    {   jbyte head[18]; jint const n = limit < 18 ? (limit < 0 ? 0 : limit) : 18;          /* a frame header is at most 18 bytes */
+        (*env)->GetByteArrayRegion(env, src, offset, n, head);
+        return (jlong)zjni_getFrameContentSize(head, (size_t)n);
+    }
+}
+JNIEXPORT jlong JNICALL P(Zstd_compressUnsafe)
   (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size, jint level, jboolean checksumFlag) {
-    if (per_buffer_on_gpu() && level >= 1 && level <= 3 && (size_t)src_size <= ZJNI_BLOCKSIZE_MAX) {
+    if (per_buffer_on_gpu() && level >= 0 && level <= 3 && (size_t)src_size <= ZJNI_BLOCKSIZE_MAX) {
         size_t const r = zjni_compress2((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size, level, checksumFlag == JNI_TRUE);
         if (gpu_result_final(r)) return (jlong)r;
     }
     {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean) =
-            (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean))cpu_sym("Java_com_github_luben_zstd_Zstd_compressUnsafe");
+            (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean))cpu_sym(PS("Zstd_compressUnsafe"));
         if (f) return f(env, cls, dst, dst_size, src, src_size, level, checksumFlag);
     }
     return -(jlong)ZJNI_ERROR_unsupported;
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressUnsafe
-  (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size) {
+JNIEXPORT jlong JNICALL P(Zstd_decompressUnsafe)(JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size) {
     if (per_buffer_on_gpu()) {
         size_t const r = zjni_decompress((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size);
         if (gpu_result_final(r)) return (jlong)r;
     }
-    {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong) =
-            (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong))cpu_sym("Java_com_github_luben_zstd_Zstd_decompressUnsafe");
+    {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong) = (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong))cpu_sym(PS("Zstd_decompressUnsafe"));
         if (f) return f(env, cls, dst, dst_size, src, src_size);
     }
     return -(jlong)ZJNI_ERROR_no_device;
@@ -450,48 +561,54 @@ JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressUnsafe
 /* ---- new, additive: batch natives over arrays of direct ByteBuffers ----------------
  * static native long compressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, int level, boolean checksum);
  * static native long decompressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results);
- * Each buffer is taken from position 0 to its capacity.  results[i] = size or the error code compress*0 /
- * decompress*0 would have returned for that buffer; the return value is 0 or a launch-level error. */
+ * static native long compressBatchDict0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, ZstdDictCompress dict, boolean checksum);
+ * Each buffer is taken from position 0 to its capacity and must be a direct buffer.  results[i] = size or the error code
+ * compress*0 / decompress*0 would have returned for that buffer; the return value is 0 or a call-level error
+ * (srcSize_wrong / dstSize_tooSmall for a null or non-direct element, as the per-buffer natives answer). */
 static jlong batch(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, jlongArray results, int compress, int level, int checksum, const zjni_cdict* cdict) {
-    jsize const n = (*env)->GetArrayLength(env, srcs);
-    const void** sp; void** dp; size_t* ss; size_t* dc; size_t* res; jlong* out; size_t r; jsize i;
+    jsize n; const void** sp; void** dp; size_t* ss; size_t* dc; size_t* res; jlong* out; size_t r; jsize i; jlong bad = 0;
+    if (srcs == NULL) return E_SRC;
+    if (dsts == NULL || results == NULL) return E_DST;
+    n = (*env)->GetArrayLength(env, srcs);
     if ((*env)->GetArrayLength(env, dsts) != n || (*env)->GetArrayLength(env, results) < n) return E_SRC;
     if (n == 0) return 0;
     sp = (const void**)malloc(n * sizeof(*sp)); dp = (void**)malloc(n * sizeof(*dp));
     ss = (size_t*)malloc(n * sizeof(*ss)); dc = (size_t*)malloc(n * sizeof(*dc)); res = (size_t*)malloc(n * sizeof(*res));
     out = (jlong*)malloc(n * sizeof(*out));
     if (!sp || !dp || !ss || !dc || !res || !out) { free(sp); free(dp); free(ss); free(dc); free(res); free(out); return E_MEM; }
-    for (i = 0; i < n; i++) {
+    for (i = 0; i < n && !bad; i++) {
         jobject s = (*env)->GetObjectArrayElement(env, srcs, i), d = (*env)->GetObjectArrayElement(env, dsts, i);
-        sp[i] = (*env)->GetDirectBufferAddress(env, s); ss[i] = (size_t)(*env)->GetDirectBufferCapacity(env, s);
-        dp[i] = (*env)->GetDirectBufferAddress(env, d); dc[i] = (size_t)(*env)->GetDirectBufferCapacity(env, d);
+        jlong const sl = s ? (*env)->GetDirectBufferCapacity(env, s) : -1, dl = d ? (*env)->GetDirectBufferCapacity(env, d) : -1;
+        sp[i] = s ? (*env)->GetDirectBufferAddress(env, s) : NULL; dp[i] = d ? (*env)->GetDirectBufferAddress(env, d) : NULL;
+        if (s == NULL || sl < 0 || (sp[i] == NULL && sl > 0)) bad = E_SRC;            /* null, or not a direct buffer */
+        else if (d == NULL || dl < 0 || (dp[i] == NULL && dl > 0)) bad = E_DST;
+        ss[i] = (size_t)(sl < 0 ? 0 : sl); dc[i] = (size_t)(dl < 0 ? 0 : dl);
+        if (s && (*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, s);              /* 2n local references would overflow the frame's table on large batches */
+        if (d && (*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, d);
     }
-    r = cdict ? zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, (size_t)n, cdict, checksum)
-      : compress ? zjni_compress_batch2(sp, ss, dp, dc, res, (size_t)n, level, checksum) : zjni_decompress_batch(sp, ss, dp, dc, res, (size_t)n);
+    if (bad) r = (size_t)bad;
+    else r = cdict ? zjni_compress_batch_usingCDict(sp, ss, dp, dc, res, (size_t)n, cdict, checksum)
+           : compress ? zjni_compress_batch2(sp, ss, dp, dc, res, (size_t)n, level, checksum) : zjni_decompress_batch(sp, ss, dp, dc, res, (size_t)n);
     if (!zjni_isError(r)) { for (i = 0; i < n; i++) out[i] = (jlong)res[i]; (*env)->SetLongArrayRegion(env, results, 0, n, out); }
     free(sp); free(dp); free(ss); free(dc); free(res); free(out);
     return (jlong)r;
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatch0
-  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jint level, jboolean checksum) {
+JNIEXPORT jlong JNICALL P(Zstd_compressBatch0)(JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jint level, jboolean checksum) {
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
     return batch(env, srcs, dsts, results, 1, level, checksum == JNI_TRUE, NULL);
 }
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_decompressBatch0
-  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results) {
+JNIEXPORT jlong JNICALL P(Zstd_decompressBatch0)(JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results) {
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
     return batch(env, srcs, dsts, results, 0, 0, 0, NULL);
 }
-/* static native long compressBatchDict0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, ZstdDictCompress dict, boolean checksum); */
-JNIEXPORT jlong JNICALL Java_com_github_luben_zstd_Zstd_compressBatchDict0
-  (JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jobject dict, jboolean checksum) {
+JNIEXPORT jlong JNICALL P(Zstd_compressBatchDict0)(JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jlongArray results, jobject dict, jboolean checksum) {
     zjni_cdict* g;
     (void)cls;
     if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
-    if (dict == NULL || !g_cdict_field) return -32;
-    g = (zjni_cdict*)dict_get((*env)->GetLongField(env, dict, g_cdict_field), 0);
-    if (!g) return -32;
+    if (dict == NULL) return E_DICT;
+    g = (zjni_cdict*)dict_get((*env)->GetLongField(env, dict, native_ptr_field(env, dict, &g_cdict_field)), 0);
+    if (!g) return E_DICT;
     return batch(env, srcs, dsts, results, 1, 0, checksum == JNI_TRUE, g);
 }
