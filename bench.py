@@ -1,28 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py — batched zstd compress + decompress of the BASELINE.json metric config on MI355X.
+"""bench.py — batched zstd compress + decompress on MI355X, BASELINE.json's metric and its named configs.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config metric|2|3|4|5shape]
   (N>1: launched by the driver through torch.distributed.run, one rank per GPU)
 
-Workload (config.workload): 65,536 x 64 KiB mixed-entropy synthetic buffers,
-level 3, generated in HBM.  One step = one GPU compress pass over the batch + one GPU decompress
-pass over the frames it produced (inputs resident in HBM when the timed region starts).  At N>1
-every rank runs the same per-GPU batch on different buffer indices (weak scaling) and the packed
-compressed output is gathered to rank 0 over RCCL inside the step.
+config (config.workload names it in the JSON line):
+  metric  65,536 x 64 KiB mixed-entropy buffers, level 3, compress + decompress      value = both ways      (the default)
+  2       65,536 frames made by the REFERENCE at its plain level 3 (64 KiB each), decompress, bit-exact   value = decompress
+  3       65,536 x 64 KiB, level 1 (ZSTD_fast) compress, frames checked by the reference                   value = compress
+  4       2^20 x 4 KiB JSON-like records, one trained ZstdDictCompress, level 3                              value = compress
+  5shape  65,536 x 128 KiB, level 3, compress + decompress (config 5's buffer shape on one GPU)              value = both ways
+One step = one GPU pass of the config's direction(s) over the whole batch, inputs resident in HBM when the timed region
+starts.  At N>1 every rank runs the same per-GPU batch on different buffer indices (weak scaling) and the packed compressed
+output is gathered to rank 0 over RCCL inside the step.
 
-value = uncompressed bytes through a full compress->decompress pass per second, whole job.
-roofline = dominant kernel's algorithmic bytes (S + C per buffer) / its HIP-event time.
-cpu_baseline = the reference's own libzstd (oracle/_ref) on this box's host cores, bounded sample.
+value        = uncompressed bytes through the config's pass per second, whole job.
+roofline     = dominant kernel's algorithmic bytes (S + C per buffer) / its HIP-event time, measured inside the library on the
+               launch stream; traffic = HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, stamped with the
+               commit they were measured on).
+cpu_baseline = the reference's own libzstd (oracle/_ref) on this box's host threads: threads and reused contexts exist before
+               the clock starts, passes are released by a barrier and repeated for >= 1 s (oracle/cpu_baseline.c), on the full
+               batch when host memory allows; all-core and single-core figures, CPU model string.
+end_to_end   = the host-pointer entries a JNI batch native binds (zjni_*_batch: pack -> H2D -> kernels -> D2H -> scatter) on a
+               bounded sample — never `value`.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -31,61 +44,150 @@ import __graft_entry__ as entry  # noqa: E402
 GIB = float(1 << 30)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    "metric": dict(level=3, n=65536, size=65536, mode="both", headline="both", metric="GiB/s compress+decompress (L3, 64Ki x 64KiB)"),
+    "2": dict(level=3, n=65536, size=65536, mode="decode_ref", headline="decompress",
+              metric="GiB/s batched decompress, 65 536 reference-made level-3 frames of 64 KiB (BASELINE config 2)"),
+    "3": dict(level=1, n=65536, size=65536, mode="both", headline="compress", metric="GiB/s batched compress level 1, 65 536 x 64 KiB (BASELINE config 3)"),
+    "4": dict(level=3, n=1 << 20, size=4096, mode="dict", headline="compress",
+              metric="GiB/s level-3 compress with a shared ZstdDictCompress, 2^20 x 4 KiB JSON-like records (BASELINE config 4)"),
+    "5shape": dict(level=3, n=65536, size=131072, mode="both", headline="both",
+                   metric="GiB/s compress+decompress (L3, 64Ki x 128KiB: BASELINE config 5's buffers on one GPU)"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--buffers", type=int, default=65536)
-    ap.add_argument("--size", type=int, default=65536)
-    ap.add_argument("--level", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="buffers in the CPU baseline sample")
-    ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded by the CPU reference")
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS))
+    ap.add_argument("--buffers", type=int, default=0, help="override the config's buffer count (diagnostics)")
+    ap.add_argument("--size", type=int, default=0)
+    ap.add_argument("--level", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="buffers in the CPU baseline (0 = the whole batch when host memory allows)")
+    ap.add_argument("--cpu-seconds", type=float, default=1.0, help="timed CPU work per direction")
+    ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded / re-made by the CPU reference")
+    ap.add_argument("--e2e-sample", type=int, default=8192, help="buffers in the end-to-end (host-pointer) leg, 0 = skip")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
-    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification sample + cpu_baseline), e.g. under a profiler")
-    ap.add_argument("--decode-only", action="store_true",
-                    help="diagnostic: time only the decode kernel on reference-compressed frames (unique set of --unique buffers, replicated)")
-    ap.add_argument("--unique", type=int, default=4096)
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
     return ap.parse_args()
 
 
-def decode_only(a, zj, dev, n, size, level):
-    """Diagnostic leg used while bringing kernels up: reference-made frames -> GPU decode."""
-    import numpy as np
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cpu_budget():
+    """(threads worth running, description): the CPUs this process may actually use for a sustained run — the scheduler affinity and
+    the cgroup CPU quota (cpu.max), not the number of processors /proc/cpuinfo shows.  On a box whose cgroup grants 16 CPUs of 256,
+    a run of a few milliseconds bursts over all of them and a run of a second is throttled to 16: the former is what round 1 measured."""
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = visible
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                     # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    threads = min(visible, affinity)
+    if quota:
+        threads = max(1, min(threads, int(quota + 0.999)))
+    return threads, {"processors_visible": visible, "affinity": affinity, "cgroup_cpu_quota": quota}
+
+
+def host_mem_available():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:          # noqa: BLE001 - the GPU box has no .git
+        return None
+
+
+def cpu_baseline_leg(a, host, size, n, level, dictionary, offsets=None):
+    """all-core + single-core timing of the reference on the host (oracle/cpu_baseline.c zso_cpu_baseline2)"""
     from oracle import port
-    B = zj.batch
-    u = min(a.unique, n)
-    raw = zj.synth_host(size, 0, u)
-    frames = port.compress_many(raw, size, level, os.cpu_count() or 1)
-    fs = np.array([len(f) for f in frames], dtype=np.int64)
-    rep = (n + u - 1) // u
-    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
-    d_blob = torch.from_numpy(np.tile(blob, rep)).to(dev)
-    sizes = np.tile(fs, rep)[:n]
-    off = np.zeros(n + 1, dtype=np.int64); off[1:] = np.cumsum(sizes)
-    d_off = torch.from_numpy(off).to(dev)
-    out = torch.empty(n * size, dtype=torch.uint8, device=dev)
-    ooff = B.uniform_offsets(n, size, dev)
-    res = torch.empty(n, dtype=torch.int64, device=dev)
-    times = []
-    for it in range(a.warmup + a.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); B.decompress(d_blob, d_off, out, ooff, res); e1.record()
-        torch.cuda.synchronize()
-        if it >= a.warmup:
-            times.append(e0.elapsed_time(e1))
-    want = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)
-    exact = bool((res == size).all()) and all(torch.equal(out[k * u * size:(k + 1) * u * size][: want.numel()], want[: min(want.numel(), (n - k * u) * size)]) for k in range(rep))
-    ms = sum(times) / len(times)
-    alg = n * size + int(off[-1])
-    print(json.dumps({"diagnostic": "decode-only", "n": n, "size": size, "level": level, "ms": ms, "exact": exact,
-                      "decompress_GiBps": n * size / GIB / (ms / 1e3), "ratio": n * size / int(off[-1]),
-                      "roofline": {"achieved": alg / 1e9 / (ms / 1e3), "frac": alg / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS}}))
+    threads, budget = host_cpu_budget()
+    total = int(offsets[-1]) if offsets is not None else n * size
+    r = port.cpu_baseline2(host, size, n, level, threads, a.cpu_seconds, dictionary, offsets=offsets)
+    k = max(1, min(n, (64 << 20) // max(size, 1)))                     # single core: 64 MiB of the same buffers
+    r1 = port.cpu_baseline2(host, size, k, level, 1, min(a.cpu_seconds, 1.0), dictionary, offsets=None if offsets is None else offsets[:k + 1])
+    tot1 = int(offsets[k]) if offsets is not None else k * size
+    return {"value": total / GIB / (r["compress_s"] + r["decompress_s"]), "unit": "GiB/s", "cores": threads, "kind": "reference",
+            "cpu_model": cpu_model(), "host": budget,
+            "sample": f"{n} x {size} B of the same generator (the {'whole batch' if n >= a._n else 'first buffers of the batch'}), level {level}"
+                      + (", shared CDict/DDict" if dictionary else "") + f"; {threads} threads with reused contexts created before the clock starts, "
+                      f"barrier start, {r['passes'][0]} + {r['passes'][1]} timed passes (>= {a.cpu_seconds:g} s each way), best pass",
+            "compress_GiBps": total / GIB / r["compress_s"], "decompress_GiBps": total / GIB / r["decompress_s"],
+            "compress_GiBps_mean_pass": total / GIB / r["mean_compress_s"], "decompress_GiBps_mean_pass": total / GIB / r["mean_decompress_s"],
+            "per_core": {"compress_GiBps": tot1 / GIB / r1["compress_s"], "decompress_GiBps": tot1 / GIB / r1["decompress_s"], "buffers": k},
+            "ratio": total / max(r["compressed_bytes"], 1), "roundtrip_exact": r["exact"], "compressed_bytes": r["compressed_bytes"]}
+
+
+def end_to_end_leg(zj, host, size, m, level, cd, dd):
+    """zjni_compress_batch* / zjni_decompress_batch* from host pointers: what a JNI batch native pays (PCIe both ways included)"""
+    L = zj.lib()
+    bound = zj.Zstd.compressBound(size)
+    src = np.ascontiguousarray(host[:m * size])
+    comp = np.empty(m * bound, dtype=np.uint8); back = np.empty(m * size, dtype=np.uint8)
+    vp = lambda base, stride: (C.c_void_p * m)(*[base + i * stride for i in range(m)])
+    sp, cp, bp = vp(src.ctypes.data, size), vp(comp.ctypes.data, bound), vp(back.ctypes.data, size)
+    ss = (C.c_size_t * m)(*([size] * m)); cc = (C.c_size_t * m)(*([bound] * m)); res = (C.c_size_t * m)(); res2 = (C.c_size_t * m)()
+    best_c = best_d = 1e30
+    for it in range(3):
+        t0 = time.perf_counter()
+        r = (L.zjni_compress_batch_usingCDict(sp, ss, cp, cc, res, m, cd, 0) if cd else L.zjni_compress_batch2(sp, ss, cp, cc, res, m, level, 0))
+        t1 = time.perf_counter()
+        assert not L.zjni_isError(r), r
+        cs = (C.c_size_t * m)(*[res[i] for i in range(m)])
+        t2 = time.perf_counter()
+        r = L.zjni_decompress_batch_usingDDict(cp, cs, bp, ss, res2, m, dd)
+        t3 = time.perf_counter()
+        assert not L.zjni_isError(r), r
+        if it:
+            best_c, best_d = min(best_c, t1 - t0), min(best_d, t3 - t2)
+    ok = all(res2[i] == size for i in range(m)) and bool((back == src).all())
+    tot = m * size
+    return {"compress_GiBps": tot / GIB / best_c, "decompress_GiBps": tot / GIB / best_d, "both_GiBps": tot / GIB / (best_c + best_d),
+            "sample": f"{m} x {size} B through zjni_compress_batch{'_usingCDict' if cd else '2'} / zjni_decompress_batch_usingDDict (host pointers: pack, H2D, kernels, D2H, scatter), best of 2 after warm-up",
+            "roundtrip_exact": ok}
 
 
 def main():
     a = parse()
+    cfg = dict(CONFIGS[a.config])
+    if a.buffers: cfg["n"] = a.buffers
+    if a.size: cfg["size"] = a.size
+    if a.level: cfg["level"] = a.level
+    n, size, level, mode = cfg["n"], cfg["size"], cfg["level"], cfg["mode"]
+    a._n = n
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,12 +201,21 @@ def main():
     zj.batch.init(local)
     dev = torch.device("cuda", local)
     B = zj.batch
-    n, size, level = a.buffers, a.size, a.level
     first = rank * n                              # disjoint buffer indices per rank (weak scaling)
     from zstd_jni_amd import shard
 
     # ---- inputs resident in HBM ----
-    src = B.synth(n, size, first, dev)
+    cdict = ddict = None; dict_bytes = None
+    if mode == "dict":                            # JSON-like records only (class 1 of the generator: every fourth buffer), one trained dictionary
+        from oracle import ref
+        big = B.synth(4 * n, size, 4 * first, dev)
+        src = big.view(n, 4, size)[:, 1, :].contiguous().view(-1)
+        del big
+        train = zj.synth_host(size, (1 << 24), 40000)
+        dict_bytes = ref.train_dict([train[i * size:(i + 1) * size] for i in range(1, 40000, 4)], 112640)   # 110 KiB from 10 000 records
+        cdict = zj.ZstdDictCompress(dict_bytes, level); ddict = zj.ZstdDictDecompress(dict_bytes)
+    else:
+        src = B.synth(n, size, first, dev)
     src_off = B.uniform_offsets(n, size, dev)
     bound = zj.Zstd.compressBound(size)
     comp = torch.empty(n * bound, dtype=torch.uint8, device=dev)
@@ -115,10 +226,17 @@ def main():
     csz = torch.empty(n, dtype=torch.int64, device=dev)
     dsz = torch.empty(n, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-
-    if a.decode_only:
-        decode_only(a, zj, dev, n, size, level)
-        return
+    host_src = None
+    if mode == "decode_ref":                      # the frames are the reference's: plain ZSTD_compress2(level), all host threads, outside the timed region
+        from oracle import port
+        host_src = src.cpu().numpy()
+        frames, fsz = port.compress_many_packed(host_src, size, level, host_cpu_budget()[0])
+        total = int(fsz.sum())
+        packed[:total].copy_(torch.from_numpy(frames[:total]))
+        csz.copy_(torch.from_numpy(fsz.astype(np.int64)))
+        packed_off[1:] = torch.cumsum(csz, 0)
+        del frames
+        torch.cuda.synchronize()
 
     ev = lambda: torch.cuda.Event(enable_timing=True)   # recorded on the stream the kernels run on
     t_c, t_p, t_d, t_g = [], [], [], []
@@ -126,13 +244,18 @@ def main():
 
     def step(timed):
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
-        e0.record(); B.compress(src, src_off, comp, comp_off, level, csz); e1.record()
-        B.pack(csz, comp, comp_off, out=packed, out_off=packed_off); e2.record()      # frames back to back
+        e0.record()
+        if mode != "decode_ref":
+            B.compress(src, src_off, comp, comp_off, level, csz, dictionary=cdict)
+        e1.record()
+        if mode != "decode_ref":
+            B.pack(csz, comp, comp_off, out=packed, out_off=packed_off)               # frames back to back
+        e2.record()
         handle = None
-        if world > 1 and not a.no_gather:                   # posted before the local decompress: xGMI transfers run beside it
+        if world > 1 and not a.no_gather and mode != "decode_ref":    # posted before the local decompress: xGMI transfers run beside it
             total = int(packed_off[-1].item())
             handle = shard.gather_packed_start(packed[:total], csz, dst=0)
-        B.decompress(packed, packed_off, back, src_off, dsz); e3.record()
+        B.decompress(packed, packed_off, back, src_off, dsz, dictionary=ddict); e3.record()
         if handle is not None:
             shard.gather_packed_finish(handle)
         e4.record()
@@ -166,60 +289,66 @@ def main():
     ok_sizes = bool((csz > 0).all()) and bool((dsz == size).all())
     roundtrip = ok_sizes and torch.equal(back, src)
     csum = int(csz.clamp(min=0).sum().item())
-    cpu = None
-    gates = {"gpu_roundtrip_exact": bool(roundtrip)}
+    cpu = None; e2e = None
+    gates = {"gpu_roundtrip_exact" if mode != "decode_ref" else "gpu_decodes_reference_frames_bit_exact": bool(roundtrip)}
     if rank == 0 and not a.skip_cpu:
         from oracle import port, ref
+        assert ref.available(), "oracle/_ref/libzstd_ref.so missing: run __graft_entry__.build() where /root/reference exists"
         k = min(a.verify_sample, n)
         sizes = csz[:k].cpu().tolist()
-        blob = comp[:k * bound].cpu().numpy()
-        host_off = None
-        host_src = src[:k * size].cpu().numpy().tobytes()
-        checker = ref if ref.available() else port
-        cpu_ok, first_bad = True, None
-        for i in range(k):
-            f = blob[i * bound:i * bound + max(sizes[i], 0)].tobytes()
-            try:
-                good = sizes[i] > 0 and checker.decompress(f, size) == host_src[i * size:(i + 1) * size]
-            except Exception as ex:          # noqa: BLE001 - report, do not crash the bench line
-                good = False
-                first_bad = first_bad or f"{i}: size {sizes[i]} {ex} head {f[:12].hex()}"
-            if not good:
-                cpu_ok = False
-                first_bad = first_bad or f"{i}: size {sizes[i]} head {f[:12].hex()}"
-        gates["cpu_decodes_gpu_frames"] = cpu_ok
-        if first_bad:
-            gates["first_bad_frame"] = first_bad
-        if ref.available():
-            # byte identity, outside the timed region: the frames above against the reference given the library's level-3
-            # table sizes, and a second GPU pass with the level's own sizes (setHashLog(16).setChainLog(15)) against the
-            # reference's plain call
-            want = [ref.compress(host_src[i * size:(i + 1) * size], 3, False, 14, 13) if level == 3 else ref.compress(host_src[i * size:(i + 1) * size], level) for i in range(k)]
+        host_k = src[:k * size].cpu().numpy().tobytes()
+        if mode != "decode_ref":
+            blob = comp[:k * bound].cpu().numpy()
+            cpu_ok, first_bad = True, None
+            for i in range(k):
+                f = blob[i * bound:i * bound + max(sizes[i], 0)].tobytes()
+                try:
+                    good = sizes[i] > 0 and (ref.decompress_using_dict(f, dict_bytes, size) if dict_bytes else ref.decompress(f, size)) == host_k[i * size:(i + 1) * size]
+                except Exception as ex:          # noqa: BLE001 - report, do not crash the bench line
+                    good = False
+                    first_bad = first_bad or f"{i}: size {sizes[i]} {ex} head {f[:12].hex()}"
+                if not good:
+                    cpu_ok = False
+                    first_bad = first_bad or f"{i}: size {sizes[i]} head {f[:12].hex()}"
+            gates["cpu_decodes_gpu_frames"] = cpu_ok
+            if first_bad:
+                gates["first_bad_frame"] = first_bad
+            # byte identity, outside the timed region: the frames above against the reference (given the library's level-3 table
+            # sizes), and a second GPU pass with the level's own sizes (setHashLog(16).setChainLog(15)) against the reference's plain call
+            if dict_bytes:
+                rc = ref.CDict(dict_bytes, level)
+                want = [rc.compress(host_k[i * size:(i + 1) * size]) for i in range(k)]
+                rc.close()
+            else:
+                want = [ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) if level == 3 else ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]
             gates["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + max(sizes[i], 0)].tobytes() == want[i] for i in range(k))
-            if level == 3:
+            if level == 3 and not dict_bytes:
                 c2 = torch.empty(k * bound, dtype=torch.uint8, device="cuda")
                 s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=16, chain_log=15)
                 torch.cuda.synchronize()
                 z2, b2 = s2.cpu().tolist(), c2.cpu().numpy()
                 gates["plain_level3_byte_identical_with_hashLog16_chainLog15"] = all(
-                    b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_src[i * size:(i + 1) * size], 3) for i in range(k))
-        neg = int((csz <= 0).sum().item())
-        if neg:
-            gates["frames_with_error_result"] = neg
-            gates["error_results"] = sorted(set(csz[csz <= 0].cpu().tolist()))[:4]
-        # CPU baseline on a bounded sample of the same workload (same generator, same indices)
-        m = min(a.cpu_sample, n)
-        sample = zj.synth_host(size, first, m)
-        threads = os.cpu_count() or 1
-        r = port.cpu_baseline(sample, size, level, threads, reps=2, use_ref=True)
+                    b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_k[i * size:(i + 1) * size], 3) for i in range(k))
+            neg = int((csz <= 0).sum().item())
+            if neg:
+                gates["frames_with_error_result"] = neg
+                gates["error_results"] = sorted(set(csz[csz <= 0].cpu().tolist()))[:4]
+        # CPU baseline: the whole batch when the host has the memory (source + bound-sized frames + packed frames + decoded copy), else its head
+        m = a.cpu_sample if a.cpu_sample else n
+        need = m * (2 * size + 2 * bound)
+        avail = host_mem_available()
+        if avail and need > 0.6 * avail:
+            m = max(1024, int(0.6 * avail // (2 * size + 2 * bound)))
+        m = min(m, n)
+        if host_src is None or host_src.size < m * size:
+            host_src = src[:m * size].cpu().numpy()
+        cpu = cpu_baseline_leg(a, host_src, size, m, level, dict_bytes)
         gpu_c_sample = int(csz[:m].sum().item())
-        gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(r["compressed_bytes"], 1)
-        gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * r["compressed_bytes"]
-        tot = m * size
-        cpu = {"value": tot / GIB / (r["compress_s"] + r["decompress_s"]), "unit": "GiB/s", "cores": threads, "kind": r["kind"],
-               "sample": f"{m} x {size} B of the same generator, level {level}, best of 2 after warm-up, one reused ctx per thread",
-               "compress_GiBps": tot / GIB / r["compress_s"], "decompress_GiBps": tot / GIB / r["decompress_s"],
-               "ratio": tot / max(r["compressed_bytes"], 1), "roundtrip_exact": r["exact"]}
+        gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
+        gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
+        if a.e2e_sample:
+            me = min(a.e2e_sample, n)
+            e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
 
     if rank == 0:
         ms = wall * 1000.0 / a.steps
@@ -229,48 +358,62 @@ def main():
         stage = {k: sum(t[k] for t in t_stage) / len(t_stage) for k in t_stage[0]} if t_stage else {}
         # kernels of the two paths with their own HIP-event durations (ms); "compress_rest" = classify + table memset +
         # entropy kernel (it runs beside the match kernel on a side stream) + sweep, i.e. compress call minus match kernel
-        kernels = {"zj_enc_match_kernel": stage.get("match", -1.0), "zj_dec_prep_kernel": stage.get("dec_prep", -1.0),
-                   "zj_dec_seq_kernel": stage.get("dec_seq", -1.0), "zj_dec_exec_kernel": stage.get("dec_exec", -1.0),
-                   "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0), "zj_pack_kernel": mp}
-        if kernels["zj_enc_match_kernel"] > 0:
-            kernels["compress_rest(entropy beside match, memset, sweep)"] = mc - kernels["zj_enc_match_kernel"]
-        dom = max((k for k in kernels if kernels[k] > 0 and not k.startswith("compress_rest")), key=lambda k: kernels[k], default=None)
+        match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else "zj_enc_match_kernel")
+        kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
+                   "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}
+        if mode != "decode_ref":
+            kernels[match_name] = stage.get("match_wide" if size > 65536 else "match", -1.0); kernels["zj_pack_kernel"] = mp
+            if kernels[match_name] > 0 and mode != "dict" and size <= 65536:
+                kernels["compress_rest(entropy beside match, memset, sweep)"] = mc - kernels[match_name]
+        slices = 1
+        if mode == "dict":                                     # the dictionary pipeline runs in slices of 131 072 records: one launch = one slice
+            slices = max(1, (n + 131071) // 131072)
+        cand = [k for k in kernels if kernels[k] > 0 and not k.startswith("compress_rest") and (cfg["headline"] != "compress" or not k.startswith("zj_dec"))
+                and (cfg["headline"] != "decompress" or k.startswith("zj_dec"))]
+        dom = max(cand, key=lambda k: kernels[k] * (slices if "dict" in k else 1), default=None)
         if dom is None:                                        # small batches: fused kernels only
             dom, dom_ms = ("zj_encode_kernel", mc) if mc >= md else ("zj_decode_kernel", md)
         else:
             dom_ms = kernels[dom]
-        achieved = alg / 1e9 / (dom_ms / 1e3)
+        alg_launch = alg / slices if (dom and "dict" in dom) else alg
+        achieved = alg_launch / 1e9 / (dom_ms / 1e3)
         traffic, traffic_note, request_roof = None, None, None
         try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            rec = pmc.get(f"L{level}_{n}x{size}", {}).get(dom.split("(")[0])
+            rec = pmc.get(f"{a.config}_L{level}_{n}x{size}", {}).get(dom.split("(")[0])
             if rec:
-                traffic, traffic_note = rec["hbm_bytes_per_launch"], pmc.get("note")
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_note = f"{pmc.get('note', '')} Measured on commit {pmc.get('measured_on_commit')} ({pmc.get('measured_on_date')}); this run is commit {git_head()}."
                 # scattered table accesses: what bounds this kernel is HBM *requests* (64-B reads, 32-B writes), not bytes —
-                # the ceiling is tools/micro/chase's measurement on this part
+                # the ceiling is tools/micro/probe's footprint sweep on this part
                 reqs = rec["fetch_bytes_per_launch"] / 64.0 + rec["write_bytes_per_launch"] / 32.0
                 request_roof = {"hbm_requests_per_launch": reqs, "achieved_G_per_s": reqs / 1e9 / (dom_ms / 1e3),
-                                "measured_ceiling_G_per_s": 52.0, "frac": reqs / 1e9 / (dom_ms / 1e3) / 52.0,
-                                "note": "random-access request ceiling measured with tools/micro/chase (65 536 dependent chains over 6 GiB)"}
+                                "measured_ceiling_G_per_s": 50.3, "frac": reqs / 1e9 / (dom_ms / 1e3) / 50.3,
+                                "note": "random-access request ceiling at a 6 GiB footprint, read-only (40.8 read+write): tools/micro/probe footprint, profiles/r02a_probe_*"}
         except OSError:
             pass
+        per_gpu = n * size / GIB
+        headline_ms = {"both": ms, "compress": mc, "decompress": md}[cfg["headline"]]
+        value = world * per_gpu / (headline_ms / 1e3)
         out = {
-            "metric": "GiB/s compress+decompress (L3, 64Ki x 64KiB)", "value": total_unc / GIB / (ms / 1e3), "unit": "GiB/s",
+            "metric": cfg["metric"], "value": value, "unit": "GiB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} x {size} B mixed-entropy buffers per GPU, zstd level {level}, one frame per buffer",
-                       "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
-                       "gather": bool(world > 1 and not a.no_gather)},
-            "compress_GiBps_per_gpu": n * size / GIB / (mc / 1e3), "decompress_GiBps_per_gpu": n * size / GIB / (md / 1e3),
+            "config": {"workload": f"{n} x {size} B {'JSON-like records' if mode == 'dict' else 'mixed-entropy buffers'} per GPU, zstd level {level}, one frame per buffer"
+                                   + (", one shared 110 KiB trained dictionary (ZstdDictCompress / ZstdDictDecompress)" if mode == "dict" else "")
+                                   + (", frames made by the reference at its plain level (hashLog 16 / chainLog 15), GPU decompress only" if mode == "decode_ref" else ""),
+                       "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
+                       "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"]},
+            "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),
             "kernel_ms": {"compress_call": mc, "decompress_call": md, **kernels, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg, "request_roof": request_roof,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg_launch, "request_roof": request_roof,
                          "decompress_path": {"achieved": alg / 1e9 / (md / 1e3), "frac": alg / 1e9 / (md / 1e3) / HBM_PEAK_GBPS},
-                         "compress_path": {"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS}},
-            "cpu_baseline": cpu, "parity": gates,
+                         "compress_path": ({"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS} if mode != "decode_ref" else None)},
+            "cpu_baseline": cpu, "end_to_end": e2e, "parity": gates,
         }
         print(json.dumps(out))
     if world > 1:

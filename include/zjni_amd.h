@@ -180,6 +180,8 @@ int zjni_kernel_info(int* decodeGrid, int* decodeLdsBytes, int* encodeGrid, int*
  * lane-per-frame sequence decode / execute / fused leftovers.  Blocks until those stages have completed;
  * stages that did not run read -1.  Profiling aid (bench.py roofline), not on the data path. */
 int zjni_last_timing(float* out5);
+/* The same five plus out8[5] = the wide match-finder kernel (frames > 64 KiB), last slice of the call; out8[6..7] read -1. */
+int zjni_last_timing2(float* out8);
 
 #ifdef __cplusplus
 }

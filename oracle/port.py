@@ -121,3 +121,53 @@ def cpu_baseline(data: bytes, buf_size: int, level: int, threads: int, reps: int
         raise RuntimeError("zso_cpu_baseline failed")
     return dict(compress_s=out[0], decompress_s=out[1], compressed_bytes=int(out[2]), exact=bool(out[3]),
                 kind="reference" if path else "port")
+
+
+def cpu_baseline2(data, buf_size: int, n: int, level: int, threads: int, min_seconds: float = 1.0, dictionary: bytes = None,
+                  hash_log: int = 0, chain_log: int = 0, offsets=None):
+    """The reference's libzstd on `threads` host threads that exist (with their reused contexts) before the clock starts, released
+    by a barrier, repeated until `min_seconds` of timed work are done — oracle/cpu_baseline.c zso_cpu_baseline2.
+    `data`: bytes or a numpy uint8 array (n buffers of buf_size bytes, or `offsets` = n+1 byte offsets).  Returns
+    dict(compress_s, decompress_s, compressed_bytes, exact, passes, mean_compress_s, mean_decompress_s)."""
+    import numpy as np
+    from . import ref
+    L = _batch_fn()
+    L.zso_cpu_baseline2.restype = C.c_int
+    L.zso_cpu_baseline2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                    C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+    if not ref.available():
+        raise RuntimeError("oracle/_ref/libzstd_ref.so is not built")
+    arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data
+    off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = (C.c_double * 8)()
+    rc = L.zso_cpu_baseline2(ref.PATH.encode(), arr.ctypes.data, None if off is None else off.ctypes.data, buf_size, n, level, hash_log, chain_log,
+                             threads, min_seconds, dictionary, len(dictionary) if dictionary else 0, out)
+    if rc != 0:
+        raise RuntimeError("zso_cpu_baseline2 failed")
+    return dict(compress_s=out[0], decompress_s=out[1], compressed_bytes=int(out[2]), exact=bool(out[3]), passes=(int(out[4]), int(out[5])),
+                mean_compress_s=out[6], mean_decompress_s=out[7], kind="reference")
+
+
+def compress_many_packed(data, buf_size: int, level: int, threads: int):
+    """The reference's ZSTD_compress2(level) over len(data)//buf_size equal-size buffers with `threads` host threads; `data` is bytes or a
+    numpy uint8 array.  Returns (packed uint8 array: the frames back to back, sizes uint64[n])."""
+    import numpy as np
+    from . import ref
+    L = _batch_fn()
+    arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data)
+    n = arr.size // buf_size
+    bound = L.zso_compress_bound(buf_size)
+    src_off = np.arange(n + 1, dtype=np.uint64) * buf_size
+    dst_off = np.arange(n + 1, dtype=np.uint64) * bound
+    out = np.empty(max(n * bound, 1), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint64)
+    if not ref.available():
+        raise RuntimeError("oracle/_ref/libzstd_ref.so is not built")
+    rc = L.zso_batch(ref.PATH.encode(), 0, level, arr.ctypes.data, src_off.ctypes.data, out.ctypes.data, dst_off.ctypes.data, sizes.ctypes.data, n, threads)
+    if rc != 0:
+        raise RuntimeError("zso_batch failed")
+    packed = np.empty(int(sizes.sum()) + 16, dtype=np.uint8)
+    pos = 0
+    for i in range(n):
+        k = int(sizes[i]); packed[pos:pos + k] = out[i * bound:i * bound + k]; pos += k
+    return packed, sizes

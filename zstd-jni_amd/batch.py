@@ -92,9 +92,9 @@ def pack(results, dst_blob, dst_off, out=None, out_off=None):
 
 
 def last_timing():
-    """ms of the stages of the last large-batch device calls (HIP events on the launch stream, see zjni_last_timing):
-    {"match": .., "dec_prep": .., "dec_seq": .., "dec_exec": .., "dec_fused": ..}; -1 where a stage did not run."""
+    """ms of the stages of the last large-batch device calls (HIP events on the launch stream, see zjni_last_timing2):
+    {"match": .., "dec_prep": .., "dec_seq": .., "dec_exec": .., "dec_fused": .., "match_wide": ..}; -1 where a stage did not run."""
     import ctypes as C
-    out = (C.c_float * 5)()
-    _check(lib().zjni_last_timing(out))
-    return dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused"), [float(x) for x in out]))
+    out = (C.c_float * 8)()
+    _check(lib().zjni_last_timing2(out))
+    return dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused", "match_wide"), [float(x) for x in out][:6]))

@@ -487,7 +487,8 @@ struct DevState {
     u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
     int matchGrid = 0;
     int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
-    hipEvent_t tev[8] = {};                           // stage boundaries of the last batch calls (zjni_last_timing)
+    hipEvent_t tev[12] = {};                          // stage boundaries of the last batch calls (zjni_last_timing): [0,1] match, [2..6] decode stages, [8,9] wide match (last slice)
+    bool tevWide = false;
     bool tevCompress = false, tevDecompress = false;
     hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t waveStream = nullptr; hipEvent_t evJoinWave = nullptr; int waveGrid = 0;   // wave-per-frame matcher beside the lane-per-frame one
@@ -690,6 +691,16 @@ int zjni_last_timing(float* out5) {
     if (d->tevDecompress && hipEventSynchronize(d->tev[6]) == hipSuccess) {
         for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&out5[1 + i], d->tev[2 + i], d->tev[3 + i]);
     }
+    return 0;
+}
+
+/* the same five durations plus out8[5] = the wide match-finder kernel (frames > 64 KiB; last slice of the call); out8[6..7] reserved (-1) */
+int zjni_last_timing2(float* out8) {
+    DevState* d = cur_state();
+    int const r = zjni_last_timing(out8);
+    if (r) return r;
+    out8[5] = out8[6] = out8[7] = -1.0f;
+    if (d->tevWide && hipEventSynchronize(d->tev[9]) == hipSuccess) (void)hipEventElapsedTime(&out8[5], d->tev[8], d->tev[9]);
     return 0;
 }
 
@@ -975,8 +986,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         for (size_t base = 0; base < n; base += sliceB) {
             if (hipMemsetAsync(wctr, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_zero_slots_kernel, dim3((u32)d->numCU * 8), dim3(256), 0, st, tb, strideB, (const u32*)(ctr + 1), (u32)base, (u32)sliceB);
+            (void)hipEventRecord(d->tev[8], st);
             hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB);
+            (void)hipEventRecord(d->tev[9], st); d->tevWide = true;
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
                                fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
