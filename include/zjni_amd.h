@@ -153,6 +153,22 @@ size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize,
                             void* const* dst, const size_t* dstCapacity,
                             size_t* result, size_t n, int level, int checksum);
 
+/* ---- one host batch over several GPUs of this process (a JVM is one process) ----
+ * The batch is cut into contiguous index ranges of about equal source bytes, one per entry of `devices` (ordinals, nDevices <= 64;
+ * an ordinal may repeat); one thread per device runs its range.  Frames and results are what the single-device entries give.
+ * mode 0: every device returns its frames to the host over its own PCIe link — no inter-GPU traffic, the right choice for host
+ *         consumers (JVM buffers).
+ * mode 1: (compress) every device packs its frames and sends them to devices[0] over xGMI (peer copies: the output gather of
+ *         section 8e, 7 links into one device), which returns the whole batch in one transfer.
+ * The calling thread's own device binding is left as it was. */
+size_t zjni_compress_batch_multi(const void* const* src, const size_t* srcSize,
+                                 void* const* dst, const size_t* dstCapacity,
+                                 size_t* result, size_t n, int level, int checksum,
+                                 const int* devices, int nDevices, int mode);
+size_t zjni_decompress_batch_multi(const void* const* src, const size_t* srcSize,
+                                   void* const* dst, const size_t* dstCapacity,
+                                   size_t* result, size_t n, const int* devices, int nDevices);
+
 /* ---- per-buffer forms with the exact argument meaning of the calls they replace ---- */
 /* ZSTD_compress2(cctx{level}, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:607 */
 size_t zjni_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level);
@@ -171,6 +187,23 @@ size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, 
  * error results are skipped. */
 size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
                               void* d_dst, const uint64_t* d_dst_off, size_t n, void* stream);
+
+/* ---- resource policy ----
+ * The large-batch pipelines keep per-frame scratch in HBM (match-finder tables and sequence records, decode cells): one buffer
+ * per pipeline and device, allocated on first use and kept, sized for a 288 GB part (65 536 frames in flight: ~26 GiB compress,
+ * ~49 GiB for frames > 64 KiB, ~34 GiB with a dictionary, ~22 GiB decompress).  A process that shares the GPU bounds that:
+ *   zjni_set_scratch_limit(bytes)  total scratch the library may hold per device (0 = no limit; values below 4 GiB are raised to
+ *                                  4 GiB).  Batches are cut into slices whose scratch fits — results are unchanged, throughput
+ *                                  drops as slices shrink — and a pipeline that needs room evicts the others' buffers.
+ *                                  Returns the limit in force.  The limit is process-wide.
+ *   zjni_scratch_bytes()           scratch currently held on the calling thread's device.
+ *   zjni_release_scratch()         free-on-idle: waits for the device's outstanding batch calls, then frees all of it (the next
+ *                                  call allocates again).  0 or an error code.
+ * Concurrent callers of one device are serialised: batch calls are enqueued under a per-device mutex and each call's first kernel
+ * waits (on the GPU) for the previous call's last one, whatever streams the callers use; the scratch is shared, results are not. */
+size_t zjni_set_scratch_limit(size_t bytes);
+size_t zjni_scratch_bytes(void);
+size_t zjni_release_scratch(void);
 
 /* ---- introspection for tests/bench ---- */
 /* Workgroups the persistent kernels launch per device and LDS bytes per workgroup. */

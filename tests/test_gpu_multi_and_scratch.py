@@ -1,0 +1,97 @@
+"""GPU (-m gpu): the multi-device host entries (zjni_*_batch_multi: one process, a thread per device) and the
+scratch budget (zjni_set_scratch_limit / zjni_release_scratch).  With one GPU on the box the multi entries are driven with the
+same ordinal twice — the sharding, the per-device threads and the peer gather are the code that runs with eight; the test with two
+distinct devices is skipped where there is one."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(zj):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    zj.batch.init(0)
+    return zj
+
+
+def _arrays(bufs, caps):
+    n = len(bufs)
+    keep = [C.create_string_buffer(bytes(b), max(len(b), 1)) for b in bufs]
+    outs = [C.create_string_buffer(max(c, 1)) for c in caps]
+    return (keep, outs, (C.c_void_p * n)(*[C.addressof(k) for k in keep]), (C.c_void_p * n)(*[C.addressof(o) for o in outs]),
+            (C.c_size_t * n)(*[len(b) for b in bufs]), (C.c_size_t * n)(*caps), (C.c_size_t * n)())
+
+
+def _multi(gpu, bufs, level, devices, mode, checksum=False):
+    L = gpu.lib()
+    caps = [gpu.Zstd.compressBound(len(b)) for b in bufs]
+    keep, outs, sp, dp, ss, dc, res = _arrays(bufs, caps)
+    dv = (C.c_int * len(devices))(*devices)
+    r = L.zjni_compress_batch_multi(sp, ss, dp, dc, res, len(bufs), level, int(checksum), dv, len(devices), mode)
+    assert not L.zjni_isError(r), L.zjni_getErrorCode(r)
+    frames = [outs[i].raw[:res[i]] for i in range(len(bufs))]
+    keep2, outs2, sp2, dp2, ss2, dc2, res2 = _arrays(frames, [len(b) for b in bufs])
+    r = L.zjni_decompress_batch_multi(sp2, ss2, dp2, dc2, res2, len(bufs), dv, len(devices))
+    assert not L.zjni_isError(r)
+    back = [outs2[i].raw[:res2[i]] for i in range(len(bufs))]
+    return frames, back
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_multi_entries_shard_and_reassemble(gpu, oracle_ref, mode):
+    rnd = random.Random(3 + mode)
+    bufs = [gpu.synth_host(rnd.choice([0, 100, 4096, 20000, 65536, 65536, 100000]) or 1, rnd.randrange(0, 100000), 1) for _ in range(600)]
+    bufs[7] = b""
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        frames, back = _multi(gpu, bufs, 1, devices, mode, checksum=bool(mode))
+        for i, (b, f, o) in enumerate(zip(bufs, frames, back)):
+            assert f == oracle_ref.compress(b, 1, bool(mode)), (devices, i, len(b))
+            assert o == b, (devices, i)
+    L = gpu.lib()
+    bad = (C.c_int * 1)(99)
+    keep, outs, sp, dp, ss, dc, res = _arrays(bufs[:2], [1000, 1000])
+    assert L.zjni_getErrorCode(L.zjni_compress_batch_multi(sp, ss, dp, dc, res, 2, 1, 0, bad, 1, 0)) == 200      # no such device
+
+
+def test_two_devices_do_not_share_state(gpu, oracle_ref):
+    L = gpu.lib()
+    if L.zjni_device_count() < 2:
+        pytest.skip("one GPU on this box")
+    bufs = [gpu.synth_host(65536, i, 1) for i in range(5000)]
+    frames, back = _multi(gpu, bufs, 3, [0, 1], 0)
+    f1, b1 = _multi(gpu, bufs, 3, [1, 0], 1)
+    for i, b in enumerate(bufs):
+        assert frames[i] == f1[i] == oracle_ref.compress(b, 3, False, 14, 13) and back[i] == b1[i] == b, i
+
+
+def test_scratch_limit_bounds_the_library(gpu, oracle_ref):
+    import torch
+    L, B = gpu.lib(), gpu.batch
+    n, size = 20000, 65536
+    src = B.synth(n, size, 0, "cuda"); off = B.uniform_offsets(n, size, "cuda")
+    bound = gpu.Zstd.compressBound(size)
+    comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); coff = B.uniform_offsets(n, bound, "cuda")
+    free = B.compress(src, off, comp, coff, 3).clone(); torch.cuda.synchronize()
+    big = L.zjni_scratch_bytes()
+    assert big > (6 << 30)                                     # sized for 288 GB: n x (tables + records), and the wide slice
+    assert L.zjni_release_scratch() == 0 and L.zjni_scratch_bytes() == 0
+    try:
+        assert L.zjni_set_scratch_limit(1) == (4 << 30)        # raised to the minimum
+        assert L.zjni_set_scratch_limit(6 << 30) == (6 << 30)
+        comp2 = torch.empty_like(comp)
+        lim = B.compress(src, off, comp2, coff, 3); torch.cuda.synchronize()
+        assert L.zjni_scratch_bytes() <= (6 << 30)
+        assert torch.equal(lim, free) and torch.equal(comp2, comp)          # slicing changes nothing but the time
+        packed, poff = B.pack(lim, comp2, coff)
+        back = torch.empty(n * size, dtype=torch.uint8, device="cuda")
+        dsz = B.decompress(packed, poff, back, off); torch.cuda.synchronize()
+        assert bool((dsz == size).all()) and torch.equal(back, src)
+        assert L.zjni_scratch_bytes() <= (6 << 30)
+    finally:
+        L.zjni_set_scratch_limit(0)
+        assert L.zjni_release_scratch() == 0

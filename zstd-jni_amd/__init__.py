@@ -134,6 +134,13 @@ def lib():
     L.zjni_last_timing.argtypes = [C.POINTER(C.c_float)]
     L.zjni_last_timing2.restype = C.c_int
     L.zjni_last_timing2.argtypes = [C.POINTER(C.c_float)]
+    L.zjni_compress_batch_multi.restype = sz
+    L.zjni_compress_batch_multi.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.zjni_decompress_batch_multi.restype = sz
+    L.zjni_decompress_batch_multi.argtypes = [vp, vp, vp, vp, vp, sz, vp, C.c_int]
+    for fn in ("zjni_set_scratch_limit", "zjni_scratch_bytes", "zjni_release_scratch"):
+        getattr(L, fn).restype = sz
+    L.zjni_set_scratch_limit.argtypes = [sz]
     L.zjni_kernel_info.restype = C.c_int
     L.zjni_kernel_info.argtypes = [C.POINTER(C.c_int)] * 4
     L.zjni_shutdown.restype = None
@@ -146,6 +153,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_decompress_batch_device", "zjni_compress_batch_device", "zjni_decompress_batch",
            "zjni_compress_batch", "zjni_compress", "zjni_decompress", "zjni_synth_fill_host",
            "zjni_synth_fill_device", "zjni_kernel_info", "zjni_pack_batch_device", "zjni_last_timing", "zjni_last_timing2",
+           "zjni_set_scratch_limit", "zjni_scratch_bytes", "zjni_release_scratch", "zjni_compress_batch_multi", "zjni_decompress_batch_multi",
            "zjni_compress_batch_device2", "zjni_compress_batch2", "zjni_compress2",
            "zjni_createDDict", "zjni_freeDDict", "zjni_getDictID_fromDDict", "zjni_decompress_batch_device_usingDDict",
            "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict",

@@ -6,6 +6,7 @@
 // independent, so no cross-XCD traffic exists and the per-XCD L2s only see their own frames.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <string.h>
 #include <stdio.h>
@@ -494,13 +495,13 @@ struct DevState {
     hipStream_t waveStream = nullptr; hipEvent_t evJoinWave = nullptr; int waveGrid = 0;   // wave-per-frame matcher beside the lane-per-frame one
     // batch calls share the per-device scratch: they are enqueued under `enqueueMu`, and each call's kernels wait (on the
     // GPU) for the previous call's last kernel, whatever streams the callers use — many host threads may call at once
-    std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;   // entropy stage beside the match kernel
+    std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;
+    std::mutex* stageMu = nullptr;                    // users of this device's host staging area (host-pointer entries)   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
 std::mutex g_mu;        // guards g_dev
-std::mutex g_stage_mu;  // serialises users of the per-device host staging area
 std::vector<DevState> g_dev;
 thread_local int t_dev = -1;
 
@@ -545,7 +546,7 @@ DevState* get_state(int ordinal) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
-        d.enqueueMu = new std::mutex();
+        d.enqueueMu = new std::mutex(); d.stageMu = new std::mutex();
         if (hipEventCreateWithFlags(&d.lastDone, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -571,6 +572,36 @@ DevState* cur_state() {
         t_dev = cur;
     }
     return get_state(t_dev);
+}
+
+// ---- scratch budget (zjni_set_scratch_limit) ----
+// The pipelines keep per-frame scratch in HBM (hash tables, sequence records, decode cells): four buffers per device, one per
+// pipeline, allocated on first use and kept.  With a limit set, a batch is cut into slices whose scratch fits and a buffer that
+// has to grow first evicts the other pipelines' buffers (after the device has drained).  0 = no limit (sized for 288 GB).
+size_t g_scratch_limit = 0;
+#define ZJ_SCRATCH_LIMIT_MIN ((size_t)4 << 30)
+size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap; }
+void scratch_free_all(DevState* d) {
+    if (d->splitBuf) (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0;
+    if (d->wideBuf) (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0;
+    if (d->cdBuf) (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; d->cdSliceCap = 0;
+    if (d->dsplitBuf) (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0;
+}
+// before a buffer holding `have` bytes is replaced by one of `need` bytes: false when even alone it would exceed the limit
+bool scratch_make_room(DevState* d, size_t have, size_t need) {
+    if (!g_scratch_limit) return true;
+    if (need > g_scratch_limit) return false;
+    if (scratch_total(d) - have + need <= g_scratch_limit) return true;
+    if (hipDeviceSynchronize() != hipSuccess) return false;      // other pipelines' kernels may still be using what is about to go
+    scratch_free_all(d);
+    return true;
+}
+// frames per slice such that `perFrame` bytes of scratch each stay inside `share` of the limit (at least 4 096: below that the
+// fused kernels run, which keep their scratch per workgroup)
+size_t scratch_slice(size_t perFrame, size_t dflt, size_t shareDiv) {
+    if (!g_scratch_limit) return dflt;
+    size_t const f = (g_scratch_limit / shareDiv) / (perFrame ? perFrame : 1);
+    return f < 4096 ? 4096 : (f < dflt ? f : dflt);
 }
 
 bool ensure_staging(DevState* d, size_t bytes) {
@@ -704,6 +735,28 @@ int zjni_last_timing2(float* out8) {
     return 0;
 }
 
+/* ---- resource policy ---- */
+size_t zjni_set_scratch_limit(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_scratch_limit = bytes == 0 ? 0 : (bytes < ZJ_SCRATCH_LIMIT_MIN ? ZJ_SCRATCH_LIMIT_MIN : bytes);
+    return g_scratch_limit;
+}
+size_t zjni_scratch_bytes(void) {
+    DevState* d = cur_state();
+    if (!d) return 0;
+    std::lock_guard<std::mutex> lk(*d->enqueueMu);
+    return scratch_total(d);
+}
+size_t zjni_release_scratch(void) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    std::lock_guard<std::mutex> lk(*d->enqueueMu);              // no batch call is being enqueued ...
+    if (hipDeviceSynchronize() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);   // ... and none is still running
+    scratch_free_all(d);
+    d->lastValid = false;
+    return 0;
+}
+
 int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* encodeLds) {
     DevState* d = cur_state();
     if (decodeLds) *decodeLds = (int)sizeof(ZDecShared);
@@ -735,6 +788,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
         size_t const need = tabBytes + seqBytes + metaBytes + 2 * listBytes + 256;
         if (d->dsplitBufCap < need) {
+            if (!scratch_make_room(d, d->dsplitBufCap, need)) return ZJNI_ERR(64);
             if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
             if (hipMalloc(&d->dsplitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->dsplitBufCap = need;
@@ -796,8 +850,9 @@ struct BatchOrder {
 static size_t decompress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                  uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
     BatchOrder order(cur_state(), stream);
-    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
-        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+    size_t const chunk = scratch_slice((size_t)ZD_SPLIT_TAB_BYTES + ZD_SPLIT_SEQ_BYTES + sizeof(ZDMeta) + 8, ZJ_CHUNK_FRAMES, 1);
+    for (size_t at = 0; at < n || at == 0; at += chunk) {
+        size_t const m = n - at < chunk ? n - at : chunk;
         size_t const r = decompress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, ddict, stream);
         if (r != 0 || n == 0) return r;
     }
@@ -878,6 +933,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
         size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256;
         if (d->splitBufCap < need) {
+            if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->splitBufCap = need;
@@ -968,12 +1024,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // share one scratch area sized for 4-byte positions and 128 KiB frames; a slice past the end of the list is empty.
         size_t sliceB = 65536;                       // as many lanes as the common path runs: 32 768 leaves half the wave slots empty (13.8 vs 18.5 GiB/s on 128 KiB frames)
         if (const char* ov = getenv("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
+        sliceB = scratch_slice((size_t)ze_lane_table_stride((u32)levelWord, true) + ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC) + 12, sliceB, 2);   // half the budget: the common-case buffer of this call has the other half
         if (sliceB > n) sliceB = n;
         if (sliceB < 64) sliceB = 64;
         u32 const strideB = ze_lane_table_stride((u32)levelWord, true);
         size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12;
         size_t const needB = tablesB + fsB + metaB + 256;
         if (d->wideBufCap < needB) {
+            if (!scratch_make_room(d, d->wideBufCap, needB)) return ZJNI_ERR(64);
             if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
             if (hipMalloc(&d->wideBuf, needB) != hipSuccess) return ZJNI_ERR(64);
             d->wideBufCap = needB;
@@ -1005,8 +1063,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
     BatchOrder order(cur_state(), stream);
-    for (size_t at = 0; at < n || at == 0; at += ZJ_CHUNK_FRAMES) {
-        size_t const m = n - at < ZJ_CHUNK_FRAMES ? n - at : ZJ_CHUNK_FRAMES;
+    size_t const chunk = scratch_slice((size_t)ze_lane_table_stride((u32)level, false) + ZE_FRAME_STRIDE(65536u) + 21, ZJ_CHUNK_FRAMES, 2);
+    for (size_t at = 0; at < n || at == 0; at += chunk) {
+        size_t const m = n - at < chunk ? n - at : chunk;
         size_t const r = compress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, level, flags, stream);
         if (r != 0 || n == 0) return r;
     }
@@ -1091,11 +1150,13 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     hipStream_t st = (hipStream_t)stream;
     u32 const flags = zj_frame_flags(checksum);
     size_t chunk = 2 * ZJ_CHUNK_FRAMES;            // 2 048 match waves = every SIMD's second wave slot as well: more table requests in flight (measured: +15 % over 65 536)
+    chunk = scratch_slice((size_t)ZC_TABLE_STRIDE + 2 * ((size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC) + 12), chunk, 1);
     if (const char* ov = getenv("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
     size_t const slice = n < chunk ? n : chunk;
     size_t const fsBytes = slice * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = (slice * 12 + 255) & ~(size_t)255, tablesBytes = slice * (size_t)ZC_TABLE_STRIDE;
     size_t const need = tablesBytes + 2 * (fsBytes + metaBytes) + 256;
     if (d->cdBufCap < need || d->cdSliceCap < slice) {
+        if (!scratch_make_room(d, d->cdBufCap, need)) return ZJNI_ERR(64);
         if (d->cdBuf) { if (hipDeviceSynchronize() != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; }
         if (hipMalloc(&d->cdBuf, need) != hipSuccess) return ZJNI_ERR(64);
         d->cdBufCap = need; d->cdSliceCap = slice;
@@ -1161,7 +1222,7 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     // staging layout: [srcOff][dstOff][result][src blob][dst blob]
     size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
     size_t const total = oDst + dstTotal + 16;
-    std::lock_guard<std::mutex> lk(g_stage_mu);   // one staging area per device
+    std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
     if (!ensure_staging(d, total)) return ZJNI_ERR(64);
     u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff);
     size_t a = 0, b = 0;
@@ -1196,6 +1257,121 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
 
 size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n) {
     return host_batch(false, src, srcSize, dst, dstCap, result, n, 0);
+}
+
+// ---- one host batch over several devices of this process (SURVEY.md section 8e at the boundary a JVM has: one process) ----
+// The batch is cut into contiguous index ranges of about equal source bytes, one per listed device; a thread per device binds it
+// (zjni_init) and runs its range through the host-pointer path.  mode 0: every device returns its frames to the host over its
+// own PCIe link (no inter-GPU traffic — the right choice when the consumer is host memory, as with JVM buffers).  mode 1
+// (compress only): the devices pack their frames and send them to devices[0] over xGMI (peer copies, the gather of section 8e),
+// which returns the whole batch to the host in one transfer.
+static void multi_ranges(const size_t* srcSize, size_t n, int nd, std::vector<size_t>& cut) {
+    size_t total = 0; for (size_t i = 0; i < n; i++) total += srcSize[i];
+    cut.assign((size_t)nd + 1, n); cut[0] = 0;
+    size_t acc = 0; int k = 1;
+    for (size_t i = 0; i < n && k < nd; i++) {
+        acc += srcSize[i];
+        while (k < nd && acc * (size_t)nd >= total * (size_t)k && acc > 0) cut[(size_t)k++] = i + 1;
+    }
+    for (; k < nd; k++) cut[(size_t)k] = n;
+    for (int j = 1; j <= nd; j++) if (cut[(size_t)j] < cut[(size_t)j - 1]) cut[(size_t)j] = cut[(size_t)j - 1];
+}
+static size_t multi_run(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                        int level, int checksum, const int* devices, int nDevices) {
+    if (n == 0) return 0;
+    if (!devices || nDevices < 1 || nDevices > 64) return ZJNI_ERR(42);
+    for (int j = 0; j < nDevices; j++) if (devices[j] < 0 || devices[j] >= dev_count()) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    std::vector<size_t> cut; multi_ranges(srcSize, n, nDevices, cut);
+    std::vector<size_t> rc((size_t)nDevices, 0);
+    std::vector<std::thread> th;
+    for (int j = 0; j < nDevices; j++) th.emplace_back([&, j]() {
+        size_t const lo = cut[(size_t)j], cnt = cut[(size_t)j + 1] - lo;
+        if (!cnt) return;
+        if (zjni_init(devices[j]) != 0) { rc[(size_t)j] = ZJNI_ERR(ZJNI_ERROR_no_device); return; }
+        rc[(size_t)j] = host_batch(compress, src + lo, srcSize + lo, dst + lo, dstCap + lo, result + lo, cnt, level, checksum);
+    });
+    for (auto& t : th) t.join();
+    for (int j = 0; j < nDevices; j++) if (zjni_isError(rc[(size_t)j])) return rc[(size_t)j];
+    return 0;
+}
+// mode 1: compress on every device, pack there, peer-copy the packed frames to devices[0], one D2H from there
+static size_t multi_compress_gather(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                    int level, int checksum, const int* devices, int nDevices) {
+    if (n == 0) return 0;
+    if (!devices || nDevices < 1 || nDevices > 64) return ZJNI_ERR(42);
+    for (int j = 0; j < nDevices; j++) if (devices[j] < 0 || devices[j] >= dev_count()) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    std::vector<size_t> cut; multi_ranges(srcSize, n, nDevices, cut);
+    struct Part { u8* dSrc = nullptr; u8* dComp = nullptr; u8* dPacked = nullptr; u64* dOff = nullptr; u64* dCOff = nullptr; u64* dRes = nullptr; u64* dPOff = nullptr;
+                  std::vector<u64> res, poff; size_t packed = 0, rc = 0; };
+    std::vector<Part> parts((size_t)nDevices);
+    auto phase1 = [&](int j) {
+        Part& p = parts[(size_t)j]; size_t const lo = cut[(size_t)j], cnt = cut[(size_t)j + 1] - lo;
+        if (!cnt) return;
+        if (zjni_init(devices[j]) != 0) { p.rc = ZJNI_ERR(ZJNI_ERROR_no_device); return; }
+        size_t st = 0, ct = 0; std::vector<u64> so(cnt + 1), co(cnt + 1);
+        for (size_t i = 0; i < cnt; i++) { so[i] = st; co[i] = ct; st += srcSize[lo + i]; ct += dstCap[lo + i]; }
+        so[cnt] = st; co[cnt] = ct;
+        std::vector<u8> stage(st + 16);
+        for (size_t i = 0; i < cnt; i++) if (srcSize[lo + i]) memcpy(stage.data() + so[i], src[lo + i], srcSize[lo + i]);
+        bool ok = hipMalloc(&p.dSrc, st + 16) == hipSuccess && hipMalloc(&p.dComp, ct + 16) == hipSuccess && hipMalloc(&p.dOff, (cnt + 1) * 8) == hipSuccess
+               && hipMalloc(&p.dCOff, (cnt + 1) * 8) == hipSuccess && hipMalloc(&p.dRes, cnt * 8) == hipSuccess && hipMalloc(&p.dPOff, (cnt + 1) * 8) == hipSuccess;
+        ok = ok && hipMemcpy(p.dSrc, stage.data(), st, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(p.dOff, so.data(), (cnt + 1) * 8, hipMemcpyHostToDevice) == hipSuccess
+                && hipMemcpy(p.dCOff, co.data(), (cnt + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { p.rc = ZJNI_ERR(64); return; }
+        size_t const r = zjni_compress_batch_device2(p.dSrc, p.dOff, p.dComp, p.dCOff, p.dRes, cnt, level, checksum, nullptr);
+        if (zjni_isError(r)) { p.rc = r; return; }
+        p.res.resize(cnt); p.poff.resize(cnt + 1);
+        if (hipMemcpy(p.res.data(), p.dRes, cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) { p.rc = ZJNI_ERR(ZJNI_ERROR_no_device); return; }
+        size_t a = 0; for (size_t i = 0; i < cnt; i++) { p.poff[i] = a; if (!zjni_isError((size_t)p.res[i])) a += p.res[i]; }
+        p.poff[cnt] = a; p.packed = a;
+        ok = hipMalloc(&p.dPacked, a + 16) == hipSuccess && hipMemcpy(p.dPOff, p.poff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { p.rc = ZJNI_ERR(64); return; }
+        size_t const r2 = zjni_pack_batch_device(p.dComp, p.dCOff, p.dRes, p.dPacked, p.dPOff, cnt, nullptr);
+        if (zjni_isError(r2) || hipDeviceSynchronize() != hipSuccess) p.rc = ZJNI_ERR(ZJNI_ERROR_no_device);
+    };
+    {   std::vector<std::thread> th; for (int j = 0; j < nDevices; j++) th.emplace_back(phase1, j); for (auto& t : th) t.join(); }
+    size_t rc = 0, total = 0;
+    for (auto& p : parts) { if (zjni_isError(p.rc) && !rc) rc = p.rc; total += p.packed; }
+    u8* gather = nullptr; std::vector<u8> host;
+    if (!rc) {
+        if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&gather, total + 16) != hipSuccess) rc = ZJNI_ERR(64);
+        size_t at = 0;
+        for (int j = 0; j < nDevices && !rc; j++) {            // the xGMI step: every device's packed frames land behind each other on devices[0]
+            Part& p = parts[(size_t)j];
+            if (p.packed && hipMemcpyPeer(gather + at, devices[0], p.dPacked, devices[j], p.packed) != hipSuccess) rc = ZJNI_ERR(ZJNI_ERROR_no_device);
+            at += p.packed;
+        }
+        host.resize(total + 16);
+        if (!rc && total && hipMemcpy(host.data(), gather, total, hipMemcpyDeviceToHost) != hipSuccess) rc = ZJNI_ERR(ZJNI_ERROR_no_device);
+        size_t base = 0;
+        for (int j = 0; j < nDevices && !rc; j++) {
+            Part& p = parts[(size_t)j]; size_t const lo = cut[(size_t)j], cnt = cut[(size_t)j + 1] - lo;
+            for (size_t i = 0; i < cnt; i++) {
+                result[lo + i] = (size_t)p.res[i];
+                if (!zjni_isError(result[lo + i]) && result[lo + i]) memcpy(dst[lo + i], host.data() + base + p.poff[i], result[lo + i]);
+            }
+            base += p.packed;
+        }
+    }
+    if (gather) { (void)hipSetDevice(devices[0]); (void)hipFree(gather); }
+    for (int j = 0; j < nDevices; j++) {
+        Part& p = parts[(size_t)j];
+        if (!p.dSrc && !p.dComp) continue;
+        (void)hipSetDevice(devices[j]);
+        (void)hipFree(p.dSrc); (void)hipFree(p.dComp); (void)hipFree(p.dPacked); (void)hipFree(p.dOff); (void)hipFree(p.dCOff); (void)hipFree(p.dRes); (void)hipFree(p.dPOff);
+    }
+    return rc;
+}
+size_t zjni_compress_batch_multi(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                 int level, int checksum, const int* devices, int nDevices, int mode) {
+    if (level == 0) level = 3;
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (mode == 1) return multi_compress_gather(src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0, devices, nDevices);
+    return multi_run(true, src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0, devices, nDevices);
+}
+size_t zjni_decompress_batch_multi(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                   const int* devices, int nDevices) {
+    return multi_run(false, src, srcSize, dst, dstCap, result, n, 0, 0, devices, nDevices);
 }
 size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
