@@ -26,7 +26,10 @@ extern "C" {
 #define ZJNI_VERSION_STRING "0.1.0-zstd1.5.7"
 #define ZJNI_ERROR_no_device 200u      /* no HIP device / kernel launch failure */
 #define ZJNI_ERROR_unsupported 201u    /* input outside the GPU path's scope (see zjni_compress_batch) */
-#define ZJNI_BLOCKSIZE_MAX (1u << 17)  /* ZSTD_BLOCKSIZE_MAX, N/zstd.h:147-148 */
+#define ZJNI_BLOCKSIZE_MAX (1u << 17)  /* ZSTD_BLOCKSIZE_MAX, N/zstd.h:147-148: inputs up to here become single-block frames */
+#define ZJNI_FRAME_MAX (2u << 20)      /* largest input the compress entries take: multi-block frames (N/compress/zstd_compress.c:4591-4692),
+                                        * byte-identical to ZSTD_compress2 with the level's own parameters, as long as the frame fits the level's
+                                        * window — 512 KiB / 1 MiB / 2 MiB at levels 1 / 2 / 3; beyond that ZJNI_ERROR_unsupported */
 
 /* ---- library / device ---- */
 const char* zjni_version(void);
@@ -66,9 +69,9 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
 
 /* Replaces ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) for n buffers at
  * once: each buffer becomes one standard zstd frame (content size in the header, no checksum,
- * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h).  Buffers larger
- * than ZJNI_BLOCKSIZE_MAX report ZJNI_ERROR_unsupported in d_result[i] (multi-block frames stay on
- * the CPU path). */
+ * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h).  Buffers larger than
+ * ZJNI_BLOCKSIZE_MAX become multi-block frames (one wavefront per frame, block after block; see ZJNI_FRAME_MAX for the
+ * range); beyond it d_result[i] reports ZJNI_ERROR_unsupported and the buffer stays on the CPU path. */
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off,
                                   void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream);

@@ -126,6 +126,21 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     return r;
 }
 
+// multi-block frames (128 KiB < srcSize <= 2 MiB): the frame loop of ze_compress_multi, lane-serial
+extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    Grp<1> g;
+    u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
+    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
+    u8* lds = (u8*)calloc(1, 160 * 1024);
+    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
+    memset(tables, 0xA5, ZE_MULTI_TABLE_BYTES);                      // the encoder clears what it uses
+    ZjProf pf; pf.start(nullptr);
+    u64 const r = ze_compress_multi(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u);
+    free(tables); free(ws); free(lds); free(sh);
+    return r;
+}
+
 // dictionary compression: digest (ZSTD_createCDict) + ZSTD_CCtx_refCDict / ZSTD_compress2
 #include "../../zstd-jni_amd/csrc/zj_cdict.h"
 extern "C" void* emu_cdict_create(const unsigned char* dict, unsigned dictSize, unsigned level) {

@@ -1,0 +1,105 @@
+"""CPU (-m "not gpu"): multi-block frames (128 KiB < input <= 2 MiB; ze_compress_multi in zstd-jni_amd/csrc/zj_encode.h + the pre-split
+heuristic of zj_presplit.h), built lane-serial (tests/emu), are byte-identical to the reference's ZSTD_compress2 at levels 1-3 with
+the level's own parameters: block sizes (ZSTD_optimalBlockSize / ZSTD_splitBlock), repcodes and the Huffman table carried from
+block to block, raw / RLE / compressed blocks, checksum, frames without content size (N/compress/zstd_compress.c:4552-4692)."""
+import random
+
+import pytest
+
+from conftest import golden
+from util import emu_lib, emu_compress_multi, emu_decompress
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_lib()
+
+
+WINDOW = {1: 1 << 19, 2: 1 << 20, 3: 1 << 21}           # the frame has to fit the level's window (clevels.h:27-30)
+
+
+def check(emu, ref, d, level, checksum=False, content_size=True, tag=None):
+    got = emu_compress_multi(emu, d, level, checksum, content_size)
+    if len(d) > WINDOW[level]:
+        assert got == -201, (tag, len(d), level)
+        return None
+    want = ref.compress(d, level, checksum, content_size=content_size)
+    assert got == want, (tag, len(d), level, checksum, content_size, len(want), got if isinstance(got, int) else len(got))
+    return got
+
+
+def test_multiblock_synthetic_classes(emu, oracle_ref, zj):
+    for size in (131073, 131080, 200000, 262144, 262145, 300000, 524288, 524289, 1048576):
+        for cls in range(5):
+            if cls < 4:
+                parts, i = [], cls
+                while sum(map(len, parts)) < size:
+                    parts.append(zj.synth_host(65536, i, 1)); i += 4
+                d = b"".join(parts)[:size]
+            else:
+                d = zj.synth_host(65536, 7, (size + 65535) // 65536)[:size]      # classes change every 64 KiB: the pre-split heuristic cuts
+            for level in (1, 2, 3):
+                check(emu, oracle_ref, d, level, tag=("synth", cls))
+
+
+def test_multiblock_xml_and_flags(emu, oracle_ref):
+    rnd = random.Random(9)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for size in (140000, 262144, 1 << 20, 1500000, 2 << 20):
+        off = rnd.randrange(0, len(xml) - size)
+        d = xml[off:off + size]
+        for level in (1, 2, 3):
+            for ck, cs in ((False, True), (True, True), (False, False), (True, False)):
+                z = check(emu, oracle_ref, d, level, ck, cs, tag=("xml", off))
+                if z is not None and ck and cs:
+                    assert emu_decompress(emu, z, len(d)) == d
+    assert emu_compress_multi(emu, xml[:(2 << 20) + 1], 3) == -201              # beyond ZE_MULTI_MAX
+    assert emu_compress_multi(emu, xml[:131072], 3) == -201                     # single-block frames are the other entry's
+
+
+def test_multiblock_block_types(emu, oracle_ref):
+    """RLE blocks (never the first one), raw blocks between compressible ones (their repcodes and Huffman table are not confirmed),
+    literal sections small enough to repeat the previous block's Huffman table, long matches across block borders"""
+    rnd = random.Random(4)
+    noise = bytes(rnd.getrandbits(8) for _ in range(300000))
+    words = [b"alpha", b"beta", b"gamma", b"delta", b"epsilon", b"zeta", b"eta", b"theta"]
+    text = b" ".join(rnd.choice(words) for _ in range(120000))
+    lowent = bytes(rnd.choice(b"abcdefgh") for _ in range(400000))
+    cases = {
+        "zeros": b"\x00" * 700000,
+        "zeros_then_text": b"\x00" * 300000 + text[:200000],
+        "text_zeros_text": text[:131072] + b"z" * 262144 + text[:150000],
+        "text": text[:600000],
+        "noise_text_noise": noise[:140000] + text[:200000] + noise[:131072] + text[200000:330000],
+        "noise": noise,
+        "lowent": lowent,
+        "long_repeat": (noise[:70000] * 8)[:500000],
+        "periodic": (b"0123456789abcdef" * 40000)[:520000],
+        "text_small_tail": text[:131072 * 3 + 5],
+        "tail_6": text[:131072 * 2 + 6],
+        "tail_7": text[:131072 * 2 + 7],
+        "rle_tail": text[:131072] + b"q" * (131072 + 40),
+        "sparse_literals": (b"A" * 5000 + noise[:300] + b"B" * 7000 + noise[300:500]) * 20,
+    }
+    for name, d in cases.items():
+        for level in (1, 2, 3):
+            check(emu, oracle_ref, d, level, tag=name)
+            check(emu, oracle_ref, d, level, True, tag=name)
+
+
+def test_multiblock_random_shapes(emu, oracle_ref, zj):
+    rnd = random.Random(77)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for k in range(40):
+        size = rnd.choice([rnd.randrange(131073, 300000), rnd.randrange(131073, 1100000), 131073, 393216, 524288])
+        parts = []
+        while sum(map(len, parts)) < size:
+            kind = rnd.randrange(5); n = rnd.choice([1000, 8192, 40000, 131072, 200000])
+            if kind == 0: parts.append(bytes(rnd.getrandbits(8) for _ in range(min(n, 50000))))
+            elif kind == 1: o = rnd.randrange(0, len(xml) - n); parts.append(xml[o:o + n])
+            elif kind == 2: parts.append(zj.synth_host(min(n, 65536), rnd.randrange(1 << 20), 1))
+            elif kind == 3: parts.append(bytes([rnd.getrandbits(8)]) * n)
+            else: parts.append(parts[rnd.randrange(len(parts))] if parts else b"seed" * 100)
+        d = b"".join(parts)[:size]
+        level = rnd.choice([1, 2, 3])
+        check(emu, oracle_ref, d, level, rnd.random() < 0.3, rnd.random() < 0.8, tag=("shape", k))

@@ -146,9 +146,10 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     with pytest.raises(gpu.ZstdException) as e:                       # T/scala/Zstd.scala:186-201
         ctx.compress(data, small)
     assert e.value.getErrorCode() == gpu.Zstd.errDstSizeTooSmall()
+    assert gpu.Zstd.compress(b"x" * 131073, 3) == oracle_ref.compress(b"x" * 131073, 3)      # a multi-block frame (tests/test_gpu_multiblock.py)
     with pytest.raises(gpu.ZstdException) as e:
-        gpu.Zstd.compress(b"x" * 131073, 3)
-    assert e.value.getErrorCode() == 201                              # multi-block frames stay on the CPU path
+        gpu.Zstd.compress(b"x" * ((2 << 20) + 1), 3)
+    assert e.value.getErrorCode() == 201                              # beyond ZJNI_FRAME_MAX: the CPU path's
     # offsets: J/ZstdCompressCtx.java:691 compressByteArray
     dst = bytearray(40000)
     n = ctx.compressByteArray(dst, 100, 39000, b"\x01" * 5 + data + b"\x02" * 3, 5, len(data))

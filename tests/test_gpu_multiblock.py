@@ -1,0 +1,70 @@
+"""GPU (-m gpu): multi-block frames (128 KiB < input <= 2 MiB) through the C-ABI are byte-identical to the reference's ZSTD_compress2
+at levels 1-3 (the level's own parameters), decode back on the GPU, and mix freely with single-block buffers in one batch."""
+import random
+
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(zj):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    zj.batch.init(0)
+    return zj
+
+
+WINDOW = {1: 1 << 19, 2: 1 << 20, 3: 1 << 21}
+
+
+def inputs(gpu, ref, seed, count):
+    rnd = random.Random(seed)
+    xml = ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(200000))
+    out = []
+    for _ in range(count):
+        size = rnd.choice([131073, rnd.randrange(131073, 300000), rnd.randrange(131073, 1100000), 262144, 524288, 1048576, rnd.randrange(1100000, 2097153), 65536, 4096, 100000])
+        parts = []
+        while sum(map(len, parts)) < size:
+            kind = rnd.randrange(6); n = rnd.choice([1000, 8192, 40000, 131072, 200000])
+            if kind == 0: parts.append(noise[:min(n, 60000)])
+            elif kind == 1: o = rnd.randrange(0, len(xml) - n); parts.append(xml[o:o + n])
+            elif kind == 2: parts.append(gpu.synth_host(min(n, 65536), rnd.randrange(1 << 20), 1))
+            elif kind == 3: parts.append(bytes([rnd.getrandbits(8)]) * n)
+            elif kind == 4: parts.append(b"".join(bytes([rnd.getrandbits(8)]) * rnd.randrange(200, 9000) + noise[:rnd.randrange(0, 12)] for _ in range(8)))
+            else: parts.append(parts[rnd.randrange(len(parts))] if parts else b"seed" * 100)
+        out.append(b"".join(parts)[:size])
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_gpu_multiblock_frames_are_the_references(gpu, oracle_ref, level):
+    datas = inputs(gpu, oracle_ref, 100 + level, 60)
+    for checksum in (False, True):
+        outs = gpu.compress_batch(datas, level, checksum=checksum)
+        good = []
+        for d, z in zip(datas, outs):
+            if len(d) > WINDOW[level]:
+                assert isinstance(z, Exception) and z.getErrorCode() == 201, len(d)
+                continue
+            want = oracle_ref.compress(d, level, checksum) if len(d) > 131072 or level < 3 else oracle_ref.compress(d, 3, checksum, 14, 13)
+            assert not isinstance(z, Exception), (len(d), z)
+            assert z == want, (len(d), level, checksum)
+            good.append((d, z))
+        back = gpu.decompress_batch([z for _, z in good], [len(d) for d, _ in good])
+        for (d, _), b in zip(good, back):
+            assert b == d
+
+
+def test_gpu_one_mebibyte_buffer_like_baseline_config_1(gpu, oracle_ref):
+    """BASELINE config 1's shape: Zstd.compress / decompress of a 1 MiB buffer at level 3 — on the GPU now, same bytes as the CPU path"""
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)[: 1 << 20]
+    z = gpu.Zstd.compress(xml, 3)
+    assert z == oracle_ref.compress(xml, 3)
+    assert gpu.Zstd.decompress(z, len(xml)) == xml
+    with pytest.raises(gpu.ZstdException) as ex:         # level 1: the frame (1 MiB) exceeds the window (512 KiB): left to the CPU path
+        gpu.Zstd.compress(xml, 1)
+    assert ex.value.getErrorCode() == 201

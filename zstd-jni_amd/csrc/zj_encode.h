@@ -78,8 +78,11 @@ struct ZEncShared {                // uniforms, outside the overlay
     // dictionary state kept across the frames one workgroup encodes (the kernel clears dictLoaded / ctDict once)
     u32 dictLoaded, dictID, dictStrategy, dictMinMatch, dictHufRep, dictHufMaxSV, dictFseRep[3];
     u32 ctDict[3];                 // e.ct[t] currently holds the dictionary's table
-    u32 dictCodes[256];            // Huffman code | nbBits << 16 of the dictionary's literal table
+    u32 dictCodes[256];            // Huffman code | nbBits << 16 of the dictionary's literal table — in a multi-block frame: the previous block's
+    u32 blkRep[2], blkNextRep[2];  // multi-block frames: repcodes confirmed by the last compressed block / left by the block being encoded
 };
+// one block of a multi-block frame (ze_compress_multi): block = frameBase[start, start + srcSize) of ze_compress_t
+struct ZEBlockArgs { const u8* frameBase; u32 frameSize, start, isFirst, lastBlock; u32* tables; };
 #define ZE_SMALL_MAX 4096u         /* frames up to this size are staged, gathered and assembled in LDS when the launch provides it */
 #define ZE_ALIGN16(x) (((x) + 15u) & ~15u)
 #define ZE_ENTROPY_LDS ZE_ALIGN16((u32)sizeof(ZEEntropy))
@@ -151,10 +154,24 @@ ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     u32 const level = ZE_LW_LEVEL(levelWord), hl = ZE_LW_HL(levelWord), cl = ZE_LW_CL(levelWord);
     u32 w, c, h, mm, st;
     if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; mm = (level == 1) ? 5 : 4; st = (level == 3) ? 2 : 1; }
-    else if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
-    else if (level == 2) { w = 17; c = 13; h = 15; mm = 5; st = 1; }
-    else { w = 17; c = 15; h = 16; mm = 5; st = 2; }
+    else if (srcSize <= (128u << 10)) {
+        if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
+        else if (level == 2) { w = 17; c = 13; h = 15; mm = 5; st = 1; }
+        else { w = 17; c = 15; h = 16; mm = 5; st = 2; }
+    } else if (srcSize <= (256u << 10)) {                     // clevels.h:52-55 (multi-block frames, ze_compress_multi)
+        if (level == 1) { w = 18; c = 13; h = 14; mm = 6; st = 1; }
+        else if (level == 2) { w = 18; c = 14; h = 14; mm = 5; st = 2; }
+        else { w = 18; c = 16; h = 16; mm = 4; st = 2; }
+    } else {                                                  // clevels.h:27-30
+        if (level == 1) { w = 19; c = 13; h = 14; mm = 7; st = 1; }
+        else if (level == 2) { w = 20; c = 15; h = 16; mm = 6; st = 1; }
+        else { w = 21; c = 16; h = 17; mm = 5; st = 2; }
+    }
     ze_adjust(w, c, h, srcSize);
+    if (srcSize > (128u << 10)) {                             // multi-block frames run the level's own table sizes (tables in HBM)
+        ZEParams q; q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = mm; q.strategy = st;
+        return q;
+    }
     if (st == 2 && (hl | cl)) {   // explicit ZSTD_c_hashLog / ZSTD_c_chainLog: override, then ZSTD_adjustCParams_internal again (zstd_compress.c:1640-1655)
         if (hl) h = hl;
         if (cl) c = cl;
@@ -404,6 +421,178 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
             }
         }
     }
+    return (u32)(iend - anchor);
+}
+
+// ---- the same two parses for one BLOCK of a multi-block frame (ze_compress_multi) ----
+// The block is base[start, end); table entries and match positions are relative to `base` (the frame), so matches reach
+// back into earlier blocks; literal positions in the records are relative to the block.  rep[] comes from the last block
+// that was emitted compressed and is left as the reference leaves it for the next one (zstd_fast.c:244-250, :352-372;
+// zstd_double_fast.c:153-163, :238-246: offsets beyond the data seen so far are parked and restored).  The frame fits its
+// window (checked by the caller), so every earlier position is a legal candidate.
+template <class E>
+ZJ_DEV u32 ze_block_fast_x(ZEOut& o, const u8* base, u32 start, u32 end, u32 hlog, u32 mls, typename E::T* table, const u32* repIn, u32* repOut) {
+    const u8* const istart = base + start; const u8* const iend = base + end; const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart + (start == 0 ? 1 : 0); const u8* ip1; const u8* ip2; const u8* ip3;
+    u32 rep1 = repIn[0], rep2 = repIn[1], saved1 = 0, saved2 = 0;
+    {   u32 const maxRep = (u32)(ip0 - base);
+        if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }
+    u32 hash0, hash1, matchE, cur0 = 0, offcode = 0, mLength = 0, step;
+    const u8* match0 = base; const u8* nextStep;
+    for (;;) {
+        step = 2; nextStep = ip0 + 128;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        u64 w0 = ld64(ip0), w1 = ld64(ip1);
+        hash0 = ze_hash_w(w0, hlog, mls); hash1 = ze_hash_w(w1, hlog, mls);
+        matchE = table[hash0];
+        bool found = false, isRep = false;
+        do {
+            u32 const t0 = ze_tag4((u32)w0), t1 = ze_tag4((u32)w1);
+            bool const m0 = E::maybe(matchE, t0);
+            u32 const rval = ld32(ip2 - rep1);
+            u64 const w2 = ld64(ip2), w3 = ld64(ip3);
+            u32 const c0 = m0 ? ld32(base + E::pos(matchE) - 1) : ~(u32)w0;
+            cur0 = (u32)(ip0 - base); table[hash0] = E::make(cur0 + 1, t0);
+            u32 const matchE1 = table[hash1];
+            table[hash1] = E::make((u32)(ip1 - base) + 1, t1);
+            bool const m1 = E::maybe(matchE1, t1);
+            u32 const c1 = m1 ? ld32(base + E::pos(matchE1) - 1) : ~(u32)w1;
+            if (((u32)w2 == rval) & (rep1 > 0)) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = (ip0[-1] == match0[-1]); ip0 -= mLength; match0 -= mLength;
+                offcode = 1; mLength += 4;
+                found = true; isRep = true; break;
+            }
+            if (m0 && c0 == (u32)w0) { found = true; break; }
+            matchE = matchE1;
+            hash0 = hash1; hash1 = ze_hash_w(w2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            cur0 = (u32)(ip0 - base);
+            if (m1 && c1 == (u32)w1) { if (step <= 4) table[hash1] = E::make((u32)(ip1 - base) + 1, ze_tag4((u32)w2)); found = true; break; }
+            matchE = table[hash1];
+            hash0 = hash1; hash1 = ze_hash_w(w3, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            w0 = w2; w1 = w3;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;
+        if (!isRep) {
+            match0 = base + E::pos(matchE) - 1;
+            rep2 = rep1; rep1 = (u32)(ip0 - match0); offcode = rep1 + 3; mLength = 4;
+            while (((ip0 > anchor) & (match0 > base)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        mLength += ze_count(ip0 + mLength, match0 + mLength, iend);
+        ze_store(o, (u32)(anchor - istart), (u32)(ip0 - anchor), offcode, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip0 <= ilimit) {
+            {   u64 const wa = ld64(base + cur0 + 2), wb = ld64(ip0 - 2);
+                table[ze_hash_w(wa, hlog, mls)] = E::make(cur0 + 2 + 1, ze_tag4((u32)wa));
+                table[ze_hash_w(wb, hlog, mls)] = E::make((u32)(ip0 - 2 - base) + 1, ze_tag4((u32)wb)); }
+            if (rep2 > 0) {
+                while ((ip0 <= ilimit) && (ld32(ip0) == ld32(ip0 - rep2))) {
+                    u32 const rLength = ze_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    {   u64 const wi = ld64(ip0); table[ze_hash_w(wi, hlog, mls)] = E::make((u32)(ip0 - base) + 1, ze_tag4((u32)wi)); }
+                    ip0 += rLength;
+                    ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+    saved2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+    repOut[0] = rep1 ? rep1 : saved1; repOut[1] = rep2 ? rep2 : saved2;
+    return (u32)(iend - anchor);
+}
+template <class E>
+ZJ_DEV u32 ze_block_dfast_x(ZEOut& o, const u8* base, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls, typename E::T* hashLong, typename E::T* hashSmall,
+                            const u32* repIn, u32* repOut) {
+    const u8* const istart = base + start; const u8* const iend = base + end; const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip = istart + (start == 0 ? 1 : 0); const u8* ip1;
+    u32 off1 = repIn[0], off2 = repIn[1], saved1 = 0, saved2 = 0;
+    {   u32 const maxRep = (u32)(ip - base);
+        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+        if (off1 > maxRep) { saved1 = off1; off1 = 0; } }
+    u32 mLength = 0, offset = 0, curr = 0, step, hl0, hl1 = 0, el0, el1 = 0;
+    const u8* nextStep; const u8* matchs0 = base; const u8* matchl0;
+    for (;;) {
+        step = 1; nextStep = ip + 256; ip1 = ip + step;
+        if (ip1 > ilimit) break;
+        u64 w = ld64(ip), w1 = ld64(ip1);
+        hl0 = ze_hash_w(w, hBitsL, 8); u32 hs0 = ze_hash_w(w, hBitsS, mls);
+        el0 = hashLong[hl0]; u32 es0 = hashSmall[hs0];
+        u32 kind = 0;
+        do {
+            curr = (u32)(ip - base);
+            u32 const tl = ze_tag8(w), ts = ze_tag4((u32)w);
+            hashLong[hl0] = E::make(curr + 1, tl); hashSmall[hs0] = E::make(curr + 1, ts);
+            bool const ml0 = E::maybe(el0, tl), ms0 = E::maybe(es0, ts);
+            u32 const rv = ld32(ip + 1 - off1);
+            u64 const cl = ml0 ? ld64(base + E::pos(el0) - 1) : ~w;
+            u32 const cs = ms0 ? ld32(base + E::pos(es0) - 1) : ~(u32)w;
+            hl1 = ze_hash_w(w1, hBitsL, 8); u32 const hs1 = ze_hash_w(w1, hBitsS, mls);
+            el1 = hashLong[hl1]; u32 const es1 = hashSmall[hs1];
+            u32 const stepN = step + ((ip1 >= nextStep) ? 1u : 0u);
+            const u8* const ip2 = ip1 + stepN;
+            u64 const w2 = (ip2 <= ilimit) ? ld64(ip2) : 0;
+            if ((off1 > 0) & (rv == (u32)(w >> 8))) {
+                mLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+                ip++;
+                ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), 1, mLength);
+                kind = 1; break;
+            }
+            if (ml0 && cl == w) {
+                matchl0 = base + E::pos(el0) - 1;
+                mLength = ze_count(ip + 8, matchl0 + 8, iend) + 8;
+                offset = (u32)(ip - matchl0);
+                while (((ip > anchor) & (matchl0 > base)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
+                kind = 2; break;
+            }
+            if (ms0 && cs == (u32)w) { matchs0 = base + E::pos(es0) - 1; kind = 3; break; }
+            if (ip1 >= nextStep) { step++; nextStep += 256; }
+            ip = ip1; ip1 = ip2;
+            hl0 = hl1; hs0 = hs1; el0 = el1; es0 = es1; w = w1; w1 = w2;
+        } while (ip1 <= ilimit);
+        if (kind == 0) break;
+        if (kind == 3) {
+            mLength = ze_count(ip + 4, matchs0 + 4, iend) + 4;
+            offset = (u32)(ip - matchs0);
+            if ((E::pos(el1) > 1) && E::maybe(el1, ze_tag8(w1)) && (ld64(base + E::pos(el1) - 1) == w1)) {
+                const u8* const matchl1 = base + E::pos(el1) - 1;
+                u32 const l1len = ze_count(ip1 + 8, matchl1 + 8, iend) + 8;
+                if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (u32)(ip - matchl1); matchs0 = matchl1; }
+            }
+            while (((ip > anchor) & (matchs0 > base)) && (ip[-1] == matchs0[-1])) { ip--; matchs0--; mLength++; }
+        }
+        if (kind >= 2) {
+            off2 = off1; off1 = offset;
+            if (step < 4) hashLong[hl1] = E::make((u32)(ip1 - base) + 1, ze_tag8(w1));
+            ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), offset + 3, mLength);
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            {   u32 const ins = curr + 2;
+                u64 const wa = ld64(base + ins), wb = ld64(ip - 2), wc = ld64(ip - 1);
+                hashLong[ze_hash_w(wa, hBitsL, 8)] = E::make(ins + 1, ze_tag8(wa));
+                hashLong[ze_hash_w(wb, hBitsL, 8)] = E::make((u32)(ip - 2 - base) + 1, ze_tag8(wb));
+                hashSmall[ze_hash_w(wa, hBitsS, mls)] = E::make(ins + 1, ze_tag4((u32)wa));
+                hashSmall[ze_hash_w(wc, hBitsS, mls)] = E::make((u32)(ip - 1 - base) + 1, ze_tag4((u32)wc));
+            }
+            while ((ip <= ilimit) && ((off2 > 0) & (ld32(ip) == ld32(ip - off2)))) {
+                u32 const rLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4;
+                u32 const t = off2; off2 = off1; off1 = t;
+                {   u64 const wi = ld64(ip);
+                    hashSmall[ze_hash_w(wi, hBitsS, mls)] = E::make((u32)(ip - base) + 1, ze_tag4((u32)wi));
+                    hashLong[ze_hash_w(wi, hBitsL, 8)] = E::make((u32)(ip - base) + 1, ze_tag8(wi)); }
+                ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+    saved2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+    repOut[0] = off1 ? off1 : saved1; repOut[1] = off2 ? off2 : saved2;
     return (u32)(iend - anchor);
 }
 
@@ -896,13 +1085,17 @@ template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
 
+// `ba` != nullptr: src0[0, srcSize) is ONE BLOCK of a multi-block frame (ze_compress_multi): no frame header or checksum here, the
+// match finder runs over the frame's tables and repcodes, the previous compressed block's Huffman table may be repeated, and the
+// return value is the size of the block with its 3-byte header.
 template <class G, class TIdx>
-ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd, u32 ldsBytes) {
-    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
+ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd, u32 ldsBytes,
+                         const ZEBlockArgs* ba = nullptr) {
+    u32 const tail = (!ba && (flags & ZE_FLAG_CHECKSUM)) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
     // Small frames whose sequences are already found: the source is staged into LDS once, literals are gathered and the
     // block body is assembled there, so the stage's many short dependent steps run at LDS latency, not HBM latency.
     u32 const a16 = ZE_ALIGN16(srcSize);
-    bool const small = pre && srcSize <= ZE_SMALL_MAX && srcSize > 0 && ldsBytes >= ZE_ENTROPY_LDS + 2u * a16 + 1024u + 128u;
+    bool const small = pre && !ba && srcSize <= ZE_SMALL_MAX && srcSize > 0 && ldsBytes >= ZE_ENTROPY_LDS + 2u * a16 + 1024u + 128u;
     u8* const xl = lds + ZE_ENTROPY_LDS;
     const u8* const src = small ? (const u8*)xl : src0;
     u8* const litBuf = small ? xl + a16 + 1024u + 64u : ws + ZE_WS_LIT;   // [staged source, later the block body | 1 KiB slack][literals]
@@ -923,8 +1116,10 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
     GRP_SERIAL(g) {
         sh.err = 0;
         if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
-        else ze_params(sh, level, srcSize);
+        else ze_params(sh, level, ba ? ba->frameSize : srcSize);
         if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
+        if (ba) { sh.hdrSize = 0; if (dstCap < 3u + 2u + 1u) sh.err = ZJ_E_DSTSIZE_TOO_SMALL; }     // zstd_compress.c:4629-4631
+        else {
         // ZSTD_writeFrameHeader (zstd_compress.c:4695-4745): with the content size (the default) a frame <= 128 KiB is single-segment;
         // without it (contentSizeFlag = 0) the window descriptor of the adjusted windowLog takes its place
         bool const noFcs = (flags & ZE_FLAG_NO_FCS) != 0;
@@ -945,6 +1140,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
             u8* const fp = dp + didBytes;
             if (noFcs) {} else if (fcsCode == 0) fp[0] = (u8)srcSize; else if (fcsCode == 1) st16(fp, srcSize - 256); else st32(fp, srcSize);
         }
+        }
     }
     g.sync();
     if (ZJ_UNI(sh.err)) return ZJ_ERR64(ZJ_UNI(sh.err));
@@ -960,7 +1156,15 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
     if (srcSize >= 7) {                                                       // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
         u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
-        if (!pre) {
+        if (!pre && ba) {                                  // one block of a frame: its tables (HBM, cleared by the caller before block 0) and repcodes carry on
+            GRP_SERIAL(g) {
+                ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+                u32 const lastLL = (strategy == 1) ? ze_block_fast_x<ZEEnt32>(o, ba->frameBase, ba->start, ba->start + srcSize, hlog, mls, ba->tables, sh.blkRep, sh.blkNextRep)
+                                                   : ze_block_dfast_x<ZEEnt32>(o, ba->frameBase, ba->start, ba->start + srcSize, hlog, clog, mls, ba->tables, ba->tables + (1u << hlog), sh.blkRep, sh.blkNextRep);
+                sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
+            }
+            zj_mem_order();
+        } else if (!pre) {
             u32 const entries = (1u << hlog) + (strategy == 2 ? (1u << clog) : 0u);
             {   u32* const w = (u32*)lds; u32 const words = (entries * (u32)sizeof(TIdx) + 3) / 4;
                 GRP_FOR(g, i, words) w[i] = 0; }
@@ -1028,7 +1232,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         u32 const strat = strategy;
         {   u32 const n = litSize;
             u32 const lhSize = 3 + (n >= 1024) + (n >= 16384);
-            u32 const hufRep = cd ? ZJ_UNI(sh.dictHufRep) : ZC_REPEAT_NONE;   // the dictionary's Huffman table is "the previous block's"
+            u32 const hufRep = (cd || ba) ? ZJ_UNI(sh.dictHufRep) : ZC_REPEAT_NONE;   // the dictionary's Huffman table is "the previous block's"; in a multi-block frame it IS the previous block's
             bool const single = (n < 256) || (hufRep == ZC_REPEAT_VALID && lhSize == 3);
             bool const preferRepeat = n <= 1024;                              // HUF_flags_preferRepeat (strategy < lazy)
             u32 const seg = (n + 3) / 4;
@@ -1066,6 +1270,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 GRP_SERIAL(g) {                                                // HUF_compress_internal (huf_compress.c:1333-1434), decisions
                     u32 const maxSV = sh.tmp[6], largest = sh.tmp[7];
                     u32 m = 2, h = 0, rep = hufRep;
+                    sh.hufMaxSV = maxSV;
                     bool useOld = false;
                     if (preferRepeat && rep == ZC_REPEAT_VALID) useOld = true;    // valid table + small input: no statistics at all
                     else if (largest == n) m = 1;
@@ -1351,6 +1556,36 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
     }
     zj_mem_order();
     g.sync();
+    if (ba) {
+        // ZSTD_compressBlock_internal's tail (zstd_compress.c:4422-4447) + the block header of ZSTD_compress_frameChunk (:4651-4661):
+        // a block of one repeated byte becomes an RLE block unless it is the frame's first; only a block emitted compressed
+        // confirms its repcodes and its Huffman table for the blocks that follow
+        u32 type = compressed ? 2u : 0u;
+        if (srcSize >= 7 && !ba->isFirst && (compressed ? cSize : 0u) < 25u) {
+            GRP_SERIAL(g) { sh.tmp[0] = 1; }
+            g.sync();
+            u32 const b0 = src0[0];
+            GRP_FOR(g, i, srcSize) { if (src0[i] != b0) sh.tmp[0] = 0; }
+            g.sync();
+            if (ZJ_UNI(sh.tmp[0])) type = 1;
+        }
+        u32 const bodySize = type == 2 ? cSize : (type == 1 ? 1u : srcSize);
+        if (dstCap < 3 + bodySize) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+        if (type == 2) {
+            if (!direct) grp_copy_wide(g, dst + 3, body, cSize);
+            if (ZJ_UNI(sh.litMode) == 2) {                     // a new Huffman table: the next block may repeat it (HUF_repeat_check)
+                u32 const maxSV = ZJ_UNI(sh.hufMaxSV);
+                GRP_FOR(g, s2, 256) sh.dictCodes[s2] = s2 <= maxSV ? ((u32)e.val[s2] | ((u32)e.nbBits[s2] << 16)) : 0u;
+                GRP_SERIAL(g) { sh.dictHufRep = ZC_REPEAT_CHECK; sh.dictHufMaxSV = maxSV; }
+            }
+            GRP_SERIAL(g) { sh.blkRep[0] = sh.blkNextRep[0]; sh.blkRep[1] = sh.blkNextRep[1]; }
+        } else if (type == 1) { GRP_SERIAL(g) { dst[3] = src0[0]; } }
+        else grp_copy_wide(g, dst + 3, src0, srcSize);
+        GRP_SERIAL(g) { u32 const bh = ba->lastBlock + (type << 1) + ((type == 2 ? cSize : srcSize) << 3); dst[0] = (u8)bh; dst[1] = (u8)(bh >> 8); dst[2] = (u8)(bh >> 16); }
+        zj_mem_order();
+        g.sync();
+        return 3 + bodySize;
+    }
     // ---- block header + placement ----
     u32 const bodySize = compressed ? cSize : srcSize;
     if (dstCap < hdr + 3 + bodySize + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
@@ -1390,6 +1625,54 @@ ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 s
                        const ZECDictDev* cd = nullptr, u32 ldsBytes = 0) {
     if (srcSize <= 65536u) return ze_compress_t<G, u16>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd, ldsBytes);
     return ze_compress_t<G, u32>(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, pre, flags, cd, ldsBytes);
+}
+
+#include "zj_presplit.h"
+// ---- multi-block frames: 128 KiB < srcSize <= ZE_MULTI_MAX (ZSTD_compress2 on a larger input: N/compress/zstd_compress.c:4591-4692) ----
+// One wavefront walks the frame block by block — the reference's loop: size of the next block (ZSTD_optimalBlockSize: full blocks
+// until the frame has saved 3 bytes, then the pre-split heuristic of zj_presplit.h), parse over the frame-wide tables, entropy stage
+// with the previous compressed block's Huffman table as repeat candidate, raw / RLE / compressed block header.  Frames are
+// byte-identical to the reference's at levels 1-3 with the level's own parameters.  The frame must fit its window (levels 1 / 2 / 3:
+// 512 KiB / 1 MiB / 2 MiB), so no position ever leaves it; larger inputs are refused (201) and stay on the CPU path.
+// `tables`: (1 << hashLog) + (1 << chainLog) u32 entries in HBM for this workgroup.
+#define ZE_MULTI_MAX (2u << 20)
+#define ZE_MULTI_TABLE_BYTES (((1u << 17) + (1u << 16)) * 4u)
+template <class G>
+ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, u32 flags, u32* tables, u32 ldsBytes) {
+    ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), srcSize);
+    if (srcSize <= ZE_BLOCK_MAX || srcSize > ZE_MULTI_MAX || srcSize > (1u << p.windowLog)) return ZJ_ERR64(201);
+    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
+    bool const noFcs = (flags & ZE_FLAG_NO_FCS) != 0;
+    u32 const hdr = noFcs ? 6u : 9u;                               // magic, descriptor, then the window byte or the 4-byte content size (single segment)
+    if (dstCap < hdr + 3 + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    GRP_SERIAL(g) {
+        st32(dst, 0xFD2FB528u);
+        if (noFcs) { dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((p.windowLog - 10u) << 3); }
+        else { dst[4] = (u8)((1u << 5) + (2u << 6) + (tail ? 4u : 0u)); st32(dst + 5, srcSize); }
+        sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0;
+    }
+    {   u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
+        GRP_FOR(g, i, entries) tables[i] = 0; }
+    zj_mem_order();
+    g.sync();
+    u32 pos = hdr, at = 0, isFirst = 1; i64 savings = 0;
+    while (at < srcSize) {
+        GRP_SERIAL(g) { sh.tmp[0] = zp_block_size(src + at, srcSize - at, p.strategy, savings, (u32*)lds); }
+        g.sync();
+        u32 const blockSize = ZJ_UNI(sh.tmp[0]);
+        g.sync();
+        ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables;
+        u64 const r = ze_compress_t<G, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, ldsBytes, &ba);
+        if (r > ZJ_ERR64(256)) return r;
+        savings += (i64)blockSize - (i64)r;
+        at += blockSize; pos += (u32)r; isFirst = 0;
+    }
+    if (dstCap < pos + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    if (tail) {
+        u64 const h = zj_xxh64(g, src, srcSize);
+        GRP_SERIAL(g) { st32(dst + pos, (u32)h); }
+    }
+    return pos + tail;
 }
 
 // Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.

@@ -142,11 +142,15 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
 // once per list — with 128 KiB of LDS for list B, exiting at once when that list is empty.
 
 __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restrict__ srcOff, u64* __restrict__ result, u32 n, u32 level,
-                                                               u32 ldsA, u32* counters, u32* listA, u32* listB) {
+                                                               u32 ldsA, u32* counters, u32* listA, u32* listB, u32* listC) {
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
-    if (size > ZE_BLOCK_MAX) { result[i] = ZJ_ERR64(201); return; }
+    if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
+        if (listC && size <= ZE_MULTI_MAX && !(ZE_LW_HL(level) | ZE_LW_CL(level))) listC[atomicAdd(&counters[4], 1u)] = i;
+        else result[i] = ZJ_ERR64(201);
+        return;
+    }
     bool const a = (ZE_LW_HL(level) | ZE_LW_CL(level)) ? (size <= 65536u)            // explicit table sizes: lane pipeline only, split by record width
                                                          : (ze_lds_need(ZE_LW_LEVEL(level), (u32)size) <= ldsA);
     if (a) listA[atomicAdd(&counters[0], 1u)] = i;
@@ -396,6 +400,31 @@ __global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ sr
     }
 }
 
+// Multi-block frames (128 KiB < input <= ZE_MULTI_MAX): one wavefront walks a frame block by block (ze_compress_multi); its
+// frame-wide hash tables sit in HBM, one set per resident workgroup.
+__global__ __launch_bounds__(64) void zj_encode_multi_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                              u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                              u8* scratch, u32* tables, u32 flags, u32 ldsBytes) {
+    __shared__ ZEncShared sh;
+    ZjProf pf; pf.start(nullptr);
+    Grp<64> g;
+    if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
+    __syncthreads();
+    u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
+    u32* const tb = tables + (size_t)blockIdx.x * (ZE_MULTI_TABLE_BYTES / 4u);
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 const k = zj_next_index(workCounter);
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
+        u64 const cap = d1 - d0;
+        u64 const r = ze_compress_multi(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, flags, tb, ldsBytes);
+        if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
 // ZSTD_createCDict on the device: one workgroup digests the dictionary held in `out` (header, zeroed tables, raw bytes)
 __global__ __launch_bounds__(64) void zj_cdict_digest_kernel(u32 dictSize, u32 level, ZECDictDev* out) {
     __shared__ ZDecShared sh;
@@ -476,6 +505,7 @@ struct DevState {
     int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
     // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
     u8* wideBuf = nullptr; size_t wideBufCap = 0;     // lane-per-frame path of list B: [tables][frame scratch][meta] for one slice
+    u32* multiTables = nullptr; int multiGrid = 0;    // multi-block frames: frame-wide hash tables, one set per resident workgroup
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
     hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
@@ -642,6 +672,7 @@ void zjni_shutdown(void) {
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
         if (d.wideBuf) (void)hipFree(d.wideBuf);
+        if (d.multiTables) (void)hipFree(d.multiTables);
         if (d.cdBuf) (void)hipFree(d.cdBuf);
         if (d.cdList) (void)hipFree(d.cdList);
         for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
@@ -910,15 +941,24 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (d->encListCap < n) {                      // grows rarely; the only synchronous step of this entry
         if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
         size_t const cap = n + (n >> 2) + 1024;
-        if (hipMalloc(&d->encList, 3 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
+        if (hipMalloc(&d->encList, 4 * cap * sizeof(u32)) != hipSuccess) return ZJNI_ERR(64);
         d->encListCap = cap;
     }
     u32* const ctr = d->counters + 16;            // [0] |A|, [1] |B|, [2] work A, [3] work B
-    u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap; u32* const listS = d->encList + 2 * d->encListCap;
-    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap; u32* const listS = d->encList + 2 * d->encListCap; u32* const listC = d->encList + 3 * d->encListCap;
+    if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);     // [0] |A|, [1] |B|, [2] work A, [3] work B, [4] |C|, [5] work C
     u32 const ldsA = (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
-                       (u32)n, (u32)levelWord, ldsA, ctr, listA, listB);
+                       (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
+    {   // list C: multi-block frames.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 768 KiB per resident workgroup.
+        if (!d->multiTables) {
+            d->multiGrid = d->numCU * 2;
+            if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
+        }
+        u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
+        hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
+                           (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy));
+    }
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
     // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
     size_t splitMin = 4096;
@@ -1186,7 +1226,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
         const u64* const so = (const u64*)d_src_off + at; const u64* const dofs = (const u64*)d_dst_off + at; u64* const res = (u64*)d_result + at;
         if (pending[par]) { if (hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device)); pending[par] = 0; }   // slice s-2 is done with this set
         if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
-        hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, so, res, (u32)m, 1u, 0xFFFFFFFFu, ctr, list, list);   // every frame <= 128 KiB is listed
+        hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((m + 255) / 256)), dim3(256), 0, st, so, res, (u32)m, 1u, 0xFFFFFFFFu, ctr, list, list, (u32*)nullptr);   // every frame <= 128 KiB is listed
         hipLaunchKernelGGL(zj_cdict_zero_tables_kernel, dim3((u32)(m < 16384 ? m : 16384)), dim3(256), 0, st, so, cd, (const u32*)list, (const u32*)ctr, tables);
         u32 const waves = (u32)((m + 63) / 64);
         u32 const gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
