@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — batched zstd compress + decompress on MI355X, BASELINE.json's metric and its named configs.
 
-  python bench.py --gpus N --steps K --warmup W [--config metric|2|3|4|5shape]
+  python bench.py --gpus N --steps K --warmup W [--config metric|1|2|3|4|5shape]
   (N>1: launched by the driver through torch.distributed.run, one rank per GPU)
 
 config (config.workload names it in the JSON line):
   metric  65,536 x 64 KiB mixed-entropy buffers, level 3, compress + decompress      value = both ways      (the default)
+  1       1,024 x 1 MiB slices of Silesia xml (tests/golden/xml-1.zst), level 3, multi-block frames                value = both ways
   2       65,536 frames made by the REFERENCE at its plain level 3 (64 KiB each), decompress, bit-exact   value = decompress
   3       65,536 x 64 KiB, level 1 (ZSTD_fast) compress, frames checked by the reference                   value = compress
   4       2^20 x 4 KiB JSON-like records, one trained ZstdDictCompress, level 3                              value = compress
@@ -46,6 +47,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_M
 
 CONFIGS = {
     "metric": dict(level=3, n=65536, size=65536, mode="both", headline="both", metric="GiB/s compress+decompress (L3, 64Ki x 64KiB)"),
+    "1": dict(level=3, n=1024, size=1 << 20, mode="xml", headline="both",
+              metric="GiB/s compress+decompress of 1 MiB buffers (Silesia xml slices), level 3, multi-block frames (BASELINE config 1's buffer on the GPU)"),
     "2": dict(level=3, n=65536, size=65536, mode="decode_ref", headline="decompress",
               metric="GiB/s batched decompress, 65 536 reference-made level-3 frames of 64 KiB (BASELINE config 2)"),
     "3": dict(level=1, n=65536, size=65536, mode="both", headline="compress", metric="GiB/s batched compress level 1, 65 536 x 64 KiB (BASELINE config 3)"),
@@ -214,6 +217,17 @@ def main():
         train = zj.synth_host(size, (1 << 24), 40000)
         dict_bytes = ref.train_dict([train[i * size:(i + 1) * size] for i in range(1, 40000, 4)], 112640)   # 110 KiB from 10 000 records
         cdict = zj.ZstdDictCompress(dict_bytes, level); ddict = zj.ZstdDictDecompress(dict_bytes)
+    elif mode == "xml":                           # BASELINE config 1's buffer: 1 MiB of text-like data ('dickens' is not in the reference; its xml fixture is)
+        from oracle import ref
+        with open(os.path.join(ROOT, "tests", "golden", "xml-1.zst"), "rb") as f:
+            xml = np.frombuffer(ref.decompress(f.read(), 6_000_000), dtype=np.uint8)
+        span = xml.size - size
+        src = torch.empty(n * size, dtype=torch.uint8, device=dev)
+        hx = torch.from_numpy(xml.copy()).to(dev)
+        for i in range(n):
+            o = ((first + i) * 4099) % span
+            src[i * size:(i + 1) * size] = hx[o:o + size]
+        del hx
     else:
         src = B.synth(n, size, first, dev)
     src_off = B.uniform_offsets(n, size, dev)
@@ -294,7 +308,7 @@ def main():
     if rank == 0 and not a.skip_cpu:
         from oracle import port, ref
         assert ref.available(), "oracle/_ref/libzstd_ref.so missing: run __graft_entry__.build() where /root/reference exists"
-        k = min(a.verify_sample, n)
+        k = min(a.verify_sample, n, max(8, (64 << 20) // size))
         sizes = csz[:k].cpu().tolist()
         host_k = src[:k * size].cpu().numpy().tobytes()
         if mode != "decode_ref":
@@ -320,9 +334,9 @@ def main():
                 want = [rc.compress(host_k[i * size:(i + 1) * size]) for i in range(k)]
                 rc.close()
             else:
-                want = [ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) if level == 3 else ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]
+                want = [ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) if (level == 3 and size <= 131072) else ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]
             gates["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + max(sizes[i], 0)].tobytes() == want[i] for i in range(k))
-            if level == 3 and not dict_bytes:
+            if level == 3 and not dict_bytes and size <= 131072:
                 c2 = torch.empty(k * bound, dtype=torch.uint8, device="cuda")
                 s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=16, chain_log=15)
                 torch.cuda.synchronize()
@@ -359,10 +373,12 @@ def main():
         # kernels of the two paths with their own HIP-event durations (ms); "compress_rest" = classify + table memset +
         # entropy kernel (it runs beside the match kernel on a side stream) + sweep, i.e. compress call minus match kernel
         match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else "zj_enc_match_kernel")
+        if size > 131072:
+            match_name = "zj_encode_multi_kernel"
         kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
                    "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}
         if mode != "decode_ref":
-            kernels[match_name] = stage.get("match_wide" if size > 65536 else "match", -1.0); kernels["zj_pack_kernel"] = mp
+            kernels[match_name] = mc if size > 131072 else stage.get("match_wide" if size > 65536 else "match", -1.0); kernels["zj_pack_kernel"] = mp
             if kernels[match_name] > 0 and mode != "dict" and size <= 65536:
                 kernels["compress_rest(entropy beside match, memset, sweep)"] = mc - kernels[match_name]
         slices = 1
@@ -399,8 +415,8 @@ def main():
         out = {
             "metric": cfg["metric"], "value": value, "unit": "GiB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{n} x {size} B {'JSON-like records' if mode == 'dict' else 'mixed-entropy buffers'} per GPU, zstd level {level}, one frame per buffer"
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if mode != "xml" else "Silesia xml (the reference's test fixture), overlapping 1 MiB slices",
+            "config": {"workload": f"{n} x {size} B {'JSON-like records' if mode == 'dict' else ('slices of Silesia xml' if mode == 'xml' else 'mixed-entropy buffers')} per GPU, zstd level {level}, one frame per buffer"
                                    + (", one shared 110 KiB trained dictionary (ZstdDictCompress / ZstdDictDecompress)" if mode == "dict" else "")
                                    + (", frames made by the reference at its plain level (hashLog 16 / chainLog 15), GPU decompress only" if mode == "decode_ref" else ""),
                        "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",

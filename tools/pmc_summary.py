@@ -1,32 +1,39 @@
-"""Condense rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gpurun_out/pmc2/l<level>_<counter>/, one pass per counter,
-driver = tools/prof_driver.py 65536 65536 <level> 1) into profiles/r01_pmc_traffic.json, which bench.py reads for
-roofline.traffic.  Counter units are KB; calibration of what one request tallies: tools/micro/chase cal."""
-import collections, csv, glob, json, os, sys
+"""Condense rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/measure_round.sh: gpurun_out/<tag>/pmc/<config>_L<level>_<n>x<size>_<COUNTER>.csv,
+one counter per pass, driver = tools/prof_driver.py <n> <size> <level> 1) into profiles/<round>_pmc_traffic.json, which bench.py reads for
+roofline.traffic, stamped with the commit the passes ran on.  Counter units are KB; what one request tallies: tools/micro/chase cal.
+usage: pmc_summary.py <gpurun_out/tag> <round, e.g. r02>   (copies the csvs to profiles/<round>_pmc/ too)"""
+import collections, csv, datetime, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc2")
-n, size = 65536, 65536
+src = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "zstd-jni_amd/csrc"], text=True).strip())
 out = {"note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
                "(TCC_EA0_RDREQ/WRREQ based). Calibrated on this kernel's access pattern with tools/micro/chase: one random "
                "4-byte read miss tallies 63.7 B, one random 4-byte write tallies 32 B; the x2 correction the guide gives "
                "for wide streaming reads does not apply to these scattered 4-8 byte accesses, so values are uncorrected.",
-       "calibration": {"random_4B_reads_per_launch": 131072000, "FETCH_SIZE_KB": 8149800.7, "WRITE_SIZE_KB_readwrite_launch": 4103834.5}}
-for level in (1, 3):
+       "calibration": {"random_4B_reads_per_launch": 131072000, "FETCH_SIZE_KB": 8149800.7, "WRITE_SIZE_KB_readwrite_launch": 4103834.5},
+       "measured_on_commit": head + ("+uncommitted csrc changes" if dirty else ""), "measured_on_date": datetime.date.today().isoformat(),
+       "driver": "tools/measure_round.sh -> tools/prof_driver.py <n> <size> <level> 1"}
+dst = os.path.join(ROOT, "profiles", rnd + "_pmc"); os.makedirs(dst, exist_ok=True)
+keys = sorted({re.sub(r"_(FETCH|WRITE)_SIZE\.csv$", "", os.path.basename(p)) for p in glob.glob(os.path.join(src, "pmc", "*_SIZE.csv"))})
+for key in keys:
     rec = collections.defaultdict(lambda: {"fetch": [], "write": []})
-    for cn, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        f = glob.glob(os.path.join(src, f"l{level}_{cn}", "**", "*counter_collection.csv"), recursive=True)
-        if not f:
+    for cn, k in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        p = os.path.join(src, "pmc", f"{key}_{cn}.csv")
+        if not os.path.exists(p):
             continue
-        for r in csv.DictReader(open(f[0])):
+        shutil.copy(p, dst)
+        for r in csv.DictReader(open(p)):
             name = r["Kernel_Name"].split("(")[0]
             if name.startswith("zj_"):
-                rec[name][key].append(float(r["Counter_Value"]) * 1024.0)
+                rec[name][k].append(float(r["Counter_Value"]) * 1024.0)
     summ = {}
     for name, v in rec.items():
-        # kernels launched several times per call (list A / list B / sweep): keep the per-call sum of the largest launches
+        # the driver runs 2 calls (1 warm-up + 1); kernels launched several times per call (lists A / B / S): the largest launch
         fetch = max(v["fetch"]) if v["fetch"] else 0.0
         write = max(v["write"]) if v["write"] else 0.0
         summ[name] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
-    out[f"L{level}_{n}x{size}"] = summ
-with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w") as f:
+    out[key] = summ
+with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
-print(json.dumps({k: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 2) for kk, vv in v.items()} for k, v in out.items() if k.startswith("L")}, indent=1))
+print(json.dumps({k: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 2) for kk, vv in v.items()} for k, v in out.items() if isinstance(v, dict) and k not in ("calibration",)}, indent=1))
