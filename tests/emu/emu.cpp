@@ -20,12 +20,12 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
-    u32* tab = (u32*)calloc(ZD_SPLIT_CELLS, 4); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
+    u16* tab = (u16*)calloc(ZD_SPLIT_CELLS, 2); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
     ZjProf pf; pf.start(nullptr);
     u64 r = ~(u64)0;
     if (usedSplit) *usedSplit = 0;
     if (zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta)) {
-        ZDSeqLane m; m.llBase = zd_k_ll_base; m.mlBase = zd_k_ml_base; m.init(src, tab, seqs, &meta);
+        u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1); ZDSeqLane m; m.llBase = symL; m.mlBase = symM; m.init(src, tab, seqs, &meta);
         while (m.st != 2) m.round();
         r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf);
         if (usedSplit && r != ~(u64)0) *usedSplit = 1;
@@ -41,7 +41,7 @@ extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
-    u32* tab = (u32*)calloc(ZD_SPLIT_CELLS, 4); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
+    u16* tab = (u16*)calloc(ZD_SPLIT_CELLS, 2); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
     ZDDictDev* dd = (ZDDictDev*)calloc(1, sizeof(ZDDictDev));
     ZjProf pf; pf.start(nullptr);
     u64 r = ~(u64)0;
@@ -51,7 +51,7 @@ extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src
     else {
         memset(sh, 0, sizeof(*sh));
         if (zd_prep_frame<true>(g, *sh, src, srcSize, dstCap, tab, &meta, dd)) {
-            ZDSeqLane m; m.llBase = zd_k_ll_base; m.mlBase = zd_k_ml_base; m.init(src, tab, seqs, &meta, dd);
+            u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1); ZDSeqLane m; m.llBase = symL; m.mlBase = symM; m.init(src, tab, seqs, &meta, dd);
             while (m.st != 2) m.round();
             r = zd_exec_frame<true>(g, *sh, src, dst, &meta, seqs, lit, pf, dd, dict);
             if (usedSplit && r != ~(u64)0) *usedSplit = 1;

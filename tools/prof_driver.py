@@ -5,7 +5,9 @@ import ctypes as C, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as e
-zj = e.load_package(); L = zj.lib()
+zj = e.load_package()
+if os.environ.get('ZJNI_LIB'): zj.LIB_PATH = os.environ['ZJNI_LIB']      # an experimental build of the library
+L = zj.lib()
 hip = C.CDLL("libamdhip64.so")
 vp = C.c_void_p
 def chk(r): assert r == 0, r
@@ -49,5 +51,7 @@ for it in range(steps + 1):
     chk(hip.hipEventElapsedTime(C.byref(ms), ev[2], ev[3])); d_ms = ms.value
     if it > 0: tp += p_ms; td += d_ms
 h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp), dsz, C.c_size_t(n * 8), 2))
-print(json.dumps({"n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+t8 = (C.c_float * 8)(); L.zjni_last_timing2(t8)
+stages = dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused", "match_wide"), [round(float(x), 3) for x in t8][:6]))
+print(json.dumps({"stages_ms": stages, "n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
                   "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))

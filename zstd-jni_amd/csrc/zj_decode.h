@@ -33,6 +33,8 @@
 #define ZD_CELL_NB(c) (((c) >> 16) & 0xFu)
 #define ZD_CELL_SYM(c) (((c) >> 20) & 0x3Fu)
 #define ZD_CELL_EXTRA(c) (((c) >> 26) & 0x1Fu)
+// the split pipeline's 2-byte form of a cell (zj_decode_split.h): symbol | tANS counter << 6, counter = (next + tableSize) >> nbBits
+ZJ_DEV u16 zd_cell16(u32 c4, u32 log) { return (u16)(ZD_CELL_SYM(c4) | (((ZD_CELL_NEXT(c4) + (1u << log)) >> ZD_CELL_NB(c4)) << 6)); }
 
 struct ZDecShared {
     u16 huf[1u << ZD_HUF_LOG_MAX];
@@ -690,8 +692,9 @@ struct ZDDictDev {
     u32 rep[3];
     u32 hufLog, llLog, ofLog, mlLog;
     u16 huf[1u << ZD_HUF_LOG_MAX];
-    u32 ll[512], of[256], ml[512];  // in the cell-table order of the split pipeline (ZD_SPLIT_OF / ZD_SPLIT_ML): a frame whose three
-                                    // tables are all "repeat" decodes straight from here
+    u32 ll[512], of[256], ml[512];
+    u16 c16[1280];                  // the same three tables as the split pipeline's 2-byte cells (LL | OF at 512 | ML at 768; zd_cell16): a frame whose
+                                    // three tables are all "repeat" decodes straight from here
 };
 // Runs on one workgroup; `sh` is scratch.  Raw-content dictionaries (no magic) have no entropy section.
 template <class G>
@@ -731,6 +734,10 @@ ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dict
     GRP_FOR(g, i, 1u << ZD_HUF_LOG_MAX) out->huf[i] = sh.huf[i];
     GRP_FOR(g, i, 512) { out->ll[i] = sh.ll[i]; out->ml[i] = sh.ml[i]; }
     GRP_FOR(g, i, 256) out->of[i] = sh.of[i];
+    if (ZJ_UNI(sh.blkType) && !ZJ_UNI(sh.err)) {
+        GRP_FOR(g, i, 512) { out->c16[i] = (u16)(i < (1u << sh.llLog) ? zd_cell16(sh.ll[i], sh.llLog) : 0u); out->c16[768u + i] = (u16)(i < (1u << sh.mlLog) ? zd_cell16(sh.ml[i], sh.mlLog) : 0u); }
+        GRP_FOR(g, i, 256) out->c16[512u + i] = (u16)(i < (1u << sh.ofLog) ? zd_cell16(sh.of[i], sh.ofLog) : 0u);
+    }
     GRP_SERIAL(g) {
         out->status = sh.err; out->dictID = sh.windowSize; out->contentOff = sh.hdrSize; out->contentSize = dictSize - sh.hdrSize;
         out->hasEntropy = sh.blkType; out->rep[0] = sh.rep[0]; out->rep[1] = sh.rep[1]; out->rep[2] = sh.rep[2];

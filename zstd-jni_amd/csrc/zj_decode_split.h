@@ -26,13 +26,15 @@
 #define ZD_SPLIT_CELLS 1280u                                  // LL 512 | OF 256 | ML 512
 #define ZD_SPLIT_OF 512u
 #define ZD_SPLIT_ML 768u
-#define ZD_SPLIT_TAB_BYTES (ZD_SPLIT_CELLS * 4u)
+#define ZD_SPLIT_TAB_BYTES (ZD_SPLIT_CELLS * 2u)
 #define ZD_SPLIT_SEQ_BYTES (ZD_SPLIT_MAXSEQ * 8u)
 
-// Decode cells go to HBM in the 4-byte form the fused kernel keeps in LDS (ZD_CELL: next | nbBits | symbol |
-// extraBits; the reference's ZSTD_seqSymbol minus baseValue, N/decompress/zstd_decompress_internal.h:68-73):
-// 5 KiB per frame instead of 10 keeps more of the tables in L2/Infinity Cache under the lane-per-frame decode;
-// baseValue comes from the symbol through two small LDS tables.
+// Decode cells go to HBM as 2 bytes: symbol (6 bits) | the tANS "nextState" counter of the table build (10 bits, < 2 * tableSize).
+// The reference's cell (ZSTD_seqSymbol, N/decompress/zstd_decompress_internal.h:68-73) follows from it: nbBits = tableLog -
+// highbit(counter), nextState base = (counter << nbBits) - tableSize (N/decompress/zstd_decompress_block.c:540-556), and
+// baseValue / nbAdditionalBits are functions of the symbol (two small LDS tables).  2.5 KiB per frame instead of 10: the
+// lane-per-frame decode reads three random cells per sequence, and what bounds it is how many of those reads leave the L2 /
+// Infinity Cache (profiles/r02*), i.e. the bytes of table alive per lane.
 // decoded sequence record: ll | ml << 18 | offset << 36 (ll, ml <= 2^17 for content <= 128 KiB; the offset field has 28 bits)
 ZJ_DEV u64 zd_seq_pack(u32 ll, u32 ml, u32 off) { return (u64)ll | ((u64)ml << 18) | ((u64)off << 36); }
 
@@ -51,7 +53,7 @@ struct ZDMeta {
 // ---------------------------------------------------------------------------------------------
 // Stage 1.  Returns true (wave-uniform) when the frame is simple and its tables/record were written.
 template <bool DICT = false, class G>
-ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u32* tab, ZDMeta* meta, const ZDDictDev* ddArg = nullptr) {
+ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u32 dstCap, u16* tab, ZDMeta* meta, const ZDDictDev* ddArg = nullptr) {
     const ZDDictDev* const dd = DICT ? ddArg : nullptr;
     bool const dictEntropy = DICT && dd && dd->hasEntropy;      // the frame may start in repeat / treeless modes
     GRP_SERIAL(g) {
@@ -110,9 +112,9 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     bool const allRepeat = dictEntropy && nbSeq && ZJ_UNI(sh.tblMode[0]) == 3 && ZJ_UNI(sh.tblMode[1]) == 3 && ZJ_UNI(sh.tblMode[2]) == 3;
     if (nbSeq && !allRepeat) {
         u32 const llLog = ZJ_UNI(sh.llLog), ofLog = ZJ_UNI(sh.ofLog), mlLog = ZJ_UNI(sh.mlLog);
-        GRP_FOR(g, u, 1u << llLog) tab[u] = sh.ll[u];
-        GRP_FOR(g, u, 1u << ofLog) tab[ZD_SPLIT_OF + u] = sh.of[u];
-        GRP_FOR(g, u, 1u << mlLog) tab[ZD_SPLIT_ML + u] = sh.ml[u];
+        GRP_FOR(g, u, 1u << llLog) tab[u] = zd_cell16(sh.ll[u], llLog);
+        GRP_FOR(g, u, 1u << ofLog) tab[ZD_SPLIT_OF + u] = zd_cell16(sh.of[u], ofLog);
+        GRP_FOR(g, u, 1u << mlLog) tab[ZD_SPLIT_ML + u] = zd_cell16(sh.ml[u], mlLog);
     }
     GRP_SERIAL(g) {
         ZDMeta m;
@@ -129,21 +131,30 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
 // ---------------------------------------------------------------------------------------------
 // Stage 2.  One lane per frame; round() is one memory round trip for every lane of the wave.
 // Bit positions are relative to the frame buffer.  N/decompress/zstd_decompress_block.c:1229-1347, :1615-1690.
+// the two per-symbol tables of stage 2: baseValue | nbAdditionalBits << 24 (LL: 36 entries, ML: 53)
+ZJ_DEV void zd_seq_symtabs(u32* ll, u32* ml, u32 first, u32 stride) {
+    for (u32 i = first; i < 36u; i += stride) ll[i] = zd_k_ll_base[i] | ((u32)zd_k_ll_bits[i] << 24);
+    for (u32 i = first; i < 53u; i += stride) ml[i] = zd_k_ml_base[i] | ((u32)zd_k_ml_bits[i] << 24);
+}
 struct ZDSeqLane {
-    const u8* src; const u32* tab; u64* seqs; ZDMeta* meta; const u32* llBase; const u32* mlBase;   // bases: LDS tables of the kernel
+    const u8* src; const u16* tab; u64* seqs; ZDMeta* meta; const u32* llBase; const u32* mlBase;   // LDS tables of the kernel: baseValue | nbAdditionalBits << 24 per symbol (zd_seq_symtabs)
     i32 A, S0; u32 sLL, sOF, sML, rep0, rep1, rep2, i, nbSeq, opos, lpos, litSize, cap, logs, endByte;
     u32 st;                       // 0 start, 1 running, 2 done
     u32 bad, dictSize;
+    // what the previous round fetched for this one: the three cells of the current states and the 16 bitstream bytes [eAt-16, eAt)
+    u64 fLo, fHi; u16 fCl, fCo, fCm; u32 eAt;    // (cells kept 2 bytes wide: widening them here would put a wait for the loads at the end of the round)
+    u64 pend; bool havePend;      // the previous sequence's record: stored at the top of the next round, ahead of that round's loads
 
-    ZJ_DEV_MEMBER void init(const u8* s, const u32* t, u64* q, ZDMeta* m, const ZDDictDev* dd = nullptr) {
+    ZJ_DEV_MEMBER void init(const u8* s, const u16* t, u64* q, ZDMeta* m, const ZDDictDev* dd = nullptr) {
         src = s; tab = t; seqs = q; meta = m;
         ZDMeta const h = *m;
-        if (dd && h.dictTables) tab = dd->ll;
+        if (dd && h.dictTables) tab = dd->c16;
         nbSeq = h.nbSeq; litSize = h.litSize; logs = h.logs;
         cap = zj_min(h.contentSize, h.blockSizeMax);
         S0 = (i32)((h.blockOff + h.seqOff) * 8u); endByte = h.blockOff + h.blockSize; A = S0;
         rep0 = 1; rep1 = 4; rep2 = 8; i = 0; opos = 0; lpos = 0; bad = 0; sLL = sOF = sML = 0; dictSize = 0;
         if (dd) { dictSize = dd->contentSize; if (dd->hasEntropy) { rep0 = dd->rep[0]; rep1 = dd->rep[1]; rep2 = dd->rep[2]; } }
+        havePend = false; fLo = fHi = 0; fCl = fCo = fCm = 0; eAt = 0;
         st = nbSeq ? 0u : 2u;
     }
     ZJ_DEV_MEMBER void finish() {
@@ -157,20 +168,29 @@ struct ZDSeqLane {
         if (s < 64u) return (hi << s) | (lo >> (64u - s));
         return s == 64u ? lo : (lo << (s - 64u));
     }
-    ZJ_DEV_MEMBER void round() {
-        // ---- addresses ----
-        u32 const e = (st == 0) ? endByte : (((u32)A + 7u) >> 3);
-        u32 const wp = e >= 16u ? e - 16u : 0u;
-        u32 const iLL = sLL, iOF = ZD_SPLIT_OF + sOF, iML = ZD_SPLIT_ML + sML;
-        // ---- one batch of loads ----
-        u64 lo = ld64(src + wp), hi = ld64(src + wp + 8);
-        u32 const cl = tab[iLL], co = tab[iOF], cm = tab[iML];
-        ZD_ROUND_FENCE5(lo, hi, cl, co, cm);
-        if (e < 16u) {                               // stream within 16 bytes of the buffer start: align [e-16, e) by hand
-            u32 const k = (16u - e) * 8u;            // shift left by k bits (8..120)
+    // issue the loads the NEXT round consumes (current states, bit position A); nothing waits for them here
+    ZJ_DEV_MEMBER void fetch() {
+        u32 const e = ((u32)A + 7u) >> 3, wp = e >= 16u ? e - 16u : 0u;
+        eAt = e;
+        fLo = ld64(src + wp); fHi = ld64(src + wp + 8);
+        fCl = tab[sLL]; fCo = tab[ZD_SPLIT_OF + sOF]; fCm = tab[ZD_SPLIT_ML + sML];
+    }
+    ZJ_DEVM void align16(u64& hi, u64& lo, u32 e) {       // stream within 16 bytes of the buffer start: align [e-16, e) by hand
+        if (e < 16u) {
+            u32 const k = (16u - e) * 8u;                // shift left by k bits (8..120)
             if (k < 64u) { hi = (hi << k) | (lo >> (64u - k)); lo <<= k; } else { hi = k == 64u ? lo : (lo << (k - 64u)); lo = 0; }
         }
+    }
+    // One round = one sequence.  The round is a dependent chain — this sequence's cells and bits give the next states and bit
+    // position, which address the next cells and bits — and a wave runs alone on its SIMD, so the chain's length is the kernel's
+    // time.  The round therefore does only what the next addresses need (bit counts, state update), issues the next round's
+    // loads, and computes the sequence itself (values, repcode history, ZSTD_execSequence's checks, the record) while they fly.
+    ZJ_DEV_MEMBER void round() {
         if (st == 0) {
+            u32 const e = endByte, wp = e >= 16u ? e - 16u : 0u;
+            u64 lo = ld64(src + wp), hi = ld64(src + wp + 8);
+            ZD_ROUND_FENCE5(lo, hi, e, e, e);
+            align16(hi, lo, e);
             // last byte carries the end mark; then the three initial states LL, OF, ML (:1640-1642)
             u32 const lastByte = (u32)(hi >> 56);
             if (lastByte == 0 || (u32)S0 >= 8u * endByte) { bad = 1; finish(); return; }
@@ -183,27 +203,42 @@ struct ZDSeqLane {
             sML = c ? (u32)(v >> (64u - c)) : 0u;
             A -= (i32)(a + b + c);
             st = 1;
+            fetch();
             return;
         }
         if (st != 1) return;
-        u32 const ofx = ZD_CELL_EXTRA(co), mlx = ZD_CELL_EXTRA(cm), llx = ZD_CELL_EXTRA(cl);
+        u64 lo = fLo, hi = fHi; u32 const e = eAt;
+        ZD_ROUND_FENCE5(lo, hi, fCl, fCo, fCm);
+        u32 const cl = fCl, co = fCo, cm = fCm;
+        align16(hi, lo, e);
+        // ---- what the next round's addresses depend on ----
+        u32 const La = logs & 0xFF, Lb = (logs >> 8) & 0xFF, Lc = (logs >> 16) & 0xFF;
+        u32 const syl = cl & 63u, syo = co & 63u, sym = cm & 63u, nsl = cl >> 6, nso = co >> 6, nsm = cm >> 6;
+        u32 const bbl = llBase[syl], bbm = mlBase[sym];
+        u32 const ofx = syo, mlx = bbm >> 24, llx = bbl >> 24;
         bool const last = (i + 1u == nbSeq);
-        u32 const nl = last ? 0u : ZD_CELL_NB(cl), nm = last ? 0u : ZD_CELL_NB(cm), no = last ? 0u : ZD_CELL_NB(co);
-        u32 const llb = llBase[ZD_CELL_SYM(cl)], mlb = mlBase[ZD_CELL_SYM(cm)];
-        u32 const ofb = ofx > 1u ? (1u << ofx) - 3u : ofx;                // OF_base of code ofx
+        u32 const nbl = La - zj_hibit(nsl), nbm = Lc - zj_hibit(nsm), nbo = Lb - zj_hibit(nso);       // the cells' nbBits
+        u32 const nl = last ? 0u : nbl, nm = last ? 0u : nbm, no = last ? 0u : nbo;
         u32 const T1 = ofx + mlx + llx, T = T1 + nl + nm + no;
         if (A - (i32)T < S0) { bad = 1; finish(); return; }
 #define ZD_TAKE(v, nb) ((u32)(((v) >> 1) >> (63u - (nb))))
-        u64 v = top64(hi, lo, e, (u32)A);
-        u32 const ofv = ZD_TAKE(v, ofx); v <<= ofx;
-        u32 const mlv = ZD_TAKE(v, mlx); v <<= mlx;
-        u32 const llv = ZD_TAKE(v, llx);
-        u64 v2 = top64(hi, lo, e, (u32)A - T1);
+        u32 const A0 = (u32)A;
+        u64 v2 = top64(hi, lo, e, A0 - T1);
         u32 const vl = ZD_TAKE(v2, nl); v2 <<= nl;
         u32 const vm = ZD_TAKE(v2, nm); v2 <<= nm;
         u32 const vo = ZD_TAKE(v2, no);
-#undef ZD_TAKE
         A -= (i32)T;
+        if (havePend) { seqs[i - 1u] = pend; havePend = false; }      // ahead of the loads: the next round's wait does not include this store's round trip
+        if (!last) { sLL = (nsl << nbl) - (1u << La) + vl; sML = (nsm << nbm) - (1u << Lc) + vm; sOF = (nso << nbo) - (1u << Lb) + vo; }
+        fetch();                                                         // (after the last sequence too: same cells, a valid bit position — no second code path)
+        // ---- the sequence itself ----
+        u32 const llb = bbl & 0xFFFFFFu, mlb = bbm & 0xFFFFFFu;
+        u32 const ofb = ofx > 1u ? (1u << ofx) - 3u : ofx;                // OF_base of code ofx
+        u64 v = top64(hi, lo, e, A0);
+        u32 const ofv = ZD_TAKE(v, ofx); v <<= ofx;
+        u32 const mlv = ZD_TAKE(v, mlx); v <<= mlx;
+        u32 const llv = ZD_TAKE(v, llx);
+#undef ZD_TAKE
         u32 const llen = llb + llv, mlen = mlb + mlv;
         u32 offset;
         if (ofx > 1u) { offset = ofb + ofv; rep2 = rep1; rep1 = rep0; rep0 = offset; }
@@ -218,12 +253,12 @@ struct ZDSeqLane {
                 rep1 = rep0; rep0 = t; offset = t;
             }
         }
-        if (!last) { sLL = ZD_CELL_NEXT(cl) + vl; sML = ZD_CELL_NEXT(cm) + vm; sOF = ZD_CELL_NEXT(co) + vo; }
         // the checks of ZSTD_execSequence (:1001-1096): literals available, room in the block, offset inside the output
         if (llen > litSize - lpos || (u64)opos + llen + mlen > cap || offset > opos + llen + dictSize) { bad = 1; finish(); return; }
-        seqs[i] = zd_seq_pack(llen, mlen, offset);
+        u64 const rec = zd_seq_pack(llen, mlen, offset);
         lpos += llen; opos += llen + mlen; i++;
-        if (i == nbSeq) { if (A != S0) bad = 1; finish(); }
+        if (i == nbSeq) { seqs[i - 1u] = rec; if (A != S0) bad = 1; finish(); }
+        else { pend = rec; havePend = true; }
     }
 };
 

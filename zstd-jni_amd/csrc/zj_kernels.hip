@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
 template <bool DICT>
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
-                                                          u32 n, u32* counter, u32* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
+                                                          u32 n, u32* counter, u16* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
                                                           const ZDDictDev* dd) {
     __shared__ ZDecShared sh;
     Grp<64> g;
@@ -93,21 +93,32 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
     }
 }
 
+// append k to a completion queue (the producer's records are visible before the entry): match kernel -> entropy kernel, sequence decode -> execution
+__device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
+    if (!doneList) return;
+    __threadfence();                                       // records + meta visible before the queue entry
+    u32 const slot = atomicAdd(doneCount, 1u);
+    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
-                                                         const u32* countPtr, u32* workCounter, const u32* tabs, u64* seqs, ZDMeta* metas,
-                                                         const ZDDictDev* dd) {
+                                                         const u32* countPtr, u32* workCounter, const u16* tabs, u64* seqs, ZDMeta* metas,
+                                                         const ZDDictDev* dd, u32* doneList, u32* doneCount) {
     __shared__ u32 llBase[36], mlBase[53];
-    if (threadIdx.x < 36) llBase[threadIdx.x] = zd_k_ll_base[threadIdx.x];
-    if (threadIdx.x < 53) mlBase[threadIdx.x] = zd_k_ml_base[threadIdx.x];
+    zd_seq_symtabs(llBase, mlBase, threadIdx.x, 64u);
     __syncthreads();
+    if (doneList) __builtin_amdgcn_s_setprio(3);            // the chain of rounds is the critical path; the execution kernel's waves beside it fill the gaps
     u32 const count = *countPtr;
     ZDSeqLane m; m.st = 2; m.llBase = llBase; m.mlBase = mlBase;
+    u32 cur = 0xFFFFFFFFu;                                   // the frame this lane is decoding
     for (;;) {
         if (m.st == 2) {
+            if (cur != 0xFFFFFFFFu) { zj_publish_done(doneList, doneCount, cur); cur = 0xFFFFFFFFu; }   // the execution kernel runs beside this one and takes frames as they finish
             u32 const k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
             u32 const i = list[k];
             m.init(src + srcOff[i], tabs + (size_t)i * ZD_SPLIT_CELLS, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, metas + i, dd);
+            cur = i;
             continue;
         }
         m.round();
@@ -118,7 +129,10 @@ template <bool DICT>
 __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
                                                           const u32* countPtr, u32* workCounter, const ZDMeta* metas, const u64* seqs, u8* scratch,
-                                                          u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw) {
+                                                          u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw,
+                                                          u32 mode, const u32* doneList, u32* procFlag) {
+    // mode 0: list entry k.  mode 1: the k-th frame the sequence-decode kernel finishes while this kernel runs beside it (bounded
+    // wait; a workgroup that gives up leaves the rest to the mode-2 pass).  mode 2: list entries mode 1 did not get to.
     ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
     ZjProf pf; pf.start(prof);
     Grp<64> g;
@@ -127,10 +141,28 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
     for (;;) {
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
-        u32 const i = ZJ_UNI(list[k]);
+        u32 i;
+        if (mode == 1) {
+            u32 v = 0xFFFFFFFFu;
+            if (threadIdx.x == 0) {
+                u64 const t0 = wall_clock64();            // 100 MHz
+                for (;;) {
+                    v = __hip_atomic_load(&doneList[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // relaxed poll, fence below (see zj_encode_kernel)
+                    if (v != 0xFFFFFFFFu || wall_clock64() - t0 > 200000000ull) break;     // 2 s
+                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                }
+            }
+            v = (u32)__builtin_amdgcn_readfirstlane((int)v);
+            if (v == 0xFFFFFFFFu) break;
+            __threadfence();
+            i = v;
+        } else {
+            i = ZJ_UNI(list[k]);
+            if (mode == 2 && ZJ_UNI(procFlag[i])) continue;
+        }
         u64 const r = zd_exec_frame<DICT>(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf, dd, dictRaw);
         pf.mark(8);
-        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; }
+        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; if (mode == 1) procFlag[i] = 1u; }
         __syncthreads();
     }
 }
@@ -165,13 +197,6 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
 // Completion queue between the match kernel and the entropy kernel running beside it: a lane that has
 // finished frame k (records and meta written) appends k; entropy workgroups consume the queue in order, so
 // the cheap frames are entropy-coded while the expensive ones are still being parsed.
-__device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
-    if (!doneList) return;
-    __threadfence();                                       // records + meta visible before the queue entry
-    u32 const slot = atomicAdd(doneCount, 1u);
-    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Work queue over a list sorted by search density (zj_enc_score_kernel), cut at `split` (the first entry whose score reaches
 // the threshold).  Entries [split, count) are the wave-per-frame kernel's alone (a lane would sit on such a frame for ~70 000
 // rounds); it takes them from the back with its own counter.  Entries [0, split) are a two-ended queue: the lane-per-frame
@@ -573,6 +598,11 @@ DevState* get_state(int ordinal) {
         d.matchGrid = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_seq_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
         d.dseqGrid = d.numCU * perCU;
+        // Resident waves of the sequence decode.  A lane takes its next frame from a counter, so fewer waves than frames / 64 only means
+        // more frames per lane; with the execution kernel beside it the pipeline's time is flat from 1 to 2 waves per CU (24.7-25.3 ms per
+        // 65 536 x 64 KiB) and the decode cells alive at a time (2.5 KiB per lane) shrink with the wave count: 1.5 waves per CU.
+        if (d.dseqGrid > d.numCU * 3 / 2) d.dseqGrid = d.numCU * 3 / 2;
+        if (const char* ov = getenv("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqGrid = v; }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
@@ -817,18 +847,21 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
     if (const char* ov = getenv("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (n >= splitMin) {
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
-        size_t const need = tabBytes + seqBytes + metaBytes + 2 * listBytes + 256;
+        size_t const need = tabBytes + seqBytes + metaBytes + 4 * listBytes + 256;
         if (d->dsplitBufCap < need) {
             if (!scratch_make_room(d, d->dsplitBufCap, need)) return ZJNI_ERR(64);
             if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
             if (hipMalloc(&d->dsplitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->dsplitBufCap = need;
         }
-        u32* const tabs = (u32*)d->dsplitBuf; u64* const seqs = (u64*)(d->dsplitBuf + tabBytes);
+        u16* const tabs = (u16*)d->dsplitBuf; u64* const seqs = (u64*)(d->dsplitBuf + tabBytes);
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
-        u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused
+        u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
+        u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass
+        static int const overlap = getenv("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
         if (hipMemsetAsync(c, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (overlap && (hipMemsetAsync(doneList, 0xFF, listBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, listBytes, st) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
         (void)hipEventRecord(d->tev[2], st);
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
                                       (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
@@ -836,16 +869,27 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
                                 (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
-        hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
-                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u32*)tabs, seqs, metas, ddDev);
-        (void)hipEventRecord(d->tev[4], st);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
-        if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, st,
-                           (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw);
-        else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, st,
-                           (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                           (const u32*)c, c + 4, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw);
+        // The execution kernel (literals + LZ77 copy, wave per frame) runs on a side stream BESIDE the sequence decode and takes
+        // frames in the order they finish there: the lane-per-frame decode is a dependent chain per frame (one wave per SIMD, mostly
+        // waiting), so the two share the CUs instead of following each other.  A sweep pass afterwards takes what the side kernel
+        // did not get to (its waits are bounded): completion never depends on the two kernels being co-scheduled.
+        if (overlap && (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
+                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u16*)tabs, seqs, metas, ddDev,
+                           overlap ? doneList : (u32*)nullptr, c + 6);
+        (void)hipEventRecord(d->tev[4], st);
+        for (int pass = overlap ? 1 : 0; pass <= (overlap ? 2 : 0); pass++) {
+            hipStream_t const es = pass == 1 ? d->sideStream : st;
+            u32* const work = pass == 2 ? c + 7 : c + 4;
+            if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
+                               (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
+                               (const u32*)c, work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+            else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
+                               (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
+                               (const u32*)c, work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+            if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        }
         (void)hipEventRecord(d->tev[5], st);
         if (ddict) hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(grid < (u32)d->decDictGrid ? grid : (u32)d->decDictGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
