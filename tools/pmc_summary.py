@@ -24,7 +24,7 @@ for key in keys:
             continue
         shutil.copy(p, dst)
         for r in csv.DictReader(open(p)):
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()     # templated kernels print as "void zj_x_kernel_t<false>(...)"
             if name.startswith("zj_"):
                 rec[name][k].append(float(r["Counter_Value"]) * 1024.0)
     summ = {}
