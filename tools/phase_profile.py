@@ -14,7 +14,7 @@ n, size = 4096, 65536
 DEC = ["lit hdr", "huf table", "huf decode", "seq hdr/tables", "seq decode(l0)", "execute", "last literals", "raw copy", "frame tail"]
 ENC = ["params+zero", "match find(l0)", "lit gather+codes", "hist+huf build", "huf encode", "seq tables", "seq encode(l0)", "block place"]
 for level in (int(os.environ.get('PP_LEVEL', '1')),):
-    for cls in (0, 2):
+    for cls in (None, 0, 1, 2, 3):
         # buffers of one class: indices cls, cls+4, ...  (generator class = index & 3)
         if cls is None: src = B.synth(n, size, 0); name = "mixed"
         else:

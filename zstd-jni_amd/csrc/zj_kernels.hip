@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 template <bool DICT>
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
                                                           u32 n, u32* counter, u16* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
-                                                          const ZDDictDev* dd) {
+                                                          const ZDDictDev* dd, u32* doneList, u32* procFlag) {
     __shared__ ZDecShared sh;
     Grp<64> g;
     for (;;) {
@@ -88,10 +88,19 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
         u64 const cap = d1 - d0;
         bool const simple = zd_prep_frame<DICT>(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
                                                 tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i, dd);
-        if (threadIdx.x == 0) { if (simple) listA[atomicAdd(&listCounts[0], 1u)] = i; else listB[atomicAdd(&listCounts[1], 1u)] = i; }
+        if (threadIdx.x == 0) {
+            if (doneList) { doneList[i] = 0xFFFFFFFFu; procFlag[i] = 0; }       // slot i of the completion queue / frame i's "executed by the side pass" flag
+            // |A| and the batch's sequence total share one 64-bit counter ([8] = |A|, [9] = sequences, see zj_dec_heavy): one same-address atomic per frame
+            if (simple) listA[(u32)atomicAdd((unsigned long long*)&listCounts[8], 1ull | ((unsigned long long)sh.nbSeq << 32))] = i;
+            else listB[atomicAdd(&listCounts[1], 1u)] = i;
+        }
         __syncthreads();
     }
 }
+// The sequence decode and the execution kernel run BESIDE each other when the frames carry enough sequences for the chain of
+// decode rounds to dominate (>= 512 per frame on average: 64 KiB buffers have ~2 500, 4 KiB records ~100); for light frames the
+// per-frame start-up dominates, every wave slot goes to the sequence decode and the execution kernel follows it.
+__device__ __forceinline__ bool zj_dec_heavy(const u32* countA) { return countA[1] >= 512u * countA[0]; }      // countA = &listCounts[8]
 
 // append k to a completion queue (the producer's records are visible before the entry): match kernel -> entropy kernel, sequence decode -> execution
 __device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
@@ -103,7 +112,9 @@ __device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u
 
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
                                                          const u32* countPtr, u32* workCounter, const u16* tabs, u64* seqs, ZDMeta* metas,
-                                                         const ZDDictDev* dd, u32* doneList, u32* doneCount) {
+                                                         const ZDDictDev* dd, u32* doneList, u32* doneCount, u32 heavyWaves) {
+    if (doneList && !zj_dec_heavy(countPtr)) doneList = nullptr;
+    if (doneList && blockIdx.x >= heavyWaves) return;        // fewer resident waves = fewer decode cells alive at a time (2.5 KiB per lane); a lane takes more frames instead
     __shared__ u32 llBase[36], mlBase[53];
     zd_seq_symtabs(llBase, mlBase, threadIdx.x, 64u);
     __syncthreads();
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
     u32 const count = ZJ_UNI(*countPtr);
+    if (mode == 1 && !zj_dec_heavy(countPtr)) return;        // light frames: everything is the mode-2 pass's
     for (;;) {
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
@@ -535,7 +547,8 @@ struct DevState {
     u32* cdList = nullptr; size_t cdListCap = 0;
     hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
-    u8* decScratch = nullptr;
+    u8* decScratch = nullptr; int dseqHeavy = 0;
+    volatile u32* decStat = nullptr;                  // pinned: [0] |A|, [1] sequences of the last split-decode slice that ran (copied back asynchronously, read without waiting)
     u8* encScratch = nullptr;
     // staging for the host-pointer entries
     unsigned long long* prof = nullptr;    // 32 phase counters (16 decode + 16 encode) when ZJNI_PROFILE is set
@@ -598,11 +611,11 @@ DevState* get_state(int ordinal) {
         d.matchGrid = d.numCU * perCU;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_seq_kernel, 64, 0) != hipSuccess || perCU < 1) perCU = 4;
         d.dseqGrid = d.numCU * perCU;
-        // Resident waves of the sequence decode.  A lane takes its next frame from a counter, so fewer waves than frames / 64 only means
-        // more frames per lane; with the execution kernel beside it the pipeline's time is flat from 1 to 2 waves per CU (24.7-25.3 ms per
-        // 65 536 x 64 KiB) and the decode cells alive at a time (2.5 KiB per lane) shrink with the wave count: 1.5 waves per CU.
-        if (d.dseqGrid > d.numCU * 3 / 2) d.dseqGrid = d.numCU * 3 / 2;
-        if (const char* ov = getenv("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqGrid = v; }
+        // Resident waves of the sequence decode when the execution kernel runs beside it (zj_dec_heavy).  A lane takes its next frame from
+        // a counter, so fewer waves than frames / 64 only means more frames per lane; the pipeline's time is flat from 1 to 2 waves per CU
+        // (24.7-25.3 ms per 65 536 x 64 KiB) and the decode cells alive at a time shrink with the wave count: 1.5 waves per CU.
+        d.dseqHeavy = d.numCU * 3 / 2;
+        if (const char* ov = getenv("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
@@ -616,6 +629,7 @@ DevState* get_state(int ordinal) {
         {   int w = 3; if (const char* ov = getenv("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
             d.waveGrid = d.numCU * w; }
         for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
+        {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, 64); d.decStat = (volatile u32*)hp; } }
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
         if (getenv("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
@@ -697,7 +711,7 @@ void zjni_shutdown(void) {
     for (auto& d : g_dev) {
         if (d.ordinal < 0) continue;
         (void)hipSetDevice(d.ordinal);
-        (void)hipFree(d.counters); (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
+        (void)hipFree(d.counters); if (d.decStat) { (void)hipHostFree((void*)d.decStat); d.decStat = nullptr; } (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
@@ -858,15 +872,20 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
-        u32* const c = d->counters + 32;          // [0] |A|, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass
-        static int const overlap = getenv("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
-        if (hipMemsetAsync(c, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        if (overlap && (hipMemsetAsync(doneList, 0xFF, listBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, listBytes, st) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A
+        static int const overlapEnv = getenv("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
+        // Running the execution kernel beside the sequence decode costs two cross-stream dependencies and an extra launch per slice
+        // (~0.3 ms) — worth it only for frames with many sequences (zj_dec_heavy, decided on the device).  The host skips the set-up
+        // when the last slice it has statistics for was light: the statistics arrive asynchronously and are never waited for, so a
+        // change of workload is followed one call late, which costs time, never correctness.
+        u32 const statA = d->decStat ? d->decStat[0] : 0u, statS = d->decStat ? d->decStat[1] : 0u;
+        int const overlap = overlapEnv && !(statA > 0u && statS < 512u * statA);
+        if (hipMemsetAsync(c, 0, 48, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         (void)hipEventRecord(d->tev[2], st);
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
+                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag);
         else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev);
+                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
@@ -876,20 +895,21 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         // did not get to (its waits are bounded): completion never depends on the two kernels being co-scheduled.
         if (overlap && (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
-                           (const u64*)d_src_off, (const u32*)listA, (const u32*)c, c + 3, (const u16*)tabs, seqs, metas, ddDev,
-                           overlap ? doneList : (u32*)nullptr, c + 6);
+                           (const u64*)d_src_off, (const u32*)listA, (const u32*)(c + 8), c + 3, (const u16*)tabs, seqs, metas, ddDev,
+                           overlap ? doneList : (u32*)nullptr, c + 6, (u32)d->dseqHeavy);
         (void)hipEventRecord(d->tev[4], st);
         for (int pass = overlap ? 1 : 0; pass <= (overlap ? 2 : 0); pass++) {
             hipStream_t const es = pass == 1 ? d->sideStream : st;
             u32* const work = pass == 2 ? c + 7 : c + 4;
             if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)c, work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
             else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)c, work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
             if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
         }
+        if (d->decStat) (void)hipMemcpyAsync((void*)d->decStat, c + 8, 8, hipMemcpyDeviceToHost, st);
         (void)hipEventRecord(d->tev[5], st);
         if (ddict) hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(grid < (u32)d->decDictGrid ? grid : (u32)d->decDictGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
