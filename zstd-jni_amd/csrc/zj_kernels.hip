@@ -1016,7 +1016,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
     {   // list C: multi-block frames.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 768 KiB per resident workgroup.
         if (!d->multiTables) {
-            d->multiGrid = d->numCU * 2;
+            int perCU = 4; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
+            d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
             if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
         }
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
