@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="buffers in the CPU baseline (0 = the whole batch when host memory allows)")
     ap.add_argument("--cpu-seconds", type=float, default=1.0, help="timed CPU work per direction")
     ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded / re-made by the CPU reference")
-    ap.add_argument("--e2e-sample", type=int, default=8192, help="buffers in the end-to-end (host-pointer) leg, 0 = skip")
+    ap.add_argument("--e2e-sample", type=int, default=65536, help="buffers in the end-to-end (host-pointer) leg (at most 4 GiB of them), 0 = skip")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
     return ap.parse_args()
@@ -179,7 +179,7 @@ def end_to_end_leg(zj, host, size, m, level, cd, dd):
     ok = all(res2[i] == size for i in range(m)) and bool((back == src).all())
     tot = m * size
     return {"compress_GiBps": tot / GIB / best_c, "decompress_GiBps": tot / GIB / best_d, "both_GiBps": tot / GIB / (best_c + best_d),
-            "sample": f"{m} x {size} B through zjni_compress_batch{'_usingCDict' if cd else '2'} / zjni_decompress_batch_usingDDict (host pointers: pack, H2D, kernels, D2H, scatter), best of 2 after warm-up",
+            "sample": f"{m} x {size} B through zjni_compress_batch{'_usingCDict' if cd else '2'} / zjni_decompress_batch_usingDDict (host pointers: gather into pinned staging on 8 threads, H2D in slices, kernels, device-side packing of the frames, D2H in slices, scatter), best of 2 after warm-up",
             "roundtrip_exact": ok}
 
 
@@ -361,7 +361,7 @@ def main():
         gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
         gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
         if a.e2e_sample:
-            me = min(a.e2e_sample, n)
+            me = max(1, min(a.e2e_sample, n, (4 << 30) // size))
             e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
 
     if rank == 0:

@@ -6,6 +6,7 @@
 // independent, so no cross-XCD traffic exists and the per-XCD L2s only see their own frames.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include <string.h>
@@ -542,6 +543,7 @@ struct DevState {
     int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
     // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
     u8* wideBuf = nullptr; size_t wideBufCap = 0;     // lane-per-frame path of list B: [tables][frame scratch][meta] for one slice
+    std::vector<hipEvent_t> stageEv;                  // host-pointer entries: one event per returned slice
     u32* multiTables = nullptr; int multiGrid = 0;    // multi-block frames: frame-wide hash tables, one set per resident workgroup
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
@@ -690,6 +692,29 @@ bool ensure_staging(DevState* d, size_t bytes) {
     }
     return true;
 }
+// Host-side copies of the host-pointer entries (caller's buffers <-> pinned staging) run on a few threads: one memcpy stream moves
+// ~10 GB/s, the PCIe link 50.  ZJNI_HOST_THREADS overrides the count (default 8; 1 = the calling thread only).
+#define ZJ_HOST_SLICE ((u64)256 << 20)
+static int host_threads() {
+    static int const t = []() { int v = 8; if (const char* ov = getenv("ZJNI_HOST_THREADS")) v = atoi(ov); return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    return t;
+}
+// fn(lo, hi) over index ranges of about equal bytes; off[0..n] = byte offsets of the items
+template <class F>
+static void par_ranges(const u64* off, size_t n, F fn) {
+    u64 const total = off[n] - off[0];
+    int T = total < ((u64)8 << 20) ? 1 : host_threads();
+    if ((size_t)T > n) T = (int)(n ? n : 1);
+    if (T <= 1) { fn((size_t)0, n); return; }
+    std::vector<size_t> cut((size_t)T + 1, n); cut[0] = 0;
+    for (int t = 1; t < T; t++) cut[(size_t)t] = (size_t)(std::lower_bound(off, off + n + 1, off[0] + total / (u64)T * (u64)t) - off);
+    for (int t = 1; t <= T; t++) if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&, t]() { fn(cut[(size_t)t], cut[(size_t)t + 1]); });
+    fn(cut[0], cut[1]);
+    for (auto& x : th) x.join();
+}
+
 }  // namespace
 
 // ============================================================================ C-ABI ============
@@ -1324,20 +1349,25 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
         if ((srcSize[i] && !src[i]) || (dstCap[i] && !dst[i])) return ZJNI_ERR(compress ? 72 : 72);
     }
     size_t const offBytes = (n + 1) * 8;
-    // staging layout: [srcOff][dstOff][result][src blob][dst blob]
-    size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
-    size_t const total = oDst + dstTotal + 16;
+    // staging layout: [srcOff][dstOff][result][packedOff][src blob][dst blob][device only, compress: packed frames]
+    size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oPOff = 3 * offBytes, oSrc = 4 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
+    size_t const oPack = (oDst + dstTotal + 15) & ~(size_t)15;
+    size_t const total = oPack + (compress ? dstTotal : 0) + 16;
     std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
     if (!ensure_staging(d, total)) return ZJNI_ERR(64);
-    u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff);
+    u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff); u64* hp = (u64*)(d->hPinned + oPOff);
     size_t a = 0, b = 0;
-    for (size_t i = 0; i < n; i++) {
-        hs[i] = a; hd[i] = b;
-        if (srcSize[i]) memcpy(d->hPinned + oSrc + a, src[i], srcSize[i]);
-        a += srcSize[i]; b += dstCap[i];
-    }
+    for (size_t i = 0; i < n; i++) { hs[i] = a; hd[i] = b; a += srcSize[i]; b += dstCap[i]; }
     hs[n] = a; hd[n] = b;
-    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcTotal, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u8* const hSrc = d->hPinned + oSrc;
+    // in slices of ~256 MiB: while the link carries slice k the host threads gather slice k + 1 into the pinned area
+    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    for (size_t lo = 0; lo < n;) {
+        size_t hi = lo + 1; while (hi < n && hs[hi] - hs[lo] < ZJ_HOST_SLICE) hi++;
+        par_ranges(hs + lo, hi - lo, [&](size_t a0, size_t a1) { for (size_t i = lo + a0; i < lo + a1; i++) if (srcSize[i]) memcpy(hSrc + hs[i], src[i], srcSize[i]); });
+        if (hs[hi] > hs[lo] && hipMemcpyAsync(d->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        lo = hi;
+    }
     size_t r;
     if (compress && cdict)
         r = zjni_compress_batch_device_usingCDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
@@ -1350,12 +1380,44 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
                                                     (u64*)(d->dStage + oRes), n, ddict, nullptr);
     if (zjni_isError(r)) return r;
     if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, n * 8, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    if (hipMemcpyAsync(d->hPinned + oDst, d->dStage + oDst, dstTotal, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    if (hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     const u64* hr = (const u64*)(d->hPinned + oRes);
-    for (size_t i = 0; i < n; i++) {
-        result[i] = (size_t)hr[i];
-        if (!zjni_isError(result[i]) && result[i]) memcpy(dst[i], d->hPinned + oDst + hd[i], result[i]);
+    const u64* from = hd;                              // where frame i's bytes start inside the returned blob
+    if (compress) {
+        // the destinations are compressBound-sized: pack the frames on the device and bring back only their bytes
+        if (hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        u64 acc = 0;
+        for (size_t i = 0; i < n; i++) { hp[i] = acc; if (!zjni_isError((size_t)hr[i])) acc += hr[i]; }
+        hp[n] = acc;
+        if (hipMemcpyAsync(d->dStage + oPOff, hp, offBytes, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        size_t const pr = zjni_pack_batch_device(d->dStage + oDst, (const u64*)(d->dStage + oDstOff), (const u64*)(d->dStage + oRes),
+                                                 d->dStage + oPack, (const u64*)(d->dStage + oPOff), n, nullptr);
+        if (zjni_isError(pr)) return pr;
+        from = hp;
+    }
+    // the way back in slices too: the host threads scatter slice k into the caller's buffers while the link carries slice k + 1
+    u8* const dOut = d->dStage + (compress ? oPack : oDst);
+    u8* const hDst = d->hPinned + oDst;
+    std::vector<size_t> cuts; cuts.push_back(0);
+    for (size_t lo = 0; lo < n;) { size_t hi = lo + 1; while (hi < n && from[hi] - from[lo] < ZJ_HOST_SLICE) hi++; cuts.push_back(hi); lo = hi; }
+    size_t const nSlices = cuts.size() - 1;
+    if (d->stageEv.size() < nSlices) {
+        size_t const have = d->stageEv.size(); d->stageEv.resize(nSlices, nullptr);
+        for (size_t k = have; k < nSlices; k++) if (hipEventCreateWithFlags(&d->stageEv[k], hipEventDisableTiming) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    }
+    for (size_t k = 0; k < nSlices; k++) {
+        size_t const lo = cuts[k], hi = cuts[k + 1];
+        if (from[hi] > from[lo] && hipMemcpyAsync(hDst + from[lo], dOut + from[lo], (size_t)(from[hi] - from[lo]), hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipEventRecord(d->stageEv[k], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    }
+    for (size_t k = 0; k < nSlices; k++) {
+        size_t const lo = cuts[k], hi = cuts[k + 1];
+        if (hipEventSynchronize(d->stageEv[k]) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        par_ranges(from + lo, hi - lo, [&](size_t a0, size_t a1) {
+            for (size_t i = lo + a0; i < lo + a1; i++) {
+                result[i] = (size_t)hr[i];
+                if (!zjni_isError(result[i]) && result[i]) memcpy(dst[i], hDst + from[i], result[i]);
+            }
+        });
     }
     return 0;
 }
