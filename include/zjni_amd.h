@@ -30,6 +30,9 @@ extern "C" {
 #define ZJNI_FRAME_MAX (2u << 20)      /* largest input the compress entries take: multi-block frames (N/compress/zstd_compress.c:4591-4692),
                                         * byte-identical to ZSTD_compress2 with the level's own parameters, as long as the frame fits the level's
                                         * window — 512 KiB / 1 MiB / 2 MiB at levels 1 / 2 / 3; beyond that ZJNI_ERROR_unsupported */
+#define ZJNI_LEVEL4_MAX (1u << 17)     /* level 4 (N/compress/clevels.h:84,110): greedy on the hash chain up to 16 KiB (ZSTD_compressBlock_greedy,
+                                        * N/compress/zstd_lazy.c:1784), double-fast with 2^17-entry tables up to here; larger inputs run the
+                                        * reference's row-based match finder, which this library does not restate: ZJNI_ERROR_unsupported */
 
 /* ---- library / device ---- */
 const char* zjni_version(void);
@@ -69,7 +72,8 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
 
 /* Replaces ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) for n buffers at
  * once: each buffer becomes one standard zstd frame (content size in the header, no checksum,
- * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h).  Buffers larger than
+ * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h), or 4 for inputs up to ZJNI_LEVEL4_MAX (plain
+ * entries only: no dictionary, no explicit table sizes; a wave-per-frame kernel with one lane parsing — exact, not fast).  Buffers larger than
  * ZJNI_BLOCKSIZE_MAX become multi-block frames (one wavefront per frame, block after block; see ZJNI_FRAME_MAX for the
  * range); beyond it d_result[i] reports ZJNI_ERROR_unsupported and the buffer stays on the CPU path. */
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off,

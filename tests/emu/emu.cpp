@@ -78,15 +78,27 @@ extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsi
 extern "C" unsigned emu_dec_shared_bytes() { return (unsigned)sizeof(ZDecShared); }
 
 #include "../../zstd-jni_amd/csrc/zj_encode.h"
+// The encode kernels are persistent: a workgroup's `sh` (static LDS), its dynamic LDS and its HBM scratch slot outlive the frame, and
+// nothing clears them between frames.  The emulation keeps one such workgroup for the life of the process — poisoned at "launch",
+// with the few fields a kernel sets before its first frame — so that state leaking from one frame into the next shows up here
+// (a stale sh.litMode did, on the GPU only, while every frame here started from calloc).
+struct EmuWg { ZEncShared* sh; u8* lds; u8* ws; };
+static EmuWg& emu_wg() {
+    static EmuWg w = { nullptr, nullptr, nullptr };
+    if (!w.sh) {
+        w.sh = (ZEncShared*)malloc(sizeof(ZEncShared)); memset(w.sh, 0xA5, sizeof(ZEncShared));
+        w.sh->dictLoaded = 0; w.sh->ctDict[0] = 0; w.sh->ctDict[1] = 0; w.sh->ctDict[2] = 0;        // zj_encode_kernel / zj_encode_multi_kernel, before the frame loop
+        w.lds = (u8*)malloc(160 * 1024); memset(w.lds, 0x5A, 160 * 1024);
+        w.ws = (u8*)malloc(ZE_SCRATCH_BYTES); memset(w.ws, 0xC3, ZE_SCRATCH_BYTES);
+    }
+    return w;
+}
 extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     Grp<1> g;
-    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
-    u8* lds = (u8*)calloc(1, 160 * 1024);
-    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     ZjProf pf; pf.start(nullptr);
     // level & 0xFF = level, bits 8-10 = frame flags (ZE_FLAG_CHECKSUM, ZE_FLAG_NO_FCS, ZE_FLAG_NO_DICTID)
     u64 r = (srcSize > ZE_BLOCK_MAX) ? ZJ_ERR64(201) : ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level & 0xFFu, ws, pf, nullptr, (level >> 8) & ZE_FLAG_MASK);
-    free(ws); free(lds); free(sh);
     return r;
 }
 extern "C" unsigned emu_enc_lds_need(unsigned level, unsigned srcSize) { return ze_lds_need(level, srcSize); }
@@ -112,9 +124,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     u32 const ldsA = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     bool const wide = (hl | cl) ? srcSize > 65536u : ze_lds_need(level, srcSize) > (ldsA > (u32)sizeof(ZEEntropy) ? ldsA : (u32)sizeof(ZEEntropy));
     u32 const maxSrc = wide ? ZE_WIDE_MAX_SRC : 65536u;
-    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
-    u8* lds = (u8*)calloc(1, 160 * 1024);
-    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     u8* table = (u8*)calloc(1, ze_lane_table_stride(lw, wide));
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(maxSrc));
     u32 meta[3];
@@ -122,7 +132,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
     u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, lw, ws, pf, &pre, flags, nullptr, 160u * 1024u);
-    free(fs); free(table); free(ws); free(lds); free(sh);
+    free(fs); free(table);
     return r;
 }
 
@@ -130,14 +140,14 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
 extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
-    ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));
-    u8* lds = (u8*)calloc(1, 160 * 1024);
-    u8* ws = (u8*)malloc(ZE_SCRATCH_BYTES);
+    EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
     memset(tables, 0xA5, ZE_MULTI_TABLE_BYTES);                      // the encoder clears what it uses
     ZjProf pf; pf.start(nullptr);
-    u64 const r = ze_compress_multi(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u);
-    free(tables); free(ws); free(lds); free(sh);
+    // zj_encode_multi_kernel's routing: a single block (level 4: match-finder tables in HBM) or a multi-block frame (levels 1-3)
+    u64 const r = srcSize <= ZE_BLOCK_MAX ? ze_compress_t<Grp<1>, u32>(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, nullptr, flags, nullptr, 160u * 1024u, nullptr, tables)
+                                          : ze_compress_multi(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u);
+    free(tables);
     return r;
 }
 

@@ -54,7 +54,7 @@ def test_multiblock_xml_and_flags(emu, oracle_ref):
                 if z is not None and ck and cs:
                     assert emu_decompress(emu, z, len(d)) == d
     assert emu_compress_multi(emu, xml[:(2 << 20) + 1], 3) == -201              # beyond ZE_MULTI_MAX
-    assert emu_compress_multi(emu, xml[:131072], 3) == -201                     # single-block frames are the other entry's
+    # (<= 128 KiB this entry is the level-4 route of the same kernel: tests/test_emu_level4.py)
 
 
 def test_multiblock_block_types(emu, oracle_ref):

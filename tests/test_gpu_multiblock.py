@@ -68,3 +68,18 @@ def test_gpu_one_mebibyte_buffer_like_baseline_config_1(gpu, oracle_ref):
     with pytest.raises(gpu.ZstdException) as ex:         # level 1: the frame (1 MiB) exceeds the window (512 KiB): left to the CPU path
         gpu.Zstd.compress(xml, 1)
     assert ex.value.getErrorCode() == 201
+
+
+def test_gpu_multiblock_repeated_calls_leave_no_state_behind(gpu, oracle_ref):
+    """The kernels are persistent: a workgroup's shared state outlives a frame and a call.  Repeating one batch several times — so that
+    a workgroup meets a frame right after another frame's (or its own) leftovers — must give the reference's bytes every time
+    (a stale "this block made a Huffman table" flag once let a later block go treeless against a table that did not exist;
+    tools/stress_gpu_multiblock.py is the long version)."""
+    for level in (1, 3):
+        datas = inputs(gpu, oracle_ref, 100 + level, 60)
+        want = [None if len(d) > WINDOW[level] else (oracle_ref.compress(d, level) if len(d) > 131072 or level < 3 else oracle_ref.compress(d, 3, False, 14, 13)) for d in datas]
+        for rep in range(6):
+            outs = gpu.compress_batch(datas, level)
+            for i, (z, w) in enumerate(zip(outs, want)):
+                if w is not None:
+                    assert z == w, (level, rep, i, len(datas[i]))

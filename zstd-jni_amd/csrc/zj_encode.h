@@ -67,7 +67,7 @@ struct ZEEntropy {                 // entropy-stage view of the LDS
 struct ZEncShared {                // uniforms, outside the overlay
     u32 err;
     u32 nbSeq, litSize, lastLL;
-    u32 windowLog, hashLog, chainLog, minMatch, strategy;
+    u32 windowLog, hashLog, chainLog, minMatch, strategy, searchLog;
     u32 hdrSize, bodySize, litSecSize;
     u32 hufLog, hufMaxSV, hufHdr, litMode, litStreams;
     u32 strBytes[4], strOff[4];
@@ -139,7 +139,7 @@ ZJ_HD void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
     if (chainLog > windowLog) chainLog = windowLog;
     if (windowLog < 10) windowLog = 10;
 }
-struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy; };
+struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLog; };      // strategy: 1 fast, 2 double-fast, 3 greedy (hash chain), 0 = not served
 // "level" arguments are level words: the level in the low byte, then ZstdCompressCtx.setHashLog / setChainLog
 // (ZSTD_c_hashLog / ZSTD_c_chainLog, 0 = not set) — honoured for the double-fast strategy, whose tables live in HBM on
 // the lane-per-frame path and can therefore have the level's own sizes (16 / 15 at level 3) or any other.
@@ -153,6 +153,18 @@ struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy; };
 ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     u32 const level = ZE_LW_LEVEL(levelWord), hl = ZE_LW_HL(levelWord), cl = ZE_LW_CL(levelWord);
     u32 w, c, h, mm, st;
+    if (level == 4) {
+        // clevels.h:84 / :110.  <= 16 KiB: greedy on the hash chain (the window log stays <= 14, where the reference does not switch to its
+        // row-based match finder, zstd_compress.c:238-245); <= 128 KiB: double-fast with 2^17-entry tables; beyond: greedy on the row
+        // finder — not served (strategy 0)
+        ZEParams q; q.searchLog = 0;
+        if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 14; mm = 4; st = 3; q.searchLog = 4; }
+        else if (srcSize <= (128u << 10)) { w = 17; c = 17; h = 17; mm = 4; st = 2; q.searchLog = 2; }
+        else { q.windowLog = q.chainLog = q.hashLog = q.minMatch = q.strategy = 0; return q; }
+        ze_adjust(w, c, h, srcSize);
+        q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = mm; q.strategy = st;
+        return q;
+    }
     if (srcSize <= (16u << 10)) { w = 14; c = 14; h = 15; mm = (level == 1) ? 5 : 4; st = (level == 3) ? 2 : 1; }
     else if (srcSize <= (128u << 10)) {
         if (level == 1) { w = 17; c = 12; h = 13; mm = 6; st = 1; }
@@ -169,7 +181,7 @@ ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     }
     ze_adjust(w, c, h, srcSize);
     if (srcSize > (128u << 10)) {                             // multi-block frames run the level's own table sizes (tables in HBM)
-        ZEParams q; q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = mm; q.strategy = st;
+        ZEParams q; q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = mm; q.strategy = st; q.searchLog = 1;
         return q;
     }
     if (st == 2 && (hl | cl)) {   // explicit ZSTD_c_hashLog / ZSTD_c_chainLog: override, then ZSTD_adjustCParams_internal again (zstd_compress.c:1640-1655)
@@ -179,12 +191,12 @@ ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     } else if (st == 2) {     // LDS budget: ZSTD_c_hashLog = 14, ZSTD_c_chainLog = 13, then adjust again
         if (h > ZE_L3_HASHLOG || c > ZE_L3_CHAINLOG) { if (h > ZE_L3_HASHLOG) h = ZE_L3_HASHLOG; if (c > ZE_L3_CHAINLOG) c = ZE_L3_CHAINLOG; ze_adjust(w, c, h, srcSize); }
     }
-    ZEParams p; p.windowLog = w; p.chainLog = c; p.hashLog = h; p.minMatch = mm; p.strategy = st;
+    ZEParams p; p.windowLog = w; p.chainLog = c; p.hashLog = h; p.minMatch = mm; p.strategy = st; p.searchLog = 1;
     return p;
 }
 ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
     ZEParams const p = ze_params_of(level, srcSize);
-    sh.windowLog = p.windowLog; sh.chainLog = p.chainLog; sh.hashLog = p.hashLog; sh.minMatch = p.minMatch; sh.strategy = p.strategy;
+    sh.windowLog = p.windowLog; sh.chainLog = p.chainLog; sh.hashLog = p.hashLog; sh.minMatch = p.minMatch; sh.strategy = p.strategy; sh.searchLog = p.searchLog;
 }
 // bytes of LDS the match-finder tables need for this (level, size, index width)
 ZJ_HD u32 ze_table_entries(u32 level, u32 maxSrc) {
@@ -419,6 +431,91 @@ ZJ_DEV u32 ze_block_dfast(ZEOut& o, const u8* src, u32 srcSize, u32 hBitsL, u32 
                 ze_store(o, (u32)(anchor - istart), 0, 1, rLength);
                 ip += rLength; anchor = ip;
             }
+        }
+    }
+    return (u32)(iend - anchor);
+}
+
+// ---- greedy parse on the hash chain: ZSTD_compressBlock_greedy = ZSTD_compressBlock_lazy_generic(depth 0, search_hashChain, noDict)
+//      (N/compress/zstd_lazy.c:1516-1780) over ZSTD_HcFindBestMatch (:667-723) and ZSTD_insertAndFindFirstIndex_internal (:632-657).
+// Table indices are the reference's: a fresh context's window starts at index 2 (ZSTD_WINDOW_START_INDEX), so position p has index
+// p + 2, entry 0 means "empty" and the chain table is addressed by (index & chainMask).  `nextToUpdate` and the lazy-skipping
+// flag (one insert per search while the parse strides over incompressible data) are the match state's, kept here.
+struct ZEChain {
+    const u8* base;                 // src - 2
+    u32* hashTable; u32* chainTable; u32 hashLog, chainMask, chainSize, nbAttemptsMax, mls, nextToUpdate, lazySkipping;
+};
+ZJ_DEV u32 ze_hc_insert_find(ZEChain& m, const u8* ip) {
+    u32 const target = (u32)(ip - m.base);
+    u32 idx = m.nextToUpdate;
+    while (idx < target) {
+        u32 const h = ze_hash(m.base + idx, m.hashLog, m.mls);
+        m.chainTable[idx & m.chainMask] = m.hashTable[h];
+        m.hashTable[h] = idx;
+        idx++;
+        if (m.lazySkipping) break;
+    }
+    m.nextToUpdate = target;
+    return m.hashTable[ze_hash(ip, m.hashLog, m.mls)];
+}
+// returns the best length (3 = none), *offBase set when a match was taken
+ZJ_DEV u32 ze_hc_find_best(ZEChain& m, const u8* ip, const u8* iLimit, u32* offBase) {
+    u32 const curr = (u32)(ip - m.base);
+    u32 const lowLimit = 2u;                                   // the frame fits its window, no dictionary: window.lowLimit
+    u32 const minChain = curr > m.chainSize ? curr - m.chainSize : 0u;
+    u32 nbAttempts = m.nbAttemptsMax, ml = 3u;
+    u32 matchIndex = ze_hc_insert_find(m, ip);
+    for (; (matchIndex >= lowLimit) & (nbAttempts > 0); nbAttempts--) {
+        const u8* const match = m.base + matchIndex;
+        u32 currentMl = 0;
+        if (ld32(match + ml - 3) == ld32(ip + ml - 3)) currentMl = ze_count(ip, match, iLimit);     // potentially better
+        if (currentMl > ml) {
+            ml = currentMl; *offBase = (curr - matchIndex) + 3u;
+            if (ip + currentMl == iLimit) break;               // best possible
+        }
+        if (matchIndex <= minChain) break;
+        matchIndex = m.chainTable[matchIndex & m.chainMask];
+    }
+    return ml;
+}
+ZJ_DEV u32 ze_block_greedy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p, u32* hashTable, u32* chainTable) {
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+    const u8* ip = istart + 1; const u8* anchor = istart;      // ip += (dictAndPrefixLength == 0)
+    u32 off1 = 1, off2 = 0;                                    // rep {1,4}: 4 > maxRep == 1 at frame start (saved; only matters to a next block)
+    ZEChain m; m.base = src - 2; m.hashTable = hashTable; m.chainTable = chainTable; m.hashLog = p.hashLog;
+    m.chainSize = 1u << p.chainLog; m.chainMask = m.chainSize - 1u; m.nbAttemptsMax = 1u << p.searchLog;
+    m.mls = p.minMatch < 4u ? 4u : (p.minMatch > 6u ? 6u : p.minMatch); m.nextToUpdate = 2u; m.lazySkipping = 0;
+    while (ip < ilimit) {
+        u32 matchLength = 0, offBase = 1u;                     // REPCODE1_TO_OFFBASE
+        const u8* start = ip + 1;
+        bool haveRep = false;
+        if ((off1 > 0) & (ld32(ip + 1 - off1) == ld32(ip + 1))) {                      // repcode at ip + 1: at depth 0 it is taken at once
+            matchLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4u; haveRep = true;
+        }
+        if (!haveRep) {
+            u32 found = 999999999u;
+            u32 const ml2 = ze_hc_find_best(m, ip, iend, &found);
+            if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+            if (matchLength < 4u) {
+                u32 const step = ((u32)(ip - anchor) >> 8) + 1u;                     // kSearchStrength
+                ip += step;
+                m.lazySkipping = step > 8u;                                          // kLazySkippingStep
+                continue;
+            }
+            if (offBase > 3u) {                                                      // a real offset: catch up
+                u32 const off = offBase - 3u;
+                while ((start > anchor) & (start - off > istart) && (start[-1] == (start - off)[-1])) { start--; matchLength++; }
+                off2 = off1; off1 = off;
+            }
+        }
+        ze_store(o, (u32)(anchor - istart), (u32)(start - anchor), offBase, matchLength);
+        anchor = ip = start + matchLength;
+        m.lazySkipping = 0;
+        while ((ip <= ilimit) & (off2 > 0) && (ld32(ip) == ld32(ip - off2))) {        // immediate repcode
+            matchLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4u;
+            { u32 const t = off2; off2 = off1; off1 = t; }
+            ze_store(o, (u32)(anchor - istart), 0u, 1u, matchLength);
+            ip += matchLength; anchor = ip;
         }
     }
     return (u32)(iend - anchor);
@@ -1090,7 +1187,7 @@ struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {
 // return value is the size of the block with its 3-byte header.
 template <class G, class TIdx>
 ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, const ZEPre* pre, u32 flags, const ZECDictDev* cd, u32 ldsBytes,
-                         const ZEBlockArgs* ba = nullptr) {
+                         const ZEBlockArgs* ba = nullptr, u32* hbmTables = nullptr) {
     u32 const tail = (!ba && (flags & ZE_FLAG_CHECKSUM)) ? 4u : 0u;         // XXH64 low 32 bits after the last block (ZSTD_writeEpilogue)
     // Small frames whose sequences are already found: the source is staged into LDS once, literals are gathered and the
     // block body is assembled there, so the stage's many short dependent steps run at LDS latency, not HBM latency.
@@ -1161,6 +1258,20 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 u32 const lastLL = (strategy == 1) ? ze_block_fast_x<ZEEnt32>(o, ba->frameBase, ba->start, ba->start + srcSize, hlog, mls, ba->tables, sh.blkRep, sh.blkNextRep)
                                                    : ze_block_dfast_x<ZEEnt32>(o, ba->frameBase, ba->start, ba->start + srcSize, hlog, clog, mls, ba->tables, ba->tables + (1u << hlog), sh.blkRep, sh.blkNextRep);
+                sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
+            }
+            zj_mem_order();
+        } else if (!pre && hbmTables) {                    // level 4: tables too large for LDS, one set per resident workgroup in HBM (zj_encode_multi_kernel)
+            u32 const entries = (1u << hlog) + (1u << clog);
+            GRP_FOR(g, i, entries) hbmTables[i] = 0;
+            zj_mem_order();
+            g.sync();
+            pf.mark(0);
+            GRP_SERIAL(g) {
+                ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+                ZEParams q; q.windowLog = sh.windowLog; q.chainLog = clog; q.hashLog = hlog; q.minMatch = mls; q.strategy = strategy; q.searchLog = sh.searchLog;
+                u32 const lastLL = (strategy == 3) ? ze_block_greedy(o, src, srcSize, q, hbmTables, hbmTables + (1u << hlog))
+                                                   : ze_block_dfast<ZEEnt32>(o, src, srcSize, hlog, clog, mls, hbmTables, hbmTables + (1u << hlog));
                 sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
             }
             zj_mem_order();
@@ -1254,6 +1365,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                     g.sync();
                 }
             }
+            // the block's tail reads sh.litMode (did this block make a new Huffman table?): every path has to leave its own answer there —
+            // a workgroup's `sh` outlives the frame, and a stale "2" would register a table that does not exist as the next block's candidate
+            if (mode != 2) { GRP_SERIAL(g) { sh.litMode = mode; } }
             if (mode == 2) {
                 if (single) ze_hist_add(g, e.hist[0], litBuf, n);
                 else {
@@ -1636,7 +1750,7 @@ ZJ_DEV u64 ze_compress(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 s
 // 512 KiB / 1 MiB / 2 MiB), so no position ever leaves it; larger inputs are refused (201) and stay on the CPU path.
 // `tables`: (1 << hashLog) + (1 << chainLog) u32 entries in HBM for this workgroup.
 #define ZE_MULTI_MAX (2u << 20)
-#define ZE_MULTI_TABLE_BYTES (((1u << 17) + (1u << 16)) * 4u)
+#define ZE_MULTI_TABLE_BYTES (((1u << 17) + (1u << 17)) * 4u)      /* level 3 frames > 256 KiB: 2^17 + 2^16 entries; level 4 at 128 KiB: 2 x 2^17 */
 template <class G>
 ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, u32 flags, u32* tables, u32 ldsBytes) {
     ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), srcSize);

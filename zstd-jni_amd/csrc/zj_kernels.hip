@@ -191,6 +191,10 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
+    if (ZE_LW_LEVEL(level) == 4u) {                   // level 4: one block per frame, match-finder tables in HBM (zj_encode_multi_kernel); larger inputs need the row finder
+        if (listC && size <= ZE_BLOCK_MAX) listC[atomicAdd(&counters[4], 1u)] = i; else result[i] = ZJ_ERR64(201);
+        return;
+    }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
         if (listC && size <= ZE_MULTI_MAX && !(ZE_LW_HL(level) | ZE_LW_CL(level))) listC[atomicAdd(&counters[4], 1u)] = i;
         else result[i] = ZJ_ERR64(201);
@@ -457,7 +461,10 @@ __global__ __launch_bounds__(64) void zj_encode_multi_kernel(const u8* __restric
         u32 const i = ZJ_UNI(list[k]);
         u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
         u64 const cap = d1 - d0;
-        u64 const r = ze_compress_multi(g, sh, zj_dyn_lds, src + s0, (u32)(s1 - s0), dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), level, ws, pf, flags, tb, ldsBytes);
+        u32 const size = (u32)(s1 - s0), capU = (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap);
+        // level 4 (one block, tables too large for LDS) or a multi-block frame of levels 1-3
+        u64 const r = size <= ZE_BLOCK_MAX ? ze_compress_t<Grp<64>, u32>(g, sh, zj_dyn_lds, src + s0, size, dst + d0, capU, level, ws, pf, nullptr, flags, nullptr, ldsBytes, nullptr, tb)
+                                           : ze_compress_multi(g, sh, zj_dyn_lds, src + s0, size, dst + d0, capU, level, ws, pf, flags, tb, ldsBytes);
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src
 namespace {
 #define ZJ_ENC_LDS_BIG 131072u
 // pass-0 LDS per level: the tables of > 16 KiB inputs up to 64 KiB (u16 positions)
+#define ZJ_LEVEL_MAX 4                 /* levels 1-3 on every path; level 4 (inputs <= 128 KiB, no dictionary, no explicit table sizes) on the HBM-table kernel */
 size_t enc_lds_pass0(int level) {
     size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);
@@ -1023,7 +1031,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     int const level = (int)ZE_LW_LEVEL((u32)levelWord);       // kernels take the level word (level | hashLog << 8 | chainLog << 16)
     bool const tuned = (ZE_LW_HL((u32)levelWord) | ZE_LW_CL((u32)levelWord)) != 0;
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
@@ -1036,7 +1044,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     u32* const ctr = d->counters + 16;            // [0] |A|, [1] |B|, [2] work A, [3] work B
     u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap; u32* const listS = d->encList + 2 * d->encListCap; u32* const listC = d->encList + 3 * d->encListCap;
     if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);     // [0] |A|, [1] |B|, [2] work A, [3] work B, [4] |C|, [5] work C
-    u32 const ldsA = (u32)enc_lds_pass0(level);
+    if (level > 3 && tuned) return ZJNI_ERR(42);
+    u32 const ldsA = level > 3 ? 0u : (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
     {   // list C: multi-block frames.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 768 KiB per resident workgroup.
@@ -1049,6 +1058,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy));
     }
+    if (level > 3) return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);   // level 4: every frame was list C's
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
     // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
     size_t splitMin = 4096;
@@ -1204,13 +1214,13 @@ static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, voi
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, 0u, stream);
 }
 size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                    uint64_t* d_result, size_t n, int level, int checksum, void* stream) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
 // ZstdCompressCtx.setHashLog / setChainLog (ZSTD_c_hashLog / ZSTD_c_chainLog; 0 = the library's choice) on top of level + checksum.
@@ -1532,7 +1542,7 @@ static size_t multi_compress_gather(const void* const* src, const size_t* srcSiz
 size_t zjni_compress_batch_multi(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
                                  int level, int checksum, const int* devices, int nDevices, int mode) {
     if (level == 0) level = 3;
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     if (mode == 1) return multi_compress_gather(src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0, devices, nDevices);
     return multi_run(true, src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0, devices, nDevices);
 }
@@ -1542,13 +1552,13 @@ size_t zjni_decompress_batch_multi(const void* const* src, const size_t* srcSize
 }
 size_t zjni_compress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level);
 }
 
 size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level, int checksum) {
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, level, checksum ? 1 : 0);
 }
 
@@ -1557,7 +1567,7 @@ size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSiz
     if (level == 0) level = 3;                    // ZSTD_CLEVEL_DEFAULT, as ZSTD_c_compressionLevel = 0 means
     int lw; size_t const e = level_word(level, hashLog, chainLog, &lw);
     if (e) return e;
-    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (level < 1 || level > ZJ_LEVEL_MAX || (level > 3 && (hashLog | chainLog))) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, lw, checksum);
 }
 size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
