@@ -33,6 +33,8 @@ extern "C" {
 #define ZJNI_LEVEL4_MAX (1u << 17)     /* level 4 (N/compress/clevels.h:84,110): greedy on the hash chain up to 16 KiB (ZSTD_compressBlock_greedy,
                                         * N/compress/zstd_lazy.c:1784), double-fast with 2^17-entry tables up to here; larger inputs run the
                                         * reference's row-based match finder, which this library does not restate: ZJNI_ERROR_unsupported */
+#define ZJNI_LAZY_MAX (1u << 14)       /* levels 5-8 (N/compress/clevels.h:111-114): lazy / lazy2 on the hash chain (ZSTD_compressBlock_lazy / _lazy2,
+                                        * N/compress/zstd_lazy.c:1516-1780) for inputs up to 16 KiB, where the reference keeps the chain */
 
 /* ---- library / device ---- */
 const char* zjni_version(void);
@@ -72,7 +74,7 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
 
 /* Replaces ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) for n buffers at
  * once: each buffer becomes one standard zstd frame (content size in the header, no checksum,
- * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h), or 4 for inputs up to ZJNI_LEVEL4_MAX (plain
+ * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h), or 4 for inputs up to ZJNI_LEVEL4_MAX / 5..8 up to ZJNI_LAZY_MAX (plain
  * entries only: no dictionary, no explicit table sizes; a wave-per-frame kernel with one lane parsing — exact, not fast).  Buffers larger than
  * ZJNI_BLOCKSIZE_MAX become multi-block frames (one wavefront per frame, block after block; see ZJNI_FRAME_MAX for the
  * range); beyond it d_result[i] reports ZJNI_ERROR_unsupported and the buffer stays on the CPU path. */

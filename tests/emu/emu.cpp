@@ -6,19 +6,30 @@
 #include <stdlib.h>
 #include <string.h>
 
+// The decode kernels are persistent too: `sh` (LDS) and the literal scratch slot outlive a frame and nothing clears them.  One
+// poisoned set per process instead of a calloc per frame, so that a decoder which relies on leftovers fails here.
+static ZDecShared* emu_dec_sh() {
+    static ZDecShared* sh = nullptr;
+    if (!sh) { sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared)); }
+    return sh;
+}
+static u8* emu_dec_lit() {
+    static u8* lit = nullptr;
+    if (!lit) { lit = (u8*)malloc(ZD_LIT_SCRATCH); memset(lit, 0x3C, ZD_LIT_SCRATCH); }
+    return lit;
+}
 extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap) {
     Grp<1> g;
-    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
-    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    ZDecShared* sh = emu_dec_sh();
+    u8* lit = emu_dec_lit();
     ZjProf pf; pf.start(nullptr);
     u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf);
-    free(lit); free(sh);
     return r;
 }
 // split pipeline: prep -> lane sequence decode -> execute; frames the pipeline hands over go through the fused path
 extern "C" unsigned long long emu_decompress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, int* usedSplit) {
     Grp<1> g;
-    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
     u16* tab = (u16*)calloc(ZD_SPLIT_CELLS, 2); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
     ZjProf pf; pf.start(nullptr);
@@ -30,7 +41,7 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
         r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf);
         if (usedSplit && r != ~(u64)0) *usedSplit = 1;
     }
-    if (r == ~(u64)0) { memset(sh, 0, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf); }
+    if (r == ~(u64)0) { memset(sh, 0x5A, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf); }
     free(seqs); free(tab); free(lit); free(sh);
     return r;
 }
@@ -39,7 +50,7 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
 extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
                                                         const unsigned char* dict, unsigned dictSize, int* usedSplit) {
     Grp<1> g;
-    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
     u16* tab = (u16*)calloc(ZD_SPLIT_CELLS, 2); u64* seqs = (u64*)malloc(ZD_SPLIT_SEQ_BYTES); ZDMeta meta;
     ZDDictDev* dd = (ZDDictDev*)calloc(1, sizeof(ZDDictDev));
@@ -49,14 +60,14 @@ extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src
     zd_ddict_digest(g, *sh, dict, dictSize, dd);
     if (dd->status) r = ZJ_ERR64(dd->status);
     else {
-        memset(sh, 0, sizeof(*sh));
+        memset(sh, 0x5A, sizeof(*sh));
         if (zd_prep_frame<true>(g, *sh, src, srcSize, dstCap, tab, &meta, dd)) {
             u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1); ZDSeqLane m; m.llBase = symL; m.mlBase = symM; m.init(src, tab, seqs, &meta, dd);
             while (m.st != 2) m.round();
             r = zd_exec_frame<true>(g, *sh, src, dst, &meta, seqs, lit, pf, dd, dict);
             if (usedSplit && r != ~(u64)0) *usedSplit = 1;
         }
-        if (r == ~(u64)0) { memset(sh, 0, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
+        if (r == ~(u64)0) { memset(sh, 0x5A, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
     }
     free(dd); free(seqs); free(tab); free(lit); free(sh);
     return r;
@@ -64,14 +75,14 @@ extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src
 extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
                                                   const unsigned char* dict, unsigned dictSize) {
     Grp<1> g;
-    ZDecShared* sh = (ZDecShared*)calloc(1, sizeof(ZDecShared));
+    ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
     ZDDictDev* dd = (ZDDictDev*)calloc(1, sizeof(ZDDictDev));
     ZjProf pf; pf.start(nullptr);
     zd_ddict_digest(g, *sh, dict, dictSize, dd);
     u64 r;
     if (dd->status) r = ZJ_ERR64(dd->status);
-    else { memset(sh, 0, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
+    else { memset(sh, 0x5A, sizeof(*sh)); r = zd_decompress<true>(g, *sh, src, srcSize, dst, dstCap, lit, pf, dd, dict); }
     free(dd); free(lit); free(sh);
     return r;
 }

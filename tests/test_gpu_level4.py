@@ -57,6 +57,28 @@ def test_gpu_level4_context_classes(gpu, oracle_ref):
     assert gpu.Zstd.compress(d, 4) == oracle_ref.compress(d, 4)
     ctx = gpu.ZstdCompressCtx(); ctx.setLevel(4); ctx.setChecksum(True)
     assert ctx.compress(d) == oracle_ref.compress(d, 4, True)
+    for level in (5, 6, 7, 8):                               # lazy / lazy2 on the hash chain, inputs <= 16 KiB
+        assert gpu.Zstd.compress(d, level) == oracle_ref.compress(d, level)
     with pytest.raises(gpu.ZstdException) as ex:
-        gpu.Zstd.compress(d, 5)                               # lazy: not served
+        gpu.Zstd.compress(d, 9)                               # btlazy2: not served
     assert ex.value.getErrorCode() == 42
+    with pytest.raises(gpu.ZstdException) as ex:
+        gpu.Zstd.compress(d * 2, 5)                           # 24 KB at level 5: the reference's row-based finder
+    assert ex.value.getErrorCode() == 201
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 8])
+def test_gpu_lazy_levels_small_inputs(gpu, oracle_ref, level):
+    datas = [d for d in _inputs(gpu, 30 + level, 1500) if len(d) <= 16384] + [gpu.synth_host(16385, 3, 1)]
+    outs = gpu.compress_batch(datas, level, checksum=(level % 2 == 0))
+    good = []
+    for d, z in zip(datas, outs):
+        if len(d) > 16384:
+            assert isinstance(z, Exception) and z.getErrorCode() == 201
+            continue
+        assert not isinstance(z, Exception), (len(d), z)
+        assert z == oracle_ref.compress(d, level, level % 2 == 0), (level, len(d))
+        good.append((d, z))
+    back = gpu.decompress_batch([z for _, z in good], [len(d) for d, _ in good])
+    for (d, _), b in zip(good, back):
+        assert b == d

@@ -35,9 +35,10 @@ while time.time() - t0 < budget:
         if rnd.random() < 0.3 and parts: parts.append(parts[rnd.randrange(len(parts))])
     d = b"".join(parts)[:size]
     ck = rnd.random() < 0.2; cs = rnd.random() < 0.85
-    got = util.emu_compress_multi(L, d, 4, ck, cs)
-    want = ref.compress(d, 4, ck, content_size=cs)
+    lvl = 4 if len(d) > 16384 else rnd.choice([4, 5, 6, 7, 8])           # levels 5-8: lazy / lazy2 on the hash chain, inputs <= 16 KiB
+    got = util.emu_compress_multi(L, d, lvl, ck, cs)
+    want = ref.compress(d, lvl, ck, content_size=cs)
     cases += 1; greedy += len(d) <= 16384
     if got != want:
-        bad += 1; open(f"/tmp/fuzz_l4_bad_{seed}_{cases}.bin", "wb").write(d); print("MISMATCH", size, ck, cs, flush=True)
+        bad += 1; open(f"/tmp/fuzz_l4_bad_{seed}_{cases}.bin", "wb").write(d); print("MISMATCH", size, lvl, ck, cs, flush=True)
 print("seed", seed, "cases", cases, "greedy", greedy, "bad", bad, flush=True)

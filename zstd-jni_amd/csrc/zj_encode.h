@@ -24,6 +24,7 @@
 // frames <= 4 KiB are then staged, gathered and assembled in LDS when the launch provides the room.
 #pragma once
 #include "zj_common.h"
+#include "zj_invprob.h"
 
 #if !ZJ_ON_GPU
 static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build
@@ -139,7 +140,7 @@ ZJ_HD void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
     if (chainLog > windowLog) chainLog = windowLog;
     if (windowLog < 10) windowLog = 10;
 }
-struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLog; };      // strategy: 1 fast, 2 double-fast, 3 greedy (hash chain), 0 = not served
+struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLog; };      // strategy (ZSTD_strategy): 1 fast, 2 double-fast, 3 greedy, 4 lazy, 5 lazy2 (3-5 on the hash chain), 0 = not served
 // "level" arguments are level words: the level in the low byte, then ZstdCompressCtx.setHashLog / setChainLog
 // (ZSTD_c_hashLog / ZSTD_c_chainLog, 0 = not set) — honoured for the double-fast strategy, whose tables live in HBM on
 // the lane-per-frame path and can therefore have the level's own sizes (16 / 15 at level 3) or any other.
@@ -153,6 +154,17 @@ struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLo
 ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     u32 const level = ZE_LW_LEVEL(levelWord), hl = ZE_LW_HL(levelWord), cl = ZE_LW_CL(levelWord);
     u32 w, c, h, mm, st;
+    if (level >= 5 && level <= 8) {
+        // clevels.h:111-114, inputs <= 16 KiB: lazy (level 5) and lazy2 (levels 6-8) on the hash chain — the window log stays <= 14, so the
+        // reference does not switch to its row-based finder; larger inputs at these levels do, and are not served (strategy 0)
+        ZEParams q; q.windowLog = q.chainLog = q.hashLog = q.minMatch = q.strategy = q.searchLog = 0;
+        if (srcSize > (16u << 10)) return q;
+        w = 14; c = 14; h = 14;
+        ze_adjust(w, c, h, srcSize);
+        q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = 4; q.strategy = level == 5 ? 4u : 5u;
+        q.searchLog = level == 5 ? 3u : (level == 6 ? 4u : (level == 7 ? 6u : 8u));
+        return q;
+    }
     if (level == 4) {
         // clevels.h:84 / :110.  <= 16 KiB: greedy on the hash chain (the window log stays <= 14, where the reference does not switch to its
         // row-based match finder, zstd_compress.c:238-245); <= 128 KiB: double-fast with 2^17-entry tables; beyond: greedy on the row
@@ -478,29 +490,57 @@ ZJ_DEV u32 ze_hc_find_best(ZEChain& m, const u8* ip, const u8* iLimit, u32* offB
     }
     return ml;
 }
-ZJ_DEV u32 ze_block_greedy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p, u32* hashTable, u32* chainTable) {
+// depth 0 = greedy, 1 = lazy, 2 = lazy2 (strategy - 3)
+ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p, u32* hashTable, u32* chainTable) {
     const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
     const u8* ip = istart + 1; const u8* anchor = istart;      // ip += (dictAndPrefixLength == 0)
     u32 off1 = 1, off2 = 0;                                    // rep {1,4}: 4 > maxRep == 1 at frame start (saved; only matters to a next block)
+    u32 const depth = p.strategy - 3u;
     ZEChain m; m.base = src - 2; m.hashTable = hashTable; m.chainTable = chainTable; m.hashLog = p.hashLog;
     m.chainSize = 1u << p.chainLog; m.chainMask = m.chainSize - 1u; m.nbAttemptsMax = 1u << p.searchLog;
     m.mls = p.minMatch < 4u ? 4u : (p.minMatch > 6u ? 6u : p.minMatch); m.nextToUpdate = 2u; m.lazySkipping = 0;
     while (ip < ilimit) {
         u32 matchLength = 0, offBase = 1u;                     // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
-        bool haveRep = false;
+        bool store = false;
         if ((off1 > 0) & (ld32(ip + 1 - off1) == ld32(ip + 1))) {                      // repcode at ip + 1: at depth 0 it is taken at once
-            matchLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4u; haveRep = true;
+            matchLength = ze_count(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4u;
+            if (depth == 0) store = true;
         }
-        if (!haveRep) {
-            u32 found = 999999999u;
-            u32 const ml2 = ze_hc_find_best(m, ip, iend, &found);
-            if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; }
+        if (!store) {
+            {   u32 found = 999999999u;                                              // first search (depth 0)
+                u32 const ml2 = ze_hc_find_best(m, ip, iend, &found);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; } }
             if (matchLength < 4u) {
                 u32 const step = ((u32)(ip - anchor) >> 8) + 1u;                     // kSearchStrength
                 ip += step;
                 m.lazySkipping = step > 8u;                                          // kLazySkippingStep
                 continue;
+            }
+            if (depth >= 1) while (ip < ilimit) {                                    // is the match that starts one (two) bytes later worth more?
+                ip++;
+                if ((offBase != 0) && ((off1 > 0) & (ld32(ip) == ld32(ip - off1)))) {
+                    u32 const mlRep = ze_count(ip + 4, ip + 4 - off1, iend) + 4u;
+                    i32 const gain2 = (i32)(mlRep * 3u), gain1 = (i32)(matchLength * 3u - zj_hibit(offBase) + 1u);
+                    if ((mlRep >= 4u) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1u; start = ip; }
+                }
+                {   u32 cand = 999999999u;
+                    u32 const ml2 = ze_hc_find_best(m, ip, iend, &cand);
+                    i32 const gain2 = (i32)(ml2 * 4u - zj_hibit(cand)), gain1 = (i32)(matchLength * 4u - zj_hibit(offBase) + 4u);
+                    if ((ml2 >= 4u) && (gain2 > gain1)) { matchLength = ml2; offBase = cand; start = ip; continue; } }
+                if ((depth == 2) && (ip < ilimit)) {
+                    ip++;
+                    if ((offBase != 0) && ((off1 > 0) & (ld32(ip) == ld32(ip - off1)))) {
+                        u32 const mlRep = ze_count(ip + 4, ip + 4 - off1, iend) + 4u;
+                        i32 const gain2 = (i32)(mlRep * 4u), gain1 = (i32)(matchLength * 4u - zj_hibit(offBase) + 1u);
+                        if ((mlRep >= 4u) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1u; start = ip; }
+                    }
+                    {   u32 cand = 999999999u;
+                        u32 const ml2 = ze_hc_find_best(m, ip, iend, &cand);
+                        i32 const gain2 = (i32)(ml2 * 4u - zj_hibit(cand)), gain1 = (i32)(matchLength * 4u - zj_hibit(offBase) + 7u);
+                        if ((ml2 >= 4u) && (gain2 > gain1)) { matchLength = ml2; offBase = cand; start = ip; continue; } }
+                }
+                break;                                                               // nothing better: store the previous solution
             }
             if (offBase > 3u) {                                                      // a real offset: catch up
                 u32 const off = offBase - 3u;
@@ -1213,7 +1253,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
     GRP_SERIAL(g) {
         sh.err = 0;
         if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
-        else ze_params(sh, level, ba ? ba->frameSize : srcSize);
+        else { ze_params(sh, level, ba ? ba->frameSize : srcSize); if (sh.strategy == 0) sh.err = 201; }     // a (level, size) the reference serves with a finder this library does not restate
         if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
         if (ba) { sh.hdrSize = 0; if (dstCap < 3u + 2u + 1u) sh.err = ZJ_E_DSTSIZE_TOO_SMALL; }     // zstd_compress.c:4629-4631
         else {
@@ -1270,7 +1310,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
             GRP_SERIAL(g) {
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 ZEParams q; q.windowLog = sh.windowLog; q.chainLog = clog; q.hashLog = hlog; q.minMatch = mls; q.strategy = strategy; q.searchLog = sh.searchLog;
-                u32 const lastLL = (strategy == 3) ? ze_block_greedy(o, src, srcSize, q, hbmTables, hbmTables + (1u << hlog))
+                u32 const lastLL = (strategy >= 3) ? ze_block_lazy(o, src, srcSize, q, hbmTables, hbmTables + (1u << hlog))
                                                    : ze_block_dfast<ZEEnt32>(o, src, srcSize, hlog, clog, mls, hbmTables, hbmTables + (1u << hlog));
                 sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL;
             }
@@ -1510,9 +1550,29 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
                         if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
                         else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
-                        else {
+                        else if (strat < 4u) {
                             u32 const dynMin = ((1u << defLog) * (10 - strat)) >> 3;
                             type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
+                        } else {
+                            // strategy >= lazy: the cheapest of predefined / new table by estimated cost (zstd_compress_sequences.c:196-222; no
+                            // previous table here: these levels are served without a dictionary and one block per frame).  An impossible choice
+                            // costs ERROR(GENERIC) = all ones there, the same here.
+                            u64 const none = ~(u64)0;
+                            u64 basicCost = none;
+                            if (defaultAllowed) {                                                              // ZSTD_crossEntropyCost(defaultNorm, defaultNormLog, count, max)
+                                u32 const shift = 8u - defLog; u64 c = 0;
+                                for (u32 s = 0; s <= max; s++) { u32 const na = defNorm[s] != -1 ? (u32)defNorm[s] : 1u; c += (u64)scount[s] * ze_k_invprob[na << shift]; }
+                                basicCost = c >> 8;
+                            }
+                            u64 compressedCost;
+                            {   u32 const tl = ze_fse_optimal_log(fseLog, nbSeq, max, 2);                      // ZSTD_NCountCost
+                                u64 ncount = none;
+                                if (ze_fse_normalize(e.norm, tl, scount, nbSeq, max, nbSeq >= 2048)) { u32 const hb = ze_fse_write_ncount((u8*)e.cumul, e.norm, max, tl); ncount = hb ? (u64)hb : none; }
+                                u32 cost = 0;                                                                  // ZSTD_entropyCost
+                                for (u32 s = 0; s <= max; s++) { u32 nr = (256u * scount[s]) / nbSeq; if (scount[s] != 0 && nr == 0) nr = 1; cost += scount[s] * ze_k_invprob[nr]; }
+                                compressedCost = (ncount << 3) + (u64)(cost >> 8);
+                            }
+                            type = (basicCost <= none && basicCost <= compressedCost) ? 0u : 2u;               // (repeatCost = ERROR(GENERIC): basic wins ties against it)
                         }
                         u32 h = 0;
                         u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];

@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
-    if (ZE_LW_LEVEL(level) == 4u) {                   // level 4: one block per frame, match-finder tables in HBM (zj_encode_multi_kernel); larger inputs need the row finder
-        if (listC && size <= ZE_BLOCK_MAX) listC[atomicAdd(&counters[4], 1u)] = i; else result[i] = ZJ_ERR64(201);
+    if (ZE_LW_LEVEL(level) >= 4u) {                   // levels 4-8: one block per frame, match-finder tables in HBM (zj_encode_multi_kernel); larger inputs need the row finder
+        if (listC && size <= (ZE_LW_LEVEL(level) == 4u ? ZE_BLOCK_MAX : (16u << 10))) listC[atomicAdd(&counters[4], 1u)] = i; else result[i] = ZJ_ERR64(201);
         return;
     }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src
 namespace {
 #define ZJ_ENC_LDS_BIG 131072u
 // pass-0 LDS per level: the tables of > 16 KiB inputs up to 64 KiB (u16 positions)
-#define ZJ_LEVEL_MAX 4                 /* levels 1-3 on every path; level 4 (inputs <= 128 KiB, no dictionary, no explicit table sizes) on the HBM-table kernel */
+#define ZJ_LEVEL_MAX 8                 /* levels 1-3 on every path; level 4 (inputs <= 128 KiB) and levels 5-8 (<= 16 KiB), no dictionary, no explicit table sizes, on the HBM-table kernel */
 size_t enc_lds_pass0(int level) {
     size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);

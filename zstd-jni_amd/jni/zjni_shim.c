@@ -361,7 +361,7 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDict0)(JNIEnv* env, jclass cls,
 static int gpu_takes(const CtxState* s, jint srcSize) {
     if (!s || s->cpuOnly || s->cpuDict || !per_buffer_on_gpu()) return 0;
     if (s->cdict) return s->contentSize;                               /* sizes beyond the attach range come back as 40 and are forwarded */
-    if (s->level == 4) return (size_t)srcSize <= ZJNI_LEVEL4_MAX && !(s->hashLog | s->chainLog);       /* level 4: one block, no explicit table sizes */
+    if (s->level >= 4 && s->level <= 8) return (size_t)srcSize <= (s->level == 4 ? ZJNI_LEVEL4_MAX : ZJNI_LAZY_MAX) && !(s->hashLog | s->chainLog);   /* one block, no explicit table sizes */
     return s->level >= 0 && s->level <= 3 && (size_t)srcSize <= ZJNI_FRAME_MAX;       /* beyond the level's window the library answers 201 and the call is forwarded */
 }
 static int frame_flags(const CtxState* s) {
@@ -538,7 +538,7 @@ JNIEXPORT jlong JNICALL P(Zstd_getFrameContentSize0)(JNIEnv* env, jclass cls, jb
 }
 JNIEXPORT jlong JNICALL P(Zstd_compressUnsafe)
   (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size, jint level, jboolean checksumFlag) {
-    if (per_buffer_on_gpu() && level >= 0 && (level <= 3 ? (size_t)src_size <= ZJNI_FRAME_MAX : (level == 4 && (size_t)src_size <= ZJNI_LEVEL4_MAX))) {
+    if (per_buffer_on_gpu() && level >= 0 && (level <= 3 ? (size_t)src_size <= ZJNI_FRAME_MAX : (level <= 8 && (size_t)src_size <= (level == 4 ? ZJNI_LEVEL4_MAX : ZJNI_LAZY_MAX)))) {
         size_t const r = zjni_compress2((void*)(intptr_t)dst, (size_t)dst_size, (const void*)(intptr_t)src, (size_t)src_size, level, checksumFlag == JNI_TRUE);
         if (gpu_result_final(r)) return (jlong)r;
     }
