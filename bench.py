@@ -361,8 +361,11 @@ def main():
         gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
         gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
         if a.e2e_sample:
-            me = max(1, min(a.e2e_sample, n, (4 << 30) // size))
-            e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
+            me = max(1, min(a.e2e_sample, n, m, (4 << 30) // size))         # (m: what the host has room for, see above)
+            try:
+                e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
+            except Exception as ex:                              # a reported extra, never a reason to lose the line (e.g. pinned staging refused on a small host)
+                e2e = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         ms = wall * 1000.0 / a.steps
