@@ -52,6 +52,36 @@ for hl, cl in ((16, 15), (17, 16), (9, 12)):
         if isinstance(z, Exception) or z != ref.compress(d, 3, False, hl, cl):
             bad += 1; print("MISMATCH tuned", hl, cl, k, len(d), flush=True)
     print(f"tables {hl}/{cl}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+# round 2: multi-block frames mixed with single-block ones (twice: a persistent workgroup meets leftovers of the same data), and
+# levels 4-8 (hash-chain finders <= 16 KiB, level 4's double-fast <= 128 KiB)
+WINDOW = {1: 1 << 19, 2: 1 << 20, 3: 1 << 21}
+for level in (1, 2, 3):
+    m = max(40, n // 40)
+    datas = [gen(rnd.choice([rnd.randrange(131073, 400000), rnd.randrange(131073, 2097153), 262144, 524288, rnd.randrange(0, 131073), 65536])) for _ in range(m)]
+    want = [None if len(d) > WINDOW[level] else (ref.compress(d, 3, False, 14, 13) if (level == 3 and len(d) <= 131072) else ref.compress(d, level)) for d in datas]
+    for rep in range(3):
+        outs = zj.compress_batch(datas, level)
+        for k, (d, z, w) in enumerate(zip(datas, outs, want)):
+            if w is None:
+                if not (isinstance(z, Exception) and z.getErrorCode() == 201): bad += 1; print("MISMATCH multi refusal", level, k, len(d), flush=True)
+            elif isinstance(z, Exception) or z != w:
+                bad += 1; print("MISMATCH multi", level, rep, k, len(d), z if isinstance(z, Exception) else len(z), flush=True)
+    good = [(d, z) for d, z in zip(datas, outs) if not isinstance(z, Exception)]
+    back = zj.decompress_batch([z for _, z in good], [len(d) for d, _ in good])
+    bad += sum(1 for b, (d, _) in zip(back, good) if b != d)
+    print(f"multi-block level {level}: {m} frames x 3, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+for level in (4, 5, 6, 7, 8):
+    cap = 131072 if level == 4 else 16384
+    for m in (n, 64):                                   # a large and a small batch
+        datas = [gen(s) for s in sizes(cap)][:m]
+        for rep in range(2):
+            outs = zj.compress_batch(datas, level, checksum=bool(rep))
+            for k, (d, z) in enumerate(zip(datas, outs)):
+                if isinstance(z, Exception) or z != ref.compress(d, level, bool(rep)):
+                    bad += 1; print("MISMATCH level", level, rep, k, len(d), z if isinstance(z, Exception) else len(z), flush=True)
+        back = zj.decompress_batch(outs, [len(d) for d in datas])
+        bad += sum(1 for b, d in zip(back, datas) if b != d)
+    print(f"level {level}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
 samples = [b",".join(recs[i * 13:i * 13 + 200])[:4096] for i in range(1000)]
 for dbytes in (ref.train_dict(samples, 112640), b",".join(recs[:300])):
     for level in (1, 3):
