@@ -347,25 +347,26 @@ def main():
             if neg:
                 gates["frames_with_error_result"] = neg
                 gates["error_results"] = sorted(set(csz[csz <= 0].cpu().tolist()))[:4]
-        # CPU baseline: the whole batch when the host has the memory (source + bound-sized frames + packed frames + decoded copy), else its head
-        m = a.cpu_sample if a.cpu_sample else n
-        need = m * (2 * size + 2 * bound)
-        avail = host_mem_available()
-        if avail and need > 0.6 * avail:
-            m = max(1024, int(0.6 * avail // (2 * size + 2 * bound)))
-        m = min(m, n)
-        if host_src is None or host_src.size < m * size:
-            host_src = src[:m * size].cpu().numpy()
-        cpu = cpu_baseline_leg(a, host_src, size, m, level, dict_bytes)
-        gpu_c_sample = int(csz[:m].sum().item())
-        gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
-        gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
-        if a.e2e_sample:
-            me = max(1, min(a.e2e_sample, n, m, (4 << 30) // size))         # (m: what the host has room for, see above)
-            try:
-                e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
-            except Exception as ex:                              # a reported extra, never a reason to lose the line (e.g. pinned staging refused on a small host)
-                e2e = {"error": f"{type(ex).__name__}: {ex}"}
+        if world == 1:                                     # the CPU legs belong to the N = 1 line only: at N > 1 seven ranks would wait for rank 0's host work
+            # CPU baseline: the whole batch when the host has the memory (source + bound-sized frames + packed frames + decoded copy), else its head
+            m = a.cpu_sample if a.cpu_sample else n
+            need = m * (2 * size + 2 * bound)
+            avail = host_mem_available()
+            if avail and need > 0.6 * avail:
+                m = max(1024, int(0.6 * avail // (2 * size + 2 * bound)))
+            m = min(m, n)
+            if host_src is None or host_src.size < m * size:
+                host_src = src[:m * size].cpu().numpy()
+            cpu = cpu_baseline_leg(a, host_src, size, m, level, dict_bytes)
+            gpu_c_sample = int(csz[:m].sum().item())
+            gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
+            gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
+            if a.e2e_sample:
+                me = max(1, min(a.e2e_sample, n, m, (4 << 30) // size))         # (m: what the host has room for, see above)
+                try:
+                    e2e = end_to_end_leg(zj, host_src, size, me, level, cdict._ptr if cdict else None, ddict._ptr if ddict else None)
+                except Exception as ex:                          # a reported extra, never a reason to lose the line (e.g. pinned staging refused on a small host)
+                    e2e = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         ms = wall * 1000.0 / a.steps
