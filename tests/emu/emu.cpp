@@ -162,6 +162,28 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
     return r;
 }
 
+// levels 4-8, frames <= 16 KiB, as the large-batch route runs them: chain parser per frame (zj_enc_match_chain_kernel's body) into the
+// record scratch, then the entropy stage on those records (zj_encode_kernel with `pre`)
+extern "C" unsigned long long emu_compress_chain(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    if (srcSize > (16u << 10)) return ZJ_ERR64(201);
+    Grp<1> g;
+    u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
+    EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
+    u32 const maxSrc = 16u << 10;
+    u32* table = (u32*)calloc(1, ((1u << 14) + (1u << 14)) * 4u);
+    u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(maxSrc));
+    u32 meta[3];
+    ZEOut o; o.seqs = (ZESeq*)fs; o.litOff = (u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
+    u32 lastLL = srcSize;
+    if (srcSize >= 7u) { ZEParams const p = ze_params_of(level, srcSize); lastLL = ze_block_lazy(o, src, srcSize, p, table, table + (1u << p.hashLog)); }
+    meta[0] = o.n; meta[1] = o.lit + lastLL; meta[2] = lastLL;
+    ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, &pre, flags, nullptr, 160u * 1024u);
+    free(fs); free(table);
+    return r;
+}
+
 // dictionary compression: digest (ZSTD_createCDict) + ZSTD_CCtx_refCDict / ZSTD_compress2
 #include "../../zstd-jni_amd/csrc/zj_cdict.h"
 extern "C" void* emu_cdict_create(const unsigned char* dict, unsigned dictSize, unsigned level) {

@@ -7,7 +7,7 @@ import random
 
 import pytest
 
-from util import emu_lib, emu_compress_multi, json_records
+from util import emu_lib, emu_compress_multi, emu_compress_chain, json_records
 
 
 @pytest.fixture(scope="module")
@@ -40,6 +40,8 @@ def test_emu_level4_byte_identical(L, zj, oracle_ref):
             got = emu_compress_multi(L, d, 4, ck, cs)
             want = oracle_ref.compress(d, 4, ck, content_size=cs)
             assert got == want, (len(d), ck, cs, got if isinstance(got, int) else len(got), len(want))
+            if len(d) <= 16384:
+                assert emu_compress_chain(L, d, 4, ck, cs) == want, ("chain route", len(d), ck, cs)
         strategies.add("greedy" if len(d) <= 16384 else "dfast")
     assert strategies == {"greedy", "dfast"}
 
@@ -61,5 +63,6 @@ def test_emu_lazy_levels_small_inputs_byte_identical(L, zj, oracle_ref, level):
             got = emu_compress_multi(L, d, level, ck, cs)
             want = oracle_ref.compress(d, level, ck, content_size=cs)
             assert got == want, (level, len(d), ck, cs, got if isinstance(got, int) else len(got), len(want))
+            assert emu_compress_chain(L, d, level, ck, cs) == want, ("chain route", level, len(d), ck, cs)      # the large-batch route: parser per lane, entropy stage on its records
         n += 1
     assert n > 60

@@ -20,7 +20,7 @@ def emu_lib():
     L.emu_decompress_split_dict.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.POINTER(C.c_int)]
     L.emu_decompress_dict.restype = C.c_ulonglong
     L.emu_decompress_dict.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
-    for fn in ("emu_compress", "emu_compress_split", "emu_compress_multi"):
+    for fn in ("emu_compress", "emu_compress_split", "emu_compress_multi", "emu_compress_chain"):
         if hasattr(L, fn):
             getattr(L, fn).restype = C.c_ulonglong
             getattr(L, fn).argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
@@ -111,6 +111,16 @@ def emu_compress_multi(L, data, level, checksum=False, content_size=True):
     cap = len(data) + (len(data) >> 8) + 64 + 128
     dst = C.create_string_buffer(cap)
     r = L.emu_compress_multi(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (0 if content_size else 0x200))
+    if r >= (1 << 63):
+        return -((1 << 64) - r)
+    return dst.raw[:r]
+
+
+def emu_compress_chain(L, data, level, checksum=False, content_size=True):
+    """levels 4-8, frames <= 16 KiB, the large-batch route (chain parser per frame, then the entropy stage on its records)"""
+    cap = len(data) + (len(data) >> 8) + 64 + 128
+    dst = C.create_string_buffer(cap)
+    r = L.emu_compress_chain(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (0 if content_size else 0x200))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

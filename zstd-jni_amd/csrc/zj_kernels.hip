@@ -191,8 +191,10 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
-    if (ZE_LW_LEVEL(level) >= 4u) {                   // levels 4-8: one block per frame, match-finder tables in HBM (zj_encode_multi_kernel); larger inputs need the row finder
-        if (listC && size <= (ZE_LW_LEVEL(level) == 4u ? ZE_BLOCK_MAX : (16u << 10))) listC[atomicAdd(&counters[4], 1u)] = i; else result[i] = ZJ_ERR64(201);
+    if (ZE_LW_LEVEL(level) >= 4u) {                   // levels 4-8: frames <= 16 KiB -> list A here = the lane-per-frame chain parsers (zj_enc_match_chain_kernel);
+        if (size <= (16u << 10)) listA[atomicAdd(&counters[0], 1u)] = i;                      // level 4 up to 128 KiB -> list C (double-fast with tables in HBM, one lane parses);
+        else if (listC && ZE_LW_LEVEL(level) == 4u && size <= ZE_BLOCK_MAX) listC[atomicAdd(&counters[4], 1u)] = i;
+        else result[i] = ZJ_ERR64(201);                                                        // larger inputs need the row finder
         return;
     }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
@@ -284,6 +286,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     list += listBase;
     if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
     else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
+}
+
+// Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
+// 64 frames per wave instead of one lane of 64 busy; the chain walk (up to 2^searchLog dependent candidate fetches per position)
+// keeps the lanes apart, so the wave runs the union of their paths, but every memory round trip still serves up to 64 frames.
+// Tables: hash then chain, u32, cleared by the host before the launch; records and meta where the entropy kernel expects them.
+#define ZE_CHAIN_MAX_SRC (16u << 10)
+#define ZE_CHAIN_TABLE_BYTES (((1u << 14) + (1u << 14)) * 4u)
+__global__ __launch_bounds__(64) void zj_enc_match_chain_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                                 const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                                 u8* tables, u8* fscratch, u32* meta) {
+    u32 const count = *countPtr;
+    for (;;) {
+        u32 const k = atomicAdd(workCounter, 1u);
+        if (k >= count) break;
+        u32 const i = list[k];
+        u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
+        u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(ZE_CHAIN_MAX_SRC); u32* const mt = meta + 3 * (size_t)k;
+        ZEOut o; o.seqs = (ZESeq*)fs; o.litOff = (u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZE_CHAIN_MAX_SRC) * 16u); o.n = 0; o.lit = 0;
+        u32 lastLL = size;
+        if (size >= 7u) {
+            ZEParams const p = ze_params_of(level, size);
+            u32* const t = (u32*)(tables + (size_t)k * ZE_CHAIN_TABLE_BYTES);
+            lastLL = ze_block_lazy(o, src + s0, size, p, t, t + (1u << p.hashLog));
+        }
+        mt[0] = o.n; mt[1] = o.lit + lastLL; mt[2] = lastLL;
+    }
 }
 
 // Wave-per-frame match finding (zj_match_wave.h): level-3 frames <= 64 KiB with the tables in LDS, claimed from the back of the
@@ -1058,7 +1087,30 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy));
     }
-    if (level > 3) return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);   // level 4: every frame was list C's
+    if (level > 3) {
+        // list A of levels 4-8 (frames <= 16 KiB): chain parsers lane-per-frame, then the entropy kernel on their records
+        u32 const maxSrcC = ZE_CHAIN_MAX_SRC;
+        size_t const tablesBytes = n * (size_t)ZE_CHAIN_TABLE_BYTES, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrcC), metaBytes = n * 12;
+        size_t const need = tablesBytes + fsBytes + metaBytes + 256;
+        if (d->splitBufCap < need) {
+            if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
+            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
+            if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+            d->splitBufCap = need;
+        }
+        u8* const tables = d->splitBuf; u8* const fs = d->splitBuf + tablesBytes; u32* const mt = (u32*)(fs + fsBytes);
+        u32* const mctr = d->counters + 24;
+        if (hipMemsetAsync(mctr, 0, 16, st) != hipSuccess || hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        u32 const waves = (u32)((n + 63) / 64);
+        hipLaunchKernelGGL(zj_enc_match_chain_kernel, dim3(waves < (u32)d->matchGrid * 2u ? waves : (u32)d->matchGrid * 2u), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off,
+                           (u32)levelWord, (const u32*)listA, (const u32*)ctr, mctr, tables, fs, mt);
+        u32 const ldsRun = (u32)sizeof(ZEEntropy);
+        u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
+        hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                           (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, (unsigned long long*)nullptr,
+                           fs, maxSrcC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
+        return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+    }
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
     // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
     size_t splitMin = 4096;
