@@ -33,8 +33,9 @@ extern "C" {
 #define ZJNI_LEVEL4_MAX (1u << 17)     /* level 4 (N/compress/clevels.h:84,110): greedy on the hash chain up to 16 KiB (ZSTD_compressBlock_greedy,
                                         * N/compress/zstd_lazy.c:1784), double-fast with 2^17-entry tables up to here; larger inputs run the
                                         * reference's row-based match finder, which this library does not restate: ZJNI_ERROR_unsupported */
-#define ZJNI_LAZY_MAX (1u << 14)       /* levels 5-8 (N/compress/clevels.h:111-114): lazy / lazy2 on the hash chain (ZSTD_compressBlock_lazy / _lazy2,
-                                        * N/compress/zstd_lazy.c:1516-1780) for inputs up to 16 KiB, where the reference keeps the chain */
+#define ZJNI_LAZY_MAX (1u << 17)       /* levels 5-8 (N/compress/clevels.h:85-88,111-114): greedy / lazy / lazy2 (ZSTD_compressBlock_lazy_generic,
+                                        * N/compress/zstd_lazy.c:1516-1780) on the hash chain for inputs up to 16 KiB and on the row-based finder
+                                        * (ZSTD_RowFindBestMatch, :1141) above, one block per frame */
 
 /* ---- library / device ---- */
 const char* zjni_version(void);

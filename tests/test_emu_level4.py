@@ -54,15 +54,14 @@ def test_emu_level4_beyond_128k_is_refused(L, zj):
 def test_emu_lazy_levels_small_inputs_byte_identical(L, zj, oracle_ref, level):
     """levels 5-8 up to 16 KiB: lazy / lazy2 on the hash chain (ZSTD_compressBlock_lazy_generic depth 1 / 2, N/compress/zstd_lazy.c:1624-1700)
     and the cost-based choice between the predefined and a new tANS table (strategy >= lazy, N/compress/zstd_compress_sequences.c:196-222)"""
-    n = 0
+    n = rows = 0
     for d in _cases(zj):
-        if len(d) > 16384:
-            if len(d) < 20000: assert emu_compress_multi(L, d, level) == -201
-            continue
         for ck, cs in ((False, True), (True, False)):
             got = emu_compress_multi(L, d, level, ck, cs)
             want = oracle_ref.compress(d, level, ck, content_size=cs)
             assert got == want, (level, len(d), ck, cs, got if isinstance(got, int) else len(got), len(want))
-            assert emu_compress_chain(L, d, level, ck, cs) == want, ("chain route", level, len(d), ck, cs)      # the large-batch route: parser per lane, entropy stage on its records
-        n += 1
-    assert n > 60
+            if len(d) <= 16384:
+                assert emu_compress_chain(L, d, level, ck, cs) == want, ("chain route", level, len(d), ck, cs)  # the large-batch route: parser per lane, entropy stage on its records
+        n += 1; rows += len(d) > 16384                          # above 16 KiB: the row-based finder (ZSTD_RowFindBestMatch)
+    assert n > 60 and rows > 20
+    assert emu_compress_multi(L, zj.synth_host(131073, 1, 1), level) == -201

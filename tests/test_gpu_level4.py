@@ -62,18 +62,21 @@ def test_gpu_level4_context_classes(gpu, oracle_ref):
     with pytest.raises(gpu.ZstdException) as ex:
         gpu.Zstd.compress(d, 9)                               # btlazy2: not served
     assert ex.value.getErrorCode() == 42
+    big = (d * 12)[:131072]
+    for level in (5, 6, 7, 8):                               # above 16 KiB: the row-based finder
+        assert gpu.Zstd.compress(big, level) == oracle_ref.compress(big, level)
     with pytest.raises(gpu.ZstdException) as ex:
-        gpu.Zstd.compress(d * 2, 5)                           # 24 KB at level 5: the reference's row-based finder
+        gpu.Zstd.compress(big + b"x", 5)                      # multi-block frames of these strategies: not served
     assert ex.value.getErrorCode() == 201
 
 
 @pytest.mark.parametrize("level", [5, 6, 7, 8])
-def test_gpu_lazy_levels_small_inputs(gpu, oracle_ref, level):
-    datas = [d for d in _inputs(gpu, 30 + level, 1500) if len(d) <= 16384] + [gpu.synth_host(16385, 3, 1)]
+def test_gpu_lazy_levels(gpu, oracle_ref, level):
+    datas = _inputs(gpu, 30 + level, 1500) + [gpu.synth_host(16385, 3, 1), gpu.synth_host(131073, 3, 1)]
     outs = gpu.compress_batch(datas, level, checksum=(level % 2 == 0))
     good = []
     for d, z in zip(datas, outs):
-        if len(d) > 16384:
+        if len(d) > 131072:
             assert isinstance(z, Exception) and z.getErrorCode() == 201
             continue
         assert not isinstance(z, Exception), (len(d), z)

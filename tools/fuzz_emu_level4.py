@@ -35,7 +35,7 @@ while time.time() - t0 < budget:
         if rnd.random() < 0.3 and parts: parts.append(parts[rnd.randrange(len(parts))])
     d = b"".join(parts)[:size]
     ck = rnd.random() < 0.2; cs = rnd.random() < 0.85
-    lvl = 4 if len(d) > 16384 else rnd.choice([4, 5, 6, 7, 8])           # levels 5-8: lazy / lazy2 on the hash chain, inputs <= 16 KiB
+    lvl = rnd.choice([4, 5, 6, 7, 8])                                   # levels 5-8: hash chain up to 16 KiB, the row-based finder above
     got = util.emu_compress_chain(L, d, lvl, ck, cs) if (len(d) <= 16384 and rnd.random() < 0.5) else util.emu_compress_multi(L, d, lvl, ck, cs)     # both routes of the kernels
     want = ref.compress(d, lvl, ck, content_size=cs)
     cases += 1; greedy += len(d) <= 16384

@@ -71,7 +71,7 @@ for level in (1, 2, 3):
     bad += sum(1 for b, (d, _) in zip(back, good) if b != d)
     print(f"multi-block level {level}: {m} frames x 3, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
 for level in (4, 5, 6, 7, 8):
-    cap = 131072 if level == 4 else 16384
+    cap = 131072
     for m in (n, 64):                                   # a large and a small batch
         datas = [gen(s) for s in sizes(cap)][:m]
         for rep in range(2):

@@ -140,7 +140,7 @@ ZJ_HD void ze_adjust(u32& windowLog, u32& chainLog, u32& hashLog, u32 srcSize) {
     if (chainLog > windowLog) chainLog = windowLog;
     if (windowLog < 10) windowLog = 10;
 }
-struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLog; };      // strategy (ZSTD_strategy): 1 fast, 2 double-fast, 3 greedy, 4 lazy, 5 lazy2 (3-5 on the hash chain), 0 = not served
+struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLog; };      // (window logs > 14 at strategies 3-5: the row-based finder, ze_params_uses_rows)      // strategy (ZSTD_strategy): 1 fast, 2 double-fast, 3 greedy, 4 lazy, 5 lazy2 (3-5 on the hash chain), 0 = not served
 // "level" arguments are level words: the level in the low byte, then ZstdCompressCtx.setHashLog / setChainLog
 // (ZSTD_c_hashLog / ZSTD_c_chainLog, 0 = not set) — honoured for the double-fast strategy, whose tables live in HBM on
 // the lane-per-frame path and can therefore have the level's own sizes (16 / 15 at level 3) or any other.
@@ -158,11 +158,18 @@ ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
         // clevels.h:111-114, inputs <= 16 KiB: lazy (level 5) and lazy2 (levels 6-8) on the hash chain — the window log stays <= 14, so the
         // reference does not switch to its row-based finder; larger inputs at these levels do, and are not served (strategy 0)
         ZEParams q; q.windowLog = q.chainLog = q.hashLog = q.minMatch = q.strategy = q.searchLog = 0;
-        if (srcSize > (16u << 10)) return q;
-        w = 14; c = 14; h = 14;
+        if (srcSize > (128u << 10)) return q;
+        if (srcSize <= (16u << 10)) {
+            w = 14; c = 14; h = 14;
+            q.strategy = level == 5 ? 4u : 5u;
+            q.searchLog = level == 5 ? 3u : (level == 6 ? 4u : (level == 7 ? 6u : 8u));
+        } else {                                              // clevels.h:85-88: greedy / lazy / lazy2 / lazy2 — on the row-based finder, the window log being > 14
+            w = 17; c = 16; h = 17;
+            q.strategy = level == 5 ? 3u : (level == 6 ? 4u : 5u);
+            q.searchLog = level == 8 ? 4u : 3u;
+        }
         ze_adjust(w, c, h, srcSize);
-        q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = 4; q.strategy = level == 5 ? 4u : 5u;
-        q.searchLog = level == 5 ? 3u : (level == 6 ? 4u : (level == 7 ? 6u : 8u));
+        q.windowLog = w; q.chainLog = c; q.hashLog = h; q.minMatch = 4;
         return q;
     }
     if (level == 4) {
@@ -206,6 +213,9 @@ ZJ_HD ZEParams ze_params_of(u32 levelWord, u32 srcSize) {
     ZEParams p; p.windowLog = w; p.chainLog = c; p.hashLog = h; p.minMatch = mm; p.strategy = st; p.searchLog = 1;
     return p;
 }
+// ZSTD_resolveRowMatchFinderMode (zstd_compress.c:238-245): greedy / lazy / lazy2 search rows of tagged entries instead of the hash
+// chain once the window log exceeds 14
+ZJ_HD bool ze_params_uses_rows(const ZEParams& p) { return p.strategy >= 3u && p.strategy <= 5u && p.windowLog > 14u; }
 ZJ_DEV void ze_params(ZEncShared& sh, u32 level, u32 srcSize) {
     ZEParams const p = ze_params_of(level, srcSize);
     sh.windowLog = p.windowLog; sh.chainLog = p.chainLog; sh.hashLog = p.hashLog; sh.minMatch = p.minMatch; sh.strategy = p.strategy; sh.searchLog = p.searchLog;
@@ -490,15 +500,91 @@ ZJ_DEV u32 ze_hc_find_best(ZEChain& m, const u8* ip, const u8* iLimit, u32* offB
     }
     return ml;
 }
-// depth 0 = greedy, 1 = lazy, 2 = lazy2 (strategy - 3)
-ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p, u32* hashTable, u32* chainTable) {
-    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+// ---- the row-based finder (ZSTD_RowFindBestMatch, N/compress/zstd_lazy.c:1141-1330, with ZSTD_row_update_internal :926-950 and
+// ZSTD_row_nextIndex :796-801): the hash table is cut into rows of 16 / 32 / 64 entries (rowLog = searchLog clamped to 4..6), a byte
+// table of the same shape holds an 8-bit tag per entry and, in each row's byte 0, the row's head; inserts walk the head downwards
+// (skipping slot 0), a search compares the tag against the whole row, visits the hits from the newest on and stops at 2^min(searchLog,
+// rowLog) candidates.  The reference's SIMD / SWAR mask and its 8-entry hash cache are ways to compute this faster: the cache always
+// holds the plain hash of its position (asserted there), so it is not modelled; the salt it mixes into the hash permutes rows and
+// tags without changing which positions share them, so it is 0 here.  hashTable: u32[1 << hashLog]; tags: u8[1 << hashLog] behind it.
+struct ZERow {
+    const u8* base; u32* hashTable; u8* tagTable; u32 rowHashLog, rowLog, rowMask, nbAttemptsMax, mls, nextToUpdate, lazySkipping;
+};
+ZJ_DEV u32 ze_row_next_index(u8* tagRow, u32 rowMask) {
+    u32 next = ((u32)tagRow[0] - 1u) & rowMask;
+    next += (next == 0) ? rowMask : 0;                     // skip slot 0 (the head itself)
+    tagRow[0] = (u8)next;
+    return next;
+}
+ZJ_DEV void ze_row_insert_range(ZERow& m, u32 from, u32 to) {
+    for (u32 idx = from; idx < to; idx++) {
+        u32 const hash = ze_hash(m.base + idx, m.rowHashLog + 8u, m.mls);
+        u32 const relRow = (hash >> 8) << m.rowLog;
+        u8* const tagRow = m.tagTable + relRow;
+        u32 const pos = ze_row_next_index(tagRow, m.rowMask);
+        tagRow[pos] = (u8)hash; m.hashTable[relRow + pos] = idx;
+    }
+}
+ZJ_DEV void ze_row_update(ZERow& m, u32 target) {            // ZSTD_row_update_internal: after a long gap only its two ends are inserted
+    u32 idx = m.nextToUpdate;
+    if (target - idx > 384u) { ze_row_insert_range(m, idx, idx + 96u); idx = target - 32u; }
+    ze_row_insert_range(m, idx, target);
+    m.nextToUpdate = target;
+}
+ZJ_DEV u32 ze_row_find_best(ZERow& m, const u8* ip, const u8* iLimit, u32* offBase) {
+    u32 const curr = (u32)(ip - m.base);
+    u32 const lowLimit = 2u;                                   // the frame fits its window, no dictionary
+    u32 nbAttempts = m.nbAttemptsMax, ml = 3u;
+    if (!m.lazySkipping) ze_row_update(m, curr); else m.nextToUpdate = curr;
+    u32 const hash = ze_hash(ip, m.rowHashLog + 8u, m.mls);
+    u32 const relRow = (hash >> 8) << m.rowLog, tag = hash & 0xFFu;
+    u32* const row = m.hashTable + relRow; u8* const tagRow = m.tagTable + relRow;
+    u32 const head = (u32)tagRow[0] & m.rowMask, rowEntries = m.rowMask + 1u;
+    u32 matchBuffer[64]; u32 numMatches = 0;
+    for (u32 j = 0; j < rowEntries && nbAttempts > 0; j++) {   // the rotated mask, newest entry first
+        u32 const matchPos = (head + j) & m.rowMask;
+        if (tagRow[matchPos] != (u8)tag) continue;
+        if (matchPos == 0) continue;
+        u32 const matchIndex = row[matchPos];
+        if (matchIndex < lowLimit) break;
+        matchBuffer[numMatches++] = matchIndex; --nbAttempts;
+    }
+    {   u32 const pos = ze_row_next_index(tagRow, m.rowMask);   // the current position goes in right away
+        tagRow[pos] = (u8)tag; row[pos] = m.nextToUpdate++; }
+    for (u32 k = 0; k < numMatches; k++) {
+        u32 const matchIndex = matchBuffer[k];
+        const u8* const match = m.base + matchIndex;
+        u32 currentMl = 0;
+        if (ld32(match + ml - 3) == ld32(ip + ml - 3)) currentMl = ze_count(ip, match, iLimit);
+        if (currentMl > ml) {
+            ml = currentMl; *offBase = (curr - matchIndex) + 3u;
+            if (ip + currentMl == iLimit) break;
+        }
+    }
+    return ml;
+}
+// search front end of the lazy parser: the hash chain (window log <= 14) or the rows
+struct ZEFinder { bool rows; ZEChain c; ZERow r; };
+ZJ_DEV u32 ze_find_best(ZEFinder& f, const u8* ip, const u8* iLimit, u32* offBase) { return f.rows ? ze_row_find_best(f.r, ip, iLimit, offBase) : ze_hc_find_best(f.c, ip, iLimit, offBase); }
+ZJ_DEV void ze_finder_skip(ZEFinder& f, bool on) { if (f.rows) f.r.lazySkipping = on ? 1u : 0u; else f.c.lazySkipping = on ? 1u : 0u; }
+
+// depth 0 = greedy, 1 = lazy, 2 = lazy2 (strategy - 3).  `second`: the chain table, or with rows the tag table (bytes)
+ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p, u32* hashTable, u32* second) {
+    bool const rows = ze_params_uses_rows(p);
+    u32* const chainTable = second;
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8 - (rows ? 8 : 0);   // (ZSTD_ROW_HASH_CACHE_SIZE)
     const u8* ip = istart + 1; const u8* anchor = istart;      // ip += (dictAndPrefixLength == 0)
     u32 off1 = 1, off2 = 0;                                    // rep {1,4}: 4 > maxRep == 1 at frame start (saved; only matters to a next block)
     u32 const depth = p.strategy - 3u;
-    ZEChain m; m.base = src - 2; m.hashTable = hashTable; m.chainTable = chainTable; m.hashLog = p.hashLog;
-    m.chainSize = 1u << p.chainLog; m.chainMask = m.chainSize - 1u; m.nbAttemptsMax = 1u << p.searchLog;
-    m.mls = p.minMatch < 4u ? 4u : (p.minMatch > 6u ? 6u : p.minMatch); m.nextToUpdate = 2u; m.lazySkipping = 0;
+    ZEFinder m; m.rows = rows;
+    u32 const mls = p.minMatch < 4u ? 4u : (p.minMatch > 6u ? 6u : p.minMatch);
+    m.c.base = src - 2; m.c.hashTable = hashTable; m.c.chainTable = chainTable; m.c.hashLog = p.hashLog;
+    m.c.chainSize = 1u << p.chainLog; m.c.chainMask = m.c.chainSize - 1u; m.c.nbAttemptsMax = 1u << p.searchLog;
+    m.c.mls = mls; m.c.nextToUpdate = 2u; m.c.lazySkipping = 0;
+    {   u32 const rowLog = p.searchLog < 4u ? 4u : (p.searchLog > 6u ? 6u : p.searchLog);
+        m.r.base = src - 2; m.r.hashTable = hashTable; m.r.tagTable = (u8*)second; m.r.rowLog = rowLog; m.r.rowMask = (1u << rowLog) - 1u;
+        m.r.rowHashLog = p.hashLog - rowLog; m.r.nbAttemptsMax = 1u << (p.searchLog < rowLog ? p.searchLog : rowLog);
+        m.r.mls = mls; m.r.nextToUpdate = 2u; m.r.lazySkipping = 0; }
     while (ip < ilimit) {
         u32 matchLength = 0, offBase = 1u;                     // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
@@ -509,12 +595,12 @@ ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p
         }
         if (!store) {
             {   u32 found = 999999999u;                                              // first search (depth 0)
-                u32 const ml2 = ze_hc_find_best(m, ip, iend, &found);
+                u32 const ml2 = ze_find_best(m, ip, iend, &found);
                 if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = found; } }
             if (matchLength < 4u) {
                 u32 const step = ((u32)(ip - anchor) >> 8) + 1u;                     // kSearchStrength
                 ip += step;
-                m.lazySkipping = step > 8u;                                          // kLazySkippingStep
+                ze_finder_skip(m, step > 8u);                                          // kLazySkippingStep
                 continue;
             }
             if (depth >= 1) while (ip < ilimit) {                                    // is the match that starts one (two) bytes later worth more?
@@ -525,7 +611,7 @@ ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p
                     if ((mlRep >= 4u) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1u; start = ip; }
                 }
                 {   u32 cand = 999999999u;
-                    u32 const ml2 = ze_hc_find_best(m, ip, iend, &cand);
+                    u32 const ml2 = ze_find_best(m, ip, iend, &cand);
                     i32 const gain2 = (i32)(ml2 * 4u - zj_hibit(cand)), gain1 = (i32)(matchLength * 4u - zj_hibit(offBase) + 4u);
                     if ((ml2 >= 4u) && (gain2 > gain1)) { matchLength = ml2; offBase = cand; start = ip; continue; } }
                 if ((depth == 2) && (ip < ilimit)) {
@@ -536,7 +622,7 @@ ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p
                         if ((mlRep >= 4u) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1u; start = ip; }
                     }
                     {   u32 cand = 999999999u;
-                        u32 const ml2 = ze_hc_find_best(m, ip, iend, &cand);
+                        u32 const ml2 = ze_find_best(m, ip, iend, &cand);
                         i32 const gain2 = (i32)(ml2 * 4u - zj_hibit(cand)), gain1 = (i32)(matchLength * 4u - zj_hibit(offBase) + 7u);
                         if ((ml2 >= 4u) && (gain2 > gain1)) { matchLength = ml2; offBase = cand; start = ip; continue; } }
                 }
@@ -550,7 +636,7 @@ ZJ_DEV u32 ze_block_lazy(ZEOut& o, const u8* src, u32 srcSize, const ZEParams& p
         }
         ze_store(o, (u32)(anchor - istart), (u32)(start - anchor), offBase, matchLength);
         anchor = ip = start + matchLength;
-        m.lazySkipping = 0;
+        ze_finder_skip(m, false);
         while ((ip <= ilimit) & (off2 > 0) && (ld32(ip) == ld32(ip - off2))) {        // immediate repcode
             matchLength = ze_count(ip + 4, ip + 4 - off2, iend) + 4u;
             { u32 const t = off2; off2 = off1; off1 = t; }
@@ -1302,7 +1388,8 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
             }
             zj_mem_order();
         } else if (!pre && hbmTables) {                    // level 4: tables too large for LDS, one set per resident workgroup in HBM (zj_encode_multi_kernel)
-            u32 const entries = (1u << hlog) + (1u << clog);
+            u32 const entries = (strategy >= 3 && ZJ_UNI(sh.windowLog) > 14u) ? (1u << hlog) + (1u << hlog) / 4u      // rows: u32 entries + a byte of tag each
+                                                                                 : (1u << hlog) + (1u << clog);
             GRP_FOR(g, i, entries) hbmTables[i] = 0;
             zj_mem_order();
             g.sync();

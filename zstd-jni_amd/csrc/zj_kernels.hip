@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
     if (i >= n) return;
     u64 const size = srcOff[i + 1] - srcOff[i];
     if (ZE_LW_LEVEL(level) >= 4u) {                   // levels 4-8: frames <= 16 KiB -> list A here = the lane-per-frame chain parsers (zj_enc_match_chain_kernel);
-        if (size <= (16u << 10)) listA[atomicAdd(&counters[0], 1u)] = i;                      // level 4 up to 128 KiB -> list C (double-fast with tables in HBM, one lane parses);
-        else if (listC && ZE_LW_LEVEL(level) == 4u && size <= ZE_BLOCK_MAX) listC[atomicAdd(&counters[4], 1u)] = i;
-        else result[i] = ZJ_ERR64(201);                                                        // larger inputs need the row finder
+        if (size <= (16u << 10)) listA[atomicAdd(&counters[0], 1u)] = i;                      // up to 128 KiB -> list C (level 4: double-fast, levels 5-8: the row-based finder;
+        else if (listC && size <= ZE_BLOCK_MAX) listC[atomicAdd(&counters[4], 1u)] = i;       //   tables in HBM, one lane parses);
+        else result[i] = ZJ_ERR64(201);                                                        // larger inputs: multi-block frames of these strategies are not served
         return;
     }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
