@@ -114,3 +114,20 @@ def test_port_encoder_scope_and_errors(oracle_port):
         oracle_port.compress(b"x" * 131073, 3)
     assert e.value.code == 40
     assert oracle_port.compress(b"", 3) == bytes.fromhex("28b52ffd2000010000")
+
+
+def test_entropy_cost_table_equals_the_references():
+    """zj_invprob.h (generated by tools/gen_invprob.py with exact integer arithmetic: floor(256 * -log2(x / 256))) is the table
+    ZSTD_entropyCost / ZSTD_crossEntropyCost index (N/compress/zstd_compress_sequences.c:21-44); compared when the reference tree is here"""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = [int(x) for x in re.findall(r"\d+", open(os.path.join(root, "zstd-jni_amd", "csrc", "zj_invprob.h")).read().split("{")[1])]
+    assert len(gen) == 256 and gen[0] == 0 and gen[1] == 2048 and gen[128] == 256 and gen[255] == 1
+    assert all(gen[i] >= gen[i + 1] for i in range(1, 255))
+    for x in (3, 5, 7, 100, 200, 251):                     # floor(2048 - 256 * log2 x), checked with integers: 2^(2048 - v) >= x^256 > 2^(2047 - v)
+        v = gen[x]
+        assert (1 << (2048 - v)) >= x ** 256 > (1 << (2047 - v))
+    src = "/root/reference/src/main/native/compress/zstd_compress_sequences.c"
+    if os.path.exists(src):
+        m = re.search(r"kInverseProbabilityLog256\[256\] = \{(.*?)\};", open(src).read(), re.S)
+        assert [int(x) for x in re.findall(r"\d+", m.group(1))] == gen
