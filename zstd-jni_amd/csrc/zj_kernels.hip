@@ -315,6 +315,45 @@ __global__ __launch_bounds__(64) void zj_enc_match_chain_kernel(const u8* __rest
     }
 }
 
+// Levels 4-8, 16 KiB < frame <= 128 KiB, large batches: the same plain-loop parsers one lane per frame — level 4's double-fast with
+// 2^17-entry tables, levels 5-8 on the row-based finder — with a table set (ZE_MULTI_TABLE_BYTES) per LANE SLOT of the launch instead
+// of per frame: a wave's lanes each claim a frame, the wave clears the claimed slots' tables together (coalesced), every lane parses
+// its frame, repeat.  Records and meta go to slice-relative slots; the entropy kernel follows on the same slice.
+__global__ __launch_bounds__(64) void zj_enc_match_big_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                               const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                               u32* tables, u8* fscratch, u32* meta, u32 listBase, u32 sliceLen) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    list += listBase;
+    u32* const t = tables + ((size_t)blockIdx.x * 64u + threadIdx.x) * (ZE_MULTI_TABLE_BYTES / 4u);
+    for (;;) {
+        u32 const k = atomicAdd(workCounter, 1u);
+        bool const have = k < count;
+        if (!__ballot(have)) break;
+        u32 size = 0, entries = 0; u64 s0 = 0; ZEParams p; p.windowLog = p.chainLog = p.hashLog = p.minMatch = p.strategy = p.searchLog = 0;
+        if (have) {
+            u32 const i = list[k];
+            s0 = srcOff[i]; size = (u32)(srcOff[i + 1] - s0);
+            p = ze_params_of(level, size);
+            entries = ze_params_uses_rows(p) ? (1u << p.hashLog) + (1u << p.hashLog) / 4u : (1u << p.hashLog) + (1u << p.chainLog);
+        }
+        for (u64 m = __ballot(have && size >= 7u); m; m &= m - 1) {          // clear the claimed slots' tables, one slot at a time, all lanes
+            u32 const j = (u32)__builtin_ctzll(m);
+            u32* const tj = tables + ((size_t)blockIdx.x * 64u + j) * (ZE_MULTI_TABLE_BYTES / 4u);
+            u32 const ej = (u32)__shfl((int)entries, (int)j, 64);
+            for (u32 x = threadIdx.x; x < ej; x += 64u) tj[x] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (have) {
+            u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(ZE_BLOCK_MAX); u32* const mt = meta + 3 * (size_t)k;
+            ZEOut o; o.seqs = (ZESeq*)fs; o.litOff = (u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZE_BLOCK_MAX) * 16u); o.n = 0; o.lit = 0;
+            u32 lastLL = size;
+            if (size >= 7u) lastLL = p.strategy >= 3u ? ze_block_lazy(o, src + s0, size, p, t, t + (1u << p.hashLog))
+                                                      : ze_block_dfast<ZEEnt32>(o, src + s0, size, p.hashLog, p.chainLog, p.minMatch, t, t + (1u << p.hashLog));
+            mt[0] = o.n; mt[1] = o.lit + lastLL; mt[2] = lastLL;
+        }
+    }
+}
+
 // Wave-per-frame match finding (zj_match_wave.h): level-3 frames <= 64 KiB with the tables in LDS, claimed from the back of the
 // sorted list.  Records and meta of list entry k go where the lane kernel would put them, completion goes to the same queue.
 __global__ __launch_bounds__(64) void zj_enc_match_wave_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
@@ -566,6 +605,7 @@ __global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src
 namespace {
 #define ZJ_ENC_LDS_BIG 131072u
 // pass-0 LDS per level: the tables of > 16 KiB inputs up to 64 KiB (u16 positions)
+#define ZJ_BIG_SLICE ((size_t)16384)    /* frames of 16-128 KiB at levels 4-8 per pass of the lane-per-frame route (655 KiB of records each) */
 #define ZJ_LEVEL_MAX 8                 /* levels 1-3 on every path; level 4 (inputs <= 128 KiB) and levels 5-8 (<= 16 KiB), no dictionary, no explicit table sizes, on the HBM-table kernel */
 size_t enc_lds_pass0(int level) {
     size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
@@ -1077,7 +1117,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     u32 const ldsA = level > 3 ? 0u : (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
-    {   // list C: multi-block frames.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 768 KiB per resident workgroup.
+    // levels 4-8, frames of 16-128 KiB: one lane per frame when the batch is large (below) and the scratch budget has room for a table set
+    // per lane slot, else one wave per frame (here)
+    bool const bigLanes = level > 3 && n >= 4096 && (!g_scratch_limit || g_scratch_limit >= ((size_t)48 << 30));
+    if (!bigLanes)
+    {   // list C: multi-block frames (levels 1-3) and the single-block frames of levels 4-8 above 16 KiB.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 1 MiB per resident workgroup.
         if (!d->multiTables) {
             int perCU = 4; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
             d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
@@ -1109,6 +1153,32 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, (unsigned long long*)nullptr,
                            fs, maxSrcC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
+        if (bigLanes) {
+            // list C in slices of ZJ_BIG_SLICE frames: [table set per lane slot][records per frame of the slice][meta]
+            size_t bigWaves = (size_t)d->numCU;           // measured at level 5, 65 536 x 64 KiB: 128 / 256 / 512 / 1 024 waves -> 3.69 / 1.95 / 2.44 / 2.74 s (1 MiB of table per lane slot: beyond one wave per CU the rows' random requests take over)
+            if (const char* ov = getenv("ZJNI_BIG_WAVES")) { long const v = atol(ov); if (v >= 1 && v <= 4096) bigWaves = (size_t)v; }
+            size_t const slots = bigWaves * 64, tablesB = slots * ZE_MULTI_TABLE_BYTES;
+            size_t const fsB = (size_t)ZJ_BIG_SLICE * ZE_FRAME_STRIDE(ZE_BLOCK_MAX), needB = tablesB + fsB + (size_t)ZJ_BIG_SLICE * 12 + 256;
+            if (d->wideBufCap < needB) {
+                if (!scratch_make_room(d, d->wideBufCap, needB)) return ZJNI_ERR(64);
+                if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
+                if (hipMalloc(&d->wideBuf, needB) != hipSuccess) return ZJNI_ERR(64);
+                d->wideBufCap = needB;
+            }
+            u32* const tb = (u32*)d->wideBuf; u8* const fsb = d->wideBuf + tablesB; u32* const mtb = (u32*)(fsb + fsB);
+            u32* const wctr = d->counters + 48;       // [2s] match work, [2s + 1] entropy work of slice s
+            size_t const passes = (n + ZJ_BIG_SLICE - 1) / ZJ_BIG_SLICE;
+            if (hipMemsetAsync(wctr, 0, 8 * passes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            for (size_t sN = 0; sN < passes; sN++) {
+                u32 const base = (u32)(sN * ZJ_BIG_SLICE);
+                hipLaunchKernelGGL(zj_enc_match_big_kernel, dim3((u32)(slots / 64)), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   (const u32*)listC, (const u32*)(ctr + 4), wctr + 2 * sN, tb, fsb, mtb, base, (u32)ZJ_BIG_SLICE);
+                u32 const gridB = (u32)(ZJ_BIG_SLICE < (size_t)d->encGridLvl[1] ? ZJ_BIG_SLICE : (size_t)d->encGridLvl[1]);
+                hipLaunchKernelGGL(zj_encode_kernel, dim3(gridB), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                                   (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), wctr + 2 * sN + 1, d->encScratch, (unsigned long long*)nullptr,
+                                   fsb, (u32)ZE_BLOCK_MAX, (const u32*)mtb, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), base, (u32)ZJ_BIG_SLICE);
+            }
+        }
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
@@ -1255,7 +1325,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
     BatchOrder order(cur_state(), stream);
-    size_t const chunk = scratch_slice((size_t)ze_lane_table_stride((u32)level, false) + ZE_FRAME_STRIDE(65536u) + 21, ZJ_CHUNK_FRAMES, 2);
+    size_t const perFrame = ZE_LW_LEVEL((u32)level) > 3u ? (size_t)ZE_CHAIN_TABLE_BYTES + ZE_FRAME_STRIDE(ZE_CHAIN_MAX_SRC) + 21
+                                                          : (size_t)ze_lane_table_stride((u32)level, false) + ZE_FRAME_STRIDE(65536u) + 21;
+    size_t const chunk = scratch_slice(perFrame, ZJ_CHUNK_FRAMES, 2);
     for (size_t at = 0; at < n || at == 0; at += chunk) {
         size_t const m = n - at < chunk ? n - at : chunk;
         size_t const r = compress_batch_device_impl(d_src, d_src_off + at, d_dst, d_dst_off + at, d_result + at, m, level, flags, stream);
