@@ -134,7 +134,8 @@ int main(int argc, char** argv) {
     }
     /* ZstdCompressCtx / ZstdDecompressCtx one-shot natives, direct buffers and byte[] */
     int const maxLevel = getenv("HARNESS_MAX_LEVEL") ? atoi(getenv("HARNESS_MAX_LEVEL")) : 3;
-    for (int level = 1; level <= maxLevel; level++) for (int ck = 0; ck < 2; ck++) {
+    int const plainMax = getenv("HARNESS_PLAIN_MAX_LEVEL") ? atoi(getenv("HARNESS_PLAIN_MAX_LEVEL")) : maxLevel;   /* the one-shot natives without a dictionary: levels 4-8 too on the GPU */
+    for (int level = 1; level <= plainMax; level++) for (int ck = 0; ck < 2; ck++) {
         jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
         R.setLevel(e, NULL, rc, level); G.setLevel(e, NULL, gc, level);
         R.setChecksum(e, NULL, rc, ck ? JNI_TRUE : JNI_FALSE); G.setChecksum(e, NULL, gc, ck ? JNI_TRUE : JNI_FALSE);
