@@ -179,6 +179,18 @@ size_t zjni_decompress_batch_multi(const void* const* src, const size_t* srcSize
                                    void* const* dst, const size_t* dstCapacity,
                                    size_t* result, size_t n, const int* devices, int nDevices);
 
+/* ---- cross-thread aggregation of per-buffer calls ----
+ * zstd-jni's per-buffer natives (N/jni_fast_zstd.c:586-640, :777-905) are called from many threads, one buffer each.  An aggregator
+ * turns concurrent blocking calls into batches: the first caller of a kind (compress at a level + checksum flag / decompress) opens a
+ * batch and waits up to maxWaitMicros (or until maxBatch callers have joined), then runs zjni_compress_batch2 / zjni_decompress_batch
+ * once for everybody.  Each call returns what the per-buffer form would (frame size or error code).  stats: calls made, batches run. */
+typedef struct zjni_aggregator zjni_aggregator;
+zjni_aggregator* zjni_createAggregator(int device, size_t maxBatch, unsigned maxWaitMicros);
+void zjni_freeAggregator(zjni_aggregator* a);
+size_t zjni_aggregator_compress(zjni_aggregator* a, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksum);
+size_t zjni_aggregator_decompress(zjni_aggregator* a, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+void zjni_aggregator_stats(zjni_aggregator* a, unsigned long long* calls, unsigned long long* batches);
+
 /* ---- per-buffer forms with the exact argument meaning of the calls they replace ---- */
 /* ZSTD_compress2(cctx{level}, dst, dstCapacity, src, srcSize): N/jni_fast_zstd.c:607 */
 size_t zjni_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level);

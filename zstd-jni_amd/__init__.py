@@ -141,6 +141,16 @@ def lib():
     for fn in ("zjni_set_scratch_limit", "zjni_scratch_bytes", "zjni_release_scratch"):
         getattr(L, fn).restype = sz
     L.zjni_set_scratch_limit.argtypes = [sz]
+    L.zjni_createAggregator.restype = vp
+    L.zjni_createAggregator.argtypes = [C.c_int, sz, C.c_uint]
+    L.zjni_freeAggregator.restype = None
+    L.zjni_freeAggregator.argtypes = [vp]
+    L.zjni_aggregator_compress.restype = sz
+    L.zjni_aggregator_compress.argtypes = [vp, vp, sz, vp, sz, C.c_int, C.c_int]
+    L.zjni_aggregator_decompress.restype = sz
+    L.zjni_aggregator_decompress.argtypes = [vp, vp, sz, vp, sz]
+    L.zjni_aggregator_stats.restype = None
+    L.zjni_aggregator_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.zjni_kernel_info.restype = C.c_int
     L.zjni_kernel_info.argtypes = [C.POINTER(C.c_int)] * 4
     L.zjni_shutdown.restype = None
@@ -159,7 +169,8 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_decompress_batch_usingDDict", "zjni_decompress_usingDDict",
            "zjni_createCDict", "zjni_freeCDict", "zjni_getDictID_fromCDict", "zjni_compress_batch_device_usingCDict",
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
-           "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced")
+           "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
+           "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

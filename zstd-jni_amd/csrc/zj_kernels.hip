@@ -8,6 +8,10 @@
 #include <mutex>
 #include <algorithm>
 #include <thread>
+#include <condition_variable>
+#include <chrono>
+#include <map>
+#include <memory>
 #include <vector>
 #include <string.h>
 #include <stdio.h>
@@ -1694,6 +1698,77 @@ size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSiz
     if (level < 1 || level > ZJ_LEVEL_MAX || (level > 3 && (hashLog | chainLog))) return ZJNI_ERR(42);
     return host_batch(true, src, srcSize, dst, dstCap, result, n, lw, checksum);
 }
+// ---- cross-thread aggregation of per-buffer calls (second half) ----
+// zstd-jni's per-buffer natives are called from many threads, one context each, one buffer per call; a GPU wants thousands of
+// buffers per launch.  An aggregator turns concurrent blocking per-buffer calls into batches: the first caller of a kind (compress
+// at a level + checksum flag, or decompress) opens a batch and waits up to maxWaitMicros for company, callers that arrive meanwhile
+// join it, the opener runs the batch entry once and everybody returns with its own result.  Results are those of the batch entries
+// (byte-identical frames); what changes is latency (up to the wait) against launches shared.  One device per aggregator.
+struct ZjAggReq { const void* src; size_t srcSize; void* dst; size_t dstCap; size_t result; };
+struct ZjAggBatch { std::vector<ZjAggReq*> reqs; bool closed = false, done = false; size_t rc = 0; };
+struct zjni_aggregator {
+    int device; size_t maxBatch; unsigned maxWaitMicros;
+    std::mutex mu; std::condition_variable cv;
+    std::map<int, std::shared_ptr<ZjAggBatch> > open;           // kind -> the batch that is still taking members
+    unsigned long long calls = 0, batches = 0;
+};
+static size_t agg_submit(zjni_aggregator* a, int kind, ZjAggReq& rq, int level, int checksum) {
+    if (!a) return ZJNI_ERR(ZJNI_ERROR_unsupported);
+    std::unique_lock<std::mutex> lk(a->mu);
+    a->calls++;
+    std::shared_ptr<ZjAggBatch> b;
+    auto it = a->open.find(kind);
+    bool leader = false;
+    if (it == a->open.end() || it->second->closed) { b = std::make_shared<ZjAggBatch>(); a->open[kind] = b; leader = true; a->batches++; }
+    else b = it->second;
+    b->reqs.push_back(&rq);
+    if (b->reqs.size() >= a->maxBatch) { b->closed = true; a->cv.notify_all(); }
+    if (!leader) {
+        a->cv.wait(lk, [&]() { return b->done; });
+        return zjni_isError(b->rc) ? b->rc : rq.result;
+    }
+    // the opener: wait for company, close the batch, run it outside the lock
+    a->cv.wait_for(lk, std::chrono::microseconds(a->maxWaitMicros), [&]() { return b->closed; });
+    b->closed = true;
+    if (a->open[kind] == b) a->open.erase(kind);
+    std::vector<ZjAggReq*> reqs = b->reqs;                       // (members only join while !closed: the list is final)
+    lk.unlock();
+    size_t const n = reqs.size();
+    std::vector<const void*> sp(n); std::vector<size_t> ss(n), dc(n), res(n); std::vector<void*> dp(n);
+    for (size_t i = 0; i < n; i++) { sp[i] = reqs[i]->src; ss[i] = reqs[i]->srcSize; dp[i] = reqs[i]->dst; dc[i] = reqs[i]->dstCap; }
+    size_t rc = 0;
+    if (zjni_init(a->device) != 0) rc = ZJNI_ERR(ZJNI_ERROR_no_device);
+    else rc = kind < 0 ? zjni_decompress_batch(sp.data(), ss.data(), dp.data(), dc.data(), res.data(), n)
+                       : zjni_compress_batch2(sp.data(), ss.data(), dp.data(), dc.data(), res.data(), n, level, checksum);
+    lk.lock();
+    for (size_t i = 0; i < n; i++) reqs[i]->result = res[i];
+    b->rc = rc; b->done = true;
+    a->cv.notify_all();
+    return zjni_isError(rc) ? rc : rq.result;
+}
+zjni_aggregator* zjni_createAggregator(int device, size_t maxBatch, unsigned maxWaitMicros) {
+    if (device < 0 || device >= dev_count() || maxBatch < 1) return nullptr;
+    zjni_aggregator* a = new zjni_aggregator();
+    a->device = device; a->maxBatch = maxBatch > 65536 ? 65536 : maxBatch; a->maxWaitMicros = maxWaitMicros;
+    return a;
+}
+void zjni_freeAggregator(zjni_aggregator* a) { delete a; }        // no call may be in flight
+size_t zjni_aggregator_compress(zjni_aggregator* a, void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum) {
+    if (level == 0) level = 3;
+    if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
+    ZjAggReq rq = { src, srcSize, dst, dstCap, 0 };
+    return agg_submit(a, level * 2 + (checksum ? 1 : 0), rq, level, checksum ? 1 : 0);
+}
+size_t zjni_aggregator_decompress(zjni_aggregator* a, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    ZjAggReq rq = { src, srcSize, dst, dstCap, 0 };
+    return agg_submit(a, -1, rq, 0, 0);
+}
+void zjni_aggregator_stats(zjni_aggregator* a, unsigned long long* calls, unsigned long long* batches) {
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (calls) *calls = a->calls;
+    if (batches) *batches = a->batches;
+}
+
 size_t zjni_compress(void* dst, size_t dstCap, const void* src, size_t srcSize, int level) {
     size_t res = 0; const void* s = src; void* dd = dst;
     size_t const r = zjni_compress_batch(&s, &srcSize, &dd, &dstCap, &res, 1, level);

@@ -67,6 +67,18 @@ static int per_buffer_on_gpu(void) {
     if (state < 0) { const char* e = getenv("ZSTD_JNI_GPU_PER_BUFFER"); state = ((e && *e == '1') || !cpu_sym(PS("Zstd_compressBound"))) ? 1 : 0; }
     return state && gpu_on();
 }
+/* ZSTD_JNI_GPU_AGGREGATE=<microseconds>: concurrent per-buffer calls of plain contexts (no dictionary, default frame layout, no explicit
+ * table sizes) are batched across threads (zjni_aggregator_*): the first caller waits that long for company.
+ * Unset / 0: every per-buffer call is a batch of one. */
+static zjni_aggregator* aggregator(void) {
+    static zjni_aggregator* agg = NULL; static int state = -1;
+    if (state < 0) {
+        const char* e = getenv("ZSTD_JNI_GPU_AGGREGATE"); long const us = e ? atol(e) : 0;
+        agg = us > 0 ? zjni_createAggregator(0, 4096, (unsigned)us) : NULL;
+        state = 1;
+    }
+    return agg;
+}
 static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
     return !(zjni_isError(r) && zjni_getErrorCode(r) >= 200);
 }
@@ -370,6 +382,8 @@ static int frame_flags(const CtxState* s) {
 static size_t gpu_compress(const CtxState* s, void* dst, size_t dstCap, const void* src, size_t srcSize) {
     size_t res = 0; const void* sp = src; void* dp = dst; size_t r;
     if (s->cdict) r = zjni_compress_batch_usingCDict(&sp, &srcSize, &dp, &dstCap, &res, 1, s->cdict, frame_flags(s));
+    else if (aggregator() && !(s->hashLog | s->chainLog) && (frame_flags(s) & ~ZJNI_FRAME_CHECKSUM) == 0)
+        return zjni_aggregator_compress(aggregator(), dst, dstCap, src, srcSize, s->level, s->checksum ? 1 : 0);
     else r = zjni_compress_batch_advanced(&sp, &srcSize, &dp, &dstCap, &res, 1, s->level, frame_flags(s), s->hashLog, s->chainLog);   /* explicit table sizes: level 3 only (40 otherwise -> forwarded) */
     return zjni_isError(r) ? r : res;
 }
@@ -428,6 +442,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArray0)
 static int gpu_dec_takes(const CtxState* s) { return s && !s->cpuOnly && !s->cpuDict && per_buffer_on_gpu(); }
 static size_t gpu_decompress(const CtxState* s, void* dst, size_t dstCap, const void* src, size_t srcSize) {
     zjni_ddict* const dd = s->ddictOwned ? s->ddictOwned : s->ddict;
+    if (!dd && aggregator()) return zjni_aggregator_decompress(aggregator(), dst, dstCap, src, srcSize);
     return dd ? zjni_decompress_usingDDict(dst, dstCap, src, srcSize, dd) : zjni_decompress(dst, dstCap, src, srcSize);
 }
 JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressDirectByteBuffer0)
