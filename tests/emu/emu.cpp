@@ -218,11 +218,20 @@ extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned c
     u8* table = (u8*)calloc(1, ZC_TABLE_STRIDE);
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(ZC_MAX_SRC));
     u32 meta[3] = {0, srcSize, srcSize};
-    if (srcSize <= ze_attach_cutoff(cd->strategy)) ze_match_lane_dict(src, srcSize, cd, table, fs, ZC_MAX_SRC, meta);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(ZC_MAX_SRC) * 16u); pre.meta = meta;
+    u32* big = nullptr;
+    if (srcSize <= ze_attach_cutoff(cd->strategy)) ze_match_lane_dict(src, srcSize, cd, table, fs, ZC_MAX_SRC, meta);
+    else if (ze_cdict_copy_mode(cd->strategy, srcSize, cd->contentSize)) {
+        // zj_encode_cdict_copy_kernel's body: the dictionary's tables copied without their tags into the workgroup's slot, the
+        // external-segment parse on lane 0 into the workgroup's record scratch, then the entropy stage on those records
+        big = (u32*)malloc(ZE_MULTI_TABLE_BYTES); memset(big, 0xA5, ZE_MULTI_TABLE_BYTES);
+        ze_cdict_copy_tables(g, cd, big);
+        ze_cdict_copy_parse(cd, src, srcSize, big, ws, meta);
+        pre.seqs = (ZESeq*)(ws + ZE_WS_SEQ); pre.litOff = (const u32*)(ws + ZE_WS_BODY); pre.copyMode = 1u;
+    }
     ZjProf pf; pf.start(nullptr);
     u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, cd->level, ws, pf, &pre, flags & ZE_FLAG_MASK, cd, 160u * 1024u);
-    free(fs); free(table); free(ws); free(lds); free(sh);
+    free(big); free(fs); free(table); free(ws); free(lds); free(sh);
     return r;
 }
 

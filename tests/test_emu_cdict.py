@@ -54,7 +54,25 @@ def check(emu, ref, dictionary, level, srcs_of):
         assert ecd.compress(x) == want, (len(dictionary), level, len(x))
         assert want == cd.compress_using(x)
         assert ref.decompress_using_dict(want, dictionary, len(x)) == x
-    assert ecd.compress(bytes(cutoff + 1)) == -40            # outside the attach range: parameter_unsupported
+    # beyond the attach range the reference copies the dictionary's tables and searches it as an external segment (copy mode,
+    # ZSTD_resetCCtx_byCopyingCDict + ZSTD_compressBlock_{fast,doubleFast}_extDict): one block, with the dictionary's own parameters
+    r2 = random.Random(len(dictionary) * 7 + level)
+    recs2 = json_records(4000, seed=11)
+    content = max(1, info.get("contentSize", len(dictionary)))
+    for size in (cutoff + 1, cutoff + 100, 20000, 32768, 50000, 65536, 100000, 131071, 131072):
+        if size <= cutoff:
+            continue
+        k = r2.randrange(0, len(recs2) - 3000)
+        for x in (b",".join(recs2[k:k + 3000])[:size], text(size, r2), dictionary[-min(len(dictionary), size // 2):] + lowent(size - min(len(dictionary), size // 2), r2),
+                  bytes(r2.getrandbits(8) for _ in range(size // 3)) + text(size - size // 3, r2)):
+            assert len(x) == size
+            want = cd.compress(x)
+            got = ecd.compress(x)
+            if size == 131072 and size >= 6 * content:             # the reference reloads the dictionary with the source's parameters there: not served
+                assert got == -40, (len(dictionary), level, size)
+                continue
+            assert got == want, ("copy mode", len(dictionary), level, size, got if isinstance(got, int) else len(got), len(want))
+    assert ecd.compress(bytes(131073)) == -40                # multi-block frames with a dictionary: parameter_unsupported
     return info
 
 

@@ -55,11 +55,17 @@ def test_gpu_cdict_batches_byte_identical(gpu, oracle_ref, level):
                 outs = gpu.decompress_batch(frames, [len(s) for s in srcs], dd)
                 for k, (s, o) in enumerate(zip(srcs, outs)):
                     assert o == s, k
-            # checksum flag + a buffer beyond the attach range in the same batch
-            srcs = [b",".join(recs[5:40]), bytes(cutoff + 1), b",".join(recs[100:140])]
+            # checksum flag + buffers beyond the attach range in the same batch: copy mode up to one block (the dictionary's tables copied, the
+            # dictionary searched as an external segment: ZSTD_resetCCtx_byCopyingCDict + ZSTD_compressBlock_*_extDict), refused beyond
+            big = [b",".join(recs[300:300 + 4000])[:sz] for sz in (cutoff + 1, 20000, 65536, 131071)] + [bytes(cutoff + 1), gpu.synth_host(50000, 3, 1)]
+            srcs = [b",".join(recs[5:40])] + big + [b",".join(recs[100:140]), bytes(131073)]
             frames = gpu.compress_batch(srcs, checksum=True, dictionary=cd)
-            assert frames[0] == ref_cd.compress(srcs[0], checksum=True) and frames[2] == ref_cd.compress(srcs[2], checksum=True)
-            assert isinstance(frames[1], gpu.ZstdException) and frames[1].getErrorCode() == 40
+            for k, (x, z) in enumerate(zip(srcs[:-1], frames[:-1])):
+                assert not isinstance(z, Exception), (k, len(x), z)
+                assert z == ref_cd.compress(x, checksum=True), (k, len(x), level, dict_size)
+            assert isinstance(frames[-1], gpu.ZstdException) and frames[-1].getErrorCode() == 201      # more than one block with a dictionary: the CPU path's
+            outs = gpu.decompress_batch(frames[:-1], [len(x) for x in srcs[:-1]], dd)
+            assert all(o == x for o, x in zip(outs, srcs[:-1]))
 
 
 def test_gpu_cdict_api_mirror(gpu, oracle_ref):
@@ -95,8 +101,8 @@ def test_gpu_cdict_api_mirror(gpu, oracle_ref):
                         ctx.compress(srcs[6], bytearray(12))
                     assert e.value.getErrorCode() == 70 and "Destination buffer is too small" in str(e.value)
                 with pytest.raises(gpu.ZstdException) as e:
-                    gpu.Zstd.compress(bytes(20000), cd)
-                assert e.value.getErrorCode() == 40
+                    gpu.Zstd.compress(bytes(140000), cd)                          # more than one block with a dictionary: not served
+                assert e.value.getErrorCode() == 201
     with pytest.raises(gpu.ZstdException):
         gpu.ZstdDictCompress(b"\x37\xa4\x30\xec" + bytes(40), 3)                    # magic + garbage
     with pytest.raises(gpu.ZstdException):

@@ -416,6 +416,203 @@ ZJ_DEV u32 ze_block_fast_dms(ZEOut& o, const u8* src, u32 srcSize, u32 hlog, u32
 }
 
 // One frame's sequences against a dictionary (plain per-lane loop): records + meta {nbSeq, litSize, lastLL}.
+// ------------------------------------------------------------------ copy-mode searches (sources beyond the attach range) ----------
+// Beyond the attach cutoff the reference COPIES the dictionary's tables into the working context (tags stripped,
+// ZSTD_resetCCtx_byCopyingCDict, zstd_compress.c:2402-2468) and parses with the dictionary as an external segment of the window:
+// ZSTD_compressBlock_fast_extDict_generic (zstd_fast.c:708-960) / ZSTD_compressBlock_doubleFast_extDict_generic
+// (zstd_double_fast.c:608-757).  Same index space as above: dictionary content offset c <-> index c + 2, source position p <-> index
+// 2 + dictSize + p; the whole dictionary is valid (loadedDictEnd != 0: lowest index = 2).  Tables: plain u32 indices.
+struct ZEExt { const u8* src; const u8* dict; u32 dictSize, prefixStartIndex; };
+ZJ_DEV const u8* ze_ext_ptr(const ZEExt& x, u32 idx) { return idx < x.prefixStartIndex ? x.dict + (idx - 2u) : x.src + (idx - x.prefixStartIndex); }
+ZJ_DEV bool ze_ext_overlap_ok(u32 prefixStartIndex, u32 repIndex) { return (u32)((prefixStartIndex - 1u) - repIndex) >= 3u; }   // ZSTD_index_overlap_check
+
+ZJ_DEV u32 ze_block_fast_ext(ZEOut& o, const u8* src, u32 srcSize, const u8* dict, u32 dictSize, u32 hlog, u32 mls, u32* hashTable, u32 rep0, u32 rep1) {
+    ZEExt x; x.src = src; x.dict = dict; x.dictSize = dictSize; x.prefixStartIndex = 2u + dictSize;
+    u32 const dictStartIndex = 2u, prefixStartIndex = x.prefixStartIndex;
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+    const u8* const dictStart = dict; const u8* const dictEnd = dict + dictSize; const u8* const prefixStart = src;
+    const u8* anchor = istart;
+    u32 off1 = rep0, off2 = rep1;
+    const u8* ip0 = istart; const u8* ip1; const u8* ip2; const u8* ip3;
+    #define ZX_IDX(p) ((u32)((p) - istart) + prefixStartIndex)
+    {   u32 const curr = ZX_IDX(ip0), maxRep = curr - dictStartIndex;
+        if (off2 >= maxRep) off2 = 0;
+        if (off1 >= maxRep) off1 = 0; }
+    for (;;) {                                                 // _start
+        u32 step = 2; const u8* nextStep = ip0 + 128;          // stepSize = targetLength + !targetLength + 1 with targetLength 0; kStepIncr
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        u32 hash0 = ze_hash(ip0, hlog, mls), hash1 = ze_hash(ip1, hlog, mls);
+        u32 idx = hashTable[hash0];
+        u32 current0 = 0, offcode = 0, mLength = 0; const u8* match0 = nullptr; const u8* matchEnd = nullptr;
+        int found = 0;                                         // 1 = repcode (_match), 2 = table match (_offset)
+        do {
+            {   u32 const current2 = ZX_IDX(ip2), repIndex = current2 - off1;
+                u32 rval;
+                if (((u32)(prefixStartIndex - repIndex) >= 4u) & (off1 > 0)) rval = ld32(ze_ext_ptr(x, repIndex));
+                else rval = ld32(ip2) ^ 1u;
+                current0 = ZX_IDX(ip0); hashTable[hash0] = current0;
+                if (ld32(ip2) == rval) {
+                    ip0 = ip2; match0 = ze_ext_ptr(x, repIndex); matchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+                    mLength = (ip0[-1] == match0[-1]); ip0 -= mLength; match0 -= mLength;
+                    offcode = 1u; mLength += 4; found = 1; break;
+                } }
+            {   u32 const mval = idx >= dictStartIndex ? ld32(ze_ext_ptr(x, idx)) : (ld32(ip0) ^ 1u);
+                if (ld32(ip0) == mval) { found = 2; break; } }
+            idx = hashTable[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = ZX_IDX(ip0); hashTable[hash0] = current0;
+            {   u32 const mval = idx >= dictStartIndex ? ld32(ze_ext_ptr(x, idx)) : (ld32(ip0) ^ 1u);
+                if (ld32(ip0) == mval) { found = 2; break; } }
+            idx = hashTable[hash1];
+            hash0 = hash1; hash1 = ze_hash(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += 128; }
+        } while (ip3 < ilimit);
+        if (!found) break;                                     // _cleanup
+        if (found == 2) {                                      // _offset
+            u32 const offset = current0 - idx;
+            const u8* const lowMatchPtr = idx < prefixStartIndex ? dictStart : prefixStart;
+            matchEnd = idx < prefixStartIndex ? dictEnd : iend;
+            match0 = ze_ext_ptr(x, idx);
+            off2 = off1; off1 = offset; offcode = offset + 3u; mLength = 4;
+            while (((ip0 > anchor) & (match0 > lowMatchPtr)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+        }
+        mLength += ze_count2(ip0 + mLength, match0 + mLength, iend, matchEnd, prefixStart);       // _match
+        ze_store(o, (u32)(anchor - istart), (u32)(ip0 - anchor), offcode, mLength);
+        ip0 += mLength; anchor = ip0;
+        if (ip1 < ip0) hashTable[hash1] = ZX_IDX(ip1);
+        if (ip0 <= ilimit) {
+            {   const u8* const p2 = ze_ext_ptr(x, current0 + 2u); hashTable[ze_hash(p2, hlog, mls)] = current0 + 2u; }
+            hashTable[ze_hash(ip0 - 2, hlog, mls)] = ZX_IDX(ip0 - 2);
+            while (ip0 <= ilimit) {
+                u32 const repIndex2 = ZX_IDX(ip0) - off2;
+                if ((ze_ext_overlap_ok(prefixStartIndex, repIndex2) & (off2 > 0)) && (ld32(ze_ext_ptr(x, repIndex2)) == ld32(ip0))) {
+                    const u8* const repMatch2 = ze_ext_ptr(x, repIndex2);
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    u32 const repLength2 = ze_count2(ip0 + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4u;
+                    { u32 const t = off2; off2 = off1; off1 = t; }
+                    ze_store(o, (u32)(anchor - istart), 0u, 1u, repLength2);
+                    hashTable[ze_hash(ip0, hlog, mls)] = ZX_IDX(ip0);
+                    ip0 += repLength2; anchor = ip0;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    #undef ZX_IDX
+    return (u32)(iend - anchor);
+}
+
+ZJ_DEV u32 ze_block_dfast_ext(ZEOut& o, const u8* src, u32 srcSize, const u8* dict, u32 dictSize, u32 hBitsL, u32 hBitsS, u32 mls, u32* hashLong, u32* hashSmall,
+                              u32 rep0, u32 rep1) {
+    ZEExt x; x.src = src; x.dict = dict; x.dictSize = dictSize; x.prefixStartIndex = 2u + dictSize;
+    u32 const dictStartIndex = 2u, prefixStartIndex = x.prefixStartIndex;
+    const u8* const istart = src; const u8* const iend = src + srcSize; const u8* const ilimit = iend - 8;
+    const u8* const dictStart = dict; const u8* const dictEnd = dict + dictSize; const u8* const prefixStart = src;
+    const u8* ip = istart; const u8* anchor = istart;
+    u32 off1 = rep0, off2 = rep1;
+    #define ZX_IDX(p) ((u32)((p) - istart) + prefixStartIndex)
+    while (ip < ilimit) {
+        u32 const hSmall = ze_hash(ip, hBitsS, mls), matchIndex = hashSmall[hSmall];
+        const u8* match = ze_ext_ptr(x, matchIndex >= dictStartIndex ? matchIndex : dictStartIndex);
+        u32 const hLong = ze_hash(ip, hBitsL, 8), matchLongIndex = hashLong[hLong];
+        const u8* matchLong = ze_ext_ptr(x, matchLongIndex >= dictStartIndex ? matchLongIndex : dictStartIndex);
+        u32 const curr = ZX_IDX(ip), repIndex = curr + 1u - off1;
+        u32 mLength;
+        hashSmall[hSmall] = hashLong[hLong] = curr;
+        if ((ze_ext_overlap_ok(prefixStartIndex, repIndex) & (off1 <= curr + 1u - dictStartIndex)) && (ld32(ze_ext_ptr(x, repIndex)) == ld32(ip + 1))) {
+            const u8* const repMatch = ze_ext_ptr(x, repIndex);
+            const u8* const repMatchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+            mLength = ze_count2(ip + 1 + 4, repMatch + 4, iend, repMatchEnd, prefixStart) + 4u;
+            ip++;
+            ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), 1u, mLength);
+        } else {
+            if ((matchLongIndex > dictStartIndex) && (ld64(matchLong) == ld64(ip))) {
+                const u8* const matchEnd = matchLongIndex < prefixStartIndex ? dictEnd : iend;
+                const u8* const lowMatchPtr = matchLongIndex < prefixStartIndex ? dictStart : prefixStart;
+                mLength = ze_count2(ip + 8, matchLong + 8, iend, matchEnd, prefixStart) + 8u;
+                u32 const offset = curr - matchLongIndex;
+                while (((ip > anchor) & (matchLong > lowMatchPtr)) && (ip[-1] == matchLong[-1])) { ip--; matchLong--; mLength++; }
+                off2 = off1; off1 = offset;
+                ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), offset + 3u, mLength);
+            } else if ((matchIndex > dictStartIndex) && (ld32(match) == ld32(ip))) {
+                u32 const h3 = ze_hash(ip + 1, hBitsL, 8), matchIndex3 = hashLong[h3];
+                const u8* match3 = ze_ext_ptr(x, matchIndex3 >= dictStartIndex ? matchIndex3 : dictStartIndex);
+                u32 offset;
+                hashLong[h3] = curr + 1u;
+                if ((matchIndex3 > dictStartIndex) && (ld64(match3) == ld64(ip + 1))) {
+                    const u8* const matchEnd = matchIndex3 < prefixStartIndex ? dictEnd : iend;
+                    const u8* const lowMatchPtr = matchIndex3 < prefixStartIndex ? dictStart : prefixStart;
+                    mLength = ze_count2(ip + 9, match3 + 8, iend, matchEnd, prefixStart) + 8u;
+                    ip++;
+                    offset = curr + 1u - matchIndex3;
+                    while (((ip > anchor) & (match3 > lowMatchPtr)) && (ip[-1] == match3[-1])) { ip--; match3--; mLength++; }
+                } else {
+                    const u8* const matchEnd = matchIndex < prefixStartIndex ? dictEnd : iend;
+                    const u8* const lowMatchPtr = matchIndex < prefixStartIndex ? dictStart : prefixStart;
+                    mLength = ze_count2(ip + 4, match + 4, iend, matchEnd, prefixStart) + 4u;
+                    offset = curr - matchIndex;
+                    while (((ip > anchor) & (match > lowMatchPtr)) && (ip[-1] == match[-1])) { ip--; match--; mLength++; }
+                }
+                off2 = off1; off1 = offset;
+                ze_store(o, (u32)(anchor - istart), (u32)(ip - anchor), offset + 3u, mLength);
+            } else {
+                ip += ((u32)(ip - anchor) >> 8) + 1;
+                continue;
+            }
+        }
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            {   u32 const indexToInsert = curr + 2u; const u8* const pi = ze_ext_ptr(x, indexToInsert);
+                hashLong[ze_hash(pi, hBitsL, 8)] = indexToInsert;
+                hashLong[ze_hash(ip - 2, hBitsL, 8)] = ZX_IDX(ip - 2);
+                hashSmall[ze_hash(pi, hBitsS, mls)] = indexToInsert;
+                hashSmall[ze_hash(ip - 1, hBitsS, mls)] = ZX_IDX(ip - 1); }
+            while (ip <= ilimit) {
+                u32 const current2 = ZX_IDX(ip), repIndex2 = current2 - off2;
+                if ((ze_ext_overlap_ok(prefixStartIndex, repIndex2) & (off2 <= current2 - dictStartIndex)) && (ld32(ze_ext_ptr(x, repIndex2)) == ld32(ip))) {
+                    const u8* const repMatch2 = ze_ext_ptr(x, repIndex2);
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    u32 const repLength2 = ze_count2(ip + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4u;
+                    { u32 const t = off2; off2 = off1; off1 = t; }
+                    ze_store(o, (u32)(anchor - istart), 0u, 1u, repLength2);
+                    hashSmall[ze_hash(ip, hBitsS, mls)] = current2;
+                    hashLong[ze_hash(ip, hBitsL, 8)] = current2;
+                    ip += repLength2; anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    #undef ZX_IDX
+    return (u32)(iend - anchor);
+}
+// sources the reference compresses with the dictionary's own parameters by copying its tables: beyond the attach cutoff, one block,
+// and within ZSTD_compressBegin_internal's "use the CDict's parameters" rule (zstd_compress.c:5308-5320: source < 128 KiB or < 6 x dictionary)
+ZJ_HD bool ze_cdict_copy_mode(u32 strategy, u32 srcSize, u32 dictContentSize) {
+    return srcSize > ze_attach_cutoff(strategy) && srcSize <= (128u << 10) && (srcSize < (128u << 10) || (u64)srcSize < (u64)dictContentSize * 6u);
+}
+
+// copy mode, the two steps a workgroup takes before the entropy stage: (all lanes) the dictionary's tables into its slot, tags stripped
+// (ZSTD_copyCDictTableIntoCCtx); (lane 0) the external-segment parse into the workgroup's record scratch.  meta = {nbSeq, litSize, lastLL}
+template <class G>
+ZJ_DEV void ze_cdict_copy_tables(const G& g, const ZECDictDev* cd, u32* slot) {
+    const u32* const t = ze_cdict_tables(cd);
+    u32 const entries = (1u << cd->hashLog) + (cd->strategy == 2 ? (1u << cd->chainLog) : 0u);
+    GRP_FOR(g, i, entries) slot[i] = t[i] >> ZC_TAG_BITS;
+}
+ZJ_DEV void ze_cdict_copy_parse(const ZECDictDev* cd, const u8* src, u32 srcSize, u32* slot, u8* ws, u32* meta) {
+    ZEOut o; o.seqs = (ZESeq*)(ws + ZE_WS_SEQ); o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+    const u8* const dict = ze_cdict_content(cd);
+    u32 const lastLL = cd->strategy == 1 ? ze_block_fast_ext(o, src, srcSize, dict, cd->contentSize, cd->hashLog, cd->minMatch, slot, cd->rep[0], cd->rep[1])
+                                         : ze_block_dfast_ext(o, src, srcSize, dict, cd->contentSize, cd->hashLog, cd->chainLog, cd->minMatch, slot, slot + (1u << cd->hashLog), cd->rep[0], cd->rep[1]);
+    meta[0] = o.n; meta[1] = o.lit + lastLL; meta[2] = lastLL;
+}
+
 // The caller has zeroed `table` (ZC_TABLE_STRIDE bytes) and checked srcSize <= ze_attach_cutoff().
 ZJ_DEV void ze_match_lane_dict(const u8* src, u32 srcSize, const ZECDictDev* cd, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
     ZEOut o; o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;

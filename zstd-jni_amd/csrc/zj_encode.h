@@ -1306,7 +1306,7 @@ template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 #define ZE_FLAG_NO_DICTID 4u     /* ZSTD_c_dictIDFlag = 0 (ZstdCompressCtx.setDictID(false)): the dictionary's ID stays out of the header */
 #define ZE_FLAG_MASK 7u
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
-struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; };   // meta = {nbSeq, litSize, lastLL}
+struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; u32 copyMode = 0; };   // meta = {nbSeq, litSize, lastLL}; copyMode: the records come from the dictionary copy-mode search (zj_cdict.h)
 
 // `ba` != nullptr: src0[0, srcSize) is ONE BLOCK of a multi-block frame (ze_compress_multi): no frame header or checksum here, the
 // match finder runs over the frame's tables and repcodes, the previous compressed block's Huffman table may be repeated, and the
@@ -1352,7 +1352,11 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         u32 const fcsCode = noFcs ? 0u : (srcSize >= 256) + (srcSize >= 65536 + 256);
         u32 const hdr = 5 + didBytes + (noFcs ? 1 : (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4)));
         sh.hdrSize = hdr;
-        if (cd && (!pre || srcSize > (sh.dictStrategy == 2 ? (16u << 10) : (8u << 10)))) sh.err = ZJ_E_PARAM_UNSUPPORTED;   // outside the attach range
+        // with a dictionary the sequences come from outside (attach-mode search up to the cutoff, copy-mode search — zj_cdict.h — beyond it while
+        // the reference still compresses with the dictionary's own parameters: one block, source < 128 KiB or < 6 x the dictionary)
+        // (the attach pipeline's entropy kernel still meets such frames — without records: it has to refuse them, the copy-mode kernel serves them)
+        if (cd && (!pre || (srcSize > (sh.dictStrategy == 2 ? (16u << 10) : (8u << 10))
+                            && !(pre->copyMode && srcSize <= (128u << 10) && (srcSize < (128u << 10) || (u64)srcSize < (u64)cd->contentSize * 6u))))) sh.err = ZJ_E_PARAM_UNSUPPORTED;
         else if (cd && noFcs) sh.err = ZJ_E_PARAM_UNSUPPORTED;               // (the attached dictionary's window descriptor is not restated here)
         else if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {

@@ -568,6 +568,48 @@ __global__ __launch_bounds__(64) void zj_enc_match_dict_kernel(const u8* __restr
     }
 }
 
+// Dictionary compression beyond the attach range (copy mode, zj_cdict.h): counted per call, then one wave per frame — the dictionary's
+// tables copied (tags stripped) into the workgroup's HBM slot, the external-segment parse on lane 0 into the workgroup's record
+// scratch, the entropy stage with the dictionary's tables as "previous block".  Such sources are rare next to the 4-16 KiB records
+// dictionaries are made for; the kernel returns at once when the call has none.
+__global__ __launch_bounds__(256) void zj_cdict_count_copy_kernel(const u64* __restrict__ srcOff, u32 n, const ZECDictDev* __restrict__ cd, u32* counter) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 const size = srcOff[i + 1] - srcOff[i];
+    if (size <= ZE_BLOCK_MAX && ze_cdict_copy_mode(cd->strategy, (u32)size, cd->contentSize)) atomicAdd(counter, 1u);
+}
+__global__ __launch_bounds__(64) void zj_encode_cdict_copy_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                                   u64* __restrict__ result, u32 n, const ZECDictDev* __restrict__ cd, const u32* copyCount, u32* workCounter,
+                                                                   u8* scratch, u32* tables, u32 flags, u32 ldsBytes) {
+    if (*copyCount == 0) return;
+    __shared__ ZEncShared sh;
+    __shared__ u32 metaL[4];
+    ZjProf pf; pf.start(nullptr);
+    Grp<64> g;
+    if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
+    __syncthreads();
+    u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
+    u32* const tb = tables + (size_t)blockIdx.x * (ZE_MULTI_TABLE_BYTES / 4u);
+    u32 const strategy = ZJ_UNI(cd->strategy), content = ZJ_UNI(cd->contentSize);
+    for (;;) {
+        u32 const i = zj_next_index(workCounter);
+        if (i >= n) break;
+        u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
+        if (s1 - s0 > ZE_BLOCK_MAX || !ze_cdict_copy_mode(strategy, (u32)(s1 - s0), content)) continue;
+        u32 const size = (u32)(s1 - s0); u64 const cap = d1 - d0;
+        ze_cdict_copy_tables(g, cd, tb);
+        zj_mem_order();
+        __syncthreads();
+        if (threadIdx.x == 0) ze_cdict_copy_parse(cd, src + s0, size, tb, ws, metaL);
+        zj_mem_order();
+        __syncthreads();
+        ZEPre pre; pre.seqs = (ZESeq*)(ws + ZE_WS_SEQ); pre.litOff = (const u32*)(ws + ZE_WS_BODY); pre.meta = metaL; pre.copyMode = 1u;
+        u64 const r = ze_compress(g, sh, zj_dyn_lds, src + s0, size, dst + d0, (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap), ZJ_UNI(cd->level), ws, pf, &pre, flags, cd, ldsBytes);
+        if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
 // Clears exactly the part of each frame's table slot its attach-mode parameters use (24 KiB for a 4 KiB record, not the
 // 96 KiB slot): one workgroup per list entry, 16 bytes per lane per step.
 __global__ __launch_bounds__(256) void zj_cdict_zero_tables_kernel(const u64* __restrict__ srcOff, const ZECDictDev* __restrict__ cd,
@@ -1470,6 +1512,19 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
         pending[par] = 1;
     }
     for (int par = 0; par < 2; par++) if (pending[par] && hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
+    {   // sources beyond the attach range (they got parameter_unsupported above): copy mode, if the call has any
+        if (!d->multiTables) {
+            int perCU = 4; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
+            d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;
+            if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
+        }
+        u32* const cc = d->counters + 56;            // [0] copy-mode frames of the call, [1] work
+        if (hipMemsetAsync(cc, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        hipLaunchKernelGGL(zj_cdict_count_copy_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u32)n, cd, cc);
+        u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
+        hipLaunchKernelGGL(zj_encode_cdict_copy_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
+                           (u64*)d_result, (u32)n, cd, (const u32*)cc, cc + 1, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy));
+    }
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
