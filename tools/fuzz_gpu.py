@@ -88,7 +88,7 @@ for dbytes in (ref.train_dict(samples, 112640), b",".join(recs[:300])):
         rcd = ref.CDict(dbytes, level)
         with zj.ZstdDictCompress(dbytes, level) as cd, zj.ZstdDictDecompress(dbytes) as dd:
             cut = 16384 if level == 3 else 8192
-            datas = [gen(s) for s in sizes(cut)]
+            datas = [gen(s) for s in sizes(cut)] + [gen(s) for s in sizes(131071)[:max(20, n // 20)]]      # attach range + copy mode (beyond it, one block)
             outs = zj.compress_batch(datas, dictionary=cd)
             for k, (d, z) in enumerate(zip(datas, outs)):
                 if isinstance(z, Exception) or z != rcd.compress(d):
