@@ -143,7 +143,10 @@ unsigned zjni_getDictID_fromCDict(const zjni_cdict* cdict);
  * (N/jni_fast_zstd.c:325-336, :586-640) and ZSTD_compress_usingCDict (compress*FastDict0, N/jni_fast_zstd.c:171-216)
  * for n buffers at once; frames are byte-identical to the reference's.  Covers the sizes at which the reference
  * searches the dictionary in place ("attach": srcSize <= 8 KiB when the dictionary's strategy is fast, <= 16 KiB when
- * it is double-fast); a larger buffer reports ZSTD_error_parameter_unsupported in its result slot. */
+ * it is double-fast) and, beyond them up to one block (128 KiB), its copy mode (ZSTD_resetCCtx_byCopyingCDict,
+ * N/compress/zstd_compress.c:2402-2468: the dictionary as an external segment) as long as the reference compresses with
+ * the dictionary's own parameters (srcSize < 128 KiB or < 6 x the dictionary's content, :5256-5257); otherwise the
+ * result slot reports ZSTD_error_parameter_unsupported (more than one block: ZJNI_ERROR_unsupported). */
 size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* d_src_off,
                                              void* d_dst, const uint64_t* d_dst_off,
                                              uint64_t* d_result, size_t n, const zjni_cdict* cdict, int checksum, void* stream);
