@@ -370,15 +370,20 @@ int main(int argc, char** argv) {
                 jlong const rr = R.cDirect(e, NULL, rc, fr, 0, 3000, src, 0, 2000);
                 CHECK(rDReset(e, NULL, rd) == gDReset(e, NULL, gd), "ZstdDecompressCtx.reset0");
                 CHECK(R.dDirect(e, NULL, rd, o1, 0, 2000, fr, 0, (jint)rr) == G.dDirect(e, NULL, gd, o2, 0, 2000, fr, 0, (jint)rr), "dictionary frame after reset0"); }
-            /* a byte[] dictionary on the compress side: the bundled library's business (forwarded), refused without it */
+            /* a byte[] dictionary on the compress side (ZSTD_CCtx_loadDictionary): digested at the first compress call, attach and copy ranges */
             {   jlong const a = rLC(e, NULL, rc, (jbyteArray)darr), b = gLC(e, NULL, gc, (jbyteArray)darr);
-                if (getenv("ZSTD_JNI_CPU_LIB")) {
-                    Obj* src = mk(1, 3000); Obj* rdst = mk(1, 4000); Obj* gdst = mk(1, 4000); fill(src->data, 3000, 0);
-                    CHECK(a == b, "loadCDict0: ref %lld shim %lld", (long long)a, (long long)b);
-                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, 4000, src, 0, 3000), gr = G.cDirect(e, NULL, gc, gdst, 0, 4000, src, 0, 3000);
-                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "compress with a byte[] dictionary: ref %lld shim %lld", (long long)rr, (long long)gr);
-                } else CHECK(b < 0, "loadCDict0 without the bundled library must refuse, got %lld", (long long)b);
+                jsize const tsizes[] = {0, 17, 3000, 8192, 20000, 65536, 131071};
+                CHECK(a == b, "loadCDict0: ref %lld shim %lld", (long long)a, (long long)b);
+                for (unsigned ti = 0; ti < sizeof tsizes / sizeof *tsizes; ti++) for (int cls2 = 0; cls2 < 2; cls2++) {
+                    jsize const n2 = tsizes[ti], cap2 = (jsize)R.bound(e, NULL, n2) + 16;
+                    Obj* src = mk(1, n2 + 1); Obj* rdst = mk(1, cap2); Obj* gdst = mk(1, cap2); fill(src->data, n2, cls2);
+                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap2, src, 0, n2), gr = G.cDirect(e, NULL, gc, gdst, 0, cap2, src, 0, n2);
+                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "compress with a byte[] dictionary L%d n=%d cls=%d: ref %lld shim %lld", level, n2, cls2, (long long)rr, (long long)gr);
+                }
                 CHECK(rLC(e, NULL, rc, NULL) == gLC(e, NULL, gc, NULL), "loadCDict0(null)");
+                {   Obj* src = mk(1, 3000); Obj* rdst = mk(1, 4000); Obj* gdst = mk(1, 4000); fill(src->data, 3000, 0);       /* ... and gone again */
+                    jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, 4000, src, 0, 3000), gr = G.cDirect(e, NULL, gc, gdst, 0, 4000, src, 0, 3000);
+                    CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "compress after loadCDict0(null): ref %lld shim %lld", (long long)rr, (long long)gr); }
             }
             R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
             R.dictFree(e, robj); G.dictFree(e, gobj);

@@ -93,7 +93,15 @@ typedef struct CtxState {
     zjni_cdict* cdict;                                     /* digest of the loaded ZstdDictCompress (owned by the dictionary object) */
     zjni_ddict* ddict;                                     /* digest of the loaded ZstdDictDecompress (owned by the dictionary object) ... */
     zjni_ddict* ddictOwned;                                /* ... or of the bytes given to loadDDict0 (owned by the context) */
+    /* ZstdCompressCtx.loadDict(byte[]) = ZSTD_CCtx_loadDictionary: the reference keeps the bytes and digests them into a CDict of its own at
+     * the first compress call, with the level set by then, and keeps that CDict until the dictionary is replaced (ZSTD_initLocalDict,
+     * N/compress/zstd_compress.c:1246-1290) — frames equal ZSTD_CCtx_refCDict's (checked against the reference: every size up to one block). */
+    void* rawDict; size_t rawDictSize; zjni_cdict* localCdict;
 } CtxState;
+static void st_drop_local_dict(CtxState* s) {
+    if (s->localCdict) { zjni_freeCDict(s->localCdict); s->localCdict = NULL; }
+    if (s->rawDict) { free(s->rawDict); s->rawDict = NULL; s->rawDictSize = 0; }
+}
 #define ST_BUCKETS 4096
 static CtxState* g_st[ST_BUCKETS];
 static pthread_mutex_t g_st_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -137,7 +145,7 @@ static jlong ctx_init(JNIEnv* env, jclass cls, const char* name, int kind) {
 static void ctx_free(JNIEnv* env, jclass cls, jlong ptr, const char* name, int kind) {
     void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym(name);
     CtxState* s = st_take(ptr, kind);
-    if (s) { if (s->ddictOwned) zjni_freeDDict(s->ddictOwned); free(s); }
+    if (s) { if (s->ddictOwned) zjni_freeDDict(s->ddictOwned); st_drop_local_dict(s); free(s); }
     if (!ptr) return;
     if (f) f(env, cls, ptr); else free((void*)(intptr_t)ptr);
 }
@@ -167,7 +175,7 @@ JNIEXPORT void JNICALL P(ZstdCompressCtx_setDictID0)(JNIEnv* env, jclass cls, jl
 /* ZSTD_CCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:364-368): parameters back to their defaults, dictionary dropped */
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
     jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdCompressCtx_reset0"));
-    CtxState* s = st_get(ptr, 'C'); if (s) st_defaults(s);
+    CtxState* s = st_get(ptr, 'C'); if (s) { st_defaults(s); st_drop_local_dict(s); }      /* ZSTD_reset_session_and_parameters clears the dictionaries too */
     return f ? f(env, cls, ptr) : 0;
 }
 /* ZSTD_DCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:712-716) */
@@ -323,7 +331,7 @@ JNIEXPORT void JNICALL P(ZstdDictDecompress_free)(JNIEnv* env, jobject obj) {
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_loadCDictFast0)(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
     jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("ZstdCompressCtx_loadCDictFast0"));
     CtxState* s = st_get(ptr, 'C');
-    if (s) { s->cdict = NULL; s->cpuDict = 0; }
+    if (s) { s->cdict = NULL; s->cpuDict = 0; st_drop_local_dict(s); }
     if (dict != NULL) {
         jlong const key = (*env)->GetLongField(env, dict, native_ptr_field(env, dict, &g_cdict_field));
         if (!key) return E_DICT;
@@ -331,14 +339,22 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_loadCDictFast0)(JNIEnv* env, jclass cl
     }
     return f ? f(env, cls, ptr, dict) : 0;
 }
-/* ZstdCompressCtx.loadDict(byte[]) -> ZSTD_CCtx_loadDictionary (N/jni_fast_zstd.c:343-357): the reference digests it per call with
- * parameters that depend on the source size; that variant is not restated on the GPU, so the context goes to the CPU path. */
+/* ZstdCompressCtx.loadDict(byte[]) -> ZSTD_CCtx_loadDictionary (N/jni_fast_zstd.c:343-357): the bytes are kept; the first compress call
+ * digests them at the level set by then (CtxState.localCdict) */
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_loadCDict0)(JNIEnv* env, jclass cls, jlong ptr, jbyteArray dict) {
     jlong (*f)(JNIEnv*, jclass, jlong, jbyteArray) = (jlong (*)(JNIEnv*, jclass, jlong, jbyteArray))cpu_sym(PS("ZstdCompressCtx_loadCDict0"));
     CtxState* s = st_get(ptr, 'C');
-    if (s) { s->cdict = NULL; s->cpuDict = (dict != NULL); }
+    if (s) {
+        s->cdict = NULL; s->cpuDict = 0; st_drop_local_dict(s);
+        if (dict != NULL) {
+            jsize const n = (*env)->GetArrayLength(env, dict);
+            s->rawDict = n > 0 ? malloc((size_t)n) : NULL;
+            if (s->rawDict) { (*env)->GetByteArrayRegion(env, dict, 0, n, (jbyte*)s->rawDict); s->rawDictSize = (size_t)n; }
+            else s->cpuDict = 1;                              /* (an empty dictionary is "no dictionary" to the reference: its own business) */
+        }
+    }
     if (f) return f(env, cls, ptr, dict);
-    return dict == NULL ? 0 : -(jlong)ZJNI_ERROR_unsupported;
+    return 0;
 }
 JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDictFast0)(JNIEnv* env, jclass cls, jlong ptr, jobject dict) {
     jlong (*f)(JNIEnv*, jclass, jlong, jobject) = (jlong (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("ZstdDecompressCtx_loadDDictFast0"));
@@ -372,7 +388,14 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDict0)(JNIEnv* env, jclass cls,
 /* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
 static int gpu_takes(const CtxState* s, jint srcSize) {
     if (!s || s->cpuOnly || s->cpuDict || !per_buffer_on_gpu()) return 0;
-    if (s->cdict) return s->contentSize;                               /* sizes beyond the attach range come back as 40 and are forwarded */
+    if (s->rawDict && !s->localCdict && !s->cpuDict) {                 /* first compress after loadDict(byte[]): the local CDict, at the level of this moment */
+        CtxState* w = (CtxState*)s;
+        int const lvl = s->level == 0 ? 3 : s->level;
+        w->localCdict = (lvl >= 1 && lvl <= 3) ? zjni_createCDict(s->rawDict, s->rawDictSize, lvl) : NULL;
+        if (!w->localCdict) w->cpuDict = 1;                            /* no digest (level > 3, under 8 bytes, refused): the bundled library has it */
+        if (w->cpuDict) return 0;
+    }
+    if (s->cdict || s->localCdict) return s->contentSize;              /* sizes the library does not take come back as 40 / 201 and are forwarded */
     if (s->level >= 4 && s->level <= 8) return (size_t)srcSize <= (s->level == 4 ? ZJNI_LEVEL4_MAX : ZJNI_LAZY_MAX) && !(s->hashLog | s->chainLog);   /* one block, no explicit table sizes */
     return s->level >= 0 && s->level <= 3 && (size_t)srcSize <= ZJNI_FRAME_MAX;       /* beyond the level's window the library answers 201 and the call is forwarded */
 }
@@ -381,14 +404,14 @@ static int frame_flags(const CtxState* s) {
 }
 static size_t gpu_compress(const CtxState* s, void* dst, size_t dstCap, const void* src, size_t srcSize) {
     size_t res = 0; const void* sp = src; void* dp = dst; size_t r;
-    if (s->cdict) r = zjni_compress_batch_usingCDict(&sp, &srcSize, &dp, &dstCap, &res, 1, s->cdict, frame_flags(s));
+    if (s->cdict || s->localCdict) r = zjni_compress_batch_usingCDict(&sp, &srcSize, &dp, &dstCap, &res, 1, s->cdict ? s->cdict : s->localCdict, frame_flags(s));
     else if (aggregator() && !(s->hashLog | s->chainLog) && (frame_flags(s) & ~ZJNI_FRAME_CHECKSUM) == 0)
         return zjni_aggregator_compress(aggregator(), dst, dstCap, src, srcSize, s->level, s->checksum ? 1 : 0);
     else r = zjni_compress_batch_advanced(&sp, &srcSize, &dp, &dstCap, &res, 1, s->level, frame_flags(s), s->hashLog, s->chainLog);   /* explicit table sizes: level 3 only (40 otherwise -> forwarded) */
     return zjni_isError(r) ? r : res;
 }
 static int gpu_compress_final(const CtxState* s, size_t r, int haveCpu) {   /* 40 / 42 = outside what the GPU path takes (attach range, table sizes): forward when possible */
-    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && (s->cdict || s->hashLog || s->chainLog) && haveCpu);
+    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && (s->cdict || s->localCdict || s->hashLog || s->chainLog) && haveCpu);
 }
 typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
 static jlong buf_forward(const char* name, jlong none, JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
