@@ -328,9 +328,8 @@ class ZstdCompressCtx(_AutoClose):
             self._cdict._ensure_open()
             return self._cdict
         if self._raw_dict is not None:
-            if self._own is None or self._own[0] != self.level:    # ZSTD_initLocalDict: a CDict at the requested level
-                if self._own is not None:
-                    self._own[1].close()
+            if self._own is None:      # ZSTD_initLocalDict (zstd_compress.c:1246-1290): a CDict made at the first compress call, at the level set by
+                                       # then, and kept until the dictionary is replaced — a later setLevel does not rebuild it (checked against the reference)
                 self._own = (self.level, ZstdDictCompress(self._raw_dict, self.level))
             return self._own[1]
         return None
