@@ -6,6 +6,23 @@
 #include <stdlib.h>
 #include <string.h>
 
+// -DEMU_EXACT (the sanitizer build): every entry point works on exact-size heap copies of the caller's source and destination, so
+// that a read past the last source byte or a write past the capacity lands in an AddressSanitizer red zone.
+#ifdef EMU_EXACT
+struct EmuExact {
+    u8* s; u8* d; u8* userDst; unsigned cap;
+    EmuExact(const unsigned char*& src, unsigned n, unsigned char*& dst, unsigned c) {
+        s = (u8*)malloc(n ? n : 1); if (n) memcpy(s, src, n);
+        d = (u8*)malloc(c ? c : 1); if (c) memcpy(d, dst, c);
+        userDst = dst; cap = c; src = s; dst = d;
+    }
+    ~EmuExact() { if (cap) memcpy(userDst, d, cap); free(s); free(d); }
+};
+#define EMU_IO(src, n, dst, c) EmuExact emuExact_(src, n, dst, c)
+#else
+#define EMU_IO(src, n, dst, c) do {} while (0)
+#endif
+
 // The decode kernels are persistent too: `sh` (LDS) and the literal scratch slot outlive a frame and nothing clears them.  One
 // poisoned set per process instead of a calloc per frame, so that a decoder which relies on leftovers fails here.
 static ZDecShared* emu_dec_sh() {
@@ -19,6 +36,7 @@ static u8* emu_dec_lit() {
     return lit;
 }
 extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     ZDecShared* sh = emu_dec_sh();
     u8* lit = emu_dec_lit();
@@ -28,6 +46,7 @@ extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned 
 }
 // split pipeline: prep -> lane sequence decode -> execute; frames the pipeline hands over go through the fused path
 extern "C" unsigned long long emu_decompress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, int* usedSplit) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
@@ -49,6 +68,7 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
 // dictionary frames through the three-stage pipeline
 extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
                                                         const unsigned char* dict, unsigned dictSize, int* usedSplit) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
@@ -74,6 +94,7 @@ extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src
 }
 extern "C" unsigned long long emu_decompress_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,
                                                   const unsigned char* dict, unsigned dictSize) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));      // a kernel's LDS is whatever the previous frame / kernel left
     u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
@@ -105,6 +126,7 @@ static EmuWg& emu_wg() {
     return w;
 }
 extern "C" unsigned long long emu_compress(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     ZjProf pf; pf.start(nullptr);
@@ -128,6 +150,7 @@ extern "C" unsigned emu_check_code_tables() {
 // split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
 // kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    EMU_IO(src, srcSize, dst, dstCap);
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK, hl = (level >> 16) & 0xFFu, cl = (level >> 24) & 0xFFu; level &= 0xFFu;   // test encoding: level | frame flags << 8 | hashLog << 16 | chainLog << 24
@@ -149,6 +172,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
 
 // multi-block frames (128 KiB < srcSize <= 2 MiB): the frame loop of ze_compress_multi, lane-serial
 extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
     EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
@@ -165,6 +189,7 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
 // levels 4-8, frames <= 16 KiB, as the large-batch route runs them: chain parser per frame (zj_enc_match_chain_kernel's body) into the
 // record scratch, then the entropy stage on those records (zj_encode_kernel with `pre`)
 extern "C" unsigned long long emu_compress_chain(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    EMU_IO(src, srcSize, dst, dstCap);
     if (srcSize > (16u << 10)) return ZJ_ERR64(201);
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
@@ -210,6 +235,7 @@ extern "C" void emu_cdict_info(const void* p, unsigned* out) {
     out[7] = cd->hufRepeat; out[8] = cd->llRepeat; out[9] = cd->ofRepeat; out[10] = cd->mlRepeat; out[11] = cd->fillStart;
 }
 extern "C" unsigned long long emu_compress_cdict(const void* p, const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned flags) {
+    EMU_IO(src, srcSize, dst, dstCap);
     const ZECDictDev* cd = (const ZECDictDev*)p;
     Grp<1> g;
     ZEncShared* sh = (ZEncShared*)calloc(1, sizeof(ZEncShared));

@@ -12,6 +12,12 @@
 
 // level word as in emu_compress_split (level | checksum << 8); returns ~0 when the wave matcher does not take the frame
 extern "C" unsigned long long emu_compress_wave(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+#ifdef EMU_EXACT       // the sanitizer build: exact-size heap copies, so that a stray read or write lands in a red zone
+    struct Exact { u8* s; u8* d; u8* user; unsigned cap; ~Exact() { if (cap) memcpy(user, d, cap); free(s); free(d); } } ex;
+    ex.s = (u8*)malloc(srcSize ? srcSize : 1); if (srcSize) memcpy(ex.s, src, srcSize);
+    ex.d = (u8*)malloc(dstCap ? dstCap : 1); if (dstCap) memcpy(ex.d, dst, dstCap);
+    ex.user = dst; ex.cap = dstCap; src = ex.s; dst = ex.d;
+#endif
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
     if (level != 3 || srcSize > 65536u || !zw_takes(ze_params_of(level, srcSize), srcSize)) return ~0ull;

@@ -11,7 +11,7 @@ def emu_lib():
     """tests/emu/libzjni_emu.so — lane-serial build of the kernel bodies (test infrastructure)."""
     d = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", d])
-    L = C.CDLL(os.path.join(d, "libzjni_emu.so"))
+    L = C.CDLL(os.environ.get("ZJNI_EMU_LIB") or os.path.join(d, "libzjni_emu.so"))
     L.emu_decompress.restype = C.c_ulonglong
     L.emu_decompress.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint]
     L.emu_decompress_split.restype = C.c_ulonglong
@@ -141,7 +141,10 @@ def emu_wave_libs():
     d = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", d])
     out = []
-    for name in ("libzjni_emu_wave.so", "libzjni_emu_wave_rev.so"):
+    names = ("libzjni_emu_wave.so", "libzjni_emu_wave_rev.so")
+    if os.environ.get("ZJNI_EMU_WAVE_LIB"):          # the sanitizer build (tests/test_emu_sanitizer.py)
+        names = (os.environ["ZJNI_EMU_WAVE_LIB"],)
+    for name in names:
         L = C.CDLL(os.path.join(d, name))
         L.emu_compress_wave.restype = C.c_ulonglong
         L.emu_compress_wave.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
