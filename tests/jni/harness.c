@@ -249,6 +249,55 @@ int main(int argc, char** argv) {
                 CHECK(rr == ((jlong*)res->data)[i] && !memcmp(one->data, dsts->elems[i]->data, (size_t)rr), "dict batch buffer %d L%d: ref %lld gpu %lld", i, level, (long long)rr, (long long)((jlong*)res->data)[i]);
             }
         }
+        {   /* the one-shot natives of class Zstd over the dictionary objects (N/jni_fast_zstd.c:133-244): Zstd.compress(dst, src, ZstdDictCompress) etc.;
+             * sizes inside and beyond the attach range, both buffer kinds, the reference's argument checks */
+            typedef jlong (*fda_fn)(JNIEnv*, jclass, jbyteArray, jint, jbyteArray, jint, jint, jobject);
+            typedef jlong (*fdb_fn)(JNIEnv*, jclass, jobject, jint, jint, jobject, jint, jint, jobject);
+            fda_fn rCA = (fda_fn)dlsym(R.h, P "Zstd_compressFastDict0"), gCA = (fda_fn)dlsym(G.h, P "Zstd_compressFastDict0");
+            fda_fn rDA = (fda_fn)dlsym(R.h, P "Zstd_decompressFastDict0"), gDA = (fda_fn)dlsym(G.h, P "Zstd_decompressFastDict0");
+            fdb_fn rCB = (fdb_fn)dlsym(R.h, P "Zstd_compressDirectByteBufferFastDict0"), gCB = (fdb_fn)dlsym(G.h, P "Zstd_compressDirectByteBufferFastDict0");
+            fdb_fn rDB = (fdb_fn)dlsym(R.h, P "Zstd_decompressDirectByteBufferFastDict0"), gDB = (fdb_fn)dlsym(G.h, P "Zstd_decompressDirectByteBufferFastDict0");
+            jsize const fdSizes[] = {0, 1, 300, 5000, 8192, 20000, 70000};
+            CHECK(rCA && gCA && rDA && gDA && rCB && gCB && rDB && gDB, "FastDict0 natives exported");
+            for (unsigned si = 0; si < sizeof fdSizes / sizeof *fdSizes && gCA && gDA && gCB && gDB; si++) for (int kind = 1; kind <= 2; kind++) {
+                jsize const n = fdSizes[si], cap = (jsize)R.bound(e, NULL, n) + 16;
+                Obj* src = mk(kind, n + 4); Obj* rdst = mk(kind, cap); Obj* gdst = mk(kind, cap); Obj* rout = mk(kind, n + 5); Obj* gout = mk(kind, n + 5);
+                fill(src->data + 2, n, si & 1);
+                jlong const rr = kind == 1 ? rCB(e, NULL, rdst, 3, cap - 3, src, 2, n, robj) : rCA(e, NULL, (jbyteArray)rdst, 3, (jbyteArray)src, 2, n, robj);
+                jlong const gr = kind == 1 ? gCB(e, NULL, gdst, 3, cap - 3, src, 2, n, gobj) : gCA(e, NULL, (jbyteArray)gdst, 3, (jbyteArray)src, 2, n, gobj);
+                CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr + 3), "compressFastDict0 L%d n=%d kind=%d: ref %lld gpu %lld", level, n, kind, (long long)rr, (long long)gr);
+                if (rr > 0) {
+                    jlong const a = kind == 1 ? rDB(e, NULL, rout, 1, n, rdst, 3, (jint)rr, rdobj) : rDA(e, NULL, (jbyteArray)rout, 1, (jbyteArray)rdst, 3, (jint)rr, rdobj);
+                    jlong const b = kind == 1 ? gDB(e, NULL, gout, 1, n, rdst, 3, (jint)rr, gdobj) : gDA(e, NULL, (jbyteArray)gout, 1, (jbyteArray)rdst, 3, (jint)rr, gdobj);
+                    CHECK(a == b && a == n && !memcmp(gout->data + 1, src->data + 2, (size_t)n), "decompressFastDict0 L%d n=%d kind=%d: ref %lld gpu %lld", level, n, kind, (long long)a, (long long)b);
+                    if (n > 10) {
+                        jlong const a2 = kind == 1 ? rDB(e, NULL, rout, 1, n - 4, rdst, 3, (jint)rr, rdobj) : rDA(e, NULL, (jbyteArray)rout, 9, (jbyteArray)rdst, 3, (jint)rr, rdobj);
+                        jlong const b2 = kind == 1 ? gDB(e, NULL, gout, 1, n - 4, rdst, 3, (jint)rr, gdobj) : gDA(e, NULL, (jbyteArray)gout, 9, (jbyteArray)rdst, 3, (jint)rr, gdobj);
+                        CHECK(a2 == b2, "decompressFastDict0 short destination n=%d kind=%d: ref %lld gpu %lld", n, kind, (long long)a2, (long long)b2);
+                    }
+                }
+            }
+            if (gCA && gDA && gCB && gDB) {
+                Obj* s = mk(2, 100); Obj* d = mk(2, 200); Obj* sb = mk(1, 100); Obj* db = mk(1, 200); Obj* zero = mk(6, 0);
+                CHECK(rCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, NULL) == gCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, NULL), "compressFastDict0 null dictionary");
+                CHECK(rCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, zero) == gCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, zero), "compressFastDict0 closed dictionary");
+                CHECK(rCA(e, NULL, NULL, 0, (jbyteArray)s, 0, 100, robj) == gCA(e, NULL, NULL, 0, (jbyteArray)s, 0, 100, gobj), "compressFastDict0 null dst");
+                CHECK(rCA(e, NULL, (jbyteArray)d, 0, NULL, 0, 100, robj) == gCA(e, NULL, (jbyteArray)d, 0, NULL, 0, 100, gobj), "compressFastDict0 null src");
+                CHECK(rCA(e, NULL, (jbyteArray)d, -1, (jbyteArray)s, 0, 100, robj) == gCA(e, NULL, (jbyteArray)d, -1, (jbyteArray)s, 0, 100, gobj), "compressFastDict0 negative dst offset");
+                CHECK(rCA(e, NULL, (jbyteArray)d, 201, (jbyteArray)s, 0, 100, robj) == gCA(e, NULL, (jbyteArray)d, 201, (jbyteArray)s, 0, 100, gobj), "compressFastDict0 dst offset beyond the array");
+                CHECK(rCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 50, 60, robj) == gCA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 50, 60, gobj), "compressFastDict0 src range");
+                CHECK(rCA(e, NULL, (jbyteArray)d, 195, (jbyteArray)s, 0, 100, robj) == gCA(e, NULL, (jbyteArray)d, 195, (jbyteArray)s, 0, 100, gobj), "compressFastDict0 dst too small");
+                CHECK(rDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, NULL) == gDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, NULL), "decompressFastDict0 null dictionary");
+                CHECK(rDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, rdobj) == gDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, 100, gdobj), "decompressFastDict0 garbage");
+                CHECK(rDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, -1, rdobj) == gDA(e, NULL, (jbyteArray)d, 0, (jbyteArray)s, 0, -1, gdobj), "decompressFastDict0 negative length");
+                CHECK(rCB(e, NULL, db, 0, 200, sb, 0, 100, NULL) == gCB(e, NULL, db, 0, 200, sb, 0, 100, NULL), "compressDirectByteBufferFastDict0 null dictionary");
+                CHECK(rCB(e, NULL, NULL, 0, 200, sb, 0, 100, robj) == gCB(e, NULL, NULL, 0, 200, sb, 0, 100, gobj), "compressDirectByteBufferFastDict0 null dst");
+                CHECK(rCB(e, NULL, db, 0, 200, sb, -1, 100, robj) == gCB(e, NULL, db, 0, 200, sb, -1, 100, gobj), "compressDirectByteBufferFastDict0 negative src offset");
+                CHECK(rCB(e, NULL, db, 0, 5, sb, 0, 100, robj) == gCB(e, NULL, db, 0, 5, sb, 0, 100, gobj), "compressDirectByteBufferFastDict0 dst too small");
+                CHECK(rDB(e, NULL, db, 0, 200, sb, 0, 100, rdobj) == gDB(e, NULL, db, 0, 200, sb, 0, 100, gdobj), "decompressDirectByteBufferFastDict0 garbage");
+                CHECK(rDB(e, NULL, db, 0, 200, NULL, 0, 100, rdobj) == gDB(e, NULL, db, 0, 200, NULL, 0, 100, gdobj), "decompressDirectByteBufferFastDict0 null src");
+            }
+        }
         {   /* without the dictionary the frame of a non-empty source no longer decodes: same error from both */
             Obj* src = mk(1, 1000); Obj* fr = mk(1, 2000); Obj* o1 = mk(1, 1000); Obj* o2 = mk(1, 1000); fill(src->data, 1000, 0);
             R.loadCDict(e, NULL, rc, robj);

@@ -597,6 +597,86 @@ JNIEXPORT jlong JNICALL P(Zstd_decompressUnsafe)(JNIEnv* env, jclass cls, jlong 
     return -(jlong)ZJNI_ERROR_no_device;
 }
 
+/* ---- class Zstd: the one-shot natives over a ZstdDictCompress / ZstdDictDecompress object (N/jni_fast_zstd.c:133-244) --------
+ * = ZSTD_compress_usingCDict / ZSTD_decompress_usingDDict on a fresh context: default frame layout, the dictionary's level.  What
+ * Zstd.compress(dst, src, ZstdDictCompress) / Zstd.decompress(dst, src, ZstdDictDecompress) and their ByteBuffer overloads call.
+ * Argument checks in the reference's order; a dictionary without a GPU digest, or a source the dictionary pipeline answers 40 / 201
+ * for, goes to the bundled library's native of the same name. */
+static size_t fastdict_compress(zjni_cdict* cd, void* dst, size_t dstCap, const void* src, size_t srcSize) {
+    size_t res = 0; const void* sp = src; void* dp = dst;
+    size_t const r = zjni_compress_batch_usingCDict(&sp, &srcSize, &dp, &dstCap, &res, 1, cd, 0);
+    return zjni_isError(r) ? r : res;
+}
+static int fastdict_final(size_t r, int haveCpu) {
+    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && haveCpu);
+}
+typedef jlong (*fd_arr_fn)(JNIEnv*, jclass, jbyteArray, jint, jbyteArray, jint, jint, jobject);
+typedef jlong (*fd_buf_fn)(JNIEnv*, jclass, jobject, jint, jint, jobject, jint, jint, jobject);
+static jlong fastdict_array(JNIEnv* env, jclass cls, jbyteArray dst, jint dst_offset, jbyteArray src, jint src_offset, jint src_length, jobject dict, int compress, const char* name) {
+    fd_arr_fn f = (fd_arr_fn)cpu_sym(name);
+    jlong key;
+    if (NULL == dict) return E_DICT;
+    key = (*env)->GetLongField(env, dict, native_ptr_field(env, dict, compress ? &g_cdict_field : &g_ddict_field));
+    if (!key) return E_DICT;
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_length) return E_SRC;
+    {   jsize dst_size = (*env)->GetArrayLength(env, dst); jsize const src_size = (*env)->GetArrayLength(env, src);
+        void* const gpu = per_buffer_on_gpu() ? dict_get(key, 0) : NULL;
+        if (dst_offset > dst_size) return E_DST;
+        if (src_size < src_offset + src_length) return E_SRC;
+        dst_size -= dst_offset;
+        if (gpu) {
+            jbyte* sb = (jbyte*)malloc((size_t)src_length + 1); jbyte* d = (jbyte*)malloc((size_t)dst_size + 1);
+            size_t r = (size_t)E_MEM;
+            if (sb && d) {
+                (*env)->GetByteArrayRegion(env, src, src_offset, src_length, sb);
+                r = compress ? fastdict_compress((zjni_cdict*)gpu, d, (size_t)dst_size, sb, (size_t)src_length)
+                             : zjni_decompress_usingDDict(d, (size_t)dst_size, sb, (size_t)src_length, (zjni_ddict*)gpu);
+                if (!zjni_isError(r)) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, d);
+            }
+            free(sb); free(d);
+            if (compress ? fastdict_final(r, f != NULL) : gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return f ? f(env, cls, dst, dst_offset, src, src_offset, src_length, dict) : -(jlong)ZJNI_ERROR_unsupported;
+}
+static jlong fastdict_direct(JNIEnv* env, jclass cls, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jobject dict, int compress, const char* name) {
+    fd_buf_fn f = (fd_buf_fn)cpu_sym(name);
+    jlong key;
+    if (NULL == dict) return E_DICT;
+    key = (*env)->GetLongField(env, dict, native_ptr_field(env, dict, compress ? &g_cdict_field : &g_ddict_field));
+    if (!key) return E_DICT;
+    if (NULL == dst) return E_DST;
+    if (NULL == src) return E_SRC;
+    if (0 > dst_offset) return E_DST;
+    if (0 > src_offset) return E_SRC;
+    if (0 > src_size) return E_SRC;
+    {   char* const d = (char*)(*env)->GetDirectBufferAddress(env, dst); char* const sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+        void* const gpu = (d && sb && dst_size >= 0 && per_buffer_on_gpu()) ? dict_get(key, 0) : NULL;   /* (the reference does not test the addresses: its own business) */
+        if (gpu) {
+            size_t const r = compress ? fastdict_compress((zjni_cdict*)gpu, d + dst_offset, (size_t)dst_size, sb + src_offset, (size_t)src_size)
+                                      : zjni_decompress_usingDDict(d + dst_offset, (size_t)dst_size, sb + src_offset, (size_t)src_size, (zjni_ddict*)gpu);
+            if (compress ? fastdict_final(r, f != NULL) : gpu_result_final(r)) return (jlong)r;
+        }
+    }
+    return f ? f(env, cls, dst, dst_offset, dst_size, src, src_offset, src_size, dict) : -(jlong)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jlong JNICALL P(Zstd_compressFastDict0)(JNIEnv* env, jclass cls, jbyteArray dst, jint dst_offset, jbyteArray src, jint src_offset, jint src_length, jobject dict) {
+    return fastdict_array(env, cls, dst, dst_offset, src, src_offset, src_length, dict, 1, PS("Zstd_compressFastDict0"));
+}
+JNIEXPORT jlong JNICALL P(Zstd_decompressFastDict0)(JNIEnv* env, jclass cls, jbyteArray dst, jint dst_offset, jbyteArray src, jint src_offset, jint src_length, jobject dict) {
+    return fastdict_array(env, cls, dst, dst_offset, src, src_offset, src_length, dict, 0, PS("Zstd_decompressFastDict0"));
+}
+JNIEXPORT jlong JNICALL P(Zstd_compressDirectByteBufferFastDict0)(JNIEnv* env, jclass cls, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jobject dict) {
+    return fastdict_direct(env, cls, dst, dst_offset, dst_size, src, src_offset, src_size, dict, 1, PS("Zstd_compressDirectByteBufferFastDict0"));
+}
+JNIEXPORT jlong JNICALL P(Zstd_decompressDirectByteBufferFastDict0)(JNIEnv* env, jclass cls, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jobject dict) {
+    return fastdict_direct(env, cls, dst, dst_offset, dst_size, src, src_offset, src_size, dict, 0, PS("Zstd_decompressDirectByteBufferFastDict0"));
+}
+
 /* ---- new, additive: batch natives over arrays of direct ByteBuffers ----------------
  * static native long compressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results, int level, boolean checksum);
  * static native long decompressBatch0(ByteBuffer[] srcs, ByteBuffer[] dsts, long[] results);
