@@ -85,7 +85,7 @@ def _check(r):
     return r
 
 
-def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0, content_size: bool = True) -> bytes:
+def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int = 0, chain_log: int = 0, content_size: bool = True, cap: int = None) -> bytes:
     """ZSTD_compress2 with the parameters zstd-jni's ZstdCompressCtx sets
     (reference src/main/native/jni_fast_zstd.c:606-607)."""
     L = lib()
@@ -99,7 +99,8 @@ def compress(data: bytes, level: int = 3, checksum: bool = False, hash_log: int 
             _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_hashLog, hash_log))      # ZstdCompressCtx.setHashLog
         if chain_log:
             _check(L.ZSTD_CCtx_setParameter(cctx, ZSTD_c_chainLog, chain_log))    # ZstdCompressCtx.setChainLog
-        cap = L.ZSTD_compressBound(len(data))
+        if cap is None:
+            cap = L.ZSTD_compressBound(len(data))                                 # (a smaller `cap`: the destination the caller's buffer offers)
         dst = C.create_string_buffer(max(cap, 1))
         r = _check(L.ZSTD_compress2(cctx, dst, cap, data, len(data)))
         return dst.raw[:r]
@@ -220,7 +221,7 @@ class CDict:
     def __del__(self):
         self.close()
 
-    def compress(self, data: bytes, checksum: bool = False, dict_id: bool = True) -> bytes:
+    def compress(self, data: bytes, checksum: bool = False, dict_id: bool = True, cap: int = None) -> bytes:
         """ZstdCompressCtx.loadDict(ZstdDictCompress) + compress: ZSTD_CCtx_refCDict then ZSTD_compress2."""
         L = lib()
         cctx = L.ZSTD_createCCtx()
@@ -229,19 +230,21 @@ class CDict:
             if not dict_id:
                 _check(L.ZSTD_CCtx_setParameter(cctx, 202, 0))                    # ZSTD_c_dictIDFlag: ZstdCompressCtx.setDictID(false)
             _check(L.ZSTD_CCtx_refCDict(cctx, self.ptr))
-            cap = L.ZSTD_compressBound(len(data))
+            if cap is None:
+                cap = L.ZSTD_compressBound(len(data))
             dst = C.create_string_buffer(max(cap, 1))
             r = _check(L.ZSTD_compress2(cctx, dst, cap, data, len(data)))
             return dst.raw[:r]
         finally:
             L.ZSTD_freeCCtx(cctx)
 
-    def compress_using(self, data: bytes) -> bytes:
+    def compress_using(self, data: bytes, cap: int = None) -> bytes:
         """Zstd.compress(dst, src, ZstdDictCompress): ZSTD_compress_usingCDict."""
         L = lib()
         cctx = L.ZSTD_createCCtx()
         try:
-            cap = L.ZSTD_compressBound(len(data))
+            if cap is None:
+                cap = L.ZSTD_compressBound(len(data))
             dst = C.create_string_buffer(max(cap, 1))
             r = _check(L.ZSTD_compress_usingCDict(cctx, dst, cap, data, len(data), self.ptr))
             return dst.raw[:r]

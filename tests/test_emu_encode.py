@@ -120,6 +120,48 @@ def test_emu_encoder_dst_too_small(emu, zj):
         assert (1 << 64) - r == 70
 
 
+def test_emu_tight_destinations(emu, oracle_ref, zj):
+    """a destination between the frame's size and Zstd.compressBound: the reference compresses straight into it and its writers want
+    working room (8 bytes of slack behind every bit stream, two-byte stores of table descriptions, 18 bytes for any frame header), so
+    it answers dstSize_tooSmall although the frame would fit, or — when the block fits raw — emits the raw block
+    (N/compress/zstd_compress.c:3024-3030).  Same answer here for every capacity (T/scala/Zstd.scala:186-201 is the reference's own
+    near-exact-destination test); tools/fuzz_emu_tight.py is the randomised version (levels 1-8, multi-block, dictionaries)."""
+    import ctypes as C
+    import random
+    rnd = random.Random(77)
+    def small(n, a):
+        d = bytearray(rnd.randrange(a) for _ in range(n))
+        if n > 40: d[n - 12:n - 4] = d[3:11]
+        return bytes(d)
+    def barely(seed):                                  # small, barely compressible: the window where the reference emits the block raw instead
+        r = random.Random(seed)
+        n = r.randrange(20, 400); a = r.choice([3, 6, 12, 24, 48, 100]); d = bytearray(r.randrange(a) for _ in range(n))
+        for _ in range(r.choice([0, 1, 2, 4])):
+            ln = r.randrange(4, 12); at = r.randrange(0, max(1, n - 2 * ln)); to = r.randrange(at + ln, max(at + ln + 1, n - ln + 1))
+            d[to:to + ln] = d[at:at + ln]
+        return bytes(d[:n])
+    inputs = [barely(2), barely(32), barely(49), barely(57), b"", b"a", b"abcdefg" * 3, small(70, 4), small(120, 12), small(200, 40), small(380, 100), bytes(rnd.getrandbits(8) for _ in range(300)),
+              golden("xmlsmall")[:3000], zj.synth_host(9000, 5, 1), zj.synth_host(65536, 1, 1), b"\x07" * 5000, zj.synth_host(140000, 3, 1)]
+    seen = {"refused although it fits": 0, "raw instead": 0}
+    for data in inputs:
+        for level in ((1, 3) if len(data) > 20000 else (1, 2, 3, 5)):
+            hl, cl = (14, 13) if (level == 3 and 8192 < len(data) <= 131072) else (0, 0)
+            for ck in (False, True):
+                full = oracle_ref.compress(data, level, ck, hl, cl)
+                fn = emu.emu_compress_multi if (len(data) > 131072 or level >= 4) else emu.emu_compress
+                caps = list(range(max(0, len(full) - 2), len(full) + 24)) + [0, 8, 17, 18, len(data), len(data) + 3, len(data) + 9, len(data) + 12, len(data) + 20]
+                for cap in (caps if len(data) < 20000 else caps[::3]):
+                    try: want = oracle_ref.compress(data, level, ck, hl, cl, cap=cap)
+                    except oracle_ref.ZstdRefError as e: want = -e.code
+                    dst = C.create_string_buffer(cap + 8)
+                    r = fn(data, len(data), dst, cap, level | (int(ck) << 8))
+                    got = -((1 << 64) - r) if r >= (1 << 63) else dst.raw[:r]
+                    assert got == want, (len(data), level, ck, cap, len(full))
+                    if isinstance(want, int) and cap >= len(full): seen["refused although it fits"] += 1
+                    if not isinstance(want, int) and want != full: seen["raw instead"] += 1
+    assert seen["refused although it fits"] > 500 and seen["raw instead"] > 0, seen
+
+
 def test_emu_encoder_tiny_text_frames(emu, oracle_ref):
     """short natural-text frames sit right at the compressed-vs-raw block decision (ZSTD_minGain): both
     pipelines must take the reference's side of it (regression: 70-byte frame with 0 sequences)"""

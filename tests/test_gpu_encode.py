@@ -156,6 +156,45 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     assert bytes(dst[100:100 + n]) == z and dst[:100] == bytes(100)
 
 
+@pytest.mark.parametrize("n_min", [1, 5000])
+def test_gpu_tight_destinations(gpu, oracle_ref, monkeypatch, n_min):
+    """destinations between a frame's size and Zstd.compressBound: the reference wants working room (8 bytes of slack behind every bit
+    stream, two-byte stores of table descriptions, 18 bytes for any header) and answers dstSize_tooSmall although the frame would fit, or
+    emits the block raw when that fits — the same answer, code or bytes, for every capacity, on the small-batch (fused) kernels and on
+    the large-batch pipeline (tests/test_emu_encode.py::test_emu_tight_destinations on the lane-serial build; T/scala/Zstd.scala:186-201)"""
+    if n_min > 1: monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")          # the lane match finder + entropy kernel route regardless of batch size
+    rnd = random.Random(78)
+    def barely(seed):
+        r = random.Random(seed)
+        n = r.randrange(20, 400); a = r.choice([3, 6, 12, 24, 48, 100]); d = bytearray(r.randrange(a) for _ in range(n))
+        for _ in range(r.choice([0, 1, 2, 4])):
+            ln = r.randrange(4, 12); at = r.randrange(0, max(1, n - 2 * ln)); to = r.randrange(at + ln, max(at + ln + 1, n - ln + 1))
+            d[to:to + ln] = d[at:at + ln]
+        return bytes(d[:n])
+    inputs = [barely(k) for k in (2, 32, 49, 57)] + [barely(1000 + k) for k in range(12)] + [b"", b"a", b"abcdefg" * 3, bytes(rnd.getrandbits(8) for _ in range(300)),
+              golden("xmlsmall")[:3000], gpu.synth_host(9000, 5, 1), gpu.synth_host(65536, 1, 1), gpu.synth_host(65536, 7, 1), b"\x07" * 5000, gpu.synth_host(140000, 3, 1)]
+    refused = raw = 0
+    for level in (1, 3, 5):
+        for ck in (False, True):
+            datas, caps, wants = [], [], []
+            for data in inputs:
+                if level >= 5 and len(data) > 16384: continue
+                hl, cl = (14, 13) if (level == 3 and 8192 < len(data) <= 131072) else (0, 0)
+                full = oracle_ref.compress(data, level, ck, hl, cl)
+                cs = list(range(max(0, len(full) - 2), len(full) + 24)) + [0, 8, 17, 18, len(data), len(data) + 3, len(data) + 9, len(data) + 12, len(data) + 20]
+                for cap in (cs if len(data) < 20000 else cs[::4]):
+                    try: want = oracle_ref.compress(data, level, ck, hl, cl, cap=cap)
+                    except oracle_ref.ZstdRefError as e: want = -e.code
+                    datas.append(data); caps.append(cap); wants.append(want)
+                    refused += isinstance(want, int) and cap >= len(full)
+                    raw += (not isinstance(want, int)) and want != full
+            outs = gpu.compress_batch(datas, level, ck, capacities=caps)
+            for d, cap, want, z in zip(datas, caps, wants, outs):
+                got = -z.getErrorCode() if isinstance(z, Exception) else z
+                assert got == want, (level, ck, len(d), cap, want if isinstance(want, int) else len(want), got if isinstance(got, int) else len(got))
+    assert refused > 500 and raw > 0, (refused, raw)
+
+
 @pytest.mark.parametrize("level", [1, 3])
 @pytest.mark.parametrize("size,count", [(4096, 2048), (65536, 1024), (131072, 256)])
 def test_gpu_device_batch_roundtrip_and_ratio(gpu, oracle_port, oracle_ref, level, size, count):

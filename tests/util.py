@@ -48,9 +48,10 @@ class EmuCDict:
         keys = ["dictID", "contentSize", "windowLog", "chainLog", "hashLog", "minMatch", "strategy", "hufRepeat", "llRepeat", "ofRepeat", "mlRepeat", "fillStart"]
         return dict(zip(keys, list(out)))
 
-    def compress(self, data, checksum=False, dict_id=True):
-        cap = len(data) + (len(data) >> 8) + 64 + 128
-        dst = C.create_string_buffer(cap)
+    def compress(self, data, checksum=False, dict_id=True, cap=None):
+        if cap is None:
+            cap = len(data) + (len(data) >> 8) + 64 + 128
+        dst = C.create_string_buffer(max(cap, 1))
         r = self.L.emu_compress_cdict(self.ptr, data, len(data), dst, cap, int(checksum) | (0 if dict_id else 4))
         if r >= (1 << 63):
             return -((1 << 64) - r)

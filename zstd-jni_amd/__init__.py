@@ -543,10 +543,12 @@ def _check_launch(r):
         raise ZstdException(r)
 
 
-def compress_batch(buffers, level=3, checksum=False, dictionary=None, hash_log=0, chain_log=0):
+def compress_batch(buffers, level=3, checksum=False, dictionary=None, hash_log=0, chain_log=0, capacities=None):
     """n independent buffers -> n zstd frames through zjni_compress_batch2 / _usingCDict / _advanced (host pointers);
-    `dictionary` is a ZstdDictCompress (its level applies); hash_log / chain_log = ZstdCompressCtx.setHashLog / setChainLog."""
-    return _host_batch(buffers, [Zstd.compressBound(len(b)) for b in buffers], True, level, checksum, dictionary, hash_log, chain_log)
+    `dictionary` is a ZstdDictCompress (its level applies); hash_log / chain_log = ZstdCompressCtx.setHashLog / setChainLog;
+    `capacities` = the destination sizes (default Zstd.compressBound of each buffer, what Zstd.compress(src) allocates)."""
+    caps = [Zstd.compressBound(len(b)) for b in buffers] if capacities is None else list(capacities)
+    return _host_batch(buffers, caps, True, level, checksum, dictionary, hash_log, chain_log)
 
 
 def decompress_batch(frames, capacities, dictionary=None):

@@ -75,6 +75,7 @@ struct ZEncShared {                // uniforms, outside the overlay
     u32 seqType[3], seqHdr[3], seqLastCount;
     u32 tstate[3];                 // tANS encoder states LL, OF, ML carried across 64-sequence batches
     u32 tmp[8];
+    u32 tight, tightHuf;           // the reference would have run out of destination somewhere on the way to this block's bytes (ze_compress_t "tight destinations")
     u32 edge[6];                   // LL/OF/ML codes of the first and of the last sequence
     // dictionary state kept across the frames one workgroup encodes (the kernel clears dictLoaded / ctDict once)
     u32 dictLoaded, dictID, dictStrategy, dictMinMatch, dictHufRep, dictHufMaxSV, dictFseRep[3];
@@ -892,7 +893,9 @@ ZJ_DEV bool ze_fse_normalize(short* norm, u32 tableLog, const u32* count, u32 to
     return true;
 }
 
-ZJ_DEV u32 ze_fse_write_ncount(u8* out0, const short* norm, u32 maxSV, u32 tableLog) {   // fse_compress.c:237-328
+// `need` (optional) = bytes of buffer the reference's writer wants: its stores are two bytes wide and each is refused when fewer than two
+// bytes are left (`out > oend - 2`, fse_compress.c:268-321) — the last store decides, and it can reach one byte past the description.
+ZJ_DEV u32 ze_fse_write_ncount(u8* out0, const short* norm, u32 maxSV, u32 tableLog, u32* need = nullptr) {   // fse_compress.c:237-328
     u8* out = out0; i32 nbBits; i32 const tableSize = 1 << tableLog; i32 remaining, threshold;
     u32 bitStream = 0; i32 bitCount = 0; u32 symbol = 0; u32 const alphabetSize = maxSV + 1; bool previousIs0 = false;
     bitStream += (tableLog - 5) << bitCount; bitCount += 4;
@@ -919,6 +922,7 @@ ZJ_DEV u32 ze_fse_write_ncount(u8* out0, const short* norm, u32 maxSV, u32 table
         if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
     }
     if (remaining != 1) return 0;
+    if (need) *need = (u32)(out - out0) + 2u;
     out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += (bitCount + 7) / 8;
     return (u32)(out - out0);
 }
@@ -1075,8 +1079,11 @@ ZJ_DEV u32 ze_huf_build(ZEEntropy& e, u32 maxSV, u32 maxNbBits) {
     return maxNbBits;
 }
 
-// HUF_compressWeights (huf_compress.c:132-176): 0 not compressible, 1 rle, else size
-ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize) {
+// HUF_compressWeights (huf_compress.c:132-176): 0 not compressible, 1 rle, else size.
+// `cap` = the room the reference's call is given (everything left of the block's destination): *tight |= 1 when its table description
+// does not fit (an error there), *tight |= 2 when its bit stream does not (8 bytes of slack: BIT_initCStream / BIT_closeCStream,
+// bitstream.h:177-186, 258-267 — "not compressible" there, i.e. the raw weights follow).  The bytes written here do not depend on `cap`.
+ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize, u32 cap = 0xFFFFFFFFu, u32* tight = nullptr) {
     const u8* const w = e.weight; u32* const count = e.scount; short* const norm = e.norm; u32 maxSV = 0, maxCount = 0; u8* op = dst;
     if (wtSize <= 1) return 0;
     for (u32 s = 0; s <= 12; s++) count[s] = 0;
@@ -1086,7 +1093,8 @@ ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize) {
     if (maxCount == 1) return 0;
     u32 const tableLog = ze_fse_optimal_log(6, wtSize, maxSV, 2);
     if (!ze_fse_normalize(norm, tableLog, count, wtSize, maxSV, false)) return 0;
-    {   u32 const h = ze_fse_write_ncount(op, norm, maxSV, tableLog); if (!h) return 0; op += h; }
+    {   u32 need = 0; u32 const h = ze_fse_write_ncount(op, norm, maxSV, tableLog, &need); if (!h) return 0; op += h;
+        if (tight && need > cap) *tight |= 1u; }
     ZEFseCT& ct = e.ct[0];
     ze_fse_build_ctable(ct, norm, maxSV, tableLog, e.cumul, e.tableSymbol);
     {   const u8* ip = w + wtSize; ZEBitW b; ZEFseCS s1, s2; u32 n = wtSize; u8* const bstart = op;   // fse_compress.c:549-606
@@ -1098,16 +1106,24 @@ ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize) {
         if (n & 2) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
         while (ip > w) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
         ze_bw_add(b, s2.value, ct.tableLog); ze_bw_add(b, s1.value, ct.tableLog);
+        if (tight) {                                              // whole bytes before the end mark's byte must stay 8 short of the end
+            u32 const used = (u32)(bstart - dst), fullBytes = (u32)((((u64)(b.p - bstart)) * 8u + b.n + 1u) >> 3);
+            if (cap < used + 9u || fullBytes + 8u >= cap - used) *tight |= 2u;
+        }
         op = bstart + ze_bw_close(b, bstart);
     }
     return (u32)(op - dst);
 }
 
-// HUF_writeCTable_wksp (huf_compress.c:248-290); 0 on failure
-ZJ_DEV u32 ze_huf_write_ctable(ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog) {
+// HUF_writeCTable_wksp (huf_compress.c:248-290); 0 on failure.  `cap` / `tight`: the reference's maxDstSize, and whether it would have
+// run out of it on the way to these bytes (the caller then treats the block as the reference does: not compressible)
+ZJ_DEV u32 ze_huf_write_ctable(ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog, u32 cap = 0xFFFFFFFFu, bool* tight = nullptr) {
     for (u32 n = 0; n < maxSV; n++) e.weight[n] = e.nbBits[n] ? (u8)(huffLog + 1 - e.nbBits[n]) : 0;
-    {   u32 const h = ze_huf_compress_weights(e, op + 1, maxSV);
-        if ((h > 1) & (h < maxSV / 2)) { op[0] = (u8)h; return h + 1; } }
+    {   u32 tw = 0;
+        u32 const h = ze_huf_compress_weights(e, op + 1, maxSV, cap ? cap - 1u : 0u, tight ? &tw : nullptr);
+        if (tight && (cap < 1u || (tw & 1u))) *tight = true;
+        if ((h > 1) & (h < maxSV / 2)) { if (tight && tw) *tight = true; op[0] = (u8)h; return h + 1; } }
+    if (tight && ((maxSV + 1) / 2) + 1 > cap) *tight = true;
     if (maxSV > 128) return 0;
     op[0] = (u8)(128 + (maxSV - 1));
     e.weight[maxSV] = 0;
@@ -1337,7 +1353,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
 
     // ---- frame header (ZSTD_writeFrameHeader, contentSizeFlag = 1; dictID of the attached dictionary if it has one) ----
     GRP_SERIAL(g) {
-        sh.err = 0;
+        sh.err = 0; sh.tight = 0; sh.tightHuf = 0;
         if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
         else { ze_params(sh, level, ba ? ba->frameSize : srcSize); if (sh.strategy == 0) sh.err = 201; }     // a (level, size) the reference serves with a finder this library does not restate
         if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
@@ -1358,7 +1374,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         if (cd && (!pre || (srcSize > (sh.dictStrategy == 2 ? (16u << 10) : (8u << 10))
                             && !(pre->copyMode && srcSize <= (128u << 10) && (srcSize < (128u << 10) || (u64)srcSize < (u64)cd->contentSize * 6u))))) sh.err = ZJ_E_PARAM_UNSUPPORTED;
         else if (cd && noFcs) sh.err = ZJ_E_PARAM_UNSUPPORTED;               // (the attached dictionary's window descriptor is not restated here)
-        else if (dstCap < hdr + 3 + tail) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
+        // room: ZSTD_writeFrameHeader wants ZSTD_FRAMEHEADERSIZE_MAX = 18 bytes whatever the header's size (zstd_compress.c:4711-4712), the block
+        // loop 3 + 2 + 1 bytes before every block (:4629-4631), the epilogue of an empty frame its 3 (+ 4) bytes (:5362, :5371)
+        else if (dstCap < 18u || (srcSize ? dstCap - hdr < 6u : dstCap < hdr + 3 + tail)) sh.err = ZJ_E_DSTSIZE_TOO_SMALL;
         else {
             st32(dst, 0xFD2FB528u); dst[4] = (u8)((noFcs ? 0u : (1u << 5)) + (fcsCode << 6) + (tail ? 4u : 0u) + didCode);
             u8* dp = dst + 5;
@@ -1377,6 +1395,15 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         return hdr + 3 + tail;
     }
     bool compressed = false; u32 cSize = 0;
+    // Tight destinations.  The reference compresses a block straight into what is left of the destination (capBody bytes behind the block
+    // header) and its writers want working room: literals and table descriptions are refused when they do not fit, every bit stream needs
+    // 8 bytes of slack behind its last whole byte (HUF_initCStream / HUF_closeCStream, huf_compress.c:862-871, 975-984; BIT_initCStream /
+    // BIT_closeCStream), table descriptions are stored two bytes at a time.  Whenever one of them gives up, ZSTD_entropyCompressSeqStore
+    // calls the block "not compressible" if it fits raw and fails with dstSize_tooSmall if not (zstd_compress.c:3024-3030) — every detour
+    // in between (raw literals where Huffman found no room, raw weights where their tANS stream found none) ends there too, because what
+    // it writes instead is larger.  So the block is assembled as always and `sh.tight` records whether any step of the reference's walk
+    // through the same bytes would have given up; a tight block is then emitted raw, or refused.
+    u32 const capBody = dstCap - hdr - 3u;
     // body goes straight into dst when even the raw fallback fits, else into HBM scratch first
     bool const direct = !small && dstCap >= hdr + 3 + srcSize + 64;
     u8* const body = small ? xl : (direct ? dst + hdr + 3 : ws + ZE_WS_BODY);   // small: over the staged source, dead once the literals are gathered
@@ -1529,7 +1556,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         else {
                             u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
                             huffLog = ze_huf_build(e, maxSV, huffLog);
-                            h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog);
+                            {   bool tg = false;
+                                h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog, capBody > lhSize ? capBody - lhSize : 0u, &tg);
+                                if (tg) sh.tightHuf = 1; }
                             sh.ctDict[0] = 0;                                     // the weights' tANS table went through e.ct[0]
                             if (!h) m = 0;
                             else {
@@ -1559,12 +1588,19 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                     u32 m = sh.litMode; u32 const h = sh.hufHdr, largest = sh.tmp[7];
                     if (m >= 2) {
                         u32 total = h + (single ? 0 : 6); bool tooBig = false;
+                        // room left for the streams in the reference's call: HUF_compress4X_usingCTable_internal wants 17 bytes up front and
+                        // its jump table, every stream 8 bytes to start and 8 of slack at its end (huf_compress.c:1080-1118, 1179-1213)
+                        i64 room = (i64)capBody - (i64)lhSize - (i64)h; bool tg = capBody < lhSize + 1u;
+                        if (!single) { if (room < 17) tg = true; room -= 6; }
                         for (u32 t = 0; t < (single ? 1u : 4u); t++) {
                             u32 const bits = sh.strBytes[t];
                             u32 const bytes = (bits + 1 + 7) >> 3;
+                            if (room <= 8 || (i64)((bits + 1) >> 3) >= room - 8) tg = true;
+                            room -= bytes;
                             sh.strBytes[t] = bytes; sh.strOff[t] = total; total += bytes;
                             if (bytes > 65535) tooBig = true;
                         }
+                        if (tg) sh.tightHuf = 1;
                         if (!single && n < 12) tooBig = true;
                         if (tooBig || total >= n - 1 || total >= n - ((n >> 6) + 2)) m = 0;
                         else if (total == 1 && largest == n) m = 1;              // one byte out: rle if all literals are the same byte (n < 8 here)
@@ -1578,11 +1614,14 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         }
                     }
                     sh.litMode = m;
+                    if (m >= 1 && sh.tightHuf) sh.tight = 1;                     // (a Huffman attempt that ends in raw literals anyway took no detour)
+                    if (m == 1 && capBody < lhSize + 1u) sh.tight = 1;           // ZSTD_compressLiterals' test before the attempt (zstd_compress_literals.c:163)
                 }
                 g.sync();
                 pf.mark(3);
                 mode = ZJ_UNI(sh.litMode);
             }
+            if (mode == 0 && n + 1u + (n > 31) + (n > 4095) > capBody) { GRP_SERIAL(g) { sh.tight = 1; } }   // ZSTD_noCompressLiterals (zstd_compress_literals.c:46)
             if (mode >= 2) {
                 u32 const streams = single ? 1u : 4u;
                 u32* const codes = e.count;                                    // histogram is dead: code | nbBits << 16 per symbol
@@ -1612,6 +1651,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
             u32 pos = ZJ_UNI(sh.litSecSize);
             GRP_SERIAL(g) {
                 u8* op = body + pos;
+                if ((i64)capBody - (i64)pos < 4) sh.tight = 1;               // "Can't fit seq hdr in output buf!" (zstd_compress.c:2939-2940)
                 if (nbSeq < 128) *op++ = (u8)nbSeq;
                 else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
                 else { op[0] = 0xFF; st16(op + 1, nbSeq - 0x7F00); op += 3; }
@@ -1667,14 +1707,17 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         }
                         u32 h = 0;
                         u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];
-                        if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1; }
+                        if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1;
+                                         if (pos >= capBody) sh.tight = 1; }   // ZSTD_buildCTable, set_rle: "not enough space" (zstd_compress_sequences.c:255)
                         else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, e.cumul, e.tableSymbol);
                         else if (type == 3) h = 0;                             // table copied below by the whole wave
                         else {
                             u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
                             if (scount[lastCode] > 1) { scount[lastCode]--; nbSeq1--; }
                             ze_fse_normalize(e.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048);
-                            h = ze_fse_write_ncount(body + pos, e.norm, max, tableLog);
+                            {   u32 need = 0;
+                                h = ze_fse_write_ncount(body + pos, e.norm, max, tableLog, &need);
+                                if ((u64)pos + need > capBody) sh.tight = 1; }            // FSE_writeNCount into what is left (zstd_compress_sequences.c:279-280)
                             ze_fse_build_ctable(e.ct[t], e.norm, max, tableLog, e.cumul, e.tableSymbol);
                             sh.seqLastCount = h;
                         }
@@ -1807,6 +1850,9 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                     }
                     g.sync();
                     ze_stage_flush(g, sh, st, ZJ_UNI(sh.tmp[5]));
+                    {   // ZSTD_encodeSequences: more than 8 bytes to start, 8 bytes of slack behind the last whole byte (zstd_compress_sequences.c:300-302, 377-378)
+                        i64 const room = (i64)capBody - (i64)pos; u32 const fullBytes = 4u * st.flushedWords + (st.carryBits >> 3);
+                        if (room <= 8 || (i64)fullBytes >= room - 8) { GRP_SERIAL(g) { sh.tight = 1; } } }
                     u32 const bitSize = ze_stage_finish(g, st);
                     GRP_SERIAL(g) { sh.tmp[2] = bitSize; }
                 } else { GRP_SERIAL(g) { sh.tmp[2] = 0xFFFFFFFFu; } }
@@ -1825,6 +1871,10 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         // ZSTD_compressBlock_internal's tail (zstd_compress.c:4422-4447) + the block header of ZSTD_compress_frameChunk (:4651-4661):
         // a block of one repeated byte becomes an RLE block unless it is the frame's first; only a block emitted compressed
         // confirms its repcodes and its Huffman table for the blocks that follow
+        if (compressed && ZJ_UNI(sh.tight)) {                  // the reference ran out of room on the way: raw (or RLE) if that fits, else dstSize_tooSmall
+            if (srcSize > capBody) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+            compressed = false;
+        }
         u32 type = compressed ? 2u : 0u;
         if (srcSize >= 7 && !ba->isFirst && (compressed ? cSize : 0u) < 25u) {
             GRP_SERIAL(g) { sh.tmp[0] = 1; }
@@ -1852,6 +1902,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         return 3 + bodySize;
     }
     // ---- block header + placement ----
+    if (compressed && ZJ_UNI(sh.tight)) compressed = false;   // the reference ran out of room on the way: a raw block if that fits, else dstSize_tooSmall
     u32 const bodySize = compressed ? cSize : srcSize;
     if (dstCap < hdr + 3 + bodySize + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
     if (compressed) {
@@ -1909,7 +1960,7 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
     u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
     bool const noFcs = (flags & ZE_FLAG_NO_FCS) != 0;
     u32 const hdr = noFcs ? 6u : 9u;                               // magic, descriptor, then the window byte or the 4-byte content size (single segment)
-    if (dstCap < hdr + 3 + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    if (dstCap < 18u) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);     // ZSTD_writeFrameHeader wants ZSTD_FRAMEHEADERSIZE_MAX (zstd_compress.c:4711-4712)
     GRP_SERIAL(g) {
         st32(dst, 0xFD2FB528u);
         if (noFcs) { dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((p.windowLog - 10u) << 3); }
