@@ -78,7 +78,11 @@ size_t zjni_decompress_batch_device(const void* d_src, const uint64_t* d_src_off
  * no dictID) that any zstd decoder accepts.  level: 1..3 (N/compress/clevels.h), or 4 for inputs up to ZJNI_LEVEL4_MAX / 5..8 up to ZJNI_LAZY_MAX (plain
  * entries only: no dictionary, no explicit table sizes; a wave-per-frame kernel with one lane parsing — exact, not fast).  Buffers larger than
  * ZJNI_BLOCKSIZE_MAX become multi-block frames (one wavefront per frame, block after block; see ZJNI_FRAME_MAX for the
- * range); beyond it d_result[i] reports ZJNI_ERROR_unsupported and the buffer stays on the CPU path. */
+ * range); beyond it d_result[i] reports ZJNI_ERROR_unsupported and the buffer stays on the CPU path.
+ * Destination capacity (d_dst_off[i+1] - d_dst_off[i]): with zjni_compressBound(srcSize) a frame always fits.  With less, the answer is
+ * ZSTD_compress2's for that capacity — which wants working room beyond the frame's bytes (18 bytes for any header, 8 bytes of slack behind
+ * each bit stream, N/compress/zstd_compress.c:4711, 3024-3030; DESIGN.md section 1 "tight destination"): ZSTD_error_dstSize_tooSmall possibly
+ * although the frame would have fitted, or a raw block where the compressed one found no room — same size, bytes or code. */
 size_t zjni_compress_batch_device(const void* d_src, const uint64_t* d_src_off,
                                   void* d_dst, const uint64_t* d_dst_off,
                                   uint64_t* d_result, size_t n, int level, void* stream);
