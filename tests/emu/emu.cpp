@@ -4,6 +4,7 @@
 #include "../../zstd-jni_amd/csrc/zj_decode.h"
 #include "../../zstd-jni_amd/csrc/zj_decode_split.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 // -DEMU_EXACT (the sanitizer build): every entry point works on exact-size heap copies of the caller's source and destination, so
@@ -162,7 +163,19 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     u8* table = (u8*)calloc(1, ze_lane_table_stride(lw, wide));
     u8* fs = (u8*)malloc(ZE_FRAME_STRIDE(maxSrc));
     u32 meta[3];
-    ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide);
+    // ZJNI_EMU_NEED=1: the need-gated double-fast machine behind zn_flags_frame (zj_need.h), as zj_enc_need_kernel + zj_enc_match_kernel run it
+    u8* nflags = nullptr;
+    {   ZEParams const p = ze_params_of(lw, srcSize);
+        if (level == 3 && !wide && getenv("ZJNI_EMU_NEED") && zn_takes(p.hashLog, p.chainLog, srcSize)) {
+            struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
+            ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));
+            nflags = (u8*)malloc(srcSize + ZN_FLAG_SLACK); memset(nflags, 0xFF, srcSize + ZN_FLAG_SLACK);
+            zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
+            if (getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
+            free(L);
+        } }
+    ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide, nflags);
+    free(nflags);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
     u64 r = ze_compress(g, *sh, lds, src, srcSize, dst, dstCap, lw, ws, pf, &pre, flags, nullptr, 160u * 1024u);

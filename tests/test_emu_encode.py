@@ -162,6 +162,20 @@ def test_emu_tight_destinations(emu, oracle_ref, zj):
     assert seen["refused although it fits"] > 500 and seen["raw instead"] > 0, seen
 
 
+def test_emu_need_gated_double_fast(emu, oracle_ref, zj, monkeypatch):
+    """the need-gated double-fast machine (zj_need.h, ZJNI_NEED=1 in the library; ZJNI_EMU_NEED=1 here): table probes are made only where some
+    other position of the frame carries the probe's key, table writes only into buckets such a probe reads — decided per position by Bloom
+    filters ahead of the parse.  Same frames as the ungated machine = the reference's (the randomised run: 400 000 frames, 0 differences)."""
+    monkeypatch.setenv("ZJNI_EMU_NEED", "1")
+    rnd = random.Random(41)
+    datas = [zj.synth_host(65536, k, 1) for k in range(8)] + [zj.synth_host(s, 100 + s, 1) for s in (64, 65, 1000, 8192, 8193, 30000, 65535)]
+    datas += [bytes([7]) * 40000, bytes(rnd.getrandbits(8) for _ in range(20000)), (b"abcdefgh" * 5000)[:33333], golden("xmlsmall")[:60000]]
+    for d in datas:
+        assert emu_compress(emu, d, 3, split=True) == expected(oracle_ref, d, 3), len(d)
+        for hl, cl in ((15, 15), (12, 9)):
+            assert emu_compress(emu, d, 3, split=True, hash_log=hl, chain_log=cl) == oracle_ref.compress(d, 3, False, hl, cl), (len(d), hl, cl)
+
+
 def test_emu_encoder_tiny_text_frames(emu, oracle_ref):
     """short natural-text frames sit right at the compressed-vs-raw block decision (ZSTD_minGain): both
     pipelines must take the reference's side of it (regression: 70-byte frame with 0 sequences)"""

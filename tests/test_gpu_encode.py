@@ -156,6 +156,21 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     assert bytes(dst[100:100 + n]) == z and dst[:100] == bytes(100)
 
 
+def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch):
+    """ZJNI_NEED=1 (experiment, off by default; zj_need.h): the flag kernel + the need-gated lane machine give the same frames"""
+    monkeypatch.setenv("ZJNI_NEED", "1")
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    rnd = random.Random(43)
+    datas = [gpu.synth_host(65536, k, 1) for k in range(96)] + [gpu.synth_host(s, 100 + s, 1) for s in (64, 65, 1000, 8192, 8193, 30000, 65535, 63, 0)]
+    datas += [bytes([7]) * 40000, bytes(rnd.getrandbits(8) for _ in range(20000)), (b"abcdefgh" * 5000)[:33333], golden("xmlsmall")[:60000]]
+    outs = gpu.compress_batch(datas, 3)
+    for d, z in zip(datas, outs):
+        assert z == (oracle_ref.compress(d, 3) if len(d) <= 8192 else oracle_ref.compress(d, 3, False, 14, 13)), len(d)
+    outs = gpu.compress_batch(datas, 3, hash_log=15, chain_log=15)
+    for d, z in zip(datas, outs):
+        assert z == oracle_ref.compress(d, 3, False, 15, 15), len(d)
+
+
 @pytest.mark.parametrize("n_min", [1, 5000])
 def test_gpu_tight_destinations(gpu, oracle_ref, monkeypatch, n_min):
     """destinations between a frame's size and Zstd.compressBound: the reference wants working room (8 bytes of slack behind every bit

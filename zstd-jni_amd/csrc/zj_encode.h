@@ -2013,16 +2013,19 @@ ZJ_DEV void ze_match_lane_serial(const u8* src, u32 srcSize, u32 level, u8* tabl
 
 // One frame through the lane machinery, start to finish (emulation and single-frame callers; the kernel
 // interleaves 64 of these per wavefront, see zj_enc_match_kernel).  Output: records + meta {nbSeq, litSize, lastLL}.
+#include "zj_need.h"
 template <class M>
-ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta) {
-    M m; m.init(src, srcSize, ze_params_of(level, srcSize), table, fscratch, maxSrc);
+ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, const u8* flags = nullptr) {
+    M m; m.init(src, srcSize, ze_params_of(level, srcSize), table, fscratch, maxSrc, flags);
     for (u32 r = 0; m.st != ZL_DONE; r++) m.round(M::phase_of(r));
     meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
 }
 // `wide`: the frame is in the launch whose fast-strategy tables hold 4-byte positions (frames > 64 KiB, and the few
 // small level-1/2 frames whose hashLog exceeds the common case)
-ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false) {
+// `flags` (zj_need.h, level 3): the frame's flag bytes — the gated machine
+ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false, const u8* flags = nullptr) {
     if (srcSize < ZL_MIN_FRAME) ze_match_lane_serial(src, srcSize, level, table, fscratch, maxSrc, meta);
+    else if (ZE_LW_LEVEL(level) == 3 && flags) ze_match_lane_t<ZLaneD<ZEEntTag, true> >(src, srcSize, level, table, fscratch, maxSrc, meta, flags);
     else if (ZE_LW_LEVEL(level) == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else if (wide) ze_match_lane_t<ZLaneF<ZEEnt32> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else ze_match_lane_t<ZLaneF<ZEEnt16> >(src, srcSize, level, table, fscratch, maxSrc, meta);

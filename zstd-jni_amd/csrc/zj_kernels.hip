@@ -248,7 +248,7 @@ template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
                                              u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                             unsigned long long* work2 = nullptr) {
+                                             unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr) {
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
     bool have = false; u32 k = 0;
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : ZL_DFAST_PERIOD; u32 ph = 0;   // double-fast machine: rounds per rotation of the non-search states
@@ -267,7 +267,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
             if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
-            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc);
+            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, flagsBase ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
             have = true;
         }
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
@@ -290,6 +290,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     list += listBase;
     if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
     else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
+}
+
+// ---- need-gated level 3 (zj_need.h; ZJNI_NEED=1) ----
+// zj_enc_need_kernel: one workgroup of 512 lanes per frame computes the frame's flag bytes (which probes can match, which writes can be
+// read) with Bloom filters in LDS; zj_enc_match_gated_kernel is zj_enc_match_kernel on the gated double-fast machine.
+struct ZNThreads {
+    __device__ __forceinline__ u32 id() const { return threadIdx.x; }
+    __device__ __forceinline__ u32 count() const { return blockDim.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+__global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase) {
+    ZNLds& L = *(ZNLds*)zj_dyn_lds;
+    ZNThreads t;
+    u32 const count = *countPtr;
+    for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+        u32 const i = list[k];
+        u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
+        if (size < ZL_MIN_FRAME) continue;               // the plain loops take these (zj_match_run)
+        ZEParams const p = ze_params_of(level, size);
+        zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);
+    }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_gated_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
+                                                           u32 listBase, u32 sliceLen, const u8* flagsBase) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    list += listBase;
+    zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase);
 }
 
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
@@ -1239,7 +1269,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
-        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256;
+        // ZJNI_NEED=1 (experiment, zj_need.h): level 3 on the need-gated machine — a flag byte per position ahead of the match kernel
+        bool needGate = false;
+        if (const char* ov = getenv("ZJNI_NEED")) {
+            u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
+            needGate = ov[0] == '1' && level == 3 && !smallWave && getenv("ZJNI_HYBRID") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
+        }
+        size_t const needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + 64 : 0;
+        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
@@ -1248,6 +1285,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         }
         u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
         u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
+        u8* const needFlags = needGate ? (u8*)(((uintptr_t)(score + n) + 63) & ~(uintptr_t)63) : nullptr;
+        if (needGate) {
+            static bool ldsSet = false;                     // more than 64 KiB of dynamic LDS has to be asked for once
+            if (!ldsSet) { if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); ldsSet = true; }
+        }
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
         bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
         // Experiment (ZJNI_HYBRID=1, off by default): at level 3 with the LDS-sized tables the two match
@@ -1280,6 +1322,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
         unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
+        if (needGate) {      // ahead of the fork: the flag kernel's workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
+            u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
+            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags);
+        }
         if (overlap) {
             // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
             // frames that parse quickly are entropy-coded while the slow ones still occupy their lanes (the match
@@ -1298,6 +1344,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machine (0 = ZL_DFAST_PERIOD)
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
+            if (needGate) {
+                hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
+                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags);
+            } else
             if (!waveOnly)
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu,
@@ -1313,6 +1363,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         } else {
             (void)hipEventRecord(d->tev[0], st);
+            if (needGate)
+                hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (const u8*)needFlags);
+            else
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (unsigned long long*)nullptr);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;

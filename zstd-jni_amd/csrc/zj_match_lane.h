@@ -40,8 +40,10 @@ ZJ_DEV u64 zl_back_fix(u64 v, u32 pos, u32 at) { u32 const sh = (8u - (pos - at)
 // the state branch that uses it and the round degenerates into one memory round trip per state again.
 #if ZJ_ON_GPU
 #define ZL_ROUND_FENCE9(a, b, c, d, e, f, g, h, i) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "v"(i))
+#define ZL_ROUND_FENCE2(a, b) asm volatile("" :: "v"(a), "v"(b))
 #else
 #define ZL_ROUND_FENCE9(a, b, c, d, e, f, g, h, i) ((void)0)
+#define ZL_ROUND_FENCE2(a, b) ((void)0)
 #endif
 ZJ_DEV u32 zl_common_fwd16(u64 a0, u64 a1, u64 b0, u64 b1) {
     u64 const x0 = a0 ^ b0, x1 = a1 ^ b1;
@@ -88,10 +90,16 @@ enum { ZC_REP1 = 0, ZC_LONG, ZC_SHORT, ZC_SHORT_L1, ZC_REPLOOP, ZC_FOUND };
 
 // ---------------------------------------------------------------------------------------------
 // double-fast (level 3).  Positions are offsets from the frame start.
-template <class E>
+// GATED (zj_need.h): a flag byte per position says which table accesses can matter — ZN_NEED_L / ZN_NEED_S: some other position of the frame
+// carries the key this probe would match on (no such position: whatever the entry holds, the byte comparison fails — the entry is not read
+// and counts as empty); ZN_INS_L / ZN_INS_S: some position of the frame will read this position's bucket (none: the entry is not written).
+// A bucket that is read at all receives every write, so a probe that is made sees exactly the entry the reference's probe sees; a probe
+// that is skipped could not have matched.  Same decisions, a fraction of the table requests.
+template <class E, bool GATED = false>
 struct ZLaneD {
     typedef typename E::T Ent;
     const u8* src; u32 n, ilimit; Ent* HL; Ent* HS; ZLHash hL, hS;
+    const u8* F; u32 fI, fN;                          // GATED: the frame's flag bytes; flags of ip and of ip1
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip, ip1, anchor, off1, off2, step, nextStep, curr;
@@ -102,9 +110,10 @@ struct ZLaneD {
     u64 wIns;                                         // the word at curr + 2 (first post-insert) when the search round already holds it
 
 
-    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
+    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc, const u8* flags = nullptr) {
         src = s; n = size; ilimit = size - 8u; hL = zl_hash_of(8, p.hashLog); hS = zl_hash_of(p.minMatch, p.chainLog);
         HL = (Ent*)table; HS = HL + (1u << p.hashLog);
+        F = flags; fI = 15u; fN = 15u;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
         needBack = needCand = more = more2 = cvalid = haveIns = false;
@@ -116,6 +125,8 @@ struct ZLaneD {
     ZJ_DEV_MEMBER u32 idx_long(u32 p) const { return p >> hL.rsh; }
     ZJ_DEV_MEMBER u32 tag_long(u32 p) const { return (p >> (hL.rsh - 15u)) & 0x7FFFu; }
     ZJ_DEV_MEMBER void put_long(u64 v, u32 pos1) { u32 const p = prod_long(v); HL[idx_long(p)] = E::make(pos1, tag_long(p)); }
+    ZJ_DEV_MEMBER void put_long_if(bool on, u64 v, u32 pos1) { if (!GATED || on) put_long(v, pos1); }
+    ZJ_DEV_MEMBER void put_short_if(bool on, u64 v, u32 pos1) { if (!GATED || on) HS[zl_hash(hS, v)] = E::make(pos1, ze_tag4((u32)v)); }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
     // outer-loop header of the reference: reset the step and make sure one more position fits
     ZJ_DEV_MEMBER void outer() {
@@ -127,7 +138,7 @@ struct ZLaneD {
     ZJ_DEV_MEMBER void fin() {             // a long/short match is final: apply the backward extension, store it
         ip -= bk; mLength += bk;
         off2 = off1; off1 = offset;
-        if (step < 4u) HL[hl1] = E::make(ip1 + 1u, tl1);
+        if (step < 4u && (!GATED || (fN & 4u))) HL[hl1] = E::make(ip1 + 1u, tl1);      // (hl1 / fN: the position that was ip1 when the match was found)
         ze_store(o, anchor, ip - anchor, offset + 3u, mLength);
         advance();
     }
@@ -167,7 +178,8 @@ struct ZLaneD {
             ZE_COUNT_ITER();
             curr = ip;
             u32 const tl = tl0, ts = ze_tag4((u32)w);
-            HL[hl0] = E::make(curr + 1u, tl); HS[hs0] = E::make(curr + 1u, ts);
+            if (!GATED || (fI & 4u)) HL[hl0] = E::make(curr + 1u, tl);
+            if (!GATED || (fI & 8u)) HS[hs0] = E::make(curr + 1u, ts);
             ml0 = E::maybe(el0, tl); ms0 = E::maybe(es0, ts);
             pa0 = ip + 1u - off1; v0 = true;
             pa1 = E::pos(el0) - 1u; v1 = ml0;
@@ -203,13 +215,25 @@ struct ZLaneD {
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
         // predicated: a slot nobody asked for costs no transaction (the fence below keeps the loads together)
         u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t0 = 0, t1 = 0;
+        u32 fa = 0, fb = 0;                              // GATED: flag bytes fetched this round (the area has 8 bytes of slack behind the frame's)
+        u32 const fw = (st == ZL_SEARCH) ? fN : fI;      // whose probes this round issues: the next position's (search) / this one's (restart)
         if (v0) r0 = ld64(src + q0);
-        if (on) { r3 = ld64(src + q3); t0 = (u32)HL[ti0]; t1 = (u32)HS[ti1]; }
+        if (on) {
+            r3 = ld64(src + q3);
+            if (!GATED || (fw & 1u)) t0 = (u32)HL[ti0];
+            if (!GATED || (fw & 2u)) t1 = (u32)HS[ti1];
+            if (GATED) {
+                if (st == ZL_SEARCH) fa = F[q3];                                       // flags of ip2 (q3 == ip2 whenever it is a position the search can reach)
+                else if ((K & ZL_EN_POST) && st == ZL_POST) { fa = F[curr + 2u]; fb = ld32(F + ip - 2u); }
+                else if ((K & ZL_EN_POST) && st == ZL_LOADW) fb = ld16(F + ip) << 16;
+            }
+        }
         if (v1) r1 = ld64(src + q1);
         if (v2) r2 = ld64(src + q2);
         if ((K & ZL_EN_COUNT) && v4) r4 = ld64(src + q4);
         if ((K & ZL_EN_COUNT) && vb) { rb0 = ld64(src + qb0); rb1 = ld64(src + qb1); }
         ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t0, t1);
+        if (GATED) ZL_ROUND_FENCE2(fa, fb);
         ZL_PROF_T2();
         u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
         u64 const d4 = zl_fwd_fix(r4, pa4, q4);
@@ -231,6 +255,7 @@ struct ZLaneD {
             } else {
                 if (ip1 >= nextStep) { step++; nextStep += 256u; }
                 ip = ip1; ip1 = ip2; w = w1; w1 = d3; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1; tl0 = tl1;
+                if (GATED) { fI = fN; fN = fa & 15u; }
                 if (ip1 > ilimit) finish();
             }
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
@@ -265,8 +290,8 @@ struct ZLaneD {
             } else {                                   // ZC_REPLOOP: immediate repcode after a match
                 u32 const rLength = acc + 4u;
                 { u32 const t = off2; off2 = off1; off1 = t; }
-                HS[zl_hash(hS, w)] = E::make(ip + 1u, ze_tag4((u32)w));
-                put_long(w, ip + 1u);
+                put_short_if((fI & 8u) != 0, w, ip + 1u);
+                put_long_if((fI & 4u) != 0, w, ip + 1u);
                 ze_store(o, anchor, 0u, 1u, rLength);
                 ip += rLength; anchor = ip;
                 if (ip <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
@@ -275,10 +300,12 @@ struct ZLaneD {
             u64 const wa = haveIns ? wIns : d0, q0 = d1, q1 = d2;
             u64 const wb = q0, wc = (q0 >> 8) | (q1 << 56);
             u32 const ins = curr + 2u;
-            put_long(wa, ins + 1u);
-            put_long(wb, ip - 2u + 1u);
-            HS[zl_hash(hS, wa)] = E::make(ins + 1u, ze_tag4((u32)wa));
-            HS[zl_hash(hS, wc)] = E::make(ip - 1u + 1u, ze_tag4((u32)wc));
+            // GATED: fa = flags of curr + 2, fb = flags of ip - 2, ip - 1, ip, ip + 1 (one byte each)
+            put_long_if((fa & 4u) != 0, wa, ins + 1u);
+            put_long_if((fb & 4u) != 0, wb, ip - 2u + 1u);
+            put_short_if((fa & 8u) != 0, wa, ins + 1u);
+            put_short_if((fb & 0x800u) != 0, wc, ip - 1u + 1u);
+            if (GATED) { fI = (fb >> 16) & 15u; fN = (fb >> 24) & 15u; }
             w = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
             if ((off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
@@ -291,6 +318,7 @@ struct ZLaneD {
             if (!more) fin();
         } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
             w = d0; w1 = d1;
+            if (GATED) { fI = (fb >> 16) & 15u; fN = (fb >> 24) & 15u; }
             if (chk && (off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
             chk = false;
@@ -316,7 +344,7 @@ struct ZLaneF {
     u32 ca, cb, acc, mpos, mLength, offcode, bk;
     bool more, needBack, chk, haveIns;               // wIns/haveIns: the word at cur0 + 2 (first post-insert) when the search round already holds it
 
-    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc) {
+    ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc, const u8* = nullptr) {
         src = s; n = size; ilimit = size - 8u; hT = zl_hash_of(p.minMatch, p.hashLog); T = (Ent*)table;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip0 = 1; anchor = 0; rep1 = 1; rep2 = 0; chk = false; lastLL = size; needBack = more = haveIns = false; bk = 0;
