@@ -379,12 +379,16 @@ def main():
         match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else "zj_enc_match_kernel")
         if size > 131072:
             match_name = "zj_encode_multi_kernel"
+        # level 3, frames <= 64 KiB, large batch: the need-gated machine (zj_need.h) behind the flag kernel unless ZJNI_NEED=0
+        gated = mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED", "2") in ("1", "2") and not os.environ.get("ZJNI_HYBRID")
+        if gated:
+            match_name = "zj_enc_match_gated_kernel"
         kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
                    "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}
         if mode != "decode_ref":
             kernels[match_name] = mc if size > 131072 else stage.get("match_wide" if size > 65536 else "match", -1.0); kernels["zj_pack_kernel"] = mp
             if kernels[match_name] > 0 and mode != "dict" and size <= 65536:
-                kernels["compress_rest(entropy beside match, memset, sweep)"] = mc - kernels[match_name]
+                kernels["compress_rest(%sentropy beside match, memset, sweep)" % ("zj_enc_need_kernel, " if gated else "")] = mc - kernels[match_name]
         slices = 1
         if mode == "dict":                                     # the dictionary pipeline runs in slices of 131 072 records: one launch = one slice
             slices = max(1, (n + 131071) // 131072)

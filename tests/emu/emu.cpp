@@ -150,6 +150,7 @@ extern "C" unsigned emu_check_code_tables() {
 
 // split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
 // kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout
+static int g_emu_force_gated = 0;
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
@@ -170,11 +171,14 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
             struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
             ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));
             nflags = (u8*)malloc(srcSize + ZN_FLAG_SLACK); memset(nflags, 0xFF, srcSize + ZN_FLAG_SLACK);
-            zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
-            if (getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
+            bool const take = getenv("ZJNI_EMU_NEED")[0] != '2' || zn_worth(one, (u32*)L, src, srcSize);     // 2: the selective mode — frames not picked run the gated machine without flags
+            if (take) zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
+            else { free(nflags); nflags = nullptr; g_emu_force_gated = 1; }
+            if (nflags && getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
             free(L);
         } }
-    ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide, nflags);
+    if (g_emu_force_gated && !nflags && srcSize >= ZL_MIN_FRAME) { ze_match_lane_t<ZLaneD<ZEEntTag, true> >(src, srcSize, lw, table, fs, maxSrc, meta, nullptr); g_emu_force_gated = 0; }
+    else ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide, nflags);
     free(nflags);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);

@@ -156,9 +156,11 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     assert bytes(dst[100:100 + n]) == z and dst[:100] == bytes(100)
 
 
-def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch):
-    """ZJNI_NEED=1 (experiment, off by default; zj_need.h): the flag kernel + the need-gated lane machine give the same frames"""
-    monkeypatch.setenv("ZJNI_NEED", "1")
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch, mode):
+    """zj_need.h: the flag kernel + the need-gated lane machine give the same frames — for every frame (ZJNI_NEED=1), for the frames the
+    flag kernel picks (2, the default), and with the ungated machine (0)"""
+    monkeypatch.setenv("ZJNI_NEED", mode)
     monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
     rnd = random.Random(43)
     datas = [gpu.synth_host(65536, k, 1) for k in range(96)] + [gpu.synth_host(s, 100 + s, 1) for s in (64, 65, 1000, 8192, 8193, 30000, 65535, 63, 0)]

@@ -248,7 +248,7 @@ template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
                                              u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                             unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr) {
+                                             unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr, const u8* gate = nullptr) {
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
     bool have = false; u32 k = 0;
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : ZL_DFAST_PERIOD; u32 ph = 0;   // double-fast machine: rounds per rotation of the non-search states
@@ -267,7 +267,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
             if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
-            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, flagsBase ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
+            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, (flagsBase && gate[k]) ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
             have = true;
         }
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
@@ -300,15 +300,25 @@ struct ZNThreads {
     __device__ __forceinline__ u32 count() const { return blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
+// `gate` (one byte per list entry): 1 = the frame has flags.  selective: only frames zn_worth() picks get them, the others run ungated.
 __global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
-                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase) {
+                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase, u8* gate, u32 selective, u32* work) {
     ZNLds& L = *(ZNLds*)zj_dyn_lds;
+    __shared__ u32 next;
     ZNThreads t;
     u32 const count = *countPtr;
-    for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+    for (;;) {                                            // frames differ (selective: most are skipped), and a list in batch order puts one class on one workgroup: a queue
+        if (threadIdx.x == 0) next = atomicAdd(work, 1u);
+        __syncthreads();
+        u32 const k = next;
+        __syncthreads();
+        if (k >= count) break;
         u32 const i = list[k];
         u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
-        if (size < ZL_MIN_FRAME) continue;               // the plain loops take these (zj_match_run)
+        bool take = size >= ZL_MIN_FRAME;                 // (the plain loops take smaller frames, zj_match_run)
+        if (take && selective) take = zn_worth(t, (u32*)&L, src + s0, size);
+        if (threadIdx.x == 0) gate[k] = take ? 1 : 0;
+        if (!take) continue;
         ZEParams const p = ze_params_of(level, size);
         zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);
     }
@@ -316,10 +326,10 @@ __global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_gated_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                                           u32 listBase, u32 sliceLen, const u8* flagsBase) {
+                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase);
+    zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
 }
 
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
@@ -688,6 +698,7 @@ size_t enc_lds_pass0(int level) {
     return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);
 }
 struct DevState {
+    bool needLdsSet = false;                      // zj_enc_need_kernel's LDS attribute has been set on this device
     int ordinal = -1;
     int numCU = 0;
     int decGrid = 0, decDictGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
@@ -1269,26 +1280,36 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
-        // ZJNI_NEED=1 (experiment, zj_need.h): level 3 on the need-gated machine — a flag byte per position ahead of the match kernel
-        bool needGate = false;
-        if (const char* ov = getenv("ZJNI_NEED")) {
-            u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-            needGate = ov[0] == '1' && level == 3 && !smallWave && getenv("ZJNI_HYBRID") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
-        }
-        size_t const needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + 64 : 0;
-        size_t const need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
+        // Level 3 on the need-gated machine (zj_need.h): a flag byte per position ahead of the match kernel.  ZJNI_NEED: 2 (default) = the frames
+        // zn_worth() picks — search-dense frames over a small alphabet, the class that sets the match kernel's time — 1 = every frame, 0 = off.
+        // 64 KiB of flags per frame slot: left out under a scratch budget (zjni_set_scratch_limit) and when the device cannot spare them.
+        u32 needMode = 2;
+        if (const char* ov = getenv("ZJNI_NEED")) needMode = (u32)atoi(ov);
+        u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
+        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
+                        && getenv("ZJNI_NO_OVERLAP") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
+        u32 const needSelective = needMode == 2 ? 1u : 0u;
+        size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 : 0;
+        size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
-            if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+            if (hipMalloc(&d->splitBuf, need) != hipSuccess) {
+                if (!needGate) return ZJNI_ERR(64);
+                (void)hipGetLastError(); needGate = false; need -= needFlagBytes; needFlagBytes = 0;          // no room for the flags: the ungated machine
+                if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
+            }
             d->splitBufCap = need;
         }
         u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
         u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
         u8* const needFlags = needGate ? (u8*)(((uintptr_t)(score + n) + 63) & ~(uintptr_t)63) : nullptr;
+        u8* const needGateMap = needGate ? needFlags + n * (size_t)ZN_FLAG_STRIDE : nullptr;
         if (needGate) {
-            static bool ldsSet = false;                     // more than 64 KiB of dynamic LDS has to be asked for once
-            if (!ldsSet) { if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); ldsSet = true; }
+            if (!d->needLdsSet) {                            // more than 64 KiB of dynamic LDS has to be asked for once per device
+                if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                d->needLdsSet = true;
+            }
         }
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
         bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
@@ -1322,9 +1343,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
         unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
+        if (needGate && hipMemsetAsync(d->counters + 208, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         if (needGate) {      // ahead of the fork: the flag kernel's workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
             u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags);
+            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags, needGateMap, needSelective, d->counters + 208);
         }
         if (overlap) {
             // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
@@ -1346,7 +1368,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
             if (needGate) {
                 hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
-                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags);
+                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
             } else
             if (!waveOnly)
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
@@ -1365,7 +1387,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             (void)hipEventRecord(d->tev[0], st);
             if (needGate)
                 hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                                   (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (const u8*)needFlags);
+                                   (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
             else
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (unsigned long long*)nullptr);

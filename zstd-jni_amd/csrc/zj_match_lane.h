@@ -223,9 +223,12 @@ struct ZLaneD {
             if (!GATED || (fw & 1u)) t0 = (u32)HL[ti0];
             if (!GATED || (fw & 2u)) t1 = (u32)HS[ti1];
             if (GATED) {
-                if (st == ZL_SEARCH) fa = F[q3];                                       // flags of ip2 (q3 == ip2 whenever it is a position the search can reach)
-                else if ((K & ZL_EN_POST) && st == ZL_POST) { fa = F[curr + 2u]; fb = ld32(F + ip - 2u); }
-                else if ((K & ZL_EN_POST) && st == ZL_LOADW) fb = ld16(F + ip) << 16;
+                fa = 15u; fb = 0x0F0F0F0Fu;                                                // a frame without flags (F == nullptr) runs ungated
+                if (F) {
+                    if (st == ZL_SEARCH) fa = F[q3];                                   // flags of ip2 (q3 == ip2 whenever it is a position the search can reach)
+                    else if ((K & ZL_EN_POST) && st == ZL_POST) { fa = F[curr + 2u]; fb = ld32(F + ip - 2u); }
+                    else if ((K & ZL_EN_POST) && st == ZL_LOADW) fb = ld16(F + ip) << 16;
+                }
             }
         }
         if (v1) r1 = ld64(src + q1);

@@ -99,4 +99,27 @@ ZJ_DEV void zn_flags_frame(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashL
     }
     t.sync();
 }
+// Is the frame worth its flags?  They cost a pass of hashing over every position; they pay where the parse visits most positions and finds
+// little: many distinct 4-byte values (few matches) over a small alphabet (no acceleration through incompressible stretches — uniformly random
+// frames are left alone, the reference's step rule makes them cheap).  Sampled in the middle of the frame: 1 024 positions.  `bm` = 136 zeroable
+// LDS words.  The answer is the same in every lane.
+#define ZN_SAMPLE 1024u
+template <class T>
+ZJ_DEV bool zn_worth(const T& t, u32* bm, const u8* src, u32 n) {
+    if (n < 4096u) return false;
+    for (u32 i = t.id(); i < 136u; i += t.count()) bm[i] = 0;
+    t.sync();
+    u32 const off = (n - 4u - ZN_SAMPLE) >> 1;
+    for (u32 p = t.id(); p < ZN_SAMPLE; p += t.count()) {
+        u32 const v = ld32(src + off + p), h = (v * 2654435761u) >> 20;
+        atomicOr(&bm[h >> 5], 1u << (h & 31u));                    // 4 096-bit set of 4-byte values
+        atomicOr(&bm[128u + ((v & 255u) >> 5)], 1u << (v & 31u));  // 256-bit set of byte values
+    }
+    t.sync();
+    u32 grams = 0, bytes = 0;
+    for (u32 i = 0; i < 128u; i++) grams += (u32)__builtin_popcount(bm[i]);
+    for (u32 i = 128u; i < 136u; i++) bytes += (u32)__builtin_popcount(bm[i]);
+    t.sync();
+    return grams * 64u >= 40u * ZN_SAMPLE && bytes <= 128u;
+}
 ZJ_HD bool zn_takes(u32 hashLog, u32 chainLog, u32 srcSize) { return hashLog <= ZN_MAX_LOG && chainLog <= ZN_MAX_LOG && srcSize >= 64u && srcSize <= 65536u; }
