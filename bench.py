@@ -408,7 +408,7 @@ def main():
             rec = pmc.get(f"{a.config}_L{level}_{n}x{size}", {}).get(dom.split("(")[0])
             if rec:
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_note = f"{pmc.get('note', '')} Measured on commit {pmc.get('measured_on_commit')} ({pmc.get('measured_on_date')}); this run is commit {git_head()}."
+                traffic_note = f"{pmc.get('note', '')} Measured on commit {rec.get('measured_on_commit', pmc.get('measured_on_commit'))} ({rec.get('measured_on_date', pmc.get('measured_on_date'))}); this run is commit {git_head()}."
                 # scattered table accesses: what bounds this kernel is HBM *requests* (64-B reads, 32-B writes), not bytes —
                 # the ceiling is tools/micro/probe's footprint sweep on this part
                 reqs = rec["fetch_bytes_per_launch"] / 64.0 + rec["write_bytes_per_launch"] / 32.0
