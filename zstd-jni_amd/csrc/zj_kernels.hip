@@ -1288,6 +1288,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
         bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
                         && getenv("ZJNI_NO_OVERLAP") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
+        if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: the ungated machine
+            if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
+            else { (void)hipGetLastError(); needGate = false; }
+        }
         u32 const needSelective = needMode == 2 ? 1u : 0u;
         size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 : 0;
         size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
@@ -1305,12 +1309,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
         u8* const needFlags = needGate ? (u8*)(((uintptr_t)(score + n) + 63) & ~(uintptr_t)63) : nullptr;
         u8* const needGateMap = needGate ? needFlags + n * (size_t)ZN_FLAG_STRIDE : nullptr;
-        if (needGate) {
-            if (!d->needLdsSet) {                            // more than 64 KiB of dynamic LDS has to be asked for once per device
-                if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-                d->needLdsSet = true;
-            }
-        }
+
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
         bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
         // Experiment (ZJNI_HYBRID=1, off by default): at level 3 with the LDS-sized tables the two match
