@@ -332,6 +332,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
 }
 
+// ZJNI_NEED=3 (experiment): the gated machine that decides two positions per round where the flags allow (ZLaneD<E, true, true>)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_skip_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
+                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    list += listBase;
+    zj_match_run<ZLaneD<ZEEntTag, true, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
+}
+
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
 // 64 frames per wave instead of one lane of 64 busy; the chain walk (up to 2^searchLog dependent candidate fetches per position)
 // keeps the lanes apart, so the wave runs the union of their paths, but every memory round trip still serves up to 64 frames.
@@ -1286,13 +1296,13 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 needMode = 2;
         if (const char* ov = getenv("ZJNI_NEED")) needMode = (u32)atoi(ov);
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
+        bool needGate = (needMode >= 1 && needMode <= 3) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
                         && getenv("ZJNI_NO_OVERLAP") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
         if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: the ungated machine
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
             else { (void)hipGetLastError(); needGate = false; }
         }
-        u32 const needSelective = needMode == 2 ? 1u : 0u;
+        u32 const needSelective = needMode >= 2 ? 1u : 0u;          // 3 (experiment): the picked frames' flags + the machine that decides two positions per round
         size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 : 0;
         size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
@@ -1365,7 +1375,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machine (0 = ZL_DFAST_PERIOD)
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
-            if (needGate) {
+            if (needGate && needMode == 3) {
+                hipLaunchKernelGGL(zj_enc_match_skip_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
+                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
+            } else if (needGate) {
                 hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                    listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
             } else
