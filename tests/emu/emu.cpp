@@ -320,3 +320,22 @@ extern "C" unsigned emu_lane_rounds(const unsigned char* src, unsigned srcSize, 
     free(flags); free(fs); free(table);
     return rounds;
 }
+
+// the flag bytes zn_flags_frame leaves for one frame with the level-3 parameters of its size (tests: they must cover the exact answer)
+extern "C" unsigned emu_need_flags(const unsigned char* src, unsigned srcSize, unsigned char* out, unsigned* params) {
+    ZEParams const p = ze_params_of(3u, srcSize);
+    if (!zn_takes(p.hashLog, p.chainLog, srcSize)) return 0;
+    struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
+    ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0x5A, sizeof(ZNLds));
+    zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, out);
+    free(L);
+    params[0] = p.hashLog; params[1] = p.chainLog; params[2] = p.minMatch;
+    return 1;
+}
+// bucket of a position's long / short probe, as the lane machine computes it
+extern "C" void emu_need_buckets(const unsigned char* src, unsigned srcSize, unsigned pos, unsigned* out) {
+    ZEParams const p = ze_params_of(3u, srcSize);
+    ZLHash const hL = zl_hash_of(8, p.hashLog), hS = zl_hash_of(p.minMatch, p.chainLog);
+    u64 const w = ld64(src + pos);
+    out[0] = zl_hash(hL, w); out[1] = zl_hash(hS, w);
+}

@@ -178,6 +178,34 @@ def test_emu_need_gated_double_fast(emu, oracle_ref, zj, monkeypatch, mode):
             assert emu_compress(emu, d, 3, split=True, hash_log=hl, chain_log=cl) == oracle_ref.compress(d, 3, False, hl, cl), (len(d), hl, cl)
 
 
+def test_need_flags_cover_the_exact_answer(emu, zj):
+    """zj_need.h's contract, checked without the parse: a position whose key (long: its 8 bytes; short: its bucket and its first 4 bytes) some
+    OTHER position of the frame shares must carry the NEED flag, and every position in the bucket of a NEED-flagged position must carry the INS
+    flag — Bloom filters may add flags (they only cost requests), never drop one.  Also: how many they add stays small."""
+    import ctypes as C
+    emu.emu_need_flags.restype = C.c_uint
+    rnd = random.Random(9)
+    frames = [zj.synth_host(65536, k, 1) for k in range(4)] + [zj.synth_host(20000, 11, 1), bytes(rnd.randrange(16) for _ in range(30000)),
+              (b"0123456789abcdef" * 4096)[:65536], bytes([3]) * 5000, bytes(rnd.getrandbits(8) for _ in range(4096))]
+    for d in frames:
+        n = len(d); flags = C.create_string_buffer(n + 16); prm = (C.c_uint * 3)()
+        assert emu.emu_need_flags(d, n, flags, prm) == 1
+        f = flags.raw[:n]; npos = n - 7
+        bk = (C.c_uint * 2)(); bl, bs = [0] * npos, [0] * npos
+        for p in range(npos):
+            emu.emu_need_buckets(d, n, p, bk); bl[p], bs[p] = bk[0], bk[1]
+        seen_l, seen_s = {}, {}
+        for p in range(npos):
+            seen_l.setdefault(d[p:p + 8], []).append(p); seen_s.setdefault((bs[p], d[p:p + 4]), []).append(p)
+        need_l = {p for ps in seen_l.values() if len(ps) > 1 for p in ps}; need_s = {p for ps in seen_s.values() if len(ps) > 1 for p in ps}
+        assert all(f[p] & 1 for p in need_l) and all(f[p] & 2 for p in need_s), n
+        flagged_l = {bl[p] for p in range(npos) if f[p] & 1}; flagged_s = {bs[p] for p in range(npos) if f[p] & 2}
+        assert all(f[p] & 4 for p in range(npos) if bl[p] in flagged_l) and all(f[p] & 8 for p in range(npos) if bs[p] in flagged_s), n
+        assert all(f[p] == 0 for p in range(npos, n))
+        extra_l = sum(1 for p in range(npos) if (f[p] & 1) and p not in need_l); extra_s = sum(1 for p in range(npos) if (f[p] & 2) and p not in need_s)
+        assert extra_l <= 0.08 * npos and extra_s <= 0.08 * npos, (n, extra_l, extra_s)          # false positives of the filters: ~5 % with 65 536 keys in
+
+
 def test_emu_encoder_tiny_text_frames(emu, oracle_ref):
     """short natural-text frames sit right at the compressed-vs-raw block decision (ZSTD_minGain): both
     pipelines must take the reference's side of it (regression: 70-byte frame with 0 sequences)"""
