@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     else zj_match_run<ZLaneF<ZEEnt16> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, work2);
 }
 
-// ---- need-gated level 3 (zj_need.h; ZJNI_NEED=1) ----
+// ---- need-gated level 3 (zj_need.h; ZJNI_NEED = 2 by default: flags for the frames zn_worth() picks) ----
 // zj_enc_need_kernel: one workgroup of 512 lanes per frame computes the frame's flag bytes (which probes can match, which writes can be
 // read) with Bloom filters in LDS; zj_enc_match_gated_kernel is zj_enc_match_kernel on the gated double-fast machine.
 struct ZNThreads {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
 }
 
-// ZJNI_NEED=3 (experiment): the gated machine that decides two positions per round where the flags allow (ZLaneD<E, true, true>)
+// ZJNI_NEED=3 (experiment, measured slower with mixed waves — DESIGN.md section 4): the gated machine that decides two positions per round where the flags allow (ZLaneD<E, true, true>)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_skip_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
