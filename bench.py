@@ -383,8 +383,8 @@ def main():
         gated = mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED", "2") in ("1", "2") and not os.environ.get("ZJNI_HYBRID")
         if gated:
             match_name = "zj_enc_match_gated_kernel"
-        elif mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED") == "3":
-            match_name = "zj_enc_match_skip_kernel"                     # experiment: two positions per round
+        elif mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED") in ("3", "4"):
+            match_name = "zj_enc_match_skip_kernel" if os.environ["ZJNI_NEED"] == "3" else "zj_enc_match_roles_kernel"     # experiments: two positions per round / waves by role
         kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
                    "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}
         if mode != "decode_ref":

@@ -4,6 +4,8 @@ rm -f gpurun_out/ab_*.json
 ZJNI_NEED=2 ZJNI_SPLIT_MIN=1 timeout 100 python -m pytest tests/test_gpu_encode.py -m gpu -x -q -k "edge or mixed or wide or explicit or checksum or tight or need" > gpurun_out/need_tests.log 2>&1; tail -2 gpurun_out/need_tests.log
 ZJNI_NEED=2 timeout 100 python bench.py --steps 3 --warmup 1 --e2e-sample 0 --cpu-sample 512 --cpu-seconds 0.2 > gpurun_out/ab_need2_verified.json 2> gpurun_out/ab_need2_verified.err
 run need2 ZJNI_NEED=2
+run need3 ZJNI_NEED=3
+run need4 ZJNI_NEED=4
 run need1 ZJNI_NEED=1
 run base ZJNI_NEED=0
 python - <<PY

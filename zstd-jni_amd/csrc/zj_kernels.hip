@@ -248,7 +248,8 @@ template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
                                              u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                             unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr, const u8* gate = nullptr) {
+                                             unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr, const u8* gate = nullptr,
+                                             const u32* sub = nullptr) {      // sub: the queue hands out sub[0 .. count) = slots k of `list` (role queues, ZJNI_NEED=4)
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
     bool have = false; u32 k = 0;
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : ZL_DFAST_PERIOD; u32 ph = 0;   // double-fast machine: rounds per rotation of the non-search states
@@ -262,6 +263,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             else {
             k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
+            if (sub) k = sub[k];
             }
             u32 const i = list[k];
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
@@ -302,7 +304,8 @@ struct ZNThreads {
 };
 // `gate` (one byte per list entry): 1 = the frame has flags.  selective: only frames zn_worth() picks get them, the others run ungated.
 __global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
-                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase, u8* gate, u32 selective, u32* work) {
+                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase, u8* gate, u32 selective, u32* work,
+                                                          u32* roleLists = nullptr, u32* roleCounts = nullptr) {      // ZJNI_NEED=4: picked slots to roleLists[0 ..), the others to roleLists[count ..)
     ZNLds& L = *(ZNLds*)zj_dyn_lds;
     __shared__ u32 next;
     ZNThreads t;
@@ -317,7 +320,10 @@ __global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__
         u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
         bool take = size >= ZL_MIN_FRAME;                 // (the plain loops take smaller frames, zj_match_run)
         if (take && selective) take = zn_worth(t, (u32*)&L, src + s0, size);
-        if (threadIdx.x == 0) gate[k] = take ? 1 : 0;
+        if (threadIdx.x == 0) {
+            gate[k] = take ? 1 : 0;
+            if (roleLists) { u32 const at = atomicAdd(&roleCounts[take ? 0 : 1], 1u); roleLists[(take ? 0u : count) + at] = k; }
+        }
         if (!take) continue;
         ZEParams const p = ze_params_of(level, size);
         zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);
@@ -340,6 +346,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
     zj_match_run<ZLaneD<ZEEntTag, true, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
+}
+
+// ZJNI_NEED=4 (experiment, NOT YET RUN ON A GPU — next round's first measurement): waves by role.  The flag kernel has sorted the
+// slots into picked frames and the rest; a wave draws a ticket and either runs the two-positions-per-round machine over picked frames only, or the
+// plain machine over the others — so the second position's code is paid only where it saves rounds.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_roles_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                           const u32* __restrict__ list, const u32* countPtr, u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta,
+                                                           u32* doneList, u32* doneCount, const u8* flagsBase, const u8* gate,
+                                                           const u32* roleLists, u32* roleCounts) {       // roleCounts: [0] picked, [1] others, [2] tickets, [3] / [4] work counters
+    __shared__ u32 role;
+    u32 const count = *countPtr, nP = roleCounts[0], nR = roleCounts[1];
+    if (threadIdx.x == 0) { u32 const t = atomicAdd(&roleCounts[2], 1u); role = ((u64)t * 64u < nP) ? 1u : 0u; }
+    __syncthreads();
+    if (ZJ_UNI(role)) zj_match_run<ZLaneD<ZEEntTag, true, true> >(src, srcOff, level, list, nP, roleCounts + 3, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, roleLists);
+    else zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, nR, roleCounts + 4, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, nullptr, nullptr, roleLists + count);
 }
 
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
@@ -1296,14 +1317,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 needMode = 2;
         if (const char* ov = getenv("ZJNI_NEED")) needMode = (u32)atoi(ov);
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-        bool needGate = (needMode >= 1 && needMode <= 3) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
+        bool needGate = (needMode >= 1 && needMode <= 4) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
                         && getenv("ZJNI_NO_OVERLAP") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
         if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: the ungated machine
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
             else { (void)hipGetLastError(); needGate = false; }
         }
         u32 const needSelective = needMode >= 2 ? 1u : 0u;          // 3 (experiment): the picked frames' flags + the machine that decides two positions per round
-        size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 : 0;
+        size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 + (needMode == 4 ? 8 * n + 64 : 0) : 0;
         size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
@@ -1319,6 +1340,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
         u8* const needFlags = needGate ? (u8*)(((uintptr_t)(score + n) + 63) & ~(uintptr_t)63) : nullptr;
         u8* const needGateMap = needGate ? needFlags + n * (size_t)ZN_FLAG_STRIDE : nullptr;
+        u32* const roleLists = (needGate && needMode == 4) ? (u32*)(((uintptr_t)(needGateMap + n) + 63) & ~(uintptr_t)63) : nullptr;   // [n] picked slots, [n] the others
+        u32* const roleCounts = d->counters + 216;          // [0] picked, [1] others, [2] tickets, [3] / [4] work
 
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
         bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
@@ -1353,9 +1376,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
         unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
         if (needGate && hipMemsetAsync(d->counters + 208, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (roleLists && hipMemsetAsync(roleCounts, 0, 20, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         if (needGate) {      // ahead of the fork: the flag kernel's workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
             u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags, needGateMap, needSelective, d->counters + 208);
+            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags, needGateMap, needSelective, d->counters + 208, roleLists, roleLists ? roleCounts : (u32*)nullptr);
         }
         if (overlap) {
             // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
@@ -1375,7 +1399,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machine (0 = ZL_DFAST_PERIOD)
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
-            if (needGate && needMode == 3) {
+            if (needGate && needMode == 4) {
+                hipLaunchKernelGGL(zj_enc_match_roles_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
+                                   listM, (const u32*)ctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, (const u8*)needFlags, (const u8*)needGateMap,
+                                   (const u32*)roleLists, roleCounts);
+            } else if (needGate && needMode == 3) {
                 hipLaunchKernelGGL(zj_enc_match_skip_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                    listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
             } else if (needGate) {
