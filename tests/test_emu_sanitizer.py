@@ -17,8 +17,11 @@ def _asan_runtime():
 
 
 @pytest.mark.parametrize("tool", [["fuzz_emu_encode.py"], ["fuzz_emu_decode.py"], ["fuzz_emu_level4.py"], ["fuzz_emu_multiblock.py"],
-                                  ["fuzz_emu_cdict_copy.py"], ["fuzz_emu_dict.py", "decode"], ["fuzz_emu_wave.py"]], ids=lambda t: "-".join(t))
+                                  ["fuzz_emu_cdict_copy.py"], ["fuzz_emu_dict.py", "decode"], ["fuzz_emu_wave.py"], ["fuzz_emu_tight.py"],
+                                  ["fuzz_emu_need.py", "NEEDMODE=1"], ["fuzz_emu_need.py", "NEEDMODE=4"]], ids=lambda t: "-".join(t))
 def test_emu_bodies_under_sanitizers(tool):
+    extra = dict(a.split("=", 1) for a in tool[1:] if "=" in a)           # NAME=value entries are environment for the tool, the rest its arguments
+    tool = [a for a in tool if "=" not in a]
     rt = _asan_runtime()
     if rt is None:
         pytest.skip("no libasan in this image")
@@ -26,9 +29,9 @@ def test_emu_bodies_under_sanitizers(tool):
     subprocess.check_call(["make", "-s", "-C", emu, "all", "asan"])
     env = dict(os.environ, ZJNI_EMU_LIB=os.path.join(emu, "libzjni_emu_asan.so"), LD_PRELOAD=rt,
                ZJNI_EMU_WAVE_LIB=os.path.join(emu, "libzjni_emu_wave_asan.so"),
-               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", **extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool[0])] + tool[1:] + ["31337", "6"], env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
-    assert "bad 0" in r.stdout or "diffs {}" in r.stdout, r.stdout[-2000:]
+    assert "bad 0" in r.stdout or "diffs {}" in r.stdout or "mismatches=0" in r.stdout, r.stdout[-2000:]
