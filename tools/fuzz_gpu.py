@@ -1,6 +1,6 @@
 """Randomised byte-identity stress on the GPU (wave64 build, C-ABI): one batch of n random buffers per level through the lane
-pipelines (plain incl. wide, explicit table sizes, dictionary), every frame compared with the reference's and decoded
-back on the GPU.  usage: fuzz_gpu.py <seed> <n>   TEST INFRASTRUCTURE."""
+pipelines (plain incl. wide, explicit table sizes, dictionary, the need-gated level-3 machines in every ZJNI_NEED mode, tight
+destinations), every frame compared with the reference's and decoded back on the GPU.  usage: fuzz_gpu.py <seed> <n>   TEST INFRASTRUCTURE."""
 import os, sys, random, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -96,4 +96,34 @@ for dbytes in (ref.train_dict(samples, 112640), b",".join(recs[:300])):
             back = zj.decompress_batch(outs, [len(d) for d in datas], dd)
             bad += sum(1 for b, d in zip(back, datas) if b != d)
         print(f"dict level {level}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+# level 3 on the need-gated machines (zj_need.h): every mode of ZJNI_NEED on the lane pipeline regardless of batch size
+os.environ["ZJNI_SPLIT_MIN"] = "1"
+for mode in ("0", "1", "2", "3", "4"):
+    os.environ["ZJNI_NEED"] = mode
+    datas = [gen(s) for s in sizes(65536)] + [bytes(rnd.randrange(16) for _ in range(rnd.randrange(4096, 65537))) for _ in range(max(8, n // 10))]
+    outs = zj.compress_batch(datas, 3)
+    for k, (d, z) in enumerate(zip(datas, outs)):
+        want = ref.compress(d, 3) if len(d) <= 8192 else ref.compress(d, 3, False, 14, 13)
+        if isinstance(z, Exception) or z != want:
+            bad += 1; print("MISMATCH need mode", mode, k, len(d), flush=True)
+    print(f"ZJNI_NEED={mode}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+del os.environ["ZJNI_NEED"]; del os.environ["ZJNI_SPLIT_MIN"]
+# tight destinations: capacities around each frame's size, answers (size, bytes or code) against ZSTD_compress2's for the same capacity
+for level in (1, 3, 5):
+    datas, caps, wants = [], [], []
+    for s in sizes(16384 if level >= 5 else 131072)[:max(50, n // 4)]:
+        d = gen(s) if rnd.random() < 0.7 else bytes(rnd.randrange(rnd.choice([3, 12, 48])) for _ in range(rnd.randrange(20, 400)))
+        hl, cl = (14, 13) if (level == 3 and 8192 < len(d) <= 131072) else (0, 0)
+        fs = len(ref.compress(d, level, False, hl, cl))
+        for cap in (fs + rnd.randrange(-2, 30), len(d) + rnd.randrange(0, 24), rnd.choice([0, 8, 17, 18, fs, fs + 8, fs + 9])):
+            cap = max(cap, 0)
+            try: want = ref.compress(d, level, False, hl, cl, cap=cap)
+            except ref.ZstdRefError as ex: want = -ex.code
+            datas.append(d); caps.append(cap); wants.append(want)
+    outs = zj.compress_batch(datas, level, capacities=caps)
+    for k, (want, z) in enumerate(zip(wants, outs)):
+        got = -z.getErrorCode() if isinstance(z, Exception) else z
+        if got != want:
+            bad += 1; print("MISMATCH tight level", level, k, len(datas[k]), caps[k], flush=True)
+    print(f"tight destinations level {level}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
 print("GPU-FUZZ", "OK" if bad == 0 else "FAILED", "bad", bad)
