@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded / re-made by the CPU reference")
     ap.add_argument("--e2e-sample", type=int, default=65536, help="buffers in the end-to-end (host-pointer) leg (at most 4 GiB of them), 0 = skip")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
+    ap.add_argument("--skip-plain3", action="store_true", help="skip the extra level-3 pass with the reference's own table sizes (hashLog 16 / chainLog 15)")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
     return ap.parse_args()
 
@@ -299,6 +300,28 @@ def main():
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
 
+    # which match finder served the timed steps: asked of the library, not inferred from the environment
+    L = zj.lib()
+    route = int(L.zjni_last_route()) if mode != "decode_ref" else 0
+    route_kernel = L.zjni_route_kernel(route).decode() if route > 0 else ""
+    stamp = L.zjni_build_stamp().decode()
+
+    # ---- the reference's own level-3 parameters (hashLog 16 / chainLog 15), on the record every run: one warm-up + a timed pass, outside `value` ----
+    plain3 = None
+    if mode == "both" and level == 3 and size <= 65536 and not a.skip_plain3:
+        csz2 = torch.empty(n, dtype=torch.int64, device=dev)
+        for it in range(2):
+            p0, p1 = ev(), ev()
+            p0.record(); B.compress(src, src_off, comp, comp_off, 3, csz2, hash_log=16, chain_log=15); p1.record()
+            torch.cuda.synchronize()
+        pms = p0.elapsed_time(p1); pst = B.last_timing(); proute = int(L.zjni_last_route())
+        plain3 = {"hashLog": 16, "chainLog": 15, "compress_ms": pms, "compress_GiBps_per_gpu": n * size / GIB / (pms / 1e3),
+                  "match_kernel": L.zjni_route_kernel(proute).decode(), "match_kernel_ms": pst.get("match", -1.0), "route": proute,
+                  "compressed_bytes": int(csz2.clamp(min=0).sum().item()),
+                  "note": "Zstd.compress(x, 3)'s own table sizes (N/compress/clevels.h:29-31) through zjni_compress_batch_device_advanced; byte identity with the reference's plain call: parity.plain_level3_byte_identical_with_hashLog16_chainLog15"}
+        B.compress(src, src_off, comp, comp_off, level, csz, dictionary=cdict)          # leave the headline's frames in `comp` for the gates below
+        torch.cuda.synchronize()
+
     # ---- parity gates (outside the timed region) ----
     ok_sizes = bool((csz > 0).all()) and bool((dsz == size).all())
     roundtrip = ok_sizes and torch.equal(back, src)
@@ -376,21 +399,16 @@ def main():
         stage = {k: sum(t[k] for t in t_stage) / len(t_stage) for k in t_stage[0]} if t_stage else {}
         # kernels of the two paths with their own HIP-event durations (ms); "compress_rest" = classify + table memset +
         # entropy kernel (it runs beside the match kernel on a side stream) + sweep, i.e. compress call minus match kernel
-        match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else "zj_enc_match_kernel")
+        match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else (route_kernel or "zj_enc_match_kernel"))
         if size > 131072:
             match_name = "zj_encode_multi_kernel"
-        # level 3, frames <= 64 KiB, large batch: the need-gated machine (zj_need.h) behind the flag kernel unless ZJNI_NEED=0
-        gated = mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED", "2") in ("1", "2") and not os.environ.get("ZJNI_HYBRID")
-        if gated:
-            match_name = "zj_enc_match_gated_kernel"
-        elif mode != "dict" and level == 3 and size <= 65536 and n >= 4096 and os.environ.get("ZJNI_NEED") in ("3", "4"):
-            match_name = "zj_enc_match_skip_kernel" if os.environ["ZJNI_NEED"] == "3" else "zj_enc_match_roles_kernel"     # experiments: two positions per round / waves by role
+        gated = route == 6 or route == 4                       # ZJNI_ROUTE_RUN_FLAGS / ZJNI_ROUTE_LANE_GATED: flag kernels beside the match kernel
         kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
                    "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}
         if mode != "decode_ref":
             kernels[match_name] = mc if size > 131072 else stage.get("match_wide" if size > 65536 else "match", -1.0); kernels["zj_pack_kernel"] = mp
             if kernels[match_name] > 0 and mode != "dict" and size <= 65536:
-                kernels["compress_rest(%sentropy beside match, memset, sweep)" % ("zj_enc_need_kernel, " if gated else "")] = mc - kernels[match_name]
+                kernels["compress_rest(%sentropy beside match, memset, sweep)" % ("zj_enc_worth_kernel, " if gated else "")] = mc - kernels[match_name]
         slices = 1
         if mode == "dict":                                     # the dictionary pipeline runs in slices of 131 072 records: one launch = one slice
             slices = max(1, (n + 131071) // 131072)
@@ -404,19 +422,21 @@ def main():
         alg_launch = alg / slices if (dom and "dict" in dom) else alg
         achieved = alg_launch / 1e9 / (dom_ms / 1e3)
         traffic, traffic_note, request_roof = None, None, None
-        try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic.json)
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             rec = pmc.get(f"{a.config}_L{level}_{n}x{size}", {}).get(dom.split("(")[0])
-            if rec:
+            if rec and rec.get("build_stamp") == stamp:        # a figure from another build of the library is not this run's: left out, and said so
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_note = f"{pmc.get('note', '')} Measured on commit {rec.get('measured_on_commit', pmc.get('measured_on_commit'))} ({rec.get('measured_on_date', pmc.get('measured_on_date'))}); this run is commit {git_head()}."
+                traffic_note = f"{pmc.get('note', '')} Measured on build {rec['build_stamp']} = this library's zjni_build_stamp()."
                 # scattered table accesses: what bounds this kernel is HBM *requests* (64-B reads, 32-B writes), not bytes —
                 # the ceiling is tools/micro/probe's footprint sweep on this part
                 reqs = rec["fetch_bytes_per_launch"] / 64.0 + rec["write_bytes_per_launch"] / 32.0
                 request_roof = {"hbm_requests_per_launch": reqs, "achieved_G_per_s": reqs / 1e9 / (dom_ms / 1e3),
                                 "measured_ceiling_G_per_s": 50.3, "frac": reqs / 1e9 / (dom_ms / 1e3) / 50.3,
                                 "note": "random-access request ceiling at a 6 GiB footprint, read-only (40.8 read+write): tools/micro/probe footprint, profiles/r02a_probe_*"}
+            elif rec:
+                traffic_note = f"profiles/r03_pmc_traffic.json holds a PMC pass of build {rec.get('build_stamp')}; this library is {stamp}: not quoted (re-run tools/pmc_traffic.sh)."
         except OSError:
             pass
         per_gpu = n * size / GIB
@@ -430,7 +450,10 @@ def main():
                                    + (", one shared 110 KiB trained dictionary (ZstdDictCompress / ZstdDictDecompress)" if mode == "dict" else "")
                                    + (", frames made by the reference at its plain level (hashLog 16 / chainLog 15), GPU decompress only" if mode == "decode_ref" else ""),
                        "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
-                       "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"]},
+                       "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"],
+                       **({"hashLog": 14, "chainLog": 13, "table_sizes": "the library's level-3 default for 8 KiB < input <= 128 KiB (= ZstdCompressCtx.setHashLog(14).setChainLog(13)); the reference's own 16 / 15: see plain_level3"} if (level == 3 and 8192 < size <= 131072 and mode in ("both",)) else {})},
+            "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel},
+            "plain_level3": plain3,
             "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),
             "kernel_ms": {"compress_call": mc, "decompress_call": md, **kernels, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),

@@ -244,6 +244,22 @@ int zjni_kernel_info(int* decodeGrid, int* decodeLdsBytes, int* encodeGrid, int*
 int zjni_last_timing(float* out5);
 /* The same five plus out8[5] = the wide match-finder kernel (frames > 64 KiB), last slice of the call; out8[6..7] read -1. */
 int zjni_last_timing2(float* out8);
+/* Which match finder served list A of the last large compress call on this device (bench.py names the roofline's kernel from this, not from the
+ * environment: a refused LDS attribute, a scratch budget or a failed allocation changes the route silently).  Negative: no device. */
+#define ZJNI_ROUTE_NONE 0         /* no large-batch compress call yet */
+#define ZJNI_ROUTE_FUSED 1        /* zj_encode_kernel alone (small batches, levels 1-2) */
+#define ZJNI_ROUTE_WAVE 2         /* zj_enc_match_wave_kernel (small level-3 batches, tables in LDS) */
+#define ZJNI_ROUTE_LANE 3         /* zj_enc_match_kernel (levels 1-2; level 3 under ZJNI_LANE_MACHINE=0 without flags) */
+#define ZJNI_ROUTE_LANE_GATED 4   /* zj_enc_match_gated_kernel (ZJNI_LANE_MACHINE=0 with flags) */
+#define ZJNI_ROUTE_RUN 5          /* zj_enc_match_run_kernel without need flags */
+#define ZJNI_ROUTE_RUN_FLAGS 6    /* zj_enc_match_run_kernel behind zj_enc_worth_kernel / zj_enc_need_kernel */
+#define ZJNI_ROUTE_HYBRID 7       /* ZJNI_HYBRID=1: lane and wave kernels side by side */
+#define ZJNI_ROUTE_OTHER 8        /* levels 4-8, dictionaries, multi-block only */
+int zjni_last_route(void);
+/* Name of the kernel a route's match-finder time (zjni_last_timing out[0]) belongs to. */
+const char* zjni_route_kernel(int route);
+/* The source revision the library was built from ("unknown" when the build had no git): profiles and PMC passes are stamped with it. */
+const char* zjni_build_stamp(void);
 
 #ifdef __cplusplus
 }

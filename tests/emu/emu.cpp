@@ -150,7 +150,7 @@ extern "C" unsigned emu_check_code_tables() {
 
 // split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
 // kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout
-static int g_emu_force_gated = 0, g_emu_skip = 0;
+static int g_emu_force_gated = 0, g_emu_run = 0;
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
@@ -171,20 +171,23 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
             struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
             ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));
             nflags = (u8*)malloc(srcSize + ZN_FLAG_SLACK); memset(nflags, 0xFF, srcSize + ZN_FLAG_SLACK);
-            char const nm = getenv("ZJNI_EMU_NEED")[0];         // 1 flags for every frame, 2 for the picked frames; 3 / 4: the same on the machine that decides two positions per round (SKIP)
-            g_emu_skip = (nm == '3' || nm == '4');
-            bool const take = (nm != '2' && nm != '4') || zn_worth(one, (u32*)L, src, srcSize);     // 2: the selective mode — frames not picked run the gated machine without flags
+            char const nm = getenv("ZJNI_EMU_NEED")[0];         // ZLaneD: 1 flags for every frame, 2 for the picked frames (the others run the gated machine without flags)
+            g_emu_run = (nm == '5' || nm == '6' || nm == '7');  // the run machine (zj_match_run.h): 5 flags for every frame, 6 for the picked frames, 7 for none
+            bool const take = nm != '7' && ((nm != '2' && nm != '6') || zn_worth(one, (u32*)L, src, srcSize));
             if (take) zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
             else { free(nflags); nflags = nullptr; g_emu_force_gated = 1; }
             if (nflags && getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
             free(L);
         } }
-    if (g_emu_force_gated && !nflags && srcSize >= ZL_MIN_FRAME) {
-        if (g_emu_skip) ze_match_lane_t<ZLaneD<ZEEntTag, true, true> >(src, srcSize, lw, table, fs, maxSrc, meta, nullptr);
-        else ze_match_lane_t<ZLaneD<ZEEntTag, true> >(src, srcSize, lw, table, fs, maxSrc, meta, nullptr);
+    if (g_emu_run && srcSize >= ZL_MIN_FRAME) {
+        if (getenv("ZJNI_EMU_JMAX")) { if (atoi(getenv("ZJNI_EMU_JMAX")) == 3) ze_match_lane_t<ZLaneR<ZEEntTag, 3u> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags); else ze_match_lane_t<ZLaneR<ZEEntTag, 7u> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags); }
+        else ze_match_lane_t<ZLaneR<ZEEntTag> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags);
         g_emu_force_gated = 0;
-    } else ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide, nflags, nflags != nullptr && g_emu_skip);
-    g_emu_skip = 0;
+    } else if (g_emu_force_gated && !nflags && srcSize >= ZL_MIN_FRAME) {
+        ze_match_lane_t<ZLaneD<ZEEntTag, true> >(src, srcSize, lw, table, fs, maxSrc, meta, nullptr);
+        g_emu_force_gated = 0;
+    } else ze_match_lane(src, srcSize, lw, table, fs, maxSrc, meta, wide, nflags);
+    g_emu_run = 0;
     free(nflags);
     ZEPre pre; pre.seqs = (ZESeq*)fs; pre.litOff = (const u32*)(fs + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); pre.meta = meta;
     ZjProf pf; pf.start(nullptr);
@@ -302,7 +305,7 @@ extern "C" unsigned emu_read_ncount(const unsigned char* src, unsigned size, uns
     return h;
 }
 
-// rounds the double-fast lane machine takes for one frame (mode 0 plain, 1 gated, 2 gated + two positions per round) — analysis aid
+// rounds the double-fast lane machines take for one frame (ZLaneD: mode 0 plain, 1 gated; the run machine: 3 with flags, 4 without) — analysis aid
 extern "C" unsigned emu_lane_rounds(const unsigned char* src, unsigned srcSize, unsigned mode) {
     u32 const lw = 3; ZEParams const p = ze_params_of(lw, srcSize);
     if (srcSize < ZL_MIN_FRAME || srcSize > 65536u) return 0;
@@ -314,7 +317,7 @@ extern "C" unsigned emu_lane_rounds(const unsigned char* src, unsigned srcSize, 
         zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, flags); free(L);
     }
     u32 rounds = 0;
-    if (mode == 2) { ZLaneD<ZEEntTag, true, true> m; m.init(src, srcSize, p, table, fs, 65536u, flags); for (u32 r = 0; m.st != ZL_DONE; r++) { m.round(m.phase_of(r)); rounds++; } }
+    if (mode == 3 || mode == 4) { ZLaneR<ZEEntTag> m; m.init(src, srcSize, p, table, fs, 65536u, mode == 3 ? flags : nullptr); for (u32 r = 0; m.st != ZL_DONE; r++) { m.round(m.phase_of(r)); rounds++; } }
     else if (mode == 1) { ZLaneD<ZEEntTag, true> m; m.init(src, srcSize, p, table, fs, 65536u, flags); for (u32 r = 0; m.st != ZL_DONE; r++) { m.round(m.phase_of(r)); rounds++; } }
     else { ZLaneD<ZEEntTag> m; m.init(src, srcSize, p, table, fs, 65536u); for (u32 r = 0; m.st != ZL_DONE; r++) { m.round(m.phase_of(r)); rounds++; } }
     free(flags); free(fs); free(table);

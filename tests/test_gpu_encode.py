@@ -156,18 +156,23 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     assert bytes(dst[100:100 + n]) == z and dst[:100] == bytes(100)
 
 
+@pytest.mark.parametrize("machine", ["run", "lane"])
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
-def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch, mode):
-    """zj_need.h: the flag kernel + the need-gated lane machine give the same frames — for every frame (ZJNI_NEED=1), for the frames the
-    flag kernel picks (2, the default), and with the ungated machine (0)"""
+def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch, mode, machine):
+    """zj_need.h + zj_match_run.h: the flag kernels beside the match kernel give the same frames — flags for every frame (ZJNI_NEED=1), for the
+    frames the worth kernel picks (2, the default), for none (0) — on the run machine (the product's route, and what zjni_last_route reports)
+    and on the previous lane machine (ZJNI_LANE_MACHINE=0)"""
     monkeypatch.setenv("ZJNI_NEED", mode)
     monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    if machine == "lane": monkeypatch.setenv("ZJNI_LANE_MACHINE", "0")
     rnd = random.Random(43)
     datas = [gpu.synth_host(65536, k, 1) for k in range(96)] + [gpu.synth_host(s, 100 + s, 1) for s in (64, 65, 1000, 8192, 8193, 30000, 65535, 63, 0)]
     datas += [bytes([7]) * 40000, bytes(rnd.getrandbits(8) for _ in range(20000)), (b"abcdefgh" * 5000)[:33333], golden("xmlsmall")[:60000]]
     outs = gpu.compress_batch(datas, 3)
     for d, z in zip(datas, outs):
         assert z == (oracle_ref.compress(d, 3) if len(d) <= 8192 else oracle_ref.compress(d, 3, False, 14, 13)), len(d)
+    route = gpu.lib().zjni_last_route()
+    assert route == {("run", "0"): 5, ("run", "1"): 6, ("run", "2"): 6, ("lane", "0"): 3, ("lane", "1"): 4, ("lane", "2"): 4}[(machine, mode)], route
     outs = gpu.compress_batch(datas, 3, hash_log=15, chain_log=15)
     for d, z in zip(datas, outs):
         assert z == oracle_ref.compress(d, 3, False, 15, 15), len(d)

@@ -1,7 +1,8 @@
 """Randomised byte-identity stress of the need-gated double-fast machine (zj_need.h: flag kernel body + ZLaneD<E, true>) on the lane-serial
 build against the reference: level 3, frames of 64 B ... 64 KiB, the library's and explicit table sizes.  NEEDMODE=1 (flags for every frame),
-2 (flags for the frames zn_worth() picks, the gated machine without flags for the rest), 3 / 4 (the same two on the machine that decides two
-positions per round, ZJNI_NEED=3 in the library; 440 000 frames, 0 differences).  usage: [NEEDMODE=2] fuzz_emu_need.py <seed> <seconds>
+2 (flags for the frames zn_worth() picks, the gated machine without flags for the rest); 5 / 6 / 7: the run machine (zj_match_run.h — the product's
+machine for large level-3 batches) with flags for every frame / the picked frames / none, ZJNI_EMU_JMAX=3|7 for other run lengths (372 000 frames
+on its first day, 0 differences).  usage: [NEEDMODE=6] fuzz_emu_need.py <seed> <seconds>
 TEST INFRASTRUCTURE."""
 import sys, os, random, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

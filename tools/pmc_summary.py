@@ -1,10 +1,11 @@
 """Condense rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/measure_round.sh: gpurun_out/<tag>/pmc/<config>_L<level>_<n>x<size>_<COUNTER>.csv,
-one counter per pass, driver = tools/prof_driver.py <n> <size> <level> 1) into profiles/<round>_pmc_traffic.json, which bench.py reads for
-roofline.traffic, stamped with the commit the passes ran on.  Counter units are KB; what one request tallies: tools/micro/chase cal.
+one counter per pass, driver = tools/prof_driver.py <n> <size> <level> 1; tools/pmc_traffic.sh does the same and keeps the driver's JSON line) into
+profiles/<round>_pmc_traffic.json, which bench.py reads for roofline.traffic.  Every record carries the zjni_build_stamp() the driver printed
+(revision + hash of csrc/): bench.py quotes a figure only when its own library has that stamp.  Counter units are KB; what one request tallies: tools/micro/chase cal.
 usage: pmc_summary.py <gpurun_out/tag> <round, e.g. r02>   (copies the csvs to profiles/<round>_pmc/ too)"""
 import collections, csv, datetime, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "zstd-jni_amd/csrc"], text=True).strip())
 out = {"note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
@@ -28,12 +29,23 @@ for key in keys:
             if name.startswith("zj_"):
                 rec[name][k].append(float(r["Counter_Value"]) * 1024.0)
     summ = {}
+    stamp = None
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):                     # the driver's own line of the pass: which build, which route
+        jp = os.path.join(src, "pmc", f"{key}_{cn}_driver.json")
+        if os.path.exists(jp):
+            for line in open(jp):
+                if line.startswith("{"):
+                    dj = json.loads(line); stamp = stamp or dj.get("build_stamp"); shutil.copy(jp, dst)
     for name, v in rec.items():
         # the driver runs 2 calls (1 warm-up + 1); kernels launched several times per call (lists A / B / S): the largest launch
         fetch = max(v["fetch"]) if v["fetch"] else 0.0
         write = max(v["write"]) if v["write"] else 0.0
-        summ[name] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
+        summ[name] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write, "build_stamp": stamp}
     out[key] = summ
+    for extra in (f"{key}_kernel_stats.csv", f"{key}_driver.json"):     # the rocprofv3 --kernel-trace --stats summary of the same driver command
+        ep = os.path.join(src, extra)
+        if os.path.exists(ep):
+            shutil.copy(ep, os.path.join(ROOT, "profiles", f"{rnd}_{extra}"))
 with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
-print(json.dumps({k: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 2) for kk, vv in v.items()} for k, v in out.items() if isinstance(v, dict) and k not in ("calibration",)}, indent=1))
+print(json.dumps({k: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 2) for kk, vv in v.items() if isinstance(vv, dict)} for k, v in out.items() if isinstance(v, dict) and k not in ("calibration",)}, indent=1))

@@ -53,5 +53,12 @@ for it in range(steps + 1):
 h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp), dsz, C.c_size_t(n * 8), 2))
 t8 = (C.c_float * 8)(); L.zjni_last_timing2(t8)
 stages = dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused", "match_wide"), [round(float(x), 3) for x in t8][:6]))
-print(json.dumps({"stages_ms": stages, "n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+if hasattr(L, "zjni_debug_wave_profile"):
+    wp = np.zeros(3 * 2048, dtype=np.uint64); L.zjni_debug_wave_profile(wp.ctypes.data_as(vp))
+    np.save(os.path.join(ROOT, "gpurun_out", "waveprof_%s.npy" % os.environ.get("AB_TAG", "x")), wp)
+import hashlib
+fp = hashlib.sha1(h_csz.tobytes()).hexdigest()[:12]
+L.zjni_build_stamp.restype = C.c_char_p; L.zjni_route_kernel.restype = C.c_char_p; L.zjni_route_kernel.argtypes = [C.c_int]
+route = int(L.zjni_last_route())
+print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "csz_sha": fp, "build_stamp": L.zjni_build_stamp().decode(), "route": route, "match_kernel": L.zjni_route_kernel(route).decode(), "stages_ms": stages, "n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
                   "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))

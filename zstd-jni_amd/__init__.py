@@ -19,12 +19,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libzjni_amd.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in
-           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_decode_split.h", "zj_encode.h", "zj_match_lane.h", "zj_match_wave.h", "zj_presplit.h", "zj_cdict.h", "zj_synth.h", "zj_need.h", "zj_invprob.h")]
+           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_decode_split.h", "zj_encode.h", "zj_match_lane.h", "zj_match_run.h", "zj_match_wave.h", "zj_presplit.h", "zj_cdict.h", "zj_synth.h", "zj_need.h", "zj_invprob.h")]
 BLOCKSIZE_MAX = 1 << 17
 ERR_NO_DEVICE = 200
 ERR_UNSUPPORTED = 201
 
 _lib = None
+
+
+def build_stamp():
+    """Revision the library is built from: `git describe --always --dirty` plus a hash of csrc/ (the GPU box has no .git, and a
+    dirty tree says nothing about WHICH edits): profiles/ and roofline.traffic are stamped with it (zjni_build_stamp)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(SOURCES + [os.path.join(ROOT, "include", "zjni_amd.h")]):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    try:
+        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        rev = "nogit"
+    return "%s+src%s" % (rev, h.hexdigest()[:10])
 
 
 def build(force=False, verbose=False):
@@ -35,7 +50,7 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB_PATH, SOURCES[0]]
+           "-DZJNI_BUILD_STAMP=\"%s\"" % build_stamp(), "-o", LIB_PATH, SOURCES[0]]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
 
@@ -154,6 +169,10 @@ def lib():
     L.zjni_kernel_info.restype = C.c_int
     L.zjni_kernel_info.argtypes = [C.POINTER(C.c_int)] * 4
     L.zjni_shutdown.restype = None
+    L.zjni_last_route.restype = C.c_int
+    L.zjni_route_kernel.restype = C.c_char_p
+    L.zjni_route_kernel.argtypes = [C.c_int]
+    L.zjni_build_stamp.restype = C.c_char_p
     _lib = L
     return L
 
@@ -170,7 +189,8 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_createCDict", "zjni_freeCDict", "zjni_getDictID_fromCDict", "zjni_compress_batch_device_usingCDict",
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
-           "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats")
+           "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
+           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

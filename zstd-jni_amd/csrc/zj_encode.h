@@ -2020,12 +2020,12 @@ ZJ_DEV void ze_match_lane_t(const u8* src, u32 srcSize, u32 level, u8* table, u8
     for (u32 r = 0; m.st != ZL_DONE; r++) m.round(M::phase_of(r));
     meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
 }
+#include "zj_match_run.h"
 // `wide`: the frame is in the launch whose fast-strategy tables hold 4-byte positions (frames > 64 KiB, and the few
 // small level-1/2 frames whose hashLog exceeds the common case)
 // `flags` (zj_need.h, level 3): the frame's flag bytes — the gated machine
-ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false, const u8* flags = nullptr, bool skip = false) {
+ZJ_DEV void ze_match_lane(const u8* src, u32 srcSize, u32 level, u8* table, u8* fscratch, u32 maxSrc, u32* meta, bool wide = false, const u8* flags = nullptr) {
     if (srcSize < ZL_MIN_FRAME) ze_match_lane_serial(src, srcSize, level, table, fscratch, maxSrc, meta);
-    else if (ZE_LW_LEVEL(level) == 3 && skip) ze_match_lane_t<ZLaneD<ZEEntTag, true, true> >(src, srcSize, level, table, fscratch, maxSrc, meta, flags);
     else if (ZE_LW_LEVEL(level) == 3 && flags) ze_match_lane_t<ZLaneD<ZEEntTag, true> >(src, srcSize, level, table, fscratch, maxSrc, meta, flags);
     else if (ZE_LW_LEVEL(level) == 3) ze_match_lane_t<ZLaneD<ZEEntTag> >(src, srcSize, level, table, fscratch, maxSrc, meta);
     else if (wide) ze_match_lane_t<ZLaneF<ZEEnt32> >(src, srcSize, level, table, fscratch, maxSrc, meta);

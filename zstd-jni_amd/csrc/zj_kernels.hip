@@ -244,17 +244,34 @@ __device__ __forceinline__ bool zj_claim_back(unsigned long long* work2, u32 cou
     return (u64)head + tail < split;
 }
 
+#ifdef ZL_PROFILE
+__device__ unsigned long long zlWaveProf[3 * 2048];      // per workgroup of the last large match launch: cycles in the round loop, XCC_ID << 32 | HW_ID, rounds
+extern "C" int zjni_debug_wave_profile(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zlWaveProf), sizeof(zlWaveProf)); }
+#endif
 template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
                                              u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
                                              unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr, const u8* gate = nullptr,
-                                             const u32* sub = nullptr) {      // sub: the queue hands out sub[0 .. count) = slots k of `list` (role queues, ZJNI_NEED=4)
+                                             const u32* ready = nullptr) {      // ready[k] != 0: the flags of list entry k are written (gate[k] says whether any will come)
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
-    bool have = false; u32 k = 0;
-    u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : ZL_DFAST_PERIOD; u32 ph = 0;   // double-fast machine: rounds per rotation of the non-search states
+#ifdef ZL_PROFILE
+    u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0;
+#endif
+    bool have = false, pend = false; u32 k = 0; u64 tPend = 0;
+    u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : M::default_period(); u32 ph = 0;   // double-fast machines: rounds per rotation of the non-search states
     for (u32 r = 0;; r++) {
-        if (m.st == ZL_DONE) {
+        if (pend) {                                       // a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
+            bool const rdy = __hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (rdy || wall_clock64() - tPend > 5000000ull) {
+                if (rdy) __threadfence();
+                u32 const i = list[k];
+                u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
+                m.init(src + s0, size, ze_params_of(level, size), tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc,
+                       rdy ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
+                pend = false; have = true;
+            }
+        } else if (m.st == ZL_DONE) {
             if (have) {
                 u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false;
                 zj_publish_done(doneList, doneCount, k);
@@ -263,20 +280,23 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             else {
             k = atomicAdd(workCounter, 1u);
             if (k >= count) break;
-            if (sub) k = sub[k];
             }
             u32 const i = list[k];
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
             if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
-            m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, (flagsBase && gate[k]) ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
-            have = true;
+            if (flagsBase && gate[k]) { pend = true; tPend = wall_clock64(); }
+            else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = true; }
         }
+#ifdef ZL_PROFILE
+        zlRounds++;
+#endif
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
         ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
+    if (threadIdx.x == 0 && blockIdx.x < 2048u && count > 4096u) { zlWaveProf[3 * blockIdx.x] = __builtin_readcyclecounter() - zlWaveT0; zlWaveProf[3 * blockIdx.x + 1] = ((u64)(u32)__builtin_amdgcn_s_getreg(63508) << 32) | (u32)__builtin_amdgcn_s_getreg(63492); zlWaveProf[3 * blockIdx.x + 2] = zlRounds; }
+    if (ZL_PROFILE > 1 && blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
 #endif
 }
 // entries [listBase, listBase + sliceLen) of a list whose length sits in device memory (a slice past its end is empty)
@@ -295,72 +315,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 }
 
 // ---- need-gated level 3 (zj_need.h; ZJNI_NEED = 2 by default: flags for the frames zn_worth() picks) ----
-// zj_enc_need_kernel: one workgroup of 512 lanes per frame computes the frame's flag bytes (which probes can match, which writes can be
-// read) with Bloom filters in LDS; zj_enc_match_gated_kernel is zj_enc_match_kernel on the gated double-fast machine.
+// zj_enc_worth_kernel decides per frame whether it gets flags (gate[k]); zj_enc_need_kernel — one workgroup of 512 lanes per picked frame, Bloom
+// filters in LDS — computes the flag bytes (which probes can match, which writes can be read) BESIDE the match kernel, whose lanes wait (bounded)
+// for ready[k] before they start a picked frame; the frames that are not picked start at once.  The flags only ever remove work, so a lane whose
+// wait runs out starts its frame without them.
 struct ZNThreads {
     __device__ __forceinline__ u32 id() const { return threadIdx.x; }
     __device__ __forceinline__ u32 count() const { return blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
-// `gate` (one byte per list entry): 1 = the frame has flags.  selective: only frames zn_worth() picks get them, the others run ungated.
-__global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
-                                                          const u32* __restrict__ list, const u32* countPtr, u8* flagsBase, u8* gate, u32 selective, u32* work,
-                                                          u32* roleLists = nullptr, u32* roleCounts = nullptr) {      // ZJNI_NEED=4: picked slots to roleLists[0 ..), the others to roleLists[count ..)
-    ZNLds& L = *(ZNLds*)zj_dyn_lds;
-    __shared__ u32 next;
+// gate[k] = 1: list entry k will get flags (its slot number goes to pickList); selective = 0: every frame the lane machine takes
+__global__ __launch_bounds__(256) void zj_enc_worth_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list, const u32* countPtr,
+                                                           u8* gate, u32* ready, u32 selective, u32* pickList, u32* pickCount) {
+    __shared__ u32 bm[136];
     ZNThreads t;
     u32 const count = *countPtr;
-    for (;;) {                                            // frames differ (selective: most are skipped), and a list in batch order puts one class on one workgroup: a queue
-        if (threadIdx.x == 0) next = atomicAdd(work, 1u);
-        __syncthreads();
-        u32 const k = next;
-        __syncthreads();
-        if (k >= count) break;
+    for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
         u32 const i = list[k];
         u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
         bool take = size >= ZL_MIN_FRAME;                 // (the plain loops take smaller frames, zj_match_run)
-        if (take && selective) take = zn_worth(t, (u32*)&L, src + s0, size);
-        if (threadIdx.x == 0) {
-            gate[k] = take ? 1 : 0;
-            if (roleLists) { u32 const at = atomicAdd(&roleCounts[take ? 0 : 1], 1u); roleLists[(take ? 0u : count) + at] = k; }
-        }
-        if (!take) continue;
-        ZEParams const p = ze_params_of(level, size);
-        zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);
+        if (take && selective) take = zn_worth(t, bm, src + s0, size);
+        if (threadIdx.x == 0) { gate[k] = take ? 1 : 0; ready[k] = 0; if (take) pickList[atomicAdd(pickCount, 1u)] = k; }
     }
 }
+__global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                          const u32* __restrict__ list, const u32* __restrict__ pickList, const u32* pickCount,
+                                                          u8* flagsBase, u32* ready, u32* work) {
+    ZNLds& L = *(ZNLds*)zj_dyn_lds;
+    __shared__ u32 next;
+    ZNThreads t;
+    u32 const count = *pickCount;
+    u32 prev = 0xFFFFFFFFu;                               // the slot whose flags this workgroup finished last: published by lane 0 in the SAME divergent region that claims
+    for (;;) {                                            // the next one (a separate `if (lane 0)` at the loop's end makes the compiler route lane 0 around the barriers)
+        if (threadIdx.x == 0) {                           // a work queue: workgroups differ in speed, and the match kernel's lanes are waiting
+            if (prev != 0xFFFFFFFFu) { __threadfence(); __hip_atomic_store(&ready[prev], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            next = atomicAdd(work, 1u);
+        }
+        __syncthreads();
+        u32 const q = next;
+        __syncthreads();
+        if (q >= count) break;
+        u32 const k = pickList[q], i = list[k];
+        u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
+        ZEParams const p = ze_params_of(level, size);
+        zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);      // (ends with a barrier: every lane's flag bytes are written)
+        prev = k;
+    }
+}
+// The level-3 match kernel of large batches: the run machine (zj_match_run.h) for every frame of the launch — register windows for the sequential
+// streams, and for the frames with flags a run of quiet positions per round; frames without flags run it with every flag set.  Mixed waves on
+// purpose: a wave of search-dense frames alone issues four times the requests per round (measured with a role split: 201 ms against 168).
+template <u32 JMAX>
+__device__ __forceinline__ void zj_enc_match_run_body(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+                                                       const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                       u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
+                                                       u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate, const u32* ready) {
+    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
+    zj_match_run<ZLaneR<ZEEntTag, JMAX> >(src, srcOff, level, list + listBase, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, ready);
+}
+#define ZJ_RUN_KERNEL(NAME, JMAX) \
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void NAME(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level, \
+                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter, \
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount, \
+                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate, const u32* ready) { \
+    zj_enc_match_run_body<JMAX>(src, srcOff, level, list, countPtr, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, listBase, sliceLen, flagsBase, gate, ready); }
+ZJ_RUN_KERNEL(zj_enc_match_run_kernel, ZR_JMAX_DEFAULT)
+#ifdef ZJ_TUNING_KERNELS                                      /* run-length sweep for A/B runs (tools/ab.sh, ZJNI_RUN_JMAX) */
+ZJ_RUN_KERNEL(zj_enc_match_run3_kernel, 3u)
+ZJ_RUN_KERNEL(zj_enc_match_run4_kernel, 4u)
+ZJ_RUN_KERNEL(zj_enc_match_run6_kernel, 6u)
+ZJ_RUN_KERNEL(zj_enc_match_run7_kernel, 7u)
+#endif
+// ZJNI_LANE_MACHINE=0: the previous machine (ZLaneD with its table accesses predicated on the flags), kept selectable for A/B runs
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_gated_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate) {
+                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate, const u32* ready) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
-}
-
-// ZJNI_NEED=3 (experiment, measured slower with mixed waves — DESIGN.md section 4): the gated machine that decides two positions per round where the flags allow (ZLaneD<E, true, true>)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_skip_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
-                                                           const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
-                                                           u32 listBase, u32 sliceLen, const u8* flagsBase, const u8* gate) {
-    u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
-    list += listBase;
-    zj_match_run<ZLaneD<ZEEntTag, true, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate);
-}
-
-// ZJNI_NEED=4 (experiment, NOT YET RUN ON A GPU — next round's first measurement): waves by role.  The flag kernel has sorted the
-// slots into picked frames and the rest; a wave draws a ticket and either runs the two-positions-per-round machine over picked frames only, or the
-// plain machine over the others — so the second position's code is paid only where it saves rounds.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_roles_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
-                                                           const u32* __restrict__ list, const u32* countPtr, u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta,
-                                                           u32* doneList, u32* doneCount, const u8* flagsBase, const u8* gate,
-                                                           const u32* roleLists, u32* roleCounts) {       // roleCounts: [0] picked, [1] others, [2] tickets, [3] / [4] work counters
-    __shared__ u32 role;
-    u32 const count = *countPtr, nP = roleCounts[0], nR = roleCounts[1];
-    if (threadIdx.x == 0) { u32 const t = atomicAdd(&roleCounts[2], 1u); role = ((u64)t * 64u < nP) ? 1u : 0u; }
-    __syncthreads();
-    if (ZJ_UNI(role)) zj_match_run<ZLaneD<ZEEntTag, true, true> >(src, srcOff, level, list, nP, roleCounts + 3, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, roleLists);
-    else zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, nR, roleCounts + 4, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, nullptr, nullptr, roleLists + count);
+    zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, ready);
 }
 
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
@@ -728,8 +761,11 @@ size_t enc_lds_pass0(int level) {
     size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);
 }
+enum { ZJ_ROUTE_FUSED = ZJNI_ROUTE_FUSED, ZJ_ROUTE_WAVE = ZJNI_ROUTE_WAVE, ZJ_ROUTE_LANE = ZJNI_ROUTE_LANE, ZJ_ROUTE_LANE_GATED = ZJNI_ROUTE_LANE_GATED,
+       ZJ_ROUTE_RUN = ZJNI_ROUTE_RUN, ZJ_ROUTE_RUN_FLAGS = ZJNI_ROUTE_RUN_FLAGS, ZJ_ROUTE_HYBRID = ZJNI_ROUTE_HYBRID, ZJ_ROUTE_OTHER = ZJNI_ROUTE_OTHER };
 struct DevState {
     bool needLdsSet = false;                      // zj_enc_need_kernel's LDS attribute has been set on this device
+    int lastRoute = 0;                            // ZJNI_ROUTE_* of the last large compress call (zjni_last_route)
     int ordinal = -1;
     int numCU = 0;
     int decGrid = 0, decDictGrid = 0, encGrid = 0;          // encGrid = largest encoder grid (level-1 LDS)
@@ -1030,6 +1066,22 @@ int zjni_last_timing2(float* out8) {
     return 0;
 }
 
+int zjni_last_route(void) { DevState* d = cur_state(); return d ? d->lastRoute : -(int)ZJNI_ERROR_no_device; }
+const char* zjni_route_kernel(int route) {
+    switch (route) {
+    case ZJNI_ROUTE_FUSED: return "zj_encode_kernel";
+    case ZJNI_ROUTE_WAVE: return "zj_enc_match_wave_kernel";
+    case ZJNI_ROUTE_LANE: case ZJNI_ROUTE_HYBRID: return "zj_enc_match_kernel";
+    case ZJNI_ROUTE_LANE_GATED: return "zj_enc_match_gated_kernel";
+    case ZJNI_ROUTE_RUN: case ZJNI_ROUTE_RUN_FLAGS: return "zj_enc_match_run_kernel";
+    default: return "";
+    }
+}
+#ifndef ZJNI_BUILD_STAMP
+#define ZJNI_BUILD_STAMP "unknown"
+#endif
+const char* zjni_build_stamp(void) { return ZJNI_BUILD_STAMP; }
+
 /* ---- resource policy ---- */
 size_t zjni_set_scratch_limit(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1211,6 +1263,13 @@ unsigned zjni_getDictID_fromDDict(const zjni_ddict* dd) { return dd ? dd->dictID
 
 // The `checksum` argument of the advanced / dictionary entries is a flag word (include/zjni_amd.h ZJNI_FRAME_*): 1 alone is what it
 // always meant; the boolean entries (zjni_compress*2) normalise their argument before they get here.
+static inline void zj_dbg_sync(const char* what) {        // ZJNI_DEBUG_SYNC=1: drain the device after a launch and say so (finding the kernel that does not return)
+    static int const on = getenv("ZJNI_DEBUG_SYNC") ? 1 : 0;
+    if (!on) return;
+    fprintf(stderr, "[zjni] waiting for %s ...", what); fflush(stderr);
+    hipError_t const e = hipDeviceSynchronize();
+    fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e)); fflush(stderr);
+}
 static inline u32 zj_frame_flags(int word) { return (u32)word & ZE_FLAG_MASK; }
 static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                          uint64_t* d_result, size_t n, int levelWord, u32 flags, void* stream) {
@@ -1222,6 +1281,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
+    d->lastRoute = ZJ_ROUTE_OTHER;
     if (d->encListCap < n) {                      // grows rarely; the only synchronous step of this entry
         if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
         size_t const cap = n + (n >> 2) + 1024;
@@ -1311,27 +1371,30 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
-        // Level 3 on the need-gated machine (zj_need.h): a flag byte per position ahead of the match kernel.  ZJNI_NEED: 2 (default) = the frames
-        // zn_worth() picks — search-dense frames over a small alphabet, the class that sets the match kernel's time — 1 = every frame, 0 = off.
-        // 64 KiB of flags per frame slot: left out under a scratch budget (zjni_set_scratch_limit) and when the device cannot spare them.
+        // Level 3, large batches: the run machine (zj_match_run.h), with need flags (zj_need.h: a flag byte per position, computed BESIDE the match
+        // kernel) for the frames they pay on.  ZJNI_NEED: 2 (default) = the frames zn_worth() picks — search-dense frames over a small alphabet —
+        // 1 = every frame, 0 = none.  64 KiB of flags per frame slot: left out under a scratch budget (zjni_set_scratch_limit) and when the device
+        // cannot spare them; the machine then runs with every flag set.  ZJNI_LANE_MACHINE=0: the previous machine (ZLaneD), for A/B runs.
         u32 needMode = 2;
         if (const char* ov = getenv("ZJNI_NEED")) needMode = (u32)atoi(ov);
+        bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
+        bool const runMachine = level == 3 && !smallWave && getenv("ZJNI_HYBRID") == nullptr && !(getenv("ZJNI_LANE_MACHINE") && atoi(getenv("ZJNI_LANE_MACHINE")) == 0);
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-        bool needGate = (needMode >= 1 && needMode <= 4) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
-                        && getenv("ZJNI_NO_OVERLAP") == nullptr && hlN <= ZN_MAX_LOG && clN <= ZN_MAX_LOG;
-        if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: the ungated machine
+        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
+                        && overlap && hlN <= ZN_MAX_LOG_L && clN <= ZN_MAX_LOG_S;
+        if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: no flags
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
             else { (void)hipGetLastError(); needGate = false; }
         }
-        u32 const needSelective = needMode >= 2 ? 1u : 0u;          // 3 (experiment): the picked frames' flags + the machine that decides two positions per round
-        size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + n + 128 + (needMode == 4 ? 8 * n + 64 : 0) : 0;
+        u32 const needSelective = needMode >= 2 ? 1u : 0u;
+        size_t needFlagBytes = needGate ? n * (size_t)ZN_FLAG_STRIDE + 9 * n + 384 : 0;     // flags, gate bytes, ready words, pick list
         size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
             if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) {
                 if (!needGate) return ZJNI_ERR(64);
-                (void)hipGetLastError(); needGate = false; need -= needFlagBytes; needFlagBytes = 0;          // no room for the flags: the ungated machine
+                (void)hipGetLastError(); needGate = false; need -= needFlagBytes; needFlagBytes = 0;          // no room for the flags
                 if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             }
             d->splitBufCap = need;
@@ -1339,12 +1402,12 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u8* const tables = d->splitBuf; fscratch = d->splitBuf + tablesBytes; meta = (u32*)(fscratch + fsBytes);
         u32* const doneList = (u32*)((u8*)meta + metaBytes); u32* const procFlag = doneList + n; u8* const score = (u8*)(procFlag + n);
         u8* const needFlags = needGate ? (u8*)(((uintptr_t)(score + n) + 63) & ~(uintptr_t)63) : nullptr;
-        u8* const needGateMap = needGate ? needFlags + n * (size_t)ZN_FLAG_STRIDE : nullptr;
-        u32* const roleLists = (needGate && needMode == 4) ? (u32*)(((uintptr_t)(needGateMap + n) + 63) & ~(uintptr_t)63) : nullptr;   // [n] picked slots, [n] the others
-        u32* const roleCounts = d->counters + 216;          // [0] picked, [1] others, [2] tickets, [3] / [4] work
+        u32* const needReady = needGate ? (u32*)(needFlags + n * (size_t)ZN_FLAG_STRIDE) : nullptr;       // (ZN_FLAG_STRIDE is a multiple of 16)
+        u32* const needPick = needGate ? needReady + n : nullptr;
+        u8* const needGateMap = needGate ? (u8*)(needPick + n) : nullptr;
+        u32* const needCtr = d->counters + 208;             // [0] flag kernel's work queue, [1] picked frames
 
         u32* const mctr = d->counters + 24;       // [0] match work, [1] completion-queue length, [2] work of the sweep pass
-        bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
         // Experiment (ZJNI_HYBRID=1, off by default): at level 3 with the LDS-sized tables the two match
         // finders share a large batch — the list is partitioned by search density, the lane-per-frame kernel (tables in HBM,
         // bound by their random requests) takes the match-dense part, the wave-per-frame kernel (tables in LDS) the rest.
@@ -1375,11 +1438,12 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
         unsigned long long* const eprof = d->prof ? d->prof + 16 : nullptr;
-        if (needGate && hipMemsetAsync(d->counters + 208, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        if (roleLists && hipMemsetAsync(roleCounts, 0, 20, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        if (needGate) {      // ahead of the fork: the flag kernel's workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
-            u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-            hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord, (const u32*)listA, (const u32*)ctr, needFlags, needGateMap, needSelective, d->counters + 208, roleLists, roleLists ? roleCounts : (u32*)nullptr);
+        if (needGate) {      // which frames get flags: decided ahead of the fork, a few microseconds per thousand frames
+            if (hipMemsetAsync(needCtr, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            u32 const gw = (u32)(n < (size_t)d->numCU * 8 ? n : (size_t)d->numCU * 8);
+            hipLaunchKernelGGL(zj_enc_worth_kernel, dim3(gw), dim3(256), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listA, (const u32*)ctr,
+                               needGateMap, needReady, needSelective, needPick, needCtr + 1);
+            zj_dbg_sync("zj_enc_worth_kernel");
         }
         if (overlap) {
             // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
@@ -1389,7 +1453,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             // actually being co-scheduled.
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-            if (hybrid && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
+                u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
+                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), getenv("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr);
+                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                zj_dbg_sync("zj_enc_need_kernel");
+            }
             (void)hipEventRecord(d->tev[0], st);
             if (hybrid) {
                 u32 const gw = (u32)(n < (size_t)d->waveGrid ? n : (size_t)d->waveGrid);
@@ -1397,25 +1468,34 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                    listM, (const u32*)ctr, work2, fscratch, maxSrc, meta, doneList, mctr + 1);
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             }
-            u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machine (0 = ZL_DFAST_PERIOD)
+            u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machines (0 = the machine's own)
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
-            if (needGate && needMode == 4) {
-                hipLaunchKernelGGL(zj_enc_match_roles_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
-                                   listM, (const u32*)ctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, (const u8*)needFlags, (const u8*)needGateMap,
-                                   (const u32*)roleLists, roleCounts);
-            } else if (needGate && needMode == 3) {
-                hipLaunchKernelGGL(zj_enc_match_skip_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
-                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
+            if (runMachine) {
+                void (*kern)(const u8*, const u64*, u32, const u32*, const u32*, u32*, u8*, u32, u8*, u32, u32*, u32*, u32*, u32, u32, const u8*, const u8*, const u32*) = zj_enc_match_run_kernel;
+#ifdef ZJ_TUNING_KERNELS
+                if (const char* ov = getenv("ZJNI_RUN_JMAX")) { int const j = atoi(ov); kern = j == 3 ? zj_enc_match_run3_kernel : j == 4 ? zj_enc_match_run4_kernel : j == 6 ? zj_enc_match_run6_kernel : j == 7 ? zj_enc_match_run7_kernel : zj_enc_match_run_kernel; }
+#endif
+                hipLaunchKernelGGL(kern, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
+                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap, (const u32*)needReady);
+                d->lastRoute = needGate ? ZJ_ROUTE_RUN_FLAGS : ZJ_ROUTE_RUN;
             } else if (needGate) {
                 hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
-                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
+                                   listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap, (const u32*)needReady);
+                d->lastRoute = ZJ_ROUTE_LANE_GATED;
             } else
-            if (!waveOnly)
+            if (!waveOnly) {
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu,
                                hybrid ? work2 : (unsigned long long*)nullptr);
+            d->lastRoute = hybrid ? ZJ_ROUTE_HYBRID : ZJ_ROUTE_LANE;
+            } else d->lastRoute = ZJ_ROUTE_WAVE;
+            if (needGate && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            zj_dbg_sync("match kernel");
             if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
+            // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
+            // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
+            if (needGate && !getenv("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
@@ -1425,9 +1505,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
         } else {
             (void)hipEventRecord(d->tev[0], st);
-            if (needGate)
-                hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                                   (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap);
+            d->lastRoute = runMachine ? ZJ_ROUTE_RUN : ZJ_ROUTE_LANE;
+            if (runMachine)
+                hipLaunchKernelGGL(zj_enc_match_run_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (const u8*)nullptr, (const u8*)nullptr, (const u32*)nullptr);
             else
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (unsigned long long*)nullptr);
@@ -1438,6 +1519,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         }
     } else {
         // small batches: the fused wave-per-frame kernel (match finding on lane 0 with the tables in LDS)
+        d->lastRoute = ZJ_ROUTE_FUSED;
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[level] ? n : (size_t)d->encGridLvl[level]);
         hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsA, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, d->prof ? d->prof + 16 : nullptr,

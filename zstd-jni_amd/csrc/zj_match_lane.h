@@ -95,16 +95,13 @@ enum { ZC_REP1 = 0, ZC_LONG, ZC_SHORT, ZC_SHORT_L1, ZC_REPLOOP, ZC_FOUND };
 // and counts as empty); ZN_INS_L / ZN_INS_S: some position of the frame will read this position's bucket (none: the entry is not written).
 // A bucket that is read at all receives every write, so a probe that is made sees exactly the entry the reference's probe sees; a probe
 // that is skipped could not have matched.  Same decisions, a fraction of the table requests.
-// SKIP (with GATED, ZJNI_NEED=3, experiment): while the step is 1 the machine keeps one more word of look-ahead (w2 = the word at ip + 2) and,
-// when the flags say that the next position needs neither probe, decides it in the same round as this one — its repcode test comes out of the
-// bytes the round fetches anyway, its table writes are made once this position is known not to match, and the probes the round issues are the
-// position's after next (a write of the skipped position into the same bucket is forwarded to them).  One round, two positions, the reference's order.
-template <class E, bool GATED = false, bool SKIP = false>
+// (Large level-3 batches run zj_match_run.h's machine — register windows, runs of flag-quiet positions per round; this one serves the
+// wide launch, and ZJNI_LANE_MACHINE=0 keeps it selectable for A/B runs.)
+template <class E, bool GATED = false>
 struct ZLaneD {
     typedef typename E::T Ent;
     const u8* src; u32 n, ilimit; Ent* HL; Ent* HS; ZLHash hL, hS;
     const u8* F; u32 fI, fN;                          // GATED: the frame's flag bytes; flags of ip and of ip1
-    u64 w2; u32 fL; bool hw2, l1stale;                // SKIP: the word at ip + 2 (valid while hw2: step == 1) and the flags of ip + 2; hl1 / tl1 not computed for ip1
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip, ip1, anchor, off1, off2, step, nextStep, curr;
@@ -118,7 +115,7 @@ struct ZLaneD {
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc, const u8* flags = nullptr) {
         src = s; n = size; ilimit = size - 8u; hL = zl_hash_of(8, p.hashLog); hS = zl_hash_of(p.minMatch, p.chainLog);
         HL = (Ent*)table; HS = HL + (1u << p.hashLog);
-        F = flags; fI = 15u; fN = 15u; fL = 15u; w2 = 0; hw2 = false; l1stale = false;
+        F = flags; fI = 15u; fN = 15u;
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
         needBack = needCand = more = more2 = cvalid = haveIns = false;
@@ -143,7 +140,6 @@ struct ZLaneD {
     ZJ_DEV_MEMBER void fin() {             // a long/short match is final: apply the backward extension, store it
         ip -= bk; mLength += bk;
         off2 = off1; off1 = offset;
-        if (SKIP && l1stale) { u32 const p1 = prod_long(w1); hl1 = idx_long(p1); tl1 = tag_long(p1); l1stale = false; }   // (the round probed ip + 2 instead of ip1)
         if (step < 4u && (!GATED || (fN & 4u))) HL[hl1] = E::make(ip1 + 1u, tl1);      // (hl1 / fN: the position that was ip1 when the match was found)
         ze_store(o, anchor, ip - anchor, offset + 3u, mLength);
         advance();
@@ -151,6 +147,7 @@ struct ZLaneD {
     ZJ_DEV_MEMBER void fin_or_back() { if (more) st = ZL_BACK; else fin(); }
 
     ZJ_DEVM u32 phase_of(u32 r) { return r % ZL_DFAST_PERIOD; }
+    ZJ_DEVM u32 default_period() { return ZL_DFAST_PERIOD; }
     ZL_PROF_MEMBERS
     // Round r of the wavefront.  A searching lane advances every round; the other states take turns (r mod 8:
     // count/backward, post-insert/reload, restart in consecutive rounds, then five search-only rounds), so a
@@ -177,7 +174,6 @@ struct ZLaneD {
         u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, ti0 = 0, ti1 = 0;
         bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vt = false;
         bool ml0 = false, ms0 = false; u32 ip2 = 0; u64 hw = 0;
-        bool sk = false; u32 pa5 = 0; bool v5 = false; u32 ffa = 0;      // SKIP: this round decides ip1 too; the word at ip + 4; where the flag bytes are read
         bool const on = (st == ZL_SEARCH) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK))
                      || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW)) || ((K & ZL_EN_START) && st == ZL_START);
         // ---- phase 1: what does this lane's state need (and the table writes that precede its reads) ----
@@ -194,11 +190,6 @@ struct ZLaneD {
             ip2 = ip1 + step + ((ip1 >= nextStep) ? 1u : 0u);
             pa3 = ip2; v3 = ip2 <= ilimit;
             hw = w1; vt = true;
-            if (SKIP && hw2) {                           // (step == 1, ip1 == ip + 1, w2 = the word at ip + 2)
-                sk = F != nullptr && (fN & 3u) == 0u && ip + 4u <= nextStep && ip + 3u <= ilimit;
-                pa3 = ip + 3u; v3 = true;               // one word further ahead than the plain machine
-                if (sk) { hw = w2; pa5 = ip + 4u; v5 = true; }
-            }
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
             pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
             if (needBack) { vb = true; if (cont == ZC_SHORT_L1) { bp0 = ip1; bp1 = mpos2; } else { bp0 = ip; bp1 = mpos; } }
@@ -209,7 +200,7 @@ struct ZLaneD {
             pa0 = curr + 2u; pa1 = ip - 2u; pa2 = ip + 6u; v0 = !haveIns; v1 = v2 = true;
             pa3 = ip - off2; v3 = off2 > 0u;
         } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
-            pa0 = ip; pa1 = SKIP ? ip + 2u : ip + 1u; v0 = v1 = true;      // SKIP: the word at ip + 2; the one at ip + 1 is put together from both
+            pa0 = ip; pa1 = ip + 1u; v0 = v1 = true;
             pa3 = ip - off2; v3 = chk && off2 > 0u;
         } else if ((K & ZL_EN_START) && st == ZL_START) {
             hw = w; vt = true;
@@ -228,8 +219,7 @@ struct ZLaneD {
         // predicated: a slot nobody asked for costs no transaction (the fence below keeps the loads together)
         u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0; u32 t0 = 0, t1 = 0;
         u32 fa = 0, fb = 0;                              // GATED: flag bytes fetched this round (the area has 8 bytes of slack behind the frame's)
-        u32 const fw = (st == ZL_SEARCH) ? (sk ? fL : fN) : fI;      // whose probes this round issues: the next position's (search; the one after with SKIP) / this one's (restart)
-        u64 r5 = 0; u32 const q5 = zl_fwd_at(n, v5 ? pa5 : 0u);
+        u32 const fw = (st == ZL_SEARCH) ? fN : fI;      // whose probes this round issues: the next position's (search) / this one's (restart)
         if (v0) r0 = ld64(src + q0);
         if (on) {
             r3 = ld64(src + q3);
@@ -238,11 +228,10 @@ struct ZLaneD {
             if (GATED) {
                 fa = 15u; fb = 0x0F0F0F0Fu;                                                // a frame without flags (F == nullptr) runs ungated
                 if (F) {
-                    if (st == ZL_SEARCH) { if (SKIP && hw2) fa = ld32(F + ip + 2u); else fa = F[q3]; }   // flags of ip2 (q3 == ip2 whenever it is a position the search can reach); SKIP: of ip + 2 .. ip + 5
-                    else if ((K & ZL_EN_POST) && st == ZL_POST) { fa = F[curr + 2u]; fb = ld32(F + ip - 2u); if (SKIP) ffa = F[ip + 2u]; }
-                    else if ((K & ZL_EN_POST) && st == ZL_LOADW) { if (SKIP) { u32 const f4 = ld32(F + ip); fb = f4 << 16; ffa = (f4 >> 16) & 15u; } else fb = ld16(F + ip) << 16; }
-                } else if (SKIP) ffa = 15u;
-                if (SKIP && v5) r5 = ld64(src + q5);
+                    if (st == ZL_SEARCH) fa = F[q3];                                   // flags of ip2 (q3 == ip2 whenever it is a position the search can reach)
+                    else if ((K & ZL_EN_POST) && st == ZL_POST) { fa = F[curr + 2u]; fb = ld32(F + ip - 2u); }
+                    else if ((K & ZL_EN_POST) && st == ZL_LOADW) fb = ld16(F + ip) << 16;
+                }
             }
         }
         if (v1) r1 = ld64(src + q1);
@@ -260,10 +249,6 @@ struct ZLaneD {
         if (st == ZL_SEARCH) {
             u32 const rv = (u32)d0; u32 es1 = t1; el1 = t0; hl1 = nhl; hs1 = nhs; tl1 = ntl;
             wIns = d3; haveIns = v3 && (ip2 == ip + 2u);        // curr + 2 == ip2: its bytes arrived with this round
-            u64 const d5 = SKIP ? zl_fwd_fix(r5, pa5, q5) : 0;
-            u32 const faw = (GATED && F) ? fa : 0x0F0F0F0Fu;     // SKIP: flags of ip + 2 .. ip + 5, one byte each
-            if (SKIP && hw2) { wIns = w2; haveIns = true; }      // the word at curr + 2 is already here
-            if (SKIP) { l1stale = sk; if (sk) { el1 = 0; es1 = 0; } }   // sk: the probes went to ip + 2 — ip1 needs none, and hl1 / tl1 are not its hashes
             if ((off1 > 0u) & (rv == (u32)(w >> 8))) {
                 begin_count(ip + 5u, ip + 5u - off1, ZC_REP1); needBack = false; needCand = false;
             } else if (ml0 && d1 == w) {
@@ -273,39 +258,11 @@ struct ZLaneD {
                 mpos = E::pos(es0) - 1u;
                 begin_count(ip + 4u, mpos + 4u, ZC_SHORT); needBack = true;
                 needCand = (E::pos(el1) > 1u) && E::maybe(el1, tl1); mpos2 = E::pos(el1) - 1u; cvalid = false;
-            } else if (SKIP && sk) {
-                // ip did not match and ip1 = ip + 1 needs no probe: decide it here.  The reference at ip1: write both entries, test the repcode at ip1 + 1.
-                l1stale = false;
-                u32 const p1 = prod_long(w1), b1l = idx_long(p1), b1s = zl_hash(hS, w1);
-                if (fN & 4u) HL[b1l] = E::make(ip1 + 1u, tag_long(p1));
-                if (fN & 8u) HS[b1s] = E::make(ip1 + 1u, ze_tag4((u32)w1));
-                curr = ip1;
-                if ((off1 > 0u) & ((u32)(d0 >> 8) == (u32)(w1 >> 8))) {
-                    ip = ip1; ip1 = ip + 1u;                   // (a repcode match at ip1 + 1: the plain machine's REP1 with ip = ip1)
-                    wIns = d3; haveIns = true;                 // the word at curr + 2 = old ip + 3
-                    begin_count(ip + 5u, ip + 5u - off1, ZC_REP1); needBack = false; needCand = false;
-                } else {
-                    // on to ip + 2 with the probes this round made for it; ip1's writes came after them: forwarded where they share a bucket
-                    u32 e0 = t0, e1 = t1;
-                    if ((fL & 1u) && b1l == nhl && (fN & 4u)) e0 = (u32)E::make(ip1 + 1u, tag_long(p1));
-                    if ((fL & 2u) && b1s == nhs && (fN & 8u)) e1 = (u32)E::make(ip1 + 1u, ze_tag4((u32)w1));
-                    ip = ip + 2u; ip1 = ip + 1u;
-                    w = w2; w1 = d3; w2 = d5;
-                    el0 = e0; es0 = e1; hl0 = nhl; hs0 = nhs; tl0 = ntl;
-                    fI = fL; fN = (faw >> 8) & 15u; fL = (faw >> 16) & 15u;
-                }
             } else {
                 bool const inc = ip1 >= nextStep;
                 if (inc) { step++; nextStep += 256u; }
-                if (SKIP && hw2) {                            // the words at ip + 2 (w2) and ip + 3 (d3) are here; ip2 is ip + 2, or ip + 3 when the step has just grown
-                    u32 const k = ip2 - (ip + 2u);            // 0 or 1
-                    w = w1; w1 = inc ? d3 : w2; w2 = d3; hw2 = !inc;
-                    fI = fN; fN = (faw >> (8u * k)) & 15u; fL = (faw >> (8u * k + 8u)) & 15u;
-                    ip = ip1; ip1 = ip2; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1; tl0 = tl1;
-                } else {
                 ip = ip1; ip1 = ip2; w = w1; w1 = d3; el0 = el1; es0 = es1; hl0 = hl1; hs0 = hs1; tl0 = tl1;
                 if (GATED) { fI = fN; fN = fa & 15u; }
-                }
                 if (ip1 > ilimit) finish();
             }
         } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
@@ -356,7 +313,6 @@ struct ZLaneD {
             put_short_if((fa & 8u) != 0, wa, ins + 1u);
             put_short_if((fb & 0x800u) != 0, wc, ip - 1u + 1u);
             if (GATED) { fI = (fb >> 16) & 15u; fN = (fb >> 24) & 15u; }
-            if (SKIP) { fL = ffa & 15u; w2 = (q0 >> 32) | (q1 << 32); hw2 = true; }      // outer() restarts with step 1
             w = (q0 >> 16) | (q1 << 48); w1 = (q0 >> 24) | (q1 << 40);
             if ((off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
@@ -369,7 +325,6 @@ struct ZLaneD {
             if (!more) fin();
         } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
             w = d0; w1 = d1;
-            if (SKIP) { w2 = d1; w1 = (d0 >> 8) | ((d1 >> 48) << 56); hw2 = true; fL = ffa & 15u; }
             if (GATED) { fI = (fb >> 16) & 15u; fN = (fb >> 24) & 15u; }
             if (chk && (off2 > 0u) && ((u32)w == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
             else outer();
@@ -423,6 +378,7 @@ struct ZLaneF {
     }
 
     ZJ_DEVM u32 phase_of(u32 r) { return r; }
+    ZJ_DEVM u32 default_period() { return ZL_DFAST_PERIOD; }      // (unused: the fast machine rotates on the round number itself)
     ZL_PROF_MEMBERS
     // The search state runs every round; count/backward, post-insert/reload and restart take turns (r mod period = 0, 1, 2;
     // see ZLaneD::round).  With one round per pair the kernel sits at ~80 % of the read+write request plateau

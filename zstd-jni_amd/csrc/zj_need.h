@@ -24,13 +24,14 @@
 #define ZN_NEED_S 2u
 #define ZN_INS_L 4u
 #define ZN_INS_S 8u
-#define ZN_MAX_LOG 15u                   /* bucket bitmaps cover tables of up to 2^15 entries */
+#define ZN_MAX_LOG_L 16u                 /* bucket bitmaps cover a long table of up to 2^16 entries (plain level 3: hashLog 16) ... */
+#define ZN_MAX_LOG_S 15u                 /* ... and a short table of up to 2^15 (chainLog 15) */
 #define ZN_FLAG_SLACK 16u                /* bytes behind a frame's flags that the lane machine may read (never interprets) */
 #define ZN_FLAG_STRIDE (65536u + ZN_FLAG_SLACK)   /* flag bytes per frame slot of the match kernel's launch (frames up to 64 KiB) */
 
 struct ZNLds {
     u64 b1L[4096], b2L[2048], b1S[4096], b2S[2048];     // blocked Bloom filters: 64-bit blocks, 4 bits per key (2.5 % false positives with all 65 536 keys in, under 1 % on average)
-    u32 bnL[1u << (ZN_MAX_LOG - 5u)], bnS[1u << (ZN_MAX_LOG - 5u)];   // buckets some needed probe falls into
+    u32 bnL[1u << (ZN_MAX_LOG_L - 5u)], bnS[1u << (ZN_MAX_LOG_S - 5u)];   // buckets some needed probe falls into
 };
 
 // Filter hashes.  32-bit multiplies run at a quarter of the VALU rate on gfx950 and this kernel is nothing but hashing, so the keys are
@@ -104,7 +105,7 @@ ZJ_DEV void zn_flags_frame(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashL
 // little: many distinct 4-byte values (few long matches) over a very small alphabet, where short repeats keep turning up and the reference's
 // step rule (one more position skipped per 256 unmatched bytes) never gets going: measured on unstructured data, 16 byte values are searched at
 // 0.29 positions per byte, 24 and more at 0.03 (they accelerate and are cheap anyway, like base64 or random bytes); text finds matches and needs
-// nearly every probe.  So: at most 16 byte values and at least 5 in 8 four-byte values distinct in a sample of 1 024 positions from the middle of
+// nearly every probe.  So: at most 16 byte values and at least 1 in 2 four-byte values distinct in a sample of 1 024 positions from the middle of
 // the frame — conservative on purpose: a frame picked in vain costs the flag pass (0.8 us amortised), a frame not picked costs nothing new.
 // `bm` = 136 zeroable LDS words.  The answer is the same in every lane.  A heuristic: it decides speed only, never bytes.
 #define ZN_SAMPLE 1024u
@@ -124,6 +125,6 @@ ZJ_DEV bool zn_worth(const T& t, u32* bm, const u8* src, u32 n) {
     for (u32 i = 0; i < 128u; i++) grams += (u32)__builtin_popcount(bm[i]);
     for (u32 i = 128u; i < 136u; i++) bytes += (u32)__builtin_popcount(bm[i]);
     t.sync();
-    return grams * 64u >= 40u * ZN_SAMPLE && bytes <= 16u;
+    return grams * 64u >= 32u * ZN_SAMPLE && bytes <= 16u;
 }
-ZJ_HD bool zn_takes(u32 hashLog, u32 chainLog, u32 srcSize) { return hashLog <= ZN_MAX_LOG && chainLog <= ZN_MAX_LOG && srcSize >= 64u && srcSize <= 65536u; }
+ZJ_HD bool zn_takes(u32 hashLog, u32 chainLog, u32 srcSize) { return hashLog <= ZN_MAX_LOG_L && chainLog <= ZN_MAX_LOG_S && srcSize >= 64u && srcSize <= 65536u; }
