@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--verify-sample", type=int, default=512, help="GPU frames re-decoded / re-made by the CPU reference")
     ap.add_argument("--e2e-sample", type=int, default=65536, help="buffers in the end-to-end (host-pointer) leg (at most 4 GiB of them), 0 = skip")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
-    ap.add_argument("--skip-plain3", action="store_true", help="skip the extra level-3 pass with the reference's own table sizes (hashLog 16 / chainLog 15)")
+    ap.add_argument("--skip-lds3", action="store_true", help="skip the extra level-3 pass with the LDS-sized tables (hashLog 14 / chainLog 13)")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
     return ap.parse_args()
 
@@ -306,19 +306,20 @@ def main():
     route_kernel = L.zjni_route_kernel(route).decode() if route > 0 else ""
     stamp = L.zjni_build_stamp().decode()
 
-    # ---- the reference's own level-3 parameters (hashLog 16 / chainLog 15), on the record every run: one warm-up + a timed pass, outside `value` ----
-    plain3 = None
-    if mode == "both" and level == 3 and size <= 65536 and not a.skip_plain3:
+    # ---- the LDS-sized level-3 tables (hashLog 14 / chainLog 13: round 2's default, now behind setHashLog / setChainLog), on the record every run:
+    # one warm-up + a timed pass, outside `value`.  The headline itself runs the reference's own sizes (16 / 15).
+    lds3 = None
+    if mode == "both" and level == 3 and size <= 65536 and not a.skip_lds3:
         csz2 = torch.empty(n, dtype=torch.int64, device=dev)
         for it in range(2):
             p0, p1 = ev(), ev()
-            p0.record(); B.compress(src, src_off, comp, comp_off, 3, csz2, hash_log=16, chain_log=15); p1.record()
+            p0.record(); B.compress(src, src_off, comp, comp_off, 3, csz2, hash_log=14, chain_log=13); p1.record()
             torch.cuda.synchronize()
         pms = p0.elapsed_time(p1); pst = B.last_timing(); proute = int(L.zjni_last_route())
-        plain3 = {"hashLog": 16, "chainLog": 15, "compress_ms": pms, "compress_GiBps_per_gpu": n * size / GIB / (pms / 1e3),
-                  "match_kernel": L.zjni_route_kernel(proute).decode(), "match_kernel_ms": pst.get("match", -1.0), "route": proute,
-                  "compressed_bytes": int(csz2.clamp(min=0).sum().item()),
-                  "note": "Zstd.compress(x, 3)'s own table sizes (N/compress/clevels.h:29-31) through zjni_compress_batch_device_advanced; byte identity with the reference's plain call: parity.plain_level3_byte_identical_with_hashLog16_chainLog15"}
+        lds3 = {"hashLog": 14, "chainLog": 13, "compress_ms": pms, "compress_GiBps_per_gpu": n * size / GIB / (pms / 1e3),
+                "match_kernel": L.zjni_route_kernel(proute).decode(), "match_kernel_ms": pst.get("match", -1.0), "route": proute,
+                "compressed_bytes": int(csz2.clamp(min=0).sum().item()),
+                "note": "ZstdCompressCtx.setHashLog(14).setChainLog(13) through zjni_compress_batch_device_advanced: the table sizes the LDS-resident finders of small batches use; byte identity with the reference given the same two parameters: parity.lds_tables_byte_identical_with_hashLog14_chainLog13"}
         B.compress(src, src_off, comp, comp_off, level, csz, dictionary=cdict)          # leave the headline's frames in `comp` for the gates below
         torch.cuda.synchronize()
 
@@ -357,15 +358,15 @@ def main():
                 want = [rc.compress(host_k[i * size:(i + 1) * size]) for i in range(k)]
                 rc.close()
             else:
-                want = [ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) if (level == 3 and size <= 131072) else ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]
+                want = [ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]      # the reference's plain call: nothing but the level set
             gates["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + max(sizes[i], 0)].tobytes() == want[i] for i in range(k))
             if level == 3 and not dict_bytes and size <= 131072:
                 c2 = torch.empty(k * bound, dtype=torch.uint8, device="cuda")
-                s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=16, chain_log=15)
+                s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=14, chain_log=13)
                 torch.cuda.synchronize()
                 z2, b2 = s2.cpu().tolist(), c2.cpu().numpy()
-                gates["plain_level3_byte_identical_with_hashLog16_chainLog15"] = all(
-                    b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_k[i * size:(i + 1) * size], 3) for i in range(k))
+                gates["lds_tables_byte_identical_with_hashLog14_chainLog13"] = all(
+                    b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) for i in range(k))
             neg = int((csz <= 0).sum().item())
             if neg:
                 gates["frames_with_error_result"] = neg
@@ -451,9 +452,9 @@ def main():
                                    + (", frames made by the reference at its plain level (hashLog 16 / chainLog 15), GPU decompress only" if mode == "decode_ref" else ""),
                        "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
                        "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"],
-                       **({"hashLog": 14, "chainLog": 13, "table_sizes": "the library's level-3 default for 8 KiB < input <= 128 KiB (= ZstdCompressCtx.setHashLog(14).setChainLog(13)); the reference's own 16 / 15: see plain_level3"} if (level == 3 and 8192 < size <= 131072 and mode in ("both",)) else {})},
+                       **({"hashLog": 16, "chainLog": 15, "table_sizes": "the reference's own for this level and size (N/compress/clevels.h + ZSTD_adjustCParams): nothing but the level is set; the LDS-sized 14 / 13 behind setHashLog / setChainLog: see lds_tables_level3"} if (level == 3 and 32768 < size <= 131072 and mode in ("both",)) else {})},
             "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel},
-            "plain_level3": plain3,
+            "lds_tables_level3": lds3,
             "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),
             "kernel_ms": {"compress_call": mc, "decompress_call": md, **kernels, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),

@@ -139,7 +139,6 @@ int main(int argc, char** argv) {
         jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL), rd = R.dinit(e, NULL), gd = G.dinit(e, NULL);
         R.setLevel(e, NULL, rc, level); G.setLevel(e, NULL, gc, level);
         R.setChecksum(e, NULL, rc, ck ? JNI_TRUE : JNI_FALSE); G.setChecksum(e, NULL, gc, ck ? JNI_TRUE : JNI_FALSE);
-        if (level == 3) { R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13); }      /* the GPU path's level-3 tables */
         for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
             jsize const n = sizes[si], off = 5, cap = (jsize)R.bound(e, NULL, n) + 40;
             for (int kind = 1; kind <= 2; kind++) {
@@ -199,6 +198,16 @@ int main(int argc, char** argv) {
             fill(src->data, n, cls);
             jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap, src, 0, n), gr = G.cDirect(e, NULL, gc, gdst, 0, cap, src, 0, n);
             CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "plain level 3 (16/15) n=%d cls=%d: ref %lld gpu %lld", n, cls, (long long)rr, (long long)gr);
+        }
+        /* setHashLog(14).setChainLog(13): the LDS-sized tables (wave-per-frame matcher / fused kernel on the GPU) = the reference given the same two */
+        CHECK(G.setHashLog(e, NULL, gc, 14) == 0 && G.setChainLog(e, NULL, gc, 13) == 0, "setCompressionHashLog/ChainLog (14/13) on a shim context");
+        R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13);
+        for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
+            jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
+            Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
+            fill(src->data, n, cls);
+            jlong const rr = R.cDirect(e, NULL, rc, rdst, 0, cap, src, 0, n), gr = G.cDirect(e, NULL, gc, gdst, 0, cap, src, 0, n);
+            CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "level 3 with hashLog 14 / chainLog 13 n=%d cls=%d: ref %lld gpu %lld", n, cls, (long long)rr, (long long)gr);
         }
         R.cfree(e, NULL, rc); G.cfree(e, NULL, gc);
     }
@@ -351,7 +360,6 @@ int main(int argc, char** argv) {
         for (int level = 1; level <= maxLevel && gCS && gReset; level += 2) {
             jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
             R.setLevel(e, NULL, rc, level); G.setLevel(e, NULL, gc, level);
-            if (level == 3) { R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13); }
             for (int pass = 0; pass < 3; pass++) {           /* content size off, on again, then after reset0 */
                 if (pass == 0) { rCS(e, NULL, rc, JNI_FALSE); gCS(e, NULL, gc, JNI_FALSE); }
                 if (pass == 1) { rCS(e, NULL, rc, JNI_TRUE); gCS(e, NULL, gc, JNI_TRUE); R.setChecksum(e, NULL, rc, JNI_TRUE); G.setChecksum(e, NULL, gc, JNI_TRUE); }

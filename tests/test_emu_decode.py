@@ -15,7 +15,7 @@ def emu():
     return emu_lib()
 
 
-@pytest.mark.parametrize("name", ["xml-1.zst", "xml-3.zst", "xml-9.zst", "xml-advanced.zst"])
+@pytest.mark.parametrize("name", ["xml-1.zst", "xml-3.zst", "xml-6.zst", "xml-9.zst", "xml-advanced.zst", "xml-1-sized.zst"])
 def test_emu_golden_xml(emu, name):
     out = emu_decompress(emu, golden(name), 6_000_000)
     assert not isinstance(out, int), out
@@ -26,6 +26,10 @@ def test_emu_multiframe(emu):
     out = emu_decompress(emu, golden("xml-sized-combined.zst"), 6_000_000)
     assert out[:102] == golden("xmlsmall")
     assert hashlib.sha256(out[102:]).hexdigest().startswith(XML_SHA256_PREFIX)
+    # T/scala/Zstd.scala's doubled streams: xml-1x2.zst / xml-1-sizedx2.zst are the frame twice (conftest.golden puts them together)
+    for name in ("xml-1x2.zst", "xml-1-sizedx2.zst"):
+        out = emu_decompress(emu, golden(name), 11_000_000)
+        assert len(out) == 2 * 5_345_280 and out[:5_345_280] == out[5_345_280:] and hashlib.sha256(out[:5_345_280]).hexdigest().startswith(XML_SHA256_PREFIX), name
 
 
 @pytest.mark.parametrize("level", [1, 3])

@@ -29,16 +29,19 @@ def test_native_library_is_the_one_running(gpu):
 
 
 def test_gpu_golden_frames_one_batch(gpu):
-    # T/scala/Zstd.scala:427-638: CLI frames at levels 1/3/9/ultra, multi-block, multi-frame
-    names = ["xml-1.zst", "xml-3.zst", "xml-9.zst", "xml-advanced.zst", "xml-sized-combined.zst", "xmlsmall-sized.zst"]
+    # T/scala/Zstd.scala:427-638: CLI frames at levels 1/3/6/9/ultra, with and without content size, multi-block, multi-frame (every frame
+    # /root/reference/src/test/resources holds: SURVEY.md section 8c)
+    names = ["xml-1.zst", "xml-3.zst", "xml-6.zst", "xml-9.zst", "xml-advanced.zst", "xml-1-sized.zst", "xml-sized-combined.zst", "xmlsmall-sized.zst", "xml-1x2.zst", "xml-1-sizedx2.zst"]
     frames = [golden(n) for n in names]
-    outs = gpu.decompress_batch(frames, [5_345_280] * 4 + [5_345_382, 102])
+    outs = gpu.decompress_batch(frames, [5_345_280] * 6 + [5_345_382, 102] + [2 * 5_345_280] * 2)
     for n, o in zip(names, outs):
         assert not isinstance(o, Exception), (n, o)
-    for o in outs[:4]:
+    for o in outs[:6]:
         assert len(o) == 5_345_280 and hashlib.sha256(o).hexdigest().startswith(XML_SHA256_PREFIX)
-    assert outs[4][:102] == golden("xmlsmall") and hashlib.sha256(outs[4][102:]).hexdigest().startswith(XML_SHA256_PREFIX)
-    assert outs[5] == golden("xmlsmall")
+    assert outs[6][:102] == golden("xmlsmall") and hashlib.sha256(outs[6][102:]).hexdigest().startswith(XML_SHA256_PREFIX)
+    assert outs[7] == golden("xmlsmall")
+    for o in outs[8:]:
+        assert len(o) == 2 * 5_345_280 and o[:5_345_280] == o[5_345_280:] and hashlib.sha256(o[:5_345_280]).hexdigest().startswith(XML_SHA256_PREFIX)
 
 
 @pytest.mark.parametrize("level", [1, 3])

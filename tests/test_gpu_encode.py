@@ -2,8 +2,8 @@
   (ii)  CPU libzstd decodes every GPU-produced frame to the original,
   (iii) sum(csize_gpu) <= 1.01 * sum(csize_cpu) at the same level,
 and the stronger statement this implementation makes: GPU frames are BYTE-IDENTICAL to the
-reference's ZSTD_compress2 (levels 1-2 always; level 3 with the LDS-sized tables = the reference with
-ZstdCompressCtx.setHashLog(14).setChainLog(13), and = default level 3 for inputs <= 8 KiB)."""
+reference's ZSTD_compress2 at levels 1-3 with nothing else set; ZstdCompressCtx.setHashLog(14).setChainLog(13)
+selects the LDS-sized level-3 tables (wave-per-frame matcher, fused kernel) = the reference given the same two parameters."""
 import os
 import random
 
@@ -23,18 +23,22 @@ def gpu(zj):
     return zj
 
 
-def ref_expected(ref, data, level):
-    return ref.compress(data, 3, False, 14, 13) if level == 3 else ref.compress(data, level)
+def ref_expected(ref, data, level, lds=False):
+    return ref.compress(data, 3, False, 14, 13) if (level == 3 and lds) else ref.compress(data, level)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+LDS = dict(hash_log=14, chain_log=13)          # level 3 on the LDS-sized tables: the small-batch finders (fused kernel, wave-per-frame matcher)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, "3lds"])
 def test_gpu_frames_byte_identical_on_edge_inputs(gpu, oracle_ref, level):
+    lds = level == "3lds"; level = 3 if lds else level
     items = [(n, d) for n, d in edge_inputs()]
-    outs = gpu.compress_batch([d for _, d in items], level)
+    outs = gpu.compress_batch([d for _, d in items], level, **(LDS if lds else {}))
     for (name, data), z in zip(items, outs):
         assert not isinstance(z, Exception), (name, z)
         assert oracle_ref.decompress(z, len(data)) == data, name
-        assert z == ref_expected(oracle_ref, data, level), name
+        assert z == ref_expected(oracle_ref, data, level, lds), name
 
 
 def test_gpu_small_inputs_identical_to_default_level3(gpu, oracle_ref):
@@ -54,11 +58,11 @@ def test_gpu_mixed_sizes_use_both_lds_passes(gpu, oracle_ref):
     # level-1 inputs of 8-16 KiB need 2^15-entry tables -> deferred to the large-LDS pass
     rnd = random.Random(9)
     datas = [gpu.synth_host(s, rnd.randrange(0, 1000), 1) for s in (100, 4096, 9000, 12000, 16384, 16385, 40000, 65536, 65537, 100000, 131072)]
-    for level in (1, 2, 3):
-        outs = gpu.compress_batch(datas, level)
+    for level, lds in ((1, False), (2, False), (3, False), (3, True)):
+        outs = gpu.compress_batch(datas, level, **(LDS if lds else {}))
         for d, z in zip(datas, outs):
             assert not isinstance(z, Exception), (level, len(d), z)
-            assert z == ref_expected(oracle_ref, d, level), (level, len(d))
+            assert z == ref_expected(oracle_ref, d, level, lds), (level, lds, len(d))
 
 
 @pytest.mark.parametrize("wide_slice", ["32768", "100"])
@@ -70,11 +74,11 @@ def test_gpu_wide_frames_through_the_lane_pipeline(gpu, oracle_ref, monkeypatch,
     rnd = random.Random(31)
     sizes = [131072, 100000, 65537, 70000, 12000, 16384, 9000, 4096, 65536, 50, 0] * 28
     datas = [gpu.synth_host(s, rnd.randrange(0, 100000), 1) if s else b"" for s in sizes]
-    for level in (1, 2, 3):
-        outs = gpu.compress_batch(datas, level)
+    for level, lds in ((1, False), (2, False), (3, False), (3, True)):
+        outs = gpu.compress_batch(datas, level, **(LDS if lds else {}))
         for k, (d, z) in enumerate(zip(datas, outs)):
             assert not isinstance(z, Exception), (level, k, len(d), z)
-            assert z == ref_expected(oracle_ref, d, level), (level, k, len(d))
+            assert z == ref_expected(oracle_ref, d, level, lds), (level, lds, k, len(d))
         assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
 
 
@@ -170,12 +174,13 @@ def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch, mode, machine)
     datas += [bytes([7]) * 40000, bytes(rnd.getrandbits(8) for _ in range(20000)), (b"abcdefgh" * 5000)[:33333], golden("xmlsmall")[:60000]]
     outs = gpu.compress_batch(datas, 3)
     for d, z in zip(datas, outs):
-        assert z == (oracle_ref.compress(d, 3) if len(d) <= 8192 else oracle_ref.compress(d, 3, False, 14, 13)), len(d)
+        assert z == oracle_ref.compress(d, 3), len(d)
     route = gpu.lib().zjni_last_route()
     assert route == {("run", "0"): 5, ("run", "1"): 6, ("run", "2"): 6, ("lane", "0"): 3, ("lane", "1"): 4, ("lane", "2"): 4}[(machine, mode)], route
-    outs = gpu.compress_batch(datas, 3, hash_log=15, chain_log=15)
-    for d, z in zip(datas, outs):
-        assert z == oracle_ref.compress(d, 3, False, 15, 15), len(d)
+    for hl, cl in ((15, 15), (14, 13)):
+        outs = gpu.compress_batch(datas, 3, hash_log=hl, chain_log=cl)
+        for d, z in zip(datas, outs):
+            assert z == oracle_ref.compress(d, 3, False, hl, cl), (len(d), hl, cl)
 
 
 @pytest.mark.parametrize("n_min", [1, 5000])
@@ -201,7 +206,7 @@ def test_gpu_tight_destinations(gpu, oracle_ref, monkeypatch, n_min):
             datas, caps, wants = [], [], []
             for data in inputs:
                 if level >= 5 and len(data) > 16384: continue
-                hl, cl = (14, 13) if (level == 3 and 8192 < len(data) <= 131072) else (0, 0)
+                hl, cl = 0, 0
                 full = oracle_ref.compress(data, level, ck, hl, cl)
                 cs = list(range(max(0, len(full) - 2), len(full) + 24)) + [0, 8, 17, 18, len(data), len(data) + 3, len(data) + 9, len(data) + 12, len(data) + 20]
                 for cap in (cs if len(data) < 20000 else cs[::4]):
@@ -259,7 +264,7 @@ def test_gpu_checksum_flag(gpu, oracle_ref, monkeypatch, split_min):
         outs = gpu.compress_batch(items, level, checksum=True)
         for d, z in zip(items, outs):
             assert not isinstance(z, Exception), (len(d), z)
-            want = oracle_ref.compress(d, 3, True, 14, 13) if level == 3 else oracle_ref.compress(d, level, True)
+            want = oracle_ref.compress(d, level, True)
             assert z == want, (len(d), level)
         back = gpu.decompress_batch(outs, [len(d) for d in items])
         assert back == items
@@ -269,7 +274,7 @@ def test_gpu_checksum_flag(gpu, oracle_ref, monkeypatch, split_min):
     with gpu.ZstdCompressCtx() as ctx:
         z = ctx.setLevel(1).setChecksum(True).compress(items[-1])
         assert z == oracle_ref.compress(items[-1], 1, True)
-    assert gpu.Zstd.compress(items[-2], 3, True) == oracle_ref.compress(items[-2], 3, True, 14, 13)
+    assert gpu.Zstd.compress(items[-2], 3, True) == oracle_ref.compress(items[-2], 3, True)
 
 
 def test_gpu_batch_larger_than_one_scratch_slice(gpu, oracle_ref):
@@ -288,7 +293,7 @@ def test_gpu_batch_larger_than_one_scratch_slice(gpu, oracle_ref):
     assert bool((csz > 0).all()) and bool((dsz == size).all()) and torch.equal(back, src)
     for i in (0, 65535, 65536, 70000):
         f = packed[int(poff[i]):int(poff[i + 1])].cpu().numpy().tobytes()
-        assert f == oracle_ref.compress(src[i * size:(i + 1) * size].cpu().numpy().tobytes(), 3, False, 14, 13), i
+        assert f == oracle_ref.compress(src[i * size:(i + 1) * size].cpu().numpy().tobytes(), 3), i
 
 
 def test_gpu_concurrent_callers(gpu, oracle_ref):
@@ -358,4 +363,4 @@ def test_gpu_wave_matcher(gpu, oracle_ref, monkeypatch, mode):
         outs = gpu.compress_batch(datas, 3, checksum=checksum) if checksum else gpu.compress_batch(datas, 3)
         for k, (d, z) in enumerate(zip(datas, outs)):
             assert not isinstance(z, Exception), (k, len(d), z)
-            assert z == oracle_ref.compress(d, 3, checksum, 14, 13), (k, len(d), checksum)
+            assert z == oracle_ref.compress(d, 3, checksum), (k, len(d), checksum)

@@ -66,7 +66,7 @@ def test_two_devices_do_not_share_state(gpu, oracle_ref):
     frames, back = _multi(gpu, bufs, 3, [0, 1], 0)
     f1, b1 = _multi(gpu, bufs, 3, [1, 0], 1)
     for i, b in enumerate(bufs):
-        assert frames[i] == f1[i] == oracle_ref.compress(b, 3, False, 14, 13) and back[i] == b1[i] == b, i
+        assert frames[i] == f1[i] == oracle_ref.compress(b, 3) and back[i] == b1[i] == b, i
 
 
 def test_scratch_limit_bounds_the_library(gpu, oracle_ref):

@@ -50,7 +50,7 @@ def test_gpu_multiblock_frames_are_the_references(gpu, oracle_ref, level):
             if len(d) > WINDOW[level]:
                 assert isinstance(z, Exception) and z.getErrorCode() == 201, len(d)
                 continue
-            want = oracle_ref.compress(d, level, checksum) if len(d) > 131072 or level < 3 else oracle_ref.compress(d, 3, checksum, 14, 13)
+            want = oracle_ref.compress(d, level, checksum)
             assert not isinstance(z, Exception), (len(d), z)
             assert z == want, (len(d), level, checksum)
             good.append((d, z))
@@ -77,7 +77,7 @@ def test_gpu_multiblock_repeated_calls_leave_no_state_behind(gpu, oracle_ref):
     tools/stress_gpu_multiblock.py is the long version)."""
     for level in (1, 3):
         datas = inputs(gpu, oracle_ref, 100 + level, 60)
-        want = [None if len(d) > WINDOW[level] else (oracle_ref.compress(d, level) if len(d) > 131072 or level < 3 else oracle_ref.compress(d, 3, False, 14, 13)) for d in datas]
+        want = [None if len(d) > WINDOW[level] else oracle_ref.compress(d, level) for d in datas]
         for rep in range(6):
             outs = gpu.compress_batch(datas, level)
             for i, (z, w) in enumerate(zip(outs, want)):

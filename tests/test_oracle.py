@@ -7,7 +7,7 @@ import pytest
 from conftest import golden, XML_SHA256_PREFIX
 from util import edge_inputs
 
-GOLDEN_XML = ["xml-1.zst", "xml-3.zst", "xml-9.zst", "xml-advanced.zst"]
+GOLDEN_XML = ["xml-1.zst", "xml-3.zst", "xml-6.zst", "xml-9.zst", "xml-advanced.zst", "xml-1-sized.zst"]
 
 
 @pytest.mark.parametrize("name", GOLDEN_XML)
@@ -23,6 +23,18 @@ def test_port_decodes_concatenated_frames(oracle_port):
     out = oracle_port.decompress(golden("xml-sized-combined.zst"), 6_000_000)
     assert out[:102] == golden("xmlsmall")
     assert hashlib.sha256(out[102:]).hexdigest().startswith(XML_SHA256_PREFIX)
+
+
+def test_port_decodes_doubled_frames(oracle_port):
+    # xml-1x2.zst / xml-1-sizedx2.zst of the reference's resources are xml-1.zst / xml-1-sized.zst twice (checked against the reference tree where it exists)
+    import os
+    for name in ("xml-1x2.zst", "xml-1-sizedx2.zst"):
+        z = golden(name)
+        refp = os.path.join("/root/reference/src/test/resources", name)
+        if os.path.exists(refp):
+            assert open(refp, "rb").read() == z, name
+        out = oracle_port.decompress(z, 11_000_000)
+        assert len(out) == 2 * 5_345_280 and out[:5_345_280] == out[5_345_280:], name
 
 
 def test_port_small_golden(oracle_port):

@@ -20,7 +20,7 @@ for level in (1, 3):
     bad = []
     for i in range(n):
         d = raw[i * size:(i + 1) * size]
-        exp = ref.compress(d, 3, False, 14, 13) if level == 3 else ref.compress(d, level)
+        exp = ref.compress(d, level)
         got = hc[i * bound:i * bound + max(int(hs[i]), 0)].tobytes()
         if got != exp: bad.append((i, int(hs[i]), len(exp)))
     print(f"L{level}: {len(bad)} bad of {n}; first: {bad[:12]}", flush=True)

@@ -39,7 +39,7 @@ for level in (1, 2, 3):
     datas = [gen(s) for s in sizes(131072)]
     outs = zj.compress_batch(datas, level)
     for k, (d, z) in enumerate(zip(datas, outs)):
-        want = ref.compress(d, 3, False, 14, 13) if level == 3 else ref.compress(d, level)
+        want = ref.compress(d, level)
         if isinstance(z, Exception) or z != want:
             bad += 1; print("MISMATCH plain", level, k, len(d), z if isinstance(z, Exception) else len(z), flush=True)
     back = zj.decompress_batch([z for z in outs if not isinstance(z, Exception)], [len(d) for d, z in zip(datas, outs) if not isinstance(z, Exception)])
@@ -58,7 +58,7 @@ WINDOW = {1: 1 << 19, 2: 1 << 20, 3: 1 << 21}
 for level in (1, 2, 3):
     m = max(40, n // 40)
     datas = [gen(rnd.choice([rnd.randrange(131073, 400000), rnd.randrange(131073, 2097153), 262144, 524288, rnd.randrange(0, 131073), 65536])) for _ in range(m)]
-    want = [None if len(d) > WINDOW[level] else (ref.compress(d, 3, False, 14, 13) if (level == 3 and len(d) <= 131072) else ref.compress(d, level)) for d in datas]
+    want = [None if len(d) > WINDOW[level] else ref.compress(d, level) for d in datas]
     for rep in range(3):
         outs = zj.compress_batch(datas, level)
         for k, (d, z, w) in enumerate(zip(datas, outs, want)):
@@ -103,7 +103,7 @@ for mode in ("0", "1", "2", "3", "4"):
     datas = [gen(s) for s in sizes(65536)] + [bytes(rnd.randrange(16) for _ in range(rnd.randrange(4096, 65537))) for _ in range(max(8, n // 10))]
     outs = zj.compress_batch(datas, 3)
     for k, (d, z) in enumerate(zip(datas, outs)):
-        want = ref.compress(d, 3) if len(d) <= 8192 else ref.compress(d, 3, False, 14, 13)
+        want = ref.compress(d, 3)
         if isinstance(z, Exception) or z != want:
             bad += 1; print("MISMATCH need mode", mode, k, len(d), flush=True)
     print(f"ZJNI_NEED={mode}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
@@ -113,7 +113,7 @@ for level in (1, 3, 5):
     datas, caps, wants = [], [], []
     for s in sizes(16384 if level >= 5 else 131072)[:max(50, n // 4)]:
         d = gen(s) if rnd.random() < 0.7 else bytes(rnd.randrange(rnd.choice([3, 12, 48])) for _ in range(rnd.randrange(20, 400)))
-        hl, cl = (14, 13) if (level == 3 and 8192 < len(d) <= 131072) else (0, 0)
+        hl, cl = 0, 0
         fs = len(ref.compress(d, level, False, hl, cl))
         for cap in (fs + rnd.randrange(-2, 30), len(d) + rnd.randrange(0, 24), rnd.choice([0, 8, 17, 18, fs, fs + 8, fs + 9])):
             cap = max(cap, 0)

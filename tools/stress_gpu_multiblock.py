@@ -10,7 +10,7 @@ datas = {lvl: T.inputs(zj, ref, 100 + lvl, 60) for lvl in (1, 2, 3)}
 want = {}
 for lvl in (1, 2, 3):
     for ck in (False, True):
-        want[lvl, ck] = [None if len(d) > T.WINDOW[lvl] else (ref.compress(d, lvl, ck) if len(d) > 131072 or lvl < 3 else ref.compress(d, 3, ck, 14, 13)) for d in datas[lvl]]
+        want[lvl, ck] = [None if len(d) > T.WINDOW[lvl] else ref.compress(d, lvl, ck) for d in datas[lvl]]
 l4 = L4._inputs(zj, 5, int(os.environ.get("L4N", "4500")))
 bad = 0
 for it in range(int(sys.argv[1])):

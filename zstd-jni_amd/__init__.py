@@ -28,18 +28,14 @@ _lib = None
 
 
 def build_stamp():
-    """Revision the library is built from: `git describe --always --dirty` plus a hash of csrc/ (the GPU box has no .git, and a
-    dirty tree says nothing about WHICH edits): profiles/ and roofline.traffic are stamped with it (zjni_build_stamp)."""
+    """What the library is built from: a hash of csrc/ and the header (the GPU box has no .git, and a revision says nothing about
+    uncommitted edits): profiles/ and roofline.traffic are stamped with it (zjni_build_stamp)."""
     import hashlib
     h = hashlib.sha1()
     for f in sorted(SOURCES + [os.path.join(ROOT, "include", "zjni_amd.h")]):
         with open(f, "rb") as fh:
             h.update(fh.read())
-    try:
-        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-    except Exception:
-        rev = "nogit"
-    return "%s+src%s" % (rev, h.hexdigest()[:10])
+    return "src" + h.hexdigest()[:12]
 
 
 def build(force=False, verbose=False):

@@ -202,11 +202,11 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
         return;
     }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
-        if (listC && size <= ZE_MULTI_MAX && !(ZE_LW_HL(level) | ZE_LW_CL(level))) listC[atomicAdd(&counters[4], 1u)] = i;
+        if (listC && size <= ZE_MULTI_MAX && (!(ZE_LW_HL(level) | ZE_LW_CL(level)) || (level & ZE_LW_IMPLICIT))) listC[atomicAdd(&counters[4], 1u)] = i;
         else result[i] = ZJ_ERR64(201);
         return;
     }
-    bool const a = (ZE_LW_HL(level) | ZE_LW_CL(level)) ? (size <= 65536u)            // explicit table sizes: lane pipeline only, split by record width
+    bool const a = ZE_LW_TUNED(level) ? (size <= 65536u)                            // table sizes beyond the LDS: lane pipeline only, split by record width
                                                          : (ze_lds_need(ZE_LW_LEVEL(level), (u32)size) <= ldsA);
     if (a) listA[atomicAdd(&counters[0], 1u)] = i;
     else listB[atomicAdd(&counters[1], 1u)] = i;
@@ -1276,7 +1276,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     DevState* d = cur_state();
     if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
     int const level = (int)ZE_LW_LEVEL((u32)levelWord);       // kernels take the level word (level | hashLog << 8 | chainLog << 16)
-    bool const tuned = (ZE_LW_HL((u32)levelWord) | ZE_LW_CL((u32)levelWord)) != 0;
+    bool const tuned = ZE_LW_TUNED((u32)levelWord);
     if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     if (n == 0) return 0;
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
@@ -1566,8 +1566,20 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                        (u8*)nullptr, maxSrc, (const u32*)nullptr, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ZJ_ENC_LDS_BIG), 0u, 0xFFFFFFFFu);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
+// Level 3 with nothing set runs the reference's own tables (hashLog 16 / chainLog 15, N/compress/clevels.h:29-31 after ZSTD_adjustCParams): every frame is
+// Zstd.compress(x, 3)'s, byte for byte, whatever the batch size — measured at the full batch the 4x larger tables cost nothing (153.6 vs 153.7 ms, the
+// kernel is bound by request count, not footprint).  ZstdCompressCtx.setHashLog(14).setChainLog(13) selects the LDS-sized tables: the wave-per-frame
+// matcher and the fused kernel of small batches (lower latency per call, 0.2 % smaller frames on the bench set, not the reference's default bytes).
+// ZJNI_L3_TABLES=lds restores that as the default (A/B runs against round 2).
+static int zj_level3_word(int lw) {
+    u32 const w = (u32)lw;
+    if (ZE_LW_LEVEL(w) != 3u || (ZE_LW_HL(w) | ZE_LW_CL(w))) return lw;
+    static int const lds = (getenv("ZJNI_L3_TABLES") && !strcmp(getenv("ZJNI_L3_TABLES"), "lds")) ? 1 : 0;
+    return lds ? lw : (int)(ZE_LW(3u, 16u, 15u) | ZE_LW_IMPLICIT | (w & ~0xFFFFFFu));
+}
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                uint64_t* d_result, size_t n, int level, u32 flags, void* stream) {
+    level = zj_level3_word(level);
     BatchOrder order(cur_state(), stream);
     size_t const perFrame = ZE_LW_LEVEL((u32)level) > 3u ? (size_t)ZE_CHAIN_TABLE_BYTES + ZE_FRAME_STRIDE(ZE_CHAIN_MAX_SRC) + 21
                                                           : (size_t)ze_lane_table_stride((u32)level, false) + ZE_FRAME_STRIDE(65536u) + 21;
