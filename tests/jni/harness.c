@@ -34,6 +34,7 @@ static jmethodID JNICALL f_GetMethodID(JNIEnv* e, jclass c, const char* n, const
 static jobject JNICALL f_NewObject(JNIEnv* e, jclass c, jmethodID m, ...) { (void)e; (void)c; (void)m; return (jobject)mk(7, 0); }
 static jbyte* JNICALL f_GetByteArrayElements(JNIEnv* e, jbyteArray a, jboolean* c) { (void)e; if (c) *c = JNI_FALSE; return (jbyte*)((Obj*)a)->data; }
 static void JNICALL f_ReleaseByteArrayElements(JNIEnv* e, jbyteArray a, jbyte* p, jint m) { (void)e; (void)a; (void)p; (void)m; }
+static jboolean JNICALL f_ExceptionCheck(JNIEnv* e) { (void)e; return JNI_FALSE; }
 static int g_deleted;
 static void JNICALL f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; g_deleted++; }
 static struct JNINativeInterface_ g_fn;
@@ -46,6 +47,7 @@ static JNIEnv* env(void) {
     g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
     g_fn.GetByteArrayElements = f_GetByteArrayElements; g_fn.ReleaseByteArrayElements = f_ReleaseByteArrayElements;
     g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef;
+    g_fn.ExceptionCheck = f_ExceptionCheck;
     g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField;
     return (JNIEnv*)&g_envp;
 }
@@ -519,6 +521,19 @@ int main(int argc, char** argv) {
         {   Obj* heap = mk(2, 100); Obj* keep = srcs->elems[0]; srcs->elems[0] = heap;      /* a heap buffer: GetDirectBufferAddress NULL, capacity -1 */
             CHECK(G.cBatch(e, NULL, (jobjectArray)srcs, (jobjectArray)dsts, (jlongArray)res, 1, JNI_FALSE) == -72, "batch with a non-direct source element");
             srcs->elems[0] = keep; }
+    }
+    /* who served the hot-path natives (zjni_shim_stats): with nothing to forward to (the GPU test) every call must have been answered by the GPU
+     * path; without a GPU (the CPU test) none may have been */
+    {   typedef void (*stats_fn)(unsigned long long*);
+        stats_fn st = (stats_fn)dlsym(G.h, "zjni_shim_stats");
+        unsigned long long v[4] = {0, 0, 0, 0};
+        CHECK(st != NULL, "zjni_shim_stats exported");
+        if (st) {
+            st(v);
+            printf("JNI-HARNESS STATS served_by_gpu=%llu forwarded_by_policy=%llu forwarded_after_gpu_declined=%llu of_those_no_device=%llu\n", v[0], v[1], v[2], v[3]);
+            if (getenv("HARNESS_EXPECT") && !strcmp(getenv("HARNESS_EXPECT"), "gpu")) CHECK(v[0] > 0 && v[1] == 0 && v[2] == 0, "GPU run: %llu served, %llu + %llu forwarded", v[0], v[1], v[2]);
+            if (getenv("HARNESS_EXPECT") && !strcmp(getenv("HARNESS_EXPECT"), "cpu")) CHECK(v[0] == 0 && v[1] > 0, "CPU-only run: %llu served by the GPU, %llu forwarded by policy", v[0], v[1]);
+        }
     }
     if (g_bad) { printf("JNI-HARNESS FAILED bad=%d checks=%d\n", g_bad, g_checks); return 1; }
     printf("JNI-HARNESS OK checks=%d\n", g_checks);

@@ -60,7 +60,7 @@ def test_shim_forwards_to_the_bundled_library_without_a_gpu():
         pytest.skip("GPU present: covered by the gpu test")
     if not _built():
         pytest.skip("no <jni.h> in this environment and no prebuilt shim")
-    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2", HARNESS_DICT_FILE=_dict_file())
+    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2", HARNESS_DICT_FILE=_dict_file(), HARNESS_EXPECT="cpu")
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
@@ -68,7 +68,7 @@ def test_shim_forwards_to_the_bundled_library_without_a_gpu():
 @pytest.mark.gpu
 def test_shim_equals_reference_jni_on_the_gpu():
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"
-    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_PLAIN_MAX_LEVEL="8")   # levels 4-8 (<= 128 KiB) through the one-shot natives as well
+    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu")      # zjni_shim_stats: served > 0, forwarded == 0   # levels 4-8 (<= 128 KiB) through the one-shot natives as well
     env.pop("ZSTD_JNI_CPU_LIB", None)                  # nothing to forward to: every result must come from the GPU library
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]

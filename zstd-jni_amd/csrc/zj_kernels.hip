@@ -8,6 +8,8 @@
 #include <mutex>
 #include <algorithm>
 #include <thread>
+#include <sched.h>
+#include <atomic>
 #include <condition_variable>
 #include <chrono>
 #include <map>
@@ -775,6 +777,8 @@ struct DevState {
     // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
     u8* wideBuf = nullptr; size_t wideBufCap = 0;     // lane-per-frame path of list B: [tables][frame scratch][meta] for one slice
     std::vector<hipEvent_t> stageEv;                  // host-pointer entries: one event per returned slice
+    hipStream_t hostIn = nullptr, hostK = nullptr, hostOut = nullptr;       // host-pointer decompress: H2D / kernels / D2H of different slices at the same time (PCIe is full duplex)
+    std::vector<hipEvent_t> pipeEv;                   // three events per slice: source landed, decoded, returned
     u32* multiTables = nullptr; int multiGrid = 0;    // multi-block frames: frame-wide hash tables, one set per resident workgroup
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
@@ -924,17 +928,30 @@ bool ensure_staging(DevState* d, size_t bytes) {
     return true;
 }
 // Host-side copies of the host-pointer entries (caller's buffers <-> pinned staging) run on a few threads: one memcpy stream moves
-// ~10 GB/s, the PCIe link 50.  ZJNI_HOST_THREADS overrides the count (default 8; 1 = the calling thread only).
+// ~10 GB/s, the PCIe link 57 each way — every byte of a batch is copied once by the host on each side, so these copies, not the link,
+// bound the entries unless enough threads share them.  Default: the CPUs this process may really use (scheduler affinity and the cgroup
+// quota, not the processors the box shows), at most 16; ZJNI_HOST_THREADS overrides (1 = the calling thread only).
 #define ZJ_HOST_SLICE ((u64)256 << 20)
 static int host_threads() {
-    static int const t = []() { int v = 8; if (const char* ov = getenv("ZJNI_HOST_THREADS")) v = atoi(ov); return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    static int const t = []() {
+        if (const char* ov = getenv("ZJNI_HOST_THREADS")) { int const v = atoi(ov); return v < 1 ? 1 : (v > 64 ? 64 : v); }
+        long v = 16;
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { long const a = CPU_COUNT(&set); if (a >= 1 && a < v) v = a; }
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[32]; long per = 0;
+            if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { long const c = (atol(q) + per - 1) / per; if (c >= 1 && c < v) v = c; }
+            fclose(f);
+        }
+        return (int)(v < 2 ? 2 : v);
+    }();
     return t;
 }
-// fn(lo, hi) over index ranges of about equal bytes; off[0..n] = byte offsets of the items
+// fn(lo, hi) over index ranges of about equal bytes; off[0..n] = byte offsets of the items; `threads` = 0: host_threads()
 template <class F>
-static void par_ranges(const u64* off, size_t n, F fn) {
+static void par_ranges(const u64* off, size_t n, F fn, int threads = 0) {
     u64 const total = off[n] - off[0];
-    int T = total < ((u64)8 << 20) ? 1 : host_threads();
+    int T = total < ((u64)8 << 20) ? 1 : (threads > 0 ? threads : host_threads());
     if ((size_t)T > n) T = (int)(n ? n : 1);
     if (T <= 1) { fn((size_t)0, n); return; }
     std::vector<size_t> cut((size_t)T + 1, n); cut[0] = 0;
@@ -977,6 +994,9 @@ void zjni_shutdown(void) {
         if (d.cdList) (void)hipFree(d.cdList);
         for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
         if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
+        if (d.hostIn) { (void)hipStreamDestroy(d.hostIn); (void)hipStreamDestroy(d.hostK); (void)hipStreamDestroy(d.hostOut); d.hostIn = d.hostK = d.hostOut = nullptr; }
+        for (hipEvent_t e : d.pipeEv) if (e) (void)hipEventDestroy(e);
+        d.pipeEv.clear();
         if (d.waveStream) { (void)hipStreamDestroy(d.waveStream); (void)hipEventDestroy(d.evJoinWave); }
         if (d.hPinned) (void)hipHostFree(d.hPinned);
         if (d.dStage) (void)hipFree(d.dStage);
@@ -1738,6 +1758,136 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
+// The first frame of a buffer, read on the host: its compressed size (0 = not a complete plain frame) and its content size (~0 = not in the header).
+// Only used to bound the destination staging of the host-pointer decompress entry: a buffer that IS one frame with a known content size needs that
+// many bytes, not the caller's whole capacity (a 4 KiB frame decoded into a 64 MiB buffer would otherwise pin and move 64 MiB).  Format: zstd
+// compression format 1.5.7, frame header (N/decompress/zstd_decompress.c:447-557) and block headers (ZSTD_getcBlockSize, :1-3 bytes).
+static size_t host_frame_extent(const u8* p, size_t n, u64* content) {
+    *content = ~(u64)0;
+    if (n < 9 || ld32(p) != 0xFD2FB528u) return 0;
+    u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6, cks = (fhd >> 2) & 1;
+    if (fhd & 8) return 0;
+    u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
+    size_t pos = 5 + !single + didSz;
+    if (n < pos + fcsSz + 3) return 0;
+    if (fcsid == 0) { if (single) *content = p[pos]; } else if (fcsid == 1) *content = (u64)ld16(p + pos) + 256; else if (fcsid == 2) *content = ld32(p + pos); else *content = ld64(p + pos);
+    pos += fcsSz;
+    for (;;) {
+        if (pos + 3 > n) return 0;
+        u32 const bh = (u32)p[pos] | ((u32)p[pos + 1] << 8) | ((u32)p[pos + 2] << 16), type = (bh >> 1) & 3, bs = bh >> 3;
+        if (type == 3) return 0;
+        pos += 3 + (type == 1 ? 1 : bs);
+        if (pos > n) return 0;
+        if (bh & 1) break;
+    }
+    pos += cks ? 4 : 0;
+    return pos <= n ? pos : 0;
+}
+
+// Host-pointer decompress as a three-stage pipeline over slices of the batch: while slice k's frames are decoded, slice k + 1's sources cross the
+// link one way and slice k - 1's output the other (PCIe: 57 GB/s each way alone, 2 x 49 at once on this box: tools/micro/pcie.py), and the host
+// threads gather / scatter the slices on either side.  The first slice is small (its transfer and kernels are the pipeline's lead-in), the others
+// large enough for the lane-per-frame sequence decode, whose time is its longest frame's chain whatever the slice size.
+static size_t host_decompress_locked(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                     const zjni_ddict* ddict, bool exactCaps);
+static size_t host_decompress(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                              const zjni_ddict* ddict) {
+    std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
+    size_t const r = host_decompress_locked(d, src, srcSize, dst, dstCap, result, n, ddict, false);
+    if (zjni_isError(r)) return r;
+    // A frame that was given its header's content size as capacity and overran it is damaged; the reference, decoding into the caller's larger
+    // buffer, goes on to the frame's end and answers from there (usually corruption_detected, not dstSize_tooSmall): those few again, with the caller's capacity
+    std::vector<size_t> again;
+    for (size_t i = 0; i < n; i++) if (result[i] == ZJNI_ERR(70)) { u64 c; if (srcSize[i] && host_frame_extent((const u8*)src[i], srcSize[i], &c) == srcSize[i] && c != ~(u64)0 && c < dstCap[i]) again.push_back(i); }
+    if (again.empty()) return 0;
+    size_t const m = again.size();
+    std::vector<const void*> s2(m); std::vector<size_t> z2(m), c2(m), r2(m); std::vector<void*> d2(m);
+    for (size_t j = 0; j < m; j++) { size_t const i = again[j]; s2[j] = src[i]; z2[j] = srcSize[i]; d2[j] = dst[i]; c2[j] = dstCap[i]; }
+    size_t const rr = host_decompress_locked(d, s2.data(), z2.data(), d2.data(), c2.data(), r2.data(), m, ddict, true);
+    if (zjni_isError(rr)) return rr;
+    for (size_t j = 0; j < m; j++) result[again[j]] = r2[j];
+    return 0;
+}
+static size_t host_decompress_locked(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+                                     const zjni_ddict* ddict, bool exactCaps) {
+    size_t const offBytes = (n + 1) * 8;
+    if (!d->hostIn) {
+        if (hipStreamCreateWithFlags(&d->hostIn, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->hostK, hipStreamNonBlocking) != hipSuccess
+            || hipStreamCreateWithFlags(&d->hostOut, hipStreamNonBlocking) != hipSuccess) { d->hostIn = d->hostK = d->hostOut = nullptr; return ZJNI_ERR(ZJNI_ERROR_no_device); }
+    }
+    // what each buffer needs on the device: the frame's own content size when the buffer is exactly one frame that says it, else the caller's capacity
+    std::vector<u64> need(n + 1, 0), srcAt(n + 1, 0);
+    {   std::vector<u64> idx(n + 1); for (size_t i = 0; i <= n; i++) idx[i] = i;
+        par_ranges(idx.data(), n, [&](size_t a0, size_t a1) {
+            for (size_t i = a0; i < a1; i++) {
+                u64 c; size_t const ext = srcSize[i] ? host_frame_extent((const u8*)src[i], srcSize[i], &c) : 0;
+                need[i] = (!exactCaps && ext == srcSize[i] && c != ~(u64)0 && c <= dstCap[i]) ? c : dstCap[i];
+            }
+        }); }
+    u64 srcTotal = 0, dstTotal = 0;
+    for (size_t i = 0; i < n; i++) { u64 const c = need[i]; need[i] = dstTotal; srcAt[i] = srcTotal; dstTotal += c; srcTotal += srcSize[i]; }
+    need[n] = dstTotal; srcAt[n] = srcTotal;                       // (need[] now holds destination offsets)
+    // staging layout: [srcOff][dstOff][result][src blob][dst blob]
+    size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + (size_t)srcTotal + 15) & ~(size_t)15;
+    size_t const total = oDst + (size_t)dstTotal + 16;
+    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);      // no room to stage this batch: the caller's CPU path takes it
+    u64* const hs = (u64*)(d->hPinned + oSrcOff); u64* const hd = (u64*)(d->hPinned + oDstOff); const u64* const hr = (const u64*)(d->hPinned + oRes);
+    memcpy(hs, srcAt.data(), offBytes); memcpy(hd, need.data(), offBytes);
+    u8* const hSrc = d->hPinned + oSrc; u8* const hDst = d->hPinned + oDst;
+    // slices by destination bytes: a small first one, then up to eight of at least ZJ_HOST_SLICE
+    std::vector<size_t> cuts; cuts.push_back(0);
+    {   u64 const big = dstTotal / 8 > ZJ_HOST_SLICE ? dstTotal / 8 : ZJ_HOST_SLICE; u64 target = big / 4;
+        for (size_t lo = 0; lo < n;) { size_t hi = lo + 1; while (hi < n && hd[hi] - hd[lo] < target) hi++; cuts.push_back(hi); lo = hi; target = big; } }
+    size_t const nSlices = cuts.size() - 1;
+    if (d->pipeEv.size() < 3 * nSlices) {
+        size_t const have = d->pipeEv.size(); d->pipeEv.resize(3 * nSlices, nullptr);
+        for (size_t k = have; k < 3 * nSlices; k++) if (hipEventCreateWithFlags(&d->pipeEv[k], hipEventDisableTiming) != hipSuccess) { d->pipeEv.resize(k); return ZJNI_ERR(ZJNI_ERROR_no_device); }
+    }
+    auto drain = [&](size_t code) { (void)hipStreamSynchronize(d->hostIn); (void)hipStreamSynchronize(d->hostK); (void)hipStreamSynchronize(d->hostOut); return code; };   // nothing of ours in flight when the staging lock drops
+    int const T = host_threads();
+    std::atomic<bool> gathering(true);               // while the sources are still being gathered the two sides share the host's threads
+    auto scatter = [&](size_t lo, size_t hi) {
+        par_ranges(hd + lo, hi - lo, [&](size_t a0, size_t a1) {
+            for (size_t i = lo + a0; i < lo + a1; i++) {
+                result[i] = (size_t)hr[i];
+                if (!zjni_isError(result[i]) && result[i]) memcpy(dst[i], hDst + hd[i], result[i]);
+            }
+        }, gathering.load() ? (T + 1) / 2 : T);
+    };
+    // the returning side runs on a thread of its own: slice k is handed to the caller as soon as it is back, whatever the enqueueing side is doing
+    std::atomic<size_t> enqueued(0); std::atomic<bool> failed(false);
+    std::thread returner([&]() {
+        (void)hipSetDevice(d->ordinal);
+        for (size_t k = 0; k < nSlices; k++) {
+            while (enqueued.load(std::memory_order_acquire) <= k) { if (failed.load()) return; std::this_thread::yield(); }
+            if (hipEventSynchronize(d->pipeEv[3 * k + 2]) != hipSuccess) { failed.store(true); return; }
+            scatter(cuts[k], cuts[k + 1]);
+        }
+    });
+    struct Joiner { std::thread& t; std::atomic<bool>& f; bool ok = false; ~Joiner() { if (!ok) f.store(true); if (t.joinable()) t.join(); } } joiner{returner, failed};
+    if (hipMemcpyAsync(d->dStage, d->hPinned, 2 * offBytes, hipMemcpyHostToDevice, d->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+    for (size_t k = 0; k < nSlices; k++) {
+        size_t const lo = cuts[k], hi = cuts[k + 1];
+        hipEvent_t const evIn = d->pipeEv[3 * k], evK = d->pipeEv[3 * k + 1], evOut = d->pipeEv[3 * k + 2];
+        par_ranges(hs + lo, hi - lo, [&](size_t a0, size_t a1) { for (size_t i = lo + a0; i < lo + a1; i++) if (srcSize[i]) memcpy(hSrc + hs[i], src[i], srcSize[i]); }, k == 0 ? T : (T + 1) / 2);
+        if (hs[hi] > hs[lo] && hipMemcpyAsync(d->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, d->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipEventRecord(evIn, d->hostIn) != hipSuccess || hipStreamWaitEvent(d->hostK, evIn, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        size_t const r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff) + lo, d->dStage + oDst, (const u64*)(d->dStage + oDstOff) + lo,
+                                                                 (u64*)(d->dStage + oRes) + lo, hi - lo, ddict, d->hostK);
+        if (zjni_isError(r)) return drain(r);
+        if (hipEventRecord(evK, d->hostK) != hipSuccess || hipStreamWaitEvent(d->hostOut, evK, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipMemcpyAsync(d->hPinned + oRes + lo * 8, d->dStage + oRes + lo * 8, (hi - lo) * 8, hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hd[hi] > hd[lo] && hipMemcpyAsync(hDst + hd[lo], d->dStage + oDst + hd[lo], (size_t)(hd[hi] - hd[lo]), hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipEventRecord(evOut, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        enqueued.store(k + 1, std::memory_order_release);
+    }
+    gathering.store(false);
+    joiner.ok = true;
+    returner.join();
+    if (failed.load()) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+    return 0;
+}
+
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
 static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
                          size_t* result, size_t n, int level, int checksum = 0, const zjni_ddict* ddict = nullptr, const zjni_cdict* cdict = nullptr) {
@@ -1751,13 +1901,15 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
         if (srcTotal > ((size_t)1 << 46) || dstTotal > ((size_t)1 << 46)) return ZJNI_ERR(64);
         if ((srcSize[i] && !src[i]) || (dstCap[i] && !dst[i])) return ZJNI_ERR(compress ? 72 : 72);
     }
+    if (!compress) return host_decompress(d, src, srcSize, dst, dstCap, result, n, ddict);
     size_t const offBytes = (n + 1) * 8;
     // staging layout: [srcOff][dstOff][result][packedOff][src blob][dst blob][device only, compress: packed frames]
     size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oPOff = 3 * offBytes, oSrc = 4 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
     size_t const oPack = (oDst + dstTotal + 15) & ~(size_t)15;
     size_t const total = oPack + (compress ? dstTotal : 0) + 16;
     std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
-    if (!ensure_staging(d, total)) return ZJNI_ERR(64);
+    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);      // no room to stage this batch: the caller's CPU path takes it
+    struct Drain { ~Drain() { (void)hipStreamSynchronize(0); } } drainOnExit;     // error returns below leave copies in flight on the staging area: none when the lock drops
     u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff); u64* hp = (u64*)(d->hPinned + oPOff);
     size_t a = 0, b = 0;
     for (size_t i = 0; i < n; i++) { hs[i] = a; hd[i] = b; a += srcSize[i]; b += dstCap[i]; }
@@ -1970,27 +2122,38 @@ size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSiz
 // join it, the opener runs the batch entry once and everybody returns with its own result.  Results are those of the batch entries
 // (byte-identical frames); what changes is latency (up to the wait) against launches shared.  One device per aggregator.
 struct ZjAggReq { const void* src; size_t srcSize; void* dst; size_t dstCap; size_t result; };
-struct ZjAggBatch { std::vector<ZjAggReq*> reqs; bool closed = false, done = false; size_t rc = 0; };
+struct ZjAggBatch { std::vector<ZjAggReq*> reqs; bool closed = false, done = false; size_t bytes = 0; };
+#define ZJ_AGG_MAX_BYTES ((size_t)2 << 30)          /* staging a batch may ask for (sources + destination capacities): a member that would push it past this opens the next batch */
 struct zjni_aggregator {
     int device; size_t maxBatch; unsigned maxWaitMicros;
     std::mutex mu; std::condition_variable cv;
     std::map<int, std::shared_ptr<ZjAggBatch> > open;           // kind -> the batch that is still taking members
     unsigned long long calls = 0, batches = 0;
 };
+static size_t agg_run(int kind, const void* const* sp, const size_t* ss, void* const* dp, const size_t* dc, size_t* res, size_t n, int level, int checksum) {
+    return kind < 0 ? zjni_decompress_batch(sp, ss, dp, dc, res, n) : zjni_compress_batch2(sp, ss, dp, dc, res, n, level, checksum);
+}
 static size_t agg_submit(zjni_aggregator* a, int kind, ZjAggReq& rq, int level, int checksum) {
     if (!a) return ZJNI_ERR(ZJNI_ERROR_unsupported);
+    // a member's own faults are its own: checked before it joins, so that no one else's call fails for them
+    if (rq.srcSize > ((size_t)1 << 46) || rq.dstCap > ((size_t)1 << 46)) return ZJNI_ERR(64);
+    if ((rq.srcSize && !rq.src) || (rq.dstCap && !rq.dst)) return ZJNI_ERR(72);
+    size_t const mine = rq.srcSize + rq.dstCap;
     std::unique_lock<std::mutex> lk(a->mu);
     a->calls++;
     std::shared_ptr<ZjAggBatch> b;
     auto it = a->open.find(kind);
     bool leader = false;
+    if (it != a->open.end() && !it->second->closed && !it->second->reqs.empty() && it->second->bytes + mine > ZJ_AGG_MAX_BYTES) {   // would outgrow the staging: that batch goes now
+        it->second->closed = true; a->cv.notify_all();
+    }
     if (it == a->open.end() || it->second->closed) { b = std::make_shared<ZjAggBatch>(); a->open[kind] = b; leader = true; a->batches++; }
     else b = it->second;
-    b->reqs.push_back(&rq);
+    b->reqs.push_back(&rq); b->bytes += mine;
     if (b->reqs.size() >= a->maxBatch) { b->closed = true; a->cv.notify_all(); }
     if (!leader) {
         a->cv.wait(lk, [&]() { return b->done; });
-        return zjni_isError(b->rc) ? b->rc : rq.result;
+        return rq.result;
     }
     // the opener: wait for company, close the batch, run it outside the lock
     a->cv.wait_for(lk, std::chrono::microseconds(a->maxWaitMicros), [&]() { return b->closed; });
@@ -2003,13 +2166,20 @@ static size_t agg_submit(zjni_aggregator* a, int kind, ZjAggReq& rq, int level, 
     for (size_t i = 0; i < n; i++) { sp[i] = reqs[i]->src; ss[i] = reqs[i]->srcSize; dp[i] = reqs[i]->dst; dc[i] = reqs[i]->dstCap; }
     size_t rc = 0;
     if (zjni_init(a->device) != 0) rc = ZJNI_ERR(ZJNI_ERROR_no_device);
-    else rc = kind < 0 ? zjni_decompress_batch(sp.data(), ss.data(), dp.data(), dc.data(), res.data(), n)
-                       : zjni_compress_batch2(sp.data(), ss.data(), dp.data(), dc.data(), res.data(), n, level, checksum);
+    else rc = agg_run(kind, sp.data(), ss.data(), dp.data(), dc.data(), res.data(), n, level, checksum);
+    if (zjni_isError(rc)) {
+        // the shared launch failed as a whole (staging, a device error): every member gets its own verdict from a call of its own — what it
+        // would have got without the aggregator — instead of a stranger's error
+        for (size_t i = 0; i < n; i++) {
+            size_t r1 = 0; size_t const rr = n == 1 ? rc : agg_run(kind, &sp[i], &ss[i], &dp[i], &dc[i], &r1, 1, level, checksum);
+            res[i] = zjni_isError(rr) ? rr : r1;
+        }
+    }
     lk.lock();
     for (size_t i = 0; i < n; i++) reqs[i]->result = res[i];
-    b->rc = rc; b->done = true;
+    b->done = true;
     a->cv.notify_all();
-    return zjni_isError(rc) ? rc : rq.result;
+    return rq.result;
 }
 zjni_aggregator* zjni_createAggregator(int device, size_t maxBatch, unsigned maxWaitMicros) {
     if (device < 0 || device >= dev_count() || maxBatch < 1) return nullptr;

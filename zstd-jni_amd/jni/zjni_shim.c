@@ -70,18 +70,38 @@ static int per_buffer_on_gpu(void) {
 /* ZSTD_JNI_GPU_AGGREGATE=<microseconds>: concurrent per-buffer calls of plain contexts (no dictionary, default frame layout, no explicit
  * table sizes) are batched across threads (zjni_aggregator_*): the first caller waits that long for company.
  * Unset / 0: every per-buffer call is a batch of one. */
-static zjni_aggregator* aggregator(void) {
-    static zjni_aggregator* agg = NULL; static int state = -1;
-    if (state < 0) {
-        const char* e = getenv("ZSTD_JNI_GPU_AGGREGATE"); long const us = e ? atol(e) : 0;
-        agg = us > 0 ? zjni_createAggregator(0, 4096, (unsigned)us) : NULL;
-        state = 1;
-    }
-    return agg;
+static zjni_aggregator* g_agg;
+static pthread_once_t g_agg_once = PTHREAD_ONCE_INIT;
+static void agg_open(void) {
+    const char* e = getenv("ZSTD_JNI_GPU_AGGREGATE"); long const us = e ? atol(e) : 0;
+    g_agg = us > 0 ? zjni_createAggregator(0, 4096, (unsigned)us) : NULL;
 }
-static int gpu_result_final(size_t r) {       /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
+static zjni_aggregator* aggregator(void) { pthread_once(&g_agg_once, agg_open); return g_agg; }   /* (two first callers used to be able to make two) */
+
+/* ---- who served a call: the integrator cannot see it from Java --------------------------------------
+ * zjni_shim_stats(out[4]): hot-path natives [0] answered by the GPU path (a size or a genuine libzstd error code), [1] sent to the bundled
+ * library by policy without asking the GPU (per-buffer natives while ZSTD_JNI_CPU_LIB is loaded and ZSTD_JNI_GPU_PER_BUFFER is not 1; contexts
+ * carrying a parameter or dictionary only the CPU understands; sizes outside the GPU path), [2] sent there after the GPU path answered 200 / 201 /
+ * 40 / 42 ("not mine"), [3] of those, the answers 200 (no device, launch failure).  Relaxed atomics: counters, not a ledger. */
+static unsigned long long g_stats[4];
+static __thread int t_gpu_declined;                              /* the GPU path has just said "not mine" on this thread: the forward that follows is [2], not [1] */
+JNIEXPORT void zjni_shim_stats(unsigned long long* out4) { int i; for (i = 0; i < 4; i++) out4[i] = __atomic_load_n(&g_stats[i], __ATOMIC_RELAXED); }
+static int stat_verdict(int final, size_t r) {
+    if (final) __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+    else {
+        t_gpu_declined = 1;
+        __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
+        if (zjni_isError(r) && zjni_getErrorCode(r) == ZJNI_ERROR_no_device) __atomic_fetch_add(&g_stats[3], 1, __ATOMIC_RELAXED);
+    }
+    return final;
+}
+static void stat_forward(void) {                                  /* a hot-path native is about to call the bundled library */
+    if (t_gpu_declined) t_gpu_declined = 0; else __atomic_fetch_add(&g_stats[1], 1, __ATOMIC_RELAXED);
+}
+static int result_final(size_t r) {           /* sizes and genuine libzstd error codes are final; 200/201 mean "not for the GPU path" */
     return !(zjni_isError(r) && zjni_getErrorCode(r) >= 200);
 }
+static int gpu_result_final(size_t r) { return stat_verdict(result_final(r), r); }
 
 /* ---- per-context state of the GPU path, keyed by nativePtr ------------------------------------------ */
 typedef struct CtxState {
@@ -256,10 +276,16 @@ static void* dict_get(jlong key, int remove) {
     return r;
 }
 /* after the bundled library's init: attach the GPU digest to whatever handle the object now carries */
-static void dict_register(JNIEnv* env, jobject obj, jfieldID field, void* gpu, int compressSide) {
+static void dict_register(JNIEnv* env, jobject obj, jfieldID field, void* gpu, int compressSide, int bundledInit) {
     jlong key = (*env)->GetLongField(env, obj, field);
-    if (!key) {                                                         /* no bundled library: the handle is ours */
-        if (!gpu) return;                                               /* nativePtr stays 0: "ZSTD_createCDict failed" on the Java side */
+    if (!key) {
+        /* nativePtr is 0.  With a bundled init that means ZSTD_createCDict / DDict FAILED there: Java's `nativePtr == 0` check must see it, and the
+         * trampolines hand nativePtr to the bundled library as its own pointer type — no private handle may go in.  Only without any bundled
+         * init (the GPU-only configuration) is the handle ours. */
+        if (bundledInit || !gpu) {
+            if (gpu) { if (compressSide) zjni_freeCDict((zjni_cdict*)gpu); else zjni_freeDDict((zjni_ddict*)gpu); }
+            return;
+        }
         key = (jlong)(intptr_t)gpu;
         (*env)->SetLongField(env, obj, field, key);
     }
@@ -282,7 +308,8 @@ JNIEXPORT void JNICALL P(ZstdDictCompress_init)(JNIEnv* env, jobject obj, jbyteA
         jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
         if (!copy) return;
         (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
-        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, level, 1), 1);
+        if ((*env)->ExceptionCheck(env)) { free(copy); return; }        /* region out of bounds: nothing was copied, nothing to digest */
+        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, level, 1), 1, f != NULL);
         free(copy);
     }
 }
@@ -292,7 +319,7 @@ JNIEXPORT void JNICALL P(ZstdDictCompress_initDirect)(JNIEnv* env, jobject obj, 
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size, level, byReference);
     {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
-        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, level, 1), 1); }   /* the device keeps its own copy either way */
+        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, level, 1), 1, f != NULL); }   /* the device keeps its own copy either way */
 }
 JNIEXPORT void JNICALL P(ZstdDictCompress_free)(JNIEnv* env, jobject obj) {
     void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym(PS("ZstdDictCompress_free"));
@@ -309,7 +336,8 @@ JNIEXPORT void JNICALL P(ZstdDictDecompress_init)(JNIEnv* env, jobject obj, jbyt
         jbyte* copy = (jbyte*)malloc((size_t)dict_size + 1);
         if (!copy) return;
         (*env)->GetByteArrayRegion(env, dict, dict_offset, dict_size, copy);
-        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, 0, 0), 0);
+        if ((*env)->ExceptionCheck(env)) { free(copy); return; }
+        dict_register(env, obj, field, dict_digest(copy, (size_t)dict_size, 0, 0), 0, f != NULL);
         free(copy);
     }
 }
@@ -319,7 +347,7 @@ JNIEXPORT void JNICALL P(ZstdDictDecompress_initDirect)(JNIEnv* env, jobject obj
     if (NULL == dict) return;
     if (f) f(env, obj, dict, dict_offset, dict_size, byReference);
     {   char* p = (char*)(*env)->GetDirectBufferAddress(env, dict);
-        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, 0, 0), 0); }
+        if (p && dict_size >= 0) dict_register(env, obj, field, dict_digest(p + dict_offset, (size_t)dict_size, 0, 0), 0, f != NULL); }
 }
 JNIEXPORT void JNICALL P(ZstdDictDecompress_free)(JNIEnv* env, jobject obj) {
     void (*f)(JNIEnv*, jobject) = (void (*)(JNIEnv*, jobject))cpu_sym(PS("ZstdDictDecompress_free"));
@@ -411,11 +439,12 @@ static size_t gpu_compress(const CtxState* s, void* dst, size_t dstCap, const vo
     return zjni_isError(r) ? r : res;
 }
 static int gpu_compress_final(const CtxState* s, size_t r, int haveCpu) {   /* 40 / 42 = outside what the GPU path takes (attach range, table sizes): forward when possible */
-    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && (s->cdict || s->localCdict || s->hashLog || s->chainLog) && haveCpu);
+    return stat_verdict(result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && (s->cdict || s->localCdict || s->hashLog || s->chainLog) && haveCpu), r);
 }
 typedef jlong (*cbuf_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
 static jlong buf_forward(const char* name, jlong none, JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint doff, jint dsize, jobject src, jint soff, jint ssize) {
     cbuf_fn f = (cbuf_fn)cpu_sym(name);
+    if (f) stat_forward(); else t_gpu_declined = 0;
     return f ? f(env, cls, ptr, dst, doff, dsize, src, soff, ssize) : none;
 }
 
@@ -582,8 +611,9 @@ JNIEXPORT jlong JNICALL P(Zstd_compressUnsafe)
     }
     {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean) =
             (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong, jint, jboolean))cpu_sym(PS("Zstd_compressUnsafe"));
-        if (f) return f(env, cls, dst, dst_size, src, src_size, level, checksumFlag);
+        if (f) { stat_forward(); return f(env, cls, dst, dst_size, src, src_size, level, checksumFlag); }
     }
+    t_gpu_declined = 0;
     return -(jlong)ZJNI_ERROR_unsupported;
 }
 JNIEXPORT jlong JNICALL P(Zstd_decompressUnsafe)(JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size) {
@@ -592,8 +622,9 @@ JNIEXPORT jlong JNICALL P(Zstd_decompressUnsafe)(JNIEnv* env, jclass cls, jlong 
         if (gpu_result_final(r)) return (jlong)r;
     }
     {   jlong (*f)(JNIEnv*, jclass, jlong, jlong, jlong, jlong) = (jlong (*)(JNIEnv*, jclass, jlong, jlong, jlong, jlong))cpu_sym(PS("Zstd_decompressUnsafe"));
-        if (f) return f(env, cls, dst, dst_size, src, src_size);
+        if (f) { stat_forward(); return f(env, cls, dst, dst_size, src, src_size); }
     }
+    t_gpu_declined = 0;
     return -(jlong)ZJNI_ERROR_no_device;
 }
 
@@ -608,7 +639,7 @@ static size_t fastdict_compress(zjni_cdict* cd, void* dst, size_t dstCap, const 
     return zjni_isError(r) ? r : res;
 }
 static int fastdict_final(size_t r, int haveCpu) {
-    return gpu_result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && haveCpu);
+    return stat_verdict(result_final(r) && !(zjni_isError(r) && (zjni_getErrorCode(r) == 40 || zjni_getErrorCode(r) == 42) && haveCpu), r);
 }
 typedef jlong (*fd_arr_fn)(JNIEnv*, jclass, jbyteArray, jint, jbyteArray, jint, jint, jobject);
 typedef jlong (*fd_buf_fn)(JNIEnv*, jclass, jobject, jint, jint, jobject, jint, jint, jobject);
@@ -641,6 +672,7 @@ static jlong fastdict_array(JNIEnv* env, jclass cls, jbyteArray dst, jint dst_of
             if (compress ? fastdict_final(r, f != NULL) : gpu_result_final(r)) return (jlong)r;
         }
     }
+    if (f) stat_forward(); else t_gpu_declined = 0;
     return f ? f(env, cls, dst, dst_offset, src, src_offset, src_length, dict) : -(jlong)ZJNI_ERROR_unsupported;
 }
 static jlong fastdict_direct(JNIEnv* env, jclass cls, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jobject dict, int compress, const char* name) {
@@ -662,6 +694,7 @@ static jlong fastdict_direct(JNIEnv* env, jclass cls, jobject dst, jint dst_offs
             if (compress ? fastdict_final(r, f != NULL) : gpu_result_final(r)) return (jlong)r;
         }
     }
+    if (f) stat_forward(); else t_gpu_declined = 0;
     return f ? f(env, cls, dst, dst_offset, dst_size, src, src_offset, src_size, dict) : -(jlong)ZJNI_ERROR_unsupported;
 }
 JNIEXPORT jlong JNICALL P(Zstd_compressFastDict0)(JNIEnv* env, jclass cls, jbyteArray dst, jint dst_offset, jbyteArray src, jint src_offset, jint src_length, jobject dict) {
