@@ -32,11 +32,19 @@ ev = [vp() for _ in range(5)]
 for x in ev: chk(hip.hipEventCreate(C.byref(x)))
 tc = td = tp = 0.0
 h_csz = np.zeros(n, dtype=np.uint64)
+PROF = bool(os.environ.get("ZJNI_PROFILE")) and hasattr(L, "zjni_debug_read_profile")
+enc_phase = None
+def read_prof():
+    a = (C.c_ulonglong * 32)(); L.zjni_debug_read_profile.argtypes = [vp]; assert L.zjni_debug_read_profile(a) == 0; return list(a)
 for it in range(steps + 1):
+    if PROF and it == steps: read_prof()                     # (clears the counters: the last step's alone)
     chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device_advanced(src, soff, comp, coff, csz, n, level, 0, hl, cl, None)); chk(hip.hipEventRecord(ev[4], None))
     chk(hip.hipDeviceSynchronize())
     ms = C.c_float(); chk(hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[4]))
     if it > 0: tc += ms.value
+    if PROF and it == steps:
+        pe = read_prof(); names = ["params+zero", "match find(l0)", "lit gather+codes", "hist+huf build", "huf encode", "seq tables", "seq encode(l0)", "block place"]
+        enc_phase = {names[i]: round(pe[16 + i] / n / 1e3, 1) for i in range(8)}          # kilo-cycles per frame, entropy kernel's lane 0
     chk(hip.hipMemcpy(h_csz.ctypes.data_as(vp), csz, C.c_size_t(n * 8), 2))
     h_poff = np.zeros(n + 1, dtype=np.uint64); h_poff[1:] = np.cumsum(h_csz)
     chk(hip.hipMemcpy(poff, h_poff.ctypes.data_as(vp), C.c_size_t((n + 1) * 8), 1))
@@ -60,5 +68,5 @@ import hashlib
 fp = hashlib.sha1(h_csz.tobytes()).hexdigest()[:12]
 L.zjni_build_stamp.restype = C.c_char_p; L.zjni_route_kernel.restype = C.c_char_p; L.zjni_route_kernel.argtypes = [C.c_int]
 route = int(L.zjni_last_route())
-print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "csz_sha": fp, "build_stamp": L.zjni_build_stamp().decode(), "route": route, "match_kernel": L.zjni_route_kernel(route).decode(), "stages_ms": stages, "n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
+print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "csz_sha": fp, "build_stamp": L.zjni_build_stamp().decode(), "route": route, "match_kernel": L.zjni_route_kernel(route).decode(), "entropy_kcycles_per_frame": enc_phase, "stages_ms": stages, "n": n, "size": size, "level": level, "hashLog": hl, "chainLog": cl, "steps": steps, "compress_ms": tc / steps, "pack_ms": tp / steps, "decode_ms": td / steps,
                   "compressed_bytes": int(h_csz.sum()), "all_decoded": bool((h_dsz == size).all())}))

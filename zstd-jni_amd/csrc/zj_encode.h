@@ -29,6 +29,7 @@
 #if !ZJ_ON_GPU
 static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build
 static inline u32 atomicMax(u32* p, u32 v) { u32 const o = *p; if (v > o) *p = v; return o; }
+static inline u32 atomicOr(u32* p, u32 v) { u32 const o = *p; *p = o | v; return o; }
 static inline u32 atomicCAS(u32* p, u32 cmp, u32 v) { u32 const o = *p; if (o == cmp) *p = v; return o; }
 #endif
 
@@ -1012,72 +1013,136 @@ ZJ_DEV void ze_huf_quicksort(ZEEntropy& e, ZENode* a, i32 low0, i32 high0) {
     }
 }
 
-// HUF_sort + HUF_buildTree + HUF_setMaxHeight + HUF_buildCTableFromTree (huf_compress.c:376-754)
-ZJ_DEV u32 ze_huf_build(ZEEntropy& e, u32 maxSV, u32 maxNbBits) {
-    ZENode* const node0 = e.node; ZENode* const node = e.node + 1;
+// HUF_buildCTable_wksp (HUF_sort + HUF_buildTree + HUF_setMaxHeight + HUF_buildCTableFromTree, huf_compress.c:376-754) by the whole wave.
+//  * HUF_sort.  The reference drops the symbols into rank buckets (exact counts below 166, log2 classes above), largest bucket first, symbols of a
+//    bucket in symbol order, and then quicksorts every bucket from count 164 upwards by count.  The result IS the order "count descending, symbol
+//    ascending" — a 256-key bitonic sort, four keys per lane — unless a quicksorted bucket of nine or more members holds two equal counts: its
+//    quicksort is not stable (smaller buckets go through its insertion sort, which is), and only the serial sort knows what it does then.
+//  * HUF_buildTree's two-queue merge is a dependent chain (one lane, <= 255 steps); the leaves' depths follow in parallel.
+//  * HUF_setMaxHeight (a table deeper than maxNbBits: rare) stays the serial repair.
+//  * HUF_buildCTableFromTree: codes of a length are handed out in symbol order — a ballot per length and 64 symbols gives every symbol its place.
+template <class G>
+ZJ_DEV u32 ze_huf_build_wave(const G& g, ZEncShared& sh, ZEEntropy& e, u32 maxSV, u32 maxNbBits) {
+    ZENode* const node = e.node + 1;
     const u32* const count = e.count;
-    for (u32 n = 0; n < 516; n++) { ZENode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; e.node[n] = z; }
-    for (u32 n = 0; n < 192; n++) { e.rankBase[n] = 0; e.rankCurr[n] = 0; }
-    for (u32 n = 0; n <= maxSV; n++) e.rankBase[ze_huf_bucket(count[n])]++;
-    for (u32 n = 191; n > 0; n--) { e.rankBase[n - 1] += e.rankBase[n]; e.rankCurr[n - 1] = e.rankBase[n - 1]; }
-    for (u32 n = 0; n <= maxSV; n++) { u32 const r = ze_huf_bucket(count[n]) + 1; u32 const pos = e.rankCurr[r]++; node[pos].count = count[n]; node[pos].byte = (u8)n; }
-    // RANK_POSITION_DISTINCT_COUNT_CUTOFF evaluates to 158 + highbit32(158) = 165 (the reference's comment says 166): the loop
-    // also visits the slot of count == 164, where nine or more equal counts are permuted by the (unstable) quicksort
-    for (u32 n = 165; n < 191; n++) { i32 const sz = (i32)e.rankCurr[n] - (i32)e.rankBase[n]; if (sz > 1) ze_huf_quicksort(e, node + e.rankBase[n], 0, sz - 1); }
-    i32 nonNull = (i32)maxSV; while (node[nonNull].count == 0) nonNull--;
-    i32 lowS = nonNull, nodeNb = 256, lowN = 256; i32 const nodeRoot = nodeNb + lowS - 1;
-    node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
-    node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
-    nodeNb++; lowS -= 2;
-    for (i32 n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
-    node0[0].count = 1u << 31;
-    while (nodeNb <= nodeRoot) {
-        i32 const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        i32 const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
-        node[nodeNb].count = node[n1].count + node[n2].count;
-        node[n1].parent = node[n2].parent = (u16)nodeNb; nodeNb++;
+    u32* const K = (u32*)e.stage;                          // 256 sort keys (the record stage is idle until the sequences section)
+    u32* const bsize = e.scount;                           // members of the quicksorted buckets (164 ..), later: codes per length / first code of a length
+    GRP_FOR(g, n, 516) { ZENode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; e.node[n] = z; }
+    GRP_FOR(g, r, 64) bsize[r] = 0;
+    GRP_SERIAL(g) { sh.tmp[5] = 0; }
+    g.sync();
+    GRP_FOR(g, n, 256) {
+        u32 const c = n <= maxSV ? count[n] : 0u;
+        K[n] = (c << 8) | (255u - n);
+        if (c >= 164u) atomicAdd(&bsize[ze_huf_bucket(c) - 164u], 1u);
     }
-    node[nodeRoot].nbBits = 0;
-    for (i32 n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
-    for (i32 n = 0; n <= nonNull; n++) node[n].nbBits = node[node[n].parent].nbBits + 1;
-    {   u32 const largestBits = node[nonNull].nbBits;
+    g.sync();
+    for (u32 k = 2; k <= 256u; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            GRP_FOR(g, t, 128) {
+                u32 const i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                u32 const a = K[i], b = K[l];
+                bool const down = (i & k) == 0u;           // this block ends up descending (the last merge: all of it)
+                if (down ? a < b : a > b) { K[i] = b; K[l] = a; }
+            }
+            g.sync();
+        }
+    }
+    GRP_FOR(g, i, 255) {
+        u32 const c0 = K[i] >> 8, c1 = K[i + 1] >> 8;
+        if (c0 == c1 && c0 >= 164u && bsize[ze_huf_bucket(c0) - 164u] >= 9u) atomicOr(&sh.tmp[5], 1u);
+    }
+    g.sync();
+    if (ZJ_UNI(sh.tmp[5])) {
+        GRP_SERIAL(g) {                                    // the reference's own sort, bucket by bucket (ze_huf_build's first part)
+            for (u32 n = 0; n < 192; n++) { e.rankBase[n] = 0; e.rankCurr[n] = 0; }
+            for (u32 n = 0; n <= maxSV; n++) e.rankBase[ze_huf_bucket(count[n])]++;
+            for (u32 n = 191; n > 0; n--) { e.rankBase[n - 1] += e.rankBase[n]; e.rankCurr[n - 1] = e.rankBase[n - 1]; }
+            for (u32 n = 0; n <= maxSV; n++) { u32 const r = ze_huf_bucket(count[n]) + 1; u32 const pos = e.rankCurr[r]++; node[pos].count = count[n]; node[pos].byte = (u8)n; }
+            for (u32 n = 165; n < 191; n++) { i32 const sz = (i32)e.rankCurr[n] - (i32)e.rankBase[n]; if (sz > 1) ze_huf_quicksort(e, node + e.rankBase[n], 0, sz - 1); }
+        }
+    } else {
+        GRP_FOR(g, pos, maxSV + 1u) { u32 const kv = K[pos]; node[pos].count = kv >> 8; node[pos].byte = (u8)(255u - (kv & 255u)); }
+    }
+    g.sync();
+    GRP_SERIAL(g) {
+        ZENode* const node0 = e.node;
+        i32 nonNull = (i32)maxSV; while (node[nonNull].count == 0) nonNull--;
+        i32 lowS = nonNull, nodeNb = 256, lowN = 256; i32 const nodeRoot = nodeNb + lowS - 1;
+        node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+        node[lowS].parent = node[lowS - 1].parent = (u16)nodeNb;
+        nodeNb++; lowS -= 2;
+        for (i32 n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+        node0[0].count = 1u << 31;
+        while (nodeNb <= nodeRoot) {
+            i32 const n1 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+            i32 const n2 = (node[lowS].count < node[lowN].count) ? lowS-- : lowN++;
+            node[nodeNb].count = node[n1].count + node[n2].count;
+            node[n1].parent = node[n2].parent = (u16)nodeNb; nodeNb++;
+        }
+        node[nodeRoot].nbBits = 0;
+        for (i32 n = nodeRoot - 1; n >= 256; n--) node[n].nbBits = node[node[n].parent].nbBits + 1;
+        sh.tmp[4] = (u32)nonNull;
+    }
+    g.sync();
+    u32 const nonNull = ZJ_UNI(sh.tmp[4]);
+    GRP_FOR(g, n, nonNull + 1u) node[n].nbBits = node[node[n].parent].nbBits + 1;
+    g.sync();
+    {   u32 const largestBits = ZJ_UNI((u32)node[nonNull].nbBits);
         if (largestBits > maxNbBits) {
-            i32 totalCost = 0; u32 const baseCost = 1u << (largestBits - maxNbBits); u32 const noSymbol = 0xF0F0F0F0u;
-            u32* const rankLast = e.scount;       // 14 entries of LDS scratch
-            i32 k = nonNull;
-            while (node[k].nbBits > maxNbBits) { totalCost += (i32)(baseCost - (1u << (largestBits - node[k].nbBits))); node[k].nbBits = (u8)maxNbBits; k--; }
-            while (node[k].nbBits == maxNbBits) --k;
-            totalCost >>= (largestBits - maxNbBits);
-            for (u32 r = 0; r < 14; r++) rankLast[r] = noSymbol;
-            {   u32 cur = maxNbBits;
-                for (i32 pos = k; pos >= 0; pos--) { if (node[pos].nbBits >= cur) continue; cur = node[pos].nbBits; rankLast[maxNbBits - cur] = (u32)pos; } }
-            while (totalCost > 0) {
-                u32 nDec = zj_hibit((u32)totalCost) + 1;
-                for (; nDec > 1; nDec--) {
-                    u32 const highPos = rankLast[nDec], lowPos = rankLast[nDec - 1];
-                    if (highPos == noSymbol) continue;
-                    if (lowPos == noSymbol) break;
-                    if (node[highPos].count <= 2 * node[lowPos].count) break;
+            GRP_SERIAL(g) {                                // HUF_setMaxHeight (huf_compress.c:376-506)
+                i32 totalCost = 0; u32 const baseCost = 1u << (largestBits - maxNbBits); u32 const noSymbol = 0xF0F0F0F0u;
+                u32* const rankLast = e.scount;
+                i32 k = (i32)nonNull;
+                while (node[k].nbBits > maxNbBits) { totalCost += (i32)(baseCost - (1u << (largestBits - node[k].nbBits))); node[k].nbBits = (u8)maxNbBits; k--; }
+                while (node[k].nbBits == maxNbBits) --k;
+                totalCost >>= (largestBits - maxNbBits);
+                for (u32 r = 0; r < 14; r++) rankLast[r] = noSymbol;
+                {   u32 cur = maxNbBits;
+                    for (i32 pos = k; pos >= 0; pos--) { if (node[pos].nbBits >= cur) continue; cur = node[pos].nbBits; rankLast[maxNbBits - cur] = (u32)pos; } }
+                while (totalCost > 0) {
+                    u32 nDec = zj_hibit((u32)totalCost) + 1;
+                    for (; nDec > 1; nDec--) {
+                        u32 const highPos = rankLast[nDec], lowPos = rankLast[nDec - 1];
+                        if (highPos == noSymbol) continue;
+                        if (lowPos == noSymbol) break;
+                        if (node[highPos].count <= 2 * node[lowPos].count) break;
+                    }
+                    while ((nDec <= 12) && (rankLast[nDec] == noSymbol)) nDec++;
+                    totalCost -= 1 << (nDec - 1);
+                    node[rankLast[nDec]].nbBits++;
+                    if (rankLast[nDec - 1] == noSymbol) rankLast[nDec - 1] = rankLast[nDec];
+                    if (rankLast[nDec] == 0) rankLast[nDec] = noSymbol;
+                    else { rankLast[nDec]--; if (node[rankLast[nDec]].nbBits != maxNbBits - nDec) rankLast[nDec] = noSymbol; }
                 }
-                while ((nDec <= 12) && (rankLast[nDec] == noSymbol)) nDec++;
-                totalCost -= 1 << (nDec - 1);
-                node[rankLast[nDec]].nbBits++;
-                if (rankLast[nDec - 1] == noSymbol) rankLast[nDec - 1] = rankLast[nDec];
-                if (rankLast[nDec] == 0) rankLast[nDec] = noSymbol;
-                else { rankLast[nDec]--; if (node[rankLast[nDec]].nbBits != maxNbBits - nDec) rankLast[nDec] = noSymbol; }
+                while (totalCost < 0) {
+                    if (rankLast[1] == noSymbol) { while (node[k].nbBits == maxNbBits) k--; node[k + 1].nbBits--; rankLast[1] = (u32)(k + 1); totalCost++; continue; }
+                    node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
+                }
             }
-            while (totalCost < 0) {
-                if (rankLast[1] == noSymbol) { while (node[k].nbBits == maxNbBits) k--; node[k + 1].nbBits--; rankLast[1] = (u32)(k + 1); totalCost++; continue; }
-                node[rankLast[1] + 1].nbBits--; rankLast[1]++; totalCost++;
-            }
+            g.sync();
         } else maxNbBits = largestBits;
     }
-    {   u16* const nbPerRank = e.cumul; u16* const valPerRank = e.cumul + 16; u16 min = 0;
-        for (u32 r = 0; r < 32; r++) e.cumul[r] = 0;
-        for (i32 n = 0; n <= nonNull; n++) nbPerRank[node[n].nbBits]++;
-        for (i32 n = (i32)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
-        for (u32 n = 0; n <= maxSV; n++) e.nbBits[node[n].byte] = node[n].nbBits;
-        for (u32 n = 0; n <= maxSV; n++) { u32 const nb = e.nbBits[n]; e.val[n] = nb ? valPerRank[nb]++ : 0; }
+    {   u32* const nbPerRank = e.scount; u32* const valPerRank = e.scount + 16;
+        GRP_FOR(g, r, 32) e.scount[r] = 0;
+        g.sync();
+        GRP_FOR(g, n, nonNull + 1u) atomicAdd(&nbPerRank[node[n].nbBits], 1u);
+        GRP_FOR(g, n, 256) { e.nbBits[n] = 0; e.val[n] = 0; }
+        g.sync();
+        GRP_SERIAL(g) { u32 min = 0; for (i32 n = (i32)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; } }
+        GRP_FOR(g, n, maxSV + 1u) e.nbBits[node[n].byte] = node[n].nbBits;
+        g.sync();
+        for (u32 r = 1; r <= maxNbBits; r++) {             // codes of length r, in symbol order
+            u32 next = valPerRank[r];
+            for (u32 base = 0; base <= maxSV; base += (u32)G::W) {
+                u32 const n = base + g.lane();
+                bool const mine = n <= maxSV && e.nbBits[n] == r;
+                u64 const m = grp_ballot(g, mine);
+                if (mine) e.val[n] = (u16)(next + (u32)__builtin_popcountll(m & (((u64)1 << g.lane()) - 1u)));
+                next += (u32)__builtin_popcountll(m);
+            }
+        }
+        g.sync();
     }
     return maxNbBits;
 }
@@ -1152,9 +1217,6 @@ ZJ_DEV void ze_huf_encode_stream(const ZEEntropy& e, u8* dst, const u8* lit, u32
 // A forward bitstream (BIT_CStream_t layout) assembled by many lanes: every lane ORs its bits into a
 // zero-initialised LDS window at its own bit offset (offsets come from a prefix sum of bit counts), then
 // the wave flushes the completed 32-bit words to HBM and carries the partial word over.
-#if !ZJ_ON_GPU
-static inline u32 atomicOr(u32* p, u32 v) { u32 const o = *p; *p = o | v; return o; }   // lane-serial build
-#endif
 struct ZEStageBits { u32* w; u8* dst; u32 flushedWords; u32 carryBits; };   // wave-uniform
 
 ZJ_DEV void ze_or_bits(u32* w, u32 bitpos, u64 lo, u64 hi, u32 nbits) {    // OR nbits (<=128) of {hi:lo} at bitpos
@@ -1542,9 +1604,10 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                     if (c) { atomicMax(&sh.tmp[6], s); atomicMax(&sh.tmp[7], c); }
                 }
                 g.sync();
-                GRP_SERIAL(g) {                                                // HUF_compress_internal (huf_compress.c:1333-1434), decisions
+                // HUF_compress_internal (huf_compress.c:1333-1434): the decisions on one lane, the table itself (when one is built) by the whole wave in between
+                GRP_SERIAL(g) {
                     u32 const maxSV = sh.tmp[6], largest = sh.tmp[7];
-                    u32 m = 2, h = 0, rep = hufRep;
+                    u32 m = 2, rep = hufRep, build = 0;
                     sh.hufMaxSV = maxSV;
                     bool useOld = false;
                     if (preferRepeat && rep == ZC_REPEAT_VALID) useOld = true;    // valid table + small input: no statistics at all
@@ -1556,22 +1619,30 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                             else for (u32 s = 0; s <= maxSV; s++) if (e.count[s] && !(sh.dictCodes[s] >> 16)) { rep = ZC_REPEAT_NONE; break; }
                         }
                         if (preferRepeat && rep != ZC_REPEAT_NONE) useOld = true;
+                        else build = 1;
+                    }
+                    sh.tmp[0] = build; sh.tmp[1] = m; sh.tmp[2] = rep; sh.tmp[3] = useOld ? 1u : 0u;
+                }
+                g.sync();
+                u32 huffLogBuilt = 0;
+                if (ZJ_UNI(sh.tmp[0])) huffLogBuilt = ze_huf_build_wave(g, sh, e, ZJ_UNI(sh.tmp[6]), ze_fse_optimal_log(11, n, ZJ_UNI(sh.tmp[6]), 1));
+                GRP_SERIAL(g) {
+                    u32 const maxSV = sh.tmp[6];
+                    u32 m = sh.tmp[1], h = 0; u32 const rep = sh.tmp[2]; bool useOld = sh.tmp[3] != 0;
+                    if (sh.tmp[0]) {
+                        u32 const huffLog = huffLogBuilt;
+                        {   bool tg = false;
+                            h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog, capBody > lhSize ? capBody - lhSize : 0u, &tg);
+                            if (tg) sh.tightHuf = 1; }
+                        sh.ctDict[0] = 0;                                     // the weights' tANS table went through e.ct[0]
+                        if (!h) m = 0;
                         else {
-                            u32 huffLog = ze_fse_optimal_log(11, n, maxSV, 1);
-                            huffLog = ze_huf_build(e, maxSV, huffLog);
-                            {   bool tg = false;
-                                h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog, capBody > lhSize ? capBody - lhSize : 0u, &tg);
-                                if (tg) sh.tightHuf = 1; }
-                            sh.ctDict[0] = 0;                                     // the weights' tANS table went through e.ct[0]
-                            if (!h) m = 0;
-                            else {
-                                if (rep != ZC_REPEAT_NONE) {                      // is the dictionary's table at least as good?
-                                    u32 oldBits = 0, newBits = 0;
-                                    for (u32 s = 0; s <= maxSV; s++) { oldBits += e.count[s] * (sh.dictCodes[s] >> 16); newBits += e.count[s] * e.nbBits[s]; }
-                                    if ((oldBits >> 3) <= h + (newBits >> 3) || h + 12 >= n) useOld = true;
-                                }
-                                if (!useOld && h + 12 >= n) m = 0;
+                            if (rep != ZC_REPEAT_NONE) {                      // is the dictionary's table at least as good?
+                                u32 oldBits = 0, newBits = 0;
+                                for (u32 s = 0; s <= maxSV; s++) { oldBits += e.count[s] * (sh.dictCodes[s] >> 16); newBits += e.count[s] * e.nbBits[s]; }
+                                if ((oldBits >> 3) <= h + (newBits >> 3) || h + 12 >= n) useOld = true;
                             }
+                            if (!useOld && h + 12 >= n) m = 0;
                         }
                     }
                     if (useOld) { m = 3; h = 0; }
@@ -1671,73 +1742,90 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 g.sync();
                 GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; atomicAdd(&cnt3[s.ll >> 24], 1u); atomicAdd(&cnt3[64 + (s.off >> 24)], 1u); atomicAdd(&cnt3[128 + (s.ml >> 24)], 1u); }
                 g.sync();
-                for (u32 t = 0; t < 3; t++) {                                 // LL, OF, ML in stream order
-                    GRP_SERIAL(g) {
-                        u32* const scount = cnt3 + 64 * t;
-                        u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;
-                        const short* const defNorm = t == 0 ? ze_k_ll_defnorm : (t == 1 ? ze_k_of_defnorm : ze_k_ml_defnorm);
-                        u32 const defMax = t == 0 ? 35u : (t == 1 ? 28u : 52u);
-                        u32 max = 0, most = 0;
-                        for (u32 s = 0; s <= maxSym; s++) { if (scount[s]) max = s; most = zj_max(most, scount[s]); }
-                        bool const defaultAllowed = (t != 1) || (max <= 28);
-                        u32 const fseRep = cd ? sh.dictFseRep[t] : ZC_REPEAT_NONE;
-                        u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
-                        if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
-                        else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
-                        else if (strat < 4u) {
-                            u32 const dynMin = ((1u << defLog) * (10 - strat)) >> 3;
-                            type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
-                        } else {
-                            // strategy >= lazy: the cheapest of predefined / new table by estimated cost (zstd_compress_sequences.c:196-222; no
-                            // previous table here: these levels are served without a dictionary and one block per frame).  An impossible choice
-                            // costs ERROR(GENERIC) = all ones there, the same here.
-                            u64 const none = ~(u64)0;
-                            u64 basicCost = none;
-                            if (defaultAllowed) {                                                              // ZSTD_crossEntropyCost(defaultNorm, defaultNormLog, count, max)
-                                u32 const shift = 8u - defLog; u64 c = 0;
-                                for (u32 s = 0; s <= max; s++) { u32 const na = defNorm[s] != -1 ? (u32)defNorm[s] : 1u; c += (u64)scount[s] * ze_k_invprob[na << shift]; }
-                                basicCost = c >> 8;
-                            }
-                            u64 compressedCost;
-                            {   u32 const tl = ze_fse_optimal_log(fseLog, nbSeq, max, 2);                      // ZSTD_NCountCost
-                                u64 ncount = none;
-                                if (ze_fse_normalize(e.norm, tl, scount, nbSeq, max, nbSeq >= 2048)) { u32 const hb = ze_fse_write_ncount((u8*)e.cumul, e.norm, max, tl); ncount = hb ? (u64)hb : none; }
-                                u32 cost = 0;                                                                  // ZSTD_entropyCost
-                                for (u32 s = 0; s <= max; s++) { u32 nr = (256u * scount[s]) / nbSeq; if (scount[s] != 0 && nr == 0) nr = 1; cost += scount[s] * ze_k_invprob[nr]; }
-                                compressedCost = (ncount << 3) + (u64)(cost >> 8);
-                            }
-                            type = (basicCost <= none && basicCost <= compressedCost) ? 0u : 2u;               // (repeatCost = ERROR(GENERIC): basic wins ties against it)
+                // ZSTD_buildSequencesStatistics: the three tables (LL, OF, ML) are independent — normalisation, table description and
+                // encoding table each on a lane of its own (lane t = table t), into scratch of its own in the idle tree area; what depends
+                // on the ORDER — where a description lands in the block, the capacity tests there, "last count" — follows on one lane.
+                struct ZESeqScr { short norm[64]; u16 cumul[64]; u8 tableSymbol[512]; u8 ncount[128]; u32 need, h, type, first; };
+                ZESeqScr* const scr = (ZESeqScr*)e.node;                      // 3 x 912 bytes of the 4 128 (the Huffman tree is done with)
+                for (u32 t = g.lane(); t < 3u; t += (u32)G::W) {
+                    ZESeqScr& q = scr[t];
+                    u32* const scount = cnt3 + 64 * t;
+                    u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;
+                    const short* const defNorm = t == 0 ? ze_k_ll_defnorm : (t == 1 ? ze_k_of_defnorm : ze_k_ml_defnorm);
+                    u32 const defMax = t == 0 ? 35u : (t == 1 ? 28u : 52u);
+                    u32 max = 0, most = 0;
+                    for (u32 s = 0; s <= maxSym; s++) { if (scount[s]) max = s; most = zj_max(most, scount[s]); }
+                    bool const defaultAllowed = (t != 1) || (max <= 28);
+                    u32 const fseRep = cd ? sh.dictFseRep[t] : ZC_REPEAT_NONE;
+                    u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
+                    if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
+                    else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
+                    else if (strat < 4u) {
+                        u32 const dynMin = ((1u << defLog) * (10 - strat)) >> 3;
+                        type = (defaultAllowed && ((nbSeq < dynMin) || (most < (nbSeq >> (defLog - 1))))) ? 0 : 2;
+                    } else {
+                        // strategy >= lazy: the cheapest of predefined / new table by estimated cost (zstd_compress_sequences.c:196-222; no
+                        // previous table here: these levels are served without a dictionary and one block per frame).  An impossible choice
+                        // costs ERROR(GENERIC) = all ones there, the same here.
+                        u64 const none = ~(u64)0;
+                        u64 basicCost = none;
+                        if (defaultAllowed) {                                                              // ZSTD_crossEntropyCost(defaultNorm, defaultNormLog, count, max)
+                            u32 const shift = 8u - defLog; u64 c = 0;
+                            for (u32 s = 0; s <= max; s++) { u32 const na = defNorm[s] != -1 ? (u32)defNorm[s] : 1u; c += (u64)scount[s] * ze_k_invprob[na << shift]; }
+                            basicCost = c >> 8;
                         }
-                        u32 h = 0;
-                        u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];
-                        if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; body[pos] = (u8)firstCode; h = 1;
-                                         if (pos >= capBody) sh.tight = 1; }   // ZSTD_buildCTable, set_rle: "not enough space" (zstd_compress_sequences.c:255)
-                        else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, e.cumul, e.tableSymbol);
-                        else if (type == 3) h = 0;                             // table copied below by the whole wave
-                        else {
-                            u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
-                            if (scount[lastCode] > 1) { scount[lastCode]--; nbSeq1--; }
-                            ze_fse_normalize(e.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048);
-                            {   u32 need = 0;
-                                h = ze_fse_write_ncount(body + pos, e.norm, max, tableLog, &need);
-                                if ((u64)pos + need > capBody) sh.tight = 1; }            // FSE_writeNCount into what is left (zstd_compress_sequences.c:279-280)
-                            ze_fse_build_ctable(e.ct[t], e.norm, max, tableLog, e.cumul, e.tableSymbol);
-                            sh.seqLastCount = h;
+                        u64 compressedCost;
+                        {   u32 const tl = ze_fse_optimal_log(fseLog, nbSeq, max, 2);                      // ZSTD_NCountCost
+                            u64 ncount = none;
+                            if (ze_fse_normalize(q.norm, tl, scount, nbSeq, max, nbSeq >= 2048)) { u32 const hb = ze_fse_write_ncount(q.ncount, q.norm, max, tl); ncount = hb ? (u64)hb : none; }
+                            u32 cost = 0;                                                                  // ZSTD_entropyCost
+                            for (u32 s = 0; s <= max; s++) { u32 nr = (256u * scount[s]) / nbSeq; if (scount[s] != 0 && nr == 0) nr = 1; cost += scount[s] * ze_k_invprob[nr]; }
+                            compressedCost = (ncount << 3) + (u64)(cost >> 8);
+                        }
+                        type = (basicCost <= none && basicCost <= compressedCost) ? 0u : 2u;               // (repeatCost = ERROR(GENERIC): basic wins ties against it)
+                    }
+                    u32 h = 0, need = 0;
+                    u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];
+                    if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; h = 1; }
+                    else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, q.cumul, q.tableSymbol);
+                    else if (type == 2) {
+                        u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
+                        if (scount[lastCode] > 1) { scount[lastCode]--; nbSeq1--; }
+                        ze_fse_normalize(q.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048);
+                        h = ze_fse_write_ncount(q.ncount, q.norm, max, tableLog, &need);
+                        ze_fse_build_ctable(e.ct[t], q.norm, max, tableLog, q.cumul, q.tableSymbol);
+                    }
+                    q.type = type; q.h = h; q.need = need; q.first = firstCode;
+                }
+                g.sync();
+                GRP_SERIAL(g) {
+                    u32 at = pos;
+                    for (u32 t = 0; t < 3; t++) {                             // LL, OF, ML in stream order
+                        ZESeqScr const& q = scr[t];
+                        u32 const type = q.type, h = q.h;
+                        if (type == 1) { body[at] = (u8)q.first; if (at >= capBody) sh.tight = 1; }   // ZSTD_buildCTable, set_rle: "not enough space" (zstd_compress_sequences.c:255)
+                        else if (type == 2) {
+                            for (u32 k = 0; k < h; k++) body[at + k] = q.ncount[k];
+                            if ((u64)at + q.need > capBody) sh.tight = 1;                              // FSE_writeNCount into what is left (zstd_compress_sequences.c:279-280)
                         }
                         sh.seqType[t] = type; sh.seqHdr[t] = h;
-                        sh.tmp[3] = (type == 3 && !sh.ctDict[t]) ? 1u : 0u;    // e.ct[t] has to be (re)loaded from the dictionary
+                        sh.tmp[3 + t] = (type == 3 && !sh.ctDict[t]) ? 1u : 0u;    // e.ct[t] has to be (re)loaded from the dictionary
                         sh.ctDict[t] = (type == 3) ? 1u : 0u;
                         if (t == 0) sh.seqLastCount = (type == 2) ? h : 0;
                         else if (type == 2) sh.seqLastCount = h;
+                        at += h;
                     }
-                    g.sync();
-                    if (ZJ_UNI(sh.tmp[3])) {
+                    sh.tmp[1] = at;
+                }
+                g.sync();
+                for (u32 t = 0; t < 3; t++) {
+                    if (ZJ_UNI(sh.tmp[3 + t])) {
                         const u32* const from = (const u32*)&cd->fse[t]; u32* const to = (u32*)&e.ct[t];
                         GRP_FOR(g, i, (u32)(sizeof(ZEFseCT) / 4)) to[i] = from[i];
-                        g.sync();
                     }
-                    pos += ZJ_UNI(sh.seqHdr[t]);
                 }
+                g.sync();
+                pos = ZJ_UNI(sh.tmp[1]);
                 pf.mark(5);
                 // ---- ZSTD_encodeSequences_body (zstd_compress_sequences.c:291-382), restructured for the wave:
                 //      per 64 sequences (last -> first) the records are staged into LDS, the per-symbol

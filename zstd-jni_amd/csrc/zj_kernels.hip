@@ -1199,7 +1199,10 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
             else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
                                (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
-            if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) {
+                (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st);          // the side kernel must not outlive this call's claim on the scratch
+                return ZJNI_ERR(ZJNI_ERROR_no_device);
+            }
         }
         if (d->decStat) (void)hipMemcpyAsync((void*)d->decStat, c + 8, 8, hipMemcpyDeviceToHost, st);
         (void)hipEventRecord(d->tev[5], st);
@@ -1465,6 +1468,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                needGateMap, needReady, needSelective, needPick, needCtr + 1);
             zj_dbg_sync("zj_enc_worth_kernel");
         }
+        // an error return after work has been queued on the side streams must not leave it running over scratch the next call reuses
+        auto bail = [&](size_t code) { (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(d->waveStream); (void)hipStreamSynchronize(st); return code; };
         if (overlap) {
             // The entropy kernel runs on a side stream BESIDE the match kernel and consumes its completion queue:
             // frames that parse quickly are entropy-coded while the slow ones still occupy their lanes (the match
@@ -1472,13 +1477,13 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             // kernel did not get to (its waits are bounded), so completion never depends on the two kernels
             // actually being co-scheduled.
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-            if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-            if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
+            if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
                 u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
                 hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), getenv("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                    (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr);
-                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
                 zj_dbg_sync("zj_enc_need_kernel");
             }
             (void)hipEventRecord(d->tev[0], st);
@@ -1486,7 +1491,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                 u32 const gw = (u32)(n < (size_t)d->waveGrid ? n : (size_t)d->waveGrid);
                 hipLaunchKernelGGL(zj_enc_match_wave_kernel, dim3(gw), dim3(64), sizeof(ZWLds), d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                    listM, (const u32*)ctr, work2, fscratch, maxSrc, meta, doneList, mctr + 1);
-                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machines (0 = the machine's own)
             if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
@@ -1509,17 +1514,17 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                hybrid ? work2 : (unsigned long long*)nullptr);
             d->lastRoute = hybrid ? ZJ_ROUTE_HYBRID : ZJ_ROUTE_LANE;
             } else d->lastRoute = ZJ_ROUTE_WAVE;
-            if (needGate && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (needGate && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             zj_dbg_sync("match kernel");
-            if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
             // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
-            if (needGate && !getenv("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (needGate && !getenv("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
-            if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, mctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 2u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
