@@ -11,6 +11,8 @@ config (config.workload names it in the JSON line):
   3       65,536 x 64 KiB, level 1 (ZSTD_fast) compress, frames checked by the reference                   value = compress
   4       2^20 x 4 KiB JSON-like records, one trained ZstdDictCompress, level 3                              value = compress
   5shape  65,536 x 128 KiB, level 3, compress + decompress (config 5's buffer shape on one GPU)              value = both ways
+  5       BASELINE config 5 itself: 2^20 x 128 KiB buffers over the job, 2^20 / N per GPU (131,072 at N = 8), level 3, both ways, in chunks of
+          65,536 buffers that reuse the device buffers (a chunk's input is generated in HBM before its timed region)         value = both ways
 One step = one GPU pass of the config's direction(s) over the whole batch, inputs resident in HBM when the timed region
 starts.  At N>1 every rank runs the same per-GPU batch on different buffer indices (weak scaling) and the packed compressed
 output is gathered to rank 0 over RCCL inside the step.
@@ -54,6 +56,8 @@ CONFIGS = {
     "3": dict(level=1, n=65536, size=65536, mode="both", headline="compress", metric="GiB/s batched compress level 1, 65 536 x 64 KiB (BASELINE config 3)"),
     "4": dict(level=3, n=1 << 20, size=4096, mode="dict", headline="compress",
               metric="GiB/s level-3 compress with a shared ZstdDictCompress, 2^20 x 4 KiB JSON-like records (BASELINE config 4)"),
+    "5": dict(level=3, n=1 << 20, size=131072, mode="both", headline="both",
+              metric="GiB/s compress+decompress, 2^20 x 128 KiB buffers sharded over the GPUs of one node, level 3 (BASELINE config 5)"),
     "5shape": dict(level=3, n=65536, size=131072, mode="both", headline="both",
                    metric="GiB/s compress+decompress (L3, 64Ki x 128KiB: BASELINE config 5's buffers on one GPU)"),
 }
@@ -74,6 +78,7 @@ def parse():
     ap.add_argument("--e2e-sample", type=int, default=65536, help="buffers in the end-to-end (host-pointer) leg (at most 4 GiB of them), 0 = skip")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of compressed output")
     ap.add_argument("--skip-lds3", action="store_true", help="skip the extra level-3 pass with the LDS-sized tables (hashLog 14 / chainLog 13)")
+    ap.add_argument("--multi", default="", choices=["", "inprocess"], help="inprocess: also time zjni_compress_batch_multi / zjni_decompress_batch_multi (one process, a thread per visible GPU, host pointers) on a sample")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
     return ap.parse_args()
 
@@ -184,6 +189,120 @@ def end_to_end_leg(zj, host, size, m, level, cd, dd):
             "roundtrip_exact": ok}
 
 
+def config5(a, zj, dev, rank, world, cfg):
+    """BASELINE config 5: 2^20 x 128 KiB buffers over the whole job (strong scaling: 2^20 / N per GPU), in chunks of 65 536 buffers per GPU that
+    reuse one set of device buffers.  Timed: compress -> pack -> (gather to rank 0, posted beside) decompress of every chunk, HIP events around each
+    chunk on the launch stream; a chunk's input is generated in HBM between the timed regions (a 128 GiB input does not stay resident beside the
+    work buffers).  value = job bytes / (max over ranks of the summed chunk times)."""
+    from zstd_jni_amd import shard
+    B = zj.batch; L = zj.lib()
+    size, level = cfg["size"], cfg["level"]
+    per_gpu = (cfg["n"] if not a.buffers else a.buffers) // world
+    chunk = min(per_gpu, 65536)
+    chunks = (per_gpu + chunk - 1) // chunk
+    bound = zj.Zstd.compressBound(size)
+    src = torch.empty(chunk * size, dtype=torch.uint8, device=dev); back = torch.empty_like(src)
+    comp = torch.empty(chunk * bound, dtype=torch.uint8, device=dev); packed = torch.empty_like(comp)
+    src_off = B.uniform_offsets(chunk, size, dev); comp_off = B.uniform_offsets(chunk, bound, dev)
+    packed_off = torch.zeros(chunk + 1, dtype=torch.int64, device=dev)
+    csz = torch.empty(chunk, dtype=torch.int64, device=dev); dsz = torch.empty(chunk, dtype=torch.int64, device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    tot_c = tot_d = tot_all = 0.0; csum = 0; exact = True; stage = []
+    def one_pass(timed):
+        nonlocal tot_c, tot_d, tot_all, csum, exact
+        for c in range(chunks):
+            m = min(chunk, per_gpu - c * chunk)
+            s = B.synth(m, size, rank * per_gpu + c * chunk, dev); src[:m * size].copy_(s); del s
+            torch.cuda.synchronize()
+            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+            e0.record(); B.compress(src[:m * size], src_off[:m + 1], comp, comp_off[:m + 1], level, csz[:m]); e1.record()
+            B.pack(csz[:m], comp, comp_off[:m + 1], out=packed, out_off=packed_off[:m + 1]); e2.record()
+            handle = None
+            if world > 1 and not a.no_gather:
+                handle = shard.gather_packed_start(packed[:int(packed_off[m].item())], csz[:m], dst=0)
+            B.decompress(packed, packed_off[:m + 1], back, src_off[:m + 1], dsz[:m])
+            if handle is not None:
+                shard.gather_packed_finish(handle)
+            e3.record(); torch.cuda.synchronize()
+            if timed:
+                tot_c += e0.elapsed_time(e1); tot_d += e2.elapsed_time(e3); tot_all += e0.elapsed_time(e3)
+                csum += int(csz[:m].clamp(min=0).sum().item()); stage.append(B.last_timing())
+                exact = exact and bool((csz[:m] > 0).all()) and bool((dsz[:m] == size).all()) and torch.equal(back[:m * size], src[:m * size])
+    for _ in range(max(a.warmup, 0) and 1):
+        one_pass(False)                               # (one warm-up pass allocates the library's scratch: a pass is 16 chunks at N = 1)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_pass(True)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([tot_all, tot_c, tot_d], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot_all, tot_c, tot_d = (float(x) for x in t.tolist())
+    if rank == 0:
+        job = world * per_gpu * size
+        ms = tot_all / a.steps
+        wide = sum(x.get("match_wide", -1.0) for x in stage) / max(len(stage), 1)
+        alg = (per_gpu * size + csum / a.steps) / chunks           # S + C of one chunk = one launch of the wide match kernel
+        out = {"metric": cfg["metric"], "value": job / GIB / (ms / 1e3), "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"2^20 x {size} B mixed-entropy buffers over the job = {per_gpu} per GPU in {chunks} chunks of {chunk}, zstd level 3, one frame per buffer",
+                          "name": "5", "level": level, "buffers_per_gpu": per_gpu, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
+                          "gather": bool(world > 1 and not a.no_gather), "value_is": "both", "timed": "HIP events around every chunk's compress -> pack -> decompress; generation of the next chunk's input lies between"},
+               "compress_GiBps_per_gpu": per_gpu * size / GIB / (tot_c / a.steps / 1e3), "decompress_GiBps_per_gpu": per_gpu * size / GIB / (tot_d / a.steps / 1e3),
+               "wall_ms_per_step_including_generation": wall * 1e3 / a.steps, "ratio": per_gpu * size * a.steps / max(csum, 1),
+               "roofline": {"bound": "hbm", "kernel": "zj_enc_match_wide_kernel", "kernel_ms": wide, "algorithmic_bytes_per_launch": alg,
+                            "achieved": alg / 1e9 / (wide / 1e3) if wide > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": (alg / 1e9 / (wide / 1e3) / HBM_PEAK_GBPS) if wide > 0 else None, "traffic": None},
+               "cpu_baseline": None, "parity": {"gpu_roundtrip_exact": bool(exact)},
+               "library": {"build_stamp": L.zjni_build_stamp().decode()}}
+        if not a.skip_cpu and world == 1:
+            from oracle import ref
+            k = 256
+            hk = src[:k * size].cpu().numpy(); zs = csz[:k].cpu().tolist(); blob = comp[:k * bound].cpu().numpy()
+            out["parity"]["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + zs[i]].tobytes() == ref.compress(hk[i * size:(i + 1) * size].tobytes(), level) for i in range(k))
+            out["cpu_baseline"] = cpu_baseline_leg(a, src[:4096 * size].cpu().numpy(), size, 4096, level, None)
+            out["cpu_baseline"]["sample"] = "4096 x 131072 B of the last chunk; " + out["cpu_baseline"]["sample"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def multi_inprocess_leg(zj, host, size, m, level):
+    """one process, a host thread per visible GPU (zjni_compress_batch_multi / zjni_decompress_batch_multi, the JVM's case): mode 0 = every device returns
+    its frames over its own PCIe link; mode 1 = frames packed and peer-copied to devices[0] first (the xGMI gather)"""
+    L = zj.lib()
+    nd = torch.cuda.device_count()
+    devs = (C.c_int * nd)(*range(nd))
+    bound = zj.Zstd.compressBound(size)
+    src = np.ascontiguousarray(host[:m * size]); comp = np.empty(m * bound, dtype=np.uint8); back = np.empty(m * size, dtype=np.uint8)
+    vp = lambda base, stride: (C.c_void_p * m)(*[base + i * stride for i in range(m)])
+    sp, cp, bp = vp(src.ctypes.data, size), vp(comp.ctypes.data, bound), vp(back.ctypes.data, size)
+    ss = (C.c_size_t * m)(*([size] * m)); cc = (C.c_size_t * m)(*([bound] * m)); res = (C.c_size_t * m)(); res2 = (C.c_size_t * m)()
+    L.zjni_compress_batch_multi.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.zjni_decompress_batch_multi.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_int]
+    out = {"devices": nd, "sample": f"{m} x {size} B from host pointers"}
+    for mode in (0, 1):
+        best = 1e30
+        for it in range(3):
+            t0 = time.perf_counter(); r = L.zjni_compress_batch_multi(sp, ss, cp, cc, res, m, level, 0, devs, nd, mode); t1 = time.perf_counter()
+            assert not L.zjni_isError(r), r
+            if it: best = min(best, t1 - t0)
+        out[f"compress_mode{mode}_GiBps"] = m * size / GIB / best
+    cs = (C.c_size_t * m)(*[res[i] for i in range(m)])
+    best = 1e30
+    for it in range(3):
+        t0 = time.perf_counter(); r = L.zjni_decompress_batch_multi(cp, cs, bp, ss, res2, m, devs, nd); t1 = time.perf_counter()
+        assert not L.zjni_isError(r), r
+        if it: best = min(best, t1 - t0)
+    out["decompress_GiBps"] = m * size / GIB / best
+    out["roundtrip_exact"] = all(res2[i] == size for i in range(m)) and bool((back == src).all())
+    return out
+
+
 def main():
     a = parse()
     cfg = dict(CONFIGS[a.config])
@@ -205,6 +324,8 @@ def main():
     zj.batch.init(local)
     dev = torch.device("cuda", local)
     B = zj.batch
+    if a.config == "5":
+        return config5(a, zj, dev, rank, world, cfg)
     first = rank * n                              # disjoint buffer indices per rank (weak scaling)
     from zstd_jni_amd import shard
 
@@ -327,7 +448,7 @@ def main():
     ok_sizes = bool((csz > 0).all()) and bool((dsz == size).all())
     roundtrip = ok_sizes and torch.equal(back, src)
     csum = int(csz.clamp(min=0).sum().item())
-    cpu = None; e2e = None
+    cpu = None; e2e = None; multi = None
     gates = {"gpu_roundtrip_exact" if mode != "decode_ref" else "gpu_decodes_reference_frames_bit_exact": bool(roundtrip)}
     if rank == 0 and not a.skip_cpu:
         from oracle import port, ref
@@ -385,6 +506,11 @@ def main():
             gpu_c_sample = int(csz[:m].sum().item())
             gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
             gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
+            if a.multi == "inprocess":
+                try:
+                    multi = multi_inprocess_leg(zj, host_src, size, max(1, min(m, 32768, (2 << 30) // size)), level)
+                except Exception as ex:
+                    multi = {"error": f"{type(ex).__name__}: {ex}"}
             if a.e2e_sample:
                 me = max(1, min(a.e2e_sample, n, m, (4 << 30) // size))         # (m: what the host has room for, see above)
                 try:
@@ -463,7 +589,7 @@ def main():
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg_launch, "request_roof": request_roof,
                          "decompress_path": {"achieved": alg / 1e9 / (md / 1e3), "frac": alg / 1e9 / (md / 1e3) / HBM_PEAK_GBPS},
                          "compress_path": ({"achieved": alg / 1e9 / (mc / 1e3), "frac": alg / 1e9 / (mc / 1e3) / HBM_PEAK_GBPS} if mode != "decode_ref" else None)},
-            "cpu_baseline": cpu, "end_to_end": e2e, "parity": gates,
+            "cpu_baseline": cpu, "end_to_end": e2e, "multi_inprocess": multi, "parity": gates,
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,6 +1,7 @@
 """GPU (-m gpu): batched decompress through the C-ABI (libzjni_amd.so, wave64 kernels) is bit-exact
 against the reference's golden frames and against frames produced by the reference's libzstd."""
 import hashlib
+import random
 import os
 
 import pytest
@@ -78,6 +79,33 @@ def test_gpu_per_buffer_api_and_errors(gpu, oracle_ref):
     src = b"\xAA" * 7 + z + b"\xBB" * 5
     n = dctx.decompressByteArray(dst, 10, len(data), src, 7, len(z))
     assert n == len(data) and bytes(dst[10:10 + n]) == data and dst[:10] == bytes(10)
+
+
+def test_gpu_host_batch_capacities_and_pipeline(gpu, oracle_ref):
+    """zjni_decompress_batch from host pointers: the three-stage pipeline over slices (more than one slice here), destinations larger than the
+    content (staging is sized by the frames' own content sizes where a buffer is one frame that states it), concatenated frames, an empty frame and a damaged frame whose header understates its content — answered like the reference decoding into the caller's capacity."""
+    rnd = random.Random(12)
+    datas = [gpu.synth_host(65536, k, 1) for k in range(6000)]                      # ~375 MiB of output: several 256 MiB-class slices
+    frames = [oracle_ref.compress(d, 1 + k % 3) for k, d in enumerate(datas)]
+    caps = [len(d) * (1 + k % 4) + (k % 7) for k, d in enumerate(datas)]            # up to 4x the content and odd
+    extra_d, extra_f, extra_c, want = [], [], [], []
+    a, b = gpu.synth_host(30000, 77, 1), gpu.synth_host(20000, 78, 1)
+    extra_f.append(oracle_ref.compress(a, 3) + oracle_ref.compress(b, 1)); extra_c.append(60000); want.append(a + b)               # two frames in one buffer
+    extra_f.append(oracle_ref.compress(b"", 3)); extra_c.append(16); want.append(b"")
+    z = bytearray(oracle_ref.compress(a, 3)); assert z[4] & 0xC0 == 0x40 and z[4] & 0x20                                           # single segment, 2-byte content size
+    z[5:7] = (int.from_bytes(z[5:7], "little") - 300).to_bytes(2, "little")                                                       # header now says 300 bytes fewer than the blocks hold
+    try:
+        oracle_ref.decompress(bytes(z), 200000); code = None
+    except oracle_ref.ZstdRefError as e:
+        code = e.code
+    assert code is not None
+    extra_f.append(bytes(z)); extra_c.append(200000); want.append(-code)
+    outs = gpu.decompress_batch(frames + extra_f, caps + extra_c)
+    for k, d in enumerate(datas):
+        assert outs[k] == d, k
+    for o, w in zip(outs[len(datas):], want):
+        if isinstance(w, int): assert isinstance(o, Exception) and o.getErrorCode() == -w, (o, w)
+        else: assert o == w
 
 
 @pytest.mark.parametrize("size,count", [(4096, 2048), (65536, 1024), (131072, 256)])

@@ -181,6 +181,10 @@ struct ZLaneR {
         u32 const qf0 = zl_fwd_at(n, fa0), qf1 = zl_fwd_at(n, fa1);
         u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
         u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0, rf0 = 0; u32 rf1 = 0, t0 = 0, t1 = 0;
+#ifdef ZR_COUNT_SLOT                                          /* analysis builds: which load slots a frame activates (tools, never the product) */
+        ZR_COUNT_SLOT(0, v0); ZR_COUNT_SLOT(1, v1); ZR_COUNT_SLOT(2, v2); ZR_COUNT_SLOT(3, v3); ZR_COUNT_SLOT(4, (K & ZL_EN_COUNT) && v4); ZR_COUNT_SLOT(5, (K & ZL_EN_COUNT) && vb);
+        ZR_COUNT_SLOT(6, vf0); ZR_COUNT_SLOT(7, (K & (ZL_EN_COUNT | ZL_EN_POST)) && vf1); ZR_COUNT_SLOT(8, vt0); ZR_COUNT_SLOT(9, vt1);
+#endif
         if (v0) r0 = ld64(src + q0);
         if (v1) r1 = ld64(src + q1);
         if (v2) r2 = ld64(src + q2);
