@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as e
-zj = e.load_package(); L = zj.lib()
+zj = e.load_package()
+if os.environ.get('ZJNI_LIB'): zj.LIB_PATH = os.environ['ZJNI_LIB']      # an experimental build of the library
+L = zj.lib()
 from oracle import ref
 hip = C.CDLL("libamdhip64.so")
 vp = C.c_void_p
@@ -40,9 +42,17 @@ ev = [vp() for _ in range(4)]
 for x in ev: chk(hip.hipEventCreate(C.byref(x)))
 tc = td = 0.0
 h_csz = np.zeros(n, dtype=np.uint64)
+PROF = bool(os.environ.get("ZJNI_PROFILE")) and hasattr(L, "zjni_debug_read_profile")
+enc_phase = None
+def read_prof():
+    a = (C.c_ulonglong * 32)(); L.zjni_debug_read_profile.argtypes = [vp]; assert L.zjni_debug_read_profile(a) == 0; return list(a)
 for it in range(steps + 1):
+    if PROF and it == steps: read_prof()
     chk(hip.hipEventRecord(ev[0], None)); chk(L.zjni_compress_batch_device_usingCDict(src, soff, comp, coff, csz, n, cd, 0, None)); chk(hip.hipEventRecord(ev[1], None))
     chk(hip.hipDeviceSynchronize())
+    if PROF and it == steps:
+        pe = read_prof(); names = ["params+zero", "match find(l0)", "lit gather+codes", "hist+huf build", "huf encode", "seq tables", "seq encode(l0)", "block place"]
+        enc_phase = {names[i]: round(pe[16 + i] / n / 1e3, 1) for i in range(8)}
     chk(hip.hipMemcpy(h_csz.ctypes.data_as(vp), csz, C.c_size_t(n * 8), 2))
     h_poff = np.zeros(n + 1, dtype=np.uint64); h_poff[1:] = np.cumsum(h_csz)
     chk(hip.hipMemcpy(poff, h_poff.ctypes.data_as(vp), C.c_size_t((n + 1) * 8), 1))
@@ -57,6 +67,6 @@ h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp)
 hb = np.zeros(n * size, dtype=np.uint8); chk(hip.hipMemcpy(hb.ctypes.data_as(vp), back, C.c_size_t(n * size), 2))
 hs = np.zeros(n * size, dtype=np.uint8); chk(hip.hipMemcpy(hs.ctypes.data_as(vp), src, C.c_size_t(n * size), 2))
 GiB = n * size / 2.0**30
-print(json.dumps({"n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "decompress_ms": td / steps,
+print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "entropy_kcycles_per_frame": enc_phase, "n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "decompress_ms": td / steps,
                   "compress_GiBps": GiB / (tc / steps / 1e3), "decompress_GiBps": GiB / (td / steps / 1e3),
                   "ratio": n * size / float(h_csz.sum()), "round_trip": bool((h_dsz == size).all() and (hb == hs).all())}))

@@ -1743,11 +1743,14 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; atomicAdd(&cnt3[s.ll >> 24], 1u); atomicAdd(&cnt3[64 + (s.off >> 24)], 1u); atomicAdd(&cnt3[128 + (s.ml >> 24)], 1u); }
                 g.sync();
                 // ZSTD_buildSequencesStatistics: the three tables (LL, OF, ML) are independent — normalisation, table description and
-                // encoding table each on a lane of its own (lane t = table t), into scratch of its own in the idle tree area; what depends
-                // on the ORDER — where a description lands in the block, the capacity tests there, "last count" — follows on one lane.
+                // encoding table each into scratch of its own in the idle tree area; what depends on the ORDER — where a description
+                // lands in the block, the capacity tests there, "last count" — follows.  One lane does all three: with a lane per table
+                // (lane t = table t) this phase fell 39 -> 31 K cycles a frame, but the divergent table index cost the kernel 50 VGPRs
+                // (174 -> 223, two waves a SIMD instead of three) and the match kernel running BESIDE it lost its co-residency: whole
+                // calls got 8-17 % slower (profiles/r03/i_entropy_vgpr_ab.txt).
                 struct ZESeqScr { short norm[64]; u16 cumul[64]; u8 tableSymbol[512]; u8 ncount[128]; u32 need, h, type, first; };
                 ZESeqScr* const scr = (ZESeqScr*)e.node;                      // 3 x 912 bytes of the 4 128 (the Huffman tree is done with)
-                for (u32 t = g.lane(); t < 3u; t += (u32)G::W) {
+                GRP_SERIAL(g) for (u32 t = 0; t < 3u; t++) {
                     ZESeqScr& q = scr[t];
                     u32* const scount = cnt3 + 64 * t;
                     u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;

@@ -565,7 +565,9 @@ __global__ __launch_bounds__(256) void zj_zero_slots_kernel(u8* base, u32 stride
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < total16; j += (size_t)gridDim.x * 256) w[j] = make_uint4(0, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(64) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
+// At most 168 VGPRs (three waves a SIMD): this kernel runs BESIDE the match kernels, and what it takes of the register file they
+// cannot have — at 223 VGPRs the dictionary match kernel ran 16.5 -> 20.8 ms a slice (profiles/r03/i_entropy_vgpr_ab.txt).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void zj_encode_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff,
                                                         u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                         u64* __restrict__ result, u32 level, const u32* __restrict__ list,
                                                         const u32* countPtr, u32* workCounter, u8* scratch, unsigned long long* prof,
