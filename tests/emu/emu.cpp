@@ -150,7 +150,7 @@ extern "C" unsigned emu_check_code_tables() {
 
 // split pipeline: lane-per-frame match finding into HBM scratch, then the entropy stage; frames the classification
 // kernel would put on list B (> 64 KiB, or fast-strategy tables beyond the common size) take the wide launch's layout
-static int g_emu_force_gated = 0, g_emu_run = 0;
+static int g_emu_force_gated = 0, g_emu_run = 0, g_emu_late = 0;
 extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);
     if (srcSize > ZE_BLOCK_MAX) return ZJ_ERR64(201);
@@ -172,14 +172,22 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
             ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));
             nflags = (u8*)malloc(srcSize + ZN_FLAG_SLACK); memset(nflags, 0xFF, srcSize + ZN_FLAG_SLACK);
             char const nm = getenv("ZJNI_EMU_NEED")[0];         // ZLaneD: 1 flags for every frame, 2 for the picked frames (the others run the gated machine without flags)
-            g_emu_run = (nm == '5' || nm == '6' || nm == '7');  // the run machine (zj_match_run.h): 5 flags for every frame, 6 for the picked frames, 7 for none
+            g_emu_run = (nm == '5' || nm == '6' || nm == '7' || nm == '8');  // the run machine (zj_match_run.h): 5 flags for every frame, 6 for the picked frames, 7 for none, 8: for every frame but LATE (taken over after a frame-dependent number of rounds, as the match kernel does when the flag kernel is still at work)
+            g_emu_late = (nm == '8');
             bool const take = nm != '7' && ((nm != '2' && nm != '6') || zn_worth(one, (u32*)L, src, srcSize));
             if (take) zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
             else { free(nflags); nflags = nullptr; g_emu_force_gated = 1; }
             if (nflags && getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
             free(L);
         } }
-    if (g_emu_run && srcSize >= ZL_MIN_FRAME) {
+    if (g_emu_run && g_emu_late && nflags && srcSize >= ZL_MIN_FRAME) {
+        ZLaneR<ZEEntTag> m; m.init(src, srcSize, ze_params_of(lw, srcSize), table, fs, maxSrc, nullptr);
+        u32 h = srcSize * 2654435761u; for (u32 i = 0; i < srcSize && i < 64u; i++) h = (h ^ src[i]) * 16777619u;
+        u32 const lateRound = (h >> 8) % (srcSize / 2u + 1u);              // anywhere in the frame's first part (a frame takes between srcSize / 8 and srcSize rounds)
+        for (u32 r = 0; m.st != ZL_DONE; r++) { m.round(m.phase_of(r)); if (r == lateRound) m.take_flags(nflags); }
+        meta[0] = m.o.n; meta[1] = m.o.lit + m.lastLL; meta[2] = m.lastLL;
+        g_emu_force_gated = 0; g_emu_late = 0;
+    } else if (g_emu_run && srcSize >= ZL_MIN_FRAME) {
         if (getenv("ZJNI_EMU_JMAX")) { if (atoi(getenv("ZJNI_EMU_JMAX")) == 3) ze_match_lane_t<ZLaneR<ZEEntTag, 3u> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags); else ze_match_lane_t<ZLaneR<ZEEntTag, 7u> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags); }
         else ze_match_lane_t<ZLaneR<ZEEntTag> >(src, srcSize, lw, table, fs, maxSrc, meta, nflags);
         g_emu_force_gated = 0;

@@ -162,14 +162,14 @@ def test_emu_tight_destinations(emu, oracle_ref, zj):
     assert seen["refused although it fits"] > 500 and seen["raw instead"] > 0, seen
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "5", "6", "7", "5j3", "6j7"])
+@pytest.mark.parametrize("mode", ["1", "2", "5", "6", "7", "8", "5j3", "6j7"])
 def test_emu_need_gated_double_fast(emu, oracle_ref, zj, monkeypatch, mode):
     """the need-gated double-fast machine (zj_need.h, ZJNI_NEED=1 in the library; ZJNI_EMU_NEED=1 here): table probes are made only where some
     other position of the frame carries the probe's key, table writes only into buckets such a probe reads — decided per position by Bloom
     filters ahead of the parse.  Same frames as the ungated machine = the reference's (tools/fuzz_emu_need.py: 1.8 million frames in both modes, 0 differences)."""
     monkeypatch.setenv("ZJNI_EMU_NEED", mode[0])              # ZLaneD: 1 flags for every frame, 2 only for the frames zn_worth() picks (the gated machine without flags for the rest);
     if len(mode) > 1:                                         # the run machine (zj_match_run.h, the product's large-batch level-3 machine): 5 flags for every frame, 6 for the
-        monkeypatch.setenv("ZJNI_EMU_JMAX", mode[2])          # picked ones, 7 for none; jN: runs of up to N quiet positions per round instead of the default
+        monkeypatch.setenv("ZJNI_EMU_JMAX", mode[2])          # picked ones, 7 for none, 8 for every frame but taken over LATE (mid-frame, as the match kernel does while the flag kernel is still at work); jN: runs of up to N quiet positions per round
     rnd = random.Random(41)
     datas = [zj.synth_host(65536, k, 1) for k in range(8)] + [zj.synth_host(s, 100 + s, 1) for s in (64, 65, 1000, 8192, 8193, 30000, 65535)]
     datas += [bytes([7]) * 40000, bytes(rnd.getrandbits(8) for _ in range(20000)), (b"abcdefgh" * 5000)[:33333], golden("xmlsmall")[:60000]]

@@ -260,10 +260,10 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
 #ifdef ZL_PROFILE
     u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0;
 #endif
-    bool have = false, pend = false; u32 k = 0; u64 tPend = 0;
+    bool have = false, pend = false, late = false; u32 k = 0; u64 tPend = 0;
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : M::default_period(); u32 ph = 0;   // double-fast machines: rounds per rotation of the non-search states
     for (u32 r = 0;; r++) {
-        if (pend) {                                       // a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
+        if (pend) {                                       // (machines that cannot take their flags late) a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
             bool const rdy = __hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (rdy || wall_clock64() - tPend > 5000000ull) {
                 if (rdy) __threadfence();
@@ -278,6 +278,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                 u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false;
                 zj_publish_done(doneList, doneCount, k);
             }
+            late = false;
             if (work2) { if (!zj_claim_front(work2, k)) break; }
             else {
             k = atomicAdd(workCounter, 1u);
@@ -287,13 +288,19 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
             if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
-            if (flagsBase && gate[k]) { pend = true; tPend = wall_clock64(); }
-            else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = true; }
+            bool const flagged = flagsBase && gate[k];
+            if (flagged && !M::takes_flags_late()) { pend = true; tPend = wall_clock64(); }
+            else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = true; late = flagged; }
         }
+        // A frame whose flags are still being computed starts WITHOUT them and takes them over when they arrive (flags only ever remove work, and what
+        // they say about a position does not depend on when it is asked): once per rotation the lane asks; the request travels with the round's own loads.
+        u32 rdyNow = 0;
+        if (M::takes_flags_late() && late && ph == 0u) rdyNow = __hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef ZL_PROFILE
         zlRounds++;
 #endif
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
+        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * ZN_FLAG_STRIDE); late = false; }
         ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
@@ -318,9 +325,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 
 // ---- need-gated level 3 (zj_need.h; ZJNI_NEED = 2 by default: flags for the frames zn_worth() picks) ----
 // zj_enc_worth_kernel decides per frame whether it gets flags (gate[k]); zj_enc_need_kernel — one workgroup of 512 lanes per picked frame, Bloom
-// filters in LDS — computes the flag bytes (which probes can match, which writes can be read) BESIDE the match kernel, whose lanes wait (bounded)
-// for ready[k] before they start a picked frame; the frames that are not picked start at once.  The flags only ever remove work, so a lane whose
-// wait runs out starts its frame without them.
+// filters in LDS — computes the flag bytes (which probes can match, which writes can be read) BESIDE the match kernel.  Every frame starts at once;
+// a lane with a picked frame asks for ready[k] once per rotation and takes the flags over mid-frame when they are there (the run machine: what a flag
+// says about a position does not depend on when it is asked, and until then every flag counts as set).  Nothing ever waits for the flag kernel: if it
+// is late, or never scheduled beside the match kernel, frames simply run longer without flags (148 against 152 ms with the bounded wait this replaced,
+// profiles/r03/l_late_flags_ab.txt).  The older gated machine (ZJNI_LANE_MACHINE=0) still waits, bounded by 50 ms, and then runs unflagged.
 struct ZNThreads {
     __device__ __forceinline__ u32 id() const { return threadIdx.x; }
     __device__ __forceinline__ u32 count() const { return blockDim.x; }

@@ -148,6 +148,8 @@ struct ZLaneD {
 
     ZJ_DEVM u32 phase_of(u32 r) { return r % ZL_DFAST_PERIOD; }
     ZJ_DEVM u32 default_period() { return ZL_DFAST_PERIOD; }
+    ZJ_DEVM bool takes_flags_late() { return false; }
+    ZJ_DEV_MEMBER void take_flags(const u8*) {}
     ZL_PROF_MEMBERS
     // Round r of the wavefront.  A searching lane advances every round; the other states take turns (r mod 8:
     // count/backward, post-insert/reload, restart in consecutive rounds, then five search-only rounds), so a
@@ -379,6 +381,8 @@ struct ZLaneF {
 
     ZJ_DEVM u32 phase_of(u32 r) { return r; }
     ZJ_DEVM u32 default_period() { return ZL_DFAST_PERIOD; }      // (unused: the fast machine rotates on the round number itself)
+    ZJ_DEVM bool takes_flags_late() { return false; }
+    ZJ_DEV_MEMBER void take_flags(const u8*) {}
     ZL_PROF_MEMBERS
     // The search state runs every round; count/backward, post-insert/reload and restart take turns (r mod period = 0, 1, 2;
     // see ZLaneD::round).  With one round per pair the kernel sits at ~80 % of the read+write request plateau

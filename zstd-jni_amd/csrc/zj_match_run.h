@@ -110,6 +110,8 @@ struct ZLaneR {
 
     ZJ_DEVM u32 phase_of(u32 r) { return r % ZR_PERIOD; }
     ZJ_DEVM u32 default_period() { return ZR_PERIOD; }
+    ZJ_DEVM bool takes_flags_late() { return true; }                 // flags may arrive while the frame is under way: every use of F tolerates "all set" before
+    ZJ_DEV_MEMBER void take_flags(const u8* flags) { F = flags; }
     ZL_PROF_MEMBERS
     ZJ_DEV_MEMBER void round(u32 r) {                 // see ZLaneD::round: search every round, the other states in turns
         switch (r) {
