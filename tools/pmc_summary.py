@@ -11,10 +11,13 @@ dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain"
 out = {"note": "HBM-side bytes per launch = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
                "(TCC_EA0_RDREQ/WRREQ based). Calibrated on this kernel's access pattern with tools/micro/chase: one random "
                "4-byte read miss tallies 63.7 B, one random 4-byte write tallies 32 B; the x2 correction the guide gives "
-               "for wide streaming reads does not apply to these scattered 4-8 byte accesses, so values are uncorrected.",
+               "for wide streaming reads does not apply to these scattered 4-8 byte accesses, so values are uncorrected. "
+               "Counter collection serialises kernels: the level-3 'metric' passes run with ZJNI_NEED_INLINE=1 (flag kernel ahead of the match kernel on one "
+               "stream, so every picked frame has its flags from its first round; in production they arrive beside the match kernel during its first ~30 ms "
+               "of ~150), and 'metricnoflags' (ZJNI_NEED=0) is the same launch with no flags at all: real traffic lies between the two, close to the first.",
        "calibration": {"random_4B_reads_per_launch": 131072000, "FETCH_SIZE_KB": 8149800.7, "WRITE_SIZE_KB_readwrite_launch": 4103834.5},
        "measured_on_commit": head + ("+uncommitted csrc changes" if dirty else ""), "measured_on_date": datetime.date.today().isoformat(),
-       "driver": "tools/measure_round.sh -> tools/prof_driver.py <n> <size> <level> 1"}
+       "driver": "tools/pmc_traffic.sh -> tools/prof_driver.py <n> <size> <level> 1"}
 dst = os.path.join(ROOT, "profiles", rnd + "_pmc"); os.makedirs(dst, exist_ok=True)
 keys = sorted({re.sub(r"_(FETCH|WRITE)_SIZE\.csv$", "", os.path.basename(p)) for p in glob.glob(os.path.join(src, "pmc", "*_SIZE.csv"))})
 for key in keys:

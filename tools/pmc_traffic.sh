@@ -3,22 +3,25 @@
 # rocprofv3 --kernel-trace --stats summary of the same driver command:   gpurun -- 'bash tools/pmc_traffic.sh [tag]'   (the last GPU action of a round)
 # Output under gpurun_out/<tag>/; `python tools/pmc_summary.py gpurun_out/<tag> r03` (where git is) condenses it into profiles/r03_pmc_traffic.json,
 # every record stamped with the zjni_build_stamp() the driver printed — bench.py quotes roofline.traffic only when that equals its own library's.
+# A list line is "<config> <level> <n> <size> [ENV=.. for the --pmc passes only]".  Counter collection SERIALISES kernels, and which of the flag kernel and the match kernel (two streams) it
+# lets go first varies from pass to pass — so the metric line runs with ZJNI_NEED_INLINE=1 (flag kernel ahead of the match kernel on one stream: every frame has its
+# flags from its first round; in production they arrive during the first ~30 ms) and a second key, metricnoflags, with ZJNI_NEED=0 gives the other bound.
 TAG=${1:-r03pmc}
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT/pmc
 cd /tmp; export TMPDIR=/tmp
-while read CFG L N S; do
+while read CFG L N S ENVS; do
   [ -z "$CFG" ] && continue
   KEY=${CFG}_L${L}_${N}x${S}
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$KEY -o s -- python $R/tools/prof_driver.py $N $S $L 3 > $OUT/${KEY}_driver.json 2> $OUT/${KEY}_stats.err
   f=$(find $OUT/stats_$KEY -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${KEY}_kernel_stats.csv
   rm -rf $OUT/stats_$KEY
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc/${KEY}_$C -o p -- python $R/tools/prof_driver.py $N $S $L 1 > $OUT/pmc/${KEY}_${C}_driver.json 2> $OUT/pmc/${KEY}_$C.err
+    timeout 200 env $ENVS rocprofv3 --pmc $C --output-format csv -d $OUT/pmc/${KEY}_$C -o p -- python $R/tools/prof_driver.py $N $S $L 1 > $OUT/pmc/${KEY}_${C}_driver.json 2> $OUT/pmc/${KEY}_$C.err
     f=$(find $OUT/pmc/${KEY}_$C -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $OUT/pmc/${KEY}_$C.csv
     rm -rf $OUT/pmc/${KEY}_$C
   done
   tail -1 $OUT/${KEY}_driver.json | cut -c1-400
 done <<LIST
-${PMC_LIST:-metric 3 65536 65536}
+${PMC_LIST:-metric 3 65536 65536 ZJNI_NEED_INLINE=1}
 LIST
 ls $OUT $OUT/pmc

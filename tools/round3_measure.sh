@@ -17,4 +17,4 @@ except Exception as ex: print("$C FAILED", ex)
 PY
 done
 timeout 300 python bench.py --config 5 --buffers 131072 --steps 2 --warmup 1 > $OUT/bench_config5_two_chunks.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5_two_chunks.json | head -c 300; echo
-PMC_LIST=$'metric 3 65536 65536\n3 1 65536 65536' bash tools/pmc_traffic.sh r03final 2>&1 | tail -8
+PMC_LIST=$'metric 3 65536 65536 ZJNI_NEED_INLINE=1\nmetricnoflags 3 65536 65536 ZJNI_NEED=0\n3 1 65536 65536' bash tools/pmc_traffic.sh r03final 2>&1 | tail -8
