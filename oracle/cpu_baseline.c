@@ -31,7 +31,7 @@ static int ref_open(RefLib* r, const char* path) {
     static void* cached = NULL;
     memset(r, 0, sizeof(*r));
     if (!path) return 0;
-    if (!cached) cached = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!cached) cached = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);     /* its own ZSTD_* first, whatever libzstd the process already has */
     r->h = cached;
     if (!r->h) return -1;
 #define SYM(field, name) *(void**)(&r->field) = dlsym(r->h, name); if (!r->field) return -1;
