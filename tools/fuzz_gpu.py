@@ -98,16 +98,18 @@ for dbytes in (ref.train_dict(samples, 112640), b",".join(recs[:300])):
         print(f"dict level {level}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
 # level 3 on the need-gated machines (zj_need.h): every mode of ZJNI_NEED on the lane pipeline regardless of batch size
 os.environ["ZJNI_SPLIT_MIN"] = "1"
-for mode in ("0", "1", "2", "3", "4"):
+for machine, mode in [(a, b) for a in ("run", "lane") for b in ("0", "1", "2")]:      # the run machine (flags taken over mid-frame, beside the match kernel) and the older gated lane machine
     os.environ["ZJNI_NEED"] = mode
+    if machine == "lane": os.environ["ZJNI_LANE_MACHINE"] = "0"
+    else: os.environ.pop("ZJNI_LANE_MACHINE", None)
     datas = [gen(s) for s in sizes(65536)] + [bytes(rnd.randrange(16) for _ in range(rnd.randrange(4096, 65537))) for _ in range(max(8, n // 10))]
     outs = zj.compress_batch(datas, 3)
     for k, (d, z) in enumerate(zip(datas, outs)):
         want = ref.compress(d, 3)
         if isinstance(z, Exception) or z != want:
             bad += 1; print("MISMATCH need mode", mode, k, len(d), flush=True)
-    print(f"ZJNI_NEED={mode}: done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
-del os.environ["ZJNI_NEED"]; del os.environ["ZJNI_SPLIT_MIN"]
+    print(f"ZJNI_NEED={mode} on the {machine} machine (route {zj.lib().zjni_last_route()}): done, bad so far {bad}, {time.time() - t0:.0f} s", flush=True)
+del os.environ["ZJNI_NEED"]; del os.environ["ZJNI_SPLIT_MIN"]; os.environ.pop("ZJNI_LANE_MACHINE", None)
 # tight destinations: capacities around each frame's size, answers (size, bytes or code) against ZSTD_compress2's for the same capacity
 for level in (1, 3, 5):
     datas, caps, wants = [], [], []
