@@ -12,12 +12,20 @@ def available():
     return os.path.exists(PATH)
 
 
+def _dl_mode():
+    """RTLD_DEEPBIND so that the library binds its own ZSTD_* whatever libzstd the process already holds — except under a
+    sanitizer runtime (tests/test_emu_sanitizer.py preloads libasan), which refuses to dlopen with that flag."""
+    if "asan" in os.environ.get("LD_PRELOAD", ""):
+        return os.RTLD_NOW
+    return os.RTLD_NOW | getattr(os, "RTLD_DEEPBIND", 0)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not available():
             raise RuntimeError(f"{PATH} missing: run `make -C oracle ref` where /root/reference exists")
-        L = C.CDLL(PATH, mode=os.RTLD_NOW | getattr(os, 'RTLD_DEEPBIND', 0))     # its own ZSTD_* first: a profiler (rocprofv3) may have a system libzstd loaded globally
+        L = C.CDLL(PATH, mode=_dl_mode())     # its own ZSTD_* first: a profiler (rocprofv3) may have a system libzstd loaded globally
         L.ZSTD_compressBound.restype = C.c_size_t
         L.ZSTD_compressBound.argtypes = [C.c_size_t]
         L.ZSTD_isError.restype = C.c_uint
@@ -169,7 +177,7 @@ def decompress_portable(frame: bytes, cap: int, dictionary: bytes = None) -> byt
     if _portable is None:
         if not os.path.exists(PORTABLE_PATH):
             raise RuntimeError(f"{PORTABLE_PATH} missing: run `make -C oracle refportable` where /root/reference exists")
-        P = C.CDLL(PORTABLE_PATH, mode=os.RTLD_NOW | getattr(os, 'RTLD_DEEPBIND', 0))
+        P = C.CDLL(PORTABLE_PATH, mode=_dl_mode())
         P.ZSTD_isError.restype = C.c_uint
         P.ZSTD_isError.argtypes = [C.c_size_t]
         P.ZSTD_getErrorName.restype = C.c_char_p
