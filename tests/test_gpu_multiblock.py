@@ -59,6 +59,15 @@ def test_gpu_multiblock_frames_are_the_references(gpu, oracle_ref, level):
             assert b == d
 
 
+def test_gpu_multiblock_level3_one_lane_parse_switch(gpu, oracle_ref, monkeypatch):
+    """level-3 blocks run the wave matcher (zj_match_wavex.h) by default; ZJNI_MULTI_WAVE=0 selects the one-lane parse of rounds 1-3 for
+    A/B runs — the same frames either way"""
+    monkeypatch.setenv("ZJNI_MULTI_WAVE", "0")
+    datas = [d for d in inputs(gpu, oracle_ref, 103, 24) if len(d) <= WINDOW[3]]
+    for d, z in zip(datas, gpu.compress_batch(datas, 3)):
+        assert z == oracle_ref.compress(d, 3), len(d)
+
+
 def test_gpu_one_mebibyte_buffer_like_baseline_config_1(gpu, oracle_ref):
     """BASELINE config 1's shape: Zstd.compress / decompress of a 1 MiB buffer at level 3 — on the GPU now, same bytes as the CPU path"""
     xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)[: 1 << 20]

@@ -1,5 +1,7 @@
 """Randomised byte-identity stress of multi-block frames (ze_compress_multi, lane-serial build of tests/emu) against the reference's
 ZSTD_compress2, 128 KiB < input <= 2 MiB, levels 1-3, with a census of the block / literals types the inputs produced.
+Level-3 blocks run the wave matcher (zj_match_wavex.h, 64 emulated lanes; ZJNI_EMU_LIB=tests/emu/libzjni_emu_rev.so visits them in
+descending order), FUZZ_SERIAL=1 the one-lane parse; FUZZ_LEVELS=3 restricts the levels.
 usage: fuzz_emu_multiblock.py <seed> <seconds>   TEST INFRASTRUCTURE."""
 import os, sys, time, random, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +11,7 @@ import util
 import __graft_entry__ as e
 zj = e.load_package(); L = util.emu_lib()
 seed = int(sys.argv[1]); budget = float(sys.argv[2])
+LEVELS = [int(x) for x in os.environ.get("FUZZ_LEVELS", "1,2,3").split(",")]; SERIAL = os.environ.get("FUZZ_SERIAL") == "1"
 rnd = random.Random(seed)
 recs = util.json_records(20000, seed=seed)
 census = collections.Counter()
@@ -43,8 +46,8 @@ while time.time() - t0 < budget:
         parts.append(piece(rnd.choice([500, 8192, 40000, 131072, 131072, 300000])))
         if rnd.random() < 0.2 and parts: parts.append(parts[rnd.randrange(len(parts))])
     d = b"".join(parts)[:size]
-    lvl = rnd.choice([1, 2, 3]); ck = rnd.random() < 0.2; cs = rnd.random() < 0.85
-    got = util.emu_compress_multi(L, d, lvl, ck, cs)
+    lvl = rnd.choice(LEVELS); ck = rnd.random() < 0.2; cs = rnd.random() < 0.85
+    got = util.emu_compress_multi(L, d, lvl, ck, cs, SERIAL)
     if len(d) > (1 << (18 + lvl)):
         ok = got == -201
     else:

@@ -1,0 +1,334 @@
+// zj_match_wavex.h — wave-per-frame double-fast match finder for ONE BLOCK of a multi-block frame (level 3, inputs above 128 KiB),
+// hash tables and frame in HBM.
+//
+// A multi-block frame is a chain: block k's parse reads the table entries and repcodes blocks 0 .. k-1 left behind
+// (N/compress/zstd_compress.c:4591-4692, N/compress/zstd_double_fast.c:105-323), so a frame cannot be spread over lanes the way a batch
+// of small frames is, and a frame's tables (2^17 + 2^16 entries) do not fit the LDS.  Rounds 1-3 ran the reference's loop on one lane of
+// the frame's wave: every position a dependent chain of three to four HBM round trips.  Here the whole wave runs it, as zj_match_wave.h
+// does for small frames: a WINDOW is the next <= 63 positions the reference's inner loop would visit if none of them matched (stride = the
+// current step), one per lane, plus one look-ahead lane; every lane hashes its position, reads both table entries and its candidates'
+// bytes, the lowest lane with a hit is where the reference's loop stops, the inserts of the lanes up to it are committed, the match is
+// extended by the whole wave (64 x 8 bytes per trip, both directions at once), the complementary inserts and the immediate-repcode loop
+// follow.  The decisions, their order and every table write are the reference's, so the records are identical to ze_block_dfast_x's
+// (tests/test_emu_multiblock.py, tools/fuzz_emu_multiblock.py on the explicit-SIMT build; tests/test_gpu_multiblock.py on the GPU).
+//
+// What differs from the LDS matcher, because every table access is an HBM request here:
+//   * no tentative inserts and read-backs: "the entry as the reference would find it" — the position of the latest lower lane of the
+//     window with the same hash, else the table's content — comes from a scoreboard in LDS (every lane ORs its bit into slot
+//     (hash & 511), reads the slot back and walks the few lower lanes named there), the table itself is read once and written once;
+//   * the window is as wide as the data asks for: on text a match turns up within a few positions, and 63 speculative lanes would spend
+//     250 random requests per sequence on entries nobody looks at (the device serves ~45 G random requests per second, DESIGN.md
+//     section 4).  The width starts at 8 lanes, doubles after a window without a hit and falls back to twice the hit lane after one;
+//     any width gives the same records;
+//   * table writes are made by exactly one lane per address and step (a later lane of the window with the same hash shadows the earlier
+//     one; the scalar inserts after a match are all lane 0's, in the reference's order), and a wait for the wave's outstanding stores
+//     sits in front of every window's table reads, which bypass the CU's L1: a window reads what the previous one wrote.
+#pragma once
+#include "zj_simt.h"
+
+#define ZX_SB_SLOTS 512u
+#define ZX_CAP_MIN 8u
+struct ZXLds {
+    u64 SL[ZX_SB_SLOTS]; u64 SS[ZX_SB_SLOTS];       // scoreboards: lanes of the current window per hash slot
+    u8 shadowL[64]; u8 shadowS[64];                  // commit: the lane is shadowed by a later committed lane with its hash
+};
+
+#if ZJ_ON_GPU
+// table entry as the wave's own earlier stores left it: device-scope load (not served from the CU's L1)
+#define ZX_TLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// every vector-memory operation of the wave so far has completed (gfx9: stores count in vmcnt until they are acknowledged)
+#define ZX_STORES_DONE() __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ZX_TLOAD(p) (*(p))
+#define ZX_STORES_DONE() ((void)0)
+#endif
+
+struct ZWaveX {
+    ZXLds* L; const u8* base; u32 nf, start, n, ilimit; u32* HL; u32* HS; ZLHash hL, hS; ZEOut o;
+#ifdef ZX_STATS
+    u64 stPasses, stHitPasses, stTrips, stLanes, stSlow;
+#define ZX_STAT(x) (x)
+#else
+#define ZX_STAT(x) ((void)0)
+#endif
+    // frame bytes [pos, pos + 8): never touches memory outside the frame; bytes before its start or past its end read as zero
+    // (they can only lengthen a count beyond its limit, and every count is cut to its limit)
+    ZJ_DEV_MEMBER u64 fb(u32 pos) const {
+        bool const neg = (i32)pos < 0;
+        u32 const q = neg ? 0u : zj_min(pos, nf - 8u);
+        u64 const v = ld64(base + q);
+        u32 const k = neg ? 0u - pos : pos - q;
+        u64 const r = neg ? (v << ((8u * k) & 63u)) : (v >> ((8u * k) & 63u));
+        return k >= 8u ? 0 : r;
+    }
+    // length of the common prefix of [a..] and [b..] (b < a), at most n - a: ZSTD_count(a, b, iend)
+    ZJ_DEV_MEMBER u32 count_fwd(u32 a, u32 b) {
+        u32 const lim = n - a;
+        for (u32 total = 0;; total += 512u) {
+            ZWV<u64> d; ZWV<bool> ne;
+            ZW_LANES(l) {
+                u64 const ra = fb(a + total + 8u * l), rb = fb(b + total + 8u * l);
+                ZW_FENCE2(ra, rb);
+                d[l] = ra ^ rb; ne[l] = d[l] != 0;
+            }
+            ZX_STAT(stTrips++);
+            u64 const m = zw_ballot(ne);
+            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); return c < lim ? c : lim; }
+            if (total + 512u >= lim) return lim;
+        }
+    }
+    // number of equal bytes going backwards from (ipos - 1, mpos - 1), at most limit (<= mpos < ipos)
+    ZJ_DEV_MEMBER u32 count_back(u32 ipos, u32 mpos, u32 limit) {
+        if (limit == 0) return 0;
+        for (u32 total = 0;; total += 512u) {
+            ZWV<u64> d; ZWV<bool> ne;
+            ZW_LANES(l) {
+                u64 const ra = fb(ipos - total - 8u - 8u * l), rb = fb(mpos - total - 8u - 8u * l);      // (before the frame: zero on both sides, cut by `limit`)
+                ZW_FENCE2(ra, rb);
+                d[l] = ra ^ rb; ne[l] = d[l] != 0;
+            }
+            ZX_STAT(stTrips++);
+            u64 const m = zw_ballot(ne);
+            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_clzll(zw_get64(d, j)) >> 3); return c < limit ? c : limit; }
+            if (total + 512u >= limit) return limit;
+        }
+    }
+    // Both directions of up to two candidate matches in ONE trip: lanes 0-15 count forwards from (a0, b0), lanes 16-31 backwards from
+    // (i0, m0), lanes 32-47 / 48-63 the same for the second candidate (two = false: idle).  128 bytes per direction; a count that
+    // runs through all of them continues in the general loops above.
+    ZJ_DEV_MEMBER void extend(u32 a0, u32 b0, u32 i0, u32 m0, u32 lim0, bool two, u32 a1, u32 b1, u32 i1, u32 m1, u32 lim1,
+                              u32& f0, u32& k0, u32& f1, u32& k1) {
+        ZWV<u64> d; ZWV<bool> ne;
+        ZW_LANES(l) {
+            u32 const j = l & 15u, q = l >> 4;
+            u32 pa, pb;
+            if (q == 0u) { pa = a0 + 8u * j; pb = b0 + 8u * j; } else if (q == 1u) { pa = i0 - 8u - 8u * j; pb = m0 - 8u - 8u * j; }
+            else if (q == 2u) { pa = a1 + 8u * j; pb = b1 + 8u * j; } else { pa = i1 - 8u - 8u * j; pb = m1 - 8u - 8u * j; }
+            bool const on = two || q < 2u;
+            u64 const xa = fb(on ? pa : 8u), xb = fb(on ? pb : 8u);
+            ZW_FENCE2(xa, xb);
+            u64 const x = xa ^ xb;
+            d[l] = x; ne[l] = x != 0;
+        }
+        ZX_STAT(stTrips++);
+        u64 const m = zw_ballot(ne);
+        {   u32 const mm = (u32)m & 0xFFFFu, fl = n - a0;
+            if (mm) { u32 const j = (u32)__builtin_ctz(mm); f0 = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); if (f0 > fl) f0 = fl; }
+            else f0 = fl <= 128u ? fl : 128u + count_fwd(a0 + 128u, b0 + 128u);
+        }
+        {   u32 const mm = (u32)(m >> 16) & 0xFFFFu;
+            if (mm) { u32 const j = (u32)__builtin_ctz(mm); k0 = 8u * j + ((u32)__builtin_clzll(zw_get64(d, 16u + j)) >> 3); if (k0 > lim0) k0 = lim0; }
+            else k0 = lim0 <= 128u ? lim0 : 128u + count_back(i0 - 128u, m0 - 128u, lim0 - 128u);
+        }
+        f1 = k1 = 0;
+        if (two) {
+            {   u32 const mm = (u32)(m >> 32) & 0xFFFFu, fl = n - a1;
+                if (mm) { u32 const j = (u32)__builtin_ctz(mm); f1 = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, 32u + j)) >> 3); if (f1 > fl) f1 = fl; }
+                else f1 = fl <= 128u ? fl : 128u + count_fwd(a1 + 128u, b1 + 128u);
+            }
+            {   u32 const mm = (u32)(m >> 48) & 0xFFFFu;
+                if (mm) { u32 const j = (u32)__builtin_ctz(mm); k1 = 8u * j + ((u32)__builtin_clzll(zw_get64(d, 48u + j)) >> 3); if (k1 > lim1) k1 = lim1; }
+                else k1 = lim1 <= 128u ? lim1 : 128u + count_back(i1 - 128u, m1 - 128u, lim1 - 128u);
+            }
+        }
+    }
+    // literal positions in the records are relative to the block
+    ZJ_DEV_MEMBER void store(u32 litPos, u32 ll, u32 offBase, u32 ml) {
+        ZW_LANES(l) { if (l == 0) { ZESeq s; s.ll = ll; s.ml = ml; s.off = offBase; s.pos = litPos - start; o.litOff[o.n] = o.lit; o.seqs[o.n] = s; } }
+        o.n++; o.lit += ll;
+    }
+
+    // the block frame[blkStart, blkEnd); returns the length of the last literal run.  repIn / repOut as ze_block_dfast_x.
+    ZJ_DEV_MEMBER u32 run(ZXLds& lds, const u8* frame, u32 frameSize, u32 blkStart, u32 blkEnd, u32 hBitsL, u32 hBitsS, u32 mls,
+                          u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut) {
+        L = &lds; base = frame; nf = frameSize; start = blkStart; n = blkEnd; ilimit = blkEnd - 8u; HL = hashLong; HS = hashSmall;
+        hL = zl_hash_of(8, hBitsL); hS = zl_hash_of(mls, hBitsS);
+        o.n = 0; o.lit = 0;
+#ifdef ZX_STATS
+        stPasses = stHitPasses = stTrips = stLanes = stSlow = 0;
+#endif
+        ZW_LANES(l) { for (u32 i = l; i < ZX_SB_SLOTS; i += 64u) { lds.SL[i] = 0; lds.SS[i] = 0; } }
+        ZW_SYNC();
+        u32 ip = blkStart + (blkStart == 0u ? 1u : 0u), anchor = blkStart;
+        u32 off1 = ZJ_UNI(repIn[0]), off2 = ZJ_UNI(repIn[1]), saved1 = 0, saved2 = 0;
+        {   u32 const maxRep = ip;                                          // zstd_double_fast.c:153-163: offsets beyond the data seen so far are parked
+            if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+            if (off1 > maxRep) { saved1 = off1; off1 = 0; } }
+        u32 step = 1, nextStep = ip + 256u, cap = ZX_CAP_MIN;
+        if (blkEnd >= 8u) for (;;) {
+            ip = ZJ_UNI(ip); anchor = ZJ_UNI(anchor); off1 = ZJ_UNI(off1); off2 = ZJ_UNI(off2); step = ZJ_UNI(step); nextStep = ZJ_UNI(nextStep); cap = ZJ_UNI(cap);
+            o.n = ZJ_UNI(o.n); o.lit = ZJ_UNI(o.lit);                       // wave-uniform by construction; this tells the compiler (scalar registers, scalar branches)
+            if (ip + step > ilimit) break;                                // ip1 > ilimit: _cleanup
+            // ---- window: lanes 0..nIter-1 are the reference's next iterations (ip = p, ip1 = p + step), lane nIter looks ahead
+            u32 kmax, room;
+            if (step == 1u) { kmax = nextStep > ip ? nextStep - ip : 1u; room = ilimit - ip; }
+            else { kmax = nextStep > ip ? (nextStep - ip + step - 1u) / step : 1u; if (kmax < 1u) kmax = 1u; room = (ilimit - ip) / step; }
+            u32 nIter = kmax < cap ? kmax : cap; if (room < nIter) nIter = room;
+            ZX_STAT(stPasses++); ZX_STAT(stLanes += nIter);
+            ZWV<u32> pos, hl, hs, eL, eS, rb, predL, predS; ZWV<u64> w, mL, mS;
+            ZWV<u32> cL, cS, kind; ZWV<bool> hit, longHit;
+            ZW_LANES(l) {
+                bool const act = l <= nIter;
+                u32 const pp = act ? ip + l * step : ip; pos[l] = pp;
+                u64 const ww = fb(pp); u32 const rr = (u32)fb(pp + 1u - off1);
+                ZW_FENCE2(ww, rr);
+                w[l] = ww; rb[l] = rr;
+                hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
+                predL[l] = 64u; predS[l] = 64u;
+            }
+            ZX_STAT(stTrips++);
+            // ---- the table as the previous windows left it, and who in this window comes before whom
+            ZX_STORES_DONE();
+            ZW_LANES(l) {
+                bool const act = l <= nIter, srch = l < nIter;
+                u32 const a = hl[l], b = hs[l];
+                u32 const x = act ? ZX_TLOAD(&HL[a]) : 0u, y = srch ? ZX_TLOAD(&HS[b]) : 0u;
+                if (act) zw_or64(&lds.SL[a & (ZX_SB_SLOTS - 1u)], 1ull << l);      // (the look-ahead lane only reads its slot; its own bit is above every reader's mask)
+                if (srch) zw_or64(&lds.SS[b & (ZX_SB_SLOTS - 1u)], 1ull << l);
+                ZW_FENCE2(x, y);
+                eL[l] = x; eS[l] = y;
+            }
+            ZX_STAT(stTrips++);
+            ZW_SYNC();
+            ZW_LANES(l) {
+                u64 const below = (1ull << l) - 1ull;
+                mL[l] = (l <= nIter) ? (lds.SL[hl[l] & (ZX_SB_SLOTS - 1u)] & below) : 0ull;
+                mS[l] = (l < nIter) ? (lds.SS[hs[l] & (ZX_SB_SLOTS - 1u)] & below) : 0ull;
+            }
+            ZW_SYNC();
+            ZW_LANES(l) { if (l <= nIter) lds.SL[hl[l] & (ZX_SB_SLOTS - 1u)] = 0; if (l < nIter) lds.SS[hs[l] & (ZX_SB_SLOTS - 1u)] = 0; }
+            ZW_SYNC();
+            for (;;) {                                                       // slots are shared by different hashes, equal hashes always share a slot
+                ZWV<u32> jL, jS, gL, gS; ZWV<bool> pend;
+                ZW_LANES(l) {
+                    jL[l] = mL[l] ? 63u - (u32)__builtin_clzll(mL[l]) : l; jS[l] = mS[l] ? 63u - (u32)__builtin_clzll(mS[l]) : l;
+                    pend[l] = (mL[l] | mS[l]) != 0;
+                }
+                if (!zw_ballot(pend)) break;
+                ZX_STAT(stSlow++);
+                zw_shfl(gL, hl, jL); zw_shfl(gS, hs, jS);
+                ZW_LANES(l) {
+                    if (mL[l]) { if (gL[l] == hl[l]) { predL[l] = jL[l]; mL[l] = 0; } else mL[l] &= ~(1ull << jL[l]); }
+                    if (mS[l]) { if (gS[l] == hs[l]) { predS[l] = jS[l]; mS[l] = 0; } else mS[l] &= ~(1ull << jS[l]); }
+                }
+            }
+            // ---- candidates (entry = position + 1; position 0 is never inserted), their bytes, the three tests of an iteration
+            ZW_LANES(l) {
+                bool const act = l <= nIter, srch = l < nIter;
+                u32 const entL = predL[l] < 64u ? ip + predL[l] * step + 1u : eL[l], entS = predS[l] < 64u ? ip + predS[l] * step + 1u : eS[l];
+                bool const vL = act && entL > 1u, vS = srch && entS > 1u;
+                u32 const a = entL - 1u, b = entS - 1u;
+                cL[l] = a; cS[l] = b;
+                u64 const cl = fb(vL ? a : 0u); u32 const cs = (u32)fb(vS ? b : 0u);
+                ZW_FENCE2(cl, cs);
+                bool const hR = srch && off1 > 0u && rb[l] == (u32)(w[l] >> 8);
+                bool const hLg = vL && cl == w[l], hSh = vS && cs == (u32)w[l];
+                longHit[l] = hLg;
+                kind[l] = hR ? 1u : (hLg ? 2u : 3u);
+                hit[l] = srch && (hR || hLg || hSh);
+            }
+            ZX_STAT(stTrips++);
+            u64 const hm = zw_ballot(hit);
+            u32 const cnt = hm ? (u32)__builtin_ctzll(hm) + 1u : nIter;      // lanes whose inserts happen
+            // ---- commit: HL[hl] = HS[hs] = position + 1 for lanes < cnt; of several lanes with one hash the last one writes
+            {   ZWV<bool> hasPred;
+                ZW_LANES(l) { hasPred[l] = l < cnt && (predL[l] < 64u || predS[l] < 64u); }
+                if (zw_ballot(hasPred)) {
+                    ZW_LANES(l) { lds.shadowL[l] = 0; lds.shadowS[l] = 0; }
+                    ZW_SYNC();
+                    ZW_LANES(l) { if (l < cnt) { if (predL[l] < 64u) lds.shadowL[predL[l]] = 1; if (predS[l] < 64u) lds.shadowS[predS[l]] = 1; } }
+                    ZW_SYNC();
+                    ZW_LANES(l) { if (l < cnt) { if (!lds.shadowL[l]) HL[hl[l]] = pos[l] + 1u; if (!lds.shadowS[l]) HS[hs[l]] = pos[l] + 1u; } }
+                    ZW_SYNC();
+                } else {
+                    ZW_LANES(l) { if (l < cnt) { HL[hl[l]] = pos[l] + 1u; HS[hs[l]] = pos[l] + 1u; } }
+                }
+            }
+            if (!hm) {                                                       // nobody matched: the loop's own bookkeeping
+                u32 const pN = ip + nIter * step;
+                if (pN >= nextStep) { step++; nextStep += 256u; }
+                ip = pN;
+                cap = cap * 2u < 63u ? cap * 2u : 63u;
+                continue;
+            }
+            ZX_STAT(stHitPasses++);
+            {   u32 const c2 = 2u * cnt; cap = c2 < ZX_CAP_MIN ? ZX_CAP_MIN : (c2 < 63u ? c2 : 63u); }
+            // ---- the match at lane K, as the reference handles it
+            u32 const K = cnt - 1u, curr = ip + K * step, ip1 = curr + step, kd = zw_get(kind, K);
+            u32 mip, mLength;
+            if (kd == 1u) {
+                u32 f0, k0, f1, k1;
+                extend(curr + 5u, curr + 5u - off1, 8u, 8u, 0u, false, 0, 0, 8u, 8u, 0, f0, k0, f1, k1);
+                mLength = 4u + f0; mip = curr + 1u;
+                store(anchor, mip - anchor, 1u, mLength);
+            } else {
+                u32 mpos, f0, k0, f1, k1;
+                if (kd == 2u) {
+                    mpos = zw_get(cL, K); mip = curr;
+                    extend(curr + 8u, mpos + 8u, curr, mpos, zj_min(curr - anchor, mpos), false, 0, 0, 8u, 8u, 0, f0, k0, f1, k1);
+                    mLength = 8u + f0;
+                } else {
+                    mpos = zw_get(cS, K); mip = curr;
+                    bool const two = zw_getb(longHit, K + 1u);               // _search_next_long: the long candidate of ip1
+                    u32 const mpos1 = two ? zw_get(cL, K + 1u) : 8u;
+                    extend(curr + 4u, mpos + 4u, curr, mpos, zj_min(curr - anchor, mpos), two, ip1 + 8u, mpos1 + 8u, ip1, mpos1, zj_min(ip1 - anchor, mpos1), f0, k0, f1, k1);
+                    mLength = 4u + f0;
+                    if (two && 8u + f1 > mLength) { mip = ip1; mLength = 8u + f1; mpos = mpos1; k0 = k1; }
+                }
+                u32 const offset = mip - mpos;
+                mip -= k0; mLength += k0;
+                off2 = off1; off1 = offset;
+                if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ip1 + 1u; } }
+                store(anchor, mip - anchor, offset + 3u, mLength);
+            }
+            ip = mip + mLength; anchor = ip;
+            if (ip <= ilimit) {
+                // complementary insertion — curr + 2 and ip - 2 (long), curr + 2 and ip - 1 (short), in this order — and the
+                // immediate-repcode loop; the bytes of both are requested together.  All of these writes are lane 0's, in the
+                // reference's order: two of them may name one bucket.
+                for (bool first = true;; first = false) {
+                    ZWV<u64> d, wi, wq; ZWV<bool> ne;
+                    ZW_LANES(l) {
+                        u32 const q = l == 0 ? curr + 2u : (l == 1 ? ip - 2u : ip - 1u);
+                        u64 const ra = fb(ip + 8u * l), rbb = fb(ip - off2 + 8u * l), rq = fb(q);
+                        ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
+                        wi[l] = ra; d[l] = ra ^ rbb; ne[l] = d[l] != 0; wq[l] = rq;
+                    }
+                    ZX_STAT(stTrips++);
+                    if (first) {
+                        u64 const q0 = zw_get64(wq, 0), q1 = zw_get64(wq, 1), q2 = zw_get64(wq, 2);
+                        ZW_LANES(l) { if (l == 0) {
+                            HL[zl_hash(hL, q0)] = curr + 3u; HL[zl_hash(hL, q1)] = ip - 1u;
+                            HS[zl_hash(hS, q0)] = curr + 3u; HS[zl_hash(hS, q2)] = ip; } }
+                    }
+                    if (off2 == 0u || (u32)zw_get64(d, 0) != 0u) break;
+                    u64 const m = zw_ballot(ne);
+                    u32 const lim = n - ip; u32 rLength;
+                    if (m) { u32 const j = (u32)__builtin_ctzll(m); rLength = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); if (rLength > lim) rLength = lim; }
+                    else rLength = lim <= 512u ? lim : 512u + count_fwd(ip + 512u, ip - off2 + 512u);
+                    { u32 const t = off2; off2 = off1; off1 = t; }
+                    {   u64 const wi0 = zw_get64(wi, 0);
+                        ZW_LANES(l) { if (l == 0) { HS[zl_hash(hS, wi0)] = ip + 1u; HL[zl_hash(hL, wi0)] = ip + 1u; } } }
+                    store(anchor, 0u, 1u, rLength);
+                    ip += rLength; anchor = ip;
+                    if (ip > ilimit) break;
+                }
+            }
+            step = 1u; nextStep = ip + 256u;
+        }
+        // zstd_double_fast.c:238-246: a parked offset comes back unless a new one took its place
+        saved2 = (saved1 != 0u && off1 != 0u) ? saved1 : saved2;
+        ZW_LANES(l) { if (l == 0) { repOut[0] = off1 ? off1 : saved1; repOut[1] = off2 ? off2 : saved2; } }
+        ZX_STORES_DONE();                                                  // the records are read by other lanes next
+        return n - anchor;
+    }
+};
+
+// One block of a multi-block frame through the wave matcher (the signature ze_compress_t's block path calls; declared in zj_encode.h).
+ZJ_DEV u32 zx_block_dfast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls,
+                               u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut) {
+    ZWaveX m; m.o = o;
+    u32 const lastLL = m.run(*(ZXLds*)lds, base, frameSize, start, end, hBitsL, hBitsS, mls, hashLong, hashSmall, repIn, repOut);
+    o = m.o;
+    return lastLL;
+}
