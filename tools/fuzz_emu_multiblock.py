@@ -1,7 +1,7 @@
 """Randomised byte-identity stress of multi-block frames (ze_compress_multi, lane-serial build of tests/emu) against the reference's
 ZSTD_compress2, 128 KiB < input <= 2 MiB, levels 1-3, with a census of the block / literals types the inputs produced.
 Level-3 blocks run the wave matcher (zj_match_wavex.h, 64 emulated lanes; ZJNI_EMU_LIB=tests/emu/libzjni_emu_rev.so visits them in
-descending order), FUZZ_SERIAL=1 the one-lane parse; FUZZ_LEVELS=3 restricts the levels.
+descending order), FUZZ_SERIAL=1 the one-lane parse, FUZZ_SERIAL=2 the wave matcher without staged spans; FUZZ_LEVELS=3 restricts the levels.
 usage: fuzz_emu_multiblock.py <seed> <seconds>   TEST INFRASTRUCTURE."""
 import os, sys, time, random, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ import util
 import __graft_entry__ as e
 zj = e.load_package(); L = util.emu_lib()
 seed = int(sys.argv[1]); budget = float(sys.argv[2])
-LEVELS = [int(x) for x in os.environ.get("FUZZ_LEVELS", "1,2,3").split(",")]; SERIAL = os.environ.get("FUZZ_SERIAL") == "1"
+LEVELS = [int(x) for x in os.environ.get("FUZZ_LEVELS", "1,2,3").split(",")]; SERIAL = {"1": True, "2": 2}.get(os.environ.get("FUZZ_SERIAL"), False)
 rnd = random.Random(seed)
 recs = util.json_records(20000, seed=seed)
 census = collections.Counter()

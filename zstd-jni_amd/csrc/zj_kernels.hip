@@ -1340,8 +1340,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
         }
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
-        // level-3 blocks of multi-block frames: the wave matcher (zj_match_wavex.h); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs
-        u32 const multiSerial = (getenv("ZJNI_MULTI_WAVE") && atoi(getenv("ZJNI_MULTI_WAVE")) == 0) ? ZE_FLAG_MULTI_SERIAL : 0u;
+        // level-3 blocks of multi-block frames: the wave matcher (zj_match_wavex.h); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
+        u32 multiSerial = 0; if (const char* ov = getenv("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
     }

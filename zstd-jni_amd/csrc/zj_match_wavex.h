@@ -28,9 +28,13 @@
 
 #define ZX_SB_SLOTS 512u
 #define ZX_CAP_MIN 8u
+#define ZX_CARRY 128u                                // bytes per staged stream
 struct ZXLds {
     u64 SL[ZX_SB_SLOTS]; u64 SS[ZX_SB_SLOTS];       // scoreboards: lanes of the current window per hash slot
     u8 shadowL[64]; u8 shadowS[64];                  // commit: the lane is shadowed by a later committed lane with its hash
+    // what the trip of a match staged (see run()): the frame's bytes from curr on, the same span one match offset back and one
+    // previous-offset back, and the 64 bytes before curr and before the match source
+    u8 stA[ZX_CARRY + 16u]; u8 stB[ZX_CARRY + 16u]; u8 stC[ZX_CARRY + 16u]; u8 stKA[64]; u8 stKB[64];
 };
 
 #if ZJ_ON_GPU
@@ -45,6 +49,7 @@ struct ZXLds {
 
 struct ZWaveX {
     ZXLds* L; const u8* base; u32 nf, start, n, ilimit; u32* HL; u32* HS; ZLHash hL, hS; ZEOut o;
+    bool carryOn, cvalid; u32 cbase, coffB, coffC;      // staged streams (ZXLds::stA ..): valid, position of stA[0], offsets of stB / stC behind it
 #ifdef ZX_STATS
     u64 stPasses, stHitPasses, stTrips, stLanes, stSlow;
 #define ZX_STAT(x) (x)
@@ -140,7 +145,8 @@ struct ZWaveX {
 
     // the block frame[blkStart, blkEnd); returns the length of the last literal run.  repIn / repOut as ze_block_dfast_x.
     ZJ_DEV_MEMBER u32 run(ZXLds& lds, const u8* frame, u32 frameSize, u32 blkStart, u32 blkEnd, u32 hBitsL, u32 hBitsS, u32 mls,
-                          u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut) {
+                          u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry = true) {
+        carryOn = carry; cvalid = false; cbase = coffB = coffC = 0;
         L = &lds; base = frame; nf = frameSize; start = blkStart; n = blkEnd; ilimit = blkEnd - 8u; HL = hashLong; HS = hashSmall;
         hL = zl_hash_of(8, hBitsL); hS = zl_hash_of(mls, hBitsS);
         o.n = 0; o.lit = 0;
@@ -167,16 +173,31 @@ struct ZWaveX {
             ZX_STAT(stPasses++); ZX_STAT(stLanes += nIter);
             ZWV<u32> pos, hl, hs, eL, eS, rb, predL, predS; ZWV<u64> w, mL, mS;
             ZWV<u32> cL, cS, kind; ZWV<bool> hit, longHit;
-            ZW_LANES(l) {
-                bool const act = l <= nIter;
-                u32 const pp = act ? ip + l * step : ip; pos[l] = pp;
-                u64 const ww = fb(pp); u32 const rr = (u32)fb(pp + 1u - off1);
-                ZW_FENCE2(ww, rr);
-                w[l] = ww; rb[l] = rr;
-                hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
-                predL[l] = 64u; predS[l] = 64u;
+            cvalid = ZJ_UNI(cvalid ? 1u : 0u) != 0u; cbase = ZJ_UNI(cbase); coffB = ZJ_UNI(coffB); coffC = ZJ_UNI(coffC);
+            if (cvalid && step == 1u && ip >= cbase && (ip - cbase) + nIter + 8u <= ZX_CARRY && (off1 == coffB || off1 == coffC || off1 == 0u)) {
+                // the window lies inside the span the last match staged: its bytes and the repcode stream's come from LDS
+                const u8* const rs = (off1 == coffB) ? lds.stB : lds.stC;   // (off1 == 0: never compared)
+                ZW_LANES(l) {
+                    bool const act = l <= nIter;
+                    u32 const pp = act ? ip + l : ip; pos[l] = pp;
+                    u64 const ww = ld64(lds.stA + (pp - cbase)); u32 const rr = ld32(rs + (pp + 1u - cbase));
+                    ZW_FENCE2(ww, rr);
+                    w[l] = ww; rb[l] = rr;
+                    hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
+                    predL[l] = 64u; predS[l] = 64u;
+                }
+            } else {
+                ZW_LANES(l) {
+                    bool const act = l <= nIter;
+                    u32 const pp = act ? ip + l * step : ip; pos[l] = pp;
+                    u64 const ww = fb(pp); u32 const rr = (u32)fb(pp + 1u - off1);
+                    ZW_FENCE2(ww, rr);
+                    w[l] = ww; rb[l] = rr;
+                    hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
+                    predL[l] = 64u; predS[l] = 64u;
+                }
+                ZX_STAT(stTrips++);
             }
-            ZX_STAT(stTrips++);
             // ---- the table as the previous windows left it, and who in this window comes before whom
             ZX_STORES_DONE();
             ZW_LANES(l) {
@@ -256,12 +277,58 @@ struct ZWaveX {
             // ---- the match at lane K, as the reference handles it
             u32 const K = cnt - 1u, curr = ip + K * step, ip1 = curr + step, kd = zw_get(kind, K);
             u32 mip, mLength;
-            if (kd == 1u) {
+            bool const two = kd == 3u && zw_getb(longHit, K + 1u);           // _search_next_long: the long candidate of ip1 has to be counted as well
+            if (carryOn && !two) {
+                // ONE trip for everything this match and what follows it can need: the frame from curr on (lanes 0-15), the same span
+                // one match offset back (16-31: the match source) and one previous offset back (32-47: the immediate-repcode candidate),
+                // the 64 bytes before curr and before the match source (48-63).  Forward and backward counts, the complementary
+                // inserts, the repcode test behind the match and the next window are then LDS reads as long as they stay inside.
+                u32 const mpos = kd == 2u ? zw_get(cL, K) : (kd == 3u ? zw_get(cS, K) : curr - off1);
+                u32 const offN = curr - mpos, offC = kd == 1u ? off2 : off1, dd = kd == 1u ? 5u : (kd == 2u ? 8u : 4u);
+                ZW_LANES(l) {
+                    u32 const j = l & 15u, q = l >> 4;
+                    u32 const p = q == 0u ? curr + 8u * j : (q == 1u ? mpos + 8u * j : (q == 2u ? curr - offC + 8u * j : (j < 8u ? curr - 64u + 8u * j : mpos - 128u + 8u * j)));
+                    u64 const x = fb(p);
+                    ZW_FENCE2(x, x);
+                    u8* const to = q == 0u ? lds.stA + 8u * j : (q == 1u ? lds.stB + 8u * j : (q == 2u ? lds.stC + 8u * j : (j < 8u ? lds.stKA + 8u * j : lds.stKB + 8u * (j - 8u))));
+                    st64(to, x);
+                }
+                ZX_STAT(stTrips++);
+                ZW_SYNC();
+                ZWV<u64> d2; ZWV<bool> ne2;
+                ZW_LANES(l) {
+                    u64 x = 0;
+                    if (l < 15u) x = ld64(lds.stA + dd + 8u * l) ^ ld64(lds.stB + dd + 8u * l);
+                    else if (l >= 16u && l < 24u) x = ld64(lds.stKA + 56u - 8u * (l - 16u)) ^ ld64(lds.stKB + 56u - 8u * (l - 16u));
+                    d2[l] = x; ne2[l] = x != 0;
+                }
+                ZW_SYNC();
+                u64 const m2 = zw_ballot(ne2);
+                u32 const a0 = curr + dd, fl = n - a0; u32 f0, k0 = 0;
+                {   u32 const mm = (u32)m2 & 0x7FFFu;
+                    if (mm) { u32 const j = (u32)__builtin_ctz(mm); f0 = 8u * j + ((u32)__builtin_ctzll(zw_get64(d2, j)) >> 3); if (f0 > fl) f0 = fl; }
+                    else f0 = fl <= 120u ? fl : 120u + count_fwd(a0 + 120u, a0 - offN + 120u); }
+                if (kd == 1u) {
+                    mLength = 4u + f0; mip = curr + 1u;
+                    store(anchor, mip - anchor, 1u, mLength);
+                } else {
+                    u32 const lim0 = zj_min(curr - anchor, mpos), mb = (u32)(m2 >> 16) & 0xFFu;
+                    if (mb) { u32 const j = (u32)__builtin_ctz(mb); k0 = 8u * j + ((u32)__builtin_clzll(zw_get64(d2, 16u + j)) >> 3); if (k0 > lim0) k0 = lim0; }
+                    else k0 = lim0 <= 64u ? lim0 : 64u + count_back(curr - 64u, mpos - 64u, lim0 - 64u);
+                    mip = curr - k0; mLength = dd + f0 + k0;
+                    off2 = off1; off1 = offN;
+                    if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ip1 + 1u; } }
+                    store(anchor, mip - anchor, offN + 3u, mLength);
+                }
+                cvalid = true; cbase = curr; coffB = offN; coffC = offC;
+            } else if (kd == 1u) {
+                cvalid = false;
                 u32 f0, k0, f1, k1;
                 extend(curr + 5u, curr + 5u - off1, 8u, 8u, 0u, false, 0, 0, 8u, 8u, 0, f0, k0, f1, k1);
                 mLength = 4u + f0; mip = curr + 1u;
                 store(anchor, mip - anchor, 1u, mLength);
             } else {
+                cvalid = false;
                 u32 mpos, f0, k0, f1, k1;
                 if (kd == 2u) {
                     mpos = zw_get(cL, K); mip = curr;
@@ -269,7 +336,6 @@ struct ZWaveX {
                     mLength = 8u + f0;
                 } else {
                     mpos = zw_get(cS, K); mip = curr;
-                    bool const two = zw_getb(longHit, K + 1u);               // _search_next_long: the long candidate of ip1
                     u32 const mpos1 = two ? zw_get(cL, K + 1u) : 8u;
                     extend(curr + 4u, mpos + 4u, curr, mpos, zj_min(curr - anchor, mpos), two, ip1 + 8u, mpos1 + 8u, ip1, mpos1, zj_min(ip1 - anchor, mpos1), f0, k0, f1, k1);
                     mLength = 4u + f0;
@@ -287,14 +353,29 @@ struct ZWaveX {
                 // immediate-repcode loop; the bytes of both are requested together.  All of these writes are lane 0's, in the
                 // reference's order: two of them may name one bucket.
                 for (bool first = true;; first = false) {
-                    ZWV<u64> d, wi, wq; ZWV<bool> ne;
-                    ZW_LANES(l) {
-                        u32 const q = l == 0 ? curr + 2u : (l == 1 ? ip - 2u : ip - 1u);
-                        u64 const ra = fb(ip + 8u * l), rbb = fb(ip - off2 + 8u * l), rq = fb(q);
-                        ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
-                        wi[l] = ra; d[l] = ra ^ rbb; ne[l] = d[l] != 0; wq[l] = rq;
+                    ZWV<u64> d, wi, wq; ZWV<bool> ne; u32 cov;
+                    u32 const e = ip - cbase;
+                    if (cvalid && e + 8u <= ZX_CARRY && (off2 == coffB || off2 == coffC || off2 == 0u)) {
+                        const u8* const xs = (off2 == coffB) ? lds.stB : lds.stC;      // (off2 == 0: not compared)
+                        u32 const nv = (ZX_CARRY - e) / 8u;                             // words inside the staged span (>= 1)
+                        cov = 8u * nv;
+                        ZW_LANES(l) {
+                            bool const in = l < nv;
+                            u32 const at = in ? e + 8u * l : 0u, q = l == 0 ? 2u : (l == 1 ? e - 2u : (l == 2 ? e - 1u : 0u));
+                            u64 const ra = ld64(lds.stA + at), rbb = ld64(xs + at), rq = ld64(lds.stA + q);
+                            ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
+                            wi[l] = ra; d[l] = in ? ra ^ rbb : 0ull; ne[l] = d[l] != 0; wq[l] = rq;
+                        }
+                    } else {
+                        cov = 512u;
+                        ZW_LANES(l) {
+                            u32 const q = l == 0 ? curr + 2u : (l == 1 ? ip - 2u : ip - 1u);
+                            u64 const ra = fb(ip + 8u * l), rbb = fb(ip - off2 + 8u * l), rq = fb(q);
+                            ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
+                            wi[l] = ra; d[l] = ra ^ rbb; ne[l] = d[l] != 0; wq[l] = rq;
+                        }
+                        ZX_STAT(stTrips++);
                     }
-                    ZX_STAT(stTrips++);
                     if (first) {
                         u64 const q0 = zw_get64(wq, 0), q1 = zw_get64(wq, 1), q2 = zw_get64(wq, 2);
                         ZW_LANES(l) { if (l == 0) {
@@ -305,7 +386,7 @@ struct ZWaveX {
                     u64 const m = zw_ballot(ne);
                     u32 const lim = n - ip; u32 rLength;
                     if (m) { u32 const j = (u32)__builtin_ctzll(m); rLength = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); if (rLength > lim) rLength = lim; }
-                    else rLength = lim <= 512u ? lim : 512u + count_fwd(ip + 512u, ip - off2 + 512u);
+                    else rLength = lim <= cov ? lim : cov + count_fwd(ip + cov, ip - off2 + cov);
                     { u32 const t = off2; off2 = off1; off1 = t; }
                     {   u64 const wi0 = zw_get64(wi, 0);
                         ZW_LANES(l) { if (l == 0) { HS[zl_hash(hS, wi0)] = ip + 1u; HL[zl_hash(hL, wi0)] = ip + 1u; } } }
@@ -326,9 +407,9 @@ struct ZWaveX {
 
 // One block of a multi-block frame through the wave matcher (the signature ze_compress_t's block path calls; declared in zj_encode.h).
 ZJ_DEV u32 zx_block_dfast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls,
-                               u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut) {
+                               u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry) {
     ZWaveX m; m.o = o;
-    u32 const lastLL = m.run(*(ZXLds*)lds, base, frameSize, start, end, hBitsL, hBitsS, mls, hashLong, hashSmall, repIn, repOut);
+    u32 const lastLL = m.run(*(ZXLds*)lds, base, frameSize, start, end, hBitsL, hBitsS, mls, hashLong, hashSmall, repIn, repOut, carry);
     o = m.o;
     return lastLL;
 }
