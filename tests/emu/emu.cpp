@@ -58,8 +58,17 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     if (zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta)) {
         u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1); ZDSeqLane m; m.llBase = symL; m.mlBase = symM; m.init(src, tab, seqs, &meta);
         while (m.st != 2) m.round();
-        r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf);
-        if (usedSplit && r != ~(u64)0) *usedSplit = 1;
+        // stage 2b as the kernels run it: its own workgroup state (poisoned), a slot per frame, the frame record marked
+        u32 const slot = getenv("EMU_LIT_SLOT") ? (u32)atoi(getenv("EMU_LIT_SLOT")) : 65536u;
+        u8* slotBuf = slot ? (u8*)malloc(slot) : nullptr;
+        if (slotBuf) {
+            ZDecShared* sh2 = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh2, 0x3C, sizeof(ZDecShared));
+            if (zd_lit_frame(g, *sh2, src, &meta, slotBuf, slot, pf)) meta.pad = 1u;
+            free(sh2);
+        }
+        r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf, nullptr, nullptr, slotBuf, slot);
+        if (usedSplit && r != ~(u64)0) *usedSplit = meta.pad ? 3 : 1;
+        free(slotBuf);
     }
     if (r == ~(u64)0) { memset(sh, 0x5A, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf); }
     free(seqs); free(tab); free(lit); free(sh);

@@ -856,7 +856,9 @@ ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
 // RLE / Huffman: into litScratch).  Returns where they are; sets sh.err and returns nullptr on error.
 // Publishes sh.litSize / litHdr / litCSize.  room = bytes left in the frame's destination.
 template <class G>
-ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u) {
+// preLit: the block's Huffman-coded literals were regenerated there by an earlier pass (zd_lit_frame, zj_decode_split.h) — the header is
+// parsed as always, the table and the streams are not touched again.
+ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u, const u8* preLit = nullptr) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -898,6 +900,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
     const u8* lit = litScratch;
     if (litType == 0) lit = bsrc + litHdr;                      // raw: read in place
     else if (litType == 1) { zd_fill(g, litScratch, bsrc[litHdr], litSize); zj_mem_order(); }
+    else if (preLit) lit = preLit;
     else {
         // ---- Huffman table (lane 0 reads weights, all lanes fill) ----
         if (litType == 2) {

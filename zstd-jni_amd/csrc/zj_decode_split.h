@@ -263,10 +263,35 @@ struct ZDSeqLane {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2b (beside stage 2).  The Huffman-coded literals of a simple frame do not depend on its sequences: while the lane-per-frame
+// decode occupies one wave per SIMD with a chain of memory round trips, this pass regenerates the literals of the same frames into a
+// per-frame slot in HBM (N/decompress/zstd_decompress_block.c:134-340, huf_decompress.c:721-835 — zd_block_literals, unchanged) and
+// marks the frame record (ZDMeta::pad = 1); stage 3 then starts at the LZ77 execution.  Frames it does not mark — raw / RLE literals,
+// literals beyond the slot, treeless literals of dictionary frames, anything wrong with the section — are stage 3's as before.
+// Returns true (wave-uniform) when `out[0, litSize)` holds the literals.
+template <class G>
+ZJ_DEV bool zd_lit_frame(const G& g, ZDecShared& sh, const u8* src, const ZDMeta* meta, u8* out, u32 slot, ZjProf& pf) {
+    GRP_SERIAL(g) {
+        ZDMeta const m = *meta;
+        sh.err = 0; sh.hufValid = 0; sh.hufX2 = 0;
+        sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.blockSizeMax = m.blockSizeMax;
+        sh.blkType = ((src[m.blockOff] & 3u) == 2u && m.litSize <= slot) ? 1u : 0u;      // Huffman with its own table, and it fits
+    }
+    g.sync();
+    if (!ZJ_UNI(sh.blkType)) return false;
+    const u8* const lit = zd_block_literals(g, sh, src + ZJ_UNI(sh.hdrSize), ZJ_UNI(sh.blkSize), out, pf, slot);
+    bool const ok = lit != nullptr && !ZJ_UNI(sh.err);
+    zj_mem_order();
+    g.sync();
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 3.  Returns the decoded size, or ~0 (wave-uniform) to hand the frame to the fused kernel.
+// preLit / preAvail: the frame's slot of stage 2b and its size; used when the frame record says the literals are there.
 template <bool DICT = false, class G>
 ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, const ZDMeta* meta, const u64* seqs, u8* litScratch, ZjProf& pf,
-                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr) {
+                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr, const u8* preLit = nullptr, u32 preAvail = 0) {
     const ZDDictDev* const dd = DICT ? ddArg : nullptr;
     const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
@@ -274,9 +299,11 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
         sh.err = m.status ? (u32)ZJ_E_CORRUPTION : 0u; sh.hufValid = 0; sh.hufX2 = 0;
         sh.hdrSize = m.blockOff; sh.blkSize = m.blockSize; sh.nbSeq = m.nbSeq; sh.blockSizeMax = m.blockSizeMax; sh.contentSize = m.contentSize;
         sh.hasChecksum = m.hasChecksum;
+        sh.litStreams = (preLit && m.pad == 1u) ? 1u : 0u;     // (a scratch word here: zd_block_literals sets it from the section header)
     }
     g.sync();
     if (ZJ_UNI(sh.err)) return ~(u64)0;
+    bool const havePre = ZJ_UNI(sh.litStreams) != 0u;
     if (DICT && dd && dd->hasEntropy && (src[ZJ_UNI(sh.hdrSize)] & 3u) == 3u) {   // treeless literals decode with the dictionary's Huffman table
         zd_load_dict_entropy(g, sh, dd, true, false);
         GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; }
@@ -285,12 +312,12 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);
     u32 const nbSeq = ZJ_UNI(sh.nbSeq), content = (u32)zj_uni64(sh.contentSize);
     u32 const cap = zj_min(content, ZJ_UNI(sh.blockSizeMax));
-    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf);
+    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, ~0u, havePre ? preLit : nullptr);
     if (ZJ_UNI(sh.err)) return ~(u64)0;
     pf.mark(2);
     u32 const litSize = ZJ_UNI(sh.litSize);
-    // bytes that may be read starting at `lit`: the rest of the block for raw literals, the scratch otherwise
-    u32 const litAvail = (ZJ_UNI(sh.litType) == 0) ? bsize - ZJ_UNI(sh.litHdr) : ZD_LIT_SCRATCH;
+    // bytes that may be read starting at `lit`: the rest of the block for raw literals, the scratch (or the frame's slot) otherwise
+    u32 const litAvail = (ZJ_UNI(sh.litType) == 0) ? bsize - ZJ_UNI(sh.litHdr) : ((havePre && ZJ_UNI(sh.litType) >= 2u) ? preAvail : ZD_LIT_SCRATCH);
     u32 lp = 0, op = 0;
     for (u32 base = 0; base < nbSeq; base += ZD_SEQ_BATCH) {
         u32 const cnt = zj_min(ZD_SEQ_BATCH, nbSeq - base);

@@ -148,14 +148,27 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
                                                           const u32* countPtr, u32* workCounter, const ZDMeta* metas, const u64* seqs, u8* scratch,
                                                           u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw,
-                                                          u32 mode, const u32* doneList, u32* procFlag) {
+                                                          u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot) {
     // mode 0: list entry k.  mode 1: the k-th frame the sequence-decode kernel finishes while this kernel runs beside it (bounded
     // wait; a workgroup that gives up leaves the rest to the mode-2 pass).  mode 2: list entries mode 1 did not get to.
+    // mode 3: literals only (zd_lit_frame), beside the sequence decode, into slot k of litSlots (litSlot bytes each); the other modes
+    // take the literals from there when the frame record says so.
     ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
     ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
     u32 const count = ZJ_UNI(*countPtr);
+    if (mode == 3) {
+        for (;;) {
+            u32 const k = zj_next_index(workCounter);
+            if (k >= count) break;
+            u32 const i = ZJ_UNI(list[k]);
+            bool const ok = zd_lit_frame(g, sh, src + srcOff[i], metas + i, litSlots + (size_t)i * litSlot, litSlot, pf);
+            if (threadIdx.x == 0 && ok) const_cast<ZDMeta*>(metas)[i].pad = 1u;
+            __syncthreads();
+        }
+        return;
+    }
     if (mode == 1 && !zj_dec_heavy(countPtr)) return;        // light frames: everything is the mode-2 pass's
     for (;;) {
         u32 const k = zj_next_index(workCounter);
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
             i = ZJ_UNI(list[k]);
             if (mode == 2 && ZJ_UNI(procFlag[i])) continue;
         }
-        u64 const r = zd_exec_frame<DICT>(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf, dd, dictRaw);
+        u64 const r = zd_exec_frame<DICT>(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf, dd, dictRaw,
+                                          litSlots ? litSlots + (size_t)i * litSlot : (const u8*)nullptr, litSlot);
         pf.mark(8);
         if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; if (mode == 1) procFlag[i] = 1u; }
         __syncthreads();
@@ -814,6 +828,7 @@ struct DevState {
     std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;
     std::mutex* stageMu = nullptr;                    // users of this device's host staging area (host-pointer entries)   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
+    u8* dlitBuf = nullptr; size_t dlitBufCap = 0;      // literal slots of the split decode pipeline (stage 2b), one per frame of a slice
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
@@ -902,12 +917,13 @@ DevState* cur_state() {
 // has to grow first evicts the other pipelines' buffers (after the device has drained).  0 = no limit (sized for 288 GB).
 size_t g_scratch_limit = 0;
 #define ZJ_SCRATCH_LIMIT_MIN ((size_t)4 << 30)
-size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap; }
+size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap + d->dlitBufCap; }
 void scratch_free_all(DevState* d) {
     if (d->splitBuf) (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0;
     if (d->wideBuf) (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0;
     if (d->cdBuf) (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; d->cdSliceCap = 0;
     if (d->dsplitBuf) (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0;
+    if (d->dlitBuf) (void)hipFree(d->dlitBuf); d->dlitBuf = nullptr; d->dlitBufCap = 0;
 }
 // before a buffer holding `have` bytes is replaced by one of `need` bytes: false when even alone it would exceed the limit
 bool scratch_make_room(DevState* d, size_t have, size_t need) {
@@ -999,6 +1015,7 @@ void zjni_shutdown(void) {
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
+        if (d.dlitBuf) (void)hipFree(d.dlitBuf);
         if (d.wideBuf) (void)hipFree(d.wideBuf);
         if (d.multiTables) (void)hipFree(d.multiTables);
         if (d.cdBuf) (void)hipFree(d.cdBuf);
@@ -1175,7 +1192,25 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
-        u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A
+        u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A, [10] work of the literal pass
+        // Stage 2b (zd_lit_frame): one literal slot per frame, as large as the budget allows (at most a block); frames whose literals do
+        // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
+        // ZJNI_DEC_LIT=0 switches the pass off (A/B runs); ZJNI_DEC_LIT_BYTES sets the budget (default 4 GiB, nothing under a scratch limit).
+        u8* litSlots = nullptr; u32 litSlot = 0;
+        {   static int const litEnv = (getenv("ZJNI_DEC_LIT") && atoi(getenv("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
+            if (litEnv && !ddict && !g_scratch_limit) {
+                size_t budget = (size_t)4 << 30; if (const char* ov = getenv("ZJNI_DEC_LIT_BYTES")) budget = (size_t)atoll(ov);
+                size_t slot = budget / n; if (slot > ZD_BLOCK_MAX) slot = ZD_BLOCK_MAX; slot &= ~(size_t)4095;
+                if (slot >= 16384) {
+                    size_t const needL = n * slot + 64;
+                    if (d->dlitBufCap < needL) {
+                        if (d->dlitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dlitBuf); d->dlitBuf = nullptr; d->dlitBufCap = 0; }
+                        if (hipMalloc(&d->dlitBuf, needL) == hipSuccess) d->dlitBufCap = needL; else { d->dlitBuf = nullptr; (void)hipGetLastError(); }
+                    }
+                    if (d->dlitBuf) { litSlots = d->dlitBuf; litSlot = (u32)slot; }
+                }
+            }
+        }
         static int const overlapEnv = getenv("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
         // Running the execution kernel beside the sequence decode costs two cross-stream dependencies and an extra launch per slice
         // (~0.3 ms) — worth it only for frames with many sequences (zj_dec_heavy, decided on the device).  The host skips the set-up
@@ -1196,20 +1231,30 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         // frames in the order they finish there: the lane-per-frame decode is a dependent chain per frame (one wave per SIMD, mostly
         // waiting), so the two share the CUs instead of following each other.  A sweep pass afterwards takes what the side kernel
         // did not get to (its waits are bounded): completion never depends on the two kernels being co-scheduled.
-        if (overlap && (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        bool const fork = overlap || litSlots;
+        if (fork && (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (litSlots) {                                 // beside the sequence decode, ahead of the mode-1 execution pass on the same side stream
+            hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, d->sideStream,
+                               (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
+                               (const u32*)(c + 8), c + 10, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot);
+        }
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
                            (const u64*)d_src_off, (const u32*)listA, (const u32*)(c + 8), c + 3, (const u16*)tabs, seqs, metas, ddDev,
                            overlap ? doneList : (u32*)nullptr, c + 6, (u32)d->dseqHeavy);
         (void)hipEventRecord(d->tev[4], st);
+        if (litSlots && !overlap && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) {
+            (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st);          // the side kernel must not outlive this call's claim on the scratch
+            return ZJNI_ERR(ZJNI_ERROR_no_device);
+        }
         for (int pass = overlap ? 1 : 0; pass <= (overlap ? 2 : 0); pass++) {
             hipStream_t const es = pass == 1 ? d->sideStream : st;
             u32* const work = pass == 2 ? c + 7 : c + 4;
             if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
             else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag);
+                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
             if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) {
                 (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st);          // the side kernel must not outlive this call's claim on the scratch
                 return ZJNI_ERR(ZJNI_ERROR_no_device);

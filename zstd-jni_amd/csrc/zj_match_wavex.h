@@ -50,6 +50,12 @@ struct ZXLds {
 struct ZWaveX {
     ZXLds* L; const u8* base; u32 nf, start, n, ilimit; u32* HL; u32* HS; ZLHash hL, hS; ZEOut o;
     bool carryOn, cvalid; u32 cbase, coffB, coffC;      // staged streams (ZXLds::stA ..): valid, position of stA[0], offsets of stB / stC behind it
+#if defined(ZX_PROFILE) && ZJ_ON_GPU       /* analysis builds (tools/ab_zxprof.sh): cycles per phase of a window, printed per block by the first workgroups */
+    u64 pf[12]; u64 pT;
+#define ZX_MARK(i) do { u64 const t_ = __builtin_readcyclecounter(); pf[i] += t_ - pT; pT = t_; } while (0)
+#else
+#define ZX_MARK(i) ((void)0)
+#endif
 #ifdef ZX_STATS
     u64 stPasses, stHitPasses, stTrips, stLanes, stSlow;
 #define ZX_STAT(x) (x)
@@ -155,6 +161,10 @@ struct ZWaveX {
 #endif
         ZW_LANES(l) { for (u32 i = l; i < ZX_SB_SLOTS; i += 64u) { lds.SL[i] = 0; lds.SS[i] = 0; } }
         ZW_SYNC();
+#if defined(ZX_PROFILE) && ZJ_ON_GPU
+        for (int j = 0; j < 12; j++) pf[j] = 0;
+        pT = __builtin_readcyclecounter(); u64 const pStart = pT;
+#endif
         u32 ip = blkStart + (blkStart == 0u ? 1u : 0u), anchor = blkStart;
         u32 off1 = ZJ_UNI(repIn[0]), off2 = ZJ_UNI(repIn[1]), saved1 = 0, saved2 = 0;
         {   u32 const maxRep = ip;                                          // zstd_double_fast.c:153-163: offsets beyond the data seen so far are parked
@@ -198,8 +208,10 @@ struct ZWaveX {
                 }
                 ZX_STAT(stTrips++);
             }
+            ZX_MARK(0);
             // ---- the table as the previous windows left it, and who in this window comes before whom
             ZX_STORES_DONE();
+            ZX_MARK(9);
             ZW_LANES(l) {
                 bool const act = l <= nIter, srch = l < nIter;
                 u32 const a = hl[l], b = hs[l];
@@ -210,6 +222,7 @@ struct ZWaveX {
                 eL[l] = x; eS[l] = y;
             }
             ZX_STAT(stTrips++);
+            ZX_MARK(1);
             ZW_SYNC();
             ZW_LANES(l) {
                 u64 const below = (1ull << l) - 1ull;
@@ -233,6 +246,7 @@ struct ZWaveX {
                     if (mS[l]) { if (gS[l] == hs[l]) { predS[l] = jS[l]; mS[l] = 0; } else mS[l] &= ~(1ull << jS[l]); }
                 }
             }
+            ZX_MARK(2);
             // ---- candidates (entry = position + 1; position 0 is never inserted), their bytes, the three tests of an iteration
             ZW_LANES(l) {
                 bool const act = l <= nIter, srch = l < nIter;
@@ -251,6 +265,7 @@ struct ZWaveX {
             ZX_STAT(stTrips++);
             u64 const hm = zw_ballot(hit);
             u32 const cnt = hm ? (u32)__builtin_ctzll(hm) + 1u : nIter;      // lanes whose inserts happen
+            ZX_MARK(3);
             // ---- commit: HL[hl] = HS[hs] = position + 1 for lanes < cnt; of several lanes with one hash the last one writes
             {   ZWV<bool> hasPred;
                 ZW_LANES(l) { hasPred[l] = l < cnt && (predL[l] < 64u || predS[l] < 64u); }
@@ -265,6 +280,7 @@ struct ZWaveX {
                     ZW_LANES(l) { if (l < cnt) { HL[hl[l]] = pos[l] + 1u; HS[hs[l]] = pos[l] + 1u; } }
                 }
             }
+            ZX_MARK(4);
             if (!hm) {                                                       // nobody matched: the loop's own bookkeeping
                 u32 const pN = ip + nIter * step;
                 if (pN >= nextStep) { step++; nextStep += 256u; }
@@ -321,6 +337,7 @@ struct ZWaveX {
                     store(anchor, mip - anchor, offN + 3u, mLength);
                 }
                 cvalid = true; cbase = curr; coffB = offN; coffC = offC;
+                ZX_MARK(5);
             } else if (kd == 1u) {
                 cvalid = false;
                 u32 f0, k0, f1, k1;
@@ -348,6 +365,7 @@ struct ZWaveX {
                 store(anchor, mip - anchor, offset + 3u, mLength);
             }
             ip = mip + mLength; anchor = ip;
+            ZX_MARK(6);
             if (ip <= ilimit) {
                 // complementary insertion — curr + 2 and ip - 2 (long), curr + 2 and ip - 1 (short), in this order — and the
                 // immediate-repcode loop; the bytes of both are requested together.  All of these writes are lane 0's, in the
@@ -396,7 +414,13 @@ struct ZWaveX {
                 }
             }
             step = 1u; nextStep = ip + 256u;
+            ZX_MARK(7);
         }
+#if defined(ZX_PROFILE) && ZJ_ON_GPU
+        if (blockIdx.x < 8u && threadIdx.x == 0 && o.n > 64u)
+            printf("zx wg %u block@%u: %u seqs, %llu kcycles; cycles/seq: window %llu  storewait %llu  tables %llu  scoreboard %llu  candidates %llu  commit %llu  stage+count %llu  slowextend+store %llu  post %llu\n",
+                   blockIdx.x, blkStart, o.n, (__builtin_readcyclecounter() - pStart) / 1000ull, pf[0] / o.n, pf[9] / o.n, pf[1] / o.n, pf[2] / o.n, pf[3] / o.n, pf[4] / o.n, pf[5] / o.n, pf[6] / o.n, pf[7] / o.n);
+#endif
         // zstd_double_fast.c:238-246: a parked offset comes back unless a new one took its place
         saved2 = (saved1 != 0u && off1 != 0u) ? saved1 : saved2;
         ZW_LANES(l) { if (l == 0) { repOut[0] = off1 ? off1 : saved1; repOut[1] = off2 ? off2 : saved2; } }
