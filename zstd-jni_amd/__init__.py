@@ -18,8 +18,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libzjni_amd.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in
-           ("zj_kernels.hip", "zj_common.h", "zj_decode.h", "zj_decode_split.h", "zj_encode.h", "zj_match_lane.h", "zj_match_run.h", "zj_match_wave.h", "zj_presplit.h", "zj_cdict.h", "zj_synth.h", "zj_need.h", "zj_invprob.h")]
+# the kernel file first (the one hipcc is given), then every header beside it: the build stamp and the rebuild test cover them all
+SOURCES = [os.path.join(_HERE, "csrc", "zj_kernels.hip")] + sorted(
+    os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h"))
 BLOCKSIZE_MAX = 1 << 17
 ERR_NO_DEVICE = 200
 ERR_UNSUPPORTED = 201

@@ -27,6 +27,18 @@
 #include "zj_simt.h"
 
 #define ZX_SB_SLOTS 512u
+#ifndef ZX_TAGS
+#define ZX_TAGS 1            /* table entries carry an 11-bit tag of the bytes the reference compares; the window's winner is presumed from the tags */
+#endif
+// Table entry: position + 1 (21 bits: frames up to 2 MiB) | tag << 21.  The tag is a function of exactly the bytes the reference's probe
+// compares (8 for the long table, 4 for the short one), so a tag mismatch proves the comparison fails (no false negatives) and a tag
+// match is right but for one probe in 2 048.
+#define ZX_POS(e) ((e) & 0x1FFFFFu)
+#if ZX_TAGS
+#define ZX_ENT(pos1, tag) ((pos1) | ((tag) << 21))
+#else
+#define ZX_ENT(pos1, tag) (pos1)
+#endif
 #define ZX_CAP_MIN 8u
 #define ZX_CARRY 128u                                // bytes per staged stream
 struct ZXLds {
@@ -63,23 +75,26 @@ struct ZWaveX {
 #define ZX_STAT(x) ((void)0)
 #endif
     // frame bytes [pos, pos + 8): never touches memory outside the frame; bytes before its start or past its end read as zero
-    // (they can only lengthen a count beyond its limit, and every count is cut to its limit)
-    ZJ_DEV_MEMBER u64 fb(u32 pos) const {
-        bool const neg = (i32)pos < 0;
-        u32 const q = neg ? 0u : zj_min(pos, nf - 8u);
-        u64 const v = ld64(base + q);
-        u32 const k = neg ? 0u - pos : pos - q;
-        u64 const r = neg ? (v << ((8u * k) & 63u)) : (v >> ((8u * k) & 63u));
-        return k >= 8u ? 0 : r;
+    // (they can only lengthen a count beyond its limit, and every count is cut to its limit).  In two halves, so that a lane block
+    // can issue all its loads (at()) before it waits for any of them (fix() — no branches: a branch per load puts a wait in
+    // front of the next load, one round trip each instead of one for all).
+    ZJ_DEV_MEMBER u32 at(u32 pos) const { i32 const p = (i32)pos, hi = (i32)(nf - 8u); return (u32)(p < 0 ? 0 : (p > hi ? hi : p)); }
+    ZJ_DEVM u64 fix(u64 v, u32 pos, u32 q) {
+        i32 const dl = (i32)pos - (i32)q;                   // > 0: bytes dropped at the low end; < 0: bytes of zero fill at the low end
+        u32 const a = dl > 0 ? (u32)dl : 0u, b = dl < 0 ? (u32)(0 - dl) : 0u;
+        u64 const r = (v >> ((8u * a) & 63u)) << ((8u * b) & 63u);
+        return (a | b) >= 8u ? 0 : r;
     }
+    ZJ_DEV_MEMBER u64 fb(u32 pos) const { u32 const q = at(pos); return fix(ld64(base + q), pos, q); }
+#define ZX_LOAD2(xa, pa, xb, pb) u64 xa, xb; { u32 const pa_ = (pa), pb_ = (pb), qa_ = at(pa_), qb_ = at(pb_); u64 const ra_ = ld64(base + qa_), rb_ = ld64(base + qb_); \
+                                   ZW_FENCE2(ra_, rb_); xa = fix(ra_, pa_, qa_); xb = fix(rb_, pb_, qb_); }
     // length of the common prefix of [a..] and [b..] (b < a), at most n - a: ZSTD_count(a, b, iend)
     ZJ_DEV_MEMBER u32 count_fwd(u32 a, u32 b) {
         u32 const lim = n - a;
         for (u32 total = 0;; total += 512u) {
             ZWV<u64> d; ZWV<bool> ne;
             ZW_LANES(l) {
-                u64 const ra = fb(a + total + 8u * l), rb = fb(b + total + 8u * l);
-                ZW_FENCE2(ra, rb);
+                ZX_LOAD2(ra, a + total + 8u * l, rb, b + total + 8u * l);
                 d[l] = ra ^ rb; ne[l] = d[l] != 0;
             }
             ZX_STAT(stTrips++);
@@ -94,8 +109,7 @@ struct ZWaveX {
         for (u32 total = 0;; total += 512u) {
             ZWV<u64> d; ZWV<bool> ne;
             ZW_LANES(l) {
-                u64 const ra = fb(ipos - total - 8u - 8u * l), rb = fb(mpos - total - 8u - 8u * l);      // (before the frame: zero on both sides, cut by `limit`)
-                ZW_FENCE2(ra, rb);
+                ZX_LOAD2(ra, ipos - total - 8u - 8u * l, rb, mpos - total - 8u - 8u * l);      // (before the frame: zero on both sides, cut by `limit`)
                 d[l] = ra ^ rb; ne[l] = d[l] != 0;
             }
             ZX_STAT(stTrips++);
@@ -116,8 +130,7 @@ struct ZWaveX {
             if (q == 0u) { pa = a0 + 8u * j; pb = b0 + 8u * j; } else if (q == 1u) { pa = i0 - 8u - 8u * j; pb = m0 - 8u - 8u * j; }
             else if (q == 2u) { pa = a1 + 8u * j; pb = b1 + 8u * j; } else { pa = i1 - 8u - 8u * j; pb = m1 - 8u - 8u * j; }
             bool const on = two || q < 2u;
-            u64 const xa = fb(on ? pa : 8u), xb = fb(on ? pb : 8u);
-            ZW_FENCE2(xa, xb);
+            ZX_LOAD2(xa, on ? pa : 8u, xb, on ? pb : 8u);
             u64 const x = xa ^ xb;
             d[l] = x; ne[l] = x != 0;
         }
@@ -143,12 +156,32 @@ struct ZWaveX {
             }
         }
     }
+    // ONE trip for everything a match at curr (source mpos) and what follows it can need: the frame from curr on (lanes 0-15), the same
+    // span from the match source on (16-31) and one previous offset back (32-47: the immediate-repcode candidate), the 64 bytes before curr
+    // and before the match source (48-63).
+    ZJ_DEV_MEMBER void stage(ZXLds& lds, u32 curr, u32 mpos, u32 offC) {
+        ZW_LANES(l) {
+            u32 const j = l & 15u, q = l >> 4;
+            u32 const p = q == 0u ? curr + 8u * j : (q == 1u ? mpos + 8u * j : (q == 2u ? curr - offC + 8u * j : (j < 8u ? curr - 64u + 8u * j : mpos - 128u + 8u * j)));
+            u64 const x = fb(p);
+            ZW_FENCE2(x, x);
+            u8* const to = q == 0u ? lds.stA + 8u * j : (q == 1u ? lds.stB + 8u * j : (q == 2u ? lds.stC + 8u * j : (j < 8u ? lds.stKA + 8u * j : lds.stKB + 8u * (j - 8u))));
+            st64(to, x);
+        }
+        ZX_STAT(stTrips++);
+        ZW_SYNC();
+    }
     // literal positions in the records are relative to the block
     ZJ_DEV_MEMBER void store(u32 litPos, u32 ll, u32 offBase, u32 ml) {
         ZW_LANES(l) { if (l == 0) { ZESeq s; s.ll = ll; s.ml = ml; s.off = offBase; s.pos = litPos - start; o.litOff[o.n] = o.lit; o.seqs[o.n] = s; } }
         o.n++; o.lit += ll;
     }
 
+    // long-table bucket and tag from ONE product (bucket = its top hashLog bits, tag = the next 11); short-table tag from the 4 compared bytes
+    ZJ_DEV_MEMBER u32 tagL_of(u32 prod) const { return (prod >> (hL.rsh - 11u)) & 0x7FFu; }
+    ZJ_DEVM u32 tagS_of(u64 w) { return ((u32)w * 2246822519u) >> 21; }
+    ZJ_DEV_MEMBER u32 entL_of(u64 w, u32 pos1, u32& bucket) const { u32 const p = zl_prod_hi(hL, w); bucket = p >> hL.rsh; return ZX_ENT(pos1, tagL_of(p)); }
+    ZJ_DEV_MEMBER u32 entS_of(u64 w, u32 pos1, u32& bucket) const { bucket = zl_hash(hS, w); return ZX_ENT(pos1, tagS_of(w)); }
     // the block frame[blkStart, blkEnd); returns the length of the last literal run.  repIn / repOut as ze_block_dfast_x.
     ZJ_DEV_MEMBER u32 run(ZXLds& lds, const u8* frame, u32 frameSize, u32 blkStart, u32 blkEnd, u32 hBitsL, u32 hBitsS, u32 mls,
                           u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry = true) {
@@ -181,7 +214,7 @@ struct ZWaveX {
             else { kmax = nextStep > ip ? (nextStep - ip + step - 1u) / step : 1u; if (kmax < 1u) kmax = 1u; room = (ilimit - ip) / step; }
             u32 nIter = kmax < cap ? kmax : cap; if (room < nIter) nIter = room;
             ZX_STAT(stPasses++); ZX_STAT(stLanes += nIter);
-            ZWV<u32> pos, hl, hs, eL, eS, rb, predL, predS; ZWV<u64> w, mL, mS;
+            ZWV<u32> pos, hl, hs, tgL, tgS, eL, eS, rb, predL, predS; ZWV<u64> w, mL, mS;
             ZWV<u32> cL, cS, kind; ZWV<bool> hit, longHit;
             cvalid = ZJ_UNI(cvalid ? 1u : 0u) != 0u; cbase = ZJ_UNI(cbase); coffB = ZJ_UNI(coffB); coffC = ZJ_UNI(coffC);
             if (cvalid && step == 1u && ip >= cbase && (ip - cbase) + nIter + 8u <= ZX_CARRY && (off1 == coffB || off1 == coffC || off1 == 0u)) {
@@ -193,17 +226,17 @@ struct ZWaveX {
                     u64 const ww = ld64(lds.stA + (pp - cbase)); u32 const rr = ld32(rs + (pp + 1u - cbase));
                     ZW_FENCE2(ww, rr);
                     w[l] = ww; rb[l] = rr;
-                    hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
+                    { u32 const pr = zl_prod_hi(hL, ww); hl[l] = pr >> hL.rsh; tgL[l] = tagL_of(pr); } hs[l] = zl_hash(hS, ww); tgS[l] = tagS_of(ww);
                     predL[l] = 64u; predS[l] = 64u;
                 }
             } else {
                 ZW_LANES(l) {
                     bool const act = l <= nIter;
                     u32 const pp = act ? ip + l * step : ip; pos[l] = pp;
-                    u64 const ww = fb(pp); u32 const rr = (u32)fb(pp + 1u - off1);
-                    ZW_FENCE2(ww, rr);
+                    ZX_LOAD2(ww, pp, rw, pp + 1u - off1);
+                    u32 const rr = (u32)rw;
                     w[l] = ww; rb[l] = rr;
-                    hl[l] = zl_hash(hL, ww); hs[l] = zl_hash(hS, ww);
+                    { u32 const pr = zl_prod_hi(hL, ww); hl[l] = pr >> hL.rsh; tgL[l] = tagL_of(pr); } hs[l] = zl_hash(hS, ww); tgS[l] = tagS_of(ww);
                     predL[l] = 64u; predS[l] = 64u;
                 }
                 ZX_STAT(stTrips++);
@@ -247,24 +280,67 @@ struct ZWaveX {
                 }
             }
             ZX_MARK(2);
-            // ---- candidates (entry = position + 1; position 0 is never inserted), their bytes, the three tests of an iteration
-            ZW_LANES(l) {
-                bool const act = l <= nIter, srch = l < nIter;
-                u32 const entL = predL[l] < 64u ? ip + predL[l] * step + 1u : eL[l], entS = predS[l] < 64u ? ip + predS[l] * step + 1u : eS[l];
-                bool const vL = act && entL > 1u, vS = srch && entS > 1u;
-                u32 const a = entL - 1u, b = entS - 1u;
-                cL[l] = a; cS[l] = b;
-                u64 const cl = fb(vL ? a : 0u); u32 const cs = (u32)fb(vS ? b : 0u);
-                ZW_FENCE2(cl, cs);
-                bool const hR = srch && off1 > 0u && rb[l] == (u32)(w[l] >> 8);
-                bool const hLg = vL && cl == w[l], hSh = vS && cs == (u32)w[l];
-                longHit[l] = hLg;
-                kind[l] = hR ? 1u : (hLg ? 2u : 3u);
-                hit[l] = srch && (hR || hLg || hSh);
+            u64 hm = 0; u32 cnt = nIter; bool needExact = true, staged = false;
+#if ZX_TAGS
+            if (carryOn) {
+                // ---- the window's winner, presumed: a lower lane of the window as entry is compared exactly (its word is in a register), a
+                //      table entry by its tag; the repcode test is exact.  No presumed hit below lane K = no hit below lane K.
+                ZWV<u32> wlo, whi, pwlo, pwhi, pslo;
+                ZW_LANES(l) { wlo[l] = (u32)w[l]; whi[l] = (u32)(w[l] >> 32); }
+                {   ZWV<u32> iL, iS;
+                    ZW_LANES(l) { iL[l] = predL[l] < 64u ? predL[l] : l; iS[l] = predS[l] < 64u ? predS[l] : l; }
+                    zw_shfl(pwlo, wlo, iL); zw_shfl(pwhi, whi, iL); zw_shfl(pslo, wlo, iS); }
+                ZW_LANES(l) {
+                    bool const act = l <= nIter, srch = l < nIter;
+                    bool pL, pS; u32 a, b;
+                    if (predL[l] < 64u) { pL = pwlo[l] == wlo[l] && pwhi[l] == whi[l]; a = ip + predL[l] * step; }
+                    else { u32 const e = eL[l]; pL = ZX_POS(e) > 1u && (e >> 21) == tgL[l]; a = ZX_POS(e) - 1u; }
+                    if (predS[l] < 64u) { pS = pslo[l] == wlo[l]; b = ip + predS[l] * step; }
+                    else { u32 const e = eS[l]; pS = ZX_POS(e) > 1u && (e >> 21) == tgS[l]; b = ZX_POS(e) - 1u; }
+                    pL = pL && act; pS = pS && srch;
+                    cL[l] = a; cS[l] = b;
+                    bool const hR = srch && off1 > 0u && rb[l] == (u32)(w[l] >> 8);
+                    longHit[l] = pL;
+                    kind[l] = hR ? 1u : (pL ? 2u : 3u);
+                    hit[l] = srch && (hR || pL || pS);
+                }
+                u64 const pm = zw_ballot(hit);
+                if (!pm) needExact = false;                              // (hm = 0, cnt = nIter)
+                else {
+                    u32 const K = (u32)__builtin_ctzll(pm), curr = ip + K * step, kd = zw_get(kind, K);
+                    if (!(kd == 3u && zw_getb(longHit, K + 1u))) {         // (a presumed long match at ip1 as well: the exact tests decide)
+                        u32 const mpos = kd == 2u ? zw_get(cL, K) : (kd == 3u ? zw_get(cS, K) : curr - off1);
+                        cvalid = false;                                  // (the staged spans are replaced; valid again once the match is settled)
+                        stage(lds, curr, mpos, kd == 1u ? off2 : off1);
+                        // the presumption checked on the staged bytes: 8 (long) or 4 (short) at the candidate against those at curr
+                        bool ok = true;
+                        if (kd == 2u) ok = ZJ_UNI((u32)(ld64(lds.stA) == ld64(lds.stB))) != 0u;
+                        else if (kd == 3u) ok = ZJ_UNI((u32)(ld32(lds.stA) == ld32(lds.stB))) != 0u;
+                        if (ok) { hm = pm; cnt = K + 1u; needExact = false; staged = true; }
+                    }
+                }
             }
-            ZX_STAT(stTrips++);
-            u64 const hm = zw_ballot(hit);
-            u32 const cnt = hm ? (u32)__builtin_ctzll(hm) + 1u : nIter;      // lanes whose inserts happen
+#endif
+            if (needExact) {
+                // ---- candidates (entry = position + 1; position 0 is never inserted), their bytes, the three tests of an iteration
+                ZW_LANES(l) {
+                    bool const act = l <= nIter, srch = l < nIter;
+                    u32 const entL = predL[l] < 64u ? ip + predL[l] * step + 1u : ZX_POS(eL[l]), entS = predS[l] < 64u ? ip + predS[l] * step + 1u : ZX_POS(eS[l]);
+                    bool const vL = act && entL > 1u, vS = srch && entS > 1u;
+                    u32 const a = entL - 1u, b = entS - 1u;
+                    cL[l] = a; cS[l] = b;
+                    ZX_LOAD2(cl, vL ? a : 0u, csw, vS ? b : 0u);
+                    u32 const cs = (u32)csw;
+                    bool const hR = srch && off1 > 0u && rb[l] == (u32)(w[l] >> 8);
+                    bool const hLg = vL && cl == w[l], hSh = vS && cs == (u32)w[l];
+                    longHit[l] = hLg;
+                    kind[l] = hR ? 1u : (hLg ? 2u : 3u);
+                    hit[l] = srch && (hR || hLg || hSh);
+                }
+                ZX_STAT(stTrips++);
+                hm = zw_ballot(hit);
+                cnt = hm ? (u32)__builtin_ctzll(hm) + 1u : nIter;            // lanes whose inserts happen
+            }
             ZX_MARK(3);
             // ---- commit: HL[hl] = HS[hs] = position + 1 for lanes < cnt; of several lanes with one hash the last one writes
             {   ZWV<bool> hasPred;
@@ -274,10 +350,10 @@ struct ZWaveX {
                     ZW_SYNC();
                     ZW_LANES(l) { if (l < cnt) { if (predL[l] < 64u) lds.shadowL[predL[l]] = 1; if (predS[l] < 64u) lds.shadowS[predS[l]] = 1; } }
                     ZW_SYNC();
-                    ZW_LANES(l) { if (l < cnt) { if (!lds.shadowL[l]) HL[hl[l]] = pos[l] + 1u; if (!lds.shadowS[l]) HS[hs[l]] = pos[l] + 1u; } }
+                    ZW_LANES(l) { if (l < cnt) { if (!lds.shadowL[l]) HL[hl[l]] = ZX_ENT(pos[l] + 1u, tgL[l]); if (!lds.shadowS[l]) HS[hs[l]] = ZX_ENT(pos[l] + 1u, tgS[l]); } }
                     ZW_SYNC();
                 } else {
-                    ZW_LANES(l) { if (l < cnt) { HL[hl[l]] = pos[l] + 1u; HS[hs[l]] = pos[l] + 1u; } }
+                    ZW_LANES(l) { if (l < cnt) { HL[hl[l]] = ZX_ENT(pos[l] + 1u, tgL[l]); HS[hs[l]] = ZX_ENT(pos[l] + 1u, tgS[l]); } }
                 }
             }
             ZX_MARK(4);
@@ -301,16 +377,7 @@ struct ZWaveX {
                 // inserts, the repcode test behind the match and the next window are then LDS reads as long as they stay inside.
                 u32 const mpos = kd == 2u ? zw_get(cL, K) : (kd == 3u ? zw_get(cS, K) : curr - off1);
                 u32 const offN = curr - mpos, offC = kd == 1u ? off2 : off1, dd = kd == 1u ? 5u : (kd == 2u ? 8u : 4u);
-                ZW_LANES(l) {
-                    u32 const j = l & 15u, q = l >> 4;
-                    u32 const p = q == 0u ? curr + 8u * j : (q == 1u ? mpos + 8u * j : (q == 2u ? curr - offC + 8u * j : (j < 8u ? curr - 64u + 8u * j : mpos - 128u + 8u * j)));
-                    u64 const x = fb(p);
-                    ZW_FENCE2(x, x);
-                    u8* const to = q == 0u ? lds.stA + 8u * j : (q == 1u ? lds.stB + 8u * j : (q == 2u ? lds.stC + 8u * j : (j < 8u ? lds.stKA + 8u * j : lds.stKB + 8u * (j - 8u))));
-                    st64(to, x);
-                }
-                ZX_STAT(stTrips++);
-                ZW_SYNC();
+                if (!staged) stage(lds, curr, mpos, offC);
                 ZWV<u64> d2; ZWV<bool> ne2;
                 ZW_LANES(l) {
                     u64 x = 0;
@@ -333,7 +400,7 @@ struct ZWaveX {
                     else k0 = lim0 <= 64u ? lim0 : 64u + count_back(curr - 64u, mpos - 64u, lim0 - 64u);
                     mip = curr - k0; mLength = dd + f0 + k0;
                     off2 = off1; off1 = offN;
-                    if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ip1 + 1u; } }
+                    if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u), t1 = zw_get(tgL, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ZX_ENT(ip1 + 1u, t1); } }
                     store(anchor, mip - anchor, offN + 3u, mLength);
                 }
                 cvalid = true; cbase = curr; coffB = offN; coffC = offC;
@@ -361,7 +428,7 @@ struct ZWaveX {
                 u32 const offset = mip - mpos;
                 mip -= k0; mLength += k0;
                 off2 = off1; off1 = offset;
-                if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ip1 + 1u; } }
+                if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u), t1 = zw_get(tgL, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ZX_ENT(ip1 + 1u, t1); } }
                 store(anchor, mip - anchor, offset + 3u, mLength);
             }
             ip = mip + mLength; anchor = ip;
@@ -388,8 +455,10 @@ struct ZWaveX {
                         cov = 512u;
                         ZW_LANES(l) {
                             u32 const q = l == 0 ? curr + 2u : (l == 1 ? ip - 2u : ip - 1u);
-                            u64 const ra = fb(ip + 8u * l), rbb = fb(ip - off2 + 8u * l), rq = fb(q);
-                            ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
+                            u32 const p0 = ip + 8u * l, p1 = ip - off2 + 8u * l, q0_ = at(p0), q1_ = at(p1), q2_ = at(q);
+                            u64 const r0_ = ld64(base + q0_), r1_ = ld64(base + q1_), r2_ = ld64(base + q2_);
+                            ZW_FENCE2(r0_, r1_); ZW_FENCE2(r2_, r2_);
+                            u64 const ra = fix(r0_, p0, q0_), rbb = fix(r1_, p1, q1_), rq = fix(r2_, q, q2_);
                             wi[l] = ra; d[l] = ra ^ rbb; ne[l] = d[l] != 0; wq[l] = rq;
                         }
                         ZX_STAT(stTrips++);
@@ -397,8 +466,8 @@ struct ZWaveX {
                     if (first) {
                         u64 const q0 = zw_get64(wq, 0), q1 = zw_get64(wq, 1), q2 = zw_get64(wq, 2);
                         ZW_LANES(l) { if (l == 0) {
-                            HL[zl_hash(hL, q0)] = curr + 3u; HL[zl_hash(hL, q1)] = ip - 1u;
-                            HS[zl_hash(hS, q0)] = curr + 3u; HS[zl_hash(hS, q2)] = ip; } }
+                            u32 b0_, b1_, b2_, b3_; u32 const e0_ = entL_of(q0, curr + 3u, b0_), e1_ = entL_of(q1, ip - 1u, b1_), e2_ = entS_of(q0, curr + 3u, b2_), e3_ = entS_of(q2, ip, b3_);
+                            HL[b0_] = e0_; HL[b1_] = e1_; HS[b2_] = e2_; HS[b3_] = e3_; } }
                     }
                     if (off2 == 0u || (u32)zw_get64(d, 0) != 0u) break;
                     u64 const m = zw_ballot(ne);
@@ -407,7 +476,7 @@ struct ZWaveX {
                     else rLength = lim <= cov ? lim : cov + count_fwd(ip + cov, ip - off2 + cov);
                     { u32 const t = off2; off2 = off1; off1 = t; }
                     {   u64 const wi0 = zw_get64(wi, 0);
-                        ZW_LANES(l) { if (l == 0) { HS[zl_hash(hS, wi0)] = ip + 1u; HL[zl_hash(hL, wi0)] = ip + 1u; } } }
+                        ZW_LANES(l) { if (l == 0) { u32 bs_, bl_; u32 const es_ = entS_of(wi0, ip + 1u, bs_), el_ = entL_of(wi0, ip + 1u, bl_); HS[bs_] = es_; HL[bl_] = el_; } } }
                     store(anchor, 0u, 1u, rLength);
                     ip += rLength; anchor = ip;
                     if (ip > ilimit) break;
