@@ -7,7 +7,10 @@ import random
 import pytest
 
 from conftest import golden
-from util import emu_lib, emu_compress_multi, emu_decompress
+import ctypes as C
+import os
+
+from util import ROOT, emu_lib, emu_compress_multi, emu_decompress
 
 
 @pytest.fixture(scope="module")
@@ -103,3 +106,32 @@ def test_multiblock_random_shapes(emu, oracle_ref, zj):
         d = b"".join(parts)[:size]
         level = rnd.choice([1, 2, 3])
         check(emu, oracle_ref, d, level, rnd.random() < 0.3, rnd.random() < 0.8, tag=("shape", k))
+
+
+def test_multiblock_wave_matcher_orders_and_switches(emu, oracle_ref, zj):
+    """level-3 blocks run the wave matcher (zstd-jni_amd/csrc/zj_match_wavex.h) in its explicit-SIMT build: 64 emulated lanes visited in
+    ascending order (libzjni_emu.so) and in descending order (libzjni_emu_rev.so — where lanes of one step store to one address the GPU
+    promises no winner, so the frames must not depend on it), with and without the staged spans, and the one-lane parse behind
+    ZE_FLAG_MULTI_SERIAL: every variant gives the reference's frame.  Inputs: what drives windows wider than a hit (noise, long
+    literal runs), equal hashes inside a window (two-letter alphabets, byte runs), matches longer than the staged span, matches that
+    reach back over block borders, steps above 1."""
+    rev = C.CDLL(os.path.join(ROOT, "tests", "emu", "libzjni_emu_rev.so"))
+    rev.emu_compress_multi.restype = C.c_ulonglong
+    rev.emu_compress_multi.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    rnd = random.Random(12)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(200000))
+    cases = [xml[:400000], xml[1000000:1000000 + 1048576],
+             bytes(rnd.choice(b"ab") for _ in range(300000)),
+             b"".join(bytes([i & 255]) * rnd.randrange(1, 40) for i in range(20000))[:330000],
+             noise[:150000] + noise[:150000] + xml[:50000],                       # a 150 000-byte match across a block border
+             (noise[:37] * 9000)[:300000], (noise[:700] * 500)[:300000],
+             noise[:140000] + xml[:140000] + noise[:3000] + xml[100:130000],
+             b"".join(zj.synth_host(65536, 2 + 4 * i, 1) for i in range(5)),      # low-entropy class: dense short matches, repcodes
+             noise[:5000] + noise[4000:4990] + b"#" + noise[4000:5000] + xml[:200000] + noise[100:400] + b"!" + noise[99:5000]]
+    for k, d in enumerate(cases):
+        want = oracle_ref.compress(d, 3)
+        for lib, name in ((emu, "ascending"), (rev, "descending")):
+            for serial in (False, 2, True):
+                if lib is rev and serial is True: continue
+                assert emu_compress_multi(lib, d, 3, serial=serial) == want, (k, name, serial)

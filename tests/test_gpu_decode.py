@@ -139,10 +139,14 @@ def force_split(monkeypatch):
     monkeypatch.setenv("ZJNI_DSPLIT_MIN", "1")        # every batch through prep -> lane sequence decode -> execute
 
 
-def test_gpu_split_pipeline_mixed_batch(gpu, oracle_ref, oracle_port, force_split):
+@pytest.mark.parametrize("lit_pass", ["on", "off", "slots16k"])
+def test_gpu_split_pipeline_mixed_batch(gpu, oracle_ref, oracle_port, force_split, monkeypatch, lit_pass):
     """three-stage decoder: simple frames (one block, <= 64 KiB) next to frames it must hand to the fused kernel
-    (multi-block, multi-frame, raw blocks, truncated, corrupted) in ONE batch; results == fused path == reference"""
+    (multi-block, multi-frame, raw blocks, truncated, corrupted) in ONE batch; results == fused path == reference.
+    lit_pass: stage 2b (zd_lit_frame: Huffman literals regenerated beside the sequence decode) on (the default), off
+    (ZJNI_DEC_LIT=0), and with 16 KiB slots so that the larger frames' literals stay with the execution kernel."""
     import random
+    if lit_pass == "off": monkeypatch.setenv("ZJNI_DEC_LIT", "0")
     rnd = random.Random(17)
     items, caps = [], []
     for name, data in edge_inputs():
@@ -160,6 +164,7 @@ def test_gpu_split_pipeline_mixed_batch(gpu, oracle_ref, oracle_port, force_spli
         bad = bytearray(good); bad[pos] ^= 0x5A
         items.append(bytes(bad)); caps.append(65536)
     items.append(good); caps.append(65535)               # destination one byte short
+    if lit_pass == "slots16k": monkeypatch.setenv("ZJNI_DEC_LIT_BYTES", str(16384 * len(items) + 4096))
     split = gpu.decompress_batch(items, caps)
     import os
     os.environ["ZJNI_DSPLIT_MIN"] = "1000000000"

@@ -34,8 +34,13 @@ def _inputs(gpu, seed, count):
     return out
 
 
+@pytest.mark.parametrize("route", ["wave", "lanes", "one-lane"])
 @pytest.mark.parametrize("count", [40, 4500])
-def test_gpu_level4_frames_are_the_references(gpu, oracle_ref, count):
+def test_gpu_level4_frames_are_the_references(gpu, oracle_ref, monkeypatch, count, route):
+    """route (frames above 16 KiB, double-fast): the wave matcher of zj_match_wavex.h on the wave-per-frame kernel (the default, any
+    batch size), the lane-slot kernel of large batches (ZJNI_L4_LANES=1), the one-lane parse (ZJNI_MULTI_WAVE=0)"""
+    if route == "lanes": monkeypatch.setenv("ZJNI_L4_LANES", "1")
+    if route == "one-lane": monkeypatch.setenv("ZJNI_MULTI_WAVE", "0")
     datas = _inputs(gpu, 7 + count, count) + [gpu.synth_host(131073, 1, 1), gpu.synth_host(300000, 2, 1)]
     for checksum in (False, True):
         outs = gpu.compress_batch(datas, 4, checksum=checksum)

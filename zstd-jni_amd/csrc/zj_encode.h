@@ -1500,6 +1500,13 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
             zj_mem_order();
             g.sync();
             pf.mark(0);
+            if (strategy == 2 && srcSize >= 64u && !(flags & ZE_FLAG_MULTI_SERIAL)) {     // level 4 (double-fast): the whole wave parses (zj_match_wavex.h), the frame as one block
+                GRP_SERIAL(g) { sh.blkRep[0] = 1; sh.blkRep[1] = 4; }
+                g.sync();
+                ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+                u32 const lastLL = zx_block_dfast_wave(lds, o, src, srcSize, 0u, srcSize, hlog, clog, mls, hbmTables, hbmTables + (1u << hlog), sh.blkRep, sh.blkNextRep, !(flags & ZE_FLAG_MULTI_NOCARRY));
+                GRP_SERIAL(g) { sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL; }
+            } else
             GRP_SERIAL(g) {
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 ZEParams q; q.windowLog = sh.windowLog; q.chainLog = clog; q.hashLog = hlog; q.minMatch = mls; q.strategy = strategy; q.searchLog = sh.searchLog;

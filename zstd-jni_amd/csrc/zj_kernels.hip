@@ -647,7 +647,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 
 // Multi-block frames (128 KiB < input <= ZE_MULTI_MAX): one wavefront walks a frame block by block (ze_compress_multi); its
 // frame-wide hash tables sit in HBM, one set per resident workgroup.
-__global__ __launch_bounds__(64) void zj_encode_multi_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
+#ifndef ZJ_MULTI_WAVES
+#define ZJ_MULTI_WAVES 2       /* resident waves per SIMD the register allocation aims at (the wave matcher's windows want ~220 VGPRs) */
+#endif
+__global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                               u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                               u8* scratch, u32* tables, u32 flags, u32 ldsBytes) {
     __shared__ ZEncShared sh;
@@ -1197,7 +1200,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
         // ZJNI_DEC_LIT=0 switches the pass off (A/B runs); ZJNI_DEC_LIT_BYTES sets the budget (default 4 GiB, nothing under a scratch limit).
         u8* litSlots = nullptr; u32 litSlot = 0;
-        {   static int const litEnv = (getenv("ZJNI_DEC_LIT") && atoi(getenv("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
+        {   int const litEnv = (getenv("ZJNI_DEC_LIT") && atoi(getenv("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
             if (litEnv && !ddict && !g_scratch_limit) {
                 size_t budget = (size_t)4 << 30; if (const char* ov = getenv("ZJNI_DEC_LIT_BYTES")) budget = (size_t)atoll(ov);
                 size_t slot = budget / n; if (slot > ZD_BLOCK_MAX) slot = ZD_BLOCK_MAX; slot &= ~(size_t)4095;
@@ -1349,6 +1352,19 @@ static inline void zj_dbg_sync(const char* what) {        // ZJNI_DEBUG_SYNC=1: 
     hipError_t const e = hipDeviceSynchronize();
     fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e)); fflush(stderr);
 }
+// Frame-wide match-finder tables of the wave-per-frame kernels (zj_encode_multi_kernel, zj_encode_cdict_copy_kernel): 1 MiB per resident
+// workgroup, allocated on first use.  Two workgroups per SIMD (8 per CU): the wave matcher of multi-block frames is a chain of round trips
+// and LDS steps per frame, a second wave beside it fills the gaps (2 048 x 1 MiB frames: 656 -> 412 ms); the LDS of the entropy stage
+// (18 KiB per workgroup) does not admit a third.  ZJNI_MULTI_PER_CU overrides.
+static bool ensure_multi_tables(DevState* d) {
+    if (d->multiTables) return true;
+    int perCU = 8; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
+    int fit = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, zj_encode_multi_kernel, 64, sizeof(ZEEntropy)) == hipSuccess && fit >= 1 && fit < perCU) perCU = fit;
+    d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
+    if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; (void)hipGetLastError(); return false; }
+    return true;
+}
 static inline u32 zj_frame_flags(int word) { return (u32)word & ZE_FLAG_MASK; }
 static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                          uint64_t* d_result, size_t n, int levelWord, u32 flags, void* stream) {
@@ -1376,14 +1392,13 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
     // levels 4-8, frames of 16-128 KiB: one lane per frame when the batch is large (below) and the scratch budget has room for a table set
     // per lane slot, else one wave per frame (here)
-    bool const bigLanes = level > 3 && n >= 4096 && (!g_scratch_limit || g_scratch_limit >= ((size_t)48 << 30));
+    // (level 4 is double-fast: its frames above 16 KiB stay on list C, where the wave matcher of zj_match_wavex.h parses them — two waves per
+    //  SIMD each on its own frame beat 256 waves of one-lane parses; ZJNI_L4_LANES=1 keeps the lane-slot route selectable for A/B runs)
+    bool const l4wave = level == 4 && !(getenv("ZJNI_L4_LANES") && atoi(getenv("ZJNI_L4_LANES")) == 1);
+    bool const bigLanes = level > 3 && !l4wave && n >= 4096 && (!g_scratch_limit || g_scratch_limit >= ((size_t)48 << 30));
     if (!bigLanes)
     {   // list C: multi-block frames (levels 1-3) and the single-block frames of levels 4-8 above 16 KiB.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 1 MiB per resident workgroup.
-        if (!d->multiTables) {
-            int perCU = 4; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
-            d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
-            if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
-        }
+        if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
         // level-3 blocks of multi-block frames: the wave matcher (zj_match_wavex.h); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
         u32 multiSerial = 0; if (const char* ov = getenv("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
@@ -1806,11 +1821,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     }
     for (int par = 0; par < 2; par++) if (pending[par] && hipStreamWaitEvent(st, d->cdEncDone[par], 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
     {   // sources beyond the attach range (they got parameter_unsupported above): copy mode, if the call has any
-        if (!d->multiTables) {
-            int perCU = 4; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
-            d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;
-            if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; return ZJNI_ERR(64); }
-        }
+        if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
         u32* const cc = d->counters + 56;            // [0] copy-mode frames of the call, [1] work
         if (hipMemsetAsync(cc, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         hipLaunchKernelGGL(zj_cdict_count_copy_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u32)n, cd, cc);
