@@ -27,7 +27,16 @@ def upload(arr):
     p = dmalloc(arr.nbytes); chk(hip.hipMemcpy(p, arr.ctypes.data_as(vp), C.c_size_t(arr.nbytes), 1)); return p
 soff = upload(np.arange(n + 1, dtype=np.uint64) * size); coff = upload(np.arange(n + 1, dtype=np.uint64) * bound)
 csz = dmalloc(n * 8); dsz = dmalloc(n * 8); poff = dmalloc((n + 1) * 8)
-chk(L.zjni_synth_fill_device(src, size, 0, n, None)); chk(hip.hipDeviceSynchronize())
+if os.environ.get("PROF_DATA") == "xml":          # bench.py --config 1's buffers: overlapping slices of the reference's xml fixture
+    from oracle import ref
+    xml = np.frombuffer(ref.decompress(open(os.path.join(ROOT, "tests", "golden", "xml-1.zst"), "rb").read(), 6_000_000), dtype=np.uint8)
+    host = np.empty(n * size, dtype=np.uint8); span = xml.size - size
+    for i in range(n):
+        o = (i * 4099) % span; host[i * size:(i + 1) * size] = xml[o:o + size]
+    chk(hip.hipMemcpy(src, host.ctypes.data_as(vp), C.c_size_t(host.nbytes), 1)); del host
+else:
+    chk(L.zjni_synth_fill_device(src, size, 0, n, None))
+chk(hip.hipDeviceSynchronize())
 ev = [vp() for _ in range(5)]
 for x in ev: chk(hip.hipEventCreate(C.byref(x)))
 tc = td = tp = 0.0

@@ -2083,9 +2083,19 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
     zj_mem_order();
     g.sync();
     u32 pos = hdr, at = 0, isFirst = 1; i64 savings = 0;
+#if defined(ZX_PROFILE) && ZJ_ON_GPU
+    u64 zxSplit = 0, zxBlocks = 0, zxT = __builtin_readcyclecounter();
+#define ZX_FRAME_MARK(acc) do { u64 const t_ = __builtin_readcyclecounter(); acc += t_ - zxT; zxT = t_; } while (0)
+#else
+#define ZX_FRAME_MARK(acc) ((void)0)
+#endif
     while (at < srcSize) {
-        GRP_SERIAL(g) { sh.tmp[0] = zp_block_size(src + at, srcSize - at, p.strategy, savings, (u32*)lds); }
+        if (p.strategy == 2 && srcSize - at >= 131072u && savings >= 3) {       // double-fast: the chunk fingerprints, all lanes
+            u32 const bs = zp_split_by_chunks_g(g, src + at, (u32*)lds);
+            GRP_SERIAL(g) { sh.tmp[0] = bs; }
+        } else GRP_SERIAL(g) { sh.tmp[0] = zp_block_size(src + at, srcSize - at, p.strategy, savings, (u32*)lds); }
         g.sync();
+        ZX_FRAME_MARK(zxSplit);
         u32 const blockSize = ZJ_UNI(sh.tmp[0]);
         g.sync();
         ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables; ba.serialParse = (flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u);
@@ -2093,7 +2103,11 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
         if (r > ZJ_ERR64(256)) return r;
         savings += (i64)blockSize - (i64)r;
         at += blockSize; pos += (u32)r; isFirst = 0;
+        ZX_FRAME_MARK(zxBlocks);
     }
+#if defined(ZX_PROFILE) && ZJ_ON_GPU
+    if (blockIdx.x < 8u && threadIdx.x == 0) printf("zx frame wg %u: %u bytes, block sizing (pre-split) %llu kcycles, blocks (parse + entropy stage) %llu kcycles\n", blockIdx.x, srcSize, (unsigned long long)(zxSplit / 1000ull), (unsigned long long)(zxBlocks / 1000ull));
+#endif
     if (dstCap < pos + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
     if (tail) {
         u64 const h = zj_xxh64(g, src, srcSize);

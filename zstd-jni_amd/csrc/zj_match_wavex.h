@@ -488,7 +488,7 @@ struct ZWaveX {
 #if defined(ZX_PROFILE) && ZJ_ON_GPU
         if (blockIdx.x < 8u && threadIdx.x == 0 && o.n > 64u)
             printf("zx wg %u block@%u: %u seqs, %llu kcycles; cycles/seq: window %llu  storewait %llu  tables %llu  scoreboard %llu  candidates %llu  commit %llu  stage+count %llu  slowextend+store %llu  post %llu\n",
-                   blockIdx.x, blkStart, o.n, (__builtin_readcyclecounter() - pStart) / 1000ull, pf[0] / o.n, pf[9] / o.n, pf[1] / o.n, pf[2] / o.n, pf[3] / o.n, pf[4] / o.n, pf[5] / o.n, pf[6] / o.n, pf[7] / o.n);
+                   blockIdx.x, blkStart, o.n, (unsigned long long)((__builtin_readcyclecounter() - pStart) / 1000ull), (unsigned long long)(pf[0] / o.n), (unsigned long long)(pf[9] / o.n), (unsigned long long)(pf[1] / o.n), (unsigned long long)(pf[2] / o.n), (unsigned long long)(pf[3] / o.n), (unsigned long long)(pf[4] / o.n), (unsigned long long)(pf[5] / o.n), (unsigned long long)(pf[6] / o.n), (unsigned long long)(pf[7] / o.n));
 #endif
         // zstd_double_fast.c:238-246: a parked offset comes back unless a new one took its place
         saved2 = (saved1 != 0u && off1 != 0u) ? saved1 : saved2;

@@ -47,6 +47,42 @@ ZJ_DEV u32 zp_split_by_chunks(const u8* p, u32* ev) {                  // level 
     }
     return 131072u;
 }
+// zp_split_by_chunks on the whole group: the 191 samples of a chunk are loaded by the lanes at once (one lane asks for them one round
+// trip after the other: 1.8 M cycles per block, measured), histograms by LDS atomics, the distance summed over the lanes — integer
+// arithmetic throughout, the same value whatever the order.  `ev`: 256 + 256 histogram words and 2 words for the sum, in LDS.
+template <class G>
+ZJ_DEV u32 zp_split_by_chunks_g(const G& g, const u8* p, u32* ev) {
+    u32* const past = ev; u32* const nw = ev + 256; u32* const sum = ev + 512;      // sum: low / high word of the 64-bit distance
+    u32 const perChunk = (8192u - 2u + 1u) / 43u, samples = (8192u - 1u + 42u) / 43u;
+    u32 nPast = perChunk, penalty = 3;
+    GRP_FOR(g, n, 256) past[n] = 0;
+    g.sync();
+    GRP_FOR(g, i, samples) atomicAdd(&past[p[i * 43u]], 1u);
+    g.sync();
+    for (u32 pos = 8192u; pos <= 131072u - 8192u; pos += 8192u) {
+        GRP_FOR(g, n, 256) nw[n] = 0;
+        GRP_SERIAL(g) { sum[0] = 0; sum[1] = 0; }
+        g.sync();
+        GRP_FOR(g, i, samples) atomicAdd(&nw[p[pos + i * 43u]], 1u);
+        g.sync();
+        {   u64 d = 0;
+            GRP_FOR(g, n, 256) d += zp_abs64((i64)past[n] * (i64)perChunk - (i64)nw[n] * (i64)nPast);
+            // (d < 2^8 entries x 2^17 x 2^12: the low words' carries are counted into the high word)
+            u32 const lo = (u32)d, hi = (u32)(d >> 32);
+            u32 const before = atomicAdd(&sum[0], lo);
+            atomicAdd(&sum[1], hi + ((u32)(before + lo) < lo ? 1u : 0u)); }
+        g.sync();
+        u64 const dist = ((u64)ZJ_UNI(sum[1]) << 32) | ZJ_UNI(sum[0]);
+        u64 const threshold = (u64)nPast * (u64)perChunk * (u64)(14u + penalty) / 16u;
+        g.sync();
+        if (dist >= threshold) return pos;
+        GRP_FOR(g, n, 256) past[n] += nw[n];
+        nPast += perChunk;
+        if (penalty > 0) penalty--;
+        g.sync();
+    }
+    return 131072u;
+}
 // ZSTD_optimalBlockSize for levels 1-3 (blockSizeMax = 128 KiB, default pre-split level)
 ZJ_DEV u32 zp_block_size(const u8* p, u32 remaining, u32 strategy, i64 savings, u32* ev) {
     if (remaining < 131072u) return remaining;
