@@ -99,8 +99,8 @@ struct ZWaveX {
             }
             ZX_STAT(stTrips++);
             u64 const m = zw_ballot(ne);
-            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); return c < lim ? c : lim; }
-            if (total + 512u >= lim) return lim;
+            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); return ZJ_UNI(c < lim ? c : lim); }
+            if (total + 512u >= lim) return ZJ_UNI(lim);
         }
     }
     // number of equal bytes going backwards from (ipos - 1, mpos - 1), at most limit (<= mpos < ipos)
@@ -114,8 +114,8 @@ struct ZWaveX {
             }
             ZX_STAT(stTrips++);
             u64 const m = zw_ballot(ne);
-            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_clzll(zw_get64(d, j)) >> 3); return c < limit ? c : limit; }
-            if (total + 512u >= limit) return limit;
+            if (m) { u32 const j = (u32)__builtin_ctzll(m); u32 const c = total + 8u * j + ((u32)__builtin_clzll(zw_get64(d, j)) >> 3); return ZJ_UNI(c < limit ? c : limit); }
+            if (total + 512u >= limit) return ZJ_UNI(limit);
         }
     }
     // Both directions of up to two candidate matches in ONE trip: lanes 0-15 count forwards from (a0, b0), lanes 16-31 backwards from
@@ -155,6 +155,7 @@ struct ZWaveX {
                 else k1 = lim1 <= 128u ? lim1 : 128u + count_back(i1 - 128u, m1 - 128u, lim1 - 128u);
             }
         }
+        f0 = ZJ_UNI(f0); k0 = ZJ_UNI(k0); f1 = ZJ_UNI(f1); k1 = ZJ_UNI(k1);      // wave-uniform by construction (ballots, read lanes): scalar registers, scalar branches
     }
     // ONE trip for everything a match at curr (source mpos) and what follows it can need: the frame from curr on (lanes 0-15), the same
     // span from the match source on (16-31) and one previous offset back (32-47: the immediate-repcode candidate), the 64 bytes before curr
@@ -391,6 +392,7 @@ struct ZWaveX {
                 {   u32 const mm = (u32)m2 & 0x7FFFu;
                     if (mm) { u32 const j = (u32)__builtin_ctz(mm); f0 = 8u * j + ((u32)__builtin_ctzll(zw_get64(d2, j)) >> 3); if (f0 > fl) f0 = fl; }
                     else f0 = fl <= 120u ? fl : 120u + count_fwd(a0 + 120u, a0 - offN + 120u); }
+                f0 = ZJ_UNI(f0);
                 if (kd == 1u) {
                     mLength = 4u + f0; mip = curr + 1u;
                     store(anchor, mip - anchor, 1u, mLength);
@@ -398,6 +400,7 @@ struct ZWaveX {
                     u32 const lim0 = zj_min(curr - anchor, mpos), mb = (u32)(m2 >> 16) & 0xFFu;
                     if (mb) { u32 const j = (u32)__builtin_ctz(mb); k0 = 8u * j + ((u32)__builtin_clzll(zw_get64(d2, 16u + j)) >> 3); if (k0 > lim0) k0 = lim0; }
                     else k0 = lim0 <= 64u ? lim0 : 64u + count_back(curr - 64u, mpos - 64u, lim0 - 64u);
+                    k0 = ZJ_UNI(k0);
                     mip = curr - k0; mLength = dd + f0 + k0;
                     off2 = off1; off1 = offN;
                     if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u), t1 = zw_get(tgL, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ZX_ENT(ip1 + 1u, t1); } }
@@ -431,7 +434,7 @@ struct ZWaveX {
                 if (step < 4u) { u32 const h1 = zw_get(hl, K + 1u), t1 = zw_get(tgL, K + 1u); ZW_LANES(l) { if (l == 0) HL[h1] = ZX_ENT(ip1 + 1u, t1); } }
                 store(anchor, mip - anchor, offset + 3u, mLength);
             }
-            ip = mip + mLength; anchor = ip;
+            ip = ZJ_UNI(mip + mLength); anchor = ip; off1 = ZJ_UNI(off1); off2 = ZJ_UNI(off2);
             ZX_MARK(6);
             if (ip <= ilimit) {
                 // complementary insertion — curr + 2 and ip - 2 (long), curr + 2 and ip - 1 (short), in this order — and the
@@ -439,6 +442,7 @@ struct ZWaveX {
                 // reference's order: two of them may name one bucket.
                 for (bool first = true;; first = false) {
                     ZWV<u64> d, wi, wq; ZWV<bool> ne; u32 cov;
+                    ip = ZJ_UNI(ip); off1 = ZJ_UNI(off1); off2 = ZJ_UNI(off2); o.n = ZJ_UNI(o.n); o.lit = ZJ_UNI(o.lit);
                     u32 const e = ip - cbase;
                     if (cvalid && e + 8u <= ZX_CARRY && (off2 == coffB || off2 == coffC || off2 == 0u)) {
                         const u8* const xs = (off2 == coffB) ? lds.stB : lds.stC;      // (off2 == 0: not compared)
@@ -474,6 +478,7 @@ struct ZWaveX {
                     u32 const lim = n - ip; u32 rLength;
                     if (m) { u32 const j = (u32)__builtin_ctzll(m); rLength = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); if (rLength > lim) rLength = lim; }
                     else rLength = lim <= cov ? lim : cov + count_fwd(ip + cov, ip - off2 + cov);
+                    rLength = ZJ_UNI(rLength);
                     { u32 const t = off2; off2 = off1; off1 = t; }
                     {   u64 const wi0 = zw_get64(wi, 0);
                         ZW_LANES(l) { if (l == 0) { u32 bs_, bl_; u32 const es_ = entS_of(wi0, ip + 1u, bs_), el_ = entL_of(wi0, ip + 1u, bl_); HS[bs_] = es_; HL[bl_] = el_; } } }
@@ -502,6 +507,11 @@ struct ZWaveX {
 ZJ_DEV u32 zx_block_dfast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls,
                                u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry) {
     ZWaveX m; m.o = o;
+    // every argument is the same in all lanes, but some reach here through memory (the block arguments): said once, so that the parse
+    // keeps them in scalar registers and branches on them with scalar branches (the pointers are left alone: an integer round trip would
+    // cost them their address space, and every load would become a flat load)
+    frameSize = ZJ_UNI(frameSize); start = ZJ_UNI(start); end = ZJ_UNI(end); hBitsL = ZJ_UNI(hBitsL); hBitsS = ZJ_UNI(hBitsS); mls = ZJ_UNI(mls);
+    carry = ZJ_UNI(carry ? 1u : 0u) != 0u;
     u32 const lastLL = m.run(*(ZXLds*)lds, base, frameSize, start, end, hBitsL, hBitsS, mls, hashLong, hashSmall, repIn, repOut, carry);
     o = m.o;
     return lastLL;
