@@ -364,3 +364,22 @@ def test_gpu_wave_matcher(gpu, oracle_ref, monkeypatch, mode):
         for k, (d, z) in enumerate(zip(datas, outs)):
             assert not isinstance(z, Exception), (k, len(d), z)
             assert z == oracle_ref.compress(d, 3, checksum), (k, len(d), checksum)
+
+
+def test_gpu_tables_cleared_ahead_between_calls(gpu, oracle_ref, monkeypatch):
+    """the lane pipeline's level-3 tables are zeroed for the NEXT call as soon as a call's match kernel is done (clear stream, zj_kernels.hip):
+    calls of equal, smaller and larger batches, other levels and a decompress call in between all find what they need — the reference's
+    bytes every time; ZJNI_PRECLEAR is read once per process, so the switch-off is exercised by tools/ab.sh runs, not here"""
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    rnd = random.Random(99)
+    def batch(k, seed):
+        return [gpu.synth_host(rnd.choice([65536, 65536, 40000, 9000, 300]), seed + i, 1) for i in range(k)]
+    want = {}
+    for rep, (k, level) in enumerate([(96, 3), (96, 3), (40, 3), (160, 3), (160, 1), (160, 3), (96, 3), (200, 3), (200, 3)]):
+        datas = batch(k, 1000 * rep)
+        outs = gpu.compress_batch(datas, level)
+        for d, z in zip(datas, outs):
+            assert z == oracle_ref.compress(d, level), (rep, k, level, len(d))
+        if rep % 3 == 1:
+            back = gpu.decompress_batch(outs, [len(d) for d in datas])
+            assert back == datas

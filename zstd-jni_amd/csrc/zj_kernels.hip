@@ -826,6 +826,11 @@ struct DevState {
     bool tevCompress = false, tevDecompress = false;
     hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t waveStream = nullptr; hipEvent_t evJoinWave = nullptr; int waveGrid = 0;   // wave-per-frame matcher beside the lane-per-frame one
+    // Level-3 tables of the lane pipeline (n x 384 KiB: 24 GiB for 65 536 frames) have to be zero when a call's match kernel starts.  Clearing them is
+    // 5-6 ms of pure HBM writes in front of a kernel that waits on latency; so a call clears them for the NEXT one as soon as its own match
+    // kernel is done, on a stream of its own (beside its entropy tail and whatever the host does next), and the next call over the same range
+    // only waits for that.  clearedValid: the range [clearedPtr, + clearedBytes) is zero, or will be when evCleared fires.
+    hipStream_t clearStream = nullptr; hipEvent_t evMatchDone = nullptr, evCleared = nullptr; u8* clearedPtr = nullptr; size_t clearedBytes = 0; bool clearedValid = false;
     // batch calls share the per-device scratch: they are enqueued under `enqueueMu`, and each call's kernels wait (on the
     // GPU) for the previous call's last kernel, whatever streams the callers use — many host threads may call at once
     std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;
@@ -891,6 +896,8 @@ DevState* get_state(int ordinal) {
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipMalloc(&d.counters, 1024) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&d.waveStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d.evJoinWave, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&d.clearStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d.evMatchDone, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&d.evCleared, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipFuncSetAttribute((const void*)zj_enc_match_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZWLds)) != hipSuccess) return nullptr;
         {   int w = 3; if (const char* ov = getenv("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
             d.waveGrid = d.numCU * w; }
@@ -922,6 +929,7 @@ size_t g_scratch_limit = 0;
 #define ZJ_SCRATCH_LIMIT_MIN ((size_t)4 << 30)
 size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap + d->dlitBufCap; }
 void scratch_free_all(DevState* d) {
+    d->clearedValid = false;                                    // (hipFree drains the device, the clear stream included)
     if (d->splitBuf) (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0;
     if (d->wideBuf) (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0;
     if (d->cdBuf) (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; d->cdSliceCap = 0;
@@ -1025,6 +1033,7 @@ void zjni_shutdown(void) {
         if (d.cdList) (void)hipFree(d.cdList);
         for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
         if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
+        if (d.clearStream) { (void)hipStreamDestroy(d.clearStream); (void)hipEventDestroy(d.evMatchDone); (void)hipEventDestroy(d.evCleared); }
         if (d.hostIn) { (void)hipStreamDestroy(d.hostIn); (void)hipStreamDestroy(d.hostK); (void)hipStreamDestroy(d.hostOut); d.hostIn = d.hostK = d.hostOut = nullptr; }
         for (hipEvent_t e : d.pipeEv) if (e) (void)hipEventDestroy(e);
         d.pipeEv.clear();
@@ -1377,6 +1386,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
     hipStream_t st = (hipStream_t)stream;
     d->lastRoute = ZJ_ROUTE_OTHER;
+    bool wasCleared = d->clearedValid; d->clearedValid = false;      // whatever this call does with the scratch, the promise of the previous one ends here
     if (d->encListCap < n) {                      // grows rarely; the only synchronous step of this entry
         if (d->encList) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->encList); d->encList = nullptr; d->encListCap = 0; }
         size_t const cap = n + (n >> 2) + 1024;
@@ -1412,7 +1422,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         size_t const need = tablesBytes + fsBytes + metaBytes + 256;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
-            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
+            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; wasCleared = false; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) return ZJNI_ERR(64);
             d->splitBufCap = need;
         }
@@ -1487,7 +1497,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         size_t need = tablesBytes + fsBytes + metaBytes + 2 * qBytes + n + 256 + needFlagBytes;
         if (d->splitBufCap < need) {
             if (!scratch_make_room(d, d->splitBufCap, need)) return ZJNI_ERR(64);
-            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; }
+            if (d->splitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0; wasCleared = false; }
             if (hipMalloc(&d->splitBuf, need) != hipSuccess) {
                 if (!needGate) return ZJNI_ERR(64);
                 (void)hipGetLastError(); needGate = false; need -= needFlagBytes; needFlagBytes = 0;          // no room for the flags
@@ -1525,7 +1535,19 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             hipLaunchKernelGGL(zj_enc_partition_done_kernel, dim3(1), dim3(1), 0, st, (const u32*)ctr, share, work2);
             listM = listS;
         }
-        if (tablesBytes && hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        static int const preclearEnv = (getenv("ZJNI_PRECLEAR") && atoi(getenv("ZJNI_PRECLEAR")) == 0) ? 0 : 1;
+        if (tablesBytes) {
+            if (wasCleared && d->clearedPtr == tables && d->clearedBytes >= tablesBytes) {          // the previous call left them zero (or is about to)
+                if (hipStreamWaitEvent(st, d->evCleared, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            } else if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        }
+        // after this call's match kernels (recorded below, at tev[1]): the same range zeroed again for the next call
+        auto preclear = [&]() {
+            if (!preclearEnv || !tablesBytes || g_scratch_limit) return;
+            if (hipEventRecord(d->evMatchDone, st) != hipSuccess || hipStreamWaitEvent(d->clearStream, d->evMatchDone, 0) != hipSuccess) return;
+            if (hipMemsetAsync(tables, 0, tablesBytes, d->clearStream) != hipSuccess || hipEventRecord(d->evCleared, d->clearStream) != hipSuccess) { (void)hipStreamSynchronize(d->clearStream); return; }
+            d->clearedPtr = tables; d->clearedBytes = tablesBytes; d->clearedValid = true;
+        };
         if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
         u32 gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
@@ -1591,6 +1613,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             zj_dbg_sync("match kernel");
             if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
+            preclear();
             // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
             // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
             if (needGate && !getenv("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
@@ -1611,6 +1634,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                (const u32*)listA, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr, 0u, 0xFFFFFFFFu, (unsigned long long*)nullptr);
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
+            preclear();
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listA, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
