@@ -654,7 +654,14 @@ __global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(con
                                                               u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                               u8* scratch, u32* tables, u32 flags, u32 ldsBytes) {
     __shared__ ZEncShared sh;
+#ifdef ZX_PROFILE          /* analysis build: the entropy stage's phase marks of workgroup 0, printed when it is done (tools/ab_call*.sh) */
+    __shared__ unsigned long long zxPhase[16];
+    if (threadIdx.x < 16) zxPhase[threadIdx.x] = 0;
+    __syncthreads();
+    ZjProf pf; pf.start(blockIdx.x == 0 ? zxPhase : nullptr);
+#else
     ZjProf pf; pf.start(nullptr);
+#endif
     Grp<64> g;
     if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
     __syncthreads();
@@ -674,6 +681,11 @@ __global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(con
         if (threadIdx.x == 0) result[i] = r;
         __syncthreads();
     }
+#ifdef ZX_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("zx phases wg 0 (kcycles): zero+params %llu  match %llu  literals gather+codes %llu  hist+huffman table %llu  huffman encode %llu  sequence tables %llu  sequence encode %llu  block place %llu\n",
+               zxPhase[0] / 1000ull, zxPhase[1] / 1000ull, zxPhase[2] / 1000ull, zxPhase[3] / 1000ull, zxPhase[4] / 1000ull, zxPhase[5] / 1000ull, zxPhase[6] / 1000ull, zxPhase[7] / 1000ull);
+#endif
 }
 
 // ZSTD_createCDict on the device: one workgroup digests the dictionary held in `out` (header, zeroed tables, raw bytes)

@@ -286,9 +286,10 @@ struct ZWaveX {
             if (carryOn) {
                 // ---- the window's winner, presumed: a lower lane of the window as entry is compared exactly (its word is in a register), a
                 //      table entry by its tag; the repcode test is exact.  No presumed hit below lane K = no hit below lane K.
-                ZWV<u32> wlo, whi, pwlo, pwhi, pslo;
-                ZW_LANES(l) { wlo[l] = (u32)w[l]; whi[l] = (u32)(w[l] >> 32); }
-                {   ZWV<u32> iL, iS;
+                ZWV<u32> wlo, whi, pwlo, pwhi, pslo; ZWV<bool> anyPred;
+                ZW_LANES(l) { wlo[l] = (u32)w[l]; whi[l] = (u32)(w[l] >> 32); pwlo[l] = pwhi[l] = pslo[l] = 0; anyPred[l] = predL[l] < 64u || predS[l] < 64u; }
+                if (zw_ballot(anyPred)) {                                // (most windows have no two lanes with one hash: no words to fetch from other lanes)
+                    ZWV<u32> iL, iS;
                     ZW_LANES(l) { iL[l] = predL[l] < 64u ? predL[l] : l; iS[l] = predS[l] < 64u ? predS[l] : l; }
                     zw_shfl(pwlo, wlo, iL); zw_shfl(pwhi, whi, iL); zw_shfl(pslo, wlo, iS); }
                 ZW_LANES(l) {
@@ -450,7 +451,7 @@ struct ZWaveX {
                         cov = 8u * nv;
                         ZW_LANES(l) {
                             bool const in = l < nv;
-                            u32 const at = in ? e + 8u * l : 0u, q = l == 0 ? 2u : (l == 1 ? e - 2u : (l == 2 ? e - 1u : 0u));
+                            u32 const at = in ? e + 8u * l : 0u, q = l == 1 ? e - 2u : (l == 3 ? e - 1u : 2u);
                             u64 const ra = ld64(lds.stA + at), rbb = ld64(xs + at), rq = ld64(lds.stA + q);
                             ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
                             wi[l] = ra; d[l] = in ? ra ^ rbb : 0ull; ne[l] = d[l] != 0; wq[l] = rq;
@@ -458,7 +459,7 @@ struct ZWaveX {
                     } else {
                         cov = 512u;
                         ZW_LANES(l) {
-                            u32 const q = l == 0 ? curr + 2u : (l == 1 ? ip - 2u : ip - 1u);
+                            u32 const q = l == 1 ? ip - 2u : (l == 3 ? ip - 1u : curr + 2u);
                             u32 const p0 = ip + 8u * l, p1 = ip - off2 + 8u * l, q0_ = at(p0), q1_ = at(p1), q2_ = at(q);
                             u64 const r0_ = ld64(base + q0_), r1_ = ld64(base + q1_), r2_ = ld64(base + q2_);
                             ZW_FENCE2(r0_, r1_); ZW_FENCE2(r2_, r2_);
@@ -468,10 +469,22 @@ struct ZWaveX {
                         ZX_STAT(stTrips++);
                     }
                     if (first) {
-                        u64 const q0 = zw_get64(wq, 0), q1 = zw_get64(wq, 1), q2 = zw_get64(wq, 2);
-                        ZW_LANES(l) { if (l == 0) {
-                            u32 b0_, b1_, b2_, b3_; u32 const e0_ = entL_of(q0, curr + 3u, b0_), e1_ = entL_of(q1, ip - 1u, b1_), e2_ = entS_of(q0, curr + 3u, b2_), e3_ = entS_of(q2, ip, b3_);
-                            HL[b0_] = e0_; HL[b1_] = e1_; HS[b2_] = e2_; HS[b3_] = e3_; } }
+                        // lanes 0 / 1: long entries of curr + 2 and ip - 2; lanes 2 / 3: short entries of curr + 2 and ip - 1 — hashed side by side.
+                        // Within a table the later insert wins a shared bucket: the earlier lane then does not store.
+                        ZWV<u32> bk, en;
+                        ZW_LANES(l) {
+                            u64 const x = wq[l];                                                 // (lanes 0 / 2: curr + 2's word, lane 1: ip - 2's, lane 3: ip - 1's — see the loads)
+                            u32 const p1 = l == 0 || l == 2 ? curr + 3u : (l == 1 ? ip - 1u : ip);
+                            u32 bL, bS; u32 const eL_ = entL_of(x, p1, bL), eS_ = entS_of(x, p1, bS);
+                            bk[l] = l < 2u ? bL : bS; en[l] = l < 2u ? eL_ : eS_;
+                        }
+                        bool const sameL = zw_get(bk, 0) == zw_get(bk, 1), sameS = zw_get(bk, 2) == zw_get(bk, 3);
+                        ZW_LANES(l) {
+                            if (l == 0 && !sameL) HL[bk[l]] = en[l];
+                            if (l == 1) HL[bk[l]] = en[l];
+                            if (l == 2 && !sameS) HS[bk[l]] = en[l];
+                            if (l == 3) HS[bk[l]] = en[l];
+                        }
                     }
                     if (off2 == 0u || (u32)zw_get64(d, 0) != 0u) break;
                     u64 const m = zw_ballot(ne);
