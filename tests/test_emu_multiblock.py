@@ -130,8 +130,10 @@ def test_multiblock_wave_matcher_orders_and_switches(emu, oracle_ref, zj):
              b"".join(zj.synth_host(65536, 2 + 4 * i, 1) for i in range(5)),      # low-entropy class: dense short matches, repcodes
              noise[:5000] + noise[4000:4990] + b"#" + noise[4000:5000] + xml[:200000] + noise[100:400] + b"!" + noise[99:5000]]
     for k, d in enumerate(cases):
-        want = oracle_ref.compress(d, 3)
-        for lib, name in ((emu, "ascending"), (rev, "descending")):
-            for serial in (False, 2, True):
-                if lib is rev and serial is True: continue
-                assert emu_compress_multi(lib, d, 3, serial=serial) == want, (k, name, serial)
+        for level in (3, 1, 2):                      # level 3: double-fast (ZWaveX); levels 1-2: fast (ZWaveF; level 2 is double-fast up to 256 KiB)
+            if len(d) > WINDOW[level]: continue
+            want = oracle_ref.compress(d, level)
+            for lib, name in ((emu, "ascending"), (rev, "descending")):
+                for serial in (False, 2, True, 4):
+                    if lib is rev and serial in (True, 4): continue
+                    assert emu_compress_multi(lib, d, level, serial=serial) == want, (k, level, name, serial)

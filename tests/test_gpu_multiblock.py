@@ -59,13 +59,16 @@ def test_gpu_multiblock_frames_are_the_references(gpu, oracle_ref, level):
             assert b == d
 
 
-def test_gpu_multiblock_level3_one_lane_parse_switch(gpu, oracle_ref, monkeypatch):
-    """level-3 blocks run the wave matcher (zj_match_wavex.h) by default; ZJNI_MULTI_WAVE=0 selects the one-lane parse of rounds 1-3 for
-    A/B runs — the same frames either way"""
-    monkeypatch.setenv("ZJNI_MULTI_WAVE", "0")
-    datas = [d for d in inputs(gpu, oracle_ref, 103, 24) if len(d) <= WINDOW[3]]
-    for d, z in zip(datas, gpu.compress_batch(datas, 3)):
-        assert z == oracle_ref.compress(d, 3), len(d)
+@pytest.mark.parametrize("switch", [("ZJNI_MULTI_WAVE", "0"), ("ZJNI_MULTI_WAVE", "2"), ("ZJNI_MULTI_WAVE_FAST", "0")])
+def test_gpu_multiblock_parse_switches(gpu, oracle_ref, monkeypatch, switch):
+    """blocks of multi-block frames run the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2) by default;
+    ZJNI_MULTI_WAVE=0 selects the one-lane parses of rounds 1-3, =2 the wave matchers without staged spans, ZJNI_MULTI_WAVE_FAST=0 the
+    one-lane parse for levels 1-2 only — the same frames either way"""
+    monkeypatch.setenv(*switch)
+    for level in (3, 1, 2):
+        datas = [d for d in inputs(gpu, oracle_ref, 100 + level, 24) if len(d) <= WINDOW[level]]
+        for d, z in zip(datas, gpu.compress_batch(datas, level)):
+            assert z == oracle_ref.compress(d, level), (level, len(d))
 
 
 def test_gpu_one_mebibyte_buffer_like_baseline_config_1(gpu, oracle_ref):

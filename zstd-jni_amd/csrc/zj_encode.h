@@ -85,7 +85,7 @@ struct ZEncShared {                // uniforms, outside the overlay
     u32 blkRep[2], blkNextRep[2];  // multi-block frames: repcodes confirmed by the last compressed block / left by the block being encoded
 };
 // one block of a multi-block frame (ze_compress_multi): block = frameBase[start, start + srcSize) of ze_compress_t
-struct ZEBlockArgs { const u8* frameBase; u32 frameSize, start, isFirst, lastBlock; u32* tables; u32 serialParse; };   // serialParse (level-3 blocks): 0 the wave matcher, 1 the one-lane parse (ZE_FLAG_MULTI_SERIAL), 2 the wave matcher without staged spans (ZE_FLAG_MULTI_NOCARRY)
+struct ZEBlockArgs { const u8* frameBase; u32 frameSize, start, isFirst, lastBlock; u32* tables; u32 serialParse; };   // serialParse: low bits 0 the wave matchers, 1 the one-lane parses (ZE_FLAG_MULTI_SERIAL), 2 the wave matchers without staged spans (ZE_FLAG_MULTI_NOCARRY); bit 2: levels 1-2 on the one-lane parse (ZE_FLAG_MULTI_FAST_SERIAL)
 #define ZE_SMALL_MAX 4096u         /* frames up to this size are staged, gathered and assembled in LDS when the launch provides it */
 #define ZE_ALIGN16(x) (((x) + 15u) & ~15u)
 #define ZE_ENTROPY_LDS ZE_ALIGN16((u32)sizeof(ZEEntropy))
@@ -1387,6 +1387,7 @@ template <> struct ZEEntOf<u32> { typedef ZEEnt32 E; };
 #define ZE_FLAG_NO_DICTID 4u     /* ZSTD_c_dictIDFlag = 0 (ZstdCompressCtx.setDictID(false)): the dictionary's ID stays out of the header */
 #define ZE_FLAG_MASK 7u
 #define ZE_FLAG_MULTI_NOCARRY 16u /* library switch (ZJNI_MULTI_WAVE=2): the wave matcher without the staged spans behind a match — A/B runs */
+#define ZE_FLAG_MULTI_FAST_SERIAL 32u /* library switch (ZJNI_MULTI_WAVE_FAST=0): levels 1-2 blocks of multi-block frames on the one-lane parse, level 3 as the other switches say */
 #define ZE_FLAG_MULTI_SERIAL 8u /* library switch, not a frame parameter (ZJNI_MULTI_WAVE=0): level-3 blocks of multi-block frames on the one-lane parse instead of zj_match_wavex.h */
 // Sequences found ahead of time by the lane-per-frame match-finder kernel (zj_enc_match_kernel)
 struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; u32 copyMode = 0; };   // meta = {nbSeq, litSize, lastLL}; copyMode: the records come from the dictionary copy-mode search (zj_cdict.h)
@@ -1394,6 +1395,8 @@ struct ZEPre { ZESeq* seqs; const u32* litOff; const u32* meta; u32 copyMode = 0
 // zj_match_wavex.h (included at the end of this file): the wave-per-frame parse of one level-3 block of a multi-block frame
 ZJ_DEV u32 zx_block_dfast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls,
                                u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry);
+ZJ_DEV u32 zx_block_fast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBits, u32 mls,
+                              u32* table, const u32* repIn, u32* repOut, bool carry);
 // `ba` != nullptr: src0[0, srcSize) is ONE BLOCK of a multi-block frame (ze_compress_multi): no frame header or checksum here, the
 // match finder runs over the frame's tables and repcodes, the previous compressed block's Huffman table may be repeated, and the
 // return value is the size of the block with its 3-byte header.
@@ -1481,9 +1484,14 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
         u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
         if (!pre && ba) {                                  // one block of a frame: its tables (HBM, cleared by the caller before block 0) and repcodes carry on
-            if (strategy == 2 && ba->serialParse != 1u) {           // level 3: the whole wave (zj_match_wavex.h); the dynamic LDS is free until the entropy stage
+            if (strategy == 1 && ba->serialParse != 1u && !(ba->serialParse & 4u)) {     // levels 1-2: the fast strategy on the whole wave (zj_match_wavex.h, ZWaveF)
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
-                u32 const lastLL = zx_block_dfast_wave(lds, o, ba->frameBase, ba->frameSize, ba->start, ba->start + srcSize, hlog, clog, mls, ba->tables, ba->tables + (1u << hlog), sh.blkRep, sh.blkNextRep, ba->serialParse == 0u);
+                u32 const lastLL = zx_block_fast_wave(lds, o, ba->frameBase, ba->frameSize, ba->start, ba->start + srcSize, hlog, mls, ba->tables, sh.blkRep, sh.blkNextRep, (ba->serialParse & 3u) == 0u);
+                GRP_SERIAL(g) { sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL; }
+            } else
+            if (strategy == 2 && (ba->serialParse & 3u) != 1u) {           // level 3: the whole wave (zj_match_wavex.h); the dynamic LDS is free until the entropy stage
+                ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+                u32 const lastLL = zx_block_dfast_wave(lds, o, ba->frameBase, ba->frameSize, ba->start, ba->start + srcSize, hlog, clog, mls, ba->tables, ba->tables + (1u << hlog), sh.blkRep, sh.blkNextRep, (ba->serialParse & 3u) == 0u);
                 GRP_SERIAL(g) { sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL; }
             } else
             GRP_SERIAL(g) {
@@ -2098,7 +2106,7 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
         ZX_FRAME_MARK(zxSplit);
         u32 const blockSize = ZJ_UNI(sh.tmp[0]);
         g.sync();
-        ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables; ba.serialParse = (flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u);
+        ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables; ba.serialParse = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
         u64 const r = ze_compress_t<G, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, ldsBytes, &ba);
         if (r > ZJ_ERR64(256)) return r;
         savings += (i64)blockSize - (i64)r;

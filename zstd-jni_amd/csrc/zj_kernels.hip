@@ -1422,8 +1422,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     {   // list C: multi-block frames (levels 1-3) and the single-block frames of levels 4-8 above 16 KiB.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 1 MiB per resident workgroup.
         if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
-        // level-3 blocks of multi-block frames: the wave matcher (zj_match_wavex.h); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
+        // blocks of multi-block frames: the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
         u32 multiSerial = 0; if (const char* ov = getenv("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
+        if (const char* ov = getenv("ZJNI_MULTI_WAVE_FAST")) { if (atoi(ov) == 0) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }     // levels 1-2 (fast strategy) on the one-lane parse
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
     }

@@ -516,6 +516,270 @@ struct ZWaveX {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The same for the fast strategy (levels 1-2): ZSTD_compressBlock_fast_noDict_generic (N/compress/zstd_fast.c:192-423), one table.
+// The reference's loop takes two positions per iteration — ip0 = B and ip1 = B + 1 — inserts both, and BEFORE it tests their table
+// candidates it tests the repcode at the next iteration's first position ip2 = B + gap (gap = the step when that position was set: 2,
+// growing by one every 128 bytes without a match).  Order of the tests of iteration k: repcode at B(k+1), candidate of B(k), candidate
+// of B(k) + 1; the first test that passes, iterations ascending, ends the loop.  A window holds K iterations: lane 2k = B(k), lane
+// 2k + 1 = B(k) + 1, lane 2K = B(K) for the last repcode test.  The entry the reference finds at a position is the table's, or the
+// position of the latest lower lane with its hash (every earlier position of the window is inserted before the position's lookup) —
+// the scoreboard of the double-fast matcher; tags, presumed winner, staged spans and the order of the table writes as there.
+struct ZWaveF : ZWaveX {
+    ZJ_DEV_MEMBER u32 entF_of(u64 w, u32 pos1, u32& bucket) const { bucket = zl_hash(hL, w); return ZX_ENT(pos1, tagS_of(w)); }
+    ZJ_DEV_MEMBER u32 run_fast(ZXLds& lds, const u8* frame, u32 frameSize, u32 blkStart, u32 blkEnd, u32 hBits, u32 mls,
+                               u32* table, const u32* repIn, u32* repOut, bool carry) {
+        carryOn = carry; cvalid = false; cbase = coffB = coffC = 0;
+        L = &lds; base = frame; nf = frameSize; start = blkStart; n = blkEnd; ilimit = blkEnd - 8u; HL = table; HS = table;
+        hL = zl_hash_of(mls, hBits); hS = hL;
+        o.n = 0; o.lit = 0;
+#ifdef ZX_STATS
+        stPasses = stHitPasses = stTrips = stLanes = stSlow = 0;
+#endif
+        ZW_LANES(l) { for (u32 i = l; i < ZX_SB_SLOTS; i += 64u) lds.SL[i] = 0; }
+        ZW_SYNC();
+        u32 ip = blkStart + (blkStart == 0u ? 1u : 0u), anchor = blkStart;
+        u32 rep1 = ZJ_UNI(repIn[0]), rep2 = ZJ_UNI(repIn[1]), saved1 = 0, saved2 = 0;
+        {   u32 const maxRep = ip;                                          // zstd_fast.c:244-250
+            if (rep2 > maxRep) { saved2 = rep2; rep2 = 0; }
+            if (rep1 > maxRep) { saved1 = rep1; rep1 = 0; } }
+        u32 step = 2, gap = 2, nextStep = ip + 128u, cap = ZX_CAP_MIN;    // cap: iterations per window
+        if (blkEnd >= 12u) for (;;) {
+            ip = ZJ_UNI(ip); anchor = ZJ_UNI(anchor); rep1 = ZJ_UNI(rep1); rep2 = ZJ_UNI(rep2); step = ZJ_UNI(step); gap = ZJ_UNI(gap); nextStep = ZJ_UNI(nextStep); cap = ZJ_UNI(cap);
+            o.n = ZJ_UNI(o.n); o.lit = ZJ_UNI(o.lit);
+            if (ip + gap + 1u >= ilimit) break;                           // ip3 >= ilimit: the iteration at ip does not run (loop header and do-while alike)
+            // ---- window: K iterations with bases ip, ip + gap, ip + gap + step, ...; a pending step change (gap != step) runs alone
+            u32 K = 1;
+            if (gap == step) {
+                u32 const q = nextStep > ip ? (nextStep - ip + step - 1u) / step : 0u;        // no step change inside: B(K) < nextStep for the checks of iterations 0 .. K - 2
+                u32 const kStep = q > 2u ? q - 1u : 1u;
+                u32 const kRoom = (ilimit - 2u - ip) / step;                                     // every iteration's ip3 = B + step + 1 < ilimit
+                K = kStep < cap ? kStep : cap; if (kRoom < K) K = kRoom; if (K < 1u) K = 1u; if (K > 31u) K = 31u;
+            }
+            u32 const nS = 2u * K;                                        // search lanes; lane nS looks ahead (repcode test only)
+            ZX_STAT(stPasses++); ZX_STAT(stLanes += nS);
+            ZWV<u32> pos, hl, tg, eT, rb, pred; ZWV<u64> w, mM; ZWV<u32> cP; ZWV<bool> hitM, hitR;
+            cvalid = ZJ_UNI(cvalid ? 1u : 0u) != 0u; cbase = ZJ_UNI(cbase); coffB = ZJ_UNI(coffB); coffC = ZJ_UNI(coffC);
+            bool const consecutive = gap == 2u && step == 2u;            // lane l = position ip + l
+            if (cvalid && consecutive && ip >= cbase && (ip - cbase) + nS + 8u <= ZX_CARRY && (rep1 == coffB || rep1 == coffC || rep1 == 0u)) {
+                const u8* const rs = (rep1 == coffB) ? lds.stB : lds.stC;
+                ZW_LANES(l) {
+                    bool const act = l <= nS;
+                    u32 const pp = act ? ip + l : ip; pos[l] = pp;
+                    u64 const ww = ld64(lds.stA + (pp - cbase)); u32 const rr = ld32(rs + (pp - cbase));
+                    ZW_FENCE2(ww, rr);
+                    w[l] = ww; rb[l] = rr;
+                    hl[l] = zl_hash(hL, ww); tg[l] = tagS_of(ww); pred[l] = 64u;
+                }
+            } else {
+                ZW_LANES(l) {
+                    bool const act = l <= nS; u32 const k = l >> 1;
+                    u32 const b = k == 0u ? ip : ip + gap + (k - 1u) * step;
+                    u32 const pp = act ? b + (l & 1u) : ip; pos[l] = pp;
+                    ZX_LOAD2(ww, pp, rw, pp - rep1);
+                    w[l] = ww; rb[l] = (u32)rw;
+                    hl[l] = zl_hash(hL, ww); tg[l] = tagS_of(ww); pred[l] = 64u;
+                }
+                ZX_STAT(stTrips++);
+            }
+            // ---- the table as the previous windows left it, and who in this window comes before whom
+            ZX_STORES_DONE();
+            ZW_LANES(l) {
+                bool const srch = l < nS;
+                u32 const x = srch ? ZX_TLOAD(&HL[hl[l]]) : 0u;
+                if (srch) zw_or64(&lds.SL[hl[l] & (ZX_SB_SLOTS - 1u)], 1ull << l);
+                ZW_FENCE2(x, x);
+                eT[l] = x;
+            }
+            ZX_STAT(stTrips++);
+            ZW_SYNC();
+            ZW_LANES(l) { mM[l] = (l < nS) ? (lds.SL[hl[l] & (ZX_SB_SLOTS - 1u)] & ((1ull << l) - 1ull)) : 0ull; }
+            ZW_SYNC();
+            ZW_LANES(l) { if (l < nS) lds.SL[hl[l] & (ZX_SB_SLOTS - 1u)] = 0; }
+            ZW_SYNC();
+            for (;;) {
+                ZWV<u32> jM, gM; ZWV<bool> pend;
+                ZW_LANES(l) { jM[l] = mM[l] ? 63u - (u32)__builtin_clzll(mM[l]) : l; pend[l] = mM[l] != 0; }
+                if (!zw_ballot(pend)) break;
+                zw_shfl(gM, hl, jM);
+                ZW_LANES(l) { if (mM[l]) { if (gM[l] == hl[l]) { pred[l] = jM[l]; mM[l] = 0; } else mM[l] &= ~(1ull << jM[l]); } }
+            }
+            // ---- tests: the repcode ones are exact (even lanes from 2 on), the candidates' presumed from tags (a lower lane as entry: exact)
+            u32 const tagsOn = (ZX_TAGS && carryOn) ? 1u : 0u;
+            {   ZWV<u32> wlo, pwlo, iP; ZWV<bool> anyPred;
+                ZW_LANES(l) { wlo[l] = (u32)w[l]; pwlo[l] = 0; iP[l] = pred[l] < 64u ? pred[l] : l; anyPred[l] = pred[l] < 64u; }
+                if (zw_ballot(anyPred)) zw_shfl(pwlo, wlo, iP);
+                ZW_LANES(l) {
+                    bool const srch = l < nS; bool pM; u32 a;
+                    if (pred[l] < 64u) { pM = pwlo[l] == wlo[l]; u32 const k = pred[l] >> 1; a = (k == 0u ? ip : ip + gap + (k - 1u) * step) + (pred[l] & 1u); }
+                    else { u32 const e = eT[l]; a = ZX_POS(e) - 1u; pM = ZX_POS(e) > 1u && (!tagsOn || (e >> 21) == tg[l]); }
+                    cP[l] = a; hitM[l] = srch && pM;
+                    hitR[l] = l >= 2u && l <= nS && !(l & 1u) && rep1 > 0u && rb[l] == wlo[l];
+                }
+            }
+            u64 hm = 0; u32 evK = 0, evT = 0;                              // winner: iteration, type (0 repcode at B(k + 1), 1 candidate of B(k), 2 candidate of B(k) + 1)
+            bool staged = false, decided = false;
+            for (u32 round = 0; !decided; round++) {
+                // round 0: presumed (tags); round 1 (a presumption failed, or no tags): every candidate's bytes fetched and compared
+                if (round == 1u || !tagsOn) {
+                    ZW_LANES(l) {
+                        bool const srch = l < nS;
+                        u32 const a = cP[l]; bool const v = srch && (pred[l] < 64u || ZX_POS(eT[l]) > 1u);
+                        u64 const c = fb(v ? a : 0u);
+                        ZW_FENCE2(c, c);
+                        hitM[l] = v && (u32)c == (u32)w[l];
+                    }
+                    ZX_STAT(stTrips++);
+                }
+                u64 const rM = zw_ballot(hitR), mAll = zw_ballot(hitM);
+                u64 const m0 = mAll & 0x5555555555555555ull, m1 = mAll & 0xAAAAAAAAAAAAAAAAull;
+                u32 eR = 0xFFFFFFFFu, e0 = 0xFFFFFFFFu, e1 = 0xFFFFFFFFu;
+                if (rM) eR = 3u * (((u32)__builtin_ctzll(rM) >> 1) - 1u);
+                if (m0) e0 = 3u * ((u32)__builtin_ctzll(m0) >> 1) + 1u;
+                if (m1) e1 = 3u * ((u32)__builtin_ctzll(m1) >> 1) + 2u;
+                u32 const ev = zj_min(eR, zj_min(e0, e1));
+                if (ev == 0xFFFFFFFFu) { hm = 0; decided = true; break; }
+                evK = ev / 3u; evT = ev % 3u; hm = 1;
+                if (round == 1u || !tagsOn || evT == 0u) { decided = true; break; }
+                // a presumed candidate hit: stage the match's spans and check the four bytes there
+                {   u32 const lane = 2u * evK + (evT == 2u ? 1u : 0u), hp = zw_get(pos, lane), mp = zw_get(cP, lane);
+                    cvalid = false;
+                    stage(lds, hp, mp, rep1);
+                    if (ZJ_UNI((u32)(ld32(lds.stA) == ld32(lds.stB))) != 0u) { staged = true; decided = true; }
+                }
+            }
+            u32 const cnt = hm ? 2u * (evK + 1u) : nS;                     // lanes whose inserts happen: both positions of every iteration up to the winner's
+            // ---- commit
+            {   ZWV<bool> hasPred;
+                ZW_LANES(l) { hasPred[l] = l < cnt && pred[l] < 64u; }
+                if (zw_ballot(hasPred)) {
+                    ZW_LANES(l) { lds.shadowL[l] = 0; }
+                    ZW_SYNC();
+                    ZW_LANES(l) { if (l < cnt && pred[l] < 64u) lds.shadowL[pred[l]] = 1; }
+                    ZW_SYNC();
+                    ZW_LANES(l) { if (l < cnt && !lds.shadowL[l]) HL[hl[l]] = ZX_ENT(pos[l] + 1u, tg[l]); }
+                    ZW_SYNC();
+                } else {
+                    ZW_LANES(l) { if (l < cnt) HL[hl[l]] = ZX_ENT(pos[l] + 1u, tg[l]); }
+                }
+            }
+            if (!hm) {                                                       // no test passed: the end of the last iteration, as the reference's loop does it
+                u32 const bK = K == 0u ? ip : ip + gap + (K - 1u) * step;
+                ip = bK; gap = step;
+                if (ip + step >= nextStep) { step++; nextStep += 128u; }
+                cap = cap * 2u < 31u ? cap * 2u : 31u;
+                continue;
+            }
+            ZX_STAT(stHitPasses++);
+            {   u32 const c2 = 2u * (evK + 1u); cap = c2 < ZX_CAP_MIN ? ZX_CAP_MIN : (c2 < 31u ? c2 : 31u); }
+            // ---- the match, as the reference handles it
+            u32 const bk = evK == 0u ? ip : ip + gap + (evK - 1u) * step;   // B(k)
+            u32 const gk = evK == 0u ? gap : step;                          // B(k + 1) - B(k)
+            u32 const cur0 = evT == 2u ? bk + 1u : bk;
+            u32 const hlane = evT == 0u ? 2u * evK + 2u : 2u * evK + (evT == 2u ? 1u : 0u);
+            u32 const hp = evT == 0u ? bk + gk : cur0;                      // where the match starts before it is extended backwards
+            u32 const mpos = evT == 0u ? hp - rep1 : zw_get(cP, hlane);
+            u32 const offC = evT == 0u ? rep2 : rep1;                       // the offset the repcode loop behind the match will test
+            u32 f0, k0;
+            if (carryOn) {
+                if (!staged) stage(lds, hp, mpos, offC);
+                ZWV<u64> d2; ZWV<bool> ne2;
+                ZW_LANES(l) {
+                    u64 x = 0;
+                    if (l < 15u) x = ld64(lds.stA + 4u + 8u * l) ^ ld64(lds.stB + 4u + 8u * l);
+                    else if (l >= 16u && l < 24u) x = ld64(lds.stKA + 56u - 8u * (l - 16u)) ^ ld64(lds.stKB + 56u - 8u * (l - 16u));
+                    d2[l] = x; ne2[l] = x != 0;
+                }
+                ZW_SYNC();
+                u64 const m2 = zw_ballot(ne2);
+                u32 const a0 = hp + 4u, fl = n - a0, offN = hp - mpos;
+                {   u32 const mm = (u32)m2 & 0x7FFFu;
+                    if (mm) { u32 const j = (u32)__builtin_ctz(mm); f0 = 8u * j + ((u32)__builtin_ctzll(zw_get64(d2, j)) >> 3); if (f0 > fl) f0 = fl; }
+                    else f0 = fl <= 120u ? fl : 120u + count_fwd(a0 + 120u, a0 - offN + 120u); }
+                u32 const lim0 = evT == 0u ? 1u : zj_min(hp - anchor, mpos), mb = (u32)(m2 >> 16) & 0xFFu;
+                if (mb) { u32 const j = (u32)__builtin_ctz(mb); k0 = 8u * j + ((u32)__builtin_clzll(zw_get64(d2, 16u + j)) >> 3); if (k0 > lim0) k0 = lim0; }
+                else k0 = lim0 <= 64u ? lim0 : 64u + count_back(hp - 64u, mpos - 64u, lim0 - 64u);
+                cvalid = true; cbase = hp; coffB = offN; coffC = offC;
+            } else {
+                u32 f1, k1;
+                extend(hp + 4u, mpos + 4u, hp, mpos, evT == 0u ? 1u : zj_min(hp - anchor, mpos), false, 0, 0, 8u, 8u, 0, f0, k0, f1, k1);
+                cvalid = false;
+            }
+            f0 = ZJ_UNI(f0); k0 = ZJ_UNI(k0);
+            u32 const mip = hp - k0, mLength = 4u + f0 + k0;
+            if (evT == 0u) store(anchor, mip - anchor, 1u, mLength);         // (the repcode's one byte backwards is unconditional in the reference: ip2 - 1 >= ip1 > anchor)
+            else {
+                u32 const offset = hp - mpos;
+                rep2 = rep1; rep1 = offset;
+                if (evT == 2u && step <= 4u) { u32 const h1 = zw_get(hl, 2u * evK + 2u), t1 = zw_get(tg, 2u * evK + 2u), p1 = bk + gk; ZW_LANES(l) { if (l == 0) HL[h1] = ZX_ENT(p1 + 1u, t1); } }
+                store(anchor, mip - anchor, offset + 3u, mLength);
+            }
+            ip = ZJ_UNI(mip + mLength); anchor = ip; rep1 = ZJ_UNI(rep1); rep2 = ZJ_UNI(rep2);
+            if (ip <= ilimit) {
+                // complementary insertion (cur0 + 2, then ip - 2) and the immediate-repcode loop; lane 0 writes, in the reference's order
+                for (bool first = true;; first = false) {
+                    ip = ZJ_UNI(ip); rep1 = ZJ_UNI(rep1); rep2 = ZJ_UNI(rep2); o.n = ZJ_UNI(o.n); o.lit = ZJ_UNI(o.lit);
+                    ZWV<u64> d, wi, wq; ZWV<bool> ne; u32 cov;
+                    u32 const e = ip - cbase;
+                    if (cvalid && e + 8u <= ZX_CARRY && cur0 + 2u >= cbase && (rep2 == coffB || rep2 == coffC || rep2 == 0u)) {
+                        const u8* const xs = (rep2 == coffB) ? lds.stB : lds.stC;
+                        u32 const nv = (ZX_CARRY - e) / 8u;
+                        cov = 8u * nv;
+                        ZW_LANES(l) {
+                            bool const in = l < nv;
+                            u32 const at = in ? e + 8u * l : 0u, q = l == 1 ? e - 2u : cur0 + 2u - cbase;
+                            u64 const ra = ld64(lds.stA + at), rbb = ld64(xs + at), rq = ld64(lds.stA + q);
+                            ZW_FENCE2(ra, rbb); ZW_FENCE2(rq, rq);
+                            wi[l] = ra; d[l] = in ? ra ^ rbb : 0ull; ne[l] = d[l] != 0; wq[l] = rq;
+                        }
+                    } else {
+                        cov = 512u;
+                        ZW_LANES(l) {
+                            u32 const q = l == 1 ? ip - 2u : cur0 + 2u;
+                            u32 const p0 = ip + 8u * l, p1 = ip - rep2 + 8u * l, q0_ = at(p0), q1_ = at(p1), q2_ = at(q);
+                            u64 const r0_ = ld64(base + q0_), r1_ = ld64(base + q1_), r2_ = ld64(base + q2_);
+                            ZW_FENCE2(r0_, r1_); ZW_FENCE2(r2_, r2_);
+                            u64 const ra = fix(r0_, p0, q0_), rbb = fix(r1_, p1, q1_), rq = fix(r2_, q, q2_);
+                            wi[l] = ra; d[l] = ra ^ rbb; ne[l] = d[l] != 0; wq[l] = rq;
+                        }
+                        ZX_STAT(stTrips++);
+                    }
+                    if (first) {
+                        u64 const q0 = zw_get64(wq, 0), q1 = zw_get64(wq, 1);
+                        ZW_LANES(l) { if (l == 0) { u32 b0_, b1_; u32 const e0_ = entF_of(q0, cur0 + 3u, b0_), e1_ = entF_of(q1, ip - 1u, b1_); HL[b0_] = e0_; HL[b1_] = e1_; } }
+                    }
+                    if (rep2 == 0u || (u32)zw_get64(d, 0) != 0u) break;
+                    u64 const m = zw_ballot(ne);
+                    u32 const lim = n - ip; u32 rLength;
+                    if (m) { u32 const j = (u32)__builtin_ctzll(m); rLength = 8u * j + ((u32)__builtin_ctzll(zw_get64(d, j)) >> 3); if (rLength > lim) rLength = lim; }
+                    else rLength = lim <= cov ? lim : cov + count_fwd(ip + cov, ip - rep2 + cov);
+                    rLength = ZJ_UNI(rLength);
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    {   u64 const wi0 = zw_get64(wi, 0);
+                        ZW_LANES(l) { if (l == 0) { u32 b_; u32 const e_ = entF_of(wi0, ip + 1u, b_); HL[b_] = e_; } } }
+                    store(anchor, 0u, 1u, rLength);
+                    ip += rLength; anchor = ip;
+                    if (ip > ilimit) break;
+                }
+            }
+            step = 2u; gap = 2u; nextStep = ip + 128u;
+        }
+        saved2 = (saved1 != 0u && rep1 != 0u) ? saved1 : saved2;         // zstd_fast.c:352-372
+        ZW_LANES(l) { if (l == 0) { repOut[0] = rep1 ? rep1 : saved1; repOut[1] = rep2 ? rep2 : saved2; } }
+        ZX_STORES_DONE();
+        return n - anchor;
+    }
+};
+ZJ_DEV u32 zx_block_fast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBits, u32 mls,
+                              u32* table, const u32* repIn, u32* repOut, bool carry) {
+    ZWaveF m; m.o = o;
+    frameSize = ZJ_UNI(frameSize); start = ZJ_UNI(start); end = ZJ_UNI(end); hBits = ZJ_UNI(hBits); mls = ZJ_UNI(mls);
+    carry = ZJ_UNI(carry ? 1u : 0u) != 0u;
+    u32 const lastLL = m.run_fast(*(ZXLds*)lds, base, frameSize, start, end, hBits, mls, table, repIn, repOut, carry);
+    o = m.o;
+    return lastLL;
+}
+
 // One block of a multi-block frame through the wave matcher (the signature ze_compress_t's block path calls; declared in zj_encode.h).
 ZJ_DEV u32 zx_block_dfast_wave(u8* lds, ZEOut& o, const u8* base, u32 frameSize, u32 start, u32 end, u32 hBitsL, u32 hBitsS, u32 mls,
                                u32* hashLong, u32* hashSmall, const u32* repIn, u32* repOut, bool carry) {
