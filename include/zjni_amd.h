@@ -255,6 +255,7 @@ int zjni_last_timing2(float* out8);
 #define ZJNI_ROUTE_RUN_FLAGS 6    /* zj_enc_match_run_kernel behind zj_enc_worth_kernel / zj_enc_need_kernel */
 #define ZJNI_ROUTE_HYBRID 7       /* ZJNI_HYBRID=1: lane and wave kernels side by side */
 #define ZJNI_ROUTE_OTHER 8        /* levels 4-8, dictionaries, multi-block only */
+#define ZJNI_ROUTE_WAVE_HBM 9     /* zj_encode_multi_kernel: level-3 frames of batches below ZJNI_L3_WAVE_MAX, wave per frame over HBM tables (zj_match_wavex.h) */
 int zjni_last_route(void);
 /* Name of the kernel a route's match-finder time (zjni_last_timing out[0]) belongs to. */
 const char* zjni_route_kernel(int route);

@@ -217,7 +217,8 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
 extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
-    u32 const flags = (level >> 8) & (ZE_FLAG_MASK | ZE_FLAG_MULTI_SERIAL | ZE_FLAG_MULTI_NOCARRY | ZE_FLAG_MULTI_FAST_SERIAL); level &= 0xFFu;     // 0x800: the one-lane parse of level-3 blocks instead of the wave matcher; 0x1000: the wave matcher without staged spans
+    u32 const flags = (level >> 8) & (ZE_FLAG_MASK | ZE_FLAG_MULTI_SERIAL | ZE_FLAG_MULTI_NOCARRY | ZE_FLAG_MULTI_FAST_SERIAL);
+    level = ZE_LW(level & 0xFFu, (level >> 16) & 0xFFu, (level >> 24) & 0xFFu);                 // hashLog << 16 | chainLog << 24: the level word of a level-3 frame on the wave route (ZJNI_ROUTE_WAVE_HBM)     // 0x800: the one-lane parse of level-3 blocks instead of the wave matcher; 0x1000: the wave matcher without staged spans
     EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
     memset(tables, 0xA5, ZE_MULTI_TABLE_BYTES);                      // the encoder clears what it uses

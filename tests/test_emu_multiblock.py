@@ -137,3 +137,24 @@ def test_multiblock_wave_matcher_orders_and_switches(emu, oracle_ref, zj):
                 for serial in (False, 2, True, 4):
                     if lib is rev and serial in (True, 4): continue
                     assert emu_compress_multi(lib, d, level, serial=serial) == want, (k, level, name, serial)
+
+
+def test_level3_single_block_frames_on_the_wave_route(emu, oracle_ref, zj):
+    """small level-3 batches (ZJNI_ROUTE_WAVE_HBM): every frame — any size up to a block — goes to the multi-block kernel, where the wave matcher parses it as
+    one block over HBM tables with the level's own table sizes (16 / 15: the reference's plain level 3) or the caller's; frames below 64 bytes take
+    the one-lane parse there"""
+    from util import edge_inputs
+    rev = C.CDLL(os.path.join(ROOT, "tests", "emu", "libzjni_emu_rev.so"))
+    rev.emu_compress_multi.restype = C.c_ulonglong
+    rev.emu_compress_multi.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    rnd = random.Random(21)
+    datas = [d for _, d in edge_inputs() if len(d) <= 131072]
+    datas += [zj.synth_host(rnd.choice([65536, 65536, 131072, 40000, 9000, 300, 64, 63, 7, 6]), 500 + k, 1) for k in range(60)]
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    datas += [xml[o:o + n] for o, n in ((0, 131072), (777777, 65536), (2000000, 100000), (5, 16384), (9, 16385))]
+    for k, d in enumerate(datas):
+        for ck in (False, True):
+            want = oracle_ref.compress(d, 3, ck)
+            assert emu_compress_multi(emu, d, 3, ck, hash_log=16, chain_log=15) == want, (k, len(d), ck)
+        assert emu_compress_multi(rev, d, 3, hash_log=16, chain_log=15) == oracle_ref.compress(d, 3), (k, len(d), "descending")
+        assert emu_compress_multi(emu, d, 3, hash_log=15, chain_log=16) == oracle_ref.compress(d, 3, False, 15, 16), (k, len(d), "15/16")

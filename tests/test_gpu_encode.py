@@ -383,3 +383,29 @@ def test_gpu_tables_cleared_ahead_between_calls(gpu, oracle_ref, monkeypatch):
         if rep % 3 == 1:
             back = gpu.decompress_batch(outs, [len(d) for d in datas])
             assert back == datas
+
+
+def test_gpu_small_level3_batches_take_the_wave_route(gpu, oracle_ref, monkeypatch):
+    """level 3, batches below ZJNI_L3_WAVE_MAX (8 192): every frame its own wave on zj_encode_multi_kernel (ZJNI_ROUTE_WAVE_HBM = 9, zj_match_wavex.h over HBM
+    tables) — the reference's plain level-3 bytes for every size up to a block, with checksum, with explicit table sizes, mixed with multi-block frames;
+    ZJNI_L3_WAVE_MAX=0 sends the same batch down the lane pipeline (route 5 / 6)"""
+    rnd = random.Random(7)
+    datas = [d for _, d in edge_inputs() if len(d) <= 131072]
+    datas += [gpu.synth_host(rnd.choice([65536, 65536, 131072, 100000, 40000, 9000, 300, 64, 63, 7, 6, 0]), 900 + k, 1) for k in range(300)]
+    datas += [golden("xmlsmall")[:60000], gpu.synth_host(300000, 5, 1)]
+    for ck in (False, True):
+        outs = gpu.compress_batch(datas, 3, checksum=ck)
+        assert gpu.lib().zjni_last_route() == 9
+        for d, z in zip(datas, outs):
+            assert z == oracle_ref.compress(d, 3, ck), (len(d), ck)
+    for hl, cl in ((17, 16), (14, 13), (12, 15)):
+        outs = gpu.compress_batch(datas[:120], 3, hash_log=hl, chain_log=cl)
+        for d, z in zip(datas[:120], outs):
+            assert z == oracle_ref.compress(d, 3, False, hl, cl), (len(d), hl, cl)
+    back = gpu.decompress_batch(gpu.compress_batch(datas, 3), [len(d) for d in datas])
+    assert back == datas
+    monkeypatch.setenv("ZJNI_L3_WAVE_MAX", "0")
+    outs = gpu.compress_batch(datas[:200], 3)
+    assert gpu.lib().zjni_last_route() in (5, 6)
+    for d, z in zip(datas[:200], outs):
+        assert z == oracle_ref.compress(d, 3), len(d)

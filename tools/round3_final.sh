@@ -1,8 +1,7 @@
 #!/bin/bash
 # Round 3, last GPU action:  gpurun --timeout 900 -- 'bash tools/round3_final.sh'   -> gpurun_out/r03final2/
-#   (1) the whole -m gpu suite on the final library, (2) bench.py lines of the configs this half of the round touched (metric, 1 at 1 024 and 4 096
-#   buffers), (3) rocprofv3 --kernel-trace --stats of the metric workload, (4) the two --pmc passes of the same (tools/pmc_traffic.sh's recipe, one key),
-#   (5) last: the multi-block tests with levels 1-2 on the wave matcher and its A/B against the one-lane parse.  Afterwards, where git is:
+#   (1) the whole -m gpu suite on the final library, (2) bench.py lines of the configs this half of the round touched (metric, 1), (3) rocprofv3 --kernel-trace --stats of the metric workload, (4) the two --pmc passes of the same (tools/pmc_traffic.sh's recipe, one key),
+#   (5) last: the multi-block tests with levels 1-2 on the wave matcher, its A/B against the one-lane parse, and small level-3 batches on the wave route against the lane pipeline.  Afterwards, where git is:
 #   python tools/pmc_summary.py gpurun_out/r03final2 r03 ; copy the lines into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r03final2; mkdir -p $OUT/pmc
 cd $R
@@ -10,12 +9,11 @@ cd $R
 # so that whatever it does, the measurements above it are in)
 ZJNI_MULTI_WAVE_FAST=0 timeout 300 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 for C in metric 1; do
-  timeout 200 python bench.py --config $C --steps 4 --warmup 1 > $OUT/bench_config$C.json 2> $OUT/bench_config$C.err
+  timeout 200 python bench.py --config $C --steps 3 --warmup 1 > $OUT/bench_config$C.json 2> $OUT/bench_config$C.err
 done
-timeout 200 python bench.py --config 1 --buffers 4096 --steps 3 --warmup 1 > $OUT/bench_config1_4096.json 2> $OUT/bench_config1_4096.err
 python - <<PY
 import json
-for C in ("metric", "1", "1_4096"):
+for C in ("metric", "1"):
     try:
         d = json.loads(open("$OUT/bench_config%s.json" % C).read().strip().splitlines()[-1])
         e = d.get("end_to_end") or {}
@@ -39,4 +37,10 @@ l1_wave ZJNI_MULTI_WAVE_FAST=1
 l1_one_lane ZJNI_MULTI_WAVE_FAST=0
 X
 echo "== level 1, 2048 x 512 KiB"; STEPS=2 bash tools/ab.sh $OUT/abL1.txt 2048 524288 1 | tee $OUT/level1_multiblock_ab.txt
+cat > $OUT/abR.txt <<X
+l3_wave_route ZJNI_L3_WAVE_MAX=8192
+l3_lane_pipeline ZJNI_L3_WAVE_MAX=0
+X
+echo "== level 3, 1024 x 64 KiB: wave route against the lane pipeline"; STEPS=2 bash tools/ab.sh $OUT/abR.txt 1024 65536 3 | tee $OUT/level3_small_batch_1024_ab.txt
+echo "== level 3, 4096 x 64 KiB"; STEPS=2 bash tools/ab.sh $OUT/abR.txt 4096 65536 3 | tee $OUT/level3_small_batch_4096_ab.txt
 ls $OUT $OUT/pmc | head -40

@@ -151,6 +151,7 @@ struct ZEParams { u32 windowLog, chainLog, hashLog, minMatch, strategy, searchLo
 #define ZE_LW_HL(lw) (((lw) >> 8) & 0xFFu)
 #define ZE_LW_CL(lw) (((lw) >> 16) & 0xFFu)
 #define ZE_LW_PERIOD(lw) (((lw) >> 24) & 0xFu)    /* match kernel only: rotation period of the double-fast lane machine, 0 = default */
+#define ZE_LW_WAVE_ROUTE (1u << 29)              /* classification only: every single-block frame of the call goes to the wave-per-frame kernel (level 3, batches too small to fill the lane pipeline) */
 #define ZE_LW_IMPLICIT (1u << 28)                /* hashLog / chainLog in the word are the level's OWN (16 / 15 at level 3: what a caller who set nothing gets) — multi-block frames, whose blocks take the level's parameters of their size, accept such a word */
 // "tuned": table sizes the LDS-resident finders (fused kernel, wave-per-frame matcher) cannot hold — everything but the LDS-sized pair itself
 #define ZE_LW_TUNED(lw) ((ZE_LW_HL(lw) | ZE_LW_CL(lw)) != 0u && !(ZE_LW_HL(lw) == ZE_L3_HASHLOG && ZE_LW_CL(lw) == ZE_L3_CHAINLOG))

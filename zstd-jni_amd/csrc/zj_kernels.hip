@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
         else result[i] = ZJ_ERR64(201);
         return;
     }
+    if (listC && (level & ZE_LW_WAVE_ROUTE)) { listC[atomicAdd(&counters[4], 1u)] = i; return; }      // a small level-3 batch: every frame its own wave (zj_match_wavex.h)
     bool const a = ZE_LW_TUNED(level) ? (size <= 65536u)                            // table sizes beyond the LDS: lane pipeline only, split by record width
                                                          : (ze_lds_need(ZE_LW_LEVEL(level), (u32)size) <= ldsA);
     if (a) listA[atomicAdd(&counters[0], 1u)] = i;
@@ -803,7 +804,7 @@ size_t enc_lds_pass0(int level) {
     size_t const need = level == 1 ? (8192u * 2u) : (level == 2 ? (32768u * 2u) : (((1u << ZE_L3_HASHLOG) + (1u << ZE_L3_CHAINLOG)) * 2u));
     return need > sizeof(ZEEntropy) ? need : sizeof(ZEEntropy);
 }
-enum { ZJ_ROUTE_FUSED = ZJNI_ROUTE_FUSED, ZJ_ROUTE_WAVE = ZJNI_ROUTE_WAVE, ZJ_ROUTE_LANE = ZJNI_ROUTE_LANE, ZJ_ROUTE_LANE_GATED = ZJNI_ROUTE_LANE_GATED,
+enum { ZJ_ROUTE_WAVE_HBM = ZJNI_ROUTE_WAVE_HBM, ZJ_ROUTE_FUSED = ZJNI_ROUTE_FUSED, ZJ_ROUTE_WAVE = ZJNI_ROUTE_WAVE, ZJ_ROUTE_LANE = ZJNI_ROUTE_LANE, ZJ_ROUTE_LANE_GATED = ZJNI_ROUTE_LANE_GATED,
        ZJ_ROUTE_RUN = ZJNI_ROUTE_RUN, ZJ_ROUTE_RUN_FLAGS = ZJNI_ROUTE_RUN_FLAGS, ZJ_ROUTE_HYBRID = ZJNI_ROUTE_HYBRID, ZJ_ROUTE_OTHER = ZJNI_ROUTE_OTHER };
 struct DevState {
     bool needLdsSet = false;                      // zj_enc_need_kernel's LDS attribute has been set on this device
@@ -1146,6 +1147,7 @@ const char* zjni_route_kernel(int route) {
     case ZJNI_ROUTE_LANE: case ZJNI_ROUTE_HYBRID: return "zj_enc_match_kernel";
     case ZJNI_ROUTE_LANE_GATED: return "zj_enc_match_gated_kernel";
     case ZJNI_ROUTE_RUN: case ZJNI_ROUTE_RUN_FLAGS: return "zj_enc_match_run_kernel";
+    case ZJNI_ROUTE_WAVE_HBM: return "zj_encode_multi_kernel";
     default: return "";
     }
 }
@@ -1409,6 +1411,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     u32* const listA = d->encList; u32* const listB = d->encList + d->encListCap; u32* const listS = d->encList + 2 * d->encListCap; u32* const listC = d->encList + 3 * d->encListCap;
     if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);     // [0] |A|, [1] |B|, [2] work A, [3] work B, [4] |C|, [5] work C
     if (level > 3 && tuned) return ZJNI_ERR(42);
+    // Level 3, batches that cannot fill the lane pipeline: a lane of that pipeline takes ~46 000 rounds for a 64 KiB text frame whatever the batch size (a
+    // floor of ~96 ms per call), while a wave of the multi-block kernel parses the same frame in ~6 000 windows (zj_match_wavex.h: ~17 ms) —
+    // so below ZJNI_L3_WAVE_MAX frames (default 8 192: four rounds of the 2 048 resident waves) every frame goes there, with the level's own tables or the caller's.
+    // (ZJNI_SPLIT_MIN — "the lane pipelines from this batch size on" — is honoured: with it set the wave route ends there.)
+    size_t l3WaveMax = 8192; if (const char* ov = getenv("ZJNI_L3_WAVE_MAX")) l3WaveMax = (size_t)atoll(ov);
+    if (const char* ov = getenv("ZJNI_SPLIT_MIN")) { size_t const v = (size_t)atoll(ov); if (v < l3WaveMax) l3WaveMax = v; }
+    bool const l3wave = level == 3 && tuned && n < l3WaveMax && !g_scratch_limit;      // (tuned: table sizes beyond the LDS — the level's own 16 / 15 included; explicit 14 / 13 keeps the LDS matcher of small batches)
+    if (l3wave) levelWord |= (int)ZE_LW_WAVE_ROUTE;
     u32 const ldsA = level > 3 ? 0u : (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
@@ -1427,6 +1437,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (const char* ov = getenv("ZJNI_MULTI_WAVE_FAST")) { if (atoi(ov) == 0) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }     // levels 1-2 (fast strategy) on the one-lane parse
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
+    }
+    if (l3wave) {                                  // the whole batch was list C's
+        d->lastRoute = ZJ_ROUTE_WAVE_HBM; d->tevCompress = false;
+        d->clearedValid = wasCleared;              // the lane pipeline's scratch was not touched: what the previous call promised about its tables still holds
+        return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     if (level > 3) {
         // list A of levels 4-8 (frames <= 16 KiB): chain parsers lane-per-frame, then the entropy kernel on their records
