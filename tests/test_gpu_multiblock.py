@@ -59,11 +59,11 @@ def test_gpu_multiblock_frames_are_the_references(gpu, oracle_ref, level):
             assert b == d
 
 
-@pytest.mark.parametrize("switch", [("ZJNI_MULTI_WAVE", "0"), ("ZJNI_MULTI_WAVE", "2"), ("ZJNI_MULTI_WAVE_FAST", "0")])
+@pytest.mark.parametrize("switch", [("ZJNI_MULTI_WAVE", "0"), ("ZJNI_MULTI_WAVE", "2"), ("ZJNI_MULTI_WAVE_FAST", "1")])
 def test_gpu_multiblock_parse_switches(gpu, oracle_ref, monkeypatch, switch):
-    """blocks of multi-block frames run the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2) by default;
-    ZJNI_MULTI_WAVE=0 selects the one-lane parses of rounds 1-3, =2 the wave matchers without staged spans, ZJNI_MULTI_WAVE_FAST=0 the
-    one-lane parse for levels 1-2 only — the same frames either way"""
+    """level-3 blocks of multi-block frames run the wave matcher (zj_match_wavex.h) by default, levels 1-2 the one-lane parse;
+    ZJNI_MULTI_WAVE=0 selects the one-lane parses of rounds 1-3, =2 the wave matchers without staged spans, ZJNI_MULTI_WAVE_FAST=1 puts levels 1-2
+    on their wave matcher too (exact, measured slower than the one-lane parse there: off by default) — the same frames either way"""
     monkeypatch.setenv(*switch)
     for level in (3, 1, 2):
         datas = [d for d in inputs(gpu, oracle_ref, 100 + level, 24) if len(d) <= WINDOW[level]]

@@ -1434,7 +1434,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
         // blocks of multi-block frames: the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
         u32 multiSerial = 0; if (const char* ov = getenv("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
-        if (const char* ov = getenv("ZJNI_MULTI_WAVE_FAST")) { if (atoi(ov) == 0) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }     // levels 1-2 (fast strategy) on the one-lane parse
+        // levels 1-2 (fast strategy): the one-lane parse unless ZJNI_MULTI_WAVE_FAST=1 — the wave version (ZWaveF) is exact but measured slower there
+        // (2 048 x 512 KiB at level 1: 156 ms against 138; one 64 KiB table per frame stays in the L2 / Infinity Cache and an iteration of the one-lane loop is one short trip)
+        {   const char* const ov = getenv("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
     }
