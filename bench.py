@@ -444,6 +444,22 @@ def main():
         B.compress(src, src_off, comp, comp_off, level, csz, dictionary=cdict)          # leave the headline's frames in `comp` for the gates below
         torch.cuda.synchronize()
 
+    # ---- what ONE call costs when the batch is small (a JVM thread's ZstdCompressCtx.compress, the aggregator's few hundred buffers): level 3, the first 1 024
+    # buffers of the same batch, one warm-up + a timed call, outside `value`.  Below ZJNI_L3_WAVE_MAX frames the library sends every frame to a wave of its
+    # own (zj_match_wavex.h on zj_encode_multi_kernel, route 9) instead of the lane pipeline, whose call costs ~95 ms whatever the batch size.
+    small = None
+    if mode == "both" and level == 3 and size <= 131072 and n >= 1024 and not a.skip_lds3:
+        ns = 1024
+        csz3 = torch.empty(ns, dtype=torch.int64, device=dev)
+        for it in range(2):                              # frames go into `packed` (free after the timed steps): `comp` keeps the headline's frames for the gates
+            p0, p1 = ev(), ev()
+            p0.record(); B.compress(src[:ns * size], src_off[:ns + 1], packed, comp_off[:ns + 1], 3, csz3); p1.record()
+            torch.cuda.synchronize()
+        sroute = int(L.zjni_last_route())
+        small = {"frames": ns, "frame_bytes": size, "compress_call_ms": p0.elapsed_time(p1), "route": sroute, "kernel": L.zjni_route_kernel(sroute).decode(),
+                 "same_sizes_as_the_full_batch": bool(torch.equal(csz3, csz[:ns])),
+                 "note": "one level-3 call over the first 1 024 buffers of the batch (HIP events around the call, inputs in HBM); route 9 = wave per frame over HBM tables (ZJNI_ROUTE_WAVE_HBM)"}
+
     # ---- parity gates (outside the timed region) ----
     ok_sizes = bool((csz > 0).all()) and bool((dsz == size).all())
     roundtrip = ok_sizes and torch.equal(back, src)
@@ -581,6 +597,7 @@ def main():
                        **({"hashLog": 16, "chainLog": 15, "table_sizes": "the reference's own for this level and size (N/compress/clevels.h + ZSTD_adjustCParams): nothing but the level is set; the LDS-sized 14 / 13 behind setHashLog / setChainLog: see lds_tables_level3"} if (level == 3 and 32768 < size <= 131072 and mode in ("both",)) else {})},
             "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel},
             "lds_tables_level3": lds3,
+            "small_batch_level3": small,
             "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),
             "kernel_ms": {"compress_call": mc, "decompress_call": md, **kernels, "rccl_gather": mg},
             "ratio": n * size / max(csum, 1),
