@@ -18,7 +18,7 @@ def _asan_runtime():
 
 @pytest.mark.parametrize("tool", [["fuzz_emu_encode.py"], ["fuzz_emu_decode.py"], ["fuzz_emu_level4.py"], ["fuzz_emu_multiblock.py"],
                                   ["fuzz_emu_cdict_copy.py"], ["fuzz_emu_dict.py", "decode"], ["fuzz_emu_wave.py"], ["fuzz_emu_tight.py"],
-                                  ["fuzz_emu_need.py", "NEEDMODE=1"], ["fuzz_emu_need.py", "NEEDMODE=4"]], ids=lambda t: "-".join(t))
+                                  ["fuzz_emu_need.py", "NEEDMODE=1"], ["fuzz_emu_need.py", "NEEDMODE=4"], ["fuzz_emu_l3wave.py"]], ids=lambda t: "-".join(t))
 def test_emu_bodies_under_sanitizers(tool):
     extra = dict(a.split("=", 1) for a in tool[1:] if "=" in a)           # NAME=value entries are environment for the tool, the rest its arguments
     tool = [a for a in tool if "=" not in a]
