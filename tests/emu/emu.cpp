@@ -213,6 +213,14 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     return r;
 }
 
+// ZSTD_splitBlock by chunks (zj_presplit.h): the one-lane walk and the whole-group version on the same 128 KiB
+extern "C" unsigned emu_presplit_chunks(const unsigned char* p, int group) {
+    Grp<1> g;
+    u32* ev = (u32*)calloc(1024, 4);
+    u32 const r = group ? zp_split_by_chunks_g(g, p, ev) : zp_split_by_chunks(p, ev);
+    free(ev);
+    return r;
+}
 // multi-block frames (128 KiB < srcSize <= 2 MiB): the frame loop of ze_compress_multi, lane-serial
 extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);

@@ -158,3 +158,24 @@ def test_level3_single_block_frames_on_the_wave_route(emu, oracle_ref, zj):
             assert emu_compress_multi(emu, d, 3, ck, hash_log=16, chain_log=15) == want, (k, len(d), ck)
         assert emu_compress_multi(rev, d, 3, hash_log=16, chain_log=15) == oracle_ref.compress(d, 3), (k, len(d), "descending")
         assert emu_compress_multi(emu, d, 3, hash_log=15, chain_log=16) == oracle_ref.compress(d, 3, False, 15, 16), (k, len(d), "15/16")
+
+
+def test_presplit_on_the_group_equals_the_one_lane_walk(emu, zj):
+    """zj_presplit.h: ZSTD_splitBlock's chunk fingerprints (N/compress/zstd_preSplit.c:152-238) sampled and compared by the whole group give the cut the one-lane
+    walk gives — on blocks whose statistics change at every chunk border, at none, and at random places"""
+    emu.emu_presplit_chunks.restype = C.c_uint
+    emu.emu_presplit_chunks.argtypes = [C.c_char_p, C.c_int]
+    rnd = random.Random(5)
+    kinds = [lambda n: bytes(rnd.getrandbits(8) for _ in range(n)), lambda n: bytes(rnd.choice(b"abcdefgh ") for _ in range(n)),
+             lambda n: bytes([rnd.getrandbits(8)]) * n, lambda n: zj.synth_host(n, rnd.randrange(1 << 20), 1)[:n],
+             lambda n: bytes(rnd.getrandbits(8) & 0x0F for _ in range(n))]
+    cuts = set()
+    for k in range(120):
+        parts = []
+        while sum(map(len, parts)) < 131072:
+            parts.append(rnd.choice(kinds)(rnd.choice([8192, 8192, 16384, 40000, 3000, 131072, 65536])))
+        d = b"".join(parts)[:131072]
+        a, b = emu.emu_presplit_chunks(d, 0), emu.emu_presplit_chunks(d, 1)
+        assert a == b, (k, a, b)
+        cuts.add(a)
+    assert len(cuts) >= 6 and 131072 in cuts, cuts          # the inputs did exercise several cut positions and "no cut"
