@@ -238,6 +238,50 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
     return r;
 }
 
+// EXPERIMENT (not in the product): what ZSTD_compressStream2 without a pledged size makes of `src` fed with ZSTD_e_continue and closed
+// with ZSTD_e_end — the stream natives' frames — rebuilt from the multi-block pieces: unknown-size parameters (equal to the one-shot ones above 256 KiB), header
+// without content size and the unknown-size window byte, the input taken in chunks of 128 KiB (one pre-split at most per chunk, savings counted with the header's
+// bytes), an empty raw last block when the total is a multiple of 128 KiB.  256 KiB < srcSize <= the level's window.  Checked against oracle/ref.py compress_stream.
+extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    EMU_IO(src, srcSize, dst, dstCap);
+    Grp<1> g;
+    u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
+    EmuWg& wg = emu_wg(); ZEncShared& sh = *wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
+    ZEParams const p = ze_params_of(level, srcSize);
+    u32 const wlogUnknown = level == 1 ? 19u : (level == 2 ? 20u : 21u);
+    if (srcSize <= (256u << 10) || srcSize > (1u << wlogUnknown) || level < 1 || level > 3) return ZJ_ERR64(201);
+    u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
+    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
+    st32(dst, 0xFD2FB528u); dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((wlogUnknown - 10u) << 3);
+    sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0;
+    u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
+    for (u32 i = 0; i < entries; i++) tables[i] = 0;
+    ZjProf pf; pf.start(nullptr);
+    u32 pos = 6, isFirst = 1; u64 r = 0; bool lastSeen = false;
+    for (u32 chunk = 0; chunk < srcSize && r <= ZJ_ERR64(256); chunk += 131072u) {
+        u32 const chunkEnd = chunk + 131072u < srcSize ? chunk + 131072u : srcSize;
+        bool const endChunk = chunkEnd == srcSize && (srcSize % 131072u) != 0u;          // the buffered rest at ZSTD_e_end: the last frame chunk
+        i64 savings = (i64)chunk - (i64)pos;                                                // consumedSrcSize - producedCSize, the header's bytes included
+        for (u32 at = chunk; at < chunkEnd; ) {
+            u32 const blockSize = zp_block_size(src + at, chunkEnd - at, p.strategy, savings, (u32*)lds);
+            ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (endChunk && at + blockSize == chunkEnd) ? 1u : 0u; ba.tables = tables; ba.serialParse = 0;
+            r = ze_compress_t<Grp<1>, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, 160u * 1024u, &ba);
+            if (r > ZJ_ERR64(256)) break;
+            lastSeen = ba.lastBlock != 0;
+            savings += (i64)blockSize - (i64)r;
+            at += blockSize; pos += (u32)r; isFirst = 0;
+        }
+    }
+    u64 out = r;
+    if (r <= ZJ_ERR64(256)) {
+        if (!lastSeen) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; pos += 3; }       // ZSTD_writeEpilogue: empty raw last block
+        if (tail) { u64 const h = zj_xxh64(g, src, srcSize); st32(dst + pos, (u32)h); pos += 4; }
+        out = pos;
+    }
+    free(tables);
+    return out;
+}
+
 // levels 4-8, frames <= 16 KiB, as the large-batch route runs them: chain parser per frame (zj_enc_match_chain_kernel's body) into the
 // record scratch, then the entropy stage on those records (zj_encode_kernel with `pre`)
 extern "C" unsigned long long emu_compress_chain(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {

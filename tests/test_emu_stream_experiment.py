@@ -1,0 +1,48 @@
+"""CPU (-m "not gpu"): EXPERIMENT, not a product route — the frames the reference's *stream* classes produce (ZSTD_compressStream2 without a pledged size:
+ZstdDirectBufferCompressingStream / ZstdOutputStream, N/jni_directbuffercompress_zstd.c:113-157) rebuilt from the multi-block pieces of the GPU path in the
+lane-serial emulation (tests/emu/emu.cpp emu_compress_stream): unknown-size parameters, header without content size, input taken in 128 KiB chunks with the
+savings counted as the stream counts them, empty raw last block when the total is a multiple of 128 KiB.  It pins down what a GPU route for the stream natives has
+to reproduce; totals of 256 KiB .. the level's window, where the unknown-size parameters equal the one-shot ones."""
+import ctypes as C
+import random
+
+import pytest
+
+from conftest import golden
+from util import emu_lib
+
+
+@pytest.fixture(scope="module")
+def emu():
+    L = emu_lib()
+    L.emu_compress_stream.restype = C.c_ulonglong
+    L.emu_compress_stream.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    return L
+
+
+def stream(L, d, level, checksum=False):
+    cap = len(d) + (len(d) >> 8) + 4096
+    dst = C.create_string_buffer(cap)
+    r = L.emu_compress_stream(d, len(d), dst, cap, level | (0x100 if checksum else 0))
+    return dst.raw[:r] if r < (1 << 63) else -((1 << 64) - r)
+
+
+def test_stream_frames_rebuilt_from_the_multiblock_pieces(emu, oracle_ref, zj):
+    rnd = random.Random(3)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+    n = 0
+    for size in (262145, 393216, 393217, 600000, 1048576, 2000000, 2097152):
+        o = rnd.randrange(0, len(xml) - size)
+        inputs = [xml[o:o + size],
+                  b"".join(zj.synth_host(65536, i, 1) for i in range(size // 65536 + 1))[:size],       # the class changes every 64 KiB: pre-splits
+                  (noise * 40)[:size]]                                                                 # raw blocks, then 70 000-byte matches
+        for d in inputs:
+            for level in (3, 1, 2):
+                if size > (1 << (18 + level)):
+                    assert stream(emu, d, level) == -201
+                    continue
+                ck = bool(n & 1); n += 1
+                for chunk in (50000, 131072):                  # how the caller slices its writes does not matter: the stream buffers 128 KiB
+                    assert stream(emu, d, level, ck) == oracle_ref.compress_stream(d, level, ck, chunk=chunk), (size, level, ck, chunk)
+    assert stream(emu, xml[:200000], 3) == -201               # below 256 KiB the unknown-size parameters differ from the one-shot ones: not covered here
