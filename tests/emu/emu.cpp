@@ -241,18 +241,22 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
 // EXPERIMENT (not in the product): what ZSTD_compressStream2 without a pledged size makes of `src` fed with ZSTD_e_continue and closed
 // with ZSTD_e_end — the stream natives' frames — rebuilt from the multi-block pieces: unknown-size parameters (equal to the one-shot ones above 256 KiB), header
 // without content size and the unknown-size window byte, the input taken in chunks of 128 KiB (one pre-split at most per chunk, savings counted with the header's
-// bytes), an empty raw last block when the total is a multiple of 128 KiB.  256 KiB < srcSize <= the level's window.  Checked against oracle/ref.py compress_stream.
+// bytes), an empty raw last block when the total is a multiple of 128 KiB (an empty stream included).  srcSize <= the level's window.  Checked against oracle/ref.py compress_stream.
 extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
     EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
     EmuWg& wg = emu_wg(); ZEncShared& sh = *wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
-    ZEParams const p = ze_params_of(level, srcSize);
     u32 const wlogUnknown = level == 1 ? 19u : (level == 2 ? 20u : 21u);
-    if (srcSize <= (256u << 10) || srcSize > (1u << wlogUnknown) || level < 1 || level > 3) return ZJ_ERR64(201);
+    if (srcSize > (1u << wlogUnknown) || level < 1 || level > 3) return ZJ_ERR64(201);
+    // totals up to 256 KiB: the stream still runs the level's default row (window 21 / 20 / 19 and its table sizes), which the one-shot parameters of such a size
+    // are not — the block arguments then name a parameter size above 256 KiB and the blocks take the one-lane parse (the wave matcher clamps its loads by that size)
+    u32 const paramSize = srcSize > (256u << 10) ? srcSize : (256u << 10) + 1u;
+    ZEParams const p = ze_params_of(level, paramSize);
     u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
     u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
     st32(dst, 0xFD2FB528u); dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((wlogUnknown - 10u) << 3);
+    if (srcSize == 0) { dst[4] = (u8)(0x20u + (tail ? 4u : 0u)); dst[5] = 0; }      // nothing was ever written: the first call is ZSTD_e_end, the size (0) is known — single segment, one-byte content size
     sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0;
     u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
     for (u32 i = 0; i < entries; i++) tables[i] = 0;
@@ -264,7 +268,7 @@ extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsi
         i64 savings = (i64)chunk - (i64)pos;                                                // consumedSrcSize - producedCSize, the header's bytes included
         for (u32 at = chunk; at < chunkEnd; ) {
             u32 const blockSize = zp_block_size(src + at, chunkEnd - at, p.strategy, savings, (u32*)lds);
-            ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (endChunk && at + blockSize == chunkEnd) ? 1u : 0u; ba.tables = tables; ba.serialParse = 0;
+            ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = paramSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (endChunk && at + blockSize == chunkEnd) ? 1u : 0u; ba.tables = tables; ba.serialParse = paramSize != srcSize ? 1u : 0u;
             r = ze_compress_t<Grp<1>, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, 160u * 1024u, &ba);
             if (r > ZJ_ERR64(256)) break;
             lastSeen = ba.lastBlock != 0;

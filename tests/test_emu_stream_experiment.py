@@ -2,7 +2,7 @@
 ZstdDirectBufferCompressingStream / ZstdOutputStream, N/jni_directbuffercompress_zstd.c:113-157) rebuilt from the multi-block pieces of the GPU path in the
 lane-serial emulation (tests/emu/emu.cpp emu_compress_stream): unknown-size parameters, header without content size, input taken in 128 KiB chunks with the
 savings counted as the stream counts them, empty raw last block when the total is a multiple of 128 KiB.  It pins down what a GPU route for the stream natives has
-to reproduce; totals of 256 KiB .. the level's window, where the unknown-size parameters equal the one-shot ones."""
+to reproduce; any total up to the level's window (above 256 KiB the unknown-size parameters equal the one-shot ones; below, the experiment names a parameter size apart from the frame size)."""
 import ctypes as C
 import random
 
@@ -45,4 +45,11 @@ def test_stream_frames_rebuilt_from_the_multiblock_pieces(emu, oracle_ref, zj):
                 ck = bool(n & 1); n += 1
                 for chunk in (50000, 131072):                  # how the caller slices its writes does not matter: the stream buffers 128 KiB
                     assert stream(emu, d, level, ck) == oracle_ref.compress_stream(d, level, ck, chunk=chunk), (size, level, ck, chunk)
-    assert stream(emu, xml[:200000], 3) == -201               # below 256 KiB the unknown-size parameters differ from the one-shot ones: not covered here
+    # up to 256 KiB the stream still runs the level's default row (window 21 / 20 / 19), which the one-shot parameters of such a size are not: the experiment
+    # names a parameter size apart from the frame size there.  An empty stream: the first call is ZSTD_e_end, so its size IS known (single segment, content size 0).
+    for size in (0, 1, 6, 7, 8, 100, 4096, 65536, 100000, 131071, 131072, 131073, 200000, 262144):
+        o = rnd.randrange(0, len(xml) - size - 1)
+        for d in (xml[o:o + size], zj.synth_host(65536, 2, 5)[:size], (noise * 4)[:size]):
+            for level in (3, 1, 2):
+                ck = bool(n & 1); n += 1
+                assert stream(emu, d, level, ck) == oracle_ref.compress_stream(d, level, ck), (size, level, ck)
