@@ -242,7 +242,16 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
 // with ZSTD_e_end — the stream natives' frames — rebuilt from the multi-block pieces: unknown-size parameters (equal to the one-shot ones above 256 KiB), header
 // without content size and the unknown-size window byte, the input taken in chunks of 128 KiB (one pre-split at most per chunk, savings counted with the header's
 // bytes), an empty raw last block when the total is a multiple of 128 KiB (an empty stream included).  srcSize <= the level's window.  Checked against oracle/ref.py compress_stream.
+static unsigned long long emu_compress_stream_f(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level, const unsigned* flushAt, unsigned nFlush);
 extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level) {
+    return emu_compress_stream_f(src, srcSize, dst, dstCap, level, nullptr, 0u);
+}
+// flushAt[0 .. nFlush): ascending byte counts after which the caller flushed (ZSTD_e_flush: the stream classes' flush()) — the bytes buffered at that moment become
+// a block of their own and the 128 KiB chunking starts again behind them; a flush with nothing buffered writes nothing
+extern "C" unsigned long long emu_compress_stream_flush(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level, const unsigned* flushAt, unsigned nFlush) {
+    return emu_compress_stream_f(src, srcSize, dst, dstCap, level, flushAt, nFlush);
+}
+static unsigned long long emu_compress_stream_f(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level, const unsigned* flushAt, unsigned nFlush) {
     EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
@@ -262,9 +271,14 @@ extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsi
     for (u32 i = 0; i < entries; i++) tables[i] = 0;
     ZjProf pf; pf.start(nullptr);
     u32 pos = 6, isFirst = 1; u64 r = 0; bool lastSeen = false;
-    for (u32 chunk = 0; chunk < srcSize && r <= ZJ_ERR64(256); chunk += 131072u) {
-        u32 const chunkEnd = chunk + 131072u < srcSize ? chunk + 131072u : srcSize;
-        bool const endChunk = chunkEnd == srcSize && (srcSize % 131072u) != 0u;          // the buffered rest at ZSTD_e_end: the last frame chunk
+    u32 fi = 0;
+    for (u32 chunk = 0, seg = 0; chunk < srcSize && r <= ZJ_ERR64(256); ) {
+        while (fi < nFlush && flushAt[fi] <= seg) fi++;                                                            // (flushes with nothing buffered)
+        bool const haveFlush = fi < nFlush && flushAt[fi] <= srcSize;
+        u32 const segEnd = haveFlush ? flushAt[fi] : srcSize;                                                      // the next flush() (or the end of what was written)
+        u32 const chunkEnd = chunk + 131072u < segEnd ? chunk + 131072u : segEnd;
+        bool const flushed = haveFlush && chunkEnd == segEnd;                                                      // this piece ends where the caller flushed
+        bool const endChunk = chunkEnd == srcSize && (chunkEnd - chunk) != 131072u && !flushed;                    // still buffered at ZSTD_e_end: the last frame chunk
         i64 savings = (i64)chunk - (i64)pos;                                                // consumedSrcSize - producedCSize, the header's bytes included
         for (u32 at = chunk; at < chunkEnd; ) {
             u32 const blockSize = zp_block_size(src + at, chunkEnd - at, p.strategy, savings, (u32*)lds);
@@ -275,6 +289,7 @@ extern "C" unsigned long long emu_compress_stream(const unsigned char* src, unsi
             savings += (i64)blockSize - (i64)r;
             at += blockSize; pos += (u32)r; isFirst = 0;
         }
+        chunk = chunkEnd; if (chunkEnd == segEnd) seg = segEnd;
     }
     u64 out = r;
     if (r <= ZJ_ERR64(256)) {

@@ -17,6 +17,8 @@ def emu():
     L = emu_lib()
     L.emu_compress_stream.restype = C.c_ulonglong
     L.emu_compress_stream.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint]
+    L.emu_compress_stream_flush.restype = C.c_ulonglong
+    L.emu_compress_stream_flush.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.c_uint]
     return L
 
 
@@ -53,3 +55,24 @@ def test_stream_frames_rebuilt_from_the_multiblock_pieces(emu, oracle_ref, zj):
             for level in (3, 1, 2):
                 ck = bool(n & 1); n += 1
                 assert stream(emu, d, level, ck) == oracle_ref.compress_stream(d, level, ck), (size, level, ck)
+
+
+def test_stream_frames_with_flushes(emu, oracle_ref, zj):
+    """flush() (ZSTD_e_flush) ends the block where the caller stands — the buffered bytes become a block of their own, the 128 KiB chunking starts again behind
+    them, a flush with nothing buffered writes nothing, and close() after a flush writes the empty last block"""
+    rnd = random.Random(5)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    n = 0
+    for size in (0, 1000, 50000, 131072, 200000, 262144, 300000, 524288):
+        o = rnd.randrange(0, len(xml) - size - 1)
+        for d in (xml[o:o + size], b"".join(zj.synth_host(65536, i, 1) for i in range(size // 65536 + 1))[:size]):
+            for level in (3, 1):
+                if size > (1 << (18 + level)): continue
+                for chunk, k in ((50000, 1), (50000, 2), (10000, 3), (131072, 1), (65536, 2), (200000, 1), (1000, 7)):
+                    calls = (size + chunk - 1) // chunk
+                    flushes = [min(j * chunk, size) for j in range(1, calls + 1) if j % k == 0]       # oracle/ref.py compress_stream flushes with every k-th write
+                    cap = len(d) + (len(d) >> 8) + 4096 + 64 * (len(flushes) + 2)
+                    dst = C.create_string_buffer(cap)
+                    ck = bool(n & 1); n += 1
+                    r = emu.emu_compress_stream_flush(d, len(d), dst, cap, level | (0x100 if ck else 0), (C.c_uint * max(len(flushes), 1))(*flushes), len(flushes))
+                    assert r < (1 << 63) and dst.raw[:r] == oracle_ref.compress_stream(d, level, ck, chunk=chunk, flush_every=k), (size, level, chunk, k)
