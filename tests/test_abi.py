@@ -110,3 +110,22 @@ def test_java_mirror_argument_checks(zj):
     ctx.close()
     with pytest.raises(RuntimeError):
         ctx.setLevel(1)                                     # T/scala/Zstd.scala:1000-1020 use-after-close
+
+
+def test_route_names_and_build_stamp(zj):
+    """zjni_route_kernel names the kernel a route's match-finder time belongs to (bench.py's roofline takes the name from here, include/zjni_amd.h ZJNI_ROUTE_*);
+    zjni_build_stamp is the hash of csrc/ + the header the library was compiled from — the one profiles/r03_pmc_traffic.json is keyed by"""
+    import ctypes as C
+    import re
+    L = zj.lib()
+    L.zjni_route_kernel.restype = C.c_char_p; L.zjni_route_kernel.argtypes = [C.c_int]
+    L.zjni_build_stamp.restype = C.c_char_p
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "zjni_amd.h")).read()
+    routes = {name: int(val) for name, val in re.findall(r"#define (ZJNI_ROUTE_[A-Z_]+) (\d+)", header)}
+    assert routes["ZJNI_ROUTE_WAVE_HBM"] == 9 and len(set(routes.values())) == len(routes)
+    want = {"ZJNI_ROUTE_FUSED": b"zj_encode_kernel", "ZJNI_ROUTE_WAVE": b"zj_enc_match_wave_kernel", "ZJNI_ROUTE_LANE": b"zj_enc_match_kernel",
+            "ZJNI_ROUTE_LANE_GATED": b"zj_enc_match_gated_kernel", "ZJNI_ROUTE_RUN": b"zj_enc_match_run_kernel", "ZJNI_ROUTE_RUN_FLAGS": b"zj_enc_match_run_kernel",
+            "ZJNI_ROUTE_HYBRID": b"zj_enc_match_kernel", "ZJNI_ROUTE_WAVE_HBM": b"zj_encode_multi_kernel", "ZJNI_ROUTE_OTHER": b"", "ZJNI_ROUTE_NONE": b""}
+    for name, val in routes.items():
+        assert L.zjni_route_kernel(val) == want[name], name
+    assert L.zjni_build_stamp().decode() == zj.build_stamp()          # the library in the tree is the one these sources give
