@@ -311,13 +311,26 @@ def main():
     if a.level: cfg["level"] = a.level
     n, size, level, mode = cfg["n"], cfg["size"], cfg["level"], cfg["mode"]
     a._n = n
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU (the form the driver uses for N > 1).
+        # Never print an n_gpus 1 line for a --gpus N request: without N devices this fails loudly instead.
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but {have} device(s) visible")
+        import socket, subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     zj = entry.load_package()
     if not os.path.exists(zj.LIB_PATH):
         zj.build()

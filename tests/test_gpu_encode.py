@@ -369,7 +369,7 @@ def test_gpu_wave_matcher(gpu, oracle_ref, monkeypatch, mode):
 def test_gpu_tables_cleared_ahead_between_calls(gpu, oracle_ref, monkeypatch):
     """the lane pipeline's level-3 tables are zeroed for the NEXT call as soon as a call's match kernel is done (clear stream, zj_kernels.hip):
     calls of equal, smaller and larger batches, other levels and a decompress call in between all find what they need — the reference's
-    bytes every time; ZJNI_PRECLEAR is read once per process, so the switch-off is exercised by tools/ab.sh runs, not here"""
+    bytes every time (the unordered cases and ZJNI_PRECLEAR=0: the next test)"""
     monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
     rnd = random.Random(99)
     def batch(k, seed):
@@ -383,6 +383,44 @@ def test_gpu_tables_cleared_ahead_between_calls(gpu, oracle_ref, monkeypatch):
         if rep % 3 == 1:
             back = gpu.decompress_batch(outs, [len(d) for d in datas])
             assert back == datas
+
+
+@pytest.mark.parametrize("preclear", ["1", "0"])
+def test_gpu_pending_table_clear_is_ordered_before_every_scratch_user(gpu, oracle_ref, monkeypatch, preclear):
+    """the clear a level-3 lane call queues for the NEXT call runs on a stream of its own, and every later user of the same
+    scratch — levels 4-8, the LDS matcher of small explicit 14 / 13 batches, a level 1-3 call with a larger table range — must order itself
+    behind it, not only the call that skips its own memset.  Device-resident calls enqueued back to back (nothing synchronises in between) after
+    a batch whose tables take milliseconds to clear (12 288 x 64 KiB: 4.5 GiB); the followers' frames must be the reference's.  Both
+    settings of ZJNI_PRECLEAR."""
+    import torch
+    monkeypatch.setenv("ZJNI_PRECLEAR", preclear)
+    monkeypatch.setenv("ZJNI_L3_WAVE_MAX", "0")
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    dev = "cuda"
+    nBig, size = 12288, 65536
+    big = gpu.batch.synth(nBig, size)
+    bigOff = gpu.batch.uniform_offsets(nBig, size, dev)
+    bound = int(gpu.lib().zjni_compressBound(size))
+    bigDst = torch.empty(nBig * bound, dtype=torch.uint8, device=dev); bigDstOff = gpu.batch.uniform_offsets(nBig, bound, dev)
+    followers = [dict(level=5, n=48, size=12000), dict(level=3, n=64, size=65536, hash_log=14, chain_log=13), dict(level=3, n=160, size=65536, hash_log=17, chain_log=16),
+                 dict(level=1, n=96, size=40000), dict(level=4, n=40, size=65536)]
+    for rep in range(3):
+        for f in followers:
+            n, fs = f["n"], f["size"]
+            src = gpu.batch.synth(n, fs, first_index=1000 * rep + 7)
+            srcOff = gpu.batch.uniform_offsets(n, fs, dev)
+            fb = int(gpu.lib().zjni_compressBound(fs))
+            dst = torch.zeros(n * fb, dtype=torch.uint8, device=dev); dstOff = gpu.batch.uniform_offsets(n, fb, dev)
+            r0 = gpu.batch.compress(big, bigOff, bigDst, bigDstOff, 3)                                     # queues the clear behind its match kernel
+            res = gpu.batch.compress(src, srcOff, dst, dstOff, f["level"], hash_log=f.get("hash_log", 0), chain_log=f.get("chain_log", 0))   # ... and this call starts under it
+            torch.cuda.synchronize()
+            assert int((r0 < 0).sum()) == 0
+            host = src.cpu().numpy().tobytes(); out = dst.cpu().numpy().tobytes(); sizes = res.cpu().tolist()
+            for i in range(n):
+                d = host[i * fs:(i + 1) * fs]
+                assert sizes[i] > 0, (rep, f, i, sizes[i])
+                want = oracle_ref.compress(d, f["level"], False, f.get("hash_log", 0), f.get("chain_log", 0))
+                assert out[i * fb:i * fb + sizes[i]] == want, (rep, f, i)
 
 
 def test_gpu_small_level3_batches_take_the_wave_route(gpu, oracle_ref, monkeypatch):

@@ -13,6 +13,8 @@
 #include <condition_variable>
 #include <chrono>
 #include <map>
+#include <string>
+#include <system_error>
 #include <memory>
 #include <vector>
 #include <string.h>
@@ -30,6 +32,19 @@
 #include "zj_synth.h"
 
 #define ZJNI_ERR(code) ((size_t)0 - (size_t)(code))
+
+// A/B and debug switches (ZJNI_*): read from the environment ONCE per process and kept — getenv() races with setenv() from other JVM threads, and the
+// per-buffer natives would otherwise pay ~30 lookups per call.  ZJNI_DEBUG_LIVE_SWITCHES=1 (set before the library loads; tests/conftest.py does) keeps
+// them live so a test can flip a switch between two calls.
+static const char* zj_env(const char* name) {
+    static bool const live = []() { const char* v = getenv("ZJNI_DEBUG_LIVE_SWITCHES"); return v && atoi(v) == 1; }();
+    if (live) return getenv(name);
+    static std::mutex m; static std::map<std::string, std::pair<bool, std::string> > cache;     // (map nodes never move: the returned pointers stay valid)
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find(name);
+    if (it == cache.end()) { const char* v = getenv(name); it = cache.emplace(name, std::make_pair(v != nullptr, std::string(v ? v : ""))).first; }
+    return it->second.first ? it->second.second.c_str() : nullptr;
+}
 
 // ============================================================================ kernels ==========
 // Next work item of a persistent workgroup: one device-scope atomic by lane 0, broadcast through
@@ -146,9 +161,9 @@ __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ s
 template <bool DICT>
 __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
-                                                          const u32* countPtr, u32* workCounter, const ZDMeta* metas, const u64* seqs, u8* scratch,
+                                                          const u32* countPtr, u32* workCounter, ZDMeta* metas, const u64* seqs, u8* scratch,
                                                           u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw,
-                                                          u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot) {
+                                                          u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot) {      // (metas: written by mode 3 only — the literal pass marks the frames it served)
     // mode 0: list entry k.  mode 1: the k-th frame the sequence-decode kernel finishes while this kernel runs beside it (bounded
     // wait; a workgroup that gives up leaves the rest to the mode-2 pass).  mode 2: list entries mode 1 did not get to.
     // mode 3: literals only (zd_lit_frame), beside the sequence decode, into slot k of litSlots (litSlot bytes each); the other modes
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
             if (k >= count) break;
             u32 const i = ZJ_UNI(list[k]);
             bool const ok = zd_lit_frame(g, sh, src + srcOff[i], metas + i, litSlots + (size_t)i * litSlot, litSlot, pf);
-            if (threadIdx.x == 0 && ok) const_cast<ZDMeta*>(metas)[i].pad = 1u;
+            if (threadIdx.x == 0 && ok) metas[i].pad = 1u;
             __syncthreads();
         }
         return;
@@ -879,12 +894,12 @@ DevState* get_state(int ordinal) {
         d.decGrid = d.numCU * perCU;
         {   int p2 = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, zj_decode_dict_kernel, 64, 0) != hipSuccess || p2 < 1) p2 = 4;
             d.decDictGrid = d.numCU * (p2 < perCU ? p2 : perCU); }
-        if (const char* ov = getenv("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
+        if (const char* ov = zj_env("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
         if (hipFuncSetAttribute((const void*)zj_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZJ_ENC_LDS_BIG) != hipSuccess) return nullptr;
         for (int lvl = 1; lvl <= 3; lvl++) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, enc_lds_pass0(lvl)) != hipSuccess || perCU < 1) perCU = 1;
             d.encGridLvl[lvl] = d.numCU * perCU;
-            if (const char* ov = getenv("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.encGridLvl[lvl] = d.numCU * v; }
+            if (const char* ov = zj_env("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.encGridLvl[lvl] = d.numCU * v; }
             if (d.encGridLvl[lvl] > d.encGrid) d.encGrid = d.encGridLvl[lvl];
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZJ_ENC_LDS_BIG) != hipSuccess || perCU < 1) perCU = 1;
@@ -899,7 +914,7 @@ DevState* get_state(int ordinal) {
         // a counter, so fewer waves than frames / 64 only means more frames per lane; the pipeline's time is flat from 1 to 2 waves per CU
         // (24.7-25.3 ms per 65 536 x 64 KiB) and the decode cells alive at a time shrink with the wave count: 1.5 waves per CU.
         d.dseqHeavy = d.numCU * 3 / 2;
-        if (const char* ov = getenv("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
+        if (const char* ov = zj_env("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
@@ -912,13 +927,13 @@ DevState* get_state(int ordinal) {
         if (hipStreamCreateWithFlags(&d.clearStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d.evMatchDone, hipEventDisableTiming) != hipSuccess
             || hipEventCreateWithFlags(&d.evCleared, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipFuncSetAttribute((const void*)zj_enc_match_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZWLds)) != hipSuccess) return nullptr;
-        {   int w = 3; if (const char* ov = getenv("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
+        {   int w = 3; if (const char* ov = zj_env("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
             d.waveGrid = d.numCU * w; }
         for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
         {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, 64); d.decStat = (volatile u32*)hp; } }
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
-        if (getenv("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
+        if (zj_env("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
         d.ordinal = ordinal;
     }
     return &d;
@@ -985,7 +1000,7 @@ bool ensure_staging(DevState* d, size_t bytes) {
 #define ZJ_HOST_SLICE ((u64)256 << 20)
 static int host_threads() {
     static int const t = []() {
-        if (const char* ov = getenv("ZJNI_HOST_THREADS")) { int const v = atoi(ov); return v < 1 ? 1 : (v > 64 ? 64 : v); }
+        if (const char* ov = zj_env("ZJNI_HOST_THREADS")) { int const v = atoi(ov); return v < 1 ? 1 : (v > 64 ? 64 : v); }
         long v = 16;
         cpu_set_t set; CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof(set), &set) == 0) { long const a = CPU_COUNT(&set); if (a >= 1 && a < v) v = a; }
@@ -994,7 +1009,7 @@ static int host_threads() {
             if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { long const c = (atol(q) + per - 1) / per; if (c >= 1 && c < v) v = c; }
             fclose(f);
         }
-        return (int)(v < 2 ? 2 : v);
+        return (int)(v < 1 ? 1 : v);
     }();
     return t;
 }
@@ -1204,7 +1219,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
     // Large batches: the three-stage pipeline (tANS decode lane-per-frame); whatever is not a simple frame, and
     // anything that fails on the way, ends on list B and goes through the fused kernel.  Small batches: fused only.
     size_t splitMin = 4096;
-    if (const char* ov = getenv("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
+    if (const char* ov = zj_env("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (n >= splitMin) {
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
         size_t const need = tabBytes + seqBytes + metaBytes + 4 * listBytes + 256;
@@ -1223,9 +1238,9 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
         // ZJNI_DEC_LIT=0 switches the pass off (A/B runs); ZJNI_DEC_LIT_BYTES sets the budget (default 4 GiB, nothing under a scratch limit).
         u8* litSlots = nullptr; u32 litSlot = 0;
-        {   int const litEnv = (getenv("ZJNI_DEC_LIT") && atoi(getenv("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
+        {   int const litEnv = (zj_env("ZJNI_DEC_LIT") && atoi(zj_env("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
             if (litEnv && !ddict && !g_scratch_limit) {
-                size_t budget = (size_t)4 << 30; if (const char* ov = getenv("ZJNI_DEC_LIT_BYTES")) budget = (size_t)atoll(ov);
+                size_t budget = (size_t)4 << 30; if (const char* ov = zj_env("ZJNI_DEC_LIT_BYTES")) { long long const v = atoll(ov); budget = v <= 0 ? 0 : ((unsigned long long)v > ((unsigned long long)64 << 30) ? (size_t)64 << 30 : (size_t)v); }
                 size_t slot = budget / n; if (slot > ZD_BLOCK_MAX) slot = ZD_BLOCK_MAX; slot &= ~(size_t)4095;
                 if (slot >= 16384) {
                     size_t const needL = n * slot + 64;
@@ -1237,7 +1252,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
                 }
             }
         }
-        static int const overlapEnv = getenv("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
+        static int const overlapEnv = zj_env("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
         // Running the execution kernel beside the sequence decode costs two cross-stream dependencies and an extra launch per slice
         // (~0.3 ms) — worth it only for frames with many sequences (zj_dec_heavy, decided on the device).  The host skips the set-up
         // when the last slice it has statistics for was light: the statistics arrive asynchronously and are never waited for, so a
@@ -1262,7 +1277,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         if (litSlots) {                                 // beside the sequence decode, ahead of the mode-1 execution pass on the same side stream
             hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, d->sideStream,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), c + 10, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), c + 10, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot);
         }
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
                            (const u64*)d_src_off, (const u32*)listA, (const u32*)(c + 8), c + 3, (const u16*)tabs, seqs, metas, ddDev,
@@ -1277,10 +1292,10 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
             u32* const work = pass == 2 ? c + 7 : c + 4;
             if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
             else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, (const ZDMeta*)metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
             if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) {
                 (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st);          // the side kernel must not outlive this call's claim on the scratch
                 return ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -1369,7 +1384,7 @@ unsigned zjni_getDictID_fromDDict(const zjni_ddict* dd) { return dd ? dd->dictID
 // The `checksum` argument of the advanced / dictionary entries is a flag word (include/zjni_amd.h ZJNI_FRAME_*): 1 alone is what it
 // always meant; the boolean entries (zjni_compress*2) normalise their argument before they get here.
 static inline void zj_dbg_sync(const char* what) {        // ZJNI_DEBUG_SYNC=1: drain the device after a launch and say so (finding the kernel that does not return)
-    static int const on = getenv("ZJNI_DEBUG_SYNC") ? 1 : 0;
+    static int const on = zj_env("ZJNI_DEBUG_SYNC") ? 1 : 0;
     if (!on) return;
     fprintf(stderr, "[zjni] waiting for %s ...", what); fflush(stderr);
     hipError_t const e = hipDeviceSynchronize();
@@ -1381,7 +1396,7 @@ static inline void zj_dbg_sync(const char* what) {        // ZJNI_DEBUG_SYNC=1: 
 // (18 KiB per workgroup) does not admit a third.  ZJNI_MULTI_PER_CU overrides.
 static bool ensure_multi_tables(DevState* d) {
     if (d->multiTables) return true;
-    int perCU = 8; if (const char* ov = getenv("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
+    int perCU = 8; if (const char* ov = zj_env("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
     int fit = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, zj_encode_multi_kernel, 64, sizeof(ZEEntropy)) == hipSuccess && fit >= 1 && fit < perCU) perCU = fit;
     d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
@@ -1415,8 +1430,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     // floor of ~96 ms per call), while a wave of the multi-block kernel parses the same frame in ~6 000 windows (zj_match_wavex.h: ~17 ms) —
     // so below ZJNI_L3_WAVE_MAX frames (default 8 192: four rounds of the 2 048 resident waves) every frame goes there, with the level's own tables or the caller's.
     // (ZJNI_SPLIT_MIN — "the lane pipelines from this batch size on" — is honoured: with it set the wave route ends there.)
-    size_t l3WaveMax = 8192; if (const char* ov = getenv("ZJNI_L3_WAVE_MAX")) l3WaveMax = (size_t)atoll(ov);
-    if (const char* ov = getenv("ZJNI_SPLIT_MIN")) { size_t const v = (size_t)atoll(ov); if (v < l3WaveMax) l3WaveMax = v; }
+    size_t l3WaveMax = 8192; if (const char* ov = zj_env("ZJNI_L3_WAVE_MAX")) l3WaveMax = (size_t)atoll(ov);
+    if (const char* ov = zj_env("ZJNI_SPLIT_MIN")) { size_t const v = (size_t)atoll(ov); if (v < l3WaveMax) l3WaveMax = v; }
     bool const l3wave = level == 3 && tuned && n < l3WaveMax && !g_scratch_limit;      // (tuned: table sizes beyond the LDS — the level's own 16 / 15 included; explicit 14 / 13 keeps the LDS matcher of small batches)
     if (l3wave) levelWord |= (int)ZE_LW_WAVE_ROUTE;
     u32 const ldsA = level > 3 ? 0u : (u32)enc_lds_pass0(level);
@@ -1426,17 +1441,17 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     // per lane slot, else one wave per frame (here)
     // (level 4 is double-fast: its frames above 16 KiB stay on list C, where the wave matcher of zj_match_wavex.h parses them — two waves per
     //  SIMD each on its own frame beat 256 waves of one-lane parses; ZJNI_L4_LANES=1 keeps the lane-slot route selectable for A/B runs)
-    bool const l4wave = level == 4 && !(getenv("ZJNI_L4_LANES") && atoi(getenv("ZJNI_L4_LANES")) == 1);
+    bool const l4wave = level == 4 && !(zj_env("ZJNI_L4_LANES") && atoi(zj_env("ZJNI_L4_LANES")) == 1);
     bool const bigLanes = level > 3 && !l4wave && n >= 4096 && (!g_scratch_limit || g_scratch_limit >= ((size_t)48 << 30));
     if (!bigLanes)
     {   // list C: multi-block frames (levels 1-3) and the single-block frames of levels 4-8 above 16 KiB.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 1 MiB per resident workgroup.
         if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
         // blocks of multi-block frames: the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
-        u32 multiSerial = 0; if (const char* ov = getenv("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
+        u32 multiSerial = 0; if (const char* ov = zj_env("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
         // levels 1-2 (fast strategy): the one-lane parse unless ZJNI_MULTI_WAVE_FAST=1 — the wave version (ZWaveF) is exact but measured slower there
         // (2 048 x 512 KiB at level 1: 156 ms against 138; one 64 KiB table per frame stays in the L2 / Infinity Cache and an iteration of the one-lane loop is one short trip)
-        {   const char* const ov = getenv("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
+        {   const char* const ov = zj_env("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
     }
@@ -1445,6 +1460,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         d->clearedValid = wasCleared;              // the lane pipeline's scratch was not touched: what the previous call promised about its tables still holds
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
+    // Everything below places something in splitBuf.  A clear the previous call queued on clearStream (24 GiB: 5-6 ms) may still be running — BatchOrder only
+    // chains `st` to `st` — so EVERY user of the buffer first orders itself behind it, not only the branch that skips its own memset (levels 4-8, the LDS matcher
+    // of small batches and a level 1-3 call with larger tables used to start under the running clear: records and table entries zeroed mid-parse).
+    if (wasCleared && hipStreamWaitEvent(st, d->evCleared, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     if (level > 3) {
         // list A of levels 4-8 (frames <= 16 KiB): chain parsers lane-per-frame, then the entropy kernel on their records
         u32 const maxSrcC = ZE_CHAIN_MAX_SRC;
@@ -1470,7 +1489,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (bigLanes) {
             // list C in slices of ZJ_BIG_SLICE frames: [table set per lane slot][records per frame of the slice][meta]
             size_t bigWaves = (size_t)d->numCU;           // measured at level 5, 65 536 x 64 KiB: 128 / 256 / 512 / 1 024 waves -> 3.69 / 1.95 / 2.44 / 2.74 s (1 MiB of table per lane slot: beyond one wave per CU the rows' random requests take over)
-            if (const char* ov = getenv("ZJNI_BIG_WAVES")) { long const v = atol(ov); if (v >= 1 && v <= 4096) bigWaves = (size_t)v; }
+            if (const char* ov = zj_env("ZJNI_BIG_WAVES")) { long const v = atol(ov); if (v >= 1 && v <= 4096) bigWaves = (size_t)v; }
             size_t const slots = bigWaves * 64, tablesB = slots * ZE_MULTI_TABLE_BYTES;
             size_t const fsB = (size_t)ZJ_BIG_SLICE * ZE_FRAME_STRIDE(ZE_BLOCK_MAX), needB = tablesB + fsB + (size_t)ZJ_BIG_SLICE * 12 + 256;
             if (d->wideBufCap < needB) {
@@ -1498,12 +1517,12 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     // Large batches: match finding goes lane-per-frame (64 frames per wave) ahead of the wave-per-frame
     // entropy stage; small batches keep the fused wave-per-frame kernel (lower latency, tables in LDS).
     size_t splitMin = 4096;
-    if (const char* ov = getenv("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
+    if (const char* ov = zj_env("ZJNI_SPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (tuned) splitMin = 1;                      // explicit table sizes exist only on the lane-per-frame path (tables in HBM)
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
     // Small level-3 batches: list A goes through the wave-per-frame matcher (tables in LDS, 64 positions per step) and the
     // entropy kernel instead of the fused kernel, whose match finder is one lane walking the frame (3-10x the latency).
-    bool const smallWave = n < splitMin && level == 3 && !tuned && getenv("ZJNI_NO_OVERLAP") == nullptr && getenv("ZJNI_NO_WAVE") == nullptr;
+    bool const smallWave = n < splitMin && level == 3 && !tuned && zj_env("ZJNI_NO_OVERLAP") == nullptr && zj_env("ZJNI_NO_WAVE") == nullptr;
     if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
@@ -1512,11 +1531,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // 1 = every frame, 0 = none.  64 KiB of flags per frame slot: left out under a scratch budget (zjni_set_scratch_limit) and when the device
         // cannot spare them; the machine then runs with every flag set.  ZJNI_LANE_MACHINE=0: the previous machine (ZLaneD), for A/B runs.
         u32 needMode = 2;
-        if (const char* ov = getenv("ZJNI_NEED")) needMode = (u32)atoi(ov);
-        bool const overlap = getenv("ZJNI_NO_OVERLAP") == nullptr;
-        bool const runMachine = level == 3 && !smallWave && getenv("ZJNI_HYBRID") == nullptr && !(getenv("ZJNI_LANE_MACHINE") && atoi(getenv("ZJNI_LANE_MACHINE")) == 0);
+        if (const char* ov = zj_env("ZJNI_NEED")) needMode = (u32)atoi(ov);
+        bool const overlap = zj_env("ZJNI_NO_OVERLAP") == nullptr;
+        bool const runMachine = level == 3 && !smallWave && zj_env("ZJNI_HYBRID") == nullptr && !(zj_env("ZJNI_LANE_MACHINE") && atoi(zj_env("ZJNI_LANE_MACHINE")) == 0);
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && getenv("ZJNI_HYBRID") == nullptr
+        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && zj_env("ZJNI_HYBRID") == nullptr
                         && overlap && hlN <= ZN_MAX_LOG_L && clN <= ZN_MAX_LOG_S;
         if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: no flags
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
@@ -1549,26 +1568,25 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // bound by their random requests) takes the match-dense part, the wave-per-frame kernel (tables in LDS) the rest.
         // Measured on the metric configuration it does not pay: the wave kernel needs the LDS the entropy kernel runs in,
         // and under the lane kernel's traffic it falls to half its stand-alone rate.
-        bool const hybrid = smallWave || (overlap && level == 3 && !tuned && getenv("ZJNI_HYBRID") != nullptr && getenv("ZJNI_NO_WAVE") == nullptr);
-        bool const waveOnly = smallWave || (hybrid && getenv("ZJNI_WAVE_ONLY") != nullptr);
+        bool const hybrid = smallWave || (overlap && level == 3 && !tuned && zj_env("ZJNI_HYBRID") != nullptr && zj_env("ZJNI_NO_WAVE") == nullptr);
+        bool const waveOnly = smallWave || (hybrid && zj_env("ZJNI_WAVE_ONLY") != nullptr);
         unsigned long long* const work2 = (unsigned long long*)(d->counters + 192);
         const u32* listM = listA;
         if (hybrid && hipMemsetAsync(work2, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);   // split = 0: the whole list is the wave kernel's
         if (hybrid && !waveOnly) {
             u32 const gs = (u32)(n < (size_t)d->numCU * 16 ? n : (size_t)d->numCU * 16);
             u32 threshold = 40;                       // text / JSON-like frames score 15-25, frames searched position by position 50+
-            if (const char* ov = getenv("ZJNI_WAVE_SCORE")) threshold = (u32)atoi(ov);
+            if (const char* ov = zj_env("ZJNI_WAVE_SCORE")) threshold = (u32)atoi(ov);
             u32 share = 150;                          // permille of the batch the wave kernel takes at most
-            if (const char* ov = getenv("ZJNI_WAVE_SHARE")) share = (u32)atoi(ov);
+            if (const char* ov = zj_env("ZJNI_WAVE_SHARE")) share = (u32)atoi(ov);
             hipLaunchKernelGGL(zj_enc_score_kernel, dim3(gs), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listA, (const u32*)ctr, score);
             hipLaunchKernelGGL(zj_enc_partition_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u32*)listA, (const u32*)ctr, (const u8*)score, threshold, share, work2, listS);
             hipLaunchKernelGGL(zj_enc_partition_done_kernel, dim3(1), dim3(1), 0, st, (const u32*)ctr, share, work2);
             listM = listS;
         }
-        static int const preclearEnv = (getenv("ZJNI_PRECLEAR") && atoi(getenv("ZJNI_PRECLEAR")) == 0) ? 0 : 1;
+        int const preclearEnv = (zj_env("ZJNI_PRECLEAR") && atoi(zj_env("ZJNI_PRECLEAR")) == 0) ? 0 : 1;
         if (tablesBytes) {
-            if (wasCleared && d->clearedPtr == tables && d->clearedBytes >= tablesBytes) {          // the previous call left them zero (or is about to)
-                if (hipStreamWaitEvent(st, d->evCleared, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (wasCleared && d->clearedPtr == tables && d->clearedBytes >= tablesBytes) {          // the previous call left them zero: `st` already waits for evCleared (above)
             } else if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         }
         // after this call's match kernels (recorded below, at tev[1]): the same range zeroed again for the next call
@@ -1581,7 +1599,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
         u32 gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
-        if (const char* ov = getenv("ZJNI_MATCH_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridM) gridM = v; }   // experiments: fewer resident waves, more frames per lane
+        if (const char* ov = zj_env("ZJNI_MATCH_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridM) gridM = v; }   // experiments: fewer resident waves, more frames per lane
         // with the sequences already found the entropy kernel only needs the entropy-stage LDS (more workgroups per CU)
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
@@ -1606,7 +1624,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
                 u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), getenv("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), zj_env("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                    (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr);
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
                 zj_dbg_sync("zj_enc_need_kernel");
@@ -1619,11 +1637,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machines (0 = the machine's own)
-            if (const char* ov = getenv("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
+            if (const char* ov = zj_env("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
             if (runMachine) {
                 void (*kern)(const u8*, const u64*, u32, const u32*, const u32*, u32*, u8*, u32, u8*, u32, u32*, u32*, u32*, u32, u32, const u8*, const u8*, const u32*) = zj_enc_match_run_kernel;
 #ifdef ZJ_TUNING_KERNELS
-                if (const char* ov = getenv("ZJNI_RUN_JMAX")) { int const j = atoi(ov); kern = j == 3 ? zj_enc_match_run3_kernel : j == 4 ? zj_enc_match_run4_kernel : j == 6 ? zj_enc_match_run6_kernel : j == 7 ? zj_enc_match_run7_kernel : zj_enc_match_run_kernel; }
+                if (const char* ov = zj_env("ZJNI_RUN_JMAX")) { int const j = atoi(ov); kern = j == 3 ? zj_enc_match_run3_kernel : j == 4 ? zj_enc_match_run4_kernel : j == 6 ? zj_enc_match_run6_kernel : j == 7 ? zj_enc_match_run7_kernel : zj_enc_match_run_kernel; }
 #endif
                 hipLaunchKernelGGL(kern, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                    listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap, (const u32*)needReady);
@@ -1646,7 +1664,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             preclear();
             // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
             // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
-            if (needGate && !getenv("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
+            if (needGate && !zj_env("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
@@ -1681,7 +1699,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // List B (frames > 64 KiB, fast-strategy frames with larger tables) through the same two stages, in slices that
         // share one scratch area sized for 4-byte positions and 128 KiB frames; a slice past the end of the list is empty.
         size_t sliceB = 65536;                       // as many lanes as the common path runs: 32 768 leaves half the wave slots empty (13.8 vs 18.5 GiB/s on 128 KiB frames)
-        if (const char* ov = getenv("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
+        if (const char* ov = zj_env("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
         sliceB = scratch_slice((size_t)ze_lane_table_stride((u32)levelWord, true) + ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC) + 12, sliceB, 2);   // half the budget: the common-case buffer of this call has the other half
         if (sliceB > n) sliceB = n;
         if (sliceB < 64) sliceB = 64;
@@ -1726,7 +1744,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
 static int zj_level3_word(int lw) {
     u32 const w = (u32)lw;
     if (ZE_LW_LEVEL(w) != 3u || (ZE_LW_HL(w) | ZE_LW_CL(w))) return lw;
-    static int const lds = (getenv("ZJNI_L3_TABLES") && !strcmp(getenv("ZJNI_L3_TABLES"), "lds")) ? 1 : 0;
+    static int const lds = (zj_env("ZJNI_L3_TABLES") && !strcmp(zj_env("ZJNI_L3_TABLES"), "lds")) ? 1 : 0;
     return lds ? lw : (int)(ZE_LW(3u, 16u, 15u) | ZE_LW_IMPLICIT | (w & ~0xFFFFFFu));
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -1823,7 +1841,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     u32 const flags = zj_frame_flags(checksum);
     size_t chunk = 2 * ZJ_CHUNK_FRAMES;            // 2 048 match waves = every SIMD's second wave slot as well: more table requests in flight (measured: +15 % over 65 536)
     chunk = scratch_slice((size_t)ZC_TABLE_STRIDE + 2 * ((size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC) + 12), chunk, 1);
-    if (const char* ov = getenv("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
+    if (const char* ov = zj_env("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
     size_t const slice = n < chunk ? n : chunk;
     size_t const fsBytes = slice * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = (slice * 12 + 255) & ~(size_t)255, tablesBytes = slice * (size_t)ZC_TABLE_STRIDE;
     size_t const need = tablesBytes + 2 * (fsBytes + metaBytes) + 256;
@@ -1982,17 +2000,22 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
             }
         }, gathering.load() ? (T + 1) / 2 : T);
     };
-    // the returning side runs on a thread of its own: slice k is handed to the caller as soon as it is back, whatever the enqueueing side is doing
-    std::atomic<size_t> enqueued(0); std::atomic<bool> failed(false);
-    std::thread returner([&]() {
+    // the returning side runs on a thread of its own: slice k is handed to the caller as soon as it is back, whatever the enqueueing side is doing.
+    // With one usable CPU (or when the thread cannot be created) the calling thread returns the slices itself after the last one is enqueued.
+    std::mutex qm; std::condition_variable qcv; size_t enqueued = 0; std::atomic<bool> failed(false);
+    auto return_slices = [&]() {
         (void)hipSetDevice(d->ordinal);
         for (size_t k = 0; k < nSlices; k++) {
-            while (enqueued.load(std::memory_order_acquire) <= k) { if (failed.load()) return; std::this_thread::yield(); }
+            {   std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&] { return enqueued > k || failed.load(); }); if (enqueued <= k) return; }
             if (hipEventSynchronize(d->pipeEv[3 * k + 2]) != hipSuccess) { failed.store(true); return; }
             scatter(cuts[k], cuts[k + 1]);
         }
-    });
-    struct Joiner { std::thread& t; std::atomic<bool>& f; bool ok = false; ~Joiner() { if (!ok) f.store(true); if (t.joinable()) t.join(); } } joiner{returner, failed};
+    };
+    std::thread returner;
+    if (T > 1) { try { returner = std::thread(return_slices); } catch (const std::system_error&) { /* no thread to be had: the serial path below */ } }
+    bool const threaded = returner.joinable();
+    struct Joiner { std::thread& t; std::atomic<bool>& f; std::mutex& m; std::condition_variable& cv; bool ok = false;
+                    ~Joiner() { if (!ok) { std::lock_guard<std::mutex> g(m); f.store(true); } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{returner, failed, qm, qcv};
     if (hipMemcpyAsync(d->dStage, d->hPinned, 2 * offBytes, hipMemcpyHostToDevice, d->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
     for (size_t k = 0; k < nSlices; k++) {
         size_t const lo = cuts[k], hi = cuts[k + 1];
@@ -2007,11 +2030,12 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
         if (hipMemcpyAsync(d->hPinned + oRes + lo * 8, d->dStage + oRes + lo * 8, (hi - lo) * 8, hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
         if (hd[hi] > hd[lo] && hipMemcpyAsync(hDst + hd[lo], d->dStage + oDst + hd[lo], (size_t)(hd[hi] - hd[lo]), hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
         if (hipEventRecord(evOut, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        enqueued.store(k + 1, std::memory_order_release);
+        {   std::lock_guard<std::mutex> g(qm); enqueued = k + 1; }
+        qcv.notify_all();
     }
     gathering.store(false);
     joiner.ok = true;
-    returner.join();
+    if (threaded) returner.join(); else return_slices();
     if (failed.load()) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
     return 0;
 }
