@@ -176,6 +176,7 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     // ZJNI_EMU_NEED=1: the need-gated double-fast machine behind zn_flags_frame (zj_need.h), as zj_enc_need_kernel + zj_enc_match_kernel run it
     u8* nflags = nullptr;
     {   ZEParams const p = ze_params_of(lw, srcSize);
+        if (level == 3 && wide && getenv("ZJNI_EMU_NEED") && getenv("ZJNI_EMU_NEED")[0] == '7') g_emu_run = 1;      // the wide launch (frames of 64-128 KiB): the run machine without flags
         if (level == 3 && !wide && getenv("ZJNI_EMU_NEED") && zn_takes(p.hashLog, p.chainLog, srcSize)) {
             struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
             ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));

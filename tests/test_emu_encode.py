@@ -179,6 +179,18 @@ def test_emu_need_gated_double_fast(emu, oracle_ref, zj, monkeypatch, mode):
             assert emu_compress(emu, d, 3, split=True, hash_log=hl, chain_log=cl) == oracle_ref.compress(d, 3, False, hl, cl), (len(d), hl, cl)
 
 
+def test_emu_wide_launch_on_the_run_machine(emu, oracle_ref, zj, monkeypatch):
+    """frames of 64-128 KiB (the wide launch, zj_enc_match_wide_kernel) run ZLaneR without flags since round 4 — register windows, no quiet runs:
+    the reference's bytes for sizes around both ends of the range, with the level's own and explicit table sizes"""
+    monkeypatch.setenv("ZJNI_EMU_NEED", "7")
+    rnd = random.Random(43)
+    datas = [zj.synth_host(131072, k, 1) for k in range(4)] + [zj.synth_host(s, 200 + s, 1) for s in (65537, 65544, 70000, 100000, 131071)]
+    datas += [bytes([9]) * 90000, bytes(rnd.getrandbits(8) for _ in range(70000)), (b"abcdefghij" * 13200)[:131000], (golden("xmlsmall") * 1300)[:131072]]
+    for d in datas:
+        assert emu_compress(emu, d, 3, split=True) == expected(oracle_ref, d, 3), len(d)
+        assert emu_compress(emu, d, 3, split=True, hash_log=15, chain_log=16) == oracle_ref.compress(d, 3, False, 15, 16), len(d)
+
+
 def test_need_flags_cover_the_exact_answer(emu, zj):
     """zj_need.h's contract, checked without the parse: a position whose key (long: its 8 bytes; short: its bucket and its first 4 bytes) some
     OTHER position of the frame shares must carry the NEED flag, and every position in the bucket of a NEED-flagged position must carry the INS

@@ -290,7 +290,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
 #ifdef ZL_PROFILE
     u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0;
 #endif
-    bool have = false, pend = false, late = false; u32 k = 0; u64 tPend = 0;
+    u32 have = 0, pend = 0, late = 0; u32 k = 0; u64 tPend = 0;          // (per-lane flags as 0 / 1 in vector registers: a loop-carried bool is a lane mask and every divergent assignment three scalar instructions)
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : M::default_period(); u32 ph = 0;   // double-fast machines: rounds per rotation of the non-search states
     for (u32 r = 0;; r++) {
         if (pend) {                                       // (machines that cannot take their flags late) a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
@@ -301,14 +301,14 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                 u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
                 m.init(src + s0, size, ze_params_of(level, size), tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc,
                        rdy ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
-                pend = false; have = true;
+                pend = 0u; have = 1u;
             }
         } else if (m.st == ZL_DONE) {
             if (have) {
-                u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = false;
+                u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = 0u;
                 zj_publish_done(doneList, doneCount, k);
             }
-            late = false;
+            late = 0u;
             if (work2) { if (!zj_claim_front(work2, k)) break; }
             else {
             k = atomicAdd(workCounter, 1u);
@@ -319,8 +319,8 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
             if (size < ZL_MIN_FRAME) { ze_match_lane_serial(src + s0, size, level, tb, fs, maxSrc, meta + 3 * (size_t)k); zj_publish_done(doneList, doneCount, k); continue; }
             bool const flagged = flagsBase && gate[k];
-            if (flagged && !M::takes_flags_late()) { pend = true; tPend = wall_clock64(); }
-            else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = true; late = flagged; }
+            if (flagged && !M::takes_flags_late()) { pend = 1u; tPend = wall_clock64(); }
+            else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = 1u; late = flagged ? 1u : 0u; }
         }
         // A frame whose flags are still being computed starts WITHOUT them and takes them over when they arrive (flags only ever remove work, and what
         // they say about a position does not depend on when it is asked): once per rotation the lane asks; the request travels with the round's own loads.
@@ -330,7 +330,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         zlRounds++;
 #endif
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
-        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * ZN_FLAG_STRIDE); late = false; }
+        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * ZN_FLAG_STRIDE); late = 0u; }
         ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
@@ -593,6 +593,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                                            u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
+    // level 3: ZLaneD.  The run machine without flags (zj_need.h's filters are sized for 64 KiB frames) was measured here in round 4 and is not faster on 128 KiB frames:
+    // 65 536 x 128 KiB 382-441 ms with ZLaneD, 445-492 ms with ZLaneR (profiles/r04/d_, e_); tests/test_emu_encode.py keeps the machine exact at these sizes.
     if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
     else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
 }

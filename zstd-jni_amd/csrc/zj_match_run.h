@@ -7,9 +7,9 @@
 // a lane read one round earlier come back from the fabric).  ZLaneD asks for the bytes at ip + 1 - off1 (repcode test), the word of the
 // position after next and a flag byte in every search round: for the search-dense class of frames that is two thirds of its requests.
 // Here a lane keeps
-//     A, B    the 16 source bytes at ip                       (one 8-byte refill per search round)
-//     RA, RB  the 16 bytes at ip - off1, the repcode stream    (one refill)
-//     FA, FB  the 16 flag bytes of ip .. ip + 15               (one refill, flagged frames only)
+//     A, B, C     the 16 .. 23 source bytes at ip                       (refilled 8 bytes at a time, only when fewer than 16 would be left: round 4)
+//     RA, RB, RC  the bytes at ip - off1, the repcode stream             (the same)
+//     FA, FB, FC  the flag bytes of ip ..                                (the same, flagged frames only)
 // and slides them as ip advances.  Everything a search round has to know before it can issue its loads is then in registers:
 //   * the repcode test of ip and of the positions behind it (bytes of A:B against RA:RB, four at a time);
 //   * with flags: how many positions behind ip are QUIET — no probe can match there (ZN_NEED_L / ZN_NEED_S clear) and the repcode test
@@ -60,6 +60,48 @@ ZJ_DEV u64 zr_ext(u64 lo, u64 hi, u32 s) {                                      
     return s >= 8u ? hi : v;
 }
 
+
+// Predicated global accesses without a divergent region (GPU): exec narrowed to the lanes that ask, ONE memory instruction, exec restored — three instructions
+// where `if (c) v = *p` compiles to a compare, s_and_saveexec, a skip branch, the access, s_or and the moves that merge the result.  The loaded value of a lane
+// that did not ask is undefined (nothing reads it: every consumer sits behind the same predicate).  The loads are invisible to the compiler's wait counting,
+// so the round waits for them itself, once, in ZR_WAIT (s_waitcnt vmcnt(0), with the results as operands so that no use can be scheduled above it).
+// The predicate of such an access is a LANE MASK (ZRM: an SGPR pair on the GPU, a bool in the lane-serial emulation) built from ballots of simple compares and
+// scalar and / or — a ballot of a composite bool makes the compiler materialise 0 / 1 in a VGPR and compare it again (two instructions per access).
+#if ZJ_ON_GPU
+typedef u64 ZRM;
+#define ZRM_OF(c) ((ZRM)__builtin_amdgcn_ballot_w64(c))        /* c: ONE compare */
+#define ZRM_NOT(m) (~(m))                                      /* (bits of inactive lanes do not matter: every use is ANDed with exec) */
+#define ZRM_NONE ((ZRM)0)
+#define ZRM_ANY(m) (((m) & __builtin_amdgcn_ballot_w64(true)) != 0)
+ZJ_DEV u64 zr_ld64_m(ZRM m, const u8* p) {
+    u64 v, sv;
+    asm volatile("s_and_saveexec_b64 %1, %2\n\tglobal_load_dwordx2 %0, %3, off\n\ts_mov_b64 exec, %1" : "=&v"(v), "=&s"(sv) : "s"(m), "v"(p) : "memory", "scc");
+    return v;
+}
+ZJ_DEV u32 zr_ld32_m(ZRM m, const u8* p) {
+    u32 v; u64 sv;
+    asm volatile("s_and_saveexec_b64 %1, %2\n\tglobal_load_dword %0, %3, off\n\ts_mov_b64 exec, %1" : "=&v"(v), "=&s"(sv) : "s"(m), "v"(p) : "memory", "scc");
+    return v;
+}
+ZJ_DEV void zr_st32_m(ZRM m, void* p, u32 v) {
+    u64 sv;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "s"(m), "v"(p), "v"(v) : "memory", "scc");
+}
+#define ZR_WAIT9(a, b, c, d, e, f, g, h, i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i) :: "memory")
+#define ZR_WAIT2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+typedef bool ZRM;
+#define ZRM_OF(c) ((bool)(c))
+#define ZRM_NOT(m) (!(m))
+#define ZRM_NONE false
+#define ZRM_ANY(m) (m)
+ZJ_DEV u64 zr_ld64_m(ZRM m, const u8* p) { return m ? ld64(p) : 0; }
+ZJ_DEV u32 zr_ld32_m(ZRM m, const u8* p) { return m ? ld32(p) : 0; }
+ZJ_DEV void zr_st32_m(ZRM m, void* p, u32 v) { if (m) *(u32*)p = v; }
+#define ZR_WAIT9(a, b, c, d, e, f, g, h, i) ((void)0)
+#define ZR_WAIT2(a, b) ((void)0)
+#endif
+
 template <class E, u32 JMAX = ZR_JMAX_DEFAULT>
 struct ZLaneR {
     typedef typename E::T Ent;
@@ -68,12 +110,13 @@ struct ZLaneR {
     ZEOut o;
     u32 st, cont, lastLL;
     u32 ip, ip1, anchor, off1, off2, step, nextStep, curr;
-    u64 A, B, RA, RB, FA, FB;                         // windows: source at ip, source at ip - off1, flags at ip (16 bytes each; valid in SEARCH)
+    u64 A, B, RA, RB, FA, FB;                         // windows: source at ip, source at ip - off1, flags at ip (valid in SEARCH)
+    u64 C, RC, FC; u32 vw;                            // their third words and the number of valid bytes (16 .. 23, the same for the three streams): LAZY refill, below
     u64 w1, wIns;                                     // once a match is found at ip: the word at ip1 (SHORT_L1's comparison), the word at curr + 2 (first post-insert)
     u32 el0, es0, el1, hl0, hs0, tl0, hl1, tl1, fN1, fIns;   // entries of ip as the reference reads them; ip1's long bucket / tag / flags (fin), flags of curr + 2
     u32 ca, cb, acc;                                  // forward count in progress
     u32 mpos, mpos2, mLength, offset, bk, bk2;
-    bool more, more2, cvalid, needBack, needCand, chk;
+    u32 more, more2, cvalid, needBack, needCand, chk;      // (0 / 1 in vector registers: a bool member lives as a lane mask and every divergent assignment is three scalar instructions)
 
     ZJ_DEV_MEMBER void init(const u8* s, u32 size, const ZEParams& p, u8* table, u8* fscratch, u32 maxSrc, const u8* flags = nullptr) {
         src = s; n = size; ilimit = size - 8u; hL = zl_hash_of(8, p.hashLog); hS = zl_hash_of(p.minMatch, p.chainLog);
@@ -82,14 +125,14 @@ struct ZLaneR {
         o.seqs = (ZESeq*)fscratch; o.litOff = (u32*)(fscratch + (size_t)ZE_FRAME_MAXSEQ(maxSrc) * 16u); o.n = 0; o.lit = 0;
         ip = 1; anchor = 0; off1 = 1; off2 = 0; chk = false; lastLL = size;
         needBack = needCand = more = more2 = cvalid = false;
-        A = B = RA = RB = 0; FA = FB = 0x0F0F0F0F0F0F0F0FULL;
+        A = B = RA = RB = 0; FA = FB = 0x0F0F0F0F0F0F0F0FULL; C = RC = FC = 0; vw = 16u;
         st = ZL_LOADW;
     }
     ZJ_DEV_MEMBER u32 prod_long(u64 v) const { return zl_prod_hi(hL, v); }
     ZJ_DEV_MEMBER u32 idx_long(u32 p) const { return p >> hL.rsh; }
     ZJ_DEV_MEMBER u32 tag_long(u32 p) const { return (p >> (hL.rsh - 15u)) & 0x7FFFu; }
-    ZJ_DEV_MEMBER void put_long_if(bool on, u64 v, u32 pos1) { if (on) { u32 const p = prod_long(v); ZR_TSTORE(&HL[idx_long(p)], E::make(pos1, tag_long(p))); } }
-    ZJ_DEV_MEMBER void put_short_if(bool on, u64 v, u32 pos1) { if (on) ZR_TSTORE(&HS[zl_hash(hS, v)], E::make(pos1, ze_tag4((u32)v))); }
+    ZJ_DEV_MEMBER void put_long_if(ZRM on, u64 v, u32 pos1) { u32 const p = prod_long(v); zr_st32_m(on, &HL[idx_long(p)], E::make(pos1, tag_long(p))); }
+    ZJ_DEV_MEMBER void put_short_if(ZRM on, u64 v, u32 pos1) { zr_st32_m(on, &HS[zl_hash(hS, v)], E::make(pos1, ze_tag4((u32)v))); }
     ZJ_DEV_MEMBER void finish() { lastLL = n - anchor; st = ZL_DONE; }
     ZJ_DEV_MEMBER void outer() {                      // outer-loop header of the reference: reset the step, make sure one more position fits
         step = 1; nextStep = ip + 256u; ip1 = ip + 1u;
@@ -113,172 +156,225 @@ struct ZLaneR {
     ZJ_DEVM bool takes_flags_late() { return true; }                 // flags may arrive while the frame is under way: every use of F tolerates "all set" before
     ZJ_DEV_MEMBER void take_flags(const u8* flags) { F = flags; }
     ZL_PROF_MEMBERS
-    ZJ_DEV_MEMBER void round(u32 r) {                 // see ZLaneD::round: search every round, the other states in turns
+    ZJ_DEV_MEMBER void round(u32 r) {                 // see ZLaneD::round: search every round, the other states in turns (r: wave-uniform)
+#ifdef ZR_ROUND_SWITCH                                /* four copies of the round, one per rotation slot (round 3's shape; A/B builds) */
         switch (r) {
-        case 0: round_t<ZL_EN_COUNT>(); break;
-        case 1: round_t<ZL_EN_POST>(); break;
-        case 2: round_t<ZL_EN_START>(); break;
-        default: round_t<0>(); break;
+        case 0: round_t<ZL_EN_COUNT>(ZL_EN_COUNT); break;
+        case 1: round_t<ZL_EN_POST>(ZL_EN_POST); break;
+        case 2: round_t<ZL_EN_START>(ZL_EN_START); break;
+        default: round_t<0>(0); break;
         }
-    }
-    template <int K>
-    ZJ_DEV_MEMBER void round_t() {
-        ZL_PROF_T0();
-        // load slots: s0 .. s4 source words (forward-clamped), sb0 / sb1 backward words, f0 (8 flag bytes) / f1 (4 flag bytes), t0 / t1 table entries
-        u32 pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, bp0 = 0, bp1 = 0, fa0 = 0, fa1 = 0, ti0 = 0, ti1 = 0;
-        bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, vb = false, vf0 = false, vf1 = false, vt0 = false, vt1 = false;
-        bool ml0 = false, ms0 = false, rep0 = false, far = false; u32 J = 0, adv = 0, fP = 0; u64 hw = 0;
-        bool const on = (st == ZL_SEARCH) || ((K & ZL_EN_COUNT) && (st == ZL_COUNT || st == ZL_BACK || st == ZL_SL1 || st == ZL_SL2))
-                     || ((K & ZL_EN_POST) && (st == ZL_POST || st == ZL_LOADW || st == ZL_FAR)) || ((K & ZL_EN_START) && st == ZL_START);
-        // ---- phase 1: what does this lane's state need (and the table writes that precede its reads) ----
-        if (st == ZL_SEARCH) {
-            ZE_COUNT_ITER();
-            curr = ip;
-            u32 const fI = (u32)FA & 15u, ts = ze_tag4((u32)A);
-            if (fI & 4u) ZR_TSTORE(&HL[hl0], E::make(ip + 1u, tl0));
-            if (fI & 8u) ZR_TSTORE(&HS[hs0], E::make(ip + 1u, ts));
-            ml0 = E::maybe(el0, tl0); ms0 = E::maybe(es0, ts);
-            pa2 = E::pos(el0) - 1u; v2 = ml0;
-            pa3 = E::pos(es0) - 1u; v3 = ms0;
-            // repcode tests of ip + j, j = 0 .. 7: bytes j + 1 .. j + 4 of the source window against the repcode window
-            u64 const y0 = zr_zero80(A ^ RA), y1 = zr_zero80(B ^ RB);
-            u64 H = zr_shr(y0, y1, 1) & zr_shr(y0, y1, 2) & zr_shr(y0, y1, 3) & zr_shr(y0, y1, 4);      // 0x80 in byte j: ip + j has a repcode match at ip + j + 1
-            if (off1 == 0u) H = 0;
-            rep0 = (H & 0x80u) != 0;
-            if (step == 1u) {
-                // quiet positions behind ip: no probe needed, no repcode match, still below nextStep and ilimit
-                u64 const NP = ~zr_zero80(FA & 0x0303030303030303ULL) & 0x8080808080808080ULL;                 // 0x80 in byte j: ip + j needs a probe
-                u64 const NQ = ((NP | H) >> 8) | (0x80ULL << 56);                                              // byte j - 1: ip + j is not quiet (j = 1 .. 7); a stop at j = 8
-                J = (u32)__builtin_ctzll(NQ) >> 3;
-                u32 const roomStep = nextStep - ip, lim0 = roomStep >= 2u ? roomStep - 2u : 0u, lim1 = ilimit - ip - 1u;      // ip + j + 1 < nextStep, ip + j + 1 <= ilimit
-                J = zj_min(zj_min(J, JMAX), zj_min(lim0, lim1));
-                adv = J + 1u;
-            } else adv = step;
-            far = adv > 8u;
-            if (!far) {
-                hw = zr_ext(A, B, adv); fP = (u32)zr_ext(FA, FB, adv) & 15u;     // the next position to decide, P = ip + adv: its word and flags
-                vt0 = (fP & 1u) != 0; vt1 = (fP & 2u) != 0;
-                pa0 = ip + 16u; v0 = true;                                        // window refills
-                pa1 = ip - off1 + 16u; v1 = true;
-                fa0 = ip + 16u; vf0 = F != nullptr;
-            }
-        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
-            pa0 = ca; pa1 = ca + 8u; pa2 = cb; pa3 = cb + 8u; v0 = v1 = v2 = v3 = true;
-            if (needBack) { vb = true; if (cont == ZC_SHORT_L1) { bp0 = ip1; bp1 = mpos2; } else { bp0 = ip; bp1 = mpos; } }
-            if (needCand) { v4 = true; pa4 = mpos2; }
-        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
-            vb = true; bp0 = ip - bk; bp1 = mpos - bk;
-        } else if ((K & ZL_EN_COUNT) && st == ZL_SL1) {
-            pa0 = ip1; v0 = true; fa1 = ip1; vf1 = F != nullptr;
-        } else if ((K & ZL_EN_COUNT) && st == ZL_SL2) {
-            hw = w1; vt0 = (fN1 & 1u) != 0;
-        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
-            pa1 = ip - 2u; pa2 = ip + 6u; v1 = v2 = true;
-            pa3 = ip - off2; v3 = off2 > 0u;
-            fa0 = ip; fa1 = ip - 2u; vf0 = vf1 = F != nullptr;
-        } else if ((K & ZL_EN_POST) && (st == ZL_LOADW || st == ZL_FAR)) {
-            pa0 = ip; v0 = true;
-            pa3 = ip - off2; v3 = st == ZL_LOADW && chk && off2 > 0u;
-            fa0 = ip; vf0 = F != nullptr;
-        } else if ((K & ZL_EN_START) && st == ZL_START) {
-            hw = A; u32 const fI = (u32)FA & 15u; vt0 = (fI & 1u) != 0; vt1 = (fI & 2u) != 0;
-            pa0 = ip + 8u; pa1 = ip - off1; pa2 = ip - off1 + 8u; v0 = v1 = v2 = true;
-            fa0 = ip + 8u; vf0 = F != nullptr;
-        }
-        // the hashes of the word whose table entries this round reads (search: P's; restart: ip's; SL2: ip1's)
-        u32 const hp = prod_long(hw), nhl = idx_long(hp), ntl = tag_long(hp), nhs = zl_hash(hS, hw);
-        ti0 = vt0 ? nhl : 0u; ti1 = vt1 ? nhs : 0u;
-        // ---- phase 2: one batch of loads for all states ----
-        ZL_PROF_T1();
-        pa0 = v0 ? pa0 : 0; pa1 = v1 ? pa1 : 0; pa2 = v2 ? pa2 : 0; pa3 = v3 ? pa3 : 0; pa4 = v4 ? pa4 : 0;
-        fa0 = vf0 ? fa0 : 0; fa1 = vf1 ? fa1 : 0;
-        if (!vb) { bp0 = 8; bp1 = 8; }
-        u32 const q0 = zl_fwd_at(n, pa0), q1 = zl_fwd_at(n, pa1), q2 = zl_fwd_at(n, pa2), q3 = zl_fwd_at(n, pa3), q4 = zl_fwd_at(n, pa4);
-        u32 const qf0 = zl_fwd_at(n, fa0), qf1 = zl_fwd_at(n, fa1);
-        u32 const qb0 = zl_back_at(bp0), qb1 = zl_back_at(bp1);
-        u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rb0 = 0, rb1 = 0, rf0 = 0; u32 rf1 = 0, t0 = 0, t1 = 0;
-#ifdef ZR_COUNT_SLOT                                          /* analysis builds: which load slots a frame activates (tools, never the product) */
-        ZR_COUNT_SLOT(0, v0); ZR_COUNT_SLOT(1, v1); ZR_COUNT_SLOT(2, v2); ZR_COUNT_SLOT(3, v3); ZR_COUNT_SLOT(4, (K & ZL_EN_COUNT) && v4); ZR_COUNT_SLOT(5, (K & ZL_EN_COUNT) && vb);
-        ZR_COUNT_SLOT(6, vf0); ZR_COUNT_SLOT(7, (K & (ZL_EN_COUNT | ZL_EN_POST)) && vf1); ZR_COUNT_SLOT(8, vt0); ZR_COUNT_SLOT(9, vt1);
+#else
+        // ONE body for every rotation slot, the slot's states behind wave-uniform branches: four specialised copies cost ~35 register moves per round
+        // where their register assignments meet again at the loop's back edge, and four times the instruction-cache footprint
+        round_t<-1>(r == 0u ? (u32)ZL_EN_COUNT : (r == 1u ? (u32)ZL_EN_POST : (r == 2u ? (u32)ZL_EN_START : 0u)));
 #endif
-        if (v0) r0 = ld64(src + q0);
-        if (v1) r1 = ld64(src + q1);
-        if (v2) r2 = ld64(src + q2);
-        if (v3) r3 = ld64(src + q3);
-        if (vt0) t0 = (u32)ZR_TLOAD(&HL[ti0]);
-        if (vt1) t1 = (u32)ZR_TLOAD(&HS[ti1]);
-        if (vf0) rf0 = ld64(F + qf0);
-        if ((K & (ZL_EN_COUNT | ZL_EN_POST)) && vf1) rf1 = ld32(F + qf1);
-        if ((K & ZL_EN_COUNT) && v4) r4 = ld64(src + q4);
-        if ((K & ZL_EN_COUNT) && vb) { rb0 = ld64(src + qb0); rb1 = ld64(src + qb1); }
-        ZL_ROUND_FENCE9(r0, r1, r2, r3, r4, rb0, rb1, t0, t1);
-        ZL_ROUND_FENCE2(rf0, rf1);
+    }
+    // One round, written flat (round 4).  The round of round 3 was ~1 220 wave-instructions (SQ counters: 784 VALU + 413 SALU + 21 VMEM), a third of
+    // them exec-mask bookkeeping: every `if (v) r = ld64(..)` was a divergent region of its own, every per-state `if / else if` merged a dozen booleans
+    // as lane masks (three SALU operations each), and at one wave per SIMD a scalar instruction costs its issue slot like a vector one.  Here
+    //   * what a state asks for is worked out by selects, for every lane, without regions (a lane in another state computes garbage that no mask lets out);
+    //   * every load and store is ONE predicated instruction — exec narrowed to the lanes that ask (zr_ld64_m / zr_st32_m: s_and_saveexec, the access,
+    //     exec back) — and the round's single wait sits in the fence;
+    //   * the clamp-and-fix arithmetic of frame-edge loads runs only in the rounds where some lane of the wave is within 8 bytes of an edge (ZR_ANY);
+    //   * each state's consume step is one flat region, and the sequence record is written at one place for every kind of match.
+    // States, loads, decisions and their order are round 3's (and the reference's): tests/test_emu_encode.py, tools/fuzz_emu_need.py.
+    template <int KT>
+    ZJ_DEV_MEMBER void round_t(u32 const KU) {
+        u32 const K = KT >= 0 ? (u32)KT : KU;          // (compile-time in the switch build, a scalar otherwise)
+        ZL_PROF_T0();
+        u32 const s = st;
+        bool const kC = (K & ZL_EN_COUNT) != 0u, kP = (K & ZL_EN_POST) != 0u, kT = (K & ZL_EN_START) != 0u;    // (wave-uniform: which states this rotation slot serves)
+        bool const isS = s == ZL_SEARCH;
+        bool const isC = kC && s == ZL_COUNT, isB = kC && s == ZL_BACK, isL1 = kC && s == ZL_SL1, isL2 = kC && s == ZL_SL2;
+        bool const isP = kP && s == ZL_POST, isW = kP && s == ZL_LOADW, isF = kP && s == ZL_FAR;
+        bool const isT = kT && s == ZL_START;
+        bool const hasF = F != nullptr;
+        ZRM const MS = ZRM_OF(s == ZL_SEARCH), MHASF = ZRM_OF(F != nullptr);
+        u32 const nm8 = n - 8u;
+        // ---- phase 1: the search state's view of ip (every lane computes it; only searching lanes act on it) ----
+        u32 const fI = (u32)FA & 15u, ts = ze_tag4((u32)A);
+        if (isS) { ZE_COUNT_ITER(); curr = ip; }
+        zr_st32_m(MS & ZRM_OF((fI & 4u) != 0u), &HL[hl0], E::make(ip + 1u, tl0));
+        zr_st32_m(MS & ZRM_OF((fI & 8u) != 0u), &HS[hs0], E::make(ip + 1u, ts));
+        bool const ml0 = isS && E::maybe(el0, tl0), ms0 = isS && E::maybe(es0, ts);
+        ZRM const ML0 = MS & ZRM_OF((el0 & 0x1FFFFu) != 0u) & ZRM_OF((el0 >> 17) == tl0), MS0 = MS & ZRM_OF((es0 & 0x1FFFFu) != 0u) & ZRM_OF((es0 >> 17) == ts);   // (E::maybe as masks)
+        u32 const cl = E::pos(el0) - 1u, cs = E::pos(es0) - 1u;
+        // repcode tests of ip + j, j = 0 .. 7: bytes j + 1 .. j + 4 of the source window against the repcode window
+        u64 const y0 = zr_zero80(A ^ RA), y1 = zr_zero80(B ^ RB);
+        u64 H = zr_shr(y0, y1, 1) & zr_shr(y0, y1, 2) & zr_shr(y0, y1, 3) & zr_shr(y0, y1, 4);          // 0x80 in byte j: ip + j has a repcode match at ip + j + 1
+        H = off1 == 0u ? 0 : H;
+        bool const rep0 = ((u32)H & 0x80u) != 0u;
+        // quiet positions behind ip (step 1 only): no probe needed, no repcode match, still below nextStep and ilimit
+        u64 const NP = ~zr_zero80(FA & 0x0303030303030303ULL) & 0x8080808080808080ULL;                     // 0x80 in byte j: ip + j needs a probe
+        u64 const NQ = ((NP | H) >> 8) | (0x80ULL << 56);                                                  // byte j - 1: ip + j is not quiet (j = 1 .. 7); a stop at j = 8
+        u32 const roomStep = nextStep - ip, lim0 = roomStep >= 2u ? roomStep - 2u : 0u, lim1 = ilimit - ip - 1u;
+        u32 const Jq = zj_min(zj_min((u32)__builtin_ctzll(NQ) >> 3, JMAX), zj_min(lim0, lim1));
+        u32 const J = step == 1u ? Jq : 0u, adv = step == 1u ? Jq + 1u : step;
+        bool const far = adv > 8u;
+        ZRM const MSN = MS & ZRM_OF(adv <= 8u);
+        u64 const hwS = zr_ext(A, B, adv); u32 const fP = (u32)zr_ext(FA, FB, adv) & 15u;                  // the next position to decide, P = ip + adv: its word and flags (adv <= 8)
+        // ---- what each state asks for: the word whose table entries are read, addresses, masks ----
+        u64 hw = hwS; u32 fT = fP;
+        ZRM MT0 = MSN, MT1 = MSN;                                   // lanes that read a long / short table entry this round (if the flags of the position say so)
+        u32 const ro = ip - off1;
+        // LAZY REFILL (round 4): the windows hold vw = 16 .. 23 valid bytes and a searching lane asks for the next 8 bytes of its three streams only when
+        // fewer than 16 would be left after this round's advance — one request per 8 bytes of progress instead of one per round (a text frame advances one
+        // byte per search round: 3 stream requests per round became 3 per 8 rounds; the kernel's time follows its request count, profiles/r04/c_slopes.txt).
+        // The next unread byte of a stream sits vw bytes behind its window's start whatever the advance will be.
+        u32 const vwn = vw - adv;                                   // valid bytes after the advance
+        ZRM const MREF = MSN & ZRM_OF(vwn < 16u);
+        u32 pa0 = ip + vw, pa1 = ro + vw, pa2 = cl, pa3 = cs, fa0 = ip + vw, fa1 = ip - 2u, bp0 = ip - bk, bp1 = mpos - bk;
+        u32 hi = ip + vw;                                           // the highest forward address the lane's state reads (frame-edge test below)
+        ZRM m0 = MREF, m1 = MREF, m2 = ML0, m3 = MS0, m4 = ZRM_NONE, mb = ZRM_NONE, mf0 = MREF, mf1 = ZRM_NONE, mOn = MREF;
+        bool const second = cont == ZC_SHORT_L1;
+        if (kC) {
+            ZRM const MC = ZRM_OF(s == ZL_COUNT), MB = ZRM_OF(s == ZL_BACK), ML1 = ZRM_OF(s == ZL_SL1), ML2 = ZRM_OF(s == ZL_SL2);
+            hw = isL2 ? w1 : hw; fT = isL2 ? fN1 : fT; MT0 = MT0 | ML2;
+            pa0 = isC ? ca : (isL1 ? ip1 : pa0); m0 = m0 | MC | ML1;
+            pa1 = isC ? ca + 8u : pa1; m1 = m1 | MC;
+            pa2 = isC ? cb : pa2; m2 = m2 | MC;
+            pa3 = isC ? cb + 8u : pa3; m3 = m3 | MC;
+            m4 = MC & ZRM_OF(needCand);
+            bp0 = isC ? (second ? ip1 : ip) : bp0; bp1 = isC ? (second ? mpos2 : mpos) : bp1; mb = (MC & ZRM_OF(needBack)) | MB;
+            fa1 = isL1 ? ip1 : fa1; mf1 = ML1;
+            hi = isC ? ca + 8u : hi; mOn = mOn | MC;
+        }
+        if (kP) {
+            bool const wf = isW || isF;
+            ZRM const MP = ZRM_OF(s == ZL_POST), MW = ZRM_OF(s == ZL_LOADW), MWF = MW | ZRM_OF(s == ZL_FAR);
+            pa0 = wf ? ip : pa0; m0 = m0 | MWF;
+            pa1 = isP ? ip - 2u : pa1; m1 = m1 | MP;
+            pa2 = isP ? ip + 6u : pa2; m2 = m2 | MP;
+            pa3 = (isP || isW) ? ip - off2 : pa3; m3 = m3 | ((MP | (MW & ZRM_OF(chk))) & ZRM_OF(off2 > 0u));
+            fa0 = (isP || wf) ? ip : fa0; mf0 = mf0 | MP | MWF;
+            mf1 = MP;
+            hi = (isP || wf) ? ip + 6u : hi; mOn = mOn | MP | MWF;
+        }
+        if (kT) {
+            ZRM const MT = ZRM_OF(s == ZL_START);
+            hw = isT ? A : hw; fT = isT ? fI : fT; MT0 = MT0 | MT; MT1 = MT1 | MT;
+            pa0 = isT ? ip + 8u : pa0; m0 = m0 | MT;
+            pa1 = isT ? ro : pa1; m1 = m1 | MT;
+            pa2 = isT ? ro + 8u : pa2; m2 = m2 | MT;
+            fa0 = isT ? ip + 8u : fa0; mf0 = mf0 | MT;
+            hi = isT ? ip + 8u : hi; mOn = mOn | MT;
+        }
+        u32 const hp = prod_long(hw), nhl = idx_long(hp), ntl = tag_long(hp), nhs = zl_hash(hS, hw);
+        bool const vt0 = (fT & 1u) != 0u, vt1 = (fT & 2u) != 0u;                                          // (meaningful for the lanes of MT0 / MT1 only)
+        MT0 = MT0 & ZRM_OF((fT & 1u) != 0u); MT1 = MT1 & ZRM_OF((fT & 2u) != 0u);
+        mf0 = mf0 & MHASF; mf1 = mf1 & MHASF;
+#ifdef ZR_COUNT_SLOT                                          /* analysis builds: which load slots a frame activates (tools, never the product) */
+        ZR_COUNT_SLOT(0, m0); ZR_COUNT_SLOT(1, m1); ZR_COUNT_SLOT(2, m2); ZR_COUNT_SLOT(3, m3); ZR_COUNT_SLOT(4, m4); ZR_COUNT_SLOT(5, mb);
+        ZR_COUNT_SLOT(6, mf0); ZR_COUNT_SLOT(7, mf1); ZR_COUNT_SLOT(8, MT0); ZR_COUNT_SLOT(9, MT1);
+#endif
+        // ---- phase 2: one batch of predicated loads ----
+        ZL_PROF_T1();
+        u32 const q0 = zj_min(pa0, nm8), q1 = zj_min(pa1, nm8), q2 = zj_min(pa2, nm8), q3 = zj_min(pa3, nm8), q4 = zj_min(mpos2, nm8), qf0 = zj_min(fa0, nm8);
+        u32 const qb0 = bp0 >= 8u ? bp0 - 8u : 0u, qb1 = bp1 >= 8u ? bp1 - 8u : 0u;
+        u64 d0 = zr_ld64_m(m0, src + q0), d1 = zr_ld64_m(m1, src + q1), d2 = zr_ld64_m(m2, src + q2), d3 = zr_ld64_m(m3, src + q3);
+        u32 t0 = zr_ld32_m(MT0, (const u8*)&HL[nhl]), t1 = zr_ld32_m(MT1, (const u8*)&HS[nhs]);
+        u64 g0 = zr_ld64_m(mf0, F + qf0);
+        u32 g1 = 0; u64 d4 = 0, b0 = 0, b1 = 0;
+        if (kC || kP) g1 = zr_ld32_m(mf1, F + fa1);                                                        // (fa1 + 4 <= n - 4: never clamped)
+        if (kC) { d4 = zr_ld64_m(m4, src + q4); b0 = zr_ld64_m(mb, src + qb0); b1 = zr_ld64_m(mb, src + qb1); }
+#ifdef ZR_EXTRA_LOADS                                         /* measurement builds only: N extra stream-like requests per search round (new lines, results unused) — the slope of the kernel time over the request count */
+        u64 x0 = zr_ld64_m(m0, src + zj_min(q0 ^ 0x2000u, nm8)), x1 = 0, x2 = 0;
+        if (ZR_EXTRA_LOADS > 1) x1 = zr_ld64_m(m1, src + zj_min(q1 ^ 0x4000u, nm8));
+        if (ZR_EXTRA_LOADS > 2) x2 = zr_ld64_m(m0, src + zj_min(q0 ^ 0x6000u, nm8));
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+#endif
+        ZR_WAIT9(d0, d1, d2, d3, d4, b0, b1, t0, t1);
+        ZR_WAIT2(g0, g1);
+#ifdef ZR_EXTRA_LOADS
+        asm volatile("" :: "v"(x0), "v"(x1), "v"(x2));
+#endif
         ZL_PROF_T2();
-        u64 const d0 = zl_fwd_fix(r0, pa0, q0), d1 = zl_fwd_fix(r1, pa1, q1), d2 = zl_fwd_fix(r2, pa2, q2), d3 = zl_fwd_fix(r3, pa3, q3);
-        u64 const d4 = zl_fwd_fix(r4, pa4, q4);
-        u64 const b0 = zl_back_fix(rb0, bp0, qb0), b1 = zl_back_fix(rb1, bp1, qb1);
-        u64 const g0 = F ? zl_fwd_fix(rf0, fa0, qf0) : 0x0F0F0F0F0F0F0F0FULL;                                   // 8 flag bytes at fa0 (a frame without flags: all set)
-        u32 const g1 = F ? (u32)zl_fwd_fix((u64)rf1, fa1, qf1) : 0x0F0F0F0Fu;                                   // 4 flag bytes at fa1 (never clamped: fa1 + 4 <= n)
-        if (!on) return;
+#ifdef ZR_EXTRA_VALU                                          /* measurement builds only: N dependent vector instructions per round — the slope of the kernel time over the instruction count */
+        {   u32 zx = ip; asm volatile(".rept %1\n\tv_add_u32 %0, %0, 1\n\t.endr" : "+v"(zx) : "n"(ZR_EXTRA_VALU)); asm volatile("" :: "v"(zx)); }
+#endif
+        // A load that was clamped at the frame's end (or start) is shifted into place — only in rounds where some lane of the wave is that close to an edge:
+        // `hi` is the highest forward address the lane's state reads (candidates and repcode sources lie below ip), a backward load is clamped below 8.
+        if (ZRM_ANY(mOn & ZRM_OF(hi > nm8))) {
+            if (pa0 > nm8) d0 = zl_fwd_fix(d0, pa0, q0);
+            if (pa1 > nm8) d1 = zl_fwd_fix(d1, pa1, q1);
+            if (pa2 > nm8) d2 = zl_fwd_fix(d2, pa2, q2);
+            if (pa3 > nm8) d3 = zl_fwd_fix(d3, pa3, q3);
+            if (fa0 > nm8) g0 = zl_fwd_fix(g0, fa0, qf0);
+        }
+        if (kC) {
+            if (ZRM_ANY(mb & (ZRM_OF(bp0 < 8u) | ZRM_OF(bp1 < 8u)))) { b0 = zl_back_fix(b0, bp0, qb0); b1 = zl_back_fix(b1, bp1, qb1); }
+        }
+        if (!hasF) { g0 = 0x0F0F0F0F0F0F0F0FULL; g1 = 0x0F0F0F0Fu; }                                       // a frame without flags: all set
         // ---- phase 3: consume ----
-        if (st == ZL_SEARCH) {
-            bool const near1 = !far && (J == 0u);                  // P is the reference's ip1 (ip + step): its long entry, bucket and tag are this round's
-            if (rep0) {
-                leave_search();
-                begin_count(ip + 5u, ip + 5u - off1, ZC_REP1); needBack = false; needCand = false;
-            } else if ((ml0 && d2 == A) || (ms0 && (u32)d3 == (u32)A)) {
-                bool const isLong = ml0 && d2 == A;
-                leave_search();
-                ip1 = ip + step;
-                if (near1) { w1 = hw; hl1 = nhl; tl1 = ntl; fN1 = fP; el1 = vt0 ? t0 : 0u; }
-                else if (!far) { w1 = zr_ext(A, B, 1u); u32 const p1 = prod_long(w1); hl1 = idx_long(p1); tl1 = tag_long(p1); fN1 = (u32)(FA >> 8) & 15u; el1 = 0; }   // ip + 1 is quiet: its probe cannot match
-                if (isLong) {
-                    mpos = E::pos(el0) - 1u;
-                    begin_count(ip + 8u, mpos + 8u, ZC_LONG); needBack = true; needCand = false;
-                    if (far) fN1 = 0;                               // (step > 8: fin() writes nothing for ip1)
-                } else {
-                    mpos = E::pos(es0) - 1u;
-                    if (far) st = ZL_SL1;                           // ip1's word, flags and long entry are not here: two more states fetch them
-                    else {
-                        begin_count(ip + 4u, mpos + 4u, ZC_SHORT); needBack = true;
-                        needCand = (E::pos(el1) > 1u) && E::maybe(el1, tl1); mpos2 = E::pos(el1) - 1u; cvalid = false;
-                    }
+        u32 emit = 0; u32 eLL = 0, eOff = 0, eML = 0;                                                 // the sequence this round completes, if any (stored once, below)
+        u32 doFin = 0, doLoop = 0;                                                                // a long / short match became final (COUNT or BACK); an immediate repcode match was counted
+        if (isS) {
+            bool const isLong = ml0 && d2 == A, isShort = !isLong && ms0 && (u32)d3 == (u32)A;
+            bool const found = rep0 || isLong || isShort;
+            bool const near1 = !far && J == 0u;                        // P is the reference's ip1 (ip + step): its long entry, bucket and tag are this round's
+            if (found) {
+                wIns = zr_ext(A, B, 2u); fIns = (u32)(FA >> 16) & 15u;                                     // (leave_search)
+                if (!rep0) {
+                    ip1 = ip + step;
+                    if (near1) { w1 = hw; hl1 = nhl; tl1 = ntl; fN1 = fP; el1 = vt0 ? t0 : 0u; }
+                    else if (!far) { w1 = zr_ext(A, B, 1u); u32 const p1 = prod_long(w1); hl1 = idx_long(p1); tl1 = tag_long(p1); fN1 = (u32)(FA >> 8) & 15u; el1 = 0; }   // ip + 1 is quiet: its probe cannot match
+                    mpos = isLong ? cl : cs;
+                    if (isLong && far) fN1 = 0;                          // (step > 8: fin() writes nothing for ip1)
                 }
+                u32 const skip = rep0 ? 5u : (isLong ? 8u : 4u);
+                ca = ip + skip; cb = (rep0 ? ro : mpos) + skip; acc = 0;
+                cont = rep0 ? ZC_REP1 : (isLong ? ZC_LONG : ZC_SHORT);
+                needBack = !rep0;
+                bool const shortNear = isShort && !rep0 && !far;
+                needCand = shortNear && (E::pos(el1) > 1u) && E::maybe(el1, tl1);
+                if (shortNear) { mpos2 = E::pos(el1) - 1u; cvalid = false; }
+                st = (isShort && !rep0 && far) ? (u32)ZL_SL1 : (u32)ZL_COUNT;      // (far short match: ip1's word, flags and long entry are not here — two more states fetch them)
             } else if (far) {
                 // no match, and the next position is out of the windows' reach: reload there
                 if (ip + step >= nextStep) { step++; nextStep += 256u; ip += step - 1u; } else ip += step;
                 if (ip + step > ilimit) finish(); else st = ZL_FAR;
             } else {
                 // no match at ip: commit the quiet run behind it, move to P with the entries this round fetched
-                u32 e0 = t0, e1 = t1;
+                u32 e0 = vt0 ? t0 : 0u, e1 = vt1 ? t1 : 0u;
 ZR_UNROLL
                 for (u32 j = 1; j <= JMAX; j++) {
                     if (!ZR_ANY(j <= J)) break;               // (wave-uniform: no lane's run is this long)
-                    if (j <= J) {
-                        u64 const wq = zr_shr(A, B, j); u32 const fq = (u32)(FA >> (8u * j));
-                        if (fq & 4u) { u32 const p = prod_long(wq), b = idx_long(p); Ent const e = E::make(ip + j + 1u, tag_long(p)); ZR_TSTORE(&HL[b], e); if (b == nhl) e0 = (u32)e; }
-                        if (fq & 8u) { u32 const b = zl_hash(hS, wq); Ent const e = E::make(ip + j + 1u, ze_tag4((u32)wq)); ZR_TSTORE(&HS[b], e); if (b == nhs) e1 = (u32)e; }
-                    }
+                    bool const inRun = j <= J;
+                    u64 const wq = zr_shr(A, B, j); u32 const fq = (u32)(FA >> (8u * j));
+                    u32 const pq = prod_long(wq), bl = idx_long(pq), bs = zl_hash(hS, wq);
+                    u32 const eL = (u32)E::make(ip + j + 1u, tag_long(pq)), eS = (u32)E::make(ip + j + 1u, ze_tag4((u32)wq));
+                    bool const wL = inRun && (fq & 4u) != 0u, wS = inRun && (fq & 8u) != 0u;
+                    ZRM const RUN = ZRM_OF(j <= J);
+                    zr_st32_m(RUN & ZRM_OF((fq & 4u) != 0u), &HL[bl], eL); zr_st32_m(RUN & ZRM_OF((fq & 8u) != 0u), &HS[bs], eS);
+                    e0 = (wL && bl == nhl && vt0) ? eL : e0; e1 = (wS && bs == nhs && vt1) ? eS : e1;          // a write into the bucket this round already asked for is forwarded
                 }
-                if (!vt0) e0 = 0;
-                if (!vt1) e1 = 0;
                 if (ip + step >= nextStep) { step++; nextStep += 256u; }       // (only ever with J == 0)
                 ip += adv;
-                A = zr_ext(A, B, adv); B = zr_ext(B, d0, adv);
-                RA = zr_ext(RA, RB, adv); RB = zr_ext(RB, d1, adv);
-                FA = zr_ext(FA, FB, adv); FB = zr_ext(FB, g0, adv);
+                // slide the three windows by adv bytes (bytes beyond the valid ones are zero and stay zero), then put the 8 bytes that were asked for behind them
+                {   bool const ref = vwn < 16u; u32 const k8 = (vwn & 7u) * 8u;                     // (refill: vwn = 8 .. 15, the new bytes land at byte vwn)
+                    u64 const sC = adv >= 8u ? 0 : (C >> (8u * adv)), sRC = adv >= 8u ? 0 : (RC >> (8u * adv)), sFC = adv >= 8u ? 0 : (FC >> (8u * adv));
+                    A = zr_ext(A, B, adv); B = zr_ext(B, C, adv);
+                    RA = zr_ext(RA, RB, adv); RB = zr_ext(RB, RC, adv);
+                    FA = zr_ext(FA, FB, adv); FB = zr_ext(FB, FC, adv);
+                    u64 const hiSh = (64u - k8) & 63u;
+                    B = ref ? (B | (d0 << k8)) : B; C = ref ? (k8 ? (d0 >> hiSh) : 0) : sC;
+                    RB = ref ? (RB | (d1 << k8)) : RB; RC = ref ? (k8 ? (d1 >> hiSh) : 0) : sRC;
+                    FB = ref ? (FB | (g0 << k8)) : FB; FC = ref ? (k8 ? (g0 >> hiSh) : 0) : sFC;
+                    vw = ref ? vwn + 8u : vwn;
+                }
                 el0 = e0; es0 = e1; hl0 = nhl; hs0 = nhs; tl0 = ntl;
                 if (ip + step > ilimit) finish();
             }
-        } else if ((K & ZL_EN_COUNT) && st == ZL_COUNT) {
+        }
+        if ((K & ZL_EN_COUNT) && isC) {
             u32 const lim = n - ca;
             u32 c = zl_common_fwd16(d0, d1, d2, d3);
-            if (c > lim) c = lim;
+            c = zj_min(c, lim);
             acc += c;
             if (needBack) {
-                bool const second = (cont == ZC_SHORT_L1);
                 u32 const limit = second ? zj_min(ip1 - anchor, mpos2) : zj_min(ip - anchor, mpos);
-                u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+                u32 const e = zj_min(zl_common_back8(b0, b1), limit);
                 bool const m = (e == 8u) && (limit > 8u);
                 if (second) { bk2 = e; more2 = m; } else { bk = e; more = m; }
                 needBack = false;
@@ -287,60 +383,75 @@ ZR_UNROLL
             if (c == 16u && lim > 16u) { ca += 16u; cb += 16u; }
             else if (cont == ZC_REP1) {
                 mLength = acc + 4u; ip += 1u;
-                ze_store(o, anchor, ip - anchor, 1u, mLength);
-                advance();
-            } else if (cont == ZC_LONG) {
-                mLength = acc + 8u; offset = ip - mpos; fin_or_back();
-            } else if (cont == ZC_SHORT) {
+                emit = 1u; eLL = ip - anchor; eOff = 1u; eML = mLength;
+            } else if (cont == ZC_SHORT && cvalid) {
                 mLength = acc + 4u; offset = ip - mpos;
-                if (cvalid) { begin_count(ip1 + 8u, mpos2 + 8u, ZC_SHORT_L1); needBack = true; }
-                else fin_or_back();
-            } else if (cont == ZC_SHORT_L1) {
-                u32 const l1len = acc + 8u;
-                if (l1len > mLength) { ip = ip1; mLength = l1len; mpos = mpos2; offset = ip - mpos; bk = bk2; more = more2; }
-                fin_or_back();
-            } else {                                   // ZC_REPLOOP: immediate repcode after a match (A = the word at ip, FA = its flags)
+                ca = ip1 + 8u; cb = mpos2 + 8u; acc = 0; cont = ZC_SHORT_L1; needBack = true;
+            } else if (cont == ZC_REPLOOP) {                   // immediate repcode after a match (A = the word at ip, FA = its flags)
                 u32 const rLength = acc + 4u;
                 { u32 const t = off2; off2 = off1; off1 = t; }
-                put_short_if(((u32)FA & 8u) != 0, A, ip + 1u);
-                put_long_if(((u32)FA & 4u) != 0, A, ip + 1u);
-                ze_store(o, anchor, 0u, 1u, rLength);
-                ip += rLength; anchor = ip;
-                if (ip <= ilimit) { chk = true; st = ZL_LOADW; } else finish();
+                put_short_if(ZRM_OF(((u32)FA & 8u) != 0u), A, ip + 1u);
+                put_long_if(ZRM_OF(((u32)FA & 4u) != 0u), A, ip + 1u);
+                emit = 1u; doLoop = 1u; eLL = 0u; eOff = 1u; eML = rLength;
+            } else {
+                if (cont == ZC_LONG) { mLength = acc + 8u; offset = ip - mpos; }
+                else if (cont == ZC_SHORT) { mLength = acc + 4u; offset = ip - mpos; }
+                else {                                         // ZC_SHORT_L1: the long match at ip1 against the short one at ip
+                    u32 const l1len = acc + 8u;
+                    if (l1len > mLength) { ip = ip1; mLength = l1len; mpos = mpos2; offset = ip - mpos; bk = bk2; more = more2; }
+                }
+                if (more) st = ZL_BACK; else doFin = 1u;
             }
-        } else if ((K & ZL_EN_COUNT) && st == ZL_BACK) {
+        }
+        if ((K & ZL_EN_COUNT) && isB) {
             u32 const limit = zj_min(ip - anchor, mpos) - bk;
-            u32 e = zl_common_back8(b0, b1); if (e > limit) e = limit;
+            u32 const e = zj_min(zl_common_back8(b0, b1), limit);
             bk += e; more = (e == 8u) && (limit > 8u);
-            if (!more) fin();
-        } else if ((K & ZL_EN_COUNT) && st == ZL_SL1) {
-            w1 = d0; fN1 = g1 & 15u; st = ZL_SL2;
-        } else if ((K & ZL_EN_COUNT) && st == ZL_SL2) {
+            doFin = more ? 0u : 1u;
+        }
+        if ((K & ZL_EN_COUNT) && isL1) { w1 = d0; fN1 = g1 & 15u; st = ZL_SL2; }
+        if ((K & ZL_EN_COUNT) && isL2) {
             el1 = vt0 ? t0 : 0u; hl1 = nhl; tl1 = ntl;            // (read after ip's own writes, as the reference reads it)
-            begin_count(ip + 4u, mpos + 4u, ZC_SHORT); needBack = true;
+            ca = ip + 4u; cb = mpos + 4u; acc = 0; cont = ZC_SHORT; st = ZL_COUNT; needBack = true;
             needCand = (E::pos(el1) > 1u) && E::maybe(el1, tl1); mpos2 = E::pos(el1) - 1u; cvalid = false;
-        } else if ((K & ZL_EN_POST) && st == ZL_POST) {
+        }
+        if (K & ZL_EN_COUNT) {
+            if (doFin) {                                       // a long / short match is final: apply the backward extension (fin)
+                ip -= bk; mLength += bk;
+                off2 = off1; off1 = offset;
+                zr_st32_m(ZRM_OF(step < 4u) & ZRM_OF((fN1 & 4u) != 0u), &HL[hl1], E::make(ip1 + 1u, tl1));      // (ip1: the position that was ip1 when the match was found)
+                emit = 1u; eLL = ip - anchor; eOff = offset + 3u; eML = mLength;
+            }
+            if (emit) {
+                ze_store(o, anchor, eLL, eOff, eML);
+                ip += eML; anchor = ip;
+                if (ip <= ilimit) { chk = chk | doLoop; st = doLoop ? (u32)ZL_LOADW : (u32)ZL_POST; }
+                else finish();
+            }
+        }
+        if ((K & ZL_EN_POST) && isP) {
             u64 const q0w = d1, q1w = d2;
             u64 const wb = q0w, wc = (q0w >> 8) | (q1w << 56);
             u32 const ins = curr + 2u;
             // fIns = flags of curr + 2, g1 = flags of ip - 2, ip - 1, ip, ip + 1 (one byte each)
-            put_long_if((fIns & 4u) != 0, wIns, ins + 1u);
-            put_long_if((g1 & 4u) != 0, wb, ip - 2u + 1u);
-            put_short_if((fIns & 8u) != 0, wIns, ins + 1u);
-            put_short_if((g1 & 0x800u) != 0, wc, ip - 1u + 1u);
+            put_long_if(ZRM_OF((fIns & 4u) != 0u), wIns, ins + 1u);
+            put_long_if(ZRM_OF((g1 & 4u) != 0u), wb, ip - 2u + 1u);
+            put_short_if(ZRM_OF((fIns & 8u) != 0u), wIns, ins + 1u);
+            put_short_if(ZRM_OF((g1 & 0x800u) != 0u), wc, ip - 1u + 1u);
             A = (q0w >> 16) | (q1w << 48); FA = g0;
-            if ((off2 > 0u) && ((u32)A == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
+            if ((off2 > 0u) && ((u32)A == (u32)d3)) { ca = ip + 4u; cb = ip + 4u - off2; acc = 0; cont = ZC_REPLOOP; st = ZL_COUNT; needBack = false; needCand = false; }
             else outer();
-        } else if ((K & ZL_EN_POST) && st == ZL_LOADW) {
+        }
+        if ((K & ZL_EN_POST) && isW) {
             A = d0; FA = g0;
-            if (chk && (off2 > 0u) && ((u32)A == (u32)d3)) { begin_count(ip + 4u, ip + 4u - off2, ZC_REPLOOP); needBack = false; needCand = false; }
+            if (chk && (off2 > 0u) && ((u32)A == (u32)d3)) { ca = ip + 4u; cb = ip + 4u - off2; acc = 0; cont = ZC_REPLOOP; st = ZL_COUNT; needBack = false; needCand = false; }
             else outer();
             chk = false;
-        } else if ((K & ZL_EN_POST) && st == ZL_FAR) {
-            A = d0; FA = g0; st = ZL_START;
-        } else if ((K & ZL_EN_START) && st == ZL_START) {
+        }
+        if ((K & ZL_EN_POST) && isF) { A = d0; FA = g0; st = ZL_START; }
+        if ((K & ZL_EN_START) && isT) {
             el0 = vt0 ? t0 : 0u; es0 = vt1 ? t1 : 0u; hl0 = nhl; hs0 = nhs; tl0 = ntl;
-            B = d0; RA = d1; RB = d2; FB = g0;
+            B = d0; RA = d1; RB = d2; FB = g0; C = RC = FC = 0; vw = 16u;
             st = ZL_SEARCH;
         }
     }
