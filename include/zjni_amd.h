@@ -133,6 +133,28 @@ size_t zjni_compress_batch_advanced(const void* const* src, const size_t* srcSiz
                                     void* const* dst, const size_t* dstCapacity,
                                     size_t* result, size_t n, int level, int checksum, int hashLog, int chainLog);
 
+/* ---- stream frames: ZstdDirectBufferCompressingStream[NoFinalizer] / ZstdOutputStream[NoFinalizer] ----
+ * Replaces ZSTD_compressStream / ZSTD_flushStream / ZSTD_endStream as the stream natives call them
+ * (N/jni_directbuffercompress_zstd.c:97-161: compressDirectByteBuffer, flushStream, endStream; N/jni_outputstream_zstd.c) for a stream that is
+ * BUFFERED UNTIL IT IS CLOSED, at most the level's unknown-size window (levels 1 / 2 / 3: 512 KiB / 1 MiB / 2 MiB): the frame ZSTD_compressStream2
+ * produces without a pledged size, byte for byte (N/compress/zstd_compress.c:6103-6300, :4591-4692) — the level's default parameter row whatever
+ * the total, no content size in the header, the input cut into the stream's 128 KiB pieces, blocks ended where the caller flushed, the empty raw
+ * last block, the checksum.  flushAt[0 .. nFlush): ascending byte counts after which the caller flushed.  final_ = 0: flushed, not closed — returns the
+ * frame's beginning up to the last flush (the bytes a later call with more input reproduces and continues).  knownEmpty: the stream was closed before
+ * any other call (its size, 0, is then known: single-segment header).  201 above the window, 42 above level 3: the bundled library's stream.
+ * The device form takes n streams: stream i = blob[off[i], off[i + 1]), its flush positions d_flush_at[d_flush_off[i] .. d_flush_off[i + 1]) (d_flush_off may be
+ * NULL: none), d_mode[i] = final | knownEmpty << 1 (NULL: all final). */
+/* ZSTD_findFrameCompressedSize + ZSTD_getFrameContentSize + ZSTD_decompressBound for one complete zstd frame at src (N/zstd.h:227-290;
+ * N/decompress/zstd_decompress.c:739-850) — what the decompress-stream natives (N/jni_directbufferdecompress_zstd.c:58-79) need to know before they can hand a
+ * whole frame to zjni_decompress instead of feeding ZSTD_decompressStream: returns the frame's size in bytes (0: src does not hold a complete well-formed zstd
+ * frame), *content = the recorded content size or ~0, *bound = an upper bound of the decoded size. */
+size_t zjni_frame_extent(const void* src, size_t srcSize, unsigned long long* content, unsigned long long* bound);
+size_t zjni_compress_stream(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksum,
+                            const uint32_t* flushAt, size_t nFlush, int final_, int knownEmpty);
+size_t zjni_compress_stream_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
+                                         uint64_t* d_result, size_t n, int level, int checksum,
+                                         const uint32_t* d_flush_at, const uint64_t* d_flush_off, const uint32_t* d_mode, void* stream);
+
 /* ---- compression dictionaries ----
  * zjni_cdict == ZSTD_CDict as zstd-jni holds it in ZstdDictCompress.nativePtr (J/ZstdDictCompress.java;
  * N/jni_fast_zstd.c:18-66: init = ZSTD_createCDict(dict, size, level), free = ZSTD_freeCDict).  The dictionary is

@@ -255,49 +255,13 @@ extern "C" unsigned long long emu_compress_stream_flush(const unsigned char* src
 static unsigned long long emu_compress_stream_f(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, unsigned level, const unsigned* flushAt, unsigned nFlush) {
     EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
-    u32 const flags = (level >> 8) & ZE_FLAG_MASK; level &= 0xFFu;
+    // test encoding of `level`: level | frame flags << 8 | 0x10000: not final (flushed, not closed) | 0x20000: closed before anything else was called (known-empty) | 0x40000: the one-lane block parses
+    u32 const flags = ((level >> 8) & ZE_FLAG_MASK) | ((level & 0x40000u) ? (ZE_FLAG_MULTI_SERIAL | ZE_FLAG_MULTI_FAST_SERIAL) : 0u);
+    u32 const final = (level & 0x10000u) ? 0u : 1u, knownEmpty = (level & 0x20000u) ? 1u : 0u; level &= 0xFFu;
     EmuWg& wg = emu_wg(); ZEncShared& sh = *wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
-    u32 const wlogUnknown = level == 1 ? 19u : (level == 2 ? 20u : 21u);
-    if (srcSize > (1u << wlogUnknown) || level < 1 || level > 3) return ZJ_ERR64(201);
-    // totals up to 256 KiB: the stream still runs the level's default row (window 21 / 20 / 19 and its table sizes), which the one-shot parameters of such a size
-    // are not — the block arguments then name a parameter size above 256 KiB and the blocks take the one-lane parse (the wave matcher clamps its loads by that size)
-    u32 const paramSize = srcSize > (256u << 10) ? srcSize : (256u << 10) + 1u;
-    ZEParams const p = ze_params_of(level, paramSize);
     u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
-    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
-    st32(dst, 0xFD2FB528u); dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((wlogUnknown - 10u) << 3);
-    if (srcSize == 0) { dst[4] = (u8)(0x20u + (tail ? 4u : 0u)); dst[5] = 0; }      // nothing was ever written: the first call is ZSTD_e_end, the size (0) is known — single segment, one-byte content size
-    sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0;
-    u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
-    for (u32 i = 0; i < entries; i++) tables[i] = 0;
     ZjProf pf; pf.start(nullptr);
-    u32 pos = 6, isFirst = 1; u64 r = 0; bool lastSeen = false;
-    u32 fi = 0;
-    for (u32 chunk = 0, seg = 0; chunk < srcSize && r <= ZJ_ERR64(256); ) {
-        while (fi < nFlush && flushAt[fi] <= seg) fi++;                                                            // (flushes with nothing buffered)
-        bool const haveFlush = fi < nFlush && flushAt[fi] <= srcSize;
-        u32 const segEnd = haveFlush ? flushAt[fi] : srcSize;                                                      // the next flush() (or the end of what was written)
-        u32 const chunkEnd = chunk + 131072u < segEnd ? chunk + 131072u : segEnd;
-        bool const flushed = haveFlush && chunkEnd == segEnd;                                                      // this piece ends where the caller flushed
-        bool const endChunk = chunkEnd == srcSize && (chunkEnd - chunk) != 131072u && !flushed;                    // still buffered at ZSTD_e_end: the last frame chunk
-        i64 savings = (i64)chunk - (i64)pos;                                                // consumedSrcSize - producedCSize, the header's bytes included
-        for (u32 at = chunk; at < chunkEnd; ) {
-            u32 const blockSize = zp_block_size(src + at, chunkEnd - at, p.strategy, savings, (u32*)lds);
-            ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = paramSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (endChunk && at + blockSize == chunkEnd) ? 1u : 0u; ba.tables = tables; ba.serialParse = paramSize != srcSize ? 1u : 0u;
-            r = ze_compress_t<Grp<1>, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, 160u * 1024u, &ba);
-            if (r > ZJ_ERR64(256)) break;
-            lastSeen = ba.lastBlock != 0;
-            savings += (i64)blockSize - (i64)r;
-            at += blockSize; pos += (u32)r; isFirst = 0;
-        }
-        chunk = chunkEnd; if (chunkEnd == segEnd) seg = segEnd;
-    }
-    u64 out = r;
-    if (r <= ZJ_ERR64(256)) {
-        if (!lastSeen) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; pos += 3; }       // ZSTD_writeEpilogue: empty raw last block
-        if (tail) { u64 const h = zj_xxh64(g, src, srcSize); st32(dst + pos, (u32)h); pos += 4; }
-        out = pos;
-    }
+    u64 const out = ze_compress_stream(g, sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u, flushAt, nFlush, final, knownEmpty);
     free(tables);
     return out;
 }

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
+typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; jint consumed, produced; int borrowed; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
 static Obj* mk(int kind, jsize len) { Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = kind; o->len = len; o->data = (char*)calloc((size_t)len + 16, kind == 4 ? 8 : 1); return o; }
 
 static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return (b && ((Obj*)b)->kind == 1) ? ((Obj*)b)->data : NULL; }
@@ -24,7 +24,10 @@ static void JNICALL f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize
 static jobject JNICALL f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (void)e; return (jobject)((Obj*)a)->elems[i]; }
 static void JNICALL f_SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const jlong* buf) { (void)e; memcpy(((Obj*)a)->data + 8 * (size_t)s, buf, 8 * (size_t)l); }
 static jclass JNICALL f_GetObjectClass(JNIEnv* e, jobject o) { (void)e; return (jclass)o; }
-static jfieldID JNICALL f_GetFieldID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)sig; return strcmp(n, "nativePtr") ? NULL : (jfieldID)(intptr_t)1; }
+static jfieldID JNICALL f_GetFieldID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)sig; return !strcmp(n, "nativePtr") ? (jfieldID)(intptr_t)1 : (!strcmp(n, "consumed") ? (jfieldID)(intptr_t)2 : (!strcmp(n, "produced") ? (jfieldID)(intptr_t)3 : NULL)); }
+static jint JNICALL f_GetIntField(JNIEnv* e, jobject o, jfieldID f) { (void)e; return (intptr_t)f == 2 ? ((Obj*)o)->consumed : ((Obj*)o)->produced; }
+static void JNICALL f_SetIntField(JNIEnv* e, jobject o, jfieldID f, jint v) { (void)e; if ((intptr_t)f == 2) ((Obj*)o)->consumed = v; else ((Obj*)o)->produced = v; }
+static jobject JNICALL f_NewDirectByteBuffer(JNIEnv* e, void* addr, jlong cap) { (void)e; Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = 1; o->len = (jsize)cap; o->data = (char*)addr; o->borrowed = 1; return (jobject)o; }
 static jlong JNICALL f_GetLongField(JNIEnv* e, jobject o, jfieldID f) { (void)e; (void)f; return ((Obj*)o)->field; }
 static void JNICALL f_SetLongField(JNIEnv* e, jobject o, jfieldID f, jlong v) { (void)e; (void)f; ((Obj*)o)->field = v; }
 static jstring JNICALL f_NewStringUTF(JNIEnv* e, const char* s) { (void)e; Obj* o = mk(5, (jsize)strlen(s) + 1); strcpy(o->data, s); return (jstring)o; }
@@ -47,7 +50,7 @@ static JNIEnv* env(void) {
     g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
     g_fn.GetByteArrayElements = f_GetByteArrayElements; g_fn.ReleaseByteArrayElements = f_ReleaseByteArrayElements;
     g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef;
-    g_fn.ExceptionCheck = f_ExceptionCheck;
+    g_fn.ExceptionCheck = f_ExceptionCheck; g_fn.GetIntField = f_GetIntField; g_fn.SetIntField = f_SetIntField; g_fn.NewDirectByteBuffer = f_NewDirectByteBuffer;
     g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField;
     return (JNIEnv*)&g_envp;
 }
@@ -504,6 +507,77 @@ int main(int argc, char** argv) {
                 }
             }
             R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
+        }
+    }
+    /* ---- the DirectByteBuffer stream classes (N/jni_directbuffercompress_zstd.c, jni_directbufferdecompress_zstd.c): the same writes, flushes and close on
+     * both libraries, whatever room the caller's target buffer has — the bytes that come out must be the same bytes; then the frames through both decompress streams */
+    if (!getenv("HARNESS_SKIP_STREAMS")) {
+        typedef jlong (*create_fn)(JNIEnv*, jclass); typedef jlong (*free_fn)(JNIEnv*, jclass, jlong); typedef jlong (*init_fn)(JNIEnv*, jobject, jlong, jint);
+        typedef jlong (*comp_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint, jobject, jint, jint); typedef jlong (*end_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint);
+        typedef jlong (*dinit_fn)(JNIEnv*, jobject, jlong);
+        struct { create_fn create; free_fn free_; init_fn init; comp_fn comp; end_fn flush, end; create_fn dcreate; free_fn dfree; dinit_fn dinit; comp_fn dstream; } S[2];
+        Lib* libs[2] = {&R, &G};
+        jsize const totals[] = {0, 1, 100, 5000, 70000, 131072, 200000, 300000, 600000, 2097152, 2200000};
+        int const streamMax = getenv("HARNESS_STREAM_MAX") ? atoi(getenv("HARNESS_STREAM_MAX")) : (1 << 30);     /* the GPU-only leg has no bundled stream to outgrow into */
+        STAGE("DirectByteBuffer streams");
+        for (int k = 0; k < 2; k++) {
+#define SS(field, name) *(void**)&S[k].field = dlsym(libs[k]->h, P "ZstdDirectBufferCompressingStreamNoFinalizer_" name)
+            SS(create, "createCStream"); SS(free_, "freeCStream"); SS(init, "initCStream"); SS(comp, "compressDirectByteBuffer"); SS(flush, "flushStream"); SS(end, "endStream");
+#undef SS
+#define SS(field, name) *(void**)&S[k].field = dlsym(libs[k]->h, P "ZstdDirectBufferDecompressingStreamNoFinalizer_" name)
+            SS(dcreate, "createDStreamNative"); SS(dfree, "freeDStreamNative"); SS(dinit, "initDStreamNative"); SS(dstream, "decompressStreamNative");
+#undef SS
+            CHECK(S[k].create && S[k].free_ && S[k].init && S[k].comp && S[k].flush && S[k].end && S[k].dcreate && S[k].dfree && S[k].dinit && S[k].dstream, "stream natives of library %d", k);
+        }
+        for (unsigned ti = 0; ti < sizeof totals / sizeof *totals; ti++) for (int variant = 0; variant < 4; variant++) {
+            jsize const total = totals[ti];
+            jint const level = 1 + (jint)((ti + (unsigned)variant) % 3u);
+            jsize const chunk = variant == 0 ? 50000 : (variant == 1 ? 131072 : (variant == 2 ? 7000 : 300000));
+            int const flushEvery = variant == 2 ? 3 : (variant == 3 ? 1 : 0);
+            jsize const room = variant == 1 ? 900 : (1 << 22);                       /* a target buffer far too small: the natives must say how much is pending */
+            if ((long long)total > (1ll << (18 + level)) && total > streamMax) continue;
+            Obj* src = mk(1, total > 0 ? total : 1); fill(src->data, total, (int)(ti % 3u));
+            char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                Obj* self = mk(7, 0); Obj* dst = mk(1, room);
+                jlong const h = S[k].create(e, NULL); jlong r = S[k].init(e, (jobject)self, h, level);
+                size_t cap = (size_t)total + (size_t)total / 64 + (1u << 16); char* out = (char*)malloc(cap); size_t n = 0; int calls = 0;
+                if (r < 0) worst[k] = r;
+                for (jsize at = 0; at < total && worst[k] == 0; ) {
+                    jsize const len = total - at < chunk ? total - at : chunk; jsize done = 0; int guard = 0;
+                    while (done < len && guard++ < 100000) {
+                        self->consumed = self->produced = 0;
+                        r = S[k].comp(e, (jobject)self, h, (jobject)dst, 0, room, (jobject)src, at + done, len - done);
+                        if (r < 0) { worst[k] = r; break; }
+                        memcpy(out + n, dst->data, (size_t)self->produced); n += (size_t)self->produced; done += self->consumed;
+                    }
+                    at += len; calls++;
+                    if (flushEvery && calls % flushEvery == 0 && worst[k] == 0) {
+                        int guard2 = 0;
+                        do { self->produced = 0; r = S[k].flush(e, (jobject)self, h, (jobject)dst, 0, room); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->produced); n += (size_t)self->produced; } while (r > 0 && guard2++ < 100000);
+                    }
+                }
+                if (worst[k] == 0) { int guard3 = 0; do { self->produced = 0; r = S[k].end(e, (jobject)self, h, (jobject)dst, 0, room); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->produced); n += (size_t)self->produced; } while (r > 0 && guard3++ < 100000); }
+                S[k].free_(e, NULL, h);
+                outs[k] = out; lens[k] = n;
+            }
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "stream of %d bytes, level %d, writes of %d, flush every %d, room %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                  (int)total, (int)level, (int)chunk, flushEvery, (int)room, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+            /* the frame back through both decompress streams: whole frame in the source buffer, room for all of it */
+            if (worst[0] == 0 && variant != 1) {
+                Obj* fr = mk(1, (jsize)lens[0] + 1); memcpy(fr->data, outs[0], lens[0]);
+                for (int k = 0; k < 2; k++) {
+                    Obj* self = mk(7, 0); Obj* back = mk(1, total + 64);
+                    jlong const h = S[k].dcreate(e, NULL); jlong r = S[k].dinit(e, (jobject)self, h);
+                    jsize got = 0, used = 0; int guard = 0;
+                    do { self->consumed = self->produced = 0;
+                         r = S[k].dstream(e, (jobject)self, h, (jobject)back, got, total + 64 - got, (jobject)fr, used, (jsize)lens[0] - used);
+                         got += self->produced; used += self->consumed; } while (r > 0 && guard++ < 1000);
+                    CHECK(r == 0 && got == total && used == (jsize)lens[0] && !memcmp(back->data, src->data, (size_t)total), "decompress stream (library %d) of the %d-byte stream frame: ret %lld, %d bytes out, %d consumed", k, (int)total, (long long)r, (int)got, (int)used);
+                    S[k].dfree(e, NULL, h);
+                }
+            }
+            free(outs[0]); free(outs[1]);
         }
     }
     /* batch natives refuse what the per-buffer natives refuse: a null or non-direct element is an error code, not a crash */

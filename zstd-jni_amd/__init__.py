@@ -170,6 +170,12 @@ def lib():
     L.zjni_route_kernel.restype = C.c_char_p
     L.zjni_route_kernel.argtypes = [C.c_int]
     L.zjni_build_stamp.restype = C.c_char_p
+    L.zjni_frame_extent.restype = sz
+    L.zjni_frame_extent.argtypes = [vp, sz, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.zjni_compress_stream.restype = sz
+    L.zjni_compress_stream.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, vp, sz, C.c_int, C.c_int]
+    L.zjni_compress_stream_batch_device.restype = sz
+    L.zjni_compress_stream_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -187,7 +193,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
            "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
-           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp")
+           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent")
 
 
 # --------------------------------------------------------------------------- Java API mirror --
@@ -566,6 +572,25 @@ def compress_batch(buffers, level=3, checksum=False, dictionary=None, hash_log=0
     `capacities` = the destination sizes (default Zstd.compressBound of each buffer, what Zstd.compress(src) allocates)."""
     caps = [Zstd.compressBound(len(b)) for b in buffers] if capacities is None else list(capacities)
     return _host_batch(buffers, caps, True, level, checksum, dictionary, hash_log, chain_log)
+
+
+def compress_stream(data, level=3, checksum=False, flush_at=(), final=True, known_empty=None):
+    """The frame com.github.luben.zstd.ZstdDirectBufferCompressingStream / ZstdOutputStream produce for `data` written without a pledged size
+    (ZSTD_compressStream2; N/jni_directbuffercompress_zstd.c:97-161), through zjni_compress_stream: `flush_at` = byte counts after which flush() was
+    called; final=False: flushed but not closed (the frame's beginning up to the last flush); known_empty: closed before any other call (default:
+    nothing was written and nothing flushed)."""
+    L = lib()
+    data = bytes(data)
+    if known_empty is None:
+        known_empty = final and not data and not flush_at
+    fl = (C.c_uint32 * max(len(flush_at), 1))(*flush_at)
+    cap = len(data) + (len(data) >> 8) + 4096 + 64 * (len(flush_at) + 2)
+    dst = C.create_string_buffer(cap)
+    src = C.create_string_buffer(data, max(len(data), 1))
+    r = L.zjni_compress_stream(dst, cap, src, len(data), level, 1 if checksum else 0, fl, len(flush_at), 1 if final else 0, 1 if known_empty else 0)
+    if L.zjni_isError(r):
+        raise ZstdException(r)
+    return dst.raw[:r]
 
 
 def decompress_batch(frames, capacities, dictionary=None):

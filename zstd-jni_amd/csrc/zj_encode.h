@@ -85,7 +85,7 @@ struct ZEncShared {                // uniforms, outside the overlay
     u32 blkRep[2], blkNextRep[2];  // multi-block frames: repcodes confirmed by the last compressed block / left by the block being encoded
 };
 // one block of a multi-block frame (ze_compress_multi): block = frameBase[start, start + srcSize) of ze_compress_t
-struct ZEBlockArgs { const u8* frameBase; u32 frameSize, start, isFirst, lastBlock; u32* tables; u32 serialParse; };   // serialParse: low bits 0 the wave matchers, 1 the one-lane parses (ZE_FLAG_MULTI_SERIAL), 2 the wave matchers without staged spans (ZE_FLAG_MULTI_NOCARRY); bit 2: levels 1-2 on the one-lane parse (ZE_FLAG_MULTI_FAST_SERIAL)
+struct ZEBlockArgs { const u8* frameBase; u32 frameSize, start, isFirst, lastBlock; u32* tables; u32 serialParse; u32 paramSize; };   // paramSize: the size the compression parameters are chosen for when it is not the frame's (a stream: unknown size, the level's default row); 0 = frameSize   // serialParse: low bits 0 the wave matchers, 1 the one-lane parses (ZE_FLAG_MULTI_SERIAL), 2 the wave matchers without staged spans (ZE_FLAG_MULTI_NOCARRY); bit 2: levels 1-2 on the one-lane parse (ZE_FLAG_MULTI_FAST_SERIAL)
 #define ZE_SMALL_MAX 4096u         /* frames up to this size are staged, gathered and assembled in LDS when the launch provides it */
 #define ZE_ALIGN16(x) (((x) + 15u) & ~15u)
 #define ZE_ENTROPY_LDS ZE_ALIGN16((u32)sizeof(ZEEntropy))
@@ -1429,7 +1429,7 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
     GRP_SERIAL(g) {
         sh.err = 0; sh.tight = 0; sh.tightHuf = 0;
         if (cd) { sh.strategy = sh.dictStrategy; sh.minMatch = sh.dictMinMatch; sh.windowLog = 0; sh.hashLog = 0; sh.chainLog = 0; }
-        else { ze_params(sh, level, ba ? ba->frameSize : srcSize); if (sh.strategy == 0) sh.err = 201; }     // a (level, size) the reference serves with a finder this library does not restate
+        else { ze_params(sh, level, ba ? (ba->paramSize ? ba->paramSize : ba->frameSize) : srcSize); if (sh.strategy == 0) sh.err = 201; }     // a (level, size) the reference serves with a finder this library does not restate
         if (pre) { sh.nbSeq = pre->meta[0]; sh.litSize = pre->meta[1]; sh.lastLL = pre->meta[2]; }
         if (ba) { sh.hdrSize = 0; if (dstCap < 3u + 2u + 1u) sh.err = ZJ_E_DSTSIZE_TOO_SMALL; }     // zstd_compress.c:4629-4631
         else {
@@ -2107,7 +2107,7 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
         ZX_FRAME_MARK(zxSplit);
         u32 const blockSize = ZJ_UNI(sh.tmp[0]);
         g.sync();
-        ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables; ba.serialParse = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
+        ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.paramSize = 0; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; ba.tables = tables; ba.serialParse = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
         u64 const r = ze_compress_t<G, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, ldsBytes, &ba);
         if (r > ZJ_ERR64(256)) return r;
         savings += (i64)blockSize - (i64)r;
@@ -2118,6 +2118,85 @@ ZJ_DEV u64 ze_compress_multi(const G& g, ZEncShared& sh, u8* lds, const u8* src,
     if (blockIdx.x < 8u && threadIdx.x == 0) printf("zx frame wg %u: %u bytes, block sizing (pre-split) %llu kcycles, blocks (parse + entropy stage) %llu kcycles\n", blockIdx.x, srcSize, (unsigned long long)(zxSplit / 1000ull), (unsigned long long)(zxBlocks / 1000ull));
 #endif
     if (dstCap < pos + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    if (tail) {
+        u64 const h = zj_xxh64(g, src, srcSize);
+        GRP_SERIAL(g) { st32(dst + pos, (u32)h); }
+    }
+    return pos + tail;
+}
+
+// ---- stream frames: what ZSTD_compressStream2 produces WITHOUT a pledged size — ZstdDirectBufferCompressingStream, ZstdOutputStream
+// (N/jni_directbuffercompress_zstd.c:97-161; N/compress/zstd_compress.c:6103-6300 ZSTD_compressStream_generic, :4591-4692 ZSTD_compress_frameChunk) ----
+// The caller hands over everything written so far (the stream is buffered until close(), at most the level's unknown-size window: 512 KiB / 1 MiB / 2 MiB at
+// levels 1 / 2 / 3, so no position ever leaves the window) and where it flushed.  What differs from ze_compress_multi, rule by rule:
+//   (i)   parameters of an UNKNOWN source size: the level's default row (level 3: window 21, chain 16, hash 17) whatever the total — a parameter size apart from
+//         the frame size, which still clamps the matchers' loads;
+//   (ii)  header without a content size: descriptor = checksum << 2, window byte (windowLog - 10) << 3.  A stream that was closed before anything else was called on
+//         it (`knownEmpty`) is the exception: its first call is ZSTD_e_end, the size (0) is known: single segment, one-byte content size;
+//   (iii) the input reaches ZSTD_compress_frameChunk in pieces of 128 KiB (the stream's input buffer), so ZSTD_optimalBlockSize sees what is left of the PIECE and
+//         `savings` at a piece's start counts the frame header's bytes as produced;
+//   (iv)  flush() ends the piece where the caller stands (flushAt[]: ascending byte counts; a flush with nothing buffered writes nothing), the 128 KiB pieces start
+//         again behind it;
+//   (v)   close() with nothing buffered (the total a multiple of 128 KiB, or a flush just before) writes an empty raw last block; otherwise the buffered rest is the
+//         last piece and its last block the frame's last.
+// `final` = 0: the caller flushed but did not close — no epilogue, the output is the frame's beginning up to the last flush (bytes past the last flush position are
+// not consumed).  Re-running with more input and final = 1 reproduces those bytes and continues: every decision depends only on the bytes before it.
+// Exact: tests/test_emu_stream.py against ZSTD_compressStream2 (oracle/ref.py compress_stream), tests/test_gpu_stream.py.
+ZJ_HD u32 ze_stream_window_log(u32 level) { return level == 1u ? 19u : (level == 2u ? 20u : 21u); }      // N/compress/clevels.h:26-30 (the rows of a source above 256 KiB)
+template <class G>
+ZJ_DEV u64 ze_compress_stream(const G& g, ZEncShared& sh, u8* lds, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u8* ws, ZjProf& pf, u32 flags, u32* tables, u32 ldsBytes,
+                              const u32* flushAt, u32 nFlush, u32 final, u32 knownEmpty) {
+    u32 const lv = ZE_LW_LEVEL(level);
+    u32 const wlog = ze_stream_window_log(lv);
+    if (lv < 1u || lv > 3u || srcSize > (1u << wlog) || srcSize > ZE_MULTI_MAX) return ZJ_ERR64(201);
+    u32 const paramSize = srcSize > (256u << 10) ? srcSize : (256u << 10) + 1u;           // any size above 256 KiB selects the row; hashLog / chainLog do not depend on it further
+    ZEParams const p = ze_params_of(lv, paramSize);
+    u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
+    if (dstCap < 18u) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    u32 total = srcSize;                                                                  // what this call consumes: everything when closing, up to the last flush otherwise
+    if (!final) { total = 0; for (u32 i = 0; i < nFlush; i++) if (flushAt[i] <= srcSize && flushAt[i] > total) total = flushAt[i]; }
+    bool const emptyKnown = final && knownEmpty && srcSize == 0u;
+    GRP_SERIAL(g) {
+        st32(dst, 0xFD2FB528u);
+        if (emptyKnown) { dst[4] = (u8)(0x20u + (tail ? 4u : 0u)); dst[5] = 0; }
+        else { dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((wlog - 10u) << 3); }
+        sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0;
+    }
+    {   u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
+        GRP_FOR(g, i, entries) tables[i] = 0; }
+    zj_mem_order();
+    g.sync();
+    u32 pos = 6, isFirst = 1, fi = 0; bool lastSeen = false;
+    if (total == 0u && !final) return 0;                                                  // nothing was flushed yet: the header goes out with the first block
+    for (u32 chunk = 0, seg = 0; chunk < total; ) {
+        while (fi < nFlush && flushAt[fi] <= seg) fi++;                                   // (flushes with nothing buffered)
+        bool const haveFlush = fi < nFlush && flushAt[fi] <= total;
+        u32 const segEnd = haveFlush ? flushAt[fi] : total;                               // the next flush() (or the end of what was written)
+        u32 const chunkEnd = chunk + 131072u < segEnd ? chunk + 131072u : segEnd;
+        bool const flushed = haveFlush && chunkEnd == segEnd;                             // this piece ends where the caller flushed
+        bool const endChunk = final && chunkEnd == total && (chunkEnd - chunk) != 131072u && !flushed;     // still buffered at ZSTD_e_end: the last frame chunk
+        i64 savings = (i64)chunk - (i64)pos;                                              // consumedSrcSize - producedCSize, the header's bytes included
+        for (u32 at = chunk; at < chunkEnd; ) {
+            if (p.strategy == 2 && chunkEnd - at >= 131072u && savings >= 3) {            // double-fast: the chunk fingerprints, all lanes
+                u32 const bs = zp_split_by_chunks_g(g, src + at, (u32*)lds);
+                GRP_SERIAL(g) { sh.tmp[0] = bs; }
+            } else GRP_SERIAL(g) { sh.tmp[0] = zp_block_size(src + at, chunkEnd - at, p.strategy, savings, (u32*)lds); }
+            g.sync();
+            u32 const blockSize = ZJ_UNI(sh.tmp[0]);
+            g.sync();
+            ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.paramSize = paramSize; ba.start = at; ba.isFirst = isFirst; ba.lastBlock = (endChunk && at + blockSize == chunkEnd) ? 1u : 0u; ba.tables = tables;
+            ba.serialParse = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
+            u64 const r = ze_compress_t<G, u32>(g, sh, lds, src + at, blockSize, dst + pos, dstCap - pos, level, ws, pf, nullptr, 0u, nullptr, ldsBytes, &ba);
+            if (r > ZJ_ERR64(256)) return r;
+            lastSeen = ba.lastBlock != 0;
+            savings += (i64)blockSize - (i64)r;
+            at += blockSize; pos += (u32)r; isFirst = 0;
+        }
+        chunk = chunkEnd; if (chunkEnd == segEnd) seg = segEnd;
+    }
+    if (!final) return pos;
+    if (dstCap < pos + 3u + tail) return ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL);
+    if (!lastSeen) { GRP_SERIAL(g) { dst[pos] = 1; dst[pos + 1] = 0; dst[pos + 2] = 0; } pos += 3; }      // ZSTD_writeEpilogue: an empty raw last block
     if (tail) {
         u64 const h = zj_xxh64(g, src, srcSize);
         GRP_SERIAL(g) { st32(dst + pos, (u32)h); }

@@ -706,6 +706,34 @@ __global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(con
 #endif
 }
 
+// Stream frames (ze_compress_stream, zj_encode.h): what the reference's stream classes produce without a pledged size, one wavefront per stream over the
+// multi-block kernel's table slots.  mode[i]: bit 0 final (close()), bit 1 the stream was closed before anything else was called on it; flushAt / flushOff:
+// the flush positions of stream i = flushAt[flushOff[i] .. flushOff[i + 1]) (flushOff == nullptr: none).
+__global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_stream_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                               u64* __restrict__ result, u32 level, u32 count, u32* workCounter, u8* scratch, u32* tables, u32 flags, u32 ldsBytes,
+                                                               const u32* __restrict__ flushAt, const u64* __restrict__ flushOff, const u32* __restrict__ mode) {
+    __shared__ ZEncShared sh;
+    ZjProf pf; pf.start(nullptr);
+    Grp<64> g;
+    if (threadIdx.x == 0) { sh.dictLoaded = 0; sh.ctDict[0] = 0; sh.ctDict[1] = 0; sh.ctDict[2] = 0; }
+    __syncthreads();
+    u8* const ws = scratch + (size_t)blockIdx.x * ZE_SCRATCH_BYTES;
+    u32* const tb = tables + (size_t)blockIdx.x * (ZE_MULTI_TABLE_BYTES / 4u);
+    for (;;) {
+        u32 const i = zj_next_index(workCounter);
+        if (i >= count) break;
+        u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
+        u64 const cap = d1 - d0, size64 = s1 - s0;
+        u32 const capU = (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap);
+        u64 const f0 = flushOff ? zj_uni64(flushOff[i]) : 0, f1 = flushOff ? zj_uni64(flushOff[i + 1]) : 0;
+        u32 const md = mode ? ZJ_UNI(mode[i]) : 1u;
+        u64 const r = size64 > ZE_MULTI_MAX ? ZJ_ERR64(201)
+                                            : ze_compress_stream(g, sh, zj_dyn_lds, src + s0, (u32)size64, dst + d0, capU, level, ws, pf, flags, tb, ldsBytes, flushAt + f0, (u32)(f1 - f0), md & 1u, (md >> 1) & 1u);
+        if (threadIdx.x == 0) result[i] = r;
+        __syncthreads();
+    }
+}
+
 // ZSTD_createCDict on the device: one workgroup digests the dictionary held in `out` (header, zeroed tables, raw bytes)
 __global__ __launch_bounds__(64) void zj_cdict_digest_kernel(u32 dictSize, u32 level, ZECDictDev* out) {
     __shared__ ZDecShared sh;
@@ -1775,6 +1803,60 @@ size_t zjni_compress_batch_device2(const void* d_src, const uint64_t* d_src_off,
     if (level < 1 || level > ZJ_LEVEL_MAX) return ZJNI_ERR(42);
     return compress_chunked(d_src, d_src_off, d_dst, d_dst_off, d_result, n, level, checksum ? ZE_FLAG_CHECKSUM : 0u, stream);
 }
+// Stream frames (include/zjni_amd.h): n streams, each buffered whole, through zj_encode_stream_kernel.
+size_t zjni_compress_stream_batch_device(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off, uint64_t* d_result, size_t n, int level, int checksum,
+                                         const uint32_t* d_flush_at, const uint64_t* d_flush_off, const uint32_t* d_mode, void* stream) {
+    if (level == 0) level = 3;
+    if (level < 1 || level > 3) return ZJNI_ERR(42);                 // the levels whose multi-block frames the kernels make (above: the bundled library's)
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(72);
+    BatchOrder order(d, stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
+    u32* const ctr = d->counters + 224;
+    if (hipMemsetAsync(ctr, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
+    u32 flags = checksum ? ZE_FLAG_CHECKSUM : 0u;
+    if (const char* ov = zj_env("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); flags |= v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
+    {   const char* const ov = zj_env("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) flags |= ZE_FLAG_MULTI_FAST_SERIAL; }      // levels 1-2: the one-lane parse (zj_encode_multi_kernel's default)
+    hipLaunchKernelGGL(zj_encode_stream_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
+                       (u64*)d_result, (u32)level, (u32)n, ctr, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy), (const u32*)d_flush_at, (const u64*)d_flush_off, (const u32*)d_mode);
+    return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+}
+// One stream from host pointers: what was written so far, where the caller flushed, closing or not.  Returns the bytes the frame has so far (final = 0: up to the
+// last flush), or an error; 201 when the total exceeds the level's unknown-size window (the bundled library's stream takes over).
+size_t zjni_compress_stream(void* dst, size_t dstCap, const void* src, size_t srcSize, int level, int checksum, const uint32_t* flushAt, size_t nFlush, int final_, int knownEmpty) {
+    if (level == 0) level = 3;
+    if (level < 1 || level > 3) return ZJNI_ERR(42);
+    if (srcSize > ((size_t)1 << ze_stream_window_log((u32)level)) || srcSize > ZE_MULTI_MAX) return ZJNI_ERR(201);
+    if ((srcSize && !src) || (dstCap && !dst) || (nFlush && !flushAt) || nFlush > (1u << 20)) return ZJNI_ERR(72);
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    size_t const cap = dstCap > ((size_t)1 << 31) ? ((size_t)1 << 31) : dstCap;
+    // staging layout: [srcOff 2][dstOff 2][result 1][flushOff 2][mode (4 bytes, padded to 8)][flush positions][src][dst]
+    size_t const oSrcOff = 0, oDstOff = 16, oRes = 32, oFOff = 40, oMode = 56, oFlush = 64, oSrc = (oFlush + 4 * nFlush + 15) & ~(size_t)15, oDst = (oSrc + srcSize + 15) & ~(size_t)15;
+    size_t const total = oDst + cap + 16;
+    std::lock_guard<std::mutex> lk(*d->stageMu);
+    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);
+    struct Drain { ~Drain() { (void)hipStreamSynchronize(0); } } drainOnExit;
+    u64* const h = (u64*)d->hPinned;
+    h[0] = 0; h[1] = srcSize; h[2] = 0; h[3] = cap; h[4] = 0; h[5] = 0; h[6] = nFlush; ((u32*)(d->hPinned + oMode))[0] = (final_ ? 1u : 0u) | (knownEmpty ? 2u : 0u); ((u32*)(d->hPinned + oMode))[1] = 0;
+    if (nFlush) memcpy(d->hPinned + oFlush, flushAt, 4 * nFlush);
+    if (srcSize) memcpy(d->hPinned + oSrc, src, srcSize);
+    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcSize, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    size_t const r = zjni_compress_stream_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff), (u64*)(d->dStage + oRes), 1, level, checksum,
+                                                       (const u32*)(d->dStage + oFlush), (const u64*)(d->dStage + oFOff), (const u32*)(d->dStage + oMode), nullptr);
+    if (zjni_isError(r)) return r;
+    if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, 8, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    size_t const out = (size_t)h[4];
+    if (zjni_isError(out) || out == 0) return out;
+    if (out > cap) return ZJNI_ERR(70);
+    if (hipMemcpyAsync(d->hPinned + oDst, d->dStage + oDst, out, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    memcpy(dst, d->hPinned + oDst, out);
+    return out;
+}
 // ZstdCompressCtx.setHashLog / setChainLog (ZSTD_c_hashLog / ZSTD_c_chainLog; 0 = the library's choice) on top of level + checksum.
 // Honoured for level 3 (double-fast), hashLog 6..17, chainLog 6..16: with 16 / 15 the frames are the reference's plain level 3.
 static size_t level_word(int level, int hashLog, int chainLog, int* out) {
@@ -1930,6 +2012,31 @@ static size_t host_frame_extent(const u8* p, size_t n, u64* content) {
     }
     pos += cks ? 4 : 0;
     return pos <= n ? pos : 0;
+}
+
+// ZSTD_findFrameCompressedSize + ZSTD_decompressBound for ONE complete zstd frame at src (N/decompress/zstd_decompress.c:739-850): the bytes the frame occupies,
+// its content size from the header (~0: not recorded) and an upper bound of what it decodes to (raw / RLE blocks exactly, compressed blocks at the block maximum).
+// 0: not a complete, well-formed zstd frame (skippable frames, truncated input, reserved bits): the caller keeps the bundled library's stream.
+size_t zjni_frame_extent(const void* srcv, size_t srcSize, unsigned long long* content, unsigned long long* bound) {
+    const u8* const p = (const u8*)srcv; u64 c = ~(u64)0;
+    size_t const ext = srcv ? host_frame_extent(p, srcSize, &c) : 0;
+    if (content) *content = c;
+    if (bound) *bound = 0;
+    if (!ext) return 0;
+    u32 const fhd = p[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
+    u32 const didSz = didc == 3 ? 4 : didc, fcsSz = fcsid == 0 ? single : (1u << fcsid);
+    u64 blockMax = 128u << 10;
+    if (!single) { u32 const wl = (p[5] >> 3) + 10u; if (wl > 31u) return 0; u64 const w = ((u64)1 << wl) + (((u64)1 << wl) >> 3) * (p[5] & 7u); if (w < blockMax) blockMax = w; }
+    else if (c < blockMax) blockMax = c;
+    size_t pos = 5 + !single + didSz + fcsSz; u64 b = 0;
+    for (;;) {
+        u32 const bh = (u32)p[pos] | ((u32)p[pos + 1] << 8) | ((u32)p[pos + 2] << 16), type = (bh >> 1) & 3, bs = bh >> 3;
+        b += type == 2 ? blockMax : bs;
+        pos += 3 + (type == 1 ? 1 : bs);
+        if (bh & 1) break;
+    }
+    if (bound) *bound = (c != ~(u64)0) ? c : b;
+    return ext;
 }
 
 // Host-pointer decompress as a three-stage pipeline over slices of the batch: while slice k's frames are decoded, slice k + 1's sources cross the

@@ -207,9 +207,11 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlo
 }
 /* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
  * class's.  Recorded when the GPU path honours the parameter, otherwise the context is marked for the CPU path; always passed on. */
+static void ss_note_parameter(jlong stream, int what, jint v);      /* the handle may be a stream class's (below) */
 static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const char* name, int what) {
     jint (*f)(JNIEnv*, jclass, jlong, jint) = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(name);
     CtxState* s = st_get(stream, what == 'd' ? 'D' : 'C');
+    ss_note_parameter(stream, what, v);
     if (s) switch (what) {
         case 'l': s->level = v; break;
         case 'k': s->checksum = (v & 0xFF) != 0; break;
@@ -763,4 +765,311 @@ JNIEXPORT jlong JNICALL P(Zstd_compressBatchDict0)(JNIEnv* env, jclass cls, jobj
     g = (zjni_cdict*)dict_get((*env)->GetLongField(env, dict, native_ptr_field(env, dict, &g_cdict_field)), 0);
     if (!g) return E_DICT;
     return batch(env, srcs, dsts, results, 1, 0, checksum == JNI_TRUE, g);
+}
+
+/* ==== ZstdDirectBufferCompressingStreamNoFinalizer (N/jni_directbuffercompress_zstd.c) on the GPU ==========================================
+ * The reference feeds ZSTD_compressStream / ZSTD_flushStream / ZSTD_endStream.  The GPU route BUFFERS the stream until it is closed (at most the level's
+ * unknown-size window: 512 KiB / 1 MiB / 2 MiB at levels 1 / 2 / 3) and makes the frame ZSTD_compressStream2 would have made, byte for byte, in one
+ * zjni_compress_stream call: compressDirectByteBuffer only takes the bytes in, flushStream returns the frame's next part up to here (the call is
+ * repeated over everything written so far and only the new bytes are handed out: every decision depends only on the bytes before it), endStream
+ * the rest and the epilogue.  Output the caller's buffer has no room for waits in the stream state and the native says how much, as the reference does.
+ * A stream that outgrows the window, carries a dictionary, uses a level above 3 or meets a GPU that declines is REPLAYED into the bundled library's
+ * stream (its natives are called with direct buffers made for the purpose) and stays there.  Like the per-buffer natives a single stream cannot amortise
+ * a launch, so with the bundled library present streams go there unless ZSTD_JNI_GPU_STREAMS=1 (or ZSTD_JNI_GPU_PER_BUFFER=1); ZSTD_JNI_GPU_STREAMS=0
+ * keeps them on the CPU in every configuration that has one. */
+typedef struct StreamState {
+    struct StreamState* next; jlong key;
+    int level, checksum, cpuMode, started, finished;
+    unsigned char* buf; size_t total, cap;                      /* everything written so far */
+    uint32_t* flushAt; size_t nFlush, flushCap;
+    size_t emitted;                                             /* bytes of the frame already made (handed out or pending) */
+    unsigned char* out; size_t outLen, outPos, outCap;          /* made, not yet taken by the caller */
+} StreamState;
+static StreamState* g_ss[256];
+static pthread_mutex_t g_ss_mu = PTHREAD_MUTEX_INITIALIZER;
+static jfieldID g_cs_consumed, g_cs_produced, g_ds_consumed, g_ds_produced;
+static StreamState* ss_get(jlong key, int create, int take) {
+    StreamState** pp; StreamState* s = NULL;
+    if (!key) return NULL;
+    pthread_mutex_lock(&g_ss_mu);
+    for (pp = &g_ss[st_bucket(key) & 255]; *pp; pp = &(*pp)->next) if ((*pp)->key == key) { s = *pp; if (take) *pp = s->next; break; }
+    if (!s && create) { s = (StreamState*)calloc(1, sizeof *s); if (s) { s->key = key; s->level = 3; s->next = g_ss[st_bucket(key) & 255]; g_ss[st_bucket(key) & 255] = s; } }
+    pthread_mutex_unlock(&g_ss_mu);
+    return s;
+}
+static void ss_reset(StreamState* s, int level) {
+    s->level = level; s->checksum = 0; s->cpuMode = 0; s->started = 0; s->finished = 0; s->total = 0; s->nFlush = 0; s->emitted = 0; s->outLen = s->outPos = 0;
+}
+static void ss_free(StreamState* s) { if (s) { free(s->buf); free(s->flushAt); free(s->out); free(s); } }
+static void ss_note_parameter(jlong stream, int what, jint v) {      /* class Zstd's parameter natives on a stream handle: level and checksum are honoured, anything else is the bundled library's */
+    StreamState* s = ss_get(stream, 0, 0);
+    if (!s) return;
+    if (what == 'l') { s->level = v == 0 ? 3 : v; if (v < 0 || v > 3) s->cpuMode = 1; }
+    else if (what == 'k') s->checksum = (v & 0xFF) != 0;
+    else s->cpuMode = 1;
+}
+static int streams_on_gpu(void) {
+    static int state = -1;
+    if (state < 0) {
+        const char* e = getenv("ZSTD_JNI_GPU_STREAMS");
+        if (e && *e == '0' && cpu_sym(PS("Zstd_compressBound"))) state = 0;
+        else state = ((e && *e == '1') || per_buffer_on_gpu()) ? 1 : 0;
+    }
+    return state && gpu_on();
+}
+static size_t ss_window(int level) { return (size_t)1 << (18 + (level < 1 ? 3 : level)); }
+static int ss_out_room(StreamState* s, size_t more) {
+    if (s->outPos == s->outLen) s->outPos = s->outLen = 0;
+    if (s->outLen + more > s->outCap) { size_t const c = (s->outLen + more) * 2 + 4096; unsigned char* p = (unsigned char*)realloc(s->out, c); if (!p) return 0; s->out = p; s->outCap = c; }
+    return 1;
+}
+static size_t ss_deliver(StreamState* s, char* dst, size_t room) {      /* pending output into the caller's buffer: bytes copied */
+    size_t k = s->outLen - s->outPos; if (k > room) k = room;
+    if (k) { memcpy(dst, s->out + s->outPos, k); s->outPos += k; }
+    return k;
+}
+typedef jlong (*cs_compress_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint, jobject, jint, jint);
+typedef jlong (*cs_end_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint);
+/* Hand everything buffered so far to the bundled library's stream (flushes where the caller flushed), collecting what it writes; afterwards the stream is the
+ * bundled library's.  -1: no bundled library or no way to wrap a buffer; the caller answers with an error code. */
+static int ss_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
+    cs_compress_fn cf = (cs_compress_fn)cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_compressDirectByteBuffer"));
+    cs_end_fn ff = (cs_end_fn)cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_flushStream"));
+    size_t at = 0, fi = 0, delivered = 0; size_t const scratchCap = 256u << 10;
+    unsigned char* scratch; jobject dbuf;
+    if (!cf || !ff || !(*env)->NewDirectByteBuffer) return -1;
+    scratch = (unsigned char*)malloc(scratchCap); if (!scratch) return -1;
+    dbuf = (*env)->NewDirectByteBuffer(env, scratch, (jlong)scratchCap);
+    if (!dbuf) { free(scratch); return -1; }
+    delivered = s->emitted - (s->outLen - s->outPos);         /* what the caller has already taken of the frame */
+    s->outLen = s->outPos = 0;
+    while (at < s->total || fi < s->nFlush) {
+        size_t const upto = fi < s->nFlush ? s->flushAt[fi] : s->total;
+        while (at < upto) {
+            size_t const n = upto - at > (1u << 30) ? (1u << 30) : upto - at;
+            jobject sbuf = (*env)->NewDirectByteBuffer(env, s->buf + at, (jlong)n);
+            jlong r; jint consumed, produced;
+            if (!sbuf) { free(scratch); return -1; }
+            r = cf(env, obj, s->key, dbuf, 0, (jint)scratchCap, sbuf, 0, (jint)n);
+            consumed = (*env)->GetIntField(env, obj, g_cs_consumed); produced = (*env)->GetIntField(env, obj, g_cs_produced);
+            if ((*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, sbuf);
+            if (r < 0 || !ss_out_room(s, (size_t)produced)) { free(scratch); return -1; }
+            memcpy(s->out + s->outLen, scratch, (size_t)produced); s->outLen += (size_t)produced;
+            at += (size_t)consumed;
+            if (consumed == 0 && produced == 0) { free(scratch); return -1; }
+        }
+        if (fi < s->nFlush) {
+            for (;;) {
+                jlong const r = ff(env, obj, s->key, dbuf, 0, (jint)scratchCap); jint const produced = (*env)->GetIntField(env, obj, g_cs_produced);
+                if (r < 0 || !ss_out_room(s, (size_t)produced)) { free(scratch); return -1; }
+                memcpy(s->out + s->outLen, scratch, (size_t)produced); s->outLen += (size_t)produced;
+                if (r == 0) break;
+            }
+            fi++;
+        }
+    }
+    if ((*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, dbuf);
+    free(scratch);
+    /* What was flushed out earlier came from the GPU route; the bundled stream has just made the same bytes again (the route is byte-identical, and a flushed
+     * prefix depends on nothing behind it): they are skipped, what follows is new. */
+    if (s->outLen < s->emitted) return -1;
+    s->outPos = delivered; s->emitted = 0;
+    s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
+    return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_createCStream)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_createCStream"));
+    jlong const h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);
+    if (h) (void)ss_get(h, 1, 0);
+    return h;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_freeCStream)(JNIEnv* env, jclass cls, jlong stream) {
+    jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_freeCStream"));
+    ss_free(ss_get(stream, 0, 1));
+    if (!stream) return 0;
+    if (f) return f(env, cls, stream);
+    free((void*)(intptr_t)stream); return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_recommendedCOutSize)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_recommendedCOutSize"));
+    return f ? f(env, cls) : (jlong)zjni_compressBound(128u << 10) + 3 + 4;          /* ZSTD_CStreamOutSize(): a block's bound + its header + the checksum */
+}
+static void cs_fields(JNIEnv* env, jobject obj) {
+    jclass const clazz = (*env)->GetObjectClass(env, obj);
+    g_cs_consumed = (*env)->GetFieldID(env, clazz, "consumed", "I"); g_cs_produced = (*env)->GetFieldID(env, clazz, "produced", "I");
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_initCStream)(JNIEnv* env, jobject obj, jlong stream, jint level) {
+    jlong (*f)(JNIEnv*, jobject, jlong, jint) = (jlong (*)(JNIEnv*, jobject, jlong, jint))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_initCStream"));
+    StreamState* s = ss_get(stream, 1, 0);
+    cs_fields(env, obj);
+    if (s) { ss_reset(s, level == 0 ? 3 : level); if (level < 0 || level > 3 || !streams_on_gpu()) s->cpuMode = 1; }
+    return f ? f(env, obj, stream, level) : 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_initCStreamWithDict)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dict, jint dict_size, jint level) {
+    jlong (*f)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint) = (jlong (*)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_initCStreamWithDict"));
+    StreamState* s = ss_get(stream, 1, 0);
+    cs_fields(env, obj);
+    if (s) { ss_reset(s, level); s->cpuMode = 1; }              /* streams with a dictionary: the bundled library's */
+    return f ? f(env, obj, stream, dict, dict_size, level) : -(jlong)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_initCStreamWithFastDict)(JNIEnv* env, jobject obj, jlong stream, jobject dict) {
+    jlong (*f)(JNIEnv*, jobject, jlong, jobject) = (jlong (*)(JNIEnv*, jobject, jlong, jobject))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_initCStreamWithFastDict"));
+    StreamState* s = ss_get(stream, 1, 0);
+    cs_fields(env, obj);
+    if (s) { ss_reset(s, 3); s->cpuMode = 1; }
+    return f ? f(env, obj, stream, dict) : -(jlong)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_compressDirectByteBuffer)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size, jobject src_buf, jint src_offset, jint src_size) {
+    cs_compress_fn f = (cs_compress_fn)cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_compressDirectByteBuffer"));
+    StreamState* s = ss_get(stream, 0, 0);
+    jlong dst_cap, src_cap; char* dp; char* sp;
+    if (s == NULL || (s->cpuMode && s->outPos == s->outLen)) return f ? f(env, obj, stream, dst_buf, dst_offset, dst_size, src_buf, src_offset, src_size) : E_MEM;
+    dst_cap = (*env)->GetDirectBufferCapacity(env, dst_buf);                        /* the reference's checks, in its order (N/jni_directbuffercompress_zstd.c:103-110) */
+    if (dst_offset + dst_size > dst_cap) return E_DST;
+    src_cap = (*env)->GetDirectBufferCapacity(env, src_buf);
+    if (src_offset + src_size > src_cap) return E_SRC;
+    dp = (char*)(*env)->GetDirectBufferAddress(env, dst_buf); if (dp == NULL) return E_MEM;
+    sp = (char*)(*env)->GetDirectBufferAddress(env, src_buf); if (sp == NULL) return E_MEM;
+    if (s->cpuMode) {                                                               /* replayed earlier: what the bundled stream wrote then goes out first */
+        size_t const k = ss_deliver(s, dp + dst_offset, (size_t)dst_size);
+        (*env)->SetIntField(env, obj, g_cs_consumed, 0); (*env)->SetIntField(env, obj, g_cs_produced, (jint)k);
+        return 1;
+    }
+    s->started = 1;
+    if (s->total + (size_t)src_size > ss_window(s->level)) {                         /* outgrows the window: the bundled library's stream takes over */
+        if (ss_replay_to_cpu(env, obj, s) != 0) return -(jlong)ZJNI_ERROR_unsupported;
+        {   size_t const k = ss_deliver(s, dp + dst_offset, (size_t)dst_size);
+            if (s->outPos < s->outLen) { (*env)->SetIntField(env, obj, g_cs_consumed, 0); (*env)->SetIntField(env, obj, g_cs_produced, (jint)k); return 1; }
+            {   jlong const r = f(env, obj, stream, dst_buf, dst_offset + (jint)k, dst_size - (jint)k, src_buf, src_offset, src_size);
+                (*env)->SetIntField(env, obj, g_cs_produced, (*env)->GetIntField(env, obj, g_cs_produced) + (jint)k);
+                return r; } }
+    }
+    if (s->total + (size_t)src_size > s->cap) {
+        size_t c = (s->total + (size_t)src_size) * 2 + 65536; unsigned char* p;
+        if (c > ss_window(s->level)) c = ss_window(s->level);
+        p = (unsigned char*)realloc(s->buf, c); if (!p) return E_MEM;
+        s->buf = p; s->cap = c;
+    }
+    if (src_size > 0) memcpy(s->buf + s->total, sp + src_offset, (size_t)src_size);
+    s->total += (size_t)src_size;
+    (*env)->SetIntField(env, obj, g_cs_consumed, src_size); (*env)->SetIntField(env, obj, g_cs_produced, 0);
+    return (jlong)((128u << 10) - (s->total & ((128u << 10) - 1)));                  /* a hint for the next write, as ZSTD_compressStream gives one */
+}
+static jlong cs_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size, int end) {
+    const char* const name = end ? PS("ZstdDirectBufferCompressingStreamNoFinalizer_endStream") : PS("ZstdDirectBufferCompressingStreamNoFinalizer_flushStream");
+    cs_end_fn f = (cs_end_fn)cpu_sym(name);
+    StreamState* s = ss_get(stream, 0, 0);
+    jlong dst_cap; char* dp; size_t k = 0;
+    if (s == NULL || (s->cpuMode && s->outPos == s->outLen)) return f ? f(env, obj, stream, dst_buf, dst_offset, dst_size) : E_MEM;
+    dst_cap = (*env)->GetDirectBufferCapacity(env, dst_buf);
+    if (dst_offset + dst_size > dst_cap) return E_DST;
+    dp = (char*)(*env)->GetDirectBufferAddress(env, dst_buf);
+    if (dp == NULL) return E_MEM;
+    if (!s->cpuMode && s->outPos == s->outLen && !s->finished) {                     /* nothing pending: make the frame's next part */
+        int const knownEmpty = end && !s->started && s->total == 0;
+        size_t const cap = s->total + (s->total >> 8) + 4096 + 64 * (s->nFlush + 4);
+        unsigned char* tmp; size_t r;
+        if (!end) {
+            s->started = 1;
+            if (s->total > (s->nFlush ? s->flushAt[s->nFlush - 1] : 0)) {            /* something was written since the last flush */
+                if (s->nFlush == s->flushCap) { size_t const c = s->flushCap * 2 + 16; uint32_t* p = (uint32_t*)realloc(s->flushAt, c * sizeof *p); if (!p) return E_MEM; s->flushAt = p; s->flushCap = c; }
+                s->flushAt[s->nFlush++] = (uint32_t)s->total;
+            } else { (*env)->SetIntField(env, obj, g_cs_produced, 0); return 0; }  /* a flush with nothing buffered writes nothing */
+        }
+        tmp = (unsigned char*)malloc(cap); if (!tmp) return E_MEM;
+        r = zjni_compress_stream(tmp, cap, s->buf, s->total, s->level, s->checksum, s->flushAt, s->nFlush, end, knownEmpty);
+        if (zjni_isError(r)) {
+            free(tmp);
+            if (zjni_getErrorCode(r) >= 200 && ss_replay_to_cpu(env, obj, s) == 0) {   /* the GPU declined: the bundled stream makes the frame from the start */
+                k = ss_deliver(s, dp + dst_offset, (size_t)dst_size);
+                if (s->outPos < s->outLen) { (*env)->SetIntField(env, obj, g_cs_produced, (jint)k); return (jlong)(s->outLen - s->outPos); }
+                {   jlong const rr = f(env, obj, stream, dst_buf, dst_offset + (jint)k, dst_size - (jint)k);
+                    (*env)->SetIntField(env, obj, g_cs_produced, (*env)->GetIntField(env, obj, g_cs_produced) + (jint)k);
+                    return rr; }
+            }
+            return (jlong)r;
+        }
+        if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); return E_MEM; }
+        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+        free(tmp);
+        if (end) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
+    }
+    k = ss_deliver(s, dp + dst_offset, (size_t)dst_size);
+    (*env)->SetIntField(env, obj, g_cs_produced, (jint)k);
+    if (s->outPos < s->outLen) return (jlong)(s->outLen - s->outPos);                /* bytes still to be taken: the caller comes back with room */
+    if (s->cpuMode) {                                                               /* the replayed part is out: the bundled stream does this flush / end itself */
+        jlong const rr = f(env, obj, stream, dst_buf, dst_offset + (jint)k, dst_size - (jint)k);
+        (*env)->SetIntField(env, obj, g_cs_produced, (*env)->GetIntField(env, obj, g_cs_produced) + (jint)k);
+        return rr;
+    }
+    if (s->finished) { int const lv = s->level, ck = s->checksum; ss_reset(s, lv); s->checksum = ck; }     /* the frame is out: the next write starts a new one, as ZSTD_endStream leaves the stream */
+    return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size) {
+    return cs_flush_or_end(env, obj, stream, dst_buf, dst_offset, dst_size, 0);
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_endStream)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size) {
+    return cs_flush_or_end(env, obj, stream, dst_buf, dst_offset, dst_size, 1);
+}
+
+/* ==== ZstdDirectBufferDecompressingStreamNoFinalizer.decompressStreamNative (N/jni_directbufferdecompress_zstd.c:58-79) ==========================
+ * At a frame boundary, when the source buffer holds a COMPLETE zstd frame and the destination has room for all it can decode to, the frame goes to the
+ * batch decoder in one piece (zjni_decompress) — also frames without a content size, whose bound comes from their block headers — and the native
+ * answers as ZSTD_decompressStream does after a frame's last byte: consumed = the frame, produced = its content, return 0.  Anything else (a frame in pieces,
+ * a small destination, skippable frames, a dictionary) is the bundled library's stream, and once it is inside a frame it stays there until the frame ends. */
+typedef jlong (*ds_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint, jobject, jint, jint);
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_createDStreamNative)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdDirectBufferDecompressingStreamNoFinalizer_createDStreamNative"));
+    jlong const h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);
+    if (h) (void)ss_get(h, 1, 0);
+    return h;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_freeDStreamNative)(JNIEnv* env, jclass cls, jlong stream) {
+    jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdDirectBufferDecompressingStreamNoFinalizer_freeDStreamNative"));
+    ss_free(ss_get(stream, 0, 1));
+    if (!stream) return 0;
+    if (f) return f(env, cls, stream);
+    free((void*)(intptr_t)stream); return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_initDStreamNative)(JNIEnv* env, jobject obj, jlong stream) {
+    jlong (*f)(JNIEnv*, jobject, jlong) = (jlong (*)(JNIEnv*, jobject, jlong))cpu_sym(PS("ZstdDirectBufferDecompressingStreamNoFinalizer_initDStreamNative"));
+    StreamState* s = ss_get(stream, 1, 0);
+    jclass const clazz = (*env)->GetObjectClass(env, obj);
+    g_ds_consumed = (*env)->GetFieldID(env, clazz, "consumed", "I"); g_ds_produced = (*env)->GetFieldID(env, clazz, "produced", "I");
+    if (s) { ss_reset(s, 3); s->cpuMode = streams_on_gpu() ? 0 : 1; }               /* (started = 1 below: the bundled stream is inside a frame) */
+    return f ? f(env, obj, stream) : 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_decompressStreamNative)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size, jobject src_buf, jint src_offset, jint src_size) {
+    ds_fn f = (ds_fn)cpu_sym(PS("ZstdDirectBufferDecompressingStreamNoFinalizer_decompressStreamNative"));
+    StreamState* s = ss_get(stream, 0, 0);
+    if (s && !s->cpuMode && !s->started && src_size > 0) {
+        jlong const dst_cap = (*env)->GetDirectBufferCapacity(env, dst_buf), src_cap = (*env)->GetDirectBufferCapacity(env, src_buf);
+        char* const dp = (char*)(*env)->GetDirectBufferAddress(env, dst_buf); char* const sp = (char*)(*env)->GetDirectBufferAddress(env, src_buf);
+        if (dst_offset + dst_size > dst_cap) return E_DST;
+        if (src_offset + src_size > src_cap) return E_SRC;
+        if (dp && sp) {
+            unsigned long long content = 0, bound = 0;
+            size_t const ext = zjni_frame_extent(sp + src_offset, (size_t)src_size, &content, &bound);
+            if (ext && (bound <= (unsigned long long)dst_size || bound <= (64ull << 20))) {
+                /* a frame without a content size is bounded by its block headers only (128 KiB per compressed block): decoded aside when that bound exceeds the
+                 * caller's room, and handed over if what it really holds fits */
+                int const aside = bound > (unsigned long long)dst_size;
+                char* const to = aside ? (char*)malloc((size_t)bound + 1) : dp + dst_offset;
+                size_t const r = to ? zjni_decompress(to, aside ? (size_t)bound : (size_t)dst_size, sp + src_offset, ext) : (size_t)E_MEM;
+                if (!zjni_isError(r) && r <= (size_t)dst_size) {
+                    if (aside) { memcpy(dp + dst_offset, to, r); free(to); }
+                    (*env)->SetIntField(env, obj, g_ds_consumed, (jint)ext); (*env)->SetIntField(env, obj, g_ds_produced, (jint)r);
+                    __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+                    return 0;
+                }
+                if (aside) free(to);
+                if (zjni_isError(r) && zjni_getErrorCode(r) < 200 && zjni_getErrorCode(r) != 70) return (jlong)r;     /* the frame is damaged: libzstd's code */
+            }
+        }
+    }
+    if (!f) return -(jlong)ZJNI_ERROR_unsupported;
+    {   jlong const r = f(env, obj, stream, dst_buf, dst_offset, dst_size, src_buf, src_offset, src_size);
+        if (s) s->started = (r > 0);                                                /* > 0: inside a frame (more input or more room wanted); 0: at a boundary again */
+        return r; }
 }
