@@ -437,6 +437,13 @@ def main():
     # which match finder served the timed steps: asked of the library, not inferred from the environment
     L = zj.lib()
     route = int(L.zjni_last_route()) if mode != "decode_ref" else 0
+    lists = None
+    if mode != "decode_ref" and hasattr(L, "zjni_last_lists"):
+        # the library says how the batch was split: a batch whose frames went through the wide launch (128 KiB buffers) names THAT kernel, not list A's
+        l3 = (C.c_uint * 3)()
+        if L.zjni_last_lists(l3) == 0:
+            lists = {"common_launch": int(l3[0]), "wide_launch": int(l3[1]), "multi_block_or_wave_per_frame": int(l3[2])}
+            if l3[1] > l3[0] and l3[1] >= l3[2]: route = 10                      # ZJNI_ROUTE_WIDE
     route_kernel = L.zjni_route_kernel(route).decode() if route > 0 else ""
     stamp = L.zjni_build_stamp().decode()
 
@@ -608,7 +615,7 @@ def main():
                        "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
                        "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"],
                        **({"hashLog": 16, "chainLog": 15, "table_sizes": "the reference's own for this level and size (N/compress/clevels.h + ZSTD_adjustCParams): nothing but the level is set; the LDS-sized 14 / 13 behind setHashLog / setChainLog: see lds_tables_level3"} if (level == 3 and 32768 < size <= 131072 and mode in ("both",)) else {})},
-            "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel},
+            "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel, "frames_per_launch": lists},
             "lds_tables_level3": lds3,
             "small_batch_level3": small,
             "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),

@@ -278,7 +278,16 @@ int zjni_last_timing2(float* out8);
 #define ZJNI_ROUTE_HYBRID 7       /* ZJNI_HYBRID=1: lane and wave kernels side by side */
 #define ZJNI_ROUTE_OTHER 8        /* levels 4-8, dictionaries, multi-block only */
 #define ZJNI_ROUTE_WAVE_HBM 9     /* zj_encode_multi_kernel: level-3 frames of batches below ZJNI_L3_WAVE_MAX, wave per frame over HBM tables (zj_match_wavex.h) */
+#define ZJNI_ROUTE_WIDE 10        /* zj_enc_match_wide_kernel: the launch of frames above 64 KiB (list B); never zjni_last_route()'s answer — see zjni_last_lists */
 int zjni_last_route(void);
+/* How the last large compress call's frames were split: out3[0] the common launch (the route above), out3[1] the wide launch (ZJNI_ROUTE_WIDE), out3[2] the
+ * multi-block / wave-per-frame kernel.  A batch of 128 KiB buffers has out3[1] = n: its match-finder time is zjni_last_timing2's out8[5] and its kernel
+ * zjni_route_kernel(ZJNI_ROUTE_WIDE).  Synchronises with the device (diagnostics only). */
+int zjni_last_lists(unsigned* out3);
+/* The same for the last large decompress call: out4[0] frames of the single-block pipeline (prep -> lane-per-frame sequence decode -> execute), out4[1] frames the
+ * fused wave-per-frame kernel decoded (what no pipeline took, or handed over), out4[2] frames of the multi-block stages (lane per BLOCK; frames of several blocks
+ * or without a content size), out4[3] their blocks.  Synchronises with the device (diagnostics only). */
+int zjni_last_decode_lists(unsigned* out4);
 /* Name of the kernel a route's match-finder time (zjni_last_timing out[0]) belongs to. */
 const char* zjni_route_kernel(int route);
 /* The source revision the library was built from ("unknown" when the build had no git): profiles and PMC passes are stamped with it. */

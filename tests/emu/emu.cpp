@@ -74,6 +74,50 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     free(seqs); free(tab); free(lit); free(sh);
     return r;
 }
+// multi-block frames (and frames without a content size) through the split pipeline's block stages: zd_prep_frame_multi -> ZDSeqLaneT<true> per block ->
+// zd_exec_frame_multi; frames the stages hand over go through the fused path.  *used = 1 when the block stages served the frame.
+extern "C" unsigned long long emu_decompress_mb(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned long long dstCap, int* used) {
+    EMU_IO(src, srcSize, dst, (unsigned)(dstCap > 0xFFFFFFFFull ? 0xFFFFFFFFull : dstCap));
+    Grp<1> g;
+    ZDecShared* sh = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh, 0xA5, sizeof(ZDecShared));
+    u8* lit = (u8*)malloc(ZD_LIT_SCRATCH);
+    u32 const blkCap = ZD_MB_MAX_BLOCKS; u64 const seqCap = (u64)blkCap * 4096u + (u64)srcSize;      // (a sequence takes at least a few bits: far more than the frame can hold)
+    ZDBlk* blks = (ZDBlk*)calloc(blkCap, sizeof(ZDBlk)); u16* tabs = (u16*)calloc((size_t)blkCap * ZD_SPLIT_CELLS, 2);
+    u64* pool = (u64*)malloc((size_t)seqCap * 8); u32* seqList = (u32*)calloc(blkCap, 4);
+    u32 blkCounter = 0, seqListCount = 0, litListCount = 0; unsigned long long seqCounter = 0, litCounter = 0; ZDFrameMB fr;
+    // EMU_MB_LIT: 0 no stage 2b (stage 3 decodes every block's literals), 1 (default) every block with a slot, 2 every other one (treeless blocks meet both cases)
+    int const litMode = getenv("EMU_MB_LIT") ? atoi(getenv("EMU_MB_LIT")) : 1;
+    u64 const litCap = litMode ? (u64)srcSize * 40u + ((u64)blkCap << 17) : 0;
+    u8* litPool = litMode ? (u8*)malloc((size_t)(litCap > ((u64)1 << 30) ? ((u64)1 << 30) : litCap) + 64) : nullptr;
+    u64 const litCapUsed = litMode ? (litCap > ((u64)1 << 30) ? ((u64)1 << 30) : litCap) : 0;
+    u32* litList = (u32*)calloc(blkCap, 4);
+    ZjProf pf; pf.start(nullptr);
+    u64 r = ~(u64)0;
+    if (used) *used = 0;
+    if (zd_prep_frame_multi(g, *sh, src, srcSize, dstCap, 0u, &fr, blks, tabs, &blkCounter, blkCap, &seqCounter, seqCap, seqList, &seqListCount, 1u,
+                            &litCounter, litCapUsed, litMode ? litList : nullptr, &litListCount)) {
+        for (u32 q = 0; q < litListCount; q++) {                  // stage 2b: a workgroup of its own per block (poisoned LDS)
+            if (litMode == 2 && (q & 1u)) continue;
+            ZDecShared* sh3 = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh3, 0x77, sizeof(ZDecShared));
+            if (zd_lit_block(g, *sh3, src, blks, litList[q], litPool, pf)) blks[litList[q]].litReady = 1u;
+            free(sh3);
+        }
+        u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1);
+        for (u32 q = seqListCount; q-- > 0; ) {                   // (any order: the blocks do not depend on each other here)
+            ZDBlk* const bk = blks + seqList[q];
+            ZDSeqLaneT<true> m; m.llBase = symL; m.mlBase = symM;
+            m.init_block(src, tabs + (size_t)seqList[q] * ZD_SPLIT_CELLS, pool + (((u64)bk->seqHi << 32) | bk->seqLo), bk);
+            while (m.st != 2) m.round();
+        }
+        ZDecShared* sh2 = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh2, 0x3C, sizeof(ZDecShared));      // stage 3 is another kernel: its own LDS
+        r = zd_exec_frame_multi(g, *sh2, src, dst, dstCap, &fr, blks, pool, lit, (u8*)sh2->ll, pf, litPool);
+        free(sh2);
+        if (used && r != ~(u64)0) *used = 1;
+    }
+    if (r == ~(u64)0) { memset(sh, 0x5A, sizeof(*sh)); r = zd_decompress(g, *sh, src, srcSize, dst, (u32)(dstCap > 0xFFFFFFFFull ? 0xFFFFFFFFull : dstCap), lit, pf); }
+    free(litList); free(litPool); free(seqList); free(pool); free(tabs); free(blks); free(lit); free(sh);
+    return r;
+}
 // dictionary decode: digest (ZSTD_createDDict) + ZSTD_decompress_usingDDict
 // dictionary frames through the three-stage pipeline
 extern "C" unsigned long long emu_decompress_split_dict(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap,

@@ -1,0 +1,95 @@
+"""CPU (-m "not gpu"): multi-block frames and frames without a content size through the block stages of the split decode pipeline (zj_decode_split.h:
+zd_prep_frame_multi -> ZDSeqLaneT<true> per block, repcode history carried symbolically -> zd_exec_frame_multi) in the lane-serial emulation — bit-exact with
+the reference for its golden frames, for one-shot frames of several blocks at every level the reference serves, for stream frames with flushes (small blocks,
+raw and RLE blocks, repeat-mode tables, treeless literals) and for frames whose blocks start with repcode matches; damaged frames fall to the fused path and are
+answered as the reference answers them."""
+import ctypes as C
+import random
+
+import pytest
+
+from conftest import golden
+from util import emu_lib
+
+
+@pytest.fixture(scope="module", params=["1", "0", "2"])        # EMU_MB_LIT: the blocks' literals by stage 2b (every block / none / every other one: treeless blocks meet both)
+def emu(request):
+    import os
+    os.environ["EMU_MB_LIT"] = request.param
+    L = emu_lib()
+    L.emu_decompress_mb.restype = C.c_ulonglong
+    L.emu_decompress_mb.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_ulonglong, C.POINTER(C.c_int)]
+    return L
+
+
+def mb(L, frame, cap):
+    dst = C.create_string_buffer(max(cap, 1)); used = C.c_int(0)
+    r = L.emu_decompress_mb(frame, len(frame), dst, cap, C.byref(used))
+    return (dst.raw[:r] if r < (1 << 63) else -((1 << 64) - r)), used.value
+
+
+def test_golden_frames_through_the_block_stages(emu, oracle_ref):
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    for name in ("xml-1.zst", "xml-3.zst", "xml-6.zst", "xml-9.zst", "xml-advanced.zst", "xml-1-sized.zst"):
+        got, used = mb(emu, golden(name), len(xml))
+        assert got == xml, name
+        assert used == 1, name                               # served by the block stages, not by the fused path
+    got, used = mb(emu, golden("xmlsmall-sized.zst"), 200)
+    assert got == oracle_ref.decompress(golden("xmlsmall-sized.zst"), 200)
+
+
+def test_reference_frames_of_several_blocks(emu, oracle_ref, zj):
+    rnd = random.Random(17)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(50000))
+    served = 0
+    for size in (131073, 200000, 262144, 400000, 1048576, 3000000):
+        o = rnd.randrange(0, len(xml) - size)
+        inputs = [xml[o:o + size], b"".join(zj.synth_host(65536, 7 * i + size, 1) for i in range(size // 65536 + 1))[:size], (noise * 70)[:size],
+                  (b"\0" * 150000 + xml[o:o + 70000] + bytes([7]) * 300000 + noise)[:size]]            # RLE blocks, raw blocks
+        for d in inputs:
+            for level in (1, 3, 5, 9, 19):
+                if level >= 9 and size > 1048576: continue
+                for ck in (False, True):
+                    z = oracle_ref.compress(d, level, ck)
+                    got, used = mb(emu, z, len(d))
+                    assert got == d, (size, level, ck)
+                    assert used == 1, (size, level, ck, 'handed over')
+                    served += used
+                    if ck and level == 3:                     # a destination one byte short is refused like the reference refuses it
+                        bad, _ = mb(emu, z, len(d) - 1)
+                        assert bad == -70
+    assert served > 60
+
+
+def test_stream_frames_with_flushes(emu, oracle_ref, zj):
+    """no content size in the header, many small blocks, the empty last block: the frames of tests/test_emu_stream.py decoded"""
+    rnd = random.Random(19)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    served = 0
+    for size in (0, 1, 1000, 70000, 131072, 300000, 2000000):
+        o = rnd.randrange(0, len(xml) - size - 1)
+        for d in (xml[o:o + size], b"".join(zj.synth_host(65536, i, 1) for i in range(size // 65536 + 1))[:size], bytes([3]) * size):
+            for level, chunk, k in ((3, 50000, 0), (1, 7000, 1), (3, 1000, 3), (5, 131072, 1), (3, 300, 1)):
+                if size > 300000 and chunk < 7000: continue
+                z = oracle_ref.compress_stream(d, level, bool(size & 1), chunk=chunk, flush_every=k)
+                got, used = mb(emu, z, len(d) + 100)
+                assert got == d, (size, level, chunk, k)
+                assert used == 1 or size == 0, (size, level, chunk, k, 'handed over')
+                served += used
+    assert served > 40
+
+
+def test_damaged_multiblock_frames_answer_as_the_reference(emu, oracle_ref):
+    rnd = random.Random(23)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    d = xml[100000:100000 + 500000]
+    z = oracle_ref.compress(d, 3, True)
+    for _ in range(150):
+        b = bytearray(z); i = rnd.randrange(4, len(b)); b[i] ^= 1 << rnd.randrange(8)
+        try:
+            want = oracle_ref.decompress_portable(bytes(b), len(d))
+        except oracle_ref.ZstdRefError as e:
+            want = -(((1 << 64) - e.code) & 0xFFFFFFFF) if e.code > (1 << 32) else -e.code
+        got, _ = mb(emu, bytes(b), len(d))
+        assert got == want, (i, got if isinstance(got, int) else len(got), want if isinstance(want, int) else len(want))

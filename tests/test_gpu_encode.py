@@ -80,6 +80,12 @@ def test_gpu_wide_frames_through_the_lane_pipeline(gpu, oracle_ref, monkeypatch,
             assert not isinstance(z, Exception), (level, k, len(d), z)
             assert z == ref_expected(oracle_ref, d, level, lds), (level, lds, k, len(d))
         assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
+        if level == 3 and not lds:          # the library says how it split the batch (zjni_last_lists): frames above 64 KiB are the wide launch's (ZJNI_ROUTE_WIDE)
+            import ctypes as C
+            l3 = (C.c_uint * 3)()
+            assert gpu.lib().zjni_last_lists(l3) == 0
+            assert l3[1] == sum(1 for s_ in sizes if s_ > 65536) and l3[0] + l3[1] + l3[2] == len(sizes), list(l3)
+            assert gpu.lib().zjni_route_kernel(10) == b"zj_enc_match_wide_kernel"
 
 
 def test_gpu_explicit_table_sizes(gpu, oracle_ref):

@@ -170,6 +170,10 @@ def lib():
     L.zjni_route_kernel.restype = C.c_char_p
     L.zjni_route_kernel.argtypes = [C.c_int]
     L.zjni_build_stamp.restype = C.c_char_p
+    L.zjni_last_decode_lists.restype = C.c_int
+    L.zjni_last_decode_lists.argtypes = [C.POINTER(C.c_uint)]
+    L.zjni_last_lists.restype = C.c_int
+    L.zjni_last_lists.argtypes = [C.POINTER(C.c_uint)]
     L.zjni_frame_extent.restype = sz
     L.zjni_frame_extent.argtypes = [vp, sz, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.zjni_compress_stream.restype = sz
@@ -193,7 +197,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
            "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
-           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent")
+           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

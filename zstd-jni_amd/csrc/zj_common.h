@@ -42,6 +42,14 @@ typedef int64_t i64;
 #define ZJ_ON_GPU 0
 #endif
 
+#if !ZJ_ON_GPU
+static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build (tests/emu)
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long const o = *p; *p = o + v; return o; }
+static inline u32 atomicMax(u32* p, u32 v) { u32 const o = *p; if (v > o) *p = v; return o; }
+static inline u32 atomicOr(u32* p, u32 v) { u32 const o = *p; *p = o | v; return o; }
+static inline u32 atomicCAS(u32* p, u32 cmp, u32 v) { u32 const o = *p; if (o == cmp) *p = v; return o; }
+#endif
+
 // ---- error codes: numerically the reference's ZSTD_ErrorCode (src/main/native/zstd_errors.h:60-98)
 enum : u32 {
     ZJ_OK = 0,

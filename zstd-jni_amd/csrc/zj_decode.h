@@ -486,7 +486,9 @@ ZJ_DEV void zd_execute_staged(const G& g, ZDecShared& sh, u8* out, const u8* lit
 // first (they only read the literal buffer); a match may read bytes that an earlier match of the same batch
 // produces, so matches run in rounds — a lane copies once no still-pending earlier lane overlaps its source
 // range (the lowest pending lane is always ready).  Long runs/matches are copied by the whole wave.
-template <bool DICT = false, class G>
+// CHECK (multi-block frames, zj_decode_split.h): the sequences come from a stage that could not test an offset against the frame's output position — a match
+// that starts before the output (or an offset of zero) sets sh.err and nothing is written.
+template <bool DICT = false, class G, bool CHECK = false>
 ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit, u32 n, u32 lp0, u32 op0, u32& litTot, u32& outTot, u8* stage = nullptr, u32 litAvail = 0, const u8* dictEnd = nullptr) {
 #if ZJ_ON_GPU
     u32 const k = g.lane();
@@ -502,6 +504,9 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
     u32 const lp = lp0 + sl - ll;                 // literal source
     u32 const op = op0 + so - ll - ml;            // output position of this sequence's literals
     u32 const mp = op + ll;                       // match destination
+    if (CHECK) {
+        if (__ballot(valid && (off == 0u || off > mp)) != 0ull) { if (k == 0) sh.err = ZJ_E_CORRUPTION; g.sync(); return; }
+    }
     if (stage && outTot <= ZD_STAGE_BYTES) { zd_execute_staged<DICT>(g, sh, out, lit, litAvail, stage, valid, ll, ml, off, lp, op, op0, outTot, dictEnd); return; }
     // ---- literals: short runs per lane, long runs by the whole wave ----
     if (ll <= 32) {
@@ -574,6 +579,10 @@ ZJ_DEV void zd_execute_batch(const G& g, ZDecShared& sh, u8* out, const u8* lit,
 #else
     u32 lp = lp0, op = op0;
     litTot = 0; outTot = 0;
+    if (CHECK) {
+        u32 p = op0;
+        for (u32 k = 0; k < n; k++) { p += sh.sLit[k]; if (sh.sOff[k] == 0u || sh.sOff[k] > p) { sh.err = ZJ_E_CORRUPTION; return; } p += sh.sMl[k]; }
+    }
     for (u32 k = 0; k < n; k++) {
         u32 const ll = sh.sLit[k], ml = sh.sMl[k], off = sh.sOff[k];
         litTot += ll; outTot += ll + ml;
@@ -858,7 +867,9 @@ ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
 template <class G>
 // preLit: the block's Huffman-coded literals were regenerated there by an earlier pass (zd_lit_frame, zj_decode_split.h) — the header is
 // parsed as always, the table and the streams are not touched again.
-ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u, const u8* preLit = nullptr) {
+// tableOnly: build the block's Huffman table (sh.huf, sh.hufValid, sh.hufX2) and stop — for a later treeless block whose literals are decoded apart from this one's
+// (zj_decode_split.h, multi-block frames); returns bsrc then.
+ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u, const u8* preLit = nullptr, bool tableOnly = false) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -898,6 +909,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
     pf.mark(0);
     u32 const litType = ZJ_UNI(sh.litType), litSize = ZJ_UNI(sh.litSize), litHdr = ZJ_UNI(sh.litHdr), litCSize = ZJ_UNI(sh.litCSize);
     const u8* lit = litScratch;
+    if (tableOnly && litType != 2) return nullptr;
     if (litType == 0) lit = bsrc + litHdr;                      // raw: read in place
     else if (litType == 1) { zd_fill(g, litScratch, bsrc[litHdr], litSize); zj_mem_order(); }
     else if (preLit) lit = preLit;
@@ -917,6 +929,7 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
             if (ZJ_UNI(sh.err)) return nullptr;
             zd_huf_fill(g, sh, ZJ_UNI(sh.bN));
             GRP_SERIAL(g) { sh.hufValid = 1; }
+            if (tableOnly) { g.sync(); return bsrc; }
         } else { GRP_SERIAL(g) { sh.litSrcOff = litHdr; } }
         g.sync();
         pf.mark(1);

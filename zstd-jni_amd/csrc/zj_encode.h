@@ -26,12 +26,6 @@
 #include "zj_common.h"
 #include "zj_invprob.h"
 
-#if !ZJ_ON_GPU
-static inline u32 atomicAdd(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }   // lane-serial build
-static inline u32 atomicMax(u32* p, u32 v) { u32 const o = *p; if (v > o) *p = v; return o; }
-static inline u32 atomicOr(u32* p, u32 v) { u32 const o = *p; *p = o | v; return o; }
-static inline u32 atomicCAS(u32* p, u32 cmp, u32 v) { u32 const o = *p; if (o == cmp) *p = v; return o; }
-#endif
 
 #define ZE_BLOCK_MAX (1u << 17)
 #define ZE_MAX_SEQ ((ZE_BLOCK_MAX / 4u) + 16u)

@@ -97,10 +97,12 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 }
 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
+// Multi-block frames (zj_decode_split.h, "multi-block frames"): what stage 1 claims from — mb.ctr[0] blocks, [1] entries of seqList, [2] entries of listM, [4..5] records of the pool (64 bit)
+struct ZDMbArgs { ZDFrameMB* frames; ZDBlk* blks; u16* tabs; u32* ctr; u32 blkCap; u32 minBlocks; unsigned long long seqCap; u32* seqList; u32* listM; unsigned long long litCap; u32* litList; };      // ctr: ... [8] lit list, [10..11] literal pool bytes (64 bit), [12] work of the literal pass
 template <bool DICT>
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
                                                           u32 n, u32* counter, u16* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
-                                                          const ZDDictDev* dd, u32* doneList, u32* procFlag) {
+                                                          const ZDDictDev* dd, u32* doneList, u32* procFlag, ZDMbArgs mb, u32 mbOnly) {
     __shared__ ZDecShared sh;
     Grp<64> g;
     for (;;) {
@@ -108,14 +110,76 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
         if (i >= n) break;
         u64 const s0 = srcOff[i], s1 = srcOff[i + 1], d0 = dstOff[i], d1 = dstOff[i + 1];
         u64 const cap = d1 - d0;
-        bool const simple = zd_prep_frame<DICT>(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
-                                                tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i, dd);
+        bool const simple = !mbOnly && zd_prep_frame<DICT>(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
+                                                           tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i, dd);
+        bool multi = false;
+        if (!DICT && !simple && mb.frames && s1 - s0 <= 0xFFFFFFFFull) {
+            // (minBlocks: a small batch keeps its single-block frames on the fused kernel — one launch instead of three)
+            multi = zd_prep_frame_multi(g, sh, src + s0, (u32)(s1 - s0), cap, i, mb.frames + i, mb.blks, mb.tabs, mb.ctr, mb.blkCap, (unsigned long long*)(mb.ctr + 4), mb.seqCap, mb.seqList, mb.ctr + 1, mb.minBlocks,
+                                        (unsigned long long*)(mb.ctr + 10), mb.litCap, mb.litList, mb.ctr + 8);
+        }
         if (threadIdx.x == 0) {
             if (doneList) { doneList[i] = 0xFFFFFFFFu; procFlag[i] = 0; }       // slot i of the completion queue / frame i's "executed by the side pass" flag
             // |A| and the batch's sequence total share one 64-bit counter ([8] = |A|, [9] = sequences, see zj_dec_heavy): one same-address atomic per frame
             if (simple) listA[(u32)atomicAdd((unsigned long long*)&listCounts[8], 1ull | ((unsigned long long)sh.nbSeq << 32))] = i;
+            else if (multi) mb.listM[atomicAdd(mb.ctr + 2, 1u)] = i;
             else listB[atomicAdd(&listCounts[1], 1u)] = i;
         }
+        __syncthreads();
+    }
+}
+// Multi-block frames, stage 2b: a WAVE per block regenerates its Huffman-coded literals into the block's slot of the literal pool (zd_lit_block)
+__global__ __launch_bounds__(64) void zj_dec_lit_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ litList, const u32* countPtr, u32* workCounter,
+                                                            ZDBlk* blks, u8* litPool) {
+    ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
+    ZjProf pf; pf.start(nullptr);
+    Grp<64> g;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 const k = zj_next_index(workCounter);
+        if (k >= count) break;
+        u32 const b = ZJ_UNI(litList[k]);
+        bool const ok = zd_lit_block(g, sh, src + zj_uni64(srcOff[ZJ_UNI(blks[b].frame)]), blks, b, litPool, pf);
+        if (threadIdx.x == 0 && ok) blks[b].litReady = 1u;
+        __syncthreads();
+    }
+}
+// Multi-block frames, stage 2: a LANE per block (ZDSeqLaneT<true>: repcode history carried symbolically), records into the pool
+__global__ __launch_bounds__(64) void zj_dec_seq_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ seqList, const u32* countPtr, u32* workCounter,
+                                                            const u16* tabs, u64* pool, ZDBlk* blks) {
+    __shared__ u32 llBase[36], mlBase[53];
+    zd_seq_symtabs(llBase, mlBase, threadIdx.x, 64u);
+    __syncthreads();
+    u32 const count = *countPtr;
+    ZDSeqLaneT<true> m; m.st = 2; m.llBase = llBase; m.mlBase = mlBase;
+    for (;;) {
+        if (m.st == 2) {
+            u32 const k = atomicAdd(workCounter, 1u);
+            if (k >= count) break;
+            u32 const b = seqList[k];
+            ZDBlk* const bk = blks + b;
+            m.init_block(src + srcOff[bk->frame], tabs + (size_t)b * ZD_SPLIT_CELLS, pool + (((u64)bk->seqHi << 32) | bk->seqLo), bk);
+            continue;
+        }
+        m.round();
+    }
+}
+// Multi-block frames, stage 3: a wave per frame walks its blocks in order (zd_exec_frame_multi); what it hands over goes to list B (the fused kernel)
+__global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff, u64* __restrict__ result,
+                                                             const u32* __restrict__ listM, const u32* countPtr, u32* workCounter, const ZDFrameMB* frames, const ZDBlk* blks, const u64* pool,
+                                                             u8* scratch, u32* listB, u32* listBCount, const u8* litPool) {
+    __shared__ ZDecShared sh;
+    ZjProf pf; pf.start(nullptr);
+    Grp<64> g;
+    u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 const k = zj_next_index(workCounter);
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(listM[k]);
+        u64 const s0 = zj_uni64(srcOff[i]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
+        u64 const r = zd_exec_frame_multi(g, sh, src + s0, dst + d0, d1 - d0, frames + i, blks, pool, lit, (u8*)sh.ll, pf, litPool);      // (sh.ll .. sh.ml: 4 KiB of LDS this kernel has no tANS tables in)
+        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; }
         __syncthreads();
     }
 }
@@ -895,6 +959,7 @@ struct DevState {
     std::mutex* stageMu = nullptr;                    // users of this device's host staging area (host-pointer entries)   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* dlitBuf = nullptr; size_t dlitBufCap = 0;      // literal slots of the split decode pipeline (stage 2b), one per frame of a slice
+    u8* dmbBuf = nullptr; size_t dmbBufCap = 0;        // multi-block frames on the split pipeline: [block tables][blocks][frames][seq list][list M][record pool]
     u8* hPinned = nullptr; size_t hPinnedCap = 0;
     u8* dStage = nullptr; size_t dStageCap = 0;
 };
@@ -985,13 +1050,14 @@ DevState* cur_state() {
 // has to grow first evicts the other pipelines' buffers (after the device has drained).  0 = no limit (sized for 288 GB).
 size_t g_scratch_limit = 0;
 #define ZJ_SCRATCH_LIMIT_MIN ((size_t)4 << 30)
-size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap + d->dlitBufCap; }
+size_t scratch_total(const DevState* d) { return d->splitBufCap + d->wideBufCap + d->cdBufCap + d->dsplitBufCap + d->dlitBufCap + d->dmbBufCap; }
 void scratch_free_all(DevState* d) {
     d->clearedValid = false;                                    // (hipFree drains the device, the clear stream included)
     if (d->splitBuf) (void)hipFree(d->splitBuf); d->splitBuf = nullptr; d->splitBufCap = 0;
     if (d->wideBuf) (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0;
     if (d->cdBuf) (void)hipFree(d->cdBuf); d->cdBuf = nullptr; d->cdBufCap = 0; d->cdSliceCap = 0;
     if (d->dsplitBuf) (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0;
+    if (d->dmbBuf) (void)hipFree(d->dmbBuf); d->dmbBuf = nullptr; d->dmbBufCap = 0;
     if (d->dlitBuf) (void)hipFree(d->dlitBuf); d->dlitBuf = nullptr; d->dlitBufCap = 0;
 }
 // before a buffer holding `have` bytes is replaced by one of `need` bytes: false when even alone it would exceed the limit
@@ -1084,6 +1150,7 @@ void zjni_shutdown(void) {
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
+        if (d.dmbBuf) (void)hipFree(d.dmbBuf);
         if (d.dlitBuf) (void)hipFree(d.dlitBuf);
         if (d.wideBuf) (void)hipFree(d.wideBuf);
         if (d.multiTables) (void)hipFree(d.multiTables);
@@ -1185,8 +1252,31 @@ int zjni_last_timing2(float* out8) {
 }
 
 int zjni_last_route(void) { DevState* d = cur_state(); return d ? d->lastRoute : -(int)ZJNI_ERROR_no_device; }
+// The last large compress call's three lists as the classification kernel filled them — out3[0] frames of the common launch (list A: what zjni_last_route names),
+// out3[1] frames of the wide launch (list B: frames above 64 KiB, zj_enc_match_wide_kernel = ZJNI_ROUTE_WIDE), out3[2] frames of the multi-block / wave-per-frame
+// kernel (list C).  Waits for the device: a diagnostic for benches and tests, not for the data path.
+int zjni_last_lists(unsigned* out3) {
+    DevState* d = cur_state();
+    if (!d || !out3) return -(int)ZJNI_ERROR_no_device;
+    u32 h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d->counters + 16, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -(int)ZJNI_ERROR_no_device;
+    out3[0] = h[0]; out3[1] = h[1]; out3[2] = h[4];
+    return 0;
+}
+// The last large decompress call: out4[0] frames of the single-block pipeline (list A), out4[1] frames the fused kernel decoded (list B: what no pipeline took, or
+// handed over), out4[2] frames of the multi-block stages (list M), out4[3] their blocks.  Waits for the device (diagnostics: benches, tests).
+int zjni_last_decode_lists(unsigned* out4) {
+    DevState* d = cur_state();
+    if (!d || !out4) return -(int)ZJNI_ERROR_no_device;
+    u32 a[12], m[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(a, d->counters + 32, sizeof a, hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy(m, d->counters + 232, sizeof m, hipMemcpyDeviceToHost) != hipSuccess) return -(int)ZJNI_ERROR_no_device;
+    out4[0] = a[8]; out4[1] = a[1]; out4[2] = m[2]; out4[3] = m[0];
+    return 0;
+}
 const char* zjni_route_kernel(int route) {
     switch (route) {
+    case ZJNI_ROUTE_WIDE: return "zj_enc_match_wide_kernel";
     case ZJNI_ROUTE_FUSED: return "zj_encode_kernel";
     case ZJNI_ROUTE_WAVE: return "zj_enc_match_wave_kernel";
     case ZJNI_ROUTE_LANE: case ZJNI_ROUTE_HYBRID: return "zj_enc_match_kernel";
@@ -1236,6 +1326,59 @@ int zjni_kernel_info(int* decodeGrid, int* decodeLds, int* encodeGrid, int* enco
 struct zjni_cdict { int ordinal; u8* buf; unsigned dictID; int level; u32 strategy; };   // buf = [ZECDictDev][tagged tables][raw dictionary bytes]
 struct zjni_ddict { int ordinal; u8* buf; size_t rawSize; unsigned dictID; };   // buf = [ZDDictDev][raw dictionary bytes]
 
+// Scratch of the multi-block stages (zj_decode_split.h): tables and records per BLOCK, claimed on the device — ZD_MB_BLOCKS blocks (4 GiB of input at 128 KiB a block)
+// and a pool of ZD_MB_SEQS records (a frame whose blocks or sequences find no room goes to the fused kernel).  ZJNI_DEC_MB=0 switches the stages off (A/B runs);
+// none under a scratch limit, none with a dictionary.
+#define ZD_MB_BLOCKS 65536u
+#define ZD_MB_SEQS ((size_t)192 << 20)
+#define ZD_MB_LIT_BYTES ((size_t)2 << 30)
+struct ZDMbHost { ZDMbArgs a; u64* pool; u8* litPool; bool on; };
+static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool haveDict) {
+    ZDMbHost h; memset(&h, 0, sizeof h);
+    int const mbEnv = (zj_env("ZJNI_DEC_MB") && atoi(zj_env("ZJNI_DEC_MB")) == 0) ? 0 : 1;
+    if (hipMemsetAsync(d->counters + 232, 0, 64, st) != hipSuccess) return h;      // (also when the stages stay off: zjni_last_decode_lists reads them)
+    if (!mbEnv || haveDict || g_scratch_limit) return h;
+    size_t const tabB = (size_t)ZD_MB_BLOCKS * ZD_SPLIT_TAB_BYTES, blkB = (size_t)ZD_MB_BLOCKS * sizeof(ZDBlk), frB = n * sizeof(ZDFrameMB), listB2 = (size_t)ZD_MB_BLOCKS * 4, lmB = n * 4;
+    size_t const poolOff = (tabB + blkB + frB + 2 * listB2 + lmB + 255) & ~(size_t)255;
+    size_t const litOff = poolOff + ZD_MB_SEQS * 8;
+    size_t const need = litOff + ZD_MB_LIT_BYTES + 256;
+    if (d->dmbBufCap < need) {
+        if (d->dmbBuf) { if (hipStreamSynchronize(st) != hipSuccess) return h; (void)hipFree(d->dmbBuf); d->dmbBuf = nullptr; d->dmbBufCap = 0; }
+        if (hipMalloc(&d->dmbBuf, need) != hipSuccess) { (void)hipGetLastError(); return h; }        // no room: the fused kernel serves these frames as before
+        d->dmbBufCap = need;
+    }
+    u32* const ctr = d->counters + 232;               // [0] blocks, [1] seq list, [2] |M|, [3] work seq, [4..5] records, [6] work exec, [8] lit list, [10..11] literal bytes, [12] work lit
+    if (hipMemsetAsync(ctr, 0, 64, st) != hipSuccess) return h;
+    h.a.tabs = (u16*)d->dmbBuf; h.a.blks = (ZDBlk*)(d->dmbBuf + tabB); h.a.frames = (ZDFrameMB*)(d->dmbBuf + tabB + blkB);
+    h.a.seqList = (u32*)(d->dmbBuf + tabB + blkB + frB); h.a.litList = h.a.seqList + ZD_MB_BLOCKS; h.a.listM = h.a.litList + ZD_MB_BLOCKS;
+    h.a.ctr = ctr; h.a.blkCap = ZD_MB_BLOCKS; h.a.seqCap = ZD_MB_SEQS; h.a.minBlocks = 1;
+    h.pool = (u64*)(d->dmbBuf + poolOff);
+    int const litEnv = (zj_env("ZJNI_DEC_MB_LIT") && atoi(zj_env("ZJNI_DEC_MB_LIT")) == 0) ? 0 : 1;       // stage 2b of these frames off (A/B runs)
+    h.a.litCap = litEnv ? ZD_MB_LIT_BYTES : 0; if (!litEnv) h.a.litList = nullptr;
+    h.litPool = d->dmbBuf + litOff;
+    h.on = true;
+    return h;
+}
+// stages 2 and 3 of the multi-block frames stage 1 put on list M; frames stage 3 hands over are appended to list B (count at listBCount) for the fused kernel behind
+static void decode_mb_launch(DevState* d, const ZDMbHost& h, hipStream_t st, const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off, uint64_t* d_result,
+                             u32* listB, u32* listBCount) {
+    if (!h.on) return;
+    // stage 2b on the side stream BESIDE stage 2 (the lane-per-block decode leaves most of every SIMD idle); stage 3 waits for both
+    bool const lit = h.a.litList != nullptr;
+    bool forked = false;
+    if (lit && hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess) {
+        hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
+                           h.a.blks, h.litPool);
+        forked = hipEventRecord(d->evJoin, d->sideStream) == hipSuccess;
+        if (!forked) (void)hipStreamSynchronize(d->sideStream);
+    }
+    hipLaunchKernelGGL(zj_dec_seq_mb_kernel, dim3((u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.seqList, (const u32*)(h.a.ctr + 1), h.a.ctr + 3,
+                       (const u16*)h.a.tabs, h.pool, h.a.blks);
+    if (forked && hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) { (void)hipStreamSynchronize(d->sideStream); }
+    hipLaunchKernelGGL(zj_dec_exec_mb_kernel, dim3((u32)d->decGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result,
+                       (const u32*)h.a.listM, (const u32*)(h.a.ctr + 2), h.a.ctr + 6, (const ZDFrameMB*)h.a.frames, (const ZDBlk*)h.a.blks, (const u64*)h.pool, d->decScratch, listB, listBCount,
+                       (const u8*)(lit ? h.litPool : nullptr));
+}
 static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                            uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
     DevState* d = cur_state();
@@ -1291,10 +1434,11 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         int const overlap = overlapEnv && !(statA > 0u && statS < 512u * statA);
         if (hipMemsetAsync(c, 0, 48, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         (void)hipEventRecord(d->tev[2], st);
+        ZDMbHost const mb = decode_mb_scratch(d, n, st, ddict != nullptr);       // frames that are not simple: multi-block, no content size (the stream classes')
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag);
+                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
         else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag);
+                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
@@ -1332,6 +1476,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
             }
         }
         if (d->decStat) (void)hipMemcpyAsync((void*)d->decStat, c + 8, 8, hipMemcpyDeviceToHost, st);
+        decode_mb_launch(d, mb, st, d_src, d_src_off, d_dst, d_dst_off, d_result, listB, c + 1);
         (void)hipEventRecord(d->tev[5], st);
         if (ddict) hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(grid < (u32)d->decDictGrid ? grid : (u32)d->decDictGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                            (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), ddDev, ddRaw);
@@ -1341,6 +1486,31 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     if (hipMemsetAsync(d->counters, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    // Small batches: frames of two blocks and more take the block stages (stage 1 in its multi-block-only mode; a frame is a chain of ~40 000 dependent steps per MiB on
+    // the fused kernel, its blocks decode side by side here); everything else, and whatever the stages hand over, is the fused kernel's as before.
+    if (!ddict) {
+        ZDMbHost mb = decode_mb_scratch(d, n, st, false);
+        size_t const lbBytes = n * 4;
+        if (mb.on && d->dsplitBufCap < lbBytes + 256) {                                   // list B of this path lives at the start of the split pipeline's buffer
+            if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
+            if (hipMalloc(&d->dsplitBuf, lbBytes + 256) != hipSuccess) { (void)hipGetLastError(); mb.on = false; } else d->dsplitBufCap = lbBytes + 256;
+        }
+        if (mb.on) {
+            u32* const c = d->counters + 32; u32* const listB = (u32*)d->dsplitBuf;
+            if (hipMemsetAsync(c, 0, 48, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            mb.a.minBlocks = 2;
+            (void)hipEventRecord(d->tev[2], st);
+            hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
+                               (u32)n, c + 2, (u16*)nullptr, (ZDMeta*)nullptr, (u32*)nullptr, listB, c, (const ZDDictDev*)nullptr, (u32*)nullptr, (u32*)nullptr, mb.a, 1u);
+            (void)hipEventRecord(d->tev[3], st); (void)hipEventRecord(d->tev[4], st);
+            decode_mb_launch(d, mb, st, d_src, d_src_off, d_dst, d_dst_off, d_result, listB, c + 1);
+            (void)hipEventRecord(d->tev[5], st);
+            hipLaunchKernelGGL(zj_decode_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)n, c + 5, d->decScratch, d->prof, (const u32*)listB, (const u32*)(c + 1), (const ZDDictDev*)nullptr, (const u8*)nullptr);
+            (void)hipEventRecord(d->tev[6], st); d->tevDecompress = true;
+            return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+        }
+    }
     if (ddict) {
         u32 const gridD = (u32)(n < (size_t)d->decDictGrid ? n : (size_t)d->decDictGrid);
         hipLaunchKernelGGL(zj_decode_dict_kernel, dim3(gridD), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
