@@ -585,10 +585,16 @@ def main():
         alg_launch = alg / slices if (dom and "dict" in dom) else alg
         achieved = alg_launch / 1e9 / (dom_ms / 1e3)
         traffic, traffic_note, request_roof = None, None, None
-        try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic.json)
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            rec = pmc.get(f"{a.config}_L{level}_{n}x{size}", {}).get(dom.split("(")[0])
+        try:                                                   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/r0N_pmc_traffic.json)
+            import glob
+            pmc, rec, pmc_name = {}, None, ""
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):      # the newest round's file first; a record of THIS build wins
+                with open(path) as f:
+                    cand_pmc = json.load(f)
+                cand_rec = cand_pmc.get(f"{a.config}_L{level}_{n}x{size}", {}).get(dom.split("(")[0])
+                if cand_rec and (rec is None or cand_rec.get("build_stamp") == stamp):
+                    take = rec is None or rec.get("build_stamp") != stamp
+                    if take: pmc, rec, pmc_name = cand_pmc, cand_rec, os.path.basename(path)
             if rec and rec.get("build_stamp") == stamp:        # a figure from another build of the library is not this run's: left out, and said so
                 traffic = rec["hbm_bytes_per_launch"]
                 traffic_note = f"{pmc.get('note', '')} Measured on build {rec['build_stamp']} = this library's zjni_build_stamp()."
@@ -599,7 +605,7 @@ def main():
                                 "measured_ceiling_G_per_s": 50.3, "frac": reqs / 1e9 / (dom_ms / 1e3) / 50.3,
                                 "note": "random-access request ceiling at a 6 GiB footprint, read-only (40.8 read+write): tools/micro/probe footprint, profiles/r02a_probe_*"}
             elif rec:
-                traffic_note = f"profiles/r03_pmc_traffic.json holds a PMC pass of build {rec.get('build_stamp')}; this library is {stamp}: not quoted (re-run tools/pmc_traffic.sh)."
+                traffic_note = f"profiles/{pmc_name} holds a PMC pass of build {rec.get('build_stamp')}; this library is {stamp}: not quoted (re-run tools/pmc_traffic.sh)."
         except OSError:
             pass
         per_gpu = n * size / GIB
