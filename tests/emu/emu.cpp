@@ -349,6 +349,7 @@ extern "C" void* emu_cdict_create(const unsigned char* dict, unsigned dictSize, 
     ZEEntropy* e = (ZEEntropy*)calloc(1, sizeof(ZEEntropy));
     ze_cdict_digest(g, *sh, *e, dictSize, level, cd);
     free(e); free(sh);
+    if (cd->status && getenv("EMU_DEBUG")) fprintf(stderr, "emu_cdict_create: digest status %u\n", cd->status);
     if (cd->status) { free(buf); return nullptr; }
     return buf;
 }
@@ -439,4 +440,22 @@ extern "C" void emu_need_buckets(const unsigned char* src, unsigned srcSize, uns
     ZLHash const hL = zl_hash_of(8, p.hashLog), hS = zl_hash_of(p.minMatch, p.chainLog);
     u64 const w = ld64(src + pos);
     out[0] = zl_hash(hL, w); out[1] = zl_hash(hS, w);
+}
+
+// the wave's tANS table construction (ze_tans_shares / ze_tans_describe / ze_tans_table) on its own, for tests/test_emu_tans.py: the shares of a histogram, their
+// description and the encoding table.  Returns 0 when the shares cannot be formed.
+extern "C" int emu_tans(const unsigned* count, unsigned maxSV, unsigned total, unsigned tableLog, int low, short* shareOut, unsigned char* descOut, unsigned* descSize, unsigned* need,
+                        unsigned short* stateOut, int* deltaFindOut, unsigned* deltaNbBitsOut) {
+    Grp<1> g;
+    static u32 cnt[64]; static short share[64]; static u32 scr[ZE_TANS_SCR]; static u32 desc32[40]; static u8 tableSymbol[4096]; static u32 bm[64 * 128]; static ZEFseCT ct;
+    memset(scr, 0xA5, sizeof scr); memset(desc32, 0x5A, sizeof desc32); memset(tableSymbol, 0xEE, sizeof tableSymbol); memset(bm, 0x77, sizeof bm); memset(&ct, 0x11, sizeof ct); memset(share, 0x22, sizeof share);
+    for (u32 s = 0; s < 64; s++) cnt[s] = s <= maxSV ? count[s] : 0;
+    if (!ze_tans_shares(g, share, tableLog, cnt, total, maxSV, low != 0, scr)) return 0;
+    memcpy(shareOut, share, 64 * sizeof(short));
+    *need = 0;
+    *descSize = ze_tans_describe(g, (u8*)desc32, share, maxSV, tableLog, scr, need);
+    memcpy(descOut, desc32, 128);
+    ze_tans_table(g, ct, share, maxSV, tableLog, tableSymbol, scr, bm);
+    memcpy(stateOut, ct.state, sizeof ct.state); memcpy(deltaFindOut, ct.deltaFind, sizeof ct.deltaFind); memcpy(deltaNbBitsOut, ct.deltaNbBits, sizeof ct.deltaNbBits);
+    return 1;
 }

@@ -93,3 +93,21 @@ def test_damaged_multiblock_frames_answer_as_the_reference(emu, oracle_ref):
             want = -(((1 << 64) - e.code) & 0xFFFFFFFF) if e.code > (1 << 32) else -e.code
         got, _ = mb(emu, bytes(b), len(d))
         assert got == want, (i, got if isinstance(got, int) else len(got), want if isinstance(want, int) else len(want))
+
+
+def test_sequences_with_many_extra_bits(emu, oracle_ref):
+    """long literal runs, long matches and far offsets: ~80 bits per sequence — the widest reads of the bitstream window"""
+    rnd = random.Random(29)
+    far = rnd.randbytes(2_000_000)
+    body = bytearray()
+    for _ in range(30):
+        n = rnd.choice([20000, 40000, 66000]); o = rnd.randrange(0, len(far) - 70000)
+        body += rnd.randbytes(n) + far[o:o + rnd.choice([300, 33000, 66000])]
+        for _ in range(rnd.choice([0, 40])):                    # bursts of short far matches between short literal runs
+            o = rnd.randrange(0, len(far) - 100); body += far[o:o + rnd.randrange(4, 40)] + rnd.randbytes(rnd.randrange(0, 3))
+    d = far + bytes(body)
+    for level in (1, 3, 7):
+        z = oracle_ref.compress(d, level, True)
+        got, used = mb(emu, z, len(d))
+        assert got == d, level
+        assert used == 1, level

@@ -97,21 +97,22 @@ ZJ_DEV void ze_cdict_digest(const G& g, ZDecShared& sh, ZEEntropy& e, u32 dictSi
                 }
             }
             u32 ofMaxRead = 31;
-            short* const ofNorm = sh.norm[0]; short* const norm = sh.norm[1];
+            short* const ofNorm = sh.norm[0]; short* norm = sh.norm[1];         // (the three share arrays stay: the encoding tables are built by the wave behind this block)
             if (!err) {                                                           // offset codes: table built over all 32 symbols
                 u32 tl = 0; u32 const h = zd_read_ncount(ofNorm, &ofMaxRead, &tl, dict + pos, dictSize - pos);
                 if (!h || h > dictSize - pos || tl > 8) err = ZJ_E_DICT_CORRUPTED;
-                else { ze_fse_build_ctable(out->fse[1], ofNorm, 31, tl, e.cumul, e.tableSymbol); pos += h; }
+                else { sh.tblMax[1] = 31; sh.tblLog[1] = tl; pos += h; }
             }
             if (!err) {                                                           // match lengths
                 u32 max = 52, tl = 0; u32 const h = zd_read_ncount(norm, &max, &tl, dict + pos, dictSize - pos);
                 if (!h || h > dictSize - pos || tl > 9) err = ZJ_E_DICT_CORRUPTED;
-                else { ze_fse_build_ctable(out->fse[2], norm, max, tl, e.cumul, e.tableSymbol); out->mlRepeat = ze_ncount_repeat(norm, max, 52); pos += h; }
+                else { sh.tblMax[2] = max; sh.tblLog[2] = tl; out->mlRepeat = ze_ncount_repeat(norm, max, 52); pos += h; }
             }
+            norm = sh.norm[2];
             if (!err) {                                                           // literal lengths
                 u32 max = 35, tl = 0; u32 const h = zd_read_ncount(norm, &max, &tl, dict + pos, dictSize - pos);
                 if (!h || h > dictSize - pos || tl > 9) err = ZJ_E_DICT_CORRUPTED;
-                else { ze_fse_build_ctable(out->fse[0], norm, max, tl, e.cumul, e.tableSymbol); out->llRepeat = ze_ncount_repeat(norm, max, 35); pos += h; }
+                else { sh.tblMax[0] = max; sh.tblLog[0] = tl; out->llRepeat = ze_ncount_repeat(norm, max, 35); pos += h; }
             }
             if (!err && pos + 12 > dictSize) err = ZJ_E_DICT_CORRUPTED;
             if (!err) {
@@ -130,11 +131,17 @@ ZJ_DEV void ze_cdict_digest(const G& g, ZDecShared& sh, ZEEntropy& e, u32 dictSi
         {   u32 const lg = zj_max(cp.hashLog + 3, cp.chainLog + 1);
             if (lg < 31 && content > (1u << lg)) fillStart = content - (1u << lg); }
         out->status = err; out->dictID = dictID; out->contentOff = contentOff; out->contentSize = content; out->hasEntropy = hasEntropy; out->fillStart = fillStart;
-        sh.err = err; sh.litSize = content; sh.litCSize = fillStart;
+        sh.err = err; sh.litSize = content; sh.litCSize = fillStart; sh.seqValid = hasEntropy;
     }
     zj_mem_order();
     g.sync();
     if (ZJ_UNI(sh.err)) return;
+    if (ZJ_UNI(sh.seqValid)) {                                                   // the dictionary's three encoding tables (ZSTD_loadCEntropy: FSE_buildCTable_wksp x 3), by the wave
+        for (u32 t = 0; t < 3u; t++)                                             // fse[0] LL <- norm[2], fse[1] OF <- norm[0], fse[2] ML <- norm[1]
+            ze_tans_table(g, out->fse[t], sh.norm[t == 0 ? 2 : (t == 1 ? 0 : 1)], ZJ_UNI(sh.tblMax[t]), ZJ_UNI(sh.tblLog[t]), e.tableSymbol, (u32*)e.rankBase, &e.hist[0][0]);
+        zj_mem_order();
+        g.sync();
+    }
     // ---- table fill (ZSTD_fillHashTableForCDict / ZSTD_fillDoubleHashTableForCDict, dtlm_full): in position order, every
     //      third position always overwrites its buckets; the two positions after it fill a bucket (the long table for
     //      double-fast) only if it is still empty.  Order-free form: a bucket ends with the LAST every-third position that

@@ -286,7 +286,8 @@ struct ZDSeqLaneT {
                 u32 t;
                 if (MB) {
                     // "repcode 1 minus one" of a symbolic entry stays symbolic (d + 1); a concrete zero is what the reference forces to -1 and then rejects
-                    u32 const r = (idx == 3u) ? rep0 : (idx == 1u ? rep1 : rep2);
+                    u32 const h0 = rep0, h1 = rep1, h2 = rep2;                  // (values first: a select between the members themselves kept the whole lane in scratch memory — 29 scratch instructions in zj_dec_seq_mb_kernel)
+                    u32 const r = (idx == 3u) ? h0 : (idx == 1u ? h1 : h2);
                     t = (idx == 3u) ? ((r & ZD_SYM) ? r + 1u : r - 1u) : r;
                     if (!(t & ZD_SYM) && t == 0u) { bad = 1; finish(); return; }
                     if ((t & ZD_SYM) && (t & 0x1FFFFFFFu) >= 0x1FFFFFFu) { bad = 1; finish(); return; }     // (d does not fit a record: never in practice, the fused kernel's then)

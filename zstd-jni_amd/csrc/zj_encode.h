@@ -832,123 +832,233 @@ ZJ_DEV u32 ze_fse_optimal_log(u32 maxTableLog, u32 srcSize, u32 maxSV, u32 minus
     return tableLog;
 }
 
-ZJ_DEV bool ze_fse_normalize_m2(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, short lowProb) {   // fse_compress.c:377-462
-    short const NOT_YET = -2; u32 s, distributed = 0, toDist;
-    u32 const lowThreshold = total >> tableLog; u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
-    for (s = 0; s <= maxSV; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProb; distributed++; total -= count[s]; continue; }
-        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
-        norm[s] = NOT_YET;
+ZJ_DEV void ze_or_bits(u32* w, u32 bitpos, u64 lo, u64 hi, u32 nbits) {    // OR nbits (<=128) of {hi:lo} at bitpos
+    u32 idx = bitpos >> 5; u32 const sh = bitpos & 31;
+    // shift the 128-bit value left by sh (<32) into 160 bits = 5 words
+    u32 const v0 = (u32)lo, v1 = (u32)(lo >> 32), v2 = (u32)hi, v3 = (u32)(hi >> 32);
+    u32 const o0 = v0 << sh;
+    u32 const o1 = sh ? ((v1 << sh) | (v0 >> (32 - sh))) : v1;
+    u32 const o2 = sh ? ((v2 << sh) | (v1 >> (32 - sh))) : v2;
+    u32 const o3 = sh ? ((v3 << sh) | (v2 >> (32 - sh))) : v3;
+    u32 const o4 = sh ? (v3 >> (32 - sh)) : 0;
+    u32 const words = (sh + nbits + 31) >> 5;
+    if (words > 0 && o0) atomicOr(&w[idx], o0);
+    if (words > 1 && o1) atomicOr(&w[idx + 1], o1);
+    if (words > 2 && o2) atomicOr(&w[idx + 2], o2);
+    if (words > 3 && o3) atomicOr(&w[idx + 3], o3);
+    if (words > 4 && o4) atomicOr(&w[idx + 4], o4);
+}
+
+// ------------------------------------------------------------------ tANS tables by the wave ----
+// What FSE_normalizeCount, FSE_writeNCount and FSE_buildCTable_wksp compute (N/compress/fse_compress.c:465-523, :237-328, :68-224), one symbol
+// per lane.  The reference walks the alphabet with running state; here every quantity a symbol needs is a prefix sum or a reduction over the
+// alphabet (<= 53 symbols: LL 36, OF 32, ML 53, Huffman weights 13), so the alphabet is handled in a few steps whatever its size:
+//   shares     a symbol's share of the 2^tableLog cells from its own count; the cells handed out and the first-largest share by LDS atomics
+//   describe   the cells left before a symbol = table size + 1 - (prefix sum of |share|) give its field's width and value in closed form; a
+//              group of zero shares is its first zero plus a run-length prefix on the symbol behind it; every lane ORs its field at the
+//              prefix sum of the widths
+//   table      occurrence j of the spread lands on the j-th position (k * step mod size) that is not reserved for a low-probability symbol;
+//              a position's slot in the state table is its symbol's first slot + its rank among that symbol's positions (bitmap popcount)
+// `scr`: 192 words of LDS.  All functions are called by every lane; results in LDS are visible when they return.
+#define ZE_TANS_SCR 192u
+// the reference's rounding table for small shares (fse_compress.c:466)
+ZE_CONST u32 ze_k_share_round[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+
+// The uncommon outcome of ze_tans_shares — the largest symbol cannot absorb the rounding surplus: shares by thresholds first, the rest
+// proportionally (fse_compress.c:377-462).  share[] on entry is overwritten.
+template <class G>
+ZJ_DEV bool ze_tans_shares_rare(const G& g, short* share, u32 tableLog, const u32* count, u32 total, u32 maxSV, i32 lowShare, u32* scr) {
+    u32* const pre = scr; u32* const red = scr + 128;
+    u32 const n = maxSV + 1u, size = 1u << tableLog;
+    u32 const lowUpTo = total >> tableLog;
+    u32 oneUpTo = (u32)(((u64)total * 3u) >> (tableLog + 1u));
+    GRP_SERIAL(g) { red[0] = 0; red[1] = 0; red[2] = 0; red[3] = 0; red[4] = 0; }
+    g.sync();
+    GRP_FOR(g, s, n) {                                              // settled at once: nothing, the low share, one cell; open (-2) otherwise
+        u32 const c = count[s]; i32 v = -2;
+        if (c == 0) v = 0; else if (c <= lowUpTo) v = lowShare; else if (c <= oneUpTo) v = 1;
+        if (c && v != -2) { atomicAdd(&red[0], 1u); atomicAdd(&red[1], c); }
+        share[s] = (short)v;
     }
-    toDist = (1u << tableLog) - distributed;
-    if (toDist == 0) return true;
-    if ((total / toDist) > lowOne) {
-        lowOne = (u32)(((u64)total * 3) / (toDist * 2));
-        for (s = 0; s <= maxSV; s++) { if ((norm[s] == NOT_YET) && (count[s] <= lowOne)) { norm[s] = 1; distributed++; total -= count[s]; } }
-        toDist = (1u << tableLog) - distributed;
+    g.sync();
+    u32 settled = ZJ_UNI(red[0]), left = total - ZJ_UNI(red[1]);
+    u32 cells = size - settled;
+    if (cells == 0) return true;
+    if (left / cells > oneUpTo) {                                   // the open symbols average more than the bar: raise it once
+        oneUpTo = (u32)(((u64)left * 3u) / (cells * 2u));
+        GRP_FOR(g, s, n) { u32 const c = count[s]; if (share[s] == -2 && c <= oneUpTo) { share[s] = 1; atomicAdd(&red[2], 1u); atomicAdd(&red[3], c); } }
+        g.sync();
+        settled += ZJ_UNI(red[2]); left -= ZJ_UNI(red[3]); cells = size - settled;
     }
-    if (distributed == maxSV + 1) {
-        u32 maxV = 0, maxC = 0;
-        for (s = 0; s <= maxSV; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
-        norm[maxV] += (short)toDist;
+    if (settled == n) {                                             // every symbol settled: the first most frequent one takes what is left
+        GRP_FOR(g, s, n) atomicMax(&red[4], (count[s] << 6) | (63u - s));
+        g.sync();
+        GRP_SERIAL(g) { u32 const s = 63u - (red[4] & 63u); share[s] = (short)(share[s] + (i32)cells); }
+        g.sync();
         return true;
     }
-    if (total == 0) {
-        for (s = 0; toDist > 0; s = (s + 1) % (maxSV + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+    if (left == 0) {                                                // nothing open: the cells go round the symbols that have a positive share
+        GRP_FOR(g, s, 64u) pre[s] = (s < n && share[s] > 0) ? 1u : 0u;
+        g.sync();
+        grp_scan_incl(g, pre, 64u);
+        u32 const holders = ZJ_UNI(pre[63]);
+        GRP_FOR(g, s, n) if (share[s] > 0) { u32 const rank = pre[s] - 1u; share[s] = (short)(share[s] + (i32)(cells / holders) + (rank < cells % holders ? 1 : 0)); }
+        g.sync();
         return true;
     }
-    {   u64 const vStepLog = 62 - tableLog; u64 const mid = (1ULL << (vStepLog - 1)) - 1;
-        u64 const rStep = ((((u64)1 << vStepLog) * toDist) + mid) / total;
-        u64 tmpTotal = mid;
-        for (s = 0; s <= maxSV; s++) {
-            if (norm[s] == NOT_YET) {
-                u64 const end = tmpTotal + (count[s] * rStep);
-                u32 const weight = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
-                if (weight < 1) return false;
-                norm[s] = (short)weight; tmpTotal = end;
-            }
+    {   // open symbols share the cells in proportion: a symbol's share = the cells its interval of the running total covers
+        u32 const fracBits = 62u - tableLog; u64 const half = ((u64)1 << (fracBits - 1u)) - 1u;
+        u64 const perCount = ((((u64)1 << fracBits) * cells) + half) / left;
+        GRP_FOR(g, s, 64u) pre[s] = (s < n && share[s] == -2) ? count[s] : 0u;
+        g.sync();
+        grp_scan_incl(g, pre, 64u);
+        GRP_FOR(g, s, n) if (share[s] == -2) {
+            u64 const hi = half + (u64)pre[s] * perCount, lo = half + (u64)(pre[s] - count[s]) * perCount;
+            u32 const w = (u32)(hi >> fracBits) - (u32)(lo >> fracBits);
+            if (w < 1u) atomicOr(&red[0], 0x80000000u);
+            share[s] = (short)w;
         }
+        g.sync();
+        return !(ZJ_UNI(red[0]) & 0x80000000u);
     }
+}
+
+// share[s] of the 2^tableLog cells for every symbol s <= maxSV with count[s] occurrences out of `total` (low: symbols at or below the floor
+// get -1, "less than one cell", instead of 1).  false: no valid table (the reference reports an error).
+template <class G>
+ZJ_DEV bool ze_tans_shares(const G& g, short* share, u32 tableLog, const u32* count, u32 total, u32 maxSV, bool low, u32* scr) {
+    u32* const red = scr + 128;
+    u32 const n = maxSV + 1u;
+    i32 const lowShare = low ? -1 : 1;
+    u32 const fracBits = 62u - tableLog, lowUpTo = total >> tableLog;
+    u64 const perCount = ((u64)1 << 62) / total, roundUnit = (u64)1 << (fracBits - 20u);
+    GRP_SERIAL(g) { red[0] = 0; red[1] = 63u; }                     // cells handed out; largest share << 6 | 63 - its (first) symbol
+    g.sync();
+    GRP_FOR(g, s, n) {
+        u32 const c = count[s]; i32 v = 0;
+        if (c != 0 && c <= lowUpTo) { v = lowShare; atomicAdd(&red[0], 1u); }
+        else if (c != 0) {
+            u64 const x = (u64)c * perCount;
+            u32 w = (u32)(x >> fracBits);
+            if (w < 8u) w += (x - ((u64)w << fracBits) > roundUnit * ze_k_share_round[w]) ? 1u : 0u;      // small shares round up past a share-dependent bar
+            v = (i32)w;
+            atomicAdd(&red[0], w); atomicMax(&red[1], (w << 6) | (63u - s));
+        }
+        share[s] = (short)v;
+    }
+    g.sync();
+    u32 const top = 63u - (ZJ_UNI(red[1]) & 63u);
+    i32 const surplus = (i32)(1u << tableLog) - (i32)ZJ_UNI(red[0]);    // what rounding left over (or overdrew): the largest share absorbs it
+    if (-surplus >= ((i32)share[top] >> 1)) { g.sync(); return ze_tans_shares_rare(g, share, tableLog, count, total, maxSV, lowShare, scr); }
+    g.sync();
+    GRP_SERIAL(g) { share[top] = (short)(share[top] + surplus); }
+    g.sync();
     return true;
 }
 
-ZJ_DEV bool ze_fse_normalize(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSV, bool useLowProb) {   // fse_compress.c:465-523
-    short const lowProb = useLowProb ? -1 : 1;
-    u64 const scale = 62 - tableLog; u64 const step = ((u64)1 << 62) / total; u64 const vStep = 1ULL << (scale - 20);
-    i32 still = 1 << tableLog; u32 s, largest = 0; short largestP = 0; u32 const lowThreshold = total >> tableLog;
-    for (s = 0; s <= maxSV; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = lowProb; still--; }
-        else {
-            short proba = (short)((count[s] * step) >> scale);
-            if (proba < 8) { u64 const restToBeat = vStep * ze_k_rtb[proba]; proba += (count[s] * step) - ((u64)proba << scale) > restToBeat; }
-            if (proba > largestP) { largestP = proba; largest = s; }
-            norm[s] = proba; still -= proba;
-        }
+// One symbol's field of the table description: `before` = cells left (+1) when the description reaches it.  A symbol behind zeros carries their run length in
+// front of its own value (the first zero of the group is a field of its own; the run counts the others: 24 per 0xFFFF, 3 per "11", then two bits).
+ZJ_DEV u32 ze_tans_field(const short* share, u32 s, u32 before, u32 size, u64& f) {
+    i32 const v = share[s];
+    bool const follows0 = s > 0u && share[s - 1u] == 0;
+    if (before <= 1u || (v == 0 && follows0)) { f = 0; return 0; }
+    u32 const thr = zj_min(size, 1u << zj_hibit(before)), nb = zj_hibit(thr) + 1u, spare = 2u * thr - 1u - before;
+    u32 c = (u32)(v + 1);
+    if (c >= thr) c += spare;
+    u32 l = nb - (c < spare ? 1u : 0u);
+    f = c;
+    if (follows0) {
+        u32 z = s - 1u; while (z > 0u && share[z - 1u] == 0) z--;
+        u32 const run = s - 1u - z, ones = 16u * (run / 24u) + 2u * ((run % 24u) / 3u);
+        f = (((u64)1 << ones) - 1u) | ((u64)((run % 24u) % 3u) << ones) | (f << (ones + 2u));
+        l += ones + 2u;
     }
-    if (-still >= (norm[largest] >> 1)) return ze_fse_normalize_m2(norm, tableLog, count, total, maxSV, lowProb);
-    norm[largest] += (short)still;
-    return true;
+    return l;
+}
+// The table description (NCount) of share[0..maxSV] into `out` (LDS, 4-byte aligned, 128 bytes, cleared here).  Returns its size in bytes, 0 when the
+// shares do not add up; *need = the bytes of destination the reference's writer asks for (its stores are two bytes wide, the last one decides).
+template <class G>
+ZJ_DEV u32 ze_tans_describe(const G& g, u8* out, const short* share, u32 maxSV, u32 tableLog, u32* scr, u32* need = nullptr) {
+    u32* const pre = scr; u32* const width = scr + 64; u32* const w32 = (u32*)out;
+    u32 const n = maxSV + 1u, size = 1u << tableLog;
+    GRP_FOR(g, s, 64u) { i32 const v = s < n ? (i32)share[s] : 0; pre[s] = (u32)(v < 0 ? -v : v); }
+    GRP_FOR(g, i, 32u) w32[i] = 0;
+    g.sync();
+    grp_scan_incl(g, pre, 64u);
+    GRP_FOR(g, s, 64u) {
+        u64 f; u32 l = 0;
+        if (s < n) { i32 const v = share[s]; l = ze_tans_field(share, s, size + 1u - (pre[s] - (u32)(v < 0 ? -v : v)), size, f); }
+        width[s] = l;
+    }
+    g.sync();
+    grp_scan_incl(g, width, 64u);
+    GRP_FOR(g, s, n) {                                              // every field at the prefix sum of the widths, behind the 4 bits of the table log
+        u64 f; i32 const v = share[s];
+        u32 const l = ze_tans_field(share, s, size + 1u - (pre[s] - (u32)(v < 0 ? -v : v)), size, f);
+        if (l) ze_or_bits(w32, 4u + width[s] - l, f, 0, l);
+    }
+    GRP_SERIAL(g) { ze_or_bits(w32, 0, tableLog - 5u, 0, 4u); }
+    g.sync();
+    u32 const bitsAll = 4u + ZJ_UNI(width[63]);
+    if (size + 1u - ZJ_UNI(pre[63]) != 1u) return 0;              // the shares have to cover the table exactly
+    if (need) *need = 2u * ((bitsAll - 1u) / 16u) + 2u;
+    return (bitsAll + 7u) >> 3;
 }
 
-// `need` (optional) = bytes of buffer the reference's writer wants: its stores are two bytes wide and each is refused when fewer than two
-// bytes are left (`out > oend - 2`, fse_compress.c:268-321) — the last store decides, and it can reach one byte past the description.
-ZJ_DEV u32 ze_fse_write_ncount(u8* out0, const short* norm, u32 maxSV, u32 tableLog, u32* need = nullptr) {   // fse_compress.c:237-328
-    u8* out = out0; i32 nbBits; i32 const tableSize = 1 << tableLog; i32 remaining, threshold;
-    u32 bitStream = 0; i32 bitCount = 0; u32 symbol = 0; u32 const alphabetSize = maxSV + 1; bool previousIs0 = false;
-    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
-    remaining = tableSize + 1; threshold = tableSize; nbBits = (i32)tableLog + 1;
-    while ((symbol < alphabetSize) && (remaining > 1)) {
-        if (previousIs0) {
-            u32 start = symbol;
-            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
-            if (symbol == alphabetSize) break;
-            while (symbol >= start + 24) { start += 24; bitStream += 0xFFFFU << bitCount; out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; }
-            while (symbol >= start + 3) { start += 3; bitStream += 3U << bitCount; bitCount += 2; }
-            bitStream += (symbol - start) << bitCount; bitCount += 2;
-            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+// The encoding table of share[0..maxSV] (state table + per-symbol transforms).  tableSymbol: 2^tableLog bytes of LDS; bm: LDS words for the rank bitmaps,
+// (maxSV + 1) * max(1, 2^tableLog / 32) of them.  `ct` may be in LDS or HBM.
+template <class G>
+ZJ_DEV void ze_tans_table(const G& g, ZEFseCT& ct, const short* share, u32 maxSV, u32 tableLog, u8* tableSymbol, u32* scr, u32* bm) {
+    u32* const all = scr; u32* const pos = scr + 64; u32* const part = scr + 128;      // cells of symbols <= s (low ones count 1) / of the spread symbols <= s
+    u32 const n = maxSV + 1u, size = 1u << tableLog, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    u32 const bmWords = size >= 32u ? size >> 5 : 1u;
+    GRP_FOR(g, s, 64u) { i32 const v = s < n ? (i32)share[s] : 0; all[s] = (u32)(v < 0 ? 1 : v); pos[s] = (u32)(v > 0 ? v : 0); }
+    GRP_FOR(g, i, n * bmWords) bm[i] = 0;
+    g.sync();
+    grp_scan_incl(g, all, 64u);
+    grp_scan_incl(g, pos, 64u);
+    u32 const nLow = ZJ_UNI(all[63]) - ZJ_UNI(pos[63]), high = size - 1u - nLow;
+    GRP_SERIAL(g) { ct.tableLog = tableLog; }
+    // per symbol: its transforms, and a low-probability symbol's reserved position at the top of the table (in symbol order, downwards)
+    GRP_FOR(g, s, n) {
+        i32 const v = share[s]; u32 const cells = (u32)(v < 0 ? 1 : v), first = all[s] - cells;
+        if (v == 0) { ct.deltaNbBits[s] = ((tableLog + 1u) << 16) - size; ct.deltaFind[s] = 0; }
+        else if (cells == 1u) { ct.deltaNbBits[s] = (tableLog << 16) - size; ct.deltaFind[s] = (i32)(first - 1u); }
+        else { u32 const outBits = tableLog - zj_hibit(cells - 1u); ct.deltaNbBits[s] = (outBits << 16) - (cells << outBits); ct.deltaFind[s] = (i32)(first - cells); }
+        if (v == -1) tableSymbol[size - 1u - ((first) - (pos[s]))] = (u8)s;           // first - pos[s] = low symbols before s
+    }
+    // the spread: visit k * step mod size for k = 0, 1, ...; the j-th visited position at or below `high` takes occurrence j.
+    // A lane takes `per` consecutive visits; with reserved positions its first j is the count of accepted visits before its chunk.
+    u32 const per = (size + 63u) >> 6;
+    if (nLow) {
+        GRP_FOR(g, l, 64u) { u32 c = 0; for (u32 k = l * per; k < (l + 1u) * per && k < size; k++) c += (((k * step) & mask) <= high) ? 1u : 0u; part[l] = c; }
+        g.sync();
+        grp_scan_incl(g, part, 64u);                                // (inclusive: part[l - 1] visits accepted before lane l's chunk)
+    }
+    g.sync();
+    GRP_FOR(g, l, 64u) {
+        u32 j = nLow ? (l ? part[l - 1u] : 0u) : l * per;
+        for (u32 k = l * per; k < (l + 1u) * per && k < size; k++) {
+            u32 const p = (k * step) & mask;
+            if (p > high) continue;
+            u32 lo = 0, hi = n - 1u;                                // the symbol whose occurrences include j: the first s with pos[s] > j
+            while (lo < hi) { u32 const mid = (lo + hi) >> 1; if (pos[mid] > j) hi = mid; else lo = mid + 1u; }
+            tableSymbol[p] = (u8)lo;
+            j++;
         }
-        {   i32 count = norm[symbol++]; i32 const max = (2 * threshold - 1) - remaining;
-            remaining -= count < 0 ? -count : count;
-            count++;
-            if (count >= threshold) count += max;
-            bitStream += (u32)count << bitCount; bitCount += nbBits; bitCount -= (count < max);
-            previousIs0 = (count == 1);
-            if (remaining < 1) return 0;
-            while (remaining < threshold) { nbBits--; threshold >>= 1; }
-        }
-        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
     }
-    if (remaining != 1) return 0;
-    if (need) *need = (u32)(out - out0) + 2u;
-    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += (bitCount + 7) / 8;
-    return (u32)(out - out0);
-}
-
-// FSE_buildCTable_wksp (fse_compress.c:68-224); cumul/tableSymbol are LDS scratch
-ZJ_DEV void ze_fse_build_ctable(ZEFseCT& ct, const short* norm, u32 maxSV, u32 tableLog, u16* cumul, u8* tableSymbol) {
-    u32 const size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
-    u32 high = size - 1, pos = 0;
-    ct.tableLog = tableLog;
-    cumul[0] = 0;
-    for (u32 u = 1; u <= maxSV + 1; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[high--] = (u8)(u - 1); }
-        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    g.sync();
+    // state table: positions in increasing order fill their symbol's slots in turn
+    GRP_FOR(g, u, size) { u32 const sy = tableSymbol[u]; atomicOr(&bm[sy * bmWords + (u >> 5)], 1u << (u & 31u)); }
+    g.sync();
+    GRP_FOR(g, u, size) {
+        u32 const sy = tableSymbol[u]; const u32* const b = bm + sy * bmWords;
+        u32 rank = (u32)__builtin_popcount(b[u >> 5] & ((1u << (u & 31u)) - 1u));
+        for (u32 w = 0; w < (u >> 5); w++) rank += (u32)__builtin_popcount(b[w]);
+        i32 const v = share[sy]; u32 const cells = (u32)(v < 0 ? 1 : v);
+        ct.state[all[sy] - cells + rank] = (u16)(size + u);
     }
-    cumul[maxSV + 1] = (u16)(size + 1);
-    for (u32 s = 0; s <= maxSV; s++) {
-        for (i32 i = 0; i < norm[s]; i++) { tableSymbol[pos] = (u8)s; do { pos = (pos + step) & mask; } while (pos > high); }
-    }
-    for (u32 u = 0; u < size; u++) { u32 const sy = tableSymbol[u]; ct.state[cumul[sy]++] = (u16)(size + u); }
-    u32 total = 0;
-    for (u32 s = 0; s <= maxSV; s++) {
-        i32 const nv = norm[s];
-        if (nv == 0) { ct.deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct.deltaFind[s] = 0; }
-        else if (nv == -1 || nv == 1) { ct.deltaNbBits[s] = (tableLog << 16) - (1u << tableLog); ct.deltaFind[s] = (i32)(total - 1); total++; }
-        else { u32 const maxBitsOut = tableLog - zj_hibit((u32)nv - 1); u32 const minStatePlus = (u32)nv << maxBitsOut;
-               ct.deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus; ct.deltaFind[s] = (i32)(total - (u32)nv); total += (u32)nv; }
-    }
+    g.sync();
 }
 
 // forward bit writer (BIT_CStream_t semantics, N/common/bitstream.h:180-250) over global memory
@@ -1142,55 +1252,74 @@ ZJ_DEV u32 ze_huf_build_wave(const G& g, ZEncShared& sh, ZEEntropy& e, u32 maxSV
     return maxNbBits;
 }
 
-// HUF_compressWeights (huf_compress.c:132-176): 0 not compressible, 1 rle, else size.
-// `cap` = the room the reference's call is given (everything left of the block's destination): *tight |= 1 when its table description
-// does not fit (an error there), *tight |= 2 when its bit stream does not (8 bytes of slack: BIT_initCStream / BIT_closeCStream,
+// HUF_compressWeights (huf_compress.c:132-176): 0 not compressible, 1 rle, else size.  Called by every lane, the result is wave-uniform: the statistics and the
+// tANS table of the weights by the wave (ze_tans_*), the two-state encode of the <= 255 weights on one lane.
+// `cap` = the room the reference's call is given (everything left of the block's destination): tight |= 1 when its table description
+// does not fit (an error there), tight |= 2 when its bit stream does not (8 bytes of slack: BIT_initCStream / BIT_closeCStream,
 // bitstream.h:177-186, 258-267 — "not compressible" there, i.e. the raw weights follow).  The bytes written here do not depend on `cap`.
-ZJ_DEV u32 ze_huf_compress_weights(ZEEntropy& e, u8* dst, u32 wtSize, u32 cap = 0xFFFFFFFFu, u32* tight = nullptr) {
-    const u8* const w = e.weight; u32* const count = e.scount; short* const norm = e.norm; u32 maxSV = 0, maxCount = 0; u8* op = dst;
+template <class G>
+ZJ_DEV u32 ze_huf_compress_weights(const G& g, ZEEntropy& e, u8* dst, u32 wtSize, u32 cap, u32& tight) {
+    const u8* const w = e.weight; u32* const count = e.scount; short* const share = e.norm;
+    u32* const scr = (u32*)e.rankBase; u32* const uni = scr + 160;        // (rankBase / rankCurr: the Huffman build is done with them)
+    u8* const desc = (u8*)&e.node[0]; u32* const bm = (u32*)&e.node[0] + 32;   // (so is the tree)
     if (wtSize <= 1) return 0;
-    for (u32 s = 0; s <= 12; s++) count[s] = 0;
-    for (u32 s = 0; s < wtSize; s++) count[w[s]]++;
-    for (u32 s = 0; s <= 12; s++) { if (count[s]) maxSV = s; if (count[s] > maxCount) maxCount = count[s]; }
+    GRP_FOR(g, s, 16u) count[s] = 0;
+    GRP_SERIAL(g) { uni[0] = 0; uni[1] = 0; uni[2] = 0; uni[3] = 0; }
+    g.sync();
+    GRP_FOR(g, i, wtSize) atomicAdd(&count[w[i]], 1u);
+    g.sync();
+    GRP_FOR(g, s, 13u) { u32 const c = count[s]; if (c) { atomicMax(&uni[0], s); atomicMax(&uni[1], c); } }
+    g.sync();
+    u32 const maxSV = ZJ_UNI(uni[0]), maxCount = ZJ_UNI(uni[1]);
     if (maxCount == wtSize) return 1;
     if (maxCount == 1) return 0;
     u32 const tableLog = ze_fse_optimal_log(6, wtSize, maxSV, 2);
-    if (!ze_fse_normalize(norm, tableLog, count, wtSize, maxSV, false)) return 0;
-    {   u32 need = 0; u32 const h = ze_fse_write_ncount(op, norm, maxSV, tableLog, &need); if (!h) return 0; op += h;
-        if (tight && need > cap) *tight |= 1u; }
+    if (!ze_tans_shares(g, share, tableLog, count, wtSize, maxSV, false, scr)) return 0;
+    u32 need = 0;
+    u32 const h = ze_tans_describe(g, desc, share, maxSV, tableLog, scr, &need);
+    if (!h) return 0;
+    GRP_FOR(g, i, h) dst[i] = desc[i];
+    if (need > cap) tight |= 1u;
+    g.sync();
     ZEFseCT& ct = e.ct[0];
-    ze_fse_build_ctable(ct, norm, maxSV, tableLog, e.cumul, e.tableSymbol);
-    {   const u8* ip = w + wtSize; ZEBitW b; ZEFseCS s1, s2; u32 n = wtSize; u8* const bstart = op;   // fse_compress.c:549-606
-        if (n <= 2) return 0;
-        b.p = op; b.acc = 0; b.n = 0;
-        if (n & 1) { ze_fse_init2(s1, ct, *--ip); ze_fse_init2(s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
-        else { ze_fse_init2(s2, ct, *--ip); ze_fse_init2(s1, ct, *--ip); }
-        n -= 2;
-        if (n & 2) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
-        while (ip > w) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
-        ze_bw_add(b, s2.value, ct.tableLog); ze_bw_add(b, s1.value, ct.tableLog);
-        if (tight) {                                              // whole bytes before the end mark's byte must stay 8 short of the end
-            u32 const used = (u32)(bstart - dst), fullBytes = (u32)((((u64)(b.p - bstart)) * 8u + b.n + 1u) >> 3);
-            if (cap < used + 9u || fullBytes + 8u >= cap - used) *tight |= 2u;
+    ze_tans_table(g, ct, share, maxSV, tableLog, e.tableSymbol, scr, bm);
+    GRP_SERIAL(g) {                                               // fse_compress.c:549-606: two interleaved states, last weight first
+        u8* const bstart = dst + h; const u8* ip = w + wtSize; ZEBitW b; ZEFseCS s1, s2; u32 n = wtSize; u32 out = 0, tg = 0;
+        if (n > 2) {
+            b.p = bstart; b.acc = 0; b.n = 0;
+            if (n & 1) { ze_fse_init2(s1, ct, *--ip); ze_fse_init2(s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+            else { ze_fse_init2(s2, ct, *--ip); ze_fse_init2(s1, ct, *--ip); }
+            n -= 2;
+            if (n & 2) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+            while (ip > w) { ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); ze_fse_encode(b, s2, ct, *--ip); ze_fse_encode(b, s1, ct, *--ip); }
+            ze_bw_add(b, s2.value, ct.tableLog); ze_bw_add(b, s1.value, ct.tableLog);
+            {   u32 const fullBytes = (u32)((((u64)(b.p - bstart)) * 8u + b.n + 1u) >> 3);      // whole bytes before the end mark's byte must stay 8 short of the end
+                if (cap < h + 9u || fullBytes + 8u >= cap - h) tg = 2u; }
+            out = h + ze_bw_close(b, bstart);
         }
-        op = bstart + ze_bw_close(b, bstart);
+        uni[2] = out; uni[3] = tg;
     }
-    return (u32)(op - dst);
+    g.sync();
+    tight |= ZJ_UNI(uni[3]);
+    return ZJ_UNI(uni[2]);
 }
 
 // HUF_writeCTable_wksp (huf_compress.c:248-290); 0 on failure.  `cap` / `tight`: the reference's maxDstSize, and whether it would have
-// run out of it on the way to these bytes (the caller then treats the block as the reference does: not compressible)
-ZJ_DEV u32 ze_huf_write_ctable(ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog, u32 cap = 0xFFFFFFFFu, bool* tight = nullptr) {
-    for (u32 n = 0; n < maxSV; n++) e.weight[n] = e.nbBits[n] ? (u8)(huffLog + 1 - e.nbBits[n]) : 0;
+// run out of it on the way to these bytes (the caller then treats the block as the reference does: not compressible).  By every lane; wave-uniform result.
+template <class G>
+ZJ_DEV u32 ze_huf_write_ctable(const G& g, ZEEntropy& e, u8* op, u32 maxSV, u32 huffLog, u32 cap, bool& tight) {
+    GRP_FOR(g, n, maxSV) e.weight[n] = e.nbBits[n] ? (u8)(huffLog + 1 - e.nbBits[n]) : 0;
+    g.sync();
     {   u32 tw = 0;
-        u32 const h = ze_huf_compress_weights(e, op + 1, maxSV, cap ? cap - 1u : 0u, tight ? &tw : nullptr);
-        if (tight && (cap < 1u || (tw & 1u))) *tight = true;
-        if ((h > 1) & (h < maxSV / 2)) { if (tight && tw) *tight = true; op[0] = (u8)h; return h + 1; } }
-    if (tight && ((maxSV + 1) / 2) + 1 > cap) *tight = true;
+        u32 const h = ze_huf_compress_weights(g, e, op + 1, maxSV, cap ? cap - 1u : 0u, tw);
+        if (cap < 1u || (tw & 1u)) tight = true;
+        if ((h > 1) & (h < maxSV / 2)) { if (tw) tight = true; GRP_SERIAL(g) { op[0] = (u8)h; } return h + 1; } }
+    if (((maxSV + 1) / 2) + 1 > cap) tight = true;
     if (maxSV > 128) return 0;
-    op[0] = (u8)(128 + (maxSV - 1));
-    e.weight[maxSV] = 0;
-    for (u32 n = 0; n < maxSV; n += 2) op[(n / 2) + 1] = (u8)((e.weight[n] << 4) + e.weight[n + 1]);
+    g.sync();
+    GRP_SERIAL(g) { op[0] = (u8)(128 + (maxSV - 1)); e.weight[maxSV] = 0; }
+    g.sync();
+    GRP_FOR(g, k, (maxSV + 1u) / 2u) op[k + 1u] = (u8)((e.weight[2u * k] << 4) + e.weight[2u * k + 1u]);
     return ((maxSV + 1) / 2) + 1;
 }
 
@@ -1214,22 +1343,6 @@ ZJ_DEV void ze_huf_encode_stream(const ZEEntropy& e, u8* dst, const u8* lit, u32
 // the wave flushes the completed 32-bit words to HBM and carries the partial word over.
 struct ZEStageBits { u32* w; u8* dst; u32 flushedWords; u32 carryBits; };   // wave-uniform
 
-ZJ_DEV void ze_or_bits(u32* w, u32 bitpos, u64 lo, u64 hi, u32 nbits) {    // OR nbits (<=128) of {hi:lo} at bitpos
-    u32 idx = bitpos >> 5; u32 const sh = bitpos & 31;
-    // shift the 128-bit value left by sh (<32) into 160 bits = 5 words
-    u32 const v0 = (u32)lo, v1 = (u32)(lo >> 32), v2 = (u32)hi, v3 = (u32)(hi >> 32);
-    u32 const o0 = v0 << sh;
-    u32 const o1 = sh ? ((v1 << sh) | (v0 >> (32 - sh))) : v1;
-    u32 const o2 = sh ? ((v2 << sh) | (v1 >> (32 - sh))) : v2;
-    u32 const o3 = sh ? ((v3 << sh) | (v2 >> (32 - sh))) : v3;
-    u32 const o4 = sh ? (v3 >> (32 - sh)) : 0;
-    u32 const words = (sh + nbits + 31) >> 5;
-    if (words > 0 && o0) atomicOr(&w[idx], o0);
-    if (words > 1 && o1) atomicOr(&w[idx + 1], o1);
-    if (words > 2 && o2) atomicOr(&w[idx + 2], o2);
-    if (words > 3 && o3) atomicOr(&w[idx + 3], o3);
-    if (words > 4 && o4) atomicOr(&w[idx + 4], o4);
-}
 
 // flush the words completed by `addBits` new bits; keeps the partial word as the new word 0
 template <class G>
@@ -1646,15 +1759,17 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 g.sync();
                 u32 huffLogBuilt = 0;
                 if (ZJ_UNI(sh.tmp[0])) huffLogBuilt = ze_huf_build_wave(g, sh, e, ZJ_UNI(sh.tmp[6]), ze_fse_optimal_log(11, n, ZJ_UNI(sh.tmp[6]), 1));
+                u32 hTab = 0;
+                if (ZJ_UNI(sh.tmp[0])) {                                         // the table's description: weights, their tANS table and code by the wave
+                    bool tg = false;
+                    hTab = ze_huf_write_ctable(g, e, body + lhSize, ZJ_UNI(sh.tmp[6]), huffLogBuilt, capBody > lhSize ? capBody - lhSize : 0u, tg);
+                    GRP_SERIAL(g) { if (tg) sh.tightHuf = 1; sh.ctDict[0] = 0; }  // (the weights' tANS table went through e.ct[0])
+                    g.sync();
+                }
                 GRP_SERIAL(g) {
                     u32 const maxSV = sh.tmp[6];
-                    u32 m = sh.tmp[1], h = 0; u32 const rep = sh.tmp[2]; bool useOld = sh.tmp[3] != 0;
+                    u32 m = sh.tmp[1], h = hTab; u32 const rep = sh.tmp[2]; bool useOld = sh.tmp[3] != 0;
                     if (sh.tmp[0]) {
-                        u32 const huffLog = huffLogBuilt;
-                        {   bool tg = false;
-                            h = ze_huf_write_ctable(e, body + lhSize, maxSV, huffLog, capBody > lhSize ? capBody - lhSize : 0u, &tg);
-                            if (tg) sh.tightHuf = 1; }
-                        sh.ctDict[0] = 0;                                     // the weights' tANS table went through e.ct[0]
                         if (!h) m = 0;
                         else {
                             if (rep != ZC_REPEAT_NONE) {                      // is the dictionary's table at least as good?
@@ -1762,24 +1877,29 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                 g.sync();
                 GRP_FOR(g, i, nbSeq) { ZESeq const s = seqs[i]; atomicAdd(&cnt3[s.ll >> 24], 1u); atomicAdd(&cnt3[64 + (s.off >> 24)], 1u); atomicAdd(&cnt3[128 + (s.ml >> 24)], 1u); }
                 g.sync();
-                // ZSTD_buildSequencesStatistics: the three tables (LL, OF, ML) are independent — normalisation, table description and
-                // encoding table each into scratch of its own in the idle tree area; what depends on the ORDER — where a description
-                // lands in the block, the capacity tests there, "last count" — follows.  One lane does all three: with a lane per table
-                // (lane t = table t) this phase fell 39 -> 31 K cycles a frame, but the divergent table index cost the kernel 50 VGPRs
-                // (174 -> 223, two waves a SIMD instead of three) and the match kernel running BESIDE it lost its co-residency: whole
-                // calls got 8-17 % slower (profiles/r03/i_entropy_vgpr_ab.txt).
-                struct ZESeqScr { short norm[64]; u16 cumul[64]; u8 tableSymbol[512]; u8 ncount[128]; u32 need, h, type, first; };
-                ZESeqScr* const scr = (ZESeqScr*)e.node;                      // 3 x 912 bytes of the 4 128 (the Huffman tree is done with)
-                GRP_SERIAL(g) for (u32 t = 0; t < 3u; t++) {
+                // ZSTD_buildSequencesStatistics: the three tables (LL, OF, ML) are independent — shares, table description and encoding table each
+                // into scratch of its own in the idle tree area; what depends on the ORDER — where a description lands in the block, the capacity
+                // tests there, "last count" — follows.  Each table is built by the whole wave (ze_tans_*: a symbol per lane, prefix sums and
+                // reductions in LDS); the choice of the encoding type is a handful of scalar decisions every lane makes alike.  (Round 3 had one
+                // lane build all three: 31-39 K cycles a frame; a lane per table cost 50 VGPRs and the co-residency with the match kernel,
+                // profiles/r03/i_entropy_vgpr_ab.txt.)
+                struct ZESeqScr { short norm[64]; u16 cumul[64]; u8 tableSymbol[512]; u8 ncount[128]; u32 need, h, type, first, max, most; };
+                ZESeqScr* const scr = (ZESeqScr*)e.node;                      // 3 x 920 bytes of the 4 128 (the Huffman tree is done with)
+                u32* const tscr = (u32*)e.rankBase;                           // ZE_TANS_SCR words (rankBase / rankCurr: done with as well)
+                u32* const tbm = &e.hist[1][0];                               // rank bitmaps: hist[1..3] + count, 1 024 words (the literals are encoded)
+                for (u32 t = 0; t < 3u; t++) {
                     ZESeqScr& q = scr[t];
                     u32* const scount = cnt3 + 64 * t;
                     u32 const maxSym = t == 0 ? 35u : (t == 1 ? 31u : 52u), fseLog = t == 1 ? 8u : 9u, defLog = t == 1 ? 5u : 6u;
                     const short* const defNorm = t == 0 ? ze_k_ll_defnorm : (t == 1 ? ze_k_of_defnorm : ze_k_ml_defnorm);
                     u32 const defMax = t == 0 ? 35u : (t == 1 ? 28u : 52u);
-                    u32 max = 0, most = 0;
-                    for (u32 s = 0; s <= maxSym; s++) { if (scount[s]) max = s; most = zj_max(most, scount[s]); }
+                    GRP_SERIAL(g) { q.max = 0; q.most = 0; }
+                    g.sync();
+                    GRP_FOR(g, s, maxSym + 1u) { u32 const c = scount[s]; if (c) { atomicMax(&q.max, s); atomicMax(&q.most, c); } }
+                    g.sync();
+                    u32 const max = ZJ_UNI(q.max), most = ZJ_UNI(q.most);
                     bool const defaultAllowed = (t != 1) || (max <= 28);
-                    u32 const fseRep = cd ? sh.dictFseRep[t] : ZC_REPEAT_NONE;
+                    u32 const fseRep = cd ? ZJ_UNI(sh.dictFseRep[t]) : ZC_REPEAT_NONE;
                     u32 type;                                              // ZSTD_selectEncodingType, strategy < lazy; 3 = the dictionary's table (set_repeat)
                     if (most == nbSeq) type = (defaultAllowed && nbSeq <= 2) ? 0 : 1;
                     else if (defaultAllowed && fseRep == ZC_REPEAT_VALID && nbSeq < 1000) type = 3;
@@ -1790,35 +1910,39 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
                         // strategy >= lazy: the cheapest of predefined / new table by estimated cost (zstd_compress_sequences.c:196-222; no
                         // previous table here: these levels are served without a dictionary and one block per frame).  An impossible choice
                         // costs ERROR(GENERIC) = all ones there, the same here.
-                        u64 const none = ~(u64)0;
-                        u64 basicCost = none;
-                        if (defaultAllowed) {                                                              // ZSTD_crossEntropyCost(defaultNorm, defaultNormLog, count, max)
-                            u32 const shift = 8u - defLog; u64 c = 0;
-                            for (u32 s = 0; s <= max; s++) { u32 const na = defNorm[s] != -1 ? (u32)defNorm[s] : 1u; c += (u64)scount[s] * ze_k_invprob[na << shift]; }
-                            basicCost = c >> 8;
-                        }
-                        u64 compressedCost;
-                        {   u32 const tl = ze_fse_optimal_log(fseLog, nbSeq, max, 2);                      // ZSTD_NCountCost
-                            u64 ncount = none;
-                            if (ze_fse_normalize(q.norm, tl, scount, nbSeq, max, nbSeq >= 2048)) { u32 const hb = ze_fse_write_ncount(q.ncount, q.norm, max, tl); ncount = hb ? (u64)hb : none; }
+                        u32 hb = 0;                                                                        // ZSTD_NCountCost: the size of the description a new table would need
+                        {   u32 const tl = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
+                            if (ze_tans_shares(g, q.norm, tl, scount, nbSeq, max, nbSeq >= 2048, tscr)) hb = ze_tans_describe(g, q.ncount, q.norm, max, tl, tscr); }
+                        GRP_SERIAL(g) {
+                            u64 const none = ~(u64)0;
+                            u64 basicCost = none;
+                            if (defaultAllowed) {                                                          // ZSTD_crossEntropyCost(defaultNorm, defaultNormLog, count, max)
+                                u32 const shift = 8u - defLog; u64 c = 0;
+                                for (u32 s = 0; s <= max; s++) { u32 const na = defNorm[s] != -1 ? (u32)defNorm[s] : 1u; c += (u64)scount[s] * ze_k_invprob[na << shift]; }
+                                basicCost = c >> 8;
+                            }
                             u32 cost = 0;                                                                  // ZSTD_entropyCost
                             for (u32 s = 0; s <= max; s++) { u32 nr = (256u * scount[s]) / nbSeq; if (scount[s] != 0 && nr == 0) nr = 1; cost += scount[s] * ze_k_invprob[nr]; }
-                            compressedCost = (ncount << 3) + (u64)(cost >> 8);
+                            u64 const compressedCost = ((hb ? (u64)hb : none) << 3) + (u64)(cost >> 8);
+                            q.type = (basicCost <= none && basicCost <= compressedCost) ? 0u : 2u;         // (repeatCost = ERROR(GENERIC): basic wins ties against it)
                         }
-                        type = (basicCost <= none && basicCost <= compressedCost) ? 0u : 2u;               // (repeatCost = ERROR(GENERIC): basic wins ties against it)
+                        g.sync();
+                        type = ZJ_UNI(q.type);
                     }
                     u32 h = 0, need = 0;
-                    u32 const lastCode = sh.edge[3 + t], firstCode = sh.edge[t];
-                    if (type == 1) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; h = 1; }
-                    else if (type == 0) ze_fse_build_ctable(e.ct[t], defNorm, defMax, defLog, q.cumul, q.tableSymbol);
+                    if (type == 1) { GRP_SERIAL(g) { ZEFseCT& ct = e.ct[t]; ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.deltaNbBits[max] = 0; ct.deltaFind[max] = 0; } h = 1; }
+                    else if (type == 0) ze_tans_table(g, e.ct[t], defNorm, defMax, defLog, q.tableSymbol, tscr, tbm);
                     else if (type == 2) {
-                        u32 nbSeq1 = nbSeq; u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
-                        if (scount[lastCode] > 1) { scount[lastCode]--; nbSeq1--; }
-                        ze_fse_normalize(q.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048);
-                        h = ze_fse_write_ncount(q.ncount, q.norm, max, tableLog, &need);
-                        ze_fse_build_ctable(e.ct[t], q.norm, max, tableLog, q.cumul, q.tableSymbol);
+                        u32 const tableLog = ze_fse_optimal_log(fseLog, nbSeq, max, 2);
+                        u32 const lastCode = ZJ_UNI(sh.edge[3 + t]);
+                        u32 nbSeq1 = nbSeq;
+                        if (ZJ_UNI(scount[lastCode]) > 1u) { g.sync(); GRP_SERIAL(g) { scount[lastCode]--; } nbSeq1--; }     // the last sequence's codes only set the final states
+                        g.sync();
+                        ze_tans_shares(g, q.norm, tableLog, scount, nbSeq1, max, nbSeq1 >= 2048, tscr);
+                        h = ze_tans_describe(g, q.ncount, q.norm, max, tableLog, tscr, &need);
+                        ze_tans_table(g, e.ct[t], q.norm, max, tableLog, q.tableSymbol, tscr, tbm);
                     }
-                    q.type = type; q.h = h; q.need = need; q.first = firstCode;
+                    GRP_SERIAL(g) { q.type = type; q.h = h; q.need = need; q.first = sh.edge[t]; }
                 }
                 g.sync();
                 GRP_SERIAL(g) {
