@@ -654,13 +654,13 @@ __global__ void zj_enc_partition_done_kernel(const u32* countPtr, u32 sharePermi
 // The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_wide_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen) {
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen, u32* doneList, u32* doneCount) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
     // level 3: ZLaneD.  The run machine without flags (zj_need.h's filters are sized for 64 KiB frames) was measured here in round 4 and is not faster on 128 KiB frames:
     // 65 536 x 128 KiB 382-441 ms with ZLaneD, 445-492 ms with ZLaneR (profiles/r04/d_, e_); tests/test_emu_encode.py keeps the machine exact at these sizes.
-    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
-    else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, (u32*)nullptr, (u32*)nullptr);
+    if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
+    else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
 }
 // zero the first `count` slots of `stride` bytes (the table slots of a slice; nothing to do for an empty slice)
 __global__ __launch_bounds__(256) void zj_zero_slots_kernel(u8* base, u32 stride, const u32* countPtr, u32 listBase, u32 sliceLen) {
@@ -1904,8 +1904,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (sliceB > n) sliceB = n;
         if (sliceB < 64) sliceB = 64;
         u32 const strideB = ze_lane_table_stride((u32)levelWord, true);
-        size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12;
-        size_t const needB = tablesB + fsB + metaB + 256;
+        size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12, qB = sliceB * 4;
+        size_t const needB = tablesB + fsB + metaB + 2 * qB + 256;
         if (d->wideBufCap < needB) {
             if (!scratch_make_room(d, d->wideBufCap, needB)) return ZJNI_ERR(64);
             if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
@@ -1913,20 +1913,35 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             d->wideBufCap = needB;
         }
         u8* const tb = d->wideBuf; u8* const fs = d->wideBuf + tablesB; u32* const mt = (u32*)(fs + fsB);
-        u32* const wctr = d->counters + 48;           // [0] match work, [1] entropy work
+        u32* const doneB = (u32*)((u8*)mt + metaB); u32* const procB = doneB + sliceB;      // completion queue of a slice's match kernel, frames the side pass encoded
+        u32* const wctr = d->counters + 48;           // [0] match work, [1] entropy work (queue order), [2] queue length, [3] work of the sweep pass
         u32 const wavesB = (u32)((sliceB + 63) / 64);
         u32 const gridMB = wavesB < (u32)d->matchGrid ? wavesB : (u32)d->matchGrid;
         u32 const gridEB = (u32)(sliceB < (size_t)d->encGridLvl[1] ? sliceB : (size_t)d->encGridLvl[1]);
+        // The entropy kernel BESIDE the match kernel, as on the common path: it takes frames off the completion queue while the slow frames still occupy
+        // their lanes; a sweep pass afterwards takes what it did not get to.  ZJNI_NO_OVERLAP: one after the other (A/B runs).
+        bool const besideB = zj_env("ZJNI_NO_OVERLAP") == nullptr;
         for (size_t base = 0; base < n; base += sliceB) {
-            if (hipMemsetAsync(wctr, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+            if (hipMemsetAsync(wctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_zero_slots_kernel, dim3((u32)d->numCU * 8), dim3(256), 0, st, tb, strideB, (const u32*)(ctr + 1), (u32)base, (u32)sliceB);
+            bool forked = false;
+            if (besideB) {
+                if (hipMemsetAsync(doneB, 0xFF, qB, st) != hipSuccess || hipMemsetAsync(procB, 0, qB, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                forked = hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess;
+            }
             (void)hipEventRecord(d->tev[8], st);
             hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                               (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB);
+                               (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB, forked ? doneB : (u32*)nullptr, forked ? wctr + 2 : (u32*)nullptr);
             (void)hipEventRecord(d->tev[9], st); d->tevWide = true;
+            if (forked) {
+                hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+                                   (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                                   fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, 1u, (const u32*)doneB, procB, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
+                if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) { (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st); return ZJNI_ERR(ZJNI_ERROR_no_device); }
+            }
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
-                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
-                               fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, 0u, (const u32*)nullptr, (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
+                               (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), forked ? wctr + 3 : wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,
+                               fs, (u32)ZE_WIDE_MAX_SRC, (const u32*)mt, forked ? 2u : 0u, (const u32*)(forked ? doneB : nullptr), forked ? procB : (u32*)nullptr, flags, (const ZECDictDev*)nullptr, (u32)sizeof(ZEEntropy), (u32)base, (u32)sliceB);
         }
         return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
     }
