@@ -221,7 +221,8 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
     u8* nflags = nullptr;
     {   ZEParams const p = ze_params_of(lw, srcSize);
         if (level == 3 && wide && getenv("ZJNI_EMU_NEED") && getenv("ZJNI_EMU_NEED")[0] == '7') g_emu_run = 1;      // the wide launch (frames of 64-128 KiB): the run machine without flags
-        if (level == 3 && !wide && getenv("ZJNI_EMU_NEED") && zn_takes(p.hashLog, p.chainLog, srcSize)) {
+        bool const wideFlags = level == 3 && wide && getenv("ZJNI_EMU_NEED") && strchr("568", getenv("ZJNI_EMU_NEED")[0]) && zn_takes_wide(p.hashLog, p.chainLog, srcSize);   // ... with flags (zn_flags_frame_wide), as the wide launch runs it
+        if ((level == 3 && !wide && getenv("ZJNI_EMU_NEED") && zn_takes(p.hashLog, p.chainLog, srcSize)) || wideFlags) {
             struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
             ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0xA5, sizeof(ZNLds));
             nflags = (u8*)malloc(srcSize + ZN_FLAG_SLACK); memset(nflags, 0xFF, srcSize + ZN_FLAG_SLACK);
@@ -229,8 +230,9 @@ extern "C" unsigned long long emu_compress_split(const unsigned char* src, unsig
             g_emu_run = (nm == '5' || nm == '6' || nm == '7' || nm == '8');  // the run machine (zj_match_run.h): 5 flags for every frame, 6 for the picked frames, 7 for none, 8: for every frame but LATE (taken over after a frame-dependent number of rounds, as the match kernel does when the flag kernel is still at work)
             g_emu_late = (nm == '8');
             bool const take = nm != '7' && ((nm != '2' && nm != '6') || zn_worth(one, (u32*)L, src, srcSize));
-            if (take) zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
-            else { free(nflags); nflags = nullptr; g_emu_force_gated = 1; }
+            if (take && wideFlags) zn_flags_frame_wide(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
+            else if (take) zn_flags_frame(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, nflags);
+            else { free(nflags); nflags = nullptr; g_emu_force_gated = wideFlags ? 0 : 1; }
             if (nflags && getenv("ZJNI_EMU_NEED_STATS")) { unsigned c[4] = {0, 0, 0, 0}; for (u32 i = 0; i < srcSize; i++) for (int b = 0; b < 4; b++) c[b] += (nflags[i] >> b) & 1; fprintf(stderr, "need flags of %u positions: needL %u needS %u insL %u insS %u\n", srcSize, c[0], c[1], c[2], c[3]); }
             free(L);
         } }
@@ -426,6 +428,14 @@ extern "C" unsigned emu_lane_rounds(const unsigned char* src, unsigned srcSize, 
 // the flag bytes zn_flags_frame leaves for one frame with the level-3 parameters of its size (tests: they must cover the exact answer)
 extern "C" unsigned emu_need_flags(const unsigned char* src, unsigned srcSize, unsigned char* out, unsigned* params) {
     ZEParams const p = ze_params_of(3u, srcSize);
+    if (zn_takes_wide(p.hashLog, p.chainLog, srcSize)) {
+        struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
+        ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0x5A, sizeof(ZNLds));
+        zn_flags_frame_wide(one, *L, src, srcSize, p.hashLog, p.chainLog, p.minMatch, out);
+        free(L);
+        params[0] = p.hashLog; params[1] = p.chainLog; params[2] = p.minMatch;
+        return 1;
+    }
     if (!zn_takes(p.hashLog, p.chainLog, srcSize)) return 0;
     struct One { u32 id() const { return 0; } u32 count() const { return 1; } void sync() const {} } one;
     ZNLds* L = (ZNLds*)malloc(sizeof(ZNLds)); memset(L, 0x5A, sizeof(ZNLds));

@@ -191,6 +191,20 @@ def test_emu_wide_launch_on_the_run_machine(emu, oracle_ref, zj, monkeypatch):
         assert emu_compress(emu, d, 3, split=True, hash_log=15, chain_log=16) == oracle_ref.compress(d, 3, False, 15, 16), len(d)
 
 
+@pytest.mark.parametrize("mode", ["5", "6", "8"])
+def test_emu_wide_launch_with_need_flags(emu, oracle_ref, zj, monkeypatch, mode):
+    """frames of 64-128 KiB with need flags (zn_flags_frame_wide: a table at a time over filters twice the size) on the run machine — flags for every frame (5),
+    for the frames zn_worth() picks (6), taken over mid-frame (8): the reference's bytes"""
+    monkeypatch.setenv("ZJNI_EMU_NEED", mode)
+    rnd = random.Random(47)
+    datas = [zj.synth_host(131072, k, 1) for k in range(8)] + [zj.synth_host(s, 300 + s, 1) for s in (65537, 65544, 70000, 100000, 131071)]
+    datas += [bytes([9]) * 90000, bytes(rnd.getrandbits(8) for _ in range(70000)), bytes(rnd.randrange(16) for _ in range(131072)), bytes(rnd.randrange(4) for _ in range(100001)),
+              (b"abcdefghij" * 13200)[:131000], (golden("xmlsmall") * 1300)[:131072]]
+    for d in datas:
+        assert emu_compress(emu, d, 3, split=True) == expected(oracle_ref, d, 3), len(d)
+        assert emu_compress(emu, d, 3, split=True, hash_log=15, chain_log=15) == oracle_ref.compress(d, 3, False, 15, 15), len(d)
+
+
 def test_need_flags_cover_the_exact_answer(emu, zj):
     """zj_need.h's contract, checked without the parse: a position whose key (long: its 8 bytes; short: its bucket and its first 4 bytes) some
     OTHER position of the frame shares must carry the NEED flag, and every position in the bucket of a NEED-flagged position must carry the INS
@@ -200,6 +214,7 @@ def test_need_flags_cover_the_exact_answer(emu, zj):
     rnd = random.Random(9)
     frames = [zj.synth_host(65536, k, 1) for k in range(4)] + [zj.synth_host(20000, 11, 1), bytes(rnd.randrange(16) for _ in range(30000)),
               (b"0123456789abcdef" * 4096)[:65536], bytes([3]) * 5000, bytes(rnd.getrandbits(8) for _ in range(4096))]
+    frames += [zj.synth_host(131072, 20 + k, 1) for k in range(4)] + [zj.synth_host(65537, 5, 1), bytes(rnd.randrange(16) for _ in range(131072)), bytes(rnd.getrandbits(8) for _ in range(100000))]      # the wide launch's sizes: zn_flags_frame_wide
     for d in frames:
         n = len(d); flags = C.create_string_buffer(n + 16); prm = (C.c_uint * 3)()
         assert emu.emu_need_flags(d, n, flags, prm) == 1

@@ -88,6 +88,24 @@ def test_gpu_wide_frames_through_the_lane_pipeline(gpu, oracle_ref, monkeypatch,
             assert gpu.lib().zjni_route_kernel(10) == b"zj_enc_match_wide_kernel"
 
 
+@pytest.mark.parametrize("need", ["1", "2", "0"])
+def test_gpu_wide_frames_with_need_flags(gpu, oracle_ref, monkeypatch, need):
+    """the wide launch (frames of 64 KiB + 1 .. 128 KiB) with need flags (zn_flags_frame_wide beside the run machine): flags for every frame (ZJNI_NEED=1), for
+    the frames zj_enc_worth_kernel picks (2, the default), for none (0: ZLaneD as before) — every frame the reference's, whichever frames got flags and whenever"""
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
+    monkeypatch.setenv("ZJNI_NEED", need)
+    rnd = random.Random(37)
+    sizes = [131072, 100000, 65537, 131071, 90000, 70000] * 40
+    datas = [gpu.synth_host(s, rnd.randrange(0, 100000), 1) for s in sizes]
+    datas += [bytes(rnd.randrange(16) for _ in range(131072)), bytes(rnd.randrange(4) for _ in range(100000)), bytes([5]) * 131072, bytes(rnd.getrandbits(8) for _ in range(80000))]
+    for rep in range(2):                     # (the second call meets tables and flag buffers the first one left)
+        outs = gpu.compress_batch(datas, 3)
+        for k, (d, z) in enumerate(zip(datas, outs)):
+            assert not isinstance(z, Exception), (k, len(d), z)
+            assert z == oracle_ref.compress(d, 3), (need, rep, k, len(d))
+    assert gpu.decompress_batch(outs, [len(d) for d in datas]) == datas
+
+
 def test_gpu_explicit_table_sizes(gpu, oracle_ref):
     """ZstdCompressCtx.setHashLog / setChainLog (level 3): byte-identical to the reference given the same two parameters;
     16 / 15 = the reference's plain level 3.  Batches and the per-buffer API; other levels refuse the parameters."""

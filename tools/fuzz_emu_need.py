@@ -2,7 +2,7 @@
 build against the reference: level 3, frames of 64 B ... 64 KiB, the library's and explicit table sizes.  NEEDMODE=1 (flags for every frame),
 2 (flags for the frames zn_worth() picks, the gated machine without flags for the rest); 5 / 6 / 7: the run machine (zj_match_run.h — the product's
 machine for large level-3 batches) with flags for every frame / the picked frames / none, ZJNI_EMU_JMAX=3|7 for other run lengths (372 000 frames
-on its first day, 0 differences).  usage: [NEEDMODE=6] fuzz_emu_need.py <seed> <seconds>
+on its first day, 0 differences); WIDE=1: frames of 64 KiB + 1 .. 128 KiB (the wide launch: zn_flags_frame_wide, modes 5 / 6 / 8).  usage: [NEEDMODE=6] [WIDE=1] fuzz_emu_need.py <seed> <seconds>
 TEST INFRASTRUCTURE."""
 import sys, os, random, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +42,7 @@ def gen(n):
 t0=time.time(); cases=0; bad=0
 while time.time()-t0<budget:
     n = rnd.choice([64,65,100,1000,8191,8192,8193,16384,20000,65535,65536]) if rnd.random()<0.4 else rnd.randrange(64,65537)
+    if os.environ.get('WIDE'): n = rnd.choice([65537,65544,98304,131071,131072]) if rnd.random()<0.3 else rnd.randrange(65537,131073)
     d=gen(n)
     if rnd.random()<0.3:
         hl=rnd.choice([6,10,12,14,15]); cl=rnd.choice([6,9,13,15])

@@ -349,7 +349,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                                              const u32* __restrict__ list, u32 count, u32* workCounter,
                                              u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32* doneList, u32* doneCount,
                                              unsigned long long* work2 = nullptr, const u8* flagsBase = nullptr, const u8* gate = nullptr,
-                                             const u32* ready = nullptr) {      // ready[k] != 0: the flags of list entry k are written (gate[k] says whether any will come)
+                                             const u32* ready = nullptr, u32 flagStride = ZN_FLAG_STRIDE) {      // ready[k] != 0: the flags of list entry k are written (gate[k] says whether any will come); flagStride: flag bytes per list entry
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
 #ifdef ZL_PROFILE
     u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                 u32 const i = list[k];
                 u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
                 m.init(src + s0, size, ze_params_of(level, size), tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc,
-                       rdy ? flagsBase + (size_t)k * ZN_FLAG_STRIDE : nullptr);
+                       rdy ? flagsBase + (size_t)k * flagStride : nullptr);
                 pend = 0u; have = 1u;
             }
         } else if (m.st == ZL_DONE) {
@@ -394,7 +394,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         zlRounds++;
 #endif
         m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
-        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * ZN_FLAG_STRIDE); late = 0u; }
+        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * flagStride); late = 0u; }
         ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
@@ -418,12 +418,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 }
 
 // ---- need-gated level 3 (zj_need.h; ZJNI_NEED = 2 by default: flags for the frames zn_worth() picks) ----
-// zj_enc_worth_kernel decides per frame whether it gets flags (gate[k]); zj_enc_need_kernel — one workgroup of 512 lanes per picked frame, Bloom
+// zj_enc_worth_kernel decides per frame whether it gets flags (gate[k]); zj_enc_need_kernel — one workgroup of 1 024 lanes per picked frame, Bloom
 // filters in LDS — computes the flag bytes (which probes can match, which writes can be read) BESIDE the match kernel.  Every frame starts at once;
 // a lane with a picked frame asks for ready[k] once per rotation and takes the flags over mid-frame when they are there (the run machine: what a flag
 // says about a position does not depend on when it is asked, and until then every flag counts as set).  Nothing ever waits for the flag kernel: if it
 // is late, or never scheduled beside the match kernel, frames simply run longer without flags (148 against 152 ms with the bounded wait this replaced,
 // profiles/r03/l_late_flags_ab.txt).  The older gated machine (ZJNI_LANE_MACHINE=0) still waits, bounded by 50 ms, and then runs unflagged.
+static u32 zj_need_threads() {        // lanes per frame of the flag kernel (one workgroup per CU: its filters take 108 KiB of LDS): ZJNI_NEED_THREADS, 64 .. 1 024
+    u32 t = 1024; if (const char* ov = zj_env("ZJNI_NEED_THREADS")) { int const v = atoi(ov); if (v >= 64 && v <= 1024) t = (u32)v & ~63u; }
+    return t;
+}
 struct ZNThreads {
     __device__ __forceinline__ u32 id() const { return threadIdx.x; }
     __device__ __forceinline__ u32 count() const { return blockDim.x; }
@@ -443,9 +447,9 @@ __global__ __launch_bounds__(256) void zj_enc_worth_kernel(const u8* __restrict_
         if (threadIdx.x == 0) { gate[k] = take ? 1 : 0; ready[k] = 0; if (take) pickList[atomicAdd(pickCount, 1u)] = k; }
     }
 }
-__global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
+__global__ __launch_bounds__(1024) void zj_enc_need_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                           const u32* __restrict__ list, const u32* __restrict__ pickList, const u32* pickCount,
-                                                          u8* flagsBase, u32* ready, u32* work) {
+                                                          u8* flagsBase, u32* ready, u32* work, u32 flagStride) {
     ZNLds& L = *(ZNLds*)zj_dyn_lds;
     __shared__ u32 next;
     ZNThreads t;
@@ -463,7 +467,8 @@ __global__ __launch_bounds__(512) void zj_enc_need_kernel(const u8* __restrict__
         u32 const k = pickList[q], i = list[k];
         u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
         ZEParams const p = ze_params_of(level, size);
-        zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * ZN_FLAG_STRIDE);      // (ends with a barrier: every lane's flag bytes are written)
+        if (size > 65536u) zn_flags_frame_wide(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * flagStride);      // (the wide launch's frames: a table at a time)
+        else zn_flags_frame(t, L, src + s0, size, p.hashLog, p.chainLog, p.minMatch, flagsBase + (size_t)k * flagStride);      // (ends with a barrier: every lane's flag bytes are written)
         prev = k;
     }
 }
@@ -654,10 +659,14 @@ __global__ void zj_enc_partition_done_kernel(const u32* countPtr, u32 sharePermi
 // The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_wide_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen, u32* doneList, u32* doneCount) {
+                                                           u8* tables, u32 tableStride, u8* fscratch, u32 maxSrc, u32* meta, u32 listBase, u32 sliceLen, u32* doneList, u32* doneCount,
+                                                           const u8* flagsBase, const u8* gate, const u32* ready) {
     u32 const count = zj_slice_count(countPtr, listBase, sliceLen);
     list += listBase;
-    // level 3: ZLaneD.  The run machine without flags (zj_need.h's filters are sized for 64 KiB frames) was measured here in round 4 and is not faster on 128 KiB frames:
+    // With need flags (level 3, flagsBase != nullptr): the run machine for every frame of the slice, flags of ZN_FLAG_STRIDE_WIDE bytes per entry for the frames
+    // zj_enc_worth_kernel picked, taken over when zj_enc_need_kernel has written them (zn_flags_frame_wide) — what zj_enc_match_run_kernel does on the common path.
+    if (flagsBase) { zj_match_run<ZLaneR<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, ready, ZN_FLAG_STRIDE_WIDE); return; }
+    // without flags, level 3: ZLaneD.  The run machine WITHOUT flags was measured here in round 4 and is not faster on 128 KiB frames:
     // 65 536 x 128 KiB 382-441 ms with ZLaneD, 445-492 ms with ZLaneR (profiles/r04/d_, e_); tests/test_emu_encode.py keeps the machine exact at these sizes.
     if (ZE_LW_LEVEL(level) == 3) zj_match_run<ZLaneD<ZEEntTag> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
     else zj_match_run<ZLaneF<ZEEnt32> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount);
@@ -1824,8 +1833,8 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
                 u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(512), sizeof(ZNLds), zj_env("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                                   (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr);
+                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(zj_need_threads()), sizeof(ZNLds), zj_env("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                   (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr, (u32)ZN_FLAG_STRIDE);
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
                 zj_dbg_sync("zj_enc_need_kernel");
             }
@@ -1905,34 +1914,71 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (sliceB < 64) sliceB = 64;
         u32 const strideB = ze_lane_table_stride((u32)levelWord, true);
         size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12, qB = sliceB * 4;
-        size_t const needB = tablesB + fsB + metaB + 2 * qB + 256;
+        // The entropy kernel BESIDE the match kernel, as on the common path: it takes frames off the completion queue while the slow frames still occupy
+        // their lanes; a sweep pass afterwards takes what it did not get to.  ZJNI_NO_OVERLAP: one after the other (A/B runs).
+        bool const besideB = zj_env("ZJNI_NO_OVERLAP") == nullptr;
+        // Level 3: need flags for the frames zj_enc_worth_kernel picks (zn_flags_frame_wide: 64 KiB + 1 .. 128 KiB) and the run machine for the slice — what the common
+        // path does for frames to 64 KiB.  Only when one slice holds the whole list (a call's frames normally do), ZJNI_NEED / ZJNI_LANE_MACHINE as there;
+        // ZJNI_NEED_WIDE=0 keeps the wide launch on ZLaneD without flags (A/B runs).
+        u32 needModeB = 2; if (const char* ov = zj_env("ZJNI_NEED")) needModeB = (u32)atoi(ov);
+        u32 const hlB = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clB = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
+        bool needW = level == 3 && (needModeB == 1 || needModeB == 2) && besideB && !g_scratch_limit && sliceB >= n && hlB <= ZN_MAX_LOG_L && clB <= ZN_MAX_LOG_S
+                     && !(zj_env("ZJNI_LANE_MACHINE") && atoi(zj_env("ZJNI_LANE_MACHINE")) == 0) && !(zj_env("ZJNI_NEED_WIDE") && atoi(zj_env("ZJNI_NEED_WIDE")) == 0);
+        if (needW && !d->needLdsSet) {
+            if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
+            else { (void)hipGetLastError(); needW = false; }
+        }
+        size_t flagB = needW ? sliceB * (size_t)ZN_FLAG_STRIDE_WIDE + 9 * sliceB + 384 : 0;      // flags, ready words, pick list, gate bytes
+        size_t needB = tablesB + fsB + metaB + 2 * qB + 256 + flagB;
         if (d->wideBufCap < needB) {
             if (!scratch_make_room(d, d->wideBufCap, needB)) return ZJNI_ERR(64);
             if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
-            if (hipMalloc(&d->wideBuf, needB) != hipSuccess) return ZJNI_ERR(64);
+            if (hipMalloc(&d->wideBuf, needB) != hipSuccess) {
+                if (!needW) return ZJNI_ERR(64);
+                (void)hipGetLastError(); needW = false; needB -= flagB; flagB = 0;                    // no room for the flags
+                if (hipMalloc(&d->wideBuf, needB) != hipSuccess) return ZJNI_ERR(64);
+            }
             d->wideBufCap = needB;
         }
         u8* const tb = d->wideBuf; u8* const fs = d->wideBuf + tablesB; u32* const mt = (u32*)(fs + fsB);
         u32* const doneB = (u32*)((u8*)mt + metaB); u32* const procB = doneB + sliceB;      // completion queue of a slice's match kernel, frames the side pass encoded
+        u8* const flagsW = needW ? (u8*)(((uintptr_t)(procB + sliceB) + 63) & ~(uintptr_t)63) : nullptr;
+        u32* const readyW = needW ? (u32*)(flagsW + sliceB * (size_t)ZN_FLAG_STRIDE_WIDE) : nullptr;
+        u32* const pickW = needW ? readyW + sliceB : nullptr;
+        u8* const gateW = needW ? (u8*)(pickW + sliceB) : nullptr;
+        u32* const needCtrW = d->counters + 212;       // [0] flag kernel's work queue, [1] picked frames
         u32* const wctr = d->counters + 48;           // [0] match work, [1] entropy work (queue order), [2] queue length, [3] work of the sweep pass
         u32 const wavesB = (u32)((sliceB + 63) / 64);
         u32 const gridMB = wavesB < (u32)d->matchGrid ? wavesB : (u32)d->matchGrid;
         u32 const gridEB = (u32)(sliceB < (size_t)d->encGridLvl[1] ? sliceB : (size_t)d->encGridLvl[1]);
-        // The entropy kernel BESIDE the match kernel, as on the common path: it takes frames off the completion queue while the slow frames still occupy
-        // their lanes; a sweep pass afterwards takes what it did not get to.  ZJNI_NO_OVERLAP: one after the other (A/B runs).
-        bool const besideB = zj_env("ZJNI_NO_OVERLAP") == nullptr;
         for (size_t base = 0; base < n; base += sliceB) {
             if (hipMemsetAsync(wctr, 0, 16, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             hipLaunchKernelGGL(zj_zero_slots_kernel, dim3((u32)d->numCU * 8), dim3(256), 0, st, tb, strideB, (const u32*)(ctr + 1), (u32)base, (u32)sliceB);
-            bool forked = false;
+            bool forked = false, flagged = false;
             if (besideB) {
                 if (hipMemsetAsync(doneB, 0xFF, qB, st) != hipSuccess || hipMemsetAsync(procB, 0, qB, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                if (needW) {                               // which frames get flags: decided ahead of the fork
+                    if (hipMemsetAsync(needCtrW, 0, 8, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+                    u32 const gw = (u32)(n < (size_t)d->numCU * 8 ? n : (size_t)d->numCU * 8);
+                    hipLaunchKernelGGL(zj_enc_worth_kernel, dim3(gw), dim3(256), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listB, (const u32*)(ctr + 1),
+                                       gateW, readyW, needModeB >= 2 ? 1u : 0u, pickW, needCtrW + 1);
+                }
                 forked = hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess;
+                if (forked && needW && hipStreamWaitEvent(d->waveStream, d->evFork, 0) == hipSuccess) {    // the flag kernel on its own stream, enqueued before the entropy kernel (its workgroups need 108 KiB of LDS each)
+                    u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
+                    hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(zj_need_threads()), sizeof(ZNLds), d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                                       (const u32*)listB, (const u32*)pickW, (const u32*)(needCtrW + 1), flagsW, readyW, needCtrW, (u32)ZN_FLAG_STRIDE_WIDE);
+                    flagged = hipEventRecord(d->evJoinWave, d->waveStream) == hipSuccess;
+                    if (!flagged) { (void)hipStreamSynchronize(d->waveStream); (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st); return ZJNI_ERR(ZJNI_ERROR_no_device); }
+                }
             }
             (void)hipEventRecord(d->tev[8], st);
             hipLaunchKernelGGL(zj_enc_match_wide_kernel, dim3(gridMB), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
-                               (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB, forked ? doneB : (u32*)nullptr, forked ? wctr + 2 : (u32*)nullptr);
+                               (const u32*)listB, (const u32*)(ctr + 1), wctr, tb, strideB, fs, (u32)ZE_WIDE_MAX_SRC, mt, (u32)base, (u32)sliceB, forked ? doneB : (u32*)nullptr, forked ? wctr + 2 : (u32*)nullptr,
+                               (const u8*)(flagged ? flagsW : nullptr), (const u8*)(flagged ? gateW : nullptr), (const u32*)(flagged ? readyW : nullptr));
+            if (flagged && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) { (void)hipStreamSynchronize(d->waveStream); (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st); return ZJNI_ERR(ZJNI_ERROR_no_device); }
             (void)hipEventRecord(d->tev[9], st); d->tevWide = true;
+            if (flagged && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) { (void)hipStreamSynchronize(d->waveStream); (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st); return ZJNI_ERR(ZJNI_ERROR_no_device); }     // the entropy kernel's workgroups fill every CU's LDS: it starts when the flags are done
             if (forked) {
                 hipLaunchKernelGGL(zj_encode_kernel, dim3(gridEB), dim3(64), (u32)sizeof(ZEEntropy), d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                    (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, (const u32*)listB, (const u32*)(ctr + 1), wctr + 1, d->encScratch, d->prof ? d->prof + 16 : nullptr,

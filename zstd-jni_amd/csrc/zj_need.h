@@ -14,7 +14,7 @@
 // filters per table in LDS (64-bit blocks, four bits per key): B1 = keys seen, B2 = keys seen again (a key whose B1 bits were already set when it arrived).  A
 // position whose key tests positive in B2 may have a twin (or is a false positive — then a probe is made that cannot match: harmless);
 // a position whose key tests negative has none: filters have no false negatives, and the word-wide atomic OR of a blocked filter
-// makes "already set" exact whichever of two twins arrives first.  Frame by frame: one workgroup of 512 lanes, three sweeps.
+// makes "already set" exact whichever of two twins arrives first.  Frame by frame: one workgroup of 1 024 lanes (the filters leave a CU room for one; 512 lanes: the flags of the metric batch arrive later and its compress call takes 148-152 ms instead of 135-143, profiles/r04/l_*), three sweeps.
 // On the bench's mixed set 16 % / 27 % of the long / short probes and 37 % / 64 % of the writes remain (exact keys; the filters add
 // a few per cent).  Decisions, their order and the frames are unchanged by construction, and checked byte for byte.
 // Measured on the metric configuration: flags for the frames zn_worth() picks — match kernel 196 -> 165 ms, flag kernel 13.8 ms.
@@ -101,6 +101,49 @@ ZJ_DEV void zn_flags_frame(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashL
     }
     t.sync();
 }
+// Frames of 64 KiB + 1 .. 128 KiB (the wide launch): twice the keys, so a filter pair takes the room both pairs have above — the long table's flags and the short
+// table's are computed one after the other, each with filters of 8 192 / 4 096 blocks over the same LDS (three sweeps per table; a sweep hashes for one table only,
+// so the hashing per position is that of a 64 KiB frame's).  The flag byte is written by the long table's pass and completed by the short table's.
+template <class T>
+ZJ_DEV void zn_flags_frame_wide(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashLog, u32 chainLog, u32 mls, u8* F) {
+    u32 const npos = n >= 8u ? n - 7u : 0u;
+    ZLHash const hL = zl_hash_of(8, hashLog), hS = zl_hash_of(mls, chainLog);
+    u64* const b1 = (u64*)&L; u64* const b2 = b1 + 8192;       // 64 KiB + 32 KiB: the room of b1L .. b2S
+    for (u32 table = 0; table < 2u; table++) {                 // 0: long, 1: short
+        u32* const bn = table == 0 ? L.bnL : L.bnS;
+        {   u32* const w = (u32*)&L; u32 const words = (u32)(sizeof(ZNLds) / 4u);
+            for (u32 i = t.id(); i < words; i += t.count()) w[i] = 0; }
+        t.sync();
+        for (u32 p = t.id(); p < npos; p += t.count()) {       // sweep 1: every key into "seen"; a key that was there already into "seen again"
+            u64 const w = ld64(src + p);
+            ZNHash const k = table == 0 ? zn_hash_long(zl_prod_hi(hL, w), w) : zn_hash_short(zl_hash(hS, w), (u32)w);
+            u64 const m = zn_mask(k.b), old = zn_atomic_or(&b1[k.a & 8191u], m);
+            if ((old & m) == m) { ZNHash const g = zn_second(k); zn_atomic_or(&b2[g.a & 4095u], zn_mask(g.b)); }
+        }
+        t.sync();
+        for (u32 p = t.id(); p < n; p += t.count()) {          // sweep 2: which probes of this table are needed, and the buckets they fall into
+            u32 f = table == 0 ? 0u : F[p];
+            if (p < npos) {
+                u64 const w = ld64(src + p);
+                if (table == 0) {
+                    u32 const ph = zl_prod_hi(hL, w); ZNHash const g = zn_second(zn_hash_long(ph, w)); u64 const m = zn_mask(g.b);
+                    if ((b2[g.a & 4095u] & m) == m) { u32 const b = ph >> hL.rsh; f |= ZN_NEED_L; atomicOr(&bn[b >> 5], 1u << (b & 31u)); }
+                } else {
+                    u32 const bs = zl_hash(hS, w); ZNHash const g = zn_second(zn_hash_short(bs, (u32)w)); u64 const m = zn_mask(g.b);
+                    if ((b2[g.a & 4095u] & m) == m) { f |= ZN_NEED_S; atomicOr(&bn[bs >> 5], 1u << (bs & 31u)); }
+                }
+            }
+            F[p] = (u8)f;
+        }
+        t.sync();
+        for (u32 p = t.id(); p < npos; p += t.count()) {       // sweep 3: which writes of this table are needed (this lane wrote F[p] itself)
+            u64 const w = ld64(src + p);
+            u32 const b = table == 0 ? zl_hash(hL, w) : zl_hash(hS, w);
+            if ((bn[b >> 5] >> (b & 31u)) & 1u) F[p] = (u8)(F[p] | (table == 0 ? ZN_INS_L : ZN_INS_S));
+        }
+        t.sync();
+    }
+}
 // Is the frame worth its flags?  They cost a pass of hashing over every position; they pay where the parse visits most positions and finds
 // little: many distinct 4-byte values (few long matches) over a very small alphabet, where short repeats keep turning up and the reference's
 // step rule (one more position skipped per 256 unmatched bytes) never gets going: measured on unstructured data, 16 byte values are searched at
@@ -128,3 +171,5 @@ ZJ_DEV bool zn_worth(const T& t, u32* bm, const u8* src, u32 n) {
     return grams * 64u >= 32u * ZN_SAMPLE && bytes <= 16u;
 }
 ZJ_HD bool zn_takes(u32 hashLog, u32 chainLog, u32 srcSize) { return hashLog <= ZN_MAX_LOG_L && chainLog <= ZN_MAX_LOG_S && srcSize >= 64u && srcSize <= 65536u; }
+ZJ_HD bool zn_takes_wide(u32 hashLog, u32 chainLog, u32 srcSize) { return hashLog <= ZN_MAX_LOG_L && chainLog <= ZN_MAX_LOG_S && srcSize > 65536u && srcSize <= 131072u; }      // zn_flags_frame_wide
+#define ZN_FLAG_STRIDE_WIDE (131072u + ZN_FLAG_SLACK)   /* flag bytes per frame slot of the wide launch */
