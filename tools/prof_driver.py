@@ -34,6 +34,12 @@ if os.environ.get("PROF_DATA") == "xml":          # bench.py --config 1's buffer
     for i in range(n):
         o = (i * 4099) % span; host[i * size:(i + 1) * size] = xml[o:o + size]
     chk(hip.hipMemcpy(src, host.ctypes.data_as(vp), C.c_size_t(host.nbytes), 1)); del host
+elif os.environ.get("PROF_CLASSES"):               # only some classes of the synthetic set (zj_synth.h: index & 3 = 0 text, 1 JSON-like, 2 low-entropy, 3 random): "01", "2", ...
+    cls = os.environ["PROF_CLASSES"]; first, width = int(cls[0]), len(cls)          # consecutive classes first .. first + width - 1
+    assert n % width == 0
+    tmp = dmalloc(4 * (n // width) * size); chk(L.zjni_synth_fill_device(tmp, size, 0, 4 * (n // width), None)); chk(hip.hipDeviceSynchronize())
+    chk(hip.hipMemcpy2D(src, C.c_size_t(width * size), vp(tmp.value + first * size), C.c_size_t(4 * size), C.c_size_t(width * size), C.c_size_t(n // width), 3))
+    chk(hip.hipDeviceSynchronize()); chk(hip.hipFree(tmp))
 else:
     chk(L.zjni_synth_fill_device(src, size, 0, n, None))
 chk(hip.hipDeviceSynchronize())
