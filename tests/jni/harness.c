@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; jint consumed, produced; int borrowed; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
+typedef struct Obj { int kind; char* data; jsize len; struct Obj** elems; jlong field; jlong srcPos, dstPos; jint consumed, produced; int borrowed; } Obj;   /* kind 1 direct buffer, 2 byte[], 3 Object[], 4 long[], 5 string, 6 object with one long field (nativePtr) */
 static Obj* mk(int kind, jsize len) { Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = kind; o->len = len; o->data = (char*)calloc((size_t)len + 16, kind == 4 ? 8 : 1); return o; }
 
 static void* JNICALL f_GetDirectBufferAddress(JNIEnv* e, jobject b) { (void)e; return (b && ((Obj*)b)->kind == 1) ? ((Obj*)b)->data : NULL; }
@@ -24,12 +24,13 @@ static void JNICALL f_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize
 static jobject JNICALL f_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { (void)e; return (jobject)((Obj*)a)->elems[i]; }
 static void JNICALL f_SetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, const jlong* buf) { (void)e; memcpy(((Obj*)a)->data + 8 * (size_t)s, buf, 8 * (size_t)l); }
 static jclass JNICALL f_GetObjectClass(JNIEnv* e, jobject o) { (void)e; return (jclass)o; }
-static jfieldID JNICALL f_GetFieldID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)sig; return !strcmp(n, "nativePtr") ? (jfieldID)(intptr_t)1 : (!strcmp(n, "consumed") ? (jfieldID)(intptr_t)2 : (!strcmp(n, "produced") ? (jfieldID)(intptr_t)3 : NULL)); }
+static jfieldID JNICALL f_GetFieldID(JNIEnv* e, jclass c, const char* n, const char* sig) { (void)e; (void)c; (void)sig; return !strcmp(n, "nativePtr") ? (jfieldID)(intptr_t)1 : (!strcmp(n, "consumed") ? (jfieldID)(intptr_t)2 : (!strcmp(n, "produced") ? (jfieldID)(intptr_t)3 : (!strcmp(n, "srcPos") ? (jfieldID)(intptr_t)4 : (!strcmp(n, "dstPos") ? (jfieldID)(intptr_t)5 : NULL)))); }
 static jint JNICALL f_GetIntField(JNIEnv* e, jobject o, jfieldID f) { (void)e; return (intptr_t)f == 2 ? ((Obj*)o)->consumed : ((Obj*)o)->produced; }
 static void JNICALL f_SetIntField(JNIEnv* e, jobject o, jfieldID f, jint v) { (void)e; if ((intptr_t)f == 2) ((Obj*)o)->consumed = v; else ((Obj*)o)->produced = v; }
 static jobject JNICALL f_NewDirectByteBuffer(JNIEnv* e, void* addr, jlong cap) { (void)e; Obj* o = (Obj*)calloc(1, sizeof(Obj)); o->kind = 1; o->len = (jsize)cap; o->data = (char*)addr; o->borrowed = 1; return (jobject)o; }
-static jlong JNICALL f_GetLongField(JNIEnv* e, jobject o, jfieldID f) { (void)e; (void)f; return ((Obj*)o)->field; }
-static void JNICALL f_SetLongField(JNIEnv* e, jobject o, jfieldID f, jlong v) { (void)e; (void)f; ((Obj*)o)->field = v; }
+static jlong JNICALL f_GetLongField(JNIEnv* e, jobject o, jfieldID f) { (void)e; return (intptr_t)f == 4 ? ((Obj*)o)->srcPos : ((intptr_t)f == 5 ? ((Obj*)o)->dstPos : ((Obj*)o)->field); }
+static void JNICALL f_SetLongField(JNIEnv* e, jobject o, jfieldID f, jlong v) { (void)e; if ((intptr_t)f == 4) ((Obj*)o)->srcPos = v; else if ((intptr_t)f == 5) ((Obj*)o)->dstPos = v; else ((Obj*)o)->field = v; }
+static jbyteArray JNICALL f_NewByteArray(JNIEnv* e, jsize n) { (void)e; return (jbyteArray)mk(2, n); }
 static jstring JNICALL f_NewStringUTF(JNIEnv* e, const char* s) { (void)e; Obj* o = mk(5, (jsize)strlen(s) + 1); strcpy(o->data, s); return (jstring)o; }
 
 static jclass JNICALL f_FindClass(JNIEnv* e, const char* n) { (void)e; (void)n; return (jclass)mk(7, 0); }
@@ -51,7 +52,7 @@ static JNIEnv* env(void) {
     g_fn.GetByteArrayElements = f_GetByteArrayElements; g_fn.ReleaseByteArrayElements = f_ReleaseByteArrayElements;
     g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef;
     g_fn.ExceptionCheck = f_ExceptionCheck; g_fn.GetIntField = f_GetIntField; g_fn.SetIntField = f_SetIntField; g_fn.NewDirectByteBuffer = f_NewDirectByteBuffer;
-    g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField;
+    g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField; g_fn.NewByteArray = f_NewByteArray;
     return (JNIEnv*)&g_envp;
 }
 
@@ -574,6 +575,87 @@ int main(int argc, char** argv) {
                          r = S[k].dstream(e, (jobject)self, h, (jobject)back, got, total + 64 - got, (jobject)fr, used, (jsize)lens[0] - used);
                          got += self->produced; used += self->consumed; } while (r > 0 && guard++ < 1000);
                     CHECK(r == 0 && got == total && used == (jsize)lens[0] && !memcmp(back->data, src->data, (size_t)total), "decompress stream (library %d) of the %d-byte stream frame: ret %lld, %d bytes out, %d consumed", k, (int)total, (long long)r, (int)got, (int)used);
+                    S[k].dfree(e, NULL, h);
+                }
+            }
+            free(outs[0]); free(outs[1]);
+        }
+    }
+    /* ZstdOutputStreamNoFinalizer / ZstdInputStreamNoFinalizer: the heap-array stream classes driven as their Java code drives them (write loop on srcPos,
+     * flush / end loops on the return value, read loop on dstPos), level and checksum through class Zstd's natives on the stream handle: the same bytes from both libraries */
+    if (!getenv("HARNESS_SKIP_STREAMS")) {
+        typedef jlong (*create_fn)(JNIEnv*, jclass); typedef jint (*free_fn)(JNIEnv*, jclass, jlong); typedef jint (*reset_fn)(JNIEnv*, jobject, jlong);
+        typedef jint (*comp_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jbyteArray, jint); typedef jint (*end_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint);
+        typedef jint (*set_fn)(JNIEnv*, jclass, jlong, jint); typedef jint (*setb_fn)(JNIEnv*, jclass, jlong, jboolean);
+        struct { create_fn create; free_fn free_; reset_fn reset; comp_fn comp; end_fn flush, end; set_fn level; setb_fn checksum; create_fn dcreate; free_fn dfree; reset_fn dinit; comp_fn dstream; } S[2];
+        Lib* libs[2] = {&R, &G};
+        jsize const totals[] = {0, 1, 100, 5000, 70000, 131072, 200000, 300000, 600000, 2097152, 2200000};
+        int const streamMax = getenv("HARNESS_STREAM_MAX") ? atoi(getenv("HARNESS_STREAM_MAX")) : (1 << 30);
+        STAGE("heap-array streams (ZstdOutputStream / ZstdInputStream)");
+        for (int k = 0; k < 2; k++) {
+#define SS(field, name) *(void**)&S[k].field = dlsym(libs[k]->h, P name)
+            SS(create, "ZstdOutputStreamNoFinalizer_createCStream"); SS(free_, "ZstdOutputStreamNoFinalizer_freeCStream"); SS(reset, "ZstdOutputStreamNoFinalizer_resetCStream");
+            SS(comp, "ZstdOutputStreamNoFinalizer_compressStream"); SS(flush, "ZstdOutputStreamNoFinalizer_flushStream"); SS(end, "ZstdOutputStreamNoFinalizer_endStream");
+            SS(level, "Zstd_setCompressionLevel"); SS(checksum, "Zstd_setCompressionChecksums");
+            SS(dcreate, "ZstdInputStreamNoFinalizer_createDStream"); SS(dfree, "ZstdInputStreamNoFinalizer_freeDStream"); SS(dinit, "ZstdInputStreamNoFinalizer_initDStream"); SS(dstream, "ZstdInputStreamNoFinalizer_decompressStream");
+#undef SS
+            CHECK(S[k].create && S[k].free_ && S[k].reset && S[k].comp && S[k].flush && S[k].end && S[k].level && S[k].checksum && S[k].dcreate && S[k].dfree && S[k].dinit && S[k].dstream, "heap-array stream natives of library %d", k);
+        }
+        for (unsigned ti = 0; ti < sizeof totals / sizeof *totals; ti++) for (int variant = 0; variant < 4; variant++) {
+            jsize const total = totals[ti];
+            jint const level = 1 + (jint)((ti + (unsigned)variant) % 3u);
+            jsize const chunk = variant == 0 ? 50000 : (variant == 1 ? 131072 : (variant == 2 ? 7000 : 300000));
+            int const flushEvery = variant == 2 ? 3 : (variant == 3 ? 1 : 0);
+            jsize const room = variant == 1 ? 900 : 131591;                           /* variant 1: a target array far too small; else ZSTD_CStreamOutSize() as the Java class uses */
+            jboolean const ck = (ti + (unsigned)variant) % 2u ? JNI_TRUE : JNI_FALSE;
+            int const frames = variant == 0 && total <= 70000 ? 2 : 1;                /* two frames through one stream object: reset keeps level and checksum */
+            if ((long long)total > (1ll << (18 + level)) && total > streamMax) continue;
+            Obj* src = mk(2, total > 0 ? total : 1); fill(src->data, total, (int)(ti % 3u));
+            char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                Obj* self = mk(7, 0); Obj* dst = mk(2, room);
+                jlong const h = S[k].create(e, NULL); jint r;
+                size_t cap = ((size_t)total + (size_t)total / 64 + (1u << 16)) * (size_t)frames; char* out = (char*)malloc(cap); size_t n = 0;
+                r = S[k].level(e, NULL, h, level); if (r < 0) worst[k] = r;
+                r = S[k].checksum(e, NULL, h, ck); if (r < 0) worst[k] = r;
+                for (int fr = 0; fr < frames && worst[k] == 0; fr++) {
+                    int calls = 0;
+                    r = S[k].reset(e, (jobject)self, h); if (r < 0) { worst[k] = r; break; }
+                    for (jsize at = 0; at < total && worst[k] == 0; ) {           /* ZstdOutputStreamNoFinalizer.write(src, at, len) */
+                        jsize const len = total - at < chunk ? total - at : chunk; int guard = 0;
+                        self->srcPos = at;
+                        while (self->srcPos < at + len && guard++ < 100000) {
+                            r = S[k].comp(e, (jobject)self, h, (jbyteArray)dst, room, (jbyteArray)src, at + len);
+                            if (r < 0) { worst[k] = r; break; }
+                            memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos;
+                        }
+                        at += len; calls++;
+                        if (flushEvery && calls % flushEvery == 0 && worst[k] == 0) {
+                            int guard2 = 0;
+                            do { r = S[k].flush(e, (jobject)self, h, (jbyteArray)dst, room); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos; } while (r > 0 && guard2++ < 100000);
+                        }
+                    }
+                    if (worst[k] == 0) { int guard3 = 0; do { r = S[k].end(e, (jobject)self, h, (jbyteArray)dst, room); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos; } while (r > 0 && guard3++ < 100000); }
+                }
+                S[k].free_(e, NULL, h);
+                outs[k] = out; lens[k] = n;
+            }
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "output stream of %d bytes x %d frames, level %d, checksum %d, writes of %d, flush every %d, room %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                  (int)total, frames, (int)level, (int)ck, (int)chunk, flushEvery, (int)room, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+            /* the frame(s) back through both input streams: everything in the source array, room for all of it; then in pieces of 4 000 bytes (the bundled stream's case) */
+            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < (streamMax == 0 ? 1 : 2); pieces++) {      /* (the GPU-only leg has no bundled stream for a frame that arrives in pieces) */
+                Obj* fr = mk(2, (jsize)lens[0] + 1); memcpy(fr->data, outs[0], lens[0]);
+                for (int k = 0; k < 2; k++) {
+                    Obj* self = mk(7, 0); Obj* back = mk(2, total * frames + 64);
+                    jlong const h = S[k].dcreate(e, NULL); jint r = S[k].dinit(e, (jobject)self, h);
+                    jsize const all = (jsize)lens[0]; jsize fed = pieces ? 0 : all; int guard = 0;
+                    self->srcPos = 0; self->dstPos = 0;
+                    do {
+                        if (pieces && self->srcPos == fed && fed < all) fed = fed + 4000 < all ? fed + 4000 : all;
+                        r = S[k].dstream(e, (jobject)self, h, (jbyteArray)back, total * frames + 64, (jbyteArray)fr, fed);
+                    } while (r >= 0 && (self->srcPos < all) && guard++ < 100000);
+                    CHECK(r == 0 && self->dstPos == (jlong)total * frames && self->srcPos == all && !memcmp(back->data, src->data, (size_t)total) && (frames == 1 || !memcmp(back->data + total, src->data, (size_t)total)),
+                          "input stream (library %d, %s) of the %d-byte x %d stream: ret %d, %lld bytes out, %lld consumed", k, pieces ? "pieces" : "whole", (int)total, frames, (int)r, (long long)self->dstPos, (long long)self->srcPos);
                     S[k].dfree(e, NULL, h);
                 }
             }

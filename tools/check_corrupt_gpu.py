@@ -2,6 +2,7 @@
 both decode pipelines, plus a batch of valid frames beside them.  TEST INFRASTRUCTURE (uses tests/golden only).
 usage: python tools/check_corrupt_gpu.py"""
 import hashlib, json, os, sys
+os.environ.setdefault("ZJNI_DEBUG_LIVE_SWITCHES", "1")    # the library caches its ZJNI_* switches per process (zj_env); this tool flips ZJNI_DSPLIT_MIN between calls
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ctypes as C

@@ -2,6 +2,7 @@
 pipelines (plain incl. wide, explicit table sizes, dictionary, the need-gated level-3 machines in every ZJNI_NEED mode, tight
 destinations), every frame compared with the reference's and decoded back on the GPU.  usage: fuzz_gpu.py <seed> <n>   TEST INFRASTRUCTURE."""
 import os, sys, random, time
+os.environ.setdefault("ZJNI_DEBUG_LIVE_SWITCHES", "1")    # the library caches its ZJNI_* switches per process (zj_env); this tool flips them between calls
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as e
@@ -103,6 +104,8 @@ for machine, mode in [(a, b) for a in ("run", "lane") for b in ("0", "1", "2")]:
     if machine == "lane": os.environ["ZJNI_LANE_MACHINE"] = "0"
     else: os.environ.pop("ZJNI_LANE_MACHINE", None)
     datas = [gen(s) for s in sizes(65536)] + [bytes(rnd.randrange(16) for _ in range(rnd.randrange(4096, 65537))) for _ in range(max(8, n // 10))]
+    if machine == "run":                             # ... and the wide launch's sizes with their flags (zn_flags_frame_wide)
+        datas += [gen(rnd.randrange(65537, 131073)) for _ in range(max(20, n // 4))] + [bytes(rnd.randrange(16) for _ in range(rnd.randrange(65537, 131073))) for _ in range(max(8, n // 10))]
     outs = zj.compress_batch(datas, 3)
     for k, (d, z) in enumerate(zip(datas, outs)):
         want = ref.compress(d, 3)

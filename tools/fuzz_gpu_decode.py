@@ -2,6 +2,7 @@
 without dictionary, against the reference's portable decoder loops.  usage: fuzz_gpu_decode.py <seed> <cases-per-round> <rounds>
 TEST INFRASTRUCTURE."""
 import os, sys, time
+os.environ.setdefault("ZJNI_DEBUG_LIVE_SWITCHES", "1")    # the library caches its ZJNI_* switches per process (zj_env); this tool flips them between calls
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as e

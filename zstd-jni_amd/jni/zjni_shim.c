@@ -9,7 +9,8 @@
  *     and sends buffers to the GPU library through its C-ABI (include/zjni_amd.h) instead of calling ZSTD_compress2 /
  *     ZSTD_decompressDCtx.  Argument checks, their order and the returned codes are the reference's
  *     (N/jni_fast_zstd.c:586-640, :777-905; N/jni_zstd.c:50-63, :230-267);
- *   - everything else (streams, training, constants, ...) is a trampoline (zjni_forward.c) into the bundled CPU
+ *   - the stream classes (DirectByteBuffer and heap-array, sections at the end of this file) buffer a stream and make its frame with one zjni_compress_stream call;
+ *   - everything else (context streams, training, constants, ...) is a trampoline (zjni_forward.c) into the bundled CPU
  *     library named by $ZSTD_JNI_CPU_LIB, looked up with dlsym — the CPU code stays where it is, this file contains none.
  *
  * Handles.  A context's nativePtr is the BUNDLED library's own ZSTD_CCtx* / ZSTD_DCtx* whenever that library is present,
@@ -207,11 +208,11 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlo
 }
 /* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
  * class's.  Recorded when the GPU path honours the parameter, otherwise the context is marked for the CPU path; always passed on. */
-static void ss_note_parameter(jlong stream, int what, jint v);      /* the handle may be a stream class's (below) */
+static int ss_note_parameter(jlong stream, int what, jint v);       /* the handle may be a stream class's (below): 1 when it is and the stream route honours the parameter */
 static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const char* name, int what) {
     jint (*f)(JNIEnv*, jclass, jlong, jint) = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(name);
     CtxState* s = st_get(stream, what == 'd' ? 'D' : 'C');
-    ss_note_parameter(stream, what, v);
+    int const streamOk = ss_note_parameter(stream, what, v);
     if (s) switch (what) {
         case 'l': s->level = v; break;
         case 'k': s->checksum = (v & 0xFF) != 0; break;
@@ -220,7 +221,7 @@ static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const cha
         default: s->cpuOnly = 1; break;                    /* 'x' / 'd': the GPU path does not implement it */
     }
     if (f) return f(env, cls, stream, v);
-    return (s && what != 'x' && what != 'd') ? 0 : -(jint)ZJNI_ERROR_unsupported;
+    return ((s && what != 'x' && what != 'd') || streamOk) ? 0 : -(jint)ZJNI_ERROR_unsupported;
 }
 #define SETTER(name, T, what) JNIEXPORT jint JNICALL P(name)(JNIEnv* env, jclass cls, jlong stream, T v) { return zstd_setter(env, cls, stream, (jint)v, PS(#name), what); }
 SETTER(Zstd_setCompressionLevel, jint, 'l')
@@ -780,6 +781,7 @@ JNIEXPORT jlong JNICALL P(Zstd_compressBatchDict0)(JNIEnv* env, jclass cls, jobj
 typedef struct StreamState {
     struct StreamState* next; jlong key;
     int level, checksum, cpuMode, started, finished;
+    int levelCpu, paramCpu;                                     /* sticky across sessions (ZstdOutputStream sets parameters once, then resets per frame): a level or a parameter only the bundled library serves */
     unsigned char* buf; size_t total, cap;                      /* everything written so far */
     uint32_t* flushAt; size_t nFlush, flushCap;
     size_t emitted;                                             /* bytes of the frame already made (handed out or pending) */
@@ -801,12 +803,13 @@ static void ss_reset(StreamState* s, int level) {
     s->level = level; s->checksum = 0; s->cpuMode = 0; s->started = 0; s->finished = 0; s->total = 0; s->nFlush = 0; s->emitted = 0; s->outLen = s->outPos = 0;
 }
 static void ss_free(StreamState* s) { if (s) { free(s->buf); free(s->flushAt); free(s->out); free(s); } }
-static void ss_note_parameter(jlong stream, int what, jint v) {      /* class Zstd's parameter natives on a stream handle: level and checksum are honoured, anything else is the bundled library's */
+static int ss_note_parameter(jlong stream, int what, jint v) {       /* class Zstd's parameter natives on a stream handle: level and checksum are honoured, anything else is the bundled library's */
     StreamState* s = ss_get(stream, 0, 0);
-    if (!s) return;
-    if (what == 'l') { s->level = v == 0 ? 3 : v; if (v < 0 || v > 3) s->cpuMode = 1; }
+    if (!s) return 0;
+    if (what == 'l') { s->level = v == 0 ? 3 : v; s->levelCpu = (v < 0 || v > 3); if (s->levelCpu) s->cpuMode = 1; }
     else if (what == 'k') s->checksum = (v & 0xFF) != 0;
-    else s->cpuMode = 1;
+    else { s->cpuMode = 1; s->paramCpu = 1; return 0; }
+    return what == 'k' || !s->levelCpu;
 }
 static int streams_on_gpu(void) {
     static int state = -1;
@@ -1071,5 +1074,271 @@ JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_decompr
     if (!f) return -(jlong)ZJNI_ERROR_unsupported;
     {   jlong const r = f(env, obj, stream, dst_buf, dst_offset, dst_size, src_buf, src_offset, src_size);
         if (s) s->started = (r > 0);                                                /* > 0: inside a frame (more input or more room wanted); 0: at a boundary again */
+        return r; }
+}
+
+/* ==== ZstdOutputStreamNoFinalizer / ZstdInputStreamNoFinalizer (N/jni_outputstream_zstd.c, N/jni_inputstream_zstd.c): the heap-array twins of the classes above ====
+ * Same route, same state: a compress stream is buffered until it is flushed or closed and zjni_compress_stream makes the frame ZSTD_compressStream2 would have
+ * made; srcPos / dstPos (long fields of the Java object) are what consumed / produced are there.  Parameters arrive through class Zstd's natives on the stream
+ * handle before the first write (ss_note_parameter: level and checksum are honoured, anything else — and Zstd.loadDictCompress / loadFastDictCompress — makes the
+ * stream the bundled library's for good); resetCStream starts a frame and keeps them, as ZSTD_CCtx_reset(session_only) does.  The arrays are copied with
+ * Get / SetByteArrayRegion, never pinned across a GPU call.  A stream that outgrows the window or meets a GPU that declines is replayed into the bundled
+ * library's stream through ITS natives (byte arrays made for the purpose). */
+static jfieldID g_os_src, g_os_dst, g_is_src, g_is_dst;
+typedef jint (*os_compress_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jbyteArray, jint);
+typedef jint (*os_end_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint);
+JNIEXPORT jlong JNICALL P(ZstdOutputStreamNoFinalizer_createCStream)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdOutputStreamNoFinalizer_createCStream"));
+    jlong const h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);
+    if (h) (void)ss_get(h, 1, 0);
+    return h;
+}
+JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_freeCStream)(JNIEnv* env, jclass cls, jlong stream) {
+    jint (*f)(JNIEnv*, jclass, jlong) = (jint (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdOutputStreamNoFinalizer_freeCStream"));
+    ss_free(ss_get(stream, 0, 1));
+    if (!stream) return 0;
+    if (f) return f(env, cls, stream);
+    free((void*)(intptr_t)stream); return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdOutputStreamNoFinalizer_recommendedCOutSize)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdOutputStreamNoFinalizer_recommendedCOutSize"));
+    return f ? f(env, cls) : (jlong)zjni_compressBound(128u << 10) + 3 + 4;
+}
+JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_resetCStream)(JNIEnv* env, jobject obj, jlong stream) {
+    jint (*f)(JNIEnv*, jobject, jlong) = (jint (*)(JNIEnv*, jobject, jlong))cpu_sym(PS("ZstdOutputStreamNoFinalizer_resetCStream"));
+    StreamState* s = ss_get(stream, 1, 0);
+    jclass const clazz = (*env)->GetObjectClass(env, obj);
+    g_os_src = (*env)->GetFieldID(env, clazz, "srcPos", "J"); g_os_dst = (*env)->GetFieldID(env, clazz, "dstPos", "J");
+    if (s) {                                                    /* a new frame; level, checksum and what only the bundled library serves stay */
+        int const lv = s->level ? s->level : 3, ck = s->checksum, lc = s->levelCpu, pc = s->paramCpu;
+        ss_reset(s, lv); s->checksum = ck; s->levelCpu = lc; s->paramCpu = pc;
+        if (lc || pc || !streams_on_gpu()) s->cpuMode = 1;
+    }
+    return f ? f(env, obj, stream) : 0;
+}
+/* the stream marked as the bundled library's before anything is forwarded: dictionaries on a stream handle */
+static void ss_mark_cpu(jlong stream) { StreamState* s = ss_get(stream, 0, 0); if (s) { s->paramCpu = 1; s->cpuMode = 1; } }
+JNIEXPORT jint JNICALL P(Zstd_loadDictCompress)(JNIEnv* env, jclass cls, jlong stream, jbyteArray dict, jint dict_size) {
+    jint (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint) = (jint (*)(JNIEnv*, jclass, jlong, jbyteArray, jint))cpu_sym(PS("Zstd_loadDictCompress"));
+    ss_mark_cpu(stream);
+    return f ? f(env, cls, stream, dict, dict_size) : -(jint)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jint JNICALL P(Zstd_loadFastDictCompress)(JNIEnv* env, jclass cls, jlong stream, jobject dict) {
+    jint (*f)(JNIEnv*, jclass, jlong, jobject) = (jint (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("Zstd_loadFastDictCompress"));
+    ss_mark_cpu(stream);
+    return f ? f(env, cls, stream, dict) : -(jint)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jint JNICALL P(Zstd_loadDictDecompress)(JNIEnv* env, jclass cls, jlong stream, jbyteArray dict, jint dict_size) {
+    jint (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint) = (jint (*)(JNIEnv*, jclass, jlong, jbyteArray, jint))cpu_sym(PS("Zstd_loadDictDecompress"));
+    ss_mark_cpu(stream);
+    return f ? f(env, cls, stream, dict, dict_size) : -(jint)ZJNI_ERROR_unsupported;
+}
+JNIEXPORT jint JNICALL P(Zstd_loadFastDictDecompress)(JNIEnv* env, jclass cls, jlong stream, jobject dict) {
+    jint (*f)(JNIEnv*, jclass, jlong, jobject) = (jint (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("Zstd_loadFastDictDecompress"));
+    ss_mark_cpu(stream);
+    return f ? f(env, cls, stream, dict) : -(jint)ZJNI_ERROR_unsupported;
+}
+/* pending output into dst[0, dst_size): bytes copied (dstPos) */
+static size_t os_deliver(JNIEnv* env, StreamState* s, jbyteArray dst, jint dst_size) {
+    size_t k = s->outLen - s->outPos; if (k > (size_t)dst_size) k = (size_t)dst_size;
+    if (k) { (*env)->SetByteArrayRegion(env, dst, 0, (jsize)k, (const jbyte*)(s->out + s->outPos)); s->outPos += k; }
+    return k;
+}
+/* everything buffered so far into the bundled library's stream through its own natives, collecting what it writes (ss_replay_to_cpu's twin): -1 when that is impossible */
+static int os_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
+    os_compress_fn cf = (os_compress_fn)cpu_sym(PS("ZstdOutputStreamNoFinalizer_compressStream"));
+    os_end_fn ff = (os_end_fn)cpu_sym(PS("ZstdOutputStreamNoFinalizer_flushStream"));
+    size_t at = 0, fi = 0, delivered; jint const scratchCap = 256 << 10, pieceCap = 1 << 20;
+    jbyteArray darr, sarr; unsigned char* tmp;
+    if (!cf || !ff || !(*env)->NewByteArray) return -1;
+    darr = (*env)->NewByteArray(env, scratchCap); sarr = (*env)->NewByteArray(env, pieceCap); tmp = (unsigned char*)malloc((size_t)scratchCap);
+    if (!darr || !sarr || !tmp) { free(tmp); return -1; }
+    delivered = s->emitted - (s->outLen - s->outPos);
+    s->outLen = s->outPos = 0;
+    while (at < s->total || fi < s->nFlush) {
+        size_t const upto = fi < s->nFlush ? s->flushAt[fi] : s->total;
+        while (at < upto) {
+            jint const n = upto - at > (size_t)pieceCap ? pieceCap : (jint)(upto - at);
+            jint r; jlong sp, dp;
+            (*env)->SetByteArrayRegion(env, sarr, 0, n, (const jbyte*)(s->buf + at));
+            (*env)->SetLongField(env, obj, g_os_src, 0);
+            r = cf(env, obj, s->key, darr, scratchCap, sarr, n);
+            sp = (*env)->GetLongField(env, obj, g_os_src); dp = (*env)->GetLongField(env, obj, g_os_dst);
+            if (r < 0 || !ss_out_room(s, (size_t)dp)) { free(tmp); return -1; }
+            if (dp) { (*env)->GetByteArrayRegion(env, darr, 0, (jsize)dp, (jbyte*)tmp); memcpy(s->out + s->outLen, tmp, (size_t)dp); s->outLen += (size_t)dp; }
+            at += (size_t)sp;
+            if (sp == 0 && dp == 0) { free(tmp); return -1; }
+        }
+        if (fi < s->nFlush) {
+            for (;;) {
+                jint const r = ff(env, obj, s->key, darr, scratchCap); jlong const dp = (*env)->GetLongField(env, obj, g_os_dst);
+                if (r < 0 || !ss_out_room(s, (size_t)dp)) { free(tmp); return -1; }
+                if (dp) { (*env)->GetByteArrayRegion(env, darr, 0, (jsize)dp, (jbyte*)tmp); memcpy(s->out + s->outLen, tmp, (size_t)dp); s->outLen += (size_t)dp; }
+                if (r == 0) break;
+            }
+            fi++;
+        }
+    }
+    if ((*env)->DeleteLocalRef) { (*env)->DeleteLocalRef(env, darr); (*env)->DeleteLocalRef(env, sarr); }
+    free(tmp);
+    if (s->outLen < s->emitted) return -1;                     /* (the flushed prefix came from the GPU route and the bundled stream has made the same bytes again: skipped) */
+    s->outPos = delivered; s->emitted = 0;
+    s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
+    return 0;
+}
+JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_compressStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size, jbyteArray src, jint src_size) {
+    os_compress_fn f = (os_compress_fn)cpu_sym(PS("ZstdOutputStreamNoFinalizer_compressStream"));
+    StreamState* s = ss_get(stream, 0, 0);
+    jlong src_pos; size_t take;
+    if (s == NULL || !g_os_src || (s->cpuMode && s->outPos == s->outLen)) return f ? f(env, obj, stream, dst, dst_size, src, src_size) : (jint)E_MEM;
+    src_pos = (*env)->GetLongField(env, obj, g_os_src);
+    if (src_pos < 0 || src_pos > src_size || src_size > (*env)->GetArrayLength(env, src) || dst_size > (*env)->GetArrayLength(env, dst)) return (jint)E_SRC;
+    if (s->cpuMode) {                                                               /* replayed earlier: what the bundled stream wrote then goes out first, nothing is consumed */
+        size_t const k = os_deliver(env, s, dst, dst_size);
+        (*env)->SetLongField(env, obj, g_os_dst, (jlong)k);
+        return 1;
+    }
+    take = (size_t)(src_size - src_pos);
+    s->started = 1;
+    if (s->total + take > ss_window(s->level)) {                                    /* outgrows the window: the bundled library's stream takes over */
+        if (os_replay_to_cpu(env, obj, s) != 0) return -(jint)ZJNI_ERROR_unsupported;
+        (*env)->SetLongField(env, obj, g_os_src, src_pos);                          /* (the replay used the field) */
+        {   size_t const k = os_deliver(env, s, dst, dst_size);
+            if (s->outPos < s->outLen || !f) { (*env)->SetLongField(env, obj, g_os_dst, (jlong)k); return 1; }
+            (*env)->SetLongField(env, obj, g_os_dst, (jlong)k); return 1; }         /* the caller's loop comes back with the same source: the bundled stream takes it then */
+    }
+    if (s->total + take > s->cap) {
+        size_t c = (s->total + take) * 2 + 65536; unsigned char* p;
+        if (c > ss_window(s->level)) c = ss_window(s->level);
+        p = (unsigned char*)realloc(s->buf, c); if (!p) return (jint)E_MEM;
+        s->buf = p; s->cap = c;
+    }
+    if (take) (*env)->GetByteArrayRegion(env, src, (jsize)src_pos, (jsize)take, (jbyte*)(s->buf + s->total));
+    s->total += take;
+    (*env)->SetLongField(env, obj, g_os_src, (jlong)src_size); (*env)->SetLongField(env, obj, g_os_dst, 0);
+    return (jint)((128u << 10) - (s->total & ((128u << 10) - 1)));
+}
+static jint os_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size, int end) {
+    const char* const name = end ? PS("ZstdOutputStreamNoFinalizer_endStream") : PS("ZstdOutputStreamNoFinalizer_flushStream");
+    os_end_fn f = (os_end_fn)cpu_sym(name);
+    StreamState* s = ss_get(stream, 0, 0);
+    size_t k = 0;
+    if (s == NULL || !g_os_dst || (s->cpuMode && s->outPos == s->outLen)) return f ? f(env, obj, stream, dst, dst_size) : (jint)E_MEM;
+    if (dst_size > (*env)->GetArrayLength(env, dst)) return (jint)E_DST;
+    if (!s->cpuMode && s->outPos == s->outLen && !s->finished) {                     /* nothing pending: make the frame's next part */
+        int const knownEmpty = end && !s->started && s->total == 0;
+        size_t const cap = s->total + (s->total >> 8) + 4096 + 64 * (s->nFlush + 4);
+        unsigned char* tmp; size_t r;
+        if (!end) {
+            s->started = 1;
+            if (s->total > (s->nFlush ? s->flushAt[s->nFlush - 1] : 0)) {
+                if (s->nFlush == s->flushCap) { size_t const c = s->flushCap * 2 + 16; uint32_t* p = (uint32_t*)realloc(s->flushAt, c * sizeof *p); if (!p) return (jint)E_MEM; s->flushAt = p; s->flushCap = c; }
+                s->flushAt[s->nFlush++] = (uint32_t)s->total;
+            } else { (*env)->SetLongField(env, obj, g_os_dst, 0); return 0; }      /* a flush with nothing buffered writes nothing */
+        }
+        tmp = (unsigned char*)malloc(cap); if (!tmp) return (jint)E_MEM;
+        r = zjni_compress_stream(tmp, cap, s->buf, s->total, s->level, s->checksum, s->flushAt, s->nFlush, end, knownEmpty);
+        if (zjni_isError(r)) {
+            free(tmp);
+            if (zjni_getErrorCode(r) >= 200 && os_replay_to_cpu(env, obj, s) == 0) {   /* the GPU declined: the bundled stream makes the frame from the start */
+                k = os_deliver(env, s, dst, dst_size);
+                (*env)->SetLongField(env, obj, g_os_dst, (jlong)k);
+                if (s->outPos < s->outLen) return (jint)(s->outLen - s->outPos);
+                {   jbyteArray rest = dst; jint room = dst_size - (jint)k; jint rr;
+                    if (k == 0) { rr = f(env, obj, stream, dst, dst_size); return rr; }
+                    /* part of the caller's array is taken: the bundled stream writes the rest through an array of its own */
+                    rest = (*env)->NewByteArray(env, room > 0 ? room : 1); if (!rest) return (jint)E_MEM;
+                    rr = f(env, obj, stream, rest, room);
+                    {   jlong const dp = (*env)->GetLongField(env, obj, g_os_dst);
+                        if (dp > 0) { jbyte* b = (jbyte*)malloc((size_t)dp); if (!b) return (jint)E_MEM; (*env)->GetByteArrayRegion(env, rest, 0, (jsize)dp, b); (*env)->SetByteArrayRegion(env, dst, (jsize)k, (jsize)dp, b); free(b); }
+                        (*env)->SetLongField(env, obj, g_os_dst, dp + (jlong)k); }
+                    if ((*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, rest);
+                    return rr; }
+            }
+            return (jint)r;
+        }
+        if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); return (jint)E_MEM; }
+        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+        free(tmp);
+        if (end) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
+    }
+    k = os_deliver(env, s, dst, dst_size);
+    (*env)->SetLongField(env, obj, g_os_dst, (jlong)k);
+    if (s->outPos < s->outLen) return (jint)(s->outLen - s->outPos);                 /* bytes still to be taken: the caller's loop comes back */
+    if (s->cpuMode) {                                                               /* the replayed part is out: the bundled stream does this flush / end itself — on the caller's next turn when bytes went out now */
+        if (k) return 1;
+        return f ? f(env, obj, stream, dst, dst_size) : 0;
+    }
+    if (s->finished) { int const lv = s->level, ck = s->checksum, lc = s->levelCpu, pc = s->paramCpu; ss_reset(s, lv); s->checksum = ck; s->levelCpu = lc; s->paramCpu = pc; }
+    return 0;
+}
+JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size) { return os_flush_or_end(env, obj, stream, dst, dst_size, 0); }
+JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_endStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size) { return os_flush_or_end(env, obj, stream, dst, dst_size, 1); }
+/* ---- ZstdInputStreamNoFinalizer.decompressStream (N/jni_inputstream_zstd.c:68-93): at a frame boundary, a COMPLETE frame in src[srcPos, src_size) whose content
+ * fits dst[dstPos, dst_size) goes to the batch decoder in one piece (as in ZstdDirectBufferDecompressingStreamNoFinalizer above); anything else is the bundled
+ * library's stream, which keeps the frame once it is inside one. */
+typedef jint (*is_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jbyteArray, jint);
+JNIEXPORT jlong JNICALL P(ZstdInputStreamNoFinalizer_createDStream)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdInputStreamNoFinalizer_createDStream"));
+    jlong const h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);
+    if (h) (void)ss_get(h, 1, 0);
+    return h;
+}
+JNIEXPORT jint JNICALL P(ZstdInputStreamNoFinalizer_freeDStream)(JNIEnv* env, jclass cls, jlong stream) {
+    jint (*f)(JNIEnv*, jclass, jlong) = (jint (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdInputStreamNoFinalizer_freeDStream"));
+    ss_free(ss_get(stream, 0, 1));
+    if (!stream) return 0;
+    if (f) return f(env, cls, stream);
+    free((void*)(intptr_t)stream); return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdInputStreamNoFinalizer_recommendedDInSize)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdInputStreamNoFinalizer_recommendedDInSize"));
+    return f ? f(env, cls) : (jlong)((128u << 10) + 3);                              /* ZSTD_DStreamInSize(): a block and its header */
+}
+JNIEXPORT jlong JNICALL P(ZstdInputStreamNoFinalizer_recommendedDOutSize)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdInputStreamNoFinalizer_recommendedDOutSize"));
+    return f ? f(env, cls) : (jlong)(128u << 10);                                    /* ZSTD_DStreamOutSize() */
+}
+JNIEXPORT jint JNICALL P(ZstdInputStreamNoFinalizer_initDStream)(JNIEnv* env, jobject obj, jlong stream) {
+    jint (*f)(JNIEnv*, jobject, jlong) = (jint (*)(JNIEnv*, jobject, jlong))cpu_sym(PS("ZstdInputStreamNoFinalizer_initDStream"));
+    StreamState* s = ss_get(stream, 1, 0);
+    jclass const clazz = (*env)->GetObjectClass(env, obj);
+    g_is_src = (*env)->GetFieldID(env, clazz, "srcPos", "J"); g_is_dst = (*env)->GetFieldID(env, clazz, "dstPos", "J");
+    if (s) { int const pc = s->paramCpu; ss_reset(s, 3); s->paramCpu = pc; s->cpuMode = (pc || !streams_on_gpu()) ? 1 : 0; }
+    return f ? f(env, obj, stream) : 0;
+}
+JNIEXPORT jint JNICALL P(ZstdInputStreamNoFinalizer_decompressStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size, jbyteArray src, jint src_size) {
+    is_fn f = (is_fn)cpu_sym(PS("ZstdInputStreamNoFinalizer_decompressStream"));
+    StreamState* s = ss_get(stream, 0, 0);
+    if (s && g_is_src && !s->cpuMode && !s->paramCpu && !s->started) {
+        jlong const sp = (*env)->GetLongField(env, obj, g_is_src), dp = (*env)->GetLongField(env, obj, g_is_dst);
+        if (sp >= 0 && sp < src_size && dp >= 0 && dp <= dst_size && src_size <= (*env)->GetArrayLength(env, src) && dst_size <= (*env)->GetArrayLength(env, dst)) {
+            size_t const avail = (size_t)(src_size - sp), room = (size_t)(dst_size - dp);
+            unsigned char* const in = (unsigned char*)malloc(avail);
+            if (in) {
+                unsigned long long content = 0, bound = 0; size_t ext;
+                (*env)->GetByteArrayRegion(env, src, (jsize)sp, (jsize)avail, (jbyte*)in);
+                ext = zjni_frame_extent(in, avail, &content, &bound);
+                if (ext && (bound <= room || bound <= (64ull << 20))) {
+                    unsigned char* const to = (unsigned char*)malloc((size_t)bound + 1);
+                    size_t const r = to ? zjni_decompress(to, (size_t)bound, in, ext) : (size_t)E_MEM;
+                    if (!zjni_isError(r) && r <= room) {
+                        if (r) (*env)->SetByteArrayRegion(env, dst, (jsize)dp, (jsize)r, (const jbyte*)to);
+                        free(to); free(in);
+                        (*env)->SetLongField(env, obj, g_is_src, sp + (jlong)ext); (*env)->SetLongField(env, obj, g_is_dst, dp + (jlong)r);
+                        __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+                        return 0;
+                    }
+                    free(to);
+                    if (zjni_isError(r) && zjni_getErrorCode(r) < 200 && zjni_getErrorCode(r) != 70) { free(in); return (jint)r; }     /* the frame is damaged: libzstd's code */
+                }
+                free(in);
+            }
+        }
+    }
+    if (!f) return -(jint)ZJNI_ERROR_unsupported;
+    {   jint const r = f(env, obj, stream, dst, dst_size, src, src_size);
+        if (s) s->started = (r > 0);
         return r; }
 }
