@@ -21,6 +21,12 @@
 #else
 #define ZD_ROUND_FENCE5(a, b, c, d, e) ((void)0)
 #endif
+// a block's "stage 2 is done" flag: set behind everything the lane wrote for the block; stage 3 polls it when it runs beside stage 2
+#if ZJ_ON_GPU
+ZJ_DEV void zj_block_ready(u32* flag) { __threadfence(); __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+static inline void zj_block_ready(u32* flag) { *flag = 1u; }
+#endif
 #define ZD_SPLIT_MAX_CONTENT 131072u
 #define ZD_SPLIT_MAXSEQ (ZD_SPLIT_MAX_CONTENT / 3u + 2u)      // every sequence emits >= 3 bytes (minimum match)
 #define ZD_SPLIT_CELLS 1280u                                  // LL 512 | OF 256 | ML 512
@@ -155,6 +161,7 @@ struct ZDBlk {                    // one block of a multi-block frame (stage 1 w
     u32 litLo, litHi;             // its slot in the literal pool (stage 2b of these frames), ~0: none
     u32 hufBlk;                   // treeless literals: the block whose Huffman table they use (its index in blks[]), ~0: none in this frame
     u32 litReady;                 // stage 2b: the Huffman-coded literals are in the slot
+    u32 seqReady;                 // stage 2 is done with the block (1 from stage 1 on for blocks without sequences): stage 3 running beside stage 2 waits for it, block by block
 };
 struct ZDFrameMB { u32 firstBlk, nBlk, hasChecksum, known; u64 contentSize; u32 frameEnd, pad; };     // known: the header carries the content size
 template <bool MB>
@@ -194,6 +201,7 @@ struct ZDSeqLaneT {
             u32 const regen = opos + (litSize - lpos);
             if (regen > cap) bad = 1;
             blk->regen = regen; blk->rep[0] = rep0; blk->rep[1] = rep1; blk->rep[2] = rep2; blk->status = bad ? 1u : 0u;
+            zj_block_ready(&blk->seqReady);       // (records, sizes and history first: stage 3 may be waiting for this block)
         } else meta->status = bad ? 1u : 0u;
         st = 2;
     }
@@ -485,7 +493,7 @@ ZJ_DEV bool zd_prep_frame_multi(const G& g, ZDecShared& sh, const u8* src, u32 s
             GRP_SERIAL(g) {
                 ZDBlk k; k.frame = frameIdx; k.blockOff = boff; k.blockSize = sz; k.type = type; k.seqOff = 0; k.nbSeq = 0; k.litSize = 0; k.logs = 0; k.regen = sz;
                 k.rep[0] = ZD_SYM; k.rep[1] = ZD_SYM | (1u << 29); k.rep[2] = ZD_SYM | (2u << 29); k.status = 0; k.blockSizeMax = bmax; k.seqLo = 0; k.seqHi = 0;
-                k.litLo = k.litHi = ~0u; k.hufBlk = ~0u; k.litReady = 0;
+                k.litLo = k.litHi = ~0u; k.hufBlk = ~0u; k.litReady = 0; k.seqReady = 1;
                 *bk = k;
             }
             at += 3 + (type == 1 ? 1u : sz);
@@ -522,7 +530,7 @@ ZJ_DEV bool zd_prep_frame_multi(const G& g, ZDecShared& sh, const u8* src, u32 s
             k.rep[0] = ZD_SYM; k.rep[1] = ZD_SYM | (1u << 29); k.rep[2] = ZD_SYM | (2u << 29); k.status = 0; k.blockSizeMax = bmax; k.seqLo = sh.tblOff[0]; k.seqHi = sh.tblOff[1];
             // Huffman-coded literals get a slot of the literal pool (stage 2b decodes the blocks' literals side by side); treeless ones name the block whose table they use
             u32 const lt = body[0] & 3u;
-            k.litLo = k.litHi = ~0u; k.hufBlk = (lt == 3u) ? lastHuf : ~0u; k.litReady = 0;
+            k.litLo = k.litHi = ~0u; k.hufBlk = (lt == 3u) ? lastHuf : ~0u; k.litReady = 0; k.seqReady = nbSeq ? 0u : 1u;
             if (lt >= 2u && litList && (lt == 2u || lastHuf != ~0u)) {
                 unsigned long long const q = atomicAdd(litCounter, (unsigned long long)((sh.litSize + 63u) & ~31u));
                 if (q + ((sh.litSize + 63u) & ~31u) <= litCap) { k.litLo = (u32)q; k.litHi = (u32)(q >> 32); litList[atomicAdd(litListCount, 1u)] = base + b; }
@@ -572,11 +580,33 @@ ZJ_DEV bool zd_lit_block(const G& g, ZDecShared& sh, const u8* src, const ZDBlk*
     return ok;
 }
 
+// stage 3 beside stage 2: until the block's flag is set (lane 0 polls, 2 s at most); wave-uniform answer, the block's record is visible behind it
+template <class G>
+ZJ_DEV bool zd_wait_block(const G& g, ZDecShared& sh, const u32* flag) {
+#if ZJ_ON_GPU
+    u32 v = 0;
+    if (g.lane() == 0) {
+        u64 const t0 = wall_clock64();                    // 100 MHz
+        for (;;) {
+            v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v || wall_clock64() - t0 > 200000000ull) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    v = (u32)__builtin_amdgcn_readfirstlane((int)v);
+    (void)sh;
+    if (!v) return false;
+    __threadfence();
+    return true;
+#else
+    (void)g; (void)sh; return *flag != 0u;
+#endif
+}
 // Stage 3.  Returns the decoded size, or ~0 (wave-uniform) to hand the frame to the fused kernel.  `stage`: ZD_STAGE_BYTES of LDS that are not the Huffman table
 // (a treeless block needs the previous block's).
 template <class G>
 ZJ_DEV u64 zd_exec_frame_multi(const G& g, ZDecShared& sh, const u8* src, u8* dst, u64 dstCap, const ZDFrameMB* fr, const ZDBlk* blks, const u64* pool, u8* litScratch, u8* stage, ZjProf& pf,
-                               const u8* litPool = nullptr) {
+                               const u8* litPool = nullptr, bool beside = false) {      // beside: stage 2 may still be at work — wait for every block's seqReady (bounded); ~0 - 1: gave up, nothing decided
     GRP_SERIAL(g) {
         ZDFrameMB const f = *fr;
         sh.err = 0; sh.hufValid = 0; sh.hufX2 = 0;
@@ -591,6 +621,9 @@ ZJ_DEV u64 zd_exec_frame_multi(const G& g, ZDecShared& sh, const u8* src, u8* ds
     u64 op = 0;
     for (u32 b = 0; b < nb; b++) {
         const ZDBlk* const bk = blks + first + b;
+        if (beside) {
+            if (!zd_wait_block(g, sh, &bk->seqReady)) return ~(u64)0 - 1u;
+        }
         GRP_SERIAL(g) {
             ZDBlk const k = *bk;
             sh.blkType = k.type; sh.hdrSize = k.blockOff; sh.blkSize = k.blockSize; sh.nbSeq = k.nbSeq; sh.blockSizeMax = k.blockSizeMax;

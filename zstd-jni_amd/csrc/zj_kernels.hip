@@ -97,6 +97,13 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 }
 
 // ---- split decode pipeline (zj_decode_split.h): prep -> lane-per-frame sequence decode -> execute ----
+// append k to a completion queue (the producer's records are visible before the entry): match kernel -> entropy kernel, sequence decode -> execution
+__device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
+    if (!doneList) return;
+    __threadfence();                                       // records + meta visible before the queue entry
+    u32 const slot = atomicAdd(doneCount, 1u);
+    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Multi-block frames (zj_decode_split.h, "multi-block frames"): what stage 1 claims from — mb.ctr[0] blocks, [1] entries of seqList, [2] entries of listM, [4..5] records of the pool (64 bit)
 struct ZDMbArgs { ZDFrameMB* frames; ZDBlk* blks; u16* tabs; u32* ctr; u32 blkCap; u32 minBlocks; unsigned long long seqCap; u32* seqList; u32* listM; unsigned long long litCap; u32* litList; };      // ctr: ... [8] lit list, [10..11] literal pool bytes (64 bit), [12] work of the literal pass
 template <bool DICT>
@@ -146,10 +153,11 @@ __global__ __launch_bounds__(64) void zj_dec_lit_mb_kernel(const u8* __restrict_
 }
 // Multi-block frames, stage 2: a LANE per block (ZDSeqLaneT<true>: repcode history carried symbolically), records into the pool
 __global__ __launch_bounds__(64) void zj_dec_seq_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ seqList, const u32* countPtr, u32* workCounter,
-                                                            const u16* tabs, u64* pool, ZDBlk* blks) {
+                                                            const u16* tabs, u64* pool, ZDBlk* blks, u32 beside) {
     __shared__ u32 llBase[36], mlBase[53];
     zd_seq_symtabs(llBase, mlBase, threadIdx.x, 64u);
     __syncthreads();
+    if (beside) __builtin_amdgcn_s_setprio(3);              // the chain of rounds is the critical path; stage 3's waves beside it (waiting for blocks, executing them) fill the gaps
     u32 const count = *countPtr;
     ZDSeqLaneT<true> m; m.st = 2; m.llBase = llBase; m.mlBase = mlBase;
     for (;;) {
@@ -167,7 +175,9 @@ __global__ __launch_bounds__(64) void zj_dec_seq_mb_kernel(const u8* __restrict_
 // Multi-block frames, stage 3: a wave per frame walks its blocks in order (zd_exec_frame_multi); what it hands over goes to list B (the fused kernel)
 __global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff, u64* __restrict__ result,
                                                              const u32* __restrict__ listM, const u32* countPtr, u32* workCounter, const ZDFrameMB* frames, const ZDBlk* blks, const u64* pool,
-                                                             u8* scratch, u32* listB, u32* listBCount, const u8* litPool) {
+                                                             u8* scratch, u32* listB, u32* listBCount, const u8* litPool, u32 mode, u32* procFlag) {
+    // mode 0: list entry k.  mode 1: the same BESIDE stage 2 — a frame's blocks are executed in order, each as soon as stage 2 has set its seqReady (bounded wait; a
+    // frame given up on is left to the mode-2 pass).  mode 2: the list entries mode 1 did not finish.
     __shared__ ZDecShared sh;
     ZjProf pf; pf.start(nullptr);
     Grp<64> g;
@@ -177,9 +187,10 @@ __global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
         u32 const i = ZJ_UNI(listM[k]);
+        if (mode == 2u && ZJ_UNI(procFlag[i])) continue;
         u64 const s0 = zj_uni64(srcOff[i]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
-        u64 const r = zd_exec_frame_multi(g, sh, src + s0, dst + d0, d1 - d0, frames + i, blks, pool, lit, (u8*)sh.ll, pf, litPool);      // (sh.ll .. sh.ml: 4 KiB of LDS this kernel has no tANS tables in)
-        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; }
+        u64 const r = zd_exec_frame_multi(g, sh, src + s0, dst + d0, d1 - d0, frames + i, blks, pool, lit, (u8*)sh.ll, pf, litPool, mode == 1u);      // (sh.ll .. sh.ml: 4 KiB of LDS this kernel has no tANS tables in)
+        if (threadIdx.x == 0 && r != ~(u64)0 - 1u) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; if (mode == 1u) procFlag[i] = 1u; }
         __syncthreads();
     }
 }
@@ -188,13 +199,6 @@ __global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict
 // per-frame start-up dominates, every wave slot goes to the sequence decode and the execution kernel follows it.
 __device__ __forceinline__ bool zj_dec_heavy(const u32* countA) { return countA[1] >= 512u * countA[0]; }      // countA = &listCounts[8]
 
-// append k to a completion queue (the producer's records are visible before the entry): match kernel -> entropy kernel, sequence decode -> execution
-__device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
-    if (!doneList) return;
-    __threadfence();                                       // records + meta visible before the queue entry
-    u32 const slot = atomicAdd(doneCount, 1u);
-    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
                                                          const u32* countPtr, u32* workCounter, const u16* tabs, u64* seqs, ZDMeta* metas,
@@ -1341,14 +1345,14 @@ struct zjni_ddict { int ordinal; u8* buf; size_t rawSize; unsigned dictID; };   
 #define ZD_MB_BLOCKS 65536u
 #define ZD_MB_SEQS ((size_t)192 << 20)
 #define ZD_MB_LIT_BYTES ((size_t)2 << 30)
-struct ZDMbHost { ZDMbArgs a; u64* pool; u8* litPool; bool on; };
+struct ZDMbHost { ZDMbArgs a; u64* pool; u8* litPool; u32* procFlag; bool on; };
 static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool haveDict) {
     ZDMbHost h; memset(&h, 0, sizeof h);
     int const mbEnv = (zj_env("ZJNI_DEC_MB") && atoi(zj_env("ZJNI_DEC_MB")) == 0) ? 0 : 1;
     if (hipMemsetAsync(d->counters + 232, 0, 64, st) != hipSuccess) return h;      // (also when the stages stay off: zjni_last_decode_lists reads them)
     if (!mbEnv || haveDict || g_scratch_limit) return h;
     size_t const tabB = (size_t)ZD_MB_BLOCKS * ZD_SPLIT_TAB_BYTES, blkB = (size_t)ZD_MB_BLOCKS * sizeof(ZDBlk), frB = n * sizeof(ZDFrameMB), listB2 = (size_t)ZD_MB_BLOCKS * 4, lmB = n * 4;
-    size_t const poolOff = (tabB + blkB + frB + 2 * listB2 + lmB + 255) & ~(size_t)255;
+    size_t const poolOff = (tabB + blkB + frB + 2 * listB2 + 2 * lmB + 255) & ~(size_t)255;          // (lmB x 2: list M, stage 3's "done beside stage 2" flags)
     size_t const litOff = poolOff + ZD_MB_SEQS * 8;
     size_t const need = litOff + ZD_MB_LIT_BYTES + 256;
     if (d->dmbBufCap < need) {
@@ -1361,6 +1365,12 @@ static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool ha
     h.a.tabs = (u16*)d->dmbBuf; h.a.blks = (ZDBlk*)(d->dmbBuf + tabB); h.a.frames = (ZDFrameMB*)(d->dmbBuf + tabB + blkB);
     h.a.seqList = (u32*)(d->dmbBuf + tabB + blkB + frB); h.a.litList = h.a.seqList + ZD_MB_BLOCKS; h.a.listM = h.a.litList + ZD_MB_BLOCKS;
     h.a.ctr = ctr; h.a.blkCap = ZD_MB_BLOCKS; h.a.seqCap = ZD_MB_SEQS; h.a.minBlocks = 1;
+    // stage 3 beside stage 2 (ZJNI_DEC_MB_OVERLAP=0: behind it, as before): a flag per frame says which ones it finished there
+    h.procFlag = nullptr;
+    if (!(zj_env("ZJNI_DEC_MB_OVERLAP") && atoi(zj_env("ZJNI_DEC_MB_OVERLAP")) == 0)) {
+        u32* const q = h.a.listM + n;
+        if (hipMemsetAsync(q, 0, lmB, st) == hipSuccess) h.procFlag = q;
+    }
     h.pool = (u64*)(d->dmbBuf + poolOff);
     int const litEnv = (zj_env("ZJNI_DEC_MB_LIT") && atoi(zj_env("ZJNI_DEC_MB_LIT")) == 0) ? 0 : 1;       // stage 2b of these frames off (A/B runs)
     h.a.litCap = litEnv ? ZD_MB_LIT_BYTES : 0; if (!litEnv) h.a.litList = nullptr;
@@ -1372,21 +1382,30 @@ static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool ha
 static void decode_mb_launch(DevState* d, const ZDMbHost& h, hipStream_t st, const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off, uint64_t* d_result,
                              u32* listB, u32* listBCount) {
     if (!h.on) return;
-    // stage 2b on the side stream BESIDE stage 2 (the lane-per-block decode leaves most of every SIMD idle); stage 3 waits for both
-    bool const lit = h.a.litList != nullptr;
-    bool forked = false;
-    if (lit && hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess) {
-        hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
-                           h.a.blks, h.litPool);
-        forked = hipEventRecord(d->evJoin, d->sideStream) == hipSuccess;
-        if (!forked) (void)hipStreamSynchronize(d->sideStream);
-    }
+    // Stage 2b (literals) and — round 4 — stage 3 on the side stream BESIDE stage 2: the lane-per-block decode leaves most of every SIMD idle, and a frame's blocks
+    // finish at different times (they differ 8 x in their number of sequences).  Stage 3 walks a frame's blocks in order as before, but starts each as soon as stage 2
+    // has set its seqReady — a 1 MiB frame is then done about one block's execution behind its slowest block instead of eight behind the whole stage; a sweep pass
+    // behind both takes the frames it gave up on (bounded waits).
+    bool const lit = h.a.litList != nullptr, beside = h.procFlag != nullptr;
+    bool const forked = (lit || beside) && hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess;
     hipLaunchKernelGGL(zj_dec_seq_mb_kernel, dim3((u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.seqList, (const u32*)(h.a.ctr + 1), h.a.ctr + 3,
-                       (const u16*)h.a.tabs, h.pool, h.a.blks);
-    if (forked && hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) { (void)hipStreamSynchronize(d->sideStream); }
+                       (const u16*)h.a.tabs, h.pool, h.a.blks, (forked && beside) ? 1u : 0u);
+    if (forked) {
+        if (lit) hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
+                                    h.a.blks, h.litPool);
+        if (beside)
+            hipLaunchKernelGGL(zj_dec_exec_mb_kernel, dim3((u32)d->decGrid), dim3(64), 0, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result,
+                               (const u32*)h.a.listM, (const u32*)(h.a.ctr + 2), h.a.ctr + 6, (const ZDFrameMB*)h.a.frames, (const ZDBlk*)h.a.blks, (const u64*)h.pool, d->decScratch, listB, listBCount,
+                               (const u8*)(lit ? h.litPool : nullptr), 1u, h.procFlag);
+        if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) { (void)hipStreamSynchronize(d->sideStream); }
+    } else if (lit) {                                   // no fork: stage 2b on the main stream
+        hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
+                           h.a.blks, h.litPool);
+    }
+    bool const swept = forked && beside;
     hipLaunchKernelGGL(zj_dec_exec_mb_kernel, dim3((u32)d->decGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result,
-                       (const u32*)h.a.listM, (const u32*)(h.a.ctr + 2), h.a.ctr + 6, (const ZDFrameMB*)h.a.frames, (const ZDBlk*)h.a.blks, (const u64*)h.pool, d->decScratch, listB, listBCount,
-                       (const u8*)(lit ? h.litPool : nullptr));
+                       (const u32*)h.a.listM, (const u32*)(h.a.ctr + 2), swept ? h.a.ctr + 14 : h.a.ctr + 6, (const ZDFrameMB*)h.a.frames, (const ZDBlk*)h.a.blks, (const u64*)h.pool, d->decScratch, listB, listBCount,
+                       (const u8*)(lit ? h.litPool : nullptr), swept ? 2u : 0u, swept ? h.procFlag : (u32*)nullptr);
 }
 static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
                                            uint64_t* d_result, size_t n, const zjni_ddict* ddict, void* stream) {
