@@ -34,9 +34,10 @@ def test_gpu_golden_and_stream_frames_take_the_block_stages(gpu, oracle_ref):
     assert l[2] == len(frames) and l[1] == 0 and l[3] > 6 * 40, l          # every frame through the block stages, none handed over
 
 
-@pytest.mark.parametrize("mb", ["1", "0"])
+@pytest.mark.parametrize("mb", ["1", "0", "behind"])
 def test_gpu_multiblock_frames_small_and_large_batches(gpu, oracle_ref, monkeypatch, mb):
-    monkeypatch.setenv("ZJNI_DEC_MB", mb)
+    monkeypatch.setenv("ZJNI_DEC_MB", "0" if mb == "0" else "1")
+    if mb == "behind": monkeypatch.setenv("ZJNI_DEC_MB_OVERLAP", "0")      # stage 3 behind stage 2 (the default runs it beside, block by block as stage 2 sets seqReady)
     rnd = random.Random(29)
     xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
     noise = bytes(rnd.getrandbits(8) for _ in range(50000))
