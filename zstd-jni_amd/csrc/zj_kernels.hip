@@ -1865,7 +1865,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machines (0 = the machine's own)
-            if (const char* ov = zj_env("ZJNI_LANE_PERIOD")) lanePeriod = (u32)atoi(ov) & 0xFu;
+            if (const char* ov = zj_env("ZJNI_LANE_PERIOD")) { lanePeriod = (u32)atoi(ov) & 0xFu; if (lanePeriod && lanePeriod < 3u) lanePeriod = 3u; }     // (three non-search states take turns: a shorter rotation would never run one of them)
             if (runMachine) {
                 void (*kern)(const u8*, const u64*, u32, const u32*, const u32*, u32*, u8*, u32, u8*, u32, u32*, u32*, u32*, u32, u32, const u8*, const u8*, const u32*) = zj_enc_match_run_kernel;
 #ifdef ZJ_TUNING_KERNELS
