@@ -55,7 +55,7 @@ def test_gpu_multiblock_frames_small_and_large_batches(gpu, oracle_ref, monkeypa
     for k, (o, d) in enumerate(zip(outs, want)):
         assert o == d, (k, len(d))
     l = lists(gpu)
-    if mb == "1": assert l[2] >= len(frames) - 2 and l[1] <= 2, l
+    if mb != "0": assert l[2] >= len(frames) - 2 and l[1] <= 2, l
     else: assert l[2] == 0, l
     # the same frames inside a large batch of single-block frames (the three-stage pipeline beside the block stages)
     monkeypatch.setenv("ZJNI_DSPLIT_MIN", "1")
@@ -66,7 +66,7 @@ def test_gpu_multiblock_frames_small_and_large_batches(gpu, oracle_ref, monkeypa
     for j, i in enumerate(order):
         assert outs[j] == want2[i], (i, len(want2[i]))
     l = lists(gpu)
-    if mb == "1": assert l[0] >= 200 and l[0] + l[2] == len(frames2) and l[1] == 0, l      # single-block frames that are not "simple" (a raw block: the random class) take the block stages too
+    if mb != "0": assert l[0] >= 200 and l[0] + l[2] == len(frames2) and l[1] == 0, l      # single-block frames that are not "simple" (a raw block: the random class) take the block stages too
     else: assert l[0] >= 200 and l[2] == 0 and l[0] + l[1] == len(frames2), l
 
 
