@@ -659,6 +659,32 @@ int main(int argc, char** argv) {
                     S[k].dfree(e, NULL, h);
                 }
             }
+            /* ... and through ZstdBufferDecompressingStreamNoFinalizer (byte[] + offsets, consumed / produced): whole, then in pieces */
+            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < (streamMax == 0 ? 1 : 2); pieces++) {
+                typedef jlong (*bcreate_fn)(JNIEnv*, jclass); typedef jlong (*bfree_fn)(JNIEnv*, jclass, jlong); typedef jlong (*binit_fn)(JNIEnv*, jobject, jlong);
+                typedef jlong (*bdec_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint, jbyteArray, jint, jint);
+                Obj* fr = mk(2, (jsize)lens[0] + 9); memcpy(fr->data + 5, outs[0], lens[0]);          /* the frame at offset 5 of its array */
+                for (int k = 0; k < 2; k++) {
+                    bcreate_fn bc = (bcreate_fn)dlsym(libs[k]->h, P "ZstdBufferDecompressingStreamNoFinalizer_createDStreamNative");
+                    bfree_fn bf = (bfree_fn)dlsym(libs[k]->h, P "ZstdBufferDecompressingStreamNoFinalizer_freeDStreamNative");
+                    binit_fn bi = (binit_fn)dlsym(libs[k]->h, P "ZstdBufferDecompressingStreamNoFinalizer_initDStreamNative");
+                    bdec_fn bd = (bdec_fn)dlsym(libs[k]->h, P "ZstdBufferDecompressingStreamNoFinalizer_decompressStreamNative");
+                    CHECK(bc && bf && bi && bd, "buffer-decompress natives of library %d", k);
+                    if (!(bc && bf && bi && bd)) continue;
+                    Obj* self = mk(7, 0); Obj* back = mk(2, total * frames + 64 + 3);
+                    jlong const h = bc(e, NULL); jlong r = bi(e, (jobject)self, h);
+                    jsize const all = (jsize)lens[0]; jsize used = 0, got = 0, fed = pieces ? 0 : all; int guard = 0;
+                    do {
+                        if (pieces && used == fed && fed < all) fed = fed + 4000 < all ? fed + 4000 : all;
+                        self->consumed = self->produced = 0;
+                        r = bd(e, (jobject)self, h, (jbyteArray)back, 3 + got, total * frames + 64 - got, (jbyteArray)fr, 5 + used, fed - used);
+                        used += self->consumed; got += self->produced;
+                    } while (r >= 0 && used < all && guard++ < 100000);
+                    CHECK(r == 0 && got == total * frames && used == all && !memcmp(back->data + 3, src->data, (size_t)total) && (frames == 1 || !memcmp(back->data + 3 + total, src->data, (size_t)total)),
+                          "buffer-decompress stream (library %d, %s) of the %d-byte x %d stream: ret %lld, %d bytes out, %d consumed", k, pieces ? "pieces" : "whole", (int)total, frames, (long long)r, (int)got, (int)used);
+                    bf(e, NULL, h);
+                }
+            }
             free(outs[0]); free(outs[1]);
         }
     }

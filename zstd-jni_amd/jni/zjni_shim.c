@@ -1342,3 +1342,71 @@ JNIEXPORT jint JNICALL P(ZstdInputStreamNoFinalizer_decompressStream)(JNIEnv* en
         if (s) s->started = (r > 0);
         return r; }
 }
+/* ---- ZstdBufferDecompressingStreamNoFinalizer.decompressStreamNative (N/jni_bufferdecompress_zstd.c:58-87): the heap-ByteBuffer twin of the DirectByteBuffer
+ * decompressing stream — byte[] + offsets in, consumed / produced int fields out; same policy: a complete frame at a frame boundary that fits the target goes to
+ * the batch decoder, anything else is the bundled library's stream.  The reference's argument checks in its order. */
+static jfieldID g_bs_consumed, g_bs_produced;
+typedef jlong (*bs_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint, jbyteArray, jint, jint);
+JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_createDStreamNative)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdBufferDecompressingStreamNoFinalizer_createDStreamNative"));
+    jlong const h = f ? f(env, cls) : (jlong)(intptr_t)calloc(1, 16);
+    if (h) (void)ss_get(h, 1, 0);
+    return h;
+}
+JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_freeDStreamNative)(JNIEnv* env, jclass cls, jlong stream) {
+    jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdBufferDecompressingStreamNoFinalizer_freeDStreamNative"));
+    ss_free(ss_get(stream, 0, 1));
+    if (!stream) return 0;
+    if (f) return f(env, cls, stream);
+    free((void*)(intptr_t)stream); return 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_recommendedDOutSizeNative)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdBufferDecompressingStreamNoFinalizer_recommendedDOutSizeNative"));
+    return f ? f(env, cls) : (jlong)(128u << 10);
+}
+JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_initDStreamNative)(JNIEnv* env, jobject obj, jlong stream) {
+    jlong (*f)(JNIEnv*, jobject, jlong) = (jlong (*)(JNIEnv*, jobject, jlong))cpu_sym(PS("ZstdBufferDecompressingStreamNoFinalizer_initDStreamNative"));
+    StreamState* s = ss_get(stream, 1, 0);
+    jclass const clazz = (*env)->GetObjectClass(env, obj);
+    g_bs_consumed = (*env)->GetFieldID(env, clazz, "consumed", "I"); g_bs_produced = (*env)->GetFieldID(env, clazz, "produced", "I");
+    if (s) { int const pc = s->paramCpu; ss_reset(s, 3); s->paramCpu = pc; s->cpuMode = (pc || !streams_on_gpu()) ? 1 : 0; }
+    return f ? f(env, obj, stream) : 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_decompressStreamNative)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_offset, jint src_size) {
+    bs_fn f = (bs_fn)cpu_sym(PS("ZstdBufferDecompressingStreamNoFinalizer_decompressStreamNative"));
+    StreamState* s = ss_get(stream, 0, 0);
+    if (s && g_bs_consumed && !s->cpuMode && !s->paramCpu && !s->started && src_size > 0) {
+        if (NULL == dst) return E_DST;
+        if (NULL == src) return E_SRC;
+        if (0 > dst_offset) return E_DST;
+        if (0 > src_offset) return E_SRC;
+        if (0 > dst_size) return E_DST;
+        if (src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
+        if (dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
+        {   unsigned char* const in = (unsigned char*)malloc((size_t)src_size);
+            if (in) {
+                unsigned long long content = 0, bound = 0; size_t ext;
+                (*env)->GetByteArrayRegion(env, src, src_offset, src_size, (jbyte*)in);
+                ext = zjni_frame_extent(in, (size_t)src_size, &content, &bound);
+                if (ext && (bound <= (unsigned long long)dst_size || bound <= (64ull << 20))) {
+                    unsigned char* const to = (unsigned char*)malloc((size_t)bound + 1);
+                    size_t const r = to ? zjni_decompress(to, (size_t)bound, in, ext) : (size_t)E_MEM;
+                    if (!zjni_isError(r) && r <= (size_t)dst_size) {
+                        if (r) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)r, (const jbyte*)to);
+                        free(to); free(in);
+                        (*env)->SetIntField(env, obj, g_bs_consumed, (jint)ext); (*env)->SetIntField(env, obj, g_bs_produced, (jint)r);
+                        __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+                        return 0;
+                    }
+                    free(to);
+                    if (zjni_isError(r) && zjni_getErrorCode(r) < 200 && zjni_getErrorCode(r) != 70) { free(in); return (jlong)r; }
+                }
+                free(in);
+            }
+        }
+    }
+    if (!f) return -(jlong)ZJNI_ERROR_unsupported;
+    {   jlong const r = f(env, obj, stream, dst, dst_offset, dst_size, src, src_offset, src_size);
+        if (s) s->started = (r > 0);
+        return r; }
+}
