@@ -138,6 +138,144 @@ int main(int argc, char** argv) {
             CHECK(!strcmp(((Obj*)R.errName(e, NULL, codes[i]))->data, ((Obj*)G.errName(e, NULL, codes[i]))->data), "getErrorName(%lld)", (long long)codes[i]);
         }
     }
+    STAGE("class Zstd: frame inspection and constants");
+    /* decompressedSize / getFrameContentSize / findFrameCompressedSize / getDictIdFromFrame / getDictIdFromDict, byte[] and direct forms, and the constants:
+     * host-side natives of the shim (no GPU, no bundled library), compared with the reference's on real frames, every truncation of their beginnings,
+     * every single-bit change of their headers, hand-made headers (dictionary ids, 8-byte sizes, window descriptors, skippable and pre-1.0 magics),
+     * magicless headers, noise, and direct-buffer ranges outside the buffer */
+    {   typedef jlong (*insp_a5)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean); typedef jlong (*insp_a4)(JNIEnv*, jclass, jbyteArray, jint, jint);
+        typedef jlong (*insp_a1)(JNIEnv*, jclass, jbyteArray); typedef jlong (*insp_b5)(JNIEnv*, jclass, jobject, jint, jint, jboolean);
+        typedef jlong (*insp_b4)(JNIEnv*, jclass, jobject, jint, jint); typedef jlong (*insp_b1)(JNIEnv*, jclass, jobject);
+        typedef jint (*const_i)(JNIEnv*, jclass); typedef jlong (*const_l)(JNIEnv*, jclass);
+        static const char* ints[] = {"windowLogMin", "windowLogMax", "chainLogMin", "chainLogMax", "hashLogMin", "hashLogMax", "searchLogMin", "searchLogMax", "magicNumber",
+                                     "blockSizeMax", "defaultCompressionLevel", "minCompressionLevel", "maxCompressionLevel"};
+        static const char* errs[] = {"NoError", "Generic", "PrefixUnknown", "VersionUnsupported", "FrameParameterUnsupported", "FrameParameterWindowTooLarge", "CorruptionDetected",
+                                     "ChecksumWrong", "DictionaryCorrupted", "DictionaryWrong", "DictionaryCreationFailed", "ParameterUnsupported", "ParameterOutOfBound",
+                                     "TableLogTooLarge", "MaxSymbolValueTooLarge", "MaxSymbolValueTooSmall", "StageWrong", "InitMissing", "MemoryAllocation", "WorkSpaceTooSmall",
+                                     "DstSizeTooSmall", "SrcSizeWrong", "DstBufferNull"};
+        char nm[160];
+        for (unsigned i = 0; i < sizeof ints / sizeof *ints; i++) {
+            snprintf(nm, sizeof nm, P "Zstd_%s", ints[i]);
+            const_i r = (const_i)dlsym(R.h, nm), g = (const_i)dlsym(G.h, nm);
+            CHECK(r && g && r(e, NULL) == g(e, NULL), "Zstd.%s: ref %d ours %d", ints[i], r ? r(e, NULL) : -1, g ? g(e, NULL) : -1);
+        }
+        for (unsigned i = 0; i < sizeof errs / sizeof *errs; i++) {
+            snprintf(nm, sizeof nm, P "Zstd_err%s", errs[i]);
+            const_l r = (const_l)dlsym(R.h, nm), g = (const_l)dlsym(G.h, nm);
+            CHECK(r && g && r(e, NULL) == g(e, NULL), "Zstd.err%s: ref %lld ours %lld", errs[i], r ? (long long)r(e, NULL) : -1, g ? (long long)g(e, NULL) : -1);
+        }
+#define II(T, name) T r_##name = (T)dlsym(R.h, P "Zstd_" #name), g_##name = (T)dlsym(G.h, P "Zstd_" #name)
+        II(insp_a5, decompressedSize0); II(insp_a5, getFrameContentSize0); II(insp_a4, findFrameCompressedSize0); II(insp_a1, getDictIdFromFrame); II(insp_a1, getDictIdFromDict);
+        II(insp_b5, decompressedDirectByteBufferSize); II(insp_b5, getDirectByteBufferFrameContentSize); II(insp_b4, findDirectByteBufferFrameCompressedSize);
+        II(insp_b1, getDictIdFromFrameBuffer); II(insp_b4, getDictIdFromDictDirect);
+#undef II
+        CHECK(g_decompressedSize0 && g_getFrameContentSize0 && g_findFrameCompressedSize0 && g_getDictIdFromFrame && g_getDictIdFromDict && g_decompressedDirectByteBufferSize &&
+              g_getDirectByteBufferFrameContentSize && g_findDirectByteBufferFrameCompressedSize && g_getDictIdFromFrameBuffer && g_getDictIdFromDictDirect, "inspection natives exported");
+        /* the cases: (bytes, length) pairs collected in one pool */
+        enum { POOL = 1 << 22, MAXCASE = 6000 };
+        char* pool = (char*)malloc(POOL); size_t used = 0; size_t at[MAXCASE]; jsize len[MAXCASE]; int nCase = 0;
+#define ADD(ptr, n_) do { if (nCase < MAXCASE && used + (size_t)(n_) + 32 <= POOL) { memcpy(pool + used, (ptr), (size_t)(n_)); memset(pool + used + (n_), 0xA5, 32); at[nCase] = used; len[nCase++] = (jsize)(n_); used += (size_t)(n_) + 32; } } while (0)
+        {   jlong rc = R.cinit(e, NULL);
+            jsize const fsz[] = {0, 1, 100, 255, 256, 300, 65535, 65536, 70000, 131072, 200000, 400000};
+            for (unsigned si = 0; si < sizeof fsz / sizeof *fsz; si++) for (int ck = 0; ck < 2; ck++) {
+                jsize const n = fsz[si], cap = (jsize)R.bound(e, NULL, n);
+                Obj* src = mk(2, n); Obj* dst = mk(2, cap);
+                fill(src->data, n, (int)(si % 3));
+                R.setLevel(e, NULL, rc, 1 + (int)(si & 1)); R.setChecksum(e, NULL, rc, ck ? JNI_TRUE : JNI_FALSE);
+                jlong const z = R.cArray(e, NULL, rc, (jbyteArray)dst, 0, cap, (jbyteArray)src, 0, n);
+                if (z <= 0) { CHECK(0, "reference compress for the inspection cases"); continue; }
+                ADD(dst->data, z);
+                for (jsize t = 0; t < 24 && t < z; t++) ADD(dst->data, t);                      /* beginnings */
+                ADD(dst->data, z - 1); ADD(dst->data, z - 3); if (z > 5) ADD(dst->data, z - 5);
+                {   char two[1 << 12]; jsize const h = z < 2000 ? (jsize)z : 2000; memcpy(two, dst->data, (size_t)h); memcpy(two + h, dst->data, (size_t)h); ADD(two, 2 * h); }      /* a second frame (or noise) behind */
+                if (si < 6) for (int bit = 0; bit < 14 * 8; bit++) { if (bit / 8 < z) { dst->data[bit / 8] ^= (char)(1 << (bit & 7)); ADD(dst->data, z < 600 ? z : 600); dst->data[bit / 8] ^= (char)(1 << (bit & 7)); } }
+                ADD(dst->data + 4, z - 4);                                                      /* the same frame without its magic number: for the magicless reads */
+                for (jsize t = 0; t < 16 && t + 4 < z; t++) ADD(dst->data + 4, t);
+            }
+            R.cfree(e, NULL, rc);
+        }
+        {   /* hand-made headers: every descriptor byte with the reserved bit clear and set, followed by enough bytes for the longest header and an empty last raw block */
+            for (int fhd = 0; fhd < 256; fhd++) for (int wl = 0; wl < 3; wl++) {
+                unsigned char h[40]; int k = 0;
+                h[k++] = 0x28; h[k++] = 0xB5; h[k++] = 0x2F; h[k++] = 0xFD; h[k++] = (unsigned char)fhd;
+                if (!((fhd >> 5) & 1)) h[k++] = (unsigned char)(wl == 0 ? 0x00 : (wl == 1 ? 0xAF : 0xB0));          /* window logs 10, 31 (+7/8), 32 */
+                else if (wl) continue;
+                {   static const int dsz[4] = {0, 1, 2, 4}, fsz2[4] = {0, 2, 4, 8};
+                    int const d = dsz[fhd & 3], f = fsz2[fhd >> 6] + (((fhd >> 5) & 1) && !(fhd >> 6));
+                    for (int i = 0; i < d; i++) h[k++] = (unsigned char)(0x11 * (i + 1) + fhd);
+                    for (int i = 0; i < f; i++) h[k++] = (unsigned char)(i == f - 1 ? 0x01 : 0x80 + i); }
+                h[k++] = 0x01; h[k++] = 0x00; h[k++] = 0x00;                                            /* raw, last, empty */
+                if (fhd & 4) { h[k++] = 0x99; h[k++] = 0xE9; h[k++] = 0xD8; h[k++] = 0x51; }
+                ADD(h, k); ADD(h, k - 1); ADD(h, k - 4); ADD(h + 4, k - 4);
+            }
+            {   static const unsigned char blocks[][12] = { {0x28,0xB5,0x2F,0xFD,0x20,0x05, 0x03,0x00,0x00, 'x', 0,0},          /* an RLE block of 0 (last) */
+                                                            {0x28,0xB5,0x2F,0xFD,0x20,0x05, 0x07,0x00,0x00, 0,0,0},             /* the reserved block type */
+                                                            {0x28,0xB5,0x2F,0xFD,0x20,0x05, 0x28,0x00,0x00, 1,2,3} };          /* raw 5, not last, and the input ends */
+                for (unsigned i = 0; i < 3; i++) for (int t = 6; t <= 12; t++) ADD(blocks[i], t); }
+            for (int v = 0; v < 16; v += 5) {                                                           /* skippable frames */
+                unsigned char sk[64]; memset(sk, 0x33, sizeof sk);
+                sk[0] = (unsigned char)(0x50 + v); sk[1] = 0x2A; sk[2] = 0x4D; sk[3] = 0x18;
+                unsigned const szs[] = {0, 1, 40, 56, 57, 0xFFFFFFF7u, 0xFFFFFFF8u, 0xFFFFFFFFu};
+                for (unsigned i = 0; i < sizeof szs / sizeof *szs; i++) {
+                    sk[4] = (unsigned char)szs[i]; sk[5] = (unsigned char)(szs[i] >> 8); sk[6] = (unsigned char)(szs[i] >> 16); sk[7] = (unsigned char)(szs[i] >> 24);
+                    ADD(sk, 64); ADD(sk, 8); ADD(sk, 7); ADD(sk, 4); ADD(sk, 3); ADD(sk, 1);
+                }
+            }
+            for (unsigned m = 0xFD2FB520u; m <= 0xFD2FB52Au; m++) { unsigned char lg[24]; memset(lg, 0, sizeof lg); lg[0] = (unsigned char)m; lg[1] = 0xB5; lg[2] = 0x2F; lg[3] = 0xFD; ADD(lg, 24); ADD(lg, 4); }
+            for (int i = 0; i < 300; i++) { char noise[48]; jsize const n = (jsize)(rnd() % 48); fill(noise, n, 2); ADD(noise, n); }
+            {   unsigned char d[16] = {0x37, 0xA4, 0x30, 0xEC, 0x78, 0x56, 0x34, 0x12, 9, 9, 9, 9, 9, 9, 9, 9};             /* dictionaries: the magic and an id */
+                for (int t = 0; t <= 16; t++) ADD(d, t);
+                d[0] ^= 1; ADD(d, 16); }
+        }
+        for (int c = 0; c < nCase; c++) {
+            jsize const n = len[c], off = 3;
+            Obj* whole = mk(2, n); Obj* shifted = mk(2, n + off + 5); Obj* dir = mk(1, n + off + 5);
+            memcpy(whole->data, pool + at[c], (size_t)n); memcpy(shifted->data + off, pool + at[c], (size_t)n + 5); memcpy(dir->data + off, pool + at[c], (size_t)n + 5);
+            for (int ml = 0; ml < 2; ml++) {
+                jboolean const m = ml ? JNI_TRUE : JNI_FALSE;
+                jlong a = r_decompressedSize0(e, NULL, (jbyteArray)shifted, off, n, m), b = g_decompressedSize0(e, NULL, (jbyteArray)shifted, off, n, m);
+                CHECK(a == b, "decompressedSize0 case %d (n=%d magicless=%d): ref %lld ours %lld", c, n, ml, (long long)a, (long long)b);
+                a = r_getFrameContentSize0(e, NULL, (jbyteArray)shifted, off, n, m); b = g_getFrameContentSize0(e, NULL, (jbyteArray)shifted, off, n, m);
+                CHECK(a == b, "getFrameContentSize0 case %d (n=%d magicless=%d): ref %lld ours %lld", c, n, ml, (long long)a, (long long)b);
+                a = r_decompressedDirectByteBufferSize(e, NULL, dir, off, n, m); b = g_decompressedDirectByteBufferSize(e, NULL, dir, off, n, m);
+                CHECK(a == b, "decompressedDirectByteBufferSize case %d (n=%d magicless=%d): ref %lld ours %lld", c, n, ml, (long long)a, (long long)b);
+                a = r_getDirectByteBufferFrameContentSize(e, NULL, dir, off, n, m); b = g_getDirectByteBufferFrameContentSize(e, NULL, dir, off, n, m);
+                CHECK(a == b, "getDirectByteBufferFrameContentSize case %d (n=%d magicless=%d): ref %lld ours %lld", c, n, ml, (long long)a, (long long)b);
+            }
+            {   jlong a = r_findFrameCompressedSize0(e, NULL, (jbyteArray)shifted, off, n), b = g_findFrameCompressedSize0(e, NULL, (jbyteArray)shifted, off, n);
+                CHECK(a == b, "findFrameCompressedSize0 case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                a = r_findDirectByteBufferFrameCompressedSize(e, NULL, dir, off, n); b = g_findDirectByteBufferFrameCompressedSize(e, NULL, dir, off, n);
+                CHECK(a == b, "findDirectByteBufferFrameCompressedSize case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                a = r_getDictIdFromFrame(e, NULL, (jbyteArray)whole); b = g_getDictIdFromFrame(e, NULL, (jbyteArray)whole);
+                CHECK(a == b, "getDictIdFromFrame case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                a = r_getDictIdFromDict(e, NULL, (jbyteArray)whole); b = g_getDictIdFromDict(e, NULL, (jbyteArray)whole);
+                CHECK(a == b, "getDictIdFromDict case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                a = r_getDictIdFromDictDirect(e, NULL, dir, off, n); b = g_getDictIdFromDictDirect(e, NULL, dir, off, n);
+                CHECK(a == b, "getDictIdFromDictDirect case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                {   Obj* exact = mk(1, n); memcpy(exact->data, pool + at[c], (size_t)n);
+                    a = r_getDictIdFromFrameBuffer(e, NULL, exact); b = g_getDictIdFromFrameBuffer(e, NULL, exact);
+                    CHECK(a == b, "getDictIdFromFrameBuffer case %d (n=%d): ref %lld ours %lld", c, n, (long long)a, (long long)b);
+                    free(exact->data); free(exact); }
+            }
+            if (c < 40) {                                                                           /* ranges outside the direct buffer */
+                jint const bad[][2] = {{-1, 4}, {0, -1}, {n + off + 5, 1}, {1, n + off + 5}, {n + off + 5, 0}, {0x7FFFFFFF, 0x7FFFFFFF}};
+                for (unsigned i = 0; i < sizeof bad / sizeof *bad; i++) {
+                    CHECK(r_findDirectByteBufferFrameCompressedSize(e, NULL, dir, bad[i][0], bad[i][1]) == g_findDirectByteBufferFrameCompressedSize(e, NULL, dir, bad[i][0], bad[i][1]), "findDirect... range %d/%d", bad[i][0], bad[i][1]);
+                    CHECK(r_decompressedDirectByteBufferSize(e, NULL, dir, bad[i][0], bad[i][1], JNI_FALSE) == g_decompressedDirectByteBufferSize(e, NULL, dir, bad[i][0], bad[i][1], JNI_FALSE), "decompressedDirect... range %d/%d", bad[i][0], bad[i][1]);
+                    CHECK(r_getDirectByteBufferFrameContentSize(e, NULL, dir, bad[i][0], bad[i][1], JNI_FALSE) == g_getDirectByteBufferFrameContentSize(e, NULL, dir, bad[i][0], bad[i][1], JNI_FALSE), "getDirect...ContentSize range %d/%d", bad[i][0], bad[i][1]);
+                }
+            }
+            free(whole->data); free(whole); free(shifted->data); free(shifted); free(dir->data); free(dir);
+        }
+        printf("JNI-HARNESS INSPECTION cases=%d\n", nCase);
+        free(pool);
+#undef ADD
+    }
+    if (getenv("HARNESS_ONLY_HELPERS")) {
+        if (g_bad) { printf("JNI-HARNESS FAILED bad=%d checks=%d\n", g_bad, g_checks); return 1; }
+        printf("JNI-HARNESS OK checks=%d\n", g_checks);
+        return 0;
+    }
     /* ZstdCompressCtx / ZstdDecompressCtx one-shot natives, direct buffers and byte[] */
     int const maxLevel = getenv("HARNESS_MAX_LEVEL") ? atoi(getenv("HARNESS_MAX_LEVEL")) : 3;
     int const plainMax = getenv("HARNESS_PLAIN_MAX_LEVEL") ? atoi(getenv("HARNESS_PLAIN_MAX_LEVEL")) : maxLevel;   /* the one-shot natives without a dictionary: levels 4-8 too on the GPU */

@@ -65,6 +65,23 @@ def test_shim_forwards_to_the_bundled_library_without_a_gpu():
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 
+@pytest.mark.parametrize("bundled", [False, True])
+def test_shim_answers_frame_inspection_and_constants_itself(bundled):
+    """Zstd.decompressedSize / getFrameContentSize / findFrameCompressedSize / getDictIdFromFrame / getDictIdFromDict (byte[] and direct forms) and the
+    36 constants are host-side natives of the shim (zjni_shim.c "frame inspection and constants": no GPU, no bundled library): equal to the reference's
+    natives on ~4 900 inputs — real frames, truncations, every header bit flipped, hand-made headers, skippable / pre-1.0 magics, magicless, noise, dictionaries,
+    bad direct ranges.  Loading the bundled library changes nothing (only pre-1.0 frames are passed to it)."""
+    if not _built():
+        pytest.skip("no <jni.h> in this environment and no prebuilt shim")
+    env = dict(os.environ, HARNESS_ONLY_HELPERS="1")
+    env.pop("ZSTD_JNI_CPU_LIB", None)
+    if bundled: env["ZSTD_JNI_CPU_LIB"] = REFJNI
+    out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout and "INSPECTION cases=4" in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+    trampolines = [l for l in open(os.path.join(ROOT, "zstd-jni_amd", "jni", "forward_list.h")) if l.startswith("FWD(")]
+    assert len(trampolines) == 9 and not any("Zstd_err" in l or "LogM" in l or "FrameCompressedSize" in l or "DictId" in l for l in trampolines), trampolines
+
+
 @pytest.mark.gpu
 def test_shim_equals_reference_jni_on_the_gpu():
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"

@@ -1,4 +1,4 @@
-/* zjni_forward.c — trampolines for the natives the GPU path has no business with (streams, training, constants, ...).
+/* zjni_forward.c — trampolines for the natives the GPU path has no business with (context streams, pledged size / progression, training).
  *
  * zstd-jni loads one library, so this one must export all 149 symbols of the reference's.  Each symbol
  * listed in forward_list.h (generated: the reference's exports minus what zjni_shim.c defines) is a signature-agnostic

@@ -10,7 +10,8 @@
  *     ZSTD_decompressDCtx.  Argument checks, their order and the returned codes are the reference's
  *     (N/jni_fast_zstd.c:586-640, :777-905; N/jni_zstd.c:50-63, :230-267);
  *   - the stream classes (DirectByteBuffer and heap-array, sections at the end of this file) buffer a stream and make its frame with one zjni_compress_stream call;
- *   - everything else (context streams, training, constants, ...) is a trampoline (zjni_forward.c) into the bundled CPU
+ *   - frame inspection (content size, frame extent, dictionary ids) and the constants of class Zstd are host-side code at the end of this file;
+ *   - what is left (context streams, pledged size / progression, training) is a trampoline (zjni_forward.c) into the bundled CPU
  *     library named by $ZSTD_JNI_CPU_LIB, looked up with dlsym — the CPU code stays where it is, this file contains none.
  *
  * Handles.  A context's nativePtr is the BUNDLED library's own ZSTD_CCtx* / ZSTD_DCtx* whenever that library is present,
@@ -243,6 +244,8 @@ SETTER(Zstd_setValidateSequences, jint, 'x')
 SETTER(Zstd_setSequenceProducerFallback, jboolean, 'x')
 SETTER(Zstd_setSearchForExternalRepcodes, jint, 'x')
 SETTER(Zstd_setDecompressionMagicless, jboolean, 'd')
+SETTER(Zstd_setDecompressionLongMax, jint, 'd')            /* ZSTD_d_windowLogMax (N/jni_zstd.c:400-404): a limit the GPU path does not apply, so the context decodes on the CPU */
+SETTER(Zstd_setRefMultipleDDicts, jboolean, 'd')           /* ZSTD_d_refMultipleDDicts (N/jni_zstd.c:522-526): the dictionary set lives in the bundled library's context */
 JNIEXPORT void JNICALL P(Zstd_registerSequenceProducer)(JNIEnv* env, jclass cls, jlong stream, jlong state, jlong fn) {
     void (*f)(JNIEnv*, jclass, jlong, jlong, jlong) = (void (*)(JNIEnv*, jclass, jlong, jlong, jlong))cpu_sym(PS("Zstd_registerSequenceProducer"));
     CtxState* s = st_get(stream, 'C'); if (s) s->cpuOnly = (fn != 0);
@@ -595,16 +598,17 @@ JNIEXPORT jlong JNICALL P(Zstd_compressBound)(JNIEnv* env, jclass cls, jlong siz
 JNIEXPORT jboolean JNICALL P(Zstd_isError)(JNIEnv* env, jclass cls, jlong code) { (void)env; (void)cls; return zjni_isError((size_t)code) != 0; }
 JNIEXPORT jstring JNICALL P(Zstd_getErrorName)(JNIEnv* env, jclass cls, jlong code) { (void)cls; return (*env)->NewStringUTF(env, zjni_getErrorName((size_t)code)); }
 JNIEXPORT jlong JNICALL P(Zstd_getErrorCode)(JNIEnv* env, jclass cls, jlong code) { (void)env; (void)cls; return (jlong)zjni_getErrorCode((size_t)code); }
-/* Zstd.getFrameContentSize(byte[], offset, limit, magicless) -> ZSTD_getFrameContentSize (N/jni_zstd.c:30-43, :86-96); the magicless
- * format is the bundled library's */
+/* Zstd.getFrameContentSize(byte[], offset, limit, magicless) -> ZSTD_getFrameContentSize (N/jni_zstd.c:30-43, :86-96) */
+static size_t frame_content_size(const uint8_t* p, size_t n, int magicless);      /* "frame inspection", at the end of this file */
+static int frame_is_legacy(const uint8_t* p, size_t n);
 JNIEXPORT jlong JNICALL P(Zstd_getFrameContentSize0)(JNIEnv* env, jclass cls, jbyteArray src, jint offset, jint limit, jboolean magicless) {
-    jlong (*f)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean) = (jlong (*)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean))cpu_sym(PS("Zstd_getFrameContentSize0"));
-    if (f) return f(env, cls, src, offset, limit, magicless);
-    if (magicless) return -(jlong)ZJNI_ERROR_unsupported;
-    {   jbyte head[18]; jint const n = limit < 18 ? (limit < 0 ? 0 : limit) : 18;          /* a frame header is at most 18 bytes */
-        (*env)->GetByteArrayRegion(env, src, offset, n, head);
-        return (jlong)zjni_getFrameContentSize(head, (size_t)n);
+    jbyte head[18]; jint const n = limit < 18 ? (limit < 0 ? 0 : limit) : 18;              /* a frame header is at most 18 bytes */
+    (*env)->GetByteArrayRegion(env, src, offset, n, head);
+    if (frame_is_legacy((const uint8_t*)head, (size_t)n)) {
+        jlong (*f)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean) = (jlong (*)(JNIEnv*, jclass, jbyteArray, jint, jint, jboolean))cpu_sym(PS("Zstd_getFrameContentSize0"));
+        if (f) return f(env, cls, src, offset, limit, magicless);
     }
+    return (jlong)frame_content_size((const uint8_t*)head, (size_t)n, magicless == JNI_TRUE);
 }
 JNIEXPORT jlong JNICALL P(Zstd_compressUnsafe)
   (JNIEnv* env, jclass cls, jlong dst, jlong dst_size, jlong src, jlong src_size, jint level, jboolean checksumFlag) {
@@ -1410,3 +1414,183 @@ JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_decompressStr
         if (s) s->started = (r > 0);
         return r; }
 }
+
+/* ---- frame inspection and constants: host-side arithmetic on a few header bytes, answered here whether or not a bundled library is loaded ------------
+ * Zstd.decompressedSize / getFrameContentSize / findFrameCompressedSize / getDictIdFromFrame / getDictIdFromDict in their byte[] and direct-buffer
+ * forms (N/jni_zstd.c:30-43, :70-227) and the constants of class Zstd (N/jni_zstd.c:573-667).  The layout parsed is the format's (RFC 8878 section 3.1.1:
+ * magic, frame header descriptor, window descriptor, dictionary id, content size; 3.1.2 skippable frames; 3.1.1.2 block headers); the answers for
+ * short, foreign and damaged inputs are libzstd's (N/decompress/zstd_decompress.c:447-545 header, :569-585 content size, :587-602 and :734-795 frame
+ * extent, :1624-1650 dictionary ids; N/decompress/zstd_decompress_block.c:63-78 block header) and tests/jni/harness.c compares every one of them with the
+ * reference library's native of the same name.  Frames of the pre-1.0 formats (magic 0xFD2FB522 .. 0xFD2FB527, which zstd-jni's build still reads) are
+ * the bundled library's: without it they are "not a zstd frame", as they are to the GPU path. */
+typedef struct { unsigned long long fcs; uint32_t dictID, headerSize; int skippable, checksum; } FrameHead;
+static uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+#define FH_ERR(code) ((size_t)0 - (size_t)(code))
+#define FH_IS_ERR(r) ((r) > (size_t)0 - 120)
+/* 0: *h filled; > 0 (not an error): that many bytes are needed; an error code otherwise */
+static size_t frame_head(FrameHead* h, const uint8_t* p, size_t n, int magicless) {
+    size_t const minIn = magicless ? 1 : 5;
+    if (n < minIn) {
+        if (n > 0 && !magicless) {                                         /* what is there must at least begin like a magic number */
+            uint8_t a[4] = { 0x28, 0xB5, 0x2F, 0xFD }, b[4] = { 0x50, 0x2A, 0x4D, 0x18 };
+            size_t const k = n < 4 ? n : 4;
+            memcpy(a, p, k); memcpy(b, p, k);
+            if (le32(a) != 0xFD2FB528u && (le32(b) & 0xFFFFFFF0u) != 0x184D2A50u) return FH_ERR(10);
+        }
+        return minIn;
+    }
+    memset(h, 0, sizeof *h);
+    if (!magicless && le32(p) != 0xFD2FB528u) {
+        if ((le32(p) & 0xFFFFFFF0u) != 0x184D2A50u) return FH_ERR(10);       /* prefix_unknown */
+        if (n < 8) return 8;
+        h->skippable = 1; h->dictID = le32(p) - 0x184D2A50u; h->headerSize = 8; h->fcs = le32(p + 4);
+        return 0;
+    }
+    {   uint8_t const fhd = p[minIn - 1];
+        unsigned const didCode = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+        static const uint8_t didSize[4] = { 0, 1, 2, 4 }, fcsSize[4] = { 0, 2, 4, 8 };
+        size_t const fhsize = minIn + !single + didSize[didCode] + fcsSize[fcsId] + (single && !fcsId);
+        size_t pos = minIn; int i;
+        if (n < fhsize) return fhsize;
+        h->headerSize = (uint32_t)fhsize;
+        if (fhd & 8) return FH_ERR(14);                                    /* frameParameter_unsupported: the reserved bit */
+        if (!single) { if ((unsigned)(p[pos++] >> 3) + 10 > 31) return FH_ERR(16); }      /* frameParameter_windowTooLarge */
+        for (i = 0; i < didSize[didCode]; i++) h->dictID |= (uint32_t)p[pos + i] << (8 * i);
+        pos += didSize[didCode];
+        h->fcs = ~0ull;
+        if (fcsId == 0) { if (single) h->fcs = p[pos]; }
+        else { h->fcs = 0; for (i = 0; i < fcsSize[fcsId]; i++) h->fcs |= (unsigned long long)p[pos + i] << (8 * i); if (fcsId == 1) h->fcs += 256; }
+        h->checksum = (fhd >> 2) & 1;
+    }
+    return 0;
+}
+static int frame_is_legacy(const uint8_t* p, size_t n) { return n >= 4 && le32(p) >= 0xFD2FB522u && le32(p) <= 0xFD2FB527u; }
+/* JNI_ZSTD_decompressedSize (N/jni_zstd.c:32-43) */
+static size_t frame_content_size(const uint8_t* p, size_t n, int magicless) {
+    FrameHead h;
+    if (magicless) return frame_head(&h, p, n, 1) != 0 ? 0 : (size_t)h.fcs;
+    if (frame_head(&h, p, n, 0) != 0) return (size_t)-2;                     /* ZSTD_CONTENTSIZE_ERROR */
+    return h.skippable ? 0 : (size_t)h.fcs;
+}
+/* ZSTD_findFrameCompressedSize */
+static size_t frame_compressed_size(const uint8_t* p, size_t n) {
+    FrameHead h; size_t pos, r;
+    if (n >= 8 && (le32(p) & 0xFFFFFFF0u) == 0x184D2A50u) {
+        uint32_t const sz = le32(p + 4);
+        if ((uint32_t)(sz + 8) < sz) return FH_ERR(14);
+        return (size_t)sz + 8 > n ? FH_ERR(72) : (size_t)sz + 8;
+    }
+    r = frame_head(&h, p, n, 0);
+    if (FH_IS_ERR(r)) return r;
+    if (r > 0) return FH_ERR(72);                                           /* srcSize_wrong */
+    pos = h.headerSize;
+    for (;;) {
+        uint32_t bh, type; size_t body;
+        if (n - pos < 3) return FH_ERR(72);
+        bh = (uint32_t)p[pos] | (uint32_t)p[pos + 1] << 8 | (uint32_t)p[pos + 2] << 16;
+        type = (bh >> 1) & 3;
+        if (type == 3) return FH_ERR(20);                                   /* corruption_detected: the reserved block type */
+        body = type == 1 ? 1 : bh >> 3;
+        if (3 + body > n - pos) return FH_ERR(72);
+        pos += 3 + body;
+        if (bh & 1) break;
+    }
+    if (h.checksum) { if (n - pos < 4) return FH_ERR(72); pos += 4; }
+    return pos;
+}
+static unsigned frame_dict_id(const uint8_t* p, size_t n) { FrameHead h; memset(&h, 0, sizeof h); return FH_IS_ERR(frame_head(&h, p, n, 0)) ? 0 : h.dictID; }
+static unsigned dict_dict_id(const uint8_t* p, size_t n) { return (n < 8 || le32(p) != 0xEC30A437u) ? 0 : le32(p + 4); }
+
+/* byte[] forms: the reference reads the array in place and checks nothing (the Java side has: J/Zstd.java), so an absurd (offset, limit) is the caller's */
+static uint8_t* array_bytes(JNIEnv* env, jbyteArray a, jint offset, jint n) {      /* a copy of a[offset, offset + n): inspection reads a header or walks block headers, never the payload twice */
+    uint8_t* b = (uint8_t*)malloc((size_t)(n > 0 ? n : 0) + 1);
+    if (b && n > 0) (*env)->GetByteArrayRegion(env, a, offset, n, (jbyte*)b);
+    return b;
+}
+#define LEGACY_TO_CPU(T_ARGS, CALL_ARGS, name, p_, n_) do { if (frame_is_legacy(p_, n_)) { jlong (*f_) T_ARGS = (jlong (*) T_ARGS)cpu_sym(PS(name)); if (f_) { jlong const r_ = f_ CALL_ARGS; free(own); return r_; } } } while (0)
+JNIEXPORT jlong JNICALL P(Zstd_decompressedSize0)(JNIEnv* env, jclass cls, jbyteArray src, jint offset, jint limit, jboolean magicless) {
+    jint const n = limit < 18 ? limit : 18;                                 /* a frame header is at most 18 bytes */
+    uint8_t* own = array_bytes(env, src, offset, n); size_t r;
+    if (!own) return E_MEM;
+    LEGACY_TO_CPU((JNIEnv*, jclass, jbyteArray, jint, jint, jboolean), (env, cls, src, offset, limit, magicless), "Zstd_decompressedSize0", own, (size_t)(n > 0 ? n : 0));
+    r = frame_content_size(own, (size_t)(n > 0 ? n : 0), magicless == JNI_TRUE); free(own);
+    return (jlong)r;                                                        /* (N/jni_zstd.c:77 compares an unsigned size with 0: unknown and error come back as -1 and -2, as from getFrameContentSize0) */
+}
+JNIEXPORT jlong JNICALL P(Zstd_findFrameCompressedSize0)(JNIEnv* env, jclass cls, jbyteArray src, jint offset, jint limit) {
+    uint8_t* own = array_bytes(env, src, offset, limit); size_t r;
+    if (!own) return E_MEM;
+    LEGACY_TO_CPU((JNIEnv*, jclass, jbyteArray, jint, jint), (env, cls, src, offset, limit), "Zstd_findFrameCompressedSize0", own, (size_t)(limit > 0 ? limit : 0));
+    r = frame_compressed_size(own, (size_t)(limit > 0 ? limit : 0)); free(own);
+    return (jlong)r;
+}
+JNIEXPORT jlong JNICALL P(Zstd_getDictIdFromFrame)(JNIEnv* env, jclass cls, jbyteArray src) {
+    jsize const len = (*env)->GetArrayLength(env, src); jint const n = len < 18 ? len : 18;
+    uint8_t* own = array_bytes(env, src, 0, n); unsigned id;
+    (void)cls;
+    if (!own) return 0;
+    id = frame_dict_id(own, (size_t)n); free(own);
+    return (jlong)id;
+}
+JNIEXPORT jlong JNICALL P(Zstd_getDictIdFromDict)(JNIEnv* env, jclass cls, jbyteArray src) {
+    jsize const len = (*env)->GetArrayLength(env, src); jint const n = len < 8 ? len : 8;
+    uint8_t* own = array_bytes(env, src, 0, n); unsigned id;
+    (void)cls;
+    if (!own) return 0;
+    id = dict_dict_id(own, (size_t)n); free(own);
+    return (jlong)id;
+}
+/* direct-buffer forms: range checked against the buffer's capacity, -ZSTD_error_GENERIC when outside (N/jni_zstd.c:104-114, :198-227) */
+static const uint8_t* direct_range(JNIEnv* env, jobject buf, jint offset, jint size, jlong* err) {
+    jlong const cap = (*env)->GetDirectBufferCapacity(env, buf); const uint8_t* p;
+    if (offset < 0 || size < 0 || offset > cap - size) { *err = -1; return NULL; }
+    p = (const uint8_t*)(*env)->GetDirectBufferAddress(env, buf);
+    if (!p) { *err = E_MEM; return NULL; }
+    return p + offset;
+}
+JNIEXPORT jlong JNICALL P(Zstd_findDirectByteBufferFrameCompressedSize)(JNIEnv* env, jclass cls, jobject src, jint offset, jint size) {
+    jlong err = 0; const uint8_t* p = direct_range(env, src, offset, size, &err); uint8_t* own = NULL;
+    if (!p) return err;
+    LEGACY_TO_CPU((JNIEnv*, jclass, jobject, jint, jint), (env, cls, src, offset, size), "Zstd_findDirectByteBufferFrameCompressedSize", p, (size_t)size);
+    return (jlong)frame_compressed_size(p, (size_t)size);
+}
+JNIEXPORT jlong JNICALL P(Zstd_decompressedDirectByteBufferSize)(JNIEnv* env, jclass cls, jobject src, jint offset, jint size, jboolean magicless) {
+    jlong err = 0; const uint8_t* p = direct_range(env, src, offset, size, &err); uint8_t* own = NULL;
+    if (!p) return err;
+    LEGACY_TO_CPU((JNIEnv*, jclass, jobject, jint, jint, jboolean), (env, cls, src, offset, size, magicless), "Zstd_decompressedDirectByteBufferSize", p, (size_t)size);
+    return (jlong)frame_content_size(p, (size_t)size, magicless == JNI_TRUE);      /* (as decompressedSize0: the unsigned comparison at N/jni_zstd.c:211 lets -1 and -2 through) */
+}
+JNIEXPORT jlong JNICALL P(Zstd_getDirectByteBufferFrameContentSize)(JNIEnv* env, jclass cls, jobject src, jint offset, jint size, jboolean magicless) {
+    jlong err = 0; const uint8_t* p = direct_range(env, src, offset, size, &err); uint8_t* own = NULL;
+    if (!p) return err;
+    LEGACY_TO_CPU((JNIEnv*, jclass, jobject, jint, jint, jboolean), (env, cls, src, offset, size, magicless), "Zstd_getDirectByteBufferFrameContentSize", p, (size_t)size);
+    return (jlong)frame_content_size(p, (size_t)size, magicless == JNI_TRUE);
+}
+JNIEXPORT jlong JNICALL P(Zstd_getDictIdFromFrameBuffer)(JNIEnv* env, jclass cls, jobject src) {
+    jlong const cap = (*env)->GetDirectBufferCapacity(env, src); const uint8_t* p;
+    (void)cls;
+    if (cap <= 0) return 0;
+    p = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
+    return p ? (jlong)frame_dict_id(p, (size_t)cap) : 0;
+}
+JNIEXPORT jlong JNICALL P(Zstd_getDictIdFromDictDirect)(JNIEnv* env, jclass cls, jobject src, jint offset, jint size) {
+    const uint8_t* p = (const uint8_t*)(*env)->GetDirectBufferAddress(env, src);
+    (void)cls;
+    return p ? (jlong)dict_dict_id(p + offset, (size_t)size) : 0;
+}
+JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_recommendedDOutSizeNative)(JNIEnv* env, jclass cls) {
+    jlong (*f)(JNIEnv*, jclass) = (jlong (*)(JNIEnv*, jclass))cpu_sym(PS("ZstdDirectBufferDecompressingStreamNoFinalizer_recommendedDOutSizeNative"));
+    return f ? f(env, cls) : (jlong)(128u << 10);                                    /* ZSTD_DStreamOutSize() */
+}
+/* the constants of zstd.h as this library's format code was written against them (a 64-bit build: N/zstd.h:133-148, :1263-1275; levels N/compress/clevels.h,
+ * ZSTD_minCLevel = -ZSTD_TARGETLENGTH_MAX) and the error enumeration (N/zstd_errors.h:60-96, the values zjni_getErrorCode returns) */
+#define CONST_INT(name, v) JNIEXPORT jint JNICALL P(Zstd_##name)(JNIEnv* env, jclass cls) { (void)env; (void)cls; return (jint)(v); }
+CONST_INT(windowLogMin, 10) CONST_INT(windowLogMax, 31) CONST_INT(chainLogMin, 6) CONST_INT(chainLogMax, 30) CONST_INT(hashLogMin, 6) CONST_INT(hashLogMax, 30)
+CONST_INT(searchLogMin, 1) CONST_INT(searchLogMax, 30) CONST_INT(magicNumber, 0xFD2FB528u) CONST_INT(blockSizeMax, 1 << 17)
+CONST_INT(defaultCompressionLevel, 3) CONST_INT(minCompressionLevel, -(1 << 17)) CONST_INT(maxCompressionLevel, 22)
+#define CONST_ERR(name, v) JNIEXPORT jlong JNICALL P(Zstd_err##name)(JNIEnv* env, jclass cls) { (void)env; (void)cls; return (jlong)(v); }
+CONST_ERR(NoError, 0) CONST_ERR(Generic, 1) CONST_ERR(PrefixUnknown, 10) CONST_ERR(VersionUnsupported, 12) CONST_ERR(FrameParameterUnsupported, 14)
+CONST_ERR(FrameParameterWindowTooLarge, 16) CONST_ERR(CorruptionDetected, 20) CONST_ERR(ChecksumWrong, 22) CONST_ERR(DictionaryCorrupted, 30)
+CONST_ERR(DictionaryWrong, 32) CONST_ERR(DictionaryCreationFailed, 34) CONST_ERR(ParameterUnsupported, 40) CONST_ERR(ParameterOutOfBound, 42)
+CONST_ERR(TableLogTooLarge, 44) CONST_ERR(MaxSymbolValueTooLarge, 46) CONST_ERR(MaxSymbolValueTooSmall, 48) CONST_ERR(StageWrong, 60)
+CONST_ERR(InitMissing, 62) CONST_ERR(MemoryAllocation, 64) CONST_ERR(WorkSpaceTooSmall, 66) CONST_ERR(DstSizeTooSmall, 70) CONST_ERR(SrcSizeWrong, 72)
+CONST_ERR(DstBufferNull, 74)
