@@ -648,6 +648,130 @@ int main(int argc, char** argv) {
             R.cfree(e, NULL, rc); G.cfree(e, NULL, gc); R.dfree(e, NULL, rd); G.dfree(e, NULL, gd);
         }
     }
+    /* ---- the context streams: ZstdCompressCtx.compress*Stream0 in the four heap / direct combinations and ZstdDecompressCtx.decompressDirectByteBufferStream0
+     * (N/jni_fast_zstd.c:392-579, :720-769).  The same directives (continue per write, flush now and then, end) on both libraries, whatever room the caller's
+     * target has: the bytes that come out must be the same bytes, every input byte must be taken, the word's error bit never set; frames whose first directive is
+     * the end (one-shot frames, also pledged, also into a small target, levels up to HARNESS_PLAIN_MAX_LEVEL); then the frames back through the decompress native */
+    if (!getenv("HARNESS_SKIP_STREAMS")) {
+        typedef jlong (*xdd_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint, jint);
+        typedef jlong (*xad_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jbyteArray, jint, jint, jint, jint);
+        typedef jlong (*xda_fn)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jobject, jint, jint, jint);
+        typedef jlong (*xaa_fn)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jbyteArray, jint, jint, jint, jint);
+        typedef jlong (*xpl_fn)(JNIEnv*, jclass, jlong, jlong); typedef jobject (*xpr_fn)(JNIEnv*, jclass, jlong);
+        typedef jlong (*xds_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint);
+        struct { xdd_fn dd; xad_fn ad; xda_fn da; xaa_fn aa; xpl_fn pledge; xpr_fn prog; xds_fn ds; } X[2];
+        Lib* libs[2] = {&R, &G};
+        jsize const totals[] = {0, 1, 100, 5000, 70000, 131072, 200000, 300000, 600000, 2097152, 2200000};
+        int const streamMax = getenv("HARNESS_STREAM_MAX") ? atoi(getenv("HARNESS_STREAM_MAX")) : (1 << 30);
+        STAGE("context streams");
+        for (int k = 0; k < 2; k++) {
+#define XS(field, name) *(void**)&X[k].field = dlsym(libs[k]->h, P name)
+            XS(dd, "ZstdCompressCtx_compressDirectByteBufferStream0"); XS(ad, "ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0");
+            XS(da, "ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0"); XS(aa, "ZstdCompressCtx_compressByteArrayStream0");
+            XS(pledge, "ZstdCompressCtx_setPledgedSrcSize0"); XS(prog, "ZstdCompressCtx_getFrameProgression0"); XS(ds, "ZstdDecompressCtx_decompressDirectByteBufferStream0");
+#undef XS
+            CHECK(X[k].dd && X[k].ad && X[k].da && X[k].aa && X[k].pledge && X[k].prog && X[k].ds, "context stream natives of library %d", k);
+        }
+        /* one directive, in combination `comb` (0 direct/direct, 1 array source, 2 array target, 3 both arrays), repeated until it reports done (or, for continue, until the
+         * source is taken); what comes out is appended to out */
+#define DIRECTIVE(k, comb, ctx, srcObjD, srcObjA, sBase, sFrom, sTo, op) do { \
+            jint spos = (sFrom); int guard_ = 0; \
+            for (;;) { \
+                jlong w_ = 0; jint const aoffD = 3, aoffS = 2; \
+                if ((comb) == 0) w_ = X[k].dd(e, NULL, ctx, (jobject)dstD, 0, room, (jobject)(srcObjD), spos, (sTo), (op)); \
+                if ((comb) == 1) w_ = X[k].ad(e, NULL, ctx, (jobject)dstD, 0, room, (jbyteArray)(srcObjA), aoffS, spos, (sTo), (op)); \
+                if ((comb) == 2) w_ = X[k].da(e, NULL, ctx, (jbyteArray)dstA, aoffD, 0, room, (jobject)(srcObjD), spos, (sTo), (op)); \
+                if ((comb) == 3) w_ = X[k].aa(e, NULL, ctx, (jbyteArray)dstA, aoffD, 0, room, (jbyteArray)(srcObjA), aoffS, spos, (sTo), (op)); \
+                if ((uint64_t)w_ & 0x80000000u) { worst[k] = (jlong)((uint64_t)w_ & 0xFFFFFFFFu); break; } \
+                {   jint const dp_ = (jint)(((uint64_t)w_ >> 32) & 0x7FFFFFFFu), sp_ = (jint)((uint64_t)w_ & 0x7FFFFFFFu); \
+                    if (sp_ < spos || sp_ > (sTo) || dp_ > room) { worst[k] = -999; break; } \
+                    if (n + (size_t)dp_ > cap) { worst[k] = -998; break; } \
+                    memcpy(out + n, ((comb) & 2) ? dstA->data + aoffD : dstD->data, (size_t)dp_); n += (size_t)dp_; \
+                    spos = sp_; } \
+                if (((op) == 0 && spos == (sTo)) || ((op) != 0 && ((uint64_t)w_ >> 63) && spos == (sTo))) break; \
+                if (++guard_ > 200000) { worst[k] = -997; break; } \
+            } } while (0)
+        for (unsigned ti = 0; ti < sizeof totals / sizeof *totals; ti++) for (int variant = 0; variant < 4; variant++) {
+            jsize const total = totals[ti];
+            jint const level = 1 + (jint)((ti + (unsigned)variant) % 3u);
+            jsize const chunk = variant == 0 ? 50000 : (variant == 1 ? 131072 : (variant == 2 ? 7000 : 300000));
+            int const flushEvery = variant == 2 ? 3 : (variant == 3 ? 1 : 0);
+            jint const room = variant == 1 ? 900 : (1 << 22);
+            int const comb = (int)((ti + (unsigned)variant) & 3u), ck = (int)(ti & 1u);
+            if ((long long)total > (1ll << (18 + level)) && total > streamMax) continue;
+            Obj* srcD = mk(1, total > 0 ? total : 1); Obj* srcA = mk(2, total + 2); fill(srcD->data, total, (int)(ti % 3u)); memcpy(srcA->data + 2, srcD->data, (size_t)total);
+            char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                Obj* dstD = mk(1, room); Obj* dstA = mk(2, room + 3);
+                jlong const ctx = libs[k]->cinit(e, NULL);
+                size_t const cap = (size_t)total + (size_t)total / 64 + (1u << 16); char* out = (char*)malloc(cap); size_t n = 0; int calls = 0;
+                libs[k]->setLevel(e, NULL, ctx, level); libs[k]->setChecksum(e, NULL, ctx, ck ? JNI_TRUE : JNI_FALSE);
+                for (jsize at = 0; at < total && worst[k] == 0; ) {
+                    jsize const len = total - at < chunk ? total - at : chunk;
+                    DIRECTIVE(k, comb, ctx, srcD, srcA, 0, at, at + len, 0);
+                    at += len; calls++;
+                    if (flushEvery && calls % flushEvery == 0 && worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, at, at, 1);
+                    if (calls == 2 && worst[k] == 0) CHECK(X[k].prog(e, NULL, ctx) != NULL, "getFrameProgression0 inside a frame (library %d)", k);
+                }
+                if (worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, total, total, 2);
+                /* the context is at a frame boundary again: a second, small frame through it */
+                if (worst[k] == 0 && total > 100) { DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 0, 60, 0); if (worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 60, 100, 2); }
+                libs[k]->cfree(e, NULL, ctx);
+                outs[k] = out; lens[k] = n;
+                free(dstD->data); free(dstD); free(dstA->data); free(dstA);
+            }
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "context stream of %d bytes, level %d ck %d, writes of %d, flush every %d, room %d, combination %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                  (int)total, (int)level, ck, (int)chunk, flushEvery, (int)room, comb, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+            free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
+        }
+        /* frames whose first directive is the end: with and without a pledged size, a pledge that does not match (libzstd replaces it by the input's size), a roomy and a tiny target, the four combinations */
+        {   int const plainMax2 = getenv("HARNESS_PLAIN_MAX_LEVEL") ? atoi(getenv("HARNESS_PLAIN_MAX_LEVEL")) : (getenv("HARNESS_MAX_LEVEL") ? atoi(getenv("HARNESS_MAX_LEVEL")) : 3);
+            jsize const ones[] = {0, 1, 300, 30000, 131072, 131073, 500000};
+            for (unsigned oi = 0; oi < sizeof ones / sizeof *ones; oi++) for (int level = 1; level <= plainMax2; level++) for (int mode = 0; mode < 4; mode++) {
+                jsize const total = ones[oi];
+                jint const room = (mode == 1) ? 700 : (1 << 20);
+                int const comb = (int)((oi + (unsigned)level + (unsigned)mode) & 3u);
+                if (level > 3 && total > 131072) continue;
+                Obj* srcD = mk(1, total > 0 ? total : 1); Obj* srcA = mk(2, total + 2); fill(srcD->data, total, (int)(oi % 3u)); memcpy(srcA->data + 2, srcD->data, (size_t)total);
+                char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+                for (int k = 0; k < 2; k++) {
+                    Obj* dstD = mk(1, room); Obj* dstA = mk(2, room + 3);
+                    jlong const ctx = libs[k]->cinit(e, NULL);
+                    size_t const cap = (size_t)total + (size_t)total / 64 + (1u << 16); char* out = (char*)malloc(cap); size_t n = 0;
+                    libs[k]->setLevel(e, NULL, ctx, level); libs[k]->setChecksum(e, NULL, ctx, (oi & 1) ? JNI_TRUE : JNI_FALSE);
+                    if (mode == 2) worst[k] = X[k].pledge(e, NULL, ctx, total);
+                    if (mode == 3) worst[k] = X[k].pledge(e, NULL, ctx, (jlong)total + 5);
+                    if (worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 0, total, 2);
+                    if (worst[k] == 0 && total >= 300) { DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 0, 300, 2); }       /* and the next frame through the same context */
+                    libs[k]->cfree(e, NULL, ctx);
+                    outs[k] = out; lens[k] = n;
+                    free(dstD->data); free(dstD); free(dstA->data); free(dstA);
+                }
+                CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "one-directive frame of %d bytes, level %d, mode %d, room %d, combination %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                           (int)total, level, mode, (int)room, comb, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+                /* back through the decompress native of both libraries: the whole frame in the source, room for all of it; then a target one byte short (an error or more calls, never wrong bytes) */
+                if (mode == 0 && worst[0] == 0 && lens[0] > 0) {
+                    jsize const flen = (jsize)lens[0];
+                    Obj* fr = mk(1, flen + 7); memcpy(fr->data + 4, outs[0], (size_t)flen);
+                    for (int k = 0; k < 2; k++) {
+                        jlong const dctx = libs[k]->dinit(e, NULL); Obj* back = mk(1, total + 300 + 9);
+                        jint dpos = 5, spos = 4; int guard = 0; uint64_t w = 0; int frames = 0;
+                        while (spos < 4 + flen && guard++ < 1000) {
+                            w = (uint64_t)X[k].ds(e, NULL, dctx, (jobject)back, dpos, total + 300 + 9, (jobject)fr, spos, 4 + flen);
+                            if (w & 0x80000000u) break;
+                            dpos = (jint)((w >> 32) & 0x7FFFFFFFu); spos = (jint)(w & 0x7FFFFFFFu); if (w >> 63) frames++;
+                        }
+                        CHECK(!(w & 0x80000000u) && (w >> 63) && spos == 4 + flen && dpos == 5 + total + (total >= 300 ? 300 : 0) && !memcmp(back->data + 5, srcD->data, (size_t)total),
+                              "decompressDirectByteBufferStream0 (library %d) of the %d-byte frame(s), level %d: word %llx, %d out, %d consumed, %d frame ends", k, (int)total, level, (unsigned long long)w, (int)dpos - 5, (int)spos - 4, frames);
+                        libs[k]->dfree(e, NULL, dctx); free(back->data); free(back);
+                    }
+                    free(fr->data); free(fr);
+                }
+                free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
+            }
+        }
+#undef DIRECTIVE
+    }
     /* ---- the DirectByteBuffer stream classes (N/jni_directbuffercompress_zstd.c, jni_directbufferdecompress_zstd.c): the same writes, flushes and close on
      * both libraries, whatever room the caller's target buffer has — the bytes that come out must be the same bytes; then the frames through both decompress streams */
     if (!getenv("HARNESS_SKIP_STREAMS")) {

@@ -119,7 +119,13 @@ typedef struct CtxState {
      * the first compress call, with the level set by then, and keeps that CDict until the dictionary is replaced (ZSTD_initLocalDict,
      * N/compress/zstd_compress.c:1246-1290) — frames equal ZSTD_CCtx_refCDict's (checked against the reference: every size up to one block). */
     void* rawDict; size_t rawDictSize; zjni_cdict* localCdict;
+    /* the context used as a stream (compress*Stream0 / decompressDirectByteBufferStream0, "the context streams" near the end of this file) */
+    struct StreamState* cx;                                /* compress: the frame being written (NULL: none yet) */
+    int hasPledged; unsigned long long pledged;            /* ZSTD_CCtx_setPledgedSrcSize for the next frame */
+    int cpuInFrame;                                        /* compress: a frame is being written by the bundled library's context (calls passed on as they came) */
+    int dInFrame;                                          /* decompress: the bundled library's stream is inside a frame */
 } CtxState;
+static void cx_drop(CtxState* c);
 static void st_drop_local_dict(CtxState* s) {
     if (s->localCdict) { zjni_freeCDict(s->localCdict); s->localCdict = NULL; }
     if (s->rawDict) { free(s->rawDict); s->rawDict = NULL; s->rawDictSize = 0; }
@@ -167,7 +173,7 @@ static jlong ctx_init(JNIEnv* env, jclass cls, const char* name, int kind) {
 static void ctx_free(JNIEnv* env, jclass cls, jlong ptr, const char* name, int kind) {
     void (*f)(JNIEnv*, jclass, jlong) = (void (*)(JNIEnv*, jclass, jlong))cpu_sym(name);
     CtxState* s = st_take(ptr, kind);
-    if (s) { if (s->ddictOwned) zjni_freeDDict(s->ddictOwned); st_drop_local_dict(s); free(s); }
+    if (s) { if (s->ddictOwned) zjni_freeDDict(s->ddictOwned); st_drop_local_dict(s); cx_drop(s); free(s); }
     if (!ptr) return;
     if (f) f(env, cls, ptr); else free((void*)(intptr_t)ptr);
 }
@@ -197,14 +203,14 @@ JNIEXPORT void JNICALL P(ZstdCompressCtx_setDictID0)(JNIEnv* env, jclass cls, jl
 /* ZSTD_CCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:364-368): parameters back to their defaults, dictionary dropped */
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
     jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdCompressCtx_reset0"));
-    CtxState* s = st_get(ptr, 'C'); if (s) { st_defaults(s); st_drop_local_dict(s); }      /* ZSTD_reset_session_and_parameters clears the dictionaries too */
+    CtxState* s = st_get(ptr, 'C'); if (s) { st_defaults(s); st_drop_local_dict(s); cx_drop(s); s->hasPledged = 0; s->cpuInFrame = 0; }      /* ZSTD_reset_session_and_parameters clears the dictionaries too, and ends a frame being streamed */
     return f ? f(env, cls, ptr) : 0;
 }
 /* ZSTD_DCtx_reset(session_and_parameters) (N/jni_fast_zstd.c:712-716) */
 JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
     jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdDecompressCtx_reset0"));
     CtxState* s = st_get(ptr, 'D');
-    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuOnly = 0; s->cpuDict = 0; }
+    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuOnly = 0; s->cpuDict = 0; s->dInFrame = 0; }
     return f ? f(env, cls, ptr) : 0;
 }
 /* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
@@ -420,8 +426,8 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_loadDDict0)(JNIEnv* env, jclass cls,
 }
 
 /* ---- compress: ZSTD_CCtx_reset + ZSTD_compress2 (N/jni_fast_zstd.c:606-607, :633-635) ----------------- */
-static int gpu_takes(const CtxState* s, jint srcSize) {
-    if (!s || s->cpuOnly || s->cpuDict || !per_buffer_on_gpu()) return 0;
+static int gpu_takes_when(const CtxState* s, jint srcSize, int on) {
+    if (!s || s->cpuOnly || s->cpuDict || !on) return 0;
     if (s->rawDict && !s->localCdict && !s->cpuDict) {                 /* first compress after loadDict(byte[]): the local CDict, at the level of this moment */
         CtxState* w = (CtxState*)s;
         int const lvl = s->level == 0 ? 3 : s->level;
@@ -433,6 +439,7 @@ static int gpu_takes(const CtxState* s, jint srcSize) {
     if (s->level >= 4 && s->level <= 8) return (size_t)srcSize <= (s->level == 4 ? ZJNI_LEVEL4_MAX : ZJNI_LAZY_MAX) && !(s->hashLog | s->chainLog);   /* one block, no explicit table sizes */
     return s->level >= 0 && s->level <= 3 && (size_t)srcSize <= ZJNI_FRAME_MAX;       /* beyond the level's window the library answers 201 and the call is forwarded */
 }
+static int gpu_takes(const CtxState* s, jint srcSize) { return gpu_takes_when(s, srcSize, per_buffer_on_gpu()); }
 static int frame_flags(const CtxState* s) {
     return (s->checksum ? ZJNI_FRAME_CHECKSUM : 0) | (s->contentSize ? 0 : ZJNI_FRAME_NO_CONTENTSIZE) | (s->dictIDFlag ? 0 : ZJNI_FRAME_NO_DICTID);
 }
@@ -1413,6 +1420,310 @@ JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_decompressStr
     {   jlong const r = f(env, obj, stream, dst, dst_offset, dst_size, src, src_offset, src_size);
         if (s) s->started = (r > 0);
         return r; }
+}
+
+/* ==== the context streams: ZstdCompressCtx.compress*Stream0 (N/jni_fast_zstd.c:392-579), setPledgedSrcSize0 (:383-390), getFrameProgression0 (:370-381) and
+ * ZstdDecompressCtx.decompressDirectByteBufferStream0 (:720-769) =======================================================================================
+ * ZSTD_compressStream2(cctx, out, in, endOp) on the context, in the four heap / direct combinations.  The route is the stream classes': a frame is buffered
+ * while it is written (ZSTD_e_continue takes the bytes in), ZSTD_e_flush hands out the frame's next part up to here, ZSTD_e_end the rest — one
+ * zjni_compress_stream call each, byte for byte what the reference's context writes over the same directives.  Two cases are one-shot frames and go where
+ * compress*0 goes: a frame whose FIRST call is ZSTD_e_end (libzstd takes the input's size as pledged: the frame ZSTD_compress2 makes, content size and
+ * all — N/compress/zstd_compress.c:6366, :6450-6560), whatever size was pledged.  A pledged size with more than one call, a dictionary, explicit
+ * table sizes, levels above 3, a frame that outgrows the level's window or a GPU that declines: the bundled library's context takes the frame — from its
+ * first byte (what was buffered is replayed into it through ITS native, output already handed out is skipped) — and keeps it until it ends.  The result word
+ * is the reference's: error -> 1 << 31 | code; else dstPos << 32 | srcPos, bit 63 when nothing is left to flush (:423-433).
+ * What differs from the reference, as for the stream classes: WHEN bytes come out (nothing before a flush or the end), never which bytes. */
+#define CX_ERR(code) ((jlong)((1ULL << 31) | (unsigned)(code)))
+static jlong cx_word(int done, size_t dpos, size_t spos) { uint64_t r = ((uint64_t)(uint32_t)dpos << 32) | (uint32_t)spos; if (done) r |= 1ULL << 63; return (jlong)r; }
+typedef jlong (*cx_dd_fn)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint, jint);
+static void cx_drop(CtxState* c) { if (c->cx) { ss_free(c->cx); c->cx = NULL; } }
+static StreamState* cx_session(CtxState* c) {
+    if (!c->cx) { c->cx = (StreamState*)calloc(1, sizeof(StreamState)); if (c->cx) ss_reset(c->cx, 3); }
+    return c->cx;
+}
+/* one call of the bundled library's direct-buffer stream native over raw memory: 0 and (*produced, *consumed, *done) or *err; -1: no such library */
+static int cx_cpu_call(JNIEnv* env, jclass cls, jlong ptr, char* dst, size_t room, const char* src, size_t n, int op, size_t* produced, size_t* consumed, int* done, unsigned* err) {
+    cx_dd_fn f = (cx_dd_fn)cpu_sym(PS("ZstdCompressCtx_compressDirectByteBufferStream0"));
+    static char nothing[8];
+    jobject dbuf, sbuf; uint64_t r;
+    if (!f || !(*env)->NewDirectByteBuffer) return -1;
+    dbuf = (*env)->NewDirectByteBuffer(env, room ? dst : nothing, (jlong)room); sbuf = (*env)->NewDirectByteBuffer(env, n ? (void*)src : (void*)nothing, (jlong)n);
+    if (!dbuf || !sbuf) return -1;
+    r = (uint64_t)f(env, cls, ptr, dbuf, 0, (jint)room, sbuf, 0, (jint)n, op);
+    if ((*env)->DeleteLocalRef) { (*env)->DeleteLocalRef(env, dbuf); (*env)->DeleteLocalRef(env, sbuf); }
+    *err = 0; *produced = *consumed = 0; *done = 0;
+    if (r & 0x80000000u) { *err = (unsigned)(r & 0x7FFFFFFFu); return 0; }
+    *produced = (size_t)((r >> 32) & 0x7FFFFFFFu); *consumed = (size_t)(r & 0x7FFFFFFFu); *done = (int)(r >> 63);
+    return 0;
+}
+/* everything buffered goes to the bundled library's context (flushes where the caller flushed); what it writes is collected, and the part the caller already
+ * has is skipped.  Afterwards the frame is the bundled library's (cpuMode). */
+static int cx_replay_to_cpu(JNIEnv* env, jclass cls, jlong ptr, StreamState* s) {
+    size_t at = 0, fi = 0; size_t const scratchCap = 256u << 10;
+    size_t const delivered = s->emitted - (s->outLen - s->outPos);
+    char* scratch = (char*)malloc(scratchCap);
+    if (!scratch) return -1;
+    s->outLen = s->outPos = 0;
+    while (at < s->total || fi < s->nFlush) {
+        size_t const upto = fi < s->nFlush ? s->flushAt[fi] : s->total;
+        int const flushing = at >= upto;                           /* the bytes up to the flush are in: now the directive itself, until it is done */
+        size_t produced, consumed; int done; unsigned err;
+        if (cx_cpu_call(env, cls, ptr, scratch, scratchCap, (const char*)s->buf + at, flushing ? 0 : upto - at, flushing ? 1 : 0, &produced, &consumed, &done, &err) != 0 || err
+            || !ss_out_room(s, produced)) { free(scratch); return -1; }
+        memcpy(s->out + s->outLen, scratch, produced); s->outLen += produced;
+        at += consumed;
+        if (flushing) { if (done) fi++; }
+        else if (!consumed && !produced) { free(scratch); return -1; }
+    }
+    free(scratch);
+    if (s->outLen < delivered) return -1;
+    s->outPos = delivered; s->emitted = 0; s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
+    return 0;
+}
+static int cx_plain(const CtxState* c) {                            /* what zjni_compress_stream can express: a level and the checksum flag */
+    int const level = c->level == 0 ? 3 : c->level;
+    return !c->cpuOnly && !c->cpuDict && !c->cdict && !c->localCdict && !c->rawDict && !(c->hashLog | c->chainLog) && level >= 1 && level <= 3;
+}
+/* One directive over raw memory: dst has `room` bytes free, src holds `n` unread bytes.  1: answered (*produced, *consumed, *done, or *err = a libzstd code);
+ * 0: this frame is not for the GPU route and nothing has been touched — the caller passes the call on as it came. */
+static int cx_stream(JNIEnv* env, jclass cls, jlong ptr, CtxState* c, char* dst, size_t room, const char* src, size_t n, int op,
+                     size_t* produced, size_t* consumed, int* done, unsigned* err) {
+    StreamState* s = c ? c->cx : NULL;
+    int const fresh = !s || (!s->started && !s->cpuMode && s->total == 0 && s->outPos == s->outLen);
+    *produced = *consumed = 0; *done = 0; *err = 0;
+    if (!c || op < 0 || op > 2 || c->cpuInFrame) return 0;
+    if (fresh) {
+        if (!streams_on_gpu()) return 0;
+        if (op == 2) {                                              /* the whole frame in one directive: a one-shot frame */
+            size_t cap, r; unsigned char* tmp;
+            if (n > 0x7FFFFFFFu || !gpu_takes_when(c, (jint)n, 1)) return 0;
+            /* (a pledged size does not matter here: ending at the first directive, libzstd replaces it by the input's size — N/compress/zstd_compress.c:6366) */
+            if (!(s = cx_session(c))) { *err = 64; return 1; }
+            cap = zjni_compressBound(n) + 64;
+            tmp = (unsigned char*)malloc(cap); if (!tmp) { *err = 64; return 1; }
+            r = gpu_compress(c, tmp, cap, src, n);
+            if (!gpu_compress_final(c, r, cpu_sym(PS("ZstdCompressCtx_compressDirectByteBufferStream0")) != NULL)) { free(tmp); return 0; }
+            if (zjni_isError(r)) { free(tmp); if (zjni_getErrorCode(r) >= 200) return 0; *err = (unsigned)zjni_getErrorCode(r); return 1; }
+            ss_reset(s, c->level);
+            if (!ss_out_room(s, r)) { free(tmp); *err = 64; return 1; }
+            memcpy(s->out, tmp, r); s->outLen = r; s->emitted = r; s->finished = 1; s->started = 1;
+            free(tmp);
+            *consumed = n;
+        } else {
+            if (c->hasPledged || !cx_plain(c)) return 0;
+            if (!(s = cx_session(c))) { *err = 64; return 1; }
+            ss_reset(s, c->level == 0 ? 3 : c->level); s->checksum = c->checksum;
+        }
+    }
+    if (s->cpuMode) {                                               /* replayed earlier: what the bundled context wrote then goes out first, then the call is its own */
+        size_t const k = ss_deliver(s, dst, room); size_t p2 = 0;
+        *produced = k;
+        if (s->outPos < s->outLen) return 1;
+        if (cx_cpu_call(env, cls, ptr, dst + k, room - k, src, n, op, &p2, consumed, done, err) != 0) { *err = ZJNI_ERROR_unsupported; return 1; }
+        *produced = k + p2;
+        if (*err || (op == 2 && *done)) { ss_reset(s, 3); c->hasPledged = 0; }
+        return 1;
+    }
+    if (!s->finished) {
+        if (s->total + n > ss_window(s->level)) {                   /* outgrows the window */
+            if (cx_replay_to_cpu(env, cls, ptr, s) != 0) { *err = ZJNI_ERROR_unsupported; return 1; }
+            return cx_stream(env, cls, ptr, c, dst, room, src, n, op, produced, consumed, done, err);
+        }
+        if (s->total + n > s->cap) {
+            size_t cc = (s->total + n) * 2 + 65536; unsigned char* p;
+            if (cc > ss_window(s->level)) cc = ss_window(s->level);
+            p = (unsigned char*)realloc(s->buf, cc); if (!p) { *err = 64; return 1; }
+            s->buf = p; s->cap = cc;
+        }
+        if (n) memcpy(s->buf + s->total, src, n);
+        s->total += n; *consumed = n; s->started = 1;
+    }
+    for (;;) {
+        *produced += ss_deliver(s, dst + *produced, room - *produced);
+        if (s->outPos < s->outLen) break;                           /* the caller comes back with room */
+        if (s->finished || op == 0 || (op == 1 && s->total <= (s->nFlush ? s->flushAt[s->nFlush - 1] : 0))) { *done = 1; break; }   /* (a flush with nothing new writes nothing) */
+        /* flush / end with nothing pending: the frame's next part */
+        if (op == 1) {
+            if (s->nFlush == s->flushCap) { size_t const fc = s->flushCap * 2 + 16; uint32_t* p = (uint32_t*)realloc(s->flushAt, fc * sizeof *p); if (!p) { *err = 64; return 1; } s->flushAt = p; s->flushCap = fc; }
+            s->flushAt[s->nFlush++] = (uint32_t)s->total;
+        }
+        {   size_t const cap = s->total + (s->total >> 8) + 4096 + 64 * (s->nFlush + 4);
+            unsigned char* tmp = (unsigned char*)malloc(cap); size_t r;
+            if (!tmp) { *err = 64; return 1; }
+            r = zjni_compress_stream(tmp, cap, s->buf, s->total, s->level, s->checksum, s->flushAt, s->nFlush, op == 2, 0);
+            if (zjni_isError(r)) {
+                free(tmp);
+                if (zjni_getErrorCode(r) < 200) { *err = (unsigned)zjni_getErrorCode(r); return 1; }
+                if (op == 1) s->nFlush--;                           /* the directive is repeated below, on the bundled context */
+                if (cx_replay_to_cpu(env, cls, ptr, s) != 0) { *err = ZJNI_ERROR_unsupported; return 1; }
+                {   size_t p2 = 0, c2 = 0; size_t const had = *produced;
+                    int const ok = cx_stream(env, cls, ptr, c, dst + had, room - had, src, 0, op, &p2, &c2, done, err);
+                    *produced = had + p2; return ok; }
+            }
+            if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); *err = 64; return 1; }
+            memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+            free(tmp);
+            if (op == 2) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
+        }
+    }
+    if (s->finished && *done) { ss_reset(s, 3); c->hasPledged = 0; }   /* the frame is out: the next directive starts a new one */
+    return 1;
+}
+static jlong cx_passed_on(CtxState* c, int op, jlong r) {          /* a call the bundled context answered: is it inside a frame now? */
+    t_gpu_declined = 0;
+    if (c) { int const ended = ((uint64_t)r & 0x80000000u) || (op == 2 && ((uint64_t)r >> 63)); c->cpuInFrame = !ended; if (ended) c->hasPledged = 0; }
+    return r;
+}
+static jlong cx_answer(size_t dpos, size_t spos, size_t produced, size_t consumed, int done, unsigned err) {
+    return err ? CX_ERR(err) : cx_word(done, dpos + produced, spos + consumed);
+}
+static int cx_array_ok(JNIEnv* env, jbyteArray a, jint array_offset, jint size) {      /* is_valid_array_stream_buffer (N/jni_fast_zstd.c:399-404) */
+    jsize cap;
+    if (0 > array_offset || 0 > size) return 0;
+    cap = (*env)->GetArrayLength(env, a);
+    return array_offset <= cap && size <= cap - array_offset;
+}
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_setPledgedSrcSize0)(JNIEnv* env, jclass cls, jlong ptr, jlong src_size) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jlong) = (jlong (*)(JNIEnv*, jclass, jlong, jlong))cpu_sym(PS("ZstdCompressCtx_setPledgedSrcSize0"));
+    CtxState* c = st_get(ptr, 'C');
+    if (src_size < 0) return E_SRC;
+    if (c && c->cx && (c->cx->started || c->cx->cpuMode) && !c->cx->finished) return f ? f(env, cls, ptr, src_size) : (jlong)-60;     /* inside a frame: ZSTD_error_stage_wrong */
+    if (c) { c->hasPledged = 1; c->pledged = (unsigned long long)src_size; }
+    return f ? f(env, cls, ptr, src_size) : 0;
+}
+/* ZSTD_getFrameProgression: while a frame is buffered here everything taken in is "ingested", nothing "consumed" yet; flushed = handed out */
+JNIEXPORT jobject JNICALL P(ZstdCompressCtx_getFrameProgression0)(JNIEnv* env, jclass cls, jlong ptr) {
+    jobject (*f)(JNIEnv*, jclass, jlong) = (jobject (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdCompressCtx_getFrameProgression0"));
+    CtxState* c = st_get(ptr, 'C'); StreamState* s = c ? c->cx : NULL;
+    if (f && !(s && !s->cpuMode && (s->started || s->total))) return f(env, cls, ptr);
+    {   jclass const k = (*env)->FindClass(env, "com/github/luben/zstd/ZstdFrameProgression");
+        jmethodID const m = k ? (*env)->GetMethodID(env, k, "<init>", "(JJJJII)V") : NULL;
+        jlong const in = s ? (jlong)s->total : 0, made = s ? (jlong)s->emitted : 0, out = s ? (jlong)(s->emitted - (s->outLen - s->outPos)) : 0;
+        return m ? (*env)->NewObject(env, k, m, in, made ? in : (jlong)0, made, out, (jint)0, (jint)0) : NULL;
+    }
+}
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBufferStream0)
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jint end_op) {
+    cx_dd_fn f = (cx_dd_fn)cpu_sym(PS("ZstdCompressCtx_compressDirectByteBufferStream0"));
+    CtxState* c = st_get(ptr, 'C');
+    char* d; char* sb; size_t produced, consumed; int done; unsigned err;
+    if (NULL == dst) return CX_ERR(70);
+    if (NULL == src) return CX_ERR(72);
+    if (0 > dst_offset || dst_offset > dst_size) return CX_ERR(70);
+    if (0 > src_offset || src_offset > src_size) return CX_ERR(72);
+    if (dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return CX_ERR(70);
+    if (src_size > (*env)->GetDirectBufferCapacity(env, src)) return CX_ERR(72);
+    d = (char*)(*env)->GetDirectBufferAddress(env, dst); sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+    if (d == NULL || sb == NULL) return CX_ERR(64);
+    if (cx_stream(env, cls, ptr, c, d + dst_offset, (size_t)(dst_size - dst_offset), sb + src_offset, (size_t)(src_size - src_offset), end_op, &produced, &consumed, &done, &err))
+        return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
+    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+}
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0)
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_array_offset, jint src_offset, jint src_size, jint end_op) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject, jint, jint, jbyteArray, jint, jint, jint, jint) =
+        (jlong (*)(JNIEnv*, jclass, jlong, jobject, jint, jint, jbyteArray, jint, jint, jint, jint))cpu_sym(PS("ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0"));
+    CtxState* c = st_get(ptr, 'C');
+    char* d; char* in; size_t produced, consumed, n; int done, mine; unsigned err;
+    if (NULL == dst) return CX_ERR(70);
+    if (NULL == src) return CX_ERR(72);
+    if (0 > dst_offset || dst_offset > dst_size) return CX_ERR(70);
+    if (0 > src_offset || src_offset > src_size) return CX_ERR(72);
+    if (dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return CX_ERR(70);
+    if (!cx_array_ok(env, src, src_array_offset, src_size)) return CX_ERR(72);
+    d = (char*)(*env)->GetDirectBufferAddress(env, dst);
+    if (d == NULL) return CX_ERR(64);
+    n = (size_t)(src_size - src_offset);
+    in = (char*)malloc(n + 1); if (!in) return CX_ERR(64);
+    if (n) (*env)->GetByteArrayRegion(env, src, src_array_offset + src_offset, (jsize)n, (jbyte*)in);
+    mine = cx_stream(env, cls, ptr, c, d + dst_offset, (size_t)(dst_size - dst_offset), in, n, end_op, &produced, &consumed, &done, &err);
+    free(in);
+    if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
+    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+}
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0)
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_array_offset, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jint end_op) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jobject, jint, jint, jint) =
+        (jlong (*)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jobject, jint, jint, jint))cpu_sym(PS("ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0"));
+    CtxState* c = st_get(ptr, 'C');
+    char* sb; char* out; size_t produced, consumed, room; int done, mine; unsigned err;
+    if (NULL == dst) return CX_ERR(70);
+    if (NULL == src) return CX_ERR(72);
+    if (0 > dst_offset || dst_offset > dst_size) return CX_ERR(70);
+    if (0 > src_offset || src_offset > src_size) return CX_ERR(72);
+    if (!cx_array_ok(env, dst, dst_array_offset, dst_size)) return CX_ERR(70);
+    if (src_size > (*env)->GetDirectBufferCapacity(env, src)) return CX_ERR(72);
+    sb = (char*)(*env)->GetDirectBufferAddress(env, src);
+    if (sb == NULL) return CX_ERR(64);
+    room = (size_t)(dst_size - dst_offset);
+    out = (char*)malloc(room + 1); if (!out) return CX_ERR(64);
+    mine = cx_stream(env, cls, ptr, c, out, room, sb + src_offset, (size_t)(src_size - src_offset), end_op, &produced, &consumed, &done, &err);
+    if (mine && produced) (*env)->SetByteArrayRegion(env, dst, dst_array_offset + dst_offset, (jsize)produced, (const jbyte*)out);
+    free(out);
+    if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
+    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+}
+JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayStream0)
+  (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_array_offset, jint dst_offset, jint dst_size, jbyteArray src, jint src_array_offset, jint src_offset, jint src_size, jint end_op) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jbyteArray, jint, jint, jint, jint) =
+        (jlong (*)(JNIEnv*, jclass, jlong, jbyteArray, jint, jint, jint, jbyteArray, jint, jint, jint, jint))cpu_sym(PS("ZstdCompressCtx_compressByteArrayStream0"));
+    CtxState* c = st_get(ptr, 'C');
+    char* in; char* out; size_t produced, consumed, room, n; int done, mine; unsigned err;
+    if (NULL == dst) return CX_ERR(70);
+    if (NULL == src) return CX_ERR(72);
+    if (0 > dst_offset || dst_offset > dst_size) return CX_ERR(70);
+    if (0 > src_offset || src_offset > src_size) return CX_ERR(72);
+    if (!cx_array_ok(env, dst, dst_array_offset, dst_size)) return CX_ERR(70);
+    if (!cx_array_ok(env, src, src_array_offset, src_size)) return CX_ERR(72);
+    room = (size_t)(dst_size - dst_offset); n = (size_t)(src_size - src_offset);
+    in = (char*)malloc(n + 1); out = (char*)malloc(room + 1);
+    if (!in || !out) { free(in); free(out); return CX_ERR(64); }
+    if (n) (*env)->GetByteArrayRegion(env, src, src_array_offset + src_offset, (jsize)n, (jbyte*)in);
+    mine = cx_stream(env, cls, ptr, c, out, room, in, n, end_op, &produced, &consumed, &done, &err);
+    if (mine && produced) (*env)->SetByteArrayRegion(env, dst, dst_array_offset + dst_offset, (jsize)produced, (const jbyte*)out);
+    free(in); free(out);
+    if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
+    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+}
+/* ZSTD_decompressStream on the context: at a frame boundary a COMPLETE frame in the source with room for all it decodes to goes to the batch decoder in one piece
+ * (as ZstdDirectBufferDecompressingStreamNoFinalizer.decompressStreamNative above); anything else is the bundled library's, until that frame ends */
+JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressDirectByteBufferStream0)
+  (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size) {
+    jlong (*f)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint) = (jlong (*)(JNIEnv*, jclass, jlong, jobject, jint, jint, jobject, jint, jint))cpu_sym(PS("ZstdDecompressCtx_decompressDirectByteBufferStream0"));
+    CtxState* c = st_get(ptr, 'D');
+    char* d; char* sb;
+    if (NULL == dst) return CX_ERR(70);
+    if (NULL == src) return CX_ERR(72);
+    if (0 > dst_offset) return CX_ERR(70);
+    if (0 > src_offset) return CX_ERR(72);
+    if (0 > dst_size) return CX_ERR(70);
+    if (0 > src_size) return CX_ERR(72);
+    if (dst_size > (*env)->GetDirectBufferCapacity(env, dst)) return CX_ERR(70);
+    if (src_size > (*env)->GetDirectBufferCapacity(env, src)) return CX_ERR(72);
+    d = (char*)(*env)->GetDirectBufferAddress(env, dst); if (d == NULL) return CX_ERR(64);
+    sb = (char*)(*env)->GetDirectBufferAddress(env, src); if (sb == NULL) return CX_ERR(64);
+    if (c && !c->dInFrame && !c->cpuOnly && !c->cpuDict && !c->ddict && !c->ddictOwned && streams_on_gpu() && src_offset < src_size && dst_offset <= dst_size) {
+        size_t const room = (size_t)(dst_size - dst_offset);
+        unsigned long long content = 0, bound = 0;
+        size_t const ext = zjni_frame_extent(sb + src_offset, (size_t)(src_size - src_offset), &content, &bound);
+        if (ext && (bound <= room || bound <= (64ull << 20))) {
+            int const aside = bound > room;
+            char* const to = aside ? (char*)malloc((size_t)bound + 1) : d + dst_offset;
+            size_t const r = to ? zjni_decompress(to, aside ? (size_t)bound : room, sb + src_offset, ext) : (size_t)E_MEM;
+            if (!zjni_isError(r) && r <= room) {
+                if (aside) { memcpy(d + dst_offset, to, r); free(to); }
+                __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+                return cx_word(1, (size_t)dst_offset + r, (size_t)src_offset + ext);
+            }
+            if (aside) free(to);
+            if (zjni_isError(r) && zjni_getErrorCode(r) < 200 && zjni_getErrorCode(r) != 70) return CX_ERR(zjni_getErrorCode(r));
+        }
+    }
+    if (!f) return CX_ERR(ZJNI_ERROR_unsupported);
+    {   uint64_t const r = (uint64_t)f(env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
+        if (c) c->dInFrame = !(r & 0x80000000u) && !(r >> 63);                       /* bit 63: ZSTD_decompressStream returned 0, a frame has just ended */
+        return (jlong)r; }
 }
 
 /* ---- frame inspection and constants: host-side arithmetic on a few header bytes, answered here whether or not a bundled library is loaded ------------
