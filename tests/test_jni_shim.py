@@ -82,6 +82,42 @@ def test_shim_answers_frame_inspection_and_constants_itself(bundled):
     assert sorted(trampolines) == ["FWD(Zstd_trainFromBuffer0)\n", "FWD(Zstd_trainFromBufferDirect0)\n"], trampolines      # dictionary training: the only natives left to the bundled library alone
 
 
+EMU_SHIM = os.path.join(ROOT, "tests", "jni", "_build", "emu", "libzstd-jni-amd.so")
+
+
+def _built_emu():
+    """the JNI library over the TEST DOUBLE of libzjni_amd.so (tests/jni/emu_abi.cpp: the 22 C-ABI entries the JNI library imports, over the kernel bodies compiled
+    lane-serial under g++) — its whole GPU route on a machine without a GPU"""
+    if not _built():
+        return False
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "jni"), "emu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return os.path.exists(EMU_SHIM)
+
+
+@pytest.mark.parametrize("leg", ["gpu-only", "bundled-library-behind"])
+def test_shim_gpu_route_over_the_emulated_kernels(leg):
+    """The two GPU legs below, on the CPU: the JNI library linked against the emulation of the C-ABI.  gpu-only: no bundled library, every native must be answered by
+    the (emulated) GPU path — one-shot natives at levels 1-8, dictionaries, frame parameters, the five stream classes, the context streams — and equal the reference's
+    JNI library (76 000 checks, none forwarded).  bundled-library-behind: ZSTD_JNI_GPU_STREAMS=1 with the reference behind it — streams that outgrow the window are
+    replayed into the bundled library mid-frame."""
+    if not _built_emu():
+        pytest.skip("no <jni.h> in this environment and no prebuilt shim")
+    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file())
+    for k in ("ZSTD_JNI_CPU_LIB", "ZSTD_JNI_GPU_STREAMS", "ZSTD_JNI_GPU_PER_BUFFER", "ZSTD_JNI_GPU_AGGREGATE"):
+        env.pop(k, None)
+    if leg == "gpu-only":
+        env.update(HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0")
+    else:
+        env.update(ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2")
+    out = subprocess.run([HARNESS, REFJNI, EMU_SHIM], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]
+    stats = [l for l in out.stdout.splitlines() if l.startswith("JNI-HARNESS STATS")][0]
+    served = int(stats.split("served_by_gpu=")[1].split()[0]); declined = int(stats.split("forwarded_after_gpu_declined=")[1].split()[0])
+    assert served > (3000 if leg == "gpu-only" else 300), stats
+    assert (declined == 0) if leg == "gpu-only" else (declined > 0), stats          # the second leg must have replayed streams into the bundled library
+
+
 @pytest.mark.gpu
 def test_shim_equals_reference_jni_on_the_gpu():
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"
