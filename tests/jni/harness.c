@@ -724,6 +724,26 @@ int main(int argc, char** argv) {
                   (int)total, (int)level, ck, (int)chunk, flushEvery, (int)room, comb, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
             free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
         }
+        /* an empty directive opens the frame, the end directive brings all of it: libzstd's one-piece path under a stream header (the bundled library's above one block) */
+        if (streamMax != 0) for (int level = 1; level <= 3; level++) for (int opener = 0; opener < 2; opener++) for (int roomy = 0; roomy < 2; roomy++) {
+            jsize const total = 330000; jint const room = roomy ? (1 << 20) : 5000; int const comb = (level + opener + roomy) & 3;
+            Obj* srcD = mk(1, total); Obj* srcA = mk(2, total + 2); g_x = 0x1234567ull + (unsigned)level; fill(srcD->data, total, 1); memcpy(srcA->data + 2, srcD->data, (size_t)total);
+            char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                Obj* dstD = mk(1, room); Obj* dstA = mk(2, room + 3);
+                jlong const ctx = libs[k]->cinit(e, NULL);
+                size_t const cap = (size_t)total + (1u << 16); char* out = (char*)malloc(cap); size_t n = 0;
+                libs[k]->setLevel(e, NULL, ctx, level);
+                DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 0, 0, opener);
+                if (worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, 0, total, 2);
+                libs[k]->cfree(e, NULL, ctx);
+                outs[k] = out; lens[k] = n;
+                free(dstD->data); free(dstD); free(dstA->data); free(dstA);
+            }
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "empty %s, then the end with %d bytes, level %d, room %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                  opener ? "flush" : "write", (int)total, level, (int)room, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+            free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
+        }
         /* frames whose first directive is the end: with and without a pledged size, a pledge that does not match (libzstd replaces it by the input's size), a roomy and a tiny target, the four combinations */
         {   int const plainMax2 = getenv("HARNESS_PLAIN_MAX_LEVEL") ? atoi(getenv("HARNESS_PLAIN_MAX_LEVEL")) : (getenv("HARNESS_MAX_LEVEL") ? atoi(getenv("HARNESS_MAX_LEVEL")) : 3);
             jsize const ones[] = {0, 1, 300, 30000, 131072, 131073, 500000};
@@ -732,6 +752,7 @@ int main(int argc, char** argv) {
                 jint const room = (mode == 1) ? 700 : (1 << 20);
                 int const comb = (int)((oi + (unsigned)level + (unsigned)mode) & 3u);
                 if (level > 3 && total > 131072) continue;
+                if (mode == 1 && total > 131072 && streamMax == 0) continue;      /* above one block into a target below the frame's bound: libzstd's buffered form, the bundled library's (none in this leg) */
                 Obj* srcD = mk(1, total > 0 ? total : 1); Obj* srcA = mk(2, total + 2); fill(srcD->data, total, (int)(oi % 3u)); memcpy(srcA->data + 2, srcD->data, (size_t)total);
                 char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
                 for (int k = 0; k < 2; k++) {
@@ -769,6 +790,90 @@ int main(int argc, char** argv) {
                 }
                 free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
             }
+        }
+        /* HARNESS_FUZZ=<seed>,<iterations>: random scripts of directives on a context — one to three frames per context, writes of random sizes (empty ones too), flushes
+         * (repeated ones too) at random, a frame that is a single end directive now and then (with a pledged size that may or may not match), any of the four heap / direct
+         * combinations, a target of a few bytes or a roomy one.  The bytes both libraries hand out over the whole script must be the same; then the concatenated frames go
+         * back through the decompress native (whole, or in random pieces when there is a bundled library to take pieces). */
+        if (getenv("HARNESS_FUZZ")) {
+            unsigned long long seed = 1; int iters = 100; int const haveCpu = getenv("ZSTD_JNI_CPU_LIB") != NULL;
+            sscanf(getenv("HARNESS_FUZZ"), "%llu,%d", &seed, &iters);
+            g_x = 0x9E3779B97F4A7C15ull ^ (seed * 0xD1B54A32D192ED03ull); if (!g_x) g_x = 1;
+            int const fuzzMaxLevel = haveCpu ? 5 : 3; int const trace = getenv("HARNESS_FUZZ_TRACE") ? atoi(getenv("HARNESS_FUZZ_TRACE")) : -1;
+#define TRACE(...) do { if (it == trace && k == 0) { printf("  script: "); printf(__VA_ARGS__); printf("\n"); } } while (0)
+            STAGE("context streams: random scripts");
+            for (int it = 0; it < iters; it++) {
+                int const nFrames = 1 + (int)(rnd() % 3u), comb = (int)(rnd() & 3u), level = 1 + (int)(rnd() % (unsigned)fuzzMaxLevel), ck = (int)(rnd() & 1u), cls = (int)(rnd() % 3u);
+                jint const room = (rnd() & 1u) ? (jint)(1 + rnd() % 2000u) : (1 << 20);
+                jsize const poolN = 400000; jsize frameLen[3]; int oneShot[3]; jlong pledge[3]; jsize grand = 0;
+                unsigned long long const script = g_x;                                      /* both libraries replay the same random script */
+                for (int f = 0; f < nFrames; f++) {
+                    unsigned const pick = rnd() % 10u;
+                    frameLen[f] = pick == 0 ? 0 : (pick < 4 ? (jsize)(rnd() % 3000u) : (pick < 8 ? (jsize)(rnd() % 140000u) : (jsize)(rnd() % 330000u)));
+                    oneShot[f] = (rnd() % 4u) == 0; pledge[f] = -1;
+                    if ((oneShot[f] || (haveCpu && (rnd() & 3u) == 0)) && (rnd() & 1u)) pledge[f] = (rnd() & 1u) ? frameLen[f] : (jlong)(rnd() % 500000u);      /* (a pledged frame in several directives is the bundled library's; a broken pledge must fail alike) */
+                    if (!oneShot[f] && level > 3 && !haveCpu) frameLen[f] = 0;
+                    if (oneShot[f] && frameLen[f] > 131072 && room < (1 << 20) && !haveCpu) { oneShot[f] = 0; pledge[f] = -1; }      /* (the buffered form of a one-directive frame: see the shim) */
+                    grand += frameLen[f];
+                }
+                Obj* srcD = mk(1, poolN); Obj* srcA = mk(2, poolN + 2); fill(srcD->data, poolN, cls); memcpy(srcA->data + 2, srcD->data, (size_t)poolN);
+                unsigned long long const afterFill = g_x;
+                char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0};
+                (void)script;
+                for (int k = 0; k < 2; k++) {
+                    Obj* dstD = mk(1, room); Obj* dstA = mk(2, room + 3);
+                    jlong const ctx = libs[k]->cinit(e, NULL);
+                    size_t const cap = (size_t)grand + (size_t)grand / 32 + (1u << 16) + 4096u * (size_t)nFrames; char* out = (char*)malloc(cap); size_t n = 0;
+                    g_x = afterFill;
+                    libs[k]->setLevel(e, NULL, ctx, level); libs[k]->setChecksum(e, NULL, ctx, ck ? JNI_TRUE : JNI_FALSE);
+                    for (int f = 0; f < nFrames && worst[k] == 0; f++) {
+                        jsize const base = (jsize)(rnd() % (unsigned)(poolN - frameLen[f] + 1)), end = base + frameLen[f];
+                        TRACE("frame %d: %d bytes at %d, oneShot %d, pledge %lld, level %d ck %d cls %d", f, (int)frameLen[f], (int)base, oneShot[f], (long long)pledge[f], level, ck, cls);
+                        if (pledge[f] >= 0) { jlong const pr = X[k].pledge(e, NULL, ctx, pledge[f]); if (pr != 0) { worst[k] = pr; break; } }
+                        if (oneShot[f]) { DIRECTIVE(k, comb, ctx, srcD, srcA, 0, base, end, 2); continue; }
+                        for (jsize at = base; worst[k] == 0; ) {
+                            unsigned const r = rnd() % 16u;
+                            jsize len = r == 0 ? 0 : (r < 6 ? (jsize)(rnd() % 2000u) : (r < 13 ? (jsize)(rnd() % 70000u) : (jsize)(rnd() % 300000u)));
+                            if (len > end - at) len = end - at;
+                            TRACE("write %d (to %d)", (int)len, (int)(at + len - base));
+                            DIRECTIVE(k, comb, ctx, srcD, srcA, 0, at, at + len, 0);
+                            at += len;
+                            if (worst[k] == 0 && (rnd() % 10u) < 3u) { TRACE("flush at %d", (int)(at - base)); DIRECTIVE(k, comb, ctx, srcD, srcA, 0, at, at, 1); if (worst[k] == 0 && (rnd() & 3u) == 0) { TRACE("flush again"); DIRECTIVE(k, comb, ctx, srcD, srcA, 0, at, at, 1); } }
+                            if (at >= end && (len > 0 || (rnd() & 1u))) break;
+                        }
+                        if (worst[k] == 0) DIRECTIVE(k, comb, ctx, srcD, srcA, 0, end, end, 2);
+                    }
+                    libs[k]->cfree(e, NULL, ctx);
+                    outs[k] = out; lens[k] = n;
+                    free(dstD->data); free(dstD); free(dstA->data); free(dstA);
+                }
+                CHECK(worst[0] == worst[1] && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "random script %d (seed %llu): %d frames, level %d ck %d, room %d, combination %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                      it, seed, nFrames, level, ck, (int)room, comb, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+                if (worst[0] == 0 && lens[0] > 0) {                                             /* the frames back, through both decompress natives */
+                    jsize const flen = (jsize)lens[0];
+                    Obj* fr = mk(1, flen + 1); memcpy(fr->data, outs[0], (size_t)flen);
+                    unsigned long long const cut = g_x;
+                    for (int k = 0; k < 2; k++) {
+                        jlong const dctx = libs[k]->dinit(e, NULL); Obj* back = mk(1, grand + 16);
+                        jint dpos = 0, spos = 0; int guard = 0; uint64_t w = 0;
+                        g_x = cut;
+                        while (spos < flen && guard++ < 100000) {
+                            jint const upto = (haveCpu && (rnd() & 1u)) ? spos + 1 + (jint)(rnd() % (unsigned)(flen - spos)) : flen;      /* pieces need a stream behind the GPU route */
+                            jint const before = spos;
+                            w = (uint64_t)X[k].ds(e, NULL, dctx, (jobject)back, dpos, grand + 16, (jobject)fr, spos, upto);
+                            if (w & 0x80000000u) break;
+                            dpos = (jint)((w >> 32) & 0x7FFFFFFFu); spos = (jint)(w & 0x7FFFFFFFu);
+                            if (spos == before && upto == flen) break;
+                        }
+                        CHECK(!(w & 0x80000000u) && spos == flen && dpos == grand, "random script %d (seed %llu): decompress native of library %d: word %llx, %d of %d out, %d of %d consumed", it, seed, k, (unsigned long long)w, (int)dpos, (int)grand, (int)spos, (int)flen);
+                        libs[k]->dfree(e, NULL, dctx); free(back->data); free(back);
+                    }
+                    free(fr->data); free(fr);
+                }
+                free(outs[0]); free(outs[1]); free(srcD->data); free(srcD); free(srcA->data); free(srcA);
+            }
+#undef TRACE
+            printf("JNI-HARNESS FUZZ seed=%llu scripts=%d\n", seed, iters);
         }
 #undef DIRECTIVE
     }

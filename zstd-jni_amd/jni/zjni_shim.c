@@ -439,7 +439,10 @@ static int gpu_takes_when(const CtxState* s, jint srcSize, int on) {
     if (s->level >= 4 && s->level <= 8) return (size_t)srcSize <= (s->level == 4 ? ZJNI_LEVEL4_MAX : ZJNI_LAZY_MAX) && !(s->hashLog | s->chainLog);   /* one block, no explicit table sizes */
     return s->level >= 0 && s->level <= 3 && (size_t)srcSize <= ZJNI_FRAME_MAX;       /* beyond the level's window the library answers 201 and the call is forwarded */
 }
-static int gpu_takes(const CtxState* s, jint srcSize) { return gpu_takes_when(s, srcSize, per_buffer_on_gpu()); }
+static int gpu_takes(const CtxState* s, jint srcSize) {           /* the one-shot natives: ZSTD_CCtx_reset(session_only) comes first, and forgets a pledged size */
+    if (s) ((CtxState*)s)->hasPledged = 0;
+    return gpu_takes_when(s, srcSize, per_buffer_on_gpu());
+}
 static int frame_flags(const CtxState* s) {
     return (s->checksum ? ZJNI_FRAME_CHECKSUM : 0) | (s->contentSize ? 0 : ZJNI_FRAME_NO_CONTENTSIZE) | (s->dictIDFlag ? 0 : ZJNI_FRAME_NO_DICTID);
 }
@@ -1463,7 +1466,12 @@ static int cx_replay_to_cpu(JNIEnv* env, jclass cls, jlong ptr, StreamState* s) 
     size_t const delivered = s->emitted - (s->outLen - s->outPos);
     char* scratch = (char*)malloc(scratchCap);
     if (!scratch) return -1;
+    scratch[0] = 0;
     s->outLen = s->outPos = 0;
+    if (s->total == 0) {                                           /* opened by an empty directive: the bundled context opens its frame the same way (no pledged size) */
+        size_t produced, consumed; int done; unsigned err;
+        if (cx_cpu_call(env, cls, ptr, scratch, scratchCap, scratch, 0, 0, &produced, &consumed, &done, &err) != 0 || err) { free(scratch); return -1; }
+    }
     while (at < s->total || fi < s->nFlush) {
         size_t const upto = fi < s->nFlush ? s->flushAt[fi] : s->total;
         int const flushing = at >= upto;                           /* the bytes up to the flush are in: now the directive itself, until it is done */
@@ -1498,6 +1506,10 @@ static int cx_stream(JNIEnv* env, jclass cls, jlong ptr, CtxState* c, char* dst,
         if (op == 2) {                                              /* the whole frame in one directive: a one-shot frame */
             size_t cap, r; unsigned char* tmp;
             if (n > 0x7FFFFFFFu || !gpu_takes_when(c, (jint)n, 1)) return 0;
+            /* libzstd compresses such a frame in one piece only when the target can take its bound (N/compress/zstd_compress.c:6145-6152); into a smaller target it
+             * goes through the stream's 128 KiB buffer, where a pre-split block is followed by the REST of its piece instead of a full block — other bytes for inputs
+             * above one block.  That form (the stream's pieces with the known size's parameters and header) is not on the GPU route. */
+            if (n > ZJNI_BLOCKSIZE_MAX && room < zjni_compressBound(n)) return 0;
             /* (a pledged size does not matter here: ending at the first directive, libzstd replaces it by the input's size — N/compress/zstd_compress.c:6366) */
             if (!(s = cx_session(c))) { *err = 64; return 1; }
             cap = zjni_compressBound(n) + 64;
@@ -1526,6 +1538,12 @@ static int cx_stream(JNIEnv* env, jclass cls, jlong ptr, CtxState* c, char* dst,
         return 1;
     }
     if (!s->finished) {
+        /* the same one-piece path inside a stream (:6145-6152: the end directive brings ALL the frame's bytes — nothing is buffered, an empty directive opened the
+         * frame — and the target can take their bound): blocks as ZSTD_compress2 cuts them, under the stream's header; above one block not the stream route's pieces */
+        if (op == 2 && n > ZJNI_BLOCKSIZE_MAX && s->total == 0 && room >= zjni_compressBound(n)) {
+            if (cx_replay_to_cpu(env, cls, ptr, s) != 0) { *err = ZJNI_ERROR_unsupported; return 1; }
+            return cx_stream(env, cls, ptr, c, dst, room, src, n, op, produced, consumed, done, err);
+        }
         if (s->total + n > ss_window(s->level)) {                   /* outgrows the window */
             if (cx_replay_to_cpu(env, cls, ptr, s) != 0) { *err = ZJNI_ERROR_unsupported; return 1; }
             return cx_stream(env, cls, ptr, c, dst, room, src, n, op, produced, consumed, done, err);
@@ -1584,13 +1602,27 @@ static int cx_array_ok(JNIEnv* env, jbyteArray a, jint array_offset, jint size) 
     cap = (*env)->GetArrayLength(env, a);
     return array_offset <= cap && size <= cap - array_offset;
 }
+/* ZSTD_CCtx_setPledgedSrcSize applies to the NEXT frame.  Where the GPU route may take that frame the pledge is kept here and handed to the bundled context only
+ * when the frame is (cx_hand_pledge, before the first call passed on): a pledge given to the bundled context for a frame the GPU route then made would wait there
+ * for a later frame. */
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_setPledgedSrcSize0)(JNIEnv* env, jclass cls, jlong ptr, jlong src_size) {
     jlong (*f)(JNIEnv*, jclass, jlong, jlong) = (jlong (*)(JNIEnv*, jclass, jlong, jlong))cpu_sym(PS("ZstdCompressCtx_setPledgedSrcSize0"));
     CtxState* c = st_get(ptr, 'C');
     if (src_size < 0) return E_SRC;
-    if (c && c->cx && (c->cx->started || c->cx->cpuMode) && !c->cx->finished) return f ? f(env, cls, ptr, src_size) : (jlong)-60;     /* inside a frame: ZSTD_error_stage_wrong */
-    if (c) { c->hasPledged = 1; c->pledged = (unsigned long long)src_size; }
+    if (c && streams_on_gpu()) {
+        if (c->cpuInFrame) return f ? f(env, cls, ptr, src_size) : (jlong)-60;
+        if (c->cx && (c->cx->started || c->cx->cpuMode) && !c->cx->finished) return (jlong)-60;      /* inside a frame: ZSTD_error_stage_wrong */
+        c->hasPledged = 1; c->pledged = (unsigned long long)src_size;
+        return 0;
+    }
     return f ? f(env, cls, ptr, src_size) : 0;
+}
+static void cx_hand_pledge(JNIEnv* env, jclass cls, jlong ptr, CtxState* c) {          /* a frame is about to start on the bundled context: its pledge goes with it */
+    if (c && c->hasPledged && !c->cpuInFrame) {
+        jlong (*f)(JNIEnv*, jclass, jlong, jlong) = (jlong (*)(JNIEnv*, jclass, jlong, jlong))cpu_sym(PS("ZstdCompressCtx_setPledgedSrcSize0"));
+        if (f) (void)f(env, cls, ptr, (jlong)c->pledged);
+        c->hasPledged = 0;
+    }
 }
 /* ZSTD_getFrameProgression: while a frame is buffered here everything taken in is "ingested", nothing "consumed" yet; flushed = handed out */
 JNIEXPORT jobject JNICALL P(ZstdCompressCtx_getFrameProgression0)(JNIEnv* env, jclass cls, jlong ptr) {
@@ -1618,7 +1650,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBufferStream0)
     if (d == NULL || sb == NULL) return CX_ERR(64);
     if (cx_stream(env, cls, ptr, c, d + dst_offset, (size_t)(dst_size - dst_offset), sb + src_offset, (size_t)(src_size - src_offset), end_op, &produced, &consumed, &done, &err))
         return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
-    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+    return f ? (cx_hand_pledge(env, cls, ptr, c), cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size, end_op))) : CX_ERR(ZJNI_ERROR_unsupported);
 }
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayToDirectByteBufferStream0)
   (JNIEnv* env, jclass cls, jlong ptr, jobject dst, jint dst_offset, jint dst_size, jbyteArray src, jint src_array_offset, jint src_offset, jint src_size, jint end_op) {
@@ -1640,7 +1672,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayToDirectByteBufferStr
     mine = cx_stream(env, cls, ptr, c, d + dst_offset, (size_t)(dst_size - dst_offset), in, n, end_op, &produced, &consumed, &done, &err);
     free(in);
     if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
-    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+    return f ? (cx_hand_pledge(env, cls, ptr, c), cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op))) : CX_ERR(ZJNI_ERROR_unsupported);
 }
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBufferToByteArrayStream0)
   (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_array_offset, jint dst_offset, jint dst_size, jobject src, jint src_offset, jint src_size, jint end_op) {
@@ -1662,7 +1694,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressDirectByteBufferToByteArrayStr
     if (mine && produced) (*env)->SetByteArrayRegion(env, dst, dst_array_offset + dst_offset, (jsize)produced, (const jbyte*)out);
     free(out);
     if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
-    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+    return f ? (cx_hand_pledge(env, cls, ptr, c), cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_offset, src_size, end_op))) : CX_ERR(ZJNI_ERROR_unsupported);
 }
 JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayStream0)
   (JNIEnv* env, jclass cls, jlong ptr, jbyteArray dst, jint dst_array_offset, jint dst_offset, jint dst_size, jbyteArray src, jint src_array_offset, jint src_offset, jint src_size, jint end_op) {
@@ -1684,7 +1716,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_compressByteArrayStream0)
     if (mine && produced) (*env)->SetByteArrayRegion(env, dst, dst_array_offset + dst_offset, (jsize)produced, (const jbyte*)out);
     free(in); free(out);
     if (mine) return cx_answer((size_t)dst_offset, (size_t)src_offset, produced, consumed, done, err);
-    return f ? cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op)) : CX_ERR(ZJNI_ERROR_unsupported);
+    return f ? (cx_hand_pledge(env, cls, ptr, c), cx_passed_on(c, end_op, f(env, cls, ptr, dst, dst_array_offset, dst_offset, dst_size, src, src_array_offset, src_offset, src_size, end_op))) : CX_ERR(ZJNI_ERROR_unsupported);
 }
 /* ZSTD_decompressStream on the context: at a frame boundary a COMPLETE frame in the source with room for all it decodes to goes to the batch decoder in one piece
  * (as ZstdDirectBufferDecompressingStreamNoFinalizer.decompressStreamNative above); anything else is the bundled library's, until that frame ends */
