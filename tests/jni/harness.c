@@ -1054,6 +1054,93 @@ int main(int argc, char** argv) {
             }
             free(outs[0]); free(outs[1]);
         }
+        /* HARNESS_FUZZ: random scripts on one ZstdOutputStreamNoFinalizer object — one to three frames (resetCStream between them), writes of random sizes through the
+         * Java class's loop on srcPos, flushes (repeated ones too), a target array of a few bytes or ZSTD_CStreamOutSize(); what both libraries hand out must be the same
+         * bytes; then the frames back through ZstdInputStreamNoFinalizer, whole or (with a bundled stream behind) in random pieces into a target of random size */
+        if (getenv("HARNESS_FUZZ")) {
+            unsigned long long seed = 1; int iters = 100; int const haveCpu = getenv("ZSTD_JNI_CPU_LIB") != NULL;
+            sscanf(getenv("HARNESS_FUZZ"), "%llu,%d", &seed, &iters);
+            g_x = 0xC2B2AE3D27D4EB4Full ^ (seed * 0x9E3779B97F4A7C15ull); if (!g_x) g_x = 1;
+            STAGE("heap-array streams: random scripts");
+            for (int it = 0; it < iters; it++) {
+                int const nFrames = 1 + (int)(rnd() % 3u), level = 1 + (int)(rnd() % (haveCpu ? 4u : 3u)), cls = (int)(rnd() % 3u);
+                jboolean const ck = (rnd() & 1u) ? JNI_TRUE : JNI_FALSE;
+                jsize const room = (rnd() & 1u) ? (jsize)(1 + rnd() % 3000u) : 131591;
+                jsize const poolN = 400000; jsize frameLen[3]; jsize grand = 0;
+                for (int f = 0; f < nFrames; f++) {
+                    unsigned const pick = rnd() % 10u;
+                    frameLen[f] = pick == 0 ? 0 : (pick < 4 ? (jsize)(rnd() % 3000u) : (pick < 8 ? (jsize)(rnd() % 140000u) : (jsize)(rnd() % 330000u)));
+                    grand += frameLen[f];
+                }
+                Obj* src = mk(2, poolN); fill(src->data, poolN, cls);
+                unsigned long long const afterFill = g_x;
+                char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0}; jsize bases[3] = {0, 0, 0};
+                for (int k = 0; k < 2; k++) {
+                    Obj* self = mk(7, 0); Obj* dst = mk(2, room);
+                    jlong const h = S[k].create(e, NULL); jint r;
+                    size_t const cap = (size_t)grand + (size_t)grand / 32 + (1u << 16) + 4096u * (size_t)nFrames; char* out = (char*)malloc(cap); size_t n = 0;
+                    g_x = afterFill;
+                    r = S[k].level(e, NULL, h, level); if (r < 0) worst[k] = r;
+                    r = S[k].checksum(e, NULL, h, ck); if (r < 0) worst[k] = r;
+#define TAKE() do { if (n + (size_t)self->dstPos > cap) { worst[k] = -998; break; } memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos; } while (0)
+                    for (int f = 0; f < nFrames && worst[k] == 0; f++) {
+                        jsize const base = (jsize)(rnd() % (unsigned)(poolN - frameLen[f] + 1)), end = base + frameLen[f];
+                        bases[f] = base;
+                        r = S[k].reset(e, (jobject)self, h); if (r < 0) { worst[k] = r; break; }
+                        for (jsize at = base; worst[k] == 0; ) {
+                            unsigned const q = rnd() % 16u; int guard = 0;
+                            jsize len = q == 0 ? 0 : (q < 6 ? (jsize)(rnd() % 2000u) : (q < 13 ? (jsize)(rnd() % 70000u) : (jsize)(rnd() % 300000u)));
+                            if (len > end - at) len = end - at;
+                            self->srcPos = at;
+                            while (self->srcPos < at + len && guard++ < 200000) {
+                                r = S[k].comp(e, (jobject)self, h, (jbyteArray)dst, room, (jbyteArray)src, at + len);
+                                if (r < 0) { worst[k] = r; break; }
+                                TAKE();
+                            }
+                            at += len;
+                            if (worst[k] == 0 && (rnd() % 10u) < 3u) for (int again = 0; again < 1 + (int)((rnd() & 3u) == 0) && worst[k] == 0; again++) {
+                                int guard2 = 0;
+                                do { r = S[k].flush(e, (jobject)self, h, (jbyteArray)dst, room); if (r < 0) { worst[k] = r; break; } TAKE(); } while (r > 0 && guard2++ < 200000);
+                            }
+                            if (at >= end && (len > 0 || (rnd() & 1u))) break;
+                        }
+                        if (worst[k] == 0) { int guard3 = 0; do { r = S[k].end(e, (jobject)self, h, (jbyteArray)dst, room); if (r < 0) { worst[k] = r; break; } TAKE(); } while (r > 0 && guard3++ < 200000); }
+                    }
+#undef TAKE
+                    S[k].free_(e, NULL, h);
+                    outs[k] = out; lens[k] = n;
+                    free(dst->data); free(dst);
+                }
+                CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "random output-stream script %d (seed %llu): %d frames, level %d ck %d, room %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
+                      it, seed, nFrames, level, (int)ck, (int)room, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+                if (worst[0] == 0 && lens[0] > 0) {
+                    jsize const all = (jsize)lens[0];
+                    Obj* fr = mk(2, all + 1); memcpy(fr->data, outs[0], lens[0]);
+                    unsigned long long const cut = g_x;
+                    for (int k = 0; k < 2; k++) {
+                        jsize const backN = haveCpu && (rnd() & 1u) ? (jsize)(1 + rnd() % 5000u) : grand + 64;      /* a target smaller than the content: the read loop empties it and comes back */
+                        Obj* self = mk(7, 0); Obj* back = mk(2, backN); char* got = (char*)malloc((size_t)grand + 64); size_t gotN = 0;
+                        jlong const h = S[k].dcreate(e, NULL); jint r = S[k].dinit(e, (jobject)self, h);
+                        jsize fed = 0; int guard = 0;
+                        g_x = cut; (void)rnd();
+                        self->srcPos = 0; self->dstPos = 0;
+                        do {
+                            if (self->srcPos == fed && fed < all) fed = (haveCpu && (rnd() & 1u)) ? fed + 1 + (jsize)(rnd() % (unsigned)(all - fed)) : all;
+                            self->dstPos = 0;
+                            r = S[k].dstream(e, (jobject)self, h, (jbyteArray)back, backN, (jbyteArray)fr, fed);
+                            if (r >= 0 && gotN + (size_t)self->dstPos <= (size_t)grand + 64) { memcpy(got + gotN, back->data, (size_t)self->dstPos); gotN += (size_t)self->dstPos; }
+                        } while (r >= 0 && (self->srcPos < all || r > 0) && guard++ < 400000);
+                        {   int same = gotN == (size_t)grand; size_t o = 0;
+                            for (int f = 0; f < nFrames && same; f++) { same = !memcmp(got + o, src->data + bases[f], (size_t)frameLen[f]); o += (size_t)frameLen[f]; }
+                            CHECK(r == 0 && same && self->srcPos == all, "random script %d (seed %llu): input stream of library %d: ret %d, %zu of %d bytes out, %lld of %d consumed", it, seed, k, (int)r, gotN, (int)grand, (long long)self->srcPos, (int)all); }
+                        S[k].dfree(e, NULL, h); free(back->data); free(back); free(got);
+                    }
+                    free(fr->data); free(fr);
+                }
+                free(outs[0]); free(outs[1]); free(src->data); free(src);
+            }
+            printf("JNI-HARNESS FUZZ (heap-array streams) seed=%llu scripts=%d\n", seed, iters);
+        }
     }
     /* batch natives refuse what the per-buffer natives refuse: a null or non-direct element is an error code, not a crash */
     if (!getenv("HARNESS_SKIP_BATCH")) {

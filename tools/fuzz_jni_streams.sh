@@ -1,7 +1,7 @@
 #!/bin/bash
 # Long random-script runs of the JNI library's context streams against the reference's JNI library, on the CPU over the C-ABI double (tests/jni/emu_abi.cpp):
 #   tools/fuzz_jni_streams.sh [first-seed] [seeds] [scripts-per-seed]     (default 100, 4, 600; even seeds: GPU route only, odd seeds: bundled library behind)
-# Each script: one to three frames on one context, writes of random sizes, flushes, single-directive frames, pledged sizes, any heap / direct combination, a
+# Each script (context streams, then the heap-array stream classes): one to three frames on one context / stream object, writes of random sizes, flushes, single-directive frames, pledged sizes, any heap / direct combination, a
 # target of a few bytes or a roomy one; the bytes handed out must equal the reference's, and the frames must decode through both decompress natives.
 cd "$(dirname "$0")/.." || exit 1
 make -s -C tests/jni emu || exit 1
