@@ -103,7 +103,7 @@ def test_shim_gpu_route_over_the_emulated_kernels(leg):
     replayed into the bundled library mid-frame."""
     if not _built_emu():
         pytest.skip("no <jni.h> in this environment and no prebuilt shim")
-    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="11,150")      # + 150 random scripts of directives on a context (tools/fuzz_jni_streams.sh runs thousands)
+    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="11,80")      # + 80 random scripts of directives on a context (tools/fuzz_jni_streams.sh runs thousands)
     for k in ("ZSTD_JNI_CPU_LIB", "ZSTD_JNI_GPU_STREAMS", "ZSTD_JNI_GPU_PER_BUFFER", "ZSTD_JNI_GPU_AGGREGATE"):
         env.pop(k, None)
     if leg == "gpu-only":
