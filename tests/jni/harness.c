@@ -858,7 +858,7 @@ int main(int argc, char** argv) {
                         jint dpos = 0, spos = 0; int guard = 0; uint64_t w = 0;
                         g_x = cut;
                         while (spos < flen && guard++ < 100000) {
-                            jint const upto = (haveCpu && (rnd() & 1u)) ? spos + 1 + (jint)(rnd() % (unsigned)(flen - spos)) : flen;      /* pieces need a stream behind the GPU route */
+                            jint const upto = ((haveCpu || getenv("HARNESS_PIECES")) && (rnd() & 1u)) ? spos + 1 + (jint)(rnd() % (unsigned)(flen - spos)) : flen;      /* pieces need a stream behind the GPU route */
                             jint const before = spos;
                             w = (uint64_t)X[k].ds(e, NULL, dctx, (jobject)back, dpos, grand + 16, (jobject)fr, spos, upto);
                             if (w & 0x80000000u) break;
@@ -944,6 +944,21 @@ int main(int argc, char** argv) {
                     CHECK(r == 0 && got == total && used == (jsize)lens[0] && !memcmp(back->data, src->data, (size_t)total), "decompress stream (library %d) of the %d-byte stream frame: ret %lld, %d bytes out, %d consumed", k, (int)total, (long long)r, (int)got, (int)used);
                     S[k].dfree(e, NULL, h);
                 }
+                /* ... and in pieces of 4 000 bytes into a target of 3 000: the bundled stream's case, or (no bundled library) the frame collected by the shim */
+                if (streamMax != 0 || getenv("HARNESS_PIECES")) for (int k = 0; k < 2; k++) {
+                    Obj* self = mk(7, 0); Obj* back = mk(1, 3000); char* all = (char*)malloc((size_t)total + 64); jsize got = 0;
+                    jlong const h = S[k].dcreate(e, NULL); jlong r = S[k].dinit(e, (jobject)self, h);
+                    jsize const flen = (jsize)lens[0]; jsize used = 0, fed = 0; int guard = 0;
+                    do {
+                        if (used == fed && fed < flen) fed = fed + 4000 < flen ? fed + 4000 : flen;
+                        self->consumed = self->produced = 0;
+                        r = S[k].dstream(e, (jobject)self, h, (jobject)back, 0, 3000, (jobject)fr, used, fed - used);
+                        if (r >= 0 && got + self->produced <= total + 64) { memcpy(all + got, back->data, (size_t)self->produced); got += self->produced; }
+                        used += self->consumed;
+                    } while (r >= 0 && (used < flen || r > 0) && guard++ < 400000);
+                    CHECK(r == 0 && got == total && used == flen && !memcmp(all, src->data, (size_t)total), "decompress stream in pieces (library %d) of the %d-byte stream frame: ret %lld, %d bytes out, %d consumed", k, (int)total, (long long)r, (int)got, (int)used);
+                    S[k].dfree(e, NULL, h); free(all);
+                }
             }
             free(outs[0]); free(outs[1]);
         }
@@ -1010,7 +1025,7 @@ int main(int argc, char** argv) {
             CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "output stream of %d bytes x %d frames, level %d, checksum %d, writes of %d, flush every %d, room %d: ref %zu bytes (%lld), shim %zu bytes (%lld)",
                   (int)total, frames, (int)level, (int)ck, (int)chunk, flushEvery, (int)room, lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
             /* the frame(s) back through both input streams: everything in the source array, room for all of it; then in pieces of 4 000 bytes (the bundled stream's case) */
-            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < (streamMax == 0 ? 1 : 2); pieces++) {      /* (the GPU-only leg has no bundled stream for a frame that arrives in pieces) */
+            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < ((streamMax == 0 && !getenv("HARNESS_PIECES")) ? 1 : 2); pieces++) {      /* (the GPU-only leg has no bundled stream for a frame that arrives in pieces) */
                 Obj* fr = mk(2, (jsize)lens[0] + 1); memcpy(fr->data, outs[0], lens[0]);
                 for (int k = 0; k < 2; k++) {
                     Obj* self = mk(7, 0); Obj* back = mk(2, total * frames + 64);
@@ -1027,7 +1042,7 @@ int main(int argc, char** argv) {
                 }
             }
             /* ... and through ZstdBufferDecompressingStreamNoFinalizer (byte[] + offsets, consumed / produced): whole, then in pieces */
-            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < (streamMax == 0 ? 1 : 2); pieces++) {
+            if (worst[0] == 0 && variant != 1) for (int pieces = 0; pieces < ((streamMax == 0 && !getenv("HARNESS_PIECES")) ? 1 : 2); pieces++) {
                 typedef jlong (*bcreate_fn)(JNIEnv*, jclass); typedef jlong (*bfree_fn)(JNIEnv*, jclass, jlong); typedef jlong (*binit_fn)(JNIEnv*, jobject, jlong);
                 typedef jlong (*bdec_fn)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint, jbyteArray, jint, jint);
                 Obj* fr = mk(2, (jsize)lens[0] + 9); memcpy(fr->data + 5, outs[0], lens[0]);          /* the frame at offset 5 of its array */
@@ -1118,14 +1133,14 @@ int main(int argc, char** argv) {
                     Obj* fr = mk(2, all + 1); memcpy(fr->data, outs[0], lens[0]);
                     unsigned long long const cut = g_x;
                     for (int k = 0; k < 2; k++) {
-                        jsize const backN = haveCpu && (rnd() & 1u) ? (jsize)(1 + rnd() % 5000u) : grand + 64;      /* a target smaller than the content: the read loop empties it and comes back */
+                        jsize const backN = (haveCpu || getenv("HARNESS_PIECES")) && (rnd() & 1u) ? (jsize)(1 + rnd() % 5000u) : grand + 64;      /* a target smaller than the content: the read loop empties it and comes back */
                         Obj* self = mk(7, 0); Obj* back = mk(2, backN); char* got = (char*)malloc((size_t)grand + 64); size_t gotN = 0;
                         jlong const h = S[k].dcreate(e, NULL); jint r = S[k].dinit(e, (jobject)self, h);
                         jsize fed = 0; int guard = 0;
                         g_x = cut; (void)rnd();
                         self->srcPos = 0; self->dstPos = 0;
                         do {
-                            if (self->srcPos == fed && fed < all) fed = (haveCpu && (rnd() & 1u)) ? fed + 1 + (jsize)(rnd() % (unsigned)(all - fed)) : all;
+                            if (self->srcPos == fed && fed < all) fed = ((haveCpu || getenv("HARNESS_PIECES")) && (rnd() & 1u)) ? fed + 1 + (jsize)(rnd() % (unsigned)(all - fed)) : all;
                             self->dstPos = 0;
                             r = S[k].dstream(e, (jobject)self, h, (jbyteArray)back, backN, (jbyteArray)fr, fed);
                             if (r >= 0 && gotN + (size_t)self->dstPos <= (size_t)grand + 64) { memcpy(got + gotN, back->data, (size_t)self->dstPos); gotN += (size_t)self->dstPos; }

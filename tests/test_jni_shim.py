@@ -107,7 +107,7 @@ def test_shim_gpu_route_over_the_emulated_kernels(leg):
     for k in ("ZSTD_JNI_CPU_LIB", "ZSTD_JNI_GPU_STREAMS", "ZSTD_JNI_GPU_PER_BUFFER", "ZSTD_JNI_GPU_AGGREGATE"):
         env.pop(k, None)
     if leg == "gpu-only":
-        env.update(HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0")
+        env.update(HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0", HARNESS_PIECES="1")      # PIECES: frames fed to the decompress streams in pieces / into small targets — collected by the shim when no bundled stream exists
     else:
         env.update(ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2")
     out = subprocess.run([HARNESS, REFJNI, EMU_SHIM], env=env, capture_output=True, text=True, timeout=900)

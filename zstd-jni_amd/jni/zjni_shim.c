@@ -210,7 +210,7 @@ JNIEXPORT jlong JNICALL P(ZstdCompressCtx_reset0)(JNIEnv* env, jclass cls, jlong
 JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlong ptr) {
     jlong (*f)(JNIEnv*, jclass, jlong) = (jlong (*)(JNIEnv*, jclass, jlong))cpu_sym(PS("ZstdDecompressCtx_reset0"));
     CtxState* s = st_get(ptr, 'D');
-    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuOnly = 0; s->cpuDict = 0; s->dInFrame = 0; }
+    if (s) { if (s->ddictOwned) { zjni_freeDDict(s->ddictOwned); s->ddictOwned = NULL; } s->ddict = NULL; s->cpuOnly = 0; s->cpuDict = 0; s->dInFrame = 0; cx_drop(s); }
     return f ? f(env, cls, ptr) : 0;
 }
 /* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
@@ -845,6 +845,7 @@ static size_t ss_deliver(StreamState* s, char* dst, size_t room) {      /* pendi
     if (k) { memcpy(dst, s->out + s->outPos, k); s->outPos += k; }
     return k;
 }
+static size_t ds_buffered(StreamState* s, char* dst, size_t room, const char* src, size_t avail, size_t* produced, size_t* consumed);      /* frames in pieces without a bundled library: defined at the end of this file */
 typedef jlong (*cs_compress_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint, jobject, jint, jint);
 typedef jlong (*cs_end_fn)(JNIEnv*, jobject, jlong, jobject, jint, jint);
 /* Hand everything buffered so far to the bundled library's stream (flushes where the caller flushed), collecting what it writes; afterwards the stream is the
@@ -1085,7 +1086,18 @@ JNIEXPORT jlong JNICALL P(ZstdDirectBufferDecompressingStreamNoFinalizer_decompr
             }
         }
     }
-    if (!f) return -(jlong)ZJNI_ERROR_unsupported;
+    if (!f) {                                                                       /* no bundled stream: the frame is collected and decoded here (ds_buffered) */
+        jlong const dst_cap = (*env)->GetDirectBufferCapacity(env, dst_buf), src_cap = (*env)->GetDirectBufferCapacity(env, src_buf);
+        char* const dp = (char*)(*env)->GetDirectBufferAddress(env, dst_buf); char* const sp = (char*)(*env)->GetDirectBufferAddress(env, src_buf);
+        size_t produced, consumed, r;
+        if (!s || !gpu_on()) return -(jlong)ZJNI_ERROR_unsupported;
+        if (dst_offset + dst_size > dst_cap) return E_DST;
+        if (src_offset + src_size > src_cap) return E_SRC;
+        if (!dp || !sp) return E_MEM;
+        r = ds_buffered(s, dp + dst_offset, (size_t)dst_size, sp + src_offset, (size_t)src_size, &produced, &consumed);
+        (*env)->SetIntField(env, obj, g_ds_consumed, (jint)consumed); (*env)->SetIntField(env, obj, g_ds_produced, (jint)produced);
+        return (jlong)r;
+    }
     {   jlong const r = f(env, obj, stream, dst_buf, dst_offset, dst_size, src_buf, src_offset, src_size);
         if (s) s->started = (r > 0);                                                /* > 0: inside a frame (more input or more room wanted); 0: at a boundary again */
         return r; }
@@ -1351,7 +1363,22 @@ JNIEXPORT jint JNICALL P(ZstdInputStreamNoFinalizer_decompressStream)(JNIEnv* en
             }
         }
     }
-    if (!f) return -(jint)ZJNI_ERROR_unsupported;
+    if (!f) {                                                                       /* no bundled stream: ds_buffered */
+        jlong const sp = g_is_src ? (*env)->GetLongField(env, obj, g_is_src) : -1, dp = g_is_dst ? (*env)->GetLongField(env, obj, g_is_dst) : -1;
+        size_t produced, consumed, r, avail, room; char* in; char* out;
+        if (!s || !gpu_on() || sp < 0 || dp < 0) return -(jint)ZJNI_ERROR_unsupported;
+        if (src_size > (*env)->GetArrayLength(env, src) || sp > src_size) return (jint)E_SRC;
+        if (dst_size > (*env)->GetArrayLength(env, dst) || dp > dst_size) return (jint)E_DST;
+        avail = (size_t)(src_size - sp); room = (size_t)(dst_size - dp);
+        in = (char*)malloc(avail + 1); out = (char*)malloc(room + 1);
+        if (!in || !out) { free(in); free(out); return (jint)E_MEM; }
+        if (avail) (*env)->GetByteArrayRegion(env, src, (jsize)sp, (jsize)avail, (jbyte*)in);
+        r = ds_buffered(s, out, room, in, avail, &produced, &consumed);
+        if (produced) (*env)->SetByteArrayRegion(env, dst, (jsize)dp, (jsize)produced, (const jbyte*)out);
+        free(in); free(out);
+        (*env)->SetLongField(env, obj, g_is_src, sp + (jlong)consumed); (*env)->SetLongField(env, obj, g_is_dst, dp + (jlong)produced);
+        return zjni_isError(r) ? (jint)r : (r > 0x7FFFFFFFu ? 0x7FFFFFFF : (jint)r);
+    }
     {   jint const r = f(env, obj, stream, dst, dst_size, src, src_size);
         if (s) s->started = (r > 0);
         return r; }
@@ -1419,7 +1446,22 @@ JNIEXPORT jlong JNICALL P(ZstdBufferDecompressingStreamNoFinalizer_decompressStr
             }
         }
     }
-    if (!f) return -(jlong)ZJNI_ERROR_unsupported;
+    if (!f) {                                                                       /* no bundled stream: ds_buffered */
+        size_t produced, consumed, r; char* in; char* out;
+        if (!s || !gpu_on() || !g_bs_consumed) return -(jlong)ZJNI_ERROR_unsupported;
+        if (NULL == dst) return E_DST;
+        if (NULL == src) return E_SRC;
+        if (0 > dst_offset || 0 > dst_size || dst_offset + dst_size > (*env)->GetArrayLength(env, dst)) return E_DST;
+        if (0 > src_offset || 0 > src_size || src_offset + src_size > (*env)->GetArrayLength(env, src)) return E_SRC;
+        in = (char*)malloc((size_t)src_size + 1); out = (char*)malloc((size_t)dst_size + 1);
+        if (!in || !out) { free(in); free(out); return E_MEM; }
+        if (src_size) (*env)->GetByteArrayRegion(env, src, src_offset, src_size, (jbyte*)in);
+        r = ds_buffered(s, out, (size_t)dst_size, in, (size_t)src_size, &produced, &consumed);
+        if (produced) (*env)->SetByteArrayRegion(env, dst, dst_offset, (jsize)produced, (const jbyte*)out);
+        free(in); free(out);
+        (*env)->SetIntField(env, obj, g_bs_consumed, (jint)consumed); (*env)->SetIntField(env, obj, g_bs_produced, (jint)produced);
+        return (jlong)r;
+    }
     {   jlong const r = f(env, obj, stream, dst, dst_offset, dst_size, src, src_offset, src_size);
         if (s) s->started = (r > 0);
         return r; }
@@ -1752,7 +1794,14 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_decompressDirectByteBufferStream0)
             if (zjni_isError(r) && zjni_getErrorCode(r) < 200 && zjni_getErrorCode(r) != 70) return CX_ERR(zjni_getErrorCode(r));
         }
     }
-    if (!f) return CX_ERR(ZJNI_ERROR_unsupported);
+    if (!f) {                                                                       /* no bundled context: ds_buffered, its state beside the context's */
+        size_t produced, consumed, r; StreamState* ds;
+        if (!c || !gpu_on() || c->cpuOnly || c->cpuDict || c->ddict || c->ddictOwned || src_offset > src_size || dst_offset > dst_size || !(ds = cx_session(c))) return CX_ERR(ZJNI_ERROR_unsupported);
+        r = ds_buffered(ds, d + dst_offset, (size_t)(dst_size - dst_offset), sb + src_offset, (size_t)(src_size - src_offset), &produced, &consumed);
+        c->dInFrame = ds->started;
+        if (zjni_isError(r)) return CX_ERR(zjni_getErrorCode(r));
+        return cx_word(r == 0, (size_t)dst_offset + produced, (size_t)src_offset + consumed);
+    }
     {   uint64_t const r = (uint64_t)f(env, cls, ptr, dst, dst_offset, dst_size, src, src_offset, src_size);
         if (c) c->dInFrame = !(r & 0x80000000u) && !(r >> 63);                       /* bit 63: ZSTD_decompressStream returned 0, a frame has just ended */
         return (jlong)r; }
@@ -1937,3 +1986,76 @@ CONST_ERR(DictionaryWrong, 32) CONST_ERR(DictionaryCreationFailed, 34) CONST_ERR
 CONST_ERR(TableLogTooLarge, 44) CONST_ERR(MaxSymbolValueTooLarge, 46) CONST_ERR(MaxSymbolValueTooSmall, 48) CONST_ERR(StageWrong, 60)
 CONST_ERR(InitMissing, 62) CONST_ERR(MemoryAllocation, 64) CONST_ERR(WorkSpaceTooSmall, 66) CONST_ERR(DstSizeTooSmall, 70) CONST_ERR(SrcSizeWrong, 72)
 CONST_ERR(DstBufferNull, 74)
+
+/* ---- decompress streams WITHOUT a bundled library behind them: a frame that arrives in pieces, or into a target smaller than its content ---------------------------
+ * With the bundled library such frames are its stream's (ZSTD_decompressStream keeps a window, not the frame).  Without it the frame is collected here — exactly
+ * the frame's bytes, never a byte of what follows it: the frame header says where the first block header is, every block header where the next one is — decoded in
+ * one piece by zjni_decompress when its last byte has arrived, and handed out as the caller brings room.  Answers follow ZSTD_decompressStream: 0 after a frame's last
+ * byte is out, else a positive hint; input is not taken while output is pending.  Frames to 256 MiB and 1 GiB of content. */
+#define DS_MAX_FRAME ((size_t)256 << 20)
+#define DS_MAX_CONTENT ((unsigned long long)1 << 30)
+/* how many bytes the collected frame must reach before more can be said (> have), or 0 with *total = the frame's size when [0, have) holds all of it; an error code */
+static size_t ds_need(const uint8_t* p, size_t have, size_t* total) {
+    FrameHead h; size_t r, pos;
+    *total = 0;
+    if (have >= 8 && (p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18) {       /* a skippable frame: 8 bytes and what they announce */
+        size_t const t = 8 + (size_t)((uint32_t)p[4] | (uint32_t)p[5] << 8 | (uint32_t)p[6] << 16 | (uint32_t)p[7] << 24);
+        if (t > DS_MAX_FRAME) return FH_ERR(ZJNI_ERROR_unsupported);
+        if (have < t) return t;
+        *total = t; return 0;
+    }
+    r = frame_head(&h, p, have, 0);
+    if (FH_IS_ERR(r)) return r;
+    if (r > 0) return r;
+    pos = h.headerSize;
+    for (;;) {
+        uint32_t bh, type; size_t body;
+        if (have < pos + 3) return pos + 3;
+        bh = (uint32_t)p[pos] | (uint32_t)p[pos + 1] << 8 | (uint32_t)p[pos + 2] << 16;
+        type = (bh >> 1) & 3;
+        if (type == 3) return FH_ERR(20);
+        body = type == 1 ? 1 : bh >> 3;
+        pos += 3 + body;
+        if (pos > DS_MAX_FRAME) return FH_ERR(ZJNI_ERROR_unsupported);
+        if (bh & 1) break;
+        if (have < pos) return pos + 3 > have ? pos + 3 : pos;          /* the block and the next block's header */
+    }
+    if (h.checksum) pos += 4;
+    if (have < pos) return pos;
+    *total = pos; return 0;
+}
+/* one call of a decompress stream on raw memory: dst has `room` bytes, src `avail` unread bytes.  Returns ZSTD_decompressStream's answer (0, a hint, or an error code) */
+static size_t ds_buffered(StreamState* s, char* dst, size_t room, const char* src, size_t avail, size_t* produced, size_t* consumed) {
+    *produced = *consumed = 0;
+    if (s->outPos == s->outLen) {
+        for (;;) {                                                  /* collect the frame */
+            size_t total = 0, take; size_t const need = ds_need(s->buf, s->total, &total);
+            if (FH_IS_ERR(need)) { s->total = 0; s->started = 0; return need; }
+            if (need == 0) {                                        /* all of it is here: decode */
+                unsigned long long content = 0, bound = 0; size_t r = 0;
+                size_t const ext = zjni_frame_extent(s->buf, total, &content, &bound);
+                s->outLen = s->outPos = 0;
+                if (ext) {
+                    if (bound > DS_MAX_CONTENT || !ss_out_room(s, (size_t)bound + 1)) { s->total = 0; s->started = 0; return FH_ERR(ZJNI_ERROR_unsupported); }
+                    r = zjni_decompress(s->out, (size_t)bound, s->buf, total);
+                    if (zjni_isError(r)) { s->total = 0; s->started = 0; return r; }
+                    s->outLen = r;
+                    __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED);
+                } else if (!(total >= 8 && (s->buf[0] & 0xF0) == 0x50)) { s->total = 0; s->started = 0; return FH_ERR(20); }       /* (a skippable frame has nothing to hand out) */
+                s->total = 0;
+                break;
+            }
+            take = need - s->total; if (take > avail - *consumed) take = avail - *consumed;
+            if (take == 0) { s->started = 1; return need - s->total; }      /* the caller comes back with more */
+            if (s->total + take > s->cap) {
+                size_t const c = (s->total + take) * 2 + 4096; unsigned char* q = (unsigned char*)realloc(s->buf, c);
+                if (!q) return (size_t)E_MEM;
+                s->buf = q; s->cap = c;
+            }
+            memcpy(s->buf + s->total, src + *consumed, take); s->total += take; *consumed += take;
+        }
+    }
+    *produced = ss_deliver(s, dst, room);
+    s->started = s->outPos < s->outLen;
+    return s->started ? s->outLen - s->outPos : 0;
+}
