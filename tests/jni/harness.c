@@ -1072,7 +1072,7 @@ int main(int argc, char** argv) {
         /* HARNESS_FUZZ: random scripts on one ZstdOutputStreamNoFinalizer object — one to three frames (resetCStream between them), writes of random sizes through the
          * Java class's loop on srcPos, flushes (repeated ones too), a target array of a few bytes or ZSTD_CStreamOutSize(); what both libraries hand out must be the same
          * bytes; then the frames back through ZstdInputStreamNoFinalizer, whole or (with a bundled stream behind) in random pieces into a target of random size */
-        if (getenv("HARNESS_FUZZ")) {
+        if (getenv("HARNESS_FUZZ") && !getenv("HARNESS_FUZZ_SKIP_HEAP")) {
             unsigned long long seed = 1; int iters = 100; int const haveCpu = getenv("ZSTD_JNI_CPU_LIB") != NULL;
             sscanf(getenv("HARNESS_FUZZ"), "%llu,%d", &seed, &iters);
             g_x = 0xC2B2AE3D27D4EB4Full ^ (seed * 0x9E3779B97F4A7C15ull); if (!g_x) g_x = 1;
