@@ -959,6 +959,29 @@ int main(int argc, char** argv) {
                     CHECK(r == 0 && got == total && used == flen && !memcmp(all, src->data, (size_t)total), "decompress stream in pieces (library %d) of the %d-byte stream frame: ret %lld, %d bytes out, %d consumed", k, (int)total, (long long)r, (int)got, (int)used);
                     S[k].dfree(e, NULL, h); free(all);
                 }
+                /* ... and with a skippable frame in front and one behind (ZSTD_decompressStream passes over them), fed in pieces of 7 bytes at first */
+                if ((streamMax != 0 || getenv("HARNESS_PIECES")) && variant == 0) {
+                    static const unsigned char skip[13] = {0x5A, 0x2A, 0x4D, 0x18, 5, 0, 0, 0, 'h', 'e', 'l', 'l', 'o'};
+                    jsize const flen = (jsize)lens[0] + 26;
+                    Obj* fr2 = mk(1, flen + 1); memcpy(fr2->data, skip, 13); memcpy(fr2->data + 13, outs[0], lens[0]); memcpy(fr2->data + 13 + lens[0], skip, 13);
+                    jlong rets[2] = {0, 0}; jsize gots[2] = {0, 0}, useds[2] = {0, 0};
+                    for (int k = 0; k < 2; k++) {
+                        Obj* self = mk(7, 0); Obj* back = mk(1, total + 64);
+                        jlong const h = S[k].dcreate(e, NULL); jlong r = S[k].dinit(e, (jobject)self, h);
+                        jsize used = 0, fed = 0, got = 0; int guard = 0;
+                        do {
+                            if (used == fed && fed < flen) fed = fed + (fed < 40 ? 7 : 50000) < flen ? fed + (fed < 40 ? 7 : 50000) : flen;
+                            self->consumed = self->produced = 0;
+                            r = S[k].dstream(e, (jobject)self, h, (jobject)back, got, total + 64 - got, (jobject)fr2, used, fed - used);
+                            got += self->produced; used += self->consumed;
+                        } while (r >= 0 && (used < flen || r > 0) && guard++ < 400000);
+                        CHECK(r == 0 && got == total && used == flen && !memcmp(back->data, src->data, (size_t)total), "decompress stream with skippable frames around (library %d), %d bytes: ret %lld, %d out, %d of %d consumed", k, (int)total, (long long)r, (int)got, (int)used, (int)flen);
+                        rets[k] = r; gots[k] = got; useds[k] = used;
+                        S[k].dfree(e, NULL, h); free(back->data); free(back);
+                    }
+                    CHECK(rets[0] == rets[1] && gots[0] == gots[1] && useds[0] == useds[1], "skippable frames: both libraries alike");
+                    free(fr2->data); free(fr2);
+                }
             }
             free(outs[0]); free(outs[1]);
         }
