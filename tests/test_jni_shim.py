@@ -95,24 +95,40 @@ def _built_emu():
     return os.path.exists(EMU_SHIM)
 
 
-@pytest.mark.parametrize("leg", ["gpu-only", "bundled-library-behind"])
-def test_shim_gpu_route_over_the_emulated_kernels(leg):
-    """The two GPU legs below, on the CPU: the JNI library linked against the emulation of the C-ABI.  gpu-only: no bundled library, every native must be answered by
-    the (emulated) GPU path — one-shot natives at levels 1-8, dictionaries, frame parameters, the five stream classes, the context streams — and equal the reference's
-    JNI library (76 000 checks, none forwarded).  bundled-library-behind: ZSTD_JNI_GPU_STREAMS=1 with the reference behind it — streams that outgrow the window are
-    replayed into the bundled library mid-frame."""
+@pytest.fixture(scope="module")
+def emu_legs():
+    """both legs started side by side (a minute of lane-serial emulation each), collected by the tests below"""
     if not _built_emu():
         pytest.skip("no <jni.h> in this environment and no prebuilt shim")
-    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="11,80")      # + 80 random scripts of directives on a context (tools/fuzz_jni_streams.sh runs thousands)
-    for k in ("ZSTD_JNI_CPU_LIB", "ZSTD_JNI_GPU_STREAMS", "ZSTD_JNI_GPU_PER_BUFFER", "ZSTD_JNI_GPU_AGGREGATE"):
-        env.pop(k, None)
-    if leg == "gpu-only":
-        env.update(HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0", HARNESS_PIECES="1")      # PIECES: frames fed to the decompress streams in pieces / into small targets — collected by the shim when no bundled stream exists
-    else:
-        env.update(ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2")
-    out = subprocess.run([HARNESS, REFJNI, EMU_SHIM], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]
-    stats = [l for l in out.stdout.splitlines() if l.startswith("JNI-HARNESS STATS")][0]
+    procs = {}
+    for leg in ("gpu-only", "bundled-library-behind"):
+        env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="11,80")      # + 80 random scripts of directives per kind (tools/fuzz_jni_streams.sh runs thousands)
+        for k in ("ZSTD_JNI_CPU_LIB", "ZSTD_JNI_GPU_STREAMS", "ZSTD_JNI_GPU_PER_BUFFER", "ZSTD_JNI_GPU_AGGREGATE"):
+            env.pop(k, None)
+        if leg == "gpu-only":
+            env.update(HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0", HARNESS_PIECES="1")      # PIECES: frames fed to the decompress streams in pieces / into small targets — collected by the shim when no bundled stream exists
+        else:
+            env.update(ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2")
+        procs[leg] = subprocess.Popen([HARNESS, REFJNI, EMU_SHIM], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = {}
+    for leg, p in procs.items():
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, e = p.communicate()
+        out[leg] = (p.returncode, o, e)
+    return out
+
+
+@pytest.mark.parametrize("leg", ["gpu-only", "bundled-library-behind"])
+def test_shim_gpu_route_over_the_emulated_kernels(emu_legs, leg):
+    """The two GPU legs below, on the CPU: the JNI library linked against the emulation of the C-ABI.  gpu-only: no bundled library, every native must be answered by
+    the (emulated) GPU path — one-shot natives at levels 1-8, dictionaries, frame parameters, the five stream classes, the context streams, frames in pieces — and equal
+    the reference's JNI library (78 000 checks, none forwarded).  bundled-library-behind: ZSTD_JNI_GPU_STREAMS=1 with the reference behind it — streams that outgrow the
+    window are replayed into the bundled library mid-frame."""
+    rc, stdout, stderr = emu_legs[leg]
+    assert rc == 0 and "JNI-HARNESS OK" in stdout, stdout[-3000:] + stderr[-500:]
+    stats = [l for l in stdout.splitlines() if l.startswith("JNI-HARNESS STATS")][0]
     served = int(stats.split("served_by_gpu=")[1].split()[0]); declined = int(stats.split("forwarded_after_gpu_declined=")[1].split()[0])
     assert served > (3000 if leg == "gpu-only" else 300), stats
     assert (declined == 0) if leg == "gpu-only" else (declined > 0), stats          # the second leg must have replayed streams into the bundled library
