@@ -2030,7 +2030,7 @@ static size_t ds_buffered(StreamState* s, char* dst, size_t room, const char* sr
     if (s->outPos == s->outLen) {
         for (;;) {                                                  /* collect the frame */
             size_t total = 0, take; size_t const need = ds_need(s->buf, s->total, &total);
-            if (FH_IS_ERR(need)) { s->total = 0; s->started = 0; return need; }
+            if (zjni_isError(need)) { s->total = 0; s->started = 0; return need; }      /* (libzstd's codes and this library's 201) */
             if (need == 0) {                                        /* all of it is here: decode */
                 unsigned long long content = 0, bound = 0; size_t r = 0;
                 size_t const ext = zjni_frame_extent(s->buf, total, &content, &bound);
