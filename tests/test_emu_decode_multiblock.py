@@ -111,3 +111,17 @@ def test_sequences_with_many_extra_bits(emu, oracle_ref):
         got, used = mb(emu, z, len(d))
         assert got == d, level
         assert used == 1, level
+
+
+def test_concrete_offsets_that_look_symbolic_are_refused(emu, oracle_ref):
+    """offset code 31 gives concrete offsets with bit 31 set — the lane-per-block decode's mark of a symbolic repcode.  Frames WITHOUT a checksum
+    (a checksum had hidden the wrong bytes): valid small offsets decode, offset codes 27 .. 31 answer as the reference answers them."""
+    from util import crafted_far_offset_frame
+    for code, extra in ((2, 1), (5, 0), (6, 3), (26, 5), (27, 0), (27, 12345), (28, 0), (29, 7), (30, 1 << 29), (31, 0), (31, 3), (31, 5), (31, (1 << 31) - 1), (31, 1 << 30)):
+        f, total = crafted_far_offset_frame(code, extra)
+        try:
+            want = oracle_ref.decompress_portable(f, total)
+        except oracle_ref.ZstdRefError as e:
+            want = -e.code
+        got, used = mb(emu, f, total)
+        assert got == want, (code, extra, got if isinstance(got, int) else len(got), want if isinstance(want, int) else len(want), used)

@@ -86,3 +86,18 @@ def test_gpu_damaged_multiblock_frames(gpu, oracle_ref):
             assert isinstance(o, Exception) and o.getErrorCode() == e.code, (o, e.code)
             continue
         assert o == want
+
+
+def test_gpu_concrete_offsets_that_look_symbolic_are_refused(gpu, oracle_ref):
+    """ADVICE r04 (see the emulation twin): crafted frames without a checksum whose one sequence carries offset codes up to 31."""
+    from util import crafted_far_offset_frame
+    cases = [(2, 1), (5, 0), (6, 3), (26, 5), (27, 0), (27, 12345), (28, 0), (29, 7), (30, 1 << 29), (31, 0), (31, 3), (31, 5), (31, (1 << 31) - 1), (31, 1 << 30)]
+    frames, totals = zip(*[crafted_far_offset_frame(c, x) for c, x in cases])
+    outs = gpu.decompress_batch(list(frames), list(totals))
+    for (c, x), f, t, o in zip(cases, frames, totals, outs):
+        try:
+            want = oracle_ref.decompress_portable(f, t)
+        except oracle_ref.ZstdRefError as e:
+            assert isinstance(o, Exception) and o.getErrorCode() == e.code, (c, x, o, e.code)
+            continue
+        assert o == want, (c, x)

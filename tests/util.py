@@ -208,3 +208,20 @@ def edge_inputs(seed=1234):
         ("binary_struct", b"".join((i % 251).to_bytes(4, "little") + b"\x00\x00\x01\x00" + bytes([rnd.getrandbits(8) & 0x0F]) for i in range(7000))),
     ]
     return out
+
+
+def crafted_far_offset_frame(of_code, extra, checksum=False, first_raw=100):
+    """A hand-built frame WITHOUT checksum: a raw block, then a compressed block of 4 raw literals and ONE sequence whose three tables are in RLE mode — literal
+    length code 3, match length code 0, offset code `of_code` with `extra` as its extra bits (N/decompress/zstd_decompress_block.c:1229-1300: offset =
+    (1 << code) - 3 + extra for code >= 2).  Offset codes 28 .. 31 give offsets far beyond any output position (and from code 31 on with bit 31 set): the
+    reference answers corruption_detected; ADVICE r04 found the lane-per-block decode taking such an offset for a symbolic repcode."""
+    assert 2 <= of_code <= 31 and 0 <= extra < (1 << of_code)
+    raw = bytes((i * 7 + 1) & 0xFF for i in range(first_raw))
+    bits = extra | (1 << of_code)                        # the extra bits, the end mark above them
+    stream = bits.to_bytes((of_code + 8) // 8, "little")
+    body = bytes([4 << 3]) + b"wxyz" + bytes([1, 0x54, 3, of_code, 0]) + stream
+    total = first_raw + 4 + 3                            # (the fourth literal follows the match)
+    hdr = b"\x28\xb5\x2f\xfd" + bytes([0x20 | (4 if checksum else 0), total])
+    blk1 = ((first_raw << 3) | 0).to_bytes(3, "little") + raw
+    blk2 = ((len(body) << 3) | (2 << 1) | 1).to_bytes(3, "little") + body
+    return hdr + blk1 + blk2, total

@@ -77,8 +77,23 @@ h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp)
 t8 = (C.c_float * 8)(); L.zjni_last_timing2(t8)
 stages = dict(zip(("match", "dec_prep", "dec_seq", "dec_exec", "dec_fused", "match_wide"), [round(float(x), 3) for x in t8][:6]))
 if hasattr(L, "zjni_debug_wave_profile"):
-    wp = np.zeros(3 * 2048, dtype=np.uint64); L.zjni_debug_wave_profile(wp.ctypes.data_as(vp))
+    wp = np.zeros(4 * 2048, dtype=np.uint64); L.zjni_debug_wave_profile(wp.ctypes.data_as(vp))
     np.save(os.path.join(ROOT, "gpurun_out", "waveprof_%s.npy" % os.environ.get("AB_TAG", "x")), wp)
+    w = wp.reshape(-1, 4)[:min(1024, (n + 63) // 64)]; t0 = w[:, 3].astype(np.int64); late = (t0 - t0.min()) / 100.0        # microseconds after the first wave
+    sys.stderr.write("match waves: %d; started > 100 us after the first: %d, > 1 ms: %d, > 10 ms: %d (latest %.1f ms); lane 0 never got a frame in %d waves\n"
+                     % (len(w), int((late > 100).sum()), int((late > 1000).sum()), int((late > 10000).sum()), late.max() / 1000.0, int((w[:, 2] <= 1).sum())))
+    if (late > 1000).any():
+        import collections
+        xcc = ((w[:, 1] >> np.uint64(32)) & np.uint64(0xF)).astype(int); lt = late > 1000
+        sys.stderr.write("  late waves by XCC %s; all waves by XCC %s; late start times (ms) 10/50/90 %% = %s; blockIdx of late waves %% 8 = %s\n" % (sorted(collections.Counter(xcc[lt].tolist()).items()), sorted(collections.Counter(xcc.tolist()).items()),
+                         [round(float(np.quantile(late[lt], q)) / 1000.0, 1) for q in (0.1, 0.5, 0.9)], sorted(collections.Counter((np.nonzero(lt)[0] % 8).tolist()).items())))
+if hasattr(L, "zjni_debug_frame_rounds") and n <= 131072:      # -DZL_PROFILE builds: the round in which each list entry's lane finished -> lanes still alive over the launch, by class
+    fr = np.zeros(131072, dtype=np.uint32); L.zjni_debug_frame_rounds(fr.ctypes.data_as(vp))
+    fr = fr[:n]; total = int(fr.max()) or 1
+    sys.stderr.write("frame finish rounds: launch %d rounds; lanes alive after 0/10/25/50/60/70/80/90/95 %% of the launch = %s\n" % (total, [int((fr > total * f).sum()) for f in (0.0, 0.1, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)]))
+    for c in range(4):            # zj_synth.h: index & 3 = 0 text, 1 JSON-like, 2 low-entropy, 3 random
+        x = fr[c::4]; sys.stderr.write("  class %d: finish round min / 10 / 50 / 90 / 99 %% / max = %s\n" % (c, [int(x.min())] + [int(np.quantile(x, q)) for q in (0.1, 0.5, 0.9, 0.99)] + [int(x.max())]))
+    np.save(os.path.join(ROOT, "gpurun_out", "framerounds_%s.npy" % os.environ.get("AB_TAG", "x")), fr)
 import hashlib
 fp = hashlib.sha1(h_csz.tobytes()).hexdigest()[:12]
 L.zjni_build_stamp.restype = C.c_char_p; L.zjni_route_kernel.restype = C.c_char_p; L.zjni_route_kernel.argtypes = [C.c_int]

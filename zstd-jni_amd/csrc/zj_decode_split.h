@@ -285,8 +285,13 @@ struct ZDSeqLaneT {
 #undef ZD_TAKE
         u32 const llen = llb + llv, mlen = mlb + mlv;
         u32 offset;
-        if (ofx > 1u) { offset = ofb + ofv; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-        else {
+        if (ofx > 1u) {
+            offset = ofb + ofv;
+            // MB: a concrete offset that does not fit a record's 27 bits must not reach the history — from offset code 31 on it would carry bit 31 and read as a
+            // symbolic entry (a crafted block decoded to wrong bytes where the reference reports corruption); such windows are the fused kernel's
+            if (MB && offset >= ZD_SYM_REC) { bad = 1; finish(); return; }
+            rep2 = rep1; rep1 = rep0; rep0 = offset;
+        } else {
             u32 const ll0 = (llen == 0u);
             if (ofx == 0u) { if (ll0) { offset = rep1; rep1 = rep0; rep0 = offset; } else offset = rep0; }
             else {

@@ -345,8 +345,10 @@ __device__ __forceinline__ bool zj_claim_back(unsigned long long* work2, u32 cou
 }
 
 #ifdef ZL_PROFILE
-__device__ unsigned long long zlWaveProf[3 * 2048];      // per workgroup of the last large match launch: cycles in the round loop, XCC_ID << 32 | HW_ID, rounds
+__device__ unsigned long long zlWaveProf[4 * 2048];      // per workgroup of the last large match launch: cycles in the round loop, XCC_ID << 32 | HW_ID, rounds of lane 0, wall clock (100 MHz) at its start
 extern "C" int zjni_debug_wave_profile(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zlWaveProf), sizeof(zlWaveProf)); }
+__device__ u32 zlFrameRounds[131072];                    // per frame of the last large match launch: the round in which its lane finished it (the launch's active lanes over time, profiles/r05/)
+extern "C" int zjni_debug_frame_rounds(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(zlFrameRounds), sizeof(zlFrameRounds)); }
 #endif
 template <class M>
 __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
@@ -356,7 +358,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                                              const u32* ready = nullptr, u32 flagStride = ZN_FLAG_STRIDE) {      // ready[k] != 0: the flags of list entry k are written (gate[k] says whether any will come); flagStride: flag bytes per list entry
     M m; m.st = ZL_DONE; m.lastLL = 0; m.o.n = 0; m.o.lit = 0;
 #ifdef ZL_PROFILE
-    u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0;
+    u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0; u64 const zlWall0 = wall_clock64();
 #endif
     u32 have = 0, pend = 0, late = 0; u32 k = 0; u64 tPend = 0;          // (per-lane flags as 0 / 1 in vector registers: a loop-carried bool is a lane mask and every divergent assignment three scalar instructions)
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : M::default_period(); u32 ph = 0;   // double-fast machines: rounds per rotation of the non-search states
@@ -374,6 +376,9 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         } else if (m.st == ZL_DONE) {
             if (have) {
                 u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = 0u;
+#ifdef ZL_PROFILE
+                if (count > 4096u && list[k] < 131072u) zlFrameRounds[list[k]] = r;          // (by frame index: the synthetic set's class is index & 3)
+#endif
                 zj_publish_done(doneList, doneCount, k);
             }
             late = 0u;
@@ -402,8 +407,8 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         ph = ph + 1u >= period ? 0u : ph + 1u;
     }
 #ifdef ZL_PROFILE
-    if (threadIdx.x == 0 && blockIdx.x < 2048u && count > 4096u) { zlWaveProf[3 * blockIdx.x] = __builtin_readcyclecounter() - zlWaveT0; zlWaveProf[3 * blockIdx.x + 1] = ((u64)(u32)__builtin_amdgcn_s_getreg(63508) << 32) | (u32)__builtin_amdgcn_s_getreg(63492); zlWaveProf[3 * blockIdx.x + 2] = zlRounds; }
-    if (ZL_PROFILE > 1 && blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, m.pR, (m.pA + m.pB + m.pC) / 1000000ull, m.pA / m.pR, m.pB / m.pR, m.pC / m.pR);
+    if (threadIdx.x == 0 && blockIdx.x < 2048u && count > 4096u) { zlWaveProf[4 * blockIdx.x] = __builtin_readcyclecounter() - zlWaveT0; zlWaveProf[4 * blockIdx.x + 1] = ((u64)(u32)__builtin_amdgcn_s_getreg(63508) << 32) | (u32)__builtin_amdgcn_s_getreg(63492); zlWaveProf[4 * blockIdx.x + 2] = zlRounds; zlWaveProf[4 * blockIdx.x + 3] = zlWall0; }
+    if (ZL_PROFILE > 1 && blockIdx.x == 0 && threadIdx.x < 4) printf("match lane profile: lane %u (frame class %u) done after %llu rounds, %llu Mcycles; cycles/round: phase1 %llu, loads %llu, phase3 %llu\n", threadIdx.x, threadIdx.x & 3, (unsigned long long)m.pR, (unsigned long long)((m.pA + m.pB + m.pC) / 1000000ull), (unsigned long long)(m.pA / m.pR), (unsigned long long)(m.pB / m.pR), (unsigned long long)(m.pC / m.pR));
 #endif
 }
 // entries [listBase, listBase + sliceLen) of a list whose length sits in device memory (a slice past its end is empty)
@@ -1893,7 +1898,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
             // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
             if (needGate && !zj_env("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
-            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridA), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
+            u32 gridE = gridA;                                  // (ZJNI_ENT_GRID: fewer entropy workgroups beside the match kernel — with <= 1 024 every match wave is resident from the start, profiles/r05/b_; the call's time does not move)
+            if (const char* ov = zj_env("ZJNI_ENT_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridE) gridE = v; }
+            hipLaunchKernelGGL(zj_encode_kernel, dim3(gridE), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
             if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));

@@ -49,6 +49,9 @@ enum { ZL_FAR = ZL_DONE + 1, ZL_SL1, ZL_SL2 };
 #ifndef ZR_JMAX_DEFAULT
 #define ZR_JMAX_DEFAULT 5u        /* quiet positions committed per round at most (measured on the metric configuration: 3 / 5 / 7 -> 133 / 123 / 135 ms) */
 #endif
+#ifndef ZR_SHADOW
+#define ZR_SHADOW 1               /* the "no match" step of a lane without a candidate is taken while the round's loads fly (round 5) */
+#endif
 #ifndef ZR_PERIOD
 #define ZR_PERIOD 4u              /* rotation of the non-search states: count, post-insert, restart, one search-only round */
 #endif
@@ -284,6 +287,39 @@ struct ZLaneR {
         if (ZR_EXTRA_LOADS > 2) x2 = zr_ld64_m(m0, src + zj_min(q0 ^ 0x6000u, nm8));
         asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
 #endif
+#if ZR_SHADOW
+        // ---- in the SHADOW of the loads (round 5): a searching lane whose entries name no candidate (no tag agrees) and whose repcode test fails cannot
+        // match at ip whatever this round's loads bring, so everything its "no match" step does — the quiet run's table writes, the advance to P, the
+        // slide of the three windows — is worked out while the loads fly instead of after the wait; what the step needs FROM the loads (P's entries,
+        // the refill words) is merged in behind the wait.  A lane with a candidate decides behind the wait as before; if the candidate's bytes differ
+        // it only forgets the candidate and takes this path in the next round (tags are 15 bits: once in ~30 000 probes).
+        bool const sure = isS && !rep0 && !far && !(ml0 || ms0);
+        u32 f0v = 0, f1v = 0, k8S = 0; bool refS = false;
+        if (sure) {
+ZR_UNROLL
+            for (u32 j = 1; j <= JMAX; j++) {
+                if (!ZR_ANY(j <= J)) break;               // (wave-uniform: no lane's run is this long)
+                bool const inRun = j <= J;
+                u64 const wq = zr_shr(A, B, j); u32 const fq = (u32)(FA >> (8u * j));
+                u32 const pq = prod_long(wq), bl = idx_long(pq), bs = zl_hash(hS, wq);
+                u32 const eL = (u32)E::make(ip + j + 1u, tag_long(pq)), eS = (u32)E::make(ip + j + 1u, ze_tag4((u32)wq));
+                bool const wL = inRun && (fq & 4u) != 0u, wS = inRun && (fq & 8u) != 0u;
+                ZRM const RUN = ZRM_OF(j <= J);
+                zr_st32_m(RUN & ZRM_OF((fq & 4u) != 0u), &HL[bl], eL); zr_st32_m(RUN & ZRM_OF((fq & 8u) != 0u), &HS[bs], eS);
+                f0v = (wL && bl == nhl && vt0) ? eL : f0v; f1v = (wS && bs == nhs && vt1) ? eS : f1v;          // a write into the bucket this round already asked for is forwarded
+            }
+            if (ip + step >= nextStep) { step++; nextStep += 256u; }       // (only ever with J == 0)
+            ip += adv;
+            refS = vwn < 16u; k8S = (vwn & 7u) * 8u;                        // (refill: vwn = 8 .. 15, the new bytes land at byte vwn — behind the wait)
+            u64 const sC = adv >= 8u ? 0 : (C >> (8u * adv)), sRC = adv >= 8u ? 0 : (RC >> (8u * adv)), sFC = adv >= 8u ? 0 : (FC >> (8u * adv));
+            A = zr_ext(A, B, adv); B = zr_ext(B, C, adv); C = sC;
+            RA = zr_ext(RA, RB, adv); RB = zr_ext(RB, RC, adv); RC = sRC;
+            FA = zr_ext(FA, FB, adv); FB = zr_ext(FB, FC, adv); FC = sFC;
+            vw = refS ? vwn + 8u : vwn;
+            hl0 = nhl; hs0 = nhs; tl0 = ntl;
+            if (ip + step > ilimit) finish();
+        }
+#endif
         ZR_WAIT9(d0, d1, d2, d3, d4, b0, b1, t0, t1);
         ZR_WAIT2(g0, g1);
 #ifdef ZR_EXTRA_LOADS
@@ -334,7 +370,17 @@ struct ZLaneR {
                 // no match, and the next position is out of the windows' reach: reload there
                 if (ip + step >= nextStep) { step++; nextStep += 256u; ip += step - 1u; } else ip += step;
                 if (ip + step > ilimit) finish(); else st = ZL_FAR;
-            } else {
+            }
+#if ZR_SHADOW
+            else if (sure) {                                   // the step was taken in the loads' shadow: P's entries (or a forwarded write) and the refill words
+                el0 = f0v ? f0v : (vt0 ? t0 : 0u); es0 = f1v ? f1v : (vt1 ? t1 : 0u);
+                u64 const hiSh = (64u - k8S) & 63u;
+                B = refS ? (B | (d0 << k8S)) : B; C = refS ? (k8S ? (d0 >> hiSh) : 0) : C;
+                RB = refS ? (RB | (d1 << k8S)) : RB; RC = refS ? (k8S ? (d1 >> hiSh) : 0) : RC;
+                FB = refS ? (FB | (g0 << k8S)) : FB; FC = refS ? (k8S ? (g0 >> hiSh) : 0) : FC;
+            } else { el0 = 0; es0 = 0; }                       // a candidate whose bytes differ: forgotten; the position takes the path above in the next round
+#else
+            else {
                 // no match at ip: commit the quiet run behind it, move to P with the entries this round fetched
                 u32 e0 = vt0 ? t0 : 0u, e1 = vt1 ? t1 : 0u;
 ZR_UNROLL
@@ -366,6 +412,7 @@ ZR_UNROLL
                 el0 = e0; es0 = e1; hl0 = nhl; hs0 = nhs; tl0 = ntl;
                 if (ip + step > ilimit) finish();
             }
+#endif
         }
         if ((K & ZL_EN_COUNT) && isC) {
             u32 const lim = n - ca;
