@@ -117,7 +117,8 @@ size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src
 /* ---- explicit table sizes: ZstdCompressCtx.setHashLog / setChainLog (J/ZstdCompressCtx.java; N/jni_fast_zstd.c setHashLog0 /
  * setChainLog0 -> ZSTD_c_hashLog / ZSTD_c_chainLog) on top of level + checksum; 0 = not set.  Honoured for level 3
  * (double-fast): hashLog 6..17, chainLog 6..16, frames byte-identical to the reference called with the same two
- * parameters — with 16 / 15 that is the reference's plain level 3.  Not set, level 3 uses 14 / 13.
+ * parameters.  Not set, level 3 uses the reference's own sizes for the input (16 / 15 at 64 KiB: the frames of a plain
+ * Zstd.compress(x, 3)); 14 / 13 are the sizes the LDS-resident finders of small batches are built for, honoured when asked for.
  * Other levels with a non-zero value: ZSTD_error_parameter_unsupported; out of range: parameter_outOfBound. */
 /* Frame-header parameters: the `checksum` argument of the *_advanced and *_usingCDict entries is a flag word —
  * ZSTD_c_checksumFlag, ZSTD_c_contentSizeFlag = 0 (ZstdCompressCtx.setContentSize0(false), N/jni_fast_zstd.c:301-308: no frame
@@ -191,6 +192,24 @@ size_t zjni_compress_batch(const void* const* src, const size_t* srcSize,
 size_t zjni_compress_batch2(const void* const* src, const size_t* srcSize,
                             void* const* dst, const size_t* dstCapacity,
                             size_t* result, size_t n, int level, int checksum);
+
+/* ---- the same entries, asynchronous: two host batches in flight (round 5) ----
+ * zstd-jni's natives block (N/jni_fast_zstd.c:586-640: one ZSTD_compress2 per call); a batch native over this library would too, and a single host batch is
+ * a chain: gather + H2D, kernels, D2H + scatter (75 + 143 + 35 ms on 65 536 x 64 KiB at level 3) — the lane pipeline wants the whole batch resident before its
+ * kernels start.  The overlap comes from the NEXT batch: every device has two staging slots with their own streams, so while one call's kernels run the other
+ * call's sources cross the link one way and a finished call's frames the other.  Two threads inside zjni_compress_batch2 / zjni_decompress_batch get that by
+ * themselves; these entries give it to one thread: _begin returns at once with a job that runs the blocking entry on a thread of the library (bound to the
+ * caller's device), zjni_batch_finish waits for it, returns the call's code and frees the job.  Every array and buffer passed to _begin belongs to the job until
+ * _finish returns; `result` is written as in the blocking entries.  NULL: no device bound, or no thread to be had.  More than two jobs may be begun; the third
+ * waits for a slot.  What compressBatch0 / decompressBatch0 of the JNI library would call to keep two Java-side batches in flight. */
+typedef struct zjni_batch_job zjni_batch_job;
+zjni_batch_job* zjni_compress_batch_begin(const void* const* src, const size_t* srcSize,
+                                          void* const* dst, const size_t* dstCapacity,
+                                          size_t* result, size_t n, int level, int checksum);
+zjni_batch_job* zjni_decompress_batch_begin(const void* const* src, const size_t* srcSize,
+                                            void* const* dst, const size_t* dstCapacity,
+                                            size_t* result, size_t n);
+size_t zjni_batch_finish(zjni_batch_job* job);
 
 /* ---- one host batch over several GPUs of this process (a JVM is one process) ----
  * The batch is cut into contiguous index ranges of about equal source bytes, one per entry of `devices` (ordinals, nDevices <= 64;

@@ -95,3 +95,38 @@ def test_scratch_limit_bounds_the_library(gpu, oracle_ref):
     finally:
         L.zjni_set_scratch_limit(0)
         assert L.zjni_release_scratch() == 0
+
+
+def test_gpu_two_host_batches_in_flight(gpu, oracle_ref):
+    """zjni_compress_batch_begin / zjni_decompress_batch_begin (round 5): jobs through the device's two staging slots at once, a third waiting for a slot;
+    frames byte-identical to the reference's, every batch back to its input."""
+    import ctypes as C
+    L = gpu.lib()
+    sets = []
+    for j in range(3):
+        bufs = [gpu.synth_host(sz, 100 * j + k, 1) for k, sz in enumerate([65536, 30000, 4096, 100, 65536, 0, 12345] * 40)]
+        n = len(bufs)
+        caps = [gpu.Zstd.compressBound(len(b)) for b in bufs]
+        srcs = [C.create_string_buffer(b, max(len(b), 1)) for b in bufs]; dsts = [C.create_string_buffer(c) for c in caps]
+        sp = (C.c_void_p * n)(*[C.addressof(x) for x in srcs]); dp = (C.c_void_p * n)(*[C.addressof(x) for x in dsts])
+        ss = (C.c_size_t * n)(*[len(b) for b in bufs]); dc = (C.c_size_t * n)(*caps); res = (C.c_size_t * n)()
+        sets.append((bufs, srcs, dsts, sp, dp, ss, dc, res, n))
+    jobs = [L.zjni_compress_batch_begin(s[3], s[5], s[4], s[6], s[7], s[8], 3, 1) for s in sets]          # three at once: two slots
+    assert all(jobs)
+    for j in jobs:
+        r = L.zjni_batch_finish(j); assert not L.zjni_isError(r), r
+    backs = []
+    for bufs, srcs, dsts, sp, dp, ss, dc, res, n in sets:
+        for k in range(n):
+            assert not L.zjni_isError(res[k]), (k, res[k])
+            assert dsts[k].raw[:res[k]] == oracle_ref.compress(bufs[k], 3, True), k
+        outs = [C.create_string_buffer(max(len(b), 1)) for b in bufs]
+        op = (C.c_void_p * n)(*[C.addressof(x) for x in outs]); oc = (C.c_size_t * n)(*[len(b) for b in bufs]); cs = (C.c_size_t * n)(*[res[k] for k in range(n)]); r2 = (C.c_size_t * n)()
+        backs.append((outs, op, oc, cs, r2))
+    jobs = [L.zjni_decompress_batch_begin(s[4], b[3], b[1], b[2], b[4], s[8]) for s, b in zip(sets, backs)]
+    assert all(jobs)
+    for j in jobs:
+        r = L.zjni_batch_finish(j); assert not L.zjni_isError(r), r
+    for (bufs, *_), (outs, op, oc, cs, r2) in zip(sets, backs):
+        for k, b in enumerate(bufs):
+            assert r2[k] == len(b) and outs[k].raw[:len(b)] == b, k

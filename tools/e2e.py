@@ -19,3 +19,25 @@ for it in range(reps + 1):
     if it: bc, bd = min(bc, t1 - t0), min(bd, t3 - t2)
 ok = all(res2[i] == size for i in range(n)) and bool((back == host).all())
 print(json.dumps({"threads": os.environ.get("ZJNI_HOST_THREADS", "default"), "compress_GiBps": n * size / 2**30 / bc, "decompress_GiBps": n * size / 2**30 / bd, "compress_ms": bc * 1e3, "decompress_ms": bd * 1e3, "roundtrip_exact": ok}))
+# two batches in flight (zjni_*_batch_begin / zjni_batch_finish, round 5): K batches, never more than two begun and unfinished
+if hasattr(L, "zjni_compress_batch_begin") and os.environ.get("E2E_PIPE", "1") != "0":
+    comp2 = np.empty(n * bound, dtype=np.uint8); back2 = np.empty(n * size, dtype=np.uint8)
+    cp2, bp2 = vp(comp2.ctypes.data, bound), vp(back2.ctypes.data, size)
+    rA, rB = (C.c_size_t * n)(), (C.c_size_t * n)(); sets = [(cp, rA), (cp2, rB)]
+    def pipe(begin, K):
+        jobs = []; t0 = time.perf_counter()
+        for k in range(K):
+            if len(jobs) == 2: r = L.zjni_batch_finish(jobs.pop(0)); assert not L.zjni_isError(r), r
+            j = begin(k & 1); assert j; jobs.append(j)
+        for j in jobs: r = L.zjni_batch_finish(j); assert not L.zjni_isError(r), r
+        return time.perf_counter() - t0
+    K = int(os.environ.get("E2E_BATCHES", "6"))
+    cb = lambda w: L.zjni_compress_batch_begin(sp, ss, sets[w][0], cc, sets[w][1], n, 3, 0)
+    pipe(cb, 2); tc = pipe(cb, K)
+    same = all(rA[i] == res[i] and rB[i] == res[i] for i in range(n)) and bool((comp2 == comp).all())
+    rd = [(C.c_size_t * n)(), (C.c_size_t * n)()]; outs = [bp, bp2]
+    db = lambda w: L.zjni_decompress_batch_begin(sets[w][0], cs, outs[w], ss, rd[w], n)
+    pipe(db, 2); td = pipe(db, K)
+    okp = all(rd[0][i] == size and rd[1][i] == size for i in range(n)) and bool((back2 == host).all())
+    print(json.dumps({"two_batches_in_flight": {"batches": K, "compress_GiBps": K * n * size / 2**30 / tc, "decompress_GiBps": K * n * size / 2**30 / td,
+                                                "compress_ms_per_batch": tc / K * 1e3, "decompress_ms_per_batch": td / K * 1e3, "same_frames": same, "roundtrip_exact": okp}}))

@@ -32,5 +32,26 @@ t0 = rows[last][0]
 for s, e, k in rows[last:last + 16]: print("  %-44s start %8.3f ms  end %8.3f ms  (%.3f)" % (k, (s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6))
 P
 rm -rf $OUT/kt_$v; }
+# ctrace <name> <cmd...>: kernels >= 1 ms and memory copies >= 1 ms of a command on one time axis (rocprofv3 --kernel-trace --memory-copy-trace)
+ctrace() { local n=$1; shift; echo "== copy + kernel timeline $n: $*"; (cd /tmp; export TMPDIR=/tmp; rm -rf $OUT/ct_$n; timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/ct_$n -o p -- "$@" > $OUT/ct_$n.log 2>&1); python3 - $OUT/ct_$n <<'P'
+import csv, sys, glob
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)): rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + r["Kernel_Name"].split("(")[0][:40]))
+for f in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)): rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C " + r.get("Direction", r.get("Name", "?"))[:40]))
+import os
+mn = float(os.environ.get("CT_MIN_MS", "1")) * 1e6; pat = os.environ.get("CT_GREP", "")
+rows = [r for r in rows if r[1] - r[0] >= mn and (not pat or any(p in r[2] for p in pat.split(",")))]; rows.sort()
+if rows:
+    t0 = rows[0][0]
+    win = os.environ.get("CT_AROUND", "")           # "name,first,last": the rows between the first-th and the last-th kernel of that name (counted from 0)
+    if win:
+        nm, a, b = win.split(","); hits = [r for r in rows if nm in r[2]]
+        if len(hits) > int(b): lo, hi = hits[int(a)][0] - 150000000, hits[int(b)][1] + 100000000; rows = [r for r in rows if lo <= r[0] <= hi]
+    else: rows = rows[-90:]
+    for s, e, k in rows: print("  %9.1f -> %9.1f ms (%7.1f)  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, k))
+P
+rm -rf $OUT/ct_$n; }
 { for step in "$@"; do eval "$step"; done; } > $OUT/$NAME.txt 2>&1
 cat $OUT/$NAME.txt

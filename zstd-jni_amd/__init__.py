@@ -100,6 +100,12 @@ def lib():
     L.zjni_compress_batch2.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int, C.c_int]
     L.zjni_compress2.restype = sz
     L.zjni_compress2.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int]
+    L.zjni_compress_batch_begin.restype = vp         # two host batches in flight (include/zjni_amd.h): begin returns a job, finish waits for it
+    L.zjni_compress_batch_begin.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz, C.c_int, C.c_int]
+    L.zjni_decompress_batch_begin.restype = vp
+    L.zjni_decompress_batch_begin.argtypes = [C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), sz]
+    L.zjni_batch_finish.restype = sz
+    L.zjni_batch_finish.argtypes = [vp]
     L.zjni_createDDict.restype = vp
     L.zjni_createDDict.argtypes = [vp, sz]
     L.zjni_freeDDict.restype = sz
@@ -197,7 +203,8 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
            "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
-           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists")
+           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists",
+           "zjni_compress_batch_begin", "zjni_decompress_batch_begin", "zjni_batch_finish")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

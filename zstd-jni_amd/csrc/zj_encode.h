@@ -9,13 +9,11 @@
 // N/compress/huf_compress.c (Huffman literals), N/compress/zstd_compress_sequences.c:157-382 +
 // N/compress/fse_compress.c (tANS sequences), N/compress/hist.c.     N/ = src/main/native/.
 //
-// Output contract: byte-identical to the reference's ZSTD_compress2 for levels 1 and 2 at every
-// size <= 128 KiB, and for level 3 whenever the level's tables fit the LDS budget (srcSize <= 8 KiB);
-// above that, level 3 runs the reference's double-fast with hashLog/chainLog = 14/13 — byte-identical
-// to the reference called with ZstdCompressCtx.setHashLog(14).setChainLog(13) (SURVEY.md Appendix B.2:
-// +0.44 % size on Silesia xml, inside the 1 % gate).  On the lane-per-frame path the tables live in HBM, so explicit
-// ZSTD_c_hashLog / ZSTD_c_chainLog (the "level word", ze_params_of) are honoured there: 16 / 15 gives the reference's plain
-// level 3.  With a dictionary (zj_cdict.h) frames are byte-identical to ZSTD_CCtx_refCDict + ZSTD_compress2.
+// Output contract: byte-identical to the reference's ZSTD_compress2 for levels 1-3 at every size the batch entries take, with the
+// reference's own table sizes for the input (level 3 at 64 KiB: hashLog / chainLog = 16 / 15, tables in HBM).  Explicit
+// ZSTD_c_hashLog / ZSTD_c_chainLog (the "level word", ze_params_of) are honoured at level 3 — 14 / 13 are the sizes the LDS-resident
+// finders of small batches are built for (byte-identical to ZstdCompressCtx.setHashLog(14).setChainLog(13); SURVEY.md Appendix B.2:
+// +0.44 % size on Silesia xml).  With a dictionary (zj_cdict.h) frames are byte-identical to ZSTD_CCtx_refCDict + ZSTD_compress2.
 //
 // LDS (fused small-batch kernel): the match-finder hash tables (position+1, u16 for buffers <= 64 KiB else u32) own the
 // LDS during match finding; the entropy stage (histograms, Huffman tree, tANS tables) overlays the same bytes

@@ -933,6 +933,26 @@ size_t enc_lds_pass0(int level) {
 }
 enum { ZJ_ROUTE_WAVE_HBM = ZJNI_ROUTE_WAVE_HBM, ZJ_ROUTE_FUSED = ZJNI_ROUTE_FUSED, ZJ_ROUTE_WAVE = ZJNI_ROUTE_WAVE, ZJ_ROUTE_LANE = ZJNI_ROUTE_LANE, ZJ_ROUTE_LANE_GATED = ZJNI_ROUTE_LANE_GATED,
        ZJ_ROUTE_RUN = ZJNI_ROUTE_RUN, ZJ_ROUTE_RUN_FLAGS = ZJNI_ROUTE_RUN_FLAGS, ZJ_ROUTE_HYBRID = ZJNI_ROUTE_HYBRID, ZJ_ROUTE_OTHER = ZJNI_ROUTE_OTHER };
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (4 by default), and a hardware queue runs its packets in order: a stream that shares
+// one with the stream of a 130 ms persistent kernel (the entropy kernel beside the match kernel, the match kernel itself) does not move until that kernel has left —
+// measured with two host batches in flight: the second batch's pack kernel and D2H copies waited 130 ms behind the first's entropy kernel (profiles/r05/e_).  This
+// library keeps up to ten streams busy at once (a caller's, three of its own per device, three per staging slot), so it asks for more queues — before the first
+// HIP call of a process that has not made one (the JVM's case: the JNI library is the only HIP user); a process that has set the variable keeps its value.
+static int const zj_more_hw_queues = []() { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+// The host-pointer entries stage a batch through pinned host memory and a device area of the same layout.  Round 5: TWO such slots per device, each with its own
+// streams and events, so that two host-pointer calls (two JVM threads in compressBatch0, or zjni_*_batch_begin twice) are in flight at once: while one call's kernels run,
+// the other's sources cross the link one way and a third's frames the other — the lane pipeline wants a whole batch resident, so the overlap a single compress call cannot
+// have (H2D 75 + kernels 143 + D2H 35 ms in sequence on the metric batch) comes from the next call.  The kernels of the two calls still follow each other (BatchOrder: they
+// share the per-device scratch).  A third concurrent call waits for a slot.
+#define ZJ_STAGE_SLOTS 2
+struct StageSlot {
+    std::mutex mu;
+    u8* hPinned = nullptr; size_t hPinnedCap = 0;
+    u8* dStage = nullptr; size_t dStageCap = 0;
+    hipStream_t hostIn = nullptr, hostK = nullptr, hostOut = nullptr;       // H2D / kernels / D2H (the decompress entry runs slices of one call on all three at once: PCIe is full duplex)
+    std::vector<hipEvent_t> stageEv;                  // one event per returned slice (compress)
+    std::vector<hipEvent_t> pipeEv;                   // three events per slice: source landed, decoded, returned (decompress)
+};
 struct DevState {
     bool needLdsSet = false;                      // zj_enc_need_kernel's LDS attribute has been set on this device
     int lastRoute = 0;                            // ZJNI_ROUTE_* of the last large compress call (zjni_last_route)
@@ -944,9 +964,9 @@ struct DevState {
     int encGridSmall = 0;                  // entropy stage with small frames staged in LDS (ZE_SMALL_LDS_BYTES)
     // dictionary compress: slice s's entropy kernel (side stream) runs beside slice s+1's match kernel; two sets of records / lists / counters
     u8* wideBuf = nullptr; size_t wideBufCap = 0;     // lane-per-frame path of list B: [tables][frame scratch][meta] for one slice
-    std::vector<hipEvent_t> stageEv;                  // host-pointer entries: one event per returned slice
-    hipStream_t hostIn = nullptr, hostK = nullptr, hostOut = nullptr;       // host-pointer decompress: H2D / kernels / D2H of different slices at the same time (PCIe is full duplex)
-    std::vector<hipEvent_t> pipeEv;                   // three events per slice: source landed, decoded, returned
+    StageSlot* slot[ZJ_STAGE_SLOTS] = {};             // host-pointer entries: their staging areas, streams and events (below)
+    std::atomic<unsigned>* slotTicket = nullptr;
+    std::mutex* hostDecompMu = nullptr;
     u32* multiTables = nullptr; int multiGrid = 0;    // multi-block frames: frame-wide hash tables, one set per resident workgroup
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
@@ -974,12 +994,9 @@ struct DevState {
     // batch calls share the per-device scratch: they are enqueued under `enqueueMu`, and each call's kernels wait (on the
     // GPU) for the previous call's last kernel, whatever streams the callers use — many host threads may call at once
     std::mutex* enqueueMu = nullptr; hipEvent_t lastDone = nullptr; bool lastValid = false;
-    std::mutex* stageMu = nullptr;                    // users of this device's host staging area (host-pointer entries)   // entropy stage beside the match kernel
     u8* dsplitBuf = nullptr; size_t dsplitBufCap = 0;  // [tables][sequences][frame records][list A][list B]
     u8* dlitBuf = nullptr; size_t dlitBufCap = 0;      // literal slots of the split decode pipeline (stage 2b), one per frame of a slice
     u8* dmbBuf = nullptr; size_t dmbBufCap = 0;        // multi-block frames on the split pipeline: [block tables][blocks][frames][seq list][list M][record pool]
-    u8* hPinned = nullptr; size_t hPinnedCap = 0;
-    u8* dStage = nullptr; size_t dStageCap = 0;
 };
 std::mutex g_mu;        // guards g_dev
 std::vector<DevState> g_dev;
@@ -1031,7 +1048,8 @@ DevState* get_state(int ordinal) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
-        d.enqueueMu = new std::mutex(); d.stageMu = new std::mutex();
+        d.enqueueMu = new std::mutex(); d.slotTicket = new std::atomic<unsigned>(0); d.hostDecompMu = new std::mutex();
+        for (int k = 0; k < ZJ_STAGE_SLOTS; k++) d.slot[k] = new StageSlot();
         if (hipEventCreateWithFlags(&d.lastDone, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&d.sideStream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -1095,7 +1113,11 @@ size_t scratch_slice(size_t perFrame, size_t dflt, size_t shareDiv) {
     return f < 4096 ? 4096 : (f < dflt ? f : dflt);
 }
 
-bool ensure_staging(DevState* d, size_t bytes) {
+bool ensure_staging(StageSlot* d, size_t bytes) {
+    if (!d->hostK) {
+        if (hipStreamCreateWithFlags(&d->hostIn, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->hostK, hipStreamNonBlocking) != hipSuccess
+            || hipStreamCreateWithFlags(&d->hostOut, hipStreamNonBlocking) != hipSuccess) { d->hostIn = d->hostK = d->hostOut = nullptr; return false; }
+    }
     if (d->hPinnedCap < bytes) {
         if (d->hPinned) (void)hipHostFree(d->hPinned);
         if (d->dStage) (void)hipFree(d->dStage);
@@ -1107,6 +1129,16 @@ bool ensure_staging(DevState* d, size_t bytes) {
     }
     return true;
 }
+// a free slot of the device, or the next one in turn when both are taken (held until the guard goes)
+struct SlotLock {
+    StageSlot* s = nullptr;
+    explicit SlotLock(DevState* d) {
+        for (int k = 0; k < ZJ_STAGE_SLOTS && !s; k++) if (d->slot[k]->mu.try_lock()) s = d->slot[k];
+        if (!s) { s = d->slot[d->slotTicket->fetch_add(1u) % ZJ_STAGE_SLOTS]; s->mu.lock(); }
+    }
+    ~SlotLock() { if (s) s->mu.unlock(); }
+    SlotLock(const SlotLock&) = delete; SlotLock& operator=(const SlotLock&) = delete;
+};
 // Host-side copies of the host-pointer entries (caller's buffers <-> pinned staging) run on a few threads: one memcpy stream moves
 // ~10 GB/s, the PCIe link 57 each way — every byte of a batch is copied once by the host on each side, so these copies, not the link,
 // bound the entries unless enough threads share them.  Default: the CPUs this process may really use (scheduler affinity and the cgroup
@@ -1177,12 +1209,15 @@ void zjni_shutdown(void) {
         for (int p = 0; p < 2; p++) { if (d.cdMatchDone[p]) (void)hipEventDestroy(d.cdMatchDone[p]); if (d.cdEncDone[p]) (void)hipEventDestroy(d.cdEncDone[p]); }
         if (d.sideStream) { (void)hipStreamDestroy(d.sideStream); (void)hipEventDestroy(d.evFork); (void)hipEventDestroy(d.evJoin); }
         if (d.clearStream) { (void)hipStreamDestroy(d.clearStream); (void)hipEventDestroy(d.evMatchDone); (void)hipEventDestroy(d.evCleared); }
-        if (d.hostIn) { (void)hipStreamDestroy(d.hostIn); (void)hipStreamDestroy(d.hostK); (void)hipStreamDestroy(d.hostOut); d.hostIn = d.hostK = d.hostOut = nullptr; }
-        for (hipEvent_t e : d.pipeEv) if (e) (void)hipEventDestroy(e);
-        d.pipeEv.clear();
+        for (int k = 0; k < ZJ_STAGE_SLOTS; k++) if (StageSlot* const sl = d.slot[k]) {
+            if (sl->hostIn) { (void)hipStreamDestroy(sl->hostIn); (void)hipStreamDestroy(sl->hostK); (void)hipStreamDestroy(sl->hostOut); }
+            for (hipEvent_t e : sl->pipeEv) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : sl->stageEv) if (e) (void)hipEventDestroy(e);
+            if (sl->hPinned) (void)hipHostFree(sl->hPinned);
+            if (sl->dStage) (void)hipFree(sl->dStage);
+            delete sl;
+        }
         if (d.waveStream) { (void)hipStreamDestroy(d.waveStream); (void)hipEventDestroy(d.evJoinWave); }
-        if (d.hPinned) (void)hipHostFree(d.hPinned);
-        if (d.dStage) (void)hipFree(d.dStage);
         d = DevState();
     }
 }
@@ -2095,23 +2130,24 @@ size_t zjni_compress_stream(void* dst, size_t dstCap, const void* src, size_t sr
     // staging layout: [srcOff 2][dstOff 2][result 1][flushOff 2][mode (4 bytes, padded to 8)][flush positions][src][dst]
     size_t const oSrcOff = 0, oDstOff = 16, oRes = 32, oFOff = 40, oMode = 56, oFlush = 64, oSrc = (oFlush + 4 * nFlush + 15) & ~(size_t)15, oDst = (oSrc + srcSize + 15) & ~(size_t)15;
     size_t const total = oDst + cap + 16;
-    std::lock_guard<std::mutex> lk(*d->stageMu);
-    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);
-    struct Drain { ~Drain() { (void)hipStreamSynchronize(0); } } drainOnExit;
-    u64* const h = (u64*)d->hPinned;
-    h[0] = 0; h[1] = srcSize; h[2] = 0; h[3] = cap; h[4] = 0; h[5] = 0; h[6] = nFlush; ((u32*)(d->hPinned + oMode))[0] = (final_ ? 1u : 0u) | (knownEmpty ? 2u : 0u); ((u32*)(d->hPinned + oMode))[1] = 0;
-    if (nFlush) memcpy(d->hPinned + oFlush, flushAt, 4 * nFlush);
-    if (srcSize) memcpy(d->hPinned + oSrc, src, srcSize);
-    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc + srcSize, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    size_t const r = zjni_compress_stream_batch_device(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff), (u64*)(d->dStage + oRes), 1, level, checksum,
-                                                       (const u32*)(d->dStage + oFlush), (const u64*)(d->dStage + oFOff), (const u32*)(d->dStage + oMode), nullptr);
+    SlotLock slotLock(d); StageSlot* const sl = slotLock.s;
+    if (!ensure_staging(sl, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);
+    hipStream_t const hst = sl->hostK;
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drainOnExit{hst};
+    u64* const h = (u64*)sl->hPinned;
+    h[0] = 0; h[1] = srcSize; h[2] = 0; h[3] = cap; h[4] = 0; h[5] = 0; h[6] = nFlush; ((u32*)(sl->hPinned + oMode))[0] = (final_ ? 1u : 0u) | (knownEmpty ? 2u : 0u); ((u32*)(sl->hPinned + oMode))[1] = 0;
+    if (nFlush) memcpy(sl->hPinned + oFlush, flushAt, 4 * nFlush);
+    if (srcSize) memcpy(sl->hPinned + oSrc, src, srcSize);
+    if (hipMemcpyAsync(sl->dStage, sl->hPinned, oSrc + srcSize, hipMemcpyHostToDevice, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    size_t const r = zjni_compress_stream_batch_device(sl->dStage + oSrc, (const u64*)(sl->dStage + oSrcOff), sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff), (u64*)(sl->dStage + oRes), 1, level, checksum,
+                                                       (const u32*)(sl->dStage + oFlush), (const u64*)(sl->dStage + oFOff), (const u32*)(sl->dStage + oMode), hst);
     if (zjni_isError(r)) return r;
-    if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, 8, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (hipMemcpyAsync(sl->hPinned + oRes, sl->dStage + oRes, 8, hipMemcpyDeviceToHost, hst) != hipSuccess || hipStreamSynchronize(hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     size_t const out = (size_t)h[4];
     if (zjni_isError(out) || out == 0) return out;
     if (out > cap) return ZJNI_ERR(70);
-    if (hipMemcpyAsync(d->hPinned + oDst, d->dStage + oDst, out, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    memcpy(dst, d->hPinned + oDst, out);
+    if (hipMemcpyAsync(sl->hPinned + oDst, sl->dStage + oDst, out, hipMemcpyDeviceToHost, hst) != hipSuccess || hipStreamSynchronize(hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    memcpy(dst, sl->hPinned + oDst, out);
     return out;
 }
 // ZstdCompressCtx.setHashLog / setChainLog (ZSTD_c_hashLog / ZSTD_c_chainLog; 0 = the library's choice) on top of level + checksum.
@@ -2300,12 +2336,15 @@ size_t zjni_frame_extent(const void* srcv, size_t srcSize, unsigned long long* c
 // link one way and slice k - 1's output the other (PCIe: 57 GB/s each way alone, 2 x 49 at once on this box: tools/micro/pcie.py), and the host
 // threads gather / scatter the slices on either side.  The first slice is small (its transfer and kernels are the pipeline's lead-in), the others
 // large enough for the lane-per-frame sequence decode, whose time is its longest frame's chain whatever the slice size.
-static size_t host_decompress_locked(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+static size_t host_decompress_locked(DevState* d, StageSlot* sl, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
                                      const zjni_ddict* ddict, bool exactCaps);
 static size_t host_decompress(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
                               const zjni_ddict* ddict) {
-    std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
-    size_t const r = host_decompress_locked(d, src, srcSize, dst, dstCap, result, n, ddict, false);
+    // One host-pointer DECOMPRESS at a time per device: the call is a three-stream pipeline over its own slices already, at the link's and the host threads' limit; a second one
+    // beside it only shares both (measured: 41 GiB/s one after the other, 27 with two in flight, profiles/r05/e_).  It still runs beside a compress call's kernels.
+    std::lock_guard<std::mutex> oneDecompress(*d->hostDecompMu);
+    SlotLock slotLock(d);                         // one of the device's staging slots, for both passes
+    size_t const r = host_decompress_locked(d, slotLock.s, src, srcSize, dst, dstCap, result, n, ddict, false);
     if (zjni_isError(r)) return r;
     // A frame that was given its header's content size as capacity and overran it is damaged; the reference, decoding into the caller's larger
     // buffer, goes on to the frame's end and answers from there (usually corruption_detected, not dstSize_tooSmall): those few again, with the caller's capacity
@@ -2315,18 +2354,14 @@ static size_t host_decompress(DevState* d, const void* const* src, const size_t*
     size_t const m = again.size();
     std::vector<const void*> s2(m); std::vector<size_t> z2(m), c2(m), r2(m); std::vector<void*> d2(m);
     for (size_t j = 0; j < m; j++) { size_t const i = again[j]; s2[j] = src[i]; z2[j] = srcSize[i]; d2[j] = dst[i]; c2[j] = dstCap[i]; }
-    size_t const rr = host_decompress_locked(d, s2.data(), z2.data(), d2.data(), c2.data(), r2.data(), m, ddict, true);
+    size_t const rr = host_decompress_locked(d, slotLock.s, s2.data(), z2.data(), d2.data(), c2.data(), r2.data(), m, ddict, true);
     if (zjni_isError(rr)) return rr;
     for (size_t j = 0; j < m; j++) result[again[j]] = r2[j];
     return 0;
 }
-static size_t host_decompress_locked(DevState* d, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
+static size_t host_decompress_locked(DevState* d, StageSlot* sl, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n,
                                      const zjni_ddict* ddict, bool exactCaps) {
     size_t const offBytes = (n + 1) * 8;
-    if (!d->hostIn) {
-        if (hipStreamCreateWithFlags(&d->hostIn, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->hostK, hipStreamNonBlocking) != hipSuccess
-            || hipStreamCreateWithFlags(&d->hostOut, hipStreamNonBlocking) != hipSuccess) { d->hostIn = d->hostK = d->hostOut = nullptr; return ZJNI_ERR(ZJNI_ERROR_no_device); }
-    }
     // what each buffer needs on the device: the frame's own content size when the buffer is exactly one frame that says it, else the caller's capacity
     std::vector<u64> need(n + 1, 0), srcAt(n + 1, 0);
     {   std::vector<u64> idx(n + 1); for (size_t i = 0; i <= n; i++) idx[i] = i;
@@ -2342,20 +2377,20 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
     // staging layout: [srcOff][dstOff][result][src blob][dst blob]
     size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oSrc = 3 * offBytes, oDst = (oSrc + (size_t)srcTotal + 15) & ~(size_t)15;
     size_t const total = oDst + (size_t)dstTotal + 16;
-    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);      // no room to stage this batch: the caller's CPU path takes it
-    u64* const hs = (u64*)(d->hPinned + oSrcOff); u64* const hd = (u64*)(d->hPinned + oDstOff); const u64* const hr = (const u64*)(d->hPinned + oRes);
+    if (!ensure_staging(sl, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);      // no room to stage this batch: the caller's CPU path takes it
+    u64* const hs = (u64*)(sl->hPinned + oSrcOff); u64* const hd = (u64*)(sl->hPinned + oDstOff); const u64* const hr = (const u64*)(sl->hPinned + oRes);
     memcpy(hs, srcAt.data(), offBytes); memcpy(hd, need.data(), offBytes);
-    u8* const hSrc = d->hPinned + oSrc; u8* const hDst = d->hPinned + oDst;
+    u8* const hSrc = sl->hPinned + oSrc; u8* const hDst = sl->hPinned + oDst;
     // slices by destination bytes: a small first one, then up to eight of at least ZJ_HOST_SLICE
     std::vector<size_t> cuts; cuts.push_back(0);
     {   u64 const big = dstTotal / 8 > ZJ_HOST_SLICE ? dstTotal / 8 : ZJ_HOST_SLICE; u64 target = big / 4;
         for (size_t lo = 0; lo < n;) { size_t hi = lo + 1; while (hi < n && hd[hi] - hd[lo] < target) hi++; cuts.push_back(hi); lo = hi; target = big; } }
     size_t const nSlices = cuts.size() - 1;
-    if (d->pipeEv.size() < 3 * nSlices) {
-        size_t const have = d->pipeEv.size(); d->pipeEv.resize(3 * nSlices, nullptr);
-        for (size_t k = have; k < 3 * nSlices; k++) if (hipEventCreateWithFlags(&d->pipeEv[k], hipEventDisableTiming) != hipSuccess) { d->pipeEv.resize(k); return ZJNI_ERR(ZJNI_ERROR_no_device); }
+    if (sl->pipeEv.size() < 3 * nSlices) {
+        size_t const have = sl->pipeEv.size(); sl->pipeEv.resize(3 * nSlices, nullptr);
+        for (size_t k = have; k < 3 * nSlices; k++) if (hipEventCreateWithFlags(&sl->pipeEv[k], hipEventDisableTiming) != hipSuccess) { sl->pipeEv.resize(k); return ZJNI_ERR(ZJNI_ERROR_no_device); }
     }
-    auto drain = [&](size_t code) { (void)hipStreamSynchronize(d->hostIn); (void)hipStreamSynchronize(d->hostK); (void)hipStreamSynchronize(d->hostOut); return code; };   // nothing of ours in flight when the staging lock drops
+    auto drain = [&](size_t code) { (void)hipStreamSynchronize(sl->hostIn); (void)hipStreamSynchronize(sl->hostK); (void)hipStreamSynchronize(sl->hostOut); return code; };   // nothing of ours in flight when the staging lock drops
     int const T = host_threads();
     std::atomic<bool> gathering(true);               // while the sources are still being gathered the two sides share the host's threads
     auto scatter = [&](size_t lo, size_t hi) {
@@ -2373,7 +2408,7 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
         (void)hipSetDevice(d->ordinal);
         for (size_t k = 0; k < nSlices; k++) {
             {   std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&] { return enqueued > k || failed.load(); }); if (enqueued <= k) return; }
-            if (hipEventSynchronize(d->pipeEv[3 * k + 2]) != hipSuccess) { failed.store(true); return; }
+            if (hipEventSynchronize(sl->pipeEv[3 * k + 2]) != hipSuccess) { failed.store(true); return; }
             scatter(cuts[k], cuts[k + 1]);
         }
     };
@@ -2382,20 +2417,20 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
     bool const threaded = returner.joinable();
     struct Joiner { std::thread& t; std::atomic<bool>& f; std::mutex& m; std::condition_variable& cv; bool ok = false;
                     ~Joiner() { if (!ok) { std::lock_guard<std::mutex> g(m); f.store(true); } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{returner, failed, qm, qcv};
-    if (hipMemcpyAsync(d->dStage, d->hPinned, 2 * offBytes, hipMemcpyHostToDevice, d->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+    if (hipMemcpyAsync(sl->dStage, sl->hPinned, 2 * offBytes, hipMemcpyHostToDevice, sl->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
     for (size_t k = 0; k < nSlices; k++) {
         size_t const lo = cuts[k], hi = cuts[k + 1];
-        hipEvent_t const evIn = d->pipeEv[3 * k], evK = d->pipeEv[3 * k + 1], evOut = d->pipeEv[3 * k + 2];
+        hipEvent_t const evIn = sl->pipeEv[3 * k], evK = sl->pipeEv[3 * k + 1], evOut = sl->pipeEv[3 * k + 2];
         par_ranges(hs + lo, hi - lo, [&](size_t a0, size_t a1) { for (size_t i = lo + a0; i < lo + a1; i++) if (srcSize[i]) memcpy(hSrc + hs[i], src[i], srcSize[i]); }, k == 0 ? T : (T + 1) / 2);
-        if (hs[hi] > hs[lo] && hipMemcpyAsync(d->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, d->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        if (hipEventRecord(evIn, d->hostIn) != hipSuccess || hipStreamWaitEvent(d->hostK, evIn, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        size_t const r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff) + lo, d->dStage + oDst, (const u64*)(d->dStage + oDstOff) + lo,
-                                                                 (u64*)(d->dStage + oRes) + lo, hi - lo, ddict, d->hostK);
+        if (hs[hi] > hs[lo] && hipMemcpyAsync(sl->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, sl->hostIn) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipEventRecord(evIn, sl->hostIn) != hipSuccess || hipStreamWaitEvent(sl->hostK, evIn, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        size_t const r = zjni_decompress_batch_device_usingDDict(sl->dStage + oSrc, (const u64*)(sl->dStage + oSrcOff) + lo, sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff) + lo,
+                                                                 (u64*)(sl->dStage + oRes) + lo, hi - lo, ddict, sl->hostK);
         if (zjni_isError(r)) return drain(r);
-        if (hipEventRecord(evK, d->hostK) != hipSuccess || hipStreamWaitEvent(d->hostOut, evK, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        if (hipMemcpyAsync(d->hPinned + oRes + lo * 8, d->dStage + oRes + lo * 8, (hi - lo) * 8, hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        if (hd[hi] > hd[lo] && hipMemcpyAsync(hDst + hd[lo], d->dStage + oDst + hd[lo], (size_t)(hd[hi] - hd[lo]), hipMemcpyDeviceToHost, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
-        if (hipEventRecord(evOut, d->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipEventRecord(evK, sl->hostK) != hipSuccess || hipStreamWaitEvent(sl->hostOut, evK, 0) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipMemcpyAsync(sl->hPinned + oRes + lo * 8, sl->dStage + oRes + lo * 8, (hi - lo) * 8, hipMemcpyDeviceToHost, sl->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hd[hi] > hd[lo] && hipMemcpyAsync(hDst + hd[lo], sl->dStage + oDst + hd[lo], (size_t)(hd[hi] - hd[lo]), hipMemcpyDeviceToHost, sl->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
+        if (hipEventRecord(evOut, sl->hostOut) != hipSuccess) return drain(ZJNI_ERR(ZJNI_ERROR_no_device));
         {   std::lock_guard<std::mutex> g(qm); enqueued = k + 1; }
         qcv.notify_all();
     }
@@ -2407,6 +2442,13 @@ static size_t host_decompress_locked(DevState* d, const void* const* src, const 
 }
 
 // ---- host-pointer batches: pack -> H2D -> kernel -> D2H -> scatter ------------------------------
+// ZJNI_HOST_TRACE=1: the phases of a host-pointer compress call on stderr, milliseconds since the process's first one (two calls in flight: which phase waits for what)
+static void host_trace(const void* job, const char* what) {
+    static bool const on = zj_env("ZJNI_HOST_TRACE") != nullptr;
+    if (!on) return;
+    static auto const t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[zjni host %p] %8.1f ms  %s\n", job, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 static size_t host_batch(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
                          size_t* result, size_t n, int level, int checksum = 0, const zjni_ddict* ddict = nullptr, const zjni_cdict* cdict = nullptr) {
     DevState* d = cur_state();
@@ -2425,66 +2467,73 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
     size_t const oSrcOff = 0, oDstOff = offBytes, oRes = 2 * offBytes, oPOff = 3 * offBytes, oSrc = 4 * offBytes, oDst = (oSrc + srcTotal + 15) & ~(size_t)15;
     size_t const oPack = (oDst + dstTotal + 15) & ~(size_t)15;
     size_t const total = oPack + (compress ? dstTotal : 0) + 16;
-    std::lock_guard<std::mutex> lk(*d->stageMu);  // one staging area per device
-    if (!ensure_staging(d, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);      // no room to stage this batch: the caller's CPU path takes it
-    struct Drain { ~Drain() { (void)hipStreamSynchronize(0); } } drainOnExit;     // error returns below leave copies in flight on the staging area: none when the lock drops
-    u64* hs = (u64*)(d->hPinned + oSrcOff); u64* hd = (u64*)(d->hPinned + oDstOff); u64* hp = (u64*)(d->hPinned + oPOff);
+    host_trace(result, "call");
+    SlotLock slotLock(d); StageSlot* const sl = slotLock.s;      // one of the device's staging slots: a second caller stages and copies while this one's kernels run
+    if (!ensure_staging(sl, total)) return ZJNI_ERR(ZJNI_ERROR_unsupported);     // no room to stage this batch: the caller's CPU path takes it
+    hipStream_t const hst = sl->hostK;            // everything of this call in order on the slot's own stream
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drainOnExit{hst};     // error returns below leave copies in flight on the staging area: none when the slot is given back
+    u64* hs = (u64*)(sl->hPinned + oSrcOff); u64* hd = (u64*)(sl->hPinned + oDstOff); u64* hp = (u64*)(sl->hPinned + oPOff);
     size_t a = 0, b = 0;
     for (size_t i = 0; i < n; i++) { hs[i] = a; hd[i] = b; a += srcSize[i]; b += dstCap[i]; }
     hs[n] = a; hd[n] = b;
-    u8* const hSrc = d->hPinned + oSrc;
+    u8* const hSrc = sl->hPinned + oSrc;
     // in slices of ~256 MiB: while the link carries slice k the host threads gather slice k + 1 into the pinned area
-    if (hipMemcpyAsync(d->dStage, d->hPinned, oSrc, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (hipMemcpyAsync(sl->dStage, sl->hPinned, oSrc, hipMemcpyHostToDevice, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     for (size_t lo = 0; lo < n;) {
         size_t hi = lo + 1; while (hi < n && hs[hi] - hs[lo] < ZJ_HOST_SLICE) hi++;
         par_ranges(hs + lo, hi - lo, [&](size_t a0, size_t a1) { for (size_t i = lo + a0; i < lo + a1; i++) if (srcSize[i]) memcpy(hSrc + hs[i], src[i], srcSize[i]); });
-        if (hs[hi] > hs[lo] && hipMemcpyAsync(d->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hs[hi] > hs[lo] && hipMemcpyAsync(sl->dStage + oSrc + hs[lo], hSrc + hs[lo], (size_t)(hs[hi] - hs[lo]), hipMemcpyHostToDevice, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         lo = hi;
     }
+    host_trace(result, "sources gathered, H2D enqueued");
     size_t r;
     if (compress && cdict)
-        r = zjni_compress_batch_device_usingCDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                                                  (u64*)(d->dStage + oRes), n, cdict, checksum, nullptr);
+        r = zjni_compress_batch_device_usingCDict(sl->dStage + oSrc, (const u64*)(sl->dStage + oSrcOff), sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff),
+                                                  (u64*)(sl->dStage + oRes), n, cdict, checksum, hst);
     else if (compress)                             // `level` may be a level word (zjni_compress_batch_advanced)
-        r = compress_chunked(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                             (u64*)(d->dStage + oRes), n, level, zj_frame_flags(checksum), nullptr);
+        r = compress_chunked(sl->dStage + oSrc, (const u64*)(sl->dStage + oSrcOff), sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff),
+                             (u64*)(sl->dStage + oRes), n, level, zj_frame_flags(checksum), hst);
     else
-        r = zjni_decompress_batch_device_usingDDict(d->dStage + oSrc, (const u64*)(d->dStage + oSrcOff), d->dStage + oDst, (const u64*)(d->dStage + oDstOff),
-                                                    (u64*)(d->dStage + oRes), n, ddict, nullptr);
+        r = zjni_decompress_batch_device_usingDDict(sl->dStage + oSrc, (const u64*)(sl->dStage + oSrcOff), sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff),
+                                                    (u64*)(sl->dStage + oRes), n, ddict, hst);
     if (zjni_isError(r)) return r;
-    if (hipMemcpyAsync(d->hPinned + oRes, d->dStage + oRes, n * 8, hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-    const u64* hr = (const u64*)(d->hPinned + oRes);
+    host_trace(result, "kernels enqueued");
+    if (hipMemcpyAsync(sl->hPinned + oRes, sl->dStage + oRes, n * 8, hipMemcpyDeviceToHost, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    const u64* hr = (const u64*)(sl->hPinned + oRes);
     const u64* from = hd;                              // where frame i's bytes start inside the returned blob
     if (compress) {
         // the destinations are compressBound-sized: pack the frames on the device and bring back only their bytes
-        if (hipStreamSynchronize(0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipStreamSynchronize(hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        host_trace(result, "kernels done");
         u64 acc = 0;
         for (size_t i = 0; i < n; i++) { hp[i] = acc; if (!zjni_isError((size_t)hr[i])) acc += hr[i]; }
         hp[n] = acc;
-        if (hipMemcpyAsync(d->dStage + oPOff, hp, offBytes, hipMemcpyHostToDevice, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        size_t const pr = zjni_pack_batch_device(d->dStage + oDst, (const u64*)(d->dStage + oDstOff), (const u64*)(d->dStage + oRes),
-                                                 d->dStage + oPack, (const u64*)(d->dStage + oPOff), n, nullptr);
+        if (hipMemcpyAsync(sl->dStage + oPOff, hp, offBytes, hipMemcpyHostToDevice, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        size_t const pr = zjni_pack_batch_device(sl->dStage + oDst, (const u64*)(sl->dStage + oDstOff), (const u64*)(sl->dStage + oRes),
+                                                 sl->dStage + oPack, (const u64*)(sl->dStage + oPOff), n, hst);
         if (zjni_isError(pr)) return pr;
         from = hp;
     }
     // the way back in slices too: the host threads scatter slice k into the caller's buffers while the link carries slice k + 1
-    u8* const dOut = d->dStage + (compress ? oPack : oDst);
-    u8* const hDst = d->hPinned + oDst;
+    u8* const dOut = sl->dStage + (compress ? oPack : oDst);
+    u8* const hDst = sl->hPinned + oDst;
     std::vector<size_t> cuts; cuts.push_back(0);
     for (size_t lo = 0; lo < n;) { size_t hi = lo + 1; while (hi < n && from[hi] - from[lo] < ZJ_HOST_SLICE) hi++; cuts.push_back(hi); lo = hi; }
     size_t const nSlices = cuts.size() - 1;
-    if (d->stageEv.size() < nSlices) {
-        size_t const have = d->stageEv.size(); d->stageEv.resize(nSlices, nullptr);
-        for (size_t k = have; k < nSlices; k++) if (hipEventCreateWithFlags(&d->stageEv[k], hipEventDisableTiming) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (sl->stageEv.size() < nSlices) {
+        size_t const have = sl->stageEv.size(); sl->stageEv.resize(nSlices, nullptr);
+        for (size_t k = have; k < nSlices; k++) if (hipEventCreateWithFlags(&sl->stageEv[k], hipEventDisableTiming) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     }
     for (size_t k = 0; k < nSlices; k++) {
         size_t const lo = cuts[k], hi = cuts[k + 1];
-        if (from[hi] > from[lo] && hipMemcpyAsync(hDst + from[lo], dOut + from[lo], (size_t)(from[hi] - from[lo]), hipMemcpyDeviceToHost, 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
-        if (hipEventRecord(d->stageEv[k], 0) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (from[hi] > from[lo] && hipMemcpyAsync(hDst + from[lo], dOut + from[lo], (size_t)(from[hi] - from[lo]), hipMemcpyDeviceToHost, hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipEventRecord(sl->stageEv[k], hst) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     }
+    host_trace(result, "D2H enqueued");
     for (size_t k = 0; k < nSlices; k++) {
         size_t const lo = cuts[k], hi = cuts[k + 1];
-        if (hipEventSynchronize(d->stageEv[k]) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (hipEventSynchronize(sl->stageEv[k]) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
+        if (k + 1 == nSlices) host_trace(result, "last slice back");
         par_ranges(from + lo, hi - lo, [&](size_t a0, size_t a1) {
             for (size_t i = lo + a0; i < lo + a1; i++) {
                 result[i] = (size_t)hr[i];
@@ -2492,11 +2541,43 @@ static size_t host_batch(bool compress, const void* const* src, const size_t* sr
             }
         });
     }
+    host_trace(result, "scattered: done");
     return 0;
 }
 
 size_t zjni_decompress_batch(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n) {
     return host_batch(false, src, srcSize, dst, dstCap, result, n, 0);
+}
+
+// ---- asynchronous host batches (include/zjni_amd.h: two in flight through the device's two staging slots) ----
+struct zjni_batch_job { std::thread worker; size_t code = 0; };
+static zjni_batch_job* batch_begin(bool compress, const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap,
+                                   size_t* result, size_t n, int level, int checksum) {
+    DevState* d = cur_state();
+    if (!d) return nullptr;
+    int const ordinal = d->ordinal;
+    zjni_batch_job* job = new (std::nothrow) zjni_batch_job();
+    if (!job) return nullptr;
+    try {
+        job->worker = std::thread([=]() {
+            if (zjni_init(ordinal) != 0) { job->code = ZJNI_ERR(ZJNI_ERROR_no_device); return; }      // binds the worker to the caller's device
+            job->code = compress ? zjni_compress_batch2(src, srcSize, dst, dstCap, result, n, level, checksum) : zjni_decompress_batch(src, srcSize, dst, dstCap, result, n);
+        });
+    } catch (const std::system_error&) { delete job; return nullptr; }
+    return job;
+}
+zjni_batch_job* zjni_compress_batch_begin(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n, int level, int checksum) {
+    return batch_begin(true, src, srcSize, dst, dstCap, result, n, level, checksum);
+}
+zjni_batch_job* zjni_decompress_batch_begin(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCap, size_t* result, size_t n) {
+    return batch_begin(false, src, srcSize, dst, dstCap, result, n, 0, 0);
+}
+size_t zjni_batch_finish(zjni_batch_job* job) {
+    if (!job) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (job->worker.joinable()) job->worker.join();
+    size_t const code = job->code;
+    delete job;
+    return code;
 }
 
 // ---- one host batch over several devices of this process (SURVEY.md section 8e at the boundary a JVM has: one process) ----
