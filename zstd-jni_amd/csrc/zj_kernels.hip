@@ -104,6 +104,14 @@ __device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u
     u32 const slot = atomicAdd(doneCount, 1u);
     __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the queue entry alone, behind a release fence the caller has made for several lanes at once (zj_match_run)
+__device__ __forceinline__ void zj_queue_done(u32* doneList, u32* doneCount, u32 k) {
+    u32 const slot = atomicAdd(doneCount, 1u);
+    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifndef ZJ_HAND_ROUNDS
+#define ZJ_HAND_ROUNDS 256u      /* rounds between a match wave's hand-overs to the entropy kernel (a power of two; 32: -5 %, 256: -7 %, 2048: -2 % of the level-3 match kernel against a fence per frame, profiles/r05/f_) */
+#endif
 // Multi-block frames (zj_decode_split.h, "multi-block frames"): what stage 1 claims from — mb.ctr[0] blocks, [1] entries of seqList, [2] entries of listM, [4..5] records of the pool (64 bit)
 struct ZDMbArgs { ZDFrameMB* frames; ZDBlk* blks; u16* tabs; u32* ctr; u32 blkCap; u32 minBlocks; unsigned long long seqCap; u32* seqList; u32* listM; unsigned long long litCap; u32* litList; };      // ctr: ... [8] lit list, [10..11] literal pool bytes (64 bit), [12] work of the literal pass
 template <bool DICT>
@@ -361,6 +369,10 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
     u64 const zlWaveT0 = __builtin_readcyclecounter(); u64 zlRounds = 0; u64 const zlWall0 = wall_clock64();
 #endif
     u32 have = 0, pend = 0, late = 0; u32 k = 0; u64 tPend = 0;          // (per-lane flags as 0 / 1 in vector registers: a loop-carried bool is a lane mask and every divergent assignment three scalar instructions)
+    // Finished frames go to the entropy kernel's queue at the WAVE's hand-overs, every ZJ_HAND_ROUNDS rounds, behind ONE release fence for all lanes that finished since
+    // (round 5).  On this part an agent-scope release writes the XCD's L2 back; a fence per finished frame — 65 536 per launch — was 8 % of the level-3 match kernel
+    // (137.5 -> 126.0 ms with the fences taken out for a timing run, profiles/r05/f_).  A lane without a frame left stays (idle) until the whole wave is.
+    u32 pubK = 0xFFFFFFFFu, idle = 0;
     u32 const period = ZE_LW_PERIOD(level) ? ZE_LW_PERIOD(level) : M::default_period(); u32 ph = 0;   // double-fast machines: rounds per rotation of the non-search states
     for (u32 r = 0;; r++) {
         if (pend) {                                       // (machines that cannot take their flags late) a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
@@ -373,20 +385,23 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
                        rdy ? flagsBase + (size_t)k * flagStride : nullptr);
                 pend = 0u; have = 1u;
             }
-        } else if (m.st == ZL_DONE) {
+        } else if (m.st == ZL_DONE && !idle) {
             if (have) {
                 u32* const mt = meta + 3 * (size_t)k; mt[0] = m.o.n; mt[1] = m.o.lit + m.lastLL; mt[2] = m.lastLL; have = 0u;
 #ifdef ZL_PROFILE
                 if (count > 4096u && list[k] < 131072u) zlFrameRounds[list[k]] = r;          // (by frame index: the synthetic set's class is index & 3)
 #endif
-                zj_publish_done(doneList, doneCount, k);
+                if (doneList) {
+                    if (pubK != 0xFFFFFFFFu) zj_publish_done(doneList, doneCount, pubK);      // (a second frame finished before the hand-over: with a fence of its own)
+                    pubK = k;
+                }
             }
             late = 0u;
-            if (work2) { if (!zj_claim_front(work2, k)) break; }
+            bool more;
+            if (work2) more = zj_claim_front(work2, k);
+            else { k = atomicAdd(workCounter, 1u); more = k < count; }
+            if (!more) { if (!doneList) break; idle = 1u; }
             else {
-            k = atomicAdd(workCounter, 1u);
-            if (k >= count) break;
-            }
             u32 const i = list[k];
             u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
             u8* const tb = tables + (size_t)k * tableStride; u8* const fs = fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc);
@@ -394,6 +409,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
             bool const flagged = flagsBase && gate[k];
             if (flagged && !M::takes_flags_late()) { pend = 1u; tPend = wall_clock64(); }
             else { m.init(src + s0, size, ze_params_of(level, size), tb, fs, maxSrc, nullptr); have = 1u; late = flagged ? 1u : 0u; }
+            }
         }
         // A frame whose flags are still being computed starts WITHOUT them and takes them over when they arrive (flags only ever remove work, and what
         // they say about a position does not depend on when it is asked): once per rotation the lane asks; the request travels with the round's own loads.
@@ -402,9 +418,19 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
 #ifdef ZL_PROFILE
         zlRounds++;
 #endif
-        m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
+        if (m.st != ZL_DONE) m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
         if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * flagStride); late = 0u; }
         ph = ph + 1u >= period ? 0u : ph + 1u;
+        if (doneList) {                                   // the wave's hand-over (wave-uniform test)
+            bool const allIdle = __ballot(!idle) == 0;
+            if ((r & (ZJ_HAND_ROUNDS - 1u)) == ZJ_HAND_ROUNDS - 1u || allIdle) {
+                if (__ballot(pubK != 0xFFFFFFFFu) != 0) {
+                    __threadfence();                      // records + meta of every frame the wave finished since the last one, before their queue entries
+                    if (pubK != 0xFFFFFFFFu) { zj_queue_done(doneList, doneCount, pubK); pubK = 0xFFFFFFFFu; }
+                }
+                if (allIdle) break;
+            }
+        }
     }
 #ifdef ZL_PROFILE
     if (threadIdx.x == 0 && blockIdx.x < 2048u && count > 4096u) { zlWaveProf[4 * blockIdx.x] = __builtin_readcyclecounter() - zlWaveT0; zlWaveProf[4 * blockIdx.x + 1] = ((u64)(u32)__builtin_amdgcn_s_getreg(63508) << 32) | (u32)__builtin_amdgcn_s_getreg(63492); zlWaveProf[4 * blockIdx.x + 2] = zlRounds; zlWaveProf[4 * blockIdx.x + 3] = zlWall0; }
