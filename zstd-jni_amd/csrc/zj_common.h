@@ -133,6 +133,19 @@ ZJ_HD u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
 // (LZ77 execution reads bytes other lanes stored a moment ago).  At workgroup scope on gfx950 this
 // emits no instruction: one CU's vector memory operations are performed in order by its L1, so only
 // the compiler has to be stopped from reordering.
+// One-sided fences between kernels that run beside each other (producer: zj_release, then relaxed atomics; consumer: relaxed poll, then zj_acquire).  On gfx950 an agent-scope
+// release is `buffer_wbl2 sc1` — the XCD's L2 written back — and an acquire `buffer_inv sc1` — its L2 invalidated; `__threadfence()` is both, and a release STORE behind it
+// writes the L2 back a second time (round 5: the hand-overs paid two write-backs and an invalidate where one write-back is what the protocol needs, profiles/r05/g_).
+ZJ_DEV void zj_release() {
+#if ZJ_ON_GPU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+}
+ZJ_DEV void zj_acquire() {
+#if ZJ_ON_GPU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
 ZJ_DEV void zj_mem_order() {
 #if ZJ_ON_GPU
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -23,7 +23,7 @@
 #endif
 // a block's "stage 2 is done" flag: set behind everything the lane wrote for the block; stage 3 polls it when it runs beside stage 2
 #if ZJ_ON_GPU
-ZJ_DEV void zj_block_ready(u32* flag) { __threadfence(); __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+ZJ_DEV void zj_block_ready(u32* flag) { zj_release(); __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 static inline void zj_block_ready(u32* flag) { *flag = 1u; }
 #endif
@@ -601,7 +601,7 @@ ZJ_DEV bool zd_wait_block(const G& g, ZDecShared& sh, const u32* flag) {
     v = (u32)__builtin_amdgcn_readfirstlane((int)v);
     (void)sh;
     if (!v) return false;
-    __threadfence();
+    zj_acquire();
     return true;
 #else
     (void)g; (void)sh; return *flag != 0u;

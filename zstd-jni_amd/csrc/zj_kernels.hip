@@ -100,9 +100,9 @@ __global__ __launch_bounds__(64) void zj_ddict_digest_kernel(const u8* dictRaw, 
 // append k to a completion queue (the producer's records are visible before the entry): match kernel -> entropy kernel, sequence decode -> execution
 __device__ __forceinline__ void zj_publish_done(u32* doneList, u32* doneCount, u32 k) {
     if (!doneList) return;
-    __threadfence();                                       // records + meta visible before the queue entry
+    zj_release();                                          // records + meta visible before the queue entry
     u32 const slot = atomicAdd(doneCount, 1u);
-    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&doneList[slot], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the queue entry alone, behind a release fence the caller has made for several lanes at once (zj_match_run)
 __device__ __forceinline__ void zj_queue_done(u32* doneList, u32* doneCount, u32 k) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
             }
             v = (u32)__builtin_amdgcn_readfirstlane((int)v);
             if (v == 0xFFFFFFFFu) break;
-            __threadfence();
+            zj_acquire();
             i = v;
         } else {
             i = ZJ_UNI(list[k]);
@@ -378,7 +378,7 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         if (pend) {                                       // (machines that cannot take their flags late) a frame that will get flags: start it when they are there — or without them when the wait runs out (50 ms)
             bool const rdy = __hip_atomic_load(&ready[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (rdy || wall_clock64() - tPend > 5000000ull) {
-                if (rdy) __threadfence();
+                if (rdy) zj_acquire();
                 u32 const i = list[k];
                 u64 const s0 = srcOff[i]; u32 const size = (u32)(srcOff[i + 1] - s0);
                 m.init(src + s0, size, ze_params_of(level, size), tables + (size_t)k * tableStride, fscratch + (size_t)k * ZE_FRAME_STRIDE(maxSrc), maxSrc,
@@ -419,13 +419,13 @@ __device__ __forceinline__ void zj_match_run(const u8* __restrict__ src, const u
         zlRounds++;
 #endif
         if (m.st != ZL_DONE) m.round(ZE_LW_LEVEL(level) == 3 ? ZJ_UNI(ph) : ZJ_UNI(r));
-        if (M::takes_flags_late() && rdyNow != 0u) { __threadfence(); m.take_flags(flagsBase + (size_t)k * flagStride); late = 0u; }
+        if (M::takes_flags_late() && rdyNow != 0u) { zj_acquire(); m.take_flags(flagsBase + (size_t)k * flagStride); late = 0u; }
         ph = ph + 1u >= period ? 0u : ph + 1u;
         if (doneList) {                                   // the wave's hand-over (wave-uniform test)
             bool const allIdle = __ballot(!idle) == 0;
             if ((r & (ZJ_HAND_ROUNDS - 1u)) == ZJ_HAND_ROUNDS - 1u || allIdle) {
                 if (__ballot(pubK != 0xFFFFFFFFu) != 0) {
-                    __threadfence();                      // records + meta of every frame the wave finished since the last one, before their queue entries
+                    zj_release();                         // records + meta of every frame the wave finished since the last one, before their queue entries
                     if (pubK != 0xFFFFFFFFu) { zj_queue_done(doneList, doneCount, pubK); pubK = 0xFFFFFFFFu; }
                 }
                 if (allIdle) break;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(1024) void zj_enc_need_kernel(const u8* __restrict_
     u32 prev = 0xFFFFFFFFu;                               // the slot whose flags this workgroup finished last: published by lane 0 in the SAME divergent region that claims
     for (;;) {                                            // the next one (a separate `if (lane 0)` at the loop's end makes the compiler route lane 0 around the barriers)
         if (threadIdx.x == 0) {                           // a work queue: workgroups differ in speed, and the match kernel's lanes are waiting
-            if (prev != 0xFFFFFFFFu) { __threadfence(); __hip_atomic_store(&ready[prev], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            if (prev != 0xFFFFFFFFu) { zj_release(); __hip_atomic_store(&ready[prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             next = atomicAdd(work, 1u);
         }
         __syncthreads();
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
             }
             v = (u32)__builtin_amdgcn_readfirstlane((int)v);
             if (v == 0xFFFFFFFFu) break;
-            __threadfence();
+            zj_acquire();
             k = v;
         } else if (mode == 2) {
             if (ZJ_UNI(procFlag[k])) continue;
