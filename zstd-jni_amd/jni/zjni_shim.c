@@ -799,8 +799,14 @@ typedef struct StreamState {
     unsigned char* buf; size_t total, cap;                      /* everything written so far */
     uint32_t* flushAt; size_t nFlush, flushCap;
     size_t emitted;                                             /* bytes of the frame already made (handed out or pending) */
+    uint64_t madeHash;                                          /* FNV-1a over those bytes: a replay into the bundled library must reproduce them (ss_same_prefix) */
     unsigned char* out; size_t outLen, outPos, outCap;          /* made, not yet taken by the caller */
 } StreamState;
+/* The prefix a GPU-route stream has handed out is followed, after a replay, by what the BUNDLED library's stream writes behind its own version of that prefix.  The two
+ * are the same bytes when the bundled library is the release this route reproduces; another libzstd behind $ZSTD_JNI_CPU_LIB may cut its blocks elsewhere, and its later
+ * blocks would then continue a prefix the caller does not hold.  So the made bytes are hashed as they are made and the replay compares. */
+static uint64_t ss_hash(uint64_t h, const unsigned char* p, size_t n) { size_t i; for (i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001B3ull; } return h; }
+#define SS_HASH0 0xCBF29CE484222325ull
 static StreamState* g_ss[256];
 static pthread_mutex_t g_ss_mu = PTHREAD_MUTEX_INITIALIZER;
 static jfieldID g_cs_consumed, g_cs_produced, g_ds_consumed, g_ds_produced;
@@ -814,7 +820,7 @@ static StreamState* ss_get(jlong key, int create, int take) {
     return s;
 }
 static void ss_reset(StreamState* s, int level) {
-    s->level = level; s->checksum = 0; s->cpuMode = 0; s->started = 0; s->finished = 0; s->total = 0; s->nFlush = 0; s->emitted = 0; s->outLen = s->outPos = 0;
+    s->level = level; s->checksum = 0; s->cpuMode = 0; s->started = 0; s->finished = 0; s->total = 0; s->nFlush = 0; s->emitted = 0; s->madeHash = SS_HASH0; s->outLen = s->outPos = 0;
 }
 static void ss_free(StreamState* s) { if (s) { free(s->buf); free(s->flushAt); free(s->out); free(s); } }
 static int ss_note_parameter(jlong stream, int what, jint v) {       /* class Zstd's parameter natives on a stream handle: level and checksum are honoured, anything else is the bundled library's */
@@ -890,8 +896,8 @@ static int ss_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
     free(scratch);
     /* What was flushed out earlier came from the GPU route; the bundled stream has just made the same bytes again (the route is byte-identical, and a flushed
      * prefix depends on nothing behind it): they are skipped, what follows is new. */
-    if (s->outLen < s->emitted) return -1;
-    s->outPos = delivered; s->emitted = 0;
+    if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (not the bytes the caller already holds: no continuation to offer) */
+    s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0;
     s->cpuMode = 1; s->total = 0; s->nFlush = 0;
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
@@ -1009,7 +1015,7 @@ static jlong cs_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jobject dst
             return (jlong)r;
         }
         if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); return E_MEM; }
-        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->madeHash = ss_hash(s->madeHash, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
         free(tmp);
         if (end) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
     }
@@ -1207,8 +1213,8 @@ static int os_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
     }
     if ((*env)->DeleteLocalRef) { (*env)->DeleteLocalRef(env, darr); (*env)->DeleteLocalRef(env, sarr); }
     free(tmp);
-    if (s->outLen < s->emitted) return -1;                     /* (the flushed prefix came from the GPU route and the bundled stream has made the same bytes again: skipped) */
-    s->outPos = delivered; s->emitted = 0;
+    if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (the flushed prefix came from the GPU route and the bundled stream has made the same bytes again: skipped — or it has not: no continuation to offer) */
+    s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0;
     s->cpuMode = 1; s->total = 0; s->nFlush = 0;
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
@@ -1285,7 +1291,7 @@ static jint os_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jbyteArray d
             return (jint)r;
         }
         if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); return (jint)E_MEM; }
-        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+        memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->madeHash = ss_hash(s->madeHash, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
         free(tmp);
         if (end) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
     }
@@ -1526,8 +1532,8 @@ static int cx_replay_to_cpu(JNIEnv* env, jclass cls, jlong ptr, StreamState* s) 
         else if (!consumed && !produced) { free(scratch); return -1; }
     }
     free(scratch);
-    if (s->outLen < delivered) return -1;
-    s->outPos = delivered; s->emitted = 0; s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (see ss_hash: the bundled stream must have made the caller's prefix again) */
+    s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0; s->cpuMode = 1; s->total = 0; s->nFlush = 0;
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
 }
@@ -1561,7 +1567,7 @@ static int cx_stream(JNIEnv* env, jclass cls, jlong ptr, CtxState* c, char* dst,
             if (zjni_isError(r)) { free(tmp); if (zjni_getErrorCode(r) >= 200) return 0; *err = (unsigned)zjni_getErrorCode(r); return 1; }
             ss_reset(s, c->level);
             if (!ss_out_room(s, r)) { free(tmp); *err = 64; return 1; }
-            memcpy(s->out, tmp, r); s->outLen = r; s->emitted = r; s->finished = 1; s->started = 1;
+            memcpy(s->out, tmp, r); s->outLen = r; s->emitted = r; s->madeHash = ss_hash(SS_HASH0, tmp, r); s->finished = 1; s->started = 1;
             free(tmp);
             *consumed = n;
         } else {
@@ -1622,7 +1628,7 @@ static int cx_stream(JNIEnv* env, jclass cls, jlong ptr, CtxState* c, char* dst,
                     *produced = had + p2; return ok; }
             }
             if (r < s->emitted || !ss_out_room(s, r - s->emitted)) { free(tmp); *err = 64; return 1; }
-            memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
+            memcpy(s->out + s->outLen, tmp + s->emitted, r - s->emitted); s->madeHash = ss_hash(s->madeHash, tmp + s->emitted, r - s->emitted); s->outLen += r - s->emitted; s->emitted = r;
             free(tmp);
             if (op == 2) { s->finished = 1; __atomic_fetch_add(&g_stats[0], 1, __ATOMIC_RELAXED); }
         }
