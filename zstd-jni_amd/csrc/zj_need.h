@@ -29,10 +29,16 @@
 #define ZN_FLAG_SLACK 16u                /* bytes behind a frame's flags that the lane machine may read (never interprets) */
 #define ZN_FLAG_STRIDE (65536u + ZN_FLAG_SLACK)   /* flag bytes per frame slot of the match kernel's launch (frames up to 64 KiB) */
 
+// Round 5: the "seen" filters are half as large again (6 144 blocks of 64 bits instead of 4 096: 140 KiB of LDS instead of 108, still one workgroup per CU).  With all 65 536 keys in,
+// a 4 096-block filter is 63 % full and says "seen" to 16 % of the keys that were not; measured on the low-entropy class of the bench set the flags asked for a long probe at 5.6 % of
+// the positions where 0.2 % have a twin, and for a short one at 19.9 % (exact: 15.9 %; 128 KiB frames: 28.0 % against 24.7 %) — every such probe is a round of the lane machine.
+#define ZN_B1_BLOCKS 6144u               /* 3 x 2 048: zn_b1() */
 struct ZNLds {
-    u64 b1L[4096], b2L[2048], b1S[4096], b2S[2048];     // blocked Bloom filters: 64-bit blocks, 4 bits per key (2.5 % false positives with all 65 536 keys in, under 1 % on average)
+    u64 b1L[ZN_B1_BLOCKS], b2L[2048], b1S[ZN_B1_BLOCKS], b2S[2048];     // blocked Bloom filters: 64-bit blocks, 4 bits per key
     u32 bnL[1u << (ZN_MAX_LOG_L - 5u)], bnS[1u << (ZN_MAX_LOG_S - 5u)];   // buckets some needed probe falls into
 };
+// block of a key in a "seen" filter of 3 x `third` blocks (third a power of two): 11 / 12 bits pick the block inside a third, 16 more the third (a full-rate 24-bit multiply)
+ZJ_DEV u32 zn_b1(u32 a, u32 third) { return (a & (third - 1u)) + third * ((((a >> 12) & 0xFFFFu) * 3u) >> 16); }
 
 // Filter hashes.  32-bit multiplies run at a quarter of the VALU rate on gfx950 and this kernel is nothing but hashing, so the keys are
 // hashed with as few of them as the filters tolerate: the long key reuses the product the bucket comes from (3 multiplies) plus one
@@ -72,9 +78,9 @@ ZJ_DEV void zn_flags_frame(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashL
     for (u32 p = t.id(); p < npos; p += t.count()) {         // sweep 1: every key into "seen"; a key that was there already into "seen again"
         u64 const w = ld64(src + p);
         ZNHash const kl = zn_hash_long(zl_prod_hi(hL, w), w), ks = zn_hash_short(zl_hash(hS, w), (u32)w);
-        {   u64 const m = zn_mask(kl.b), old = zn_atomic_or(&L.b1L[kl.a & 4095u], m);
+        {   u64 const m = zn_mask(kl.b), old = zn_atomic_or(&L.b1L[zn_b1(kl.a, 2048u)], m);
             if ((old & m) == m) { ZNHash const g = zn_second(kl); zn_atomic_or(&L.b2L[g.a & 2047u], zn_mask(g.b)); } }
-        {   u64 const m = zn_mask(ks.b), old = zn_atomic_or(&L.b1S[ks.a & 4095u], m);
+        {   u64 const m = zn_mask(ks.b), old = zn_atomic_or(&L.b1S[zn_b1(ks.a, 2048u)], m);
             if ((old & m) == m) { ZNHash const g = zn_second(ks); zn_atomic_or(&L.b2S[g.a & 2047u], zn_mask(g.b)); } }
     }
     t.sync();
@@ -102,13 +108,13 @@ ZJ_DEV void zn_flags_frame(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashL
     t.sync();
 }
 // Frames of 64 KiB + 1 .. 128 KiB (the wide launch): twice the keys, so a filter pair takes the room both pairs have above — the long table's flags and the short
-// table's are computed one after the other, each with filters of 8 192 / 4 096 blocks over the same LDS (three sweeps per table; a sweep hashes for one table only,
+// table's are computed one after the other, each with filters of 12 288 / 4 096 blocks over the same LDS (three sweeps per table; a sweep hashes for one table only,
 // so the hashing per position is that of a 64 KiB frame's).  The flag byte is written by the long table's pass and completed by the short table's.
 template <class T>
 ZJ_DEV void zn_flags_frame_wide(const T& t, ZNLds& L, const u8* src, u32 n, u32 hashLog, u32 chainLog, u32 mls, u8* F) {
     u32 const npos = n >= 8u ? n - 7u : 0u;
     ZLHash const hL = zl_hash_of(8, hashLog), hS = zl_hash_of(mls, chainLog);
-    u64* const b1 = (u64*)&L; u64* const b2 = b1 + 8192;       // 64 KiB + 32 KiB: the room of b1L .. b2S
+    u64* const b1 = (u64*)&L; u64* const b2 = b1 + 2u * ZN_B1_BLOCKS;       // 96 KiB + 32 KiB: the room of b1L .. b2S
     for (u32 table = 0; table < 2u; table++) {                 // 0: long, 1: short
         u32* const bn = table == 0 ? L.bnL : L.bnS;
         {   u32* const w = (u32*)&L; u32 const words = (u32)(sizeof(ZNLds) / 4u);
@@ -117,7 +123,7 @@ ZJ_DEV void zn_flags_frame_wide(const T& t, ZNLds& L, const u8* src, u32 n, u32 
         for (u32 p = t.id(); p < npos; p += t.count()) {       // sweep 1: every key into "seen"; a key that was there already into "seen again"
             u64 const w = ld64(src + p);
             ZNHash const k = table == 0 ? zn_hash_long(zl_prod_hi(hL, w), w) : zn_hash_short(zl_hash(hS, w), (u32)w);
-            u64 const m = zn_mask(k.b), old = zn_atomic_or(&b1[k.a & 8191u], m);
+            u64 const m = zn_mask(k.b), old = zn_atomic_or(&b1[zn_b1(k.a, 4096u)], m);
             if ((old & m) == m) { ZNHash const g = zn_second(k); zn_atomic_or(&b2[g.a & 4095u], zn_mask(g.b)); }
         }
         t.sync();
