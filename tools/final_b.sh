@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 evidence, second call (after tools/r04_final_a.sh + tools/pmc_summary.py):  gpurun --timeout 1700 -- 'bash tools/r04_final_b.sh'
-#   every BASELINE config as a bench.py line under gpurun_out/r04final/ — cp them to profiles/r04_bench_config*.json
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r04final; mkdir -p $OUT
+# A round's evidence, second call (after tools/final_a.sh + tools/pmc_summary.py):  gpurun --timeout 1700 -- 'bash tools/final_b.sh r05'
+#   every BASELINE config as a bench.py line under gpurun_out/<round>final/ — cp them to profiles/<round>_bench_config*.json
+RND=${1:-r05}; R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/${RND}final; mkdir -p $OUT
 cd $R
 for C in metric 3 2 4 1 5shape; do
   timeout 300 python bench.py --config $C --steps 4 --warmup 1 > $OUT/bench_config$C.json 2> $OUT/bench_config$C.err
