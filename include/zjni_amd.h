@@ -257,6 +257,10 @@ size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, 
  * error results are skipped. */
 size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
                               void* d_dst, const uint64_t* d_dst_off, size_t n, void* stream);
+/* The same with the packed offsets made on the device: d_packed_off[0 .. n] (out) = exclusive prefix sums of the sizes (error results count as 0),
+ * then the frames move there.  One call instead of a scan by the caller plus the pack (round 5). */
+size_t zjni_pack_batch_device2(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
+                               void* d_dst, uint64_t* d_packed_off, size_t n, void* stream);
 
 /* ---- resource policy ----
  * The large-batch pipelines keep per-frame scratch in HBM (match-finder tables and sequence records, decode cells): one buffer

@@ -130,3 +130,22 @@ def test_gpu_two_host_batches_in_flight(gpu, oracle_ref):
     for (bufs, *_), (outs, op, oc, cs, r2) in zip(sets, backs):
         for k, b in enumerate(bufs):
             assert r2[k] == len(b) and outs[k].raw[:len(b)] == b, k
+
+
+def test_gpu_pack_makes_its_own_offsets(gpu):
+    """zjni_pack_batch_device2 (round 5): the exclusive scan of the sizes on the device (error results count as 0), then the frames back to back — equal to torch's scan + the plain pack"""
+    import torch
+    B = gpu.batch
+    for n, size in ((1, 100), (1000, 5000), (4097, 3000), (70001, 300)):
+        src = B.synth(n, size, 3, "cuda"); src_off = B.uniform_offsets(n, size, "cuda")
+        bound = gpu.Zstd.compressBound(size)
+        comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); comp_off = B.uniform_offsets(n, bound, "cuda")
+        csz = B.compress(src, src_off, comp, comp_off, 1)
+        csz[n // 3] = -70                                             # an error result in the middle: skipped, counts as 0
+        want_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); want_off[1:] = torch.cumsum(csz.clamp(min=0), 0)
+        a, a_off = B.pack(csz, comp, comp_off)                         # torch scan + zjni_pack_batch_device
+        out = torch.zeros(int(want_off[-1].item()) + 64, dtype=torch.uint8, device="cuda"); off = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda")
+        b, b_off = B.pack(csz, comp, comp_off, out=out, out_off=off)   # zjni_pack_batch_device2
+        torch.cuda.synchronize()
+        assert torch.equal(b_off, want_off) and torch.equal(a_off, want_off), (n, size)
+        assert torch.equal(b[:a.numel()], a), (n, size)

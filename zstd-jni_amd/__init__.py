@@ -148,6 +148,8 @@ def lib():
     L.zjni_synth_fill_device.argtypes = [vp, sz, C.c_uint64, sz, vp]
     L.zjni_pack_batch_device.restype = sz
     L.zjni_pack_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.zjni_pack_batch_device2.restype = sz
+    L.zjni_pack_batch_device2.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     L.zjni_last_timing.restype = C.c_int
     L.zjni_last_timing.argtypes = [C.POINTER(C.c_float)]
     L.zjni_last_timing2.restype = C.c_int
@@ -204,7 +206,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
            "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
            "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists",
-           "zjni_compress_batch_begin", "zjni_decompress_batch_begin", "zjni_batch_finish")
+           "zjni_compress_batch_begin", "zjni_decompress_batch_begin", "zjni_batch_finish", "zjni_pack_batch_device2")
 
 
 # --------------------------------------------------------------------------- Java API mirror --

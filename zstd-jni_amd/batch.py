@@ -74,13 +74,18 @@ def decompress(src_blob, src_off, dst_blob, dst_off, results=None, dictionary=No
 
 def pack(results, dst_blob, dst_off, out=None, out_off=None):
     """Tightly pack a compress batch's variable-size outputs (sizes = results) into one blob:
-    returns (packed_blob, packed_off int64[n+1]).  The exclusive scan is torch plumbing; the byte
-    movement is zj_pack_kernel.  With `out` (uint8, capacity >= sum of sizes) and `out_off`
-    (int64[n+1]) preallocated nothing synchronises with the host."""
+    returns (packed_blob, packed_off int64[n+1]).  With `out` (uint8, capacity >= sum of sizes) and `out_off`
+    (int64[n+1]) preallocated the exclusive scan and the byte movement are one library call
+    (zjni_pack_batch_device2) and nothing synchronises with the host; without `out` the scan is torch's,
+    because the blob's size has to come back first."""
     n = results.numel()
-    sizes = results.clamp(min=0)
     if out_off is None:
         out_off = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
+    if out is not None and out_off.is_contiguous() and results.is_contiguous():
+        _check(lib().zjni_pack_batch_device2(dst_blob.data_ptr(), dst_off.data_ptr(), results.data_ptr(), out.data_ptr(),
+                                             out_off.data_ptr(), n, _stream_ptr()))
+        return out, out_off
+    sizes = results.clamp(min=0)
     out_off[0] = 0
     torch.cumsum(sizes, 0, out=out_off[1:])
     if out is None:

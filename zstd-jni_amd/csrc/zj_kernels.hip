@@ -2874,6 +2874,33 @@ size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, 
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
 }
 
+// exclusive prefix sums of a batch's result sizes (error results count as 0) -> off[0 .. n]: one workgroup, a contiguous run per lane, one scan over the lanes' sums
+__global__ __launch_bounds__(1024) void zj_pack_offsets_kernel(const u64* __restrict__ sizes, u64* __restrict__ off, u32 n) {
+    __shared__ u64 part[1024];
+    u32 const t = threadIdx.x, per = (n + 1023u) / 1024u, lo = t * per, hi = zj_min(lo + per, n);
+    u64 sum = 0;
+    for (u32 i = lo; i < hi; i++) { u64 const z = sizes[i]; sum += z > ((u64)1 << 40) ? 0 : z; }
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {                // (Hillis-Steele over 1 024 sums)
+        u64 const v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u64 run = t ? part[t - 1] : 0;
+    for (u32 i = lo; i < hi; i++) { off[i] = run; u64 const z = sizes[i]; run += z > ((u64)1 << 40) ? 0 : z; }
+    if (t == 1023u) off[n] = part[1023];
+}
+size_t zjni_pack_batch_device2(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
+                               void* d_dst, uint64_t* d_packed_off, size_t n, void* stream) {
+    DevState* d = cur_state();
+    if (!d) return ZJNI_ERR(ZJNI_ERROR_no_device);
+    if (n > 0xFFFFFFFFull) return ZJNI_ERR(64);
+    if (n == 0) return hipMemsetAsync(d_packed_off, 0, 8, (hipStream_t)stream) == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+    hipLaunchKernelGGL(zj_pack_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const u64*)d_sizes, (u64*)d_packed_off, (u32)n);
+    return zjni_pack_batch_device(d_src, d_src_off, d_sizes, d_dst, d_packed_off, n, stream);
+}
 size_t zjni_pack_batch_device(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
                               void* d_dst, const uint64_t* d_dst_off, size_t n, void* stream) {
     DevState* d = cur_state();
