@@ -130,3 +130,18 @@ def test_route_names_and_build_stamp(zj):
     for name, val in routes.items():
         assert L.zjni_route_kernel(val) == want[name], name
     assert L.zjni_build_stamp().decode() == zj.build_stamp()          # the library in the tree is the one these sources give
+
+
+def test_asynchronous_entries_fail_loudly_without_gpu(zj):
+    """zjni_compress_batch_begin / zjni_decompress_batch_begin (round 5): no device, no job — and zjni_batch_finish of no job says so; there is no CPU path behind them either"""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = zj.lib()
+    buf = C.create_string_buffer(b"x" * 100, 100); dst = C.create_string_buffer(200)
+    sp = (C.c_void_p * 1)(C.addressof(buf)); dp = (C.c_void_p * 1)(C.addressof(dst)); ss = (C.c_size_t * 1)(100); dc = (C.c_size_t * 1)(200); res = (C.c_size_t * 1)()
+    assert not L.zjni_compress_batch_begin(sp, ss, dp, dc, res, 1, 3, 0)
+    assert not L.zjni_decompress_batch_begin(sp, ss, dp, dc, res, 1)
+    r = L.zjni_batch_finish(None)
+    assert L.zjni_isError(r) and L.zjni_getErrorCode(r) == 200
