@@ -25,7 +25,8 @@ cpu_baseline = the reference's own libzstd (oracle/_ref) on this box's host thre
                the clock starts, passes are released by a barrier and repeated for >= 1 s (oracle/cpu_baseline.c), on the full
                batch when host memory allows; all-core and single-core figures, CPU model string.
 end_to_end   = the host-pointer entries a JNI batch native binds (zjni_*_batch: pack -> H2D -> kernels -> D2H -> scatter) on a
-               bounded sample — never `value`.
+               bounded sample — never `value`; one blocking call, and (two_batches_in_flight) 8 batches through
+               zjni_compress_batch_begin / zjni_batch_finish with two in flight, run by tools/e2e.py in a process of its own.
 """
 import argparse
 import ctypes as C
