@@ -398,6 +398,17 @@ extern "C" unsigned emu_huf_weights(const unsigned char* hdr, unsigned size, uns
     return h ? nbSym : 0;
 }
 
+// a tANS decode table both ways: zd_build_fse (one lane) and zd_fse_spread + zd_fse_finish_wave (the second pass by the wave, round 5); bit 0 / bit 1 of the result: each one's verdict
+extern "C" int emu_fse_dtable(const short* norm, unsigned maxSV, unsigned tableLog, unsigned kind, unsigned* serialOut, unsigned* waveOut) {
+    Grp<1> g;
+    static u32 a[512], b[512], bm[ZD_FSE_BM_WORDS]; u16 sn1[64], sn2[64];
+    memset(a, 0xA5, sizeof a); memset(b, 0x5A, sizeof b); memset(bm, 0x3C, sizeof bm);
+    bool const ok1 = zd_build_fse(a, norm, sn1, maxSV, tableLog, kind);
+    bool const ok2 = zd_fse_spread(b, norm, sn2, maxSV, tableLog);
+    if (ok2) zd_fse_finish_wave(g, b, sn2, tableLog, kind, bm);
+    memcpy(serialOut, a, sizeof(u32) << tableLog); memcpy(waveOut, b, sizeof(u32) << tableLog);
+    return (ok1 ? 1 : 0) | (ok2 ? 2 : 0);
+}
 // the kernels' NCount reader on its own (zd_read_ncount): header bytes or 0; norm[0..*maxSV], *tableLog filled on success
 extern "C" unsigned emu_read_ncount(const unsigned char* src, unsigned size, unsigned maxSV, short* normOut, unsigned* maxOut, unsigned* logOut) {
     short norm[256]; u32 mx = maxSV, tl = 0;

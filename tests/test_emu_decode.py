@@ -247,3 +247,36 @@ def test_huffman_tree_description_reader_matches_reference(emu, oracle_ref):
             ok += 1
             assert e == nb.value and tl2.value == tl.value and w.raw[:nb.value] == w2.raw[:nb.value], s.hex()
     assert ok > 800
+
+
+def test_emu_fse_table_by_the_wave():
+    """zd_fse_spread + zd_fse_finish_wave (round 5: the decode tables' second pass on the whole wave, a slot's state from its rank among its symbol's slots) gives
+    zd_build_fse's cells — random normalised distributions with low-probability (-1) symbols, every table log and kind, and the format's three default distributions"""
+    import ctypes as C
+    import random
+    from util import emu_lib
+    L = emu_lib()
+    rnd = random.Random(41)
+    cases = 0
+    for _ in range(4000):
+        kind = rnd.randrange(3); maxsv = rnd.randrange(1, (36, 32, 53)[kind]); log = rnd.randrange(5, (10, 9, 10)[kind]); size = 1 << log
+        nlow = rnd.randrange(0, min(maxsv + 1, size // 2, 30) + 1) if rnd.random() < 0.7 else 0
+        syms = list(range(maxsv + 1)); rnd.shuffle(syms)
+        low = set(syms[:nlow]); rest = [s for s in syms if s not in low]
+        norm = [0] * 64
+        for s in low: norm[s] = -1
+        left = size - nlow
+        if not rest:
+            continue
+        k = rnd.randrange(1, len(rest) + 1); chosen = rest[:k]
+        if left < k:
+            continue
+        cuts = sorted(rnd.sample(range(1, left), k - 1)) if k > 1 else []
+        parts = [b - a for a, b in zip([0] + cuts, cuts + [left])]
+        for s, c in zip(chosen, parts): norm[s] = c
+        arr = (C.c_short * 64)(*norm); a = (C.c_uint * 512)(); b = (C.c_uint * 512)()
+        r = L.emu_fse_dtable(arr, maxsv, log, kind, a, b)
+        assert r == 3, (r, norm[:maxsv + 1], log)
+        assert list(a)[:size] == list(b)[:size], (kind, log, norm[:maxsv + 1])
+        cases += 1
+    assert cases > 3000

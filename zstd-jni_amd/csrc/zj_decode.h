@@ -194,7 +194,9 @@ ZJ_DEV u32 zd_read_ncount(short* norm, u32* maxSV, u32* tableLog, const u8* src,
 // N/decompress/zstd_decompress_block.c:485-603.  kind: 0 LL, 1 OF, 2 ML (extra-bits lookup).
 ZJ_DEV u32 zd_extra_bits(u32 kind, u32 sym) { return kind == 1 ? sym : (kind == 0 ? zd_ll_bits(sym) : zd_ml_bits(sym)); }
 
-ZJ_DEV bool zd_build_fse(u32* cells, const short* norm, u16* symNext, u32 maxSV, u32 tableLog, u32 kind) {
+// In two parts: the spread (low-probability symbols to the table's end, the others along the walk pos += step: cells[u] = the symbol of slot u), and the pass that turns
+// a slot's symbol into its cell — the slot's rank among its symbol's slots decides the state it leads to (nextState = symbolNext[symbol]++ in ascending slot order).
+ZJ_DEV bool zd_fse_spread(u32* cells, const short* norm, u16* symNext, u32 maxSV, u32 tableLog) {
     u32 const size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
     u32 high = size - 1, pos = 0;
     for (u32 s = 0; s <= maxSV; s++) {
@@ -206,14 +208,48 @@ ZJ_DEV bool zd_build_fse(u32* cells, const short* norm, u16* symNext, u32 maxSV,
             do { pos = (pos + step) & mask; } while (pos > high);
         }
     }
-    if (pos != 0) return false;
+    return pos == 0;
+}
+ZJ_DEV void zd_fse_finish(u32* cells, u16* symNext, u32 tableLog, u32 kind) {
+    u32 const size = 1u << tableLog;
     for (u32 u = 0; u < size; u++) {
         u32 const sym = cells[u];
         u32 const ns = symNext[sym]++;
         u32 const nb = tableLog - zj_hibit(ns);
         cells[u] = ZD_CELL((ns << nb) - size, nb, sym, zd_extra_bits(kind, sym));
     }
+}
+ZJ_DEV bool zd_build_fse(u32* cells, const short* norm, u16* symNext, u32 maxSV, u32 tableLog, u32 kind) {
+    if (!zd_fse_spread(cells, norm, symNext, maxSV, tableLog)) return false;
+    zd_fse_finish(cells, symNext, tableLog, kind);
     return true;
+}
+// The second part by the whole wave (round 5).  On one lane it is a chain of 512 dependent LDS read-modify-writes (symbolNext[symbol]++) — ~70 us of the ~100 a frame
+// spends in zj_dec_prep_kernel; here every slot finds its rank by counting: a bitmap of its slots per symbol (bm: 54 symbols x 16 words, zeroed here), the rank of slot u =
+// the set bits below u in its symbol's bitmap.  Same cells (tests/test_emu_decode.py::test_emu_fse_table_by_the_wave).  symNext keeps the spread's starting values.
+#define ZD_FSE_BM_WORDS (54u * 16u)
+static_assert(ZD_FSE_BM_WORDS * 4u <= (2u << ZD_HUF_LOG_MAX), "the bitmaps fit the Huffman table's room (ZDecShared::huf), which stage 1 lends them");
+#if ZJ_ON_GPU
+ZJ_DEV void zd_or32(u32* p, u32 v) { atomicOr(p, v); }
+#else
+static inline void zd_or32(u32* p, u32 v) { *p |= v; }
+#endif
+template <class G>
+ZJ_DEV void zd_fse_finish_wave(const G& g, u32* cells, const u16* symNext, u32 tableLog, u32 kind, u32* bm) {
+    u32 const size = 1u << tableLog;
+    GRP_FOR(g, i, ZD_FSE_BM_WORDS) bm[i] = 0;
+    g.sync();
+    GRP_FOR(g, u, size) { u32 const sym = cells[u] & 63u; zd_or32(&bm[sym * 16u + (u >> 5)], 1u << (u & 31u)); }
+    g.sync();
+    GRP_FOR(g, u, size) {
+        u32 const sym = cells[u] & 63u; const u32* const b = bm + sym * 16u; u32 const w = u >> 5;
+        u32 rank = (u32)__builtin_popcount(b[w] & ((1u << (u & 31u)) - 1u));
+        for (u32 x = 0; x < w; x++) rank += (u32)__builtin_popcount(b[x]);
+        u32 const ns = (u32)symNext[sym] + rank;
+        u32 const nb = tableLog - zj_hibit(ns);
+        cells[u] = ZD_CELL((ns << nb) - size, nb, sym, zd_extra_bits(kind, sym));
+    }
+    g.sync();
 }
 
 // ------------------------------------------------------------------ private lane-0 state -----
@@ -1007,8 +1043,9 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
 
 // Sequences section header + the three tANS tables into sh.ll/of/ml (N/decompress/zstd_decompress_block.c:695-782,
 // :485-603).  Publishes sh.nbSeq, sh.seqOff (first byte of the bitstream), sh.llLog/ofLog/mlLog; sets sh.err.
+// `bm` (optional): ZD_FSE_BM_WORDS words of LDS the caller can spare — the tables' second pass then runs on the whole wave (zd_fse_finish_wave)
 template <class G>
-ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u32 seqSecOff) {
+ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u32 seqSecOff, u32* bm = nullptr) {
     GRP_SERIAL(g) {
         u32 err = 0, ip = seqSecOff, nbSeq = 0;
         if (ip >= bsize) err = ZJ_E_SRCSIZE_WRONG;
@@ -1054,11 +1091,12 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
             u32* cells = t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml);
             if (mode == 2) {
                 u32 const tl = sh.tblLog[t];
-                if (!zd_build_fse(cells, sh.norm[t], sh.symNext + 64 * t, sh.tblMax[t], tl, t)) sh.err = ZJ_E_CORRUPTION;
+                if (!(bm ? zd_fse_spread(cells, sh.norm[t], sh.symNext + 64 * t, sh.tblMax[t], tl) : zd_build_fse(cells, sh.norm[t], sh.symNext + 64 * t, sh.tblMax[t], tl, t))) sh.err = ZJ_E_CORRUPTION;
                 if (t == 0) sh.llLog = tl; else if (t == 1) sh.ofLog = tl; else sh.mlLog = tl;
             } else if (mode == 0) {
                 u32 const log = (t == 1) ? 5 : 6;
-                zd_build_fse(cells, t == 0 ? zd_k_ll_defnorm : (t == 1 ? zd_k_of_defnorm : zd_k_ml_defnorm), sh.symNext + 64 * t, t == 0 ? 35 : (t == 1 ? 28 : 52), log, t);
+                const short* const dn = t == 0 ? zd_k_ll_defnorm : (t == 1 ? zd_k_of_defnorm : zd_k_ml_defnorm); u32 const dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                if (bm) zd_fse_spread(cells, dn, sh.symNext + 64 * t, dmax, log); else zd_build_fse(cells, dn, sh.symNext + 64 * t, dmax, log, t);
                 if (t == 0) sh.llLog = log; else if (t == 1) sh.ofLog = log; else sh.mlLog = log;
             } else if (mode == 1) {
                 u32 const sym = sh.tblMax[t];
@@ -1067,6 +1105,13 @@ ZJ_DEV void zd_seq_tables(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize,
             }
         }
         g.sync();
+        if (bm && !ZJ_UNI(sh.err)) {                   // the spread tables' second pass, a table at a time on the whole wave
+            for (u32 t = 0; t < 3u; t++) {
+                u32 const mode = ZJ_UNI(sh.tblMode[t]);
+                if (mode != 0u && mode != 2u) continue;
+                zd_fse_finish_wave(g, t == 0 ? sh.ll : (t == 1 ? sh.of : sh.ml), sh.symNext + 64 * t, ZJ_UNI(t == 0 ? sh.llLog : (t == 1 ? sh.ofLog : sh.mlLog)), t, bm);
+            }
+        }
     }
 }
 

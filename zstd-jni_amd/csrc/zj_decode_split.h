@@ -111,7 +111,7 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     if (!ZJ_UNI(sh.blkType)) return false;
     u32 const boff = ZJ_UNI(sh.hdrSize), bsize = ZJ_UNI(sh.blkSize);
     if (dictEntropy) { zd_load_dict_entropy(g, sh, dd, false, true); g.sync(); }      // repeat modes copy the dictionary's tables
-    zd_seq_tables(g, sh, src + boff, bsize, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize));
+    zd_seq_tables(g, sh, src + boff, bsize, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize), (u32*)sh.huf);      // (stage 1 decodes no literals: the Huffman table's room is free)
     g.sync();
     u32 const nbSeq = ZJ_UNI(sh.nbSeq);
     if (ZJ_UNI(sh.err) || nbSeq > ZD_SPLIT_MAXSEQ) { GRP_SERIAL(g) { sh.err = 0; } g.sync(); return false; }
@@ -512,7 +512,7 @@ ZJ_DEV bool zd_prep_frame_multi(const G& g, ZDecShared& sh, const u8* src, u32 s
         }
         g.sync();
         if (!ZJ_UNI(sh.litType)) return false;
-        zd_seq_tables(g, sh, body, sz, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize));
+        zd_seq_tables(g, sh, body, sz, ZJ_UNI(sh.litHdr) + ZJ_UNI(sh.litCSize), (u32*)sh.huf);
         g.sync();
         u32 const nbSeq = ZJ_UNI(sh.nbSeq);
         if (ZJ_UNI(sh.err) || nbSeq > ZD_SPLIT_MAXSEQ) { GRP_SERIAL(g) { sh.err = 0; } g.sync(); return false; }
