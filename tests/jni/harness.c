@@ -335,7 +335,7 @@ int main(int argc, char** argv) {
     if (maxLevel >= 3) {
         jlong rc = R.cinit(e, NULL), gc = G.cinit(e, NULL);
         R.setLevel(e, NULL, rc, 3); G.setLevel(e, NULL, gc, 3);
-        CHECK(G.setHashLog(e, NULL, gc, 16) == 0 && G.setChainLog(e, NULL, gc, 15) == 0, "setCompressionHashLog/ChainLog on a shim context");
+        CHECK(G.setHashLog(e, NULL, gc, 16) == 16 && G.setChainLog(e, NULL, gc, 15) == 15, "setCompressionHashLog/ChainLog on a shim context (ZSTD_CCtx_setParameter answers the value in force)");
         for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
             jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
             Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
@@ -344,8 +344,8 @@ int main(int argc, char** argv) {
             CHECK(rr == gr && rr > 0 && !memcmp(rdst->data, gdst->data, (size_t)rr), "plain level 3 (16/15) n=%d cls=%d: ref %lld gpu %lld", n, cls, (long long)rr, (long long)gr);
         }
         /* setHashLog(14).setChainLog(13): the LDS-sized tables (wave-per-frame matcher / fused kernel on the GPU) = the reference given the same two */
-        CHECK(G.setHashLog(e, NULL, gc, 14) == 0 && G.setChainLog(e, NULL, gc, 13) == 0, "setCompressionHashLog/ChainLog (14/13) on a shim context");
-        R.setHashLog(e, NULL, rc, 14); R.setChainLog(e, NULL, rc, 13);
+        {   jint const gh = G.setHashLog(e, NULL, gc, 14), gl = G.setChainLog(e, NULL, gc, 13), rh = R.setHashLog(e, NULL, rc, 14), rl = R.setChainLog(e, NULL, rc, 13);
+            CHECK(gh == rh && gl == rl && rh == 14 && rl == 13, "setCompressionHashLog/ChainLog (14/13): shim %d / %d, reference %d / %d", (int)gh, (int)gl, (int)rh, (int)rl); }
         for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) for (int cls = 0; cls < 3; cls++) {
             jsize const n = sizes[si], cap = (jsize)R.bound(e, NULL, n) + 8;
             Obj* src = mk(1, n); Obj* rdst = mk(1, cap); Obj* gdst = mk(1, cap);
@@ -1093,6 +1093,45 @@ int main(int argc, char** argv) {
                     bf(e, NULL, h);
                 }
             }
+            free(outs[0]); free(outs[1]);
+        }
+        /* parameters set INSIDE a frame (class Zstd's natives on the raw handle; the Java stream classes refuse it, the natives do not — ADVICE r04): the checksum flag and a
+         * dictionary answer ZSTD_error_stage_wrong, the level is accepted and belongs to the NEXT frame (C/zstd_compress.c ZSTD_CCtx_setParameter past zcss_init); both libraries
+         * give the same answers and the same two frames */
+        {
+            typedef jint (*dict_fn)(JNIEnv*, jclass, jlong, jbyteArray, jint);
+            jsize const total = 50000; Obj* src = mk(2, total); Obj* dict = mk(2, 4096);
+            char* outs[2]; size_t lens[2] = {0, 0}; jint answers[2][3] = {{1, 1, 1}, {1, 1, 1}}; jlong worst[2] = {0, 0};
+            STAGE("heap-array streams: parameters inside a frame");
+            fill(src->data, total, 1); fill(dict->data, 4096, 1);
+            for (int k = 0; k < 2; k++) {
+                dict_fn loadDict = (dict_fn)dlsym(libs[k]->h, P "Zstd_loadDictCompress");
+                Obj* self = mk(7, 0); Obj* dst = mk(2, 131591);
+                jlong const h = S[k].create(e, NULL); jint r;
+                char* out = (char*)malloc(4 * (size_t)total); size_t n = 0;
+                CHECK(loadDict != NULL, "Zstd_loadDictCompress of library %d", k);
+                r = S[k].level(e, NULL, h, 1); if (r < 0) worst[k] = r;
+                for (int fr = 0; fr < 2 && worst[k] == 0; fr++) {
+                    int guard = 0;
+                    r = S[k].reset(e, (jobject)self, h); if (r < 0) { worst[k] = r; break; }
+                    self->srcPos = 0;
+                    while (self->srcPos < total && guard++ < 100000) {
+                        r = S[k].comp(e, (jobject)self, h, (jbyteArray)dst, 131591, (jbyteArray)src, total); if (r < 0) { worst[k] = r; break; }
+                        memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos;
+                    }
+                    if (fr == 0 && worst[k] == 0) {
+                        answers[k][0] = S[k].checksum(e, NULL, h, JNI_TRUE);
+                        answers[k][1] = S[k].level(e, NULL, h, 3);
+                        answers[k][2] = loadDict ? loadDict(e, NULL, h, (jbyteArray)dict, 4096) : 1;
+                    }
+                    if (worst[k] == 0) { int guard3 = 0; do { r = S[k].end(e, (jobject)self, h, (jbyteArray)dst, 131591); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos; } while (r > 0 && guard3++ < 100000); }
+                }
+                S[k].free_(e, NULL, h);
+                outs[k] = out; lens[k] = n;
+            }
+            CHECK(answers[0][0] == -60 && answers[0][1] == 3 && answers[0][2] == -60, "the reference inside a frame: checksum %d, level %d, dictionary %d", (int)answers[0][0], (int)answers[0][1], (int)answers[0][2]);
+            CHECK(!memcmp(answers[0], answers[1], sizeof answers[0]), "parameters inside a frame: the shim answers checksum %d, level %d, dictionary %d", (int)answers[1][0], (int)answers[1][1], (int)answers[1][2]);
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "two frames around parameters set inside the first: ref %zu bytes (%lld), shim %zu bytes (%lld)", lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
             free(outs[0]); free(outs[1]);
         }
         /* HARNESS_FUZZ: random scripts on one ZstdOutputStreamNoFinalizer object — one to three frames (resetCStream between them), writes of random sizes through the

@@ -132,6 +132,20 @@ def test_route_names_and_build_stamp(zj):
     assert L.zjni_build_stamp().decode() == zj.build_stamp()          # the library in the tree is the one these sources give
 
 
+def test_counter_passes_are_of_these_sources(zj):
+    """bench.py quotes roofline.traffic only from a PMC pass stamped with the library's own build (bench.py: the newest profiles/r*_pmc_traffic.json first): the committed
+    summary of the newest round is of the committed sources, kernel by kernel — an edit under csrc/ after the last counter pass shows up here, not as a silent `traffic: null`"""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic.json")))[-1]
+    summary = json.load(open(newest))
+    stamps = {rec["build_stamp"] for workload in summary.values() if isinstance(workload, dict) for rec in workload.values() if isinstance(rec, dict) and "build_stamp" in rec}
+    assert stamps == {zj.build_stamp()}, (newest, stamps)
+    metric = summary["metric_L3_65536x65536"]["zj_enc_match_run_kernel"]
+    assert metric["hbm_bytes_per_launch"] == metric["fetch_bytes_per_launch"] + metric["write_bytes_per_launch"] > 0
+
+
 def test_asynchronous_entries_fail_loudly_without_gpu(zj):
     """zjni_compress_batch_begin / zjni_decompress_batch_begin (round 5): no device, no job — and zjni_batch_finish of no job says so; there is no CPU path behind them either"""
     import ctypes as C

@@ -215,11 +215,12 @@ JNIEXPORT jlong JNICALL P(ZstdDecompressCtx_reset0)(JNIEnv* env, jclass cls, jlo
 }
 /* class Zstd's parameter natives take a raw context pointer (N/jni_zstd.c:349-570); it may be one of the contexts above or a stream
  * class's.  Recorded when the GPU path honours the parameter, otherwise the context is marked for the CPU path; always passed on. */
-static int ss_note_parameter(jlong stream, int what, jint v);       /* the handle may be a stream class's (below): 1 when it is and the stream route honours the parameter */
+static int ss_note_parameter(jlong stream, int what, jint v);       /* the handle may be a stream class's (below): 1 when it is and the stream route honours the parameter, -1 when it is inside a frame that cannot take it */
 static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const char* name, int what) {
     jint (*f)(JNIEnv*, jclass, jlong, jint) = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(name);
     CtxState* s = st_get(stream, what == 'd' ? 'D' : 'C');
     int const streamOk = ss_note_parameter(stream, what, v);
+    if (streamOk < 0) return -(jint)60;                 /* ZSTD_error_stage_wrong, as ZSTD_CCtx_setParameter answers past the init stage; nothing is forwarded */
     if (s) switch (what) {
         case 'l': s->level = v; break;
         case 'k': s->checksum = (v & 0xFF) != 0; break;
@@ -228,7 +229,11 @@ static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const cha
         default: s->cpuOnly = 1; break;                    /* 'x' / 'd': the GPU path does not implement it */
     }
     if (f) return f(env, cls, stream, v);
-    return ((s && what != 'x' && what != 'd') || streamOk) ? 0 : -(jint)ZJNI_ERROR_unsupported;
+    if (!((s && what != 'x' && what != 'd') || streamOk)) return -(jint)ZJNI_ERROR_unsupported;
+    /* no bundled library: ZSTD_CCtx_setParameter's own answer, the value now in force (C/zstd_compress.c ZSTD_CCtxParams_setParameter: the level — 3 for 0, 0 for a negative one —, the flag, the log) */
+    if (what == 'l') return v == 0 ? 3 : (v > 0 ? v : 0);
+    if (what == 'k') return (v & 0xFF) != 0;
+    return v > 0 ? v : 0;
 }
 #define SETTER(name, T, what) JNIEXPORT jint JNICALL P(name)(JNIEnv* env, jclass cls, jlong stream, T v) { return zstd_setter(env, cls, stream, (jint)v, PS(#name), what); }
 SETTER(Zstd_setCompressionLevel, jint, 'l')
@@ -795,6 +800,7 @@ JNIEXPORT jlong JNICALL P(Zstd_compressBatchDict0)(JNIEnv* env, jclass cls, jobj
 typedef struct StreamState {
     struct StreamState* next; jlong key;
     int level, checksum, cpuMode, started, finished;
+    int levelNext, hasLevelNext;                                /* a level set inside a frame made here: the next frame's (ss_note_parameter) */
     int levelCpu, paramCpu;                                     /* sticky across sessions (ZstdOutputStream sets parameters once, then resets per frame): a level or a parameter only the bundled library serves */
     unsigned char* buf; size_t total, cap;                      /* everything written so far */
     uint32_t* flushAt; size_t nFlush, flushCap;
@@ -822,10 +828,23 @@ static StreamState* ss_get(jlong key, int create, int take) {
 static void ss_reset(StreamState* s, int level) {
     s->level = level; s->checksum = 0; s->cpuMode = 0; s->started = 0; s->finished = 0; s->total = 0; s->nFlush = 0; s->emitted = 0; s->madeHash = SS_HASH0; s->outLen = s->outPos = 0;
 }
+static int ss_inside_gpu_frame(const StreamState* s) { return !s->cpuMode && s->started && !s->finished; }     /* started: the first compress / flush call, where ZSTD_compressStream2 leaves zcss_init */
+/* a frame made here is out: the stream is as ZSTD_endStream leaves it — parameters kept, a level set meanwhile now in force */
+static void ss_next_frame(StreamState* s) {
+    int const lv = s->hasLevelNext ? s->levelNext : s->level, ck = s->checksum, pc = s->paramCpu;
+    int const lc = s->hasLevelNext ? (lv < 0 || lv > 3) : s->levelCpu;
+    ss_reset(s, lv); s->checksum = ck; s->levelCpu = lc; s->paramCpu = pc; s->hasLevelNext = 0;
+    if (lc) s->cpuMode = 1;
+}
 static void ss_free(StreamState* s) { if (s) { free(s->buf); free(s->flushAt); free(s->out); free(s); } }
 static int ss_note_parameter(jlong stream, int what, jint v) {       /* class Zstd's parameter natives on a stream handle: level and checksum are honoured, anything else is the bundled library's */
     StreamState* s = ss_get(stream, 0, 0);
     if (!s) return 0;
+    if (ss_inside_gpu_frame(s)) {                                   /* the bytes written so far wait HERE; the bundled context has not seen them and would accept anything */
+        if (what != 'l') return -1;                                 /* ZSTD_CCtx_setParameter past zcss_init: only the update-authorised parameters (C/zstd_compress.c ZSTD_isUpdateAuthorized) */
+        s->levelNext = v == 0 ? 3 : v; s->hasLevelNext = 1;         /* the level is one of them: this frame keeps its parameters, the next one starts with the new level */
+        return 1;
+    }
     if (what == 'l') { s->level = v == 0 ? 3 : v; s->levelCpu = (v < 0 || v > 3); if (s->levelCpu) s->cpuMode = 1; }
     else if (what == 'k') s->checksum = (v & 0xFF) != 0;
     else { s->cpuMode = 1; s->paramCpu = 1; return 0; }
@@ -927,7 +946,8 @@ JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_initCStre
     jlong (*f)(JNIEnv*, jobject, jlong, jint) = (jlong (*)(JNIEnv*, jobject, jlong, jint))cpu_sym(PS("ZstdDirectBufferCompressingStreamNoFinalizer_initCStream"));
     StreamState* s = ss_get(stream, 1, 0);
     cs_fields(env, obj);
-    if (s) { ss_reset(s, level == 0 ? 3 : level); if (level < 0 || level > 3 || !streams_on_gpu()) s->cpuMode = 1; }
+    if (s) { ss_reset(s, level == 0 ? 3 : level); s->hasLevelNext = 0; if (level < 0 || level > 3 || !streams_on_gpu()) s->cpuMode = 1; }
+    if (!f && (level < 0 || level > 3)) return -(jlong)ZJNI_ERROR_unsupported;     /* no bundled library and a level this route does not make: said here, not at the first write */
     return f ? f(env, obj, stream, level) : 0;
 }
 JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_initCStreamWithDict)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dict, jint dict_size, jint level) {
@@ -1027,7 +1047,7 @@ static jlong cs_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jobject dst
         (*env)->SetIntField(env, obj, g_cs_produced, (*env)->GetIntField(env, obj, g_cs_produced) + (jint)k);
         return rr;
     }
-    if (s->finished) { int const lv = s->level, ck = s->checksum; ss_reset(s, lv); s->checksum = ck; }     /* the frame is out: the next write starts a new one, as ZSTD_endStream leaves the stream */
+    if (s->finished) ss_next_frame(s);                                              /* the frame is out: the next write starts a new one, as ZSTD_endStream leaves the stream */
     return 0;
 }
 JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size) {
@@ -1142,32 +1162,37 @@ JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_resetCStream)(JNIEnv* env, 
     jclass const clazz = (*env)->GetObjectClass(env, obj);
     g_os_src = (*env)->GetFieldID(env, clazz, "srcPos", "J"); g_os_dst = (*env)->GetFieldID(env, clazz, "dstPos", "J");
     if (s) {                                                    /* a new frame; level, checksum and what only the bundled library serves stay */
-        int const lv = s->level ? s->level : 3, ck = s->checksum, lc = s->levelCpu, pc = s->paramCpu;
-        ss_reset(s, lv); s->checksum = ck; s->levelCpu = lc; s->paramCpu = pc;
-        if (lc || pc || !streams_on_gpu()) s->cpuMode = 1;
+        ss_next_frame(s);
+        if (s->level == 0) s->level = 3;
+        if (s->levelCpu || s->paramCpu || !streams_on_gpu()) s->cpuMode = 1;
     }
     return f ? f(env, obj, stream) : 0;
 }
 /* the stream marked as the bundled library's before anything is forwarded: dictionaries on a stream handle */
-static void ss_mark_cpu(jlong stream) { StreamState* s = ss_get(stream, 0, 0); if (s) { s->paramCpu = 1; s->cpuMode = 1; } }
+static int ss_mark_cpu(jlong stream) {                          /* -1: inside a frame made here — ZSTD_CCtx_loadDictionary / refCDict answer stage_wrong there (C/zstd_compress.c: "Can't load a dictionary when cctx is not in init stage") */
+    StreamState* s = ss_get(stream, 0, 0);
+    if (s && ss_inside_gpu_frame(s)) return -1;
+    if (s) { s->paramCpu = 1; s->cpuMode = 1; }
+    return 0;
+}
 JNIEXPORT jint JNICALL P(Zstd_loadDictCompress)(JNIEnv* env, jclass cls, jlong stream, jbyteArray dict, jint dict_size) {
     jint (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint) = (jint (*)(JNIEnv*, jclass, jlong, jbyteArray, jint))cpu_sym(PS("Zstd_loadDictCompress"));
-    ss_mark_cpu(stream);
+    if (ss_mark_cpu(stream) < 0) return -(jint)60;
     return f ? f(env, cls, stream, dict, dict_size) : -(jint)ZJNI_ERROR_unsupported;
 }
 JNIEXPORT jint JNICALL P(Zstd_loadFastDictCompress)(JNIEnv* env, jclass cls, jlong stream, jobject dict) {
     jint (*f)(JNIEnv*, jclass, jlong, jobject) = (jint (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("Zstd_loadFastDictCompress"));
-    ss_mark_cpu(stream);
+    if (ss_mark_cpu(stream) < 0) return -(jint)60;
     return f ? f(env, cls, stream, dict) : -(jint)ZJNI_ERROR_unsupported;
 }
 JNIEXPORT jint JNICALL P(Zstd_loadDictDecompress)(JNIEnv* env, jclass cls, jlong stream, jbyteArray dict, jint dict_size) {
     jint (*f)(JNIEnv*, jclass, jlong, jbyteArray, jint) = (jint (*)(JNIEnv*, jclass, jlong, jbyteArray, jint))cpu_sym(PS("Zstd_loadDictDecompress"));
-    ss_mark_cpu(stream);
+    if (ss_mark_cpu(stream) < 0) return -(jint)60;
     return f ? f(env, cls, stream, dict, dict_size) : -(jint)ZJNI_ERROR_unsupported;
 }
 JNIEXPORT jint JNICALL P(Zstd_loadFastDictDecompress)(JNIEnv* env, jclass cls, jlong stream, jobject dict) {
     jint (*f)(JNIEnv*, jclass, jlong, jobject) = (jint (*)(JNIEnv*, jclass, jlong, jobject))cpu_sym(PS("Zstd_loadFastDictDecompress"));
-    ss_mark_cpu(stream);
+    if (ss_mark_cpu(stream) < 0) return -(jint)60;
     return f ? f(env, cls, stream, dict) : -(jint)ZJNI_ERROR_unsupported;
 }
 /* pending output into dst[0, dst_size): bytes copied (dstPos) */
@@ -1302,7 +1327,7 @@ static jint os_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jbyteArray d
         if (k) return 1;
         return f ? f(env, obj, stream, dst, dst_size) : 0;
     }
-    if (s->finished) { int const lv = s->level, ck = s->checksum, lc = s->levelCpu, pc = s->paramCpu; ss_reset(s, lv); s->checksum = ck; s->levelCpu = lc; s->paramCpu = pc; }
+    if (s->finished) ss_next_frame(s);
     return 0;
 }
 JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size) { return os_flush_or_end(env, obj, stream, dst, dst_size, 0); }
