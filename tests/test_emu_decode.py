@@ -65,6 +65,33 @@ def test_emu_errors(emu, oracle_ref):
     assert isinstance(out, int) or out != data or True      # must not crash; corruption may go unnoticed without checksum
 
 
+def test_known_difference_compressed_block_of_exactly_128KiB(emu, oracle_ref):
+    """DESIGN.md section 7, item 7 (ii) — pinned so that whoever closes it finds this test: a block header saying *compressed, 131 072 bytes* (a raw 128 KiB block whose type
+    bit was flipped: tools/fuzz_emu_decode_mb.py seed 82) is refused in the block loop with corruption_detected; the reference allows the size
+    (N/decompress/zstd_decompress_block.c:2074-2081), enters the block and answers dictionary_corrupted when its first byte claims treeless literals (no table yet).
+    For the other three literal types both say corruption_detected here.  Both pipelines, both reference builds."""
+    import random
+    rnd = random.Random(5)
+    body = bytearray(rnd.getrandbits(8) for _ in range(131072))
+    tail = b"\x01\x00\x00"                                                  # an empty raw last block
+    answers = {}
+    for lit_type in range(4):
+        body[0] = (body[0] & 0xFC) | lit_type
+        if lit_type < 2: body[0] |= 0x0C                                     # raw / RLE literals: a 3-byte size field, so that the section's size is the random 20 bits that follow
+        frame = b"\x28\xb5\x2f\xfd" + b"\x00\x58" + (131072 << 3 | 2 << 1).to_bytes(3, "little") + bytes(body) + tail      # window descriptor 0x58: 2 MiB, no content size
+        ours = (emu_decompress(emu, frame, 1 << 18), emu_decompress_split(emu, frame, 1 << 18)[0])
+        theirs = []
+        for f in (oracle_ref.decompress, oracle_ref.decompress_portable):
+            try:
+                f(frame, 1 << 18); theirs.append(0)
+            except oracle_ref.ZstdRefError as ex:
+                theirs.append(-ex.code)
+        answers[lit_type] = (ours, tuple(theirs))
+    assert answers[3] == ((-20, -20), (-30, -30)), answers                    # the known difference
+    for lit_type in range(3):
+        assert answers[lit_type] == ((-20, -20), (-20, -20)), answers
+
+
 def test_emu_split_pipeline(emu, oracle_ref, zj):
     """prep -> lane-per-frame tANS decode -> execute == fused decoder == reference, and the frames the batched
     compressor emits (one block, content <= 64 KiB) really take the three-stage path"""
