@@ -594,7 +594,7 @@ static size_t decode_frame(u8* dst, size_t dstCap, const u8* src, size_t srcSize
             } else {
                 size_t d;
                 if (sz > fh.blockSizeMax) { r = ERR(srcSize_wrong); goto done; }    /* zstd_decompress_block.c:2081 */
-                if (sz >= BLOCK_MAX) { r = ERR(corruption_detected); goto done; }   /* zstd_decompress_block.c:2073-2081 */
+                /* a compressed block of exactly blockSizeMax is allowed since 1.5.4 (zstd_decompress_block.c:2073-2081): the block is entered and answers for itself */
                 d = decode_block(ds, dst, op, oend, ip, sz, fh.blockSizeMax);
                 if (zso_is_error(d)) { r = d; goto done; }
                 op += d;

@@ -88,6 +88,13 @@ def test_known_difference_compressed_block_of_exactly_128KiB(emu, oracle_ref):
                 theirs.append(-ex.code)
         answers[lit_type] = (ours, tuple(theirs))
     assert answers[3] == ((-20, -20), (-30, -30)), answers                    # the known difference
+    # ... and the frame of this kind that is VALID: raw literals filling the block, no sequences — the reference (and the oracle restatement) decode it, the kernels refuse it
+    n_lit = 131072 - 3 - 1
+    lits = bytes(rnd.getrandbits(8) for _ in range(n_lit))
+    valid = b"\x28\xb5\x2f\xfd" + b"\x00\x58" + (131072 << 3 | 2 << 1 | 1).to_bytes(3, "little") + bytes([0 | 3 << 2 | (n_lit & 0xF) << 4, (n_lit >> 4) & 0xFF, n_lit >> 12]) + lits + b"\x00"
+    from oracle import port
+    assert oracle_ref.decompress(valid, 1 << 18) == lits and oracle_ref.decompress_portable(valid, 1 << 18) == lits and port.decompress(valid, 1 << 18) == lits
+    assert emu_decompress(emu, valid, 1 << 18) == -20 and emu_decompress_split(emu, valid, 1 << 18)[0] == -20
     for lit_type in range(3):
         assert answers[lit_type] == ((-20, -20), (-20, -20)), answers
 
