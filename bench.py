@@ -37,8 +37,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-# HIP's default number of hardware queues for this process, said out loud: the library would ask for 16 in a process whose first HIP call is its own (two host batches in
-# flight need them, profiles/r05/e_); the device-resident pipelines timed here measured 3 % faster with 4 (profiles/r05/raw_call25.txt).
+# HIP's default number of hardware queues (4), said out loud and recorded in the line (`hw_queues`): it is what a process gets whose launcher sets nothing — the library
+# does not touch the environment.  Two host batches in flight want 16 (profiles/r05/e_): that figure comes from a child process started with 16 and says so.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 sys.path.insert(0, ROOT)
 
@@ -144,12 +144,15 @@ def git_head():
         return None
 
 
-def cpu_baseline_leg(a, host, size, n, level, dictionary, offsets=None):
-    """all-core + single-core timing of the reference on the host (oracle/cpu_baseline.c zso_cpu_baseline2)"""
+def cpu_baseline_leg(a, host, size, n, level, dictionary, offsets=None, keep=None):
+    """all-core + single-core timing of the reference on the host (oracle/cpu_baseline.c zso_cpu_baseline3).  keep (a dict): receives the reference's frames of
+    the whole sample ("frames": back to back, "sizes") for the byte-identity gate over every frame of the batch."""
     from oracle import port
     threads, budget = host_cpu_budget()
     total = int(offsets[-1]) if offsets is not None else n * size
-    r = port.cpu_baseline2(host, size, n, level, threads, a.cpu_seconds, dictionary, offsets=offsets)
+    r = port.cpu_baseline2(host, size, n, level, threads, a.cpu_seconds, dictionary, offsets=offsets, keep_frames=keep is not None)
+    if keep is not None:
+        keep["frames"] = r.pop("frames"); keep["sizes"] = r.pop("sizes")
     k = max(1, min(n, (64 << 20) // max(size, 1)))                     # single core: 64 MiB of the same buffers
     r1 = port.cpu_baseline2(host, size, k, level, 1, min(a.cpu_seconds, 1.0), dictionary, offsets=None if offsets is None else offsets[:k + 1])
     tot1 = int(offsets[k]) if offsets is not None else k * size
@@ -189,14 +192,14 @@ def end_to_end_leg(zj, host, size, m, level, cd, dd):
     ok = all(res2[i] == size for i in range(m)) and bool((back == src).all())
     tot = m * size
     csum = int(sum(res[i] for i in range(m)))
-    # Two batches in flight (zjni_*_batch_begin / zjni_batch_finish: the device's two staging slots): tools/e2e.py in a process of its own, because it needs more HIP hardware
-    # queues than this one runs with (GPU_MAX_HW_QUEUES: 4 here — the device-resident timed region is 3 % faster with HIP's default — 16 there, the library's own default for a
-    # process whose first HIP call is the library's, as in a JVM).  8 batches of the same shape, never more than two begun and not finished; rate = batches / wall time.
+    # Two batches in flight (zjni_*_batch_begin / zjni_batch_finish: the device's two staging slots): tools/e2e.py in a process of its own, STARTED with GPU_MAX_HW_QUEUES=16
+    # (what INTEGRATION.md section 2 tells a deployment to put into the JVM's environment; this process runs with HIP's default 4, recorded as `hw_queues` in both places).
+    # 8 batches of the same shape, never more than two begun and not finished; rate = batches / wall time.
     piped = None
     if not cd and level == 3:
         try:
             L.zjni_release_scratch()                              # the child allocates its own pipelines' scratch (~70 GiB) beside this process's buffers
-            env = dict(os.environ); env.pop("GPU_MAX_HW_QUEUES", None); env["E2E_BATCHES"] = "8"
+            env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = "16"; env["E2E_BATCHES"] = "8"
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e.py"), str(m), str(size), "1"], env=env, capture_output=True, text=True, timeout=600)
             for line in out.stdout.splitlines():
                 if line.startswith("{") and "two_batches_in_flight" in line:
@@ -204,7 +207,8 @@ def end_to_end_leg(zj, host, size, m, level, cd, dd):
             if piped is None:
                 piped = {"error": (out.stderr or out.stdout)[-200:]}
             else:
-                piped["note"] = "tools/e2e.py as a child process (16 HIP hardware queues): zjni_compress_batch_begin / zjni_decompress_batch_begin, two jobs in flight, zjni_batch_finish in order"
+                piped["hw_queues"] = 16
+                piped["note"] = "tools/e2e.py as a child process started with GPU_MAX_HW_QUEUES=16 (the launcher's setting, not the library's): zjni_compress_batch_begin / zjni_decompress_batch_begin, two jobs in flight, zjni_batch_finish in order"
         except Exception as ex:                                  # noqa: BLE001 - a reported extra
             piped = {"error": f"{type(ex).__name__}: {str(ex)[:160]}"}
     # what the host link gives: pinned copies of 1 GiB each way (best of 3), and the time the calls' own bytes need at those rates with both
@@ -481,6 +485,8 @@ def main():
 
     # which match finder served the timed steps: asked of the library, not inferred from the environment
     L = zj.lib()
+    L.zjni_scratch_bytes.restype = C.c_size_t; L.zjni_scratch_bytes.argtypes = []
+    scratch_bytes = int(L.zjni_scratch_bytes())       # what the timed steps made the library allocate and keep on this device (before the extra legs below)
     route = int(L.zjni_last_route()) if mode != "decode_ref" else 0
     lists = None
     if mode != "decode_ref" and hasattr(L, "zjni_last_lists"):
@@ -583,7 +589,22 @@ def main():
             m = min(m, n)
             if host_src is None or host_src.size < m * size:
                 host_src = src[:m * size].cpu().numpy()
-            cpu = cpu_baseline_leg(a, host_src, size, m, level, dict_bytes)
+            kept = {} if mode != "decode_ref" else None
+            cpu = cpu_baseline_leg(a, host_src, size, m, level, dict_bytes, keep=kept)
+            if kept and kept.get("frames") is not None:
+                # EVERY frame of the batch the CPU leg covered against the reference's frame of the same buffer (the gate above looks at the first k):
+                # the headline's frames (still in `comp`) packed back to back on the device, the reference's uploaded, sizes and bytes compared there
+                B.pack(csz[:m], comp, comp_off[:m + 1], out=packed, out_off=packed_off[:m + 1])
+                torch.cuda.synchronize()
+                rs = torch.from_numpy(kept["sizes"].astype(np.int64)).to(dev)
+                same_sizes = bool(torch.equal(rs, csz[:m]))
+                tot_ref = int(kept["sizes"].sum())
+                same = same_sizes and bool(torch.equal(packed[:tot_ref], torch.from_numpy(kept["frames"][:tot_ref]).to(dev)))
+                gates["all_frames_byte_identical_to_reference"] = {"frames_compared": m, "of": n, "identical": bool(same), "sizes_equal": same_sizes}
+                if not same_sizes:
+                    gates["all_frames_byte_identical_to_reference"]["first_size_difference"] = int((rs != csz[:m]).nonzero()[0].item())
+                del rs
+            kept = None
             gpu_c_sample = int(csz[:m].sum().item())
             gates["ratio_gpu_over_cpu_size"] = gpu_c_sample / max(cpu["compressed_bytes"], 1)
             gates["ratio_within_1pct"] = gpu_c_sample <= 1.01 * cpu["compressed_bytes"]
@@ -666,7 +687,8 @@ def main():
                        "name": a.config, "level": level, "buffers_per_gpu": n, "buffer_bytes": size, "parallelism": f"batch-sharded x{world}",
                        "gather": bool(world > 1 and not a.no_gather), "value_is": cfg["headline"],
                        **({"hashLog": 16, "chainLog": 15, "table_sizes": "the reference's own for this level and size (N/compress/clevels.h + ZSTD_adjustCParams): nothing but the level is set; the LDS-sized 14 / 13 behind setHashLog / setChainLog: see lds_tables_level3"} if (level == 3 and 32768 < size <= 131072 and mode in ("both",)) else {})},
-            "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel, "frames_per_launch": lists},
+            "library": {"build_stamp": stamp, "match_route": route, "match_kernel": route_kernel, "frames_per_launch": lists,
+                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "scratch_bytes": scratch_bytes, "scratch_GiB": scratch_bytes / GIB},
             "lds_tables_level3": lds3,
             "small_batch_level3": small,
             "compress_GiBps_per_gpu": (per_gpu / (mc / 1e3)) if mode != "decode_ref" else None, "decompress_GiBps_per_gpu": per_gpu / (md / 1e3),

@@ -196,8 +196,10 @@ static double pool_pass(Pool* p, int mode, const unsigned char* src, const size_
     t1 = now_s();
     return t1 - t0;
 }
-int zso_cpu_baseline2(const char* libpath, const void* data, const size_t* srcOffIn, size_t bufSize, size_t n, int level, int hashLog, int chainLog,
-                      int threads, double minSeconds, const void* dict, size_t dictSize, double* out) {
+/* keepPacked / keepCap / keepSizes (optional): the reference's frames of the last compress pass, back to back, and their sizes — bench.py compares EVERY frame of
+ * the GPU's batch with them (outside the timed region).  keepCap too small: nothing is copied and out[2] still says how many bytes there were. */
+int zso_cpu_baseline3(const char* libpath, const void* data, const size_t* srcOffIn, size_t bufSize, size_t n, int level, int hashLog, int chainLog,
+                      int threads, double minSeconds, const void* dict, size_t dictSize, double* out, unsigned char* keepPacked, size_t keepCap, size_t* keepSizes) {
     RefLib lib; Pool p; size_t i, total = 0, maxSrc = bufSize; int t, rc = -1, passes; double best, sum, s;
     size_t* srcOff = (size_t*)malloc(sizeof(size_t) * (n + 1)); size_t* cOff = (size_t*)malloc(sizeof(size_t) * (n + 1));
     size_t* cSize = (size_t*)malloc(sizeof(size_t) * n); size_t* dSize = (size_t*)malloc(sizeof(size_t) * n); size_t* pOff = (size_t*)malloc(sizeof(size_t) * (n + 1));
@@ -237,6 +239,8 @@ int zso_cpu_baseline2(const char* libpath, const void* data, const size_t* srcOf
     if (!packed || p.failed) { p.failed = 1; }
     else {
         for (i = 0; i < n; i++) memcpy(packed + pOff[i], comp + cOff[i], pOff[i + 1] - pOff[i]);
+        if (keepPacked && keepCap >= total) memcpy(keepPacked, packed, total);
+        if (keepSizes) for (i = 0; i < n; i++) keepSizes[i] = cSize[i];
         pool_pass(&p, 1, packed, pOff, back, srcOff, dSize);
         for (passes = 0, best = 1e30, sum = 0; passes < 2 || sum < minSeconds; passes++) {
             s = pool_pass(&p, 1, packed, pOff, back, srcOff, dSize);
@@ -254,4 +258,8 @@ done:
     if (p.ddict) p.df.freeDDict(p.ddict);
     free(srcOff); free(cOff); free(cSize); free(dSize); free(pOff); free(comp); free(packed); free(back); free(th); free(args);
     return rc;
+}
+int zso_cpu_baseline2(const char* libpath, const void* data, const size_t* srcOffIn, size_t bufSize, size_t n, int level, int hashLog, int chainLog,
+                      int threads, double minSeconds, const void* dict, size_t dictSize, double* out) {
+    return zso_cpu_baseline3(libpath, data, srcOffIn, bufSize, n, level, hashLog, chainLog, threads, minSeconds, dict, dictSize, out, NULL, 0, NULL);
 }

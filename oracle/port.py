@@ -124,28 +124,38 @@ def cpu_baseline(data: bytes, buf_size: int, level: int, threads: int, reps: int
 
 
 def cpu_baseline2(data, buf_size: int, n: int, level: int, threads: int, min_seconds: float = 1.0, dictionary: bytes = None,
-                  hash_log: int = 0, chain_log: int = 0, offsets=None):
+                  hash_log: int = 0, chain_log: int = 0, offsets=None, keep_frames: bool = False):
     """The reference's libzstd on `threads` host threads that exist (with their reused contexts) before the clock starts, released
     by a barrier, repeated until `min_seconds` of timed work are done — oracle/cpu_baseline.c zso_cpu_baseline2.
     `data`: bytes or a numpy uint8 array (n buffers of buf_size bytes, or `offsets` = n+1 byte offsets).  Returns
-    dict(compress_s, decompress_s, compressed_bytes, exact, passes, mean_compress_s, mean_decompress_s)."""
+    dict(compress_s, decompress_s, compressed_bytes, exact, passes, mean_compress_s, mean_decompress_s) — with keep_frames also
+    frames (numpy uint8: the reference's frames back to back) and sizes (numpy uint64[n])."""
     import numpy as np
     from . import ref
     L = _batch_fn()
-    L.zso_cpu_baseline2.restype = C.c_int
-    L.zso_cpu_baseline2.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                    C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+    L.zso_cpu_baseline3.restype = C.c_int
+    L.zso_cpu_baseline3.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                    C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.c_void_p, C.c_size_t, C.c_void_p]
     if not ref.available():
         raise RuntimeError("oracle/_ref/libzstd_ref.so is not built")
     arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data
     off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
     out = (C.c_double * 8)()
-    rc = L.zso_cpu_baseline2(ref.PATH.encode(), arr.ctypes.data, None if off is None else off.ctypes.data, buf_size, n, level, hash_log, chain_log,
-                             threads, min_seconds, dictionary, len(dictionary) if dictionary else 0, out)
+    keep = sizes = None
+    if keep_frames:                                        # room for every frame at its bound (never more than that)
+        total_src = int(off[-1]) if off is not None else n * buf_size
+        keep = np.empty(total_src + (total_src >> 7) + 1024 * n + 64, dtype=np.uint8); sizes = np.zeros(n, dtype=np.uint64)
+    rc = L.zso_cpu_baseline3(ref.PATH.encode(), arr.ctypes.data, None if off is None else off.ctypes.data, buf_size, n, level, hash_log, chain_log,
+                             threads, min_seconds, dictionary, len(dictionary) if dictionary else 0, out,
+                             keep.ctypes.data if keep is not None else None, keep.size if keep is not None else 0, sizes.ctypes.data if sizes is not None else None)
     if rc != 0:
-        raise RuntimeError("zso_cpu_baseline2 failed")
-    return dict(compress_s=out[0], decompress_s=out[1], compressed_bytes=int(out[2]), exact=bool(out[3]), passes=(int(out[4]), int(out[5])),
-                mean_compress_s=out[6], mean_decompress_s=out[7], kind="reference")
+        raise RuntimeError("zso_cpu_baseline3 failed")
+    r = dict(compress_s=out[0], decompress_s=out[1], compressed_bytes=int(out[2]), exact=bool(out[3]), passes=(int(out[4]), int(out[5])),
+             mean_compress_s=out[6], mean_decompress_s=out[7], kind="reference")
+    if keep_frames:
+        r["frames"] = keep[:int(out[2])] if int(out[2]) <= keep.size else None
+        r["sizes"] = sizes
+    return r
 
 
 def compress_many_packed(data, buf_size: int, level: int, threads: int):

@@ -105,6 +105,6 @@ def huffman_weights(hist, max_bits=11):
     return bytes([127 + last]) + body
 
 
-def build(content, dict_id, lit_hist, of_norm, of_log, ml_norm, ml_log, ll_norm, ll_log, reps=(1, 4, 8)):
-    return (struct.pack("<II", 0xEC30A437, dict_id) + huffman_weights(lit_hist) + write_ncount(of_norm, of_log)
+def build(content, dict_id, lit_hist, of_norm, of_log, ml_norm, ml_log, ll_norm, ll_log, reps=(1, 4, 8), huf_max_bits=11):
+    return (struct.pack("<II", 0xEC30A437, dict_id) + huffman_weights(lit_hist, huf_max_bits) + write_ncount(of_norm, of_log)
             + write_ncount(ml_norm, ml_log) + write_ncount(ll_norm, ll_log) + struct.pack("<III", *reps) + content)

@@ -156,3 +156,49 @@ def test_emu_cdict_without_dict_id(emu, oracle_ref):
                 if src:
                     assert want != rc.compress(src, ck)
         rc.close(); ec.close()
+
+
+def test_dictionary_with_a_huffman_table_12_bits_deep(emu, oracle_ref):
+    """A dictionary whose literals table is 12 bits deep (HUF_TABLELOG_MAX: HUF_readCTable, N/compress/huf_compress.c:292-345, and ZSTD_loadDEntropy's
+    HUF_readDTableX2_wksp, N/decompress/zstd_decompress.c:1473, both take it; the trainer never writes one) was refused at load in rounds 1-5.  Compress side: the
+    same frames as ZSTD_CCtx_refCDict + ZSTD_compress2, treeless literals coded with the dictionary's 12-bit codes included.  Decompress side: those frames on both
+    pipelines, and damaged ones answered as the reference's portable build answers them."""
+    from util import emu_decompress_dict
+    r = random.Random(12)
+    alphabet = b"etaoinshrdlu."                                     # 13 symbols, counts 1, 1, 2, 4 ... 2048: a code 12 bits deep
+    hist = [0] * 256
+    for k, ch in enumerate(reversed(alphabet)):
+        hist[ch] = 1 if k == 0 else 1 << (k - 1)
+    pool = bytes(ch for ch in alphabet for _ in range(hist[ch]))
+
+    def draw(n):
+        return bytes(r.choice(pool) for _ in range(n))
+    content = draw(3000) + alphabet * 3
+    d = du.build(content, 4242, hist, du.normalise([1] * 20, 7), 7, du.normalise([3 if i < 20 else 1 for i in range(53)], 8), 8, du.normalise([4 if i < 10 else 1 for i in range(36)], 8), 8,
+                 huf_max_bits=12)
+    import ctypes as C
+    R = oracle_ref.lib()
+    R.HUF_readStats.restype = C.c_size_t
+    R.HUF_readStats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
+    w = C.create_string_buffer(256); rank = (C.c_uint * 16)(); nb = C.c_uint(0); tl = C.c_uint(0)
+    assert not R.ZSTD_isError(R.HUF_readStats(w, 256, rank, C.byref(nb), C.byref(tl), d[8:], len(d) - 8)) and tl.value == 12
+    treeless = 0
+    for level in (1, 3):
+        cd = oracle_ref.CDict(d, level); ecd = EmuCDict(emu, d, level)
+        assert ecd.info()["hufRepeat"] == 1
+        for n in (40, 90, 200, 500, 1200, 3000, 7000):
+            for x in (draw(n), draw(n // 2) + content[100:100 + n // 2]):
+                want = cd.compress(x)
+                assert ecd.compress(x) == want, (level, n)
+                hdr = 4 + 1 + 2 + (1 if len(x) < 256 else 2)        # magic, descriptor, dictID 4242 in 2 bytes, content size
+                treeless += (want[hdr] >> 1) & 3 == 2 and want[hdr + 3] & 3 == 3
+                for split in (False, True):
+                    assert emu_decompress_dict(emu, want, len(x), d, split=split) == x, (level, n, split)
+                for _ in range(25):
+                    zb = bytearray(want); zb[r.randrange(hdr, len(zb))] ^= 1 << r.randrange(8); zb = bytes(zb)
+                    try: p = oracle_ref.decompress_portable(zb, len(x), d)
+                    except oracle_ref.ZstdRefError as e: p = -e.code
+                    for split in (False, True):
+                        assert emu_decompress_dict(emu, zb, len(x), d, split=split) == p, (level, n, split, zb.hex())
+        cd.close(); ecd.close()
+    assert treeless >= 8, treeless                                  # literals coded with the dictionary's own 12-bit table

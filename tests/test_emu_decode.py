@@ -65,38 +65,100 @@ def test_emu_errors(emu, oracle_ref):
     assert isinstance(out, int) or out != data or True      # must not crash; corruption may go unnoticed without checksum
 
 
-def test_known_difference_compressed_block_of_exactly_128KiB(emu, oracle_ref):
-    """DESIGN.md section 7, item 7 (ii) — pinned so that whoever closes it finds this test: a block header saying *compressed, 131 072 bytes* (a raw 128 KiB block whose type
-    bit was flipped: tools/fuzz_emu_decode_mb.py seed 82) is refused in the block loop with corruption_detected; the reference allows the size
-    (N/decompress/zstd_decompress_block.c:2074-2081), enters the block and answers dictionary_corrupted when its first byte claims treeless literals (no table yet).
-    For the other three literal types both say corruption_detected here.  Both pipelines, both reference builds."""
+def _mb(emu, frame, cap):
+    import ctypes as C
+    emu.emu_decompress_mb.restype = C.c_ulonglong
+    emu.emu_decompress_mb.argtypes = [C.c_char_p, C.c_uint, C.c_char_p, C.c_ulonglong, C.POINTER(C.c_int)]
+    dst = C.create_string_buffer(max(cap, 1)); used = C.c_int(0)
+    r = emu.emu_decompress_mb(frame, len(frame), dst, cap, C.byref(used))
+    return dst.raw[:r] if r < (1 << 63) else -((1 << 64) - r)
+
+
+def _ref_answers(oracle_ref, frame, cap):
+    out = []
+    for f in (oracle_ref.decompress, oracle_ref.decompress_portable):
+        try:
+            out.append(f(frame, cap))
+        except oracle_ref.ZstdRefError as ex:
+            out.append(-ex.code)
+    return out
+
+
+def test_compressed_block_of_exactly_128KiB(emu, oracle_ref):
+    """A block header saying *compressed, 131 072 bytes* is entered, as the reference's 1.5.7 enters it (N/decompress/zstd_decompress_block.c:2073-2081: the
+    specification allows a compressed block of exactly blockSizeMax; libzstd's encoder never writes one).  Rounds 1-5 refused it in the block loop (the rule of the
+    decoders before 1.5.4) — found by tools/fuzz_emu_decode_mb.py seed 82.  Damaged forms (a raw 128 KiB block whose type bit was flipped, all four literal types:
+    the reference answers dictionary_corrupted when the first byte claims treeless literals) and the VALID frame of this kind (raw literals filling the block, no
+    sequences) on all three pipelines against both reference builds."""
     import random
     rnd = random.Random(5)
     body = bytearray(rnd.getrandbits(8) for _ in range(131072))
     tail = b"\x01\x00\x00"                                                  # an empty raw last block
-    answers = {}
     for lit_type in range(4):
         body[0] = (body[0] & 0xFC) | lit_type
         if lit_type < 2: body[0] |= 0x0C                                     # raw / RLE literals: a 3-byte size field, so that the section's size is the random 20 bits that follow
         frame = b"\x28\xb5\x2f\xfd" + b"\x00\x58" + (131072 << 3 | 2 << 1).to_bytes(3, "little") + bytes(body) + tail      # window descriptor 0x58: 2 MiB, no content size
-        ours = (emu_decompress(emu, frame, 1 << 18), emu_decompress_split(emu, frame, 1 << 18)[0])
-        theirs = []
-        for f in (oracle_ref.decompress, oracle_ref.decompress_portable):
-            try:
-                f(frame, 1 << 18); theirs.append(0)
-            except oracle_ref.ZstdRefError as ex:
-                theirs.append(-ex.code)
-        answers[lit_type] = (ours, tuple(theirs))
-    assert answers[3] == ((-20, -20), (-30, -30)), answers                    # the known difference
-    # ... and the frame of this kind that is VALID: raw literals filling the block, no sequences — the reference (and the oracle restatement) decode it, the kernels refuse it
+        theirs = _ref_answers(oracle_ref, frame, 1 << 18)
+        assert theirs[0] == theirs[1] == (-30 if lit_type == 3 else -20), (lit_type, theirs)
+        assert emu_decompress(emu, frame, 1 << 18) == theirs[1], lit_type
+        assert emu_decompress_split(emu, frame, 1 << 18)[0] == theirs[1], lit_type
+        assert _mb(emu, frame, 1 << 18) == theirs[1], lit_type
     n_lit = 131072 - 3 - 1
     lits = bytes(rnd.getrandbits(8) for _ in range(n_lit))
-    valid = b"\x28\xb5\x2f\xfd" + b"\x00\x58" + (131072 << 3 | 2 << 1 | 1).to_bytes(3, "little") + bytes([0 | 3 << 2 | (n_lit & 0xF) << 4, (n_lit >> 4) & 0xFF, n_lit >> 12]) + lits + b"\x00"
     from oracle import port
-    assert oracle_ref.decompress(valid, 1 << 18) == lits and oracle_ref.decompress_portable(valid, 1 << 18) == lits and port.decompress(valid, 1 << 18) == lits
-    assert emu_decompress(emu, valid, 1 << 18) == -20 and emu_decompress_split(emu, valid, 1 << 18)[0] == -20
-    for lit_type in range(3):
-        assert answers[lit_type] == ((-20, -20), (-20, -20)), answers
+    for last, extra in ((1, b""), (0, tail)):                                # as the frame's only block, and followed by another one
+        for sized in (False, True):                                          # without / with a content size (the latter: the split pipeline's "simple" frame when it is the only block)
+            head = b"\x28\xb5\x2f\xfd" + (b"\x80\x58" + n_lit.to_bytes(4, "little") if sized else b"\x00\x58")
+            valid = head + (131072 << 3 | 2 << 1 | last).to_bytes(3, "little") + bytes([0 | 3 << 2 | (n_lit & 0xF) << 4, (n_lit >> 4) & 0xFF, n_lit >> 12]) + lits + b"\x00" + extra
+            assert oracle_ref.decompress(valid, 1 << 18) == lits and oracle_ref.decompress_portable(valid, 1 << 18) == lits and port.decompress(valid, 1 << 18) == lits
+            assert emu_decompress(emu, valid, 1 << 18) == lits and emu_decompress_split(emu, valid, 1 << 18)[0] == lits and _mb(emu, valid, 1 << 18) == lits, (last, sized)
+            assert emu_decompress(emu, valid, n_lit - 1) == _ref_answers(oracle_ref, valid, n_lit - 1)[1]
+
+
+def test_huffman_tables_12_bits_deep(emu, oracle_ref):
+    """Literals coded with a Huffman table 12 bits deep — HUF_TABLELOG_MAX (N/common/huf.h:37), what the reference's decoder takes (ZSTD_HUFFDTABLE_CAPACITY_LOG,
+    N/decompress/zstd_decompress_internal.h:78; HUF_readDTableX1_wksp / X2, N/decompress/huf_decompress.c:385-518, :1179-1263) although its own encoder stops at 11
+    (LitHufLog) — were refused in rounds 1-5.  Sections made by the reference's own HUF_compress{1,4}X_repeat at tableLog 12 and hand-built ones (one stream, every
+    count of weight-1 symbols: the slots the 2 048-cell form of the table keeps two to a cell, zd_huf_fill), as a frame's only block (with and without a content size:
+    the three-stage pipeline and the block stages), followed by a treeless block that reuses the table, and damaged — every pipeline against both reference builds."""
+    import random
+    from util import deep_huffman_literals, literals_only_block, frame_of_blocks, hand_huffman_section
+    rnd = random.Random(12)
+    deep = 0
+    for seed in range(8):
+        n = rnd.choice([20000, 70000, 131000])
+        lits, sec, depth = deep_huffman_literals(oracle_ref, n, seed)
+        deep += depth == 12
+        blk = literals_only_block(n, sec[4], 4)
+        for frame in (frame_of_blocks([blk]), frame_of_blocks([blk], content_size=n)):
+            assert _ref_answers(oracle_ref, frame, n) == [lits, lits]
+            assert emu_decompress(emu, frame, n) == lits, (seed, depth)
+            assert emu_decompress_split(emu, frame, n)[0] == lits, (seed, depth)
+            assert _mb(emu, frame, n) == lits, (seed, depth)
+        # ... a second block whose treeless literals use the first block's table: the same literals' streams without the tree description
+        tree = sec[4][0] + 1 if sec[4][0] < 128 else 1 + (sec[4][0] - 127 + 1) // 2
+        two = frame_of_blocks([literals_only_block(n, sec[4], 4, last=False), literals_only_block(n, sec[4][tree:], 4, treeless=True)])
+        assert _ref_answers(oracle_ref, two, 2 * n) == [lits * 2, lits * 2]
+        assert emu_decompress(emu, two, 2 * n) == lits * 2 and _mb(emu, two, 2 * n) == lits * 2, seed
+        for _ in range(60):                                              # damaged: the same answer as the portable build — bytes or code
+            zb = bytearray(frame_of_blocks([blk], content_size=n) if rnd.random() < 0.5 else two)
+            for _ in range(rnd.randrange(1, 3)):
+                at = rnd.randrange(6, min(len(zb), 400)) if rnd.random() < 0.6 else rnd.randrange(6, len(zb))
+                zb[at] ^= 1 << rnd.randrange(8)
+            zb = bytes(zb)
+            want = _ref_answers(oracle_ref, zb, 2 * n)[1]
+            assert emu_decompress(emu, zb, 2 * n) == want and emu_decompress_split(emu, zb, 2 * n)[0] == want and _mb(emu, zb, 2 * n) == want, (seed, zb[:40].hex())
+    assert deep >= 6
+    for w1 in (2, 4, 6, 30, 64, 116):                                    # hand-built: w1 symbols of 12 bits, one stream and four
+        for n, streams in ((rnd.randrange(200, 1000), 1), (rnd.randrange(3000, 9000), 4)):
+            lits, section = hand_huffman_section(rnd, n, w1, streams)
+            frame = frame_of_blocks([literals_only_block(n, section, streams)], content_size=n)
+            assert _ref_answers(oracle_ref, frame, n) == [lits, lits], (w1, streams)
+            assert emu_decompress(emu, frame, n) == lits and emu_decompress_split(emu, frame, n)[0] == lits and _mb(emu, frame, n) == lits, (w1, streams)
+            for _ in range(40):
+                zb = bytearray(frame); zb[rnd.randrange(14, len(zb))] ^= 1 << rnd.randrange(8); zb = bytes(zb)
+                want = _ref_answers(oracle_ref, zb, n)[1]
+                assert emu_decompress(emu, zb, n) == want and emu_decompress_split(emu, zb, n)[0] == want, (w1, streams, zb.hex())
 
 
 def test_emu_split_pipeline(emu, oracle_ref, zj):
@@ -248,6 +310,7 @@ def test_huffman_tree_description_reader_matches_reference(emu, oracle_ref):
     reference's workspace test refuses it (fse_decompress.c:273).  Same verdict, symbol count, depth and weights."""
     import ctypes as C
     import random
+    from util import hand_huffman_section
     R = oracle_ref.lib()
     R.HUF_readStats.restype = C.c_size_t
     R.HUF_readStats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
@@ -258,10 +321,14 @@ def test_huffman_tree_description_reader_matches_reference(emu, oracle_ref):
     for _ in range(20):
         a = rnd.choice([4, 17, 60, 200])
         seeds.append(oracle_ref.compress(bytes(min(255, int(rnd.expovariate(1.0 / a))) for _ in range(3000)), 3)[9:149])
-    ok = 0
+    ok = 0; deep = 0
     for it in range(40000):
         k = rnd.random()
-        if k < 0.6:
+        if k < 0.05:                                    # a description 12 bits deep (hand_huffman_section), whole or with a flipped bit
+            sec = hand_huffman_section(rnd, 10, rnd.choice([2, 4, 10, 40, 116]), 1)[1]
+            s = bytearray(sec[:1 + (sec[0] - 127 + 1) // 2])
+            if rnd.random() < 0.5: s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
+        elif k < 0.6:
             s = bytearray(rnd.choice(seeds)); a = rnd.randrange(0, 8); s = s[a:a + rnd.randrange(1, 140)]
             for _ in range(rnd.randrange(0, 3)):
                 if s: s[rnd.randrange(len(s))] ^= 1 << rnd.randrange(8)
@@ -275,12 +342,13 @@ def test_huffman_tree_description_reader_matches_reference(emu, oracle_ref):
         r = R.HUF_readStats(w, 256, rank, C.byref(nb), C.byref(tl), s, len(s))
         w2 = C.create_string_buffer(256); tl2 = C.c_uint(0)
         e = emu.emu_huf_weights(s, len(s), w2, C.byref(tl2))
-        if R.ZSTD_isError(r) or tl.value > 11:          # 12-bit-deep tables: accepted by the reference, not by the kernels
-            assert e == 0 or tl.value > 11, s.hex()
+        if R.ZSTD_isError(r):
+            assert e == 0, s.hex()
         else:
+            deep += tl.value == 12
             ok += 1
             assert e == nb.value and tl2.value == tl.value and w.raw[:nb.value] == w2.raw[:nb.value], s.hex()
-    assert ok > 800
+    assert ok > 800 and deep > 20, (ok, deep)          # (tables 12 bits deep included: HUF_TABLELOG_MAX)
 
 
 def test_emu_fse_table_by_the_wave():

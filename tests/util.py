@@ -225,3 +225,92 @@ def crafted_far_offset_frame(of_code, extra, checksum=False, first_raw=100):
     blk1 = ((first_raw << 3) | 0).to_bytes(3, "little") + raw
     blk2 = ((len(body) << 3) | (2 << 1) | 1).to_bytes(3, "little") + body
     return hdr + blk1 + blk2, total
+
+
+def deep_huffman_literals(ref, n, seed, depth=12):
+    """`n` literal bytes whose Huffman code the reference's coder builds `depth` bits deep (a geometric distribution over ~40 symbols), the reference's
+    HUF_compress{1,4}X_repeat output for them at tableLog = depth (tree description + streams) — what an encoder other than libzstd's (LitHufLog 11) may put into a
+    literals section — and the table depth HUF_readStats reports for it.  Returns (literals, {1: section1, 4: section4}, depth_read)."""
+    R = ref.lib()
+    rnd = random.Random(seed)
+    syms = list(range(256)); rnd.shuffle(syms)
+    k = rnd.randrange(24, 60)
+    lits = bytearray()
+    while len(lits) < n:
+        j = 0
+        while j < k - 1 and rnd.random() < 0.5: j += 1
+        lits.append(syms[j])
+    lits = bytes(lits[:n])
+    out = {}
+    for streams, fn in ((1, R.HUF_compress1X_repeat), (4, R.HUF_compress4X_repeat)):
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        dst = C.create_string_buffer(n + 1024); wk = (C.c_ulonglong * 2048)(); ct = (C.c_size_t * 300)(); rep = C.c_int(0)
+        r = fn(dst, len(dst), lits, n, 255, depth, wk, C.sizeof(wk), ct, C.byref(rep), 0)
+        assert not R.ZSTD_isError(r) and r > 1, R.ZSTD_getErrorName(r)
+        out[streams] = dst.raw[:r]
+    R.HUF_readStats.restype = C.c_size_t
+    R.HUF_readStats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
+    w = C.create_string_buffer(256); rank = (C.c_uint * 16)(); nb = C.c_uint(0); tl = C.c_uint(0)
+    assert not R.ZSTD_isError(R.HUF_readStats(w, 256, rank, C.byref(nb), C.byref(tl), out[4], len(out[4])))
+    return lits, out, tl.value
+
+
+def literals_only_block(lits_len, section, streams, last=True, treeless=False):
+    """a compressed block holding one Huffman-coded literals section (5-byte header form for 4 streams, 3-byte for one) and no sequences"""
+    c = len(section)
+    if streams == 1:
+        assert lits_len < 1024 and c < 1024
+        hdr = ((3 if treeless else 2) | 0 << 2 | lits_len << 4 | c << 14).to_bytes(3, "little")
+    else:
+        hdr = ((3 if treeless else 2) | 3 << 2 | lits_len << 4 | c << 22).to_bytes(5, "little")
+    body = hdr + section + b"\x00"
+    return (len(body) << 3 | 2 << 1 | (1 if last else 0)).to_bytes(3, "little") + body
+
+
+def frame_of_blocks(blocks, content_size=None, window_descriptor=0x58):
+    """magic + a header with a window descriptor (2 MiB by default) and optionally an 8-byte content size + the blocks"""
+    if content_size is None:
+        return b"\x28\xb5\x2f\xfd" + bytes([0x00, window_descriptor]) + b"".join(blocks)
+    return b"\x28\xb5\x2f\xfd" + bytes([0xC0, window_descriptor]) + content_size.to_bytes(8, "little") + b"".join(blocks)
+
+
+def hand_huffman_section(rnd, n, w1, streams):
+    """a Huffman-coded literals section written by hand (N/compress/huf_compress.c:248-290 direct weights, :991-1118 the streams): a complete prefix code 12 bits
+    deep with exactly `w1` symbols of 12 bits (w1 even), symbols < 128 so that the 4-bit weight list describes it.  Returns (literals, section bytes)."""
+    assert w1 % 2 == 0 and 2 <= w1 <= 116
+    # code lengths: w1 leaves at depth 12; the w1/2 internal nodes above them are completed into a full tree by one leaf at each depth where the count is odd
+    lengths = [12] * w1
+    need = w1 // 2                                  # nodes at depth 11 that are parents of the 12-bit leaves
+    depth = 11
+    while depth >= 1:
+        if need % 2 == 1 or (depth == 1 and need == 1):
+            lengths.append(depth); need += 1
+        need //= 2; depth -= 1
+    assert need == 1 and len(lengths) <= 128 and sum(2.0 ** -l for l in lengths) == 1.0
+    syms = sorted(rnd.sample(range(128), len(lengths)))
+    rnd.shuffle(lengths)
+    nb = dict(zip(syms, lengths))
+    last = syms[-1]
+    weights = [13 - nb[s] if s in nb else 0 for s in range(last)]                     # the last symbol's weight is implied
+    hdr = bytes([127 + len(weights)]) + bytes(((weights[i] << 4) | (weights[i + 1] if i + 1 < len(weights) else 0)) for i in range(0, len(weights), 2))
+    # canonical codes: slots by ascending weight, ascending symbol inside a weight; code = first slot >> (weight - 1)
+    code = {}; slot = 0
+    for w in range(1, 13):
+        for s in syms:
+            if 13 - nb[s] == w: code[s] = slot >> (w - 1); slot += 1 << (w - 1)
+    assert slot == 4096
+    pool = [s for s in syms for _ in range(max(1, 4096 >> nb[s] >> 4))]
+    lits = bytes(rnd.choice(pool) if rnd.random() < 0.8 else rnd.choice(syms) for _ in range(n))
+
+    def stream(part):
+        acc = 0; pos = 0
+        for b in reversed(part):
+            acc |= code[b] << pos; pos += nb[b]
+        acc |= 1 << pos
+        return acc.to_bytes(pos // 8 + 1, "little")
+    if streams == 1:
+        return lits, hdr + stream(lits)
+    seg = (n + 3) // 4
+    parts = [stream(lits[i * seg:(i + 1) * seg] if i < 3 else lits[3 * seg:]) for i in range(4)]
+    return lits, hdr + b"".join(len(p).to_bytes(2, "little") for p in parts[:3]) + b"".join(parts)

@@ -2,9 +2,7 @@
 zd_lit_block -> zd_exec_frame_multi; lane-serial build) against the reference: one-shot frames of several blocks (levels 1-19,
 checksum on/off), stream frames with flushes, and damaged copies of both (bit flips, byte stores, truncation, short destinations),
 which have to be answered like the reference's portable decoder loops answer them (bytes, or the same error code).
-Known difference, counted apart (known_full_size_block): a COMPRESSED block whose header says exactly 128 KiB (a raw 128 KiB block whose type bit was flipped) is refused
-here with corruption_detected before its content is looked at (zj_decode.h: the block loop); the reference decodes such a block and reports what it finds inside — for
-treeless literals without a table that is dictionary_corrupted (round 5, seed 82: 2 of 120 000 damaged frames).
+(Rounds 1-5 counted one class apart: a compressed block of exactly 128 KiB, refused in the block loop; entered like the reference enters it since round 6.)
 usage: fuzz_emu_decode_mb.py <seed> <seconds> [EMU_MB_LIT]   TEST INFRASTRUCTURE."""
 import sys, time, random, os
 import ctypes as C
@@ -41,17 +39,7 @@ def gen(n):
     while left > 0:
         m = min(left, rnd.choice([1000, 30000, 131072, 200000])); parts.append(gen(m)[:m]); left -= m
     return b"".join(parts)
-def full_size_compressed_block(z):
-    """a compressed block of exactly 128 KiB somewhere in the frame's block chain (the known difference above)"""
-    if len(z) < 6: return False
-    fhd = z[4]; ss = (fhd >> 5) & 1; pos = 5 + (0 if ss else 1) + [0, 1, 2, 4][fhd & 3] + [1 if ss else 0, 2, 4, 8][fhd >> 6]
-    while pos + 3 <= len(z):
-        h = z[pos] | z[pos + 1] << 8 | z[pos + 2] << 16; t = (h >> 1) & 3; sz = h >> 3
-        if t == 2 and sz == 131072: return True
-        if (h & 1) or t == 3: return False
-        pos += 3 + (1 if t == 1 else sz)
-    return False
-t0 = time.time(); cases = 0; bad = 0; corrupted = 0; served = 0; known = 0
+t0 = time.time(); cases = 0; bad = 0; corrupted = 0; served = 0
 while time.time() - t0 < budget:
     n = rnd.choice([rnd.randrange(131073, 400000), rnd.randrange(131073, 1200000), 262144, 262145, 393216, rnd.randrange(0, 131073)])
     d = gen(n)[:n]; lvl = rnd.choice([1, 2, 3, 4, 5, 7, 9, 12, 16, 19] if n < 600000 else [1, 3, 5, 9])
@@ -79,9 +67,7 @@ while time.time() - t0 < budget:
             try: want = ref.decompress_portable(zb, c2)
             except ref.ZstdRefError as ex: want = -ex.code
             got, _ = mb(zb, c2)
-            if got != want and isinstance(got, int) and got == -20 and full_size_compressed_block(zb):
-                known += 1
-            elif got != want:
+            if got != want:
                 bad += 1; open(f'/tmp/fuzz_mb_bad_{seed}_{cases}_{corrupted}.zst', 'wb').write(zb)
                 print('REFDIFF', kind, n, lvl, 'cap', c2, 'portable', want if isinstance(want, int) else len(want), 'ours', got if isinstance(got, int) else len(got), flush=True)
-print('seed', seed, 'cases', cases, 'served_by_block_stages', served, 'corrupted', corrupted, 'known_full_size_block', known, 'bad', bad, flush=True)
+print('seed', seed, 'cases', cases, 'served_by_block_stages', served, 'corrupted', corrupted, 'bad', bad, flush=True)

@@ -1,23 +1,12 @@
 """Randomised stress with DAMAGED DICTIONARIES (flipped bits / stored bytes in the header and entropy tables, truncation) against the
 reference, kernel bodies lane-serial:  decode <seed> <seconds>  — frames compressed with the good dictionary, decoded with the
 damaged one on both pipelines: same bytes or the same refusal code as the reference's portable build;  encode <seed> <seconds> —
-ZSTD_createCDict accepts / refuses the same dictionaries, and where it accepts the frames are byte-identical (12-bit-deep Huffman tables,
-see below, and dictionaries under 8 bytes excepted: the reference ignores them, the device digest refuses them and the shim leaves them to the bundled library).
-Round 1: 25 M decode and 1.2 M encode cases; the only differences: dictionaries whose damaged Huffman table is 12 bits deep
-(refused at load here with dictionary_corrupted; the reference loads them and fails in the block — DESIGN.md §7).  TEST INFRASTRUCTURE."""
+ZSTD_createCDict accepts / refuses the same dictionaries, and where it accepts the frames are byte-identical (dictionaries under 8 bytes excepted: the reference
+ignores them, the device digest refuses them and the shim leaves them to the bundled library).
+Round 1: 25 M decode and 1.2 M encode cases; the only differences then: dictionaries whose damaged Huffman table is 12 bits deep — refused at load in rounds 1-5,
+loaded like the reference loads them since round 6 (zd_huf_fill's 2 048-cell form of a 12-bit table), so no class is counted apart any more.  TEST INFRASTRUCTURE."""
 import sys
 mode = sys.argv.pop(1)
-
-def huf_depth_12(ref, bd):
-    """the known difference: the dictionary's (damaged) Huffman table description reads as 12 bits deep (HUF_readStats at offset 8)"""
-    import ctypes as C
-    R = ref.lib()
-    R.HUF_readStats.restype = C.c_size_t
-    R.HUF_readStats.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_char_p, C.c_size_t]
-    if len(bd) < 9: return False
-    w = C.create_string_buffer(256); rank = (C.c_uint * 16)(); nb = C.c_uint(0); tl = C.c_uint(0)
-    r = R.HUF_readStats(w, 256, rank, C.byref(nb), C.byref(tl), bd[8:], len(bd) - 8)
-    return r < (1 << 62) and tl.value == 12
 
 def run_decode():
     import sys, random, time, collections
@@ -49,7 +38,7 @@ def run_decode():
         if not isinstance(p,int): acc+=1
         for x in (o,o2):
             if x!=p:
-                key=(p if isinstance(p,int) else 'ok', x if isinstance(x,int) else 'ok/bytes differ') + (('known: 12-bit Huffman table',) if huf_depth_12(ref, bd) else ())
+                key=(p if isinstance(p,int) else 'ok', x if isinstance(x,int) else 'ok/bytes differ')
                 diff[key]+=1
                 if diff[key]==1: open(f'/tmp/dict_bad_{seed}_{cases}.dict','wb').write(bd); open(f'/tmp/dict_bad_{seed}_{cases}.zst','wb').write(z); print('first',key,'case',cases,'mode',m,flush=True)
             else: same+=1
@@ -82,7 +71,7 @@ def run_encode():
         except ValueError: ec=None
         cases+=1
         if (rc is None)!=(ec is None):
-            key=('ref rejects' if rc is None else 'ref accepts', 'ours rejects' if ec is None else 'ours accepts') + (('known: 12-bit Huffman table',) if huf_depth_12(ref, bd) else ()); diff[key]+=1
+            key=('ref rejects' if rc is None else 'ref accepts', 'ours rejects' if ec is None else 'ours accepts'); diff[key]+=1
             if diff[key]==1: open(f'/tmp/cdict_bad_{seed}_{cases}.dict','wb').write(bd); print('first',key,'mode',m,'len',len(bd),flush=True)
         elif rc is None: both_rej+=1
         else:

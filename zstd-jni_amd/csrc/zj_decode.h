@@ -19,7 +19,9 @@
 #include "zj_common.h"
 
 #define ZD_BLOCK_MAX (1u << 17)
-#define ZD_HUF_LOG_MAX 11u          // literals Huffman depth limit of the format (LitHufLog, N/common/zstd_internal.h:101)
+#define ZD_HUF_LOG_MAX 12u          // deepest literals Huffman table the reference's decoder takes (HUF_TABLELOG_MAX, N/common/huf.h:37; ZSTD_HUFFDTABLE_CAPACITY_LOG,
+                                    // N/decompress/zstd_decompress_internal.h:78) — its encoder stops at 11 (LitHufLog, N/common/zstd_internal.h:101), other writers need not
+#define ZD_HUF_CELLS_LOG 11u        // ... in 2^11 cells of LDS whatever the depth: a 12-bit table is kept as its PAIRS of slots (zd_huf_fill)
 #define ZD_HWIN 256u                // bytes of bitstream staged per Huffman stream per round
 #define ZD_HSYM 128u                // symbols decoded per stream per round (128*11 bits <= 176 B < ZD_HWIN)
 #define ZD_HWIN_STRIDE (ZD_HWIN + 16u)
@@ -37,7 +39,7 @@
 ZJ_DEV u16 zd_cell16(u32 c4, u32 log) { return (u16)(ZD_CELL_SYM(c4) | (((ZD_CELL_NEXT(c4) + (1u << log)) >> ZD_CELL_NB(c4)) << 6)); }
 
 struct ZDecShared {
-    u16 huf[1u << ZD_HUF_LOG_MAX];
+    u16 huf[1u << ZD_HUF_CELLS_LOG];
     u32 llBase[36];                 // LL_base (N/decompress/zstd_decompress_internal.h) per code
     u32 mlBase[53];
     u8 win[4 * ZD_HWIN_STRIDE];     // bitstream windows
@@ -52,6 +54,7 @@ struct ZDecShared {
     u32 err;
     u32 llLog, mlLog, ofLog, hufLog, hufValid, seqValid;
     u32 hufX2;                      // the reference would decode with its two-code-per-cell table (matters only for corrupted streams)
+    u32 hufW1;                      // 12-bit table: its weight-1 symbols (the slots below this hold one symbol each, two to a cell; zd_huf_fill), else 0
     u32 rep[3];
     u32 blkType, blkSize, blkLast;
     u32 hdrSize, windowSize, hasChecksum, blockSizeMax;
@@ -228,7 +231,7 @@ ZJ_DEV bool zd_build_fse(u32* cells, const short* norm, u16* symNext, u32 maxSV,
 // spends in zj_dec_prep_kernel; here every slot finds its rank by counting: a bitmap of its slots per symbol (bm: 54 symbols x 16 words, zeroed here), the rank of slot u =
 // the set bits below u in its symbol's bitmap.  Same cells (tests/test_emu_decode.py::test_emu_fse_table_by_the_wave).  symNext keeps the spread's starting values.
 #define ZD_FSE_BM_WORDS (54u * 16u)
-static_assert(ZD_FSE_BM_WORDS * 4u <= (2u << ZD_HUF_LOG_MAX), "the bitmaps fit the Huffman table's room (ZDecShared::huf), which stage 1 lends them");
+static_assert(ZD_FSE_BM_WORDS * 4u <= (2u << ZD_HUF_CELLS_LOG), "the bitmaps fit the Huffman table's room (ZDecShared::huf), which stage 1 lends them");
 #if ZJ_ON_GPU
 ZJ_DEV void zd_or32(u32* p, u32 v) { atomicOr(p, v); }
 #else
@@ -707,25 +710,39 @@ ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* 
             u32 const w = sh.weights[n];
             if (w) { sh.symPos[n] = (u16)start[w]; start[w] += 1u << (w - 1); }
         }
-        sh.hufLog = tl;
+        sh.hufLog = tl; sh.hufW1 = tl > ZD_HUF_CELLS_LOG ? rank[1] : 0u;
     }
     *nbSymOut = oSize + 1;
     return iSize + 1;
 }
 
-// Huffman decode table from the weights zd_huf_read_weights left in sh (all lanes): cell = nbBits << 8 | symbol
+// Huffman decode table from the weights zd_huf_read_weights left in sh (all lanes): cell = nbBits << 8 | symbol.
+// A table 12 bits deep (HUF_TABLELOG_MAX; 4 096 slots in the reference, N/decompress/huf_decompress.c:385-518) is kept in the same 2 048 cells: slots are laid out
+// by ascending weight, the weight-1 symbols (one slot each, an even number of them: N/common/entropy_common.c:300) first, so from slot hufW1 on a symbol's 2^(w-1)
+// slots are whole pairs and cell j serves slots 2j and 2j + 1; below it cell j holds the two weight-1 symbols of its slots, one per byte (12 bits each).
 template <class G>
 ZJ_DEV void zd_huf_fill(const G& g, ZDecShared& sh, u32 nbSym) {
     u32 const log = ZJ_UNI(sh.hufLog);
+    bool const deep = log > ZD_HUF_CELLS_LOG;
     GRP_FOR(g, s, nbSym) {
         u32 const w = sh.weights[s];
         if (w) {
-            u32 const len = 1u << (w - 1), p0 = sh.symPos[s];
-            u16 const cell = (u16)(((log + 1 - w) << 8) | s);
-            for (u32 k = 0; k < len; k++) sh.huf[p0 + k] = cell;
+            u32 const p0 = sh.symPos[s];
+            if (deep && w == 1u) ((u8*)sh.huf)[p0] = (u8)s;
+            else {
+                u32 const len = deep ? 1u << (w - 2) : 1u << (w - 1), c0 = deep ? p0 >> 1 : p0;
+                u16 const cell = (u16)(((log + 1 - w) << 8) | s);
+                for (u32 k = 0; k < len; k++) sh.huf[c0 + k] = cell;
+            }
         }
     }
 }
+// the cell of slot `idx` (the next hufLog bits of the stream) of a table deeper than ZD_HUF_CELLS_LOG
+ZJ_DEV u32 zd_huf_cell_deep(const ZDecShared& sh, u32 idx) {
+    u32 const c = sh.huf[idx >> 1];
+    return idx < sh.hufW1 ? (ZD_HUF_LOG_MAX << 8) | ((c >> (8u * (idx & 1u))) & 0xFFu) : c;
+}
+ZJ_DEV u32 zd_huf_cell(const ZDecShared& sh, u32 idx, u32 log) { return log > ZD_HUF_CELLS_LOG ? zd_huf_cell_deep(sh, idx) : sh.huf[idx]; }
 
 // ------------------------------------------------------------------ dictionaries -------------
 // A digested dictionary in HBM = what ZSTD_createDDict keeps (N/decompress/zstd_ddict.c:36-130,
@@ -736,7 +753,8 @@ struct ZDDictDev {
     u32 dictID, contentOff, contentSize, hasEntropy;
     u32 rep[3];
     u32 hufLog, llLog, ofLog, mlLog;
-    u16 huf[1u << ZD_HUF_LOG_MAX];
+    u32 hufW1;                      // ZDecShared::hufW1 of the table below
+    u16 huf[1u << ZD_HUF_CELLS_LOG];
     u32 ll[512], of[256], ml[512];
     u16 c16[1280];                  // the same three tables as the split pipeline's 2-byte cells (LL | OF at 512 | ML at 768; zd_cell16): a frame whose
                                     // three tables are all "repeat" decodes straight from here
@@ -776,7 +794,7 @@ ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dict
     }
     g.sync();
     if (!ZJ_UNI(sh.err) && ZJ_UNI(sh.blkType)) { zd_huf_fill(g, sh, ZJ_UNI(sh.bN)); g.sync(); }
-    GRP_FOR(g, i, 1u << ZD_HUF_LOG_MAX) out->huf[i] = sh.huf[i];
+    GRP_FOR(g, i, 1u << ZD_HUF_CELLS_LOG) out->huf[i] = sh.huf[i];
     GRP_FOR(g, i, 512) { out->ll[i] = sh.ll[i]; out->ml[i] = sh.ml[i]; }
     GRP_FOR(g, i, 256) out->of[i] = sh.of[i];
     if (ZJ_UNI(sh.blkType) && !ZJ_UNI(sh.err)) {
@@ -786,7 +804,7 @@ ZJ_DEV void zd_ddict_digest(const G& g, ZDecShared& sh, const u8* dict, u32 dict
     GRP_SERIAL(g) {
         out->status = sh.err; out->dictID = sh.windowSize; out->contentOff = sh.hdrSize; out->contentSize = dictSize - sh.hdrSize;
         out->hasEntropy = sh.blkType; out->rep[0] = sh.rep[0]; out->rep[1] = sh.rep[1]; out->rep[2] = sh.rep[2];
-        out->hufLog = sh.hufLog; out->llLog = sh.llLog; out->ofLog = sh.ofLog; out->mlLog = sh.mlLog;
+        out->hufLog = sh.hufLog; out->hufW1 = sh.hufW1; out->llLog = sh.llLog; out->ofLog = sh.ofLog; out->mlLog = sh.mlLog;
     }
     zj_mem_order();
     g.sync();
@@ -802,7 +820,7 @@ ZJ_DEV void zd_load_dict_entropy(const G& g, ZDecShared& sh, const ZDDictDev* dd
 #if ZJ_ON_GPU
 #pragma clang loop unroll(disable)
 #endif
-        for (u32 i = g.lane(); i < (1u << ZD_HUF_LOG_MAX) / 2u; i += (u32)g.W) h32[i] = s32[i];
+        for (u32 i = g.lane(); i < (1u << ZD_HUF_CELLS_LOG) / 2u; i += (u32)g.W) h32[i] = s32[i];
     }
     if (fse) {
 #if ZJ_ON_GPU
@@ -826,6 +844,25 @@ ZJ_DEV void zd_huf_stream_round(ZDecShared& sh, u32 t) {
     const u8* const win = sh.win + t * ZD_HWIN_STRIDE;
     u32 const startByte = (u32)S0 >> 3;
     u32 k = 0;
+    if (log > ZD_HUF_CELLS_LOG) {                              // a table 12 bits deep (no libzstd encoder writes one): 4 symbols per refill, cells through zd_huf_cell_deep
+        while (k < todo) {
+            u64 c;
+            u32 const byteEnd = ((u32)A + 7) >> 3;
+            if (A <= S0) c = 0;
+            else if (byteEnd >= startByte + 8) c = ld64(win + (byteEnd - 8 - lo)) << (8 * byteEnd - (u32)A);
+            else c = ld64(win + (startByte - lo)) << (64 - (u32)(A - S0));
+            u32 const m = zj_min(4u, todo - k);
+            for (u32 j = 0; j < m; j++) {
+                u32 const cell = zd_huf_cell_deep(sh, (u32)(c >> (64 - ZD_HUF_LOG_MAX)));
+                u32 const nb = cell >> 8;
+                sh.hstage[t][k + j] = (u8)cell;
+                c <<= nb; A -= (i32)nb;
+            }
+            k += m;
+        }
+        sh.hA[t] = (u32)A; sh.hCnt[t] = todo;
+        return;
+    }
     while (k < todo) {
         // refill a 64-bit container whose MSB is bit A-1 (>= 57 valid bits, zeros below S0)
         u64 c;
@@ -883,8 +920,8 @@ ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
             u64 c = 0; for (u32 k = 0; k < 8u && k < len; k++) c |= (u64)bsrc[startByte + k] << (8u * k);
             idx = (u32)(c >> (64u - D));
         }
-        u32 const c1 = sh.huf[idx >> (D - log)], k1 = c1 >> 8;
-        u32 const c2 = sh.huf[((idx << k1) & ((1u << D) - 1u)) >> (D - log)], k2 = c2 >> 8;
+        u32 const c1 = zd_huf_cell(sh, idx >> (D - log), log), k1 = c1 >> 8;
+        u32 const c2 = zd_huf_cell(sh, ((idx << k1) & ((1u << D) - 1u)) >> (D - log), log), k2 = c2 >> 8;
         bool const two = k1 + k2 <= D;
         if (last) {
             out[i] = (u8)c1;
@@ -1255,7 +1292,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0; sh.hufX2 = 0;
             if (dd && dd->hasEntropy) {
                 sh.rep[0] = dd->rep[0]; sh.rep[1] = dd->rep[1]; sh.rep[2] = dd->rep[2]; sh.hufValid = 1; sh.seqValid = 1; sh.hufX2 = 1;   // ZSTD_loadDEntropy builds the two-code table (zstd_decompress.c:1473)
-                sh.hufLog = dd->hufLog; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
+                sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
             }
             if (err) sh.err = err;
         }
@@ -1280,8 +1317,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
                     else {
                         if (sz > srcSize - ipos - 3) err = ZJ_E_SRCSIZE_WRONG;
                         else if (type == 0 && sz > fcap - opos) err = ZJ_E_DSTSIZE_TOO_SMALL;
-                        else if (type == 2 && sz > sh.blockSizeMax) err = ZJ_E_SRCSIZE_WRONG;
-                        else if (type == 2 && sz >= ZD_BLOCK_MAX) err = ZJ_E_CORRUPTION;
+                        else if (type == 2 && sz > sh.blockSizeMax) err = ZJ_E_SRCSIZE_WRONG;      // (a compressed block of exactly blockSizeMax is entered: zstd_decompress_block.c:2073-2081)
                     }
                 }
                 if (err) sh.err = err;

@@ -365,7 +365,7 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     bool const havePre = ZJ_UNI(sh.litStreams) != 0u;
     if (DICT && dd && dd->hasEntropy && (src[ZJ_UNI(sh.hdrSize)] & 3u) == 3u) {   // treeless literals decode with the dictionary's Huffman table
         zd_load_dict_entropy(g, sh, dd, true, false);
-        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; }
+        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; }
         g.sync();
     }
     const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);

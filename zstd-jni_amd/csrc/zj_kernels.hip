@@ -962,9 +962,9 @@ enum { ZJ_ROUTE_WAVE_HBM = ZJNI_ROUTE_WAVE_HBM, ZJ_ROUTE_FUSED = ZJNI_ROUTE_FUSE
 // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (4 by default), and a hardware queue runs its packets in order: a stream that shares
 // one with the stream of a 130 ms persistent kernel (the entropy kernel beside the match kernel, the match kernel itself) does not move until that kernel has left —
 // measured with two host batches in flight: the second batch's pack kernel and D2H copies waited 130 ms behind the first's entropy kernel (profiles/r05/e_).  This
-// library keeps up to ten streams busy at once (a caller's, three of its own per device, three per staging slot), so it asks for more queues — before the first
-// HIP call of a process that has not made one (the JVM's case: the JNI library is the only HIP user); a process that has set the variable keeps its value.
-static int const zj_more_hw_queues = []() { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+// library keeps up to ten streams busy at once (a caller's, three of its own per device, three per staging slot): a deployment that keeps two host batches in flight
+// sets GPU_MAX_HW_QUEUES=16 in the environment the process is STARTED with.  The library itself never touches the environment: it is
+// dlopen()ed into a running JVM, where setenv() races with every other thread's getenv() (rounds 4-5 called setenv from a static initialiser here).
 // The host-pointer entries stage a batch through pinned host memory and a device area of the same layout.  Round 5: TWO such slots per device, each with its own
 // streams and events, so that two host-pointer calls (two JVM threads in compressBatch0, or zjni_*_batch_begin twice) are in flight at once: while one call's kernels run,
 // the other's sources cross the link one way and a third's frames the other — the lane pipeline wants a whole batch resident, so the overlap a single compress call cannot
