@@ -76,9 +76,24 @@ def test_scratch_limit_bounds_the_library(gpu, oracle_ref):
     src = B.synth(n, size, 0, "cuda"); off = B.uniform_offsets(n, size, "cuda")
     bound = gpu.Zstd.compressBound(size)
     comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); coff = B.uniform_offsets(n, bound, "cuda")
+    assert L.zjni_release_scratch() == 0 and L.zjni_scratch_bytes() == 0
     free = B.compress(src, off, comp, coff, 3).clone(); torch.cuda.synchronize()
     big = L.zjni_scratch_bytes()
-    assert big > (6 << 30)                                     # sized for 288 GB: n x (tables + records), and the wide slice
+    assert big > (6 << 30)                                     # sized for 288 GB: n x (tables + records + flags)
+    # ... and NOT the wide slice (list B: frames of 64 KiB + 1 .. 128 KiB; rounds 1-5 allocated its 20 000 x 1.1 MiB here whatever the batch held): round 6 allocates it
+    # when a call has such frames.  n x (384 KiB tables + 320 KiB records + 64 KiB flags) and small change:
+    assert big < n * (800 << 10), big
+    n2 = 4200                                                  # a batch WITH wide frames: the slice appears, sized for it, and the frames are the reference's
+    src2 = B.synth(n2, 131072, 7, "cuda"); off2 = B.uniform_offsets(n2, 131072, "cuda"); bound2 = gpu.Zstd.compressBound(131072)
+    compw = torch.empty(n2 * bound2, dtype=torch.uint8, device="cuda"); coffw = B.uniform_offsets(n2, bound2, "cuda")
+    szw = B.compress(src2, off2, compw, coffw, 3); torch.cuda.synchronize()
+    assert L.zjni_scratch_bytes() > big + n2 * (1 << 20)
+    hs = src2[:8 * 131072].cpu().numpy().tobytes(); hc = compw[:8 * bound2].cpu().numpy().tobytes()
+    for i in range(8):
+        assert hc[i * bound2:i * bound2 + int(szw[i])] == oracle_ref.compress(hs[i * 131072:(i + 1) * 131072], 3), i
+    del src2, compw
+    again = B.compress(src, off, comp, coff, 3); torch.cuda.synchronize()          # with the slice in place a batch without wide frames goes through as before
+    assert torch.equal(again, free)
     assert L.zjni_release_scratch() == 0 and L.zjni_scratch_bytes() == 0
     try:
         assert L.zjni_set_scratch_limit(1) == (4 << 30)        # raised to the minimum

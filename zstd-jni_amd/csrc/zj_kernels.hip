@@ -999,6 +999,7 @@ struct DevState {
     hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
     u32* counters = nullptr;       // [0] decode, [16] encode (separate cache lines)
     u8* decScratch = nullptr; int dseqHeavy = 0;
+    volatile u32* encStat = nullptr; hipEvent_t evLists = nullptr;      // pinned: the classify kernel's list counts of the running compress call ([0] |A|, [1] |B|, [4] |C|), valid behind evLists — asked for only while the wide slice does not exist
     volatile u32* decStat = nullptr;                  // pinned: [0] |A|, [1] sequences of the last split-decode slice that ran (copied back asynchronously, read without waiting)
     u8* encScratch = nullptr;
     // staging for the host-pointer entries
@@ -1088,6 +1089,7 @@ DevState* get_state(int ordinal) {
             d.waveGrid = d.numCU * w; }
         for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
         {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, 64); d.decStat = (volatile u32*)hp; } }
+        {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&d.evLists, hipEventDisableTiming) == hipSuccess) { memset(hp, 0, 64); d.encStat = (volatile u32*)hp; } }
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
         if (zj_env("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
@@ -1222,7 +1224,7 @@ void zjni_shutdown(void) {
     for (auto& d : g_dev) {
         if (d.ordinal < 0) continue;
         (void)hipSetDevice(d.ordinal);
-        (void)hipFree(d.counters); if (d.decStat) { (void)hipHostFree((void*)d.decStat); d.decStat = nullptr; } (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
+        (void)hipFree(d.counters); if (d.decStat) { (void)hipHostFree((void*)d.decStat); d.decStat = nullptr; } if (d.encStat) { (void)hipHostFree((void*)d.encStat); d.encStat = nullptr; (void)hipEventDestroy(d.evLists); } (void)hipFree(d.decScratch); (void)hipFree(d.encScratch);
         if (d.encList) (void)hipFree(d.encList);
         if (d.splitBuf) (void)hipFree(d.splitBuf);
         if (d.dsplitBuf) (void)hipFree(d.dsplitBuf);
@@ -1422,6 +1424,7 @@ static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool ha
     size_t const litOff = poolOff + ZD_MB_SEQS * 8;
     size_t const need = litOff + ZD_MB_LIT_BYTES + 256;
     if (d->dmbBufCap < need) {
+        if (!scratch_make_room(d, d->dmbBufCap, need)) return h;
         if (d->dmbBuf) { if (hipStreamSynchronize(st) != hipSuccess) return h; (void)hipFree(d->dmbBuf); d->dmbBuf = nullptr; d->dmbBufCap = 0; }
         if (hipMalloc(&d->dmbBuf, need) != hipSuccess) { (void)hipGetLastError(); return h; }        // no room: the fused kernel serves these frames as before
         d->dmbBufCap = need;
@@ -1731,6 +1734,12 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     u32 const ldsA = level > 3 ? 0u : (u32)enc_lds_pass0(level);
     hipLaunchKernelGGL(zj_enc_classify_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u64*)d_src_off, (u64*)d_result,
                        (u32)n, (u32)levelWord, ldsA, ctr, listA, listB, listC);
+    // The wide slice (list B: frames of 64 KiB + 1 .. 128 KiB, ~1.1 MiB of tables and records per frame of a 65 536-frame slice) is allocated when a call HAS such
+    // frames (rounds 1-5: by any large level 1-3 call, 72 GiB).  While it does not exist the list counts come back to pinned memory behind an event, and the call waits
+    // for them where it would allocate — by then list A's kernels are queued, so the device is not kept waiting; once it exists nothing is asked.
+    bool listsAsked = false;
+    if (level <= 3 && d->encStat && d->wideBufCap == 0 && !l3wave)
+        listsAsked = hipMemcpyAsync((void*)d->encStat, ctr, 24, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(d->evLists, st) == hipSuccess;
     // levels 4-8, frames of 16-128 KiB: one lane per frame when the batch is large (below) and the scratch budget has room for a table set
     // per lane slot, else one wave per frame (here)
     // (level 4 is double-fast: its frames above 16 KiB stay on list C, where the wave matcher of zj_match_wavex.h parses them — two waves per
@@ -1994,6 +2003,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     if (n >= splitMin) {
         // List B (frames > 64 KiB, fast-strategy frames with larger tables) through the same two stages, in slices that
         // share one scratch area sized for 4-byte positions and 128 KiB frames; a slice past the end of the list is empty.
+        auto bailB = [&](size_t code) { (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(d->waveStream); (void)hipStreamSynchronize(st); return code; };
         size_t sliceB = 65536;                       // as many lanes as the common path runs: 32 768 leaves half the wave slots empty (13.8 vs 18.5 GiB/s on 128 KiB frames)
         if (const char* ov = zj_env("ZJNI_WIDE_SLICE")) sliceB = (size_t)atoll(ov);
         sliceB = scratch_slice((size_t)ze_lane_table_stride((u32)levelWord, true) + ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC) + 12, sliceB, 2);   // half the budget: the common-case buffer of this call has the other half
@@ -2017,6 +2027,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         }
         size_t flagB = needW ? sliceB * (size_t)ZN_FLAG_STRIDE_WIDE + 9 * sliceB + 384 : 0;      // flags, ready words, pick list, gate bytes
         size_t needB = tablesB + fsB + metaB + 2 * qB + 256 + flagB;
+        if (d->wideBufCap < needB && listsAsked) {                 // no wide slice yet: is there a list B at all?
+            if (hipEventSynchronize(d->evLists) != hipSuccess) return bailB(ZJNI_ERR(ZJNI_ERROR_no_device));
+            if (d->encStat[1] == 0u) return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
+        }
         if (d->wideBufCap < needB) {
             if (!scratch_make_room(d, d->wideBufCap, needB)) return ZJNI_ERR(64);
             if (d->wideBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->wideBuf); d->wideBuf = nullptr; d->wideBufCap = 0; }
