@@ -7,7 +7,7 @@ import os
 import pytest
 
 from conftest import golden, XML_SHA256_PREFIX
-from util import edge_inputs
+from util import edge_inputs, needs_tuning_build
 
 pytestmark = pytest.mark.gpu
 
@@ -164,6 +164,7 @@ def test_gpu_split_pipeline_mixed_batch(gpu, oracle_ref, oracle_port, force_spli
         bad = bytearray(good); bad[pos] ^= 0x5A
         items.append(bytes(bad)); caps.append(65536)
     items.append(good); caps.append(65535)               # destination one byte short
+    if lit_pass == "slots16k": needs_tuning_build(gpu)
     if lit_pass == "slots16k": monkeypatch.setenv("ZJNI_DEC_LIT_BYTES", str(16384 * len(items) + 4096))
     split = gpu.decompress_batch(items, caps)
     import os

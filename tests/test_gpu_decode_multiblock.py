@@ -8,6 +8,8 @@ import pytest
 
 from conftest import golden
 
+from util import needs_tuning_build
+
 pytestmark = pytest.mark.gpu
 
 
@@ -37,6 +39,7 @@ def test_gpu_golden_and_stream_frames_take_the_block_stages(gpu, oracle_ref):
 @pytest.mark.parametrize("mb", ["1", "0", "behind"])
 def test_gpu_multiblock_frames_small_and_large_batches(gpu, oracle_ref, monkeypatch, mb):
     monkeypatch.setenv("ZJNI_DEC_MB", "0" if mb == "0" else "1")
+    if mb == "behind": needs_tuning_build(gpu)
     if mb == "behind": monkeypatch.setenv("ZJNI_DEC_MB_OVERLAP", "0")      # stage 3 behind stage 2 (the default runs it beside, block by block as stage 2 sets seqReady)
     rnd = random.Random(29)
     xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)

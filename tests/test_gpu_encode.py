@@ -10,7 +10,7 @@ import random
 import pytest
 
 from conftest import golden
-from util import edge_inputs
+from util import needs_tuning_build, edge_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -190,6 +190,7 @@ def test_gpu_need_gated_double_fast(gpu, oracle_ref, monkeypatch, mode, machine)
     """zj_need.h + zj_match_run.h: the flag kernels beside the match kernel give the same frames — flags for every frame (ZJNI_NEED=1), for the
     frames the worth kernel picks (2, the default), for none (0) — on the run machine (the product's route, and what zjni_last_route reports)
     and on the previous lane machine (ZJNI_LANE_MACHINE=0)"""
+    if machine == "lane": needs_tuning_build(gpu)
     monkeypatch.setenv("ZJNI_NEED", mode)
     monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
     if machine == "lane": monkeypatch.setenv("ZJNI_LANE_MACHINE", "0")
@@ -363,6 +364,7 @@ def test_gpu_wave_matcher(gpu, oracle_ref, monkeypatch, mode):
     the small-batch path (the default below 4 096 buffers), as the only matcher of the large-batch pipeline, and sharing a
     batch with the lane-per-frame matcher through the partitioned queue (ZJNI_HYBRID, an experiment that stays off)"""
     if mode != "small-batch":
+        needs_tuning_build(gpu)
         monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")
         monkeypatch.setenv("ZJNI_HYBRID", "1")
     if mode == "wave-only":
@@ -417,6 +419,7 @@ def test_gpu_pending_table_clear_is_ordered_before_every_scratch_user(gpu, oracl
     a batch whose tables take milliseconds to clear (12 288 x 64 KiB: 4.5 GiB); the followers' frames must be the reference's.  Both
     settings of ZJNI_PRECLEAR."""
     import torch
+    if preclear == "0": needs_tuning_build(gpu)
     monkeypatch.setenv("ZJNI_PRECLEAR", preclear)
     monkeypatch.setenv("ZJNI_L3_WAVE_MAX", "0")
     monkeypatch.setenv("ZJNI_SPLIT_MIN", "1")

@@ -6,7 +6,7 @@ import random
 
 import pytest
 
-from util import json_records
+from util import json_records, needs_tuning_build
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,7 @@ def _inputs(gpu, seed, count):
 def test_gpu_level4_frames_are_the_references(gpu, oracle_ref, monkeypatch, count, route):
     """route (frames above 16 KiB, double-fast): the wave matcher of zj_match_wavex.h on the wave-per-frame kernel (the default, any
     batch size), the lane-slot kernel of large batches (ZJNI_L4_LANES=1), the one-lane parse (ZJNI_MULTI_WAVE=0)"""
+    if route != "wave": needs_tuning_build(gpu)
     if route == "lanes": monkeypatch.setenv("ZJNI_L4_LANES", "1")
     if route == "one-lane": monkeypatch.setenv("ZJNI_MULTI_WAVE", "0")
     datas = _inputs(gpu, 7 + count, count) + [gpu.synth_host(131073, 1, 1), gpu.synth_host(300000, 2, 1)]

@@ -6,6 +6,8 @@ import pytest
 
 from conftest import golden
 
+from util import needs_tuning_build
+
 pytestmark = pytest.mark.gpu
 
 
@@ -64,6 +66,7 @@ def test_gpu_multiblock_parse_switches(gpu, oracle_ref, monkeypatch, switch):
     """level-3 blocks of multi-block frames run the wave matcher (zj_match_wavex.h) by default, levels 1-2 the one-lane parse;
     ZJNI_MULTI_WAVE=0 selects the one-lane parses of rounds 1-3, =2 the wave matchers without staged spans, ZJNI_MULTI_WAVE_FAST=1 puts levels 1-2
     on their wave matcher too (exact, measured slower than the one-lane parse there: off by default) — the same frames either way"""
+    needs_tuning_build(gpu)
     monkeypatch.setenv(*switch)
     for level in (3, 1, 2):
         datas = [d for d in inputs(gpu, oracle_ref, 100 + level, 24) if len(d) <= WINDOW[level]]

@@ -314,3 +314,11 @@ def hand_huffman_section(rnd, n, w1, streams):
     seg = (n + 3) // 4
     parts = [stream(lits[i * seg:(i + 1) * seg] if i < 3 else lits[3 * seg:]) for i in range(4)]
     return lits, hdr + b"".join(len(p).to_bytes(2, "little") for p in parts[:3]) + b"".join(parts)
+
+
+def needs_tuning_build(zj):
+    """skip unless libzjni_amd.so is a TUNING build (tools/build_variant.sh ... -DZJ_TUNING_KERNELS: its stamp ends in "+tuning"): the experiment knobs and the losing
+    routes they select (ZJNI_HYBRID, ZJNI_LANE_MACHINE, ZJNI_MULTI_WAVE, ZJNI_L4_LANES, ZJNI_PRECLEAR, ...) read as unset in the product library (zj_tune, zj_kernels.hip)"""
+    import pytest
+    if b"+tuning" not in zj.lib().zjni_build_stamp():
+        pytest.skip("a switch of tuning builds only (-DZJ_TUNING_KERNELS)")

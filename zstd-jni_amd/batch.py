@@ -82,6 +82,8 @@ def pack(results, dst_blob, dst_off, out=None, out_off=None):
     if out_off is None:
         out_off = torch.zeros(n + 1, dtype=torch.int64, device=results.device)
     if out is not None and out_off.is_contiguous() and results.is_contiguous():
+        if out_off.numel() != n + 1 or out_off.dtype != torch.int64 or out.dtype != torch.uint8 or results.dtype != torch.int64:
+            raise ValueError("pack: out_off must be int64[n + 1], out uint8, results int64[n]")      # (the device writes n + 1 offsets: nothing else checks them)
         _check(lib().zjni_pack_batch_device2(dst_blob.data_ptr(), dst_off.data_ptr(), results.data_ptr(), out.data_ptr(),
                                              out_off.data_ptr(), n, _stream_ptr()))
         return out, out_off

@@ -138,6 +138,9 @@ ZJ_HD u32 zj_max(u32 a, u32 b) { return a > b ? a : b; }
 // writes the L2 back a second time (round 5: the hand-overs paid two write-backs and an invalidate where one write-back is what the protocol needs, profiles/r05/g_).
 ZJ_DEV void zj_release() {
 #if ZJ_ON_GPU
+    // the producers' stores include predicated ones issued through inline asm (zr_st32_m, zj_match_run.h), which the compiler's own wait counting does not see: the wait
+    // for them is spelled out instead of left to what the fence happens to emit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
 }

@@ -1590,11 +1590,13 @@ ZJ_DEV u64 ze_compress_t(const G& g, ZEncShared& sh, u8* lds, const u8* src0, u3
         // ---- match finding: zero the tables (all lanes), then the sequential parse (lane 0) ----
         u32 const strategy = ZJ_UNI(sh.strategy), hlog = ZJ_UNI(sh.hashLog), clog = ZJ_UNI(sh.chainLog), mls = ZJ_UNI(sh.minMatch);
         if (!pre && ba) {                                  // one block of a frame: its tables (HBM, cleared by the caller before block 0) and repcodes carry on
+#if defined(ZJ_TUNING_KERNELS) || !ZJ_ON_GPU          /* ZWaveF: exact, measured slower than the one-lane parse at levels 1-2 (2 048 x 512 KiB: 156 ms against 138) — tuning builds and the emulation only */
             if (strategy == 1 && ba->serialParse != 1u && !(ba->serialParse & 4u)) {     // levels 1-2: the fast strategy on the whole wave (zj_match_wavex.h, ZWaveF)
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 u32 const lastLL = zx_block_fast_wave(lds, o, ba->frameBase, ba->frameSize, ba->start, ba->start + srcSize, hlog, mls, ba->tables, sh.blkRep, sh.blkNextRep, (ba->serialParse & 3u) == 0u);
                 GRP_SERIAL(g) { sh.nbSeq = o.n; sh.litSize = o.lit + lastLL; sh.lastLL = lastLL; }
             } else
+#endif
             if (strategy == 2 && (ba->serialParse & 3u) != 1u) {           // level 3: the whole wave (zj_match_wavex.h); the dynamic LDS is free until the entropy stage
                 ZEOut o; o.seqs = seqs; o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
                 u32 const lastLL = zx_block_dfast_wave(lds, o, ba->frameBase, ba->frameSize, ba->start, ba->start + srcSize, hlog, clog, mls, ba->tables, ba->tables + (1u << hlog), sh.blkRep, sh.blkNextRep, (ba->serialParse & 3u) == 0u);

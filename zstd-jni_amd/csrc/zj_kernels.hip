@@ -46,6 +46,15 @@ static const char* zj_env(const char* name) {
     return it->second.first ? it->second.second.c_str() : nullptr;
 }
 
+// Experiment knobs (grid sizes, losing routes kept for A/B runs, measurement hooks) exist in a TUNING build only — tools/build_variant.sh <name> -DZJ_TUNING_KERNELS,
+// its stamp ends in "+tuning" — and read as unset in the product, which keeps ten documented switches: ZJNI_SPLIT_MIN, ZJNI_DSPLIT_MIN,
+// ZJNI_L3_WAVE_MAX, ZJNI_NEED, ZJNI_DEC_LIT, ZJNI_DEC_MB, ZJNI_WIDE_SLICE, ZJNI_HOST_THREADS, ZJNI_HOST_TRACE, ZJNI_DEBUG_SYNC (+ ZJNI_DEBUG_LIVE_SWITCHES above).
+#ifdef ZJ_TUNING_KERNELS
+static const char* zj_tune(const char* name) { return zj_env(name); }
+#else
+static constexpr const char* zj_tune(const char*) { return nullptr; }
+#endif
+
 // ============================================================================ kernels ==========
 // Next work item of a persistent workgroup: one device-scope atomic by lane 0, broadcast through
 // v_readfirstlane so the index (and everything derived from it) is wave-uniform.
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // is late, or never scheduled beside the match kernel, frames simply run longer without flags (148 against 152 ms with the bounded wait this replaced,
 // profiles/r03/l_late_flags_ab.txt).  The older gated machine (ZJNI_LANE_MACHINE=0) still waits, bounded by 50 ms, and then runs unflagged.
 static u32 zj_need_threads() {        // lanes per frame of the flag kernel (one workgroup per CU: its filters take 108 KiB of LDS): ZJNI_NEED_THREADS, 64 .. 1 024
-    u32 t = 1024; if (const char* ov = zj_env("ZJNI_NEED_THREADS")) { int const v = atoi(ov); if (v >= 64 && v <= 1024) t = (u32)v & ~63u; }
+    u32 t = 1024; if (const char* ov = zj_tune("ZJNI_NEED_THREADS")) { int const v = atoi(ov); if (v >= 64 && v <= 1024) t = (u32)v & ~63u; }
     return t;
 }
 struct ZNThreads {
@@ -531,6 +540,7 @@ ZJ_RUN_KERNEL(zj_enc_match_run4_kernel, 4u)
 ZJ_RUN_KERNEL(zj_enc_match_run6_kernel, 6u)
 ZJ_RUN_KERNEL(zj_enc_match_run7_kernel, 7u)
 #endif
+#ifdef ZJ_TUNING_KERNELS
 // ZJNI_LANE_MACHINE=0: the previous machine (ZLaneD with its table accesses predicated on the flags), kept selectable for A/B runs
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_gated_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
                                                            const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
@@ -540,6 +550,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     list += listBase;
     zj_match_run<ZLaneD<ZEEntTag, true> >(src, srcOff, level, list, count, workCounter, tables, tableStride, fscratch, maxSrc, meta, doneList, doneCount, nullptr, flagsBase, gate, ready);
 }
+#endif
 
 // Levels 4-8, frames <= 16 KiB: the hash-chain parsers (ze_block_lazy: greedy / lazy / lazy2), one LANE per frame as plain loops —
 // 64 frames per wave instead of one lane of 64 busy; the chain walk (up to 2^searchLog dependent candidate fetches per position)
@@ -640,6 +651,7 @@ __global__ __launch_bounds__(64) void zj_enc_match_wave_kernel(const u8* __restr
     }
 }
 
+#ifdef ZJ_TUNING_KERNELS      /* the ZJNI_HYBRID experiment (DESIGN history, round 2): it stayed off and lives in tuning builds only */
 // Search-density score of each listed frame: distinct 4-byte values among 1 024 consecutive positions from the middle of the
 // frame (hashed into a 4 096-bit set), 0..63.  Text-like frames (few distinct values: almost every position starts a match)
 // score low, frames that are searched position by position score high.
@@ -690,6 +702,7 @@ __global__ void zj_enc_partition_done_kernel(const u32* countPtr, u32 sharePermi
     u32 const count = *countPtr, cap = (u32)(((u64)count * sharePermille) / 1000u);
     w[2] = count - (w[4] < cap ? w[4] : cap);
 }
+#endif
 
 // The wide launch: frames > 64 KiB and the fast-strategy frames whose tables exceed the common size; 4-byte positions.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void zj_enc_match_wide_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u32 level,
@@ -941,9 +954,14 @@ __global__ __launch_bounds__(256) void zj_pack_kernel(const u8* __restrict__ src
         u64 const sz = sizes[i];
         if (sz > ((u64)1 << 40)) continue;              // error result: nothing to move
         const u8* s = src + srcOff[i]; u8* d = dst + dstOff[i];
-        u32 const n16 = (u32)(sz >> 4);
-        for (u32 k = threadIdx.x; k < n16; k += 256) { u64 a = ld64(s + 16 * k), b = ld64(s + 16 * k + 8); st64(d + 16 * k, a); st64(d + 16 * k + 8, b); }
-        for (u32 k = (n16 << 4) + threadIdx.x; k < (u32)sz; k += 256) d[k] = s[k];
+        // the destination is packed to the byte: bytes up to its first 16-byte boundary one by one, then 16 bytes per lane as ONE aligned store (the loads may
+        // straddle; round 6 — two 8-byte stores at an arbitrary byte offset were 2-4 write requests each: 3.5 ms for 2 GB on the metric batch)
+        u32 const head = zj_min((u32)sz, (u32)((0u - (u32)(uintptr_t)d) & 15u));
+        if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+        s += head; d += head;
+        u32 const rest = (u32)sz - head, n16 = rest >> 4;
+        for (u32 k = threadIdx.x; k < n16; k += 256) { uint4 v; v.x = ld32(s + 16 * k); v.y = ld32(s + 16 * k + 4); v.z = ld32(s + 16 * k + 8); v.w = ld32(s + 16 * k + 12); *(uint4*)(d + 16 * k) = v; }
+        for (u32 k = (n16 << 4) + threadIdx.x; k < rest; k += 256) d[k] = s[k];
     }
 }
 
@@ -1051,12 +1069,12 @@ DevState* get_state(int ordinal) {
         d.decGrid = d.numCU * perCU;
         {   int p2 = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, zj_decode_dict_kernel, 64, 0) != hipSuccess || p2 < 1) p2 = 4;
             d.decDictGrid = d.numCU * (p2 < perCU ? p2 : perCU); }
-        if (const char* ov = zj_env("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
+        if (const char* ov = zj_tune("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.decGrid = d.numCU * v; }   // occupancy experiments
         if (hipFuncSetAttribute((const void*)zj_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZJ_ENC_LDS_BIG) != hipSuccess) return nullptr;
         for (int lvl = 1; lvl <= 3; lvl++) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, enc_lds_pass0(lvl)) != hipSuccess || perCU < 1) perCU = 1;
             d.encGridLvl[lvl] = d.numCU * perCU;
-            if (const char* ov = zj_env("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.encGridLvl[lvl] = d.numCU * v; }
+            if (const char* ov = zj_tune("ZJNI_DEBUG_WG_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v < perCU) d.encGridLvl[lvl] = d.numCU * v; }
             if (d.encGridLvl[lvl] > d.encGrid) d.encGrid = d.encGridLvl[lvl];
         }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_encode_kernel, 64, ZJ_ENC_LDS_BIG) != hipSuccess || perCU < 1) perCU = 1;
@@ -1071,7 +1089,7 @@ DevState* get_state(int ordinal) {
         // a counter, so fewer waves than frames / 64 only means more frames per lane; the pipeline's time is flat from 1 to 2 waves per CU
         // (24.7-25.3 ms per 65 536 x 64 KiB) and the decode cells alive at a time shrink with the wave count: 1.5 waves per CU.
         d.dseqHeavy = d.numCU * 3 / 2;
-        if (const char* ov = zj_env("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
+        if (const char* ov = zj_tune("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
@@ -1085,14 +1103,14 @@ DevState* get_state(int ordinal) {
         if (hipStreamCreateWithFlags(&d.clearStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d.evMatchDone, hipEventDisableTiming) != hipSuccess
             || hipEventCreateWithFlags(&d.evCleared, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipFuncSetAttribute((const void*)zj_enc_match_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZWLds)) != hipSuccess) return nullptr;
-        {   int w = 3; if (const char* ov = zj_env("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
+        {   int w = 3; if (const char* ov = zj_tune("ZJNI_WAVE_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 3) w = v; }
             d.waveGrid = d.numCU * w; }
         for (int p = 0; p < 2; p++) if (hipEventCreateWithFlags(&d.cdMatchDone[p], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d.cdEncDone[p], hipEventDisableTiming) != hipSuccess) return nullptr;
         {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, 64); d.decStat = (volatile u32*)hp; } }
         {   void* hp = nullptr; if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&d.evLists, hipEventDisableTiming) == hipSuccess) { memset(hp, 0, 64); d.encStat = (volatile u32*)hp; } }
         if (hipMalloc(&d.decScratch, (size_t)(d.decGrid > d.dexecGrid ? d.decGrid : d.dexecGrid) * ZD_LIT_SCRATCH) != hipSuccess) return nullptr;
         if (hipMalloc(&d.encScratch, (size_t)d.encGrid * ZE_SCRATCH_BYTES) != hipSuccess) return nullptr;
-        if (zj_env("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
+        if (zj_tune("ZJNI_PROFILE")) { if (hipMalloc(&d.prof, 32 * 8) != hipSuccess || hipMemset(d.prof, 0, 32 * 8) != hipSuccess) return nullptr; }
         d.ordinal = ordinal;
     }
     return &d;
@@ -1370,7 +1388,11 @@ const char* zjni_route_kernel(int route) {
 #ifndef ZJNI_BUILD_STAMP
 #define ZJNI_BUILD_STAMP "unknown"
 #endif
+#ifdef ZJ_TUNING_KERNELS
+const char* zjni_build_stamp(void) { return ZJNI_BUILD_STAMP "+tuning"; }
+#else
 const char* zjni_build_stamp(void) { return ZJNI_BUILD_STAMP; }
+#endif
 
 /* ---- resource policy ---- */
 size_t zjni_set_scratch_limit(size_t bytes) {
@@ -1436,12 +1458,12 @@ static ZDMbHost decode_mb_scratch(DevState* d, size_t n, hipStream_t st, bool ha
     h.a.ctr = ctr; h.a.blkCap = ZD_MB_BLOCKS; h.a.seqCap = ZD_MB_SEQS; h.a.minBlocks = 1;
     // stage 3 beside stage 2 (ZJNI_DEC_MB_OVERLAP=0: behind it, as before): a flag per frame says which ones it finished there
     h.procFlag = nullptr;
-    if (!(zj_env("ZJNI_DEC_MB_OVERLAP") && atoi(zj_env("ZJNI_DEC_MB_OVERLAP")) == 0)) {
+    if (!(zj_tune("ZJNI_DEC_MB_OVERLAP") && atoi(zj_tune("ZJNI_DEC_MB_OVERLAP")) == 0)) {
         u32* const q = h.a.listM + n;
         if (hipMemsetAsync(q, 0, lmB, st) == hipSuccess) h.procFlag = q;
     }
     h.pool = (u64*)(d->dmbBuf + poolOff);
-    int const litEnv = (zj_env("ZJNI_DEC_MB_LIT") && atoi(zj_env("ZJNI_DEC_MB_LIT")) == 0) ? 0 : 1;       // stage 2b of these frames off (A/B runs)
+    int const litEnv = (zj_tune("ZJNI_DEC_MB_LIT") && atoi(zj_tune("ZJNI_DEC_MB_LIT")) == 0) ? 0 : 1;       // stage 2b of these frames off (A/B runs)
     h.a.litCap = litEnv ? ZD_MB_LIT_BYTES : 0; if (!litEnv) h.a.litList = nullptr;
     h.litPool = d->dmbBuf + litOff;
     h.on = true;
@@ -1510,7 +1532,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         u8* litSlots = nullptr; u32 litSlot = 0;
         {   int const litEnv = (zj_env("ZJNI_DEC_LIT") && atoi(zj_env("ZJNI_DEC_LIT")) == 0) ? 0 : 1;
             if (litEnv && !ddict && !g_scratch_limit) {
-                size_t budget = (size_t)4 << 30; if (const char* ov = zj_env("ZJNI_DEC_LIT_BYTES")) { long long const v = atoll(ov); budget = v <= 0 ? 0 : ((unsigned long long)v > ((unsigned long long)64 << 30) ? (size_t)64 << 30 : (size_t)v); }
+                size_t budget = (size_t)4 << 30; if (const char* ov = zj_tune("ZJNI_DEC_LIT_BYTES")) { long long const v = atoll(ov); budget = v <= 0 ? 0 : ((unsigned long long)v > ((unsigned long long)64 << 30) ? (size_t)64 << 30 : (size_t)v); }
                 size_t slot = budget / n; if (slot > ZD_BLOCK_MAX) slot = ZD_BLOCK_MAX; slot &= ~(size_t)4095;
                 if (slot >= 16384) {
                     size_t const needL = n * slot + 64;
@@ -1522,7 +1544,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
                 }
             }
         }
-        static int const overlapEnv = zj_env("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
+        static int const overlapEnv = zj_tune("ZJNI_DEC_NO_OVERLAP") ? 0 : 1;
         // Running the execution kernel beside the sequence decode costs two cross-stream dependencies and an extra launch per slice
         // (~0.3 ms) — worth it only for frames with many sequences (zj_dec_heavy, decided on the device).  The host skips the set-up
         // when the last slice it has statistics for was light: the statistics arrive asynchronously and are never waited for, so a
@@ -1693,7 +1715,7 @@ static inline void zj_dbg_sync(const char* what) {        // ZJNI_DEBUG_SYNC=1: 
 // (18 KiB per workgroup) does not admit a third.  ZJNI_MULTI_PER_CU overrides.
 static bool ensure_multi_tables(DevState* d) {
     if (d->multiTables) return true;
-    int perCU = 8; if (const char* ov = zj_env("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
+    int perCU = 8; if (const char* ov = zj_tune("ZJNI_MULTI_PER_CU")) { int const v = atoi(ov); if (v >= 1 && v <= 16) perCU = v; }
     int fit = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, zj_encode_multi_kernel, 64, sizeof(ZEEntropy)) == hipSuccess && fit >= 1 && fit < perCU) perCU = fit;
     d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
@@ -1744,17 +1766,17 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     // per lane slot, else one wave per frame (here)
     // (level 4 is double-fast: its frames above 16 KiB stay on list C, where the wave matcher of zj_match_wavex.h parses them — two waves per
     //  SIMD each on its own frame beat 256 waves of one-lane parses; ZJNI_L4_LANES=1 keeps the lane-slot route selectable for A/B runs)
-    bool const l4wave = level == 4 && !(zj_env("ZJNI_L4_LANES") && atoi(zj_env("ZJNI_L4_LANES")) == 1);
+    bool const l4wave = level == 4 && !(zj_tune("ZJNI_L4_LANES") && atoi(zj_tune("ZJNI_L4_LANES")) == 1);
     bool const bigLanes = level > 3 && !l4wave && n >= 4096 && (!g_scratch_limit || g_scratch_limit >= ((size_t)48 << 30));
     if (!bigLanes)
     {   // list C: multi-block frames (levels 1-3) and the single-block frames of levels 4-8 above 16 KiB.  The launch is unconditional (an empty list costs an empty kernel); its tables are a fixed 1 MiB per resident workgroup.
         if (!ensure_multi_tables(d)) return ZJNI_ERR(64);
         u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
         // blocks of multi-block frames: the wave matchers (zj_match_wavex.h: double-fast at level 3, fast at levels 1-2); ZJNI_MULTI_WAVE=0 keeps the one-lane parse selectable for A/B runs, =2 the wave matcher without staged spans
-        u32 multiSerial = 0; if (const char* ov = zj_env("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
+        u32 multiSerial = 0; if (const char* ov = zj_tune("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); multiSerial = v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
         // levels 1-2 (fast strategy): the one-lane parse unless ZJNI_MULTI_WAVE_FAST=1 — the wave version (ZWaveF) is exact but measured slower there
         // (2 048 x 512 KiB at level 1: 156 ms against 138; one 64 KiB table per frame stays in the L2 / Infinity Cache and an iteration of the one-lane loop is one short trip)
-        {   const char* const ov = zj_env("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
+        {   const char* const ov = zj_tune("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                            (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
     }
@@ -1792,7 +1814,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (bigLanes) {
             // list C in slices of ZJ_BIG_SLICE frames: [table set per lane slot][records per frame of the slice][meta]
             size_t bigWaves = (size_t)d->numCU;           // measured at level 5, 65 536 x 64 KiB: 128 / 256 / 512 / 1 024 waves -> 3.69 / 1.95 / 2.44 / 2.74 s (1 MiB of table per lane slot: beyond one wave per CU the rows' random requests take over)
-            if (const char* ov = zj_env("ZJNI_BIG_WAVES")) { long const v = atol(ov); if (v >= 1 && v <= 4096) bigWaves = (size_t)v; }
+            if (const char* ov = zj_tune("ZJNI_BIG_WAVES")) { long const v = atol(ov); if (v >= 1 && v <= 4096) bigWaves = (size_t)v; }
             size_t const slots = bigWaves * 64, tablesB = slots * ZE_MULTI_TABLE_BYTES;
             size_t const fsB = (size_t)ZJ_BIG_SLICE * ZE_FRAME_STRIDE(ZE_BLOCK_MAX), needB = tablesB + fsB + (size_t)ZJ_BIG_SLICE * 12 + 256;
             if (d->wideBufCap < needB) {
@@ -1825,7 +1847,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
     u8* fscratch = nullptr; u32* meta = nullptr; u32 const maxSrc = 65536u;
     // Small level-3 batches: list A goes through the wave-per-frame matcher (tables in LDS, 64 positions per step) and the
     // entropy kernel instead of the fused kernel, whose match finder is one lane walking the frame (3-10x the latency).
-    bool const smallWave = n < splitMin && level == 3 && !tuned && zj_env("ZJNI_NO_OVERLAP") == nullptr && zj_env("ZJNI_NO_WAVE") == nullptr;
+    bool const smallWave = n < splitMin && level == 3 && !tuned && zj_tune("ZJNI_NO_OVERLAP") == nullptr && zj_tune("ZJNI_NO_WAVE") == nullptr;
     if (n >= splitMin || smallWave) {
         u32 const tableStride = ze_lane_table_stride((u32)levelWord, false);   // fast: u16 entries; dfast: 4-byte tagged entries
         size_t const tablesBytes = smallWave ? 0 : n * (size_t)tableStride, fsBytes = n * (size_t)ZE_FRAME_STRIDE(maxSrc), metaBytes = n * 12, qBytes = n * 4;
@@ -1835,10 +1857,10 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // cannot spare them; the machine then runs with every flag set.  ZJNI_LANE_MACHINE=0: the previous machine (ZLaneD), for A/B runs.
         u32 needMode = 2;
         if (const char* ov = zj_env("ZJNI_NEED")) needMode = (u32)atoi(ov);
-        bool const overlap = zj_env("ZJNI_NO_OVERLAP") == nullptr;
-        bool const runMachine = level == 3 && !smallWave && zj_env("ZJNI_HYBRID") == nullptr && !(zj_env("ZJNI_LANE_MACHINE") && atoi(zj_env("ZJNI_LANE_MACHINE")) == 0);
+        bool const overlap = zj_tune("ZJNI_NO_OVERLAP") == nullptr;
+        bool const runMachine = level == 3 && !smallWave && zj_tune("ZJNI_HYBRID") == nullptr && !(zj_tune("ZJNI_LANE_MACHINE") && atoi(zj_tune("ZJNI_LANE_MACHINE")) == 0);
         u32 const hlN = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clN = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
-        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && zj_env("ZJNI_HYBRID") == nullptr
+        bool needGate = (needMode == 1 || needMode == 2) && level == 3 && !smallWave && !g_scratch_limit && zj_tune("ZJNI_HYBRID") == nullptr
                         && overlap && hlN <= ZN_MAX_LOG_L && clN <= ZN_MAX_LOG_S;
         if (needGate && !d->needLdsSet) {                    // more than 64 KiB of dynamic LDS has to be asked for, once per device; refused: no flags
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
@@ -1871,23 +1893,25 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // bound by their random requests) takes the match-dense part, the wave-per-frame kernel (tables in LDS) the rest.
         // Measured on the metric configuration it does not pay: the wave kernel needs the LDS the entropy kernel runs in,
         // and under the lane kernel's traffic it falls to half its stand-alone rate.
-        bool const hybrid = smallWave || (overlap && level == 3 && !tuned && zj_env("ZJNI_HYBRID") != nullptr && zj_env("ZJNI_NO_WAVE") == nullptr);
-        bool const waveOnly = smallWave || (hybrid && zj_env("ZJNI_WAVE_ONLY") != nullptr);
+        bool const hybrid = smallWave || (overlap && level == 3 && !tuned && zj_tune("ZJNI_HYBRID") != nullptr && zj_tune("ZJNI_NO_WAVE") == nullptr);
+        bool const waveOnly = smallWave || (hybrid && zj_tune("ZJNI_WAVE_ONLY") != nullptr);
         unsigned long long* const work2 = (unsigned long long*)(d->counters + 192);
         const u32* listM = listA;
         if (hybrid && hipMemsetAsync(work2, 0, 32, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);   // split = 0: the whole list is the wave kernel's
+#ifdef ZJ_TUNING_KERNELS
         if (hybrid && !waveOnly) {
             u32 const gs = (u32)(n < (size_t)d->numCU * 16 ? n : (size_t)d->numCU * 16);
             u32 threshold = 40;                       // text / JSON-like frames score 15-25, frames searched position by position 50+
-            if (const char* ov = zj_env("ZJNI_WAVE_SCORE")) threshold = (u32)atoi(ov);
+            if (const char* ov = zj_tune("ZJNI_WAVE_SCORE")) threshold = (u32)atoi(ov);
             u32 share = 150;                          // permille of the batch the wave kernel takes at most
-            if (const char* ov = zj_env("ZJNI_WAVE_SHARE")) share = (u32)atoi(ov);
+            if (const char* ov = zj_tune("ZJNI_WAVE_SHARE")) share = (u32)atoi(ov);
             hipLaunchKernelGGL(zj_enc_score_kernel, dim3(gs), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listA, (const u32*)ctr, score);
             hipLaunchKernelGGL(zj_enc_partition_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const u32*)listA, (const u32*)ctr, (const u8*)score, threshold, share, work2, listS);
             hipLaunchKernelGGL(zj_enc_partition_done_kernel, dim3(1), dim3(1), 0, st, (const u32*)ctr, share, work2);
             listM = listS;
         }
-        int const preclearEnv = (zj_env("ZJNI_PRECLEAR") && atoi(zj_env("ZJNI_PRECLEAR")) == 0) ? 0 : 1;
+#endif
+        int const preclearEnv = (zj_tune("ZJNI_PRECLEAR") && atoi(zj_tune("ZJNI_PRECLEAR")) == 0) ? 0 : 1;
         if (tablesBytes) {
             if (wasCleared && d->clearedPtr == tables && d->clearedBytes >= tablesBytes) {          // the previous call left them zero: `st` already waits for evCleared (above)
             } else if (hipMemsetAsync(tables, 0, tablesBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -1902,7 +1926,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         if (hipMemsetAsync(mctr, 0, 12, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
         u32 const waves = (u32)((n + 63) / 64);
         u32 gridM = waves < (u32)d->matchGrid ? waves : (u32)d->matchGrid;
-        if (const char* ov = zj_env("ZJNI_MATCH_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridM) gridM = v; }   // experiments: fewer resident waves, more frames per lane
+        if (const char* ov = zj_tune("ZJNI_MATCH_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridM) gridM = v; }   // experiments: fewer resident waves, more frames per lane
         // with the sequences already found the entropy kernel only needs the entropy-stage LDS (more workgroups per CU)
         u32 const ldsRun = (u32)sizeof(ZEEntropy);
         u32 const gridA = (u32)(n < (size_t)d->encGridLvl[1] ? n : (size_t)d->encGridLvl[1]);
@@ -1925,9 +1949,9 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (hipMemsetAsync(doneList, 0xFF, qBytes, st) != hipSuccess || hipMemsetAsync(procFlag, 0, qBytes, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
             if (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             if ((hybrid || needGate) && hipStreamWaitEvent(d->waveStream, d->evFork, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
-            if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 104 KiB of LDS each, which a CU full of waiting entropy workgroups does not have
+            if (needGate) {      // the flag kernel on its own stream, enqueued before the entropy kernel: its workgroups take 140 KiB of LDS each (sizeof(ZNLds)), which a CU full of waiting entropy workgroups does not have
                 u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
-                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(zj_need_threads()), sizeof(ZNLds), zj_env("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
+                hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(zj_need_threads()), sizeof(ZNLds), zj_tune("ZJNI_NEED_INLINE") ? st : d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                    (const u32*)listA, (const u32*)needPick, (const u32*)(needCtr + 1), needFlags, needReady, needCtr, (u32)ZN_FLAG_STRIDE);
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
                 zj_dbg_sync("zj_enc_need_kernel");
@@ -1940,21 +1964,24 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                 if (hipEventRecord(d->evJoinWave, d->waveStream) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             }
             u32 lanePeriod = 0;                                    // rotation period of the double-fast lane machines (0 = the machine's own)
-            if (const char* ov = zj_env("ZJNI_LANE_PERIOD")) { lanePeriod = (u32)atoi(ov) & 0xFu; if (lanePeriod && lanePeriod < 3u) lanePeriod = 3u; }     // (three non-search states take turns: a shorter rotation would never run one of them)
+            if (const char* ov = zj_tune("ZJNI_LANE_PERIOD")) { lanePeriod = (u32)atoi(ov) & 0xFu; if (lanePeriod && lanePeriod < 3u) lanePeriod = 3u; }     // (three non-search states take turns: a shorter rotation would never run one of them)
             if (runMachine) {
                 void (*kern)(const u8*, const u64*, u32, const u32*, const u32*, u32*, u8*, u32, u8*, u32, u32*, u32*, u32*, u32, u32, const u8*, const u8*, const u32*) = zj_enc_match_run_kernel;
 #ifdef ZJ_TUNING_KERNELS
-                if (const char* ov = zj_env("ZJNI_RUN_JMAX")) { int const j = atoi(ov); kern = j == 3 ? zj_enc_match_run3_kernel : j == 4 ? zj_enc_match_run4_kernel : j == 6 ? zj_enc_match_run6_kernel : j == 7 ? zj_enc_match_run7_kernel : zj_enc_match_run_kernel; }
+                if (const char* ov = zj_tune("ZJNI_RUN_JMAX")) { int const j = atoi(ov); kern = j == 3 ? zj_enc_match_run3_kernel : j == 4 ? zj_enc_match_run4_kernel : j == 6 ? zj_enc_match_run6_kernel : j == 7 ? zj_enc_match_run7_kernel : zj_enc_match_run_kernel; }
 #endif
                 hipLaunchKernelGGL(kern, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                    listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap, (const u32*)needReady);
                 d->lastRoute = needGate ? ZJ_ROUTE_RUN_FLAGS : ZJ_ROUTE_RUN;
-            } else if (needGate) {
+            }
+#ifdef ZJ_TUNING_KERNELS
+            else if (needGate) {
                 hipLaunchKernelGGL(zj_enc_match_gated_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                    listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu, (const u8*)needFlags, (const u8*)needGateMap, (const u32*)needReady);
                 d->lastRoute = ZJ_ROUTE_LANE_GATED;
-            } else
-            if (!waveOnly) {
+            }
+#endif
+            else if (!waveOnly) {
             hipLaunchKernelGGL(zj_enc_match_kernel, dim3(gridM), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord | (lanePeriod << 24),
                                listM, (const u32*)ctr, mctr, tables, tableStride, fscratch, maxSrc, meta, doneList, mctr + 1, 0u, 0xFFFFFFFFu,
                                hybrid ? work2 : (unsigned long long*)nullptr);
@@ -1965,11 +1992,11 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
             if (hybrid && hipStreamWaitEvent(st, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             (void)hipEventRecord(d->tev[1], st); d->tevCompress = true;
             preclear();
-            // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 104 KiB each: the entropy kernel starts when the flags are done
+            // the entropy kernel's persistent workgroups fill the LDS of every CU; the flag kernel's need 140 KiB each: the entropy kernel starts when the flags are done
             // (measured without this: whichever kernel the dispatcher places first wins, and every second call the picked frames' lanes wait out their 50 ms)
-            if (needGate && !zj_env("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
+            if (needGate && !zj_tune("ZJNI_NEED_INLINE") && hipStreamWaitEvent(d->sideStream, d->evJoinWave, 0) != hipSuccess) return bail(ZJNI_ERR(ZJNI_ERROR_no_device));
             u32 gridE = gridA;                                  // (ZJNI_ENT_GRID: fewer entropy workgroups beside the match kernel — with <= 1 024 every match wave is resident from the start, profiles/r05/b_; the call's time does not move)
-            if (const char* ov = zj_env("ZJNI_ENT_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridE) gridE = v; }
+            if (const char* ov = zj_tune("ZJNI_ENT_GRID")) { u32 const v = (u32)atoi(ov); if (v >= 1 && v < gridE) gridE = v; }
             hipLaunchKernelGGL(zj_encode_kernel, dim3(gridE), dim3(64), ldsRun, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst,
                                (const u64*)d_dst_off, (u64*)d_result, (u32)levelWord, listM, (const u32*)ctr, ctr + 2, d->encScratch, eprof,
                                fscratch, maxSrc, (const u32*)meta, 1u, (const u32*)doneList, procFlag, flags, (const ZECDictDev*)nullptr, (u32)(ldsRun), 0u, 0xFFFFFFFFu);
@@ -2013,14 +2040,14 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         size_t const tablesB = sliceB * (size_t)strideB, fsB = sliceB * (size_t)ZE_FRAME_STRIDE(ZE_WIDE_MAX_SRC), metaB = sliceB * 12, qB = sliceB * 4;
         // The entropy kernel BESIDE the match kernel, as on the common path: it takes frames off the completion queue while the slow frames still occupy
         // their lanes; a sweep pass afterwards takes what it did not get to.  ZJNI_NO_OVERLAP: one after the other (A/B runs).
-        bool const besideB = zj_env("ZJNI_NO_OVERLAP") == nullptr;
+        bool const besideB = zj_tune("ZJNI_NO_OVERLAP") == nullptr;
         // Level 3: need flags for the frames zj_enc_worth_kernel picks (zn_flags_frame_wide: 64 KiB + 1 .. 128 KiB) and the run machine for the slice — what the common
         // path does for frames to 64 KiB.  Only when one slice holds the whole list (a call's frames normally do), ZJNI_NEED / ZJNI_LANE_MACHINE as there;
         // ZJNI_NEED_WIDE=0 keeps the wide launch on ZLaneD without flags (A/B runs).
         u32 needModeB = 2; if (const char* ov = zj_env("ZJNI_NEED")) needModeB = (u32)atoi(ov);
         u32 const hlB = ZE_LW_HL(levelWord) ? ZE_LW_HL(levelWord) : (tuned ? 16u : (u32)ZE_L3_HASHLOG), clB = ZE_LW_CL(levelWord) ? ZE_LW_CL(levelWord) : (tuned ? 15u : (u32)ZE_L3_CHAINLOG);
         bool needW = level == 3 && (needModeB == 1 || needModeB == 2) && besideB && !g_scratch_limit && sliceB >= n && hlB <= ZN_MAX_LOG_L && clB <= ZN_MAX_LOG_S
-                     && !(zj_env("ZJNI_LANE_MACHINE") && atoi(zj_env("ZJNI_LANE_MACHINE")) == 0) && !(zj_env("ZJNI_NEED_WIDE") && atoi(zj_env("ZJNI_NEED_WIDE")) == 0);
+                     && !(zj_tune("ZJNI_LANE_MACHINE") && atoi(zj_tune("ZJNI_LANE_MACHINE")) == 0) && !(zj_tune("ZJNI_NEED_WIDE") && atoi(zj_tune("ZJNI_NEED_WIDE")) == 0);
         if (needW && !d->needLdsSet) {
             if (hipFuncSetAttribute((const void*)zj_enc_need_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZNLds)) == hipSuccess) d->needLdsSet = true;
             else { (void)hipGetLastError(); needW = false; }
@@ -2065,7 +2092,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
                                        gateW, readyW, needModeB >= 2 ? 1u : 0u, pickW, needCtrW + 1);
                 }
                 forked = hipEventRecord(d->evFork, st) == hipSuccess && hipStreamWaitEvent(d->sideStream, d->evFork, 0) == hipSuccess;
-                if (forked && needW && hipStreamWaitEvent(d->waveStream, d->evFork, 0) == hipSuccess) {    // the flag kernel on its own stream, enqueued before the entropy kernel (its workgroups need 108 KiB of LDS each)
+                if (forked && needW && hipStreamWaitEvent(d->waveStream, d->evFork, 0) == hipSuccess) {    // the flag kernel on its own stream, enqueued before the entropy kernel (its workgroups need 140 KiB of LDS each)
                     u32 const gn = (u32)(n < (size_t)d->numCU ? n : (size_t)d->numCU);
                     hipLaunchKernelGGL(zj_enc_need_kernel, dim3(gn), dim3(zj_need_threads()), sizeof(ZNLds), d->waveStream, (const u8*)d_src, (const u64*)d_src_off, (u32)levelWord,
                                        (const u32*)listB, (const u32*)pickW, (const u32*)(needCtrW + 1), flagsW, readyW, needCtrW, (u32)ZN_FLAG_STRIDE_WIDE);
@@ -2106,7 +2133,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
 static int zj_level3_word(int lw) {
     u32 const w = (u32)lw;
     if (ZE_LW_LEVEL(w) != 3u || (ZE_LW_HL(w) | ZE_LW_CL(w))) return lw;
-    static int const lds = (zj_env("ZJNI_L3_TABLES") && !strcmp(zj_env("ZJNI_L3_TABLES"), "lds")) ? 1 : 0;
+    static int const lds = (zj_tune("ZJNI_L3_TABLES") && !strcmp(zj_tune("ZJNI_L3_TABLES"), "lds")) ? 1 : 0;
     return lds ? lw : (int)(ZE_LW(3u, 16u, 15u) | ZE_LW_IMPLICIT | (w & ~0xFFFFFFu));
 }
 static size_t compress_chunked(const void* d_src, const uint64_t* d_src_off, void* d_dst, const uint64_t* d_dst_off,
@@ -2151,8 +2178,8 @@ size_t zjni_compress_stream_batch_device(const void* d_src, const uint64_t* d_sr
     if (hipMemsetAsync(ctr, 0, 4, st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device);
     u32 const gc = (u32)(n < (size_t)d->multiGrid ? n : (size_t)d->multiGrid);
     u32 flags = checksum ? ZE_FLAG_CHECKSUM : 0u;
-    if (const char* ov = zj_env("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); flags |= v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
-    {   const char* const ov = zj_env("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) flags |= ZE_FLAG_MULTI_FAST_SERIAL; }      // levels 1-2: the one-lane parse (zj_encode_multi_kernel's default)
+    if (const char* ov = zj_tune("ZJNI_MULTI_WAVE")) { int const v = atoi(ov); flags |= v == 0 ? ZE_FLAG_MULTI_SERIAL : (v == 2 ? ZE_FLAG_MULTI_NOCARRY : 0u); }
+    {   const char* const ov = zj_tune("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) flags |= ZE_FLAG_MULTI_FAST_SERIAL; }      // levels 1-2: the one-lane parse (zj_encode_multi_kernel's default)
     hipLaunchKernelGGL(zj_encode_stream_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                        (u64*)d_result, (u32)level, (u32)n, ctr, d->encScratch, d->multiTables, flags, (u32)sizeof(ZEEntropy), (const u32*)d_flush_at, (const u64*)d_flush_off, (const u32*)d_mode);
     return hipGetLastError() == hipSuccess ? 0 : ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -2258,7 +2285,7 @@ size_t zjni_compress_batch_device_usingCDict(const void* d_src, const uint64_t* 
     u32 const flags = zj_frame_flags(checksum);
     size_t chunk = 2 * ZJ_CHUNK_FRAMES;            // 2 048 match waves = every SIMD's second wave slot as well: more table requests in flight (measured: +15 % over 65 536)
     chunk = scratch_slice((size_t)ZC_TABLE_STRIDE + 2 * ((size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC) + 12), chunk, 1);
-    if (const char* ov = zj_env("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
+    if (const char* ov = zj_tune("ZJNI_CD_SLICE")) { size_t const v = (size_t)atoll(ov); if (v >= 64) chunk = v; }
     size_t const slice = n < chunk ? n : chunk;
     size_t const fsBytes = slice * (size_t)ZE_FRAME_STRIDE(ZC_MAX_SRC), metaBytes = (slice * 12 + 255) & ~(size_t)255, tablesBytes = slice * (size_t)ZC_TABLE_STRIDE;
     size_t const need = tablesBytes + 2 * (fsBytes + metaBytes) + 256;
@@ -2891,9 +2918,10 @@ size_t zjni_synth_fill_device(void* d_dst, size_t bufSize, uint64_t firstIndex, 
 // exclusive prefix sums of a batch's result sizes (error results count as 0) -> off[0 .. n]: one workgroup, a contiguous run per lane, one scan over the lanes' sums
 __global__ __launch_bounds__(1024) void zj_pack_offsets_kernel(const u64* __restrict__ sizes, u64* __restrict__ off, u32 n) {
     __shared__ u64 part[1024];
-    u32 const t = threadIdx.x, per = (n + 1023u) / 1024u, lo = t * per, hi = zj_min(lo + per, n);
+    u32 const t = threadIdx.x;
+    u64 const per = ((u64)n + 1023u) / 1024u, lo0 = (u64)t * per, lo = lo0 < n ? lo0 : n, hi = lo + per < n ? lo + per : n;      // (64-bit: n up to 2^32 - 1 — ADVICE r05)
     u64 sum = 0;
-    for (u32 i = lo; i < hi; i++) { u64 const z = sizes[i]; sum += z > ((u64)1 << 40) ? 0 : z; }
+    for (u64 i = lo; i < hi; i++) { u64 const z = sizes[i]; sum += z > ((u64)1 << 40) ? 0 : z; }
     part[t] = sum;
     __syncthreads();
     for (u32 d = 1; d < 1024u; d <<= 1) {                // (Hillis-Steele over 1 024 sums)
@@ -2903,7 +2931,7 @@ __global__ __launch_bounds__(1024) void zj_pack_offsets_kernel(const u64* __rest
         __syncthreads();
     }
     u64 run = t ? part[t - 1] : 0;
-    for (u32 i = lo; i < hi; i++) { off[i] = run; u64 const z = sizes[i]; run += z > ((u64)1 << 40) ? 0 : z; }
+    for (u64 i = lo; i < hi; i++) { off[i] = run; u64 const z = sizes[i]; run += z > ((u64)1 << 40) ? 0 : z; }
     if (t == 1023u) off[n] = part[1023];
 }
 size_t zjni_pack_batch_device2(const void* d_src, const uint64_t* d_src_off, const uint64_t* d_sizes,
