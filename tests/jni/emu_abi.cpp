@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <mutex>
 #include "../../include/zjni_amd.h"
 
 typedef unsigned long long u64;
@@ -131,6 +133,25 @@ size_t zjni_decompress_usingDDict(void* dst, size_t dstCapacity, const void* src
 }
 
 // no aggregation in the double: ZSTD_JNI_GPU_AGGREGATE is a launch-sharing device, and there are no launches here
+// the asynchronous entries (include/zjni_amd.h: a job that runs the blocking entry on a thread of the library): here a std::thread over the double's blocking entries
+struct zjni_batch_job { std::thread th; size_t code; };
+static std::mutex g_emu_mu;                     // the lane-serial bodies keep their "LDS" and scratch in statics: one job's frames at a time (the real library's kernels of two jobs follow each other too)
+zjni_batch_job* zjni_compress_batch_begin(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity, size_t* result, size_t n, int level, int checksum) {
+    if (zjni_device_count() <= 0) return nullptr;
+    zjni_batch_job* j = new zjni_batch_job(); j->code = 0;
+    j->th = std::thread([=]() { std::lock_guard<std::mutex> g(g_emu_mu); j->code = zjni_compress_batch2(src, srcSize, dst, dstCapacity, result, n, level, checksum); });
+    return j;
+}
+zjni_batch_job* zjni_decompress_batch_begin(const void* const* src, const size_t* srcSize, void* const* dst, const size_t* dstCapacity, size_t* result, size_t n) {
+    if (zjni_device_count() <= 0) return nullptr;
+    zjni_batch_job* j = new zjni_batch_job(); j->code = 0;
+    j->th = std::thread([=]() { std::lock_guard<std::mutex> g(g_emu_mu); j->code = zjni_decompress_batch(src, srcSize, dst, dstCapacity, result, n); });
+    return j;
+}
+size_t zjni_batch_finish(zjni_batch_job* j) {
+    if (!j) return ERR(ZJNI_ERROR_no_device);
+    j->th.join(); size_t const c = j->code; delete j; return c;
+}
 zjni_aggregator* zjni_createAggregator(int, size_t, unsigned) { return nullptr; }
 size_t zjni_aggregator_compress(zjni_aggregator*, void*, size_t, const void*, size_t, int, int) { return ERR(ZJNI_ERROR_no_device); }
 size_t zjni_aggregator_decompress(zjni_aggregator*, void*, size_t, const void*, size_t) { return ERR(ZJNI_ERROR_no_device); }

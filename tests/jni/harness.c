@@ -41,6 +41,9 @@ static void JNICALL f_ReleaseByteArrayElements(JNIEnv* e, jbyteArray a, jbyte* p
 static jboolean JNICALL f_ExceptionCheck(JNIEnv* e) { (void)e; return JNI_FALSE; }
 static int g_deleted;
 static void JNICALL f_DeleteLocalRef(JNIEnv* e, jobject o) { (void)e; (void)o; g_deleted++; }
+static int g_globals = 0;                                 /* global references alive: the asynchronous batch natives hold two per job until batchFinish0 */
+static jobject JNICALL f_NewGlobalRef(JNIEnv* e, jobject o) { (void)e; if (o) g_globals++; return o; }
+static void JNICALL f_DeleteGlobalRef(JNIEnv* e, jobject o) { (void)e; if (o) g_globals--; }
 static struct JNINativeInterface_ g_fn;
 static const struct JNINativeInterface_* g_envp = &g_fn;
 static JNIEnv* env(void) {
@@ -50,7 +53,7 @@ static JNIEnv* env(void) {
     g_fn.SetByteArrayRegion = f_SetByteArrayRegion; g_fn.GetObjectArrayElement = f_GetObjectArrayElement;
     g_fn.SetLongArrayRegion = f_SetLongArrayRegion; g_fn.NewStringUTF = f_NewStringUTF;
     g_fn.GetByteArrayElements = f_GetByteArrayElements; g_fn.ReleaseByteArrayElements = f_ReleaseByteArrayElements;
-    g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef;
+    g_fn.FindClass = f_FindClass; g_fn.GetMethodID = f_GetMethodID; g_fn.NewObject = f_NewObject; g_fn.DeleteLocalRef = f_DeleteLocalRef; g_fn.NewGlobalRef = f_NewGlobalRef; g_fn.DeleteGlobalRef = f_DeleteGlobalRef;
     g_fn.ExceptionCheck = f_ExceptionCheck; g_fn.GetIntField = f_GetIntField; g_fn.SetIntField = f_SetIntField; g_fn.NewDirectByteBuffer = f_NewDirectByteBuffer;
     g_fn.GetObjectClass = f_GetObjectClass; g_fn.GetFieldID = f_GetFieldID; g_fn.GetLongField = f_GetLongField; g_fn.SetLongField = f_SetLongField; g_fn.NewByteArray = f_NewByteArray;
     return (JNIEnv*)&g_envp;
@@ -72,6 +75,9 @@ typedef struct {
     jint (*setHashLog)(JNIEnv*, jclass, jlong, jint); jint (*setChainLog)(JNIEnv*, jclass, jlong, jint);     /* reference only */
     jlong (*cBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jint, jboolean);                 /* shim only */
     jlong (*dBatch)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray);
+    jlong (*cBatchBegin)(JNIEnv*, jclass, jobjectArray, jobjectArray, jint, jboolean);                         /* shim only (round 6) */
+    jlong (*dBatchBegin)(JNIEnv*, jclass, jobjectArray, jobjectArray);
+    jlong (*batchFinish)(JNIEnv*, jclass, jlong, jlongArray);
     void (*dictInit)(JNIEnv*, jobject, jbyteArray, jint, jint, jint); void (*dictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint, jint);
     void (*dictFree)(JNIEnv*, jobject); jlong (*loadCDict)(JNIEnv*, jclass, jlong, jobject);
     void (*ddictInit)(JNIEnv*, jobject, jbyteArray, jint, jint); void (*ddictInitDirect)(JNIEnv*, jobject, jobject, jint, jint, jint);
@@ -93,13 +99,14 @@ static int load(Lib* L, const char* path, int isRef) {
     S(cUnsafe, "Zstd_compressUnsafe"); S(dUnsafe, "Zstd_decompressUnsafe");
     S(setHashLog, "Zstd_setCompressionHashLog"); S(setChainLog, "Zstd_setCompressionChainLog");
     S(cBatch, "Zstd_compressBatch0"); S(dBatch, "Zstd_decompressBatch0");
+    S(cBatchBegin, "Zstd_compressBatchBegin0"); S(dBatchBegin, "Zstd_decompressBatchBegin0"); S(batchFinish, "Zstd_batchFinish0");
     S(dictInit, "ZstdDictCompress_init"); S(dictInitDirect, "ZstdDictCompress_initDirect"); S(dictFree, "ZstdDictCompress_free");
     S(loadCDict, "ZstdCompressCtx_loadCDictFast0"); S(cBatchDict, "Zstd_compressBatchDict0");
     S(ddictInit, "ZstdDictDecompress_init"); S(ddictInitDirect, "ZstdDictDecompress_initDirect"); S(ddictFree, "ZstdDictDecompress_free"); S(loadDDict, "ZstdDecompressCtx_loadDDictFast0");
 #undef S
     if (!L->cinit || !L->cDirect || !L->cArray || !L->dDirect || !L->dArray || !L->bound || !L->errName || !L->cUnsafe) { printf("%s: hot-path natives missing\n", path); return 0; }
     if (!L->setHashLog || !L->setChainLog) { printf("%s: setCompressionHashLog/ChainLog missing\n", path); return 0; }
-    if (!isRef && (!L->cBatch || !L->dBatch || !L->cBatchDict)) { printf("%s: batch natives missing\n", path); return 0; }
+    if (!isRef && (!L->cBatch || !L->dBatch || !L->cBatchDict || !L->cBatchBegin || !L->dBatchBegin || !L->batchFinish)) { printf("%s: batch natives missing\n", path); return 0; }
     if (!L->dictInit || !L->dictInitDirect || !L->dictFree || !L->loadCDict || !L->ddictInit || !L->ddictInitDirect || !L->ddictFree || !L->loadDDict) { printf("%s: ZstdDictCompress natives missing\n", path); return 0; }
     return 1;
 }
@@ -489,6 +496,48 @@ int main(int argc, char** argv) {
         jlong const r2 = G.dBatch(e, NULL, (jobjectArray)fr, (jobjectArray)outs, (jlongArray)res2);
         CHECK(r2 == 0, "decompressBatch0 returned %lld", (long long)r2);
         for (int i = 0; i < NB; i++) CHECK(((jlong*)res2->data)[i] == srcs->elems[i]->len && !memcmp(outs->elems[i]->data, srcs->elems[i]->data, (size_t)srcs->elems[i]->len), "batch round trip %d", i);
+        /* the asynchronous natives (round 6): THREE compress jobs begun before any is finished (two staging slots: the third waits for one), finished in order — the same
+         * frames as the blocking native; then two decompress jobs in flight; global references held per job and released by batchFinish0; the refusals */
+        {   enum { NJ = 3 }; Obj* d2[NJ]; Obj* r3[NJ]; jlong job[NJ];
+            int const g0 = g_globals;
+            for (int k = 0; k < NJ; k++) {
+                d2[k] = mk(3, NB); d2[k]->elems = (Obj**)calloc(NB, sizeof(Obj*)); r3[k] = mk(4, NB);
+                for (int i = 0; i < NB; i++) d2[k]->elems[i] = mk(1, dsts->elems[i]->len);
+                job[k] = G.cBatchBegin(e, NULL, (jobjectArray)srcs, (jobjectArray)d2[k], 1, JNI_FALSE);
+                CHECK(job[k] > 0, "compressBatchBegin0 job %d: %lld", k, (long long)job[k]);
+            }
+            CHECK(g_globals == g0 + 2 * NJ, "global references held by %d jobs: %d", NJ, g_globals - g0);
+            for (int k = 0; k < NJ; k++) {
+                jlong const fr3 = job[k] > 0 ? G.batchFinish(e, NULL, job[k], (jlongArray)r3[k]) : -1;
+                CHECK(fr3 == 0, "batchFinish0 job %d: %lld", k, (long long)fr3);
+                for (int i = 0; i < NB; i++) CHECK(((jlong*)r3[k]->data)[i] == ((jlong*)res->data)[i] && !memcmp(d2[k]->elems[i]->data, dsts->elems[i]->data, (size_t)((jlong*)res->data)[i]), "asynchronous job %d buffer %d differs from the blocking native", k, i);
+            }
+            CHECK(g_globals == g0, "global references released: %d left", g_globals - g0);
+            {   Obj* o2[2]; Obj* r4[2]; jlong dj[2];
+                for (int k = 0; k < 2; k++) { o2[k] = mk(3, NB); o2[k]->elems = (Obj**)calloc(NB, sizeof(Obj*)); r4[k] = mk(4, NB); for (int i = 0; i < NB; i++) o2[k]->elems[i] = mk(1, srcs->elems[i]->len);
+                    dj[k] = G.dBatchBegin(e, NULL, (jobjectArray)fr, (jobjectArray)o2[k]); CHECK(dj[k] > 0, "decompressBatchBegin0 job %d: %lld", k, (long long)dj[k]); }
+                for (int k = 0; k < 2; k++) { CHECK(dj[k] > 0 && G.batchFinish(e, NULL, dj[k], (jlongArray)r4[k]) == 0, "batchFinish0 of decompress job %d", k);
+                    for (int i = 0; i < NB; i++) CHECK(((jlong*)r4[k]->data)[i] == srcs->elems[i]->len && !memcmp(o2[k]->elems[i]->data, srcs->elems[i]->data, (size_t)srcs->elems[i]->len), "asynchronous round trip job %d buffer %d", k, i); }
+            }
+            /* refusals: what the blocking natives answer, as Begin's return (<= 0: nothing begun); a results array too short still finishes and frees the job */
+            CHECK(G.cBatchBegin(e, NULL, NULL, (jobjectArray)dsts, 1, JNI_FALSE) == -72, "compressBatchBegin0(null srcs)");
+            CHECK(G.cBatchBegin(e, NULL, (jobjectArray)srcs, NULL, 1, JNI_FALSE) == -70, "compressBatchBegin0(null dsts)");
+            {   Obj* few = mk(3, 2); few->elems = (Obj**)calloc(2, sizeof(Obj*)); few->elems[0] = mk(1, 10); few->elems[1] = mk(1, 10);
+                CHECK(G.cBatchBegin(e, NULL, (jobjectArray)srcs, (jobjectArray)few, 1, JNI_FALSE) == -72, "compressBatchBegin0(array lengths differ)");
+                Obj* holes = mk(3, 2); holes->elems = (Obj**)calloc(2, sizeof(Obj*)); holes->elems[0] = mk(1, 10);
+                CHECK(G.cBatchBegin(e, NULL, (jobjectArray)holes, (jobjectArray)few, 1, JNI_FALSE) == -72, "compressBatchBegin0(null element)");
+                CHECK(G.dBatchBegin(e, NULL, (jobjectArray)few, (jobjectArray)holes) == -70, "decompressBatchBegin0(null destination element)");
+                Obj* shortRes = mk(4, 1);
+                jlong const j2 = G.cBatchBegin(e, NULL, (jobjectArray)few, (jobjectArray)few, 1, JNI_FALSE);      /* (10-byte destinations: per-buffer dstSize_tooSmall, the call itself is fine) */
+                CHECK(j2 > 0 && G.batchFinish(e, NULL, j2, (jlongArray)shortRes) == -70, "batchFinish0(results too short)");
+                Obj* res5 = mk(4, 2); jlong const j3 = G.cBatchBegin(e, NULL, (jobjectArray)few, (jobjectArray)few, 1, JNI_FALSE);
+                CHECK(j3 > 0 && G.batchFinish(e, NULL, j3, (jlongArray)res5) == 0 && ((jlong*)res5->data)[0] == -70 && ((jlong*)res5->data)[1] == -70, "per-buffer codes of an asynchronous job");
+                Obj* none = mk(3, 0); Obj* res0 = mk(4, 0); jlong const j0 = G.cBatchBegin(e, NULL, (jobjectArray)none, (jobjectArray)none, 1, JNI_FALSE);
+                CHECK(j0 > 0 && G.batchFinish(e, NULL, j0, (jlongArray)res0) == 0, "an empty asynchronous batch");
+                CHECK(G.batchFinish(e, NULL, 0, (jlongArray)res5) == -72 && G.batchFinish(e, NULL, -64, (jlongArray)res5) == -72, "batchFinish0 of no job");
+            }
+            CHECK(g_globals == g0, "global references after the refusals: %d left", g_globals - g0);
+        }
         R.cfree(e, NULL, rc);
     }
     STAGE("frame parameters");
@@ -1132,6 +1181,43 @@ int main(int argc, char** argv) {
             CHECK(answers[0][0] == -60 && answers[0][1] == 3 && answers[0][2] == -60, "the reference inside a frame: checksum %d, level %d, dictionary %d", (int)answers[0][0], (int)answers[0][1], (int)answers[0][2]);
             CHECK(!memcmp(answers[0], answers[1], sizeof answers[0]), "parameters inside a frame: the shim answers checksum %d, level %d, dictionary %d", (int)answers[1][0], (int)answers[1][1], (int)answers[1][2]);
             CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "two frames around parameters set inside the first: ref %zu bytes (%lld), shim %zu bytes (%lld)", lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
+            free(outs[0]); free(outs[1]);
+        }
+        if (getenv("ZSTD_JNI_CPU_LIB")) {
+            /* a level set inside a frame the GPU route is buffering, and the stream then OUTGROWS the level's window (level 1: 512 KiB) — the frame is replayed into the
+             * bundled library, which must recompress it at the level the frame STARTED with (the setter is held back until the replay is done); the next frame runs at the new level */
+            jsize const first = 50000, more = 700000; Obj* src = mk(2, first); Obj* big = mk(2, more);
+            char* outs[2]; size_t lens[2] = {0, 0}; jlong worst[2] = {0, 0}; jint ans[2] = {-1, -1};
+            STAGE("heap-array streams: a level set inside a frame that is replayed later");
+            fill(src->data, first, 1); fill(big->data, more, 2);
+            for (int k = 0; k < 2; k++) {
+                Obj* self = mk(7, 0); Obj* dst = mk(2, 131591);
+                jlong const h = S[k].create(e, NULL); jint r;
+                char* out = (char*)malloc(4 * (size_t)(first + more)); size_t n = 0;
+                r = S[k].level(e, NULL, h, 1); if (r < 0) worst[k] = r;
+                for (int fr = 0; fr < 2 && worst[k] == 0; fr++) {
+                    int guard = 0;
+                    r = S[k].reset(e, (jobject)self, h); if (r < 0) { worst[k] = r; break; }
+                    self->srcPos = 0;
+                    while (self->srcPos < first && guard++ < 100000) {
+                        r = S[k].comp(e, (jobject)self, h, (jbyteArray)dst, 131591, (jbyteArray)src, first); if (r < 0) { worst[k] = r; break; }
+                        memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos;
+                    }
+                    if (fr == 0 && worst[k] == 0) {
+                        ans[k] = S[k].level(e, NULL, h, 3);
+                        self->srcPos = 0; guard = 0;
+                        while (self->srcPos < more && guard++ < 100000) {
+                            r = S[k].comp(e, (jobject)self, h, (jbyteArray)dst, 131591, (jbyteArray)big, more); if (r < 0) { worst[k] = r; break; }
+                            memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos;
+                        }
+                    }
+                    if (worst[k] == 0) { int guard3 = 0; do { r = S[k].end(e, (jobject)self, h, (jbyteArray)dst, 131591); if (r < 0) { worst[k] = r; break; } memcpy(out + n, dst->data, (size_t)self->dstPos); n += (size_t)self->dstPos; } while (r > 0 && guard3++ < 100000); }
+                }
+                S[k].free_(e, NULL, h);
+                outs[k] = out; lens[k] = n;
+            }
+            CHECK(ans[0] == 3 && ans[1] == 3, "level inside the frame: ref %d shim %d", (int)ans[0], (int)ans[1]);
+            CHECK(worst[0] == 0 && worst[1] == 0 && lens[0] == lens[1] && !memcmp(outs[0], outs[1], lens[0]), "a replayed frame keeps the level it started with: ref %zu bytes (%lld), shim %zu bytes (%lld)", lens[0], (long long)worst[0], lens[1], (long long)worst[1]);
             free(outs[0]); free(outs[1]);
         }
         /* HARNESS_FUZZ: random scripts on one ZstdOutputStreamNoFinalizer object — one to three frames (resetCStream between them), writes of random sizes through the

@@ -83,7 +83,7 @@ def test_scratch_limit_bounds_the_library(gpu, oracle_ref):
     # ... and NOT the wide slice (list B: frames of 64 KiB + 1 .. 128 KiB; rounds 1-5 allocated its 20 000 x 1.1 MiB here whatever the batch held): round 6 allocates it
     # when a call has such frames.  n x (384 KiB tables + 320 KiB records + 64 KiB flags) and small change:
     assert big < n * (800 << 10), big
-    n2 = 4200                                                  # a batch WITH wide frames: the slice appears, sized for it, and the frames are the reference's
+    n2 = 8200                                                  # (>= ZJNI_L3_WAVE_MAX: the lane pipeline) a batch WITH wide frames: the slice appears, sized for it, and the frames are the reference's
     src2 = B.synth(n2, 131072, 7, "cuda"); off2 = B.uniform_offsets(n2, 131072, "cuda"); bound2 = gpu.Zstd.compressBound(131072)
     compw = torch.empty(n2 * bound2, dtype=torch.uint8, device="cuda"); coffw = B.uniform_offsets(n2, bound2, "cuda")
     szw = B.compress(src2, off2, compw, coffw, 3); torch.cuda.synchronize()

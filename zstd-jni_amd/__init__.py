@@ -18,6 +18,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libzjni_amd.so")
+if os.environ.get("ZJNI_LIB"):          # another build of the same library (tools/build_variant.sh: A/B variants, the tuning build with its experiment knobs) — never another implementation
+    LIB_PATH = os.environ["ZJNI_LIB"]
 # the kernel file first (the one hipcc is given), then every header beside it: the build stamp and the rebuild test cover them all
 SOURCES = [os.path.join(_HERE, "csrc", "zj_kernels.hip")] + sorted(
     os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h"))

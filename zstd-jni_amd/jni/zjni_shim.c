@@ -221,6 +221,7 @@ static jint zstd_setter(JNIEnv* env, jclass cls, jlong stream, jint v, const cha
     CtxState* s = st_get(stream, what == 'd' ? 'D' : 'C');
     int const streamOk = ss_note_parameter(stream, what, v);
     if (streamOk < 0) return -(jint)60;                 /* ZSTD_error_stage_wrong, as ZSTD_CCtx_setParameter answers past the init stage; nothing is forwarded */
+    if (streamOk == 2) return v == 0 ? 3 : (v > 0 ? v : 0);   /* a level inside a frame made here: the next frame's — the bundled context hears of it when this frame is out or replayed (ss_forward_level), ZSTD_CCtx_setParameter's own answer meanwhile */
     if (s) switch (what) {
         case 'l': s->level = v; break;
         case 'k': s->checksum = (v & 0xFF) != 0; break;
@@ -787,6 +788,80 @@ JNIEXPORT jlong JNICALL P(Zstd_compressBatchDict0)(JNIEnv* env, jclass cls, jobj
     return batch(env, srcs, dsts, results, 1, 0, checksum == JNI_TRUE, g);
 }
 
+/* ---- the same, asynchronous (round 6): two Java-side batches in flight from ONE thread ------------------------
+ * static native long compressBatchBegin0(ByteBuffer[] srcs, ByteBuffer[] dsts, int level, boolean checksum);   // -> job handle; <= 0: the error the blocking native would return (0 - code), nothing begun
+ * static native long decompressBatchBegin0(ByteBuffer[] srcs, ByteBuffer[] dsts);
+ * static native long batchFinish0(long job, long[] results);                                                    // waits, writes results[0 .. n), frees the job; returns what the blocking native returns
+ * zstd-jni's natives block (N/jni_fast_zstd.c:586-640: one ZSTD_compress2 per call) and so do the batch natives above; a single host batch is a chain — gather + H2D,
+ * kernels, D2H + scatter — and the overlap comes from the NEXT batch (zjni_compress_batch_begin / zjni_batch_finish, include/zjni_amd.h: two staging slots per
+ * device).  Begin takes the buffers' addresses and capacities as the blocking natives do and holds GLOBAL references on the two arrays until Finish: the arrays and
+ * their direct buffers belong to the job meanwhile (the array keeps its elements reachable; overwriting an element before Finish is the caller's error, as handing a
+ * ZstdDirectBufferCompressingStream's target to someone else is, N/jni_directbuffercompress_zstd.c:97-161).  A job that is never finished leaks its references. */
+typedef struct BatchJob { zjni_batch_job* job; jobject srcsRef, dstsRef; const void** sp; void** dp; size_t* ss; size_t* dc; size_t* res; jsize n; } BatchJob;
+static void batch_job_free(JNIEnv* env, BatchJob* j) {
+    if (!j) return;
+    if (j->srcsRef && (*env)->DeleteGlobalRef) (*env)->DeleteGlobalRef(env, j->srcsRef);
+    if (j->dstsRef && (*env)->DeleteGlobalRef) (*env)->DeleteGlobalRef(env, j->dstsRef);
+    free(j->sp); free(j->dp); free(j->ss); free(j->dc); free(j->res); free(j);
+}
+static jlong batch_begin(JNIEnv* env, jobjectArray srcs, jobjectArray dsts, int compress, int level, int checksum) {
+    jsize n, i; jlong bad = 0; BatchJob* j;
+    if (srcs == NULL) return E_SRC;
+    if (dsts == NULL) return E_DST;
+    n = (*env)->GetArrayLength(env, srcs);
+    if ((*env)->GetArrayLength(env, dsts) != n) return E_SRC;
+    j = (BatchJob*)calloc(1, sizeof(*j));
+    if (!j) return E_MEM;
+    j->n = n;
+    j->sp = (const void**)malloc((n + 1) * sizeof(*j->sp)); j->dp = (void**)malloc((n + 1) * sizeof(*j->dp));
+    j->ss = (size_t*)malloc((n + 1) * sizeof(*j->ss)); j->dc = (size_t*)malloc((n + 1) * sizeof(*j->dc)); j->res = (size_t*)calloc((size_t)n + 1, sizeof(*j->res));
+    if (!j->sp || !j->dp || !j->ss || !j->dc || !j->res) { batch_job_free(env, j); return E_MEM; }
+    for (i = 0; i < n && !bad; i++) {
+        jobject s = (*env)->GetObjectArrayElement(env, srcs, i), d = (*env)->GetObjectArrayElement(env, dsts, i);
+        jlong const sl = s ? (*env)->GetDirectBufferCapacity(env, s) : -1, dl = d ? (*env)->GetDirectBufferCapacity(env, d) : -1;
+        j->sp[i] = s ? (*env)->GetDirectBufferAddress(env, s) : NULL; j->dp[i] = d ? (*env)->GetDirectBufferAddress(env, d) : NULL;
+        if (s == NULL || sl < 0 || (j->sp[i] == NULL && sl > 0)) bad = E_SRC;
+        else if (d == NULL || dl < 0 || (j->dp[i] == NULL && dl > 0)) bad = E_DST;
+        j->ss[i] = (size_t)(sl < 0 ? 0 : sl); j->dc[i] = (size_t)(dl < 0 ? 0 : dl);
+        if (s && (*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, s);
+        if (d && (*env)->DeleteLocalRef) (*env)->DeleteLocalRef(env, d);
+    }
+    if (bad) { batch_job_free(env, j); return bad; }
+    if ((*env)->NewGlobalRef) { j->srcsRef = (*env)->NewGlobalRef(env, srcs); j->dstsRef = (*env)->NewGlobalRef(env, dsts); }
+    if (n == 0) return (jlong)(intptr_t)j;                               /* an empty batch: a job that finishes at once */
+    j->job = compress ? zjni_compress_batch_begin(j->sp, j->ss, j->dp, j->dc, j->res, (size_t)n, level, checksum)
+                      : zjni_decompress_batch_begin(j->sp, j->ss, j->dp, j->dc, j->res, (size_t)n);
+    if (!j->job) { batch_job_free(env, j); return -(jlong)ZJNI_ERROR_no_device; }
+    return (jlong)(intptr_t)j;
+}
+JNIEXPORT jlong JNICALL P(Zstd_compressBatchBegin0)(JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts, jint level, jboolean checksum) {
+    (void)cls;
+    if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
+    return batch_begin(env, srcs, dsts, 1, level, checksum == JNI_TRUE);
+}
+JNIEXPORT jlong JNICALL P(Zstd_decompressBatchBegin0)(JNIEnv* env, jclass cls, jobjectArray srcs, jobjectArray dsts) {
+    (void)cls;
+    if (!gpu_on()) return -(jlong)ZJNI_ERROR_no_device;
+    return batch_begin(env, srcs, dsts, 0, 0, 0);
+}
+JNIEXPORT jlong JNICALL P(Zstd_batchFinish0)(JNIEnv* env, jclass cls, jlong job, jlongArray results) {
+    BatchJob* const j = (BatchJob*)(intptr_t)job; size_t r = 0; jlong ret;
+    (void)cls;
+    if (job <= 0) return E_SRC;                                           /* not a job: Begin's error codes are <= 0 */
+    if (j->job) r = zjni_batch_finish(j->job);                            /* always waited for and freed, whatever `results` is */
+    ret = (jlong)r;
+    if (!zjni_isError(r)) {
+        if (results == NULL || (*env)->GetArrayLength(env, results) < j->n) ret = E_DST;
+        else if (j->n) {
+            jlong* const out = (jlong*)malloc((size_t)j->n * sizeof(*out)); jsize i;
+            if (!out) ret = E_MEM;
+            else { for (i = 0; i < j->n; i++) out[i] = (jlong)j->res[i]; (*env)->SetLongArrayRegion(env, results, 0, j->n, out); free(out); }
+        }
+    }
+    batch_job_free(env, j);
+    return ret;
+}
+
 /* ==== ZstdDirectBufferCompressingStreamNoFinalizer (N/jni_directbuffercompress_zstd.c) on the GPU ==========================================
  * The reference feeds ZSTD_compressStream / ZSTD_flushStream / ZSTD_endStream.  The GPU route BUFFERS the stream until it is closed (at most the level's
  * unknown-size window: 512 KiB / 1 MiB / 2 MiB at levels 1 / 2 / 3) and makes the frame ZSTD_compressStream2 would have made, byte for byte, in one
@@ -801,6 +876,7 @@ typedef struct StreamState {
     struct StreamState* next; jlong key;
     int level, checksum, cpuMode, started, finished;
     int levelNext, hasLevelNext;                                /* a level set inside a frame made here: the next frame's (ss_note_parameter) */
+    int fwdLevel, fwdLevelPending;                              /* ... and not yet passed on to the bundled context: it would recompress a REPLAYED frame at the new level — passed on when the frame is out, or right behind a replay (ss_forward_level) */
     int levelCpu, paramCpu;                                     /* sticky across sessions (ZstdOutputStream sets parameters once, then resets per frame): a level or a parameter only the bundled library serves */
     unsigned char* buf; size_t total, cap;                      /* everything written so far */
     uint32_t* flushAt; size_t nFlush, flushCap;
@@ -830,6 +906,15 @@ static void ss_reset(StreamState* s, int level) {
 }
 static int ss_inside_gpu_frame(const StreamState* s) { return !s->cpuMode && s->started && !s->finished; }     /* started: the first compress / flush call, where ZSTD_compressStream2 leaves zcss_init */
 /* a frame made here is out: the stream is as ZSTD_endStream leaves it — parameters kept, a level set meanwhile now in force */
+/* the bundled context gets a level that was set inside a frame made here: behind a replay (the bundled stream is then inside the frame at the OLD level, where ZSTD_CCtx_setParameter
+ * accepts a level for the next frame) or when the frame is out */
+static void ss_forward_level(JNIEnv* env, StreamState* s) {
+    jint (*f)(JNIEnv*, jclass, jlong, jint);
+    if (!s->fwdLevelPending) return;
+    s->fwdLevelPending = 0;
+    f = (jint (*)(JNIEnv*, jclass, jlong, jint))cpu_sym(PS("Zstd_setCompressionLevel"));
+    if (f) (void)f(env, NULL, s->key, (jint)s->fwdLevel);
+}
 static void ss_next_frame(StreamState* s) {
     int const lv = s->hasLevelNext ? s->levelNext : s->level, ck = s->checksum, pc = s->paramCpu;
     int const lc = s->hasLevelNext ? (lv < 0 || lv > 3) : s->levelCpu;
@@ -843,7 +928,8 @@ static int ss_note_parameter(jlong stream, int what, jint v) {       /* class Zs
     if (ss_inside_gpu_frame(s)) {                                   /* the bytes written so far wait HERE; the bundled context has not seen them and would accept anything */
         if (what != 'l') return -1;                                 /* ZSTD_CCtx_setParameter past zcss_init: only the update-authorised parameters (C/zstd_compress.c ZSTD_isUpdateAuthorized) */
         s->levelNext = v == 0 ? 3 : v; s->hasLevelNext = 1;         /* the level is one of them: this frame keeps its parameters, the next one starts with the new level */
-        return 1;
+        s->fwdLevel = v; s->fwdLevelPending = 1;
+        return 2;
     }
     if (what == 'l') { s->level = v == 0 ? 3 : v; s->levelCpu = (v < 0 || v > 3); if (s->levelCpu) s->cpuMode = 1; }
     else if (what == 'k') s->checksum = (v & 0xFF) != 0;
@@ -918,6 +1004,7 @@ static int ss_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
     if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (not the bytes the caller already holds: no continuation to offer) */
     s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0;
     s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    ss_forward_level(env, s);
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
 }
@@ -1047,7 +1134,7 @@ static jlong cs_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jobject dst
         (*env)->SetIntField(env, obj, g_cs_produced, (*env)->GetIntField(env, obj, g_cs_produced) + (jint)k);
         return rr;
     }
-    if (s->finished) ss_next_frame(s);                                              /* the frame is out: the next write starts a new one, as ZSTD_endStream leaves the stream */
+    if (s->finished) { ss_forward_level(env, s); ss_next_frame(s); }                /* the frame is out: the next write starts a new one, as ZSTD_endStream leaves the stream */
     return 0;
 }
 JNIEXPORT jlong JNICALL P(ZstdDirectBufferCompressingStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jobject dst_buf, jint dst_offset, jint dst_size) {
@@ -1162,7 +1249,7 @@ JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_resetCStream)(JNIEnv* env, 
     jclass const clazz = (*env)->GetObjectClass(env, obj);
     g_os_src = (*env)->GetFieldID(env, clazz, "srcPos", "J"); g_os_dst = (*env)->GetFieldID(env, clazz, "dstPos", "J");
     if (s) {                                                    /* a new frame; level, checksum and what only the bundled library serves stay */
-        ss_next_frame(s);
+        ss_forward_level(env, s); ss_next_frame(s);
         if (s->level == 0) s->level = 3;
         if (s->levelCpu || s->paramCpu || !streams_on_gpu()) s->cpuMode = 1;
     }
@@ -1241,6 +1328,7 @@ static int os_replay_to_cpu(JNIEnv* env, jobject obj, StreamState* s) {
     if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (the flushed prefix came from the GPU route and the bundled stream has made the same bytes again: skipped — or it has not: no continuation to offer) */
     s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0;
     s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    ss_forward_level(env, s);
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
 }
@@ -1327,7 +1415,7 @@ static jint os_flush_or_end(JNIEnv* env, jobject obj, jlong stream, jbyteArray d
         if (k) return 1;
         return f ? f(env, obj, stream, dst, dst_size) : 0;
     }
-    if (s->finished) ss_next_frame(s);
+    if (s->finished) { ss_forward_level(env, s); ss_next_frame(s); }
     return 0;
 }
 JNIEXPORT jint JNICALL P(ZstdOutputStreamNoFinalizer_flushStream)(JNIEnv* env, jobject obj, jlong stream, jbyteArray dst, jint dst_size) { return os_flush_or_end(env, obj, stream, dst, dst_size, 0); }
@@ -1559,6 +1647,7 @@ static int cx_replay_to_cpu(JNIEnv* env, jclass cls, jlong ptr, StreamState* s) 
     free(scratch);
     if (s->outLen < s->emitted || ss_hash(SS_HASH0, s->out, s->emitted) != s->madeHash) return -1;      /* (see ss_hash: the bundled stream must have made the caller's prefix again) */
     s->outPos = delivered; s->emitted = 0; s->madeHash = SS_HASH0; s->cpuMode = 1; s->total = 0; s->nFlush = 0;
+    ss_forward_level(env, s);
     __atomic_fetch_add(&g_stats[2], 1, __ATOMIC_RELAXED);
     return 0;
 }
