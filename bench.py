@@ -67,7 +67,7 @@ CONFIGS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--skip-lds3", action="store_true", help="skip the extra level-3 pass with the LDS-sized tables (hashLog 14 / chainLog 13)")
     ap.add_argument("--multi", default="", choices=["", "inprocess"], help="inprocess: also time zjni_compress_batch_multi / zjni_decompress_batch_multi (one process, a thread per visible GPU, host pointers) on a sample")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU reference legs (verification + cpu_baseline + end_to_end), e.g. under a profiler")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_model():
@@ -352,8 +352,34 @@ def multi_inprocess_leg(zj, host, size, m, level):
     return out
 
 
-def main():
-    a = parse()
+class GpuPlatform:
+    """Where a step runs: the device of this rank, its stream events, the C-ABI's batch entries (zstd-jni_amd/batch.py) and RCCL.  main() goes through this object for
+    everything that needs a GPU, so that tests/test_bench_gloo.py can run the SAME control flow — rank -> first buffer index, the step loop, the posted gather, the
+    barriers, the MAX over ranks, rank 0's line — at world size 2 over gloo with a stand-in that decodes and encodes on the CPU (test infrastructure; never a bench mode)."""
+    native = True
+
+    def __init__(self, zj, local):
+        self.zj, self.local, self.B = zj, local, zj.batch
+        self.dev = torch.device("cuda", local)
+
+    def init_dist(self):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=self.dev)
+
+    def init_device(self):
+        if not os.path.exists(self.zj.LIB_PATH):
+            self.zj.build()
+        self.B.init(self.local)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)       # recorded on the stream the kernels run on
+
+
+def main(argv=None, platform_factory=GpuPlatform):
+    a = parse(argv)
     cfg = dict(CONFIGS[a.config])
     if a.buffers: cfg["n"] = a.buffers
     if a.size: cfg["size"] = a.size
@@ -376,16 +402,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     zj = entry.load_package()
-    if not os.path.exists(zj.LIB_PATH):
-        zj.build()
-    zj.batch.init(local)
-    dev = torch.device("cuda", local)
-    B = zj.batch
+    P = platform_factory(zj, local)
+    if world > 1:
+        P.init_dist()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    P.init_device()
+    dev = P.dev
+    B = P.B
     if a.config == "5":
         return config5(a, zj, dev, rank, world, cfg)
     first = rank * n                              # disjoint buffer indices per rank (weak scaling)
@@ -423,7 +447,7 @@ def main():
     back = torch.empty(n * size, dtype=torch.uint8, device=dev)
     csz = torch.empty(n, dtype=torch.int64, device=dev)
     dsz = torch.empty(n, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
+    P.sync()
     host_src = None
     if mode == "decode_ref":                      # the frames are the reference's: plain ZSTD_compress2(level), all host threads, outside the timed region
         from oracle import port
@@ -434,9 +458,9 @@ def main():
         csz.copy_(torch.from_numpy(fsz.astype(np.int64)))
         packed_off[1:] = torch.cumsum(csz, 0)
         del frames
-        torch.cuda.synchronize()
+        P.sync()
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)   # recorded on the stream the kernels run on
+    ev = P.event
     t_c, t_p, t_d, t_g = [], [], [], []
     t_stage = []                                        # per-kernel HIP-event times from inside the library (same stream)
 
@@ -458,7 +482,7 @@ def main():
             shard.gather_packed_finish(handle)
         e4.record()
         if timed:
-            torch.cuda.synchronize()
+            P.sync()
             t_c.append(e0.elapsed_time(e1)); t_p.append(e1.elapsed_time(e2)); t_d.append(e2.elapsed_time(e3)); t_g.append(e3.elapsed_time(e4))
             t_stage.append(B.last_timing())
 
@@ -466,17 +490,17 @@ def main():
         step(False)                                      # one-time scratch allocation (tens of GiB, kept by the library) is set-up, not a step
     for _ in range(a.warmup):
         step(False)
-    torch.cuda.synchronize()
+    P.sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    P.sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
-    torch.cuda.synchronize()
+    P.sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    P.sync()
     wall = time.perf_counter() - t0
     if world > 1:
         w = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -484,19 +508,20 @@ def main():
         wall = float(w.item())
 
     # which match finder served the timed steps: asked of the library, not inferred from the environment
-    L = zj.lib()
-    L.zjni_scratch_bytes.restype = C.c_size_t; L.zjni_scratch_bytes.argtypes = []
-    scratch_bytes = int(L.zjni_scratch_bytes())       # what the timed steps made the library allocate and keep on this device (before the extra legs below)
-    route = int(L.zjni_last_route()) if mode != "decode_ref" else 0
-    lists = None
-    if mode != "decode_ref" and hasattr(L, "zjni_last_lists"):
+    L = zj.lib() if P.native else None
+    scratch_bytes = 0; route = 0; lists = None
+    if P.native:
+        L.zjni_scratch_bytes.restype = C.c_size_t; L.zjni_scratch_bytes.argtypes = []
+        scratch_bytes = int(L.zjni_scratch_bytes())       # what the timed steps made the library allocate and keep on this device (before the extra legs below)
+        route = int(L.zjni_last_route()) if mode != "decode_ref" else 0
+    if P.native and mode != "decode_ref" and hasattr(L, "zjni_last_lists"):
         # the library says how the batch was split: a batch whose frames went through the wide launch (128 KiB buffers) names THAT kernel, not list A's
         l3 = (C.c_uint * 3)()
         if L.zjni_last_lists(l3) == 0:
             lists = {"common_launch": int(l3[0]), "wide_launch": int(l3[1]), "multi_block_or_wave_per_frame": int(l3[2])}
             if l3[1] > l3[0] and l3[1] >= l3[2]: route = 10                      # ZJNI_ROUTE_WIDE
     route_kernel = L.zjni_route_kernel(route).decode() if route > 0 else ""
-    stamp = L.zjni_build_stamp().decode()
+    stamp = L.zjni_build_stamp().decode() if P.native else "stand-in"
 
     # ---- the LDS-sized level-3 tables (hashLog 14 / chainLog 13: round 2's default, now behind setHashLog / setChainLog), on the record every run:
     # one warm-up + a timed pass, outside `value`.  The headline itself runs the reference's own sizes (16 / 15).
@@ -506,14 +531,14 @@ def main():
         for it in range(2):
             p0, p1 = ev(), ev()
             p0.record(); B.compress(src, src_off, comp, comp_off, 3, csz2, hash_log=14, chain_log=13); p1.record()
-            torch.cuda.synchronize()
+            P.sync()
         pms = p0.elapsed_time(p1); pst = B.last_timing(); proute = int(L.zjni_last_route())
         lds3 = {"hashLog": 14, "chainLog": 13, "compress_ms": pms, "compress_GiBps_per_gpu": n * size / GIB / (pms / 1e3),
                 "match_kernel": L.zjni_route_kernel(proute).decode(), "match_kernel_ms": pst.get("match", -1.0), "route": proute,
                 "compressed_bytes": int(csz2.clamp(min=0).sum().item()),
                 "note": "ZstdCompressCtx.setHashLog(14).setChainLog(13) through zjni_compress_batch_device_advanced: the table sizes the LDS-resident finders of small batches use; byte identity with the reference given the same two parameters: parity.lds_tables_byte_identical_with_hashLog14_chainLog13"}
         B.compress(src, src_off, comp, comp_off, level, csz, dictionary=cdict)          # leave the headline's frames in `comp` for the gates below
-        torch.cuda.synchronize()
+        P.sync()
 
     # ---- what ONE call costs when the batch is small (a JVM thread's ZstdCompressCtx.compress, the aggregator's few hundred buffers): level 3, the first 1 024
     # buffers of the same batch, one warm-up + a timed call, outside `value`.  Below ZJNI_L3_WAVE_MAX frames the library sends every frame to a wave of its
@@ -525,7 +550,7 @@ def main():
         for it in range(2):                              # frames go into `packed` (free after the timed steps): `comp` keeps the headline's frames for the gates
             p0, p1 = ev(), ev()
             p0.record(); B.compress(src[:ns * size], src_off[:ns + 1], packed, comp_off[:ns + 1], 3, csz3); p1.record()
-            torch.cuda.synchronize()
+            P.sync()
         sroute = int(L.zjni_last_route())
         small = {"frames": ns, "frame_bytes": size, "compress_call_ms": p0.elapsed_time(p1), "route": sroute, "kernel": L.zjni_route_kernel(sroute).decode(),
                  "same_sizes_as_the_full_batch": bool(torch.equal(csz3, csz[:ns])),
@@ -569,9 +594,9 @@ def main():
                 want = [ref.compress(host_k[i * size:(i + 1) * size], level) for i in range(k)]      # the reference's plain call: nothing but the level set
             gates["frames_byte_identical_to_reference"] = all(blob[i * bound:i * bound + max(sizes[i], 0)].tobytes() == want[i] for i in range(k))
             if level == 3 and not dict_bytes and size <= 131072:
-                c2 = torch.empty(k * bound, dtype=torch.uint8, device="cuda")
-                s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, "cuda"), c2, B.uniform_offsets(k, bound, "cuda"), 3, hash_log=14, chain_log=13)
-                torch.cuda.synchronize()
+                c2 = torch.empty(k * bound, dtype=torch.uint8, device=dev)
+                s2 = B.compress(src[:k * size], B.uniform_offsets(k, size, dev), c2, B.uniform_offsets(k, bound, dev), 3, hash_log=14, chain_log=13)
+                P.sync()
                 z2, b2 = s2.cpu().tolist(), c2.cpu().numpy()
                 gates["lds_tables_byte_identical_with_hashLog14_chainLog13"] = all(
                     b2[i * bound:i * bound + max(z2[i], 0)].tobytes() == ref.compress(host_k[i * size:(i + 1) * size], 3, False, 14, 13) for i in range(k))
@@ -595,7 +620,7 @@ def main():
                 # EVERY frame of the batch the CPU leg covered against the reference's frame of the same buffer (the gate above looks at the first k):
                 # the headline's frames (still in `comp`) packed back to back on the device, the reference's uploaded, sizes and bytes compared there
                 B.pack(csz[:m], comp, comp_off[:m + 1], out=packed, out_off=packed_off[:m + 1])
-                torch.cuda.synchronize()
+                P.sync()
                 rs = torch.from_numpy(kept["sizes"].astype(np.int64)).to(dev)
                 same_sizes = bool(torch.equal(rs, csz[:m]))
                 tot_ref = int(kept["sizes"].sum())

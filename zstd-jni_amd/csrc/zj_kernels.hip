@@ -217,6 +217,27 @@ __global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict
 __device__ __forceinline__ bool zj_dec_heavy(const u32* countA) { return countA[1] >= 512u * countA[0]; }      // countA = &listCounts[8]
 
 
+// Longest first (round 6).  The sequence decode is a lane per frame and a lane's time is its frame's sequence count (one per round); the batch is about two frames per
+// resident lane, handed out from a counter in list order.  In the order stage 1 happened to finish them, the lanes' first frames end together half-way through the
+// launch and their second frames together at its end: the execution kernel beside it idled, got half the batch at once, and the other half when the decode left — a
+// 5.6 ms tail behind a 12.3 ms decode (profiles/r05/ d).  Sorted by descending sequence count (a counting sort over 256 buckets of 32 sequences, one workgroup, ~30 us)
+// every lane starts on a long frame and the launch ends on short ones that finish spread out: the makespan is LPT's, and what is left for the execution kernel when
+// the decode leaves is a handful of short frames.  The literal pass and the sweep pass walk the same order.  Light batches (zj_dec_heavy false: 4 KiB records, equal
+// costs) and lists beyond 2^18 frames are copied as they are.
+__global__ __launch_bounds__(1024) void zj_dec_sort_kernel(const u32* __restrict__ listA, const u32* countA, const ZDMeta* __restrict__ metas, u32* __restrict__ listS) {
+    __shared__ u32 hist[256], base[256];
+    u32 const count = countA[0], t = threadIdx.x;
+    if (!zj_dec_heavy(countA) || count > (1u << 18)) { for (u32 k = blockIdx.x * 1024u + t; k < count; k += gridDim.x * 1024u) listS[k] = listA[k]; return; }     // (every workgroup of the launch copies; the sort is workgroup 0's)
+    if (blockIdx.x) return;
+    if (t < 256u) hist[t] = 0;
+    __syncthreads();
+    for (u32 k = t; k < count; k += 1024u) { u32 const q = metas[listA[k]].nbSeq >> 5; atomicAdd(&hist[q < 255u ? q : 255u], 1u); }
+    __syncthreads();
+    if (t == 0) { u32 run = 0; for (int b = 255; b >= 0; b--) { base[b] = run; run += hist[b]; } }
+    __syncthreads();
+    for (u32 k = t; k < count; k += 1024u) { u32 const i = listA[k], q = metas[i].nbSeq >> 5; listS[atomicAdd(&base[q < 255u ? q : 255u], 1u)] = i; }
+}
+
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
                                                          const u32* countPtr, u32* workCounter, const u16* tabs, u64* seqs, ZDMeta* metas,
                                                          const ZDDictDev* dd, u32* doneList, u32* doneCount, u32 heavyWaves) {
@@ -1509,7 +1530,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
     if (const char* ov = zj_env("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (n >= splitMin) {
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
-        size_t const need = tabBytes + seqBytes + metaBytes + 4 * listBytes + 256;
+        size_t const need = tabBytes + seqBytes + metaBytes + 5 * listBytes + 256;
         if (d->dsplitBufCap < need) {
             if (!scratch_make_room(d, d->dsplitBufCap, need)) return ZJNI_ERR(64);
             if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
@@ -1520,6 +1541,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
+        u32* const listRaw = procFlag + n;        // list A as stage 1 appends it; `listA` below is what zj_dec_sort_kernel makes of it (longest frames first)
         u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A, [10] work of the literal pass
         // Stage 2b (zd_lit_frame): one literal slot per frame, as large as the budget allows (at most a block); frames whose literals do
         // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
@@ -1550,9 +1572,10 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         (void)hipEventRecord(d->tev[2], st);
         ZDMbHost const mb = decode_mb_scratch(d, n, st, ddict != nullptr);       // frames that are not simple: multi-block, no content size (the stream classes')
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+                                      (u32)n, c + 2, tabs, metas, listRaw, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
         else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+                                (u32)n, c + 2, tabs, metas, listRaw, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+        hipLaunchKernelGGL(zj_dec_sort_kernel, dim3(32), dim3(1024), 0, st, (const u32*)listRaw, (const u32*)(c + 8), (const ZDMeta*)metas, listA);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
