@@ -655,7 +655,7 @@ def main(argv=None, platform_factory=GpuPlatform):
         # entropy kernel (it runs beside the match kernel on a side stream) + sweep, i.e. compress call minus match kernel
         match_name = "zj_enc_match_dict_kernel(last slice)" if mode == "dict" else ("zj_enc_match_wide_kernel" if size > 65536 else (route_kernel or "zj_enc_match_kernel"))
         if size > 131072:
-            match_name = "zj_encode_multi_kernel"
+            match_name = route_kernel if route == 11 else "zj_encode_multi_kernel"       # (11 = ZJNI_ROUTE_PIPE: the pipelined pair of waves, decided on the device)
         gated = route == 6 or route == 4                       # ZJNI_ROUTE_RUN_FLAGS / ZJNI_ROUTE_LANE_GATED: flag kernels beside the match kernel
         kernels = {"zj_dec_prep_kernel": stage.get("dec_prep", -1.0), "zj_dec_seq_kernel": stage.get("dec_seq", -1.0),
                    "zj_dec_exec_kernel": stage.get("dec_exec", -1.0), "zj_decode_kernel(leftovers)": stage.get("dec_fused", -1.0)}

@@ -302,6 +302,8 @@ int zjni_last_timing2(float* out8);
 #define ZJNI_ROUTE_OTHER 8        /* levels 4-8, dictionaries, multi-block only */
 #define ZJNI_ROUTE_WAVE_HBM 9     /* zj_encode_multi_kernel: level-3 frames of batches below ZJNI_L3_WAVE_MAX, wave per frame over HBM tables (zj_match_wavex.h) */
 #define ZJNI_ROUTE_WIDE 10        /* zj_enc_match_wide_kernel: the launch of frames above 64 KiB (list B); never zjni_last_route()'s answer — see zjni_last_lists */
+#define ZJNI_ROUTE_PIPE 11        /* zj_encode_pipe_kernel (round 6): multi-block frames of a batch that leaves wave slots empty, a parse wave a block ahead of an entropy wave per frame;
+                                     decided on the device from the list counts, so zjni_last_route() says it only after zjni_last_lists() has read them */
 int zjni_last_route(void);
 /* How the last large compress call's frames were split: out3[0] the common launch (the route above), out3[1] the wide launch (ZJNI_ROUTE_WIDE), out3[2] the
  * multi-block / wave-per-frame kernel.  A batch of 128 KiB buffers has out3[1] = n: its match-finder time is zjni_last_timing2's out8[5] and its kernel

@@ -273,14 +273,24 @@ extern "C" unsigned long long emu_compress_multi(const unsigned char* src, unsig
     EMU_IO(src, srcSize, dst, dstCap);
     Grp<1> g;
     u32 const flags = (level >> 8) & (ZE_FLAG_MASK | ZE_FLAG_MULTI_SERIAL | ZE_FLAG_MULTI_NOCARRY | ZE_FLAG_MULTI_FAST_SERIAL);
+    bool const pipelined = (level & 0x8000u) != 0;                   // 0x8000: the pipelined pair of roles (zj_encode_pipe_kernel) instead of the one-wave loop
     level = ZE_LW(level & 0xFFu, (level >> 16) & 0xFFu, (level >> 24) & 0xFFu);                 // hashLog << 16 | chainLog << 24: the level word of a level-3 frame on the wave route (ZJNI_ROUTE_WAVE_HBM)     // 0x800: the one-lane parse of level-3 blocks instead of the wave matcher; 0x1000: the wave matcher without staged spans
     EmuWg& wg = emu_wg(); ZEncShared* sh = wg.sh; u8* lds = wg.lds; u8* ws = wg.ws;
     u32* tables = (u32*)malloc(ZE_MULTI_TABLE_BYTES);
     memset(tables, 0xA5, ZE_MULTI_TABLE_BYTES);                      // the encoder clears what it uses
     ZjProf pf; pf.start(nullptr);
     // zj_encode_multi_kernel's routing: a single block (level 4: match-finder tables in HBM) or a multi-block frame (levels 1-3)
-    u64 const r = srcSize <= ZE_BLOCK_MAX ? ze_compress_t<Grp<1>, u32>(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, nullptr, flags, nullptr, 160u * 1024u, nullptr, tables)
-                                          : ze_compress_multi(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u);
+    u64 r;
+    if (srcSize > ZE_BLOCK_MAX && pipelined) {
+        // zj_encode_pipe_kernel's two waves (round 6): a parse role and an entropy role with their own uniforms, LDS regions and scratch slots, run one after the other
+        static ZEncShared* shP = nullptr; static u8* ldsP = nullptr; static u8* ws1 = nullptr;
+        if (!shP) { shP = (ZEncShared*)malloc(sizeof(ZEncShared)); ldsP = (u8*)malloc(160 * 1024); ws1 = (u8*)malloc(ZE_SCRATCH_BYTES); }
+        memset(shP, 0xA5, sizeof(ZEncShared)); memset(ldsP, 0x5A, 160 * 1024); memset(ws1, 0xC3, ZE_SCRATCH_BYTES);
+        ZEPipe pipe; memset(&pipe, 0xA5, sizeof pipe);
+        r = ze_compress_multi_pipe_serial(g, *shP, *sh, ldsP, lds, pipe, src, srcSize, dst, dstCap, level, ws, ws1, pf, flags, tables, 160u * 1024u);
+    } else
+    r = srcSize <= ZE_BLOCK_MAX ? ze_compress_t<Grp<1>, u32>(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, nullptr, flags, nullptr, 160u * 1024u, nullptr, tables)
+                                : ze_compress_multi(g, *sh, lds, src, srcSize, dst, dstCap, level, ws, pf, flags, tables, 160u * 1024u);
     free(tables);
     return r;
 }

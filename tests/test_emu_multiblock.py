@@ -28,6 +28,8 @@ def check(emu, ref, d, level, checksum=False, content_size=True, tag=None):
         return None
     want = ref.compress(d, level, checksum, content_size=content_size)
     assert got == want, (tag, len(d), level, checksum, content_size, len(want), got if isinstance(got, int) else len(got))
+    piped = emu_compress_multi(emu, d, level, checksum, content_size, pipelined=True)          # zj_encode_pipe_kernel's two roles (round 6): a parse wave ahead of an entropy wave
+    assert piped == want, ("pipelined", tag, len(d), level, checksum, content_size, len(want), piped if isinstance(piped, int) else len(piped))
     return got
 
 
@@ -179,3 +181,28 @@ def test_presplit_on_the_group_equals_the_one_lane_walk(emu, zj):
         assert a == b, (k, a, b)
         cuts.add(a)
     assert len(cuts) >= 6 and 131072 in cuts, cuts          # the inputs did exercise several cut positions and "no cut"
+
+
+def test_pipelined_roles_in_tight_destinations(emu, oracle_ref, zj):
+    """zj_encode_pipe_kernel (round 6): the parse role runs a block ahead of the entropy role on an UPPER BOUND of the previous block's compressed size and waits for the
+    real answer where the bound decides nothing — data that does not compress, blocks of one repeated byte (RLE blocks), tiny last blocks, destinations with little room
+    (the reference's "tight" detours: raw blocks, dstSize_tooSmall).  Every capacity around the frame's size gives the reference's answer, bytes or code; a wrong
+    assumption would surface as error 1 (the entropy role checks each one against the block's real result)."""
+    rnd = random.Random(66)
+    noise = bytes(rnd.getrandbits(8) for _ in range(300000))
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    datas = [xml[1000:1000 + 300000], noise[:140000] + xml[:150000], xml[:131072] + bytes([7]) * 140000 + xml[5000:9000], bytes([9]) * 131072 + noise[:20000] + bytes([9]) * 131072,
+             zj.synth_host(65536, 5, 1) * 4 + noise[:3], (noise[:5000] * 60)[:270000], xml[:131072] + noise[:131072] + xml[:6]]
+    for k, d in enumerate(datas):
+        for level in (3, 1):
+            if len(d) > WINDOW[level]: continue
+            full = oracle_ref.compress(d, level)
+            assert emu_compress_multi(emu, d, level, pipelined=True) == full, (k, level)
+            fs = len(full)
+            for cap in sorted({fs - 1, fs, fs + 1, fs + 7, fs + 8, fs + 9, fs + 64, fs + 1024, fs + 1030, fs // 2, 17, 18, len(d), len(d) + 20, fs + 131072 + 1100}):
+                try:
+                    want = oracle_ref.compress(d, level, cap=cap)
+                except oracle_ref.ZstdRefError as ex:
+                    want = -ex.code
+                got = emu_compress_multi(emu, d, level, pipelined=True, cap=cap)
+                assert got == want, (k, level, cap, fs, got if isinstance(got, int) else len(got), want if isinstance(want, int) else len(want))

@@ -98,3 +98,43 @@ def test_gpu_multiblock_repeated_calls_leave_no_state_behind(gpu, oracle_ref):
             for i, (z, w) in enumerate(zip(outs, want)):
                 if w is not None:
                     assert z == w, (level, rep, i, len(datas[i]))
+
+
+@pytest.mark.parametrize("route", ["pipelined", "one-wave"])
+def test_gpu_multiblock_pipelined_pair_of_waves(gpu, oracle_ref, monkeypatch, route):
+    """zj_encode_pipe_kernel (round 6): a batch of multi-block frames that leaves wave slots empty is parsed a block AHEAD of its entropy stage, two waves per frame — the
+    parse wave runs on an upper bound of the previous block's compressed size and waits for the real answer where the bound decides nothing (noise, one repeated byte,
+    tight destinations); the entropy wave checks every assumption (a wrong one would come back as error 1).  Frames and refusals are the reference's at every capacity;
+    the library names the kernel (ZJNI_ROUTE_PIPE after zjni_last_lists).  one-wave: the same batch on zj_encode_multi_kernel (ZJNI_PIPE_MAX=0, tuning builds)."""
+    import ctypes as C
+    if route == "one-wave":
+        needs_tuning_build(gpu)
+        monkeypatch.setenv("ZJNI_PIPE_MAX", "0")
+    rnd = random.Random(77)
+    xml = oracle_ref.decompress(golden("xml-1.zst"), 6_000_000)
+    noise = bytes(rnd.getrandbits(8) for _ in range(300000))
+    datas = [xml[1000:1000 + 300000], noise[:140000] + xml[:150000], xml[:131072] + bytes([7]) * 140000 + xml[5000:9000], bytes([9]) * 131072 + noise[:20000] + bytes([9]) * 131072,
+             gpu.synth_host(65536, 5, 1) * 4 + noise[:3], (noise[:5000] * 60)[:270000], xml[:131072] + noise[:131072] + xml[:6], xml[:1 << 20], xml[777:777 + (2 << 20)]]
+    datas += [d for d in inputs(gpu, oracle_ref, 7, 30) if len(d) > 131072]
+    for level in (3, 1, 2):
+        ds = [d for d in datas if len(d) <= WINDOW[level]]
+        want = [oracle_ref.compress(d, level) for d in ds]
+        outs = gpu.compress_batch(ds, level)
+        l3 = (C.c_uint * 3)()
+        assert gpu.lib().zjni_last_lists(l3) == 0 and l3[2] == len(ds)
+        assert gpu.lib().zjni_last_route() == (11 if route == "pipelined" else 9), gpu.lib().zjni_last_route()
+        for k, (z, w) in enumerate(zip(outs, want)):
+            assert z == w, (level, k, len(ds[k]), z if isinstance(z, Exception) else "bytes differ")
+        assert gpu.decompress_batch(outs, [len(d) for d in ds]) == ds
+        # destinations around the frame's size: the reference's bytes or its refusal, frame by frame
+        caps, exp = [], []
+        for d, w in zip(ds, want):
+            fs = len(w); cap = rnd.choice([fs - 1, fs, fs + 1, fs + 7, fs + 8, fs + 9, fs + 64, fs + 1030, fs // 2, 17, 18, len(d), len(d) + 20])
+            caps.append(cap)
+            try:
+                exp.append(oracle_ref.compress(d, level, cap=cap))
+            except oracle_ref.ZstdRefError as ex:
+                exp.append(-ex.code)
+        outs = gpu.compress_batch(ds, level, capacities=caps)
+        for k, (z, w) in enumerate(zip(outs, exp)):
+            assert (-z.getErrorCode() if isinstance(z, Exception) else z) == w, (level, k, caps[k], len(want[k]))

@@ -107,12 +107,12 @@ def emu_decompress_split(L, frame, cap):
     return dst.raw[:r], bool(used.value)
 
 
-def emu_compress_multi(L, data, level, checksum=False, content_size=True, serial=False, hash_log=0, chain_log=0):
+def emu_compress_multi(L, data, level, checksum=False, content_size=True, serial=False, hash_log=0, chain_log=0, pipelined=False, cap=None):
     """multi-block frames (ze_compress_multi, lane-serial): frame bytes or -code.  serial: level-3 blocks on the one-lane parse
     (ZE_FLAG_MULTI_SERIAL) instead of the wave matcher (zj_match_wavex.h, 64 emulated lanes); serial=2: the wave matchers without staged spans; serial=4: levels 1-2 on the one-lane parse, level 3 on the wave matcher"""
-    cap = len(data) + (len(data) >> 8) + 64 + 128
-    dst = C.create_string_buffer(cap)
-    r = L.emu_compress_multi(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (0 if content_size else 0x200) | (0x800 if serial is True else 0x1000 if serial == 2 else 0x2000 if serial == 4 else 0) | (hash_log << 16) | (chain_log << 24))
+    if cap is None: cap = len(data) + (len(data) >> 8) + 64 + 128
+    dst = C.create_string_buffer(max(cap, 1))
+    r = L.emu_compress_multi(data, len(data), dst, cap, level | (0x100 if checksum else 0) | (0 if content_size else 0x200) | (0x800 if serial is True else 0x1000 if serial == 2 else 0x2000 if serial == 4 else 0) | (0x8000 if pipelined else 0) | (hash_log << 16) | (chain_log << 24))
     if r >= (1 << 63):
         return -((1 << 64) - r)
     return dst.raw[:r]

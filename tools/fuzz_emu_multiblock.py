@@ -38,6 +38,7 @@ def piece(n):
         while len(out) < n: out += bytes([rnd.getrandbits(8)]) * rnd.randrange(200, 9000) + os.urandom(rnd.randrange(0, 12))
         return bytes(out[:n])
     a = piece(n // 2); return (a + piece(n - len(a)))[:n]
+PIPE = os.environ.get("FUZZ_PIPE") == "1"      # zj_encode_pipe_kernel's two roles (round 6: the parse role a block ahead of the entropy role) instead of the one-wave loop
 t0 = time.time(); cases = bad = 0
 while time.time() - t0 < budget:
     size = rnd.choice([rnd.randrange(131073, 300000), rnd.randrange(131073, 600000), rnd.randrange(131073, 2097153), 131073, 262144, 262145, 524288, 1048576])
@@ -47,7 +48,7 @@ while time.time() - t0 < budget:
         if rnd.random() < 0.2 and parts: parts.append(parts[rnd.randrange(len(parts))])
     d = b"".join(parts)[:size]
     lvl = rnd.choice(LEVELS); ck = rnd.random() < 0.2; cs = rnd.random() < 0.85
-    got = util.emu_compress_multi(L, d, lvl, ck, cs, SERIAL)
+    got = util.emu_compress_multi(L, d, lvl, ck, cs, SERIAL, pipelined=PIPE)
     if len(d) > (1 << (18 + lvl)):
         ok = got == -201
     else:

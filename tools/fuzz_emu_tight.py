@@ -106,7 +106,9 @@ while time.time() - t0 < budget:
     hl = cl = 0
     if level == 3 and 8192 < n <= 131072: hl, cl = 14, 13                                       # the library's level-3 tables for these sizes
     word = level | (int(checksum) << 8) | ((0 if content_size else 1) << 9)
-    if n > 131072 or (level >= 4 and (n > 16384 or rnd.random() < 0.5)): fn = L.emu_compress_multi      # zj_encode_multi_kernel's routes
+    if n > 131072 or (level >= 4 and (n > 16384 or rnd.random() < 0.5)):
+        fn = L.emu_compress_multi      # zj_encode_multi_kernel's routes
+        if n > 131072 and rnd.random() < 0.5: word |= 0x8000                                           # ... and zj_encode_pipe_kernel's pair of roles (round 6)
     elif level >= 4: fn = L.emu_compress_chain                                                      # chain parser per lane + entropy stage on its records
     else: fn = L.emu_compress if rnd.random() < 0.6 else L.emu_compress_split                        # fused / lane match finder + entropy stage
     full = reference(data, None, level, checksum, content_size, hl, cl)

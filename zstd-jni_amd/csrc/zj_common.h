@@ -82,6 +82,20 @@ struct Grp {
 #endif
 };
 
+// One wave of a workgroup that holds SEVERAL, each at work of its own (zj_encode_pipe_kernel: a parse wave and an entropy wave per frame): the group is the
+// wave, so its sync() must not be the workgroup's barrier — the waves run different code and would meet different numbers of them.  A wave's LDS and vector
+// memory instructions are issued in order; what a sync has to do is make the compiler keep that order and wait for what is outstanding.
+struct GrpWave {
+    static constexpr int W = 64;
+#if ZJ_ON_GPU
+    ZJ_DEV u32 lane() const { return threadIdx.x & 63u; }
+    ZJ_DEV void sync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else
+    u32 lane() const { return 0; }
+    void sync() const {}
+#endif
+};
+
 // Values that lane 0 publishes through LDS are the same in every lane, but the compiler cannot know
 // that and would build exec-masked ("divergent") control flow around them.  With single-wave
 // workgroups hipcc also elides s_barrier, so a divergent loop whose exit depends on such a value can

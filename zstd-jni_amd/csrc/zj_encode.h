@@ -2322,6 +2322,195 @@ ZJ_DEV u64 ze_compress_stream(const G& g, ZEncShared& sh, u8* lds, const u8* src
     return pos + tail;
 }
 
+// ---- multi-block frames, PIPELINED (round 6): a parse wave one block ahead of an entropy wave ------------------------------------------------------------
+// ze_compress_multi is a chain per frame — size of the next block, parse, entropy stage, block by block on one wave: 8 x (16 + 11) ms for a 1 MiB frame, and a
+// batch of a thousand such frames (BASELINE config 1) leaves three quarters of the device idle while every frame waits for its own chain.  What block b + 1's
+// PARSE needs from block b's ENTROPY STAGE is little (N/compress/zstd_compress.c:4383-4448, :4591-4692): whether b was emitted compressed — only then are its
+// repcodes the next block's (ZSTD_blockState_confirmRepcodesAndEntropyTables, :4436-4439) — and whether the frame has saved 3 bytes yet (ZSTD_optimalBlockSize,
+// :4552-4581: only then is the pre-splitter asked).  Both follow WITH CERTAINTY from an upper bound on b's compressed size that the parse can compute itself:
+//   U(b) = 3 + (litSize + 3) + 3 + 1 + 150 + ceil((26 nbSeq + extra bits + 26 + 15) / 8) + 8
+// — raw literals are the literal stage's worst case (ZSTD_compressLiterals falls back to them), 9 + 8 + 9 bits the widest tANS codes of a sequence, 150 bytes three
+// table descriptions.  U(b) < blockSize - minGain makes the block compressed whatever the entropy stage finds (ZSTD_entropyCompressSeqStore :3019-3035), provided
+// the destination has room to spare (no "tight" detour) and the sequences carry >= 256 extra bits (so the block is neither the "< 4 bytes" oddity of
+// ZSTD_entropyCompressSeqStore_internal nor short enough — < 25 bytes — to be turned into an RLE block).  Where the bound says nothing (data that does not
+// compress, tiny blocks, tight destinations) the parse wave WAITS for the entropy wave's answer, as the one-wave loop does for every block.
+// The two waves share a workgroup: records and literal offsets go through the workgroup's two scratch slots in HBM (block b in slot b & 1), block descriptions,
+// results and the two counters through LDS; fences are workgroup-scope (no L2 write-back).  The entropy wave CHECKS every assumption the parse wave made about
+// a block when it has that block's real result (type and size against U): a wrong one fails the frame (error 1) instead of writing other bytes.
+// Exact: tests/test_emu_multiblock.py (the emulation runs the same two roles, the entropy role stepping whenever the parse role waits).
+struct ZEPipeBlk { u32 start, size, nbSeq, litSize, lastLL, isFirst, lastBlock, assumePrev, prevU; };      // (nbSeq, litSize, lastLL: ZEPre::meta)
+struct ZEPipe {
+    u32 ready;                      // blocks the parse wave has published
+    u32 done;                       // blocks the entropy wave has finished
+    u32 err;                        // the entropy wave gave the frame up (the parse wave stops)
+    u32 resType[2], resSize[2];     // block b's result at [b & 1]: block type (0 raw, 1 RLE, 2 compressed), bytes written (3-byte header included)
+    ZEPipeBlk blk[2];               // block b's description at [b & 1]
+    u32 sum;                        // scratch of the parse wave (extra-bit total)
+};
+#if ZJ_ON_GPU
+ZJ_DEV u32 ze_pipe_load(const u32* p) { return *(const volatile u32*)p; }
+ZJ_DEV void ze_pipe_add(u32* p, u32 v) { atomicAdd(p, v); }
+#else
+static inline u32 ze_pipe_load(const u32* p) { return *p; }
+static inline void ze_pipe_add(u32* p, u32 v) { *p += v; }
+#endif
+// the entropy wave's state between blocks
+struct ZEPipeE { u32 b, pos, finished; u64 result; };
+template <class G>
+ZJ_DEV void ze_pipe_entropy_init(const G& g, ZEncShared& sh, ZEPipeE& st, u8* dst, u32 dstCap, u32 srcSize, u32 level, u32 flags) {
+    ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), srcSize);
+    bool const noFcs = (flags & ZE_FLAG_NO_FCS) != 0;
+    st.b = 0; st.pos = noFcs ? 6u : 9u; st.finished = 0; st.result = 0;
+    if (dstCap < 18u) { st.finished = 1; st.result = ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL); return; }
+    GRP_SERIAL(g) {
+        u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
+        st32(dst, 0xFD2FB528u);
+        if (noFcs) { dst[4] = (u8)(tail ? 4u : 0u); dst[5] = (u8)((p.windowLog - 10u) << 3); }
+        else { dst[4] = (u8)((1u << 5) + (2u << 6) + (tail ? 4u : 0u)); st32(dst + 5, srcSize); }
+        sh.dictHufRep = ZC_REPEAT_NONE; sh.dictHufMaxSV = 0; sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.blkNextRep[0] = 1; sh.blkNextRep[1] = 4;
+    }
+    g.sync();
+}
+// one block: the parse wave has published it (pipe.ready > st.b)
+template <class G>
+ZJ_DEV void ze_pipe_entropy_step(const G& g, ZEncShared& sh, u8* lds, ZEPipe& pipe, ZEPipeE& st, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level, u32 flags,
+                                 u8* ws0, u8* ws1, ZjProf& pf, u32 ldsBytes) {
+    u32 const b = st.b;
+    ZEPipeBlk* const kb = &pipe.blk[b & 1u];
+    u32 const start = ZJ_UNI(kb->start), size = ZJ_UNI(kb->size), lastBlock = ZJ_UNI(kb->lastBlock);
+    if (b >= 1u && ZJ_UNI(kb->assumePrev)) {              // what the parse wave took for granted about block b - 1 when it parsed this one
+        if (ZJ_UNI(pipe.resType[(b - 1u) & 1u]) != 2u || ZJ_UNI(pipe.resSize[(b - 1u) & 1u]) > ZJ_UNI(kb->prevU)) {
+            GRP_SERIAL(g) { pipe.err = 1; } st.finished = 1; st.result = ZJ_ERR64(ZJ_E_GENERIC); zj_mem_order(); g.sync(); return; }
+    }
+    u8* const ws = (b & 1u) ? ws1 : ws0;
+    ZEPre pre; pre.seqs = (ZESeq*)(ws + ZE_WS_SEQ); pre.litOff = (const u32*)(ws + ZE_WS_BODY); pre.meta = &kb->nbSeq;
+    ZEBlockArgs ba; ba.frameBase = src; ba.frameSize = srcSize; ba.paramSize = 0; ba.start = start; ba.isFirst = ZJ_UNI(kb->isFirst); ba.lastBlock = lastBlock; ba.tables = nullptr; ba.serialParse = 0;
+    u64 const r = ze_compress_t<G, u32>(g, sh, lds, src + start, size, dst + st.pos, dstCap - st.pos, level, ws, pf, &pre, flags, nullptr, ldsBytes, &ba);
+    if (r > ZJ_ERR64(256)) { GRP_SERIAL(g) { pipe.err = 1; } st.finished = 1; st.result = r; zj_mem_order(); g.sync(); return; }
+    zj_mem_order();
+    u32 const type = (ZJ_UNI((u32)dst[st.pos]) >> 1) & 3u;
+    GRP_SERIAL(g) { pipe.resType[b & 1u] = type; pipe.resSize[b & 1u] = (u32)r; }
+    zj_mem_order(); g.sync();
+    GRP_SERIAL(g) { pipe.done = b + 1u; }
+    zj_mem_order(); g.sync();
+    st.pos += (u32)r; st.b = b + 1u;
+    if (lastBlock) {
+        u32 const tail = (flags & ZE_FLAG_CHECKSUM) ? 4u : 0u;
+        st.finished = 1;
+        if (dstCap < st.pos + tail) { st.result = ZJ_ERR64(ZJ_E_DSTSIZE_TOO_SMALL); return; }
+        if (tail) { u64 const h = zj_xxh64(g, src, srcSize); GRP_SERIAL(g) { st32(dst + st.pos, (u32)h); } }
+        st.result = st.pos + tail;
+    }
+}
+// The parse wave, the whole frame.  wait(k): returns once pipe.done >= k (or the entropy wave has given up) — a poll on the GPU; in the emulation it steps the entropy
+// role.  ldsP: >= sizeof(ZXLds) and >= 2 064 bytes (the pre-splitter's histograms).
+template <class G, class WaitFn>
+ZJ_DEV void ze_pipe_parse_role(const G& g, ZEncShared& sh, u8* lds, ZEPipe& pipe, const u8* src, u32 srcSize, u32 dstCap, u32 level, u32 flags, u32* tables, u8* ws0, u8* ws1, WaitFn wait) {
+    ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), srcSize);
+    u32 const hdr = (flags & ZE_FLAG_NO_FCS) ? 6u : 9u;
+    GRP_SERIAL(g) { ze_params(sh, level, srcSize); sh.blkRep[0] = 1; sh.blkRep[1] = 4; sh.blkNextRep[0] = 1; sh.blkNextRep[1] = 4; sh.err = 0; }
+    {   u32 const entries = (1u << p.hashLog) + (p.strategy == 2 ? (1u << p.chainLog) : 0u);
+        GRP_FOR(g, i, entries) tables[i] = 0; }
+    zj_mem_order();
+    g.sync();
+    u32 at = 0, b = 0, folded = 0;                 // folded: blocks whose real results are in savExact / posExact
+    i64 savExact = 0; u64 posExact = hdr;
+    u32 sizeOf[2] = {0, 0}, uOf[2] = {0, 0}; bool prevCertain = false;
+    u32 const serial = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
+    while (at < srcSize) {
+        if (b >= 2u) wait(b - 1u);                 // the slot of block b (block b - 2's) is free, block b - 2's result is in
+        if (ZJ_UNI(ze_pipe_load(&pipe.err))) return;
+        while (folded + 1u < b && folded < ZJ_UNI(ze_pipe_load(&pipe.done))) { u32 const r = ZJ_UNI(ze_pipe_load(&pipe.resSize[folded & 1u])); savExact += (i64)sizeOf[folded & 1u] - (i64)r; posExact += r; folded++; }
+        bool prevCompressed = false, assume = false;
+        if (b >= 1u) {
+            bool const asksSavings = srcSize - at >= 131072u;                    // (zp_block_size looks at `savings` for a full block only)
+            i64 const savLow = savExact + (i64)sizeOf[(b - 1u) & 1u] - (i64)uOf[(b - 1u) & 1u];
+            if (prevCertain && folded + 1u == b && (!asksSavings || savLow >= 3)) { assume = true; prevCompressed = true; }
+            else {
+                wait(b);
+                if (ZJ_UNI(ze_pipe_load(&pipe.err))) return;
+                while (folded < b) { u32 const r = ZJ_UNI(ze_pipe_load(&pipe.resSize[folded & 1u])); savExact += (i64)sizeOf[folded & 1u] - (i64)r; posExact += r; folded++; }
+                prevCompressed = ZJ_UNI(ze_pipe_load(&pipe.resType[(b - 1u) & 1u])) == 2u;
+            }
+        }
+        i64 const savings = assume ? 3 : savExact;                              // (assumed: the bound says >= 3 where anything looks at it)
+        if (prevCompressed) { GRP_SERIAL(g) { sh.blkRep[0] = sh.blkNextRep[0]; sh.blkRep[1] = sh.blkNextRep[1]; } g.sync(); }
+        if (p.strategy == 2 && srcSize - at >= 131072u && savings >= 3) {
+            u32 const bs = zp_split_by_chunks_g(g, src + at, (u32*)lds);
+            GRP_SERIAL(g) { sh.tmp[0] = bs; }
+        } else GRP_SERIAL(g) { sh.tmp[0] = zp_block_size(src + at, srcSize - at, p.strategy, savings, (u32*)lds); }
+        g.sync();
+        u32 const blockSize = ZJ_UNI(sh.tmp[0]);
+        g.sync();
+        u8* const ws = (b & 1u) ? ws1 : ws0;
+        ZEOut o; o.seqs = (ZESeq*)(ws + ZE_WS_SEQ); o.litOff = (u32*)(ws + ZE_WS_BODY); o.n = 0; o.lit = 0;
+        u32 lastLL = blockSize;
+        if (blockSize >= 7u) {                                                 // ZSTD_buildSeqStore: MIN_CBLOCK_SIZE + 3 + 1 + 1 (ze_compress_t)
+            u32 const strategy = p.strategy, hlog = p.hashLog, clog = p.chainLog, mls = p.minMatch;
+#if defined(ZJ_TUNING_KERNELS) || !ZJ_ON_GPU
+            if (strategy == 1 && serial != 1u && !(serial & 4u)) lastLL = zx_block_fast_wave(lds, o, src, srcSize, at, at + blockSize, hlog, mls, tables, sh.blkRep, sh.blkNextRep, (serial & 3u) == 0u);
+            else
+#endif
+            if (strategy == 2 && (serial & 3u) != 1u) lastLL = zx_block_dfast_wave(lds, o, src, srcSize, at, at + blockSize, hlog, clog, mls, tables, tables + (1u << hlog), sh.blkRep, sh.blkNextRep, (serial & 3u) == 0u);
+            else {
+                GRP_SERIAL(g) {
+                    u32 const l2 = (strategy == 1) ? ze_block_fast_x<ZEEnt32>(o, src, at, at + blockSize, hlog, mls, tables, sh.blkRep, sh.blkNextRep)
+                                                   : ze_block_dfast_x<ZEEnt32>(o, src, at, at + blockSize, hlog, clog, mls, tables, tables + (1u << hlog), sh.blkRep, sh.blkNextRep);
+                    sh.tmp[1] = l2; sh.tmp[2] = o.n; sh.tmp[3] = o.lit;
+                }
+                g.sync();
+                lastLL = ZJ_UNI(sh.tmp[1]); o.n = ZJ_UNI(sh.tmp[2]); o.lit = ZJ_UNI(sh.tmp[3]);
+            }
+            zj_mem_order();
+        }
+        g.sync();
+        u32 const nbSeq = blockSize >= 7u ? o.n : 0u, litSize = blockSize >= 7u ? o.lit + lastLL : blockSize;
+        // the bound: extra bits of the block's sequences (the records as the parse left them: raw ll, ml, offBase)
+        GRP_SERIAL(g) { pipe.sum = 0; }
+        g.sync();
+        {   u32 acc = 0;
+            GRP_FOR(g, i, nbSeq) { ZESeq const q = o.seqs[i]; acc += ze_ll_bits_of(ze_ll_code(q.ll)) + ze_ml_bits_of(ze_ml_code(q.ml - 3u)) + zj_hibit(q.off); }
+            if (acc) ze_pipe_add(&pipe.sum, acc); }
+        g.sync();
+        u32 const extra = ZJ_UNI(pipe.sum);
+        u64 const U64 = 3ull + litSize + 3ull + 3ull + 1ull + 150ull + ((26ull * nbSeq + extra + 26ull + 15ull) >> 3) + 8ull;
+        u32 const U = U64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)U64;
+        u64 posHigh = posExact;
+        for (u32 j = folded; j < b; j++) posHigh += zj_min(uOf[j & 1u], sizeOf[j & 1u] + 3u);
+        bool const certain = blockSize >= 7u && nbSeq >= 1u && extra >= 256u && U < blockSize - ((blockSize >> 6) + 2u)
+                             && (u64)dstCap >= posHigh + blockSize + 3u + 1024u;
+        GRP_SERIAL(g) {
+            ZEPipeBlk k; k.start = at; k.size = blockSize; k.nbSeq = nbSeq; k.litSize = litSize; k.lastLL = lastLL; k.isFirst = b == 0u ? 1u : 0u;
+            k.lastBlock = (at + blockSize == srcSize) ? 1u : 0u; k.assumePrev = assume ? 1u : 0u; k.prevU = b ? uOf[(b - 1u) & 1u] : 0u;
+            pipe.blk[b & 1u] = k;
+        }
+        zj_mem_order(); g.sync();
+        GRP_SERIAL(g) { pipe.ready = b + 1u; }
+        zj_mem_order(); g.sync();
+        sizeOf[b & 1u] = blockSize; uOf[b & 1u] = U; prevCertain = certain;
+        at += blockSize; b++;
+    }
+}
+
+#if !ZJ_ON_GPU
+// the same two roles one after the other (tests/emu): the entropy role steps whenever the parse role waits for it, and to the end when the parse role is done
+template <class G>
+static u64 ze_compress_multi_pipe_serial(const G& g, ZEncShared& shP, ZEncShared& shE, u8* ldsP, u8* ldsE, ZEPipe& pipe, const u8* src, u32 srcSize, u8* dst, u32 dstCap, u32 level,
+                                         u8* ws0, u8* ws1, ZjProf& pf, u32 flags, u32* tables, u32 ldsBytes) {
+    ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), srcSize);
+    if (srcSize <= ZE_BLOCK_MAX || srcSize > ZE_MULTI_MAX || srcSize > (1u << p.windowLog)) return ZJ_ERR64(201);
+    pipe.ready = 0; pipe.done = 0; pipe.err = 0;
+    ZEPipeE st;
+    ze_pipe_entropy_init(g, shE, st, dst, dstCap, srcSize, level, flags);
+    if (st.finished) return st.result;
+    auto step = [&]() { ze_pipe_entropy_step(g, shE, ldsE, pipe, st, src, srcSize, dst, dstCap, level, flags, ws0, ws1, pf, ldsBytes); };
+    ze_pipe_parse_role(g, shP, ldsP, pipe, src, srcSize, dstCap, level, flags, tables, ws0, ws1,
+                       [&](u32 k) { while (pipe.done < k && !pipe.err && !st.finished && pipe.ready > st.b) step(); });
+    while (!st.finished && pipe.ready > st.b) step();
+    return st.finished ? st.result : ZJ_ERR64(ZJ_E_GENERIC);
+}
+#endif
+
 // Per-frame HBM scratch of the lane-per-frame match finder: sequence records then literal offsets.
 #define ZE_FRAME_MAXSEQ(maxSrc) (((maxSrc) / 4u) + 16u)
 #define ZE_FRAME_STRIDE(maxSrc) (ZE_FRAME_MAXSEQ(maxSrc) * 20u)

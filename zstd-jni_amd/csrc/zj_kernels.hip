@@ -217,27 +217,6 @@ __global__ __launch_bounds__(64) void zj_dec_exec_mb_kernel(const u8* __restrict
 __device__ __forceinline__ bool zj_dec_heavy(const u32* countA) { return countA[1] >= 512u * countA[0]; }      // countA = &listCounts[8]
 
 
-// Longest first (round 6).  The sequence decode is a lane per frame and a lane's time is its frame's sequence count (one per round); the batch is about two frames per
-// resident lane, handed out from a counter in list order.  In the order stage 1 happened to finish them, the lanes' first frames end together half-way through the
-// launch and their second frames together at its end: the execution kernel beside it idled, got half the batch at once, and the other half when the decode left — a
-// 5.6 ms tail behind a 12.3 ms decode (profiles/r05/ d).  Sorted by descending sequence count (a counting sort over 256 buckets of 32 sequences, one workgroup, ~30 us)
-// every lane starts on a long frame and the launch ends on short ones that finish spread out: the makespan is LPT's, and what is left for the execution kernel when
-// the decode leaves is a handful of short frames.  The literal pass and the sweep pass walk the same order.  Light batches (zj_dec_heavy false: 4 KiB records, equal
-// costs) and lists beyond 2^18 frames are copied as they are.
-__global__ __launch_bounds__(1024) void zj_dec_sort_kernel(const u32* __restrict__ listA, const u32* countA, const ZDMeta* __restrict__ metas, u32* __restrict__ listS) {
-    __shared__ u32 hist[256], base[256];
-    u32 const count = countA[0], t = threadIdx.x;
-    if (!zj_dec_heavy(countA) || count > (1u << 18)) { for (u32 k = blockIdx.x * 1024u + t; k < count; k += gridDim.x * 1024u) listS[k] = listA[k]; return; }     // (every workgroup of the launch copies; the sort is workgroup 0's)
-    if (blockIdx.x) return;
-    if (t < 256u) hist[t] = 0;
-    __syncthreads();
-    for (u32 k = t; k < count; k += 1024u) { u32 const q = metas[listA[k]].nbSeq >> 5; atomicAdd(&hist[q < 255u ? q : 255u], 1u); }
-    __syncthreads();
-    if (t == 0) { u32 run = 0; for (int b = 255; b >= 0; b--) { base[b] = run; run += hist[b]; } }
-    __syncthreads();
-    for (u32 k = t; k < count; k += 1024u) { u32 const i = listA[k], q = metas[i].nbSeq >> 5; listS[atomicAdd(&base[q < 255u ? q : 255u], 1u)] = i; }
-}
-
 __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list,
                                                          const u32* countPtr, u32* workCounter, const u16* tabs, u64* seqs, ZDMeta* metas,
                                                          const ZDDictDev* dd, u32* doneList, u32* doneCount, u32 heavyWaves) {
@@ -339,7 +318,7 @@ __global__ __launch_bounds__(256) void zj_enc_classify_kernel(const u64* __restr
         return;
     }
     if (size > ZE_BLOCK_MAX) {                        // multi-block frames (list C, zj_encode_multi_kernel) up to ZE_MULTI_MAX, without explicit table sizes
-        if (listC && size <= ZE_MULTI_MAX && (!(ZE_LW_HL(level) | ZE_LW_CL(level)) || (level & ZE_LW_IMPLICIT))) listC[atomicAdd(&counters[4], 1u)] = i;
+        if (listC && size <= ZE_MULTI_MAX && (!(ZE_LW_HL(level) | ZE_LW_CL(level)) || (level & ZE_LW_IMPLICIT))) { listC[atomicAdd(&counters[4], 1u)] = i; atomicAdd(&counters[6], 1u); }      // ([6]: the multi-block frames among list C — zj_pipe_route)
         else result[i] = ZJ_ERR64(201);
         return;
     }
@@ -805,6 +784,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
 }
 
+// Which of the two kernels serves list C is decided on the device, by both, from the classify kernel's counters (countPtr = &counters[4]: |C|, work, multi-block frames):
+// the pipelined one when every frame is resident at once (|C| <= pipeMax workgroups) and at least half of them are multi-block frames; the other one returns at once.
+__device__ __forceinline__ bool zj_pipe_route(const u32* countPtr, u32 pipeMax) { u32 const c = countPtr[0]; return pipeMax != 0u && c <= pipeMax && 2u * countPtr[2] >= c && c != 0u; }
 // Multi-block frames (128 KiB < input <= ZE_MULTI_MAX): one wavefront walks a frame block by block (ze_compress_multi); its
 // frame-wide hash tables sit in HBM, one set per resident workgroup.
 #ifndef ZJ_MULTI_WAVES
@@ -812,7 +794,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 #endif
 __global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
                                                               u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
-                                                              u8* scratch, u32* tables, u32 flags, u32 ldsBytes) {
+                                                              u8* scratch, u32* tables, u32 flags, u32 ldsBytes, u32 pipeMax) {
+    if (zj_pipe_route(countPtr, pipeMax)) return;          // zj_encode_pipe_kernel's batch (queued ahead of this launch)
     __shared__ ZEncShared sh;
 #ifdef ZX_PROFILE          /* analysis build: the entropy stage's phase marks of workgroup 0, printed when it is done (tools/ab_call*.sh) */
     __shared__ unsigned long long zxPhase[16];
@@ -846,6 +829,69 @@ __global__ __launch_bounds__(64, ZJ_MULTI_WAVES) void zj_encode_multi_kernel(con
         printf("zx phases wg 0 (kcycles): zero+params %llu  match %llu  literals gather+codes %llu  hist+huffman table %llu  huffman encode %llu  sequence tables %llu  sequence encode %llu  block place %llu\n",
                zxPhase[0] / 1000ull, zxPhase[1] / 1000ull, zxPhase[2] / 1000ull, zxPhase[3] / 1000ull, zxPhase[4] / 1000ull, zxPhase[5] / 1000ull, zxPhase[6] / 1000ull, zxPhase[7] / 1000ull);
 #endif
+}
+
+// Multi-block frames, PIPELINED (round 6; zj_encode.h "multi-block frames, PIPELINED"): a workgroup of TWO waves per frame — wave 1 parses block b + 1 while wave 0
+// entropy-codes block b.  For batches that cannot fill the device with one-wave chains (a thousand 1 MiB frames: BASELINE config 1); with every wave slot taken the
+// one-wave kernel above does the same work in fewer wave-milliseconds, so large batches stay there (compress_batch_device_impl).  Scratch: two slots of encScratch
+// per workgroup (block b in slot b & 1), one table set; dynamic LDS: [ZEEntropy of the entropy wave][ZJ_PIPE_LDS_P bytes of the parse wave].
+#define ZJ_PIPE_LDS_P 10240u
+static_assert(sizeof(ZXLds) <= ZJ_PIPE_LDS_P && 2064u <= ZJ_PIPE_LDS_P, "the parse wave's LDS holds the wave matcher's scoreboards, or the pre-splitter's histograms");
+__global__ __launch_bounds__(128, 2) void zj_encode_pipe_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst, const u64* __restrict__ dstOff,
+                                                             u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
+                                                             u8* scratch, u32* tables, u32 flags, u32 ldsBytesE, u32 pipeMax) {
+    if (!zj_pipe_route(countPtr, pipeMax)) return;
+    __shared__ ZEncShared shE, shP;
+    __shared__ ZEPipe pipe;
+    __shared__ u32 nextK;
+    u32 const role = threadIdx.x >> 6;                     // 0: the entropy wave (and single-block frames of the list), 1: the parse wave
+    GrpWave g;
+    ZjProf pf; pf.start(nullptr);
+    if (threadIdx.x == 0) { shE.dictLoaded = 0; shE.ctDict[0] = 0; shE.ctDict[1] = 0; shE.ctDict[2] = 0; shP.dictLoaded = 0; shP.ctDict[0] = 0; shP.ctDict[1] = 0; shP.ctDict[2] = 0; }
+    __syncthreads();
+    u8* const ws0 = scratch + (size_t)(2u * blockIdx.x) * ZE_SCRATCH_BYTES; u8* const ws1 = ws0 + ZE_SCRATCH_BYTES;
+    u32* const tb = tables + (size_t)blockIdx.x * (ZE_MULTI_TABLE_BYTES / 4u);
+    u8* const ldsE = zj_dyn_lds; u8* const ldsP = zj_dyn_lds + ldsBytesE;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        if (threadIdx.x == 0) nextK = atomicAdd(workCounter, 1u);
+        __syncthreads();
+        u32 const k = ZJ_UNI(nextK);
+        __syncthreads();                                    // (both waves have it before the next round writes it)
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(list[k]);
+        u64 const s0 = zj_uni64(srcOff[i]), s1 = zj_uni64(srcOff[i + 1]), d0 = zj_uni64(dstOff[i]), d1 = zj_uni64(dstOff[i + 1]);
+        u64 const cap = d1 - d0;
+        u32 const size = (u32)(s1 - s0), capU = (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap);
+        ZEParams const p = ze_params_of(ZE_LW_LEVEL(level), size);
+        if (size <= ZE_BLOCK_MAX) {                         // level 4 (one block, tables too large for LDS): the entropy wave alone, as zj_encode_multi_kernel does it
+            if (role == 0) { u64 const r = ze_compress_t<GrpWave, u32>(g, shE, ldsE, src + s0, size, dst + d0, capU, level, ws0, pf, nullptr, flags, nullptr, ldsBytesE, nullptr, tb); if ((threadIdx.x & 63u) == 0) result[i] = r; }
+        } else if (size > ZE_MULTI_MAX || size > (1u << p.windowLog)) { if (threadIdx.x == 0) result[i] = ZJ_ERR64(201); }
+        else {
+            if (threadIdx.x == 0) { pipe.ready = 0; pipe.done = 0; pipe.err = 0; }
+            __syncthreads();
+            if (role == 1) {
+                ze_pipe_parse_role(g, shP, ldsP, pipe, src + s0, size, capU, level, flags, tb, ws0, ws1, [&](u32 want) {
+                    for (;;) {
+                        if (ZJ_UNI(ze_pipe_load(&pipe.done)) >= want || ZJ_UNI(ze_pipe_load(&pipe.err))) break;
+                        __builtin_amdgcn_s_sleep(32);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                });
+            } else {
+                ZEPipeE st;
+                ze_pipe_entropy_init(g, shE, st, dst + d0, capU, size, level, flags);
+                if (st.finished) { if ((threadIdx.x & 63u) == 0) pipe.err = 1; }
+                while (!st.finished) {
+                    while (ZJ_UNI(ze_pipe_load(&pipe.ready)) <= st.b) __builtin_amdgcn_s_sleep(32);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    ze_pipe_entropy_step(g, shE, ldsE, pipe, st, src + s0, size, dst + d0, capU, level, flags, ws0, ws1, pf, ldsBytesE);
+                }
+                if ((threadIdx.x & 63u) == 0) result[i] = st.result;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Stream frames (ze_compress_stream, zj_encode.h): what the reference's stream classes produce without a pledged size, one wavefront per stream over the
@@ -1028,6 +1074,8 @@ struct DevState {
     std::atomic<unsigned>* slotTicket = nullptr;
     std::mutex* hostDecompMu = nullptr;
     u32* multiTables = nullptr; int multiGrid = 0;    // multi-block frames: frame-wide hash tables, one set per resident workgroup
+    u32 lastPipeMax = 0;                              // what the last compress call passed to zj_pipe_route (diagnostics: zjni_last_lists)
+    int pipeGrid = 0;                                 // ... and the resident workgroups of the pipelined kernel (two waves, two scratch slots each); 0: not available
     u8* cdBuf = nullptr; size_t cdBufCap = 0; size_t cdSliceCap = 0;
     u32* cdList = nullptr; size_t cdListCap = 0;
     hipEvent_t cdMatchDone[2] = {}, cdEncDone[2] = {};
@@ -1376,6 +1424,7 @@ int zjni_last_lists(unsigned* out3) {
     u32 h[8];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d->counters + 16, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -(int)ZJNI_ERROR_no_device;
     out3[0] = h[0]; out3[1] = h[1]; out3[2] = h[4];
+    if (d->lastRoute == ZJ_ROUTE_WAVE_HBM && d->lastPipeMax && h[4] && h[4] <= d->lastPipeMax && 2u * h[6] >= h[4]) d->lastRoute = ZJNI_ROUTE_PIPE;      // zj_pipe_route, restated for the diagnostics
     return 0;
 }
 // The last large decompress call: out4[0] frames of the single-block pipeline (list A), out4[1] frames the fused kernel decoded (list B: what no pipeline took, or
@@ -1392,6 +1441,7 @@ int zjni_last_decode_lists(unsigned* out4) {
 const char* zjni_route_kernel(int route) {
     switch (route) {
     case ZJNI_ROUTE_WIDE: return "zj_enc_match_wide_kernel";
+    case ZJNI_ROUTE_PIPE: return "zj_encode_pipe_kernel";
     case ZJNI_ROUTE_FUSED: return "zj_encode_kernel";
     case ZJNI_ROUTE_WAVE: return "zj_enc_match_wave_kernel";
     case ZJNI_ROUTE_LANE: case ZJNI_ROUTE_HYBRID: return "zj_enc_match_kernel";
@@ -1530,7 +1580,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
     if (const char* ov = zj_env("ZJNI_DSPLIT_MIN")) splitMin = (size_t)atoll(ov);
     if (n >= splitMin) {
         size_t const tabBytes = n * (size_t)ZD_SPLIT_TAB_BYTES, seqBytes = n * (size_t)ZD_SPLIT_SEQ_BYTES, metaBytes = n * sizeof(ZDMeta), listBytes = n * 4;
-        size_t const need = tabBytes + seqBytes + metaBytes + 5 * listBytes + 256;
+        size_t const need = tabBytes + seqBytes + metaBytes + 4 * listBytes + 256;
         if (d->dsplitBufCap < need) {
             if (!scratch_make_room(d, d->dsplitBufCap, need)) return ZJNI_ERR(64);
             if (d->dsplitBuf) { if (hipStreamSynchronize(st) != hipSuccess) return ZJNI_ERR(ZJNI_ERROR_no_device); (void)hipFree(d->dsplitBuf); d->dsplitBuf = nullptr; d->dsplitBufCap = 0; }
@@ -1541,7 +1591,6 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
-        u32* const listRaw = procFlag + n;        // list A as stage 1 appends it; `listA` below is what zj_dec_sort_kernel makes of it (longest frames first)
         u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A, [10] work of the literal pass
         // Stage 2b (zd_lit_frame): one literal slot per frame, as large as the budget allows (at most a block); frames whose literals do
         // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
@@ -1572,10 +1621,9 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         (void)hipEventRecord(d->tev[2], st);
         ZDMbHost const mb = decode_mb_scratch(d, n, st, ddict != nullptr);       // frames that are not simple: multi-block, no content size (the stream classes')
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                      (u32)n, c + 2, tabs, metas, listRaw, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
         else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                (u32)n, c + 2, tabs, metas, listRaw, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
-        hipLaunchKernelGGL(zj_dec_sort_kernel, dim3(32), dim3(1024), 0, st, (const u32*)listRaw, (const u32*)(c + 8), (const ZDMeta*)metas, listA);
+                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
@@ -1738,6 +1786,14 @@ static bool ensure_multi_tables(DevState* d) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, zj_encode_multi_kernel, 64, sizeof(ZEEntropy)) == hipSuccess && fit >= 1 && fit < perCU) perCU = fit;
     d->multiGrid = d->numCU * perCU; if (d->multiGrid > d->encGrid) d->multiGrid = d->encGrid;     // encScratch has one slot per resident entropy workgroup
     if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; (void)hipGetLastError(); return false; }
+    {   int pfit = 0; size_t const lds = sizeof(ZEEntropy) + ZJ_PIPE_LDS_P;
+        d->pipeGrid = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pfit, zj_encode_pipe_kernel, 128, lds) == hipSuccess && pfit >= 1) {
+            int gp = d->numCU * pfit;
+            if (gp > d->multiGrid) gp = d->multiGrid;             // a table set per workgroup
+            if (gp > d->encGrid / 2) gp = d->encGrid / 2;         // two scratch slots per workgroup
+            d->pipeGrid = gp;
+        } else (void)hipGetLastError(); }
     return true;
 }
 static inline u32 zj_frame_flags(int word) { return (u32)word & ZE_FLAG_MASK; }
@@ -1795,8 +1851,18 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         // levels 1-2 (fast strategy): the one-lane parse unless ZJNI_MULTI_WAVE_FAST=1 — the wave version (ZWaveF) is exact but measured slower there
         // (2 048 x 512 KiB at level 1: 156 ms against 138; one 64 KiB table per frame stays in the L2 / Infinity Cache and an iteration of the one-lane loop is one short trip)
         {   const char* const ov = zj_tune("ZJNI_MULTI_WAVE_FAST"); if (!(ov && atoi(ov) == 1)) multiSerial |= ZE_FLAG_MULTI_FAST_SERIAL; }
+        // Batches that leave wave slots empty (every frame resident at once and room to spare) take the pipelined kernel: a parse wave a block ahead of an entropy wave per
+        // frame — 1 024 x 1 MiB: the frame's chain is the parse alone.  With the slots full the one-wave kernel does the same work in fewer wave-milliseconds.
+        // ZJNI_PIPE_MAX (tuning builds): the largest batch that takes it (0: never).
+        u32 pipeMax = level <= 3 ? (u32)d->pipeGrid : 0u; if (const char* ov = zj_tune("ZJNI_PIPE_MAX")) { long long const v = atoll(ov); pipeMax = v <= 0 ? 0u : ((size_t)v < (size_t)d->pipeGrid ? (u32)v : (u32)d->pipeGrid); }
+        d->lastPipeMax = pipeMax;
+        if (pipeMax) {
+            u32 const gp = (u32)(n < (size_t)pipeMax ? n : (size_t)pipeMax);
+            hipLaunchKernelGGL(zj_encode_pipe_kernel, dim3(gp), dim3(128), (u32)(sizeof(ZEEntropy) + ZJ_PIPE_LDS_P), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
+                               (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy), pipeMax);
+        }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
-                           (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy));
+                           (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy), pipeMax);
     }
     if (l3wave) {                                  // the whole batch was list C's
         d->lastRoute = ZJ_ROUTE_WAVE_HBM; d->tevCompress = false;
