@@ -841,9 +841,11 @@ __global__ __launch_bounds__(128, 2) void zj_encode_pipe_kernel(const u8* __rest
                                                              u64* __restrict__ result, u32 level, const u32* __restrict__ list, const u32* countPtr, u32* workCounter,
                                                              u8* scratch, u32* tables, u32 flags, u32 ldsBytesE, u32 pipeMax) {
     if (!zj_pipe_route(countPtr, pipeMax)) return;
-    __shared__ ZEncShared shE, shP;
-    __shared__ ZEPipe pipe;
-    __shared__ u32 nextK;
+    // (ONE LDS object: declared as separate variables the two waves' uniforms came out OVERLAID — group_segment_fixed_size 1 440 instead of 2 700: each is used by one
+    //  role's code only, and the LDS lowering does not know that the roles run at the same time on different waves)
+    struct PipeShared { ZEncShared e, p; ZEPipe pipe; u32 nextK; };
+    __shared__ PipeShared S;
+    ZEncShared& shE = S.e; ZEncShared& shP = S.p; ZEPipe& pipe = S.pipe; u32& nextK = S.nextK;
     u32 const role = threadIdx.x >> 6;                     // 0: the entropy wave (and single-block frames of the list), 1: the parse wave
     GrpWave g;
     ZjProf pf; pf.start(nullptr);
