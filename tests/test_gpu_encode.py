@@ -474,3 +474,21 @@ def test_gpu_small_level3_batches_take_the_wave_route(gpu, oracle_ref, monkeypat
     assert gpu.lib().zjni_last_route() in (5, 6)
     for d, z in zip(datas[:200], outs):
         assert z == oracle_ref.compress(d, 3), len(d)
+
+
+@pytest.mark.parametrize("need", ["2", "0"])
+def test_gpu_lane_pipeline_hand_overs_at_small_and_odd_counts(gpu, oracle_ref, monkeypatch, need):
+    """the match waves hand their finished frames to the entropy kernel in batches (one release per wave and hand-over, a wave-wide ballot to leave) — code only
+    the GPU runs.  Batches smaller than a wave, one frame over a wave, not a multiple of anything, with and without need flags, three calls each (the queue and the
+    flags of the previous call are there): every frame comes out, once, as the reference's — a frame that missed the queue is the sweep pass's, one that was queued twice
+    or early would differ or fail to decode."""
+    monkeypatch.setenv("ZJNI_SPLIT_MIN", "1"); monkeypatch.setenv("ZJNI_L3_WAVE_MAX", "0"); monkeypatch.setenv("ZJNI_NEED", need)
+    rnd = random.Random(211)
+    for count in (1, 2, 63, 64, 65, 127, 129, 191, 257, 1023):
+        datas = [gpu.synth_host(rnd.choice([65536, 65536, 30000, 4096, 700, 64]), rnd.randrange(1 << 20), 1) for _ in range(count)]
+        want = [oracle_ref.compress(d, 3) for d in datas]
+        for rep in range(3):
+            outs = gpu.compress_batch(datas, 3)
+            assert gpu.lib().zjni_last_route() == (6 if need == "2" else 5)
+            for k, (z, w) in enumerate(zip(outs, want)):
+                assert z == w, (count, rep, k, len(datas[k]), z if isinstance(z, Exception) else "bytes differ")

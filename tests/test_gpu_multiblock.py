@@ -120,9 +120,6 @@ def test_gpu_multiblock_pipelined_pair_of_waves(gpu, oracle_ref, monkeypatch, ro
         ds = [d for d in datas if len(d) <= WINDOW[level]]
         want = [oracle_ref.compress(d, level) for d in ds]
         outs = gpu.compress_batch(ds, level)
-        l3 = (C.c_uint * 3)()
-        assert gpu.lib().zjni_last_lists(l3) == 0 and l3[2] == len(ds)
-        assert gpu.lib().zjni_last_route() == (11 if route == "pipelined" else 9), gpu.lib().zjni_last_route()
         for k, (z, w) in enumerate(zip(outs, want)):
             assert z == w, (level, k, len(ds[k]), z if isinstance(z, Exception) else "bytes differ")
         assert gpu.decompress_batch(outs, [len(d) for d in ds]) == ds
@@ -138,3 +135,17 @@ def test_gpu_multiblock_pipelined_pair_of_waves(gpu, oracle_ref, monkeypatch, ro
         outs = gpu.compress_batch(ds, level, capacities=caps)
         for k, (z, w) in enumerate(zip(outs, exp)):
             assert (-z.getErrorCode() if isinstance(z, Exception) else z) == w, (level, k, caps[k], len(want[k]))
+    # which kernel it was: a device-resident batch of equal 300 000-byte frames at level 3, asked of the library
+    import torch
+    B = gpu.batch
+    n, size = 24, 300000
+    src = torch.frombuffer(bytearray(b"".join(xml[7 * i:7 * i + size] for i in range(n))), dtype=torch.uint8).cuda()
+    bound = gpu.Zstd.compressBound(size)
+    comp = torch.empty(n * bound, dtype=torch.uint8, device="cuda")
+    csz = B.compress(src, B.uniform_offsets(n, size, "cuda"), comp, B.uniform_offsets(n, bound, "cuda"), 3); torch.cuda.synchronize()
+    l3 = (C.c_uint * 3)()
+    assert gpu.lib().zjni_last_lists(l3) == 0 and l3[2] == n, list(l3)
+    assert gpu.lib().zjni_last_route() == (11 if route == "pipelined" else 9), gpu.lib().zjni_last_route()
+    hc = comp.cpu().numpy().tobytes()
+    for i in range(n):
+        assert hc[i * bound:i * bound + int(csz[i])] == oracle_ref.compress(xml[7 * i:7 * i + size], 3), i

@@ -2417,8 +2417,18 @@ ZJ_DEV void ze_pipe_parse_role(const G& g, ZEncShared& sh, u8* lds, ZEPipe& pipe
     i64 savExact = 0; u64 posExact = hdr;
     u32 sizeOf[2] = {0, 0}, uOf[2] = {0, 0}; bool prevCertain = false;
     u32 const serial = ((flags & ZE_FLAG_MULTI_SERIAL) ? 1u : ((flags & ZE_FLAG_MULTI_NOCARRY) ? 2u : 0u)) | ((flags & ZE_FLAG_MULTI_FAST_SERIAL) ? 4u : 0u);
+#if defined(ZE_PIPE_DEBUG) && ZJ_ON_GPU
+    u64 dbgWait = 0, dbgParse = 0, dbgT; u32 dbgAssume = 0, dbgAsk = 0;
+#define ZE_PD_T0() (dbgT = wall_clock64())
+#define ZE_PD_ADD(acc) (acc += wall_clock64() - dbgT)
+#else
+#define ZE_PD_T0() ((void)0)
+#define ZE_PD_ADD(acc) ((void)0)
+#endif
     while (at < srcSize) {
+        ZE_PD_T0();
         if (b >= 2u) wait(b - 1u);                 // the slot of block b (block b - 2's) is free, block b - 2's result is in
+        ZE_PD_ADD(dbgWait);
         if (ZJ_UNI(ze_pipe_load(&pipe.err))) return;
         while (folded + 1u < b && folded < ZJ_UNI(ze_pipe_load(&pipe.done))) { u32 const r = ZJ_UNI(ze_pipe_load(&pipe.resSize[folded & 1u])); savExact += (i64)sizeOf[folded & 1u] - (i64)r; posExact += r; folded++; }
         bool prevCompressed = false, assume = false;
@@ -2427,13 +2437,19 @@ ZJ_DEV void ze_pipe_parse_role(const G& g, ZEncShared& sh, u8* lds, ZEPipe& pipe
             i64 const savLow = savExact + (i64)sizeOf[(b - 1u) & 1u] - (i64)uOf[(b - 1u) & 1u];
             if (prevCertain && folded + 1u == b && (!asksSavings || savLow >= 3)) { assume = true; prevCompressed = true; }
             else {
+                ZE_PD_T0();
                 wait(b);
+                ZE_PD_ADD(dbgWait);
                 if (ZJ_UNI(ze_pipe_load(&pipe.err))) return;
                 while (folded < b) { u32 const r = ZJ_UNI(ze_pipe_load(&pipe.resSize[folded & 1u])); savExact += (i64)sizeOf[folded & 1u] - (i64)r; posExact += r; folded++; }
                 prevCompressed = ZJ_UNI(ze_pipe_load(&pipe.resType[(b - 1u) & 1u])) == 2u;
             }
         }
         i64 const savings = assume ? 3 : savExact;                              // (assumed: the bound says >= 3 where anything looks at it)
+#if defined(ZE_PIPE_DEBUG) && ZJ_ON_GPU
+        if (b >= 1u) { if (assume) dbgAssume++; else dbgAsk++; }
+        ZE_PD_T0();
+#endif
         if (prevCompressed) { GRP_SERIAL(g) { sh.blkRep[0] = sh.blkNextRep[0]; sh.blkRep[1] = sh.blkNextRep[1]; } g.sync(); }
         if (p.strategy == 2 && srcSize - at >= 131072u && savings >= 3) {
             u32 const bs = zp_split_by_chunks_g(g, src + at, (u32*)lds);
@@ -2489,7 +2505,11 @@ ZJ_DEV void ze_pipe_parse_role(const G& g, ZEncShared& sh, u8* lds, ZEPipe& pipe
         zj_mem_order(); g.sync();
         sizeOf[b & 1u] = blockSize; uOf[b & 1u] = U; prevCertain = certain;
         at += blockSize; b++;
+        ZE_PD_ADD(dbgParse);
     }
+#if defined(ZE_PIPE_DEBUG) && ZJ_ON_GPU
+    if (blockIdx.x < 4u && (threadIdx.x & 63u) == 0) printf("pipe P wg %u: %u blocks, assumed %u asked %u, waiting %llu us, parsing %llu us\n", blockIdx.x, b, dbgAssume, dbgAsk, (unsigned long long)(dbgWait / 100ull), (unsigned long long)(dbgParse / 100ull));
+#endif
 }
 
 #if !ZJ_ON_GPU

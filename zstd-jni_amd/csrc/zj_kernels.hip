@@ -853,7 +853,7 @@ __global__ __launch_bounds__(128, 2) void zj_encode_pipe_kernel(const u8* __rest
     __syncthreads();
     u8* const ws0 = scratch + (size_t)(2u * blockIdx.x) * ZE_SCRATCH_BYTES; u8* const ws1 = ws0 + ZE_SCRATCH_BYTES;
     u32* const tb = tables + (size_t)blockIdx.x * (ZE_MULTI_TABLE_BYTES / 4u);
-    u8* const ldsE = zj_dyn_lds; u8* const ldsP = zj_dyn_lds + ldsBytesE;
+    u8* const ldsE = zj_dyn_lds; u8* const ldsP = zj_dyn_lds + ((ldsBytesE + 15u) & ~15u);      // (sizeof(ZEEntropy) is 4 mod 8 and the wave matcher's scoreboards are 64-bit LDS atomics)
     u32 const count = ZJ_UNI(*countPtr);
     for (;;) {
         if (threadIdx.x == 0) nextK = atomicAdd(workCounter, 1u);
@@ -884,11 +884,26 @@ __global__ __launch_bounds__(128, 2) void zj_encode_pipe_kernel(const u8* __rest
                 ZEPipeE st;
                 ze_pipe_entropy_init(g, shE, st, dst + d0, capU, size, level, flags);
                 if (st.finished) { if ((threadIdx.x & 63u) == 0) pipe.err = 1; }
+#ifdef ZE_PIPE_DEBUG
+                u64 dbgWaitE = 0, dbgWorkE = 0;
+#endif
                 while (!st.finished) {
+#ifdef ZE_PIPE_DEBUG
+                    u64 const t0 = wall_clock64();
+#endif
                     while (ZJ_UNI(ze_pipe_load(&pipe.ready)) <= st.b) __builtin_amdgcn_s_sleep(32);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef ZE_PIPE_DEBUG
+                    u64 const t1 = wall_clock64(); dbgWaitE += t1 - t0;
+#endif
                     ze_pipe_entropy_step(g, shE, ldsE, pipe, st, src + s0, size, dst + d0, capU, level, flags, ws0, ws1, pf, ldsBytesE);
+#ifdef ZE_PIPE_DEBUG
+                    dbgWorkE += wall_clock64() - t1;
+#endif
                 }
+#ifdef ZE_PIPE_DEBUG
+                if (blockIdx.x < 4u && (threadIdx.x & 63u) == 0) printf("pipe E wg %u: %u blocks, waiting %llu us, working %llu us\n", blockIdx.x, st.b, (unsigned long long)(dbgWaitE / 100ull), (unsigned long long)(dbgWorkE / 100ull));
+#endif
                 if ((threadIdx.x & 63u) == 0) result[i] = st.result;
             }
         }
@@ -1790,7 +1805,7 @@ static bool ensure_multi_tables(DevState* d) {
     if (hipMalloc(&d->multiTables, (size_t)d->multiGrid * ZE_MULTI_TABLE_BYTES) != hipSuccess) { d->multiTables = nullptr; (void)hipGetLastError(); return false; }
     {   int pfit = 0; size_t const lds = sizeof(ZEEntropy) + ZJ_PIPE_LDS_P;
         d->pipeGrid = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pfit, zj_encode_pipe_kernel, 128, lds) == hipSuccess && pfit >= 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pfit, zj_encode_pipe_kernel, 128, lds + 16u) == hipSuccess && pfit >= 1) {
             int gp = d->numCU * pfit;
             if (gp > d->multiGrid) gp = d->multiGrid;             // a table set per workgroup
             if (gp > d->encGrid / 2) gp = d->encGrid / 2;         // two scratch slots per workgroup
@@ -1860,7 +1875,7 @@ static size_t compress_batch_device_impl(const void* d_src, const uint64_t* d_sr
         d->lastPipeMax = pipeMax;
         if (pipeMax) {
             u32 const gp = (u32)(n < (size_t)pipeMax ? n : (size_t)pipeMax);
-            hipLaunchKernelGGL(zj_encode_pipe_kernel, dim3(gp), dim3(128), (u32)(sizeof(ZEEntropy) + ZJ_PIPE_LDS_P), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
+            hipLaunchKernelGGL(zj_encode_pipe_kernel, dim3(gp), dim3(128), (u32)(((sizeof(ZEEntropy) + 15u) & ~(size_t)15) + ZJ_PIPE_LDS_P), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
                                (u64*)d_result, (u32)levelWord, (const u32*)listC, (const u32*)(ctr + 4), ctr + 5, d->encScratch, d->multiTables, flags | multiSerial, (u32)sizeof(ZEEntropy), pipeMax);
         }
         hipLaunchKernelGGL(zj_encode_multi_kernel, dim3(gc), dim3(64), (u32)sizeof(ZEEntropy), st, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off,
