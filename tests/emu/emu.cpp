@@ -55,7 +55,12 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
     ZjProf pf; pf.start(nullptr);
     u64 r = ~(u64)0;
     if (usedSplit) *usedSplit = 0;
-    if (zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta)) {
+    bool const simple = zd_prep_frame(g, *sh, src, srcSize, dstCap, tab, &meta);
+    if (!simple) {                                               // zj_dec_prep_kernel: a frame of one stored block is copied by stage 1 itself (round 6); usedSplit = 4
+        u64 res = 0;
+        if (zd_prep_frame_stored(g, *sh, src, srcSize, dst, dstCap, &res)) { if (usedSplit) *usedSplit = 4; free(seqs); free(tab); free(lit); free(sh); return res; }
+    }
+    if (simple) {
         u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1); ZDSeqLane m; m.llBase = symL; m.mlBase = symM; m.init(src, tab, seqs, &meta);
         while (m.st != 2) m.round();
         // stage 2b as the kernels run it: its own workgroup state (poisoned), a slot per frame, the frame record marked
@@ -94,6 +99,8 @@ extern "C" unsigned long long emu_decompress_mb(const unsigned char* src, unsign
     ZjProf pf; pf.start(nullptr);
     u64 r = ~(u64)0;
     if (used) *used = 0;
+    {   u64 res = 0;                                             // (stage 1 tries the stored-block copy before the block stages, as the kernel does)
+        if (zd_prep_frame_stored(g, *sh, src, srcSize, dst, dstCap, &res)) { if (used) *used = 2; free(litList); free(litPool); free(seqList); free(pool); free(tabs); free(blks); free(lit); free(sh); return res; } }
     if (zd_prep_frame_multi(g, *sh, src, srcSize, dstCap, 0u, &fr, blks, tabs, &blkCounter, blkCap, &seqCounter, seqCap, seqList, &seqListCount, 1u,
                             &litCounter, litCapUsed, litMode ? litList : nullptr, &litListCount)) {
         for (u32 q = 0; q < litListCount; q++) {                  // stage 2b: a workgroup of its own per block (poisoned LDS)

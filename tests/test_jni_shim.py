@@ -137,7 +137,7 @@ def test_shim_gpu_route_over_the_emulated_kernels(emu_legs, leg):
 @pytest.mark.gpu
 def test_shim_equals_reference_jni_on_the_gpu():
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"
-    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0", HARNESS_FUZZ="12,60", HARNESS_FUZZ_SKIP_HEAP="1")      # (the heap-array classes' random scripts run in the CPU legs: same shim code, same C-ABI calls)      # (streams: nothing to outgrow into, totals stay within the level's window)      # zjni_shim_stats: served > 0, forwarded == 0   # levels 4-8 (<= 128 KiB) through the one-shot natives as well
+    env = dict(os.environ, HARNESS_DICT_FILE=_dict_file(), HARNESS_PLAIN_MAX_LEVEL="8", HARNESS_EXPECT="gpu", HARNESS_STREAM_MAX="0", HARNESS_FUZZ="12,25", HARNESS_FUZZ_SKIP_HEAP="1")      # (the heap-array classes' random scripts run in the CPU legs: same shim code, same C-ABI calls)      # (streams: nothing to outgrow into, totals stay within the level's window)      # zjni_shim_stats: served > 0, forwarded == 0   # levels 4-8 (<= 128 KiB) through the one-shot natives as well
     env.pop("ZSTD_JNI_CPU_LIB", None)                  # nothing to forward to: every result must come from the GPU library
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]
@@ -148,6 +148,6 @@ def test_shim_streams_on_the_gpu_with_the_bundled_library_behind():
     """the stream natives with BOTH a GPU and the bundled library (ZSTD_JNI_GPU_STREAMS=1): streams within the level's window come from the GPU route, a stream that
     outgrows it is replayed into the bundled library's stream and continues there — the same bytes as the reference either way, whatever room the target buffer has"""
     assert all(os.path.exists(p) for p in (SHIM, REFJNI, HARNESS)), "prebuilt JNI shim / reference JNI library / harness missing"
-    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2", HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="13,60", HARNESS_FUZZ_SKIP_HEAP="1")
+    env = dict(os.environ, ZSTD_JNI_CPU_LIB=REFJNI, ZSTD_JNI_GPU_STREAMS="1", HARNESS_SKIP_BATCH="1", HARNESS_MAX_LEVEL="2", HARNESS_DICT_FILE=_dict_file(), HARNESS_FUZZ="13,25", HARNESS_FUZZ_SKIP_HEAP="1")
     out = subprocess.run([HARNESS, REFJNI, SHIM], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "JNI-HARNESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-500:]

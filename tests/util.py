@@ -98,13 +98,13 @@ def json_records(n, seed=1, first=0):
 
 
 def emu_decompress_split(L, frame, cap):
-    """three-stage decode pipeline (prep -> lane sequence decode -> execute); returns (bytes | -code, took_split_path)"""
+    """three-stage decode pipeline (prep -> lane sequence decode -> execute); returns (bytes | -code, which path answered)"""
     dst = C.create_string_buffer(max(cap, 1))
     used = C.c_int(0)
     r = L.emu_decompress_split(frame, len(frame), dst, cap, C.byref(used))
     if r >= (1 << 63):
-        return -((1 << 64) - r), bool(used.value)
-    return dst.raw[:r], bool(used.value)
+        return -((1 << 64) - r), used.value
+    return dst.raw[:r], used.value                      # 0: the fused decoder answered; 1 or 3: the three stages (3: literals from stage 2b); 4: stage 1 copied a frame of one stored block
 
 
 def emu_compress_multi(L, data, level, checksum=False, content_size=True, serial=False, hash_log=0, chain_log=0, pipelined=False, cap=None):

@@ -134,6 +134,47 @@ ZJ_DEV bool zd_prep_frame(const G& g, ZDecShared& sh, const u8* src, u32 srcSize
     return true;
 }
 
+// Stage 1, frames of ONE STORED BLOCK (round 6): what the compressors write for data that does not compress — a quarter of the bench batches — is a header and a raw
+// (or RLE) block; such a frame is not "simple" (no sequences to decode on a lane) and went through the block stages behind everything else (a 0.9 ms tail of four
+// launches for 16 384 copies).  Stage 1 is a wave per frame already: it copies the block where it stands.  Only the plain case is taken — known content size equal to the
+// block's, the block the frame's last and within blockSizeMax, the buffer ending with the frame, room in the destination, no dictionary ID; a checksum is verified —
+// and everything else (and a checksum that does not match) stays with the paths that report errors.  Returns true (wave-uniform) when dst holds the frame's content.
+template <class G>
+ZJ_DEV bool zd_prep_frame_stored(const G& g, ZDecShared& sh, const u8* src, u32 srcSize, u8* dst, u64 dstCap, u64* result) {
+    GRP_SERIAL(g) {
+        u32 ok = 0;
+        if (srcSize >= 9 && ld32(src) == 0xFD2FB528u) {
+            u32 const fhd = src[4], didc = fhd & 3, single = (fhd >> 5) & 1, fcsid = fhd >> 6;
+            u32 const fcsSz = fcsid == 0 ? single : (1u << fcsid);
+            u32 const hdr = 5 + !single + fcsSz;
+            if (!(fhd & 8) && didc == 0 && fcsSz != 0 && fcsSz <= 4 && srcSize >= hdr + 3) {
+                u32 pos = 5; u64 window = 0; u32 content = 0; bool wok = true;
+                if (!single) { u32 const wd = src[pos++], wl = (wd >> 3) + 10; if (wl > 27) wok = false; window = (u64)1 << wl; window += (window >> 3) * (wd & 7); }
+                if (fcsid == 0) content = src[pos]; else if (fcsid == 1) content = ld16(src + pos) + 256; else content = ld32(src + pos);
+                if (single) window = content;
+                u32 const bh = ld24(src + hdr), last = bh & 1, type = (bh >> 1) & 3, sz = bh >> 3;
+                u32 const tail = ((fhd >> 2) & 1) ? 4u : 0u, body = type == 1 ? 1u : sz;
+                u32 const bmax = window < ZD_BLOCK_MAX ? (u32)window : ZD_BLOCK_MAX;
+                if (wok && last && type < 2 && sz == content && sz <= bmax && (u64)sz <= dstCap && (u64)hdr + 3 + body + tail == srcSize) {
+                    ok = 1; sh.hdrSize = hdr + 3; sh.blkSize = sz; sh.blkType = type; sh.hasChecksum = tail ? 1u : 0u;
+                }
+            }
+        }
+        sh.litType = ok;
+    }
+    g.sync();
+    if (!ZJ_UNI(sh.litType)) return false;
+    u32 const boff = ZJ_UNI(sh.hdrSize), sz = ZJ_UNI(sh.blkSize), type = ZJ_UNI(sh.blkType);
+    if (type == 0) grp_copy_wide(g, dst, src + boff, sz); else zd_fill(g, dst, src[boff], sz);
+    zj_mem_order();
+    g.sync();
+    if (ZJ_UNI(sh.hasChecksum)) {
+        if ((u32)zj_xxh64(g, dst, sz) != ZJ_UNI(ld32(src + boff + (type == 1 ? 1u : sz)))) return false;      // (the fused kernel says checksum_wrong)
+    }
+    GRP_SERIAL(g) { *result = sz; }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 2.  One lane per frame; round() is one memory round trip for every lane of the wave.
 // Bit positions are relative to the frame buffer.  N/decompress/zstd_decompress_block.c:1229-1347, :1615-1690.

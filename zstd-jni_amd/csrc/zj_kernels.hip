@@ -126,7 +126,7 @@ struct ZDMbArgs { ZDFrameMB* frames; ZDBlk* blks; u16* tabs; u32* ctr; u32 blkCa
 template <bool DICT>
 __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u64* __restrict__ dstOff,
                                                           u32 n, u32* counter, u16* tabs, ZDMeta* metas, u32* listA, u32* listB, u32* listCounts,
-                                                          const ZDDictDev* dd, u32* doneList, u32* procFlag, ZDMbArgs mb, u32 mbOnly) {
+                                                          const ZDDictDev* dd, u32* doneList, u32* procFlag, ZDMbArgs mb, u32 mbOnly, u8* __restrict__ dst, u64* __restrict__ result) {
     __shared__ ZDecShared sh;
     Grp<64> g;
     for (;;) {
@@ -136,8 +136,9 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
         u64 const cap = d1 - d0;
         bool const simple = !mbOnly && zd_prep_frame<DICT>(g, sh, src + s0, (u32)(s1 - s0), (u32)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap),
                                                            tabs + (size_t)i * ZD_SPLIT_CELLS, metas + i, dd);
-        bool multi = false;
-        if (!DICT && !simple && mb.frames && s1 - s0 <= 0xFFFFFFFFull) {
+        bool multi = false, stored = false;
+        if (!DICT && !simple && dst && s1 - s0 <= 0xFFFFFFFFull) stored = zd_prep_frame_stored(g, sh, src + s0, (u32)(s1 - s0), dst + d0, cap, result + i);      // one raw / RLE block: copied here ([11] counts them)
+        if (!DICT && !simple && !stored && mb.frames && s1 - s0 <= 0xFFFFFFFFull) {
             // (minBlocks: a small batch keeps its single-block frames on the fused kernel — one launch instead of three)
             multi = zd_prep_frame_multi(g, sh, src + s0, (u32)(s1 - s0), cap, i, mb.frames + i, mb.blks, mb.tabs, mb.ctr, mb.blkCap, (unsigned long long*)(mb.ctr + 4), mb.seqCap, mb.seqList, mb.ctr + 1, mb.minBlocks,
                                         (unsigned long long*)(mb.ctr + 10), mb.litCap, mb.litList, mb.ctr + 8);
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
             if (doneList) { doneList[i] = 0xFFFFFFFFu; procFlag[i] = 0; }       // slot i of the completion queue / frame i's "executed by the side pass" flag
             // |A| and the batch's sequence total share one 64-bit counter ([8] = |A|, [9] = sequences, see zj_dec_heavy): one same-address atomic per frame
             if (simple) listA[(u32)atomicAdd((unsigned long long*)&listCounts[8], 1ull | ((unsigned long long)sh.nbSeq << 32))] = i;
+            else if (stored) atomicAdd(&listCounts[11], 1u);
             else if (multi) mb.listM[atomicAdd(mb.ctr + 2, 1u)] = i;
             else listB[atomicAdd(&listCounts[1], 1u)] = i;
         }
@@ -225,7 +227,10 @@ __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ s
     __shared__ u32 llBase[36], mlBase[53];
     zd_seq_symtabs(llBase, mlBase, threadIdx.x, 64u);
     __syncthreads();
-    if (doneList) __builtin_amdgcn_s_setprio(3);            // the chain of rounds is the critical path; the execution kernel's waves beside it fill the gaps
+#ifndef ZD_SEQ_PRIO
+#define ZD_SEQ_PRIO 3
+#endif
+    if (doneList) __builtin_amdgcn_s_setprio(ZD_SEQ_PRIO);   // the chain of rounds is the critical path; the execution kernel's waves beside it fill the gaps
     u32 const count = *countPtr;
     ZDSeqLane m; m.st = 2; m.llBase = llBase; m.mlBase = mlBase;
     u32 cur = 0xFFFFFFFFu;                                   // the frame this lane is decoding
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
                                                           const u32* countPtr, u32* workCounter, ZDMeta* metas, const u64* seqs, u8* scratch,
                                                           u32* listB, u32* listBCount, unsigned long long* prof, const ZDDictDev* dd, const u8* dictRaw,
-                                                          u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot) {      // (metas: written by mode 3 only — the literal pass marks the frames it served)
+                                                          u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot, u32* processed) {      // (metas: written by mode 3 only — the literal pass marks the frames it served; processed: frames mode 1 executed)
     // mode 0: list entry k.  mode 1: the k-th frame the sequence-decode kernel finishes while this kernel runs beside it (bounded
     // wait; a workgroup that gives up leaves the rest to the mode-2 pass).  mode 2: list entries mode 1 did not get to.
     // mode 3: literals only (zd_lit_frame), beside the sequence decode, into slot k of litSlots (litSlot bytes each); the other modes
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
         return;
     }
     if (mode == 1 && !zj_dec_heavy(countPtr)) return;        // light frames: everything is the mode-2 pass's
+    if (mode == 2 && processed && ZJ_UNI(*processed) == count) return;      // the pass beside the sequence decode took every frame (round 6: walking the list to find that out was 0.7 ms)
     for (;;) {
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
         u64 const r = zd_exec_frame<DICT>(g, sh, src + srcOff[i], dst + dstOff[i], metas + i, seqs + (size_t)i * ZD_SPLIT_MAXSEQ, lit, pf, dd, dictRaw,
                                           litSlots ? litSlots + (size_t)i * litSlot : (const u8*)nullptr, litSlot);
         pf.mark(8);
-        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; if (mode == 1) procFlag[i] = 1u; }
+        if (threadIdx.x == 0) { if (r == ~(u64)0) listB[atomicAdd(listBCount, 1u)] = i; else result[i] = r; if (mode == 1) { procFlag[i] = 1u; if (processed) atomicAdd(processed, 1u); } }
         __syncthreads();
     }
 }
@@ -1608,7 +1614,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         ZDMeta* const metas = (ZDMeta*)(d->dsplitBuf + tabBytes + seqBytes);
         u32* const listA = (u32*)(d->dsplitBuf + tabBytes + seqBytes + metaBytes); u32* const listB = listA + n;
         u32* const doneList = listB + n; u32* const procFlag = doneList + n;       // completion queue of the sequence decode, frames the side pass executed
-        u32* const c = d->counters + 32;          // [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A, [10] work of the literal pass
+        u32* const c = d->counters + 32;          // [0] frames the pass beside the sequence decode executed, [1] |B|, [2] work prep, [3] work seq, [4] work exec, [5] work fused, [6] queue length, [7] work of the sweep pass, [8] |A|, [9] sequences in A, [10] work of the literal pass, [11] frames of one stored block copied by stage 1
         // Stage 2b (zd_lit_frame): one literal slot per frame, as large as the budget allows (at most a block); frames whose literals do
         // not fit a slot stay with the execution kernel.  Without a dictionary only (treeless literals need the dictionary's table).
         // ZJNI_DEC_LIT=0 switches the pass off (A/B runs); ZJNI_DEC_LIT_BYTES sets the budget (default 4 GiB, nothing under a scratch limit).
@@ -1638,9 +1644,9 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         (void)hipEventRecord(d->tev[2], st);
         ZDMbHost const mb = decode_mb_scratch(d, n, st, ddict != nullptr);       // frames that are not simple: multi-block, no content size (the stream classes')
         if (ddict) hipLaunchKernelGGL(zj_dec_prep_kernel_t<true>, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+                                      (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u, (u8*)d_dst, (u64*)d_result);
         else hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u);
+                                (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u, (u8*)d_dst, (u64*)d_result);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
         u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
@@ -1653,7 +1659,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         if (litSlots) {                                 // beside the sequence decode, ahead of the mode-1 execution pass on the same side stream
             hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, d->sideStream,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), c + 10, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), c + 10, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot, c);
         }
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
                            (const u64*)d_src_off, (const u32*)listA, (const u32*)(c + 8), c + 3, (const u16*)tabs, seqs, metas, ddDev,
@@ -1668,10 +1674,10 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
             u32* const work = pass == 2 ? c + 7 : c + 4;
             if (ddict) hipLaunchKernelGGL(zj_dec_exec_kernel_t<true>, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot, c);
             else hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, es,
                                (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot);
+                               (const u32*)(c + 8), work, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, (u32)pass, (const u32*)doneList, procFlag, litSlots, litSlot, c);
             if (pass == 1 && (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess)) {
                 (void)hipStreamSynchronize(d->sideStream); (void)hipStreamSynchronize(st);          // the side kernel must not outlive this call's claim on the scratch
                 return ZJNI_ERR(ZJNI_ERROR_no_device);
@@ -1703,7 +1709,7 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
             mb.a.minBlocks = 2;
             (void)hipEventRecord(d->tev[2], st);
             hipLaunchKernelGGL(zj_dec_prep_kernel, dim3(grid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u64*)d_dst_off,
-                               (u32)n, c + 2, (u16*)nullptr, (ZDMeta*)nullptr, (u32*)nullptr, listB, c, (const ZDDictDev*)nullptr, (u32*)nullptr, (u32*)nullptr, mb.a, 1u);
+                               (u32)n, c + 2, (u16*)nullptr, (ZDMeta*)nullptr, (u32*)nullptr, listB, c, (const ZDDictDev*)nullptr, (u32*)nullptr, (u32*)nullptr, mb.a, 1u, (u8*)d_dst, (u64*)d_result);
             (void)hipEventRecord(d->tev[3], st); (void)hipEventRecord(d->tev[4], st);
             decode_mb_launch(d, mb, st, d_src, d_src_off, d_dst, d_dst_off, d_result, listB, c + 1);
             (void)hipEventRecord(d->tev[5], st);
