@@ -313,6 +313,9 @@ int zjni_last_lists(unsigned* out3);
  * fused wave-per-frame kernel decoded (what no pipeline took, or handed over), out4[2] frames of the multi-block stages (lane per BLOCK; frames of several blocks
  * or without a content size), out4[3] their blocks.  Synchronises with the device (diagnostics only). */
 int zjni_last_decode_lists(unsigned* out4);
+/* zjni_last_decode_lists plus out5[4]: frames that are a header and ONE stored (raw or RLE) block — what ZSTD_compress2 writes for data that does not compress
+ * (N/compress/zstd_compress.c:4591-4692, ZSTD_noCompressBlock) — which stage 1 of the large-batch pipeline copies itself; they are on none of the three lists. */
+int zjni_last_decode_lists2(unsigned* out5);
 /* Name of the kernel a route's match-finder time (zjni_last_timing out[0]) belongs to. */
 const char* zjni_route_kernel(int route);
 /* The source revision the library was built from ("unknown" when the build had no git): profiles and PMC passes are stamped with it. */

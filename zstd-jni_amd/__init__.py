@@ -182,6 +182,9 @@ def lib():
     L.zjni_build_stamp.restype = C.c_char_p
     L.zjni_last_decode_lists.restype = C.c_int
     L.zjni_last_decode_lists.argtypes = [C.POINTER(C.c_uint)]
+    if hasattr(L, "zjni_last_decode_lists2"):            # (absent from older variant libraries loaded through ZJNI_LIB for A/B runs; tests/test_abi.py checks the product library's exports)
+        L.zjni_last_decode_lists2.restype = C.c_int
+        L.zjni_last_decode_lists2.argtypes = [C.POINTER(C.c_uint)]
     L.zjni_last_lists.restype = C.c_int
     L.zjni_last_lists.argtypes = [C.POINTER(C.c_uint)]
     L.zjni_frame_extent.restype = sz
@@ -207,7 +210,7 @@ EXPORTS = ("zjni_version", "zjni_device_count", "zjni_init", "zjni_shutdown", "z
            "zjni_compress_batch_usingCDict", "zjni_compress_usingCDict",
            "zjni_compress_batch_device_advanced", "zjni_compress_batch_advanced",
            "zjni_createAggregator", "zjni_freeAggregator", "zjni_aggregator_compress", "zjni_aggregator_decompress", "zjni_aggregator_stats",
-           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists",
+           "zjni_last_route", "zjni_route_kernel", "zjni_build_stamp", "zjni_compress_stream", "zjni_compress_stream_batch_device", "zjni_frame_extent", "zjni_last_lists", "zjni_last_decode_lists", "zjni_last_decode_lists2",
            "zjni_compress_batch_begin", "zjni_decompress_batch_begin", "zjni_batch_finish", "zjni_pack_batch_device2")
 
 

@@ -1461,6 +1461,17 @@ int zjni_last_decode_lists(unsigned* out4) {
     out4[0] = a[8]; out4[1] = a[1]; out4[2] = m[2]; out4[3] = m[0];
     return 0;
 }
+// ... and out5[4]: frames of one stored (raw / RLE) block that stage 1 copied itself (round 6; they are on none of the three lists)
+int zjni_last_decode_lists2(unsigned* out5) {
+    DevState* d = cur_state();
+    if (!d || !out5) return -(int)ZJNI_ERROR_no_device;
+    int const r = zjni_last_decode_lists(out5);
+    if (r) return r;
+    u32 s = 0;
+    if (hipMemcpy(&s, d->counters + 32 + 11, sizeof s, hipMemcpyDeviceToHost) != hipSuccess) return -(int)ZJNI_ERROR_no_device;
+    out5[4] = s;
+    return 0;
+}
 const char* zjni_route_kernel(int route) {
     switch (route) {
     case ZJNI_ROUTE_WIDE: return "zj_enc_match_wide_kernel";
