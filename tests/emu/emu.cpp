@@ -45,6 +45,8 @@ extern "C" unsigned long long emu_decompress(const unsigned char* src, unsigned 
     u64 r = zd_decompress(g, *sh, src, srcSize, dst, dstCap, lit, pf);
     return r;
 }
+// zd_huf_streams_wave's counters (zj_decode.h): taken, left at the check, left after the tries, repeated passes, lanes that decoded again
+extern "C" void emu_hp_stats(unsigned long long* out5, int reset) { for (int i = 0; i < 5; i++) { out5[i] = zd_hp_stats[i]; if (reset) zd_hp_stats[i] = 0; } }
 // split pipeline: prep -> lane sequence decode -> execute; frames the pipeline hands over go through the fused path
 extern "C" unsigned long long emu_decompress_split(const unsigned char* src, unsigned srcSize, unsigned char* dst, unsigned dstCap, int* usedSplit) {
     EMU_IO(src, srcSize, dst, dstCap);
@@ -68,10 +70,14 @@ extern "C" unsigned long long emu_decompress_split(const unsigned char* src, uns
         u8* slotBuf = slot ? (u8*)malloc(slot) : nullptr;
         if (slotBuf) {
             ZDecShared* sh2 = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh2, 0x3C, sizeof(ZDecShared));
-            if (zd_lit_frame(g, *sh2, src, &meta, slotBuf, slot, pf)) meta.pad = 1u;
+            u8* hp = (u8*)malloc(ZD_HP_LDS); memset(hp, 0x77, ZD_HP_LDS);
+            if (zd_lit_frame(g, *sh2, src, &meta, slotBuf, slot, pf, getenv("EMU_NO_HP") ? nullptr : hp)) meta.pad = 1u;
+            free(hp);
             free(sh2);
         }
-        r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf, nullptr, nullptr, slotBuf, slot);
+        {   u8* hp = (u8*)malloc(ZD_HP_LDS); memset(hp, 0x78, ZD_HP_LDS);
+            r = zd_exec_frame(g, *sh, src, dst, &meta, seqs, lit, pf, nullptr, nullptr, slotBuf, slot, getenv("EMU_NO_HP") ? nullptr : hp);
+            free(hp); }
         if (usedSplit && r != ~(u64)0) *usedSplit = meta.pad ? 3 : 1;
         free(slotBuf);
     }
@@ -106,7 +112,9 @@ extern "C" unsigned long long emu_decompress_mb(const unsigned char* src, unsign
         for (u32 q = 0; q < litListCount; q++) {                  // stage 2b: a workgroup of its own per block (poisoned LDS)
             if (litMode == 2 && (q & 1u)) continue;
             ZDecShared* sh3 = (ZDecShared*)malloc(sizeof(ZDecShared)); memset(sh3, 0x77, sizeof(ZDecShared));
-            if (zd_lit_block(g, *sh3, src, blks, litList[q], litPool, pf)) blks[litList[q]].litReady = 1u;
+            u8* hp = (u8*)malloc(ZD_HP_LDS); memset(hp, 0x79, ZD_HP_LDS);
+            if (zd_lit_block(g, *sh3, src, blks, litList[q], litPool, pf, getenv("EMU_NO_HP") ? nullptr : hp)) blks[litList[q]].litReady = 1u;
+            free(hp);
             free(sh3);
         }
         u32 symL[36], symM[53]; zd_seq_symtabs(symL, symM, 0, 1);

@@ -65,6 +65,8 @@ struct ZDecShared {
     u32 bN, bLitStart, bOutStart, bLitTotal, bOutTotal, seqDone, winLo;
     u32 tblOff[3], tblMode[3], tblLog[3], tblMax[3];
     u32 dictSize;                   // bytes of dictionary content before the frame's output (0 = none)
+    u32 hpAgain;                    // zd_huf_streams_wave: a lane's start moved / the streams check out
+    u32 hufGcd;                     // greatest common divisor of the table's code lengths (1 for a table that came from a dictionary)
     // --- tANS tables last: the execute-only kernel of the split pipeline allocates the struct without them ---
     short norm[3][64];              // NCount of the LL / OF / ML table being described
     u16 symNext[64 * 3];
@@ -73,6 +75,8 @@ struct ZDecShared {
     u32 of[256];
 };
 #define ZD_SHARED_NO_FSE (sizeof(ZDecShared) - (512u + 512u + 256u) * 4u - 3u * 64u * 2u - 64u * 3u * 2u)
+#define ZD_HP_LDS_OFF ((ZD_SHARED_NO_FSE + 15u) & ~15u)      // ... and behind it the lanes' windows of zd_huf_streams_wave
+#define ZD_EXEC_LDS (ZD_HP_LDS_OFF + 64u * 72u)             // = ZD_HP_LDS (defined with the pass below)
 
 // format constants (N/common/zstd_internal.h:113-165, N/decompress/zstd_decompress_internal.h:28-58)
 #define ZD_LL_BASE_INIT { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 }
@@ -711,6 +715,10 @@ ZJ_DEV u32 zd_huf_read_weights(ZDecShared& sh, const u8* src, u32 srcSize, u32* 
             if (w) { sh.symPos[n] = (u16)start[w]; start[w] += 1u << (w - 1); }
         }
         sh.hufLog = tl; sh.hufW1 = tl > ZD_HUF_CELLS_LOG ? rank[1] : 0u;
+        {   u32 gcd = 0;                                       // of the code lengths in use (zd_huf_streams_wave: codes start on that lattice)
+            for (u32 w = 1; w <= tl; w++) { if (rank[w]) { u32 a = tl + 1u - w, b = gcd; while (b) { u32 const r = a % b; a = b; b = r; } gcd = a; } }
+            sh.hufGcd = gcd ? gcd : 1u;
+        }
     }
     *nbSymOut = oSize + 1;
     return iSize + 1;
@@ -933,6 +941,176 @@ ZJ_DEV bool zd_huf_x2_accepts(ZDecShared& sh, const u8* bsrc, u32 t, u8* out) {
     return A == S0;
 }
 
+// ------------------------------------------------------------------ the four streams by the whole wave (round 6) ----
+// A Huffman stream is a chain — a code's length says where the next code starts — and the rounds of zd_block_literals run it on ONE lane per stream: 4 of a wave's 64
+// lanes walk ~7 000 (text) to 16 000 (few distinct bytes) dependent LDS look-ups each for a 64 KiB frame while 60 idle (the literal pass of the batch decode: 9 ms of a
+// 20 ms call).  But a prefix code RE-SYNCHRONISES: a decoder started at an arbitrary bit falls into step with the true parse within a few codes.  So a stream's bits
+// are cut into ZD_HP_LANES spans with a lane each (4 x 16 = the wave):
+//   pass G  every lane but a stream's first starts ZD_HP_SYNC bits ABOVE its span and decodes down to the span's edge; where that lands is its guess of the first code
+//           of the true parse inside the span (the stream's first lane starts at the stream's own first code).  Codes start a multiple of the code lengths' common
+//           divisor below the stream's first code, so the guess starts on that lattice: a table of codes of ONE length — what few equally likely byte values give,
+//           and where no decoder ever falls into step from the wrong phase — is guessed exactly;
+//   pass V  every lane decodes its span from its start — counting, no stores — and notes where it crossed into the next span.  A lane whose start is not where its
+//           predecessor really ended takes that end as its start and decodes again; the first lane's start is exact, so by induction every lane's is once nothing
+//           changes any more (ZD_HP_TRIES repeats at most, then the section is left to the rounds);
+//   check   the last lane ends exactly on the stream's first bit and the counts add up to the stream's regenerated size: what the reference's decoders ask of a valid
+//           stream (N/decompress/huf_decompress.c:697, :830).  Anything else is NOT judged here — the rounds decode the section again and answer as the reference does
+//           (which decoder it would have picked matters there: zd_huf_x2_accepts);
+//   pass W  the counts' prefix sums are the lanes' places in the output; every lane decodes its span once more and stores, 8 symbols to a store.
+// A lane's chain is (ZD_HP_SYNC / code length) + 2 x (stream / 16) look-ups instead of the stream's length.  Each pass runs in rounds like the one-lane decode's: the
+// wave stages the next ZD_HP_WIN bytes under every lane's cursor in LDS (coalesced 16-byte loads; 64 lanes refilling straight from memory, a cache line each, made the
+// sequence decode beside this pass wait: measured, profiles/r06), then every lane decodes out of its window.  Tables to ZD_HUF_CELLS_LOG bits; deeper ones (no libzstd
+// encoder writes them) stay with the rounds, and so does every caller that has no LDS to spare for the windows (hpWin = nullptr).
+#define ZD_HP_LANES 16u
+#define ZD_HP_SYNC 192u
+#define ZD_HP_TRIES 4u
+#define ZD_HP_MIN_LIT 2048u          // smaller sections: the passes' fixed costs outweigh the chain
+#define ZD_HP_WIN 64u                // bytes staged per lane and round
+#define ZD_HP_STRIDE (ZD_HP_WIN + 8u)
+#define ZD_HP_LDS (64u * ZD_HP_STRIDE)
+static_assert(ZD_EXEC_LDS == ZD_HP_LDS_OFF + ZD_HP_LDS, "ZD_EXEC_LDS");
+static_assert(ZD_HP_LDS <= (512u + 512u + 256u) * 4u, "the multi-block execution stage lends its staging area");
+#if !ZJ_ON_GPU
+static unsigned long long zd_hp_stats[5];        // lane-serial build (tests/emu): sections taken, left at the check, left after ZD_HP_TRIES, repeated passes V, lanes that decoded again
+#define ZD_HP_STAT(i, n) (zd_hp_stats[i] += (n))
+#else
+#define ZD_HP_STAT(i, n) ((void)0)
+#endif
+// the edge of span j of a stream: span j is (edge(j + 1), edge(j)]
+ZJ_DEV i32 zd_hp_edge(i32 A0, i32 S0, u32 j) { return A0 - (i32)((u64)(u32)(A0 - S0) * j / ZD_HP_LANES); }
+// One pass.  Lane l decodes from bit position pA[l] (exclusive top) while the position is above its limit and it has decoded fewer than its cap; pA / pK run along.
+//   mode 0 (G): lanes 1.. of a stream, limit = the span's upper edge, cap ZD_HP_SYNC      mode 1 (V): lanes flagged in pC, limit = the span's lower edge, cap = the stream's size + 1
+//   mode 2 (W): every lane, no limit, cap = pC[l] codes, symbols to out + pO[l]
+#ifndef ZD_HP_PASS_ATTR
+#define ZD_HP_PASS_ATTR ZJ_DEV
+#endif
+template <class G>
+ZD_HP_PASS_ATTR void zd_hp_pass(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* hpWin, u8* out, u32 mode) {
+    u32 const log = ZJ_UNI(sh.hufLog);
+    u32* const pC = sh.sOff; u32* const pA = (u32*)&sh.hstage[0][0]; u32* const pK = pA + 64; u32* const pO = (u32*)&sh.win[0];
+    u32* const pLim = pO + 64; u32* const pCap = pO + 128;
+    GRP_FOR(g, l, 64u) {
+        u32 const t = l / ZD_HP_LANES, j = l % ZD_HP_LANES;
+        i32 const A0 = (i32)sh.hA0[t], S0 = (i32)sh.hS0[t];
+        bool const on = mode == 0u ? j != 0u : (mode == 1u ? (pC[l] & 0x80000000u) != 0u : true);
+        pLim[l] = mode == 0u ? (u32)zd_hp_edge(A0, S0, j) : (mode == 1u ? (u32)zd_hp_edge(A0, S0, j + 1u) : 0xFFFFFFFFu);        // (-1: below every position)
+        pCap[l] = !on ? 0u : (mode == 0u ? ZD_HP_SYNC : (mode == 1u ? sh.hN[t] + 1u : pC[l]));
+        pK[l] = 0;
+    }
+    g.sync();
+    for (;;) {
+        GRP_SERIAL(g) { sh.hpAgain = 0; }
+        g.sync();
+        // stage: the 64 bytes under every working lane's cursor, never below its stream's first byte
+        GRP_FOR(g, i, 64u * (ZD_HP_WIN / 16u)) {
+            u32 const l = i / (ZD_HP_WIN / 16u), c = i % (ZD_HP_WIN / 16u);
+            if ((i32)pA[l] > (i32)pLim[l] && pK[l] < pCap[l]) {
+                u32 const startByte = sh.hS0[l / ZD_HP_LANES] >> 3, be = (pA[l] + 7u) >> 3;
+                u32 lo = be > ZD_HP_WIN ? be - ZD_HP_WIN : 0u; if (lo < startByte) lo = startByte;
+                u32 const o = lo + 16u * c;
+                u64 a = 0, b = 0;
+                if (o + 16u <= bsize) { a = ld64(bsrc + o); b = ld64(bsrc + o + 8); }
+                else { for (u32 k = 0; k < 16u; k++) { if (o + k < bsize) { if (k < 8u) a |= (u64)bsrc[o + k] << (8u * k); else b |= (u64)bsrc[o + k] << (8u * (k - 8u)); } } }
+                st64(hpWin + l * ZD_HP_STRIDE + 16u * c, a); st64(hpWin + l * ZD_HP_STRIDE + 16u * c + 8u, b);
+                if (c == 0) sh.hpAgain = 1;
+            }
+        }
+        g.sync();
+        if (!ZJ_UNI(sh.hpAgain)) break;
+        GRP_FOR(g, l, 64u) {
+            i32 a = (i32)pA[l]; i32 const lim = (i32)pLim[l]; u32 k = pK[l]; u32 const cap = pCap[l];
+            if (a > lim && k < cap) {
+                i32 const S0 = (i32)sh.hS0[l / ZD_HP_LANES];
+                u32 const startByte = (u32)S0 >> 3, be = ((u32)a + 7u) >> 3;
+                u32 lo = be > ZD_HP_WIN ? be - ZD_HP_WIN : 0u; if (lo < startByte) lo = startByte;
+                const u8* const win = hpWin + l * ZD_HP_STRIDE;
+                u8* const dst = mode == 2u ? out + pO[l] : nullptr;
+                u32 k0 = k; u64 acc = 0;                                  // W: symbols k0.. of this lane gather in acc, 8 to a store
+                while (a > lim && k < cap) {
+                    u32 const byteEnd = ((u32)a + 7u) >> 3;
+                    u64 c;
+                    if (byteEnd >= lo + 8u) c = ld64(win + (byteEnd - 8u - lo)) << (8u * byteEnd - (u32)a);       // >= 57 bits below a
+                    else if (lo == startByte) c = ld64(win) << (64u - (u32)(a - S0));                              // fewer than 64 bits of the stream left: zeros below its first bit
+                    else break;                                                                                    // the window is used up
+                    for (u32 q = 0; q < 5u && a > lim && k < cap; q++) {
+                        u32 const cell = sh.huf[(u32)(c >> (64u - log))], nb = cell >> 8;
+                        c <<= nb; a -= (i32)nb;
+                        if (mode == 2u) {
+                            acc |= (u64)(cell & 0xFFu) << (8u * ((k - k0) & 7u));
+                            if (((k - k0) & 7u) == 7u) { st64(dst + (k - 7u), acc); acc = 0; }
+                        }
+                        k++;
+                    }
+                }
+                if (mode == 2u) { for (u32 r = k - ((k - k0) & 7u); r < k; r++) { dst[r] = (u8)acc; acc >>= 8; } }
+                pA[l] = (u32)a; pK[l] = k;
+            }
+        }
+        g.sync();
+    }
+}
+// true (wave-uniform): out[0, litSize) holds the section's literals.  false: nothing decided, the caller's rounds run as if this had not been tried.
+// hpWin: ZD_HP_LDS bytes of LDS for the lanes' windows.
+template <class G>
+ZJ_DEV bool zd_huf_streams_wave(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* out, u8* hpWin) {
+    if (!hpWin || ZJ_UNI(sh.litStreams) != 4u || ZJ_UNI(sh.hufLog) > ZD_HUF_CELLS_LOG || ZJ_UNI(sh.litSize) < ZD_HP_MIN_LIT) return false;
+    u32 const gcd = ZJ_UNI(sh.hufGcd);
+    u32* const pS = sh.sLit; u32* const pE = sh.sMl; u32* const pC = sh.sOff;          // per lane: start, end, codes | 1 << 31 "decode (again)"   (the execution stage's arrays: idle here)
+    u32* const pA = (u32*)&sh.hstage[0][0]; u32* const pK = pA + 64; u32* const pO = (u32*)&sh.win[0];       // running position, running count, place in the output (idle too: the rounds' staging)
+    // pass G
+    GRP_FOR(g, l, 64u) {
+        u32 const t = l / ZD_HP_LANES, j = l % ZD_HP_LANES;
+        i32 const A0 = (i32)sh.hA0[t], S0 = (i32)sh.hS0[t];
+        i32 const edge = zd_hp_edge(A0, S0, j);
+        i32 from = edge + (i32)ZD_HP_SYNC < A0 ? edge + (i32)ZD_HP_SYNC : A0;
+        from = A0 - (i32)((u32)(A0 - from) / gcd * gcd);                                // on the lattice of the code lengths' common divisor
+        pA[l] = (u32)(j ? from : A0);
+    }
+    g.sync();
+    zd_hp_pass(g, sh, bsrc, bsize, hpWin, nullptr, 0u);
+    GRP_FOR(g, l, 64u) { pS[l] = pA[l]; pC[l] = 0x80000000u; }
+    g.sync();
+    // pass V until nothing changes
+    for (u32 tries = 0; ; tries++) {
+        GRP_FOR(g, l, 64u) { if (pC[l] & 0x80000000u) pA[l] = pS[l]; }
+        g.sync();
+        zd_hp_pass(g, sh, bsrc, bsize, hpWin, nullptr, 1u);
+        GRP_FOR(g, l, 64u) { if (pC[l] & 0x80000000u) { pE[l] = pA[l]; pC[l] = pK[l]; } }
+        GRP_SERIAL(g) { sh.hpAgain = 0; }
+        g.sync();
+        GRP_FOR(g, l, 64u) {
+            if ((l % ZD_HP_LANES) && pE[l - 1u] != pS[l]) { pS[l] = pE[l - 1u]; pC[l] = 0x80000000u; sh.hpAgain = 1; ZD_HP_STAT(4, 1); }
+        }
+        g.sync();
+        if (!ZJ_UNI(sh.hpAgain)) break;
+        if (tries == ZD_HP_TRIES) { ZD_HP_STAT(2, 1); return false; }
+        ZD_HP_STAT(3, 1);
+    }
+    // check
+    GRP_SERIAL(g) {
+        u32 ok = 1;
+        for (u32 t = 0; t < 4u; t++) {
+            u32 sum = 0; for (u32 j = 0; j < ZD_HP_LANES; j++) sum += pC[t * ZD_HP_LANES + j];
+            if (sum != sh.hN[t] || pE[t * ZD_HP_LANES + ZD_HP_LANES - 1u] != sh.hS0[t]) ok = 0;
+        }
+        sh.hpAgain = ok;
+    }
+    g.sync();
+    if (!ZJ_UNI(sh.hpAgain)) { ZD_HP_STAT(1, 1); return false; }
+    ZD_HP_STAT(0, 1);
+    // pass W
+    GRP_FOR(g, l, 64u) {
+        u32 const t = l / ZD_HP_LANES, j = l % ZD_HP_LANES;
+        u32 at = sh.hDst[t]; for (u32 q = 0; q < j; q++) at += pC[t * ZD_HP_LANES + q];
+        pO[l] = at; pA[l] = pS[l];
+    }
+    g.sync();
+    zd_hp_pass(g, sh, bsrc, bsize, hpWin, out, 2u);
+    zj_mem_order();
+    g.sync();
+    return true;
+}
+
 // ------------------------------------------------------------------ block --------------------
 // Literals section of one compressed block: parses its header and regenerates the literals (raw: in place;
 // RLE / Huffman: into litScratch).  Returns where they are; sets sh.err and returns nullptr on error.
@@ -942,7 +1120,7 @@ template <class G>
 // parsed as always, the table and the streams are not touched again.
 // tableOnly: build the block's Huffman table (sh.huf, sh.hufValid, sh.hufX2) and stop — for a later treeless block whose literals are decoded apart from this one's
 // (zj_decode_split.h, multi-block frames); returns bsrc then.
-ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u, const u8* preLit = nullptr, bool tableOnly = false) {
+ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u32 bsize, u8* litScratch, ZjProf& pf, u32 room = ~0u, const u8* preLit = nullptr, bool tableOnly = false, u8* hpWin = nullptr) {
     // ---- literals section header (lane 0) : N/decompress/zstd_decompress_block.c:134-340
     GRP_SERIAL(g) {
         u32 err = 0;
@@ -1036,6 +1214,8 @@ ZJ_DEV const u8* zd_block_literals(const G& g, ZDecShared& sh, const u8* bsrc, u
         }
         g.sync();
         if (ZJ_UNI(sh.err)) return nullptr;
+        // ---- the four streams by the whole wave where that applies (round 6), else ----
+        if (zd_huf_streams_wave(g, sh, bsrc, bsize, litScratch, hpWin)) return lit;
         // ---- rounds: stage windows (all lanes) -> decode (<=4 lanes) -> flush (all lanes) ----
         {   u32 const maxN = ZJ_UNI(zj_max(zj_max(sh.hN[0], sh.hN[1]), zj_max(sh.hN[2], sh.hN[3])));
             u32 const rounds = (maxN + ZD_HSYM - 1) / ZD_HSYM;
@@ -1292,7 +1472,7 @@ ZJ_DEV u64 zd_decompress(const G& g, ZDecShared& sh, const u8* src, u32 srcSize,
             sh.rep[0] = 1; sh.rep[1] = 4; sh.rep[2] = 8; sh.hufValid = 0; sh.seqValid = 0; sh.hufX2 = 0;
             if (dd && dd->hasEntropy) {
                 sh.rep[0] = dd->rep[0]; sh.rep[1] = dd->rep[1]; sh.rep[2] = dd->rep[2]; sh.hufValid = 1; sh.seqValid = 1; sh.hufX2 = 1;   // ZSTD_loadDEntropy builds the two-code table (zstd_decompress.c:1473)
-                sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
+                sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; sh.hufGcd = 1; sh.llLog = dd->llLog; sh.ofLog = dd->ofLog; sh.mlLog = dd->mlLog;
             }
             if (err) sh.err = err;
         }

@@ -370,7 +370,7 @@ typedef ZDSeqLaneT<false> ZDSeqLane;
 // literals beyond the slot, treeless literals of dictionary frames, anything wrong with the section — are stage 3's as before.
 // Returns true (wave-uniform) when `out[0, litSize)` holds the literals.
 template <class G>
-ZJ_DEV bool zd_lit_frame(const G& g, ZDecShared& sh, const u8* src, const ZDMeta* meta, u8* out, u32 slot, ZjProf& pf) {
+ZJ_DEV bool zd_lit_frame(const G& g, ZDecShared& sh, const u8* src, const ZDMeta* meta, u8* out, u32 slot, ZjProf& pf, u8* hpWin = nullptr) {      // hpWin: ZD_HP_LDS bytes of LDS (zd_huf_streams_wave) or none
     GRP_SERIAL(g) {
         ZDMeta const m = *meta;
         sh.err = 0; sh.hufValid = 0; sh.hufX2 = 0;
@@ -379,7 +379,7 @@ ZJ_DEV bool zd_lit_frame(const G& g, ZDecShared& sh, const u8* src, const ZDMeta
     }
     g.sync();
     if (!ZJ_UNI(sh.blkType)) return false;
-    const u8* const lit = zd_block_literals(g, sh, src + ZJ_UNI(sh.hdrSize), ZJ_UNI(sh.blkSize), out, pf, slot);
+    const u8* const lit = zd_block_literals(g, sh, src + ZJ_UNI(sh.hdrSize), ZJ_UNI(sh.blkSize), out, pf, slot, nullptr, false, hpWin);
     bool const ok = lit != nullptr && !ZJ_UNI(sh.err);
     zj_mem_order();
     g.sync();
@@ -391,7 +391,7 @@ ZJ_DEV bool zd_lit_frame(const G& g, ZDecShared& sh, const u8* src, const ZDMeta
 // preLit / preAvail: the frame's slot of stage 2b and its size; used when the frame record says the literals are there.
 template <bool DICT = false, class G>
 ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, const ZDMeta* meta, const u64* seqs, u8* litScratch, ZjProf& pf,
-                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr, const u8* preLit = nullptr, u32 preAvail = 0) {
+                         const ZDDictDev* ddArg = nullptr, const u8* dictRaw = nullptr, const u8* preLit = nullptr, u32 preAvail = 0, u8* hpWin = nullptr) {
     const ZDDictDev* const dd = DICT ? ddArg : nullptr;
     const u8* const dictEnd = dd ? dictRaw + dd->contentOff + dd->contentSize : nullptr;
     GRP_SERIAL(g) {
@@ -406,13 +406,13 @@ ZJ_DEV u64 zd_exec_frame(const G& g, ZDecShared& sh, const u8* src, u8* dst, con
     bool const havePre = ZJ_UNI(sh.litStreams) != 0u;
     if (DICT && dd && dd->hasEntropy && (src[ZJ_UNI(sh.hdrSize)] & 3u) == 3u) {   // treeless literals decode with the dictionary's Huffman table
         zd_load_dict_entropy(g, sh, dd, true, false);
-        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; }
+        GRP_SERIAL(g) { sh.hufValid = 1; sh.hufX2 = 1; sh.hufLog = dd->hufLog; sh.hufW1 = dd->hufW1; sh.hufGcd = 1; }
         g.sync();
     }
     const u8* const bsrc = src + ZJ_UNI(sh.hdrSize); u32 const bsize = ZJ_UNI(sh.blkSize);
     u32 const nbSeq = ZJ_UNI(sh.nbSeq), content = (u32)zj_uni64(sh.contentSize);
     u32 const cap = zj_min(content, ZJ_UNI(sh.blockSizeMax));
-    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, ~0u, havePre ? preLit : nullptr);
+    const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, ~0u, havePre ? preLit : nullptr, false, hpWin);
     if (ZJ_UNI(sh.err)) return ~(u64)0;
     pf.mark(2);
     u32 const litSize = ZJ_UNI(sh.litSize);
@@ -601,7 +601,7 @@ ZJ_DEV bool zd_prep_frame_multi(const G& g, ZDecShared& sh, const u8* src, u32 s
 // and in stage 3 a frame's literals are decoded block after block on 4 of 64 lanes).  A treeless block first rebuilds the table of the block that described it.
 // Returns true (wave-uniform) when the slot holds the literals; stage 3 decodes what is not marked itself.
 template <class G>
-ZJ_DEV bool zd_lit_block(const G& g, ZDecShared& sh, const u8* src, const ZDBlk* blks, u32 b, u8* pool, ZjProf& pf) {
+ZJ_DEV bool zd_lit_block(const G& g, ZDecShared& sh, const u8* src, const ZDBlk* blks, u32 b, u8* pool, ZjProf& pf, u8* hpWin = nullptr) {
     GRP_SERIAL(g) {
         ZDBlk const k = blks[b];
         sh.err = 0; sh.hufValid = 0; sh.hufX2 = 0;
@@ -619,7 +619,7 @@ ZJ_DEV bool zd_lit_block(const G& g, ZDecShared& sh, const u8* src, const ZDBlk*
         g.sync();
     }
     u8* const out = pool + (((u64)ZJ_UNI(sh.tblOff[1]) << 32) | ZJ_UNI(sh.tblOff[0]));
-    const u8* const lit = zd_block_literals(g, sh, src + ZJ_UNI(sh.hdrSize), ZJ_UNI(sh.blkSize), out, pf, ~0u);
+    const u8* const lit = zd_block_literals(g, sh, src + ZJ_UNI(sh.hdrSize), ZJ_UNI(sh.blkSize), out, pf, ~0u, nullptr, false, hpWin);
     bool const ok = lit == out && !ZJ_UNI(sh.err);
     zj_mem_order();
     g.sync();
@@ -705,7 +705,7 @@ ZJ_DEV u64 zd_exec_frame_multi(const G& g, ZDecShared& sh, const u8* src, u8* ds
             curHuf = hufBlk;
         }
         if (havePre && lt0 == 3u) { GRP_SERIAL(g) { sh.hufValid = 1; } g.sync(); }      // (the header parse asks for a table; stage 2b had it, and nothing below reads one)
-        const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, ~0u, preLit);
+        const u8* const lit = zd_block_literals(g, sh, bsrc, bsize, litScratch, pf, ~0u, preLit, false, stage);      // (stage: idle until the block is executed; ZD_HP_LDS <= its 5 KiB)
         if (lit == nullptr || ZJ_UNI(sh.err)) return ~(u64)0;
         if (!havePre && lt0 == 2u) curHuf = first + b;                  // (the table this block described is the one in LDS now)
         u32 const litSize = ZJ_UNI(sh.litSize);

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64, 4) void zj_dec_prep_kernel_t(const u8* __restri
 // Multi-block frames, stage 2b: a WAVE per block regenerates its Huffman-coded literals into the block's slot of the literal pool (zd_lit_block)
 __global__ __launch_bounds__(64) void zj_dec_lit_mb_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ litList, const u32* countPtr, u32* workCounter,
                                                             ZDBlk* blks, u8* litPool) {
-    ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
+    ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables, the windows of zd_huf_streams_wave behind it (ZD_EXEC_LDS)
     ZjProf pf; pf.start(nullptr);
     Grp<64> g;
     u32 const count = ZJ_UNI(*countPtr);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void zj_dec_lit_mb_kernel(const u8* __restrict_
         u32 const k = zj_next_index(workCounter);
         if (k >= count) break;
         u32 const b = ZJ_UNI(litList[k]);
-        bool const ok = zd_lit_block(g, sh, src + zj_uni64(srcOff[ZJ_UNI(blks[b].frame)]), blks, b, litPool, pf);
+        bool const ok = zd_lit_block(g, sh, src + zj_uni64(srcOff[ZJ_UNI(blks[b].frame)]), blks, b, litPool, pf, (u8*)zj_dyn_lds + ZD_HP_LDS_OFF);
         if (threadIdx.x == 0 && ok) blks[b].litReady = 1u;
         __syncthreads();
     }
@@ -248,6 +248,25 @@ __global__ __launch_bounds__(64) void zj_dec_seq_kernel(const u8* __restrict__ s
     }
 }
 
+// Stage 2b: the Huffman-coded literals of list A's frames into their slots (zd_lit_frame), beside the sequence decode and ahead of the execution pass on the same side
+// stream.  A kernel of its own since round 6 (it was the execution kernel's mode 3): the four streams are decoded by the whole wave (zd_huf_streams_wave), whose
+// windows take ZD_HP_LDS bytes of LDS behind the workgroup state — the execution kernel keeps its registers and its workgroups per CU.
+__global__ __launch_bounds__(64) void zj_dec_lit_kernel(const u8* __restrict__ src, const u64* __restrict__ srcOff, const u32* __restrict__ list, const u32* countPtr,
+                                                         u32* workCounter, ZDMeta* metas, u8* litSlots, u32 litSlot, unsigned long long* prof) {
+    ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables, the windows behind it (ZD_EXEC_LDS)
+    ZjProf pf; pf.start(prof);
+    Grp<64> g;
+    u32 const count = ZJ_UNI(*countPtr);
+    for (;;) {
+        u32 const k = zj_next_index(workCounter);
+        if (k >= count) break;
+        u32 const i = ZJ_UNI(list[k]);
+        bool const ok = zd_lit_frame(g, sh, src + srcOff[i], metas + i, litSlots + (size_t)i * litSlot, litSlot, pf, (u8*)zj_dyn_lds + ZD_HP_LDS_OFF);
+        if (threadIdx.x == 0 && ok) metas[i].pad = 1u;      // the frame record says where the execution stage finds the literals
+        __syncthreads();
+    }
+}
+
 template <bool DICT>
 __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict__ src, const u64* __restrict__ srcOff, u8* __restrict__ dst,
                                                           const u64* __restrict__ dstOff, u64* __restrict__ result, const u32* __restrict__ list,
@@ -256,24 +275,12 @@ __global__ __launch_bounds__(64) void zj_dec_exec_kernel_t(const u8* __restrict_
                                                           u32 mode, const u32* doneList, u32* procFlag, u8* litSlots, u32 litSlot, u32* processed) {      // (metas: written by mode 3 only — the literal pass marks the frames it served; processed: frames mode 1 executed)
     // mode 0: list entry k.  mode 1: the k-th frame the sequence-decode kernel finishes while this kernel runs beside it (bounded
     // wait; a workgroup that gives up leaves the rest to the mode-2 pass).  mode 2: list entries mode 1 did not get to.
-    // mode 3: literals only (zd_lit_frame), beside the sequence decode, into slot k of litSlots (litSlot bytes each); the other modes
-    // take the literals from there when the frame record says so.
+    // litSlots: slot i holds frame i's literals when its record says so (zj_dec_lit_kernel, beside the sequence decode).
     ZDecShared& sh = *(ZDecShared*)zj_dyn_lds;          // allocated without the tANS tables (ZD_SHARED_NO_FSE)
     ZjProf pf; pf.start(prof);
     Grp<64> g;
     u8* const lit = scratch + (size_t)blockIdx.x * ZD_LIT_SCRATCH;
     u32 const count = ZJ_UNI(*countPtr);
-    if (mode == 3) {
-        for (;;) {
-            u32 const k = zj_next_index(workCounter);
-            if (k >= count) break;
-            u32 const i = ZJ_UNI(list[k]);
-            bool const ok = zd_lit_frame(g, sh, src + srcOff[i], metas + i, litSlots + (size_t)i * litSlot, litSlot, pf);
-            if (threadIdx.x == 0 && ok) metas[i].pad = 1u;
-            __syncthreads();
-        }
-        return;
-    }
     if (mode == 1 && !zj_dec_heavy(countPtr)) return;        // light frames: everything is the mode-2 pass's
     if (mode == 2 && processed && ZJ_UNI(*processed) == count) return;      // the pass beside the sequence decode took every frame (round 6: walking the list to find that out was 0.7 ms)
     for (;;) {
@@ -1112,7 +1119,7 @@ struct DevState {
     u32* encList = nullptr; size_t encListCap = 0;   // two index lists of encListCap entries each
     u8* splitBuf = nullptr; size_t splitBufCap = 0;    // lane-per-frame path: [tables][frame scratch][meta]
     int matchGrid = 0;
-    int dseqGrid = 0, dexecGrid = 0;                  // split decode pipeline
+    int dseqGrid = 0, dexecGrid = 0, dlitGrid = 0;                  // split decode pipeline
     hipEvent_t tev[12] = {};                          // stage boundaries of the last batch calls (zjni_last_timing): [0,1] match, [2..6] decode stages, [8,9] wide match (last slice)
     bool tevWide = false;
     bool tevCompress = false, tevDecompress = false;
@@ -1179,6 +1186,8 @@ DevState* get_state(int ordinal) {
         if (const char* ov = zj_tune("ZJNI_DSEQ_WAVES")) { int const v = atoi(ov); if (v >= 1) d.dseqHeavy = v; }
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_exec_kernel, 64, ZD_SHARED_NO_FSE) != hipSuccess || perCU < 1) perCU = 8;
         d.dexecGrid = d.numCU * perCU;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, zj_dec_lit_kernel, 64, ZD_EXEC_LDS) != hipSuccess || perCU < 1) perCU = 8;
+        d.dlitGrid = d.numCU * perCU;
         for (auto& e : d.tev) { if (hipEventCreate(&e) != hipSuccess) return nullptr; }
         d.enqueueMu = new std::mutex(); d.slotTicket = new std::atomic<unsigned>(0); d.hostDecompMu = new std::mutex();
         for (int k = 0; k < ZJ_STAGE_SLOTS; k++) d.slot[k] = new StageSlot();
@@ -1582,7 +1591,7 @@ static void decode_mb_launch(DevState* d, const ZDMbHost& h, hipStream_t st, con
     hipLaunchKernelGGL(zj_dec_seq_mb_kernel, dim3((u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.seqList, (const u32*)(h.a.ctr + 1), h.a.ctr + 3,
                        (const u16*)h.a.tabs, h.pool, h.a.blks, (forked && beside) ? 1u : 0u);
     if (forked) {
-        if (lit) hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
+        if (lit) hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dlitGrid), dim3(64), ZD_EXEC_LDS, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
                                     h.a.blks, h.litPool);
         if (beside)
             hipLaunchKernelGGL(zj_dec_exec_mb_kernel, dim3((u32)d->decGrid), dim3(64), 0, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result,
@@ -1590,7 +1599,7 @@ static void decode_mb_launch(DevState* d, const ZDMbHost& h, hipStream_t st, con
                                (const u8*)(lit ? h.litPool : nullptr), 1u, h.procFlag);
         if (hipEventRecord(d->evJoin, d->sideStream) != hipSuccess || hipStreamWaitEvent(st, d->evJoin, 0) != hipSuccess) { (void)hipStreamSynchronize(d->sideStream); }
     } else if (lit) {                                   // no fork: stage 2b on the main stream
-        hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dexecGrid), dim3(64), ZD_SHARED_NO_FSE, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
+        hipLaunchKernelGGL(zj_dec_lit_mb_kernel, dim3((u32)d->dlitGrid), dim3(64), ZD_EXEC_LDS, st, (const u8*)d_src, (const u64*)d_src_off, (const u32*)h.a.litList, (const u32*)(h.a.ctr + 8), h.a.ctr + 12,
                            h.a.blks, h.litPool);
     }
     bool const swept = forked && beside;
@@ -1660,7 +1669,8 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
                                 (u32)n, c + 2, tabs, metas, listA, listB, c, ddDev, overlap ? doneList : (u32*)nullptr, procFlag, mb.a, 0u, (u8*)d_dst, (u64*)d_result);
         (void)hipEventRecord(d->tev[3], st);
         u32 const waves = (u32)((n + 63) / 64);
-        u32 const gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
+        u32 gridX = (u32)(n < (size_t)d->dexecGrid ? n : (size_t)d->dexecGrid);
+        if (const char* ov = zj_tune("ZJNI_DEXEC_PER_CU")) { int const v = atoi(ov); if (v >= 1 && (u32)(v * d->numCU) < gridX) gridX = (u32)(v * d->numCU); }      // (tuning builds: fewer execution / literal workgroups beside the sequence decode)
         // The execution kernel (literals + LZ77 copy, wave per frame) runs on a side stream BESIDE the sequence decode and takes
         // frames in the order they finish there: the lane-per-frame decode is a dependent chain per frame (one wave per SIMD, mostly
         // waiting), so the two share the CUs instead of following each other.  A sweep pass afterwards takes what the side kernel
@@ -1668,9 +1678,10 @@ static size_t decompress_batch_device_impl(const void* d_src, const uint64_t* d_
         bool const fork = overlap || litSlots;
         if (fork && (hipEventRecord(d->evFork, st) != hipSuccess || hipStreamWaitEvent(d->sideStream, d->evFork, 0) != hipSuccess)) return ZJNI_ERR(ZJNI_ERROR_no_device);
         if (litSlots) {                                 // beside the sequence decode, ahead of the mode-1 execution pass on the same side stream
-            hipLaunchKernelGGL(zj_dec_exec_kernel, dim3(gridX), dim3(64), ZD_SHARED_NO_FSE, d->sideStream,
-                               (const u8*)d_src, (const u64*)d_src_off, (u8*)d_dst, (const u64*)d_dst_off, (u64*)d_result, (const u32*)listA,
-                               (const u32*)(c + 8), c + 10, metas, (const u64*)seqs, d->decScratch, listB, c + 1, d->prof, ddDev, ddRaw, 3u, (const u32*)doneList, procFlag, litSlots, litSlot, c);
+            u32 gridL = (u32)(n < (size_t)d->dlitGrid ? n : (size_t)d->dlitGrid);
+            if (const char* ov = zj_tune("ZJNI_DLIT_PER_CU")) { int const v = atoi(ov); if (v >= 1 && (u32)(v * d->numCU) < gridL) gridL = (u32)(v * d->numCU); }
+            hipLaunchKernelGGL(zj_dec_lit_kernel, dim3(gridL), dim3(64), ZD_EXEC_LDS, d->sideStream, (const u8*)d_src, (const u64*)d_src_off, (const u32*)listA,
+                               (const u32*)(c + 8), c + 10, metas, litSlots, litSlot, d->prof);
         }
         hipLaunchKernelGGL(zj_dec_seq_kernel, dim3(waves < (u32)d->dseqGrid ? waves : (u32)d->dseqGrid), dim3(64), 0, st, (const u8*)d_src,
                            (const u64*)d_src_off, (const u32*)listA, (const u32*)(c + 8), c + 3, (const u16*)tabs, seqs, metas, ddDev,
