@@ -126,7 +126,7 @@ def test_route_names_and_build_stamp(zj):
     want = {"ZJNI_ROUTE_FUSED": b"zj_encode_kernel", "ZJNI_ROUTE_WAVE": b"zj_enc_match_wave_kernel", "ZJNI_ROUTE_LANE": b"zj_enc_match_kernel",
             "ZJNI_ROUTE_LANE_GATED": b"zj_enc_match_gated_kernel", "ZJNI_ROUTE_RUN": b"zj_enc_match_run_kernel", "ZJNI_ROUTE_RUN_FLAGS": b"zj_enc_match_run_kernel",
             "ZJNI_ROUTE_HYBRID": b"zj_enc_match_kernel", "ZJNI_ROUTE_WAVE_HBM": b"zj_encode_multi_kernel", "ZJNI_ROUTE_OTHER": b"", "ZJNI_ROUTE_NONE": b"",
-            "ZJNI_ROUTE_WIDE": b"zj_enc_match_wide_kernel"}
+            "ZJNI_ROUTE_WIDE": b"zj_enc_match_wide_kernel", "ZJNI_ROUTE_PIPE": b"zj_encode_pipe_kernel"}
     for name, val in routes.items():
         assert L.zjni_route_kernel(val) == want[name], name
     assert L.zjni_build_stamp().decode() == zj.build_stamp()          # the library in the tree is the one these sources give

@@ -417,3 +417,32 @@ def test_frames_of_one_stored_block_are_copied_by_stage_1(emu, oracle_ref):
             out, used = emu_decompress_split(emu, z, n)
             assert out == want[1] and used == 4 and _mb(emu, z, n) == want[1], n
             assert emu_decompress_split(emu, z, n - 1)[0] == _ref_answers(oracle_ref, z, n - 1)[1]
+
+
+def test_four_huffman_streams_by_the_whole_wave(emu, oracle_ref):
+    """zd_huf_streams_wave (round 6): a literals section's four streams cut into 16 spans each, every span decoded by a lane from a GUESSED first code, the guesses checked
+    by a counting pass (a lane whose predecessor ended elsewhere decodes again), then written.  Code tables of every temper — one code length (never falls into step:
+    the guess sits on the lengths' lattice), geometric (at once), near-uniform with a rare long code (slowly: repeated passes, or the section is left to the one-lane
+    rounds) — decode to the reference's bytes on both batch pipelines; the counters say the wave took sections, repeated passes, and gave some up.  Damaged streams
+    (bits flipped inside the section) answer what the reference's portable decoder answers: the wave decides nothing about a stream that does not check out."""
+    import ctypes as C
+    import random
+    from util import skewed_literal_inputs
+    rnd = random.Random(11)
+    emu.emu_hp_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    st = (C.c_ulonglong * 5)()
+    emu.emu_hp_stats(st, 1)
+    frames = 0
+    for d in skewed_literal_inputs():
+        for level in (1, 3):
+            z = oracle_ref.compress(d, level, level == 1)
+            assert emu_decompress_split(emu, z, len(d))[0] == d and _mb(emu, z, len(d)) == d, (len(d), level, len(set(d)))
+            frames += 1
+            if len(d) <= 20000:
+                for _ in range(6):                                   # damage somewhere behind the headers: mostly inside the Huffman streams
+                    zb = bytearray(z); p = rnd.randrange(12, len(zb)); zb[p] ^= 1 << rnd.randrange(8); zb = bytes(zb)
+                    want = _ref_answers(oracle_ref, zb, len(d))[1]
+                    assert emu_decompress_split(emu, zb, len(d))[0] == want and _mb(emu, zb, len(d)) == want, (len(d), level, p)
+    emu.emu_hp_stats(st, 0)
+    taken, at_check, after_tries, repeats, lanes_again = list(st)
+    assert taken > frames and repeats > 0 and at_check > 0, list(st)       # (sections taken on both pipelines; some guesses were wrong; damaged streams were left to the rounds)

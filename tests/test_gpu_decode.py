@@ -261,3 +261,27 @@ def test_gpu_streamed_frames_without_content_size(gpu, oracle_ref):
             assert all(isinstance(o, Exception) and o.getErrorCode() == 70 for o in short)
         finally:
             os.environ.pop("ZJNI_DSPLIT_MIN", None)
+
+
+def test_gpu_four_huffman_streams_by_the_whole_wave(gpu, oracle_ref, monkeypatch):
+    """the GPU twin of tests/test_emu_decode.py::test_four_huffman_streams_by_the_whole_wave: zd_huf_streams_wave on real lanes (zj_dec_lit_kernel beside the sequence
+    decode; zj_dec_lit_mb_kernel for the block stages) — code tables of one length, geometric, near-uniform with a rare long code; damaged streams answer what the
+    reference's portable decoder answers (bytes or refusal), whichever kernel ends up deciding"""
+    from util import skewed_literal_inputs
+    monkeypatch.setenv("ZJNI_DSPLIT_MIN", "1")              # the three-stage pipeline whatever the batch size
+    rnd = random.Random(12)
+    frames, caps, want = [], [], []
+    for d in skewed_literal_inputs():
+        for level in (1, 3):
+            z = oracle_ref.compress(d, level, level == 1)
+            frames.append(z); caps.append(len(d)); want.append(d)
+            for _ in range(4):
+                zb = bytearray(z); p = rnd.randrange(12, len(zb)); zb[p] ^= 1 << rnd.randrange(8); zb = bytes(zb)
+                try: w = oracle_ref.decompress_portable(zb, len(d))
+                except oracle_ref.ZstdRefError as ex: w = -ex.code
+                frames.append(zb); caps.append(len(d)); want.append(w)
+    order = list(range(len(frames))); rnd.shuffle(order)
+    outs = gpu.decompress_batch([frames[i] for i in order], [caps[i] for i in order])
+    for j, i in enumerate(order):
+        got = -abs(outs[j].getErrorCode()) if isinstance(outs[j], Exception) else outs[j]
+        assert got == want[i], (i, caps[i], want[i] if isinstance(want[i], int) else "bytes", got if isinstance(got, int) else "bytes differ")

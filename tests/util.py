@@ -322,3 +322,27 @@ def needs_tuning_build(zj):
     import pytest
     if b"+tuning" not in zj.lib().zjni_build_stamp():
         pytest.skip("a switch of tuning builds only (-DZJ_TUNING_KERNELS)")
+
+
+def skewed_literal_inputs(seed=7):
+    """inputs whose frames carry LARGE Huffman-coded literal sections with code tables of every temper (tests of zd_huf_streams_wave, zj_decode.h): few equally likely byte
+    values (codes of one length: a decoder never falls into step from the wrong phase), two lengths, geometric distributions (fast to fall into step), a near-uniform one
+    with a rare long code (slow), alphabets of 2 to 200 values, runs of repeats in between so that the frames have sequences as well; sizes to 128 KiB"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    def draw(n, values, weights):
+        return bytes(rnd.choices(values, weights=weights, k=n))
+    for n in (2048, 5000, 20000, 65536, 131072):
+        for nsym, shape in ((2, "flat"), (4, "flat"), (16, "flat"), (64, "flat"), (3, "geo"), (12, "geo"), (40, "geo"), (200, "geo"), (17, "near"), (33, "near"), (6, "two")):
+            values = rnd.sample(range(256), nsym)
+            if shape == "flat": w = [1.0] * nsym
+            elif shape == "geo": w = [0.7 ** i + 1e-4 for i in range(nsym)]
+            elif shape == "near": w = [1.0] * (nsym - 1) + [0.02]
+            else: w = [4.0] * 2 + [1.0] * (nsym - 2)
+            d = bytearray(draw(n, values, w))
+            for _ in range(n // 4000):                                  # some matches: the frames get sequences (the batch pipeline's "simple" class)
+                a = rnd.randrange(0, max(1, n - 300)); ln = rnd.randrange(8, 200); b = rnd.randrange(0, max(1, n - ln))
+                d[b:b + ln] = d[a:a + ln][:len(d[b:b + ln])]
+            out.append(bytes(d[:n]))
+    return out

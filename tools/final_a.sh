@@ -11,6 +11,6 @@ cd $R
 ( cd /tmp; export TMPDIR=/tmp
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 5 --warmup 2 > $OUT/bench_metric_with_stats.json 2> $OUT/bench_stats.err
   f=$(find $OUT/stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_metric_kernel_stats.csv; rm -rf $OUT/stats )
-PMC_LIST=$'metric 3 65536 65536 ZJNI_NEED_INLINE=1\nmetricnoflags 3 65536 65536 ZJNI_NEED=0\n5shape 3 65536 131072\n3 1 65536 65536\n2 3 65536 65536 ZJNI_NEED_INLINE=1' bash tools/pmc_traffic.sh ${RND}final 2>&1 | tail -6
+PMC_LIST=$'metric 3 65536 65536 ZJNI_NEED_INLINE=1\nmetricnoflags 3 65536 65536 ZJNI_NEED=0\n5shape 3 65536 131072\n3 1 65536 65536\n2 3 65536 65536 ZJNI_NEED_INLINE=1\n1 3 1024 1048576 PROF_DATA=xml\n4 3 1048576 4096' bash tools/pmc_traffic.sh ${RND}final 2>&1 | tail -6
 echo "== SQ counters of the match kernel (final build)"; bash tools/sq_counters.sh final | grep match_run > $OUT/sq_counters.txt; cat $OUT/sq_counters.txt
 ls $OUT

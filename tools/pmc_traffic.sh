@@ -12,11 +12,15 @@ cd /tmp; export TMPDIR=/tmp
 while read CFG L N S ENVS; do
   [ -z "$CFG" ] && continue
   KEY=${CFG}_L${L}_${N}x${S}
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$KEY -o s -- python $R/tools/prof_driver.py $N $S $L 3 > $OUT/${KEY}_driver.json 2> $OUT/${KEY}_stats.err
+  # the driver: tools/prof_driver.py <n> <size> <level> <steps>; config 4 (dictionary, 4 KiB records): tools/prof_cdict.py <n> <level> <steps>.  PROF_* settings (the data the
+  # driver generates: PROF_DATA=xml = config 1's slices of the xml fixture) belong to the stats pass as well as to the counter passes.
+  DATA_ENVS=$(echo $ENVS | tr ' ' '\n' | grep '^PROF_' | tr '\n' ' ')
+  if [ "$CFG" = 4 ]; then DRV3="python $R/tools/prof_cdict.py $N $L 3"; DRV1="python $R/tools/prof_cdict.py $N $L 1"; else DRV3="python $R/tools/prof_driver.py $N $S $L 3"; DRV1="python $R/tools/prof_driver.py $N $S $L 1"; fi
+  timeout 300 env $DATA_ENVS rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$KEY -o s -- $DRV3 > $OUT/${KEY}_driver.json 2> $OUT/${KEY}_stats.err
   f=$(find $OUT/stats_$KEY -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${KEY}_kernel_stats.csv
   rm -rf $OUT/stats_$KEY
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 env $ENVS rocprofv3 --pmc $C --output-format csv -d $OUT/pmc/${KEY}_$C -o p -- python $R/tools/prof_driver.py $N $S $L 1 > $OUT/pmc/${KEY}_${C}_driver.json 2> $OUT/pmc/${KEY}_$C.err
+    timeout 300 env $ENVS rocprofv3 --pmc $C --output-format csv -d $OUT/pmc/${KEY}_$C -o p -- $DRV1 > $OUT/pmc/${KEY}_${C}_driver.json 2> $OUT/pmc/${KEY}_$C.err
     f=$(find $OUT/pmc/${KEY}_$C -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $OUT/pmc/${KEY}_$C.csv
     rm -rf $OUT/pmc/${KEY}_$C
   done

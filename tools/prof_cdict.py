@@ -67,6 +67,7 @@ h_dsz = np.zeros(n, dtype=np.uint64); chk(hip.hipMemcpy(h_dsz.ctypes.data_as(vp)
 hb = np.zeros(n * size, dtype=np.uint8); chk(hip.hipMemcpy(hb.ctypes.data_as(vp), back, C.c_size_t(n * size), 2))
 hs = np.zeros(n * size, dtype=np.uint8); chk(hip.hipMemcpy(hs.ctypes.data_as(vp), src, C.c_size_t(n * size), 2))
 GiB = n * size / 2.0**30
-print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "entropy_kcycles_per_frame": enc_phase, "n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "decompress_ms": td / steps,
+L.zjni_build_stamp.restype = C.c_char_p
+print(json.dumps({"tag": os.environ.get("AB_TAG", ""), "build_stamp": L.zjni_build_stamp().decode(), "entropy_kcycles_per_frame": enc_phase, "n": n, "size": size, "level": level, "steps": steps, "compress_ms": tc / steps, "decompress_ms": td / steps,
                   "compress_GiBps": GiB / (tc / steps / 1e3), "decompress_GiBps": GiB / (td / steps / 1e3),
                   "ratio": n * size / float(h_csz.sum()), "round_trip": bool((h_dsz == size).all() and (hb == hs).all())}))
