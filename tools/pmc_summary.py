@@ -43,7 +43,16 @@ for key in keys:
         # the driver runs 2 calls (1 warm-up + 1); kernels launched several times per call (lists A / B / S): the largest launch
         fetch = max(v["fetch"]) if v["fetch"] else 0.0
         write = max(v["write"]) if v["write"] else 0.0
-        summ[name] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write, "build_stamp": stamp}
+        extra = {}
+        if ("match_run" in name or "match_wide" in name) and "noflags" not in key:
+            # the level-3 match kernels with need flags: counter collection serialises the kernels and now and then lets a call's match kernel go AHEAD of its flag kernel
+            # (round 6: the metric key's WRITE_SIZE pass, second call — 120.8 GB, exactly the no-flags figure, against 67.6 GB in the call where the order held and in every
+            # pass of key 2, the same command).  The figure quoted is the full-size launch with its flags in place: the smallest launch that is at least half the largest.
+            pick = lambda xs: min(x for x in xs if x >= 0.5 * max(xs)) if xs else 0.0
+            if v["fetch"] and pick(v["fetch"]) != fetch or v["write"] and pick(v["write"]) != write:
+                extra = {"launches_fetch_bytes": v["fetch"], "launches_write_bytes": v["write"], "picked": "the full-size launch whose flag kernel ran ahead of it (the smallest launch >= half the largest)"}
+            fetch, write = pick(v["fetch"]), pick(v["write"])
+        summ[name] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write, "build_stamp": stamp, **extra}
     out[key] = summ
     for extra in (f"{key}_kernel_stats.csv", f"{key}_driver.json"):     # the rocprofv3 --kernel-trace --stats summary of the same driver command
         ep = os.path.join(src, extra)
