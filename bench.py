@@ -519,6 +519,7 @@ def main(argv=None, platform_factory=GpuPlatform):
         l3 = (C.c_uint * 3)()
         if L.zjni_last_lists(l3) == 0:
             lists = {"common_launch": int(l3[0]), "wide_launch": int(l3[1]), "multi_block_or_wave_per_frame": int(l3[2])}
+            route = int(L.zjni_last_route())                                      # (again: whether list C went to the pipelined pair of waves is decided on the device — ZJNI_ROUTE_PIPE is known once the lists are)
             if l3[1] > l3[0] and l3[1] >= l3[2]: route = 10                      # ZJNI_ROUTE_WIDE
     route_kernel = L.zjni_route_kernel(route).decode() if route > 0 else ""
     stamp = L.zjni_build_stamp().decode() if P.native else "stand-in"

@@ -12,10 +12,10 @@ cd /tmp; export TMPDIR=/tmp
 while read CFG L N S ENVS; do
   [ -z "$CFG" ] && continue
   KEY=${CFG}_L${L}_${N}x${S}
-  # the driver: tools/prof_driver.py <n> <size> <level> <steps>; config 4 (dictionary, 4 KiB records): tools/prof_cdict.py <n> <level> <steps>.  PROF_* settings (the data the
+  # the driver: tools/prof_driver.py <n> <size> <level> <steps>; config 4 (dictionary, 4 KiB JSON-like records, bench.py's own dictionary): tools/prof_cdict.py <n> <level> <steps> 1 bench.  PROF_* settings (the data the
   # driver generates: PROF_DATA=xml = config 1's slices of the xml fixture) belong to the stats pass as well as to the counter passes.
   DATA_ENVS=$(echo $ENVS | tr ' ' '\n' | grep '^PROF_' | tr '\n' ' ')
-  if [ "$CFG" = 4 ]; then DRV3="python $R/tools/prof_cdict.py $N $L 3"; DRV1="python $R/tools/prof_cdict.py $N $L 1"; else DRV3="python $R/tools/prof_driver.py $N $S $L 3"; DRV1="python $R/tools/prof_driver.py $N $S $L 1"; fi
+  if [ "$CFG" = 4 ]; then DRV3="python $R/tools/prof_cdict.py $N $L 3 1 bench"; DRV1="python $R/tools/prof_cdict.py $N $L 1 1 bench"; else DRV3="python $R/tools/prof_driver.py $N $S $L 3"; DRV1="python $R/tools/prof_driver.py $N $S $L 1"; fi
   timeout 300 env $DATA_ENVS rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$KEY -o s -- $DRV3 > $OUT/${KEY}_driver.json 2> $OUT/${KEY}_stats.err
   f=$(find $OUT/stats_$KEY -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${KEY}_kernel_stats.csv
   rm -rf $OUT/stats_$KEY

@@ -1,6 +1,6 @@
 """Profiling driver without torch for the dictionary path (BASELINE config 4 shape): n x 4 KiB mixed-entropy buffers,
 ZstdDictCompress level `level`, compress -> pack -> decompress with the dictionary through the C-ABI only.
-usage: prof_cdict.py [n] [level] [steps] [cls]   cls = 0..3: only that class of the generator (1 = JSON), default mixed"""
+usage: prof_cdict.py [n] [level] [steps] [cls] [bench]   cls = 0..3: only that class of the generator (1 = JSON), default mixed; "bench": the dictionary bench.py --config 4 trains"""
 import ctypes as C, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,8 +23,12 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 cls = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 size = 4096
 assert L.zjni_init(0) == 0
-host = zj.synth_host(size, 1 << 20, 16000)
-dic = ref.train_dict([host[i * size:(i + 1) * size] for i in range(16000) if cls < 0 or (i & 3) == cls][:4000], 112640)
+if len(sys.argv) > 5 and sys.argv[5] == "bench":      # bench.py --config 4's own dictionary: 110 KiB trained on 10 000 JSON-like records (its data: cls = 1)
+    host = zj.synth_host(size, 1 << 24, 40000)
+    dic = ref.train_dict([host[i * size:(i + 1) * size] for i in range(1, 40000, 4)], 112640)
+else:
+    host = zj.synth_host(size, 1 << 20, 16000)
+    dic = ref.train_dict([host[i * size:(i + 1) * size] for i in range(16000) if cls < 0 or (i & 3) == cls][:4000], 112640)
 cd = L.zjni_createCDict(dic, len(dic), level); dd = L.zjni_createDDict(dic, len(dic))
 assert cd and dd
 bound = L.zjni_compressBound(size)
