@@ -308,6 +308,18 @@ def config5(a, zj, dev, rank, world, cfg):
                             "frac": (alg / 1e9 / (wide / 1e3) / HBM_PEAK_GBPS) if wide > 0 else None, "traffic": None},
                "cpu_baseline": None, "parity": {"gpu_roundtrip_exact": bool(exact)},
                "library": {"build_stamp": L.zjni_build_stamp().decode()}}
+        if chunk == 65536 and size == 131072:        # a chunk IS config 5shape's launch (65 536 x 128 KiB of the same generator): its counter pass, when it is of this build
+            try:
+                import glob
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                    with open(path) as f:
+                        rec = json.load(f).get(f"5shape_L{level}_{chunk}x{size}", {}).get("zj_enc_match_wide_kernel")
+                    if rec and rec.get("build_stamp") == out["library"]["build_stamp"]:
+                        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_note"] = f"the 5shape launch's PMC passes ({os.path.basename(path)}), build {rec['build_stamp']} = this library's"
+                        break
+            except OSError:
+                pass
         if not a.skip_cpu and world == 1:
             from oracle import ref
             k = 256
